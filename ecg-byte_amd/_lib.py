@@ -1,0 +1,74 @@
+"""ctypes binding of libecgbyte_hip.so (the C ABI declared in include/ecgbyte.h).
+
+The HIP library is the product: there is no CPU fallback.  If the shared object is missing,
+or a device entry point is called without a GPU, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_PKG, "libecgbyte_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+ECGB_OK = 0
+ERRORS = {-1: "INVALID", -2: "NOMEM", -3: "UNSUPPORTED", -4: "HIP", -5: "NODEVICE"}
+
+
+class EcgbError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libecgbyte_hip: {ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            f"{SO_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C ecg-byte_amd/csrc`). "
+            "There is no CPU fallback for the encode path.")
+    L = C.CDLL(SO_PATH)
+    vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
+    u32p = C.POINTER(C.c_uint32)
+    L.ecgb_last_error.restype = C.c_char_p
+    L.ecgb_version.restype = u32
+    L.ecgb_tokenizer_create.argtypes = [u32p, u32p, u32p, sz, C.POINTER(vp)]
+    L.ecgb_tokenizer_create.restype = C.c_int
+    L.ecgb_tokenizer_destroy.argtypes = [vp]
+    L.ecgb_tokenizer_destroy.restype = None
+    L.ecgb_tokenizer_info.argtypes = [vp, u32p, u32p, u32p]
+    L.ecgb_tokenizer_info.restype = C.c_int
+    L.ecgb_tokenizer_copy_nodes.argtypes = [vp, C.POINTER(C.c_uint64), sz]
+    L.ecgb_tokenizer_copy_nodes.restype = sz
+    L.ecgb_quantize_hip.argtypes = [vp, sz, C.c_double, C.c_double, vp, vp, vp]
+    L.ecgb_quantize_hip.restype = C.c_int
+    L.ecgb_encode_scratch_bytes.argtypes = [vp, sz, sz]
+    L.ecgb_encode_scratch_bytes.restype = sz
+    L.ecgb_encode_hip.argtypes = [vp, vp, sz, sz, vp, sz, vp, vp, sz, vp]
+    L.ecgb_encode_hip.restype = C.c_int
+    L.ecgb_quantize_encode_hip.argtypes = [vp, vp, sz, sz, C.c_double, C.c_double, vp, sz, vp, vp, sz, vp]
+    L.ecgb_quantize_encode_hip.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != ECGB_OK:
+        raise EcgbError(rc, (lib().ecgb_last_error() or b"").decode("utf-8", "replace"))

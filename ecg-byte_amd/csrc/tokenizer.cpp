@@ -1,0 +1,210 @@
+// tokenizer.cpp -- host side of the tokenizer handle: builds the byte trie that
+// rust_bpe.encode_text builds on every call (reference: ecg_byte/rust_bpe/src/lib.rs:127-161),
+// once, and lays it out for the device.
+//
+// Layout choice (MI355X): the encode kernel walks the trie one symbol per step with one
+// dependent lookup per step, so a node must be ONE aligned 8-byte LDS/L2 read:
+//   child bitmap (one bit per symbol class) | first-child id | token id
+// Children of a node are numbered consecutively in class order, so
+//   child(node, cls) = first_child + popcount(bitmap & ((1 << cls) - 1)).
+// Breadth-first numbering puts the shallow (hot) nodes at low ids; the kernel keeps nodes
+// [0, n_lds) in LDS and reads any deeper remainder through L2.
+#include "tokenizer.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <new>
+#include <queue>
+
+namespace ecgb {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+}  // namespace ecgb
+
+extern "C" const char *ecgb_last_error(void) { return ecgb::g_last_error.c_str(); }
+
+extern "C" uint32_t ecgb_version(void) { return (1u << 16) | 0u; }
+
+namespace {
+
+struct BuildNode {
+    std::array<int32_t, ecgb::kMaxClasses> child;
+    int64_t token = -1;
+    BuildNode() { child.fill(-1); }
+};
+
+}  // namespace
+
+extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t *offsets,
+                                     const uint32_t *ids, size_t n_merges, ecgb_tokenizer **out)
+{
+    using namespace ecgb;
+    if (!out || (n_merges && (!flat_bytes || !offsets || !ids))) {
+        set_error("ecgb_tokenizer_create: NULL argument");
+        return ECGB_ERR_INVALID;
+    }
+    *out = nullptr;
+    ecgb_tokenizer *tok = new (std::nothrow) ecgb_tokenizer();
+    if (!tok) { set_error("ecgb_tokenizer_create: out of host memory"); return ECGB_ERR_NOMEM; }
+    try {
+        // ---- symbol classes: 0..25 are 'a'..'z' (the quantiser's alphabet index IS the
+        // class), further byte values that occur in an expansion get 26..31.
+        std::memset(tok->byte_to_class, kOtherClass, sizeof(tok->byte_to_class));
+        for (uint32_t c = 0; c < ECGB_ALPHABET; ++c) {
+            tok->byte_to_class['a' + c] = (uint8_t)c;
+            tok->class_to_byte[c] = (uint8_t)('a' + c);
+        }
+        uint32_t n_classes = ECGB_ALPHABET;
+        bool used[256] = { false };
+        for (size_t i = 0; i < n_merges; ++i) {
+            if (offsets[i + 1] < offsets[i]) { delete tok; set_error("ecgb_tokenizer_create: offsets not monotone"); return ECGB_ERR_INVALID; }
+            for (uint32_t k = offsets[i]; k < offsets[i + 1]; ++k) {
+                if (flat_bytes[k] > 255u) { delete tok; set_error("ecgb_tokenizer_create: expansion element > 255"); return ECGB_ERR_INVALID; }
+                used[flat_bytes[k]] = true;
+            }
+        }
+        for (uint32_t b = 0; b < 256; ++b) {
+            if (!used[b] || tok->byte_to_class[b] != kOtherClass) continue;
+            if (n_classes == kMaxClasses) {
+                delete tok;
+                set_error("ecgb_tokenizer_create: more than 32 distinct byte values (a..z plus 6) in the merges");
+                return ECGB_ERR_UNSUPPORTED;
+            }
+            tok->byte_to_class[b] = (uint8_t)n_classes;
+            tok->class_to_byte[n_classes] = (uint8_t)b;
+            ++n_classes;
+        }
+        tok->n_classes = n_classes;
+        tok->n_merges = (uint32_t)n_merges;
+
+        // ---- pointer trie, insertion order of lib.rs:155-161
+        std::vector<BuildNode> bn(1);
+        auto insert = [&](const uint32_t *seq, size_t len, uint32_t token_id) {
+            int32_t node = 0;
+            for (size_t k = 0; k < len; ++k) {
+                uint8_t cls = tok->byte_to_class[seq[k]];
+                int32_t ch = bn[node].child[cls];
+                if (ch < 0) {
+                    ch = (int32_t)bn.size();
+                    bn[node].child[cls] = ch;
+                    bn.emplace_back();
+                }
+                node = ch;
+            }
+            bn[node].token = token_id;  // later duplicates overwrite (lib.rs:145)
+        };
+        for (uint32_t c = 0; c < n_classes; ++c) {  // the single-byte tokens that have a class
+            uint32_t b = tok->class_to_byte[c];
+            insert(&b, 1, b);
+        }
+        for (size_t i = 0; i < n_merges; ++i)
+            insert(flat_bytes + offsets[i], offsets[i + 1] - offsets[i], ids[i]);
+
+        if (bn.size() >= 65535) {
+            delete tok;
+            set_error("ecgb_tokenizer_create: trie has >= 65535 nodes");
+            return ECGB_ERR_UNSUPPORTED;
+        }
+        // ---- breadth-first renumbering, children consecutive in class order
+        std::vector<int32_t> order;  // new id -> old id
+        std::vector<uint32_t> depth;
+        order.reserve(bn.size());
+        order.push_back(0);
+        depth.push_back(0);
+        std::vector<uint32_t> first_child(bn.size(), 0);
+        for (size_t head = 0; head < order.size(); ++head) {
+            const BuildNode &n = bn[order[head]];
+            first_child[head] = (uint32_t)order.size();
+            for (uint32_t c = 0; c < kMaxClasses; ++c)
+                if (n.child[c] >= 0) { order.push_back(n.child[c]); depth.push_back(depth[head] + 1); }
+        }
+        tok->nodes.resize(order.size());
+        uint32_t max_depth = 0;
+        for (size_t i = 0; i < order.size(); ++i) {
+            const BuildNode &n = bn[order[i]];
+            uint32_t bitmap = 0;
+            for (uint32_t c = 0; c < kMaxClasses; ++c) if (n.child[c] >= 0) bitmap |= 1u << c;
+            uint32_t token = kNoToken;
+            if (i != 0 && n.token >= 0) {  // the root's own token is never consulted (lib.rs:170-181)
+                if (n.token >= (int64_t)kNoToken) {
+                    delete tok;
+                    set_error("ecgb_tokenizer_create: token id >= 65535");
+                    return ECGB_ERR_UNSUPPORTED;
+                }
+                token = (uint32_t)n.token;
+            }
+            tok->nodes[i] = pack_node(bitmap, first_child[i], token);
+            max_depth = std::max(max_depth, depth[i]);
+        }
+        tok->max_depth = max_depth;
+        // root children are nodes 1..n_classes in class order
+        for (uint32_t c = 0; c < kMaxClasses; ++c) tok->single_id[c] = 0;
+        for (uint32_t c = 0; c < n_classes; ++c) tok->single_id[c] = (uint16_t)(tok->nodes[1 + c] >> 48);
+    } catch (const std::bad_alloc &) {
+        delete tok;
+        set_error("ecgb_tokenizer_create: out of host memory");
+        return ECGB_ERR_NOMEM;
+    }
+
+    // ---- upload
+    // Without a device the handle stays host-only (introspection works, every device entry
+    // point then returns ECGB_ERR_NODEVICE): lets the trie layout be tested on CPU-only boxes.
+    int dev = -1, n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = tok;
+        return ECGB_OK;
+    }
+    tok->device = dev;
+    const size_t nbytes = tok->nodes.size() * sizeof(uint64_t);
+    uint8_t lut[256 + 64 + 32];
+    std::memcpy(lut, tok->byte_to_class, 256);
+    std::memcpy(lut + 256, tok->single_id, 64);
+    std::memcpy(lut + 320, tok->class_to_byte, 32);
+    if (hipMalloc((void **)&tok->nodes_dev, nbytes) != hipSuccess ||
+        hipMalloc((void **)&tok->lut_dev, sizeof(lut)) != hipSuccess) {
+        ecgb_tokenizer_destroy(tok);
+        ecgb::set_error("ecgb_tokenizer_create: hipMalloc failed");
+        return ECGB_ERR_NOMEM;
+    }
+    if (hipMemcpy(tok->nodes_dev, tok->nodes.data(), nbytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(tok->lut_dev, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) {
+        ecgb_tokenizer_destroy(tok);
+        ecgb::set_error("ecgb_tokenizer_create: hipMemcpy failed");
+        return ECGB_ERR_HIP;
+    }
+    *out = tok;
+    return ECGB_OK;
+}
+
+extern "C" void ecgb_tokenizer_destroy(ecgb_tokenizer *tok)
+{
+    if (!tok) return;
+    if (tok->nodes_dev) (void)hipFree(tok->nodes_dev);
+    if (tok->lut_dev) (void)hipFree(tok->lut_dev);
+    delete tok;
+}
+
+extern "C" size_t ecgb_tokenizer_copy_nodes(const ecgb_tokenizer *tok, uint64_t *out, size_t cap)
+{
+    if (!tok) return 0;
+    const size_t n = tok->nodes.size();
+    if (out) std::memcpy(out, tok->nodes.data(), std::min(n, cap) * sizeof(uint64_t));
+    return n;
+}
+
+extern "C" int ecgb_tokenizer_info(const ecgb_tokenizer *tok, uint32_t *n_nodes, uint32_t *max_depth,
+                                   uint32_t *n_classes)
+{
+    if (!tok) { ecgb::set_error("ecgb_tokenizer_info: NULL handle"); return ECGB_ERR_INVALID; }
+    if (n_nodes) *n_nodes = (uint32_t)tok->nodes.size();
+    if (max_depth) *max_depth = tok->max_depth;
+    if (n_classes) *n_classes = tok->n_classes;
+    return ECGB_OK;
+}

@@ -1,0 +1,109 @@
+/*
+ * ecgbyte.h -- C ABI of libecgbyte_hip.so, the MI355X (gfx950) implementation of the
+ * ECG-Byte tokenizer hot path:  (B,12,L) float64 signal -> 26-symbol stream -> BPE token ids
+ * -> LLM input sequences.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers/sizes and returns an `int` status
+ * (ECGB_OK or a negative ECGB_ERR_*); nothing throws across the boundary.  Pointers named
+ * `*_dev` are device (HBM) pointers, all others are host pointers.  The caller owns every
+ * buffer.  `stream` is a `hipStream_t` passed as `void*` (NULL = the default stream); device
+ * entry points only enqueue work on it and never synchronise.  A tokenizer handle is
+ * immutable after creation, so concurrent calls on different streams are safe as long as
+ * each call brings its own `scratch_dev`.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference root):
+ *   ecgb_tokenizer_create      trie construction inside rust_bpe.encode_text,
+ *                              ecg_byte/rust_bpe/src/lib.rs:153-161 (built per CALL there,
+ *                              once per tokenizer here)
+ *   ecgb_quantize_hip          normalize_all, ecg_byte/utils/tokenizer_utils.py:14-19
+ *   ecgb_encode_hip            rust_bpe.encode_text, ecg_byte/rust_bpe/src/lib.rs:149-193
+ *   ecgb_quantize_encode_hip   the per-sample front end of ECGTokenDataset.__getitem__,
+ *                              ecg_byte/data_loader.py:74-76 (normalize_all -> join -> encode_text)
+ *   ecgb_assemble_hip          ECGTokenDataset._prepare_training, ecg_byte/data_loader.py:101-132
+ *                              (+ the id->LLM-id mapping of data_loader.py:80)
+ *   ecgb_bpe_train_hip         rust_bpe.byte_pair_encoding, ecg_byte/rust_bpe/src/lib.rs:58-125
+ * INTEGRATION.md shows the binding a reference maintainer would add for each.
+ */
+#ifndef ECGBYTE_H
+#define ECGBYTE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECGB_OK 0
+#define ECGB_ERR_INVALID (-1)     /* bad argument (NULL pointer, zero size, bad range) */
+#define ECGB_ERR_NOMEM (-2)       /* host or device allocation failed */
+#define ECGB_ERR_UNSUPPORTED (-3) /* input outside the documented limits of this build */
+#define ECGB_ERR_HIP (-4)         /* a HIP runtime call failed; see ecgb_last_error() */
+#define ECGB_ERR_NODEVICE (-5)    /* no usable gfx950 device */
+
+#define ECGB_ALPHABET 26 /* tokenizer_utils.py:12 */
+
+typedef struct ecgb_tokenizer ecgb_tokenizer; /* opaque */
+
+/* Human-readable description of the last error raised on the calling thread. */
+const char *ecgb_last_error(void);
+
+/* Library / ABI version (major<<16 | minor). */
+uint32_t ecgb_version(void);
+
+/* ---- tokenizer handle -------------------------------------------------------------------
+ * `merges` in the reference is list[(list[int] expansion_bytes, int id)]; here flattened:
+ * expansion i = flat_bytes[offsets[i] .. offsets[i+1]), token id = ids[i], i in list order
+ * (later duplicates overwrite earlier ones, lib.rs:145).  The 256 single-byte tokens
+ * (lib.rs:155-157) are implied.  Builds the trie on the host, lays it out for the device
+ * (breadth-first, 8 bytes per node) and uploads it.  With no GPU present the handle is
+ * host-only: introspection works, device entry points return ECGB_ERR_NODEVICE.
+ * Limits of this build: at most 32 distinct byte values across all expansions plus
+ * 'a'..'z'; < 65535 trie nodes; token ids < 65535.  Violations -> ECGB_ERR_UNSUPPORTED. */
+int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t *offsets,
+                          const uint32_t *ids, size_t n_merges, ecgb_tokenizer **out);
+void ecgb_tokenizer_destroy(ecgb_tokenizer *tok);
+/* Introspection: number of trie nodes / deepest path (longest expansion) / symbol classes. */
+int ecgb_tokenizer_info(const ecgb_tokenizer *tok, uint32_t *n_nodes, uint32_t *max_depth,
+                        uint32_t *n_classes);
+
+/* Copies up to `cap` packed trie nodes (host copy; layout in DESIGN.md) and returns the node
+ * count.  Works on a host-only handle (no GPU present). */
+size_t ecgb_tokenizer_copy_nodes(const ecgb_tokenizer *tok, uint64_t *out, size_t cap);
+
+/* ---- quantiser --------------------------------------------------------------------------
+ * normalize_all for n float64 samples: sym_dev[i] = alphabet index 0..25 ('a'+index is the
+ * reference's character).  If clipped_dev != NULL it also receives the reference's first
+ * return value (clip((x-a)/d, 0, 1), float64).  Bit-exact with the reference for every
+ * finite and infinite input; NaN maps to index 0 (numpy's NaN->uint8 cast is unspecified). */
+int ecgb_quantize_hip(const double *signal_dev, size_t n, double percentile_1,
+                      double percentile_99, uint8_t *sym_dev, double *clipped_dev,
+                      void *stream);
+
+/* ---- encoder ----------------------------------------------------------------------------
+ * Scratch the encode entry points need for a batch of `batch` streams of `n_per_stream`
+ * symbols each (device bytes). */
+size_t ecgb_encode_scratch_bytes(const ecgb_tokenizer *tok, size_t batch, size_t n_per_stream);
+
+/* Greedy longest-match encode (lib.rs:163-190) of `batch` independent byte streams.
+ * text_dev: batch x n_per_stream raw bytes (what `text.as_bytes()` is in the reference).
+ * ids_dev:  batch x ids_stride uint32; stream b's tokens start at ids_dev + b*ids_stride.
+ *           Tokens beyond ids_stride are not written (counts still report the full length).
+ * counts_dev: batch uint32, the full token count of each stream. */
+int ecgb_encode_hip(const ecgb_tokenizer *tok, const uint8_t *text_dev, size_t batch,
+                    size_t n_per_stream, uint32_t *ids_dev, size_t ids_stride,
+                    uint32_t *counts_dev, void *scratch_dev, size_t scratch_bytes,
+                    void *stream);
+
+/* Fused front end: quantise `batch` records of n_per_record float64 samples (a (12,L) record
+ * is read in C order = lead-major, data_loader.py:75) and encode each record's symbol
+ * stream.  Same output convention as ecgb_encode_hip. */
+int ecgb_quantize_encode_hip(const ecgb_tokenizer *tok, const double *signal_dev, size_t batch,
+                             size_t n_per_record, double percentile_1, double percentile_99,
+                             uint32_t *ids_dev, size_t ids_stride, uint32_t *counts_dev,
+                             void *scratch_dev, size_t scratch_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECGBYTE_H */
