@@ -465,6 +465,18 @@ extern "C" int ecgb_quantize_hip(const double *signal_dev, size_t n, double perc
                            (hipStream_t)stream);
 }
 
+extern "C" int ecgb_quantizer_thresholds(double percentile_1, double percentile_99, double *thr25)
+{
+    if (!thr25) { ecgb::set_error("ecgb_quantizer_thresholds: NULL argument"); return ECGB_ERR_INVALID; }
+    QuantParams qp = make_quant_params(percentile_1, percentile_99);
+    if (!qp.use_thresholds) {
+        ecgb::set_error("ecgb_quantizer_thresholds: degenerate percentiles (scale <= 0 or non-finite)");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    for (int k = 1; k <= 25; ++k) thr25[k - 1] = qp.thr[k];
+    return ECGB_OK;
+}
+
 extern "C" size_t ecgb_encode_scratch_bytes(const ecgb_tokenizer *, size_t batch, size_t n_per_stream)
 {
     const size_t half_stride = (n_per_stream + 1) / 2;

@@ -19,9 +19,8 @@
  *   ecgb_encode_hip            rust_bpe.encode_text, ecg_byte/rust_bpe/src/lib.rs:149-193
  *   ecgb_quantize_encode_hip   the per-sample front end of ECGTokenDataset.__getitem__,
  *                              ecg_byte/data_loader.py:74-76 (normalize_all -> join -> encode_text)
- *   ecgb_assemble_hip          ECGTokenDataset._prepare_training, ecg_byte/data_loader.py:101-132
- *                              (+ the id->LLM-id mapping of data_loader.py:80)
- *   ecgb_bpe_train_hip         rust_bpe.byte_pair_encoding, ecg_byte/rust_bpe/src/lib.rs:58-125
+ *   ecgb_assemble_hip          ECGTokenDataset._prepare_training / _prepare_inference,
+ *                              ecg_byte/data_loader.py:91-132 (+ the id->LLM-id mapping of :80)
  * INTEGRATION.md shows the binding a reference maintainer would add for each.
  */
 #ifndef ECGBYTE_H
@@ -80,6 +79,13 @@ int ecgb_quantize_hip(const double *signal_dev, size_t n, double percentile_1,
                       double percentile_99, uint8_t *sym_dev, double *clipped_dev,
                       void *stream);
 
+/* The 25 exact step positions the device quantiser compares against: thr[k-1] (k = 1..25) is the
+ * smallest float64 x whose reference level is >= k, found on the host by bisection over float64
+ * bit patterns with the reference's own operation sequence.  Returns ECGB_ERR_UNSUPPORTED for
+ * degenerate parameters (non-positive or non-finite scale), for which the device falls back to
+ * the literal-division kernel.  Host-only; exposed so the staircase can be tested without a GPU. */
+int ecgb_quantizer_thresholds(double percentile_1, double percentile_99, double *thr25);
+
 /* ---- encoder ----------------------------------------------------------------------------
  * Scratch the encode entry points need for a batch of `batch` streams of `n_per_stream`
  * symbols each (device bytes). */
@@ -102,6 +108,26 @@ int ecgb_quantize_encode_hip(const ecgb_tokenizer *tok, const double *signal_dev
                              size_t n_per_record, double percentile_1, double percentile_99,
                              uint32_t *ids_dev, size_t ids_stride, uint32_t *counts_dev,
                              void *scratch_dev, size_t scratch_bytes, void *stream);
+
+/* ---- sequence assembly -------------------------------------------------------------------
+ * ECGTokenDataset._prepare_training (inference == 0, data_loader.py:101-132) or
+ * _prepare_inference (inference != 0, data_loader.py:91-99) for a whole batch.
+ * ids_dev/ids_stride/counts_dev: encoder output as produced by ecgb_*encode_hip.
+ * lut_dev[k] = LLM token id of tokenizer id k ("signal_{k}", data_loader.py:80).
+ * q_ids/a_ids: concatenated question / answer LLM ids with batch+1 offsets each.
+ * Training: row_len must be pad_to_max + 4 and every sample needs len(Q)+len(A) <= pad_to_max
+ * (the reference asserts, data_loader.py:123; the caller checks before the launch).
+ * Outputs are batch x row_len: input_ids (int64), attn_mask (float32, 0 where the id equals
+ * pad_id), labels (int64, -100 before the answer) and position_ids (int64); inference
+ * writes input_ids, attn_mask and lengths_dev only (rows padded with pad_id). */
+int ecgb_assemble_hip(const uint32_t *ids_dev, size_t ids_stride, const uint32_t *counts_dev,
+                      size_t batch, const int32_t *lut_dev, size_t lut_len,
+                      const int32_t *q_ids_dev, const uint32_t *q_offsets_dev,
+                      const int32_t *a_ids_dev, const uint32_t *a_offsets_dev,
+                      int32_t pad_id, int32_t bos_id, int32_t eos_id, int32_t sig_start_id,
+                      int32_t sig_end_id, uint32_t pad_to_max, int inference, uint32_t row_len,
+                      int64_t *input_ids_dev, float *attn_mask_dev, int64_t *labels_dev,
+                      int64_t *position_ids_dev, uint32_t *lengths_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,296 @@
+"""GPU parity tests (run with -m gpu on the MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs, against the committed golden fixtures, and
+-- at BASELINE's full size -- through size-independent properties.  Bar: bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_tokenizer, oracle_batch, random_merges
+from oracle import assemble as OA
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from ecg_byte_amd import _lib
+    assert os.path.exists(_lib.SO_PATH), "HIP extension not built -- no fallback exists"
+    return torch.device("cuda", 0)
+
+
+def _encode_bytes(tk, texts, **kw):
+    """texts: list of equal-length bytes -> list of np.uint32 arrays."""
+    n = len(texts[0])
+    t = torch.from_numpy(np.frombuffer(b"".join(texts), dtype=np.uint8).reshape(len(texts), n).copy()).cuda()
+    ids, counts = tk.encode_bytes(t, **kw)
+    ids, counts = ids.cpu().numpy(), counts.cpu().numpy()
+    return [ids[b, : min(counts[b], ids.shape[1])].astype(np.uint32) for b in range(len(texts))], counts
+
+
+# ---- quantiser -----------------------------------------------------------------------------
+def test_quantiser_vs_reference_golden(dev):
+    from ecg_byte_amd.tokenizer import quantize
+    z = np.load(os.path.join(GOLDEN, "quantize_ref.npz"))
+    for i in range(int(z["n_cases"])):
+        p1, p99 = map(float, z[f"p_{i}"])
+        pc = {"percentile_1": p1, "percentile_99": p99}
+        x = torch.from_numpy(z[f"x_{i}"]).cuda()
+        sym = quantize(x, pc).cpu().numpy()                                   # threshold kernel
+        assert np.array_equal(sym, z[f"sym_{i}"]), f"case {i}: staircase kernel"
+        clipped, sym2 = quantize(x, pc, want_clipped=True)                    # literal-division kernel
+        assert np.array_equal(sym2.cpu().numpy(), z[f"sym_{i}"]), f"case {i}: division kernel"
+        assert np.array_equal(clipped.cpu().numpy(), z[f"clipped_{i}"]), f"case {i}: clipped"
+
+
+def test_quantiser_edges_nan_unaligned_tail(dev):
+    from ecg_byte_amd.tokenizer import quantize
+    rng = np.random.default_rng(0)
+    pc = {"percentile_1": -0.3, "percentile_99": 0.9}
+    for n in (1, 2, 3, 5, 255, 1027, 100003):
+        x = rng.normal(0.3, 0.8, size=n)
+        x[rng.integers(0, n, size=max(1, n // 50))] = np.nan
+        got = quantize(torch.from_numpy(x).cuda(), pc).cpu().numpy()
+        assert np.array_equal(got, O.quantize(x, pc["percentile_1"], pc["percentile_99"])), n   # NaN -> 0
+    # degenerate percentiles (scale <= 0): literal-division kernel, same as the oracle
+    bad = {"percentile_1": 5.0, "percentile_99": -10.0}
+    x = rng.normal(0, 10, size=1000)
+    got = quantize(torch.from_numpy(x).cuda(), bad).cpu().numpy()
+    assert np.array_equal(got, O.quantize(x, 5.0, -10.0))
+    # tokenizer_utils mirror returns the reference's shapes/dtypes
+    from ecg_byte_amd import tokenizer_utils as tu
+    c, s = tu.normalize_all(np.array([[0.0, 1.5, -2.0, 2.0]]), {"percentile_1": -1, "percentile_99": 1})
+    assert s.dtype.kind == "U" and "".join(s[0]) == "mzaz" and c.dtype == np.float64
+
+
+# ---- encoder: known-answer vectors through the drop-in module ---------------------------------
+def test_rust_bpe_encode_text_known_answers(dev):
+    from ecg_byte_amd import rust_bpe
+    assert rust_bpe.encode_text("abc", [([98, 99], 256), ([97, 98], 257)]) == [257, 99]
+    m = [([97, 97], 256)]
+    assert rust_bpe.encode_text("aaaa", m) == [256, 256]
+    assert rust_bpe.encode_text("aaa", m) == [256, 97]
+    assert rust_bpe.encode_text("abc", [([97, 98, 99], 256), ([97, 98, 99], 257)]) == [257]
+    m = [([97, 98, 99, 100], 256)]
+    assert rust_bpe.encode_text("abcd", m) == [256]
+    assert rust_bpe.encode_text("abcx", m) == [97, 98, 99, 120]
+    assert rust_bpe.encode_text("", m) == []
+    assert rust_bpe.encode_text("Hello, wörld", []) == list("Hello, wörld".encode("utf-8"))
+    assert rust_bpe.encode_text("a", [([97], 300)]) == [300]          # a length-1 expansion overrides the byte
+    with pytest.raises(TypeError):
+        rust_bpe.encode_text(123, m)
+
+
+# ---- encoder vs oracle on seeded inputs -------------------------------------------------------
+@pytest.mark.parametrize("tag,L", [("c1", 1000), ("c2", 5000)])
+@pytest.mark.parametrize("B", [1, 3, 64])
+def test_quantize_encode_fixture_tokenizers(dev, tag, L, B):
+    from ecg_byte_amd import synth
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    vocab, merges, pc = load_tokenizer(tag)
+    tk = HipTokenizer(merges)
+    x = synth.synth_ecg(B, L, seed=0)
+    ids, counts = tk.quantize_encode(torch.from_numpy(x).cuda(), pc)
+    ids, counts = ids.cpu().numpy(), counts.cpu().numpy()
+    ref = oracle_batch(O.Trie(merges), x, pc)
+    z = np.load(os.path.join(GOLDEN, "encode_oracle.npz"))
+    for b in range(B):
+        assert counts[b] == ref[b].size
+        assert np.array_equal(ids[b, : counts[b]].astype(np.uint32), ref[b]), f"record {b}"
+        if b < 3:
+            assert np.array_equal(ids[b, : counts[b]], z[f"{tag}_ids_{b}"])   # committed anchor
+
+
+def test_four_streams_per_workgroup_with_ragged_tail(dev):
+    """batch >= 1024 takes the 4-streams-per-workgroup kernel; 1030 leaves a partial workgroup."""
+    from ecg_byte_amd import synth
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    _, merges, pc = load_tokenizer("c1")
+    tk = HipTokenizer(merges)
+    base = synth.synth_ecg(103, 1000, seed=4)
+    x = np.concatenate([base] * 10)                                      # 1030 records
+    ids, counts = tk.quantize_encode(torch.from_numpy(x).cuda(), pc)
+    ids, counts = ids.cpu().numpy(), counts.cpu().numpy()
+    ref = oracle_batch(O.Trie(merges), base, pc)
+    for b in range(x.shape[0]):
+        r = ref[b % 103]
+        assert counts[b] == r.size and np.array_equal(ids[b, : r.size].astype(np.uint32), r), b
+
+
+@pytest.mark.parametrize("n", [1, 2, 31, 255, 256, 257, 511, 513, 65535, 65536, 65537, 131073, 200001])
+def test_stream_lengths_across_chunk_and_segment_boundaries(dev, n):
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    rng = np.random.default_rng(n)
+    merges = random_merges(rng, 300, alphabet=b"abcd", max_len=9)
+    tk = HipTokenizer(merges)
+    texts = [bytes(rng.choice(np.frombuffer(b"aaabbcd", dtype=np.uint8), size=n)) for _ in range(3)]
+    got, counts = _encode_bytes(tk, texts)
+    for b, t in enumerate(texts):
+        ref = O.encode_text(t, merges)
+        assert counts[b] == len(ref) and np.array_equal(got[b], ref), (n, b)
+
+
+def test_empty_batch_and_empty_streams(dev):
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    tk = HipTokenizer([([97, 98], 256)])
+    ids, counts = tk.encode_bytes(torch.zeros((3, 0), dtype=torch.uint8, device="cuda"))
+    assert counts.cpu().tolist() == [0, 0, 0]
+    ids, counts = tk.quantize_encode(torch.zeros((0, 12, 10), dtype=torch.float64, device="cuda"),
+                                     {"percentile_1": 0.0, "percentile_99": 1.0})
+    assert ids.shape[0] == 0 and counts.shape[0] == 0
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_random_merges_duplicates_interior_nodes_extra_bytes(dev, seed):
+    """Non-prefix-closed vocabularies, duplicate expansions (last wins), bytes outside a..z in the
+    merges (extra symbol classes) and bytes that occur in no merge at all."""
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    rng = np.random.default_rng(100 + seed)
+    alphabet = [b"abc", b"abcdefgh", b"xyz.,", b"ab\x00\xff", b"mnopqr \n"][seed]
+    merges = random_merges(rng, int(rng.integers(20, 600)), alphabet=alphabet, max_len=14, dup_frac=0.15)
+    tk = HipTokenizer(merges)
+    pool = np.frombuffer(alphabet + b"~Q", dtype=np.uint8)
+    for n in (7, 1000, 5003):
+        texts = [bytes(rng.choice(pool, size=n)) for _ in range(4)]
+        got, counts = _encode_bytes(tk, texts)
+        for b, t in enumerate(texts):
+            ref = O.encode_text(t, merges)
+            assert counts[b] == len(ref) and np.array_equal(got[b], ref), (seed, n, b)
+
+
+def test_chains_that_never_resynchronise(dev):
+    """Adversarial for the speculative chunk parse: with the single token 'ab' over 'ababab...'
+    a parse started at an odd offset never meets the true chain, and long same-symbol runs with
+    power-of-two tokens make the true chain jump over whole chunks.  The fixed-point stitch
+    must still return the sequential answer."""
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    cases = []
+    cases.append(([([97, 98], 256)], b"b" + b"ab" * 40000))             # every chunk starts mis-phased
+    cases.append(([([97, 98], 256)], b"ab" * 40000 + b"a"))
+    runs = [([97] * (1 << k), 256 + k - 1) for k in range(1, 11)]        # a^2 .. a^1024
+    cases.append((runs, b"a" * 70001))
+    cases.append((runs, (b"a" * 1000 + b"b") * 90))
+    three = [([97, 98, 99], 256), ([98, 99, 97], 257), ([99, 97, 98], 258)]
+    cases.append((three, b"c" + b"abc" * 30000))
+    for merges, text in cases:
+        tk = HipTokenizer(merges)
+        got, counts = _encode_bytes(tk, [text])
+        ref = O.encode_text(text, merges)
+        assert counts[0] == len(ref) and np.array_equal(got[0], ref)
+
+
+def test_ids_stride_truncates_but_counts_full_and_prefix_stable(dev):
+    from ecg_byte_amd import synth
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    _, merges, pc = load_tokenizer("c2")
+    tk = HipTokenizer(merges)
+    x = synth.synth_ecg(5, 5000, seed=9)
+    xd = torch.from_numpy(x).cuda()
+    full, counts = tk.quantize_encode(xd, pc)
+    cut, counts2 = tk.quantize_encode(xd, pc, ids_stride=1020)
+    assert torch.equal(counts, counts2) and cut.shape == (5, 1020)
+    assert torch.equal(cut, full[:, :1020])
+
+
+# ---- full-size properties (BASELINE configs[1]: 12x5000, vocab 4k) ----------------------------
+def test_full_size_properties(dev):
+    """4096 records of 12x5000: every record's token lengths sum to 60000 (a checksum of the whole
+    decode), ids are in range, and a seeded sample of records equals the oracle bit for bit."""
+    from ecg_byte_amd import synth
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    vocab, merges, pc = load_tokenizer("c2")
+    tk = HipTokenizer(merges)
+    B, L = 4096, 5000
+    base = synth.synth_ecg(256, L, seed=21)
+    rng = np.random.default_rng(3)
+    gains = rng.uniform(0.8, 1.2, size=(B // 256, 1, 1, 1))
+    x = (base[None] * gains).reshape(B, 12, L)                           # 4096 distinct records
+    xd = torch.from_numpy(x).cuda()
+    ids, counts = tk.quantize_encode(xd, pc)
+    tok_len = np.zeros(256 + len(merges), dtype=np.int64)
+    tok_len[:256] = 1
+    for seq, tid in merges:
+        tok_len[tid] = len(seq)
+    tl = torch.from_numpy(tok_len).cuda()
+    col = torch.arange(ids.shape[1], device="cuda")[None, :]
+    valid = col < counts[:, None]
+    idl = ids.long().clamp_(0, tok_len.size - 1)
+    assert bool(((ids >= 0) & (ids < tok_len.size) | ~valid).all())
+    sums = (tl[idl] * valid).sum(dim=1)
+    assert bool((sums == 12 * L).all()), "token lengths do not tile the symbol stream"
+    trie = O.Trie(merges)
+    ids_h, counts_h = ids.cpu().numpy(), counts.cpu().numpy()
+    for b in rng.choice(B, size=48, replace=False):
+        ref = trie.quantize_encode(x[b], pc["percentile_1"], pc["percentile_99"])
+        assert counts_h[b] == ref.size and np.array_equal(ids_h[b, : ref.size].astype(np.uint32), ref), b
+        if b % 7 == 0:   # reference's own check: decode(encode(x)) == x (train_tokenizer.py:58-60)
+            text = O.symbols_to_text(O.quantize(x[b], pc["percentile_1"], pc["percentile_99"])).decode()
+            assert O.decode_text(ids_h[b, : counts_h[b]].tolist(), vocab) == text
+    # idempotence: same input, same output
+    ids2, counts2 = tk.quantize_encode(xd, pc)
+    assert torch.equal(counts, counts2) and bool(((ids == ids2) | ~valid).all())
+
+
+# ---- sequence assembly ------------------------------------------------------------------------
+def test_assemble_vs_reference_golden(dev):
+    from ecg_byte_amd.data_loader import BatchAssembler
+    with open(os.path.join(GOLDEN, "assemble_ref.json")) as f:
+        cases = json.load(f)
+    for c in cases:
+        sp = c["special"]
+        sig = np.asarray(c["sig"], dtype=np.int64)
+        # identity-shifted LUT: tokenizer id k -> LLM id k + 128260 covers the golden's id range
+        lut = np.arange(0, 4000, dtype=np.int32) + 128260
+        asm = BatchAssembler([([97, 98], 256)], lut, sp["<pad>"], sp["<bos>"], sp["<eos>"],
+                             sp["<sig_start>"], sp["<sig_end>"], c["pad_to_max"])
+        n = max(1, sig.size)
+        ids = torch.zeros((1, n), dtype=torch.int32, device="cuda")
+        ids[0, : sig.size] = torch.from_numpy((sig - 128260).astype(np.int32)).cuda()
+        counts = torch.tensor([sig.size], dtype=torch.int32, device="cuda")
+        r = asm.assemble(ids, counts, [c["q"]], [c["a"]])
+        for k in ("tokenized_signal", "attn_mask", "quantized_signal_ids_input", "position_ids"):
+            assert np.array_equal(r[k][0].cpu().numpy(), np.asarray(c[k])), (c["pad_to_max"], k)
+        inf = asm.assemble(ids, counts, [c["q"]], inference=True)
+        m = int(inf["lengths"][0])
+        assert np.array_equal(inf["tokenized_signal"][0, :m].cpu().numpy(), np.asarray(c["inference_tokenized_signal"]))
+        assert np.array_equal(inf["attn_mask"][0, :m].cpu().numpy(), np.asarray(c["inference_attn_mask"]))
+
+
+def test_batch_assembler_end_to_end_vs_oracle_pipeline(dev):
+    """signal -> quantise -> encode -> LUT -> rows, batch of 33, against the oracle pipeline
+    (quantize_encode oracle + restated _prepare_training), incl. pad ids appearing inside Q."""
+    from ecg_byte_amd import synth
+    from ecg_byte_amd.data_loader import BatchAssembler
+    vocab, merges, pc = load_tokenizer("c2")
+    rng = np.random.default_rng(17)
+    keys = list(vocab.keys())
+    rng.shuffle(keys)                                                     # pickled-dict order is arbitrary
+    lut = np.zeros(max(keys) + 1, dtype=np.int32)
+    lut[keys] = 128256 + np.arange(len(keys))
+    pad, bos, eos, s0, s1 = 132014, 128000, 128001, 132012, 132013
+    B, L, P = 33, 5000, 1020
+    x = synth.synth_ecg(B, L, seed=33)
+    x[5, :, 600:] = 0.0                                                   # a highly compressible record -> padded row
+    x[6] = 0.0
+    qs = [rng.integers(1000, 100000, size=int(rng.integers(0, 25))).tolist() for _ in range(B)]
+    ans = [rng.integers(1000, 100000, size=int(rng.integers(0, 33))).tolist() for _ in range(B)]
+    qs[2][3:5] = [pad, pad]                                               # mask is by VALUE (data_loader.py:21-22)
+    asm = BatchAssembler(merges, lut, pad, bos, eos, s0, s1, P)
+    out = asm(torch.from_numpy(x).cuda(), pc, qs, ans)
+    trie = O.Trie(merges)
+    n_padded = 0
+    for b in range(B):
+        sig = lut[trie.quantize_encode(x[b], pc["percentile_1"], pc["percentile_99"])]
+        r = OA.prepare_training(sig.tolist(), qs[b], ans[b], pad, bos, eos, s0, s1, P)
+        n_padded += int(r["tokenized_signal"][0] == pad)
+        for k in r:
+            assert np.array_equal(out[k][b].cpu().numpy(), r[k]), (b, k)
+        assert out["attn_mask"].dtype == torch.float32 and out["position_ids"].dtype == torch.int64
+    assert n_padded >= 2
+    with pytest.raises(AssertionError):
+        asm.assemble(*asm.encode(torch.from_numpy(x[:1]).cuda(), pc, max_tokens=P), [list(range(1000))], [list(range(30))])

@@ -1,0 +1,192 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol that
+include/ecgbyte.h declares, the packed trie layout reproduces the oracle's greedy parse, the
+quantiser's threshold staircase is exact, and device entry points fail loudly without a GPU.
+No compute kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+from helpers import load_tokenizer, random_merges
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ecg_byte_amd import _lib
+    if not os.path.exists(_lib.SO_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "ecgbyte.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ecgb_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = _header_functions()
+    assert len(names) >= 10
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/ecgbyte.h but not exported"
+    assert lib.ecgb_version() >> 16 == 1
+
+
+def _make_tok(lib, merges):
+    from ecg_byte_amd.tokenizer import flatten_merges
+    flat, off, ids = flatten_merges(merges)
+    h = C.c_void_p()
+    u32p = C.POINTER(C.c_uint32)
+    rc = lib.ecgb_tokenizer_create(flat.ctypes.data_as(u32p), off.ctypes.data_as(u32p),
+                                   ids.ctypes.data_as(u32p), len(merges), C.byref(h))
+    return rc, h
+
+
+def _nodes(lib, h):
+    n = lib.ecgb_tokenizer_copy_nodes(h, None, 0)
+    out = np.empty(n, dtype=np.uint64)
+    lib.ecgb_tokenizer_copy_nodes(h, out.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+    return out
+
+
+def _walk_packed(nodes, byte_to_class, text):
+    """Greedy longest match over the packed device trie -- mirrors encode_kernel's step."""
+    out, i, n = [], 0, len(text)
+    nodes = [int(v) for v in nodes]
+    while i < n:
+        node, j, best_len, best_tok = 0, i, 0, None
+        while True:
+            rec = nodes[node]
+            tok = rec >> 48
+            if j != i and tok != 0xFFFF:
+                best_len, best_tok = j - i, tok
+            if j < n:
+                cls = byte_to_class.get(text[j], 255)
+                bm = rec & 0xFFFFFFFF
+                if cls < 32 and (bm >> cls) & 1:
+                    node = ((rec >> 32) & 0xFFFF) + bin(bm & ((1 << cls) - 1)).count("1")
+                    j += 1
+                    continue
+            break
+        if best_len == 0:
+            best_len, best_tok = 1, text[i]
+        out.append(best_tok)
+        i += best_len
+    return out
+
+
+def _classes(merges):
+    b2c = {ord("a") + c: c for c in range(26)}
+    extra = sorted({b for seq, _ in merges for b in seq} - set(b2c))
+    for k, b in enumerate(extra):
+        b2c[b] = 26 + k
+    return b2c
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_packed_trie_reproduces_oracle(lib, seed):
+    rng = np.random.default_rng(seed)
+    alphabet = [b"abcdef", b"ab", b"abcxyz.,!", b"mnop\x80\xff"][seed]
+    merges = random_merges(rng, int(rng.integers(5, 300)), alphabet=alphabet)
+    rc, h = _make_tok(lib, merges)
+    assert rc == 0
+    try:
+        nodes = _nodes(lib, h)
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        assert lib.ecgb_tokenizer_info(h, C.byref(a), C.byref(b), C.byref(c)) == 0
+        assert a.value == nodes.size and b.value == max(len(m[0]) for m in merges)
+        b2c = _classes(merges)
+        assert c.value == len(b2c)
+        for _ in range(10):
+            pool = np.frombuffer(alphabet + b"qz~", dtype=np.uint8)
+            text = bytes(rng.choice(pool, size=int(rng.integers(0, 500))))
+            assert _walk_packed(nodes, b2c, text) == O.encode_text(text, merges)
+    finally:
+        lib.ecgb_tokenizer_destroy(h)
+
+
+def test_packed_trie_fixture_tokenizer(lib):
+    _, merges, pc = load_tokenizer("c1")
+    from ecg_byte_amd import synth
+    rc, h = _make_tok(lib, merges)
+    assert rc == 0
+    nodes = _nodes(lib, h)
+    lib.ecgb_tokenizer_destroy(h)
+    x = synth.synth_ecg(1, 1000, seed=0)
+    text = O.symbols_to_text(O.quantize(x[0], pc["percentile_1"], pc["percentile_99"]))[:3000]
+    assert _walk_packed(nodes, _classes(merges), text) == O.encode_text(text, merges)
+
+
+def test_tokenizer_limits_are_reported(lib):
+    many = [([i, i + 1], 256 + i) for i in range(0, 80, 2)]          # > 32 symbol classes
+    rc, h = _make_tok(lib, many)
+    assert rc == -3 and b"32 distinct" in lib.ecgb_last_error()
+    rc, h = _make_tok(lib, [([97, 98], 70000)])                        # token id does not fit
+    assert rc == -3
+    rc, h = _make_tok(lib, [([97, 300], 256)])                         # not a byte
+    assert rc == -1
+
+
+def test_device_entry_points_fail_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    rc, h = _make_tok(lib, [([97, 98], 256)])
+    assert rc == 0                                                     # host-only handle
+    dummy = (C.c_uint8 * 4096)()
+    p = C.cast(dummy, C.c_void_p)
+    rc = lib.ecgb_quantize_encode_hip(h, p, 1, 16, 0.0, 1.0, p, 16, p, p, 4096, None)
+    assert rc == -5 and b"no device copy" in lib.ecgb_last_error()
+    rc = lib.ecgb_encode_hip(h, p, 1, 16, p, 16, p, p, 4096, None)
+    assert rc == -5
+    lib.ecgb_tokenizer_destroy(h)
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    with pytest.raises(TypeError):
+        HipTokenizer([([97, 98], 256)]).quantize_encode(torch.zeros(1, 12, 10, dtype=torch.float64),
+                                                        {"percentile_1": 0.0, "percentile_99": 1.0})
+
+
+def test_quantiser_staircase_is_exact(lib):
+    """Classifying by the host-computed thresholds == the reference arithmetic, for the
+    reference-generated golden inputs (incl. +-4 ulp around every bin edge)."""
+    z = np.load(os.path.join(GOLDEN, "quantize_ref.npz"))
+    for i in range(int(z["n_cases"])):
+        p1, p99 = map(float, z[f"p_{i}"])
+        thr = np.empty(25, dtype=np.float64)
+        assert lib.ecgb_quantizer_thresholds(p1, p99, thr.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        assert np.all(np.diff(thr) >= 0)
+        x = z[f"x_{i}"].reshape(-1)
+        level = np.searchsorted(thr, x, side="right").astype(np.uint8)   # #{k : x >= thr[k]}
+        assert np.array_equal(level, z[f"sym_{i}"].reshape(-1)), f"case {i}"
+        # each threshold is the first float64 of its level
+        below = np.nextafter(thr, -np.inf)
+        assert np.array_equal(O.quantize(thr, p1, p99), np.arange(1, 26))
+        assert np.array_equal(O.quantize(below, p1, p99), np.arange(0, 25))
+    thr = np.empty(25)
+    assert lib.ecgb_quantizer_thresholds(5.0, -10.0, thr.ctypes.data_as(C.POINTER(C.c_double))) == -3
+
+
+def test_rust_bpe_vocab_bookkeeping():
+    from ecg_byte_amd import rust_bpe
+    vocab, merges = rust_bpe.vocab_merges_from_pairs([(97, 97), (256, 98), (200, 257)])
+    assert merges == [([97, 97], 256), ([97, 97, 98], 257), ([200, 97, 97, 98], 258)]
+    assert vocab[258] == "<200>aab" and vocab[65] == "A" and vocab[128] == "<128>"   # lib.rs:50-56
+    assert (vocab, merges) == O.pairs_to_vocab_merges([(97, 97), (256, 98), (200, 257)])
+
+
+def test_tokenizer_pickle_format_roundtrip(tmp_path):
+    from ecg_byte_amd import tokenizer_utils as tu
+    vocab, merges, _ = load_tokenizer("c1")
+    p = tmp_path / "tok.pkl"
+    tu.save_vocab_and_merges(vocab, merges, str(p))
+    v2, m2 = tu.load_vocab_and_merges(str(p))
+    assert v2 == vocab and m2 == merges
+    sym = np.array([["a", "z"], ["m", "b"]])
+    back = tu.reverse_normalize_all(sym, {"percentile_1": -1.0, "percentile_99": 1.0})
+    assert np.array_equal(back, O.dequantize(np.array([[0, 25], [12, 1]], dtype=np.uint8), -1.0, 1.0))
