@@ -17,32 +17,40 @@
 // ---- Encoder ---------------------------------------------------------------------------
 // Greedy longest match is a sequential chain i -> i + len(i).  Walking the trie from EVERY
 // position would cost ~21 lookups per symbol on ECG streams; following only the chain costs
-// ~1.15.  So each stream is cut into 256-symbol chunks, one lane per chunk:
-//   pass 0  every lane parses its chunk speculatively from the chunk start, setting one
-//           bit per token start in an LDS bitmap, storing ids of tokens longer than one
-//           symbol in a half-resolution id array, and recording where its chain leaves the chunk;
+// ~1.15.  One persistent workgroup per CU keeps the trie (8 B/node, breadth-first) in LDS and
+// works through its share of the batch, E streams at a time, in 32768-symbol segments:
+//   stage   256 lanes per stream read the float64 samples (coalesced 16-byte loads), classify
+//           them against the staircase and write the symbols straight into LDS -- the symbol
+//           stream never exists in HBM (for byte-stream input: LUT classify instead);
+//   pass 0  the segment is cut into 128-symbol chunks, one lane each; every lane parses its
+//           chunk speculatively from the chunk start, keeps one bit per token start in an LDS
+//           bitmap, stores ids of tokens longer than one symbol in a half-resolution id
+//           array (L2-resident per-workgroup scratch) and records where its chain leaves;
 //   stitch  lane c re-parses from the exit of chunk c-1 until it lands on a position its own
 //           speculative chain marked (greedy chains re-synchronise after ~40 symbols on
 //           ECG data) -- iterated to a fixed point, so the result is the true chain whatever
 //           the data (worst case: one iteration per chunk);
 //   emit    popcount + group scan of the bitmap gives every token its output slot.
-// The trie (8 B/node, breadth-first) sits in LDS as far as it fits; deeper nodes come from L2.
+// Inner loop = two LDS reads (symbol byte, trie node) and ~20 VALU ops per symbol; no global
+// memory on the dependent path.  Trie nodes that do not fit LDS are read through L2.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstring>
 #include <limits>
 #include <string>
+#include <type_traits>
 
 #include "tokenizer.hpp"
 
 namespace {
 
-constexpr int kChunk = 256;                 // symbols per lane-chunk (multiple of 32)
+constexpr int kChunk = 128;                 // symbols per lane-chunk (multiple of 32)
 constexpr int kLanes = 256;                 // lanes (chunks) per stream per segment
-constexpr int kSeg = kChunk * kLanes;       // symbols per segment = 65536
-constexpr int kWordsPerChunk = kChunk / 32; // 8
-constexpr int kMarkWords = kSeg / 32;       // 2048 words = 8 KiB per stream in flight
+constexpr int kSeg = kChunk * kLanes;       // symbols per segment = 32768
+constexpr int kWordsPerChunk = kChunk / 32; // 4
+constexpr int kMarkWords = kSeg / 32;       // 1024 words = 4 KiB per stream in flight
+constexpr int kHalfPerSlot = kSeg / 2;      // u16 id slots per stream in flight (global scratch)
 
 // ------------------------------------------------------------------------------------------
 // Reference arithmetic of normalize_all, one operation per line (compiled with
@@ -117,8 +125,11 @@ __device__ __forceinline__ uint32_t level_from_thresholds(double x, double a, do
     return (uint32_t)b;
 }
 
-// sym[i] = level(x[i]); four samples per thread per iteration, one 4-byte store.
+// Records are rows: record r reads x + r*n and writes sym + r*sym_stride (blockIdx.y strides
+// over records, blockIdx.x/threads over the row).  Vector variant: n % 4 == 0 and 16-byte
+// aligned x, four samples per thread per iteration, one 4-byte store.
 __global__ __launch_bounds__(256) void quantize_thr_kernel(const double *__restrict__ x, size_t n,
+                                                           size_t rows, size_t sym_stride,
                                                            QuantParams qp, uint8_t *__restrict__ sym)
 {
     __shared__ double thr[28];
@@ -126,51 +137,54 @@ __global__ __launch_bounds__(256) void quantize_thr_kernel(const double *__restr
     __syncthreads();
     const size_t n4 = n / 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const double2 v0 = *reinterpret_cast<const double2 *>(x + 4 * i);
-        const double2 v1 = *reinterpret_cast<const double2 *>(x + 4 * i + 2);
-        uint32_t w = level_from_thresholds(v0.x, qp.a, qp.scale, thr);
-        w |= level_from_thresholds(v0.y, qp.a, qp.scale, thr) << 8;
-        w |= level_from_thresholds(v1.x, qp.a, qp.scale, thr) << 16;
-        w |= level_from_thresholds(v1.y, qp.a, qp.scale, thr) << 24;
-        *reinterpret_cast<uint32_t *>(sym + 4 * i) = w;
+    for (size_t r = blockIdx.y; r < rows; r += gridDim.y) {
+        const double *xr = x + r * n;
+        uint8_t *sr = sym + r * sym_stride;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const double2 v0 = *reinterpret_cast<const double2 *>(xr + 4 * i);
+            const double2 v1 = *reinterpret_cast<const double2 *>(xr + 4 * i + 2);
+            uint32_t w = level_from_thresholds(v0.x, qp.a, qp.scale, thr);
+            w |= level_from_thresholds(v0.y, qp.a, qp.scale, thr) << 8;
+            w |= level_from_thresholds(v1.x, qp.a, qp.scale, thr) << 16;
+            w |= level_from_thresholds(v1.y, qp.a, qp.scale, thr) << 24;
+            *reinterpret_cast<uint32_t *>(sr + 4 * i) = w;
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-        const size_t i = n4 * 4 + threadIdx.x;
-        sym[i] = (uint8_t)level_from_thresholds(x[i], qp.a, qp.scale, thr);
-    }
+}
+
+// Scalar staircase variant for rows the vector variant cannot take (n % 4 != 0 / unaligned).
+__global__ __launch_bounds__(256) void quantize_thr_scalar_kernel(const double *__restrict__ x, size_t n,
+                                                                  size_t rows, size_t sym_stride,
+                                                                  QuantParams qp, uint8_t *__restrict__ sym)
+{
+    __shared__ double thr[28];
+    if (threadIdx.x < 28) thr[threadIdx.x] = qp.thr[threadIdx.x];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t r = blockIdx.y; r < rows; r += gridDim.y)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+            sym[r * sym_stride + i] = (uint8_t)level_from_thresholds(x[r * n + i], qp.a, qp.scale, thr);
 }
 
 // Literal operation sequence of tokenizer_utils.py:15-17 (IEEE fp64 division on the device).
 __global__ __launch_bounds__(256) void quantize_exact_kernel(const double *__restrict__ x, size_t n,
+                                                             size_t rows, size_t sym_stride,
                                                              double a, double d,
                                                              uint8_t *__restrict__ sym,
                                                              double *__restrict__ clipped)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        double nrm = (x[i] - a) / d;
-        double c = nrm;
-        if (c < 0.0) c = 0.0;
-        if (c > 1.0) c = 1.0;
-        double s = floor(c * 26.0);
-        if (s > 25.0) s = 25.0;
-        if (clipped) clipped[i] = c;
-        sym[i] = (s == s) ? (uint8_t)s : (uint8_t)0;
-    }
-}
-
-// raw bytes -> symbol classes (generic encode_text entry)
-__global__ __launch_bounds__(256) void classify_kernel(const uint8_t *__restrict__ raw, size_t n,
-                                                       const uint8_t *__restrict__ lut,
-                                                       uint8_t *__restrict__ cls)
-{
-    __shared__ uint8_t s_lut[256];
-    s_lut[threadIdx.x] = lut[threadIdx.x];
-    __syncthreads();
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        cls[i] = s_lut[raw[i]];
+    for (size_t r = blockIdx.y; r < rows; r += gridDim.y)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            double nrm = (x[r * n + i] - a) / d;
+            double c = nrm;
+            if (c < 0.0) c = 0.0;
+            if (c > 1.0) c = 1.0;
+            double s = floor(c * 26.0);
+            if (s > 25.0) s = 25.0;
+            if (clipped) clipped[r * n + i] = c;
+            sym[r * sym_stride + i] = (s == s) ? (uint8_t)s : (uint8_t)0;
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -179,18 +193,33 @@ struct EncodeArgs {
     uint32_t n_nodes;
     uint32_t n_lds_nodes;     // nodes [0, n_lds_nodes) are staged in LDS
     const uint8_t *lut;       // 256 B byte->class | 32 x u16 single_id | 32 B class->byte
-    const uint8_t *cls;       // batch x n symbol classes
-    const uint8_t *raw;       // batch x n raw bytes (only read for class kOtherClass); may be NULL
-    uint16_t *ids_half;       // batch x half_stride scratch
-    size_t half_stride;
+    const double *signal;     // batch x n float64 samples            (INPUT_F64)
+    const uint8_t *raw;       // batch x n raw bytes                  (INPUT_BYTES)
+    QuantParams qp;
+    uint16_t *ids_half;       // gridDim.x x E x kHalfPerSlot scratch (per workgroup, reused)
     uint32_t *ids_out;        // batch x ids_stride
     size_t ids_stride;
     uint32_t *counts;         // batch
     uint32_t n;               // symbols per stream
     uint32_t batch;
+    uint32_t margin;          // symbols staged past the segment end (>= trie depth), multiple of 16
+#ifdef ECGB_PROFILE
+    unsigned long long *prof; // per workgroup: 8 words of phase timers / counters (dev builds only)
+#endif
 };
 
-// clear bits [lo, hi) of a lane-owned run of mark words (absolute bit indices in the segment)
+#ifdef ECGB_PROFILE
+unsigned long long *g_prof_dev = nullptr;
+#define PROF_STAMP(k) do { if (A.prof && threadIdx.x == 0) A.prof[blockIdx.x * 8 + (k)] += clock64() - t_prof; t_prof = clock64(); } while (0)
+#define PROF_COUNT(k, v) do { if (A.prof && threadIdx.x == 0) A.prof[blockIdx.x * 8 + (k)] += (v); } while (0)
+#else
+#define PROF_STAMP(k) do { } while (0)
+#define PROF_COUNT(k, v) do { } while (0)
+#endif
+
+constexpr int INPUT_F64 = 0, INPUT_BYTES = 1;
+
+// clear bits [lo, hi) of a lane-owned run of mark words (segment-relative bit indices)
 __device__ __forceinline__ void clear_bits(uint32_t *marks, uint32_t lo, uint32_t hi)
 {
     if (lo >= hi) return;
@@ -203,161 +232,255 @@ __device__ __forceinline__ void clear_bits(uint32_t *marks, uint32_t lo, uint32_
     }
 }
 
-// E streams per workgroup, kLanes lanes each.
-template <int E>
+// Persistent kernel: E streams per workgroup at a time, kLanes lanes each.
+// ALL_LDS: the whole trie is staged in LDS.  VEC: n % 2 == 0 and 16-byte aligned rows, so
+// the float64 samples can be read two at a time.
+template <int E, int INPUT, bool ALL_LDS, bool VEC>
 __global__ __launch_bounds__(kLanes *E) void encode_kernel(EncodeArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t sym_cap = kSeg + A.margin;                 // bytes per stream slot, multiple of 16
     uint64_t *s_trie = reinterpret_cast<uint64_t *>(smem);
-    uint32_t *s_marks_all = reinterpret_cast<uint32_t *>(s_trie + A.n_lds_nodes);
+    double *s_thr = reinterpret_cast<double *>(s_trie + A.n_lds_nodes);        // 28
+    uint8_t *s_sym_all = reinterpret_cast<uint8_t *>(s_thr + 28);
+    uint32_t *s_marks_all = reinterpret_cast<uint32_t *>(s_sym_all + (size_t)E * sym_cap);
     uint32_t *s_exit_all = s_marks_all + E * kMarkWords;
-    uint32_t *s_wsum_all = s_exit_all + E * kLanes;          // E x 4 wave totals
-    uint16_t *s_single = reinterpret_cast<uint16_t *>(s_wsum_all + E * 4);  // 32 entries
+    uint32_t *s_wsum_all = s_exit_all + E * kLanes;            // E x 4 wave totals
+    uint16_t *s_single = reinterpret_cast<uint16_t *>(s_wsum_all + E * 4);     // 32 entries
+    uint8_t *s_b2c = reinterpret_cast<uint8_t *>(s_single + 32);               // 256 (INPUT_BYTES)
 
     const int tid = threadIdx.x;
     const int g = tid / kLanes;          // stream slot inside the workgroup
     const int c = tid % kLanes;          // chunk index inside the segment
     for (uint32_t i = tid; i < A.n_lds_nodes; i += kLanes * E) s_trie[i] = A.trie[i];
+    if (tid < 28) s_thr[tid] = A.qp.thr[tid];
     if (tid < 32) s_single[tid] = reinterpret_cast<const uint16_t *>(A.lut + 256)[tid];
+    if (INPUT == INPUT_BYTES && tid < 256) s_b2c[tid] = A.lut[tid];
 
-    uint32_t *marks = s_marks_all + g * kMarkWords;   // this stream's bitmap (segment-relative bits)
+    uint8_t *sym = s_sym_all + (size_t)g * sym_cap;   // sym[k] = class of position seg_base + k
+    uint32_t *marks = s_marks_all + g * kMarkWords;   // bit k = a token starts at seg_base + k
     uint32_t *exits = s_exit_all + g * kLanes;
     uint32_t *wsum = s_wsum_all + g * 4;
-
-    const uint32_t b = blockIdx.x * E + g;
-    const bool live = b < A.batch;
-    const uint32_t n = A.n;
-    const uint8_t *cls = A.cls + (size_t)(live ? b : 0) * n;
-    const uint8_t *raw = A.raw ? A.raw + (size_t)(live ? b : 0) * n : nullptr;
-    uint16_t *ids_half = A.ids_half + (size_t)(live ? b : 0) * A.half_stride;
-    uint32_t *out = A.ids_out + (size_t)(live ? b : 0) * A.ids_stride;
+    uint32_t *my = marks + c * kWordsPerChunk;        // lane-owned words
+    uint16_t *ids_half = A.ids_half + ((size_t)blockIdx.x * E + g) * kHalfPerSlot;
     const uint64_t *g_trie = A.trie;
     const uint32_t n_lds = A.n_lds_nodes;
+    const uint32_t n = A.n;
+    const double qa = A.qp.a, qscale = A.qp.scale;
+#ifdef ECGB_PROFILE
+    long long t_prof = clock64();
+#endif
 
-    uint32_t carry = 0;     // true chain position entering the segment
-    uint32_t out_off = 0;   // tokens emitted so far for this stream
+    const uint32_t units = (A.batch + E - 1) / E;
+    for (uint32_t unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        const uint32_t b = unit * E + g;
+        const bool live = b < A.batch;
+        const size_t row = (size_t)(live ? b : 0) * n;
+        uint32_t *out = A.ids_out + (size_t)(live ? b : 0) * A.ids_stride;
+        uint32_t carry = 0;     // true chain position entering the segment
+        uint32_t out_off = 0;   // tokens emitted so far for this stream
 
-    for (uint32_t seg_base = 0; seg_base < n; seg_base += kSeg) {
-        const uint32_t seg_end = min(seg_base + (uint32_t)kSeg, n);
-        const uint32_t s_c = min(seg_base + (uint32_t)c * kChunk, seg_end);   // chunk [s_c, e_c)
-        const uint32_t e_c = min(s_c + (uint32_t)kChunk, seg_end);
-        uint32_t *my = marks + c * kWordsPerChunk;   // lane-owned words; bit index = pos - seg_base
+        for (uint32_t seg_base = 0; seg_base < n; seg_base += kSeg) {
+            const uint32_t seg_end = min(seg_base + (uint32_t)kSeg, n);
+            const uint32_t s_c = min(seg_base + (uint32_t)c * kChunk, seg_end);   // chunk [s_c, e_c)
+            const uint32_t e_c = min(s_c + (uint32_t)kChunk, seg_end);
+            __syncthreads();   // previous segment/unit fully emitted; (first time) trie + tables staged
+
+            // ---- stage: positions [seg_base, seg_base + stage_len) -> symbol classes in LDS;
+            // positions >= n get the sentinel class (no trie node has that child bit).
+            {
+                const uint32_t stage_len = min(sym_cap, (n - seg_base + 16u) & ~15u);   // >= 1 sentinel past n
+                if (live) {
+                    if (INPUT == INPUT_F64) {
+                        const double *x = A.signal + row + seg_base;
+                        for (uint32_t k = (uint32_t)c * 4; k < stage_len; k += kLanes * 4) {
+                            uint32_t w;
+                            if (VEC && seg_base + k + 4 <= n) {
+                                const double2 v0 = *reinterpret_cast<const double2 *>(x + k);
+                                const double2 v1 = *reinterpret_cast<const double2 *>(x + k + 2);
+                                w = level_from_thresholds(v0.x, qa, qscale, s_thr);
+                                w |= level_from_thresholds(v0.y, qa, qscale, s_thr) << 8;
+                                w |= level_from_thresholds(v1.x, qa, qscale, s_thr) << 16;
+                                w |= level_from_thresholds(v1.y, qa, qscale, s_thr) << 24;
+                            } else {
+                                w = 0;
 #pragma unroll
-        for (int w = 0; w < kWordsPerChunk; ++w) my[w] = 0;
-        __syncthreads();   // trie staged (first segment) / previous segment's emit done
+                                for (int t = 0; t < 4; ++t) {
+                                    const uint32_t pos = seg_base + k + t;
+                                    const uint32_t lv = (pos < n) ? level_from_thresholds(x[k + t], qa, qscale, s_thr)
+                                                                  : ecgb::kOtherClass;
+                                    w |= lv << (8 * t);
+                                }
+                            }
+                            *reinterpret_cast<uint32_t *>(sym + k) = w;
+                        }
+                    } else {
+                        const uint8_t *t8 = A.raw + row + seg_base;
+                        for (uint32_t k = (uint32_t)c; k < stage_len; k += kLanes)
+                            sym[k] = (seg_base + k < n) ? s_b2c[t8[k]] : (uint8_t)ecgb::kOtherClass;
+                    }
+                }
+#pragma unroll
+                for (int w = 0; w < kWordsPerChunk; ++w) my[w] = 0;
+            }
+            __syncthreads();
+            PROF_STAMP(0);
 
-        // Parse the chunk from `start`, merging into whatever chain the chunk already holds.
-        // Returns the position at which the chain leaves the chunk.
-        auto run = [&](uint32_t start, uint32_t old_exit) -> uint32_t {
-            if (start >= e_c) {   // chain jumps over this chunk
-                clear_bits(marks, s_c - seg_base, e_c - seg_base);
-                return start;
-            }
-            clear_bits(marks, s_c - seg_base, start - seg_base);
-            {   // already on the existing chain?
-                uint32_t r = start - seg_base;
-                if ((marks[r >> 5] >> (r & 31)) & 1u) return old_exit;
-            }
-            uint32_t p = start, j = start, node = 0, best_len = 0, best_tok = 0;
-            for (;;) {
-                const uint64_t rec = (node < n_lds) ? s_trie[node] : g_trie[node];
-                const uint32_t tok = (uint32_t)(rec >> 48);
-                if (j != p && tok != ecgb::kNoToken) { best_len = j - p; best_tok = tok; }
-                bool adv = false;
-                if (j < n) {
-                    const uint32_t s = cls[j];
-                    if (s < ecgb::kMaxClasses) {
-                        const uint32_t bm = (uint32_t)rec, bit = 1u << s;
-                        if (bm & bit) {
-                            node = ((uint32_t)(rec >> 32) & 0xFFFFu) + __popc(bm & (bit - 1u));
-                            ++j;
-                            adv = true;
+            // Parse the chunk from `start`, merging into whatever chain the chunk already holds.
+            // Returns the position at which the chain leaves the chunk.  FIRST = speculative pass
+            // over a zeroed bitmap (nothing to clear, nothing to merge into).  The bitmap word under
+            // the current token start is kept in a register (`wbits`) and written back when the
+            // chain moves to another word, so the per-token work is register-only.
+            auto run = [&](auto first_tag, uint32_t start, uint32_t old_exit) -> uint32_t {
+                constexpr bool FIRST = decltype(first_tag)::value;
+                const uint32_t rel_end = e_c - seg_base;
+                if constexpr (!FIRST) {
+                    if (start >= e_c) {   // chain jumps over this chunk
+#pragma unroll
+                        for (int w = 0; w < kWordsPerChunk; ++w) my[w] = 0;
+                        return start;
+                    }
+                    clear_bits(marks, s_c - seg_base, start - seg_base);
+                }
+                uint32_t r = start - seg_base;        // token start, segment-relative
+                uint32_t widx = r >> 5;
+                uint32_t wbits = FIRST ? 0u : marks[widx];
+                if constexpr (!FIRST) {   // already on the existing chain?
+                    if ((wbits >> (r & 31)) & 1u) return old_exit;
+                }
+                uint32_t j = r, node = 0, best_len = 0, best_tok = 0;
+                // ONE flat loop, one trie step OR one token emission per trip, every lane back in
+                // step at the bottom.  (Written with `continue`, LLVM splits the two back edges into
+                // nested loops and a wave then waits for its slowest lane on every TOKEN, ~10x the
+                // trips; the single latch with a convergent no-op keeps it flat.)
+                uint32_t result = 0;
+                bool done = false;
+                while (!done) {
+                    const uint32_t s = sym[j];
+                    uint64_t rec;
+                    if constexpr (ALL_LDS) rec = s_trie[node];
+                    else rec = (node < n_lds) ? s_trie[node] : g_trie[node];
+                    const uint32_t tok = (uint32_t)(rec >> 48);
+                    if (j != r && tok != ecgb::kNoToken) { best_len = j - r; best_tok = tok; }
+                    const uint32_t bm = (uint32_t)rec, bit = 1u << s;
+                    if (bm & bit) {
+                        node = ((uint32_t)(rec >> 32) & 0xFFFFu) + __popc(bm & (bit - 1u));
+                        ++j;
+                    } else {
+                        // emit the token [r, r + len); the cursor word is the one holding bit r
+                        const uint32_t len = best_len ? best_len : 1u;   // unmatched byte: lib.rs:186-189
+                        wbits |= 1u << (r & 31);
+                        if (len >= 2) ids_half[r >> 1] = (uint16_t)best_tok;
+                        if constexpr (!FIRST) {   // drop marks of the old chain inside (r, r + len)
+                            uint32_t lo = r + 1;
+                            const uint32_t hi = min(r + len, rel_end);
+                            while (lo < hi) {
+                                const uint32_t w = lo >> 5;
+                                if (w != widx) { marks[widx] = wbits; widx = w; wbits = marks[w]; }
+                                const uint32_t top = min(hi, (w + 1) << 5);
+                                uint32_t m = (top == ((w + 1) << 5)) ? 0xFFFFFFFFu : ((1u << (top & 31)) - 1u);
+                                m &= 0xFFFFFFFFu << (lo & 31);
+                                wbits &= ~m;
+                                lo = top;
+                            }
+                        }
+                        r += len; j = r; node = 0; best_len = 0;
+                        if (r >= rel_end) {
+                            marks[widx] = wbits;
+                            result = seg_base + r;
+                            done = true;
+                        } else {
+                            const uint32_t nw = r >> 5;
+                            if (nw != widx) { marks[widx] = wbits; widx = nw; wbits = FIRST ? 0u : marks[nw]; }
+                            if constexpr (!FIRST) {
+                                if ((wbits >> (r & 31)) & 1u) {   // re-synchronised with the old chain
+                                    marks[widx] = wbits;
+                                    result = old_exit;
+                                    done = true;
+                                }
+                            }
                         }
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
-                if (adv) continue;
-                // emit the token [p, p + len)
-                const uint32_t len = best_len ? best_len : 1u;   // unmatched byte: lib.rs:186-189
-                const uint32_t r = p - seg_base;
-                clear_bits(marks, r + 1, min(r + len, e_c - seg_base));
-                marks[r >> 5] |= 1u << (r & 31);
-                if (len >= 2) ids_half[p >> 1] = (uint16_t)best_tok;
-                p += len; j = p; node = 0; best_len = 0;
-                if (p >= e_c) return p;
-                const uint32_t r2 = p - seg_base;
-                if ((marks[r2 >> 5] >> (r2 & 31)) & 1u) return old_exit;   // re-synchronised
-            }
-        };
+                return result;
+            };
 
-        uint32_t entry = s_c;
-        uint32_t my_exit = s_c;
-        if (live) my_exit = run(s_c, s_c);
-        exits[c] = my_exit;
-        // stitch to a fixed point: entry(c) must equal exit(c-1), entry(0) = carry
-        for (;;) {
+            uint32_t entry = s_c;
+            uint32_t my_exit = s_c;
+            if (live && s_c < e_c) my_exit = run(std::true_type{}, s_c, s_c);
+            exits[c] = my_exit;
+            PROF_STAMP(1);
+            // stitch to a fixed point: entry(c) must equal exit(c-1), entry(0) = carry
+            for (;;) {
+                __syncthreads();
+                const uint32_t want = (c == 0) ? carry : exits[c - 1];
+                const int changed = live && (want != entry);
+                const int any = __syncthreads_or(changed);
+                if (!any) break;
+                PROF_COUNT(4, 1);
+                if (changed) {
+                    entry = want;
+                    my_exit = run(std::false_type{}, entry, my_exit);
+                    exits[c] = my_exit;
+                }
+            }
+            const uint32_t carry_out = exits[kLanes - 1];
+            PROF_STAMP(2);
+
+            // ---- emit: lane c owns the tokens that start in its chunk
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int w = 0; w < kWordsPerChunk; ++w) cnt += __popc(my[w]);
+            uint32_t incl = cnt;
+            const int lane = tid & 63, wv = c >> 6;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t t = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += t;
+            }
+            if (lane == 63) wsum[wv] = incl;
             __syncthreads();
-            const uint32_t want = (c == 0) ? carry : exits[c - 1];
-            const int changed = live && (want != entry);
-            const int any = __syncthreads_or(changed);
-            if (!any) break;
-            if (changed) {
-                entry = want;
-                my_exit = run(entry, my_exit);
-                exits[c] = my_exit;
-            }
-        }
-        const uint32_t carry_out = exits[kLanes - 1];
-
-        // emit: lane c owns the tokens that start in its chunk
-        uint32_t cnt = 0;
+            uint32_t base = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < kWordsPerChunk; ++w) cnt += __popc(my[w]);
-        uint32_t incl = cnt;
-        const int lane = tid & 63, wv = c >> 6;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) wsum[wv] = incl;
-        __syncthreads();
-        uint32_t base = 0, total = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { uint32_t t = wsum[k]; if (k < wv) base += t; total += t; }
-        uint32_t off = out_off + base + incl - cnt;
-        if (live) {
-            for (int w = 0; w < kWordsPerChunk; ++w) {
-                uint32_t bits = my[w];
-                while (bits) {
-                    const uint32_t t = __ffs(bits) - 1;
-                    bits &= bits - 1;
-                    const uint32_t r = (uint32_t)c * kChunk + w * 32 + t;   // segment-relative
-                    const uint32_t p = seg_base + r;
-                    bool single;
-                    if (p + 1 < seg_end) single = (marks[(r + 1) >> 5] >> ((r + 1) & 31)) & 1u;
-                    else single = (carry_out == p + 1);
-                    uint32_t id;
-                    if (single) {
-                        const uint32_t s = cls[p];
-                        id = (s < ecgb::kMaxClasses) ? (uint32_t)s_single[s] : (raw ? (uint32_t)raw[p] : 0u);
-                    } else {
-                        id = ids_half[p >> 1];
+            for (int k = 0; k < 4; ++k) { uint32_t t = wsum[k]; if (k < wv) base += t; total += t; }
+            uint32_t off = out_off + base + incl - cnt;
+            if (live) {
+                const uint32_t seg_len = seg_end - seg_base;
+                for (int w = 0; w < kWordsPerChunk; ++w) {
+                    uint32_t bits = my[w];
+                    while (bits) {
+                        const uint32_t t = __ffs(bits) - 1;
+                        bits &= bits - 1;
+                        const uint32_t r = (uint32_t)c * kChunk + w * 32 + t;   // segment-relative
+                        bool single;
+                        if (r + 1 < seg_len) single = (marks[(r + 1) >> 5] >> ((r + 1) & 31)) & 1u;
+                        else single = (carry_out == seg_base + r + 1);
+                        uint32_t id;
+                        if (single) {
+                            const uint32_t s = sym[r];
+                            if (INPUT == INPUT_BYTES && s == ecgb::kOtherClass) id = A.raw[row + seg_base + r];
+                            else id = s_single[s];
+                        } else {
+                            id = ids_half[r >> 1];
+                        }
+                        if (off < A.ids_stride) out[off] = id;
+                        ++off;
                     }
-                    if (off < A.ids_stride) out[off] = id;
-                    ++off;
                 }
             }
+            out_off += total;
+            carry = carry_out;
+            PROF_STAMP(3);
         }
-        out_off += total;
-        carry = carry_out;
-        __syncthreads();   // marks/exits are rewritten by the next segment
+        if (live && c == 0) A.counts[b] = out_off;
     }
-    if (live && c == 0) A.counts[b] = out_off;
 }
 
-size_t lds_bytes_for(int E, uint32_t n_lds_nodes)
+size_t lds_bytes_for(int E, uint32_t n_lds_nodes, uint32_t margin)
 {
-    return (size_t)n_lds_nodes * 8 + (size_t)E * (kMarkWords * 4 + kLanes * 4 + 16) + 64;
+    return (size_t)n_lds_nodes * 8 + 28 * 8 + (size_t)E * (kSeg + margin) +
+           (size_t)E * (kMarkWords * 4 + kLanes * 4 + 16) + 64 + 256;
 }
 
 int check_hip(hipError_t e, const char *what)
@@ -370,63 +493,96 @@ int check_hip(hipError_t e, const char *what)
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 
-int launch_encode(const ecgb_tokenizer *tok, const uint8_t *cls, const uint8_t *raw, size_t batch,
-                  size_t n, uint16_t *ids_half, size_t half_stride, uint32_t *ids_out,
-                  size_t ids_stride, uint32_t *counts, hipStream_t stream)
+struct Plan { int E; unsigned grid; uint32_t margin; uint32_t n_lds; size_t lds; };
+
+// Streams per workgroup: 2 (512 lanes) once that still gives every CU a workgroup, else 1 so
+// small batches spread over more CUs.  The grid is persistent: at most one workgroup per CU.
+Plan make_plan(const ecgb_tokenizer *tok, size_t batch)
 {
+    Plan p;
+    const size_t cus = tok->n_cus > 0 ? (size_t)tok->n_cus : 256;
+    p.E = (batch >= 2 * cus) ? 2 : 1;
+    const size_t units = (batch + p.E - 1) / p.E;
+    p.grid = (unsigned)std::max<size_t>(1, std::min(units, cus));
+    p.margin = (tok->max_depth + 1 + 15u) & ~15u;
+    const size_t lds_cap = 160 * 1024;
+    const size_t fixed = lds_bytes_for(p.E, 0, p.margin);
+    p.n_lds = (fixed >= lds_cap) ? 0u : (uint32_t)std::min<size_t>(tok->nodes.size(), (lds_cap - fixed) / 8);
+    p.lds = lds_bytes_for(p.E, p.n_lds, p.margin);
+    return p;
+}
+
+template <int INPUT>
+int launch_encode(const ecgb_tokenizer *tok, const double *signal, const uint8_t *raw, const QuantParams &qp,
+                  size_t batch, size_t n, uint16_t *ids_half, uint32_t *ids_out, size_t ids_stride,
+                  uint32_t *counts, hipStream_t stream)
+{
+    const Plan pl = make_plan(tok, batch);
+    if (pl.lds > 160 * 1024) {
+        ecgb::set_error("encode: trie depth needs more LDS margin than a CU has");
+        return ECGB_ERR_UNSUPPORTED;
+    }
     EncodeArgs A;
     A.trie = tok->nodes_dev;
     A.n_nodes = (uint32_t)tok->nodes.size();
+    A.n_lds_nodes = pl.n_lds;
     A.lut = tok->lut_dev;
-    A.cls = cls;
+    A.signal = signal;
     A.raw = raw;
+    A.qp = qp;
     A.ids_half = ids_half;
-    A.half_stride = half_stride;
     A.ids_out = ids_out;
     A.ids_stride = ids_stride;
     A.counts = counts;
     A.n = (uint32_t)n;
     A.batch = (uint32_t)batch;
-    // Streams per workgroup: 4 (1024 lanes, one workgroup per CU sharing one LDS trie) once
-    // the batch fills the chip that way, else 1 so small batches still spread over CUs.
-    const int E = (batch >= 1024) ? 4 : 1;
-    const size_t lds_cap = 160 * 1024;
-    const size_t fixed = lds_bytes_for(E, 0);
-    uint32_t n_lds = (uint32_t)std::min<size_t>(A.n_nodes, (lds_cap - fixed) / 8);
-    A.n_lds_nodes = n_lds;
-    const size_t lds = lds_bytes_for(E, n_lds);
-    const unsigned grid = (unsigned)((batch + E - 1) / E);
-    hipError_t e;
-    if (E == 4) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&encode_kernel<4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(encode_kernel<4>)");
-        hipLaunchKernelGGL(encode_kernel<4>, dim3(grid), dim3(kLanes * 4), lds, stream, A);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&encode_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(encode_kernel<1>)");
-        hipLaunchKernelGGL(encode_kernel<1>, dim3(grid), dim3(kLanes), lds, stream, A);
-    }
+    A.margin = pl.margin;
+#ifdef ECGB_PROFILE
+    A.prof = g_prof_dev;
+#endif
+    const bool all_lds = (pl.n_lds == A.n_nodes);
+    const bool vec = (INPUT == INPUT_F64) && (n % 2 == 0) && ((reinterpret_cast<uintptr_t>(signal) & 15u) == 0);
+    void (*kern)(EncodeArgs) = nullptr;
+#define ECGB_PICK(EE) \
+    (all_lds ? (vec ? encode_kernel<EE, INPUT, true, true> : encode_kernel<EE, INPUT, true, false>) \
+             : (vec ? encode_kernel<EE, INPUT, false, true> : encode_kernel<EE, INPUT, false, false>))
+    kern = (pl.E == 2) ? ECGB_PICK(2) : ECGB_PICK(1);
+#undef ECGB_PICK
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(encode_kernel)");
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(kLanes * pl.E), pl.lds, stream, A);
     return check_hip(hipGetLastError(), "encode_kernel launch");
 }
 
-unsigned stream_grid(size_t work_items)
+// grid for `rows` rows of `items` work items each: x covers a row (grid-stride), y the rows;
+// about 8 workgroups per CU in total so the memory system stays full.
+dim3 row_grid(size_t items, size_t rows)
 {
-    size_t blocks = (work_items + 255) / 256;
-    return (unsigned)std::max<size_t>(1, std::min<size_t>(blocks, 256 * 8));
+    const size_t per_row = std::max<size_t>(1, (items + 255) / 256);
+    const size_t gy = std::max<size_t>(1, std::min<size_t>(rows, 65535));
+    const size_t want = 256 * 8;
+    const size_t gx = std::max<size_t>(1, std::min<size_t>(per_row, (want + gy - 1) / gy));
+    return dim3((unsigned)gx, (unsigned)gy);
 }
 
-int launch_quantize(const double *x, size_t n, double p1, double p99, uint8_t *sym, double *clipped,
-                    hipStream_t stream)
+// Quantise `rows` rows of n samples; row r's symbols go to sym + r*sym_stride.
+int launch_quantize(const double *x, size_t n, size_t rows, size_t sym_stride, double p1, double p99,
+                    uint8_t *sym, double *clipped, hipStream_t stream)
 {
     QuantParams qp = make_quant_params(p1, p99);
-    const bool aligned = ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(sym) & 3u) == 0);
-    if (qp.use_thresholds && !clipped && aligned) {
-        hipLaunchKernelGGL(quantize_thr_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0, stream, x, n, qp, sym);
+    const bool vec = (n % 4 == 0) && (sym_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(sym) & 3u) == 0);
+    if (qp.use_thresholds && !clipped) {
+        if (vec)
+            hipLaunchKernelGGL(quantize_thr_kernel, row_grid(n / 4, rows), dim3(256), 0, stream, x, n, rows,
+                               sym_stride, qp, sym);
+        else
+            hipLaunchKernelGGL(quantize_thr_scalar_kernel, row_grid(n, rows), dim3(256), 0, stream, x, n, rows,
+                               sym_stride, qp, sym);
     } else {
-        hipLaunchKernelGGL(quantize_exact_kernel, dim3(stream_grid(n)), dim3(256), 0, stream, x, n, qp.a, qp.d,
-                           sym, clipped);
+        hipLaunchKernelGGL(quantize_exact_kernel, row_grid(n, rows), dim3(256), 0, stream, x, n, rows, sym_stride,
+                           qp.a, qp.d, sym, clipped);
     }
     return check_hip(hipGetLastError(), "quantize kernel launch");
 }
@@ -442,8 +598,8 @@ int check_common(const ecgb_tokenizer *tok, size_t batch, size_t n, const void *
         ecgb::set_error(std::string(who) + ": tokenizer handle has no device copy (no GPU at creation)");
         return ECGB_ERR_NODEVICE;
     }
-    if (n >= 0x7FFFFFFFull || batch >= 0x7FFFFFFFull) {
-        ecgb::set_error(std::string(who) + ": stream longer than 2^31-1 symbols or batch too large");
+    if (n >= 0x7FFF0000ull || batch >= 0x7FFFFFFFull) {
+        ecgb::set_error(std::string(who) + ": stream longer than 2^31 symbols or batch too large");
         return ECGB_ERR_UNSUPPORTED;
     }
     if (scratch_bytes < ecgb_encode_scratch_bytes(tok, batch, n)) {
@@ -455,15 +611,9 @@ int check_common(const ecgb_tokenizer *tok, size_t batch, size_t n, const void *
 
 }  // namespace
 
-extern "C" int ecgb_quantize_hip(const double *signal_dev, size_t n, double percentile_1,
-                                 double percentile_99, uint8_t *sym_dev, double *clipped_dev,
-                                 void *stream)
-{
-    if (n == 0) return ECGB_OK;
-    if (!signal_dev || !sym_dev) { ecgb::set_error("ecgb_quantize_hip: NULL argument"); return ECGB_ERR_INVALID; }
-    return launch_quantize(signal_dev, n, percentile_1, percentile_99, sym_dev, clipped_dev,
-                           (hipStream_t)stream);
-}
+#ifdef ECGB_PROFILE
+extern "C" void ecgb_debug_set_profile_buffer(unsigned long long *dev) { g_prof_dev = dev; }
+#endif
 
 extern "C" int ecgb_quantizer_thresholds(double percentile_1, double percentile_99, double *thr25)
 {
@@ -477,10 +627,29 @@ extern "C" int ecgb_quantizer_thresholds(double percentile_1, double percentile_
     return ECGB_OK;
 }
 
-extern "C" size_t ecgb_encode_scratch_bytes(const ecgb_tokenizer *, size_t batch, size_t n_per_stream)
+extern "C" int ecgb_quantize_hip(const double *signal_dev, size_t n, double percentile_1,
+                                 double percentile_99, uint8_t *sym_dev, double *clipped_dev,
+                                 void *stream)
 {
-    const size_t half_stride = (n_per_stream + 1) / 2;
-    return align_up(batch * n_per_stream) + align_up(batch * half_stride * 2) + kAlign;
+    if (n == 0) return ECGB_OK;
+    if (!signal_dev || !sym_dev) { ecgb::set_error("ecgb_quantize_hip: NULL argument"); return ECGB_ERR_INVALID; }
+    // one flat row; split long inputs into rows of 2^20 samples so the 2-D grid fills the chip
+    const size_t row = 1u << 20;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t full = n / row;
+    int rc = ECGB_OK;
+    if (full) rc = launch_quantize(signal_dev, row, full, row, percentile_1, percentile_99, sym_dev, clipped_dev, st);
+    if (rc == ECGB_OK && n % row)
+        rc = launch_quantize(signal_dev + full * row, n % row, 1, n % row, percentile_1, percentile_99,
+                             sym_dev + full * row, clipped_dev ? clipped_dev + full * row : nullptr, st);
+    return rc;
+}
+
+extern "C" size_t ecgb_encode_scratch_bytes(const ecgb_tokenizer *tok, size_t batch, size_t n_per_stream)
+{
+    // per resident workgroup: E half-resolution id arrays of one segment (reused, L2-resident)
+    const size_t cus = (tok && tok->n_cus > 0) ? (size_t)tok->n_cus : 256;
+    return align_up(cus * 2 * kHalfPerSlot * sizeof(uint16_t)) + kAlign;
 }
 
 extern "C" int ecgb_encode_hip(const ecgb_tokenizer *tok, const uint8_t *text_dev, size_t batch,
@@ -495,15 +664,11 @@ extern "C" int ecgb_encode_hip(const ecgb_tokenizer *tok, const uint8_t *text_de
     hipStream_t st = (hipStream_t)stream;
     if (n_per_stream == 0) return check_hip(hipMemsetAsync(counts_dev, 0, batch * 4, st), "hipMemsetAsync");
     if (!text_dev) { ecgb::set_error("ecgb_encode_hip: NULL text"); return ECGB_ERR_INVALID; }
-    uint8_t *cls = reinterpret_cast<uint8_t *>(align_up(reinterpret_cast<uintptr_t>(scratch_dev)));
-    uint16_t *half = reinterpret_cast<uint16_t *>(cls + align_up(batch * n_per_stream));
-    const size_t total = batch * n_per_stream;
-    hipLaunchKernelGGL(classify_kernel, dim3(stream_grid(total)), dim3(256), 0, st, text_dev, total,
-                       tok->lut_dev, cls);
-    rc = check_hip(hipGetLastError(), "classify_kernel launch");
-    if (rc) return rc;
-    return launch_encode(tok, cls, text_dev, batch, n_per_stream, half, (n_per_stream + 1) / 2, ids_dev,
-                         ids_stride, counts_dev, st);
+    uint16_t *half = reinterpret_cast<uint16_t *>(align_up(reinterpret_cast<uintptr_t>(scratch_dev)));
+    QuantParams qp;
+    std::memset(&qp, 0, sizeof(qp));
+    return launch_encode<INPUT_BYTES>(tok, nullptr, text_dev, qp, batch, n_per_stream, half, ids_dev, ids_stride,
+                                      counts_dev, st);
 }
 
 extern "C" int ecgb_quantize_encode_hip(const ecgb_tokenizer *tok, const double *signal_dev, size_t batch,
@@ -518,10 +683,13 @@ extern "C" int ecgb_quantize_encode_hip(const ecgb_tokenizer *tok, const double 
     hipStream_t st = (hipStream_t)stream;
     if (n_per_record == 0) return check_hip(hipMemsetAsync(counts_dev, 0, batch * 4, st), "hipMemsetAsync");
     if (!signal_dev) { ecgb::set_error("ecgb_quantize_encode_hip: NULL signal"); return ECGB_ERR_INVALID; }
-    uint8_t *cls = reinterpret_cast<uint8_t *>(align_up(reinterpret_cast<uintptr_t>(scratch_dev)));
-    uint16_t *half = reinterpret_cast<uint16_t *>(cls + align_up(batch * n_per_record));
-    rc = launch_quantize(signal_dev, batch * n_per_record, percentile_1, percentile_99, cls, nullptr, st);
-    if (rc) return rc;
-    return launch_encode(tok, cls, nullptr, batch, n_per_record, half, (n_per_record + 1) / 2, ids_dev,
-                         ids_stride, counts_dev, st);
+    const QuantParams qp = make_quant_params(percentile_1, percentile_99);
+    if (!qp.use_thresholds) {
+        ecgb::set_error("ecgb_quantize_encode_hip: degenerate percentiles (percentile_99 + 1 + 1e-6 <= percentile_1 "
+                        "or non-finite); quantise with ecgb_quantize_hip and encode with ecgb_encode_hip instead");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    uint16_t *half = reinterpret_cast<uint16_t *>(align_up(reinterpret_cast<uintptr_t>(scratch_dev)));
+    return launch_encode<INPUT_F64>(tok, signal_dev, nullptr, qp, batch, n_per_record, half, ids_dev, ids_stride,
+                                    counts_dev, st);
 }

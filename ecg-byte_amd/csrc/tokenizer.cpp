@@ -34,7 +34,7 @@ extern "C" uint32_t ecgb_version(void) { return (1u << 16) | 0u; }
 namespace {
 
 struct BuildNode {
-    std::array<int32_t, ecgb::kMaxClasses> child;
+    std::array<int32_t, 32> child;
     int64_t token = -1;
     BuildNode() { child.fill(-1); }
 };
@@ -73,7 +73,7 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
             if (!used[b] || tok->byte_to_class[b] != kOtherClass) continue;
             if (n_classes == kMaxClasses) {
                 delete tok;
-                set_error("ecgb_tokenizer_create: more than 32 distinct byte values (a..z plus 6) in the merges");
+                set_error("ecgb_tokenizer_create: more than 31 distinct byte values (a..z plus 5) in the merges");
                 return ECGB_ERR_UNSUPPORTED;
             }
             tok->byte_to_class[b] = (uint8_t)n_classes;
@@ -88,7 +88,7 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
         auto insert = [&](const uint32_t *seq, size_t len, uint32_t token_id) {
             int32_t node = 0;
             for (size_t k = 0; k < len; ++k) {
-                uint8_t cls = tok->byte_to_class[seq[k]];
+                const uint8_t cls = tok->byte_to_class[seq[k]];   // < kMaxClasses: every merge byte has a class
                 int32_t ch = bn[node].child[cls];
                 if (ch < 0) {
                     ch = (int32_t)bn.size();
@@ -144,7 +144,7 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
         }
         tok->max_depth = max_depth;
         // root children are nodes 1..n_classes in class order
-        for (uint32_t c = 0; c < kMaxClasses; ++c) tok->single_id[c] = 0;
+        for (uint32_t c = 0; c < 32; ++c) { tok->single_id[c] = 0; if (c >= n_classes) tok->class_to_byte[c] = 0; }
         for (uint32_t c = 0; c < n_classes; ++c) tok->single_id[c] = (uint16_t)(tok->nodes[1 + c] >> 48);
     } catch (const std::bad_alloc &) {
         delete tok;
@@ -162,6 +162,8 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
         return ECGB_OK;
     }
     tok->device = dev;
+    hipDeviceProp_t prop;
+    tok->n_cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     const size_t nbytes = tok->nodes.size() * sizeof(uint64_t);
     uint8_t lut[256 + 64 + 32];
     std::memcpy(lut, tok->byte_to_class, 256);

@@ -57,7 +57,7 @@ uint32_t ecgb_version(void);
  * (lib.rs:155-157) are implied.  Builds the trie on the host, lays it out for the device
  * (breadth-first, 8 bytes per node) and uploads it.  With no GPU present the handle is
  * host-only: introspection works, device entry points return ECGB_ERR_NODEVICE.
- * Limits of this build: at most 32 distinct byte values across all expansions plus
+ * Limits of this build: at most 31 distinct byte values across all expansions plus
  * 'a'..'z'; < 65535 trie nodes; token ids < 65535.  Violations -> ECGB_ERR_UNSUPPORTED. */
 int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t *offsets,
                           const uint32_t *ids, size_t n_merges, ecgb_tokenizer **out);

@@ -69,7 +69,7 @@ def _walk_packed(nodes, byte_to_class, text):
             if j < n:
                 cls = byte_to_class.get(text[j], 255)
                 bm = rec & 0xFFFFFFFF
-                if cls < 32 and (bm >> cls) & 1:
+                if cls < 31 and (bm >> cls) & 1:
                     node = ((rec >> 32) & 0xFFFF) + bin(bm & ((1 << cls) - 1)).count("1")
                     j += 1
                     continue
@@ -124,9 +124,9 @@ def test_packed_trie_fixture_tokenizer(lib):
 
 
 def test_tokenizer_limits_are_reported(lib):
-    many = [([i, i + 1], 256 + i) for i in range(0, 80, 2)]          # > 32 symbol classes
+    many = [([i, i + 1], 256 + i) for i in range(0, 80, 2)]          # > 31 symbol classes
     rc, h = _make_tok(lib, many)
-    assert rc == -3 and b"32 distinct" in lib.ecgb_last_error()
+    assert rc == -3 and b"31 distinct" in lib.ecgb_last_error()
     rc, h = _make_tok(lib, [([97, 98], 70000)])                        # token id does not fit
     assert rc == -3
     rc, h = _make_tok(lib, [([97, 300], 256)])                         # not a byte
