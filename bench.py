@@ -178,7 +178,7 @@ def main():
             "tokens_per_record": tokens_total / records_total,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "encode_kernel<2, INPUT_F64> (fused quantise+encode, one launch per step)",
+                         "kernel": "encode_wave_kernel<64, INPUT_F64> (fused quantise+encode, one launch per step)",
                          "kernel_ms": dev_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline:

@@ -67,6 +67,8 @@ def lib():
     L.ecgb_quantize_encode_hip.restype = C.c_int
     L.ecgb_quantizer_thresholds.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double)]
     L.ecgb_quantizer_thresholds.restype = C.c_int
+    L.ecgb_set_encode_plan.argtypes = [C.c_int]
+    L.ecgb_set_encode_plan.restype = C.c_int
     i32 = C.c_int32
     L.ecgb_assemble_hip.argtypes = [vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32,
                                     C.c_int, u32, vp, vp, vp, vp, vp, vp]

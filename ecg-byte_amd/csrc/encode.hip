@@ -45,13 +45,6 @@
 
 namespace {
 
-constexpr int kChunk = 128;                 // symbols per lane-chunk (multiple of 32)
-constexpr int kLanes = 256;                 // lanes (chunks) per stream per segment
-constexpr int kSeg = kChunk * kLanes;       // symbols per segment = 32768
-constexpr int kWordsPerChunk = kChunk / 32; // 4
-constexpr int kMarkWords = kSeg / 32;       // 1024 words = 4 KiB per stream in flight
-constexpr int kHalfPerSlot = kSeg / 2;      // u16 id slots per stream in flight (global scratch)
-
 // ------------------------------------------------------------------------------------------
 // Reference arithmetic of normalize_all, one operation per line (compiled with
 // -ffp-contract=off so nothing is fused).  Returns the alphabet index; NaN -> 0.
@@ -122,6 +115,22 @@ __device__ __forceinline__ uint32_t level_from_thresholds(double x, double a, do
     int b = (q >= 0.0) ? ((q < 26.0) ? (int)q : 25) : 0;  // NaN -> 0
     while (x < thr[b]) --b;                                // thr[0] = -inf stops it
     while (b < 25 && x >= thr[b + 1]) ++b;
+    return (uint32_t)b;
+}
+
+// Level of x without table lookups in the common case.  q = (x-a)*(26/d) differs from the value
+// the reference floors, fl(clip(fl(fl(x-a)/d))*26), by a few ulp (< 1e-13 absolute, both round
+// the same real number); so unless q lies within 1e-9 of one of the integers 1..25 the two
+// floors agree and clamp(floor(q), 0, 25) IS the reference level.  Only the (rare) ambiguous
+// inputs consult the exact staircase.  NaN -> 0, +-inf -> 25 / 0, as level_from_thresholds.
+__device__ __forceinline__ uint32_t level_fast(double x, double a, double scale, const double *thr)
+{
+    const double q = (x - a) * scale;
+    const double f = floor(q);
+    const double t = q - f;
+    int b = (q >= 0.0) ? ((q < 26.0) ? (int)f : 25) : 0;
+    const bool ambiguous = (t < 1e-9 || t > 1.0 - 1e-9) && (q > 0.5) && (q < 25.5);
+    if (ambiguous) b = (int)level_from_thresholds(x, a, scale, thr);
     return (uint32_t)b;
 }
 
@@ -196,7 +205,7 @@ struct EncodeArgs {
     const double *signal;     // batch x n float64 samples            (INPUT_F64)
     const uint8_t *raw;       // batch x n raw bytes                  (INPUT_BYTES)
     QuantParams qp;
-    uint16_t *ids_half;       // gridDim.x x E x kHalfPerSlot scratch (per workgroup, reused)
+    uint16_t *ids_half;       // per resident stream slot: half-resolution id array of one segment
     uint32_t *ids_out;        // batch x ids_stride
     size_t ids_stride;
     uint32_t *counts;         // batch
@@ -210,8 +219,8 @@ struct EncodeArgs {
 
 #ifdef ECGB_PROFILE
 unsigned long long *g_prof_dev = nullptr;
-#define PROF_STAMP(k) do { if (A.prof && threadIdx.x == 0) A.prof[blockIdx.x * 8 + (k)] += clock64() - t_prof; t_prof = clock64(); } while (0)
-#define PROF_COUNT(k, v) do { if (A.prof && threadIdx.x == 0) A.prof[blockIdx.x * 8 + (k)] += (v); } while (0)
+#define PROF_STAMP(k) do { if (A.prof && (threadIdx.x & 63) == 0) { atomicAdd(&A.prof[blockIdx.x * 8 + (k)], (unsigned long long)(clock64() - t_prof)); } t_prof = clock64(); } while (0)
+#define PROF_COUNT(k, v) do { if (A.prof && (threadIdx.x & 63) == 0) atomicAdd(&A.prof[blockIdx.x * 8 + (k)], (unsigned long long)(v)); } while (0)
 #else
 #define PROF_STAMP(k) do { } while (0)
 #define PROF_COUNT(k, v) do { } while (0)
@@ -232,255 +241,384 @@ __device__ __forceinline__ void clear_bits(uint32_t *marks, uint32_t lo, uint32_
     }
 }
 
-// Persistent kernel: E streams per workgroup at a time, kLanes lanes each.
-// ALL_LDS: the whole trie is staged in LDS.  VEC: n % 2 == 0 and 16-byte aligned rows, so
-// the float64 samples can be read two at a time.
-template <int E, int INPUT, bool ALL_LDS, bool VEC>
-__global__ __launch_bounds__(kLanes *E) void encode_kernel(EncodeArgs A)
+// LDS address of symbol position k.  Lanes own consecutive CHUNK-byte chunks, so lanes at equal
+// offsets would all read the same LDS bank (CHUNK = 64 or 128 bytes = 16 or 32 banks apart): a
+// 32-way conflict on every symbol read.  XOR-ing address bits [6:2] (the bank index) with the
+// low five bits of the chunk number spreads 32 consecutive chunks over the 32 banks.  Groups of
+// four positions stay contiguous and aligned; the map is a bijection on 2 * CHUNK-byte blocks.
+template <int CHUNK>
+__device__ __forceinline__ uint32_t swz(uint32_t k)
 {
+    return k ^ (((k / CHUNK) & 31u) << 2);
+}
+
+// ---- stage: positions [seg_base, seg_base + stage_len) of one stream -> symbol classes in LDS.
+// `lane`/`nlanes`: the cooperating lanes.  Positions >= n get the sentinel class (no trie node
+// has that child bit, so a walk can never pass the end of the stream).
+template <int CHUNK, int INPUT, bool VEC>
+__device__ __forceinline__ void stage_symbols(uint8_t *sym, uint32_t stage_len, uint32_t n_here,
+                                              const double *x, const uint8_t *t8, uint32_t lane,
+                                              uint32_t nlanes, double qa, double qscale,
+                                              const double *s_thr, const uint8_t *s_b2c)
+{
+    if (INPUT == INPUT_F64) {
+        // whole groups of 4 samples inside the record: vector path, 4 groups (8 x 16-byte loads)
+        // in flight per lane before the first use
+        const uint32_t vec_len = VEC ? (min(stage_len, n_here) & ~3u) : 0u;
+        const uint32_t step = nlanes * 4;
+        uint32_t k = lane * 4;
+        for (; k + 3 * step < vec_len; k += 4 * step) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[2 * u] = *reinterpret_cast<const double2 *>(x + k + u * step);
+                v[2 * u + 1] = *reinterpret_cast<const double2 *>(x + k + u * step + 2);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                uint32_t w = level_fast(v[2 * u].x, qa, qscale, s_thr);
+                w |= level_fast(v[2 * u].y, qa, qscale, s_thr) << 8;
+                w |= level_fast(v[2 * u + 1].x, qa, qscale, s_thr) << 16;
+                w |= level_fast(v[2 * u + 1].y, qa, qscale, s_thr) << 24;
+                *reinterpret_cast<uint32_t *>(sym + swz<CHUNK>(k + u * step)) = w;
+            }
+        }
+        for (; k < vec_len; k += step) {
+            const double2 v0 = *reinterpret_cast<const double2 *>(x + k);
+            const double2 v1 = *reinterpret_cast<const double2 *>(x + k + 2);
+            uint32_t w = level_fast(v0.x, qa, qscale, s_thr);
+            w |= level_fast(v0.y, qa, qscale, s_thr) << 8;
+            w |= level_fast(v1.x, qa, qscale, s_thr) << 16;
+            w |= level_fast(v1.y, qa, qscale, s_thr) << 24;
+            *reinterpret_cast<uint32_t *>(sym + swz<CHUNK>(k)) = w;
+        }
+        // the rest (record tail, odd/unaligned rows, sentinel padding) one sample at a time
+        for (uint32_t kk = vec_len + lane * 4; kk < stage_len; kk += step) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t lv = (kk + t < n_here) ? level_fast(x[kk + t], qa, qscale, s_thr)
+                                                      : ecgb::kOtherClass;
+                w |= lv << (8 * t);
+            }
+            *reinterpret_cast<uint32_t *>(sym + swz<CHUNK>(kk)) = w;
+        }
+    } else {
+        for (uint32_t k = lane; k < stage_len; k += nlanes)
+            sym[swz<CHUNK>(k)] = (k < n_here) ? s_b2c[t8[k]] : (uint8_t)ecgb::kOtherClass;
+    }
+}
+
+// ---- walk: parse one chunk [s_rel, e_rel) (segment-relative) from `start_rel`, merging into
+// whatever chain the chunk already holds.  Returns the segment-relative position at which the
+// chain leaves the chunk, or `old_exit` when it lands on a position the existing chain marked.
+// FIRST = speculative pass over a zeroed bitmap (nothing to clear, nothing to merge into).
+//
+// ONE flat loop, one trie step OR one token emission per trip, every lane back in step at the
+// bottom.  (Written with `continue`, LLVM splits the two back edges into nested loops and a wave
+// then waits for its slowest lane on every TOKEN, ~10x the trips; the single latch with a
+// convergent no-op keeps it flat.)  Marks are set and cleared with no-return LDS atomics: nothing
+// is on the dependent path but the two reads.
+template <int CHUNK, bool FIRST, bool ALL_LDS>
+__device__ __forceinline__ uint32_t walk_chunk(const uint8_t *sym, uint32_t *marks, uint16_t *ids_half,
+                                               const uint64_t *s_trie, const uint64_t *g_trie,
+                                               uint32_t n_lds, uint32_t s_rel, uint32_t e_rel,
+                                               uint32_t start_rel, uint32_t old_exit)
+{
+    if constexpr (!FIRST) {
+        if (start_rel >= e_rel) {   // chain jumps over this chunk
+            clear_bits(marks, s_rel, e_rel);
+            return start_rel;
+        }
+        clear_bits(marks, s_rel, start_rel);
+        if ((marks[start_rel >> 5] >> (start_rel & 31)) & 1u) return old_exit;   // already on the chain
+    }
+    uint32_t r = start_rel;        // token start
+    uint32_t j = r, node = 0, best_j = r, best_tok = 0;
+    uint32_t result = 0;
+    bool done = false;
+    while (!done) {
+        const uint32_t s = sym[swz<CHUNK>(j)];
+        uint64_t rec;
+        if constexpr (ALL_LDS) rec = s_trie[node];
+        else rec = (node < n_lds) ? s_trie[node] : g_trie[node];
+        const uint32_t bm = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
+        const uint32_t tok = hi >> 16;
+        if (tok != ecgb::kNoToken) { best_j = j; best_tok = tok; }   // the root carries none
+        const uint32_t bit = 1u << s;
+        if (bm & bit) {
+            node = (hi & 0xFFFFu) + __popc(bm & (bit - 1u));
+            ++j;
+        } else {
+            // emit the token [r, r + len)
+            const uint32_t len = max(best_j - r, 1u);   // unmatched byte: lib.rs:186-189
+            atomicOr(&marks[r >> 5], 1u << (r & 31));
+            if (len >= 2) ids_half[r >> 1] = (uint16_t)best_tok;
+            if constexpr (!FIRST) {   // drop marks of the old chain inside (r, r + len)
+                uint32_t lo = r + 1;
+                const uint32_t hi_pos = min(r + len, e_rel);
+                while (lo < hi_pos) {
+                    const uint32_t w = lo >> 5;
+                    const uint32_t top = min(hi_pos, (w + 1) << 5);
+                    uint32_t m = (top == ((w + 1) << 5)) ? 0xFFFFFFFFu : ((1u << (top & 31)) - 1u);
+                    m &= 0xFFFFFFFFu << (lo & 31);
+                    atomicAnd(&marks[w], ~m);
+                    lo = top;
+                }
+            }
+            r += len; j = r; node = 0; best_j = r;
+            if (r >= e_rel) {
+                result = r;
+                done = true;
+            } else if constexpr (!FIRST) {
+                if ((marks[r >> 5] >> (r & 31)) & 1u) {   // re-synchronised with the old chain
+                    result = old_exit;
+                    done = true;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return result;
+}
+
+// ---- emit helper: token ids of the marks in `bits` (word index `w_rel` of the segment).
+template <int CHUNK, int INPUT>
+__device__ __forceinline__ uint32_t emit_word(uint32_t bits, uint32_t w_rel, const uint32_t *marks,
+                                              const uint8_t *sym, const uint16_t *ids_half,
+                                              const uint16_t *s_single, const uint8_t *raw_seg,
+                                              uint32_t seg_len, uint32_t carry_out_rel, uint32_t *out,
+                                              uint32_t off, size_t ids_stride)
+{
+    while (bits) {
+        const uint32_t t = __ffs(bits) - 1;
+        bits &= bits - 1;
+        const uint32_t r = w_rel * 32 + t;
+        bool single;
+        if (r + 1 < seg_len) single = (marks[(r + 1) >> 5] >> ((r + 1) & 31)) & 1u;
+        else single = (carry_out_rel == r + 1);
+        uint32_t id;
+        if (single) {
+            const uint32_t s = sym[swz<CHUNK>(r)];
+            if (INPUT == INPUT_BYTES && s == ecgb::kOtherClass) id = raw_seg[r];
+            else id = s_single[s];
+        } else {
+            id = ids_half[r >> 1];
+        }
+        if (off < ids_stride) out[off] = id;
+        ++off;
+    }
+    return off;
+}
+
+// ==========================================================================================
+// Kernel 1 (large batches): ONE WAVE = ONE STREAM.  A workgroup is W independent waves that share
+// only the LDS trie; each wave takes streams b = wave_id, wave_id + total_waves, ... and walks
+// them in segments of 64 chunks, one lane per chunk.  All synchronisation is wave-local (shuffles,
+// ballots, program order of the wave's own LDS traffic): no workgroup barrier after start-up, so
+// the waves of a CU drift into different phases and the HBM-bound staging of some overlaps the
+// LDS-latency-bound parsing of others.
+template <int CHUNK, int INPUT, bool ALL_LDS, bool VEC>
+__global__ __launch_bounds__(1024) void encode_wave_kernel(EncodeArgs A)
+{
+    constexpr uint32_t SEG = 64 * CHUNK, WORDS = CHUNK / 32, MARKW = SEG / 32;
     extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t sym_cap = kSeg + A.margin;                 // bytes per stream slot, multiple of 16
+    const uint32_t n_waves = blockDim.x >> 6;
+    const uint32_t sym_cap = SEG + A.margin;                  // multiple of 16
     uint64_t *s_trie = reinterpret_cast<uint64_t *>(smem);
     double *s_thr = reinterpret_cast<double *>(s_trie + A.n_lds_nodes);        // 28
-    uint8_t *s_sym_all = reinterpret_cast<uint8_t *>(s_thr + 28);
-    uint32_t *s_marks_all = reinterpret_cast<uint32_t *>(s_sym_all + (size_t)E * sym_cap);
-    uint32_t *s_exit_all = s_marks_all + E * kMarkWords;
-    uint32_t *s_wsum_all = s_exit_all + E * kLanes;            // E x 4 wave totals
-    uint16_t *s_single = reinterpret_cast<uint16_t *>(s_wsum_all + E * 4);     // 32 entries
-    uint8_t *s_b2c = reinterpret_cast<uint8_t *>(s_single + 32);               // 256 (INPUT_BYTES)
+    uint16_t *s_single = reinterpret_cast<uint16_t *>(s_thr + 28);             // 32
+    uint8_t *s_b2c = reinterpret_cast<uint8_t *>(s_single + 32);               // 256
+    uint8_t *s_sym_all = s_b2c + 256;
+    uint32_t *s_marks_all = reinterpret_cast<uint32_t *>(s_sym_all + (size_t)n_waves * sym_cap);
 
-    const int tid = threadIdx.x;
-    const int g = tid / kLanes;          // stream slot inside the workgroup
-    const int c = tid % kLanes;          // chunk index inside the segment
-    for (uint32_t i = tid; i < A.n_lds_nodes; i += kLanes * E) s_trie[i] = A.trie[i];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, c = tid & 63;
+    for (uint32_t i = tid; i < A.n_lds_nodes; i += blockDim.x) s_trie[i] = A.trie[i];
     if (tid < 28) s_thr[tid] = A.qp.thr[tid];
     if (tid < 32) s_single[tid] = reinterpret_cast<const uint16_t *>(A.lut + 256)[tid];
-    if (INPUT == INPUT_BYTES && tid < 256) s_b2c[tid] = A.lut[tid];
+    if (tid < 256) s_b2c[tid] = A.lut[tid];
+    __syncthreads();   // the only workgroup barrier
 
-    uint8_t *sym = s_sym_all + (size_t)g * sym_cap;   // sym[k] = class of position seg_base + k
-    uint32_t *marks = s_marks_all + g * kMarkWords;   // bit k = a token starts at seg_base + k
-    uint32_t *exits = s_exit_all + g * kLanes;
-    uint32_t *wsum = s_wsum_all + g * 4;
-    uint32_t *my = marks + c * kWordsPerChunk;        // lane-owned words
-    uint16_t *ids_half = A.ids_half + ((size_t)blockIdx.x * E + g) * kHalfPerSlot;
+    uint8_t *sym = s_sym_all + (size_t)wave * sym_cap;
+    uint32_t *marks = s_marks_all + wave * MARKW;
+    uint32_t *my = marks + c * WORDS;
+    const uint32_t gw = blockIdx.x * n_waves + wave, total_waves = gridDim.x * n_waves;
+    uint16_t *ids_half = A.ids_half + (size_t)gw * (SEG / 2);
     const uint64_t *g_trie = A.trie;
-    const uint32_t n_lds = A.n_lds_nodes;
-    const uint32_t n = A.n;
+    const uint32_t n_lds = A.n_lds_nodes, n = A.n;
     const double qa = A.qp.a, qscale = A.qp.scale;
 #ifdef ECGB_PROFILE
     long long t_prof = clock64();
 #endif
 
-    const uint32_t units = (A.batch + E - 1) / E;
-    for (uint32_t unit = blockIdx.x; unit < units; unit += gridDim.x) {
-        const uint32_t b = unit * E + g;
-        const bool live = b < A.batch;
-        const size_t row = (size_t)(live ? b : 0) * n;
-        uint32_t *out = A.ids_out + (size_t)(live ? b : 0) * A.ids_stride;
-        uint32_t carry = 0;     // true chain position entering the segment
-        uint32_t out_off = 0;   // tokens emitted so far for this stream
-
-        for (uint32_t seg_base = 0; seg_base < n; seg_base += kSeg) {
-            const uint32_t seg_end = min(seg_base + (uint32_t)kSeg, n);
-            const uint32_t s_c = min(seg_base + (uint32_t)c * kChunk, seg_end);   // chunk [s_c, e_c)
-            const uint32_t e_c = min(s_c + (uint32_t)kChunk, seg_end);
-            __syncthreads();   // previous segment/unit fully emitted; (first time) trie + tables staged
-
-            // ---- stage: positions [seg_base, seg_base + stage_len) -> symbol classes in LDS;
-            // positions >= n get the sentinel class (no trie node has that child bit).
-            {
-                const uint32_t stage_len = min(sym_cap, (n - seg_base + 16u) & ~15u);   // >= 1 sentinel past n
-                if (live) {
-                    if (INPUT == INPUT_F64) {
-                        const double *x = A.signal + row + seg_base;
-                        for (uint32_t k = (uint32_t)c * 4; k < stage_len; k += kLanes * 4) {
-                            uint32_t w;
-                            if (VEC && seg_base + k + 4 <= n) {
-                                const double2 v0 = *reinterpret_cast<const double2 *>(x + k);
-                                const double2 v1 = *reinterpret_cast<const double2 *>(x + k + 2);
-                                w = level_from_thresholds(v0.x, qa, qscale, s_thr);
-                                w |= level_from_thresholds(v0.y, qa, qscale, s_thr) << 8;
-                                w |= level_from_thresholds(v1.x, qa, qscale, s_thr) << 16;
-                                w |= level_from_thresholds(v1.y, qa, qscale, s_thr) << 24;
-                            } else {
-                                w = 0;
+    for (uint32_t b = gw; b < A.batch; b += total_waves) {
+        const size_t row = (size_t)b * n;
+        uint32_t *out = A.ids_out + (size_t)b * A.ids_stride;
+        uint32_t carry = 0, out_off = 0;
+        for (uint32_t seg_base = 0; seg_base < n; seg_base += SEG) {
+            const uint32_t seg_len = min(SEG, n - seg_base);
+            const uint32_t s_rel = min(c * (uint32_t)CHUNK, seg_len), e_rel = min(s_rel + CHUNK, seg_len);
+            const uint32_t stage_len = min(sym_cap, (n - seg_base + 16u) & ~15u);   // >= 1 sentinel past n
+            stage_symbols<CHUNK, INPUT, VEC>(sym, stage_len, n - seg_base, A.signal + row + seg_base,
+                                      A.raw + row + seg_base, c, 64, qa, qscale, s_thr, s_b2c);
 #pragma unroll
-                                for (int t = 0; t < 4; ++t) {
-                                    const uint32_t pos = seg_base + k + t;
-                                    const uint32_t lv = (pos < n) ? level_from_thresholds(x[k + t], qa, qscale, s_thr)
-                                                                  : ecgb::kOtherClass;
-                                    w |= lv << (8 * t);
-                                }
-                            }
-                            *reinterpret_cast<uint32_t *>(sym + k) = w;
-                        }
-                    } else {
-                        const uint8_t *t8 = A.raw + row + seg_base;
-                        for (uint32_t k = (uint32_t)c; k < stage_len; k += kLanes)
-                            sym[k] = (seg_base + k < n) ? s_b2c[t8[k]] : (uint8_t)ecgb::kOtherClass;
-                    }
+            for (uint32_t w = 0; w < WORDS; ++w) my[w] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            PROF_STAMP(0);
+
+            uint32_t entry = s_rel, my_exit = s_rel;
+            if (s_rel < e_rel)
+                my_exit = walk_chunk<CHUNK, true, ALL_LDS>(sym, marks, ids_half, s_trie, g_trie, n_lds, s_rel, e_rel, s_rel, s_rel);
+            PROF_STAMP(1);
+            // stitch to a fixed point: entry(c) must equal exit(c-1), entry(0) = carry
+            const uint32_t carry_rel = carry - seg_base;
+            for (;;) {
+                const uint32_t prev = __shfl_up(my_exit, 1, 64);
+                const uint32_t want = (c == 0) ? carry_rel : prev;
+                const bool changed = (want != entry);
+                if (!__any(changed)) break;
+                PROF_COUNT(4, 1);
+                if (changed) {
+                    entry = want;
+                    my_exit = walk_chunk<CHUNK, false, ALL_LDS>(sym, marks, ids_half, s_trie, g_trie, n_lds, s_rel, e_rel,
+                                                                entry, my_exit);
                 }
-#pragma unroll
-                for (int w = 0; w < kWordsPerChunk; ++w) my[w] = 0;
+                __builtin_amdgcn_wave_barrier();
             }
+            const uint32_t carry_out_rel = __shfl(my_exit, 63, 64);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            PROF_STAMP(2);
+
+            // emit: lane c owns the tokens that start in its chunk
+            uint32_t cnt = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < WORDS; ++w) cnt += __popc(my[w]);
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d, 64);
+                if (c >= (uint32_t)d) incl += t;
+            }
+            const uint32_t total = __shfl(incl, 63, 64);
+            uint32_t off = out_off + incl - cnt;
+            for (uint32_t w = 0; w < WORDS; ++w)
+                off = emit_word<CHUNK, INPUT>(my[w], c * WORDS + w, marks, sym, ids_half, s_single,
+                                       A.raw + row + seg_base, seg_len, carry_out_rel, out, off, A.ids_stride);
+            out_off += total;
+            carry = seg_base + carry_out_rel;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            PROF_STAMP(3);
+        }
+        if (c == 0) A.counts[b] = out_off;
+    }
+}
+
+// ==========================================================================================
+// Kernel 2 (small batches): ONE WORKGROUP OF 256 LANES = ONE STREAM, segments of 256 chunks of
+// 128 symbols, so a single record still spreads over 4 waves and few records over many CUs.
+// Same stage / walk / stitch / emit, with workgroup barriers between the phases.
+constexpr int kChunk = 128;                 // symbols per lane-chunk (multiple of 32)
+constexpr int kLanes = 256;                 // lanes (chunks) per stream per segment
+constexpr int kSeg = kChunk * kLanes;       // symbols per segment = 32768
+constexpr int kWordsPerChunk = kChunk / 32; // 4
+constexpr int kMarkWords = kSeg / 32;       // 1024 words = 4 KiB
+constexpr int kHalfPerSlot = kSeg / 2;      // u16 id slots per resident stream (global scratch)
+
+template <int INPUT, bool ALL_LDS, bool VEC>
+__global__ __launch_bounds__(kLanes) void encode_wg_kernel(EncodeArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t sym_cap = kSeg + A.margin;
+    uint64_t *s_trie = reinterpret_cast<uint64_t *>(smem);
+    double *s_thr = reinterpret_cast<double *>(s_trie + A.n_lds_nodes);        // 28
+    uint16_t *s_single = reinterpret_cast<uint16_t *>(s_thr + 28);             // 32
+    uint8_t *s_b2c = reinterpret_cast<uint8_t *>(s_single + 32);               // 256
+    uint8_t *sym = s_b2c + 256;
+    uint32_t *marks = reinterpret_cast<uint32_t *>(sym + sym_cap);
+    uint32_t *exits = marks + kMarkWords;
+    uint32_t *wsum = exits + kLanes;                                           // 4 wave totals
+
+    const uint32_t c = threadIdx.x;
+    for (uint32_t i = c; i < A.n_lds_nodes; i += kLanes) s_trie[i] = A.trie[i];
+    if (c < 28) s_thr[c] = A.qp.thr[c];
+    if (c < 32) s_single[c] = reinterpret_cast<const uint16_t *>(A.lut + 256)[c];
+    s_b2c[c] = A.lut[c];
+
+    uint32_t *my = marks + c * kWordsPerChunk;
+    uint16_t *ids_half = A.ids_half + (size_t)blockIdx.x * kHalfPerSlot;
+    const uint64_t *g_trie = A.trie;
+    const uint32_t n_lds = A.n_lds_nodes, n = A.n;
+    const double qa = A.qp.a, qscale = A.qp.scale;
+#ifdef ECGB_PROFILE
+    long long t_prof = clock64();
+#endif
+
+    for (uint32_t b = blockIdx.x; b < A.batch; b += gridDim.x) {
+        const size_t row = (size_t)b * n;
+        uint32_t *out = A.ids_out + (size_t)b * A.ids_stride;
+        uint32_t carry = 0, out_off = 0;
+        for (uint32_t seg_base = 0; seg_base < n; seg_base += kSeg) {
+            const uint32_t seg_len = min((uint32_t)kSeg, n - seg_base);
+            const uint32_t s_rel = min(c * (uint32_t)kChunk, seg_len), e_rel = min(s_rel + kChunk, seg_len);
+            __syncthreads();   // previous segment fully emitted; (first time) trie + tables staged
+            const uint32_t stage_len = min(sym_cap, (n - seg_base + 16u) & ~15u);
+            stage_symbols<kChunk, INPUT, VEC>(sym, stage_len, n - seg_base, A.signal + row + seg_base,
+                                      A.raw + row + seg_base, c, kLanes, qa, qscale, s_thr, s_b2c);
+#pragma unroll
+            for (int w = 0; w < kWordsPerChunk; ++w) my[w] = 0;
             __syncthreads();
             PROF_STAMP(0);
 
-            // Parse the chunk from `start`, merging into whatever chain the chunk already holds.
-            // Returns the position at which the chain leaves the chunk.  FIRST = speculative pass
-            // over a zeroed bitmap (nothing to clear, nothing to merge into).  The bitmap word under
-            // the current token start is kept in a register (`wbits`) and written back when the
-            // chain moves to another word, so the per-token work is register-only.
-            auto run = [&](auto first_tag, uint32_t start, uint32_t old_exit) -> uint32_t {
-                constexpr bool FIRST = decltype(first_tag)::value;
-                const uint32_t rel_end = e_c - seg_base;
-                if constexpr (!FIRST) {
-                    if (start >= e_c) {   // chain jumps over this chunk
-#pragma unroll
-                        for (int w = 0; w < kWordsPerChunk; ++w) my[w] = 0;
-                        return start;
-                    }
-                    clear_bits(marks, s_c - seg_base, start - seg_base);
-                }
-                uint32_t r = start - seg_base;        // token start, segment-relative
-                uint32_t widx = r >> 5;
-                uint32_t wbits = FIRST ? 0u : marks[widx];
-                if constexpr (!FIRST) {   // already on the existing chain?
-                    if ((wbits >> (r & 31)) & 1u) return old_exit;
-                }
-                uint32_t j = r, node = 0, best_len = 0, best_tok = 0;
-                // ONE flat loop, one trie step OR one token emission per trip, every lane back in
-                // step at the bottom.  (Written with `continue`, LLVM splits the two back edges into
-                // nested loops and a wave then waits for its slowest lane on every TOKEN, ~10x the
-                // trips; the single latch with a convergent no-op keeps it flat.)
-                uint32_t result = 0;
-                bool done = false;
-                while (!done) {
-                    const uint32_t s = sym[j];
-                    uint64_t rec;
-                    if constexpr (ALL_LDS) rec = s_trie[node];
-                    else rec = (node < n_lds) ? s_trie[node] : g_trie[node];
-                    const uint32_t tok = (uint32_t)(rec >> 48);
-                    if (j != r && tok != ecgb::kNoToken) { best_len = j - r; best_tok = tok; }
-                    const uint32_t bm = (uint32_t)rec, bit = 1u << s;
-                    if (bm & bit) {
-                        node = ((uint32_t)(rec >> 32) & 0xFFFFu) + __popc(bm & (bit - 1u));
-                        ++j;
-                    } else {
-                        // emit the token [r, r + len); the cursor word is the one holding bit r
-                        const uint32_t len = best_len ? best_len : 1u;   // unmatched byte: lib.rs:186-189
-                        wbits |= 1u << (r & 31);
-                        if (len >= 2) ids_half[r >> 1] = (uint16_t)best_tok;
-                        if constexpr (!FIRST) {   // drop marks of the old chain inside (r, r + len)
-                            uint32_t lo = r + 1;
-                            const uint32_t hi = min(r + len, rel_end);
-                            while (lo < hi) {
-                                const uint32_t w = lo >> 5;
-                                if (w != widx) { marks[widx] = wbits; widx = w; wbits = marks[w]; }
-                                const uint32_t top = min(hi, (w + 1) << 5);
-                                uint32_t m = (top == ((w + 1) << 5)) ? 0xFFFFFFFFu : ((1u << (top & 31)) - 1u);
-                                m &= 0xFFFFFFFFu << (lo & 31);
-                                wbits &= ~m;
-                                lo = top;
-                            }
-                        }
-                        r += len; j = r; node = 0; best_len = 0;
-                        if (r >= rel_end) {
-                            marks[widx] = wbits;
-                            result = seg_base + r;
-                            done = true;
-                        } else {
-                            const uint32_t nw = r >> 5;
-                            if (nw != widx) { marks[widx] = wbits; widx = nw; wbits = FIRST ? 0u : marks[nw]; }
-                            if constexpr (!FIRST) {
-                                if ((wbits >> (r & 31)) & 1u) {   // re-synchronised with the old chain
-                                    marks[widx] = wbits;
-                                    result = old_exit;
-                                    done = true;
-                                }
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                return result;
-            };
-
-            uint32_t entry = s_c;
-            uint32_t my_exit = s_c;
-            if (live && s_c < e_c) my_exit = run(std::true_type{}, s_c, s_c);
+            uint32_t entry = s_rel, my_exit = s_rel;
+            if (s_rel < e_rel)
+                my_exit = walk_chunk<kChunk, true, ALL_LDS>(sym, marks, ids_half, s_trie, g_trie, n_lds, s_rel, e_rel, s_rel, s_rel);
             exits[c] = my_exit;
             PROF_STAMP(1);
-            // stitch to a fixed point: entry(c) must equal exit(c-1), entry(0) = carry
+            const uint32_t carry_rel = carry - seg_base;
             for (;;) {
                 __syncthreads();
-                const uint32_t want = (c == 0) ? carry : exits[c - 1];
-                const int changed = live && (want != entry);
+                const uint32_t want = (c == 0) ? carry_rel : exits[c - 1];
+                const int changed = (want != entry);
                 const int any = __syncthreads_or(changed);
                 if (!any) break;
                 PROF_COUNT(4, 1);
                 if (changed) {
                     entry = want;
-                    my_exit = run(std::false_type{}, entry, my_exit);
+                    my_exit = walk_chunk<kChunk, false, ALL_LDS>(sym, marks, ids_half, s_trie, g_trie, n_lds, s_rel, e_rel,
+                                                                 entry, my_exit);
                     exits[c] = my_exit;
                 }
             }
-            const uint32_t carry_out = exits[kLanes - 1];
+            const uint32_t carry_out_rel = exits[kLanes - 1];
             PROF_STAMP(2);
 
-            // ---- emit: lane c owns the tokens that start in its chunk
             uint32_t cnt = 0;
 #pragma unroll
             for (int w = 0; w < kWordsPerChunk; ++w) cnt += __popc(my[w]);
             uint32_t incl = cnt;
-            const int lane = tid & 63, wv = c >> 6;
+            const uint32_t lane = c & 63, wv = c >> 6;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
-                uint32_t t = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += t;
+                const uint32_t t = __shfl_up(incl, d, 64);
+                if (lane >= (uint32_t)d) incl += t;
             }
             if (lane == 63) wsum[wv] = incl;
             __syncthreads();
             uint32_t base = 0, total = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { uint32_t t = wsum[k]; if (k < wv) base += t; total += t; }
+            for (uint32_t k = 0; k < 4; ++k) { const uint32_t t = wsum[k]; if (k < wv) base += t; total += t; }
             uint32_t off = out_off + base + incl - cnt;
-            if (live) {
-                const uint32_t seg_len = seg_end - seg_base;
-                for (int w = 0; w < kWordsPerChunk; ++w) {
-                    uint32_t bits = my[w];
-                    while (bits) {
-                        const uint32_t t = __ffs(bits) - 1;
-                        bits &= bits - 1;
-                        const uint32_t r = (uint32_t)c * kChunk + w * 32 + t;   // segment-relative
-                        bool single;
-                        if (r + 1 < seg_len) single = (marks[(r + 1) >> 5] >> ((r + 1) & 31)) & 1u;
-                        else single = (carry_out == seg_base + r + 1);
-                        uint32_t id;
-                        if (single) {
-                            const uint32_t s = sym[r];
-                            if (INPUT == INPUT_BYTES && s == ecgb::kOtherClass) id = A.raw[row + seg_base + r];
-                            else id = s_single[s];
-                        } else {
-                            id = ids_half[r >> 1];
-                        }
-                        if (off < A.ids_stride) out[off] = id;
-                        ++off;
-                    }
-                }
-            }
+            for (int w = 0; w < kWordsPerChunk; ++w)
+                off = emit_word<kChunk, INPUT>(my[w], c * kWordsPerChunk + w, marks, sym, ids_half, s_single,
+                                       A.raw + row + seg_base, seg_len, carry_out_rel, out, off, A.ids_stride);
             out_off += total;
-            carry = carry_out;
+            carry = seg_base + carry_out_rel;
             PROF_STAMP(3);
         }
-        if (live && c == 0) A.counts[b] = out_off;
+        if (c == 0) A.counts[b] = out_off;
     }
-}
-
-size_t lds_bytes_for(int E, uint32_t n_lds_nodes, uint32_t margin)
-{
-    return (size_t)n_lds_nodes * 8 + 28 * 8 + (size_t)E * (kSeg + margin) +
-           (size_t)E * (kMarkWords * 4 + kLanes * 4 + 16) + 64 + 256;
 }
 
 int check_hip(hipError_t e, const char *what)
@@ -492,23 +630,58 @@ int check_hip(hipError_t e, const char *what)
 
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+constexpr size_t kLdsCap = 160 * 1024;
+constexpr size_t kLdsTables = 28 * 8 + 64 + 256;
+constexpr int kWaveChunk = 64;               // chunk of the wave-per-stream kernel
+constexpr size_t kWaveSeg = 64 * kWaveChunk; // 4096 symbols per wave segment
+static_assert(kWaveSeg == 4096, "wave segment");
+constexpr size_t kMaxWaves = 16;
+constexpr int kWaveChunkBig = 128;           // experimental variant (plan mode 3): 8192-symbol segments
 
-struct Plan { int E; unsigned grid; uint32_t margin; uint32_t n_lds; size_t lds; };
+int g_plan_mode = 0;   // 0 auto, 1 workgroup-per-stream, 2 wave-per-stream (tests / tuning)
 
-// Streams per workgroup: 2 (512 lanes) once that still gives every CU a workgroup, else 1 so
-// small batches spread over more CUs.  The grid is persistent: at most one workgroup per CU.
+struct Plan {
+    int wave_chunk;    // chunk size of the wave kernel
+    bool wave;         // wave-per-stream kernel
+    unsigned grid, block;
+    uint32_t margin, n_lds;
+    size_t lds;
+};
+
+// Large batches: wave-per-stream, as many waves per CU as LDS allows (trie first, then
+// 4.8 KiB per wave), one persistent workgroup per CU.  Small batches: workgroup-per-stream so
+// that few records still spread over many lanes and CUs.
 Plan make_plan(const ecgb_tokenizer *tok, size_t batch)
 {
     Plan p;
     const size_t cus = tok->n_cus > 0 ? (size_t)tok->n_cus : 256;
-    p.E = (batch >= 2 * cus) ? 2 : 1;
-    const size_t units = (batch + p.E - 1) / p.E;
-    p.grid = (unsigned)std::max<size_t>(1, std::min(units, cus));
-    p.margin = (tok->max_depth + 1 + 15u) & ~15u;
-    const size_t lds_cap = 160 * 1024;
-    const size_t fixed = lds_bytes_for(p.E, 0, p.margin);
-    p.n_lds = (fixed >= lds_cap) ? 0u : (uint32_t)std::min<size_t>(tok->nodes.size(), (lds_cap - fixed) / 8);
-    p.lds = lds_bytes_for(p.E, p.n_lds, p.margin);
+    p.margin = (tok->max_depth + 1 + 255u) & ~255u;   // keeps the symbol buffer a whole number of swizzle blocks
+    const size_t n_nodes = tok->nodes.size();
+    p.wave = (g_plan_mode >= 2) || (g_plan_mode == 0 && batch >= 2 * cus);
+    p.wave_chunk = (g_plan_mode == 3) ? kWaveChunkBig : kWaveChunk;
+    if (p.wave) {
+        const size_t seg = 64 * (size_t)p.wave_chunk;
+        const size_t per_wave = seg + p.margin + seg / 8;
+        size_t waves = (g_plan_mode == 3) ? 8 : kMaxWaves;
+        const size_t trie_bytes = n_nodes * 8;
+        if (kLdsTables + trie_bytes + waves * per_wave > kLdsCap) {
+            // shrink to 8 waves before giving up LDS residency of the trie
+            const size_t fit = (kLdsCap > kLdsTables + trie_bytes) ? (kLdsCap - kLdsTables - trie_bytes) / per_wave : 0;
+            waves = std::max<size_t>(std::min<size_t>(8, waves), std::min<size_t>(waves, fit));
+        }
+        const size_t left = (kLdsCap > kLdsTables + waves * per_wave) ? kLdsCap - kLdsTables - waves * per_wave : 0;
+        p.n_lds = (uint32_t)std::min<size_t>(n_nodes, left / 8);
+        p.block = (unsigned)(waves * 64);
+        const size_t wgs = (batch + waves - 1) / waves;
+        p.grid = (unsigned)std::max<size_t>(1, std::min(wgs, cus));
+        p.lds = kLdsTables + (size_t)p.n_lds * 8 + waves * per_wave;
+    } else {
+        const size_t fixed = kLdsTables + kSeg + p.margin + kMarkWords * 4 + kLanes * 4 + 16;
+        p.n_lds = (fixed >= kLdsCap) ? 0u : (uint32_t)std::min<size_t>(n_nodes, (kLdsCap - fixed) / 8);
+        p.block = kLanes;
+        p.grid = (unsigned)std::max<size_t>(1, std::min(batch, 2 * cus));
+        p.lds = fixed + (size_t)p.n_lds * 8;
+    }
     return p;
 }
 
@@ -518,7 +691,7 @@ int launch_encode(const ecgb_tokenizer *tok, const double *signal, const uint8_t
                   uint32_t *counts, hipStream_t stream)
 {
     const Plan pl = make_plan(tok, batch);
-    if (pl.lds > 160 * 1024) {
+    if (pl.lds > kLdsCap) {
         ecgb::set_error("encode: trie depth needs more LDS margin than a CU has");
         return ECGB_ERR_UNSUPPORTED;
     }
@@ -543,16 +716,20 @@ int launch_encode(const ecgb_tokenizer *tok, const double *signal, const uint8_t
     const bool all_lds = (pl.n_lds == A.n_nodes);
     const bool vec = (INPUT == INPUT_F64) && (n % 2 == 0) && ((reinterpret_cast<uintptr_t>(signal) & 15u) == 0);
     void (*kern)(EncodeArgs) = nullptr;
-#define ECGB_PICK(EE) \
-    (all_lds ? (vec ? encode_kernel<EE, INPUT, true, true> : encode_kernel<EE, INPUT, true, false>) \
-             : (vec ? encode_kernel<EE, INPUT, false, true> : encode_kernel<EE, INPUT, false, false>))
-    kern = (pl.E == 2) ? ECGB_PICK(2) : ECGB_PICK(1);
-#undef ECGB_PICK
+    if (pl.wave && pl.wave_chunk == kWaveChunkBig)
+        kern = all_lds ? (vec ? encode_wave_kernel<kWaveChunkBig, INPUT, true, true> : encode_wave_kernel<kWaveChunkBig, INPUT, true, false>)
+                       : (vec ? encode_wave_kernel<kWaveChunkBig, INPUT, false, true> : encode_wave_kernel<kWaveChunkBig, INPUT, false, false>);
+    else if (pl.wave)
+        kern = all_lds ? (vec ? encode_wave_kernel<kWaveChunk, INPUT, true, true> : encode_wave_kernel<kWaveChunk, INPUT, true, false>)
+                       : (vec ? encode_wave_kernel<kWaveChunk, INPUT, false, true> : encode_wave_kernel<kWaveChunk, INPUT, false, false>);
+    else
+        kern = all_lds ? (vec ? encode_wg_kernel<INPUT, true, true> : encode_wg_kernel<INPUT, true, false>)
+                       : (vec ? encode_wg_kernel<INPUT, false, true> : encode_wg_kernel<INPUT, false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-    if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(encode_kernel)");
-    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(kLanes * pl.E), pl.lds, stream, A);
-    return check_hip(hipGetLastError(), "encode_kernel launch");
+    if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(encode kernel)");
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(pl.block), pl.lds, stream, A);
+    return check_hip(hipGetLastError(), "encode kernel launch");
 }
 
 // grid for `rows` rows of `items` work items each: x covers a row (grid-stride), y the rows;
@@ -615,6 +792,13 @@ int check_common(const ecgb_tokenizer *tok, size_t batch, size_t n, const void *
 extern "C" void ecgb_debug_set_profile_buffer(unsigned long long *dev) { g_prof_dev = dev; }
 #endif
 
+extern "C" int ecgb_set_encode_plan(int mode)
+{
+    if (mode < 0 || mode > 3) { ecgb::set_error("ecgb_set_encode_plan: mode must be 0..3"); return ECGB_ERR_INVALID; }
+    g_plan_mode = mode;
+    return ECGB_OK;
+}
+
 extern "C" int ecgb_quantizer_thresholds(double percentile_1, double percentile_99, double *thr25)
 {
     if (!thr25) { ecgb::set_error("ecgb_quantizer_thresholds: NULL argument"); return ECGB_ERR_INVALID; }
@@ -647,9 +831,11 @@ extern "C" int ecgb_quantize_hip(const double *signal_dev, size_t n, double perc
 
 extern "C" size_t ecgb_encode_scratch_bytes(const ecgb_tokenizer *tok, size_t batch, size_t n_per_stream)
 {
-    // per resident workgroup: E half-resolution id arrays of one segment (reused, L2-resident)
+    // one half-resolution id array of one segment per resident stream slot (reused, L2-resident):
+    // wave kernel: CUs x 16 waves x 2048 entries; workgroup kernel: 2 x CUs x 16384 entries
     const size_t cus = (tok && tok->n_cus > 0) ? (size_t)tok->n_cus : 256;
-    return align_up(cus * 2 * kHalfPerSlot * sizeof(uint16_t)) + kAlign;
+    const size_t a = cus * kMaxWaves * (64 * (size_t)kWaveChunkBig / 2), b = 2 * cus * (size_t)kHalfPerSlot;
+    return align_up(std::max(a, b) * sizeof(uint16_t)) + kAlign;
 }
 
 extern "C" int ecgb_encode_hip(const ecgb_tokenizer *tok, const uint8_t *text_dev, size_t batch,

@@ -36,6 +36,11 @@ def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def set_encode_plan(mode: int) -> None:
+    """0 = automatic, 1 = workgroup-per-stream kernel, 2 = wave-per-stream kernel (tests/tuning)."""
+    _lib.check(_lib.lib().ecgb_set_encode_plan(int(mode)))
+
+
 class HipTokenizer:
     """Immutable device tokenizer built from the reference's `merges` list."""
 

@@ -101,6 +101,13 @@ int ecgb_encode_hip(const ecgb_tokenizer *tok, const uint8_t *text_dev, size_t b
                     uint32_t *counts_dev, void *scratch_dev, size_t scratch_bytes,
                     void *stream);
 
+/* Which of the two encode kernels a call uses: 0 = automatic (wave-per-stream for batches of at
+ * least 2 x CUs, workgroup-per-stream below), 1 = always workgroup-per-stream, 2 = always
+ * wave-per-stream, 3 = wave-per-stream with 128-symbol chunks (tuning experiment).  All produce
+ * identical output; the switch exists for tests and tuning.
+ * Process-wide, not thread-safe against concurrent encode calls. */
+int ecgb_set_encode_plan(int mode);
+
 /* Fused front end: quantise `batch` records of n_per_record float64 samples (a (12,L) record
  * is read in C order = lead-major, data_loader.py:75) and encode each record's symbol
  * stream.  Same output convention as ecgb_encode_hip. */

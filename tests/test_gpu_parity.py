@@ -24,6 +24,15 @@ def dev():
     return torch.device("cuda", 0)
 
 
+@pytest.fixture(params=[0, 1, 2], ids=["plan-auto", "plan-workgroup", "plan-wave"])
+def plan(request, dev):
+    """Runs a test under each encode kernel: automatic choice, workgroup-per-stream, wave-per-stream."""
+    from ecg_byte_amd.tokenizer import set_encode_plan
+    set_encode_plan(request.param)
+    yield request.param
+    set_encode_plan(0)
+
+
 def _encode_bytes(tk, texts, **kw):
     """texts: list of equal-length bytes -> list of np.uint32 arrays."""
     n = len(texts[0])
@@ -69,7 +78,7 @@ def test_quantiser_edges_nan_unaligned_tail(dev):
 
 
 # ---- encoder: known-answer vectors through the drop-in module ---------------------------------
-def test_rust_bpe_encode_text_known_answers(dev):
+def test_rust_bpe_encode_text_known_answers(dev, plan):
     from ecg_byte_amd import rust_bpe
     assert rust_bpe.encode_text("abc", [([98, 99], 256), ([97, 98], 257)]) == [257, 99]
     m = [([97, 97], 256)]
@@ -89,7 +98,7 @@ def test_rust_bpe_encode_text_known_answers(dev):
 # ---- encoder vs oracle on seeded inputs -------------------------------------------------------
 @pytest.mark.parametrize("tag,L", [("c1", 1000), ("c2", 5000)])
 @pytest.mark.parametrize("B", [1, 3, 64])
-def test_quantize_encode_fixture_tokenizers(dev, tag, L, B):
+def test_quantize_encode_fixture_tokenizers(dev, plan, tag, L, B):
     from ecg_byte_amd import synth
     from ecg_byte_amd.tokenizer import HipTokenizer
     vocab, merges, pc = load_tokenizer(tag)
@@ -107,7 +116,7 @@ def test_quantize_encode_fixture_tokenizers(dev, tag, L, B):
 
 
 def test_four_streams_per_workgroup_with_ragged_tail(dev):
-    """batch >= 1024 takes the 4-streams-per-workgroup kernel; 1030 leaves a partial workgroup."""
+    """batch >= 2 x CUs takes the wave-per-stream kernel; 1030 records leave a partly filled last workgroup."""
     from ecg_byte_amd import synth
     from ecg_byte_amd.tokenizer import HipTokenizer
     _, merges, pc = load_tokenizer("c1")
@@ -122,8 +131,8 @@ def test_four_streams_per_workgroup_with_ragged_tail(dev):
         assert counts[b] == r.size and np.array_equal(ids[b, : r.size].astype(np.uint32), r), b
 
 
-@pytest.mark.parametrize("n", [1, 2, 31, 255, 256, 257, 511, 513, 65535, 65536, 65537, 131073, 200001])
-def test_stream_lengths_across_chunk_and_segment_boundaries(dev, n):
+@pytest.mark.parametrize("n", [1, 2, 31, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 8193, 32767, 32768, 32769, 65537, 200001])
+def test_stream_lengths_across_chunk_and_segment_boundaries(dev, plan, n):
     from ecg_byte_amd.tokenizer import HipTokenizer
     rng = np.random.default_rng(n)
     merges = random_merges(rng, 300, alphabet=b"abcd", max_len=9)
@@ -135,7 +144,7 @@ def test_stream_lengths_across_chunk_and_segment_boundaries(dev, n):
         assert counts[b] == len(ref) and np.array_equal(got[b], ref), (n, b)
 
 
-def test_empty_batch_and_empty_streams(dev):
+def test_empty_batch_and_empty_streams(dev, plan):
     from ecg_byte_amd.tokenizer import HipTokenizer
     tk = HipTokenizer([([97, 98], 256)])
     ids, counts = tk.encode_bytes(torch.zeros((3, 0), dtype=torch.uint8, device="cuda"))
@@ -146,7 +155,7 @@ def test_empty_batch_and_empty_streams(dev):
 
 
 @pytest.mark.parametrize("seed", range(5))
-def test_random_merges_duplicates_interior_nodes_extra_bytes(dev, seed):
+def test_random_merges_duplicates_interior_nodes_extra_bytes(dev, plan, seed):
     """Non-prefix-closed vocabularies, duplicate expansions (last wins), bytes outside a..z in the
     merges (extra symbol classes) and bytes that occur in no merge at all."""
     from ecg_byte_amd.tokenizer import HipTokenizer
@@ -163,7 +172,7 @@ def test_random_merges_duplicates_interior_nodes_extra_bytes(dev, seed):
             assert counts[b] == len(ref) and np.array_equal(got[b], ref), (seed, n, b)
 
 
-def test_chains_that_never_resynchronise(dev):
+def test_chains_that_never_resynchronise(dev, plan):
     """Adversarial for the speculative chunk parse: with the single token 'ab' over 'ababab...'
     a parse started at an odd offset never meets the true chain, and long same-symbol runs with
     power-of-two tokens make the true chain jump over whole chunks.  The fixed-point stitch
@@ -184,7 +193,7 @@ def test_chains_that_never_resynchronise(dev):
         assert counts[0] == len(ref) and np.array_equal(got[0], ref)
 
 
-def test_ids_stride_truncates_but_counts_full_and_prefix_stable(dev):
+def test_ids_stride_truncates_but_counts_full_and_prefix_stable(dev, plan):
     from ecg_byte_amd import synth
     from ecg_byte_amd.tokenizer import HipTokenizer
     _, merges, pc = load_tokenizer("c2")
