@@ -34,6 +34,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def measured_traffic_bytes():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r*/hbm_pmc.json; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for
+    16 B/lane coalesced reads).  None if no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_pmc.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return (2.0 * d["FETCH_SIZE"]["per_launch_mean"] + d["WRITE_SIZE"]["per_launch_mean"]) * 1024.0
+
+
 def _gen_chunk(args):
     from ecg_byte_amd import synth
     start, count, L, seed = args
@@ -177,7 +190,8 @@ def main():
             "records_per_s": records_total / (wall / args.steps),
             "tokens_per_record": tokens_total / records_total,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic_bytes() if (B == 4096 and L == 5000) else None,
                          "kernel": "encode_wave_kernel<64, INPUT_F64> (fused quantise+encode, one launch per step)",
                          "kernel_ms": dev_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }

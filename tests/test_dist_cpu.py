@@ -1,0 +1,70 @@
+"""World-size-2 gloo test of the multi-GPU glue (runs on CPU): the record sharding rule equals
+torch's DistributedSampler, shards cover the batch, and the bookkeeping reductions give the
+single-process result.  The per-record compute in this test is the CPU oracle (the HIP path
+needs a GPU); what is under test is ecg-byte_amd/parallel.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import load_tokenizer
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_records, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ecg_byte_amd import parallel, synth
+        from oracle import oracle as O
+        _, merges, pc = load_tokenizer("c1")
+        trie = O.Trie(merges)
+        idx = parallel.shard_indices(n_records, rank, world)
+        x = synth.synth_ecg(n_records, 1000, seed=5)
+        counts = torch.tensor([trie.quantize_encode(x[i], pc["percentile_1"], pc["percentile_99"]).size for i in idx],
+                              dtype=torch.int32)
+        wall, total = parallel.reduce_step_stats(0.5 + rank, int(counts.sum()), torch.device("cpu"))
+        allc = parallel.gather_counts(counts)
+        ret[rank] = (idx, wall, total, allc.tolist())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_indices_equals_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+    from ecg_byte_amd import parallel
+    for n in (0, 1, 5, 8, 33):
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                want = list(DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=False)) if n else []
+                assert parallel.shard_indices(n, rank, world) == want, (n, world, rank)
+
+
+@pytest.mark.timeout(300)
+def test_world_size_2_gloo():
+    world, n_records = 2, 7
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n_records, ret), nprocs=world, join=True)
+    from ecg_byte_amd import synth
+    from oracle import oracle as O
+    _, merges, pc = load_tokenizer("c1")
+    trie = O.Trie(merges)
+    x = synth.synth_ecg(n_records, 1000, seed=5)
+    single = [trie.quantize_encode(x[i], pc["percentile_1"], pc["percentile_99"]).size for i in range(n_records)]
+    covered = sorted(set(ret[0][0]) | set(ret[1][0]))
+    assert covered == list(range(n_records))
+    for rank in range(world):
+        idx, wall, total, allc = ret[rank]
+        assert wall == 1.5                                            # MAX over ranks
+        assert total == sum(single[i] for i in ret[0][0]) + sum(single[i] for i in ret[1][0])
+        assert allc == [single[i] for i in ret[0][0]] + [single[i] for i in ret[1][0]]
