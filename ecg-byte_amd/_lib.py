@@ -69,6 +69,10 @@ def lib():
     L.ecgb_quantizer_thresholds.restype = C.c_int
     L.ecgb_set_encode_plan.argtypes = [C.c_int]
     L.ecgb_set_encode_plan.restype = C.c_int
+    L.ecgb_bpe_train_scratch_bytes.argtypes = [sz, u32]
+    L.ecgb_bpe_train_scratch_bytes.restype = sz
+    L.ecgb_bpe_train_hip.argtypes = [vp, sz, u32, vp, vp, vp, vp, vp, sz, vp]
+    L.ecgb_bpe_train_hip.restype = C.c_int
     i32 = C.c_int32
     L.ecgb_assemble_hip.argtypes = [vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32,
                                     C.c_int, u32, vp, vp, vp, vp, vp, vp]

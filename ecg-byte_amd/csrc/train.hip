@@ -1,0 +1,549 @@
+// train.hip -- BPE tokenizer training on MI355X (gfx950).
+//
+// Reference: rust_bpe.byte_pair_encoding, ecg_byte/rust_bpe/src/lib.rs:58-125, with
+//   get_stats  lib.rs:28-48   histogram of ALL adjacent pairs (overlapping windows count),
+//   arg-max    lib.rs:92-94   most frequent pair,
+//   merge      lib.rs:10-26   left-to-right, non-overlapping replacement, ids compacted.
+// Tie-break among equal counts: the reference's depends on hash-map iteration order and thread
+// schedule; here it is DEFINED as the numerically smallest (left, right).
+//
+// The reference recounts every pair on every merge (two full passes over the ids per merge,
+// hash-map inserts dominating).  Here the ids live in HBM as uint32 and the pair counts in a dense
+// V x V table (V = 256 + num_merges) that is built once and then only PATCHED: a merge changes
+// counts only next to its sites, so the rewrite pass emits ~5 count deltas per site.  Per merge:
+//   1. arg-max over the live part of the table          (reads V_cur x V words)
+//   2. per-tile survivor counts                          (reads N_i)
+//   3. exclusive scan of the tile counts                 (one workgroup)
+//   4. rewrite + compaction + count deltas               (reads N_i, writes N_{i+1})
+// Runs of one symbol merged with itself ("aaa" -> "Xa") need the offset parity inside the run;
+// tiles and per-thread spans are even-sized, so parity is carried by a "last non-uniform span"
+// look-up instead of a full segmented scan.  No host synchronisation inside the merge loop: the
+// chosen pair, the current length and the stop flag stay on the device.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "tokenizer.hpp"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kPerThread = 16;                        // even: a span of one repeated symbol keeps run parity
+constexpr uint32_t kTile = kThreads * kPerThread;     // 4096 ids per tile
+constexpr uint32_t kGrid = 2048;                      // persistent grid (8 workgroups per CU)
+constexpr uint32_t kHashSlots = 2048;                 // per-workgroup LDS table of count deltas
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+
+struct TrainState {
+    uint32_t n_cur;        // ids in the current buffer
+    uint32_t n_next;       // ids after the merge in flight
+    uint32_t left, right;  // pair chosen for the merge in flight
+    uint32_t new_id;
+    uint32_t active;       // 0 once no pair is left (lib.rs:88-90) -- later merges are no-ops
+    uint32_t done;         // merges performed
+    uint32_t pad;
+};
+
+struct TileInfo {
+    uint32_t count0;       // survivors if the run entering the tile has even length so far
+    uint32_t flags;        // bit0: lead run has odd length in this tile (count1 = count0 - 1 ... see below)
+                           // bit1: whole tile is `left` (l == r merges);  bit2: parity of trailing run of `left`
+};
+
+struct TrainArgs {
+    TrainState *st;
+    uint32_t *table;       // V x V pair counts
+    uint32_t V;
+    uint32_t *buf[2];      // ping-pong id buffers
+    TileInfo *tiles;       // per tile
+    uint32_t *tile_off;    // per tile: exclusive output offset; lead parity in the top bit
+    uint64_t *partial;     // kGrid arg-max partials: count << 32 | ~key
+    uint32_t *pairs_out;   // 2 x num_merges
+    uint32_t n0;           // initial length
+};
+
+// ---- LDS delta table --------------------------------------------------------------------
+__device__ __forceinline__ void delta_add(uint32_t *s_key, int *s_val, uint32_t *table, uint32_t key, int d)
+{
+    uint32_t h = (key * 2654435761u) >> 21;   // 11 bits
+    for (int probe = 0; probe < 16; ++probe) {
+        const uint32_t prev = atomicCAS(&s_key[h], kEmpty, key);
+        if (prev == kEmpty || prev == key) { atomicAdd(&s_val[h], d); return; }
+        h = (h + 1) & (kHashSlots - 1);
+    }
+    atomicAdd(&table[key], (uint32_t)d);      // table full around h: go to memory
+}
+
+__device__ __forceinline__ void delta_flush(uint32_t *s_key, int *s_val, uint32_t *table)
+{
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kHashSlots; i += kThreads) {
+        const uint32_t k = s_key[i];
+        const int v = s_val[i];
+        if (k != kEmpty && v != 0) atomicAdd(&table[k], (uint32_t)v);
+        s_key[i] = kEmpty;
+        s_val[i] = 0;
+    }
+    __syncthreads();
+}
+
+// ---- 0. bytes -> ids, initial histogram ----------------------------------------------------
+__global__ __launch_bounds__(kThreads) void init_kernel(TrainArgs A, const uint8_t *text)
+{
+    __shared__ uint32_t s_key[kHashSlots];
+    __shared__ int s_val[kHashSlots];
+    for (uint32_t i = threadIdx.x; i < kHashSlots; i += kThreads) { s_key[i] = kEmpty; s_val[i] = 0; }
+    __syncthreads();
+    const uint32_t n = A.n0;
+    const uint32_t n_tiles = (n + kTile - 1) / kTile;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint32_t base = t * kTile;
+        for (uint32_t k = threadIdx.x; k < kTile; k += kThreads) {
+            const uint32_t i = base + k;
+            if (i < n) {
+                const uint32_t a = text[i];
+                A.buf[0][i] = a;                                    // lib.rs:72
+                if (i + 1 < n) delta_add(s_key, s_val, A.table, a * A.V + text[i + 1], 1);   // ids.windows(2)
+            }
+        }
+        delta_flush(s_key, s_val, A.table);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        A.st->n_cur = n; A.st->n_next = n; A.st->active = 1; A.st->done = 0;
+        A.st->left = A.st->right = A.st->new_id = 0;
+    }
+}
+
+// ---- 1. arg-max ------------------------------------------------------------------------------
+// key order: larger count first, then smaller (left,right): pack count<<32 | ~index and take max.
+__global__ __launch_bounds__(kThreads) void argmax_partial_kernel(TrainArgs A, uint32_t merge_index)
+{
+    __shared__ unsigned long long s_best[kThreads / 64];
+    const uint32_t v_cur = 256u + merge_index;            // ids that can exist so far
+    const uint64_t total = (uint64_t)v_cur * A.V;
+    unsigned long long best = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kThreads) {
+        const uint32_t c = A.table[i];
+        if (c) {
+            const unsigned long long cand = ((unsigned long long)c << 32) | (uint32_t)~(uint32_t)i;
+            best = cand > best ? cand : best;
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long o = __shfl_down(best, d, 64);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w) best = s_best[w] > best ? s_best[w] : best;
+        A.partial[blockIdx.x] = best;
+    }
+}
+
+// One workgroup: commit the previous merge (length, counter), pick the pair of this one.
+__global__ __launch_bounds__(kThreads) void argmax_final_kernel(TrainArgs A, uint32_t merge_index, uint32_t n_partials)
+{
+    __shared__ unsigned long long s_best[kThreads / 64];
+    unsigned long long best = 0;
+    for (uint32_t i = threadIdx.x; i < n_partials; i += kThreads) {
+        const unsigned long long o = A.partial[i];
+        best = o > best ? o : best;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long o = __shfl_down(best, d, 64);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w) best = s_best[w] > best ? s_best[w] : best;
+        TrainState *st = A.st;
+        if (st->active && merge_index > 0) { st->n_cur = st->n_next; }   // commit merge_index - 1
+        if (st->active && (best >> 32) != 0) {
+            const uint32_t idx = ~(uint32_t)best;
+            st->left = idx / A.V;
+            st->right = idx % A.V;
+            st->new_id = 256u + merge_index;                                // lib.rs:97
+            A.pairs_out[2 * merge_index] = st->left;
+            A.pairs_out[2 * merge_index + 1] = st->right;
+            st->done = merge_index + 1;
+        } else {
+            st->active = 0;                                                 // lib.rs:88-90: pairs.is_empty() -> break
+        }
+    }
+}
+
+// ---- helpers for the rewrite ------------------------------------------------------------------
+// Per thread: 16 consecutive ids (+1 before, +2 after).  `lead_par` = parity of the number of
+// consecutive `left` ids immediately before the thread's first id (only used when left == right).
+struct Span {
+    uint32_t a[kPerThread + 3];   // a[0] = id before the span, a[1..16] the span, a[17], a[18] after
+};
+
+__device__ __forceinline__ void load_span(Span &s, const uint32_t *src, uint32_t i0, uint32_t n)
+{
+#pragma unroll
+    for (int k = 0; k < kPerThread + 3; ++k) {
+        const int64_t i = (int64_t)i0 + k - 1;
+        s.a[k] = (i >= 0 && i < (int64_t)n) ? src[i] : kEmpty;   // kEmpty never equals a real id
+    }
+}
+
+// number of trailing `l` ids of the span (0..16)
+__device__ __forceinline__ uint32_t trailing_l(const Span &s, uint32_t l)
+{
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = kPerThread; k >= 1; --k) { if (s.a[k] == l && c == (uint32_t)(kPerThread - k)) ++c; }
+    return c;
+}
+
+// Lead parity of each thread inside the workgroup for l == r merges: the trailing-run parity of
+// the nearest previous thread whose span is not all `l` (spans are even-sized, so all-`l` spans
+// pass parity through); `tile_par` if every previous thread of the tile is all `l`.
+// Contains workgroup barriers: call from uniform control flow.
+__device__ __forceinline__ uint32_t thread_lead_parity(uint32_t tail, uint32_t tile_par, uint32_t *s_wave)
+{
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(tail != kPerThread);
+    const int last = m ? 63 - __clzll((long long)m) : 0;
+    const uint32_t last_tail = __shfl(tail, last, 64);
+    const unsigned long long before = m & ((1ull << lane) - 1ull);
+    const int src = before ? 63 - __clzll((long long)before) : 0;
+    const uint32_t src_tail = __shfl(tail, src, 64);
+    if (lane == 0) s_wave[wv] = m ? (2u | (last_tail & 1u)) : 0u;
+    __syncthreads();
+    uint32_t par;
+    if (before) par = src_tail & 1u;
+    else {
+        par = tile_par;
+        for (int w = (int)wv - 1; w >= 0; --w)
+            if (s_wave[w] & 2u) { par = s_wave[w] & 1u; break; }
+    }
+    __syncthreads();
+    return par;
+}
+
+// Classify the span.  Bit k of site_mask: a merge starts at element k; bit k of second_mask:
+// element k is consumed as the right half of a site (k = 1..16).  `site_after`: element 17 starts
+// a site.  `lead_par` is only used when l == r.
+__device__ __forceinline__ void classify(const Span &s, uint32_t l, uint32_t r, uint32_t lead_par,
+                                         uint32_t &site_mask, uint32_t &second_mask, uint32_t &site_after)
+{
+    site_mask = 0; second_mask = 0;
+    if (l != r) {
+#pragma unroll
+        for (int k = 1; k <= kPerThread; ++k) {
+            if (s.a[k] == l && s.a[k + 1] == r) site_mask |= 1u << k;
+            if (s.a[k - 1] == l && s.a[k] == r) second_mask |= 1u << k;
+        }
+        site_after = (s.a[kPerThread + 1] == l && s.a[kPerThread + 2] == r) ? 1u : 0u;
+    } else {
+        uint32_t q = lead_par;                                  // run offset parity of element 1
+#pragma unroll
+        for (int k = 1; k <= kPerThread; ++k) {
+            if (s.a[k] == l) {
+                if (q == 0) { if (s.a[k + 1] == l) site_mask |= 1u << k; }
+                else second_mask |= 1u << k;
+                q ^= 1u;
+            } else q = 0;
+        }
+        site_after = (s.a[kPerThread + 1] == l && q == 0 && s.a[kPerThread + 2] == l) ? 1u : 0u;
+    }
+}
+
+// ---- 2. per-tile survivor counts (+ run facts of the tile for l == r merges) -------------------
+// flags bit0: the run of `l` that starts the tile has odd length (then an odd entering run costs the
+//             tile one more id);  bit1: the whole tile is `l` (even-sized: parity passes through);
+//       bit2: parity of the run of `l` that ends the tile (for the next tile's lead parity).
+__global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint32_t src_sel)
+{
+    __shared__ uint32_t s_wave[kThreads / 64];
+    __shared__ uint32_t s_cnt[kThreads / 64];
+    __shared__ uint32_t s_first[kThreads / 64];
+    __shared__ uint32_t s_last[kThreads / 64];
+    __shared__ uint32_t s_lead_extra;
+    const TrainState st = *A.st;
+    if (!st.active) return;
+    const uint32_t *src = A.buf[src_sel];
+    const uint32_t n = st.n_cur, l = st.left, r = st.right;
+    const bool same = (l == r);
+    const uint32_t n_tiles = (n + kTile - 1) / kTile;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint32_t i0 = t * kTile + threadIdx.x * kPerThread;
+        Span s;
+        load_span(s, src, i0, n);
+        uint32_t dropped = 0, tail = 0;
+        if (!same) {
+#pragma unroll
+            for (int k = 1; k <= kPerThread; ++k) dropped += (s.a[k - 1] == l && s.a[k] == r) ? 1u : 0u;
+        } else {
+            tail = trailing_l(s, l);
+            const uint32_t par = thread_lead_parity(tail, 0u, s_wave);   // as if the entering run were even
+            uint32_t site_mask, second_mask, sa;
+            classify(s, l, r, par, site_mask, second_mask, sa);
+            dropped = __popc(second_mask);
+        }
+        uint32_t d = dropped;
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+        if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = d;
+        uint32_t flags = 0;
+        if (same) {
+            const unsigned long long m = __ballot(tail != kPerThread);
+            const int last = m ? 63 - __clzll((long long)m) : 0;
+            const uint32_t last_tail = __shfl(tail, last, 64);
+            if ((threadIdx.x & 63) == 0) {
+                s_first[threadIdx.x >> 6] = m ? (uint32_t)__ffsll((long long)m) - 1u : 64u;
+                s_last[threadIdx.x >> 6] = m ? (2u | (last_tail & 1u)) : 0u;
+            }
+            __syncthreads();
+            uint32_t first_thread = kThreads;
+            for (int w = 0; w < kThreads / 64; ++w)
+                if (s_first[w] != 64u) { first_thread = w * 64 + s_first[w]; break; }
+            if (threadIdx.x == first_thread) {
+                uint32_t c = 0;
+#pragma unroll
+                for (int k = 1; k <= kPerThread; ++k) { if (s.a[k] == l && c == (uint32_t)(k - 1)) ++c; }
+                s_lead_extra = c;                     // leading `l` ids inside the first non-uniform span
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const bool whole = (first_thread == kThreads);
+                uint32_t tp = 0;
+                for (int w = kThreads / 64 - 1; w >= 0; --w) if (s_last[w] & 2u) { tp = s_last[w] & 1u; break; }
+                flags = (whole ? 2u : (s_lead_extra & 1u)) | (tp << 2);
+            }
+        } else {
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (int w = 0; w < kThreads / 64; ++w) total += s_cnt[w];
+            const uint32_t in_tile = min(kTile, n - t * kTile);
+            A.tiles[t].count0 = in_tile - total;
+            A.tiles[t].flags = flags;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- 3. scan of tile counts (one workgroup) ---------------------------------------------------
+__global__ __launch_bounds__(1024) void tile_scan_kernel(TrainArgs A)
+{
+    __shared__ uint32_t s_cnt[1024];
+    __shared__ uint32_t s_par[1024];
+    __shared__ uint32_t s_wsum[16];
+    __shared__ uint32_t s_carry, s_carry_par;
+    TrainState *st = A.st;
+    if (!st->active) return;
+    const uint32_t n = st->n_cur;
+    const bool same = st->left == st->right;
+    const uint32_t n_tiles = (n + kTile - 1) / kTile;
+    if (threadIdx.x == 0) { s_carry = 0; s_carry_par = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        const uint32_t t = base + threadIdx.x;
+        TileInfo ti = { 0, 0 };
+        if (t < n_tiles) ti = A.tiles[t];
+        s_cnt[threadIdx.x] = ti.count0;
+        s_par[threadIdx.x] = ti.flags;
+        __syncthreads();
+        if (same && threadIdx.x == 0) {
+            // lead parity of each tile: parity of the run of `left` ending just before it
+            uint32_t par = s_carry_par;
+            const uint32_t lim = min(1024u, n_tiles - base);
+            for (uint32_t k = 0; k < lim; ++k) {
+                const uint32_t f = s_par[k];
+                if (par && (f & 1u)) s_cnt[k] -= 1u;        // odd entering run + odd leading run: one more id is consumed
+                s_par[k] = par;                              // this tile's lead parity
+                if (f & 2u) { /* uniform, even-sized tile: parity passes through */ }
+                else par = (f >> 2) & 1u;                    // trailing run parity, but if the lead run reaches the tail...
+            }
+            s_carry_par = par;
+        }
+        __syncthreads();
+        // block-exclusive scan of s_cnt
+        uint32_t v = s_cnt[threadIdx.x];
+        uint32_t incl = v;
+        const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (uint32_t w = 0; w < wv; ++w) before += s_wsum[w];
+        if (t < n_tiles) A.tile_off[t] = (before + incl - v) | ((same ? s_par[threadIdx.x] : 0u) << 31);
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t tot = 0; for (int w = 0; w < 16; ++w) tot += s_wsum[w]; s_carry += tot; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st->n_next = s_carry;
+}
+
+// ---- 4. rewrite + compaction + count deltas ---------------------------------------------------
+__global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t src_sel)
+{
+    __shared__ uint32_t s_key[kHashSlots];
+    __shared__ int s_val[kHashSlots];
+    __shared__ uint32_t s_wave[kThreads / 64];
+    __shared__ uint32_t s_wsum[kThreads / 64];
+    const TrainState st = *A.st;
+    if (!st.active) return;
+    for (uint32_t i = threadIdx.x; i < kHashSlots; i += kThreads) { s_key[i] = kEmpty; s_val[i] = 0; }
+    __syncthreads();
+    const uint32_t *src = A.buf[src_sel];
+    uint32_t *dst = A.buf[src_sel ^ 1u];
+    const uint32_t n = st.n_cur, l = st.left, r = st.right, X = st.new_id, V = A.V;
+    const uint32_t n_tiles = (n + kTile - 1) / kTile;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint32_t i0 = t * kTile + threadIdx.x * kPerThread;
+        const uint32_t off_word = A.tile_off[t];
+        const uint32_t tile_par = off_word >> 31, tile_off = off_word & 0x7FFFFFFFu;
+        Span s;
+        load_span(s, src, i0, n);
+        uint32_t lead_par = 0;
+        if (l == r) lead_par = thread_lead_parity(trailing_l(s, l), tile_par, s_wave);
+        uint32_t site_mask, second_mask, sa;
+        classify(s, l, r, lead_par, site_mask, second_mask, sa);
+        // Is the element BEFORE the span (a[0]) a site?  For l != r directly; for l == r, a[0] (if it
+        // is `l`) is the last id of the run counted by lead_par, so its run offset parity is
+        // lead_par ^ 1: a site iff that is even and a[1] == l.
+        uint32_t site0;
+        if (l != r) site0 = (s.a[0] == l && s.a[1] == r) ? 1u : 0u;
+        else site0 = (s.a[0] == l && lead_par == 1u && s.a[1] == l) ? 1u : 0u;
+        site_mask |= site0;                 // bit 0 = element before the span
+        site_mask |= sa << (kPerThread + 1);
+        // local survivors
+        const uint32_t valid = (i0 < n) ? min((uint32_t)kPerThread, n - i0) : 0u;
+        uint32_t kept = 0;
+#pragma unroll
+        for (int k = 1; k <= kPerThread; ++k) kept += ((uint32_t)k <= valid && !((second_mask >> k) & 1u)) ? 1u : 0u;
+        uint32_t incl = kept;
+        const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        uint32_t w_off = tile_off;
+        for (uint32_t w = 0; w < wv; ++w) w_off += s_wsum[w];
+        uint32_t o = w_off + incl - kept;
+        // walk the span: write survivors, emit count deltas
+#pragma unroll
+        for (int k = 1; k <= kPerThread; ++k) {
+            if ((uint32_t)k > valid) continue;
+            const bool is_site = (site_mask >> k) & 1u;
+            const bool is_second = (second_mask >> k) & 1u;
+            const bool site_prev = (site_mask >> (k - 1)) & 1u;
+            const bool site_next = (site_mask >> (k + 1)) & 1u;
+            // old pair (a[k], a[k+1]) disappears iff a site starts at k-1, k or k+1
+            if (s.a[k + 1] != kEmpty && (site_prev || is_site || site_next))
+                delta_add(s_key, s_val, A.table, s.a[k] * V + s.a[k + 1], -1);
+            if (!is_second) {
+                const uint32_t val = is_site ? X : s.a[k];
+                dst[o++] = val;
+                // new pair (val, next kept value) counts iff this or the next kept element is a merged id
+                const int kn = is_site ? k + 2 : k + 1;             // next kept element
+                const uint32_t an = (kn <= kPerThread + 2) ? s.a[kn] : kEmpty;
+                if (an != kEmpty) {
+                    bool next_site;
+                    if (kn <= kPerThread + 1) next_site = (site_mask >> kn) & 1u;
+                    else {
+                        // kn == 18 (only when element 16 is a site): element 18 starts a site iff it and
+                        // element 19 match; for l == r it sits at an even run offset (16 was even, 17 odd)
+                        const uint32_t i19 = i0 + kPerThread + 2;   // a[19] = src[i0 - 1 + 19]
+                        const uint32_t a19 = (i19 < n) ? src[i19] : kEmpty;
+                        next_site = (an == l && a19 == r);
+                    }
+                    const uint32_t next_val = next_site ? X : an;
+                    if (is_site || next_site) delta_add(s_key, s_val, A.table, val * V + next_val, 1);
+                }
+            }
+        }
+        delta_flush(s_key, s_val, A.table);
+    }
+}
+
+// ---- final: commit the last merge and hand the ids out -----------------------------------------
+__global__ __launch_bounds__(kThreads) void finish_kernel(TrainArgs A, uint32_t num_merges, uint32_t *ids_out,
+                                                          uint64_t *n_ids_out, uint32_t *n_done_out)
+{
+    __shared__ uint32_t s_n, s_sel;
+    if (threadIdx.x == 0) {
+        const TrainState st = *A.st;
+        // n_next of the last performed merge is committed here (no later argmax_final ran)
+        const uint32_t n = (st.done > 0 && st.active) ? st.n_next : st.n_cur;
+        s_n = n;
+        s_sel = st.done & 1u;
+        if (blockIdx.x == 0) { *n_ids_out = n; *n_done_out = st.done; }
+    }
+    __syncthreads();
+    const uint32_t *src = A.buf[s_sel];
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < s_n; i += gridDim.x * kThreads) ids_out[i] = src[i];
+}
+
+int check_hip(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return ECGB_OK;
+    ecgb::set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return ECGB_ERR_HIP;
+}
+
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace
+
+extern "C" size_t ecgb_bpe_train_scratch_bytes(size_t n, uint32_t num_merges)
+{
+    const size_t V = 256 + (size_t)num_merges;
+    const size_t tiles = (n + kTile - 1) / kTile + 1;
+    return align256(sizeof(TrainState)) + align256(V * V * 4) + 2 * align256(n * 4 + 64) + align256(tiles * sizeof(TileInfo)) +
+           align256(tiles * 4) + align256(kGrid * 8) + 1024;
+}
+
+extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t num_merges, uint32_t *pairs_dev,
+                                  uint32_t *n_done_dev, uint32_t *ids_out_dev, uint64_t *n_ids_dev,
+                                  void *scratch_dev, size_t scratch_bytes, void *stream)
+{
+    if (!pairs_dev || !n_done_dev || !ids_out_dev || !n_ids_dev || !scratch_dev || (n && !text_dev)) {
+        ecgb::set_error("ecgb_bpe_train_hip: NULL argument");
+        return ECGB_ERR_INVALID;
+    }
+    if (n >= 0x7FFFFFFFull || num_merges > 65000u) {
+        ecgb::set_error("ecgb_bpe_train_hip: text longer than 2^31-1 bytes or more than 65000 merges");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    if (scratch_bytes < ecgb_bpe_train_scratch_bytes(n, num_merges)) {
+        ecgb::set_error("ecgb_bpe_train_hip: scratch smaller than ecgb_bpe_train_scratch_bytes()");
+        return ECGB_ERR_INVALID;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t V = 256 + (size_t)num_merges;
+    const size_t tiles = (n + kTile - 1) / kTile + 1;
+    uint8_t *p = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(scratch_dev) + 255) / 256 * 256);
+    TrainArgs A;
+    A.st = reinterpret_cast<TrainState *>(p); p += align256(sizeof(TrainState));
+    A.table = reinterpret_cast<uint32_t *>(p); p += align256(V * V * 4);
+    A.buf[0] = reinterpret_cast<uint32_t *>(p); p += align256(n * 4 + 64);
+    A.buf[1] = reinterpret_cast<uint32_t *>(p); p += align256(n * 4 + 64);
+    A.tiles = reinterpret_cast<TileInfo *>(p); p += align256(tiles * sizeof(TileInfo));
+    A.tile_off = reinterpret_cast<uint32_t *>(p); p += align256(tiles * 4);
+    A.partial = reinterpret_cast<uint64_t *>(p); p += align256(kGrid * 8);
+    A.V = (uint32_t)V;
+    A.pairs_out = pairs_dev;
+    A.n0 = (uint32_t)n;
+    int rc = check_hip(hipMemsetAsync(A.table, 0, V * V * 4, st), "hipMemsetAsync(table)");
+    if (rc) return rc;
+    const unsigned tile_grid = (unsigned)std::max<size_t>(1, std::min<size_t>(kGrid, (n + kTile - 1) / kTile));
+    hipLaunchKernelGGL(init_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, text_dev);
+    for (uint32_t i = 0; i < num_merges; ++i) {
+        const size_t live = (size_t)(256 + i) * V;
+        const unsigned ag = (unsigned)std::max<size_t>(1, std::min<size_t>(kGrid, (live + kThreads * 8 - 1) / (kThreads * 8)));
+        hipLaunchKernelGGL(argmax_partial_kernel, dim3(ag), dim3(kThreads), 0, st, A, i);
+        hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(kThreads), 0, st, A, i, ag);
+        hipLaunchKernelGGL(tile_count_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, i & 1u);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, A);
+        hipLaunchKernelGGL(rewrite_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, i & 1u);
+    }
+    hipLaunchKernelGGL(finish_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, num_merges, ids_out_dev, n_ids_dev,
+                       n_done_dev);
+    return check_hip(hipGetLastError(), "bpe train launches");
+}

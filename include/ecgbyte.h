@@ -21,6 +21,7 @@
  *                              ecg_byte/data_loader.py:74-76 (normalize_all -> join -> encode_text)
  *   ecgb_assemble_hip          ECGTokenDataset._prepare_training / _prepare_inference,
  *                              ecg_byte/data_loader.py:91-132 (+ the id->LLM-id mapping of :80)
+ *   ecgb_bpe_train_hip         rust_bpe.byte_pair_encoding, ecg_byte/rust_bpe/src/lib.rs:58-125
  * INTEGRATION.md shows the binding a reference maintainer would add for each.
  */
 #ifndef ECGBYTE_H
@@ -135,6 +136,20 @@ int ecgb_assemble_hip(const uint32_t *ids_dev, size_t ids_stride, const uint32_t
                       int32_t sig_end_id, uint32_t pad_to_max, int inference, uint32_t row_len,
                       int64_t *input_ids_dev, float *attn_mask_dev, int64_t *labels_dev,
                       int64_t *position_ids_dev, uint32_t *lengths_dev, void *stream);
+
+/* ---- tokenizer training ------------------------------------------------------------------
+ * rust_bpe.byte_pair_encoding (lib.rs:58-125) on the device: up to num_merges rounds of
+ * { most frequent adjacent pair; replace it left to right, non-overlapping, by id 256+i }.
+ * Stops early when no pair is left (lib.rs:88-90).  Tie-break among equal counts: numerically
+ * smallest (left, right) -- the reference's is hash-order/schedule dependent.
+ * text_dev: n bytes.  pairs_dev: 2*num_merges uint32, (left,right) of merge i at [2i],[2i+1]
+ * (the caller derives vocab strings / byte expansions, lib.rs:101-110).  n_done_dev: merges
+ * performed.  ids_out_dev: n uint32, the final ids; n_ids_dev: their number.  Everything is
+ * enqueued on `stream`; no host synchronisation. */
+size_t ecgb_bpe_train_scratch_bytes(size_t n, uint32_t num_merges);
+int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t num_merges, uint32_t *pairs_dev,
+                       uint32_t *n_done_dev, uint32_t *ids_out_dev, uint64_t *n_ids_dev,
+                       void *scratch_dev, size_t scratch_bytes, void *stream);
 
 #ifdef __cplusplus
 }

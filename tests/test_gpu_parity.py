@@ -303,3 +303,27 @@ def test_batch_assembler_end_to_end_vs_oracle_pipeline(dev):
     assert n_padded >= 2
     with pytest.raises(AssertionError):
         asm.assemble(*asm.encode(torch.from_numpy(x[:1]).cuda(), pc, max_tokens=P), [list(range(1000))], [list(range(30))])
+
+
+def test_train_tokenizer_cli_end_to_end(dev, tmp_path):
+    """The reference's train_tokenizer.py flow on the reference's on-disk formats: .npy records,
+    a sampled-files list, a pickled-dict percentiles .npy -> tokenizer .pkl + round-trip check."""
+    from ecg_byte_amd import synth, train_tokenizer
+    from ecg_byte_amd import tokenizer_utils as tu
+    pc = synth.synth_percentiles(250, seed=0, n_samples=20000)
+    np.save(tmp_path / "pc.npy", pc)                                 # preprocess_utils.py:208-210
+    paths = []
+    x = synth.synth_ecg(12, 250, seed=8)
+    for i in range(12):
+        p = tmp_path / f"ecg_{i}_0.npy"
+        np.save(p, x[i])
+        paths.append(str(p))
+    (tmp_path / "sampled.txt").write_text("\n".join(paths) + "\n")
+    out = tmp_path / "tokenizer_50.pkl"
+    args = train_tokenizer.get_args(["--train", "--num_merges", "50", "--sampled_files", str(tmp_path / "sampled.txt"),
+                                     "--percentiles", str(tmp_path / "pc.npy"), "--check_ecg", paths[3], "--out", str(out)])
+    assert train_tokenizer.main(args) is True
+    vocab, merges = tu.load_vocab_and_merges(str(out))
+    corpus = tu.process_large_file(str(tmp_path / "sampled.txt"), pc, 2)
+    assert corpus == "".join(O.symbols_to_text(O.quantize(x[i], pc["percentile_1"], pc["percentile_99"])).decode() for i in range(12))
+    assert (vocab, merges) == O.byte_pair_encoding(corpus, 50, fast=False)[1:]

@@ -1,0 +1,102 @@
+"""GPU tests of the HIP BPE trainer against the CPU oracle (literal lib.rs loop and its
+fast equivalent), which share the DEFINED tie-break (smallest (left,right)); plus the
+properties the reference guarantees whatever its tie-break."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _train(text, num_merges):
+    from ecg_byte_amd import rust_bpe
+    return rust_bpe.byte_pair_encoding(text, num_merges, 1)
+
+
+def test_trainer_known_answers():
+    ids, vocab, merges = _train("aaabdaaabac", 2)
+    assert merges == [([97, 97], 256), ([97, 98], 257)]              # step 1: tie -> smallest pair
+    assert ids == [256, 257, 100, 256, 257, 97, 99]
+    assert vocab[256] == "aa" and vocab[257] == "ab"
+    assert _train("ab", 5)[0] == [256] and len(_train("ab", 5)[2]) == 1   # stops when no pair is left
+    assert _train("", 3) == ([], {i: O.byte_to_string(i) for i in range(256)}, [])
+    assert _train("a", 3)[0] == [97]
+    assert _train("aaaa", 1)[0] == [256, 256]
+    assert _train("aaa", 1)[0] == [256, 97]                              # merge([a,a,a]) = [X,a]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_trainer_equals_oracle_small(seed):
+    rng = np.random.default_rng(seed)
+    for _ in range(6):
+        n = int(rng.integers(0, 3000))
+        k = int(rng.choice([1, 2, 3, 5, 26]))
+        text = bytes(rng.integers(97, 97 + k, size=n).astype(np.uint8))
+        nm = int(rng.integers(0, 70))
+        got = _train(text, nm)
+        assert got == O.byte_pair_encoding(text, nm, fast=False), (seed, n, k, nm)
+
+
+@pytest.mark.parametrize("n,alphabet", [(4095, b"a"), (4096, b"a"), (4097, b"a"), (20000, b"ab"), (70001, b"aab"),
+                                        (16 * 4096 + 7, b"a"), (9000, b"abab")])
+def test_trainer_runs_across_thread_and_tile_boundaries(n, alphabet):
+    """Long same-symbol runs (merge of a symbol with itself) across 16-id spans and 4096-id tiles."""
+    rng = np.random.default_rng(n)
+    text = bytes(rng.choice(np.frombuffer(alphabet, dtype=np.uint8), size=n))
+    if alphabet == b"a":
+        text = b"b" * (n % 5) + text      # shift the run against the tile grid
+    assert _train(text, 14) == O.byte_pair_encoding(text, 14, fast=True)
+
+
+def test_trainer_on_ecg_corpus_matches_fixture_prefix():
+    """200 synthetic records (12x1000): the first 300 merges equal the oracle trainer's, the ids decode
+    back to the text (train_tokenizer.py:58-60) and each chosen pair was a most-frequent pair."""
+    from ecg_byte_amd import synth
+    from helpers import load_tokenizer
+    _, _, pc = load_tokenizer("c1")
+    x = synth.synth_ecg(200, 1000, seed=1)
+    text = O.symbols_to_text(O.quantize(x, pc["percentile_1"], pc["percentile_99"]))
+    ids, vocab, merges = _train(text, 300)
+    ref = O.byte_pair_encoding(text, 300, fast=True)
+    assert merges == ref[2]
+    assert ids == ref[0]
+    assert O.decode_text(ids, vocab) == text.decode("ascii")
+    assert all(m[1] == 256 + i for i, m in enumerate(merges))
+
+
+def test_trained_tokenizer_feeds_the_encoder():
+    """train -> encode round trip entirely on the device path."""
+    from ecg_byte_amd import rust_bpe
+    rng = np.random.default_rng(2)
+    text = bytes(rng.choice(np.frombuffer(b"aaabbc", dtype=np.uint8), size=50000))
+    ids, vocab, merges = _train(text, 200)
+    enc = rust_bpe.encode_text(text.decode(), merges)
+    assert "".join(vocab[i] for i in enc) == text.decode()
+    assert enc == O.encode_text(text, merges)
+
+
+@pytest.mark.parametrize("tag,L,nm", [("c1", 1000, 1000), ("c2", 5000, 4000)])
+def test_trainer_reproduces_committed_tokenizers_at_full_size(tag, L, nm):
+    """SURVEY.md §8d tokenizers: 2 000 synthetic records (seed 1) -> the committed (vocab, merges)
+    pickles, which the ORACLE trainer produced.  Whole pipeline on the device: quantise -> train."""
+    import bench
+    from helpers import load_tokenizer
+    from ecg_byte_amd import rust_bpe
+    from ecg_byte_amd.tokenizer import quantize
+    from ecg_byte_amd.trainer import bpe_train_device
+    vocab, merges, pc = load_tokenizer(tag)
+    x = bench.make_signals(2000, L, seed=1, start=0, workers=8)
+    text = (quantize(torch.from_numpy(x).cuda(), pc).view(-1) + 97).contiguous()
+    del x
+    ids, n_ids, pairs, n_done = bpe_train_device(text, nm)
+    assert int(n_done) == nm
+    v2, m2 = rust_bpe.vocab_merges_from_pairs(pairs.cpu().tolist())
+    assert m2 == merges and v2 == vocab
+    # the final ids tile the corpus: token lengths sum to the text length
+    lens = np.ones(256 + nm, dtype=np.int64)
+    for seq, tid in merges:
+        lens[tid] = len(seq)
+    got = ids[: int(n_ids)].cpu().numpy()
+    assert int(lens[got].sum()) == text.numel()
