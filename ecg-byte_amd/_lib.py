@@ -77,6 +77,32 @@ def lib():
     L.ecgb_assemble_hip.argtypes = [vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32,
                                     C.c_int, u32, vp, vp, vp, vp, vp, vp]
     L.ecgb_assemble_hip.restype = C.c_int
+    # ---- decoder ops (include/ecgbyte_decoder.h)
+    f32, ll, ci = C.c_float, C.c_longlong, C.c_int
+    sigs = {
+        "ecgb_embed_fwd": [vp, vp, vp, sz, ci, f32, vp],
+        "ecgb_embed_bwd": [vp, vp, vp, sz, ci, f32, vp],
+        "ecgb_rmsnorm_fwd": [vp, vp, vp, vp, vp, vp, sz, ci, f32, ci, vp],
+        "ecgb_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, sz, ci, ci, vp],
+        "ecgb_rope": [vp, vp, vp, sz, ci, ci, sz, ci, vp],
+        "ecgb_glu_fwd": [vp, vp, sz, ci, ci, vp],
+        "ecgb_glu_bwd": [vp, vp, vp, sz, ci, ci, vp],
+        "ecgb_add_bf16": [vp, vp, vp, sz, vp],
+        "ecgb_transpose_bf16": [vp, vp, ci, ci, vp],
+        "ecgb_f32_to_bf16": [vp, vp, sz, vp],
+        "ecgb_gemm_nt_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, ci, ll, ll, ll, vp],
+        "ecgb_gemm_nt_bf16_heads": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, ci, ll, ll, ci, ll, ll, ci, ll, ll, vp],
+        "ecgb_count_labels": [vp, sz, ci, vp, vp],
+        "ecgb_ce_fwd_bwd": [vp, vp, vp, vp, vp, sz, ci, sz, vp],
+        "ecgb_sumsq": [vp, sz, ci, vp, vp],
+        "ecgb_adam_step": [vp, vp, ci, vp, vp, sz, vp, f32, f32, f32, f32, f32, f32, ci, vp],
+        "ecgb_softmax_causal_fwd": [vp, vp, ci, ci, ci, f32, vp],
+        "ecgb_softmax_bwd": [vp, vp, ci, ci, f32, vp],
+    }
+    for name, args in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
     _lib = L
     return L
 

@@ -1,0 +1,674 @@
+// decoder_ops.hip -- the HBM-bound pieces of the causal-LM step on MI355X (gfx950): embedding,
+// RMSNorm, RoPE, SwiGLU, residual add, cross-entropy, Adam, gradient-norm; forward and backward.
+// bf16 tensors in HBM, fp32 arithmetic in registers, 16-byte (8 x bf16) accesses.
+//
+// Reference behaviour (vendored transformers 4.46.0.dev0, paths relative to the reference root):
+//   LlamaRMSNorm.forward              transformers/src/transformers/models/llama/modeling_llama.py:67-72
+//   apply_rotary_pos_emb/rotate_half  modeling_llama.py:193-224 (half-split layout)
+//   LlamaMLP.forward (SiLU gate)      modeling_llama.py:238-258
+//   ForCausalLMLoss                   transformers/src/transformers/loss/loss_utils.py:32-47
+//   Adam(weight_decay = L2)           ecg_byte/main.py:262-264 ; clip_grad_norm_ ecg_byte/runners/train.py:26
+#include <hip/hip_bf16.h>
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "tokenizer.hpp"
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) unsigned short;
+
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f)
+{
+    __hip_bfloat16 b = __float2bfloat16(f);   // round to nearest even, NaN stays NaN
+    return *reinterpret_cast<unsigned short *>(&b);
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+int ok_or(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return ECGB_OK;
+    ecgb::set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return ECGB_ERR_HIP;
+}
+
+unsigned grid_for(size_t items, unsigned per_block)
+{
+    size_t b = (items + per_block - 1) / per_block;
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(b, 256 * 16));
+}
+
+// ---- embedding -------------------------------------------------------------------------------
+// out[t, :] = table[ids[t], :] * scale   (scale = 1 for Llama; sqrt(hidden) for Gemma)
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long *ids, const unsigned short *table, unsigned short *out,
+                                                        size_t T, int H, float scale)
+{
+    const int per_row = H / 8;
+    const size_t total = T * per_row;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / per_row;
+        const int c = (int)(i % per_row);
+        bf16x8 v = *reinterpret_cast<const bf16x8 *>(table + (size_t)ids[t] * H + c * 8);
+        if (scale != 1.0f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) * scale);
+        }
+        *reinterpret_cast<bf16x8 *>(out + t * H + c * 8) = v;
+    }
+}
+
+// grad_table(fp32)[ids[t], :] += dout[t, :] * scale
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long *ids, const unsigned short *dout, float *grad_table,
+                                                        size_t T, int H, float scale)
+{
+    const int per_row = H / 8;
+    const size_t total = T * per_row;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / per_row;
+        const int c = (int)(i % per_row);
+        const bf16x8 v = *reinterpret_cast<const bf16x8 *>(dout + t * H + c * 8);
+        float *g = grad_table + (size_t)ids[t] * H + c * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(g + j, bf2f(v[j]) * scale);
+    }
+}
+
+// ---- RMSNorm ---------------------------------------------------------------------------------
+// One wave per row.  y = w * bf16(x * rsqrt(mean(x^2) + eps))  (Llama; gemma: (1 + w), fp32 product)
+// Optionally fuses the residual add that precedes it: x = a + b is written to `sum_out`.
+template <bool GEMMA>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const unsigned short *a, const unsigned short *b,
+                                                          const unsigned short *w, unsigned short *y,
+                                                          unsigned short *sum_out, float *rstd, size_t rows, int H, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t r = wave; r < rows; r += n_waves) {
+        const unsigned short *pa = a + r * H;
+        float ss = 0.f;
+        for (int c = lane * 8; c < H; c += 64 * 8) {
+            bf16x8 v = *reinterpret_cast<const bf16x8 *>(pa + c);
+            if (b) {
+                const bf16x8 u = *reinterpret_cast<const bf16x8 *>(b + r * H + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + bf2f(u[j]));
+                *reinterpret_cast<bf16x8 *>(sum_out + r * H + c) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]); ss += f * f; }
+        }
+        ss = wave_sum(ss);
+        const float rs = rsqrtf(ss / (float)H + eps);
+        if (lane == 0 && rstd) rstd[r] = rs;
+        const unsigned short *px = b ? sum_out + r * H : pa;
+        for (int c = lane * 8; c < H; c += 64 * 8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(px + c);
+            const bf16x8 g = *reinterpret_cast<const bf16x8 *>(w + c);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (GEMMA) o[j] = f2bf(bf2f(v[j]) * rs * (1.0f + bf2f(g[j])));
+                else o[j] = f2bf(bf2f(f2bf(bf2f(v[j]) * rs)) * bf2f(g[j]));
+            }
+            *reinterpret_cast<bf16x8 *>(y + r * H + c) = o;
+        }
+    }
+}
+
+// dx = rs * (dy*w' - xhat * mean(dy*w'*xhat)) [+ dres];   dw(fp32) += sum_rows dy * xhat
+// w' = w (Llama) or 1 + w (Gemma).  One wave per row; dw accumulated per block in LDS then atomics.
+template <bool GEMMA>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const unsigned short *x, const unsigned short *w,
+                                                          const float *rstd, const unsigned short *dy,
+                                                          const unsigned short *dres, unsigned short *dx, float *dw,
+                                                          size_t rows, int H)
+{
+    extern __shared__ float s_dw[];   // H floats
+    for (int c = threadIdx.x; c < H; c += blockDim.x) s_dw[c] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t r = wave; r < rows; r += n_waves) {
+        const float rs = rstd[r];
+        float dot = 0.f;
+        for (int c = lane * 8; c < H; c += 64 * 8) {
+            const bf16x8 vx = *reinterpret_cast<const bf16x8 *>(x + r * H + c);
+            const bf16x8 vg = *reinterpret_cast<const bf16x8 *>(dy + r * H + c);
+            const bf16x8 vw = *reinterpret_cast<const bf16x8 *>(w + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float wf = GEMMA ? 1.0f + bf2f(vw[j]) : bf2f(vw[j]);
+                dot += bf2f(vg[j]) * wf * bf2f(vx[j]) * rs;
+            }
+        }
+        dot = wave_sum(dot) / (float)H;
+        for (int c = lane * 8; c < H; c += 64 * 8) {
+            const bf16x8 vx = *reinterpret_cast<const bf16x8 *>(x + r * H + c);
+            const bf16x8 vg = *reinterpret_cast<const bf16x8 *>(dy + r * H + c);
+            const bf16x8 vw = *reinterpret_cast<const bf16x8 *>(w + c);
+            bf16x8 vr;
+            if (dres) vr = *reinterpret_cast<const bf16x8 *>(dres + r * H + c);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = bf2f(vx[j]) * rs;
+                const float g = bf2f(vg[j]);
+                const float wf = GEMMA ? 1.0f + bf2f(vw[j]) : bf2f(vw[j]);
+                float d = rs * (g * wf - xh * dot);
+                if (dres) d += bf2f(vr[j]);
+                o[j] = f2bf(d);
+                atomicAdd(&s_dw[c + j], g * xh);
+            }
+            *reinterpret_cast<bf16x8 *>(dx + r * H + c) = o;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += blockDim.x) atomicAdd(dw + c, s_dw[c]);
+}
+
+// ---- RoPE --------------------------------------------------------------------------------------
+// x: [T, n_heads, D] (token-major, heads contiguous); cos/sin: [T, D/2] fp32.  In place.
+// forward:  (x1, x2) -> (x1*c - x2*s, x2*c + x1*s);  backward (INVERSE): (g1*c + g2*s, g2*c - g1*s)
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void rope_kernel(unsigned short *x, const float *cs, const float *sn, size_t T,
+                                                   int n_heads, int D, size_t row_stride)
+{
+    const int half = D / 2;
+    const size_t total = T * n_heads * (half / 8 > 0 ? half / 8 : 1);
+    const int per_head = half / 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % per_head);
+        const size_t th = i / per_head;
+        const int h = (int)(th % n_heads);
+        const size_t t = th / n_heads;
+        unsigned short *p = x + t * row_stride + (size_t)h * D + c * 8;
+        bf16x8 a = *reinterpret_cast<bf16x8 *>(p), b = *reinterpret_cast<bf16x8 *>(p + half);
+        const float *pc = cs + t * half + c * 8, *ps = sn + t * half + c * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // HF holds cos/sin in the activation dtype (bf16): modeling_llama.py:163-165
+            const float cc = bf2f(f2bf(pc[j])), ss = bf2f(f2bf(ps[j]));
+            const float x1 = bf2f(a[j]), x2 = bf2f(b[j]);
+            if (!INVERSE) { a[j] = f2bf(x1 * cc - x2 * ss); b[j] = f2bf(x2 * cc + x1 * ss); }
+            else { a[j] = f2bf(x1 * cc + x2 * ss); b[j] = f2bf(x2 * cc - x1 * ss); }
+        }
+        *reinterpret_cast<bf16x8 *>(p) = a;
+        *reinterpret_cast<bf16x8 *>(p + half) = b;
+    }
+}
+
+// ---- SwiGLU / GeGLU ------------------------------------------------------------------------------
+// gu: [T, 2*I] with gate in [:, :I] and up in [:, I:]  (one fused gate|up projection);  h: [T, I]
+template <bool GELU_TANH>
+__device__ __forceinline__ float act(float g)
+{
+    if (GELU_TANH) { const float k = 0.7978845608028654f; return 0.5f * g * (1.f + tanhf(k * (g + 0.044715f * g * g * g))); }
+    return g / (1.f + __expf(-g));
+}
+template <bool GELU_TANH>
+__device__ __forceinline__ float act_grad(float g)
+{
+    if (GELU_TANH) {
+        const float k = 0.7978845608028654f;
+        const float u = k * (g + 0.044715f * g * g * g), t = tanhf(u);
+        return 0.5f * (1.f + t) + 0.5f * g * (1.f - t * t) * k * (1.f + 3.f * 0.044715f * g * g);
+    }
+    const float s = 1.f / (1.f + __expf(-g));
+    return s * (1.f + g * (1.f - s));
+}
+
+template <bool GELU_TANH>
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const unsigned short *gu, unsigned short *h, size_t T, int I)
+{
+    const int per_row = I / 8;
+    const size_t total = T * per_row;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / per_row;
+        const int c = (int)(i % per_row) * 8;
+        const bf16x8 g = *reinterpret_cast<const bf16x8 *>(gu + t * 2 * I + c);
+        const bf16x8 u = *reinterpret_cast<const bf16x8 *>(gu + t * 2 * I + I + c);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(f2bf(act<GELU_TANH>(bf2f(g[j])))) * bf2f(u[j]));
+        *reinterpret_cast<bf16x8 *>(h + t * I + c) = o;
+    }
+}
+
+template <bool GELU_TANH>
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const unsigned short *gu, const unsigned short *dh, unsigned short *dgu,
+                                                      size_t T, int I)
+{
+    const int per_row = I / 8;
+    const size_t total = T * per_row;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t t = i / per_row;
+        const int c = (int)(i % per_row) * 8;
+        const bf16x8 g = *reinterpret_cast<const bf16x8 *>(gu + t * 2 * I + c);
+        const bf16x8 u = *reinterpret_cast<const bf16x8 *>(gu + t * 2 * I + I + c);
+        const bf16x8 d = *reinterpret_cast<const bf16x8 *>(dh + t * I + c);
+        bf16x8 og, ou;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gf = bf2f(g[j]), uf = bf2f(u[j]), df = bf2f(d[j]);
+            og[j] = f2bf(df * uf * act_grad<GELU_TANH>(gf));
+            ou[j] = f2bf(df * act<GELU_TANH>(gf));
+        }
+        *reinterpret_cast<bf16x8 *>(dgu + t * 2 * I + c) = og;
+        *reinterpret_cast<bf16x8 *>(dgu + t * 2 * I + I + c) = ou;
+    }
+}
+
+// ---- elementwise add (residual) -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_kernel(const unsigned short *a, const unsigned short *b, unsigned short *o, size_t n8)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const bf16x8 x = reinterpret_cast<const bf16x8 *>(a)[i], y = reinterpret_cast<const bf16x8 *>(b)[i];
+        bf16x8 z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] = f2bf(bf2f(x[j]) + bf2f(y[j]));
+        reinterpret_cast<bf16x8 *>(o)[i] = z;
+    }
+}
+
+// ---- cross-entropy over a chunk of rows ------------------------------------------------------------
+// logits: [rows, V] bf16 (upcast to fp32, loss_utils.py:36).  labels[r] = target of row r or -100.
+// Writes per-row loss (0 for ignored rows), accumulates sum_loss; overwrites logits IN PLACE with
+// dlogits = (softmax - onehot) * inv_count  (0 for ignored rows).  One workgroup per row.
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(unsigned short *logits, const long long *labels, float *row_loss,
+                                                         float *sum_loss, const float *inv_count_ptr, size_t rows, int V,
+                                                         size_t ld)
+{
+    __shared__ float s_red[4];
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (size_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        unsigned short *p = logits + r * ld;
+        const long long lab = labels[r];
+        const bool valid = lab >= 0 && lab < V;
+        const int V8 = V & ~7;
+        float m = -INFINITY;
+        for (int c = threadIdx.x * 8; c < V8; c += 256 * 8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = fmaxf(m, bf2f(v[j]));
+        }
+        for (int c = V8 + threadIdx.x; c < V; c += 256) m = fmaxf(m, bf2f(p[c]));
+        m = wave_max(m);
+        if (lane == 0) s_red[wv] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        __syncthreads();
+        float s = 0.f;
+        for (int c = threadIdx.x * 8; c < V8; c += 256 * 8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += __expf(bf2f(v[j]) - m);
+        }
+        for (int c = V8 + threadIdx.x; c < V; c += 256) s += __expf(bf2f(p[c]) - m);
+        s = wave_sum(s);
+        if (lane == 0) s_red[wv] = s;
+        __syncthreads();
+        s = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        const float lse = m + logf(s);
+        const float inv_count = *inv_count_ptr;
+        if (threadIdx.x == 0) {
+            const float l = valid ? lse - bf2f(p[lab]) : 0.f;
+            row_loss[r] = l;
+            if (valid) atomicAdd(sum_loss, l * inv_count);
+        }
+        __syncthreads();
+        const float scale = valid ? inv_count : 0.f;
+        for (int c = threadIdx.x * 8; c < V8; c += 256 * 8) {
+            bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float g = __expf(bf2f(v[j]) - lse);
+                if (c + j == lab) g -= 1.f;
+                v[j] = f2bf(g * scale);
+            }
+            *reinterpret_cast<bf16x8 *>(p + c) = v;
+        }
+        for (int c = V8 + threadIdx.x; c < V; c += 256) {
+            float g = __expf(bf2f(p[c]) - lse);
+            if (c == lab) g -= 1.f;
+            p[c] = f2bf(g * scale);
+        }
+        for (int c = V + threadIdx.x; c < (int)ld; c += 256) p[c] = 0;   // padded vocabulary columns carry no gradient
+        __syncthreads();
+    }
+}
+
+// number of labels != -100 -> *inv_count = 1 / max(count, 1)   (mean reduction, loss_utils.py:24-29)
+__global__ __launch_bounds__(256) void count_labels_kernel(const long long *labels, size_t n, int V, float *inv_count)
+{
+    __shared__ unsigned s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    unsigned c = 0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) c += (labels[i] >= 0 && labels[i] < V) ? 1u : 0u;
+    atomicAdd(&s_cnt, c);
+    __syncthreads();
+    if (threadIdx.x == 0) *inv_count = 1.0f / (float)(s_cnt ? s_cnt : 1u);
+}
+
+// ---- optimizer -------------------------------------------------------------------------------------
+// sum of squares of a bf16 or fp32 gradient tensor, accumulated into *acc (fp32)
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_kernel(const T *g, size_t n, float *acc)
+{
+    __shared__ float s_red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float f;
+        if constexpr (sizeof(T) == 2) f = bf2f(g[i]); else f = g[i];
+        s += f * f;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+}
+
+// torch.optim.Adam with weight_decay as L2 (main.py:262-264), preceded by clip_grad_norm_(1.0)
+// (train.py:26): clip = min(1, max_norm / (sqrt(*sumsq) + 1e-6)).  Moments fp32, params bf16.
+template <typename G>
+__global__ __launch_bounds__(256) void adam_kernel(unsigned short *p, const G *g, float *m, float *v, size_t n,
+                                                   const float *sumsq, float max_norm, float lr, float b1, float b2,
+                                                   float eps, float wd, float bc1, float bc2)
+{
+    const float norm = sqrtf(*sumsq);
+    const float clip = fminf(1.0f, max_norm / (norm + 1e-6f));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float gf;
+        if constexpr (sizeof(G) == 2) gf = bf2f(g[i]); else gf = g[i];
+        const float pf = bf2f(p[i]);
+        gf = gf * clip + wd * pf;
+        const float mm = b1 * m[i] + (1.f - b1) * gf;
+        const float vv = b2 * v[i] + (1.f - b2) * gf * gf;
+        m[i] = mm; v[i] = vv;
+        const float denom = sqrtf(vv / bc2) + eps;
+        p[i] = f2bf(pf - lr * (mm / bc1) / denom);
+    }
+}
+
+// out[c][r] = in[r][c]  (bf16), 64x64 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const unsigned short *in, unsigned short *out, int R, int Cc)
+{
+    __shared__ unsigned short tile[64][66];
+    const int tiles_c = (Cc + 63) / 64, tiles_r = (R + 63) / 64;
+    for (int t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {
+        const int tr = t / tiles_c, tc = t % tiles_c;
+        for (int k = threadIdx.x; k < 64 * 64; k += 256) {
+            const int r = k / 64, c = k % 64;
+            const int gr = tr * 64 + r, gc = tc * 64 + c;
+            tile[r][c] = (gr < R && gc < Cc) ? in[(size_t)gr * Cc + gc] : 0;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 64 * 64; k += 256) {
+            const int c = k / 64, r = k % 64;
+            const int gr = tr * 64 + r, gc = tc * 64 + c;
+            if (gr < R && gc < Cc) out[(size_t)gc * R + gr] = tile[r][c];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *in, unsigned short *out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = f2bf(in[i]);
+}
+
+// ---- attention softmax (scores materialised) -------------------------------------------------------
+// One wave per row i of one (batch, head): keys j <= i with mask[b, j] != 0.
+__global__ __launch_bounds__(256) void softmax_causal_fwd_kernel(unsigned short *scores, const float *mask, size_t rows_total,
+                                                                 int n_heads, int S, float scale)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t row = wave; row < rows_total; row += n_waves) {
+        const size_t bh = row / S;
+        const int i = (int)(row % S);
+        const float *mk = mask + (bh / n_heads) * S;
+        unsigned short *p = scores + row * S;
+        const int lim = i + 1;                       // keys 0..i
+        float m = -INFINITY;
+        for (int c = lane * 8; c < lim; c += 64 * 8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (c + j < lim && mk[c + j] != 0.f) m = fmaxf(m, bf2f(v[j]) * scale);
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int c = lane * 8; c < lim; c += 64 * 8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (c + j < lim && mk[c + j] != 0.f) sum += __expf(bf2f(v[j]) * scale - m);
+        }
+        sum = wave_sum(sum);
+        const float inv = sum > 0.f ? 1.f / sum : 0.f;
+        for (int c = lane * 8; c < S; c += 64 * 8) {
+            bf16x8 v = *reinterpret_cast<const bf16x8 *>(p + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool vis = (c + j < lim) && mk[c + j] != 0.f;
+                v[j] = vis ? f2bf(__expf(bf2f(v[j]) * scale - m) * inv) : (unsigned short)0;
+            }
+            *reinterpret_cast<bf16x8 *>(p + c) = v;
+        }
+    }
+}
+
+// dS = scale * P * (dP - sum_j P*dP), in place on dp.  One wave per row.
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const unsigned short *P, unsigned short *dP, size_t rows_total, int S,
+                                                          float scale)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t row = wave; row < rows_total; row += n_waves) {
+        const int i = (int)(row % S);
+        const int lim8 = ((i + 1) + 7) & ~7;         // P is zero beyond key i
+        const unsigned short *p = P + row * S;
+        unsigned short *d = dP + row * S;
+        float dot = 0.f;
+        for (int c = lane * 8; c < lim8; c += 64 * 8) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(p + c), g = *reinterpret_cast<const bf16x8 *>(d + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += bf2f(a[j]) * bf2f(g[j]);
+        }
+        dot = wave_sum(dot);
+        for (int c = lane * 8; c < S; c += 64 * 8) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(p + c);
+            bf16x8 g = *reinterpret_cast<const bf16x8 *>(d + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = f2bf(scale * bf2f(a[j]) * (bf2f(g[j]) - dot));
+            *reinterpret_cast<bf16x8 *>(d + c) = g;
+        }
+    }
+}
+
+}  // namespace
+
+#define ECGB_CHECK_LAUNCH(name) return ok_or(hipGetLastError(), name)
+
+extern "C" int ecgb_embed_fwd(const int64_t *ids_dev, const void *table_dev, void *out_dev, size_t tokens, int hidden,
+                              float scale, void *stream)
+{
+    if (hidden % 8) { ecgb::set_error("ecgb_embed_fwd: hidden must be a multiple of 8"); return ECGB_ERR_INVALID; }
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for(tokens * (hidden / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long *)ids_dev, (const unsigned short *)table_dev, (unsigned short *)out_dev, tokens, hidden, scale);
+    ECGB_CHECK_LAUNCH("embed_fwd");
+}
+
+extern "C" int ecgb_embed_bwd(const int64_t *ids_dev, const void *dout_dev, float *grad_table_dev, size_t tokens, int hidden,
+                              float scale, void *stream)
+{
+    if (hidden % 8) { ecgb::set_error("ecgb_embed_bwd: hidden must be a multiple of 8"); return ECGB_ERR_INVALID; }
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(tokens * (hidden / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long *)ids_dev, (const unsigned short *)dout_dev, grad_table_dev, tokens, hidden, scale);
+    ECGB_CHECK_LAUNCH("embed_bwd");
+}
+
+extern "C" int ecgb_rmsnorm_fwd(const void *x_dev, const void *residual_dev, const void *w_dev, void *y_dev, void *sum_out_dev,
+                                float *rstd_dev, size_t rows, int hidden, float eps, int gemma, void *stream)
+{
+    if (hidden % 8 || (residual_dev && !sum_out_dev)) { ecgb::set_error("ecgb_rmsnorm_fwd: bad arguments"); return ECGB_ERR_INVALID; }
+    const dim3 grid(grid_for(rows, 4));
+    if (gemma)
+        hipLaunchKernelGGL(rmsnorm_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x_dev,
+                           (const unsigned short *)residual_dev, (const unsigned short *)w_dev, (unsigned short *)y_dev,
+                           (unsigned short *)sum_out_dev, rstd_dev, rows, hidden, eps);
+    else
+        hipLaunchKernelGGL(rmsnorm_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x_dev,
+                           (const unsigned short *)residual_dev, (const unsigned short *)w_dev, (unsigned short *)y_dev,
+                           (unsigned short *)sum_out_dev, rstd_dev, rows, hidden, eps);
+    ECGB_CHECK_LAUNCH("rmsnorm_fwd");
+}
+
+extern "C" int ecgb_rmsnorm_bwd(const void *x_dev, const void *w_dev, const float *rstd_dev, const void *dy_dev,
+                                const void *dres_dev, void *dx_dev, float *dw_dev, size_t rows, int hidden, int gemma, void *stream)
+{
+    if (hidden % 8) { ecgb::set_error("ecgb_rmsnorm_bwd: hidden must be a multiple of 8"); return ECGB_ERR_INVALID; }
+    const dim3 grid((unsigned)std::min<size_t>(std::max<size_t>(1, rows / 4), 1024));
+    const size_t lds = (size_t)hidden * 4;
+    if (gemma)
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short *)x_dev,
+                           (const unsigned short *)w_dev, rstd_dev, (const unsigned short *)dy_dev, (const unsigned short *)dres_dev,
+                           (unsigned short *)dx_dev, dw_dev, rows, hidden);
+    else
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short *)x_dev,
+                           (const unsigned short *)w_dev, rstd_dev, (const unsigned short *)dy_dev, (const unsigned short *)dres_dev,
+                           (unsigned short *)dx_dev, dw_dev, rows, hidden);
+    ECGB_CHECK_LAUNCH("rmsnorm_bwd");
+}
+
+extern "C" int ecgb_rope(void *x_dev, const float *cos_dev, const float *sin_dev, size_t tokens, int n_heads, int head_dim,
+                         size_t row_stride, int inverse, void *stream)
+{
+    if (head_dim % 16) { ecgb::set_error("ecgb_rope: head_dim must be a multiple of 16"); return ECGB_ERR_INVALID; }
+    const dim3 grid(grid_for(tokens * n_heads * (head_dim / 16), 256));
+    if (inverse)
+        hipLaunchKernelGGL(rope_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (unsigned short *)x_dev, cos_dev, sin_dev,
+                           tokens, n_heads, head_dim, row_stride);
+    else
+        hipLaunchKernelGGL(rope_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (unsigned short *)x_dev, cos_dev, sin_dev,
+                           tokens, n_heads, head_dim, row_stride);
+    ECGB_CHECK_LAUNCH("rope");
+}
+
+extern "C" int ecgb_glu_fwd(const void *gate_up_dev, void *h_dev, size_t tokens, int inter, int gelu_tanh, void *stream)
+{
+    if (inter % 8) { ecgb::set_error("ecgb_glu_fwd: intermediate size must be a multiple of 8"); return ECGB_ERR_INVALID; }
+    const dim3 grid(grid_for(tokens * (inter / 8), 256));
+    if (gelu_tanh) hipLaunchKernelGGL(glu_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)gate_up_dev, (unsigned short *)h_dev, tokens, inter);
+    else hipLaunchKernelGGL(glu_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)gate_up_dev, (unsigned short *)h_dev, tokens, inter);
+    ECGB_CHECK_LAUNCH("glu_fwd");
+}
+
+extern "C" int ecgb_glu_bwd(const void *gate_up_dev, const void *dh_dev, void *dgate_up_dev, size_t tokens, int inter,
+                            int gelu_tanh, void *stream)
+{
+    if (inter % 8) { ecgb::set_error("ecgb_glu_bwd: intermediate size must be a multiple of 8"); return ECGB_ERR_INVALID; }
+    const dim3 grid(grid_for(tokens * (inter / 8), 256));
+    if (gelu_tanh) hipLaunchKernelGGL(glu_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)gate_up_dev, (const unsigned short *)dh_dev, (unsigned short *)dgate_up_dev, tokens, inter);
+    else hipLaunchKernelGGL(glu_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)gate_up_dev, (const unsigned short *)dh_dev, (unsigned short *)dgate_up_dev, tokens, inter);
+    ECGB_CHECK_LAUNCH("glu_bwd");
+}
+
+extern "C" int ecgb_add_bf16(const void *a_dev, const void *b_dev, void *out_dev, size_t n, void *stream)
+{
+    if (n % 8) { ecgb::set_error("ecgb_add_bf16: n must be a multiple of 8"); return ECGB_ERR_INVALID; }
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)a_dev,
+                       (const unsigned short *)b_dev, (unsigned short *)out_dev, n / 8);
+    ECGB_CHECK_LAUNCH("add_bf16");
+}
+
+extern "C" int ecgb_count_labels(const int64_t *labels_dev, size_t n, int vocab, float *inv_count_dev, void *stream)
+{
+    hipLaunchKernelGGL(count_labels_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const long long *)labels_dev, n, vocab, inv_count_dev);
+    ECGB_CHECK_LAUNCH("count_labels");
+}
+
+extern "C" int ecgb_ce_fwd_bwd(void *logits_dev, const int64_t *labels_dev, float *row_loss_dev, float *sum_loss_dev,
+                               const float *inv_count_dev, size_t rows, int vocab, size_t ld, void *stream)
+{
+    if (ld % 8) { ecgb::set_error("ecgb_ce_fwd_bwd: leading dimension must be a multiple of 8"); return ECGB_ERR_INVALID; }
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3((unsigned)std::min<size_t>(std::max<size_t>(rows, 1), 4096)), dim3(256), 0,
+                       (hipStream_t)stream, (unsigned short *)logits_dev, (const long long *)labels_dev, row_loss_dev, sum_loss_dev,
+                       inv_count_dev, rows, vocab, ld);
+    ECGB_CHECK_LAUNCH("ce_fwd_bwd");
+}
+
+extern "C" int ecgb_sumsq(const void *g_dev, size_t n, int is_fp32, float *acc_dev, void *stream)
+{
+    const dim3 grid(grid_for(n, 256 * 8));
+    if (is_fp32) hipLaunchKernelGGL(sumsq_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)g_dev, n, acc_dev);
+    else hipLaunchKernelGGL(sumsq_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)g_dev, n, acc_dev);
+    ECGB_CHECK_LAUNCH("sumsq");
+}
+
+extern "C" int ecgb_adam_step(void *param_dev, const void *grad_dev, int grad_is_fp32, float *m_dev, float *v_dev, size_t n,
+                              const float *sumsq_dev, float max_norm, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int step, void *stream)
+{
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    const dim3 grid(grid_for(n, 256 * 4));
+    if (grad_is_fp32)
+        hipLaunchKernelGGL(adam_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (unsigned short *)param_dev, (const float *)grad_dev,
+                           m_dev, v_dev, n, sumsq_dev, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+    else
+        hipLaunchKernelGGL(adam_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (unsigned short *)param_dev,
+                           (const unsigned short *)grad_dev, m_dev, v_dev, n, sumsq_dev, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+    ECGB_CHECK_LAUNCH("adam_step");
+}
+
+extern "C" int ecgb_transpose_bf16(const void *in_dev, void *out_dev, int rows, int cols, void *stream)
+{
+    const size_t tiles = (size_t)((rows + 63) / 64) * ((cols + 63) / 64);
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)std::min<size_t>(std::max<size_t>(tiles, 1), 256 * 16)), dim3(256), 0,
+                       (hipStream_t)stream, (const unsigned short *)in_dev, (unsigned short *)out_dev, rows, cols);
+    ECGB_CHECK_LAUNCH("transpose_bf16");
+}
+
+extern "C" int ecgb_f32_to_bf16(const float *in_dev, void *out_dev, size_t n, void *stream)
+{
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, in_dev, (unsigned short *)out_dev, n);
+    ECGB_CHECK_LAUNCH("f32_to_bf16");
+}
+
+extern "C" int ecgb_softmax_causal_fwd(void *scores_dev, const float *attn_mask_dev, int batch_heads, int n_heads, int seq,
+                                       float scale, void *stream)
+{
+    if (seq % 8) { ecgb::set_error("ecgb_softmax_causal_fwd: seq must be a multiple of 8"); return ECGB_ERR_INVALID; }
+    const size_t rows = (size_t)batch_heads * seq;
+    hipLaunchKernelGGL(softmax_causal_fwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (unsigned short *)scores_dev, attn_mask_dev, rows, n_heads, seq, scale);
+    ECGB_CHECK_LAUNCH("softmax_causal_fwd");
+}
+
+extern "C" int ecgb_softmax_bwd(const void *p_dev, void *dp_dev, int batch_heads, int seq, float scale, void *stream)
+{
+    if (seq % 8) { ecgb::set_error("ecgb_softmax_bwd: seq must be a multiple of 8"); return ECGB_ERR_INVALID; }
+    const size_t rows = (size_t)batch_heads * seq;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short *)p_dev, (unsigned short *)dp_dev, rows, seq, scale);
+    ECGB_CHECK_LAUNCH("softmax_bwd");
+}

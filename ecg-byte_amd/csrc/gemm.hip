@@ -1,0 +1,224 @@
+// gemm.hip -- bf16 GEMM on the CDNA4 matrix cores (gfx950), the projections of the decoder.
+//
+//   C[M,N] = A[M,K] . B[N,K]^T          (both operands K-contiguous: y = x W^T with W = [out, in],
+//                                        the layout of every nn.Linear in modeling_llama.py:227-258,273-395)
+// fp32 accumulation in `v_mfma_f32_32x32x16_bf16`, bf16 (or fp32-accumulate) output.
+// The two backward products are the same kernel on transposed operands (ecgb_transpose_bf16):
+//   dX = dY . W      = NT(dY [M,N], W^T [K,N])        dW = dY^T . X = NT(dY^T [N,M], X^T [K,M]).
+//
+// Structure: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 each = 2x2 MFMA
+// tiles of 32x32), K-step 64.  Operand tiles go global -> LDS with `global_load_lds_dwordx4`
+// (no VGPR round trip), double buffered, the next K-tile in flight behind a counted vmcnt and raw
+// s_barrier while the current one feeds the MFMAs.  LDS rows are 128 B (64 bf16); the 16-byte
+// slot index is XOR-swizzled with the row ((row >> 1) & 7) on the SOURCE address side (the LDS
+// side of an LDS-DMA is lane-linear), so the 32 rows a ds_read_b128 wave-instruction touches
+// land on different banks.  Workgroups are remapped so that consecutive tiles of one C row-block
+// share an XCD's L2.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "tokenizer.hpp"
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kTileBytes = BM * BK * 2;           // 16 KiB per operand tile
+
+struct GemmArgs {
+    const unsigned short *A;    // [M, K], row stride lda
+    const unsigned short *B;    // [N, K], row stride ldb
+    void *C;                    // [M, N], row stride ldc (bf16, or fp32 when accumulate)
+    int M, N, K;
+    long long lda, ldb, ldc;
+    long long batch_a, batch_b, batch_c;   // element strides between batch entries (blockIdx.z)
+    // two-level batch addressing (attention heads): z = zo * inner + zi
+    int inner;                              // 0 = plain batch strides above
+    long long outer_a, inner_a, outer_b, inner_b, outer_c, inner_c;
+    int div_a, div_b;
+    int tiles_m, tiles_n;
+    int accumulate_f32;         // C is fp32 and C += A.B^T
+    float alpha;
+};
+
+__device__ __forceinline__ unsigned short f2bf_rn(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// Issue the LDS-DMA loads of one 128x64 operand tile: 16 wave-instructions of 1 KiB (8 rows), 4 per wave.
+// LDS image: row r at r*128 B, slot s (16 B) holds logical chunk s ^ ((r >> 1) & 7).
+__device__ __forceinline__ void stage_tile(const unsigned short *g, long long ld, int row0, int rows_valid, int k0,
+                                           unsigned char *lds_tile, int wave, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int inst = wave * 4 + i;                 // 0..15
+        const int r = inst * 8 + (lane >> 3);          // row inside the tile
+        const int slot = lane & 7;
+        const int chunk = slot ^ ((r >> 1) & 7);
+        int gr = row0 + r;
+        gr = gr < rows_valid ? gr : rows_valid - 1;    // clamp: out-of-range rows are never stored
+        const unsigned short *src = g + (long long)gr * ld + k0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(lds_tile + inst * 1024), 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs G)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * kTileBytes];   // [buf][A|B]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // XCD-aware remap: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of tiles
+    const int nwg = G.tiles_m * G.tiles_n;
+    const int orig = blockIdx.x;
+    const int q = nwg / 8, rr = nwg % 8, xcd = orig % 8;
+    const int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
+    const int tm = wgid / G.tiles_n, tn = wgid % G.tiles_n;
+    const int row0 = tm * BM, col0 = tn * BN;
+    long long off_a, off_b, off_c;
+    if (G.inner) {
+        const int zo = blockIdx.z / G.inner, zi = blockIdx.z % G.inner;
+        off_a = zo * G.outer_a + (zi / G.div_a) * G.inner_a;
+        off_b = zo * G.outer_b + (zi / G.div_b) * G.inner_b;
+        off_c = zo * G.outer_c + zi * G.inner_c;
+    } else {
+        off_a = (long long)blockIdx.z * G.batch_a;
+        off_b = (long long)blockIdx.z * G.batch_b;
+        off_c = (long long)blockIdx.z * G.batch_c;
+    }
+    const unsigned short *A = G.A + off_a;
+    const unsigned short *B = G.B + off_b;
+
+    const int wr = wave >> 1, wc = wave & 1;           // wave position in the 2x2 grid
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int KT = G.K / BK;
+    stage_tile(A, G.lda, row0, G.M, 0, lds, wave, lane);
+    stage_tile(B, G.ldb, col0, G.N, 0, lds + kTileBytes, wave, lane);
+    const int lr = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < KT; ++kt) {
+        unsigned char *cur = lds + (kt & 1) * 2 * kTileBytes;
+        if (kt + 1 < KT) {
+            unsigned char *nxt = lds + ((kt + 1) & 1) * 2 * kTileBytes;
+            stage_tile(A, G.lda, row0, G.M, (kt + 1) * BK, nxt, wave, lane);
+            stage_tile(B, G.ldb, col0, G.N, (kt + 1) * BK, nxt + kTileBytes, wave, lane);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // this wave's 8 loads of tile kt have landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                            // ... and every other wave's
+        const unsigned char *At = cur, *Bt = cur + kTileBytes;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 a[2], b[2];
+            const int chunk = ks * 2 + lh;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra = wr * 64 + i * 32 + lr;
+                a[i] = *reinterpret_cast<const bf16x8 *>(At + ra * 128 + ((chunk ^ ((ra >> 1) & 7)) << 4));
+                const int rb = wc * 64 + i * 32 + lr;
+                b[i] = *reinterpret_cast<const bf16x8 *>(Bt + rb * 128 + ((chunk ^ ((rb >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                            // everyone done reading `cur` before it is restaged
+    }
+
+    // epilogue: acc[i][j][reg] is C[row0 + wr*64 + i*32 + (reg&3) + 8*(reg>>2) + 4*lh][col0 + wc*64 + j*32 + lr]
+    const float alpha = G.alpha;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = col0 + wc * 64 + j * 32 + lr;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = row0 + wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                if (r < G.M && c < G.N) {
+                    const float v = acc[i][j][reg] * alpha;
+                    if (G.accumulate_f32) {
+                        float *Cf = reinterpret_cast<float *>(G.C) + off_c;
+                        Cf[(long long)r * G.ldc + c] += v;
+                    } else {
+                        unsigned short *Cb = reinterpret_cast<unsigned short *>(G.C) + off_c;
+                        Cb[(long long)r * G.ldc + c] = f2bf_rn(v);
+                    }
+                }
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
+                                 int M, int N, int K, float alpha, int accumulate_f32, int batch, long long batch_a,
+                                 long long batch_b, long long batch_c, void *stream)
+{
+    if (!a_dev || !b_dev || !c_dev || M <= 0 || N <= 0 || K <= 0 || batch <= 0) {
+        ecgb::set_error("ecgb_gemm_nt_bf16: bad argument");
+        return ECGB_ERR_INVALID;
+    }
+    if (K % BK || lda % 8 || ldb % 8 || ((uintptr_t)a_dev & 15) || ((uintptr_t)b_dev & 15)) {
+        ecgb::set_error("ecgb_gemm_nt_bf16: K must be a multiple of 64 and operands 16-byte aligned with strides % 8 == 0");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    GemmArgs G;
+    G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = c_dev;
+    G.M = M; G.N = N; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = ldc;
+    G.batch_a = batch_a; G.batch_b = batch_b; G.batch_c = batch_c;
+    G.tiles_m = (M + BM - 1) / BM; G.tiles_n = (N + BN - 1) / BN;
+    G.accumulate_f32 = accumulate_f32; G.alpha = alpha;
+    G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, G);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
+}
+
+extern "C" int ecgb_gemm_nt_bf16_heads(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev,
+                                       long long ldc, int M, int N, int K, float alpha, int batch, int inner,
+                                       long long outer_a, long long inner_a, int div_a, long long outer_b,
+                                       long long inner_b, int div_b, long long outer_c, long long inner_c, void *stream)
+{
+    if (!a_dev || !b_dev || !c_dev || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || inner <= 0 || div_a <= 0 || div_b <= 0) {
+        ecgb::set_error("ecgb_gemm_nt_bf16_heads: bad argument");
+        return ECGB_ERR_INVALID;
+    }
+    if (K % BK || lda % 8 || ldb % 8 || ((uintptr_t)a_dev & 15) || ((uintptr_t)b_dev & 15) || outer_a % 8 || inner_a % 8 ||
+        outer_b % 8 || inner_b % 8) {
+        ecgb::set_error("ecgb_gemm_nt_bf16_heads: K must be a multiple of 64 and every operand offset 16-byte aligned");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    GemmArgs G;
+    G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = c_dev;
+    G.M = M; G.N = N; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = ldc;
+    G.batch_a = G.batch_b = G.batch_c = 0;
+    G.tiles_m = (M + BM - 1) / BM; G.tiles_n = (N + BN - 1) / BN;
+    G.accumulate_f32 = 0; G.alpha = alpha;
+    G.inner = inner; G.outer_a = outer_a; G.inner_a = inner_a; G.div_a = div_a;
+    G.outer_b = outer_b; G.inner_b = inner_b; G.div_b = div_b; G.outer_c = outer_c; G.inner_c = inner_c;
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, G);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
+}

@@ -1,0 +1,142 @@
+"""Thin wrappers over the decoder C ABI (include/ecgbyte_decoder.h): torch tensors in, torch
+tensors out, all compute in libecgbyte_hip.so.  bf16 everywhere unless noted."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _L():
+    return _lib.lib()
+
+
+def _bf(t):
+    assert t.dtype == torch.bfloat16 and t.is_cuda and t.is_contiguous(), "expects contiguous CUDA bf16"
+    return t
+
+
+def embed_fwd(ids, table, scale=1.0):
+    out = torch.empty(ids.shape + (table.shape[1],), dtype=torch.bfloat16, device=table.device)
+    _lib.check(_L().ecgb_embed_fwd(_p(ids.contiguous()), _p(_bf(table)), _p(out), ids.numel(), table.shape[1], float(scale), _st()))
+    return out
+
+
+def embed_bwd(ids, dout, grad_table_f32, scale=1.0):
+    _lib.check(_L().ecgb_embed_bwd(_p(ids.contiguous()), _p(_bf(dout)), _p(grad_table_f32), ids.numel(), dout.shape[-1], float(scale), _st()))
+
+
+def rmsnorm_fwd(x, w, eps, residual=None, gemma=False):
+    """Returns (y, rstd, x_sum): x_sum = x + residual when residual is given (else x itself)."""
+    H = x.shape[-1]
+    rows = x.numel() // H
+    y = torch.empty_like(x)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    s = torch.empty_like(x) if residual is not None else None
+    _lib.check(_L().ecgb_rmsnorm_fwd(_p(_bf(x)), _p(residual), _p(_bf(w)), _p(y), _p(s), _p(rstd), rows, H, float(eps), int(gemma), _st()))
+    return y, rstd, (s if residual is not None else x)
+
+
+def rmsnorm_bwd(x, w, rstd, dy, dw_f32, dres=None, gemma=False):
+    H = x.shape[-1]
+    dx = torch.empty_like(x)
+    _lib.check(_L().ecgb_rmsnorm_bwd(_p(_bf(x)), _p(_bf(w)), _p(rstd), _p(_bf(dy)), _p(dres), _p(dx), _p(dw_f32), x.numel() // H, H, int(gemma), _st()))
+    return dx
+
+
+def rope_(x, cos, sin, n_heads, head_dim, row_stride, inverse=False):
+    """In place on a [tokens, ...] view whose heads start at x.data_ptr(): x may be a slice of a fused qkv buffer."""
+    tokens = cos.shape[0]
+    _lib.check(_L().ecgb_rope(_p(x), _p(cos), _p(sin), tokens, n_heads, head_dim, row_stride, int(inverse), _st()))
+    return x
+
+
+def glu_fwd(gate_up, gelu_tanh=False):
+    inter = gate_up.shape[-1] // 2
+    h = torch.empty(gate_up.shape[:-1] + (inter,), dtype=torch.bfloat16, device=gate_up.device)
+    _lib.check(_L().ecgb_glu_fwd(_p(_bf(gate_up)), _p(h), gate_up.numel() // (2 * inter), inter, int(gelu_tanh), _st()))
+    return h
+
+
+def glu_bwd(gate_up, dh, gelu_tanh=False):
+    inter = gate_up.shape[-1] // 2
+    d = torch.empty_like(gate_up)
+    _lib.check(_L().ecgb_glu_bwd(_p(_bf(gate_up)), _p(_bf(dh)), _p(d), gate_up.numel() // (2 * inter), inter, int(gelu_tanh), _st()))
+    return d
+
+
+def add(a, b):
+    o = torch.empty_like(a)
+    _lib.check(_L().ecgb_add_bf16(_p(_bf(a)), _p(_bf(b)), _p(o), a.numel(), _st()))
+    return o
+
+
+def transpose(x2d):
+    R, Cc = x2d.shape
+    o = torch.empty((Cc, R), dtype=torch.bfloat16, device=x2d.device)
+    _lib.check(_L().ecgb_transpose_bf16(_p(_bf(x2d)), _p(o), R, Cc, _st()))
+    return o
+
+
+def gemm_nt(a, b, out=None, alpha=1.0, accumulate_f32=False):
+    """C[M,N] = alpha * A[M,K] @ B[N,K]^T.  a, b: 2-D bf16 (row stride = shape[1] or a column slice view)."""
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if accumulate_f32 else torch.bfloat16, device=a.device)
+    _lib.check(_L().ecgb_gemm_nt_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, float(alpha),
+                                      int(accumulate_f32), 1, 0, 0, 0, _st()))
+    return out
+
+
+def gemm_nt_heads(a, lda, b, ldb, c, ldc, M, N, K, alpha, batch, inner, outer_a, inner_a, div_a, outer_b, inner_b, div_b,
+                  outer_c, inner_c):
+    _lib.check(_L().ecgb_gemm_nt_bf16_heads(_p(a), lda, _p(b), ldb, _p(c), ldc, M, N, K, float(alpha), batch, inner,
+                                            outer_a, inner_a, div_a, outer_b, inner_b, div_b, outer_c, inner_c, _st()))
+
+
+def softmax_causal_fwd_(scores, attn_mask, n_heads, scale):
+    BH, S, _ = scores.shape
+    _lib.check(_L().ecgb_softmax_causal_fwd(_p(_bf(scores)), _p(attn_mask), BH, n_heads, S, float(scale), _st()))
+    return scores
+
+
+def softmax_bwd_(p, dp, scale):
+    BH, S, _ = p.shape
+    _lib.check(_L().ecgb_softmax_bwd(_p(_bf(p)), _p(_bf(dp)), BH, S, float(scale), _st()))
+    return dp
+
+
+def count_labels(labels, vocab):
+    inv = torch.empty(1, dtype=torch.float32, device=labels.device)
+    _lib.check(_L().ecgb_count_labels(_p(labels), labels.numel(), vocab, _p(inv), _st()))
+    return inv
+
+
+def ce_fwd_bwd_(logits, labels, inv_count, sum_loss, vocab):
+    """logits [rows, ld] bf16 overwritten with dlogits; returns per-row losses (fp32)."""
+    rows, ld = logits.shape
+    row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    _lib.check(_L().ecgb_ce_fwd_bwd(_p(_bf(logits)), _p(labels), _p(row_loss), _p(sum_loss), _p(inv_count), rows, vocab, ld, _st()))
+    return row_loss
+
+
+def sumsq(g, acc):
+    _lib.check(_L().ecgb_sumsq(_p(g), g.numel(), int(g.dtype == torch.float32), _p(acc), _st()))
+
+
+def adam_step_(p, g, m, v, sumsq_acc, max_norm, lr, beta1, beta2, eps, weight_decay, step):
+    _lib.check(_L().ecgb_adam_step(_p(p), _p(g), int(g.dtype == torch.float32), _p(m), _p(v), p.numel(), _p(sumsq_acc),
+                                   float(max_norm), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                   int(step), _st()))

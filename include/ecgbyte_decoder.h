@@ -1,0 +1,98 @@
+/*
+ * ecgbyte_decoder.h -- C ABI of the causal-LM step kernels in libecgbyte_hip.so (MI355X, gfx950).
+ *
+ * The reference runs this part of the hot path through HuggingFace transformers on ATen kernels
+ * (vendored transformers 4.46.0.dev0; no hand-written CUDA of its own on this path).  Each entry
+ * point below replaces the ATen calls behind one module; paths relative to the reference root:
+ *   ecgb_embed_fwd/bwd     nn.Embedding in LlamaModel.forward, transformers/src/transformers/models/llama/modeling_llama.py:889
+ *   ecgb_rmsnorm_fwd/bwd   LlamaRMSNorm.forward, modeling_llama.py:67-72 (gemma=1: GemmaRMSNorm, models/gemma/modeling_gemma.py:51-68)
+ *   ecgb_rope              apply_rotary_pos_emb / rotate_half, modeling_llama.py:193-224
+ *   ecgb_gemm_nt_bf16      every nn.Linear of the block (q/k/v/o_proj, gate/up/down_proj, lm_head), modeling_llama.py:227-395,1209
+ *   ecgb_softmax_causal_fwd/bwd   the softmax of LlamaSdpaAttention.forward incl. the causal + left-padding mask,
+ *                          modeling_llama.py:526-614,981-1100 (QK^T and PV are ecgb_gemm_nt_bf16 batches)
+ *   ecgb_glu_fwd/bwd       LlamaMLP act_fn(gate) * up, modeling_llama.py:238-258 (gelu_tanh=1: GemmaMLP)
+ *   ecgb_ce_fwd_bwd        ForCausalLMLoss, transformers/src/transformers/loss/loss_utils.py:24-47
+ *   ecgb_sumsq, ecgb_adam_step   clip_grad_norm_(1.0) + Adam(weight_decay = L2), ecg_byte/runners/train.py:26, ecg_byte/main.py:262-264
+ * All tensors are device pointers; bf16 = IEEE bfloat16 bit patterns; `stream` as in ecgbyte.h.
+ * Same status codes as ecgbyte.h.
+ */
+#ifndef ECGBYTE_DECODER_H
+#define ECGBYTE_DECODER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* out[t,:] = table[ids[t],:] * scale (bf16);  grad_table(fp32)[ids[t],:] += dout[t,:] * scale */
+int ecgb_embed_fwd(const int64_t *ids_dev, const void *table_dev, void *out_dev, size_t tokens, int hidden,
+                   float scale, void *stream);
+int ecgb_embed_bwd(const int64_t *ids_dev, const void *dout_dev, float *grad_table_dev, size_t tokens, int hidden,
+                   float scale, void *stream);
+
+/* y = w * bf16(x * rsqrt(mean(x^2)+eps)).  If residual_dev != NULL: x := x + residual first, written to
+ * sum_out_dev.  rstd_dev (fp32 per row) is saved for the backward. */
+int ecgb_rmsnorm_fwd(const void *x_dev, const void *residual_dev, const void *w_dev, void *y_dev, void *sum_out_dev,
+                     float *rstd_dev, size_t rows, int hidden, float eps, int gemma, void *stream);
+/* dx = rstd * (dy*w - xhat * mean(dy*w*xhat)) [+ dres];  dw_dev (fp32) += sum over rows of dy * xhat */
+int ecgb_rmsnorm_bwd(const void *x_dev, const void *w_dev, const float *rstd_dev, const void *dy_dev,
+                     const void *dres_dev, void *dx_dev, float *dw_dev, size_t rows, int hidden, int gemma, void *stream);
+
+/* In-place rotary embedding of x [tokens, n_heads, head_dim] (row stride in elements), half-split
+ * layout; cos/sin fp32 [tokens, head_dim/2].  inverse=1 applies the transpose rotation (backward). */
+int ecgb_rope(void *x_dev, const float *cos_dev, const float *sin_dev, size_t tokens, int n_heads, int head_dim,
+              size_t row_stride, int inverse, void *stream);
+
+/* h = act(gate) * up with gate|up stored side by side: gate_up [tokens, 2*inter], h [tokens, inter] */
+int ecgb_glu_fwd(const void *gate_up_dev, void *h_dev, size_t tokens, int inter, int gelu_tanh, void *stream);
+int ecgb_glu_bwd(const void *gate_up_dev, const void *dh_dev, void *dgate_up_dev, size_t tokens, int inter,
+                 int gelu_tanh, void *stream);
+
+int ecgb_add_bf16(const void *a_dev, const void *b_dev, void *out_dev, size_t n, void *stream);
+int ecgb_transpose_bf16(const void *in_dev, void *out_dev, int rows, int cols, void *stream);
+int ecgb_f32_to_bf16(const float *in_dev, void *out_dev, size_t n, void *stream);
+
+/* C[M,N] = alpha * A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulation on the matrix cores.
+ * accumulate_f32 = 0: C is bf16; 1: C is fp32 and C += result.  batch > 1: blockIdx.z strides. */
+int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
+                      int M, int N, int K, float alpha, int accumulate_f32, int batch, long long batch_a,
+                      long long batch_b, long long batch_c, void *stream);
+/* Same, with two-level batch addressing for attention heads: batch entry z = (zo, zi), zo = z / inner,
+ * zi = z % inner; operand X starts at X + zo*outer_x + (zi / div_x)*inner_x  (div_b > 1 shares one KV head
+ * among div_b query heads). */
+int ecgb_gemm_nt_bf16_heads(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
+                            int M, int N, int K, float alpha, int batch, int inner, long long outer_a, long long inner_a,
+                            int div_a, long long outer_b, long long inner_b, int div_b, long long outer_c,
+                            long long inner_c, void *stream);
+
+/* inv_count = 1 / max(#labels in [0, vocab), 1) */
+int ecgb_count_labels(const int64_t *labels_dev, size_t n, int vocab, float *inv_count_dev, void *stream);
+/* Cross-entropy of `rows` rows of logits [rows, ld] (first `vocab` columns valid) against labels (-100 =
+ * ignored); sum_loss_dev += sum(row losses) * inv_count; logits are overwritten with d(loss)/d(logits). */
+int ecgb_ce_fwd_bwd(void *logits_dev, const int64_t *labels_dev, float *row_loss_dev, float *sum_loss_dev,
+                    const float *inv_count_dev, size_t rows, int vocab, size_t ld, void *stream);
+
+/* acc_dev += sum(g^2) */
+int ecgb_sumsq(const void *g_dev, size_t n, int is_fp32, float *acc_dev, void *stream);
+/* One Adam step (moments fp32, params bf16) with the gradient first scaled by min(1, max_norm/(sqrt(*sumsq)+1e-6))
+ * and weight decay applied as L2 (grad += wd * param), as torch.optim.Adam does. */
+int ecgb_adam_step(void *param_dev, const void *grad_dev, int grad_is_fp32, float *m_dev, float *v_dev, size_t n,
+                   const float *sumsq_dev, float max_norm, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, void *stream);
+
+/* Attention probabilities, round 1: scores are materialised ([batch*heads, S, S] bf16) by batched
+ * ecgb_gemm_nt_bf16 calls and normalised here (a fused flash-style kernel is the next step).
+ * In place: P[bh,i,j] = softmax_j(scale * scores[bh,i,j]) over the keys j <= i with attn_mask[b,j] != 0
+ * (b = bh / n_heads; attn_mask float32 [batch, S]); fp32 softmax, bf16 result; rows with no visible key
+ * become all zeros (pad rows: the reference's outputs there are don't-care, modeling_llama.py:1032-1042). */
+int ecgb_softmax_causal_fwd(void *scores_dev, const float *attn_mask_dev, int batch_heads, int n_heads, int seq,
+                            float scale, void *stream);
+/* In place on dp_dev: dS = scale * P * (dP - rowsum(P * dP)). */
+int ecgb_softmax_bwd(const void *p_dev, void *dp_dev, int batch_heads, int seq, float scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECGBYTE_DECODER_H */

@@ -1,0 +1,185 @@
+"""GPU numerics tests of the decoder kernels against plain PyTorch fp32 references of the same op
+(bf16 inputs upcast).  Tolerances: outputs are bf16, so elementwise |err| <= 2^-7 * scale (one bf16
+ulp of the result magnitude) unless noted; reductions accumulate in fp32."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from ecg_byte_amd import decoder_ops
+    return decoder_ops
+
+
+def _bf(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(*shape, device="cuda", generator=g) * scale).to(torch.bfloat16)
+
+
+def _close(got, ref, atol, rtol=2 ** -7):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item():.4g} (tol {tol[err.argmax()].item():.4g})"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 136, 128), (1024, 3072, 2048), (64, 512, 8192)])
+def test_gemm_nt(ops, M, N, K):
+    a, b = _bf(M, K, seed=1), _bf(N, K, seed=2)
+    ref = a.float() @ b.float().T
+    _close(ops.gemm_nt(a, b), ref, atol=1e-2 * math.sqrt(K) / 8)
+    # asymmetric identity check (catches transposed output maps)
+    eye = torch.eye(K, device="cuda", dtype=torch.bfloat16)[:M] if M <= K else None
+    if eye is not None:
+        _close(ops.gemm_nt(eye, b), b.float().T[:M], atol=1e-6)
+    # fp32 accumulate mode and alpha
+    acc = torch.ones((M, N), device="cuda")
+    ops.gemm_nt(a, b, out=acc, alpha=0.5, accumulate_f32=True)
+    assert torch.allclose(acc, 1 + 0.5 * ref, atol=2e-2 * math.sqrt(K) / 8, rtol=1e-3)
+    # strided operand views (column slices of a wider buffer)
+    wide = _bf(M, K + 64, seed=3)
+    _close(ops.gemm_nt(wide[:, 64:], b), wide[:, 64:].float() @ b.float().T, atol=1e-2 * math.sqrt(K) / 8)
+
+
+def test_transpose_and_backward_products(ops):
+    M, N, K = 384, 256, 192
+    x, w, dy = _bf(M, K, seed=4), _bf(N, K, seed=5), _bf(M, N, seed=6)
+    assert torch.equal(ops.transpose(x), x.T.contiguous())
+    _close(ops.gemm_nt(dy, ops.transpose(w)), dy.float() @ w.float(), atol=0.2)            # dX = dY W
+    _close(ops.gemm_nt(ops.transpose(dy), ops.transpose(x)), dy.float().T @ x.float(), atol=0.3)   # dW = dY^T X
+
+
+@pytest.mark.parametrize("gemma", [False, True])
+def test_rmsnorm(ops, gemma):
+    rows, H, eps = 300, 2048, 1e-5
+    x, r, w = _bf(rows, H, seed=7), _bf(rows, H, seed=8), _bf(H, scale=0.5, seed=9)
+    y, rstd, xs = ops.rmsnorm_fwd(x, w, eps, residual=r, gemma=gemma)
+    xsum = (x.float() + r.float()).to(torch.bfloat16)
+    assert torch.equal(xs, xsum)
+    xf = xsum.float()
+    rs = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    ref = (xf * rs * (1 + w.float())) if gemma else ((xf * rs).to(torch.bfloat16).float() * w.float())
+    _close(y, ref, atol=1e-3)
+    assert torch.allclose(rstd, rs.squeeze(-1), rtol=1e-5)
+    # backward vs autograd of the fp32 formula
+    dy, dres = _bf(rows, H, seed=10), _bf(rows, H, seed=11)
+    xa = xf.clone().requires_grad_(True)
+    wa = w.float().clone().requires_grad_(True)
+    ya = xa * torch.rsqrt(xa.pow(2).mean(-1, keepdim=True) + eps) * ((1 + wa) if gemma else wa)
+    ya.backward(dy.float())
+    dw = torch.zeros(H, device="cuda")
+    dx = ops.rmsnorm_bwd(xsum, w, rstd, dy, dw, dres=dres, gemma=gemma)
+    _close(dx, xa.grad + dres.float(), atol=2e-2)
+    assert torch.allclose(dw, wa.grad, atol=0.15, rtol=2e-2)
+
+
+def test_rope_forward_inverse(ops):
+    T, Hq, D = 257, 6, 64
+    x = _bf(T, Hq * D, seed=12)
+    pos = torch.arange(T, device="cuda").float()
+    inv = 1.0 / (500000.0 ** (torch.arange(0, D, 2, device="cuda").float() / D))
+    fr = pos[:, None] * inv[None]
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    y = x.clone()
+    ops.rope_(y, cos, sin, Hq, D, Hq * D)
+    xf = x.float().view(T, Hq, D)
+    c = cos.to(torch.bfloat16).float()[:, None, :]
+    s = sin.to(torch.bfloat16).float()[:, None, :]
+    x1, x2 = xf[..., : D // 2], xf[..., D // 2:]
+    ref = torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], -1).view(T, Hq * D)   # q*cos + rotate_half(q)*sin
+    _close(y, ref, atol=1e-3)
+    z = y.clone()
+    ops.rope_(z, cos, sin, Hq, D, Hq * D, inverse=True)                       # transpose rotation = backward
+    _close(z, x.float() * (c.repeat(1, Hq, 2).view(T, -1) ** 2 + s.repeat(1, Hq, 2).view(T, -1) ** 2), atol=3e-2)
+
+
+@pytest.mark.parametrize("gelu", [False, True])
+def test_glu(ops, gelu):
+    T, I = 130, 1024
+    gu, dh = _bf(T, 2 * I, seed=13), _bf(T, I, seed=14)
+    g = gu[:, :I].float().clone().requires_grad_(True)
+    u = gu[:, I:].float().clone().requires_grad_(True)
+    act = torch.nn.functional.gelu(g, approximate="tanh") if gelu else torch.nn.functional.silu(g)
+    h = act * u
+    h.backward(dh.float())
+    _close(ops.glu_fwd(gu, gelu_tanh=gelu), h.detach(), atol=2e-3, rtol=2 ** -6)
+    d = ops.glu_bwd(gu, dh, gelu_tanh=gelu)
+    _close(d[:, :I], g.grad, atol=2e-2)
+    _close(d[:, I:], u.grad, atol=2e-2)
+
+
+def test_embedding(ops):
+    V, H, T = 500, 256, 1000
+    table = _bf(V, H, seed=15)
+    ids = torch.randint(0, V, (T,), device="cuda")
+    assert torch.equal(ops.embed_fwd(ids, table), table[ids])
+    dout = _bf(T, H, seed=16)
+    g = torch.zeros(V, H, device="cuda")
+    ops.embed_bwd(ids, dout, g)
+    ref = torch.zeros(V, H, device="cuda").index_add_(0, ids, dout.float())
+    assert torch.allclose(g, ref, atol=1e-4, rtol=1e-5)
+
+
+def test_cross_entropy_forward_backward(ops):
+    rows, V, ld = 300, 1003, 1008
+    logits = _bf(rows, ld, scale=3.0, seed=17)
+    labels = torch.randint(0, V, (rows,), device="cuda")
+    labels[::7] = -100
+    lf = logits[:, :V].float().clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lf, labels, ignore_index=-100, reduction="mean")
+    ref.backward()
+    inv = ops.count_labels(labels, V)
+    assert abs(inv.item() - 1.0 / (labels >= 0).sum().item()) < 1e-9
+    total = torch.zeros(1, device="cuda")
+    work = logits.clone()
+    row_loss = ops.ce_fwd_bwd_(work, labels, inv, total, V)
+    assert abs(total.item() - ref.item()) < 1e-4 * max(1.0, abs(ref.item()))
+    assert bool((row_loss[::7] == 0).all())
+    _close(work[:, :V], lf.grad, atol=2e-5, rtol=2 ** -7)
+    assert bool((work[:, V:] == 0).all())
+
+
+def test_softmax_causal_mask_and_backward(ops):
+    B, Hh, S = 2, 3, 136
+    scores = _bf(B * Hh, S, S, seed=18)
+    mask = torch.ones(B, S, device="cuda")
+    mask[0, :9] = 0                                   # left padding on batch entry 0
+    scale = 0.125
+    p = ops.softmax_causal_fwd_(scores.clone(), mask, Hh, scale)
+    sf = scores.float() * scale
+    vis = torch.tril(torch.ones(S, S, device="cuda", dtype=torch.bool))[None] & (mask.repeat_interleave(Hh, 0)[:, None, :] != 0)
+    ref = torch.softmax(sf.masked_fill(~vis, float("-inf")), -1)
+    ref = torch.nan_to_num(ref, nan=0.0)              # fully masked (pad) rows -> zeros
+    _close(p, ref, atol=2e-3)
+    assert bool((p[0, :9] == 0).all())
+    dp = _bf(B * Hh, S, S, seed=19)
+    pf = p.float()
+    want = scale * pf * (dp.float() - (pf * dp.float()).sum(-1, keepdim=True))
+    _close(ops.softmax_bwd_(p, dp.clone(), scale), want, atol=2e-3)
+
+
+def test_adam_with_clipping_matches_torch(ops):
+    n = 10007
+    p0 = _bf(n, seed=20)
+    g = _bf(n, scale=0.01, seed=21)
+    ref_p = p0.float().clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    p = p0.clone()
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        gs = (g.float() * step * 50).to(torch.bfloat16)          # norm > 1 -> clipping active
+        ref_p.grad = gs.float().clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        acc = torch.zeros(1, device="cuda")
+        ops.sumsq(gs, acc)
+        assert abs(acc.item() - gs.float().pow(2).sum().item()) < 1e-3 * acc.item()
+        ops.adam_step_(p, gs, m, v, acc, 1.0, 1e-3, 0.9, 0.99, 1e-8, 1e-2, step)
+        # the bf16 parameter follows the fp32 trajectory to within bf16 rounding of the parameter
+        _close(p, ref_p.detach(), atol=1e-3 * step, rtol=2 ** -7 * step)
