@@ -91,7 +91,8 @@ def lib():
         "ecgb_transpose_bf16": [vp, vp, ci, ci, vp],
         "ecgb_f32_to_bf16": [vp, vp, sz, vp],
         "ecgb_gemm_nt_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, ci, ll, ll, ll, vp],
-        "ecgb_gemm_nt_bf16_heads": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, ci, ll, ll, ci, ll, ll, ci, ll, ll, vp],
+        "ecgb_gemm_nt_bf16_heads": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, ci, ci, ll, ll, ci, ll, ll, ci, ll, ll, vp],
+        "ecgb_transpose_bf16_strided": [vp, vp, ci, ci, ll, ll, ci, ci, ll, ll, ll, ll, vp],
         "ecgb_count_labels": [vp, sz, ci, vp, vp],
         "ecgb_ce_fwd_bwd": [vp, vp, vp, vp, vp, sz, ci, sz, vp],
         "ecgb_sumsq": [vp, sz, ci, vp, vp],

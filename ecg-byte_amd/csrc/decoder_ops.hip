@@ -430,6 +430,34 @@ __global__ __launch_bounds__(256) void transpose_kernel(const unsigned short *in
     }
 }
 
+// batched, strided variant: matrix z = (zo, zi) of R x Cc elements, input rows ld_in apart, output rows ld_out apart
+__global__ __launch_bounds__(256) void transpose_strided_kernel(const unsigned short *in, unsigned short *out, int R, int Cc,
+                                                                long long ld_in, long long ld_out, int inner,
+                                                                long long outer_in, long long inner_in, long long outer_out,
+                                                                long long inner_out)
+{
+    __shared__ unsigned short tile[64][66];
+    const int zo = blockIdx.y / inner, zi = blockIdx.y % inner;
+    const unsigned short *src = in + zo * outer_in + zi * inner_in;
+    unsigned short *dst = out + zo * outer_out + zi * inner_out;
+    const int tiles_c = (Cc + 63) / 64, tiles_r = (R + 63) / 64;
+    for (int t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {
+        const int tr = t / tiles_c, tc = t % tiles_c;
+        for (int k = threadIdx.x; k < 64 * 64; k += 256) {
+            const int r = k / 64, c = k % 64;
+            const int gr = tr * 64 + r, gc = tc * 64 + c;
+            tile[r][c] = (gr < R && gc < Cc) ? src[(long long)gr * ld_in + gc] : 0;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 64 * 64; k += 256) {
+            const int c = k / 64, r = k % 64;
+            const int gr = tr * 64 + r, gc = tc * 64 + c;
+            if (gr < R && gc < Cc) dst[(long long)gc * ld_out + gr] = tile[r][c];
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *in, unsigned short *out, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = f2bf(in[i]);
@@ -671,4 +699,16 @@ extern "C" int ecgb_softmax_bwd(const void *p_dev, void *dp_dev, int batch_heads
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(grid_for(rows, 4)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short *)p_dev, (unsigned short *)dp_dev, rows, seq, scale);
     ECGB_CHECK_LAUNCH("softmax_bwd");
+}
+
+extern "C" int ecgb_transpose_bf16_strided(const void *in_dev, void *out_dev, int rows, int cols, long long ld_in, long long ld_out,
+                                           int batch, int inner, long long outer_in, long long inner_in, long long outer_out,
+                                           long long inner_out, void *stream)
+{
+    if (batch <= 0 || inner <= 0 || batch > 65535) { ecgb::set_error("ecgb_transpose_bf16_strided: bad batch"); return ECGB_ERR_INVALID; }
+    const size_t tiles = (size_t)((rows + 63) / 64) * ((cols + 63) / 64);
+    hipLaunchKernelGGL(transpose_strided_kernel, dim3((unsigned)std::min<size_t>(std::max<size_t>(tiles, 1), 1024), (unsigned)batch),
+                       dim3(256), 0, (hipStream_t)stream, (const unsigned short *)in_dev, (unsigned short *)out_dev, rows, cols,
+                       ld_in, ld_out, inner, outer_in, inner_in, outer_out, inner_out);
+    ECGB_CHECK_LAUNCH("transpose_bf16_strided");
 }

@@ -195,7 +195,7 @@ extern "C" int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b
 }
 
 extern "C" int ecgb_gemm_nt_bf16_heads(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev,
-                                       long long ldc, int M, int N, int K, float alpha, int batch, int inner,
+                                       long long ldc, int M, int N, int K, float alpha, int accumulate_f32, int batch, int inner,
                                        long long outer_a, long long inner_a, int div_a, long long outer_b,
                                        long long inner_b, int div_b, long long outer_c, long long inner_c, void *stream)
 {
@@ -213,7 +213,7 @@ extern "C" int ecgb_gemm_nt_bf16_heads(const void *a_dev, long long lda, const v
     G.M = M; G.N = N; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = ldc;
     G.batch_a = G.batch_b = G.batch_c = 0;
     G.tiles_m = (M + BM - 1) / BM; G.tiles_n = (N + BN - 1) / BN;
-    G.accumulate_f32 = 0; G.alpha = alpha;
+    G.accumulate_f32 = accumulate_f32; G.alpha = alpha;
     G.inner = inner; G.outer_a = outer_a; G.inner_a = inner_a; G.div_a = div_a;
     G.outer_b = outer_b; G.inner_b = inner_b; G.div_b = div_b; G.outer_c = outer_c; G.inner_c = inner_c;
     hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, (unsigned)batch), dim3(256), 0,

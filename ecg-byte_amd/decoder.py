@@ -1,0 +1,421 @@
+"""Causal-LM training step on the MI355X kernels of libecgbyte_hip.so -- the model side of the
+reference's hot path.
+
+`HipCausalLM` presents the slice of the HuggingFace surface that ecg_byte/main.py:141-165 and
+ecg_byte/models/llm.py:17-24 touch:
+    out = llm(input_ids=..., attention_mask=..., labels=..., position_ids=...);  out.loss.backward()
+    llm.config.{hidden_size, pad_token_id}, llm.device, llm.resize_token_embeddings(n),
+    state_dict()/load_state_dict() with HF parameter names (checkpoints, main.py:193-195,299-306)
+and runs Llama-architecture decoders (vendored transformers/models/llama/modeling_llama.py:859-1225):
+pre-norm blocks with RMSNorm, half-split RoPE (default or llama3 frequencies), grouped-query
+causal attention with the reference's left-padding mask, SwiGLU MLP, tied lm_head, mean CE over
+labels != -100.  Every tensor op is a kernel of include/ecgbyte_decoder.h; torch supplies
+parameters, buffers, streams and (for N > 1) RCCL all-reduce.
+
+Layout choices (MI355X): q/k/v and gate/up projections are fused into one weight each (one big
+GEMM instead of three / two); every weight keeps a transposed shadow copy so that all three GEMMs
+of a linear layer (y = xW^T, dx = dy W, dW = dy^T x) are the same K-contiguous NT kernel; the
+vocabulary is padded to a multiple of 128 rows; the loss head only materialises logits for rows
+whose (shifted) label is not -100 -- identical loss and gradients, a fraction of the work.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import decoder_ops as ops
+
+
+@dataclass
+class DecoderConfig:
+    vocab_size: int = 128256
+    hidden_size: int = 2048
+    intermediate_size: int = 8192
+    num_hidden_layers: int = 16
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 8
+    head_dim: int | None = None
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    rope_scaling: dict | None = field(default_factory=lambda: {
+        "factor": 32.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+        "original_max_position_embeddings": 8192, "rope_type": "llama3"})
+    tie_word_embeddings: bool = True
+    pad_token_id: int | None = None
+    initializer_range: float = 0.02
+
+    def __post_init__(self):
+        if self.head_dim is None:
+            self.head_dim = self.hidden_size // self.num_attention_heads
+
+    @staticmethod
+    def llama_3_2_1b(**kw):
+        """Published Llama-3.2-1B dimensions."""
+        return DecoderConfig(**kw)
+
+
+def rope_inv_freq(cfg: DecoderConfig) -> torch.Tensor:
+    """_compute_default_rope_parameters / _compute_llama3_parameters
+    (transformers/src/transformers/modeling_rope_utils.py:29-68,310-351)."""
+    dim = cfg.head_dim
+    inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.int64).float() / dim))
+    rs = cfg.rope_scaling
+    if not rs or rs.get("rope_type", rs.get("type", "default")) == "default":
+        return inv_freq
+    if rs.get("rope_type", rs.get("type")) != "llama3":
+        raise NotImplementedError(f"rope_type {rs.get('rope_type')}")
+    factor, lo, hi, old = rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"], rs["original_max_position_embeddings"]
+    low_freq_wavelen, high_freq_wavelen = old / lo, old / hi
+    wavelen = 2 * math.pi / inv_freq
+    inv_freq_llama = torch.where(wavelen > low_freq_wavelen, inv_freq / factor, inv_freq)
+    smooth = (old / wavelen - lo) / (hi - lo)
+    smoothed = (1 - smooth) * inv_freq_llama / factor + smooth * inv_freq_llama
+    is_medium = ~(wavelen < high_freq_wavelen) * ~(wavelen > low_freq_wavelen)
+    return torch.where(is_medium, smoothed, inv_freq_llama)
+
+
+class _LossFn(torch.autograd.Function):
+    """Ties the hand-written forward/backward into autograd so `out.loss.backward()` works."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, input_ids, attention_mask, labels, position_ids):
+        ctx.model = model
+        return model._forward_loss(input_ids, attention_mask, labels, position_ids)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.model._backward(grad_out)
+        return None, None, None, None, None, None
+
+
+class HipCausalLM(nn.Module):
+    def __init__(self, cfg: DecoderConfig, device="cuda", seed: int = 0):
+        super().__init__()
+        self.cfg = cfg
+        self.config = SimpleNamespace(hidden_size=cfg.hidden_size, pad_token_id=cfg.pad_token_id, vocab_size=cfg.vocab_size)
+        H, I, D = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
+        Hq, Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
+        assert cfg.tie_word_embeddings, "untied lm_head not needed by the reference's models"
+        assert H % 64 == 0 and I % 64 == 0 and D % 64 == 0, "GEMM K-step is 64"
+        self.qkv = Hq * D + 2 * Hkv * D
+        dev = torch.device(device)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+
+        def init(*shape):   # LlamaPreTrainedModel._init_weights: N(0, initializer_range), modeling_llama.py:737-746
+            return (torch.randn(*shape, generator=g) * cfg.initializer_range).to(torch.bfloat16).to(dev)
+
+        self.v_pad = (cfg.vocab_size + 127) // 128 * 128
+        emb = torch.zeros(self.v_pad, H, dtype=torch.bfloat16, device=dev)
+        emb[: cfg.vocab_size] = init(cfg.vocab_size, H)
+        if cfg.pad_token_id is not None and cfg.pad_token_id < cfg.vocab_size:
+            emb[cfg.pad_token_id].zero_()
+        self.embed = nn.Parameter(emb)
+        self.wqkv = nn.ParameterList([nn.Parameter(init(self.qkv, H)) for _ in range(cfg.num_hidden_layers)])
+        self.wo = nn.ParameterList([nn.Parameter(init(H, Hq * D)) for _ in range(cfg.num_hidden_layers)])
+        self.wgu = nn.ParameterList([nn.Parameter(init(2 * I, H)) for _ in range(cfg.num_hidden_layers)])
+        self.wdown = nn.ParameterList([nn.Parameter(init(H, I)) for _ in range(cfg.num_hidden_layers)])
+        ones = lambda: nn.Parameter(torch.ones(H, dtype=torch.bfloat16, device=dev))
+        self.ln1 = nn.ParameterList([ones() for _ in range(cfg.num_hidden_layers)])
+        self.ln2 = nn.ParameterList([ones() for _ in range(cfg.num_hidden_layers)])
+        self.norm = ones()
+        self.register_buffer("inv_freq", rope_inv_freq(cfg).to(dev), persistent=False)
+        self._t = {}            # transposed shadow weights
+        self._t_version = {}    # parameter version each shadow was made from
+        self.embed_grad32 = None
+        self.full_logits = False   # True: run the loss head over every row, as the reference materialises it
+        self._saved = None
+
+    # ---- HF-style surface -------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.embed.device
+
+    def forward(self, input_ids=None, attention_mask=None, labels=None, position_ids=None, output_attentions=False, **_):
+        if labels is None:
+            raise NotImplementedError("HipCausalLM.forward computes the training loss; pass labels")
+        anchor = self.norm   # any parameter that requires grad, so autograd records the node
+        loss = _LossFn.apply(anchor, self, input_ids, attention_mask, labels, position_ids)
+        return SimpleNamespace(loss=loss, logits=None, attentions=None)
+
+    def resize_token_embeddings(self, n: int):
+        """transformers/modeling_utils.py:2080-2176, with new rows drawn as modeling_utils.py:2464-2489 does:
+        N(mean of the old table, 1e-9 * covariance) -- i.e. the mean row up to ~1e-5 noise."""
+        old = self.cfg.vocab_size
+        if n == old:
+            return
+        H = self.cfg.hidden_size
+        v_pad = (n + 127) // 128 * 128
+        emb = torch.zeros(v_pad, H, dtype=torch.bfloat16, device=self.device)
+        keep = min(old, n)
+        emb[:keep] = self.embed.data[:keep]
+        if n > old:
+            mean = self.embed.data[:old].float().mean(0)
+            emb[old:n] = mean.to(torch.bfloat16)
+        self.embed = nn.Parameter(emb)
+        self.cfg.vocab_size = n
+        self.config.vocab_size = n
+        self.v_pad = v_pad
+        self.embed_grad32 = None
+        self._t.pop("embed", None)
+
+    def _hf_named(self):
+        """(HF name, tensor view) pairs, modeling_llama.py parameter names."""
+        c = self.cfg
+        H, I, D, Hq, Hkv = c.hidden_size, c.intermediate_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        yield "model.embed_tokens.weight", self.embed.data[: c.vocab_size]
+        for i in range(c.num_hidden_layers):
+            p = f"model.layers.{i}."
+            w = self.wqkv[i].data
+            yield p + "self_attn.q_proj.weight", w[: Hq * D]
+            yield p + "self_attn.k_proj.weight", w[Hq * D: Hq * D + Hkv * D]
+            yield p + "self_attn.v_proj.weight", w[Hq * D + Hkv * D:]
+            yield p + "self_attn.o_proj.weight", self.wo[i].data
+            yield p + "mlp.gate_proj.weight", self.wgu[i].data[:I]
+            yield p + "mlp.up_proj.weight", self.wgu[i].data[I:]
+            yield p + "mlp.down_proj.weight", self.wdown[i].data
+            yield p + "input_layernorm.weight", self.ln1[i].data
+            yield p + "post_attention_layernorm.weight", self.ln2[i].data
+        yield "model.norm.weight", self.norm.data
+        yield "lm_head.weight", self.embed.data[: c.vocab_size]
+
+    def state_dict(self, *a, **k):
+        return {n: t.clone() for n, t in self._hf_named()}
+
+    def load_state_dict(self, sd, strict=True):
+        names = dict(self._hf_named())
+        missing = [n for n in names if n not in sd and n != "lm_head.weight"]
+        unexpected = [n for n in sd if n not in names and not n.endswith("rotary_emb.inv_freq")]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        with torch.no_grad():
+            for n, t in names.items():
+                if n in sd and n != "lm_head.weight":
+                    t.copy_(sd[n].to(device=t.device, dtype=t.dtype))
+        self._t.clear()
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    # ---- helpers --------------------------------------------------------------------------
+    def _shadow(self, key, p):
+        """Transposed copy of a weight, refreshed when the parameter was updated in place."""
+        ver = p._version
+        if self._t_version.get(key) != ver or key not in self._t:
+            self._t[key] = ops.transpose(p.data)
+            self._t_version[key] = ver
+        return self._t[key]
+
+    def _rope_tables(self, position_ids):
+        pos = position_ids.reshape(-1).float()
+        fr = pos[:, None] * self.inv_freq[None, :].float()
+        return fr.cos().contiguous(), fr.sin().contiguous()
+
+    # ---- forward ------------------------------------------------------------------------------
+    def _forward_loss(self, input_ids, attention_mask, labels, position_ids):
+        c = self.cfg
+        H, I, D, Hq, Hkv = c.hidden_size, c.intermediate_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        G = Hq // Hkv
+        dev = self.device
+        input_ids = input_ids.to(dev).contiguous()
+        B, S = input_ids.shape
+        assert S % 64 == 0, "sequence length must be a multiple of 64 (GEMM K-step); the reference uses pad_to_max+4 = 1024"
+        T = B * S
+        mask = (attention_mask.to(dev).float() if attention_mask is not None else torch.ones(B, S, device=dev)).contiguous()
+        if position_ids is None:
+            position_ids = torch.arange(S, device=dev)[None].expand(B, S)
+        cos, sin = self._rope_tables(position_ids.to(dev))
+        QKV = self.qkv
+        scale = 1.0 / math.sqrt(D)
+        saved = []
+        x = ops.embed_fwd(input_ids.view(-1), self.embed.data)          # [T, H]
+        delta = None
+        for i in range(c.num_hidden_layers):
+            h1, rstd1, x1 = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta)
+            qkv = ops.gemm_nt(h1, self.wqkv[i].data)                    # [T, QKV]
+            ops.rope_(qkv, cos, sin, Hq, D, QKV)
+            _rope_offset(qkv, Hq * D, cos, sin, Hkv, D, QKV)
+            P = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
+            ops.gemm_nt_heads((qkv, 0), QKV, (qkv, Hq * D), QKV, P, S, S, S, D, 1.0, B * Hq, Hq,
+                              S * QKV, D, 1, S * QKV, D, G, Hq * S * S, S * S)
+            ops.softmax_causal_fwd_(P, mask, Hq, scale)
+            vT = torch.empty((B, Hkv, D, S), dtype=torch.bfloat16, device=dev)
+            ops.transpose_strided(qkv, Hq * D + Hkv * D, vT, 0, S, D, QKV, S, B * Hkv, Hkv, S * QKV, D, Hkv * D * S, D * S)
+            ao = torch.empty((T, Hq * D), dtype=torch.bfloat16, device=dev)
+            ops.gemm_nt_heads(P, S, vT, S, ao, Hq * D, S, D, S, 1.0, B * Hq, Hq, Hq * S * S, S * S, 1,
+                              Hkv * D * S, D * S, G, S * Hq * D, D)
+            attn_delta = ops.gemm_nt(ao, self.wo[i].data)               # [T, H]
+            h2, rstd2, x2 = ops.rmsnorm_fwd(x1, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta)
+            gu = ops.gemm_nt(h2, self.wgu[i].data)                      # [T, 2I]
+            hm = ops.glu_fwd(gu)
+            delta = ops.gemm_nt(hm, self.wdown[i].data)
+            saved.append((x1, rstd1, h1, qkv, P, ao, x2, rstd2, h2, gu, hm))
+            x = x2
+        hf, rstdf, xf = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta)
+
+        # ---- loss head: ForCausalLMLoss shifts (loss_utils.py:39-41): row t predicts labels[t+1]
+        labels = labels.to(dev)
+        shifted = torch.full((B, S), -100, dtype=torch.int64, device=dev)
+        shifted[:, :-1] = labels[:, 1:]
+        shifted = shifted.view(-1)
+        inv_count = ops.count_labels(shifted, c.vocab_size)
+        rows = torch.arange(T, device=dev) if self.full_logits else torch.nonzero(shifted != -100).view(-1)
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        if self.embed_grad32 is None:
+            self.embed_grad32 = torch.zeros((self.v_pad, H), dtype=torch.float32, device=dev)
+        else:
+            self.embed_grad32.zero_()
+        dhf = torch.zeros((T, H), dtype=torch.bfloat16, device=dev)
+        embed_t = self._shadow("embed", self.embed)                      # [H, v_pad]
+        chunk = 4096
+        for s0 in range(0, rows.numel(), chunk):
+            r = rows[s0:s0 + chunk]
+            hr = hf.index_select(0, r)                                   # gather (plumbing)
+            lab = shifted.index_select(0, r)
+            logits = ops.gemm_nt(hr, self.embed.data)                    # [n, v_pad]
+            ops.ce_fwd_bwd_(logits, lab, inv_count, loss, c.vocab_size)  # logits <- dlogits
+            dhr = ops.gemm_nt(logits, embed_t)                           # [n, H] = dlogits . E
+            dhf.index_copy_(0, r, dhr)
+            n = r.numel()
+            npad = (n + 63) // 64 * 64                                   # contraction over rows: K-step 64
+            dlt = torch.zeros((self.v_pad, npad), dtype=torch.bfloat16, device=dev)
+            ops.transpose_strided(logits, 0, dlt, 0, n, self.v_pad, self.v_pad, npad, 1, 1, 0, 0, 0, 0)
+            hrt = torch.zeros((H, npad), dtype=torch.bfloat16, device=dev)
+            ops.transpose_strided(hr, 0, hrt, 0, n, H, H, npad, 1, 1, 0, 0, 0, 0)
+            ops.gemm_nt(dlt, hrt, out=self.embed_grad32, accumulate_f32=True)   # dE += dlogits^T . h
+        self._saved = (saved, input_ids, mask, cos, sin, (xf, rstdf), dhf, (B, S))
+        return loss.squeeze(0)
+
+    # ---- backward -------------------------------------------------------------------------------
+    def _backward(self, grad_out):
+        c = self.cfg
+        H, I, D, Hq, Hkv = c.hidden_size, c.intermediate_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        G = Hq // Hkv
+        QKV = self.qkv
+        saved, input_ids, mask, cos, sin, (xf, rstdf), dhf, (B, S) = self._saved
+        self._saved = None
+        dev = self.device
+        T = B * S
+        scale = 1.0 / math.sqrt(D)
+        go = float(grad_out)   # d(final)/d(loss); 1.0 for loss.backward()
+        if go != 1.0:
+            dhf = (dhf.float() * go).to(torch.bfloat16)
+            self.embed_grad32.mul_(go)
+
+        def wgrad(dy, xin, param):
+            """param.grad = dy^T . xin (bf16)"""
+            g = ops.gemm_nt(ops.transpose(dy), ops.transpose(xin))
+            param.grad = g if param.grad is None else ops.add(param.grad, g)
+
+        def lngrad(param, dw32):
+            g = dw32.to(torch.bfloat16)
+            param.grad = g if param.grad is None else ops.add(param.grad, g)
+
+        dw = torch.zeros(H, dtype=torch.float32, device=dev)
+        g = ops.rmsnorm_bwd(xf, self.norm.data, rstdf, dhf, dw)          # grad of the residual stream
+        lngrad(self.norm, dw)
+        for i in reversed(range(c.num_hidden_layers)):
+            x1, rstd1, h1, qkv, P, ao, x2, rstd2, h2, gu, hm = saved.pop()
+            # MLP
+            wgrad(g, hm, self.wdown[i])
+            d_hm = ops.gemm_nt(g, self._shadow(("wdown", i), self.wdown[i]))        # [T, I]
+            d_gu = ops.glu_bwd(gu, d_hm)
+            del d_hm, hm
+            wgrad(d_gu, h2, self.wgu[i])
+            d_h2 = ops.gemm_nt(d_gu, self._shadow(("wgu", i), self.wgu[i]))         # [T, H]
+            del d_gu, gu
+            dw = torch.zeros(H, dtype=torch.float32, device=dev)
+            g2 = ops.rmsnorm_bwd(x2, self.ln2[i].data, rstd2, d_h2, dw, dres=g)
+            lngrad(self.ln2[i], dw)
+            # attention output projection
+            wgrad(g2, ao, self.wo[i])
+            d_ao = ops.gemm_nt(g2, self._shadow(("wo", i), self.wo[i]))             # [T, Hq*D]
+            # attention core
+            d_qkv = torch.empty((T, QKV), dtype=torch.bfloat16, device=dev)
+            dP = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
+            ops.gemm_nt_heads(d_ao, Hq * D, (qkv, Hq * D + Hkv * D), QKV, dP, S, S, S, D, 1.0, B * Hq, Hq,
+                              S * Hq * D, D, 1, S * QKV, D, G, Hq * S * S, S * S)   # dP = dO . V^T
+            ops.softmax_bwd_(P, dP, scale)                                           # dP <- dS
+            kT = torch.empty((B, Hkv, D, S), dtype=torch.bfloat16, device=dev)
+            ops.transpose_strided(qkv, Hq * D, kT, 0, S, D, QKV, S, B * Hkv, Hkv, S * QKV, D, Hkv * D * S, D * S)
+            ops.gemm_nt_heads(dP, S, kT, S, (d_qkv, 0), QKV, S, D, S, 1.0, B * Hq, Hq, Hq * S * S, S * S, 1,
+                              Hkv * D * S, D * S, G, S * QKV, D)                     # dQ = dS . K
+            tmpT = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
+            qT = torch.empty((B, Hq, D, S), dtype=torch.bfloat16, device=dev)
+            ops.transpose_strided(qkv, 0, qT, 0, S, D, QKV, S, B * Hq, Hq, S * QKV, D, Hq * D * S, D * S)
+            doT = torch.empty((B, Hq, D, S), dtype=torch.bfloat16, device=dev)
+            ops.transpose_strided(d_ao, 0, doT, 0, S, D, Hq * D, S, B * Hq, Hq, S * Hq * D, D, Hq * D * S, D * S)
+            dkv32 = torch.zeros((2, B, S, Hkv * D), dtype=torch.float32, device=dev)
+            for which, (src, rhs) in enumerate(((dP, qT), (P, doT))):                # dK = dS^T . Q ; dV = P^T . dO
+                ops.transpose_strided(src, 0, tmpT, 0, S, S, S, S, B * Hq, 1, S * S, 0, S * S, 0)
+                for j in range(G):   # the G query heads of a KV head accumulate into the same fp32 tile
+                    ops.gemm_nt_heads((tmpT, j * S * S), S, (rhs, j * D * S), S, dkv32[which], Hkv * D, S, D, S, 1.0,
+                                      B * Hkv, Hkv, Hq * S * S, G * S * S, 1, Hq * D * S, G * D * S, 1,
+                                      S * Hkv * D, D, accumulate_f32=True)
+            d_qkv[:, Hq * D: Hq * D + Hkv * D] = dkv32[0].view(T, Hkv * D).to(torch.bfloat16)
+            d_qkv[:, Hq * D + Hkv * D:] = dkv32[1].view(T, Hkv * D).to(torch.bfloat16)
+            del dP, tmpT, P
+            ops.rope_(d_qkv, cos, sin, Hq, D, QKV, inverse=True)
+            _rope_offset(d_qkv, Hq * D, cos, sin, Hkv, D, QKV, inverse=True)
+            wgrad(d_qkv, h1, self.wqkv[i])
+            d_h1 = ops.gemm_nt(d_qkv, self._shadow(("wqkv", i), self.wqkv[i]))      # [T, H]
+            dw = torch.zeros(H, dtype=torch.float32, device=dev)
+            g = ops.rmsnorm_bwd(x1, self.ln1[i].data, rstd1, d_h1, dw, dres=g2)
+            lngrad(self.ln1[i], dw)
+        ops.embed_bwd(input_ids.view(-1), g, self.embed_grad32)
+        eg = self.embed_grad32.to(torch.bfloat16)
+        self.embed.grad = eg if self.embed.grad is None else ops.add(self.embed.grad, eg)
+        self.embed_grad32.zero_()
+
+    # ---- fused optimizer (clip_grad_norm_(1.0) + Adam with L2, Noam schedule) -------------------------
+    def make_optimizer(self, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2, warmup=500, max_norm=1.0):
+        return HipAdam(self, lr, betas, eps, weight_decay, warmup, max_norm)
+
+
+def _rope_offset(buf, col_off, cos, sin, n_heads, D, row_stride, inverse=False):
+    """RoPE on the heads that start `col_off` elements into each row of a fused buffer."""
+    import ctypes as C
+    from . import _lib
+    _lib.check(_lib.lib().ecgb_rope(C.c_void_p(buf.data_ptr() + 2 * col_off), C.c_void_p(cos.data_ptr()),
+                                    C.c_void_p(sin.data_ptr()), cos.shape[0], n_heads, D, row_stride, int(inverse),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+
+class HipAdam:
+    """ecg_byte/runners/train.py:26 + ecg_byte/main.py:262-264 + ecg_byte/scheduler.py:3-27 on the device:
+    global-norm clip to 1.0, Adam (weight decay as L2), lr = d_model^-0.5 * min(t^-0.5, t * warmup^-1.5).
+    Moments are fp32 (the reference's follow the bf16 parameter dtype)."""
+
+    def __init__(self, model: HipCausalLM, lr, betas, eps, weight_decay, warmup, max_norm):
+        self.model, self.betas, self.eps, self.wd, self.warmup, self.max_norm = model, betas, eps, weight_decay, warmup, max_norm
+        self.init_lr = model.cfg.hidden_size ** -0.5
+        self.fixed_lr = None if warmup else lr
+        self.t = 0
+        self.state = {}
+
+    def zero_grad(self):
+        for p in self.model.parameters():
+            p.grad = None
+
+    def lr(self, t):
+        if self.fixed_lr is not None:
+            return self.fixed_lr
+        return self.init_lr * min(t ** -0.5, t * self.warmup ** -1.5)
+
+    def step_and_update_lr(self):
+        self.t += 1
+        params = [p for p in self.model.parameters() if p.grad is not None]
+        acc = torch.zeros(1, dtype=torch.float32, device=self.model.device)
+        for p in params:
+            ops.sumsq(p.grad, acc)
+        lr = self.lr(self.t)
+        for p in params:
+            st = self.state.get(id(p))
+            if st is None or st[0].shape != p.shape:
+                st = (torch.zeros(p.shape, dtype=torch.float32, device=p.device), torch.zeros(p.shape, dtype=torch.float32, device=p.device))
+                self.state[id(p)] = st
+            ops.adam_step_(p.data, p.grad, st[0], st[1], acc, self.max_norm, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t)
+        self.model._t.clear()   # weights changed: transposed shadows are stale
+
+    step = step_and_update_lr

@@ -101,9 +101,19 @@ def gemm_nt(a, b, out=None, alpha=1.0, accumulate_f32=False):
 
 
 def gemm_nt_heads(a, lda, b, ldb, c, ldc, M, N, K, alpha, batch, inner, outer_a, inner_a, div_a, outer_b, inner_b, div_b,
-                  outer_c, inner_c):
-    _lib.check(_L().ecgb_gemm_nt_bf16_heads(_p(a), lda, _p(b), ldb, _p(c), ldc, M, N, K, float(alpha), batch, inner,
-                                            outer_a, inner_a, div_a, outer_b, inner_b, div_b, outer_c, inner_c, _st()))
+                  outer_c, inner_c, accumulate_f32=False):
+    """a, b, c: tensors or (tensor, element_offset) pairs."""
+    def ptr(x):
+        if isinstance(x, tuple):
+            return C.c_void_p(x[0].data_ptr() + x[1] * x[0].element_size())
+        return _p(x)
+    _lib.check(_L().ecgb_gemm_nt_bf16_heads(ptr(a), lda, ptr(b), ldb, ptr(c), ldc, M, N, K, float(alpha), int(accumulate_f32), batch,
+                                            inner, outer_a, inner_a, div_a, outer_b, inner_b, div_b, outer_c, inner_c, _st()))
+
+
+def transpose_strided(src, src_off, dst, dst_off, rows, cols, ld_in, ld_out, batch, inner, outer_in, inner_in, outer_out, inner_out):
+    _lib.check(_L().ecgb_transpose_bf16_strided(C.c_void_p(src.data_ptr() + 2 * src_off), C.c_void_p(dst.data_ptr() + 2 * dst_off),
+                                                rows, cols, ld_in, ld_out, batch, inner, outer_in, inner_in, outer_out, inner_out, _st()))
 
 
 def softmax_causal_fwd_(scores, attn_mask, n_heads, scale):

@@ -52,6 +52,10 @@ int ecgb_glu_bwd(const void *gate_up_dev, const void *dh_dev, void *dgate_up_dev
 
 int ecgb_add_bf16(const void *a_dev, const void *b_dev, void *out_dev, size_t n, void *stream);
 int ecgb_transpose_bf16(const void *in_dev, void *out_dev, int rows, int cols, void *stream);
+/* Batch of strided matrices: entry z = (z / inner, z % inner) starts at base + zo*outer + zi*inner_stride. */
+int ecgb_transpose_bf16_strided(const void *in_dev, void *out_dev, int rows, int cols, long long ld_in, long long ld_out,
+                                int batch, int inner, long long outer_in, long long inner_in, long long outer_out,
+                                long long inner_out, void *stream);
 int ecgb_f32_to_bf16(const float *in_dev, void *out_dev, size_t n, void *stream);
 
 /* C[M,N] = alpha * A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulation on the matrix cores.
@@ -63,7 +67,7 @@ int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b_dev, long 
  * zi = z % inner; operand X starts at X + zo*outer_x + (zi / div_x)*inner_x  (div_b > 1 shares one KV head
  * among div_b query heads). */
 int ecgb_gemm_nt_bf16_heads(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
-                            int M, int N, int K, float alpha, int batch, int inner, long long outer_a, long long inner_a,
+                            int M, int N, int K, float alpha, int accumulate_f32, int batch, int inner, long long outer_a, long long inner_a,
                             int div_a, long long outer_b, long long inner_b, int div_b, long long outer_c,
                             long long inner_c, void *stream);
 

@@ -1,0 +1,119 @@
+"""GPU test of the whole decoder step (HipCausalLM) against goldens generated from the VENDORED
+transformers LlamaForCausalLM (tests/golden/make_decoder_golden.py): tiny config, GQA, llama3 RoPE
+scaling, left-padded batch, -100 labels.  Tolerances (bf16 compute vs the fp32 reference run):
+loss within 1e-2 relative (the reference's own bf16 run differs from its fp32 run by ~1e-4 here);
+every parameter gradient within 3e-2 of the fp32 gradient in relative Frobenius norm and with
+cosine similarity > 0.999."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _load():
+    z = np.load(os.path.join(GOLDEN, "decoder_llama_tiny.npz"))
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    cfg = DecoderConfig(vocab_size=300, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                        num_key_value_heads=1, rms_norm_eps=1e-5, rope_theta=500000.0, pad_token_id=299,
+                        rope_scaling={"factor": 32.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                      "original_max_position_embeddings": 32, "rope_type": "llama3"})
+    m = HipCausalLM(cfg)
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    m.load_state_dict(sd)
+    return z, m
+
+
+def _batch(z):
+    return dict(input_ids=torch.from_numpy(z["input_ids"]).cuda(), attention_mask=torch.from_numpy(z["attention_mask"]).cuda(),
+                labels=torch.from_numpy(z["labels"]).cuda(), position_ids=torch.from_numpy(z["position_ids"]).cuda())
+
+
+def test_rope_frequencies_match_reference():
+    z, m = _load()
+    assert np.allclose(m.inv_freq.cpu().numpy(), z["inv_freq"], rtol=1e-6, atol=0)
+
+
+def test_state_dict_roundtrip_hf_names():
+    z, m = _load()
+    sd = m.state_dict()
+    for k in z.files:
+        if k.startswith("w:"):
+            assert torch.equal(sd[k[2:]].float().cpu(), torch.from_numpy(z[k])), k
+    assert "lm_head.weight" in sd and torch.equal(sd["lm_head.weight"], sd["model.embed_tokens.weight"])
+
+
+@pytest.mark.parametrize("full_logits", [False, True])
+def test_loss_and_gradients_vs_vendored_transformers(full_logits):
+    z, m = _load()
+    m.full_logits = full_logits
+    out = m(**_batch(z))
+    loss = out.loss
+    assert abs(loss.item() - float(z["loss_fp32"])) <= 1e-2 * float(z["loss_fp32"]), (loss.item(), float(z["loss_fp32"]))
+    loss.backward()
+    c = m.cfg
+    D, Hq, Hkv, I = c.head_dim, c.num_attention_heads, c.num_key_value_heads, c.intermediate_size
+    grads = {"model.embed_tokens.weight": m.embed.grad[: c.vocab_size], "model.norm.weight": m.norm.grad}
+    for i in range(c.num_hidden_layers):
+        p = f"model.layers.{i}."
+        g = m.wqkv[i].grad
+        grads[p + "self_attn.q_proj.weight"] = g[: Hq * D]
+        grads[p + "self_attn.k_proj.weight"] = g[Hq * D: Hq * D + Hkv * D]
+        grads[p + "self_attn.v_proj.weight"] = g[Hq * D + Hkv * D:]
+        grads[p + "self_attn.o_proj.weight"] = m.wo[i].grad
+        grads[p + "mlp.gate_proj.weight"] = m.wgu[i].grad[:I]
+        grads[p + "mlp.up_proj.weight"] = m.wgu[i].grad[I:]
+        grads[p + "mlp.down_proj.weight"] = m.wdown[i].grad
+        grads[p + "input_layernorm.weight"] = m.ln1[i].grad
+        grads[p + "post_attention_layernorm.weight"] = m.ln2[i].grad
+    for name, g in grads.items():
+        ref = torch.from_numpy(z["g:" + name]).cuda()
+        g = g.float()
+        rel = (g - ref).norm() / ref.norm().clamp_min(1e-12)
+        cos = torch.nn.functional.cosine_similarity(g.flatten(), ref.flatten(), dim=0)
+        assert rel.item() < 3e-2 and cos.item() > 0.999, (name, rel.item(), cos.item())
+
+
+def test_training_steps_reduce_loss_and_follow_torch_adam():
+    """Three optimizer steps with the fused HipAdam on the tiny model: loss goes down, and the first
+    step equals clip_grad_norm_(1.0) + torch.optim.Adam(L2) applied to the same gradients."""
+    z, m = _load()
+    opt = m.make_optimizer(warmup=500)
+    batch = _batch(z)
+    losses = []
+    for step in range(3):
+        opt.zero_grad()
+        out = m(**batch)
+        out.loss.backward()
+        if step == 0:
+            p0 = m.wo[0].data.float().clone()
+            g0 = [p.grad.float().clone() for p in m.parameters()]
+            ref = p0.clone().requires_grad_(True)
+            total = torch.sqrt(sum((g * g).sum() for g in g0))
+            ref.grad = m.wo[0].grad.float() * min(1.0, 1.0 / (total.item() + 1e-6))
+            topt = torch.optim.Adam([ref], lr=opt.lr(1), betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+            topt.step()
+        opt.step_and_update_lr()
+        if step == 0:
+            assert torch.allclose(m.wo[0].data.float(), ref.detach().to(torch.bfloat16).float(), atol=2e-3, rtol=2e-2)
+        losses.append(out.loss.item())
+    assert losses[2] < losses[0], losses
+
+
+def test_resize_token_embeddings_and_pad_rows():
+    z, m = _load()
+    old = m.embed.data[:300].clone()
+    m.resize_token_embeddings(300 + 256 + 50 + 3)          # main.py:144-151: signal tokens + 3 specials
+    assert m.cfg.vocab_size == 609 and m.embed.shape[0] % 128 == 0
+    assert torch.equal(m.embed.data[:300], old)
+    assert torch.allclose(m.embed.data[300:609].float(), old.float().mean(0).to(torch.bfloat16).float()[None].expand(309, -1))
+    b = _batch(z)
+    b["input_ids"] = b["input_ids"].clone()
+    b["input_ids"][1, 5] = 600
+    out = m(**b)
+    out.loss.backward()
+    assert torch.isfinite(out.loss) and m.embed.grad[600].abs().sum() > 0
