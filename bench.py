@@ -99,6 +99,124 @@ def cpu_baseline(merges, pc, L, seed, budget_s=12.0):
     }
 
 
+MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
+
+
+def train_cpu_baseline(cfg_kw, S, threads=6):
+    """One forward+backward of the same architecture in plain PyTorch on the host CPU (the reference's
+    CPU path is HF transformers on ATen CPU kernels; torch.set_num_threads(6) is the reference's own
+    setting, ecg_byte/main.py:2).  fp32, batch 1, random weights of the published dimensions."""
+    import torch
+    from oracle import llama_ref as R
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        cfgd = dict(cfg_kw)
+        params = R.random_params(cfgd, seed=0, dtype=torch.float32)
+        for p in params.values():
+            p.requires_grad_(True)
+        g = torch.Generator().manual_seed(2)
+        ids = torch.randint(1000, 100000, (1, S), generator=g)
+        mask = torch.ones(1, S)
+        pos = torch.arange(S)[None]
+        labels = torch.full((1, S), -100); labels[:, -20:] = ids[:, -20:]
+        inv = R.llama3_inv_freq(cfgd["head_dim"], 500000.0, {"factor": 32.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                                             "original_max_position_embeddings": 8192})
+        t0 = time.perf_counter()
+        loss = R.llama_loss(params, cfgd, ids, mask, labels, pos, inv)
+        loss.backward()
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(old)
+    return {"value": 1.0 / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"1 sample (seq {S}) forward+backward, fp32, PyTorch CPU eager restatement of the decoder "
+                      f"(oracle/llama_ref.py) in {dt:.1f} s; optimizer step not included", "host_cpus": os.cpu_count()}
+
+
+def bench_train(args, tk, vocab, merges, pc, world, rank, dev):
+    """Train samples/s of Llama-3.2-1B (seq 1024, bf16, B per GPU) on the HIP decoder, batches built
+    through the real front end: synthetic ECG -> quantise+encode -> LUT -> assemble."""
+    import torch
+    import torch.distributed as dist
+    from ecg_byte_amd.data_loader import BatchAssembler
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    from ecg_byte_amd.parallel import GradAllReduce
+    B, S, L = args.train_batch, 1024, args.L
+    base = 128256
+    keys = list(vocab.keys())
+    n_vocab = base + len(keys) + 3                       # main.py:144-151: signal tokens, <sig_start>, <sig_end>, <pad>
+    lut = np.zeros(max(keys) + 1, dtype=np.int32)
+    lut[keys] = base + np.arange(len(keys))               # ids follow the pickled dict order
+    sig_start, sig_end, pad = n_vocab - 3, n_vocab - 2, n_vocab - 1
+    bos, eos = 128000, 128001
+    cfg = DecoderConfig.llama_3_2_1b(vocab_size=n_vocab, pad_token_id=pad)
+    model = HipCausalLM(cfg, device=dev, seed=0)
+    model.full_logits = bool(args.full_logits)
+    if world > 1:
+        model.grad_sync = GradAllReduce()
+    opt = model.make_optimizer()                          # Adam(0.9, 0.99, 1e-8, wd 1e-2) + Noam(500) + clip 1.0
+    asm = BatchAssembler(tk, lut, pad, bos, eos, sig_start, sig_end, S - 4, device=dev)
+    rng = np.random.default_rng(2 + rank)
+    x = torch.from_numpy(make_signals(B, L, seed=0, start=10_000_000 + rank * B, workers=8)).to(dev)
+    qs = [rng.integers(1000, 100000, size=int(rng.integers(8, 25))).tolist() for _ in range(B)]
+    ans = [rng.integers(1000, 100000, size=int(rng.integers(4, 33))).tolist() for _ in range(B)]
+
+    def step():
+        batch = asm(x, pc, qs, ans)                       # quantise + encode + assemble on the device
+        opt.zero_grad()
+        out = model(input_ids=batch["tokenized_signal"], attention_mask=batch["attn_mask"],
+                    labels=batch["quantized_signal_ids_input"], position_ids=batch["position_ids"])
+        out.loss.backward()
+        opt.step_and_update_lr()
+        return out.loss
+
+    for _ in range(max(1, args.warmup)):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.train_steps):
+        loss = step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    n_valid = sum(len(a) + 1 for a in ans)                # answer tokens + eos carry labels
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    sec = wall / args.train_steps
+    # algorithmic FLOPs (SURVEY.md §8d): 3 x (2 x matmul params x tokens + causal attention), loss head over the rows it runs on
+    H, I, Lyr = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    per_layer = H * (cfg.num_attention_heads * cfg.head_dim + 2 * cfg.num_key_value_heads * cfg.head_dim) + cfg.num_attention_heads * cfg.head_dim * H + 3 * H * I
+    tokens = B * S
+    head_rows = tokens if model.full_logits else n_valid
+    flops = 3 * (2 * Lyr * per_layer * tokens + Lyr * 2 * S * H * tokens + 2 * H * n_vocab * head_rows)
+    achieved = flops / sec / 1e12
+    out = {"metric": "train_samples_per_sec", "value": B * world / sec, "unit": "samples/s", "ms_per_step": sec * 1e3,
+           "steps": args.train_steps, "dtype": "bf16", "final_loss": float(loss.item()),
+           "config": {"workload": f"C3: Llama-3.2-1B dims (16 layers, hidden 2048, 32/8 heads, vocab {n_vocab}), seq {S}, "
+                                  f"batch {B}/GPU, full fine-tune, random init; batches built by quantise+encode+assemble on device",
+                      "loss_head_rows": "all" if model.full_logits else "labelled only (identical loss/gradients)",
+                      "parallelism": f"dp{world}" + (" (per-layer async all-reduce over RCCL)" if world > 1 else "")},
+           "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_nt_kernel (bf16 MFMA 32x32x16)",
+                        "algorithmic_flops_per_step": flops, "step_ms_hip_events": ev0.elapsed_time(ev1) / args.train_steps}}
+    if rank == 0 and not args.no_cpu_baseline:
+        cfg_kw = dict(vocab_size=n_vocab, hidden_size=H, intermediate_size=I, num_hidden_layers=Lyr,
+                      num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads,
+                      head_dim=cfg.head_dim, rms_norm_eps=cfg.rms_norm_eps)
+        out["cpu_baseline"] = train_cpu_baseline(cfg_kw, S)
+    del model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +225,10 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="records per GPU")
     ap.add_argument("--L", type=int, default=5000, help="samples per lead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the train-step part (encode metric only)")
+    ap.add_argument("--train-batch", type=int, default=32, help="samples per GPU per train step")
+    ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--full-logits", action="store_true", help="loss head over every row, as the reference materialises it")
     args = ap.parse_args()
 
     import torch
@@ -127,7 +249,7 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
     tag = "c2" if args.L == 5000 else "c1"
-    _, merges, pc = load_tokenizer(tag)
+    vocab, merges, pc = load_tokenizer(tag)
     tk = HipTokenizer(merges)
     B, L = args.batch, args.L
     n = 12 * L
@@ -173,6 +295,12 @@ def main():
     else:
         tokens_total = tokens_rank
 
+    train = None
+    if not args.no_train:
+        del xd, ids
+        torch.cuda.empty_cache()
+        train = bench_train(args, tk, vocab, merges, pc, world, rank, dev)
+
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
         records_total = B * world
@@ -197,6 +325,8 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(merges, pc, L, seed=0)
+        if train is not None:
+            out["train"] = train
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -128,6 +128,7 @@ class HipCausalLM(nn.Module):
         self.embed_grad32 = None
         self.full_logits = False   # True: run the loss head over every row, as the reference materialises it
         self._saved = None
+        self.grad_sync = None      # parallel.GradAllReduce: told as soon as a layer's gradients are final
 
     # ---- HF-style surface -------------------------------------------------------------------
     @property
@@ -363,10 +364,15 @@ class HipCausalLM(nn.Module):
             dw = torch.zeros(H, dtype=torch.float32, device=dev)
             g = ops.rmsnorm_bwd(x1, self.ln1[i].data, rstd1, d_h1, dw, dres=g2)
             lngrad(self.ln1[i], dw)
+            if self.grad_sync is not None:   # this layer's gradients are final: start their all-reduce now
+                self.grad_sync.on_grads_ready([self.wqkv[i], self.wo[i], self.wgu[i], self.wdown[i], self.ln1[i], self.ln2[i]])
         ops.embed_bwd(input_ids.view(-1), g, self.embed_grad32)
         eg = self.embed_grad32.to(torch.bfloat16)
         self.embed.grad = eg if self.embed.grad is None else ops.add(self.embed.grad, eg)
         self.embed_grad32.zero_()
+        if self.grad_sync is not None:
+            self.grad_sync.on_grads_ready([self.embed, self.norm])
+            self.grad_sync.finish()
 
     # ---- fused optimizer (clip_grad_norm_(1.0) + Adam with L2, Noam schedule) -------------------------
     def make_optimizer(self, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2, warmup=500, max_norm=1.0):

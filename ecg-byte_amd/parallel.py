@@ -42,3 +42,30 @@ def gather_counts(counts: torch.Tensor) -> torch.Tensor:
     out = [torch.empty_like(counts) for _ in range(dist.get_world_size())]
     dist.all_gather(out, counts)
     return torch.cat(out)
+
+
+class GradAllReduce:
+    """Data-parallel gradient exchange for HipCausalLM (the reference wraps its model in
+    DistributedDataParallel, ecg_byte/main.py:165: bucketed all-reduce(avg) of trainable grads,
+    fired during backward).  Here the model calls `on_grads_ready(params)` as soon as a layer's
+    gradients are final; each call enqueues one asynchronous all-reduce per tensor (RCCL over
+    xGMI with backend "nccl"; gloo in the CPU test), overlapping the exchange of layer i with the
+    backward of layer i-1.  `finish()` waits for all of them and turns sums into means."""
+
+    def __init__(self, process_group=None):
+        self.pg = process_group
+        self.pending = []
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+
+    def on_grads_ready(self, params):
+        if self.world == 1:
+            return
+        for p in params:
+            if p.grad is not None:
+                self.pending.append((p, dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
+
+    def finish(self):
+        for p, work in self.pending:
+            work.wait()
+            p.grad.div_(self.world)
+        self.pending = []

@@ -1,0 +1,97 @@
+"""Plain-PyTorch restatement of the reference's decoder step -- TEST INFRASTRUCTURE, NOT PRODUCT CODE
+(same rules as oracle/oracle.py; also bench.py's cpu_baseline for the train metric).
+
+Follows the vendored transformers 4.46.0.dev0 under /root/reference/transformers/src/transformers:
+  LlamaRMSNorm            models/llama/modeling_llama.py:67-72   (normalise in fp32, cast, THEN * weight)
+  rotate_half / RoPE      models/llama/modeling_llama.py:193-224, 145-165 (cos/sin cast to the activation dtype)
+  LlamaSdpaAttention      models/llama/modeling_llama.py:526-614 with the 4-D causal + padding mask of 1047-1100
+  LlamaMLP                models/llama/modeling_llama.py:238-258
+  LlamaDecoderLayer       models/llama/modeling_llama.py:635-701
+  ForCausalLMLoss         loss/loss_utils.py:24-47 (float upcast, shift, ignore_index -100, mean)
+Pinned against outputs of the reference itself: tests/golden/decoder_llama_tiny.npz
+(tests/test_oracle_decoder.py, fp32, 1e-5).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def rms_norm(x, w, eps):
+    dt = x.dtype
+    xf = x.float()
+    xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    return w * xf.to(dt)
+
+
+def rotate_half(x):
+    x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def llama_loss(params, cfg, input_ids, attention_mask, labels, position_ids, inv_freq):
+    """params: dict of HF-named tensors (requires_grad as wanted).  Returns the scalar loss."""
+    H, D = cfg["hidden_size"], cfg["head_dim"]
+    Hq, Hkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    B, S = input_ids.shape
+    emb = params["model.embed_tokens.weight"]
+    dt = emb.dtype
+    x = emb[input_ids]
+    freqs = position_ids[:, :, None].float() * inv_freq[None, None, :].float()
+    e = torch.cat((freqs, freqs), -1)
+    cos, sin = e.cos().to(dt)[:, None], e.sin().to(dt)[:, None]
+    causal = torch.tril(torch.ones(S, S, dtype=torch.bool, device=x.device))
+    visible = causal[None, None] & (attention_mask[:, None, None, :] != 0)
+    bias = torch.zeros(B, 1, S, S, dtype=dt, device=x.device).masked_fill(~visible, torch.finfo(dt).min)
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"model.layers.{i}."
+        h = rms_norm(x, params[p + "input_layernorm.weight"], cfg["rms_norm_eps"])
+        q = F.linear(h, params[p + "self_attn.q_proj.weight"]).view(B, S, Hq, D).transpose(1, 2)
+        k = F.linear(h, params[p + "self_attn.k_proj.weight"]).view(B, S, Hkv, D).transpose(1, 2)
+        v = F.linear(h, params[p + "self_attn.v_proj.weight"]).view(B, S, Hkv, D).transpose(1, 2)
+        q = q * cos + rotate_half(q) * sin
+        k = k * cos + rotate_half(k) * sin
+        k = k.repeat_interleave(Hq // Hkv, 1)
+        v = v.repeat_interleave(Hq // Hkv, 1)
+        a = F.scaled_dot_product_attention(q, k, v, attn_mask=bias)
+        a = a.transpose(1, 2).reshape(B, S, Hq * D)
+        x = x + F.linear(a, params[p + "self_attn.o_proj.weight"])
+        h = rms_norm(x, params[p + "post_attention_layernorm.weight"], cfg["rms_norm_eps"])
+        g = F.silu(F.linear(h, params[p + "mlp.gate_proj.weight"])) * F.linear(h, params[p + "mlp.up_proj.weight"])
+        x = x + F.linear(g, params[p + "mlp.down_proj.weight"])
+    x = rms_norm(x, params["model.norm.weight"], cfg["rms_norm_eps"])
+    logits = F.linear(x, emb).float()
+    return F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels[:, 1:].reshape(-1), ignore_index=-100)
+
+
+def random_params(cfg, seed=0, dtype=torch.float32, device="cpu", std=0.02):
+    g = torch.Generator().manual_seed(seed)
+    H, I, D = cfg["hidden_size"], cfg["intermediate_size"], cfg["head_dim"]
+    Hq, Hkv, V = cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["vocab_size"]
+    r = lambda *s: (torch.randn(*s, generator=g) * std).to(torch.bfloat16).to(dtype).to(device)
+    p = {"model.embed_tokens.weight": r(V, H), "model.norm.weight": torch.ones(H, dtype=dtype, device=device)}
+    for i in range(cfg["num_hidden_layers"]):
+        q = f"model.layers.{i}."
+        p[q + "self_attn.q_proj.weight"] = r(Hq * D, H)
+        p[q + "self_attn.k_proj.weight"] = r(Hkv * D, H)
+        p[q + "self_attn.v_proj.weight"] = r(Hkv * D, H)
+        p[q + "self_attn.o_proj.weight"] = r(H, Hq * D)
+        p[q + "mlp.gate_proj.weight"] = r(I, H)
+        p[q + "mlp.up_proj.weight"] = r(I, H)
+        p[q + "mlp.down_proj.weight"] = r(H, I)
+        p[q + "input_layernorm.weight"] = (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16).to(dtype).to(device)
+        p[q + "post_attention_layernorm.weight"] = (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16).to(dtype).to(device)
+    return p
+
+
+def llama3_inv_freq(head_dim, theta, scaling):
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    if not scaling:
+        return inv_freq
+    factor, lo, hi, old = scaling["factor"], scaling["low_freq_factor"], scaling["high_freq_factor"], scaling["original_max_position_embeddings"]
+    wavelen = 2 * math.pi / inv_freq
+    out = torch.where(wavelen > old / lo, inv_freq / factor, inv_freq)
+    smooth = (old / wavelen - lo) / (hi - lo)
+    smoothed = (1 - smooth) * out / factor + smooth * out
+    medium = ~(wavelen < old / hi) * ~(wavelen > old / lo)
+    return torch.where(medium, smoothed, out)

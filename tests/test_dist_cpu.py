@@ -68,3 +68,39 @@ def test_world_size_2_gloo():
         assert wall == 1.5                                            # MAX over ranks
         assert total == sum(single[i] for i in ret[0][0]) + sum(single[i] for i in ret[1][0])
         assert allc == [single[i] for i in ret[0][0]] + [single[i] for i in ret[1][0]]
+
+
+def _grad_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ecg_byte_amd import parallel
+        torch.manual_seed(0)
+        layers = [torch.nn.Parameter(torch.randn(4, 3)) for _ in range(3)]
+        x = torch.randn(6, 3)
+        shard = x[rank::world]                       # this rank's records
+        sync = parallel.GradAllReduce()
+        for i in reversed(range(3)):                 # "backward": layer grads become final one by one
+            layers[i].grad = (shard @ layers[i].detach().T).sum(0)[:, None].expand(4, 3).clone() / shard.shape[0]
+            sync.on_grads_ready([layers[i]])
+        sync.finish()
+        ret[rank] = [p.grad.clone() for p in layers]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_grad_all_reduce_world_size_2_gloo():
+    """GradAllReduce (the DDP replacement of HipCausalLM) averages per-layer gradients across ranks."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_grad_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    torch.manual_seed(0)
+    layers = [torch.randn(4, 3) for _ in range(3)]
+    x = torch.randn(6, 3)
+    for i in range(3):
+        per_rank = [(x[r::world] @ layers[i].T).sum(0)[:, None].expand(4, 3) / x[r::world].shape[0] for r in range(world)]
+        want = sum(per_rank) / world
+        for r in range(world):
+            assert torch.allclose(ret[r][i], want, atol=1e-6)

@@ -117,3 +117,40 @@ def test_resize_token_embeddings_and_pad_rows():
     out = m(**b)
     out.loss.backward()
     assert torch.isfinite(out.loss) and m.embed.grad[600].abs().sum() > 0
+
+
+def test_gqa_4_to_1_vs_decoder_oracle():
+    """A second shape (4 query heads per KV head, 3 layers, S = 128, default RoPE) against the
+    PyTorch oracle run in fp32 on the same device; exercises the per-group dK/dV accumulation."""
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    from oracle import llama_ref as R
+    cfgd = dict(vocab_size=515, hidden_size=256, intermediate_size=448, num_hidden_layers=3, num_attention_heads=4,
+                num_key_value_heads=1, head_dim=64, rms_norm_eps=1e-6)
+    params = R.random_params(cfgd, seed=3, device="cuda", std=0.05)
+    cfg = DecoderConfig(vocab_size=515, hidden_size=256, intermediate_size=448, num_hidden_layers=3, num_attention_heads=4,
+                        num_key_value_heads=1, rms_norm_eps=1e-6, rope_theta=10000.0, rope_scaling=None, pad_token_id=514)
+    m = HipCausalLM(cfg)
+    m.load_state_dict(params)
+    B, S = 2, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ids = torch.randint(0, 514, (B, S), device="cuda", generator=g)
+    mask = torch.ones(B, S, device="cuda"); mask[1, :70] = 0; ids[1, :70] = 514
+    pos = (torch.cumsum(mask, 1) - 1).clamp(min=0).long(); pos[mask == 0] = 0
+    labels = torch.full((B, S), -100, device="cuda"); labels[:, -30:] = ids[:, -30:]
+    ref_p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = R.llama_loss(ref_p, cfgd, ids, mask, labels, pos, R.llama3_inv_freq(64, 10000.0, None).cuda())
+    ref.backward()
+    out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
+    out.loss.backward()
+    assert abs(out.loss.item() - ref.item()) <= 1e-2 * ref.item()
+    Hq, Hkv, D = 4, 1, 64
+    for i in range(3):
+        got = m.wqkv[i].grad.float()
+        want = torch.cat([ref_p[f"model.layers.{i}.self_attn.{n}_proj.weight"].grad for n in "qkv"], 0)
+        rel = (got - want).norm() / want.norm()
+        assert rel.item() < 3e-2, (i, rel.item())
+        for name, gp in (("mlp.down_proj.weight", m.wdown[i].grad), ("self_attn.o_proj.weight", m.wo[i].grad)):
+            want = ref_p[f"model.layers.{i}.{name}"].grad
+            assert ((gp.float() - want).norm() / want.norm()).item() < 3e-2, (i, name)
+    want = ref_p["model.embed_tokens.weight"].grad
+    assert ((m.embed.grad[:515].float() - want).norm() / want.norm()).item() < 3e-2

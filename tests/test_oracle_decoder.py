@@ -1,0 +1,35 @@
+"""CPU test pinning the decoder oracle (oracle/llama_ref.py) to the vendored transformers goldens."""
+import os
+
+import numpy as np
+import torch
+
+from helpers import GOLDEN
+from oracle import llama_ref as R
+
+CFG = dict(vocab_size=300, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+           num_key_value_heads=1, head_dim=64, rms_norm_eps=1e-5)
+SCALING = {"factor": 32.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 32}
+
+
+def test_decoder_oracle_matches_vendored_transformers_fp32():
+    z = np.load(os.path.join(GOLDEN, "decoder_llama_tiny.npz"))
+    inv = R.llama3_inv_freq(64, 500000.0, SCALING)
+    assert np.allclose(inv.numpy(), z["inv_freq"], rtol=1e-6, atol=0)
+    params = {k[2:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("w:")}
+    loss = R.llama_loss(params, CFG, torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]),
+                        torch.from_numpy(z["labels"]), torch.from_numpy(z["position_ids"]), inv)
+    assert abs(loss.item() - float(z["loss_fp32"])) < 1e-5
+    loss.backward()
+    for k, p in params.items():
+        ref = torch.from_numpy(z["g:" + k])
+        assert torch.allclose(p.grad, ref, atol=1e-6, rtol=1e-4), k
+
+
+def test_decoder_oracle_bf16_close_to_reference_bf16():
+    z = np.load(os.path.join(GOLDEN, "decoder_llama_tiny.npz"))
+    inv = R.llama3_inv_freq(64, 500000.0, SCALING)
+    params = {k[2:]: torch.from_numpy(z[k]).to(torch.bfloat16) for k in z.files if k.startswith("w:")}
+    loss = R.llama_loss(params, CFG, torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]),
+                        torch.from_numpy(z["labels"]), torch.from_numpy(z["position_ids"]), inv)
+    assert abs(loss.item() - float(z["loss_bf16"])) < 2e-3
