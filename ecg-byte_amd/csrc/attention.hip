@@ -1,0 +1,441 @@
+// attention.hip -- fused causal grouped-query attention for MI355X (gfx950): forward, dQ, dK/dV.
+//
+// Reference: LlamaSdpaAttention.forward + the 4-D causal/left-padding mask
+// (transformers/src/transformers/models/llama/modeling_llama.py:526-614, 981-1100): key j is visible
+// to query i iff j <= i and attention_mask[b, j] != 0; softmax in fp32, P cast to bf16 for P.V.
+// Rows without a visible key (left-padding rows) produce zeros (don't-care in the reference).
+//
+// No S x S tensor ever exists in HBM.  One workgroup = 4 waves = 128 rows of one (batch, head);
+// K/V (or Q/dO) tiles of 64 rows are staged in LDS, once plain and once transposed.
+// The MFMA orientation is chosen so that the softmax row index sits on the LANE in every product:
+//   S^T = K . Q^T           A = K rows from LDS, B = Q rows held in registers   -> acc[key rows][q lanes]
+//   O^T = V^T . P^T         A = V^T rows from LDS, B = the S^T accumulator itself (cast to bf16)
+// so row max / row sum / rescale are per-lane scalars (one cross-half shuffle each), and the
+// accumulator of the first product is the B operand of the second with NO data movement: element
+// j of a 32x32x16 B fragment built from accumulator registers 8s..8s+7 is k = 16s + 8(j>>2) + 4h + (j&3)
+// (h = lane >> 5), and the transposed LDS tile is read in that same k order (two 8-byte reads).
+// The backward kernels reuse the scheme with the roles permuted (lanes = queries for dQ, lanes = keys
+// for dK/dV, which loops over the query heads of its KV group, so no atomics anywhere).
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "tokenizer.hpp"
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using bf16x4 = __attribute__((ext_vector_type(4))) short;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+__device__ __forceinline__ unsigned short f2bf(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+
+struct AttnArgs {
+    const unsigned short *q, *k, *v;      // [B*S rows]; row strides ldq/ldk/ldv; head hq at q + hq*D, kv head g at k + g*D
+    long long ldq, ldk, ldv;
+    const float *mask;                    // [B, S]
+    unsigned short *o;                    // forward output / (backward) forward output, row stride ldo
+    long long ldo;
+    float *lse;                           // [B, Hq, S]  (log2 domain, scale folded in; +inf for rows without keys)
+    const unsigned short *d_o;            // backward: dO, row stride ldo
+    float *delta;                         // [B, Hq, S]  rowsum(dO * O)
+    unsigned short *dq, *dk, *dv;         // backward outputs, row strides lddq / lddk / lddv
+    long long lddq, lddk, lddv;
+    int B, S, Hq, Hkv;
+    float scale;
+};
+
+// ---- LDS tile helpers (tiles of 64 rows x D) -----------------------------------------------------------
+// plain tile: row r at r*D*2 bytes, 16-byte slot c stored at slot c ^ ((r >> 1) & 7)
+template <int D>
+__device__ __forceinline__ void stage_plain(unsigned char *lds, const unsigned short *g, long long ld, int row0, int rows_valid)
+{
+    constexpr int kSlots = D / 8;
+    for (int i = threadIdx.x; i < 64 * kSlots; i += 256) {
+        const int r = i / kSlots, c = i % kSlots;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row0 + r < rows_valid) v = *reinterpret_cast<const bf16x8 *>(g + (long long)(row0 + r) * ld + c * 8);
+        *reinterpret_cast<bf16x8 *>(lds + r * (D * 2) + ((c ^ ((r >> 1) & 7)) << 4)) = v;
+    }
+}
+// A-operand fragment of a plain tile: row r, k = 16*ks + 8*h .. +7
+template <int D>
+__device__ __forceinline__ bf16x8 frag_plain(const unsigned char *lds, int r, int ks, int h)
+{
+    const int c = ks * 2 + h;
+    return *reinterpret_cast<const bf16x8 *>(lds + r * (D * 2) + ((c ^ ((r >> 1) & 7)) << 4));
+}
+// transposed tile: element (d, r) of a [D][64] image; row d at d*128 bytes, 8-byte slot s = r/4 stored at s ^ (d & 15)
+template <int D>
+__device__ __forceinline__ void stage_transposed(unsigned char *lds, const unsigned short *g, long long ld, int row0, int rows_valid)
+{
+    constexpr int kSlots = D / 8;
+    for (int i = threadIdx.x; i < 64 * kSlots; i += 256) {
+        const int r = i % 64, c = i / 64;          // consecutive lanes -> consecutive rows r (same d chunk): spreads LDS banks
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row0 + r < rows_valid) v = *reinterpret_cast<const bf16x8 *>(g + (long long)(row0 + r) * ld + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = c * 8 + j;
+            *reinterpret_cast<short *>(lds + d * 128 + ((((r >> 2) ^ (d & 15))) << 3) + (r & 3) * 2) = v[j];
+        }
+    }
+}
+// A-operand fragment of a transposed tile for accumulator-order k: row d, block kb (32 rows), k-step s (16 rows):
+// elements 0..3 = rows kb*32 + 16s + 4h + 0..3, elements 4..7 = rows kb*32 + 16s + 8 + 4h + 0..3
+__device__ __forceinline__ bf16x8 frag_transposed(const unsigned char *lds, int d, int kb, int s, int h)
+{
+    const int r0 = kb * 32 + 16 * s + 4 * h;
+    const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(lds + d * 128 + ((((r0 >> 2) ^ (d & 15))) << 3));
+    const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(lds + d * 128 + (((((r0 + 8) >> 2) ^ (d & 15))) << 3));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+// B-operand fragment made from accumulator registers 8s..8s+7
+__device__ __forceinline__ bf16x8 frag_from_acc(const float *p8)
+{
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (short)f2bf(p8[j]);
+    return f;
+}
+// row-operand fragments held in registers: row `row` of a global matrix, k = 16*ks + 8*h .. +7
+template <int D>
+__device__ __forceinline__ void load_row_frags(bf16x8 (&f)[D / 16], const unsigned short *g, long long ld, long long row, bool valid, int h)
+{
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (valid) v = *reinterpret_cast<const bf16x8 *>(g + row * ld + ks * 16 + h * 8);
+        f[ks] = v;
+    }
+}
+// accumulator (lane = row index, registers = d) -> global [row][d]: 4 consecutive d per register group
+template <int D>
+__device__ __forceinline__ void store_accT(const f32x16 (&acc)[D / 32], unsigned short *g, long long ld, long long row, bool valid, int h, float mul)
+{
+    if (!valid) return;
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            bf16x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (short)f2bf(acc[db][gq * 4 + j] * mul);
+            *reinterpret_cast<bf16x4 *>(g + row * ld + db * 32 + gq * 8 + 4 * h) = v;
+        }
+}
+
+// =====================================================================================================
+// forward: grid (ceil(S/128), Hq, B)
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds_k[64 * D * 2];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_vt[D * 128];
+    __shared__ float lds_mask[64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hq = blockIdx.y, g = hq / (A.Hq / A.Hkv);
+    const int q0 = blockIdx.x * 128;
+    const int qi = q0 + wave * 32 + lr;
+    const bool qvalid = qi < A.S;
+    const long long rowbase = (long long)b * A.S;
+    const unsigned short *Q = A.q + (long long)hq * D, *K = A.k + (long long)g * D, *V = A.v + (long long)g * D;
+    bf16x8 qf[D / 16];
+    load_row_frags<D>(qf, Q, A.ldq, rowbase + qi, qvalid, h);
+    f32x16 accO[D / 32];
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accO[db][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const float sc = A.scale * kLog2e;
+    const int k_end = min(A.S, q0 + 128);
+    const int wave_qmax = q0 + wave * 32 + 31;
+    for (int k0 = 0; k0 < k_end; k0 += 64) {
+        __syncthreads();
+        stage_plain<D>(lds_k, K + rowbase * A.ldk, A.ldk, k0, A.S);
+        stage_transposed<D>(lds_vt, V + rowbase * A.ldv, A.ldv, k0, A.S);
+        if (threadIdx.x < 64) lds_mask[threadIdx.x] = (k0 + (int)threadIdx.x < A.S) ? A.mask[rowbase + k0 + (int)threadIdx.x] : 0.f;
+        __syncthreads();
+        if (k0 > wave_qmax) continue;
+        float p[2][16];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_k, kb * 32 + lr, ks, h), qf[ks], s, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;       // key inside the tile
+                const bool vis = (k0 + kl <= qi) && (lds_mask[kl] != 0.f);
+                const float v = vis ? s[r] * sc : -INFINITY;
+                p[kb][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);
+        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;   // no key visible yet: every p below is exp2(-inf) = 0
+        const float alpha = exp2f(m - m_safe);                     // m = -inf -> 0 (accumulators are still zero then)
+        float lsum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = exp2f(p[kb][r] - m_safe); p[kb][r] = e; lsum += e; }
+        l = l * alpha + lsum;
+        m = m_new;
+#pragma unroll
+        for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accO[db][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = frag_from_acc(&p[kb][8 * s2]);
+#pragma unroll
+                for (int db = 0; db < D / 32; ++db)
+                    accO[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_vt, db * 32 + lr, kb, s2, h), pf, accO[db], 0, 0, 0);
+            }
+    }
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    store_accT<D>(accO, A.o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h, inv);
+    if (qvalid && h == 0) A.lse[((long long)b * A.Hq + hq) * A.S + qi] = lt > 0.f ? m + log2f(lt) : INFINITY;
+}
+
+// =====================================================================================================
+// backward, dQ (and delta): grid (ceil(S/128), Hq, B); lanes = queries
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds_k[64 * D * 2];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_v[64 * D * 2];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_kt[D * 128];
+    __shared__ float lds_mask[64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, hq = blockIdx.y, g = hq / (A.Hq / A.Hkv);
+    const int q0 = blockIdx.x * 128;
+    const int qi = q0 + wave * 32 + lr;
+    const bool qvalid = qi < A.S;
+    const long long rowbase = (long long)b * A.S;
+    const unsigned short *Q = A.q + (long long)hq * D, *K = A.k + (long long)g * D, *V = A.v + (long long)g * D;
+    bf16x8 qf[D / 16], dof[D / 16], of[D / 16];
+    load_row_frags<D>(qf, Q, A.ldq, rowbase + qi, qvalid, h);
+    load_row_frags<D>(dof, A.d_o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h);
+    load_row_frags<D>(of, A.o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h);
+    float delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += bf2f((unsigned short)dof[ks][j]) * bf2f((unsigned short)of[ks][j]);
+    delta += __shfl_xor(delta, 32, 64);
+    const long long stat = ((long long)b * A.Hq + hq) * A.S + qi;
+    if (qvalid && h == 0) A.delta[stat] = delta;
+    const float lse = qvalid ? A.lse[stat] : INFINITY;
+    f32x16 accQ[D / 32];
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accQ[db][r] = 0.f;
+    const float sc = A.scale * kLog2e;
+    const int k_end = min(A.S, q0 + 128);
+    const int wave_qmax = q0 + wave * 32 + 31;
+    for (int k0 = 0; k0 < k_end; k0 += 64) {
+        __syncthreads();
+        stage_plain<D>(lds_k, K + rowbase * A.ldk, A.ldk, k0, A.S);
+        stage_plain<D>(lds_v, V + rowbase * A.ldv, A.ldv, k0, A.S);
+        stage_transposed<D>(lds_kt, K + rowbase * A.ldk, A.ldk, k0, A.S);
+        if (threadIdx.x < 64) lds_mask[threadIdx.x] = (k0 + (int)threadIdx.x < A.S) ? A.mask[rowbase + k0 + (int)threadIdx.x] : 0.f;
+        __syncthreads();
+        if (k0 > wave_qmax) continue;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_k, kb * 32 + lr, ks, h), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_v, kb * 32 + lr, ks, h), dof[ks], dp, 0, 0, 0);
+            }
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const bool vis = (k0 + kl <= qi) && (lds_mask[kl] != 0.f);
+                const float pr = vis ? exp2f(s[r] * sc - lse) : 0.f;
+                ds[r] = pr * (dp[r] - delta) * A.scale;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 dsf = frag_from_acc(&ds[8 * s2]);
+#pragma unroll
+                for (int db = 0; db < D / 32; ++db)
+                    accQ[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_kt, db * 32 + lr, kb, s2, h), dsf, accQ[db], 0, 0, 0);
+            }
+        }
+    }
+    store_accT<D>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, 1.f);
+}
+
+// =====================================================================================================
+// backward, dK and dV: grid (ceil(S/128), Hkv, B); lanes = keys; loops over the query heads of the group
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs A)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds_q[64 * D * 2];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_do[64 * D * 2];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_qt[D * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_dot[D * 128];
+    __shared__ float lds_lse[64], lds_delta[64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, g = blockIdx.y, G = A.Hq / A.Hkv;
+    const int kk0 = blockIdx.x * 128;
+    const int ki = kk0 + wave * 32 + lr;
+    const bool kvalid = ki < A.S;
+    const long long rowbase = (long long)b * A.S;
+    bf16x8 kf[D / 16], vf[D / 16];
+    load_row_frags<D>(kf, A.k + (long long)g * D, A.ldk, rowbase + ki, kvalid, h);
+    load_row_frags<D>(vf, A.v + (long long)g * D, A.ldv, rowbase + ki, kvalid, h);
+    const bool kvis = kvalid && A.mask[rowbase + (kvalid ? ki : 0)] != 0.f;
+    f32x16 accK[D / 32], accV[D / 32];
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accK[db][r] = 0.f; accV[db][r] = 0.f; }
+    const float sc = A.scale * kLog2e;
+    const int wave_kmin = kk0 + wave * 32;
+    for (int j = 0; j < G; ++j) {
+        const int hq = g * G + j;
+        const unsigned short *Q = A.q + (long long)hq * D + rowbase * A.ldq;
+        const unsigned short *dO = A.d_o + (long long)hq * D + rowbase * A.ldo;
+        const long long stat = ((long long)b * A.Hq + hq) * A.S;
+        for (int t0 = (kk0 / 64) * 64; t0 < A.S; t0 += 64) {      // query tiles that can see this key block
+            __syncthreads();
+            stage_plain<D>(lds_q, Q, A.ldq, t0, A.S);
+            stage_plain<D>(lds_do, dO, A.ldo, t0, A.S);
+            stage_transposed<D>(lds_qt, Q, A.ldq, t0, A.S);
+            stage_transposed<D>(lds_dot, dO, A.ldo, t0, A.S);
+            if (threadIdx.x < 64) {
+                const bool v = t0 + (int)threadIdx.x < A.S;
+                lds_lse[threadIdx.x] = v ? A.lse[stat + t0 + threadIdx.x] : INFINITY;
+                lds_delta[threadIdx.x] = v ? A.delta[stat + t0 + threadIdx.x] : 0.f;
+            }
+            __syncthreads();
+            if (t0 + 63 < wave_kmin) continue;        // every query of the tile precedes every key of this wave
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < D / 16; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_q, qb * 32 + lr, ks, h), kf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_do, qb * 32 + lr, ks, h), vf[ks], dp, 0, 0, 0);
+                }
+                float pr[16], ds[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;     // query inside the tile
+                    const bool vis = kvis && (ki <= t0 + ql);
+                    const float e = vis ? exp2f(s[r] * sc - lds_lse[ql]) : 0.f;
+                    pr[r] = e;
+                    ds[r] = e * (dp[r] - lds_delta[ql]) * A.scale;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 pf = frag_from_acc(&pr[8 * s2]);
+                    const bf16x8 dsf = frag_from_acc(&ds[8 * s2]);
+#pragma unroll
+                    for (int db = 0; db < D / 32; ++db) {
+                        accV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_dot, db * 32 + lr, qb, s2, h), pf, accV[db], 0, 0, 0);
+                        accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_qt, db * 32 + lr, qb, s2, h), dsf, accK[db], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    store_accT<D>(accK, A.dk + (long long)g * D, A.lddk, rowbase + ki, kvalid, h, 1.f);
+    store_accT<D>(accV, A.dv + (long long)g * D, A.lddv, rowbase + ki, kvalid, h, 1.f);
+}
+
+int check_args(const AttnArgs &A, int D, const char *who)
+{
+    if (A.B <= 0 || A.S <= 0 || A.Hq <= 0 || A.Hkv <= 0 || A.Hq % A.Hkv) {
+        ecgb::set_error(std::string(who) + ": bad shape");
+        return ECGB_ERR_INVALID;
+    }
+    if (D != 64) {
+        ecgb::set_error(std::string(who) + ": head_dim must be 64 in this build");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    if (A.ldq % 8 || A.ldk % 8 || A.ldv % 8 || A.ldo % 8) {
+        ecgb::set_error(std::string(who) + ": row strides must be multiples of 8 elements");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    return ECGB_OK;
+}
+
+int launched(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return ECGB_OK;
+    ecgb::set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return ECGB_ERR_HIP;
+}
+
+}  // namespace
+
+extern "C" int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev, long long ldk, const void *v_dev, long long ldv,
+                             const float *attn_mask_dev, void *o_dev, long long ldo, float *lse_dev, int batch, int seq,
+                             int n_q_heads, int n_kv_heads, int head_dim, float scale, void *stream)
+{
+    AttnArgs A = {};
+    A.q = (const unsigned short *)q_dev; A.k = (const unsigned short *)k_dev; A.v = (const unsigned short *)v_dev;
+    A.ldq = ldq; A.ldk = ldk; A.ldv = ldv; A.mask = attn_mask_dev; A.o = (unsigned short *)o_dev; A.ldo = ldo; A.lse = lse_dev;
+    A.B = batch; A.S = seq; A.Hq = n_q_heads; A.Hkv = n_kv_heads; A.scale = scale;
+    int rc = check_args(A, head_dim, "ecgb_attn_fwd");
+    if (rc) return rc;
+    const dim3 grid((unsigned)((seq + 127) / 128), (unsigned)n_q_heads, (unsigned)batch);
+    hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, A);
+    return launched("attn_fwd_kernel");
+}
+
+extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev, long long ldk, const void *v_dev, long long ldv,
+                             const float *attn_mask_dev, const void *o_dev, const void *do_dev, long long ldo,
+                             const float *lse_dev, float *delta_dev, void *dq_dev, long long lddq, void *dk_dev, long long lddk,
+                             void *dv_dev, long long lddv, int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim,
+                             float scale, void *stream)
+{
+    AttnArgs A = {};
+    A.q = (const unsigned short *)q_dev; A.k = (const unsigned short *)k_dev; A.v = (const unsigned short *)v_dev;
+    A.ldq = ldq; A.ldk = ldk; A.ldv = ldv; A.mask = attn_mask_dev; A.o = (unsigned short *)const_cast<void *>(o_dev); A.ldo = ldo;
+    A.lse = const_cast<float *>(lse_dev); A.d_o = (const unsigned short *)do_dev; A.delta = delta_dev;
+    A.dq = (unsigned short *)dq_dev; A.dk = (unsigned short *)dk_dev; A.dv = (unsigned short *)dv_dev;
+    A.lddq = lddq; A.lddk = lddk; A.lddv = lddv;
+    A.B = batch; A.S = seq; A.Hq = n_q_heads; A.Hkv = n_kv_heads; A.scale = scale;
+    int rc = check_args(A, head_dim, "ecgb_attn_bwd");
+    if (rc) return rc;
+    if (lddq % 4 || lddk % 4 || lddv % 4) { ecgb::set_error("ecgb_attn_bwd: gradient row strides must be multiples of 4"); return ECGB_ERR_UNSUPPORTED; }
+    const dim3 gq((unsigned)((seq + 127) / 128), (unsigned)n_q_heads, (unsigned)batch);
+    const dim3 gk((unsigned)((seq + 127) / 128), (unsigned)n_kv_heads, (unsigned)batch);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(256), 0, (hipStream_t)stream, A);
+    return launched("attn_bwd kernels");
+}

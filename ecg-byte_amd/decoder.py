@@ -129,6 +129,7 @@ class HipCausalLM(nn.Module):
         self.full_logits = False   # True: run the loss head over every row, as the reference materialises it
         self._saved = None
         self.grad_sync = None      # parallel.GradAllReduce: told as soon as a layer's gradients are final
+        self.fused_attention = cfg.head_dim == 64   # False: materialised scores (batched GEMM + softmax kernels)
 
     # ---- HF-style surface -------------------------------------------------------------------
     @property
@@ -237,15 +238,18 @@ class HipCausalLM(nn.Module):
             qkv = ops.gemm_nt(h1, self.wqkv[i].data)                    # [T, QKV]
             ops.rope_(qkv, cos, sin, Hq, D, QKV)
             _rope_offset(qkv, Hq * D, cos, sin, Hkv, D, QKV)
-            P = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
-            ops.gemm_nt_heads((qkv, 0), QKV, (qkv, Hq * D), QKV, P, S, S, S, D, 1.0, B * Hq, Hq,
-                              S * QKV, D, 1, S * QKV, D, G, Hq * S * S, S * S)
-            ops.softmax_causal_fwd_(P, mask, Hq, scale)
-            vT = torch.empty((B, Hkv, D, S), dtype=torch.bfloat16, device=dev)
-            ops.transpose_strided(qkv, Hq * D + Hkv * D, vT, 0, S, D, QKV, S, B * Hkv, Hkv, S * QKV, D, Hkv * D * S, D * S)
-            ao = torch.empty((T, Hq * D), dtype=torch.bfloat16, device=dev)
-            ops.gemm_nt_heads(P, S, vT, S, ao, Hq * D, S, D, S, 1.0, B * Hq, Hq, Hq * S * S, S * S, 1,
-                              Hkv * D * S, D * S, G, S * Hq * D, D)
+            if self.fused_attention:
+                ao, P = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)       # P slot holds the row log-sum-exps
+            else:
+                P = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
+                ops.gemm_nt_heads((qkv, 0), QKV, (qkv, Hq * D), QKV, P, S, S, S, D, 1.0, B * Hq, Hq,
+                                  S * QKV, D, 1, S * QKV, D, G, Hq * S * S, S * S)
+                ops.softmax_causal_fwd_(P, mask, Hq, scale)
+                vT = torch.empty((B, Hkv, D, S), dtype=torch.bfloat16, device=dev)
+                ops.transpose_strided(qkv, Hq * D + Hkv * D, vT, 0, S, D, QKV, S, B * Hkv, Hkv, S * QKV, D, Hkv * D * S, D * S)
+                ao = torch.empty((T, Hq * D), dtype=torch.bfloat16, device=dev)
+                ops.gemm_nt_heads(P, S, vT, S, ao, Hq * D, S, D, S, 1.0, B * Hq, Hq, Hq * S * S, S * S, 1,
+                                  Hkv * D * S, D * S, G, S * Hq * D, D)
             attn_delta = ops.gemm_nt(ao, self.wo[i].data)               # [T, H]
             h2, rstd2, x2 = ops.rmsnorm_fwd(x1, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta)
             gu = ops.gemm_nt(h2, self.wgu[i].data)                      # [T, 2I]
@@ -333,30 +337,34 @@ class HipCausalLM(nn.Module):
             wgrad(g2, ao, self.wo[i])
             d_ao = ops.gemm_nt(g2, self._shadow(("wo", i), self.wo[i]))             # [T, Hq*D]
             # attention core
-            d_qkv = torch.empty((T, QKV), dtype=torch.bfloat16, device=dev)
-            dP = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
-            ops.gemm_nt_heads(d_ao, Hq * D, (qkv, Hq * D + Hkv * D), QKV, dP, S, S, S, D, 1.0, B * Hq, Hq,
-                              S * Hq * D, D, 1, S * QKV, D, G, Hq * S * S, S * S)   # dP = dO . V^T
-            ops.softmax_bwd_(P, dP, scale)                                           # dP <- dS
-            kT = torch.empty((B, Hkv, D, S), dtype=torch.bfloat16, device=dev)
-            ops.transpose_strided(qkv, Hq * D, kT, 0, S, D, QKV, S, B * Hkv, Hkv, S * QKV, D, Hkv * D * S, D * S)
-            ops.gemm_nt_heads(dP, S, kT, S, (d_qkv, 0), QKV, S, D, S, 1.0, B * Hq, Hq, Hq * S * S, S * S, 1,
-                              Hkv * D * S, D * S, G, S * QKV, D)                     # dQ = dS . K
-            tmpT = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
-            qT = torch.empty((B, Hq, D, S), dtype=torch.bfloat16, device=dev)
-            ops.transpose_strided(qkv, 0, qT, 0, S, D, QKV, S, B * Hq, Hq, S * QKV, D, Hq * D * S, D * S)
-            doT = torch.empty((B, Hq, D, S), dtype=torch.bfloat16, device=dev)
-            ops.transpose_strided(d_ao, 0, doT, 0, S, D, Hq * D, S, B * Hq, Hq, S * Hq * D, D, Hq * D * S, D * S)
-            dkv32 = torch.zeros((2, B, S, Hkv * D), dtype=torch.float32, device=dev)
-            for which, (src, rhs) in enumerate(((dP, qT), (P, doT))):                # dK = dS^T . Q ; dV = P^T . dO
-                ops.transpose_strided(src, 0, tmpT, 0, S, S, S, S, B * Hq, 1, S * S, 0, S * S, 0)
-                for j in range(G):   # the G query heads of a KV head accumulate into the same fp32 tile
-                    ops.gemm_nt_heads((tmpT, j * S * S), S, (rhs, j * D * S), S, dkv32[which], Hkv * D, S, D, S, 1.0,
-                                      B * Hkv, Hkv, Hq * S * S, G * S * S, 1, Hq * D * S, G * D * S, 1,
-                                      S * Hkv * D, D, accumulate_f32=True)
-            d_qkv[:, Hq * D: Hq * D + Hkv * D] = dkv32[0].view(T, Hkv * D).to(torch.bfloat16)
-            d_qkv[:, Hq * D + Hkv * D:] = dkv32[1].view(T, Hkv * D).to(torch.bfloat16)
-            del dP, tmpT, P
+            if self.fused_attention:
+                d_qkv = ops.attn_bwd(qkv, mask, ao, d_ao, P, B, S, Hq, Hkv, D, scale)
+            else:
+                d_qkv = torch.empty((T, QKV), dtype=torch.bfloat16, device=dev)
+                dP = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
+                ops.gemm_nt_heads(d_ao, Hq * D, (qkv, Hq * D + Hkv * D), QKV, dP, S, S, S, D, 1.0, B * Hq, Hq,
+                                  S * Hq * D, D, 1, S * QKV, D, G, Hq * S * S, S * S)   # dP = dO . V^T
+                ops.softmax_bwd_(P, dP, scale)                                           # dP <- dS
+                kT = torch.empty((B, Hkv, D, S), dtype=torch.bfloat16, device=dev)
+                ops.transpose_strided(qkv, Hq * D, kT, 0, S, D, QKV, S, B * Hkv, Hkv, S * QKV, D, Hkv * D * S, D * S)
+                ops.gemm_nt_heads(dP, S, kT, S, (d_qkv, 0), QKV, S, D, S, 1.0, B * Hq, Hq, Hq * S * S, S * S, 1,
+                                  Hkv * D * S, D * S, G, S * QKV, D)                     # dQ = dS . K
+                tmpT = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
+                qT = torch.empty((B, Hq, D, S), dtype=torch.bfloat16, device=dev)
+                ops.transpose_strided(qkv, 0, qT, 0, S, D, QKV, S, B * Hq, Hq, S * QKV, D, Hq * D * S, D * S)
+                doT = torch.empty((B, Hq, D, S), dtype=torch.bfloat16, device=dev)
+                ops.transpose_strided(d_ao, 0, doT, 0, S, D, Hq * D, S, B * Hq, Hq, S * Hq * D, D, Hq * D * S, D * S)
+                dkv32 = torch.zeros((2, B, S, Hkv * D), dtype=torch.float32, device=dev)
+                for which, (src, rhs) in enumerate(((dP, qT), (P, doT))):                # dK = dS^T . Q ; dV = P^T . dO
+                    ops.transpose_strided(src, 0, tmpT, 0, S, S, S, S, B * Hq, 1, S * S, 0, S * S, 0)
+                    for j in range(G):   # the G query heads of a KV head accumulate into the same fp32 tile
+                        ops.gemm_nt_heads((tmpT, j * S * S), S, (rhs, j * D * S), S, dkv32[which], Hkv * D, S, D, S, 1.0,
+                                          B * Hkv, Hkv, Hq * S * S, G * S * S, 1, Hq * D * S, G * D * S, 1,
+                                          S * Hkv * D, D, accumulate_f32=True)
+                d_qkv[:, Hq * D: Hq * D + Hkv * D] = dkv32[0].view(T, Hkv * D).to(torch.bfloat16)
+                d_qkv[:, Hq * D + Hkv * D:] = dkv32[1].view(T, Hkv * D).to(torch.bfloat16)
+                del dP, tmpT
+            del P
             ops.rope_(d_qkv, cos, sin, Hq, D, QKV, inverse=True)
             _rope_offset(d_qkv, Hq * D, cos, sin, Hkv, D, QKV, inverse=True)
             wgrad(d_qkv, h1, self.wqkv[i])

@@ -150,3 +150,28 @@ def adam_step_(p, g, m, v, sumsq_acc, max_norm, lr, beta1, beta2, eps, weight_de
     _lib.check(_L().ecgb_adam_step(_p(p), _p(g), int(g.dtype == torch.float32), _p(m), _p(v), p.numel(), _p(sumsq_acc),
                                    float(max_norm), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                                    int(step), _st()))
+
+
+def _off(t, off):
+    return C.c_void_p(t.data_ptr() + off * t.element_size())
+
+
+def attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale):
+    """Fused attention on a fused qkv buffer [B*S, Hq*D + 2*Hkv*D] (q | k | v).  Returns (o [B*S, Hq*D], lse)."""
+    QKV = qkv.shape[1]
+    o = torch.empty((B * S, Hq * D), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B, Hq, S), dtype=torch.float32, device=qkv.device)
+    _lib.check(_L().ecgb_attn_fwd(_off(qkv, 0), QKV, _off(qkv, Hq * D), QKV, _off(qkv, Hq * D + Hkv * D), QKV, _p(mask),
+                                  _p(o), Hq * D, _p(lse), B, S, Hq, Hkv, D, float(scale), _st()))
+    return o, lse
+
+
+def attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale):
+    """Returns d_qkv with the same fused layout as qkv."""
+    QKV = qkv.shape[1]
+    d_qkv = torch.empty_like(qkv)
+    delta = torch.empty((B, Hq, S), dtype=torch.float32, device=qkv.device)
+    _lib.check(_L().ecgb_attn_bwd(_off(qkv, 0), QKV, _off(qkv, Hq * D), QKV, _off(qkv, Hq * D + Hkv * D), QKV, _p(mask),
+                                  _p(o), _p(_bf(do)), Hq * D, _p(lse), _p(delta), _off(d_qkv, 0), QKV, _off(d_qkv, Hq * D), QKV,
+                                  _off(d_qkv, Hq * D + Hkv * D), QKV, B, S, Hq, Hkv, D, float(scale), _st()))
+    return d_qkv

@@ -8,8 +8,9 @@
  *   ecgb_rmsnorm_fwd/bwd   LlamaRMSNorm.forward, modeling_llama.py:67-72 (gemma=1: GemmaRMSNorm, models/gemma/modeling_gemma.py:51-68)
  *   ecgb_rope              apply_rotary_pos_emb / rotate_half, modeling_llama.py:193-224
  *   ecgb_gemm_nt_bf16      every nn.Linear of the block (q/k/v/o_proj, gate/up/down_proj, lm_head), modeling_llama.py:227-395,1209
- *   ecgb_softmax_causal_fwd/bwd   the softmax of LlamaSdpaAttention.forward incl. the causal + left-padding mask,
- *                          modeling_llama.py:526-614,981-1100 (QK^T and PV are ecgb_gemm_nt_bf16 batches)
+ *   ecgb_attn_fwd/bwd      LlamaSdpaAttention.forward incl. the causal + left-padding mask, modeling_llama.py:526-614,981-1100
+ *   ecgb_softmax_causal_fwd/bwd   the same through materialised scores (QK^T and PV as ecgb_gemm_nt_bf16 batches);
+ *                          kept as the second implementation the fused kernels are tested against
  *   ecgb_glu_fwd/bwd       LlamaMLP act_fn(gate) * up, modeling_llama.py:238-258 (gelu_tanh=1: GemmaMLP)
  *   ecgb_ce_fwd_bwd        ForCausalLMLoss, transformers/src/transformers/loss/loss_utils.py:24-47
  *   ecgb_sumsq, ecgb_adam_step   clip_grad_norm_(1.0) + Adam(weight_decay = L2), ecg_byte/runners/train.py:26, ecg_byte/main.py:262-264
@@ -95,6 +96,21 @@ int ecgb_softmax_causal_fwd(void *scores_dev, const float *attn_mask_dev, int ba
                             float scale, void *stream);
 /* In place on dp_dev: dS = scale * P * (dP - rowsum(P * dP)). */
 int ecgb_softmax_bwd(const void *p_dev, void *dp_dev, int batch_heads, int seq, float scale, void *stream);
+
+/* Fused causal grouped-query attention (no S x S tensor in HBM): K/V tiles staged in LDS, softmax in
+ * registers, MFMA for QK^T and PV.  q/k/v/o are [batch*seq] rows with the given row strides (elements);
+ * query head hq starts at q + hq*head_dim, KV head g at k + g*head_dim (so slices of a fused qkv buffer work).
+ * Key j is visible to query i iff j <= i and attn_mask[b, j] != 0; rows without a visible key give zeros.
+ * lse_dev [batch, n_q_heads, seq] fp32 is saved for the backward.  head_dim == 64 in this build. */
+int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev, long long ldk, const void *v_dev, long long ldv,
+                  const float *attn_mask_dev, void *o_dev, long long ldo, float *lse_dev, int batch, int seq,
+                  int n_q_heads, int n_kv_heads, int head_dim, float scale, void *stream);
+/* dq/dk/dv from dO (same layout as o).  delta_dev [batch, n_q_heads, seq] fp32 is scratch (rowsum(dO*O)).
+ * dK/dV sum over the query heads of each KV group inside the kernel (no atomics). */
+int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev, long long ldk, const void *v_dev, long long ldv,
+                  const float *attn_mask_dev, const void *o_dev, const void *do_dev, long long ldo, const float *lse_dev,
+                  float *delta_dev, void *dq_dev, long long lddq, void *dk_dev, long long lddk, void *dv_dev,
+                  long long lddv, int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim, float scale, void *stream);
 
 #ifdef __cplusplus
 }

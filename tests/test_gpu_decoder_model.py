@@ -47,10 +47,12 @@ def test_state_dict_roundtrip_hf_names():
     assert "lm_head.weight" in sd and torch.equal(sd["lm_head.weight"], sd["model.embed_tokens.weight"])
 
 
+@pytest.mark.parametrize("fused_attention", [True, False], ids=["fused-attn", "materialised-scores"])
 @pytest.mark.parametrize("full_logits", [False, True])
-def test_loss_and_gradients_vs_vendored_transformers(full_logits):
+def test_loss_and_gradients_vs_vendored_transformers(full_logits, fused_attention):
     z, m = _load()
     m.full_logits = full_logits
+    m.fused_attention = fused_attention
     out = m(**_batch(z))
     loss = out.loss
     assert abs(loss.item() - float(z["loss_fp32"])) <= 1e-2 * float(z["loss_fp32"]), (loss.item(), float(z["loss_fp32"]))
@@ -119,7 +121,8 @@ def test_resize_token_embeddings_and_pad_rows():
     assert torch.isfinite(out.loss) and m.embed.grad[600].abs().sum() > 0
 
 
-def test_gqa_4_to_1_vs_decoder_oracle():
+@pytest.mark.parametrize("fused_attention", [True, False], ids=["fused-attn", "materialised-scores"])
+def test_gqa_4_to_1_vs_decoder_oracle(fused_attention):
     """A second shape (4 query heads per KV head, 3 layers, S = 128, default RoPE) against the
     PyTorch oracle run in fp32 on the same device; exercises the per-group dK/dV accumulation."""
     from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
@@ -130,6 +133,7 @@ def test_gqa_4_to_1_vs_decoder_oracle():
     cfg = DecoderConfig(vocab_size=515, hidden_size=256, intermediate_size=448, num_hidden_layers=3, num_attention_heads=4,
                         num_key_value_heads=1, rms_norm_eps=1e-6, rope_theta=10000.0, rope_scaling=None, pad_token_id=514)
     m = HipCausalLM(cfg)
+    m.fused_attention = fused_attention
     m.load_state_dict(params)
     B, S = 2, 128
     g = torch.Generator(device="cuda").manual_seed(5)

@@ -183,3 +183,34 @@ def test_adam_with_clipping_matches_torch(ops):
         ops.adam_step_(p, gs, m, v, acc, 1.0, 1e-3, 0.9, 0.99, 1e-8, 1e-2, step)
         # the bf16 parameter follows the fp32 trajectory to within bf16 rounding of the parameter
         _close(p, ref_p.detach(), atol=1e-3 * step, rtol=2 ** -7 * step)
+
+
+@pytest.mark.parametrize("B,S,Hq,Hkv", [(2, 128, 4, 1), (1, 192, 2, 2), (3, 64, 2, 1), (2, 320, 8, 2)])
+def test_fused_attention_forward_backward(ops, B, S, Hq, Hkv):
+    """Fused attention (no S x S tensor) vs an fp32 PyTorch reference with the reference's mask semantics
+    (causal AND key not padded; modeling_llama.py:1047-1100), incl. left padding and partial 128-row blocks."""
+    D = 64
+    QKV = Hq * D + 2 * Hkv * D
+    qkv = _bf(B * S, QKV, seed=30)
+    mask = torch.ones(B, S, device="cuda")
+    mask[0, : S // 3] = 0
+    scale = 1.0 / math.sqrt(D)
+    o, lse = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)
+    x = qkv.float().view(B, S, QKV).clone().requires_grad_(True)
+    q = x[..., : Hq * D].reshape(B, S, Hq, D).transpose(1, 2)
+    k = x[..., Hq * D: Hq * D + Hkv * D].reshape(B, S, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, 1)
+    v = x[..., Hq * D + Hkv * D:].reshape(B, S, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, 1)
+    vis = torch.tril(torch.ones(S, S, device="cuda", dtype=torch.bool))[None, None] & (mask[:, None, None, :] != 0)
+    sc = (q @ k.transpose(-1, -2)) * scale
+    p = torch.nan_to_num(torch.softmax(sc.masked_fill(~vis, float("-inf")), -1), nan=0.0)
+    ref = (p.to(torch.bfloat16).float() @ v).transpose(1, 2).reshape(B * S, Hq * D)
+    _close(o, ref, atol=2e-2)
+    assert bool((o.view(B, S, -1)[0, : S // 3] == 0).all())                 # pad rows -> zeros
+    do = _bf(B * S, Hq * D, seed=31)
+    ref.backward(do.float())
+    d_qkv = ops.attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale)
+    want = x.grad.view(B * S, QKV)
+    for name, lo, hi in (("dq", 0, Hq * D), ("dk", Hq * D, Hq * D + Hkv * D), ("dv", Hq * D + Hkv * D, QKV)):
+        g, w = d_qkv[:, lo:hi].float(), want[:, lo:hi]
+        rel = (g - w).norm() / w.norm()
+        assert rel.item() < 2e-2, (name, rel.item())
