@@ -55,16 +55,44 @@ struct AttnArgs {
 };
 
 // ---- LDS tile helpers (tiles of 64 rows x D) -----------------------------------------------------------
-// plain tile: row r at r*D*2 bytes, 16-byte slot c stored at slot c ^ ((r >> 1) & 7)
+// Staging work item = 4 consecutive rows x one 16-byte chunk (8 d): 16 row groups x D/8 chunks per tile, i.e.
+// 128 items for D = 64 -- threads 0..127 take one tile, 128..255 another.  The four 16-byte global loads of an
+// item are issued back to back into registers (`Stage4`), one tile AHEAD of its use, and written to LDS
+// after the barrier that retires the previous tile: plain image (row r at r*D*2 bytes, 16-byte slot c at
+// c ^ ((r >> 1) & 7)) and/or transposed image ([D][64]: row d at d*128 bytes, the 8-byte slot holding rows
+// 4*rg..4*rg+3 at rg ^ (d & 15)).
+struct Stage4 { bf16x8 v[4]; };
+
 template <int D>
-__device__ __forceinline__ void stage_plain(unsigned char *lds, const unsigned short *g, long long ld, int row0, int rows_valid)
+__device__ __forceinline__ void stage_load(Stage4 &st, const unsigned short *g, long long ld, int row0, int rows_valid, int item)
 {
-    constexpr int kSlots = D / 8;
-    for (int i = threadIdx.x; i < 64 * kSlots; i += 256) {
-        const int r = i / kSlots, c = i % kSlots;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (row0 + r < rows_valid) v = *reinterpret_cast<const bf16x8 *>(g + (long long)(row0 + r) * ld + c * 8);
-        *reinterpret_cast<bf16x8 *>(lds + r * (D * 2) + ((c ^ ((r >> 1) & 7)) << 4)) = v;
+    const int rg = item % 16, c = item / 16;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = row0 + rg * 4 + t;
+        st.v[t] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < rows_valid) st.v[t] = *reinterpret_cast<const bf16x8 *>(g + (long long)r * ld + c * 8);
+    }
+}
+template <int D>
+__device__ __forceinline__ void stage_write_plain(unsigned char *lds, const Stage4 &st, int item)
+{
+    const int rg = item % 16, c = item / 16;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = rg * 4 + t;
+        *reinterpret_cast<bf16x8 *>(lds + r * (D * 2) + ((c ^ ((r >> 1) & 7)) << 4)) = st.v[t];
+    }
+}
+__device__ __forceinline__ void stage_write_transposed(unsigned char *lds, const Stage4 &st, int item)
+{
+    const int rg = item % 16, c = item / 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int d = c * 8 + j;
+        bf16x4 w;
+        w[0] = st.v[0][j]; w[1] = st.v[1][j]; w[2] = st.v[2][j]; w[3] = st.v[3][j];
+        *reinterpret_cast<bf16x4 *>(lds + d * 128 + ((rg ^ (d & 15)) << 3)) = w;
     }
 }
 // A-operand fragment of a plain tile: row r, k = 16*ks + 8*h .. +7
@@ -73,22 +101,6 @@ __device__ __forceinline__ bf16x8 frag_plain(const unsigned char *lds, int r, in
 {
     const int c = ks * 2 + h;
     return *reinterpret_cast<const bf16x8 *>(lds + r * (D * 2) + ((c ^ ((r >> 1) & 7)) << 4));
-}
-// transposed tile: element (d, r) of a [D][64] image; row d at d*128 bytes, 8-byte slot s = r/4 stored at s ^ (d & 15)
-template <int D>
-__device__ __forceinline__ void stage_transposed(unsigned char *lds, const unsigned short *g, long long ld, int row0, int rows_valid)
-{
-    constexpr int kSlots = D / 8;
-    for (int i = threadIdx.x; i < 64 * kSlots; i += 256) {
-        const int r = i % 64, c = i / 64;          // consecutive lanes -> consecutive rows r (same d chunk): spreads LDS banks
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (row0 + r < rows_valid) v = *reinterpret_cast<const bf16x8 *>(g + (long long)(row0 + r) * ld + c * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int d = c * 8 + j;
-            *reinterpret_cast<short *>(lds + d * 128 + ((((r >> 2) ^ (d & 15))) << 3) + (r & 3) * 2) = v[j];
-        }
-    }
 }
 // A-operand fragment of a transposed tile for accumulator-order k: row d, block kb (32 rows), k-step s (16 rows):
 // elements 0..3 = rows kb*32 + 16s + 4h + 0..3, elements 4..7 = rows kb*32 + 16s + 8 + 4h + 0..3
@@ -162,11 +174,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
     const float sc = A.scale * kLog2e;
     const int k_end = min(A.S, q0 + 128);
     const int wave_qmax = q0 + wave * 32 + 31;
+    static_assert(D == 64, "staging assumes 128 work items per tile");
+    const int item = threadIdx.x & 127;
+    const bool first_half = threadIdx.x < 128;
+    const unsigned short *src = first_half ? K + rowbase * A.ldk : V + rowbase * A.ldv;
+    const long long src_ld = first_half ? A.ldk : A.ldv;
+    Stage4 st;
+    stage_load<D>(st, src, src_ld, 0, A.S, item);
     for (int k0 = 0; k0 < k_end; k0 += 64) {
         __syncthreads();
-        stage_plain<D>(lds_k, K + rowbase * A.ldk, A.ldk, k0, A.S);
-        stage_transposed<D>(lds_vt, V + rowbase * A.ldv, A.ldv, k0, A.S);
+        if (first_half) stage_write_plain<D>(lds_k, st, item); else stage_write_transposed(lds_vt, st, item);
         if (threadIdx.x < 64) lds_mask[threadIdx.x] = (k0 + (int)threadIdx.x < A.S) ? A.mask[rowbase + k0 + (int)threadIdx.x] : 0.f;
+        if (k0 + 64 < k_end) stage_load<D>(st, src, src_ld, k0 + 64, A.S, item);   // next tile in flight behind the MFMAs
         __syncthreads();
         if (k0 > wave_qmax) continue;
         float p[2][16];
@@ -256,12 +275,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
     const float sc = A.scale * kLog2e;
     const int k_end = min(A.S, q0 + 128);
     const int wave_qmax = q0 + wave * 32 + 31;
+    static_assert(D == 64, "staging assumes 128 work items per tile");
+    const int item = threadIdx.x & 127;
+    const bool first_half = threadIdx.x < 128;
+    const unsigned short *src = first_half ? K + rowbase * A.ldk : V + rowbase * A.ldv;
+    const long long src_ld = first_half ? A.ldk : A.ldv;
+    Stage4 st;
+    stage_load<D>(st, src, src_ld, 0, A.S, item);
     for (int k0 = 0; k0 < k_end; k0 += 64) {
         __syncthreads();
-        stage_plain<D>(lds_k, K + rowbase * A.ldk, A.ldk, k0, A.S);
-        stage_plain<D>(lds_v, V + rowbase * A.ldv, A.ldv, k0, A.S);
-        stage_transposed<D>(lds_kt, K + rowbase * A.ldk, A.ldk, k0, A.S);
+        if (first_half) { stage_write_plain<D>(lds_k, st, item); stage_write_transposed(lds_kt, st, item); }
+        else stage_write_plain<D>(lds_v, st, item);
         if (threadIdx.x < 64) lds_mask[threadIdx.x] = (k0 + (int)threadIdx.x < A.S) ? A.mask[rowbase + k0 + (int)threadIdx.x] : 0.f;
+        if (k0 + 64 < k_end) stage_load<D>(st, src, src_ld, k0 + 64, A.S, item);
         __syncthreads();
         if (k0 > wave_qmax) continue;
 #pragma unroll
@@ -321,52 +347,70 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs A)
         for (int r = 0; r < 16; ++r) { accK[db][r] = 0.f; accV[db][r] = 0.f; }
     const float sc = A.scale * kLog2e;
     const int wave_kmin = kk0 + wave * 32;
-    for (int j = 0; j < G; ++j) {
-        const int hq = g * G + j;
-        const unsigned short *Q = A.q + (long long)hq * D + rowbase * A.ldq;
-        const unsigned short *dO = A.d_o + (long long)hq * D + rowbase * A.ldo;
-        const long long stat = ((long long)b * A.Hq + hq) * A.S;
-        for (int t0 = (kk0 / 64) * 64; t0 < A.S; t0 += 64) {      // query tiles that can see this key block
-            __syncthreads();
-            stage_plain<D>(lds_q, Q, A.ldq, t0, A.S);
-            stage_plain<D>(lds_do, dO, A.ldo, t0, A.S);
-            stage_transposed<D>(lds_qt, Q, A.ldq, t0, A.S);
-            stage_transposed<D>(lds_dot, dO, A.ldo, t0, A.S);
-            if (threadIdx.x < 64) {
-                const bool v = t0 + (int)threadIdx.x < A.S;
-                lds_lse[threadIdx.x] = v ? A.lse[stat + t0 + threadIdx.x] : INFINITY;
-                lds_delta[threadIdx.x] = v ? A.delta[stat + t0 + threadIdx.x] : 0.f;
+    static_assert(D == 64, "staging assumes 128 work items per tile");
+    const int item = threadIdx.x & 127;
+    const bool first_half = threadIdx.x < 128;            // first half stages Q, second half dO
+    const int t_begin = (kk0 / 64) * 64;                   // first query tile that can see this key block
+    const int tiles_per_head = (A.S - t_begin + 63) / 64;
+    const int n_steps = G * tiles_per_head;
+    auto src_of = [&](int step, int &t0, long long &stat) -> const unsigned short * {
+        const int hq = g * G + step / tiles_per_head;
+        t0 = t_begin + (step % tiles_per_head) * 64;
+        stat = ((long long)b * A.Hq + hq) * A.S;
+        return first_half ? A.q + (long long)hq * D + rowbase * A.ldq : A.d_o + (long long)hq * D + rowbase * A.ldo;
+    };
+    const long long src_ld = first_half ? A.ldq : A.ldo;
+    Stage4 st;
+    {
+        int t0; long long stat;
+        const unsigned short *src = src_of(0, t0, stat);
+        stage_load<D>(st, src, src_ld, t0, A.S, item);
+    }
+    for (int step = 0; step < n_steps; ++step) {
+        int t0; long long stat;
+        (void)src_of(step, t0, stat);
+        __syncthreads();
+        if (first_half) { stage_write_plain<D>(lds_q, st, item); stage_write_transposed(lds_qt, st, item); }
+        else { stage_write_plain<D>(lds_do, st, item); stage_write_transposed(lds_dot, st, item); }
+        if (threadIdx.x < 64) {
+            const bool v = t0 + (int)threadIdx.x < A.S;
+            lds_lse[threadIdx.x] = v ? A.lse[stat + t0 + threadIdx.x] : INFINITY;
+            lds_delta[threadIdx.x] = v ? A.delta[stat + t0 + threadIdx.x] : 0.f;
+        }
+        if (step + 1 < n_steps) {
+            int t1; long long stat1;
+            const unsigned short *src = src_of(step + 1, t1, stat1);
+            stage_load<D>(st, src, src_ld, t1, A.S, item);   // next tile in flight behind the MFMAs
+        }
+        __syncthreads();
+        if (t0 + 63 < wave_kmin) continue;        // every query of the tile precedes every key of this wave
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_q, qb * 32 + lr, ks, h), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_do, qb * 32 + lr, ks, h), vf[ks], dp, 0, 0, 0);
             }
-            __syncthreads();
-            if (t0 + 63 < wave_kmin) continue;        // every query of the tile precedes every key of this wave
+            float pr[16], ds[16];
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                f32x16 s, dp;
+            for (int r = 0; r < 16; ++r) {
+                const int ql = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;     // query inside the tile
+                const bool vis = kvis && (ki <= t0 + ql);
+                const float e = vis ? exp2f(s[r] * sc - lds_lse[ql]) : 0.f;
+                pr[r] = e;
+                ds[r] = e * (dp[r] - lds_delta[ql]) * A.scale;
+            }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = frag_from_acc(&pr[8 * s2]);
+                const bf16x8 dsf = frag_from_acc(&ds[8 * s2]);
 #pragma unroll
-                for (int ks = 0; ks < D / 16; ++ks) {
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_q, qb * 32 + lr, ks, h), kf[ks], s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_do, qb * 32 + lr, ks, h), vf[ks], dp, 0, 0, 0);
-                }
-                float pr[16], ds[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;     // query inside the tile
-                    const bool vis = kvis && (ki <= t0 + ql);
-                    const float e = vis ? exp2f(s[r] * sc - lds_lse[ql]) : 0.f;
-                    pr[r] = e;
-                    ds[r] = e * (dp[r] - lds_delta[ql]) * A.scale;
-                }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 pf = frag_from_acc(&pr[8 * s2]);
-                    const bf16x8 dsf = frag_from_acc(&ds[8 * s2]);
-#pragma unroll
-                    for (int db = 0; db < D / 32; ++db) {
-                        accV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_dot, db * 32 + lr, qb, s2, h), pf, accV[db], 0, 0, 0);
-                        accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_qt, db * 32 + lr, qb, s2, h), dsf, accK[db], 0, 0, 0);
-                    }
+                for (int db = 0; db < D / 32; ++db) {
+                    accV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_dot, db * 32 + lr, qb, s2, h), pf, accV[db], 0, 0, 0);
+                    accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_qt, db * 32 + lr, qb, s2, h), dsf, accK[db], 0, 0, 0);
                 }
             }
         }

@@ -136,34 +136,50 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs G)
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // (B.A^T)[n][m]: lane = m
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                            // everyone done reading `cur` before it is restaged
     }
 
-    // epilogue: acc[i][j][reg] is C[row0 + wr*64 + i*32 + (reg&3) + 8*(reg>>2) + 4*lh][col0 + wc*64 + j*32 + lr]
+    // epilogue.  The products above are B.A^T, so acc[i][j] holds a TRANSPOSED 32x32 tile: lane lr is output
+    // row m = row0 + wr*64 + i*32 + lr, register reg is output column n = col0 + wc*64 + j*32 + (reg&3) + 8*(reg>>2) + 4*lh:
+    // every group of four registers is four consecutive columns of one row -> one 8-byte (bf16) / 16-byte (fp32) store.
     const float alpha = G.alpha;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        const int r = row0 + wr * 64 + i * 32 + lr;
+        if (r >= G.M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = col0 + wc * 64 + j * 32 + lr;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int r = row0 + wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                if (r < G.M && c < G.N) {
-                    const float v = acc[i][j][reg] * alpha;
+            for (int gq = 0; gq < 4; ++gq) {
+                const int c = col0 + wc * 64 + j * 32 + gq * 8 + 4 * lh;
+                if (c + 3 < G.N && (G.ldc & 3) == 0) {
                     if (G.accumulate_f32) {
-                        float *Cf = reinterpret_cast<float *>(G.C) + off_c;
-                        Cf[(long long)r * G.ldc + c] += v;
+                        float4 *p = reinterpret_cast<float4 *>(reinterpret_cast<float *>(G.C) + off_c + (long long)r * G.ldc + c);
+                        float4 v = *p;
+                        v.x += acc[i][j][gq * 4 + 0] * alpha; v.y += acc[i][j][gq * 4 + 1] * alpha;
+                        v.z += acc[i][j][gq * 4 + 2] * alpha; v.w += acc[i][j][gq * 4 + 3] * alpha;
+                        *p = v;
                     } else {
-                        unsigned short *Cb = reinterpret_cast<unsigned short *>(G.C) + off_c;
-                        Cb[(long long)r * G.ldc + c] = f2bf_rn(v);
+                        using us4 = __attribute__((ext_vector_type(4))) unsigned short;
+                        us4 v;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = f2bf_rn(acc[i][j][gq * 4 + t] * alpha);
+                        *reinterpret_cast<us4 *>(reinterpret_cast<unsigned short *>(G.C) + off_c + (long long)r * G.ldc + c) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (c + t >= G.N) continue;
+                        const float v = acc[i][j][gq * 4 + t] * alpha;
+                        if (G.accumulate_f32) reinterpret_cast<float *>(G.C)[off_c + (long long)r * G.ldc + c + t] += v;
+                        else reinterpret_cast<unsigned short *>(G.C)[off_c + (long long)r * G.ldc + c + t] = f2bf_rn(v);
                     }
                 }
             }
-        }
+    }
 }
 
 }  // namespace
