@@ -133,7 +133,7 @@ def train_cpu_baseline(cfg_kw, S, threads=6):
                       f"(oracle/llama_ref.py) in {dt:.1f} s; optimizer step not included", "host_cpus": os.cpu_count()}
 
 
-def bench_train(args, tk, vocab, merges, pc, world, rank, dev):
+def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
     """Train samples/s of Llama-3.2-1B (seq 1024, bf16, B per GPU) on the HIP decoder, batches built
     through the real front end: synthetic ECG -> quantise+encode -> LUT -> assemble."""
     import torch
@@ -157,7 +157,7 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev):
     opt = model.make_optimizer()                          # Adam(0.9, 0.99, 1e-8, wd 1e-2) + Noam(500) + clip 1.0
     asm = BatchAssembler(tk, lut, pad, bos, eos, sig_start, sig_end, S - 4, device=dev)
     rng = np.random.default_rng(2 + rank)
-    x = torch.from_numpy(make_signals(B, L, seed=0, start=10_000_000 + rank * B, workers=8)).to(dev)
+    x = torch.from_numpy(x_host).to(dev)
     qs = [rng.integers(1000, 100000, size=int(rng.integers(8, 25))).tolist() for _ in range(B)]
     ans = [rng.integers(1000, 100000, size=int(rng.integers(4, 33))).tolist() for _ in range(B)]
 
@@ -239,6 +239,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # host-side synthetic data first: the generator forks worker processes, which must happen before
+    # this process initialises HIP / RCCL
+    workers = max(1, min(8, (os.cpu_count() or 1) // max(1, world)))
+    x = make_signals(args.batch, args.L, seed=0, start=rank * args.batch, workers=workers)   # rank r owns records rB..rB+B-1
+    x_train = None if args.no_train else make_signals(args.train_batch, args.L, seed=0,
+                                                      start=10_000_000 + rank * args.train_batch, workers=workers)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -253,8 +259,6 @@ def main():
     tk = HipTokenizer(merges)
     B, L = args.batch, args.L
     n = 12 * L
-    workers = max(1, min(8, (os.cpu_count() or 1) // max(1, world)))
-    x = make_signals(B, L, seed=0, start=rank * B, workers=workers)   # rank r owns records rB..rB+B-1
     xd = torch.from_numpy(x).to(dev)
     del x
     ids = torch.empty((B, n), dtype=torch.int32, device=dev)
@@ -299,7 +303,7 @@ def main():
     if not args.no_train:
         del xd, ids
         torch.cuda.empty_cache()
-        train = bench_train(args, tk, vocab, merges, pc, world, rank, dev)
+        train = bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_train)
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
