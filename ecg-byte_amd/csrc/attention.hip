@@ -30,13 +30,6 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr float kLog2e = 1.4426950408889634f;
 
-__device__ __forceinline__ unsigned short f2bf(float f)
-{
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
 __device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
 
 struct AttnArgs {
@@ -113,13 +106,22 @@ __device__ __forceinline__ bf16x8 frag_transposed(const unsigned char *lds, int 
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
     return f;
 }
+// two fp32 -> packed bf16 pair, one v_cvt_pk_bf16_f32 (round to nearest even)
+using bf2_t = __attribute__((ext_vector_type(2))) __bf16;
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+{
+    bf2_t v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
 // B-operand fragment made from accumulator registers 8s..8s+7
 __device__ __forceinline__ bf16x8 frag_from_acc(const float *p8)
 {
-    bf16x8 f;
+    using u4 = __attribute__((ext_vector_type(4))) unsigned;
+    u4 w;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = (short)f2bf(p8[j]);
-    return f;
+    for (int j = 0; j < 4; ++j) w[j] = pack_bf16(p8[2 * j], p8[2 * j + 1]);
+    return __builtin_bit_cast(bf16x8, w);
 }
 // row-operand fragments held in registers: row `row` of a global matrix, k = 16*ks + 8*h .. +7
 template <int D>
@@ -141,10 +143,11 @@ __device__ __forceinline__ void store_accT(const f32x16 (&acc)[D / 32], unsigned
     for (int db = 0; db < D / 32; ++db)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            bf16x4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (short)f2bf(acc[db][gq * 4 + j] * mul);
-            *reinterpret_cast<bf16x4 *>(g + row * ld + db * 32 + gq * 8 + 4 * h) = v;
+            using u2 = __attribute__((ext_vector_type(2))) unsigned;
+            u2 v;
+            v[0] = pack_bf16(acc[db][gq * 4 + 0] * mul, acc[db][gq * 4 + 1] * mul);
+            v[1] = pack_bf16(acc[db][gq * 4 + 2] * mul, acc[db][gq * 4 + 3] * mul);
+            *reinterpret_cast<u2 *>(g + row * ld + db * 32 + gq * 8 + 4 * h) = v;
         }
 }
 
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
     __shared__ __attribute__((aligned(16))) unsigned char lds_k[64 * D * 2];
     __shared__ __attribute__((aligned(16))) unsigned char lds_vt[D * 128];
     __shared__ float lds_mask[64];
+    __shared__ int lds_flag;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, hq = blockIdx.y, g = hq / (A.Hq / A.Hkv);
     const int q0 = blockIdx.x * 128;
@@ -184,10 +188,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
     for (int k0 = 0; k0 < k_end; k0 += 64) {
         __syncthreads();
         if (first_half) stage_write_plain<D>(lds_k, st, item); else stage_write_transposed(lds_vt, st, item);
-        if (threadIdx.x < 64) lds_mask[threadIdx.x] = (k0 + (int)threadIdx.x < A.S) ? A.mask[rowbase + k0 + (int)threadIdx.x] : 0.f;
+        if (threadIdx.x < 64) {   // wave 0: key mask of the tile + "tile holds a padded / out-of-range key" flag
+            const float mk = (k0 + (int)threadIdx.x < A.S) ? A.mask[rowbase + k0 + (int)threadIdx.x] : 0.f;
+            lds_mask[threadIdx.x] = mk;
+            const bool any0 = __any(mk == 0.f);
+            if (threadIdx.x == 0) lds_flag = any0 ? 1 : 0;
+        }
         if (k0 + 64 < k_end) stage_load<D>(st, src, src_ld, k0 + 64, A.S, item);   // next tile in flight behind the MFMAs
         __syncthreads();
         if (k0 > wave_qmax) continue;
+        // masks only matter on tiles that touch the diagonal of this wave's rows or hold padded keys
+        const bool need_mask = (k0 + 63 > q0 + wave * 32) || lds_flag;
         float p[2][16];
         float tmax = -INFINITY;
 #pragma unroll
@@ -198,13 +209,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
 #pragma unroll
             for (int ks = 0; ks < D / 16; ++ks)
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_k, kb * 32 + lr, ks, h), qf[ks], s, 0, 0, 0);
+            if (need_mask) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;       // key inside the tile
-                const bool vis = (k0 + kl <= qi) && (lds_mask[kl] != 0.f);
-                const float v = vis ? s[r] * sc : -INFINITY;
-                p[kb][r] = v;
-                tmax = fmaxf(tmax, v);
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;       // key inside the tile
+                    const bool vis = (k0 + kl <= qi) && (lds_mask[kl] != 0.f);
+                    const float v = vis ? s[r] * sc : -INFINITY;
+                    p[kb][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float v = s[r] * sc; p[kb][r] = v; tmax = fmaxf(tmax, v); }
             }
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -247,6 +263,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
     __shared__ __attribute__((aligned(16))) unsigned char lds_v[64 * D * 2];
     __shared__ __attribute__((aligned(16))) unsigned char lds_kt[D * 128];
     __shared__ float lds_mask[64];
+    __shared__ int lds_flag;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, hq = blockIdx.y, g = hq / (A.Hq / A.Hkv);
     const int q0 = blockIdx.x * 128;
@@ -286,10 +303,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
         __syncthreads();
         if (first_half) { stage_write_plain<D>(lds_k, st, item); stage_write_transposed(lds_kt, st, item); }
         else stage_write_plain<D>(lds_v, st, item);
-        if (threadIdx.x < 64) lds_mask[threadIdx.x] = (k0 + (int)threadIdx.x < A.S) ? A.mask[rowbase + k0 + (int)threadIdx.x] : 0.f;
+        if (threadIdx.x < 64) {
+            const float mk = (k0 + (int)threadIdx.x < A.S) ? A.mask[rowbase + k0 + (int)threadIdx.x] : 0.f;
+            lds_mask[threadIdx.x] = mk;
+            const bool any0 = __any(mk == 0.f);
+            if (threadIdx.x == 0) lds_flag = any0 ? 1 : 0;
+        }
         if (k0 + 64 < k_end) stage_load<D>(st, src, src_ld, k0 + 64, A.S, item);
         __syncthreads();
         if (k0 > wave_qmax) continue;
+        const bool need_mask = (k0 + 63 > q0 + wave * 32) || lds_flag;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 s, dp;
@@ -301,12 +324,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_v, kb * 32 + lr, ks, h), dof[ks], dp, 0, 0, 0);
             }
             float ds[16];
+            if (need_mask) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const bool vis = (k0 + kl <= qi) && (lds_mask[kl] != 0.f);
-                const float pr = vis ? exp2f(s[r] * sc - lse) : 0.f;
-                ds[r] = pr * (dp[r] - delta) * A.scale;
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const bool vis = (k0 + kl <= qi) && (lds_mask[kl] != 0.f);
+                    const float pr = vis ? exp2f(s[r] * sc - lse) : 0.f;
+                    ds[r] = pr * (dp[r] - delta) * A.scale;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ds[r] = exp2f(s[r] * sc - lse) * (dp[r] - delta) * A.scale;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -395,10 +423,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs A)
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_do, qb * 32 + lr, ks, h), vf[ks], dp, 0, 0, 0);
             }
             float pr[16], ds[16];
+            const bool diag = t0 + qb * 32 < wave_kmin + 32;              // some query of the block may precede some key of the wave
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;     // query inside the tile
-                const bool vis = kvis && (ki <= t0 + ql);
+                const bool vis = kvis && (!diag || ki <= t0 + ql);
                 const float e = vis ? exp2f(s[r] * sc - lds_lse[ql]) : 0.f;
                 pr[r] = e;
                 ds[r] = e * (dp[r] - lds_delta[ql]) * A.scale;
