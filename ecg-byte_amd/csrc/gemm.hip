@@ -25,8 +25,7 @@ namespace {
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int kTileBytes = BM * BK * 2;           // 16 KiB per operand tile
+constexpr int BK = 64;                            // K-step; LDS rows are BK bf16 = 128 bytes
 
 struct GemmArgs {
     const unsigned short *A;    // [M, K], row stride lda
@@ -52,14 +51,16 @@ __device__ __forceinline__ unsigned short f2bf_rn(float f)
     return (unsigned short)(u >> 16);
 }
 
-// Issue the LDS-DMA loads of one 128x64 operand tile: 16 wave-instructions of 1 KiB (8 rows), 4 per wave.
-// LDS image: row r at r*128 B, slot s (16 B) holds logical chunk s ^ ((r >> 1) & 7).
+// Issue the LDS-DMA loads of one ROWS x 64 operand tile: ROWS/8 wave-instructions of 1 KiB (8 rows each),
+// ROWS/8/NW per wave.  LDS image: row r at r*128 B, slot s (16 B) holds logical chunk s ^ ((r >> 1) & 7).
+template <int ROWS, int NW>
 __device__ __forceinline__ void stage_tile(const unsigned short *g, long long ld, int row0, int rows_valid, int k0,
                                            unsigned char *lds_tile, int wave, int lane)
 {
+    constexpr int PER_WAVE = ROWS / 8 / NW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int inst = wave * 4 + i;                 // 0..15
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int inst = wave * PER_WAVE + i;
         const int r = inst * 8 + (lane >> 3);          // row inside the tile
         const int slot = lane & 7;
         const int chunk = slot ^ ((r >> 1) & 7);
@@ -71,9 +72,18 @@ __device__ __forceinline__ void stage_tile(const unsigned short *g, long long ld
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs G)
+// BM x BN output tile, WGM x WGN waves, each wave (BM/WGM) x (BN/WGN) = TM x TN MFMA tiles of 32x32.
+//   <128,128,2,2>: 4 waves, 64 KiB LDS, 2 workgroups per CU -- small grids and ragged shapes
+//   <256,256,2,4>: 8 waves, 128 KiB LDS, 1 workgroup per CU, half the L2->LDS bytes per FLOP -- the big projections
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel(GemmArgs G)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * kTileBytes];   // [buf][A|B]
+    constexpr int NW = WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;        // wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;          // MFMA tiles per wave
+    constexpr int kABytes = BM * BK * 2, kBBytes = BN * BK * 2, kBufBytes = kABytes + kBBytes;
+    constexpr int kLoadsPerTile = BM / 8 / NW + BN / 8 / NW;   // LDS-DMA instructions per wave per K-tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [buf][A|B]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // XCD-aware remap: blocks b, b+8, ... share an XCD; give each XCD a contiguous run of tiles
     const int nwg = G.tiles_m * G.tiles_n;
@@ -96,46 +106,53 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs G)
     const unsigned short *A = G.A + off_a;
     const unsigned short *B = G.B + off_b;
 
-    const int wr = wave >> 1, wc = wave & 1;           // wave position in the 2x2 grid
-    f32x16 acc[2][2];
+    const int wr = wave / WGN, wc = wave % WGN;        // wave position in the WGM x WGN grid
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int KT = G.K / BK;
-    stage_tile(A, G.lda, row0, G.M, 0, lds, wave, lane);
-    stage_tile(B, G.ldb, col0, G.N, 0, lds + kTileBytes, wave, lane);
+    stage_tile<BM, NW>(A, G.lda, row0, G.M, 0, lds, wave, lane);
+    stage_tile<BN, NW>(B, G.ldb, col0, G.N, 0, lds + kABytes, wave, lane);
     const int lr = lane & 31, lh = lane >> 5;
     for (int kt = 0; kt < KT; ++kt) {
-        unsigned char *cur = lds + (kt & 1) * 2 * kTileBytes;
+        unsigned char *cur = lds + (kt & 1) * kBufBytes;
         if (kt + 1 < KT) {
-            unsigned char *nxt = lds + ((kt + 1) & 1) * 2 * kTileBytes;
-            stage_tile(A, G.lda, row0, G.M, (kt + 1) * BK, nxt, wave, lane);
-            stage_tile(B, G.ldb, col0, G.N, (kt + 1) * BK, nxt + kTileBytes, wave, lane);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // this wave's 8 loads of tile kt have landed
+            unsigned char *nxt = lds + ((kt + 1) & 1) * kBufBytes;
+            stage_tile<BM, NW>(A, G.lda, row0, G.M, (kt + 1) * BK, nxt, wave, lane);
+            stage_tile<BN, NW>(B, G.ldb, col0, G.N, (kt + 1) * BK, nxt + kABytes, wave, lane);
+            // this wave's loads of tile kt have landed once only the kLoadsPerTile just issued are outstanding
+            if constexpr (kLoadsPerTile == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (kLoadsPerTile == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (kLoadsPerTile == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();                            // ... and every other wave's
-        const unsigned char *At = cur, *Bt = cur + kTileBytes;
+        const unsigned char *At = cur, *Bt = cur + kABytes;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 a[2], b[2];
+            bf16x8 a[TM], b[TN];
             const int chunk = ks * 2 + lh;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ra = wr * 64 + i * 32 + lr;
+            for (int i = 0; i < TM; ++i) {
+                const int ra = wr * WTM + i * 32 + lr;
                 a[i] = *reinterpret_cast<const bf16x8 *>(At + ra * 128 + ((chunk ^ ((ra >> 1) & 7)) << 4));
-                const int rb = wc * 64 + i * 32 + lr;
-                b[i] = *reinterpret_cast<const bf16x8 *>(Bt + rb * 128 + ((chunk ^ ((rb >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TN; ++j) {
+                const int rb = wc * WTN + j * 32 + lr;
+                b[j] = *reinterpret_cast<const bf16x8 *>(Bt + rb * 128 + ((chunk ^ ((rb >> 1) & 7)) << 4));
+            }
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);   // (B.A^T)[n][m]: lane = m
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -143,18 +160,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs G)
     }
 
     // epilogue.  The products above are B.A^T, so acc[i][j] holds a TRANSPOSED 32x32 tile: lane lr is output
-    // row m = row0 + wr*64 + i*32 + lr, register reg is output column n = col0 + wc*64 + j*32 + (reg&3) + 8*(reg>>2) + 4*lh:
+    // row m = row0 + wr*WTM + i*32 + lr, register reg is output column n = col0 + wc*WTN + j*32 + (reg&3) + 8*(reg>>2) + 4*lh:
     // every group of four registers is four consecutive columns of one row -> one 8-byte (bf16) / 16-byte (fp32) store.
     const float alpha = G.alpha;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = row0 + wr * 64 + i * 32 + lr;
+    for (int i = 0; i < TM; ++i) {
+        const int r = row0 + wr * WTM + i * 32 + lr;
         if (r >= G.M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const int c = col0 + wc * 64 + j * 32 + gq * 8 + 4 * lh;
+                const int c = col0 + wc * WTN + j * 32 + gq * 8 + 4 * lh;
                 if (c + 3 < G.N && (G.ldc & 3) == 0) {
                     if (G.accumulate_f32) {
                         float4 *p = reinterpret_cast<float4 *>(reinterpret_cast<float *>(G.C) + off_c + (long long)r * G.ldc + c);
@@ -182,7 +199,42 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs G)
     }
 }
 
+int g_gemm_tile = 0;   // 0 auto, 128 / 256 forced (tuning)
+
+int launch_gemm(GemmArgs &G, int batch, hipStream_t stream)
+{
+    // the 256x256 tile halves L2->LDS traffic per FLOP but needs enough tiles to fill the chip
+    const long long tiles256 = (long long)((G.M + 255) / 256) * ((G.N + 255) / 256) * batch;
+    const bool big = g_gemm_tile == 256 || (g_gemm_tile == 0 && tiles256 >= 192 && G.M >= 256 && G.N >= 256);
+    hipError_t e;
+    if (big) {
+        constexpr int lds = 2 * (256 + 256) * BK * 2;
+        auto kern = gemm_nt_kernel<256, 256, 2, 4>;
+        G.tiles_m = (G.M + 255) / 256; G.tiles_n = (G.N + 255) / 256;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess)
+            hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, (unsigned)batch), dim3(512), lds, stream, G);
+    } else {
+        constexpr int lds = 2 * (128 + 128) * BK * 2;
+        auto kern = gemm_nt_kernel<128, 128, 2, 2>;
+        G.tiles_m = (G.M + 127) / 128; G.tiles_n = (G.N + 127) / 128;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess)
+            hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, (unsigned)batch), dim3(256), lds, stream, G);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
+}
+
 }  // namespace
+
+extern "C" int ecgb_set_gemm_tile(int tile)
+{
+    if (tile != 0 && tile != 128 && tile != 256) { ecgb::set_error("ecgb_set_gemm_tile: 0, 128 or 256"); return ECGB_ERR_INVALID; }
+    g_gemm_tile = tile;
+    return ECGB_OK;
+}
 
 extern "C" int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
                                  int M, int N, int K, float alpha, int accumulate_f32, int batch, long long batch_a,
@@ -200,14 +252,9 @@ extern "C" int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b
     G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = c_dev;
     G.M = M; G.N = N; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = ldc;
     G.batch_a = batch_a; G.batch_b = batch_b; G.batch_c = batch_c;
-    G.tiles_m = (M + BM - 1) / BM; G.tiles_n = (N + BN - 1) / BN;
     G.accumulate_f32 = accumulate_f32; G.alpha = alpha;
     G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, (unsigned)batch), dim3(256), 0,
-                       (hipStream_t)stream, G);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
-    return ECGB_OK;
+    return launch_gemm(G, batch, (hipStream_t)stream);
 }
 
 extern "C" int ecgb_gemm_nt_bf16_heads(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev,
@@ -228,13 +275,8 @@ extern "C" int ecgb_gemm_nt_bf16_heads(const void *a_dev, long long lda, const v
     G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = c_dev;
     G.M = M; G.N = N; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = ldc;
     G.batch_a = G.batch_b = G.batch_c = 0;
-    G.tiles_m = (M + BM - 1) / BM; G.tiles_n = (N + BN - 1) / BN;
     G.accumulate_f32 = accumulate_f32; G.alpha = alpha;
     G.inner = inner; G.outer_a = outer_a; G.inner_a = inner_a; G.div_a = div_a;
     G.outer_b = outer_b; G.inner_b = inner_b; G.div_b = div_b; G.outer_c = outer_c; G.inner_c = inner_c;
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, (unsigned)batch), dim3(256), 0,
-                       (hipStream_t)stream, G);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
-    return ECGB_OK;
+    return launch_gemm(G, batch, (hipStream_t)stream);
 }

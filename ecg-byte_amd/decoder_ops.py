@@ -88,6 +88,11 @@ def transpose(x2d):
     return o
 
 
+def set_gemm_tile(tile: int):
+    """0 = automatic, 128 / 256 = force that output tile (tests, tuning)."""
+    _lib.check(_L().ecgb_set_gemm_tile(int(tile)))
+
+
 def gemm_nt(a, b, out=None, alpha=1.0, accumulate_f32=False):
     """C[M,N] = alpha * A[M,K] @ B[N,K]^T.  a, b: 2-D bf16 (row stride = shape[1] or a column slice view)."""
     M, K = a.shape

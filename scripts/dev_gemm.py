@@ -7,11 +7,16 @@ shapes = [(32768, 3072, 2048), (32768, 16384, 2048), (32768, 2048, 8192), (32768
 for M, N, K in shapes:
     a = torch.randn(M, K, device="cuda").to(torch.bfloat16); b = torch.randn(N, K, device="cuda").to(torch.bfloat16)
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    for _ in range(2): ops.gemm_nt(a, b, out=out)
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(5): ops.gemm_nt(a, b, out=out)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
+    res = []
+    for tile in (128, 256):
+        ops.set_gemm_tile(tile)
+        for _ in range(2): ops.gemm_nt(a, b, out=out)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(5): ops.gemm_nt(a, b, out=out)
+        torch.cuda.synchronize(); res.append((time.perf_counter() - t) / 5)
+    ops.set_gemm_tile(0)
+    dt = min(res)
     t0 = time.perf_counter()
     for _ in range(5): torch.matmul(a, b.T, out=out)
     torch.cuda.synchronize(); dt2 = (time.perf_counter() - t0) / 5
-    print(f"M{M} N{N} K{K}: {dt*1e3:.3f} ms  {2*M*N*K/dt/1e12:.0f} TFLOP/s   (torch/hipBLASLt {2*M*N*K/dt2/1e12:.0f})")
+    print(f"M{M} N{N} K{K}: tile128 {2*M*N*K/res[0]/1e12:.0f}  tile256 {2*M*N*K/res[1]/1e12:.0f} TFLOP/s   (torch/hipBLASLt {2*M*N*K/dt2/1e12:.0f})")

@@ -29,8 +29,17 @@ def _close(got, ref, atol, rtol=2 ** -7):
     assert bool((err <= tol).all()), f"max err {err.max().item():.4g} (tol {tol[err.argmax()].item():.4g})"
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 136, 128), (1024, 3072, 2048), (64, 512, 8192)])
-def test_gemm_nt(ops, M, N, K):
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 136, 128), (1024, 3072, 2048), (64, 512, 8192), (520, 300, 192)])
+def test_gemm_nt(ops, M, N, K, tile):
+    ops.set_gemm_tile(tile)
+    try:
+        _gemm_checks(ops, M, N, K)
+    finally:
+        ops.set_gemm_tile(0)
+
+
+def _gemm_checks(ops, M, N, K):
     a, b = _bf(M, K, seed=1), _bf(N, K, seed=2)
     ref = a.float() @ b.float().T
     _close(ops.gemm_nt(a, b), ref, atol=1e-2 * math.sqrt(K) / 8)
