@@ -8,7 +8,7 @@ for M, N, K in shapes:
     a = torch.randn(M, K, device="cuda").to(torch.bfloat16); b = torch.randn(N, K, device="cuda").to(torch.bfloat16)
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     res = []
-    for tile in (128, 256):
+    for tile in (128, 256, 257):
         ops.set_gemm_tile(tile)
         for _ in range(2): ops.gemm_nt(a, b, out=out)
         torch.cuda.synchronize(); t = time.perf_counter()
@@ -19,4 +19,4 @@ for M, N, K in shapes:
     t0 = time.perf_counter()
     for _ in range(5): torch.matmul(a, b.T, out=out)
     torch.cuda.synchronize(); dt2 = (time.perf_counter() - t0) / 5
-    print(f"M{M} N{N} K{K}: tile128 {2*M*N*K/res[0]/1e12:.0f}  tile256 {2*M*N*K/res[1]/1e12:.0f} TFLOP/s   (torch/hipBLASLt {2*M*N*K/dt2/1e12:.0f})")
+    print(f"M{M} N{N} K{K}: tile128 {2*M*N*K/res[0]/1e12:.0f}  tile256 {2*M*N*K/res[1]/1e12:.0f}  tile256/m16 {2*M*N*K/res[2]/1e12:.0f} TFLOP/s   (torch/hipBLASLt {2*M*N*K/dt2/1e12:.0f})")

@@ -29,7 +29,7 @@ def _close(got, ref, atol, rtol=2 ** -7):
     assert bool((err <= tol).all()), f"max err {err.max().item():.4g} (tol {tol[err.argmax()].item():.4g})"
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [128, 256, 257])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 136, 128), (1024, 3072, 2048), (64, 512, 8192), (520, 300, 192)])
 def test_gemm_nt(ops, M, N, K, tile):
     ops.set_gemm_tile(tile)
