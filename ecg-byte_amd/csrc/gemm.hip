@@ -314,6 +314,121 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16(GemmArgs G)
     }
 }
 
+// ---- TN product for weight gradients: C[N,K] = A^T . B with A = dY [M,N] and B = X [M,K] (both ROW-major, the
+// contraction index m is the slow one).  Same MFMA / LDS-image / epilogue scheme as gemm_nt_kernel_m16; only the
+// staging differs: a thread loads 4 consecutive m-rows x 8 columns (four 16-byte loads, issued one K-tile ahead
+// into registers) and writes them transposed -- eight 8-byte LDS writes, each 4 consecutive m of one output row --
+// so the LDS image is again [output row][64 contraction elements] and no transposed copy ever exists in HBM.
+template <int BN_, int BK_, int WGM, int WGN>
+__global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_m16(GemmArgs G)
+{
+    // naming: output is [N rows (from A's columns)] x [K cols (from B's columns)], contraction over M in steps of 64
+    constexpr int NW = WGM * WGN;
+    constexpr int WTM = BN_ / WGM, WTN = BK_ / WGN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int kABytes = BN_ * 64 * 2, kBBytes = BK_ * 64 * 2, kBufBytes = kABytes + kBBytes;
+    static_assert(BN_ == 256 && BK_ == 256 && NW == 8, "one staging item per thread per operand");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nwg = G.tiles_m * G.tiles_n;
+    const int orig = blockIdx.x;
+    const int q = nwg / 8, rr = nwg % 8, xcd = orig % 8;
+    const int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
+    const int tm = wgid / G.tiles_n, tn = wgid % G.tiles_n;
+    const int row0 = tm * BN_, col0 = tn * BK_;          // output row block (columns of A), output column block (columns of B)
+    const unsigned short *A = G.A, *B = G.B;
+    // staging item of this thread: columns c8*8 .. +7 of the operand's 256-column block, rows mg*4 .. +3 of the 64-row K-tile
+    const int c8 = tid & 31, mg = tid >> 5;               // 32 column chunks x 16 row groups = 512 items
+    const int wr = wave / WGN, wc = wave % WGN;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int KT_all = G.M / 64;
+    const int per = (KT_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kt_begin = (int)blockIdx.y * per;
+    const int KT = min(KT_all, kt_begin + per);
+    if (kt_begin >= KT) return;
+    bf16x8 ra[4], rb[4];
+    auto load_items = [&](int kt) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long long m = (long long)kt * 64 + mg * 4 + t;
+            const int ca = min(row0 + c8 * 8, G.N - 8), cb = min(col0 + c8 * 8, G.K - 8);   // clamped columns are never stored
+            ra[t] = *reinterpret_cast<const bf16x8 *>(A + m * G.lda + ca);
+            rb[t] = *reinterpret_cast<const bf16x8 *>(B + m * G.ldb + cb);
+        }
+    };
+    auto write_items = [&](unsigned char *buf) {
+        using bf16x4 = __attribute__((ext_vector_type(4))) short;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = c8 * 8 + j;                     // output row inside the block = operand column
+            const int slot = (mg >> 1) ^ ((r >> 1) & 7);  // 16-byte slot of contraction elements 8*(mg>>1) .. +7
+            bf16x4 wa, wb;
+            wa[0] = ra[0][j]; wa[1] = ra[1][j]; wa[2] = ra[2][j]; wa[3] = ra[3][j];
+            wb[0] = rb[0][j]; wb[1] = rb[1][j]; wb[2] = rb[2][j]; wb[3] = rb[3][j];
+            *reinterpret_cast<bf16x4 *>(buf + r * 128 + (slot << 4) + (mg & 1) * 8) = wa;
+            *reinterpret_cast<bf16x4 *>(buf + kABytes + r * 128 + (slot << 4) + (mg & 1) * 8) = wb;
+        }
+    };
+    load_items(kt_begin);
+    write_items(lds + (kt_begin & 1) * kBufBytes);
+    const int lm = lane & 15, lq = lane >> 4;
+    for (int kt = kt_begin; kt < KT; ++kt) {
+        unsigned char *cur = lds + (kt & 1) * kBufBytes;
+        if (kt + 1 < KT) load_items(kt + 1);              // in flight behind this tile's MFMAs
+        __syncthreads();                                  // tile kt visible to every wave
+        const unsigned char *At = cur, *Bt = cur + kABytes;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[TM], b[TN];
+            const int chunk = ks * 4 + lq;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wr * WTM + i * 16 + lm;
+                a[i] = *reinterpret_cast<const bf16x8 *>(At + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wc * WTN + j * 16 + lm;
+                b[j] = *reinterpret_cast<const bf16x8 *>(Bt + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4));
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (kt + 1 < KT) write_items(lds + ((kt + 1) & 1) * kBufBytes);   // the other buffer: its last reader finished before the barrier above
+    }
+    const float alpha = G.alpha;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = row0 + wr * WTM + i * 16 + lm;
+        if (r >= G.N) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = col0 + wc * WTN + j * 16 + lq * 4;
+            if (c + 3 >= G.K) continue;
+            if (G.accumulate_f32) {   // split over the contraction: fp32 partial sums meet in memory
+                float *p = reinterpret_cast<float *>(G.C) + (long long)r * G.ldc + c;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) atomicAdd(p + t, acc[i][j][t] * alpha);
+            } else {
+                using us4 = __attribute__((ext_vector_type(4))) unsigned short;
+                us4 v;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = f2bf_rn(acc[i][j][t] * alpha);
+                *reinterpret_cast<us4 *>(reinterpret_cast<unsigned short *>(G.C) + (long long)r * G.ldc + c) = v;
+            }
+        }
+    }
+}
+
 int g_gemm_tile = 0;   // 0 auto; forced: 128 = 128x128 tile, 256 = 256x256 on 16x16x32 MFMA, 257 = 256x256 on 32x32x16 MFMA
 
 int launch_gemm(GemmArgs &G, int batch, hipStream_t stream)
@@ -401,4 +516,33 @@ extern "C" int ecgb_gemm_nt_bf16_heads(const void *a_dev, long long lda, const v
     G.inner = inner; G.outer_a = outer_a; G.inner_a = inner_a; G.div_a = div_a;
     G.outer_b = outer_b; G.inner_b = inner_b; G.div_b = div_b; G.outer_c = outer_c; G.inner_c = inner_c;
     return launch_gemm(G, batch, (hipStream_t)stream);
+}
+
+// dW-style product: C[N,K] (bf16, row stride ldc) = alpha * A^T . B, A = [M,N] row-major (lda), B = [M,K] row-major (ldb).
+extern "C" int ecgb_gemm_tn_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
+                                 int M, int N, int K, float alpha, int splits, void *stream)
+{
+    if (!a_dev || !b_dev || !c_dev || M <= 0 || N <= 0 || K <= 0) { ecgb::set_error("ecgb_gemm_tn_bf16: bad argument"); return ECGB_ERR_INVALID; }
+    if (M % 64 || N % 8 || K % 8 || N < 8 || K < 8 || lda % 8 || ldb % 8 || ldc % 4 || ((uintptr_t)a_dev & 15) || ((uintptr_t)b_dev & 15) ||
+        ((uintptr_t)c_dev & 7)) {
+        ecgb::set_error("ecgb_gemm_tn_bf16: M % 64, N % 8, K % 8, 16-byte aligned operands required");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    GemmArgs G;
+    G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = c_dev;
+    G.M = M; G.N = N; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = ldc;
+    G.batch_a = G.batch_b = G.batch_c = 0;
+    G.tiles_m = (N + 255) / 256; G.tiles_n = (K + 255) / 256;
+    if (splits < 1 || splits > 64) { ecgb::set_error("ecgb_gemm_tn_bf16: splits must be 1..64"); return ECGB_ERR_INVALID; }
+    G.accumulate_f32 = splits > 1 ? 1 : 0; G.alpha = alpha;      // splits > 1: c_dev is a ZEROED fp32 [N, ldc] buffer
+    G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
+    constexpr int lds = 2 * (256 + 256) * 64 * 2;
+    auto kern = gemm_tn_kernel_m16<256, 256, 2, 4>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), (unsigned)splits), dim3(512), lds, (hipStream_t)stream, G);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) { ecgb::set_error(std::string("gemm_tn_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
 }

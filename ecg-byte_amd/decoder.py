@@ -310,7 +310,7 @@ class HipCausalLM(nn.Module):
 
         def wgrad(dy, xin, param):
             """param.grad = dy^T . xin (bf16)"""
-            g = ops.gemm_nt(ops.transpose(dy), ops.transpose(xin))
+            g = ops.gemm_tn(dy, xin)          # contraction over the token rows of both operands: no transposed copies
             param.grad = g if param.grad is None else ops.add(param.grad, g)
 
         def lngrad(param, dw32):

@@ -105,6 +105,24 @@ def gemm_nt(a, b, out=None, alpha=1.0, accumulate_f32=False):
     return out
 
 
+def gemm_tn(a, b, alpha=1.0):
+    """C[N,K] = alpha * A[M,N]^T @ B[M,K]  (weight gradient dW = dY^T X) without transposed copies."""
+    M, N = a.shape
+    K = b.shape[1]
+    assert b.shape[0] == M and a.stride(1) == 1 and b.stride(1) == 1
+    tiles = ((N + 255) // 256) * ((K + 255) // 256)
+    splits = 1 if tiles >= 192 else max(1, min(8, 256 // tiles, M // 64))
+    if splits == 1:
+        out = torch.empty((N, K), dtype=torch.bfloat16, device=a.device)
+        _lib.check(_L().ecgb_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), K, M, N, K, float(alpha), 1, _st()))
+        return out
+    acc = torch.zeros((N, K), dtype=torch.float32, device=a.device)
+    _lib.check(_L().ecgb_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(acc), K, M, N, K, float(alpha), splits, _st()))
+    out = torch.empty((N, K), dtype=torch.bfloat16, device=a.device)
+    _lib.check(_L().ecgb_f32_to_bf16(_p(acc), _p(out), acc.numel(), _st()))
+    return out
+
+
 def gemm_nt_heads(a, lda, b, ldb, c, ldc, M, N, K, alpha, batch, inner, outer_a, inner_a, div_a, outer_b, inner_b, div_b,
                   outer_c, inner_c, accumulate_f32=False):
     """a, b, c: tensors or (tensor, element_offset) pairs."""

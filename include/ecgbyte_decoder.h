@@ -64,6 +64,12 @@ int ecgb_f32_to_bf16(const float *in_dev, void *out_dev, size_t n, void *stream)
 int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
                       int M, int N, int K, float alpha, int accumulate_f32, int batch, long long batch_a,
                       long long batch_b, long long batch_c, void *stream);
+/* Weight-gradient product without transposed copies: C[N,K] = alpha * A^T . B with A = [M,N] and B = [M,K]
+ * row-major (dW = dY^T . X, the contraction index is the row index of both operands).  M % 64 == 0.
+ * splits == 1: C is bf16.  splits > 1: the contraction is cut into `splits` slices run by separate workgroups
+ * (small outputs would otherwise leave most CUs idle) and C must be a ZEROED fp32 buffer that receives the sum. */
+int ecgb_gemm_tn_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
+                      int M, int N, int K, float alpha, int splits, void *stream);
 /* Output tile choice: 0 = automatic (256x256 tiles / 8 waves on v_mfma_f32_16x16x32_bf16 when they fill the chip,
  * else 128x128 / 4 waves on 32x32x16); forced: 128, 256, or 257 = 256x256 on 32x32x16 (tests, tuning). */
 int ecgb_set_gemm_tile(int tile);

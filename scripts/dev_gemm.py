@@ -20,3 +20,11 @@ for M, N, K in shapes:
     for _ in range(5): torch.matmul(a, b.T, out=out)
     torch.cuda.synchronize(); dt2 = (time.perf_counter() - t0) / 5
     print(f"M{M} N{N} K{K}: tile128 {2*M*N*K/res[0]/1e12:.0f}  tile256 {2*M*N*K/res[1]/1e12:.0f}  tile256/m16 {2*M*N*K/res[2]/1e12:.0f} TFLOP/s   (torch/hipBLASLt {2*M*N*K/dt2/1e12:.0f})")
+
+for M, N, K in [(32768, 3072, 2048), (32768, 16384, 2048), (32768, 2048, 8192), (32768, 2048, 2048)]:
+    dy = torch.randn(M, N, device="cuda").to(torch.bfloat16); x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    for _ in range(2): ops.gemm_tn(dy, x)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(5): ops.gemm_tn(dy, x)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
+    print(f"TN dW[{N},{K}] over M={M}: {dt*1e3:.3f} ms  {2*M*N*K/dt/1e12:.0f} TFLOP/s")

@@ -223,3 +223,12 @@ def test_fused_attention_forward_backward(ops, B, S, Hq, Hkv):
         g, w = d_qkv[:, lo:hi].float(), want[:, lo:hi]
         rel = (g - w).norm() / w.norm()
         assert rel.item() < 2e-2, (name, rel.item())
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 256, 256), (512, 512, 256), (4096, 3072, 2048), (192, 264, 520), (128, 8, 40)])
+def test_gemm_tn_weight_gradient(ops, M, N, K):
+    """dW = dY^T X straight from the row-major operands (no transposed copies), incl. ragged N/K edges."""
+    dy, x = _bf(M, N, seed=40), _bf(M, K, seed=41)
+    ref = dy.float().T @ x.float()
+    _close(ops.gemm_tn(dy, x), ref, atol=1e-2 * math.sqrt(M) / 4)
+    _close(ops.gemm_tn(dy, x, alpha=0.25), 0.25 * ref, atol=1e-2 * math.sqrt(M) / 8)
