@@ -88,6 +88,7 @@ def lib():
         "ecgb_glu_fwd": [vp, vp, sz, ci, ci, vp],
         "ecgb_glu_bwd": [vp, vp, vp, sz, ci, ci, vp],
         "ecgb_add_bf16": [vp, vp, vp, sz, vp],
+        "ecgb_dropout_bf16": [vp, vp, sz, f32, C.c_uint64, vp],
         "ecgb_transpose_bf16": [vp, vp, ci, ci, vp],
         "ecgb_f32_to_bf16": [vp, vp, sz, vp],
         "ecgb_gemm_nt_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, ci, ll, ll, ll, vp],

@@ -275,6 +275,29 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const unsigned short *gu, 
     }
 }
 
+// ---- dropout (LoRA input dropout, peft LoraLayer) ---------------------------------------------------
+__device__ __forceinline__ unsigned mix32(unsigned long long seed, unsigned long long idx)
+{
+    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+__global__ __launch_bounds__(256) void dropout_kernel(const unsigned short *x, unsigned short *o, size_t n8, float p, float inv_keep,
+                                                      unsigned long long seed)
+{
+    const unsigned thr = (unsigned)(p * 4294967296.0);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        bf16x8 v = reinterpret_cast<const bf16x8 *>(x)[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool keep = mix32(seed, i * 8 + j) >= thr;
+            v[j] = keep ? f2bf(bf2f(v[j]) * inv_keep) : (unsigned short)0;
+        }
+        reinterpret_cast<bf16x8 *>(o)[i] = v;
+    }
+}
+
 // ---- elementwise add (residual) -----------------------------------------------------------------
 __global__ __launch_bounds__(256) void add_kernel(const unsigned short *a, const unsigned short *b, unsigned short *o, size_t n8)
 {
@@ -711,4 +734,12 @@ extern "C" int ecgb_transpose_bf16_strided(const void *in_dev, void *out_dev, in
                        dim3(256), 0, (hipStream_t)stream, (const unsigned short *)in_dev, (unsigned short *)out_dev, rows, cols,
                        ld_in, ld_out, inner, outer_in, inner_in, outer_out, inner_out);
     ECGB_CHECK_LAUNCH("transpose_bf16_strided");
+}
+
+extern "C" int ecgb_dropout_bf16(const void *x_dev, void *out_dev, size_t n, float p, uint64_t seed, void *stream)
+{
+    if (n % 8 || !(p >= 0.f && p < 1.f)) { ecgb::set_error("ecgb_dropout_bf16: n % 8 == 0 and 0 <= p < 1 required"); return ECGB_ERR_INVALID; }
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x_dev,
+                       (unsigned short *)out_dev, n / 8, p, 1.0f / (1.0f - p), (unsigned long long)seed);
+    ECGB_CHECK_LAUNCH("dropout_bf16");
 }

@@ -40,7 +40,7 @@ struct GemmArgs {
     long long outer_a, inner_a, outer_b, inner_b, outer_c, inner_c;
     int div_a, div_b;
     int tiles_m, tiles_n;
-    int accumulate_f32;         // C is fp32 and C += A.B^T
+    int accumulate_f32;         // 0: C (bf16) = ..;  1: C is fp32 and C += ..;  2: C is bf16 and C += ..
     float alpha;
 };
 
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel(GemmArgs G)
             for (int gq = 0; gq < 4; ++gq) {
                 const int c = col0 + wc * WTN + j * 32 + gq * 8 + 4 * lh;
                 if (c + 3 < G.N && (G.ldc & 3) == 0) {
-                    if (G.accumulate_f32) {
+                    if (G.accumulate_f32 == 1) {
                         float4 *p = reinterpret_cast<float4 *>(reinterpret_cast<float *>(G.C) + off_c + (long long)r * G.ldc + c);
                         float4 v = *p;
                         v.x += acc[i][j][gq * 4 + 0] * alpha; v.y += acc[i][j][gq * 4 + 1] * alpha;
@@ -182,18 +182,28 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel(GemmArgs G)
                         *p = v;
                     } else {
                         using us4 = __attribute__((ext_vector_type(4))) unsigned short;
+                        us4 *p = reinterpret_cast<us4 *>(reinterpret_cast<unsigned short *>(G.C) + off_c + (long long)r * G.ldc + c);
                         us4 v;
+                        if (G.accumulate_f32 == 2) {   // bf16 C += alpha * A.B^T
+                            const us4 o = *p;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] = f2bf_rn(acc[i][j][gq * 4 + t] * alpha);
-                        *reinterpret_cast<us4 *>(reinterpret_cast<unsigned short *>(G.C) + off_c + (long long)r * G.ldc + c) = v;
+                            for (int t = 0; t < 4; ++t) v[t] = f2bf_rn(__uint_as_float((unsigned)o[t] << 16) + acc[i][j][gq * 4 + t] * alpha);
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) v[t] = f2bf_rn(acc[i][j][gq * 4 + t] * alpha);
+                        }
+                        *p = v;
                     }
                 } else {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         if (c + t >= G.N) continue;
                         const float v = acc[i][j][gq * 4 + t] * alpha;
-                        if (G.accumulate_f32) reinterpret_cast<float *>(G.C)[off_c + (long long)r * G.ldc + c + t] += v;
-                        else reinterpret_cast<unsigned short *>(G.C)[off_c + (long long)r * G.ldc + c + t] = f2bf_rn(v);
+                        if (G.accumulate_f32 == 1) reinterpret_cast<float *>(G.C)[off_c + (long long)r * G.ldc + c + t] += v;
+                        else {
+                            unsigned short *q = reinterpret_cast<unsigned short *>(G.C) + off_c + (long long)r * G.ldc + c + t;
+                            *q = f2bf_rn(G.accumulate_f32 == 2 ? __uint_as_float((unsigned)*q << 16) + v : v);
+                        }
                     }
                 }
             }
@@ -289,25 +299,35 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16(GemmArgs G)
         for (int j = 0; j < TN; ++j) {
             const int c = col0 + wc * WTN + j * 16 + lq * 4;
             if (c + 3 < G.N && (G.ldc & 3) == 0) {
-                if (G.accumulate_f32) {
+                if (G.accumulate_f32 == 1) {
                     float4 *p = reinterpret_cast<float4 *>(reinterpret_cast<float *>(G.C) + off_c + (long long)r * G.ldc + c);
                     float4 v = *p;
                     v.x += acc[i][j][0] * alpha; v.y += acc[i][j][1] * alpha; v.z += acc[i][j][2] * alpha; v.w += acc[i][j][3] * alpha;
                     *p = v;
                 } else {
                     using us4 = __attribute__((ext_vector_type(4))) unsigned short;
+                    us4 *p = reinterpret_cast<us4 *>(reinterpret_cast<unsigned short *>(G.C) + off_c + (long long)r * G.ldc + c);
                     us4 v;
+                    if (G.accumulate_f32 == 2) {
+                        const us4 o = *p;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] = f2bf_rn(acc[i][j][t] * alpha);
-                    *reinterpret_cast<us4 *>(reinterpret_cast<unsigned short *>(G.C) + off_c + (long long)r * G.ldc + c) = v;
+                        for (int t = 0; t < 4; ++t) v[t] = f2bf_rn(__uint_as_float((unsigned)o[t] << 16) + acc[i][j][t] * alpha);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = f2bf_rn(acc[i][j][t] * alpha);
+                    }
+                    *p = v;
                 }
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (c + t >= G.N) continue;
                     const float v = acc[i][j][t] * alpha;
-                    if (G.accumulate_f32) reinterpret_cast<float *>(G.C)[off_c + (long long)r * G.ldc + c + t] += v;
-                    else reinterpret_cast<unsigned short *>(G.C)[off_c + (long long)r * G.ldc + c + t] = f2bf_rn(v);
+                    if (G.accumulate_f32 == 1) reinterpret_cast<float *>(G.C)[off_c + (long long)r * G.ldc + c + t] += v;
+                    else {
+                        unsigned short *q = reinterpret_cast<unsigned short *>(G.C) + off_c + (long long)r * G.ldc + c + t;
+                        *q = f2bf_rn(G.accumulate_f32 == 2 ? __uint_as_float((unsigned)*q << 16) + v : v);
+                    }
                 }
             }
         }

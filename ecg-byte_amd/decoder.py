@@ -78,6 +78,58 @@ def rope_inv_freq(cfg: DecoderConfig) -> torch.Tensor:
     return torch.where(is_medium, smoothed, inv_freq_llama)
 
 
+class LoraSite(nn.Module):
+    """LoRA adapters of one (possibly fused) projection, as peft's LoraLayer computes them
+    (ecg_byte/main.py:131-155: r 16, alpha 32, dropout 0.05 on q,k,v,o,gate,up,down):
+        y[:, block b] += (alpha / r) * (dropout(x) A_b^T) B_b^T,   A_b: [r, in] kaiming-uniform, B_b: [out_b, r] zeros.
+    The rank is padded to the GEMM K-step (64): A rows / B columns r..63 are zero and stay zero (their
+    gradients are products with those zeros).  peft is neither vendored nor installed: parity unpinned."""
+
+    def __init__(self, in_dim, out_blocks, r, alpha, dropout, device, gen):
+        super().__init__()
+        assert r <= 64
+        self.r, self.scale, self.p = r, alpha / r, dropout
+        self.blocks = list(out_blocks)                       # (column offset, width) inside the fused output
+        nb = len(self.blocks)
+        A = torch.zeros(64 * nb, in_dim)
+        bound = 1.0 / math.sqrt(in_dim)                      # kaiming_uniform_(a=sqrt(5)) on [r, in]
+        for b in range(nb):
+            A[64 * b: 64 * b + r] = (torch.rand(r, in_dim, generator=gen) * 2 - 1) * bound
+        self.A = nn.Parameter(A.to(torch.bfloat16).to(device))
+        self.B = nn.ParameterList([nn.Parameter(torch.zeros(w, 64, dtype=torch.bfloat16, device=device)) for _, w in self.blocks])
+        self.seed = int(torch.randint(0, 2 ** 31, (1,), generator=gen))
+        self.calls = 0
+
+    def forward_add(self, x, y, training):
+        """y (the base projection's output, [T, sum of widths]) += the adapter branches.  Returns what backward needs."""
+        seed = None
+        xd = x
+        if training and self.p > 0:
+            self.calls += 1
+            seed = self.seed + 7919 * self.calls
+            xd = ops.dropout(x, self.p, seed)
+        t = ops.gemm_nt(xd, self.A.data)                     # [T, 64 * nb]
+        for b, (off, w) in enumerate(self.blocks):
+            ops.gemm_nt(t[:, 64 * b: 64 * b + 64], self.B[b].data, out=y[:, off: off + w], alpha=self.scale, accumulate=True)
+        return xd, t, seed
+
+    def backward(self, dy, saved):
+        """Sets A.grad / B[b].grad and returns the adapters' contribution to d(input)."""
+        xd, t, seed = saved
+        dt = torch.empty_like(t)
+        for b, (off, w) in enumerate(self.blocks):
+            dyb = dy[:, off: off + w]
+            gB = ops.gemm_tn(dyb, t[:, 64 * b: 64 * b + 64], alpha=self.scale)
+            self.B[b].grad = gB if self.B[b].grad is None else ops.add(self.B[b].grad, gB)
+            ops.gemm_nt(dyb, ops.transpose(self.B[b].data), out=dt[:, 64 * b: 64 * b + 64], alpha=self.scale)
+        gA = ops.gemm_tn(dt, xd)
+        self.A.grad = gA if self.A.grad is None else ops.add(self.A.grad, gA)
+        dx = ops.gemm_nt(dt, ops.transpose(self.A.data))
+        if seed is not None:
+            ops.dropout(dx, self.p, seed, out=dx)
+        return dx
+
+
 class _LossFn(torch.autograd.Function):
     """Ties the hand-written forward/backward into autograd so `out.loss.backward()` works."""
 
@@ -123,6 +175,8 @@ class HipCausalLM(nn.Module):
         self.ln2 = nn.ParameterList([ones() for _ in range(cfg.num_hidden_layers)])
         self.norm = ones()
         self.register_buffer("inv_freq", rope_inv_freq(cfg).to(dev), persistent=False)
+        self._anchor = nn.Parameter(torch.zeros(1, device=dev))   # keeps the autograd node alive when the base is frozen
+        self.lora = None        # nn.ModuleDict of LoraSite per layer once enable_lora() ran
         self._t = {}            # transposed shadow weights
         self._t_version = {}    # parameter version each shadow was made from
         self.embed_grad32 = None
@@ -139,7 +193,7 @@ class HipCausalLM(nn.Module):
     def forward(self, input_ids=None, attention_mask=None, labels=None, position_ids=None, output_attentions=False, **_):
         if labels is None:
             raise NotImplementedError("HipCausalLM.forward computes the training loss; pass labels")
-        anchor = self.norm   # any parameter that requires grad, so autograd records the node
+        anchor = self._anchor   # a parameter that requires grad, so autograd records the node
         loss = _LossFn.apply(anchor, self, input_ids, attention_mask, labels, position_ids)
         return SimpleNamespace(loss=loss, logits=None, attentions=None)
 
@@ -163,6 +217,38 @@ class HipCausalLM(nn.Module):
         self.v_pad = v_pad
         self.embed_grad32 = None
         self._t.pop("embed", None)
+
+    def enable_lora(self, r=16, alpha=32, dropout=0.05, seed=0):
+        """get_peft_model(llm, LoraConfig(r, lora_alpha, target_modules=[q,k,v,o,gate,up,down]_proj, lora_dropout))
+        (ecg_byte/main.py:131-155): base weights, norms and embeddings are frozen, only the adapters train."""
+        c = self.cfg
+        H, I, D, Hq, Hkv = c.hidden_size, c.intermediate_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        for p in self.parameters():
+            p.requires_grad_(False)
+        self._anchor.requires_grad_(True)
+        sites = nn.ModuleList()
+        for _ in range(c.num_hidden_layers):
+            sites.append(nn.ModuleDict({
+                "qkv": LoraSite(H, [(0, Hq * D), (Hq * D, Hkv * D), (Hq * D + Hkv * D, Hkv * D)], r, alpha, dropout, self.device, gen),
+                "o": LoraSite(Hq * D, [(0, H)], r, alpha, dropout, self.device, gen),
+                "gu": LoraSite(H, [(0, I), (I, I)], r, alpha, dropout, self.device, gen),
+                "down": LoraSite(I, [(0, H)], r, alpha, dropout, self.device, gen),
+            }))
+        self.lora = sites
+        return self
+
+    def lora_named(self):
+        """(peft-style name, tensor) pairs of the adapter weights: lora_A [r, in], lora_B [out, r]."""
+        names = {"qkv": ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"], "o": ["self_attn.o_proj"],
+                 "gu": ["mlp.gate_proj", "mlp.up_proj"], "down": ["mlp.down_proj"]}
+        for i, layer in enumerate(self.lora):
+            for key, mods in names.items():
+                site = layer[key]
+                for b, mod in enumerate(mods):
+                    pre = f"base_model.model.model.layers.{i}.{mod}."
+                    yield pre + "lora_A.default.weight", site.A.data[64 * b: 64 * b + site.r]
+                    yield pre + "lora_B.default.weight", site.B[b].data[:, : site.r]
 
     def _hf_named(self):
         """(HF name, tensor view) pairs, modeling_llama.py parameter names."""
@@ -236,6 +322,9 @@ class HipCausalLM(nn.Module):
         for i in range(c.num_hidden_layers):
             h1, rstd1, x1 = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta)
             qkv = ops.gemm_nt(h1, self.wqkv[i].data)                    # [T, QKV]
+            ls = [None] * 4
+            if self.lora is not None:
+                ls[0] = self.lora[i]["qkv"].forward_add(h1, qkv, self.training)
             ops.rope_(qkv, cos, sin, Hq, D, QKV)
             _rope_offset(qkv, Hq * D, cos, sin, Hkv, D, QKV)
             if self.fused_attention:
@@ -251,11 +340,17 @@ class HipCausalLM(nn.Module):
                 ops.gemm_nt_heads(P, S, vT, S, ao, Hq * D, S, D, S, 1.0, B * Hq, Hq, Hq * S * S, S * S, 1,
                                   Hkv * D * S, D * S, G, S * Hq * D, D)
             attn_delta = ops.gemm_nt(ao, self.wo[i].data)               # [T, H]
+            if self.lora is not None:
+                ls[1] = self.lora[i]["o"].forward_add(ao, attn_delta, self.training)
             h2, rstd2, x2 = ops.rmsnorm_fwd(x1, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta)
             gu = ops.gemm_nt(h2, self.wgu[i].data)                      # [T, 2I]
+            if self.lora is not None:
+                ls[2] = self.lora[i]["gu"].forward_add(h2, gu, self.training)
             hm = ops.glu_fwd(gu)
             delta = ops.gemm_nt(hm, self.wdown[i].data)
-            saved.append((x1, rstd1, h1, qkv, P, ao, x2, rstd2, h2, gu, hm))
+            if self.lora is not None:
+                ls[3] = self.lora[i]["down"].forward_add(hm, delta, self.training)
+            saved.append((x1, rstd1, h1, qkv, P, ao, x2, rstd2, h2, gu, hm, ls))
             x = x2
         hf, rstdf, xf = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta)
 
@@ -282,6 +377,8 @@ class HipCausalLM(nn.Module):
             ops.ce_fwd_bwd_(logits, lab, inv_count, loss, c.vocab_size)  # logits <- dlogits
             dhr = ops.gemm_nt(logits, embed_t)                           # [n, H] = dlogits . E
             dhf.index_copy_(0, r, dhr)
+            if self.lora is not None:
+                continue                                                 # frozen base: no embedding / lm_head gradient
             n = r.numel()
             npad = (n + 63) // 64 * 64                                   # contraction over rows: K-step 64
             dlt = torch.zeros((self.v_pad, npad), dtype=torch.bfloat16, device=dev)
@@ -308,12 +405,18 @@ class HipCausalLM(nn.Module):
             dhf = (dhf.float() * go).to(torch.bfloat16)
             self.embed_grad32.mul_(go)
 
+        frozen = self.lora is not None
+
         def wgrad(dy, xin, param):
             """param.grad = dy^T . xin (bf16)"""
+            if frozen:
+                return
             g = ops.gemm_tn(dy, xin)          # contraction over the token rows of both operands: no transposed copies
             param.grad = g if param.grad is None else ops.add(param.grad, g)
 
         def lngrad(param, dw32):
+            if frozen:
+                return
             g = dw32.to(torch.bfloat16)
             param.grad = g if param.grad is None else ops.add(param.grad, g)
 
@@ -321,14 +424,18 @@ class HipCausalLM(nn.Module):
         g = ops.rmsnorm_bwd(xf, self.norm.data, rstdf, dhf, dw)          # grad of the residual stream
         lngrad(self.norm, dw)
         for i in reversed(range(c.num_hidden_layers)):
-            x1, rstd1, h1, qkv, P, ao, x2, rstd2, h2, gu, hm = saved.pop()
+            x1, rstd1, h1, qkv, P, ao, x2, rstd2, h2, gu, hm, ls = saved.pop()
             # MLP
             wgrad(g, hm, self.wdown[i])
             d_hm = ops.gemm_nt(g, self._shadow(("wdown", i), self.wdown[i]))        # [T, I]
+            if frozen:
+                d_hm = ops.add(d_hm, self.lora[i]["down"].backward(g, ls[3]))
             d_gu = ops.glu_bwd(gu, d_hm)
             del d_hm, hm
             wgrad(d_gu, h2, self.wgu[i])
             d_h2 = ops.gemm_nt(d_gu, self._shadow(("wgu", i), self.wgu[i]))         # [T, H]
+            if frozen:
+                d_h2 = ops.add(d_h2, self.lora[i]["gu"].backward(d_gu, ls[2]))
             del d_gu, gu
             dw = torch.zeros(H, dtype=torch.float32, device=dev)
             g2 = ops.rmsnorm_bwd(x2, self.ln2[i].data, rstd2, d_h2, dw, dres=g)
@@ -336,6 +443,8 @@ class HipCausalLM(nn.Module):
             # attention output projection
             wgrad(g2, ao, self.wo[i])
             d_ao = ops.gemm_nt(g2, self._shadow(("wo", i), self.wo[i]))             # [T, Hq*D]
+            if frozen:
+                d_ao = ops.add(d_ao, self.lora[i]["o"].backward(g2, ls[1]))
             # attention core
             if self.fused_attention:
                 d_qkv = ops.attn_bwd(qkv, mask, ao, d_ao, P, B, S, Hq, Hkv, D, scale)
@@ -369,17 +478,22 @@ class HipCausalLM(nn.Module):
             _rope_offset(d_qkv, Hq * D, cos, sin, Hkv, D, QKV, inverse=True)
             wgrad(d_qkv, h1, self.wqkv[i])
             d_h1 = ops.gemm_nt(d_qkv, self._shadow(("wqkv", i), self.wqkv[i]))      # [T, H]
+            if frozen:
+                d_h1 = ops.add(d_h1, self.lora[i]["qkv"].backward(d_qkv, ls[0]))
             dw = torch.zeros(H, dtype=torch.float32, device=dev)
             g = ops.rmsnorm_bwd(x1, self.ln1[i].data, rstd1, d_h1, dw, dres=g2)
             lngrad(self.ln1[i], dw)
             if self.grad_sync is not None:   # this layer's gradients are final: start their all-reduce now
-                self.grad_sync.on_grads_ready([self.wqkv[i], self.wo[i], self.wgu[i], self.wdown[i], self.ln1[i], self.ln2[i]])
-        ops.embed_bwd(input_ids.view(-1), g, self.embed_grad32)
-        eg = self.embed_grad32.to(torch.bfloat16)
-        self.embed.grad = eg if self.embed.grad is None else ops.add(self.embed.grad, eg)
-        self.embed_grad32.zero_()
+                ready = list(self.lora[i].parameters()) if frozen else [self.wqkv[i], self.wo[i], self.wgu[i], self.wdown[i], self.ln1[i], self.ln2[i]]
+                self.grad_sync.on_grads_ready(ready)
+        if not frozen:
+            ops.embed_bwd(input_ids.view(-1), g, self.embed_grad32)
+            eg = self.embed_grad32.to(torch.bfloat16)
+            self.embed.grad = eg if self.embed.grad is None else ops.add(self.embed.grad, eg)
+            self.embed_grad32.zero_()
         if self.grad_sync is not None:
-            self.grad_sync.on_grads_ready([self.embed, self.norm])
+            if not frozen:
+                self.grad_sync.on_grads_ready([self.embed, self.norm])
             self.grad_sync.finish()
 
     # ---- fused optimizer (clip_grad_norm_(1.0) + Adam with L2, Noam schedule) -------------------------

@@ -93,15 +93,25 @@ def set_gemm_tile(tile: int):
     _lib.check(_L().ecgb_set_gemm_tile(int(tile)))
 
 
-def gemm_nt(a, b, out=None, alpha=1.0, accumulate_f32=False):
-    """C[M,N] = alpha * A[M,K] @ B[N,K]^T.  a, b: 2-D bf16 (row stride = shape[1] or a column slice view)."""
+def gemm_nt(a, b, out=None, alpha=1.0, accumulate_f32=False, accumulate=False):
+    """C[M,N] = alpha * A[M,K] @ B[N,K]^T.  a, b: 2-D bf16 (row stride = shape[1] or a column slice view).
+    accumulate_f32: `out` is fp32 and receives +=;  accumulate: `out` is bf16 and receives +=."""
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K and a.stride(1) == 1 and b.stride(1) == 1
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32 if accumulate_f32 else torch.bfloat16, device=a.device)
+    mode = 1 if accumulate_f32 else (2 if accumulate else 0)
     _lib.check(_L().ecgb_gemm_nt_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, float(alpha),
-                                      int(accumulate_f32), 1, 0, 0, 0, _st()))
+                                      mode, 1, 0, 0, 0, _st()))
+    return out
+
+
+def dropout(x, p, seed, out=None):
+    """Inverted dropout; the same (p, seed) reproduces the mask (call it on the gradient for the backward)."""
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_L().ecgb_dropout_bf16(_p(_bf(x)), _p(out), x.numel(), float(p), int(seed), _st()))
     return out
 
 

@@ -51,6 +51,9 @@ int ecgb_glu_fwd(const void *gate_up_dev, void *h_dev, size_t tokens, int inter,
 int ecgb_glu_bwd(const void *gate_up_dev, const void *dh_dev, void *dgate_up_dev, size_t tokens, int inter,
                  int gelu_tanh, void *stream);
 
+/* Inverted dropout with a counter-based generator: out[i] = keep(seed, i) ? x[i] / (1 - p) : 0; the same (seed, p)
+ * reproduces the mask, so the backward pass is the same call on the gradient.  In place allowed. */
+int ecgb_dropout_bf16(const void *x_dev, void *out_dev, size_t n, float p, uint64_t seed, void *stream);
 int ecgb_add_bf16(const void *a_dev, const void *b_dev, void *out_dev, size_t n, void *stream);
 int ecgb_transpose_bf16(const void *in_dev, void *out_dev, int rows, int cols, void *stream);
 /* Batch of strided matrices: entry z = (z / inner, z % inner) starts at base + zo*outer + zi*inner_stride. */
@@ -60,7 +63,8 @@ int ecgb_transpose_bf16_strided(const void *in_dev, void *out_dev, int rows, int
 int ecgb_f32_to_bf16(const float *in_dev, void *out_dev, size_t n, void *stream);
 
 /* C[M,N] = alpha * A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulation on the matrix cores.
- * accumulate_f32 = 0: C is bf16; 1: C is fp32 and C += result.  batch > 1: blockIdx.z strides. */
+ * accumulate_f32 = 0: C is bf16; 1: C is fp32 and C += result; 2: C is bf16 and C += result (LoRA branch added to
+ * the base projection).  batch > 1: blockIdx.z strides. */
 int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
                       int M, int N, int K, float alpha, int accumulate_f32, int batch, long long batch_a,
                       long long batch_b, long long batch_c, void *stream);

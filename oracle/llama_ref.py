@@ -29,7 +29,15 @@ def rotate_half(x):
     return torch.cat((-x2, x1), dim=-1)
 
 
-def llama_loss(params, cfg, input_ids, attention_mask, labels, position_ids, inv_freq):
+def _lin(params, name, x, lora_scale):
+    """nn.Linear, plus the LoRA branch y += scale * B(A x) when `<name>.lora_A/B` are present (peft LoraLayer, dropout 0)."""
+    y = F.linear(x, params[name + ".weight"])
+    if lora_scale is not None and (name + ".lora_A") in params:
+        y = y + lora_scale * F.linear(F.linear(x, params[name + ".lora_A"]), params[name + ".lora_B"])
+    return y
+
+
+def llama_loss(params, cfg, input_ids, attention_mask, labels, position_ids, inv_freq, lora_scale=None):
     """params: dict of HF-named tensors (requires_grad as wanted).  Returns the scalar loss."""
     H, D = cfg["hidden_size"], cfg["head_dim"]
     Hq, Hkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
@@ -46,19 +54,19 @@ def llama_loss(params, cfg, input_ids, attention_mask, labels, position_ids, inv
     for i in range(cfg["num_hidden_layers"]):
         p = f"model.layers.{i}."
         h = rms_norm(x, params[p + "input_layernorm.weight"], cfg["rms_norm_eps"])
-        q = F.linear(h, params[p + "self_attn.q_proj.weight"]).view(B, S, Hq, D).transpose(1, 2)
-        k = F.linear(h, params[p + "self_attn.k_proj.weight"]).view(B, S, Hkv, D).transpose(1, 2)
-        v = F.linear(h, params[p + "self_attn.v_proj.weight"]).view(B, S, Hkv, D).transpose(1, 2)
+        q = _lin(params, p + "self_attn.q_proj", h, lora_scale).view(B, S, Hq, D).transpose(1, 2)
+        k = _lin(params, p + "self_attn.k_proj", h, lora_scale).view(B, S, Hkv, D).transpose(1, 2)
+        v = _lin(params, p + "self_attn.v_proj", h, lora_scale).view(B, S, Hkv, D).transpose(1, 2)
         q = q * cos + rotate_half(q) * sin
         k = k * cos + rotate_half(k) * sin
         k = k.repeat_interleave(Hq // Hkv, 1)
         v = v.repeat_interleave(Hq // Hkv, 1)
         a = F.scaled_dot_product_attention(q, k, v, attn_mask=bias)
         a = a.transpose(1, 2).reshape(B, S, Hq * D)
-        x = x + F.linear(a, params[p + "self_attn.o_proj.weight"])
+        x = x + _lin(params, p + "self_attn.o_proj", a, lora_scale)
         h = rms_norm(x, params[p + "post_attention_layernorm.weight"], cfg["rms_norm_eps"])
-        g = F.silu(F.linear(h, params[p + "mlp.gate_proj.weight"])) * F.linear(h, params[p + "mlp.up_proj.weight"])
-        x = x + F.linear(g, params[p + "mlp.down_proj.weight"])
+        g = F.silu(_lin(params, p + "mlp.gate_proj", h, lora_scale)) * _lin(params, p + "mlp.up_proj", h, lora_scale)
+        x = x + _lin(params, p + "mlp.down_proj", g, lora_scale)
     x = rms_norm(x, params["model.norm.weight"], cfg["rms_norm_eps"])
     logits = F.linear(x, emb).float()
     return F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels[:, 1:].reshape(-1), ignore_index=-100)

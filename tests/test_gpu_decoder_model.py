@@ -93,7 +93,7 @@ def test_training_steps_reduce_loss_and_follow_torch_adam():
         out.loss.backward()
         if step == 0:
             p0 = m.wo[0].data.float().clone()
-            g0 = [p.grad.float().clone() for p in m.parameters()]
+            g0 = [p.grad.float().clone() for p in m.parameters() if p.grad is not None]
             ref = p0.clone().requires_grad_(True)
             total = torch.sqrt(sum((g * g).sum() for g in g0))
             ref.grad = m.wo[0].grad.float() * min(1.0, 1.0 / (total.item() + 1e-6))
@@ -158,3 +158,62 @@ def test_gqa_4_to_1_vs_decoder_oracle(fused_attention):
             assert ((gp.float() - want).norm() / want.norm()).item() < 3e-2, (i, name)
     want = ref_p["model.embed_tokens.weight"].grad
     assert ((m.embed.grad[:515].float() - want).norm() / want.norm()).item() < 3e-2
+
+
+def test_lora_adapters_vs_oracle():
+    """LoRA mode (the reference's launch mode, main.py:131-155): frozen base, r = 16, alpha = 32, adapters on
+    q,k,v,o,gate,up,down; dropout 0 for the parity check.  B is given non-zero values so that every adapter
+    gradient is exercised.  peft is not in the tree: the oracle restates y = Wx + (alpha/r) B(Ax)."""
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    from oracle import llama_ref as R
+    cfgd = dict(vocab_size=515, hidden_size=256, intermediate_size=448, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, head_dim=64, rms_norm_eps=1e-6)
+    params = R.random_params(cfgd, seed=4, device="cuda", std=0.05)
+    cfg = DecoderConfig(vocab_size=515, hidden_size=256, intermediate_size=448, num_hidden_layers=2, num_attention_heads=4,
+                        num_key_value_heads=2, rms_norm_eps=1e-6, rope_theta=10000.0, rope_scaling=None, pad_token_id=514)
+    m = HipCausalLM(cfg)
+    m.load_state_dict(params)
+    m.enable_lora(r=16, alpha=32, dropout=0.0, seed=1)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    ref_p = {k: v.clone() for k, v in params.items()}
+    for name, t in m.lora_named():
+        if "lora_B" in name:
+            t.copy_((torch.randn(t.shape, device="cuda", generator=g) * 0.05).to(torch.bfloat16))
+        key = name.replace("base_model.model.", "").replace(".default.weight", "")
+        ref_p[key] = t.float().clone().requires_grad_(True)
+    B, S = 2, 128
+    ids = torch.randint(0, 514, (B, S), device="cuda", generator=g)
+    mask = torch.ones(B, S, device="cuda"); mask[0, :50] = 0; ids[0, :50] = 514
+    pos = (torch.cumsum(mask, 1) - 1).clamp(min=0).long(); pos[mask == 0] = 0
+    labels = torch.full((B, S), -100, device="cuda"); labels[:, -25:] = ids[:, -25:]
+    ref = R.llama_loss(ref_p, cfgd, ids, mask, labels, pos, R.llama3_inv_freq(64, 10000.0, None).cuda(), lora_scale=2.0)
+    ref.backward()
+    out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
+    out.loss.backward()
+    assert abs(out.loss.item() - ref.item()) <= 1e-2 * ref.item()
+    assert all(p.grad is None for n, p in m.named_parameters() if "lora" not in n), "base must stay frozen"
+    grads = {}
+    names = {"qkv": ["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"], "o": ["self_attn.o_proj"],
+             "gu": ["mlp.gate_proj", "mlp.up_proj"], "down": ["mlp.down_proj"]}
+    for i, layer in enumerate(m.lora):
+        for key, mods in names.items():
+            site = layer[key]
+            for b, mod in enumerate(mods):
+                grads[f"model.layers.{i}.{mod}.lora_A"] = site.A.grad[64 * b: 64 * b + 16]
+                grads[f"model.layers.{i}.{mod}.lora_B"] = site.B[b].grad[:, :16]
+                assert float(site.A.grad[64 * b + 16: 64 * b + 64].abs().max()) == 0.0      # rank padding stays inert
+                assert float(site.B[b].grad[:, 16:].abs().max()) == 0.0
+    for k, gq in grads.items():
+        want = ref_p[k].grad
+        rel = (gq.float() - want).norm() / want.norm().clamp_min(1e-12)
+        assert rel.item() < 4e-2, (k, rel.item())
+    # an optimizer step only moves the adapters; dropout path runs
+    opt = m.make_optimizer()
+    before = m.wo[0].data.clone()
+    opt.step_and_update_lr()
+    assert torch.equal(m.wo[0].data, before)
+    m.lora[0]["o"].p = 0.05
+    m.train()
+    out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
+    out.loss.backward()
+    assert torch.isfinite(out.loss)
