@@ -152,6 +152,8 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
     cfg = DecoderConfig.llama_3_2_1b(vocab_size=n_vocab, pad_token_id=pad)
     model = HipCausalLM(cfg, device=dev, seed=0)
     model.full_logits = bool(args.full_logits)
+    if args.lora:
+        model.enable_lora(r=16, alpha=32, dropout=0.05)      # ecg_byte/main.py:131-138
     if world > 1:
         model.grad_sync = GradAllReduce()
     opt = model.make_optimizer()                          # Adam(0.9, 0.99, 1e-8, wd 1e-2) + Noam(500) + clip 1.0
@@ -197,11 +199,14 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
     tokens = B * S
     head_rows = tokens if model.full_logits else n_valid
     flops = 3 * (2 * Lyr * per_layer * tokens + Lyr * 2 * S * H * tokens + 2 * H * n_vocab * head_rows)
+    if args.lora:   # frozen base: no weight-gradient products (2/3 of the matmul work remains), adapters add ~1 %
+        flops = 2 * (2 * Lyr * per_layer * tokens + 2 * H * n_vocab * head_rows) + 3 * Lyr * 2 * S * H * tokens
     achieved = flops / sec / 1e12
     out = {"metric": "train_samples_per_sec", "value": B * world / sec, "unit": "samples/s", "ms_per_step": sec * 1e3,
            "steps": args.train_steps, "dtype": "bf16", "final_loss": float(loss.item()),
            "config": {"workload": f"C3: Llama-3.2-1B dims (16 layers, hidden 2048, 32/8 heads, vocab {n_vocab}), seq {S}, "
-                                  f"batch {B}/GPU, full fine-tune, random init; batches built by quantise+encode+assemble on device",
+                                  f"batch {B}/GPU, {'LoRA r16 on q,k,v,o,gate,up,down (frozen base)' if args.lora else 'full fine-tune'}, "
+                                  f"random init; batches built by quantise+encode+assemble on device",
                       "loss_head_rows": "all" if model.full_logits else "labelled only (identical loss/gradients)",
                       "parallelism": f"dp{world}" + (" (per-layer async all-reduce over RCCL)" if world > 1 else "")},
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -229,6 +234,7 @@ def main():
     ap.add_argument("--train-batch", type=int, default=32, help="samples per GPU per train step")
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--full-logits", action="store_true", help="loss head over every row, as the reference materialises it")
+    ap.add_argument("--lora", action="store_true", help="train LoRA adapters (r16, alpha 32, dropout 0.05; frozen base) as the reference's script does")
     args = ap.parse_args()
 
     import torch

@@ -13,7 +13,12 @@ ids = torch.randint(1000, 100000, (B, S), device="cuda", generator=g)
 mask = torch.ones(B, S, device="cuda"); mask[:, :100] = 0; ids[:, :100] = cfg.pad_token_id
 pos = (torch.cumsum(mask, 1) - 1).clamp(min=0).long(); pos[mask == 0] = 0
 labels = torch.full((B, S), -100, device="cuda"); labels[:, -20:] = ids[:, -20:]
-for full in (False, True):
+modes = [("full-ft", False), ("full-ft+full-logits", True)]
+if len(sys.argv) > 2 and sys.argv[2] == "lora":
+    m.enable_lora(r=16, alpha=32, dropout=0.05)
+    opt = m.make_optimizer()
+    modes = [("lora", False)]
+for name, full in modes:
     m.full_logits = full
     for it in range(4):
         torch.cuda.synchronize(); t = time.perf_counter()
@@ -24,4 +29,4 @@ for full in (False, True):
         torch.cuda.synchronize(); t2 = time.perf_counter()
         opt.step_and_update_lr()
         torch.cuda.synchronize(); t3 = time.perf_counter()
-        print(f"full_logits={full} it{it}: fwd {1e3*(t1-t):.0f} ms bwd {1e3*(t2-t1):.0f} ms opt {1e3*(t3-t2):.0f} ms  total {1e3*(t3-t):.0f} ms  {B/(t3-t):.1f} samples/s  loss {out.loss.item():.4f}  mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+        print(f"{name} it{it}: fwd {1e3*(t1-t):.0f} ms bwd {1e3*(t2-t1):.0f} ms opt {1e3*(t3-t2):.0f} ms  total {1e3*(t3-t):.0f} ms  {B/(t3-t):.1f} samples/s  loss {out.loss.item():.4f}  mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
