@@ -448,6 +448,60 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs A)
     store_accT<D>(accV, A.dv + (long long)g * D, A.lddv, rowbase + ki, kvalid, h, 1.f);
 }
 
+// =====================================================================================================
+// decode step: one query per (batch, head) against the KV cache.  grid (Hq, B), one wave per workgroup.
+// q [B, Hq*D]; k/v cache rows [B, cap] with row stride ld (elements), kv head g at + g*D; len = keys in the cache
+// (incl. the new one); key j visible iff mask[b, j] != 0.  HBM-bound (reads the cache once).
+__global__ __launch_bounds__(64) void attn_decode_kernel(const unsigned short *q, const unsigned short *kc, const unsigned short *vc,
+                                                         long long ld, long long cap, const float *mask, long long mask_ld,
+                                                         unsigned short *o, int len, int Hq, int Hkv, float scale)
+{
+    extern __shared__ float s_p[];                      // len scores / probabilities
+    constexpr int D = 64;
+    const int hq = blockIdx.x, b = blockIdx.y, g = hq / (Hq / Hkv), lane = threadIdx.x;
+    const unsigned short *qp = q + ((long long)b * Hq + hq) * D;
+    float qf[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) qf[d] = bf2f(qp[d]);
+    const unsigned short *K = kc + (long long)b * cap * ld + (long long)g * D;
+    const unsigned short *V = vc + (long long)b * cap * ld + (long long)g * D;
+    float m = -INFINITY;
+    for (int j = lane; j < len; j += 64) {
+        float sdot = -INFINITY;
+        if (mask[(long long)b * mask_ld + j] != 0.f) {
+            const bf16x8 *kr = reinterpret_cast<const bf16x8 *>(K + (long long)j * ld);
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < D / 8; ++c) {
+                const bf16x8 kv = kr[c];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc += qf[c * 8 + t] * bf2f((unsigned short)kv[t]);
+            }
+            sdot = acc * scale;
+        }
+        s_p[j] = sdot;
+        m = fmaxf(m, sdot);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    float l = 0.f;
+    for (int j = lane; j < len; j += 64) {
+        const float e = (m == -INFINITY) ? 0.f : __expf(s_p[j] - m);
+        s_p[j] = e;
+        l += e;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) l += __shfl_xor(l, d, 64);
+    __syncthreads();
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    float acc = 0.f;                                   // lane = output dimension d
+    for (int j = 0; j < len; ++j) {
+        const float pj = bf2f((unsigned short)(pack_bf16(s_p[j] * inv, 0.f) & 0xFFFFu));   // P is cast to bf16 before P.V, as SDPA does
+        acc += pj * bf2f(V[(long long)j * ld + lane]);
+    }
+    o[((long long)b * Hq + hq) * D + lane] = (unsigned short)(pack_bf16(acc, 0.f) & 0xFFFFu);
+}
+
 int check_args(const AttnArgs &A, int D, const char *who)
 {
     if (A.B <= 0 || A.S <= 0 || A.Hq <= 0 || A.Hkv <= 0 || A.Hq % A.Hkv) {
@@ -511,4 +565,17 @@ extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev
     hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, (hipStream_t)stream, A);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(256), 0, (hipStream_t)stream, A);
     return launched("attn_bwd kernels");
+}
+
+extern "C" int ecgb_attn_decode(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,
+                                const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, int n_q_heads,
+                                int n_kv_heads, int head_dim, float scale, void *stream)
+{
+    if (head_dim != 64) { ecgb::set_error("ecgb_attn_decode: head_dim must be 64 in this build"); return ECGB_ERR_UNSUPPORTED; }
+    if (batch <= 0 || kv_len <= 0 || kv_len > capacity || n_q_heads % n_kv_heads || ld % 8) { ecgb::set_error("ecgb_attn_decode: bad shape"); return ECGB_ERR_INVALID; }
+    if ((size_t)kv_len * 4 > 64 * 1024) { ecgb::set_error("ecgb_attn_decode: cache longer than 16384 keys"); return ECGB_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(attn_decode_kernel, dim3((unsigned)n_q_heads, (unsigned)batch), dim3(64), (size_t)kv_len * 4, (hipStream_t)stream,
+                       (const unsigned short *)q_dev, (const unsigned short *)k_cache_dev, (const unsigned short *)v_cache_dev, ld, capacity,
+                       attn_mask_dev, mask_ld, (unsigned short *)o_dev, kv_len, n_q_heads, n_kv_heads, scale);
+    return launched("attn_decode_kernel");
 }

@@ -191,8 +191,12 @@ class HipCausalLM(nn.Module):
         return self.embed.device
 
     def forward(self, input_ids=None, attention_mask=None, labels=None, position_ids=None, output_attentions=False, **_):
-        if labels is None:
-            raise NotImplementedError("HipCausalLM.forward computes the training loss; pass labels")
+        if labels is None:   # inference forward: logits only (no autograd graph)
+            with torch.no_grad():
+                B, S = input_ids.shape
+                hf = self._hidden_states(input_ids, attention_mask, position_ids)
+                logits = ops.gemm_nt(hf, self.embed.data)[:, :self.cfg.vocab_size].float().view(B, S, -1)
+            return SimpleNamespace(loss=None, logits=logits, attentions=None)
         anchor = self._anchor   # a parameter that requires grad, so autograd records the node
         loss = _LossFn.apply(anchor, self, input_ids, attention_mask, labels, position_ids)
         return SimpleNamespace(loss=loss, logits=None, attentions=None)
@@ -388,6 +392,132 @@ class HipCausalLM(nn.Module):
             ops.gemm_nt(dlt, hrt, out=self.embed_grad32, accumulate_f32=True)   # dE += dlogits^T . h
         self._saved = (saved, input_ids, mask, cos, sin, (xf, rstdf), dhf, (B, S))
         return loss.squeeze(0)
+
+    # ---- inference -----------------------------------------------------------------------------
+    def _hidden_states(self, input_ids, attention_mask=None, position_ids=None, kv_out=None):
+        """Final-normed hidden states [B*S, H] of a whole (left-padded) batch, nothing saved for backward.  kv_out: optional
+        list of per-layer caches [B, cap, 2*Hkv*D]; rows [:S] receive the roped keys and the values (DynamicCache.update,
+        cache_utils.py:408-470)."""
+        c = self.cfg
+        D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        dev = self.device
+        input_ids = input_ids.to(dev).contiguous()
+        B, S = input_ids.shape
+        mask = (attention_mask.to(dev).float() if attention_mask is not None else torch.ones(B, S, device=dev)).contiguous()
+        if position_ids is None:
+            position_ids = torch.arange(S, device=dev)[None].expand(B, S)
+        cos, sin = self._rope_tables(position_ids.to(dev))
+        QKV = self.qkv
+        scale = 1.0 / math.sqrt(D)
+        x = ops.embed_fwd(input_ids.view(-1), self.embed.data)
+        delta = None
+        for i in range(c.num_hidden_layers):
+            h1, _, x = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta)
+            qkv = ops.gemm_nt(h1, self.wqkv[i].data)
+            if self.lora is not None:
+                self.lora[i]["qkv"].forward_add(h1, qkv, False)
+            ops.rope_(qkv, cos, sin, Hq, D, QKV)
+            _rope_offset(qkv, Hq * D, cos, sin, Hkv, D, QKV)
+            if kv_out is not None:
+                kv_out[i][:, :S].copy_(qkv.view(B, S, QKV)[:, :, Hq * D:])
+            ao, _ = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)
+            attn_delta = ops.gemm_nt(ao, self.wo[i].data)
+            if self.lora is not None:
+                self.lora[i]["o"].forward_add(ao, attn_delta, False)
+            h2, _, x = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta)
+            gu = ops.gemm_nt(h2, self.wgu[i].data)
+            if self.lora is not None:
+                self.lora[i]["gu"].forward_add(h2, gu, False)
+            hm = ops.glu_fwd(gu)
+            delta = ops.gemm_nt(hm, self.wdown[i].data)
+            if self.lora is not None:
+                self.lora[i]["down"].forward_add(hm, delta, False)
+        hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta)
+        return hf
+
+    def _decode_step(self, tokens, pos, mask, caches, n):
+        """Hidden state [B, H] of one new token per sequence, written at cache row n-1 (n = keys valid after the update)."""
+        c = self.cfg
+        D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        QKV = self.qkv
+        scale = 1.0 / math.sqrt(D)
+        cos, sin = self._rope_tables(pos)
+        x = ops.embed_fwd(tokens, self.embed.data)                       # [B, H]
+        delta = None
+        for i in range(c.num_hidden_layers):
+            h1, _, x = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta)
+            qkv = ops.gemm_nt(h1, self.wqkv[i].data)                     # [B, QKV]
+            if self.lora is not None:
+                self.lora[i]["qkv"].forward_add(h1, qkv, False)
+            ops.rope_(qkv, cos, sin, Hq, D, QKV)
+            _rope_offset(qkv, Hq * D, cos, sin, Hkv, D, QKV)
+            caches[i][:, n - 1].copy_(qkv[:, Hq * D:])
+            ao = ops.attn_decode(qkv, caches[i], mask, n, Hq, Hkv, D, scale)
+            attn_delta = ops.gemm_nt(ao, self.wo[i].data)
+            if self.lora is not None:
+                self.lora[i]["o"].forward_add(ao, attn_delta, False)
+            h2, _, x = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta)
+            gu = ops.gemm_nt(h2, self.wgu[i].data)
+            if self.lora is not None:
+                self.lora[i]["gu"].forward_add(h2, gu, False)
+            hm = ops.glu_fwd(gu)
+            delta = ops.gemm_nt(hm, self.wdown[i].data)
+            if self.lora is not None:
+                self.lora[i]["down"].forward_add(hm, delta, False)
+        hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta)
+        return hf
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, max_new_tokens=128, pad_token_id=None, eos_token_id=None,
+                 use_cache=True, return_logits=False, **_):
+        """Greedy search with the semantics of GenerationMixin.generate / _sample(do_sample=False)
+        (generation/utils.py:1877, 3131-3250) as LLM.generate calls it (ecg_byte/models/llm.py:26-37): positions from the
+        attention mask (utils.py:410-411), finished sequences keep emitting pad_token_id, stop when every sequence has
+        produced eos_token_id or after max_new_tokens.  Returns [B, S0 + generated] int64 (prompt included)."""
+        c = self.cfg
+        dev = self.device
+        input_ids = input_ids.to(dev).long()
+        B, S0 = input_ids.shape
+        cap = S0 + max_new_tokens
+        mask = torch.zeros((B, cap), dtype=torch.float32, device=dev)
+        mask[:, :S0] = attention_mask.to(dev).float() if attention_mask is not None else 1.0
+        eos = None
+        if eos_token_id is not None:
+            eos = torch.as_tensor(eos_token_id, device=dev).view(-1)
+            if pad_token_id is None:
+                pad_token_id = int(eos[0])                                 # utils.py: "Setting pad_token_id to eos_token_id"
+
+        def positions(m):
+            p = m.long().cumsum(-1) - 1
+            return p.masked_fill(m == 0, 1)
+
+        width = 2 * c.num_key_value_heads * c.head_dim
+        caches = [torch.empty((B, cap, width), dtype=torch.bfloat16, device=dev) for _ in range(c.num_hidden_layers)] if use_cache else None
+        seq = input_ids
+        unfinished = torch.ones(B, dtype=torch.long, device=dev)
+        step_logits = []
+        for t in range(max_new_tokens):
+            n = S0 + t                                                       # tokens in `seq`
+            if t == 0 or not use_cache:
+                m = mask[:, :n].contiguous()
+                hf = self._hidden_states(seq, m, positions(m), caches)
+                last = hf.view(B, n, -1)[:, -1].contiguous()
+            else:
+                pos = positions(mask[:, :n])[:, -1]
+                last = self._decode_step(seq[:, -1].contiguous(), pos, mask, caches, n)
+            logits = ops.gemm_nt(last, self.embed.data)[:, :c.vocab_size].float()
+            if return_logits:
+                step_logits.append(logits)
+            nxt = logits.argmax(-1)
+            if eos is not None:
+                nxt = nxt * unfinished + pad_token_id * (1 - unfinished)
+            seq = torch.cat([seq, nxt[:, None]], 1)
+            mask[:, n] = 1.0
+            if eos is not None:
+                unfinished = unfinished * (~torch.isin(nxt, eos)).long()
+                if int(unfinished.max()) == 0:
+                    break
+        return (seq, torch.stack(step_logits, 1)) if return_logits else seq
 
     # ---- backward -------------------------------------------------------------------------------
     def _backward(self, grad_out):

@@ -208,3 +208,14 @@ def attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale):
                                   _p(o), _p(_bf(do)), Hq * D, _p(lse), _p(delta), _off(d_qkv, 0), QKV, _off(d_qkv, Hq * D), QKV,
                                   _off(d_qkv, Hq * D + Hkv * D), QKV, B, S, Hq, Hkv, D, float(scale), _st()))
     return d_qkv
+
+
+def attn_decode(qkv_new, cache, mask, kv_len, Hq, Hkv, D, scale):
+    """One decode step.  qkv_new [B, (Hq+2Hkv)*D] holds the new token's roped q|k|v; cache [B, cap, 2*Hkv*D] (k | v) already
+    contains the new token's k, v in row kv_len-1; mask [B, cap] fp32.  Returns o [B, Hq*D]."""
+    B, cap, W = cache.shape
+    q = qkv_new[:, :Hq * D].contiguous()
+    o = torch.empty((B, Hq * D), dtype=torch.bfloat16, device=q.device)
+    _lib.check(_L().ecgb_attn_decode(_p(q), _off(cache, 0), _off(cache, Hkv * D), W, cap, _p(mask), mask.stride(0), _p(o),
+                                     B, int(kv_len), Hq, Hkv, D, float(scale), _st()))
+    return o

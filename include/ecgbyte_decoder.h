@@ -125,6 +125,15 @@ int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev, long long
                   float *delta_dev, void *dq_dev, long long lddq, void *dk_dev, long long lddk, void *dv_dev,
                   long long lddv, int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim, float scale, void *stream);
 
+/* One decode step of generate(): q [batch, n_q_heads*head_dim] against a KV cache whose rows (one per position) are
+ * `ld` elements apart, `capacity` rows per batch entry, KV head g at + g*head_dim; the first kv_len rows are valid
+ * (the new token included); attn_mask [batch, mask_ld] marks padded positions with 0.
+ * Reference: LlamaSdpaAttention.forward with past_key_value (modeling_llama.py:563-575), DynamicCache.update
+ * (cache_utils.py:408).  o [batch, n_q_heads*head_dim]. */
+int ecgb_attn_decode(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,
+                     const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, int n_q_heads,
+                     int n_kv_heads, int head_dim, float scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,12 @@ def _lin(params, name, x, lora_scale):
 
 def llama_loss(params, cfg, input_ids, attention_mask, labels, position_ids, inv_freq, lora_scale=None):
     """params: dict of HF-named tensors (requires_grad as wanted).  Returns the scalar loss."""
+    logits = llama_logits(params, cfg, input_ids, attention_mask, position_ids, inv_freq, lora_scale)
+    return F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels[:, 1:].reshape(-1), ignore_index=-100)
+
+
+def llama_logits(params, cfg, input_ids, attention_mask, position_ids, inv_freq, lora_scale=None):
+    """Float logits [B, S, V] of LlamaForCausalLM.forward (modeling_llama.py:1135-1213)."""
     H, D = cfg["hidden_size"], cfg["head_dim"]
     Hq, Hkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
     B, S = input_ids.shape
@@ -68,8 +74,25 @@ def llama_loss(params, cfg, input_ids, attention_mask, labels, position_ids, inv
         g = F.silu(_lin(params, p + "mlp.gate_proj", h, lora_scale)) * _lin(params, p + "mlp.up_proj", h, lora_scale)
         x = x + _lin(params, p + "mlp.down_proj", g, lora_scale)
     x = rms_norm(x, params["model.norm.weight"], cfg["rms_norm_eps"])
-    logits = F.linear(x, emb).float()
-    return F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels[:, 1:].reshape(-1), ignore_index=-100)
+    return F.linear(x, emb).float()
+
+
+def greedy_generate(params, cfg, input_ids, attention_mask, inv_freq, max_new_tokens, eos_token_id, pad_token_id):
+    """GenerationMixin greedy search (generation/utils.py:3131, do_sample=False) without a cache: re-runs the
+    full forward per step; position ids as HF derives them from the mask (cumsum - 1)."""
+    ids, mask = input_ids.clone(), attention_mask.clone()
+    done = torch.zeros(ids.shape[0], dtype=torch.bool, device=ids.device)
+    for _ in range(max_new_tokens):
+        pos = (torch.cumsum(mask, 1) - 1).long()
+        pos.masked_fill_(mask == 0, 1)                      # generation/utils.py:410-411
+        nxt = llama_logits(params, cfg, ids, mask, pos, inv_freq)[:, -1].argmax(-1)
+        nxt = torch.where(done, torch.full_like(nxt, pad_token_id), nxt)
+        ids = torch.cat([ids, nxt[:, None]], 1)
+        mask = torch.cat([mask, torch.ones_like(mask[:, :1])], 1)
+        done = done | (nxt == eos_token_id)
+        if bool(done.all()):
+            break
+    return ids
 
 
 def random_params(cfg, seed=0, dtype=torch.float32, device="cpu", std=0.02):

@@ -217,3 +217,83 @@ def test_lora_adapters_vs_oracle():
     out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
     out.loss.backward()
     assert torch.isfinite(out.loss)
+
+
+def _load_generate():
+    z, m = _load()
+    zg = np.load(os.path.join(GOLDEN, "decoder_generate_tiny.npz"))
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    m.load_state_dict({k: (v * 4.0 if "proj" in k else v) for k, v in sd.items()})   # as make_generate_golden.py does
+    m.eval()
+    return zg, m
+
+
+def _check_greedy(seq, logits, want_seq, want_scores, S0, tol):
+    """Greedy paths are compared step by step: while the paths agree the bf16 logits must be within `tol` of the
+    reference's fp32 scores; a sequence may leave the reference path only at a step where the reference's own top-2
+    margin is below `tol` (a tie at bf16 resolution), after which it is no longer comparable.  `tol` is 1.5x the largest
+    deviation of the reference's OWN bf16 run from its fp32 scores on this fixture (stored by make_generate_golden.py)."""
+    B = seq.shape[0]
+    exact = 0
+    for b in range(B):
+        for t in range(want_scores.shape[1]):
+            if S0 + t >= seq.shape[1]:
+                break
+            ref = want_scores[b, t]
+            if np.isfinite(ref).all() and want_seq[b, S0 + t] == ref.argmax():     # an unfinished reference row
+                err = np.abs(logits[b, t] - ref).max()
+                assert err < tol, (b, t, err)
+            if seq[b, S0 + t] != want_seq[b, S0 + t]:
+                top2 = np.sort(ref)[-2:]
+                assert top2[1] - top2[0] < tol, (b, t, seq[b, S0 + t], want_seq[b, S0 + t], top2)
+                break
+            exact += 1
+    return exact
+
+
+@pytest.mark.parametrize("use_cache", [True, False], ids=["kv-cache", "recompute"])
+def test_generate_greedy_vs_vendored_transformers(use_cache):
+    """HipCausalLM.generate against GenerationMixin.generate of the vendored transformers (fixture made by
+    tests/golden/make_generate_golden.py): left-padded prompts of length 45, eos reached by one sequence at step 5
+    (it must keep emitting pad), 24 new tokens."""
+    zg, m = _load_generate()
+    ids = torch.from_numpy(zg["input_ids"]).cuda()
+    mask = torch.from_numpy(zg["attention_mask"]).cuda()
+    S0 = ids.shape[1]
+    seq, logits = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=int(zg["max_new_tokens"]),
+                             pad_token_id=int(zg["pad_token_id"]), eos_token_id=int(zg["eos_token_id"]), use_cache=use_cache,
+                             return_logits=True)
+    seq = seq.cpu().numpy()
+    want = zg["sequences"]
+    assert (seq[:, :S0] == zg["input_ids"]).all()
+    exact = _check_greedy(seq, logits.cpu().numpy(), want, zg["scores"], S0, 1.5 * float(zg["ref_bf16_deviation"].max()))
+    assert exact >= 30, exact                                   # 24 + 24 + 6 comparable steps at most
+    # the finished sequence pads from the step after its eos
+    row = seq[1, S0:]
+    k = list(row).index(int(zg["eos_token_id"]))
+    assert (row[k + 1:] == int(zg["pad_token_id"])).all() and (want[1, S0:] == row).all()
+
+
+def test_generate_without_eos_and_logits_forward():
+    zg, m = _load_generate()
+    ids = torch.from_numpy(zg["input_ids"]).cuda()
+    mask = torch.from_numpy(zg["attention_mask"]).cuda()
+    S0 = ids.shape[1]
+    seq, logits = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=24, pad_token_id=299, return_logits=True)
+    assert seq.shape == (3, S0 + 24)
+    exact = _check_greedy(seq.cpu().numpy(), logits.cpu().numpy(), zg["sequences_no_eos"], zg["scores_no_eos"], S0,
+                          1.5 * float(zg["ref_bf16_deviation"].max()))
+    assert exact >= 40, exact
+    # logits-only forward (labels=None) over the prompt: last row equals the first generate step
+    pos = (mask.cumsum(-1) - 1).masked_fill(mask == 0, 1)
+    out = m(input_ids=ids, attention_mask=mask, position_ids=pos)
+    assert out.loss is None and out.logits.shape == (3, S0, 300)
+    assert (out.logits[:, -1] - logits[:, 0]).abs().max().item() < 1e-6
+
+
+def test_generate_stops_when_every_sequence_finished():
+    zg, m = _load_generate()
+    ids = torch.from_numpy(zg["input_ids"]).cuda()[1:2]
+    mask = torch.from_numpy(zg["attention_mask"]).cuda()[1:2]
+    seq = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=24, pad_token_id=299, eos_token_id=int(zg["eos_token_id"]))
+    assert seq.shape[1] == ids.shape[1] + 6 and int(seq[0, -1]) == int(zg["eos_token_id"])   # HF returns as soon as all are done
