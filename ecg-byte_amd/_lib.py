@@ -57,6 +57,8 @@ def lib():
     L.ecgb_tokenizer_info.restype = C.c_int
     L.ecgb_tokenizer_copy_nodes.argtypes = [vp, C.POINTER(C.c_uint64), sz]
     L.ecgb_tokenizer_copy_nodes.restype = sz
+    L.ecgb_tokenizer_copy_runbits.argtypes = [vp, u32p, sz]
+    L.ecgb_tokenizer_copy_runbits.restype = sz
     L.ecgb_quantize_hip.argtypes = [vp, sz, C.c_double, C.c_double, vp, vp, vp]
     L.ecgb_quantize_hip.restype = C.c_int
     L.ecgb_encode_scratch_bytes.argtypes = [vp, sz, sz]

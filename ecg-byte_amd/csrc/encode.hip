@@ -201,6 +201,11 @@ struct EncodeArgs {
     const uint64_t *trie;     // packed nodes (global copy, all of them)
     uint32_t n_nodes;
     uint32_t n_lds_nodes;     // nodes [0, n_lds_nodes) are staged in LDS
+    const uint32_t *runbits;  // per-node continuation / token bit tables (tokenizer.hpp), all of them staged in LDS
+    uint32_t n_runwords;      // even
+    const uint8_t *tok_len;   // token id -> length (flow kernel)
+    uint32_t n_toklen;        // multiple of 8
+    uint32_t chunk;           // flow kernel: symbols per lane-chunk; a segment is 64 chunks
     const uint8_t *lut;       // 256 B byte->class | 32 x u16 single_id | 32 B class->byte
     const double *signal;     // batch x n float64 samples            (INPUT_F64)
     const uint8_t *raw;       // batch x n raw bytes                  (INPUT_BYTES)
@@ -227,6 +232,8 @@ unsigned long long *g_prof_dev = nullptr;
 #endif
 
 constexpr int INPUT_F64 = 0, INPUT_BYTES = 1;
+constexpr uint32_t kLenBias = 30;          // flow kernel: a symbol byte >= kLenBias holds kLenBias + the length of the token that starts there
+constexpr size_t kFlowSlot = 4096;         // u16 id slots per resident wave of the flow kernel (one segment, full resolution)
 
 // clear bits [lo, hi) of a lane-owned run of mark words (segment-relative bit indices)
 __device__ __forceinline__ void clear_bits(uint32_t *marks, uint32_t lo, uint32_t hi)
@@ -249,7 +256,8 @@ __device__ __forceinline__ void clear_bits(uint32_t *marks, uint32_t lo, uint32_
 template <int CHUNK>
 __device__ __forceinline__ uint32_t swz(uint32_t k)
 {
-    return k ^ (((k / CHUNK) & 31u) << 2);
+    if constexpr (CHUNK == 0) return k;   // no swizzle: the flow kernel picks a chunk length that spreads over the banks by itself
+    else return k ^ (((k / CHUNK) & 31u) << 2);
 }
 
 // ---- stage: positions [seg_base, seg_base + stage_len) of one stream -> symbol classes in LDS.
@@ -309,6 +317,42 @@ __device__ __forceinline__ void stage_symbols(uint8_t *sym, uint32_t stage_len, 
     }
 }
 
+// ---- change map: bit k of `dmap` = (class of position k != class of position k - 1), bit 0 set.  A run of
+// equal symbols is a run of zero bits, so the walk reads the length of the run ahead of it with one
+// find-first-set instead of one trie step per symbol.
+template <int CHUNK>
+__device__ __forceinline__ void build_dmap(const uint8_t *sym, uint32_t *dmap, uint32_t stage_len, uint32_t lane, uint32_t nlanes)
+{
+    const uint32_t n_words = (stage_len + 31) >> 5;
+    for (uint32_t w = lane; w < n_words; w += nlanes) {
+        uint32_t prev = (w == 0) ? 0xFFu : sym[swz<CHUNK>(32 * w - 1)];   // 0xFF is no class: bit 0 of word 0 is set
+        uint32_t bits = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < 8; ++g) {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(sym + swz<CHUNK>(32 * w + 4 * g));
+            const uint32_t x = v ^ ((v << 8) | prev);                                  // byte t != 0 iff symbol t differs from t - 1
+            const uint32_t nz = ((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) >> 7) & 0x01010101u;   // bit 8t = byte t non-zero
+            bits |= ((nz | (nz >> 7) | (nz >> 14) | (nz >> 21)) & 0xFu) << (4 * g);
+            prev = v >> 24;
+        }
+        dmap[w] = bits;
+    }
+}
+
+// what a walk needs besides the chunk bounds
+struct WalkCtx {
+    const uint8_t *sym;       // symbol classes of the segment (swizzled)
+    uint32_t *marks;          // token-start bitmap of the segment
+    const uint32_t *dmap;     // change map of the segment
+    uint16_t *ids_half;
+    const uint64_t *s_trie, *g_trie;
+    const uint32_t *s_run;    // run bit tables
+    uint32_t n_lds;
+#ifdef ECGB_PROFILE
+    unsigned long long *prof; // this workgroup's counters
+#endif
+};
+
 // ---- walk: parse one chunk [s_rel, e_rel) (segment-relative) from `start_rel`, merging into
 // whatever chain the chunk already holds.  Returns the segment-relative position at which the
 // chain leaves the chunk, or `old_exit` when it lands on a position the existing chain marked.
@@ -318,13 +362,20 @@ __device__ __forceinline__ void stage_symbols(uint8_t *sym, uint32_t stage_len, 
 // bottom.  (Written with `continue`, LLVM splits the two back edges into nested loops and a wave
 // then waits for its slowest lane on every TOKEN, ~10x the trips; the single latch with a
 // convergent no-op keeps it flat.)  Marks are set and cleared with no-return LDS atomics: nothing
-// is on the dependent path but the two reads.
+// is on the dependent path but the reads at the top of a trip, all issued together.
+//
+// A step is one of (tokenizer.hpp describes the node layout):
+//   branch        the symbol differs from the previous one (or the walk is at the root): child by bitmap + popcount;
+//   continuation  the symbol repeats the previous one and the node is the head of its same-class chain: one node;
+//   run           it repeats and the node is inside the chain: the chain is consecutive node ids, so the walk takes
+//                 m = min(run length ahead, chain length below, 32) symbols at once; the deepest token-carrying node
+//                 it passes comes from the token bit table (the node it lands on is examined by the next trip).
 template <int CHUNK, bool FIRST, bool ALL_LDS>
-__device__ __forceinline__ uint32_t walk_chunk(const uint8_t *sym, uint32_t *marks, uint16_t *ids_half,
-                                               const uint64_t *s_trie, const uint64_t *g_trie,
-                                               uint32_t n_lds, uint32_t s_rel, uint32_t e_rel,
+__device__ __forceinline__ uint32_t walk_chunk(const WalkCtx &W, uint32_t s_rel, uint32_t e_rel,
                                                uint32_t start_rel, uint32_t old_exit)
 {
+    const uint8_t *sym = W.sym;
+    uint32_t *marks = W.marks;
     if constexpr (!FIRST) {
         if (start_rel >= e_rel) {   // chain jumps over this chunk
             clear_bits(marks, s_rel, e_rel);
@@ -334,26 +385,65 @@ __device__ __forceinline__ uint32_t walk_chunk(const uint8_t *sym, uint32_t *mar
         if ((marks[start_rel >> 5] >> (start_rel & 31)) & 1u) return old_exit;   // already on the chain
     }
     uint32_t r = start_rel;        // token start
-    uint32_t j = r, node = 0, best_j = r, best_tok = 0;
+    uint32_t j = r, node = 0, best_j = r, best_node = 0;
     uint32_t result = 0;
     bool done = false;
     while (!done) {
+#ifdef ECGB_PROFILE
+        if (W.prof && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&W.prof[FIRST ? 5 : 6], 1ull);
+#endif
         const uint32_t s = sym[swz<CHUNK>(j)];
         uint64_t rec;
-        if constexpr (ALL_LDS) rec = s_trie[node];
-        else rec = (node < n_lds) ? s_trie[node] : g_trie[node];
+        if constexpr (ALL_LDS) rec = W.s_trie[node];
+        else rec = (node < W.n_lds) ? W.s_trie[node] : W.g_trie[node];
+        const uint32_t dk = j >> 5, u = node + 1, rk = (u >> 5) * 2;
+        const uint32_t d0 = W.dmap[dk], d1 = W.dmap[dk + 1];
+        const uint2 r0 = *reinterpret_cast<const uint2 *>(W.s_run + rk), r1 = *reinterpret_cast<const uint2 *>(W.s_run + rk + 2);
+        const uint32_t dw = __builtin_amdgcn_alignbit(d1, d0, j & 31);        // bit t: position j + t starts a new run
         const uint32_t bm = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
-        const uint32_t tok = hi >> 16;
-        if (tok != ecgb::kNoToken) { best_j = j; best_tok = tok; }   // the root carries none
-        const uint32_t bit = 1u << s;
-        if (bm & bit) {
-            node = (hi & 0xFFFFu) + __popc(bm & (bit - 1u));
-            ++j;
+        const uint32_t fc = hi & 0xFFFFu;
+        if ((hi >> 16) != ecgb::kNoToken) { best_j = j; best_node = node; }   // the root carries none
+        bool advanced = false;
+        if (node != 0 && !(dw & 1u)) {              // the symbol repeats the one this node was entered by
+            if (bm & ecgb::kContFlag) {
+                advanced = true;
+                if (bm & ecgb::kHeadFlag) {
+                    node = fc + __popc(bm & ecgb::kBranchMask);
+                    ++j;
+                } else {
+                    const uint32_t cw = __builtin_amdgcn_alignbit(r1.x, r0.x, u & 31);   // bit t: node u + t has a continuation
+                    const uint32_t tw = __builtin_amdgcn_alignbit(r1.y, r0.y, u & 31);   // bit t: node u + t carries a token
+                    const uint32_t z = min((uint32_t)__ffs(dw) - 1u, 32u);               // symbols of this run ahead (>= 1)
+                    const uint32_t ones = min((uint32_t)__ffs(~cw) - 1u, 32u);
+                    const uint32_t m = min(z, ones + 1u);
+                    const uint32_t passed = tw & ((1u << (m - 1u)) - 1u);                // nodes u .. u + m - 2
+                    if (passed) {
+                        const uint32_t q = 31u - __clz(passed);
+                        best_j = j + q + 1u;
+                        best_node = u + q;
+                    }
+                    node += m;
+                    j += m;
+                }
+            }
         } else {
+            const uint32_t bit = 1u << s;
+            if (bm & bit) {
+                node = fc + __popc(bm & (bit - 1u));
+                ++j;
+                advanced = true;
+            }
+        }
+        if (!advanced) {
             // emit the token [r, r + len)
             const uint32_t len = max(best_j - r, 1u);   // unmatched byte: lib.rs:186-189
             atomicOr(&marks[r >> 5], 1u << (r & 31));
-            if (len >= 2) ids_half[r >> 1] = (uint16_t)best_tok;
+            if (len >= 2) {
+                uint64_t brec;
+                if constexpr (ALL_LDS) brec = W.s_trie[best_node];
+                else brec = (best_node < W.n_lds) ? W.s_trie[best_node] : W.g_trie[best_node];
+                W.ids_half[r >> 1] = (uint16_t)(brec >> 48);
+            }
             if constexpr (!FIRST) {   // drop marks of the old chain inside (r, r + len)
                 uint32_t lo = r + 1;
                 const uint32_t hi_pos = min(r + len, e_rel);
@@ -413,27 +503,49 @@ __device__ __forceinline__ uint32_t emit_word(uint32_t bits, uint32_t w_rel, con
 
 // ==========================================================================================
 // Kernel 1 (large batches): ONE WAVE = ONE STREAM.  A workgroup is W independent waves that share
-// only the LDS trie; each wave takes streams b = wave_id, wave_id + total_waves, ... and walks
-// them in segments of 64 chunks, one lane per chunk.  All synchronisation is wave-local (shuffles,
-// ballots, program order of the wave's own LDS traffic): no workgroup barrier after start-up, so
-// the waves of a CU drift into different phases and the HBM-bound staging of some overlaps the
-// LDS-latency-bound parsing of others.
-template <int CHUNK, int INPUT, bool ALL_LDS, bool VEC>
-__global__ __launch_bounds__(1024) void encode_wave_kernel(EncodeArgs A)
+// only the LDS tables; each wave takes streams b = wave_id, wave_id + total_waves, ... and parses
+// them in segments of 64 chunks.  All synchronisation is wave-local (shuffles, ballots, program
+// order of the wave's own LDS traffic): no workgroup barrier after start-up, so the waves of a CU
+// drift into different phases and the HBM-bound staging of some overlaps the parsing of others.
+//
+// Per segment:
+//   parse    lane c starts a greedy parse at the start of chunk c (lane 0: at the carry, which is the
+//            one start known to lie on the real chain).  Every token start is CLAIMED with a returning
+//            LDS atomic-or on the segment's bitmap; a parse that reaches a position somebody claimed
+//            before has joined that parse and stops, otherwise it keeps going -- past its chunk,
+//            through later chunks, to the end of the segment.  Every position is therefore parsed at
+//            most once, nothing is ever re-walked, and a lane is idle only from its join to the end
+//            of the loop.  Each token's id goes to a full-resolution scratch array in global memory
+//            (0xFFFF for a single symbol).
+//   resolve  the claimed positions are the real chain plus the speculative prefixes that joined it.
+//            Token lengths of all claimed positions are pulled back (id -> length table) into the
+//            symbol bytes, then lane c follows the length pointers through positions [64c, 64c+64)
+//            from a guessed entry; entries are corrected from the left neighbour's exit until
+//            nothing changes (a few LDS hops per pass, no trie walking).
+//   emit     exclusive scan of the per-lane token counts, ids written in stream order.
+template <int INPUT, bool ALL_LDS, bool VEC>
+__global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
 {
-    constexpr uint32_t SEG = 64 * CHUNK, WORDS = CHUNK / 32, MARKW = SEG / 32;
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t n_waves = blockDim.x >> 6;
-    const uint32_t sym_cap = SEG + A.margin;                  // multiple of 16
+    const uint32_t CH = A.chunk, SEG = 64u * CH, MARKW = SEG / 32;            // SEG is a multiple of 64
+    const uint32_t sym_cap = SEG + A.margin;                                   // multiple of 16
     uint64_t *s_trie = reinterpret_cast<uint64_t *>(smem);
     double *s_thr = reinterpret_cast<double *>(s_trie + A.n_lds_nodes);        // 28
     uint16_t *s_single = reinterpret_cast<uint16_t *>(s_thr + 28);             // 32
     uint8_t *s_b2c = reinterpret_cast<uint8_t *>(s_single + 32);               // 256
-    uint8_t *s_sym_all = s_b2c + 256;
+    uint32_t *s_run = reinterpret_cast<uint32_t *>(s_b2c + 256);               // n_runwords (even)
+    uint8_t *s_len = reinterpret_cast<uint8_t *>(s_run + A.n_runwords);        // n_toklen (multiple of 8)
+    uint8_t *s_sym_all = s_len + A.n_toklen;
     uint32_t *s_marks_all = reinterpret_cast<uint32_t *>(s_sym_all + (size_t)n_waves * sym_cap);
+    const uint32_t dmap_words = sym_cap / 32 + 2;                              // + the word a window read may touch past the end
+    uint32_t *s_dmap_all = s_marks_all + n_waves * MARKW;
 
     const uint32_t tid = threadIdx.x, wave = tid >> 6, c = tid & 63;
     for (uint32_t i = tid; i < A.n_lds_nodes; i += blockDim.x) s_trie[i] = A.trie[i];
+    for (uint32_t i = tid; i < A.n_runwords; i += blockDim.x) s_run[i] = A.runbits[i];
+    for (uint32_t i = tid; i < A.n_toklen / 4; i += blockDim.x)
+        reinterpret_cast<uint32_t *>(s_len)[i] = reinterpret_cast<const uint32_t *>(A.tok_len)[i];
     if (tid < 28) s_thr[tid] = A.qp.thr[tid];
     if (tid < 32) s_single[tid] = reinterpret_cast<const uint16_t *>(A.lut + 256)[tid];
     if (tid < 256) s_b2c[tid] = A.lut[tid];
@@ -441,11 +553,10 @@ __global__ __launch_bounds__(1024) void encode_wave_kernel(EncodeArgs A)
 
     uint8_t *sym = s_sym_all + (size_t)wave * sym_cap;
     uint32_t *marks = s_marks_all + wave * MARKW;
-    uint32_t *my = marks + c * WORDS;
+    uint32_t *dmap = s_dmap_all + wave * dmap_words;
     const uint32_t gw = blockIdx.x * n_waves + wave, total_waves = gridDim.x * n_waves;
-    uint16_t *ids_half = A.ids_half + (size_t)gw * (SEG / 2);
-    const uint64_t *g_trie = A.trie;
-    const uint32_t n_lds = A.n_lds_nodes, n = A.n;
+    uint16_t *ids_full = A.ids_half + (size_t)gw * kFlowSlot;
+    const uint32_t n = A.n;
     const double qa = A.qp.a, qscale = A.qp.scale;
 #ifdef ECGB_PROFILE
     long long t_prof = clock64();
@@ -457,22 +568,128 @@ __global__ __launch_bounds__(1024) void encode_wave_kernel(EncodeArgs A)
         uint32_t carry = 0, out_off = 0;
         for (uint32_t seg_base = 0; seg_base < n; seg_base += SEG) {
             const uint32_t seg_len = min(SEG, n - seg_base);
-            const uint32_t s_rel = min(c * (uint32_t)CHUNK, seg_len), e_rel = min(s_rel + CHUNK, seg_len);
             const uint32_t stage_len = min(sym_cap, (n - seg_base + 16u) & ~15u);   // >= 1 sentinel past n
-            stage_symbols<CHUNK, INPUT, VEC>(sym, stage_len, n - seg_base, A.signal + row + seg_base,
-                                      A.raw + row + seg_base, c, 64, qa, qscale, s_thr, s_b2c);
-#pragma unroll
-            for (uint32_t w = 0; w < WORDS; ++w) my[w] = 0;
+            stage_symbols<0, INPUT, VEC>(sym, stage_len, n - seg_base, A.signal + row + seg_base,
+                                         A.raw + row + seg_base, c, 64, qa, qscale, s_thr, s_b2c);
+            for (uint32_t w = c; w < MARKW; w += 64) marks[w] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            build_dmap<0>(sym, dmap, stage_len, c, 64);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             PROF_STAMP(0);
 
-            uint32_t entry = s_rel, my_exit = s_rel;
-            if (s_rel < e_rel)
-                my_exit = walk_chunk<CHUNK, true, ALL_LDS>(sym, marks, ids_half, s_trie, g_trie, n_lds, s_rel, e_rel, s_rel, s_rel);
-            PROF_STAMP(1);
-            // stitch to a fixed point: entry(c) must equal exit(c-1), entry(0) = carry
+            // ---- parse
             const uint32_t carry_rel = carry - seg_base;
+            {
+                uint32_t r = (c == 0) ? carry_rel : max(c * CH, carry_rel);   // chunks the carry token covers start at the carry
+                uint32_t j = r, node = 0, best_j = r, best_node = 0;
+                bool live = r < seg_len;
+                while (live) {
+#ifdef ECGB_PROFILE
+                    if (A.prof && c == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&A.prof[blockIdx.x * 8 + 5], 1ull);
+#endif
+                    uint32_t claimed = 0;
+                    if (node == 0) claimed = atomicOr(&marks[r >> 5], 1u << (r & 31));   // node == 0 <=> at a token start
+                    const uint32_t s = sym[j];
+                    uint64_t rec;
+                    if constexpr (ALL_LDS) rec = s_trie[node];
+                    else rec = (node < A.n_lds_nodes) ? s_trie[node] : A.trie[node];
+                    const uint32_t dk = j >> 5, u = node + 1, rk = (u >> 5) * 2;
+                    const uint32_t d0 = dmap[dk], d1 = dmap[dk + 1];
+                    const uint2 r0 = *reinterpret_cast<const uint2 *>(s_run + rk), r1 = *reinterpret_cast<const uint2 *>(s_run + rk + 2);
+                    if (node == 0 && ((claimed >> (r & 31)) & 1u)) {
+                        live = false;                                                    // joined a parse that got here first
+                    } else {
+                        const uint32_t dw = __builtin_amdgcn_alignbit(d1, d0, j & 31);   // bit t: position j + t starts a new run
+                        const uint32_t bm = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
+                        const uint32_t fc = hi & 0xFFFFu;
+                        if ((hi >> 16) != ecgb::kNoToken) { best_j = j; best_node = node; }   // the root carries none
+                        bool advanced = false;
+                        if (node != 0 && !(dw & 1u)) {              // the symbol repeats the one this node was entered by
+                            if (bm & ecgb::kContFlag) {
+                                advanced = true;
+                                if (bm & ecgb::kHeadFlag) {
+                                    node = fc + __popc(bm & ecgb::kBranchMask);
+                                    ++j;
+                                } else {
+                                    const uint32_t cw = __builtin_amdgcn_alignbit(r1.x, r0.x, u & 31);
+                                    const uint32_t tw = __builtin_amdgcn_alignbit(r1.y, r0.y, u & 31);
+                                    const uint32_t z = min((uint32_t)__ffs(dw) - 1u, 32u);
+                                    const uint32_t ones = min((uint32_t)__ffs(~cw) - 1u, 32u);
+                                    const uint32_t m = min(z, ones + 1u);
+                                    const uint32_t passed = tw & ((1u << (m - 1u)) - 1u);
+                                    if (passed) {
+                                        const uint32_t q = 31u - __clz(passed);
+                                        best_j = j + q + 1u;
+                                        best_node = u + q;
+                                    }
+                                    node += m;
+                                    j += m;
+                                }
+                            }
+                        } else {
+                            const uint32_t bit = 1u << s;
+                            if (bm & bit) {
+                                node = fc + __popc(bm & (bit - 1u));
+                                ++j;
+                                advanced = true;
+                            }
+                        }
+                        if (!advanced) {
+                            // emit the token [r, r + len): its id (the root's kNoToken for an unmatched or single symbol)
+                            uint64_t brec;
+                            if constexpr (ALL_LDS) brec = s_trie[best_node];
+                            else brec = (best_node < A.n_lds_nodes) ? s_trie[best_node] : A.trie[best_node];
+                            const uint32_t len = max(best_j - r, 1u);   // unmatched byte: lib.rs:186-189
+                            ids_full[r] = (len >= 2) ? (uint16_t)(brec >> 48) : (uint16_t)ecgb::kNoToken;
+                            r += len; j = r; node = 0; best_j = r; best_node = 0;
+                            live = r < seg_len;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the ids other lanes stored are read below (same CU, same L1)
+            __builtin_amdgcn_wave_barrier();
+            PROF_STAMP(1);
+
+            // ---- resolve: lane c owns positions [64c, 64c + 64)
+            const uint32_t pbase = 64u * c;
+            const uint32_t s_blk = min(pbase, seg_len), e_blk = min(pbase + 64u, seg_len);
+            const uint32_t w0 = (2 * c < MARKW) ? marks[2 * c] : 0u, w1 = (2 * c + 1 < MARKW) ? marks[2 * c + 1] : 0u;
+            const unsigned long long claimed_bits = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
+            for (unsigned long long rem = claimed_bits; rem;) {   // token lengths into the symbol bytes, four loads in flight
+                uint32_t p[4], idv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    p[t] = 0xFFFFFFFFu;
+                    if (rem) {
+                        p[t] = pbase + (uint32_t)__ffsll((long long)rem) - 1u;
+                        rem &= rem - 1;
+                        idv[t] = ids_full[p[t]];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (p[t] != 0xFFFFFFFFu && idv[t] != ecgb::kNoToken) sym[p[t]] = (uint8_t)(kLenBias + s_len[idv[t]]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            auto follow = [&](uint32_t p, unsigned long long &on_chain) {   // length pointers through this lane's block
+                on_chain = 0;
+                while (p < e_blk) {
+                    on_chain |= 1ull << (p - pbase);
+                    const uint32_t bb = sym[p];
+                    p += (bb < kLenBias) ? 1u : bb - kLenBias;
+                }
+                return p;
+            };
+            unsigned long long chain = 0;
+            uint32_t entry = (c == 0) ? carry_rel : (claimed_bits ? pbase + (uint32_t)__ffsll((long long)claimed_bits) - 1u : e_blk);
+            entry = max(entry, s_blk);
+            uint32_t my_exit = follow(entry, chain);
             for (;;) {
                 const uint32_t prev = __shfl_up(my_exit, 1, 64);
                 const uint32_t want = (c == 0) ? carry_rel : prev;
@@ -481,19 +698,15 @@ __global__ __launch_bounds__(1024) void encode_wave_kernel(EncodeArgs A)
                 PROF_COUNT(4, 1);
                 if (changed) {
                     entry = want;
-                    my_exit = walk_chunk<CHUNK, false, ALL_LDS>(sym, marks, ids_half, s_trie, g_trie, n_lds, s_rel, e_rel,
-                                                                entry, my_exit);
+                    my_exit = follow(entry, chain);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
             const uint32_t carry_out_rel = __shfl(my_exit, 63, 64);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             PROF_STAMP(2);
 
-            // emit: lane c owns the tokens that start in its chunk
-            uint32_t cnt = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < WORDS; ++w) cnt += __popc(my[w]);
+            // ---- emit: lane c owns the tokens that start in its block
+            const uint32_t cnt = (uint32_t)__popcll(chain);
             uint32_t incl = cnt;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -502,9 +715,30 @@ __global__ __launch_bounds__(1024) void encode_wave_kernel(EncodeArgs A)
             }
             const uint32_t total = __shfl(incl, 63, 64);
             uint32_t off = out_off + incl - cnt;
-            for (uint32_t w = 0; w < WORDS; ++w)
-                off = emit_word<CHUNK, INPUT>(my[w], c * WORDS + w, marks, sym, ids_half, s_single,
-                                       A.raw + row + seg_base, seg_len, carry_out_rel, out, off, A.ids_stride);
+            for (unsigned long long rem = chain; rem;) {
+                uint32_t p[4], idv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    p[t] = 0xFFFFFFFFu;
+                    if (rem) {
+                        p[t] = pbase + (uint32_t)__ffsll((long long)rem) - 1u;
+                        rem &= rem - 1;
+                        idv[t] = ids_full[p[t]];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (p[t] == 0xFFFFFFFFu) continue;
+                    uint32_t id = idv[t];
+                    if (id == ecgb::kNoToken) {                       // single symbol: its byte still holds the class
+                        const uint32_t cls = sym[p[t]];
+                        if (INPUT == INPUT_BYTES && cls == ecgb::kOtherClass) id = A.raw[row + seg_base + p[t]];
+                        else id = s_single[cls];
+                    }
+                    if (off < A.ids_stride) out[off] = id;
+                    ++off;
+                }
+            }
             out_off += total;
             carry = seg_base + carry_out_rel;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -535,25 +769,30 @@ __global__ __launch_bounds__(kLanes) void encode_wg_kernel(EncodeArgs A)
     double *s_thr = reinterpret_cast<double *>(s_trie + A.n_lds_nodes);        // 28
     uint16_t *s_single = reinterpret_cast<uint16_t *>(s_thr + 28);             // 32
     uint8_t *s_b2c = reinterpret_cast<uint8_t *>(s_single + 32);               // 256
-    uint8_t *sym = s_b2c + 256;
+    uint32_t *s_run = reinterpret_cast<uint32_t *>(s_b2c + 256);               // n_runwords (even)
+    uint8_t *sym = reinterpret_cast<uint8_t *>(s_run + A.n_runwords);
     uint32_t *marks = reinterpret_cast<uint32_t *>(sym + sym_cap);
     uint32_t *exits = marks + kMarkWords;
     uint32_t *wsum = exits + kLanes;                                           // 4 wave totals
+    uint32_t *dmap = wsum + 4;                                                 // sym_cap / 32 + 2 words
 
     const uint32_t c = threadIdx.x;
     for (uint32_t i = c; i < A.n_lds_nodes; i += kLanes) s_trie[i] = A.trie[i];
+    for (uint32_t i = c; i < A.n_runwords; i += kLanes) s_run[i] = A.runbits[i];
     if (c < 28) s_thr[c] = A.qp.thr[c];
     if (c < 32) s_single[c] = reinterpret_cast<const uint16_t *>(A.lut + 256)[c];
     s_b2c[c] = A.lut[c];
 
     uint32_t *my = marks + c * kWordsPerChunk;
     uint16_t *ids_half = A.ids_half + (size_t)blockIdx.x * kHalfPerSlot;
-    const uint64_t *g_trie = A.trie;
-    const uint32_t n_lds = A.n_lds_nodes, n = A.n;
-    const double qa = A.qp.a, qscale = A.qp.scale;
 #ifdef ECGB_PROFILE
+    const WalkCtx W{sym, marks, dmap, ids_half, s_trie, A.trie, s_run, A.n_lds_nodes, A.prof ? A.prof + blockIdx.x * 8 : nullptr};
     long long t_prof = clock64();
+#else
+    const WalkCtx W{sym, marks, dmap, ids_half, s_trie, A.trie, s_run, A.n_lds_nodes};
 #endif
+    const uint32_t n = A.n;
+    const double qa = A.qp.a, qscale = A.qp.scale;
 
     for (uint32_t b = blockIdx.x; b < A.batch; b += gridDim.x) {
         const size_t row = (size_t)b * n;
@@ -569,11 +808,13 @@ __global__ __launch_bounds__(kLanes) void encode_wg_kernel(EncodeArgs A)
 #pragma unroll
             for (int w = 0; w < kWordsPerChunk; ++w) my[w] = 0;
             __syncthreads();
+            build_dmap<kChunk>(sym, dmap, stage_len, c, kLanes);
+            __syncthreads();
             PROF_STAMP(0);
 
             uint32_t entry = s_rel, my_exit = s_rel;
             if (s_rel < e_rel)
-                my_exit = walk_chunk<kChunk, true, ALL_LDS>(sym, marks, ids_half, s_trie, g_trie, n_lds, s_rel, e_rel, s_rel, s_rel);
+                my_exit = walk_chunk<kChunk, true, ALL_LDS>(W, s_rel, e_rel, s_rel, s_rel);
             exits[c] = my_exit;
             PROF_STAMP(1);
             const uint32_t carry_rel = carry - seg_base;
@@ -586,8 +827,7 @@ __global__ __launch_bounds__(kLanes) void encode_wg_kernel(EncodeArgs A)
                 PROF_COUNT(4, 1);
                 if (changed) {
                     entry = want;
-                    my_exit = walk_chunk<kChunk, false, ALL_LDS>(sym, marks, ids_half, s_trie, g_trie, n_lds, s_rel, e_rel,
-                                                                 entry, my_exit);
+                    my_exit = walk_chunk<kChunk, false, ALL_LDS>(W, s_rel, e_rel, entry, my_exit);
                     exits[c] = my_exit;
                 }
             }
@@ -631,52 +871,63 @@ int check_hip(hipError_t e, const char *what)
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 constexpr size_t kLdsCap = 160 * 1024;
-constexpr size_t kLdsTables = 28 * 8 + 64 + 256;
-constexpr int kWaveChunk = 64;               // chunk of the wave-per-stream kernel
-constexpr size_t kWaveSeg = 64 * kWaveChunk; // 4096 symbols per wave segment
-static_assert(kWaveSeg == 4096, "wave segment");
+constexpr size_t kLdsTablesFixed = 28 * 8 + 64 + 256;
 constexpr size_t kMaxWaves = 16;
-constexpr int kWaveChunkBig = 128;           // experimental variant (plan mode 3): 8192-symbol segments
-
+constexpr uint32_t kFlowChunks[] = {62, 60, 58, 54, 52, 50, 46, 44, 42, 38, 36, 34};   // not multiples of 8: lanes at equal
+                                                                                       // chunk offsets land in different LDS banks
 int g_plan_mode = 0;   // 0 auto, 1 workgroup-per-stream, 2 wave-per-stream (tests / tuning)
 
 struct Plan {
-    int wave_chunk;    // chunk size of the wave kernel
-    bool wave;         // wave-per-stream kernel
+    uint32_t chunk;    // chunk length of the flow kernel
+    bool wave;         // wave-per-stream (flow) kernel
     unsigned grid, block;
     uint32_t margin, n_lds;
     size_t lds;
 };
 
-// Large batches: wave-per-stream, as many waves per CU as LDS allows (trie first, then
-// 4.8 KiB per wave), one persistent workgroup per CU.  Small batches: workgroup-per-stream so
-// that few records still spread over many lanes and CUs.
+inline size_t flow_per_wave(uint32_t chunk, uint32_t margin)
+{
+    const size_t seg = 64 * (size_t)chunk, cap = seg + margin;
+    return cap + seg / 8 + (cap / 32 + 2) * 4;   // symbols, claim bitmap, change map
+}
+
+// Large batches: wave-per-stream, 16 waves per CU (fewer only if the tables leave no room for a useful
+// segment), the segment as long as LDS allows, one persistent workgroup per CU.  Small batches, or a
+// tokenizer whose token lengths do not fit the flow kernel's byte encoding: workgroup-per-stream, so that
+// few records still spread over many lanes and CUs.
 Plan make_plan(const ecgb_tokenizer *tok, size_t batch)
 {
     Plan p;
     const size_t cus = tok->n_cus > 0 ? (size_t)tok->n_cus : 256;
-    p.margin = (tok->max_depth + 1 + 255u) & ~255u;   // keeps the symbol buffer a whole number of swizzle blocks
     const size_t n_nodes = tok->nodes.size();
-    p.wave = (g_plan_mode >= 2) || (g_plan_mode == 0 && batch >= 2 * cus);
-    p.wave_chunk = (g_plan_mode == 3) ? kWaveChunkBig : kWaveChunk;
+    const bool flow_ok = !tok->tok_len.empty() && tok->max_depth + kLenBias <= 255 && tok->tok_len.size() <= 16384;
+    p.wave = flow_ok && ((g_plan_mode >= 2) || (g_plan_mode == 0 && batch >= 2 * cus));
+    p.chunk = 0;
     if (p.wave) {
-        const size_t seg = 64 * (size_t)p.wave_chunk;
-        const size_t per_wave = seg + p.margin + seg / 8;
-        size_t waves = (g_plan_mode == 3) ? 8 : kMaxWaves;
+        p.margin = (tok->max_depth + 1 + 15u) & ~15u;
+        const size_t tables = kLdsTablesFixed + tok->runbits.size() * 4 + tok->tok_len.size();
         const size_t trie_bytes = n_nodes * 8;
-        if (kLdsTables + trie_bytes + waves * per_wave > kLdsCap) {
-            // shrink to 8 waves before giving up LDS residency of the trie
-            const size_t fit = (kLdsCap > kLdsTables + trie_bytes) ? (kLdsCap - kLdsTables - trie_bytes) / per_wave : 0;
-            waves = std::max<size_t>(std::min<size_t>(8, waves), std::min<size_t>(waves, fit));
+        size_t waves = 8;
+        p.chunk = 34;
+        bool found = false;
+        for (size_t w : {(size_t)16, (size_t)12, (size_t)8}) {
+            if (tables + trie_bytes >= kLdsCap) break;
+            const size_t per_wave_max = (kLdsCap - tables - trie_bytes) / w;
+            for (uint32_t ch : kFlowChunks)
+                if (flow_per_wave(ch, p.margin) <= per_wave_max) { waves = w; p.chunk = ch; found = true; break; }
+            if (found) break;
         }
-        const size_t left = (kLdsCap > kLdsTables + waves * per_wave) ? kLdsCap - kLdsTables - waves * per_wave : 0;
+        const size_t per_wave = flow_per_wave(p.chunk, p.margin);
+        const size_t left = (kLdsCap > tables + waves * per_wave) ? kLdsCap - tables - waves * per_wave : 0;
         p.n_lds = (uint32_t)std::min<size_t>(n_nodes, left / 8);
         p.block = (unsigned)(waves * 64);
         const size_t wgs = (batch + waves - 1) / waves;
         p.grid = (unsigned)std::max<size_t>(1, std::min(wgs, cus));
-        p.lds = kLdsTables + (size_t)p.n_lds * 8 + waves * per_wave;
+        p.lds = tables + (size_t)p.n_lds * 8 + waves * per_wave;
     } else {
-        const size_t fixed = kLdsTables + kSeg + p.margin + kMarkWords * 4 + kLanes * 4 + 16;
+        p.margin = (tok->max_depth + 1 + 255u) & ~255u;   // keeps the symbol buffer a whole number of swizzle blocks
+        const size_t tables = kLdsTablesFixed + tok->runbits.size() * 4;
+        const size_t fixed = tables + kSeg + p.margin + kMarkWords * 4 + kLanes * 4 + 16 + ((kSeg + p.margin) / 32 + 2) * 4;
         p.n_lds = (fixed >= kLdsCap) ? 0u : (uint32_t)std::min<size_t>(n_nodes, (kLdsCap - fixed) / 8);
         p.block = kLanes;
         p.grid = (unsigned)std::max<size_t>(1, std::min(batch, 2 * cus));
@@ -699,6 +950,11 @@ int launch_encode(const ecgb_tokenizer *tok, const double *signal, const uint8_t
     A.trie = tok->nodes_dev;
     A.n_nodes = (uint32_t)tok->nodes.size();
     A.n_lds_nodes = pl.n_lds;
+    A.runbits = tok->runbits_dev;
+    A.n_runwords = (uint32_t)tok->runbits.size();
+    A.tok_len = tok->toklen_dev;
+    A.n_toklen = (uint32_t)tok->tok_len.size();
+    A.chunk = pl.chunk;
     A.lut = tok->lut_dev;
     A.signal = signal;
     A.raw = raw;
@@ -716,12 +972,9 @@ int launch_encode(const ecgb_tokenizer *tok, const double *signal, const uint8_t
     const bool all_lds = (pl.n_lds == A.n_nodes);
     const bool vec = (INPUT == INPUT_F64) && (n % 2 == 0) && ((reinterpret_cast<uintptr_t>(signal) & 15u) == 0);
     void (*kern)(EncodeArgs) = nullptr;
-    if (pl.wave && pl.wave_chunk == kWaveChunkBig)
-        kern = all_lds ? (vec ? encode_wave_kernel<kWaveChunkBig, INPUT, true, true> : encode_wave_kernel<kWaveChunkBig, INPUT, true, false>)
-                       : (vec ? encode_wave_kernel<kWaveChunkBig, INPUT, false, true> : encode_wave_kernel<kWaveChunkBig, INPUT, false, false>);
-    else if (pl.wave)
-        kern = all_lds ? (vec ? encode_wave_kernel<kWaveChunk, INPUT, true, true> : encode_wave_kernel<kWaveChunk, INPUT, true, false>)
-                       : (vec ? encode_wave_kernel<kWaveChunk, INPUT, false, true> : encode_wave_kernel<kWaveChunk, INPUT, false, false>);
+    if (pl.wave)
+        kern = all_lds ? (vec ? encode_flow_kernel<INPUT, true, true> : encode_flow_kernel<INPUT, true, false>)
+                       : (vec ? encode_flow_kernel<INPUT, false, true> : encode_flow_kernel<INPUT, false, false>);
     else
         kern = all_lds ? (vec ? encode_wg_kernel<INPUT, true, true> : encode_wg_kernel<INPUT, true, false>)
                        : (vec ? encode_wg_kernel<INPUT, false, true> : encode_wg_kernel<INPUT, false, false>);
@@ -794,7 +1047,7 @@ extern "C" void ecgb_debug_set_profile_buffer(unsigned long long *dev) { g_prof_
 
 extern "C" int ecgb_set_encode_plan(int mode)
 {
-    if (mode < 0 || mode > 3) { ecgb::set_error("ecgb_set_encode_plan: mode must be 0..3"); return ECGB_ERR_INVALID; }
+    if (mode < 0 || mode > 2) { ecgb::set_error("ecgb_set_encode_plan: mode must be 0..2"); return ECGB_ERR_INVALID; }
     g_plan_mode = mode;
     return ECGB_OK;
 }
@@ -831,10 +1084,10 @@ extern "C" int ecgb_quantize_hip(const double *signal_dev, size_t n, double perc
 
 extern "C" size_t ecgb_encode_scratch_bytes(const ecgb_tokenizer *tok, size_t batch, size_t n_per_stream)
 {
-    // one half-resolution id array of one segment per resident stream slot (reused, L2-resident):
-    // wave kernel: CUs x 16 waves x 2048 entries; workgroup kernel: 2 x CUs x 16384 entries
+    // one id array of one segment per resident stream slot (reused, L2-resident): flow kernel: CUs x 16 waves x
+    // 4096 entries (full resolution); workgroup kernel: 2 x CUs x 16384 entries (half resolution)
     const size_t cus = (tok && tok->n_cus > 0) ? (size_t)tok->n_cus : 256;
-    const size_t a = cus * kMaxWaves * (64 * (size_t)kWaveChunkBig / 2), b = 2 * cus * (size_t)kHalfPerSlot;
+    const size_t a = cus * kMaxWaves * kFlowSlot, b = 2 * cus * (size_t)kHalfPerSlot;
     return align_up(std::max(a, b) * sizeof(uint16_t)) + kAlign;
 }
 

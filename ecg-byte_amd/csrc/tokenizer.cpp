@@ -2,13 +2,18 @@
 // rust_bpe.encode_text builds on every call (reference: ecg_byte/rust_bpe/src/lib.rs:127-161),
 // once, and lays it out for the device.
 //
-// Layout choice (MI355X): the encode kernel walks the trie one symbol per step with one
-// dependent lookup per step, so a node must be ONE aligned 8-byte LDS/L2 read:
-//   child bitmap (one bit per symbol class) | first-child id | token id
-// Children of a node are numbered consecutively in class order, so
-//   child(node, cls) = first_child + popcount(bitmap & ((1 << cls) - 1)).
-// Breadth-first numbering puts the shallow (hot) nodes at low ids; the kernel keeps nodes
-// [0, n_lds) in LDS and reads any deeper remainder through L2.
+// Layout choice (MI355X): the encode kernel walks the trie with one dependent lookup per
+// step, so a node must be ONE aligned 8-byte LDS/L2 read:
+//   branch-child bitmap (one bit per symbol class) + 2 flags | first-branch-child id | token id
+// Branch children (classes other than the one the node was entered by) are numbered
+// consecutively in class order:
+//   child(node, cls) = first + popcount(bitmap & ((1 << cls) - 1)).
+// Quantised ECG is mostly runs of equal symbols and ~3/4 of a trained trie's nodes lie on
+// same-class chains (m, mm, mmm, ...), so those chains are numbered consecutively: the child
+// by the entering class is node + 1 (for the head of a chain: right after its branch
+// children), and a run of k equal symbols is ONE step of k nodes.  Numbering is otherwise
+// breadth-first, so shallow (hot) nodes get low ids; the kernel keeps nodes [0, n_lds) in
+// LDS and reads any deeper remainder through L2.
 #include "tokenizer.hpp"
 
 #include <hip/hip_runtime.h>
@@ -54,7 +59,7 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
     if (!tok) { set_error("ecgb_tokenizer_create: out of host memory"); return ECGB_ERR_NOMEM; }
     try {
         // ---- symbol classes: 0..25 are 'a'..'z' (the quantiser's alphabet index IS the
-        // class), further byte values that occur in an expansion get 26..31.
+        // class), further byte values that occur in an expansion get 26..28.
         std::memset(tok->byte_to_class, kOtherClass, sizeof(tok->byte_to_class));
         for (uint32_t c = 0; c < ECGB_ALPHABET; ++c) {
             tok->byte_to_class['a' + c] = (uint8_t)c;
@@ -73,7 +78,7 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
             if (!used[b] || tok->byte_to_class[b] != kOtherClass) continue;
             if (n_classes == kMaxClasses) {
                 delete tok;
-                set_error("ecgb_tokenizer_create: more than 31 distinct byte values (a..z plus 5) in the merges");
+                set_error("ecgb_tokenizer_create: more than 29 distinct byte values (a..z plus 3) in the merges");
                 return ECGB_ERR_UNSUPPORTED;
             }
             tok->byte_to_class[b] = (uint8_t)n_classes;
@@ -111,25 +116,54 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
             set_error("ecgb_tokenizer_create: trie has >= 65535 nodes");
             return ECGB_ERR_UNSUPPORTED;
         }
-        // ---- breadth-first renumbering, children consecutive in class order
+        // ---- renumbering: breadth-first over blocks; a block = the branch children of a node in
+        // class order, followed (for a chain head) by the whole same-class chain below it
+        const size_t nb = bn.size();
+        std::vector<int32_t> cin(nb, -1), parent(nb, -1);      // entering class, parent (old ids)
+        std::vector<uint32_t> depth_old(nb, 0);
+        {
+            std::vector<int32_t> stack{0};
+            while (!stack.empty()) {
+                const int32_t v = stack.back();
+                stack.pop_back();
+                for (uint32_t c = 0; c < kMaxClasses; ++c) {
+                    const int32_t ch = bn[v].child[c];
+                    if (ch < 0) continue;
+                    cin[ch] = (int32_t)c;
+                    parent[ch] = v;
+                    depth_old[ch] = depth_old[v] + 1;
+                    stack.push_back(ch);
+                }
+            }
+        }
+        auto is_head = [&](int32_t v) { return v != 0 && (parent[v] == 0 || cin[parent[v]] != cin[v]); };
+        auto cont_of = [&](int32_t v) { return (v != 0) ? bn[v].child[cin[v]] : -1; };
         std::vector<int32_t> order;  // new id -> old id
-        std::vector<uint32_t> depth;
-        order.reserve(bn.size());
+        order.reserve(nb);
         order.push_back(0);
-        depth.push_back(0);
-        std::vector<uint32_t> first_child(bn.size(), 0);
+        std::vector<uint32_t> first_child(nb, 0);   // by new id
         for (size_t head = 0; head < order.size(); ++head) {
-            const BuildNode &n = bn[order[head]];
+            const int32_t v = order[head];
             first_child[head] = (uint32_t)order.size();
             for (uint32_t c = 0; c < kMaxClasses; ++c)
-                if (n.child[c] >= 0) { order.push_back(n.child[c]); depth.push_back(depth[head] + 1); }
+                if (bn[v].child[c] >= 0 && (v == 0 || (int32_t)c != cin[v])) order.push_back(bn[v].child[c]);
+            if (is_head(v))
+                for (int32_t w = cont_of(v); w >= 0; w = cont_of(w)) order.push_back(w);
         }
         tok->nodes.resize(order.size());
+        tok->runbits.assign(2 * (order.size() / 32 + 3), 0u);
         uint32_t max_depth = 0;
         for (size_t i = 0; i < order.size(); ++i) {
-            const BuildNode &n = bn[order[i]];
+            const int32_t v = order[i];
+            const BuildNode &n = bn[v];
             uint32_t bitmap = 0;
-            for (uint32_t c = 0; c < kMaxClasses; ++c) if (n.child[c] >= 0) bitmap |= 1u << c;
+            for (uint32_t c = 0; c < kMaxClasses; ++c)
+                if (n.child[c] >= 0 && (v == 0 || (int32_t)c != cin[v])) bitmap |= 1u << c;
+            if (is_head(v)) bitmap |= kHeadFlag;
+            if (cont_of(v) >= 0) {
+                bitmap |= kContFlag;
+                tok->runbits[2 * (i / 32)] |= 1u << (i % 32);
+            }
             uint32_t token = kNoToken;
             if (i != 0 && n.token >= 0) {  // the root's own token is never consulted (lib.rs:170-181)
                 if (n.token >= (int64_t)kNoToken) {
@@ -138,11 +172,23 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
                     return ECGB_ERR_UNSUPPORTED;
                 }
                 token = (uint32_t)n.token;
+                tok->runbits[2 * (i / 32) + 1] |= 1u << (i % 32);
             }
             tok->nodes[i] = pack_node(bitmap, first_child[i], token);
-            max_depth = std::max(max_depth, depth[i]);
+            max_depth = std::max(max_depth, depth_old[v]);
         }
         tok->max_depth = max_depth;
+        // token id -> length, for the encoder's pointer-following pass (only when every length fits a byte)
+        if (max_depth <= 255) {
+            uint32_t max_id = 255;
+            for (size_t i = 0; i < n_merges; ++i) if (ids[i] < kNoToken) max_id = std::max(max_id, ids[i]);
+            tok->tok_len.assign(((size_t)max_id + 1 + 7) & ~(size_t)7, 0);
+            for (uint32_t b = 0; b < 256; ++b) tok->tok_len[b] = 1;
+            for (size_t i = 0; i < order.size(); ++i) {
+                const int64_t t = bn[order[i]].token;
+                if (i != 0 && t >= 0) tok->tok_len[(size_t)t] = (uint8_t)depth_old[order[i]];
+            }
+        }
         // root children are nodes 1..n_classes in class order
         for (uint32_t c = 0; c < 32; ++c) { tok->single_id[c] = 0; if (c >= n_classes) tok->class_to_byte[c] = 0; }
         for (uint32_t c = 0; c < n_classes; ++c) tok->single_id[c] = (uint16_t)(tok->nodes[1 + c] >> 48);
@@ -169,13 +215,19 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
     std::memcpy(lut, tok->byte_to_class, 256);
     std::memcpy(lut + 256, tok->single_id, 64);
     std::memcpy(lut + 320, tok->class_to_byte, 32);
+    const size_t rbytes = tok->runbits.size() * sizeof(uint32_t);
     if (hipMalloc((void **)&tok->nodes_dev, nbytes) != hipSuccess ||
+        hipMalloc((void **)&tok->runbits_dev, rbytes) != hipSuccess ||
+        hipMalloc((void **)&tok->toklen_dev, std::max<size_t>(8, tok->tok_len.size())) != hipSuccess ||
         hipMalloc((void **)&tok->lut_dev, sizeof(lut)) != hipSuccess) {
         ecgb_tokenizer_destroy(tok);
         ecgb::set_error("ecgb_tokenizer_create: hipMalloc failed");
         return ECGB_ERR_NOMEM;
     }
     if (hipMemcpy(tok->nodes_dev, tok->nodes.data(), nbytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(tok->runbits_dev, tok->runbits.data(), rbytes, hipMemcpyHostToDevice) != hipSuccess ||
+        (!tok->tok_len.empty() &&
+         hipMemcpy(tok->toklen_dev, tok->tok_len.data(), tok->tok_len.size(), hipMemcpyHostToDevice) != hipSuccess) ||
         hipMemcpy(tok->lut_dev, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) {
         ecgb_tokenizer_destroy(tok);
         ecgb::set_error("ecgb_tokenizer_create: hipMemcpy failed");
@@ -189,6 +241,8 @@ extern "C" void ecgb_tokenizer_destroy(ecgb_tokenizer *tok)
 {
     if (!tok) return;
     if (tok->nodes_dev) (void)hipFree(tok->nodes_dev);
+    if (tok->runbits_dev) (void)hipFree(tok->runbits_dev);
+    if (tok->toklen_dev) (void)hipFree(tok->toklen_dev);
     if (tok->lut_dev) (void)hipFree(tok->lut_dev);
     delete tok;
 }
@@ -198,6 +252,14 @@ extern "C" size_t ecgb_tokenizer_copy_nodes(const ecgb_tokenizer *tok, uint64_t 
     if (!tok) return 0;
     const size_t n = tok->nodes.size();
     if (out) std::memcpy(out, tok->nodes.data(), std::min(n, cap) * sizeof(uint64_t));
+    return n;
+}
+
+extern "C" size_t ecgb_tokenizer_copy_runbits(const ecgb_tokenizer *tok, uint32_t *out, size_t cap)
+{
+    if (!tok) return 0;
+    const size_t n = tok->runbits.size();
+    if (out) std::memcpy(out, tok->runbits.data(), std::min(n, cap) * sizeof(uint32_t));
     return n;
 }
 

@@ -8,14 +8,24 @@
 
 namespace ecgb {
 
-constexpr uint32_t kMaxClasses = 31;      // usable symbol classes (bits 0..30 of a node's child bitmap)
-constexpr uint32_t kOtherClass = 31;      // byte that occurs in no expansion and is not a..z; also the
-                                          // end-of-stream sentinel: bit 31 is never set in any bitmap
+constexpr uint32_t kMaxClasses = 29;      // usable symbol classes (bits 0..28 of a node's child bitmap)
+constexpr uint32_t kOtherClass = 29;      // byte that occurs in no expansion and is not a..z; also the
+                                          // end-of-stream sentinel: bit 29 is never set in any bitmap
 constexpr uint32_t kNoToken = 0xFFFFu;    // node carries no token id
+constexpr uint32_t kHeadFlag = 1u << 30;  // node was entered by a different class than its parent was (or from the root)
+constexpr uint32_t kContFlag = 1u << 31;  // node has a child of the class it was entered by (its "continuation")
+constexpr uint32_t kBranchMask = (1u << 30) - 1u;
 
-// Device trie node, 8 bytes:  [31:0] child bitmap over symbol classes,
-// [47:32] id of the first child (children of a node are consecutive, in class order),
-// [63:48] token id carried by the node (kNoToken if none).
+// Device trie node, 8 bytes:
+//   [28:0]  bitmap of the BRANCH children: classes other than the one the node was entered by
+//   [30]    kHeadFlag, [31] kContFlag
+//   [47:32] id of the first branch child (branch children are consecutive, in class order)
+//   [63:48] token id carried by the node (kNoToken if none)
+// The continuation child of a head node sits right after its branch children
+// (first + popcount(bitmap)), followed by the rest of the same-class chain: for every other
+// node the continuation child is node + 1.  A run of equal symbols therefore walks consecutive
+// node ids and can be taken several symbols at a time (encode.hip, walk_chunk).  The root has
+// no entering class: all its children are branch children and both flags are clear.
 inline uint64_t pack_node(uint32_t bitmap, uint32_t first_child, uint32_t token)
 {
     return (uint64_t)bitmap | ((uint64_t)(first_child & 0xFFFFu) << 32) | ((uint64_t)(token & 0xFFFFu) << 48);
@@ -26,7 +36,11 @@ void set_error(const std::string &msg);
 }  // namespace ecgb
 
 struct ecgb_tokenizer {
-    std::vector<uint64_t> nodes;       // breadth-first packed trie, node 0 = root
+    std::vector<uint64_t> nodes;       // packed trie, node 0 = root, its children 1..n_classes in class order
+    std::vector<uint32_t> runbits;     // word pairs k: [2k] bit u%32 = node 32k+u has kContFlag, [2k+1] = carries a token;
+                                       // two zero pairs of padding (the kernel reads a 64-node window past any node)
+    std::vector<uint8_t> tok_len;      // token id -> expansion length (1 for the byte tokens; 0 = id not in the vocabulary),
+                                       // padded to a multiple of 8 entries; empty if some expansion is longer than 255
     uint8_t byte_to_class[256];        // raw byte -> symbol class (kOtherClass if none)
     uint16_t single_id[32];            // token id of the length-1 match of each class
     uint8_t class_to_byte[32];
@@ -35,6 +49,8 @@ struct ecgb_tokenizer {
     uint32_t n_merges = 0;
     // device copies
     uint64_t *nodes_dev = nullptr;
+    uint32_t *runbits_dev = nullptr;
+    uint8_t *toklen_dev = nullptr;
     uint8_t *lut_dev = nullptr;        // 256 B byte_to_class | 64 B single_id | 32 B class_to_byte
     int device = -1;
     int n_cus = 0;                     // compute units of `device` (persistent grid size)

@@ -56,9 +56,9 @@ uint32_t ecgb_version(void);
  * expansion i = flat_bytes[offsets[i] .. offsets[i+1]), token id = ids[i], i in list order
  * (later duplicates overwrite earlier ones, lib.rs:145).  The 256 single-byte tokens
  * (lib.rs:155-157) are implied.  Builds the trie on the host, lays it out for the device
- * (breadth-first, 8 bytes per node) and uploads it.  With no GPU present the handle is
+ * (8 bytes per node, same-class chains numbered consecutively) and uploads it.  With no GPU present the handle is
  * host-only: introspection works, device entry points return ECGB_ERR_NODEVICE.
- * Limits of this build: at most 31 distinct byte values across all expansions plus
+ * Limits of this build: at most 29 distinct byte values across all expansions plus
  * 'a'..'z'; < 65535 trie nodes; token ids < 65535.  Violations -> ECGB_ERR_UNSUPPORTED. */
 int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t *offsets,
                           const uint32_t *ids, size_t n_merges, ecgb_tokenizer **out);
@@ -70,6 +70,10 @@ int ecgb_tokenizer_info(const ecgb_tokenizer *tok, uint32_t *n_nodes, uint32_t *
 /* Copies up to `cap` packed trie nodes (host copy; layout in DESIGN.md) and returns the node
  * count.  Works on a host-only handle (no GPU present). */
 size_t ecgb_tokenizer_copy_nodes(const ecgb_tokenizer *tok, uint64_t *out, size_t cap);
+/* Copies up to `cap` words of the per-node bit tables the run step of the encoder uses (word pair k:
+ * [2k] bit u = node 32k+u has a continuation child, [2k+1] bit u = node 32k+u carries a token; padded
+ * with zero pairs) and returns the word count. */
+size_t ecgb_tokenizer_copy_runbits(const ecgb_tokenizer *tok, uint32_t *out, size_t cap);
 
 /* ---- quantiser --------------------------------------------------------------------------
  * normalize_all for n float64 samples: sym_dev[i] = alphabet index 0..25 ('a'+index is the
@@ -104,8 +108,8 @@ int ecgb_encode_hip(const ecgb_tokenizer *tok, const uint8_t *text_dev, size_t b
 
 /* Which of the two encode kernels a call uses: 0 = automatic (wave-per-stream for batches of at
  * least 2 x CUs, workgroup-per-stream below), 1 = always workgroup-per-stream, 2 = always
- * wave-per-stream, 3 = wave-per-stream with 128-symbol chunks (tuning experiment).  All produce
- * identical output; the switch exists for tests and tuning.
+ * wave-per-stream (falls back to workgroup-per-stream for tokenizers with an expansion longer than
+ * 225 bytes).  All produce identical output; the switch exists for tests and tuning.
  * Process-wide, not thread-safe against concurrent encode calls. */
 int ecgb_set_encode_plan(int mode);
 

@@ -1,0 +1,52 @@
+"""Node visit histogram of the run-step walk over the packed device trie (host copy), serial parse of a few records."""
+import os, sys, pickle, json, ctypes as C
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import oracle as O
+from ecg_byte_amd import _lib, synth
+from ecg_byte_amd.tokenizer import flatten_merges
+G = os.path.join(ROOT, "tests", "golden")
+vocab, merges = pickle.load(open(os.path.join(G, "tokenizer_c2.pkl"), "rb"))
+pct = json.load(open(os.path.join(G, "percentiles_c2.json")))
+lib = _lib.lib()
+flat, off, ids = flatten_merges(merges)
+h = C.c_void_p(); u32p = C.POINTER(C.c_uint32)
+assert lib.ecgb_tokenizer_create(flat.ctypes.data_as(u32p), off.ctypes.data_as(u32p), ids.ctypes.data_as(u32p), len(merges), C.byref(h)) == 0
+n = lib.ecgb_tokenizer_copy_nodes(h, None, 0)
+nodes = np.empty(n, dtype=np.uint64); lib.ecgb_tokenizer_copy_nodes(h, nodes.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+nodes = [int(v) for v in nodes]
+HEAD, CONT, BRANCH = 1 << 30, 1 << 31, (1 << 30) - 1
+visits = np.zeros(n, dtype=np.int64)
+sig = synth.synth_ecg(6, 5000, seed=3)
+for rec in range(6):
+    cls = O.quantize(sig[rec], pct["percentile_1"], pct["percentile_99"]).reshape(-1).astype(np.int64).tolist() + [29] * 300
+    N = 60000; i = 0
+    while i < N:
+        node, j, best_j = 0, i, i
+        while True:
+            visits[node] += 1
+            rec_ = nodes[node]; bm, fc, tok = rec_ & 0xFFFFFFFF, (rec_ >> 32) & 0xFFFF, rec_ >> 48
+            if tok != 0xFFFF: best_j = j
+            if node != 0 and cls[j] == cls[j - 1]:
+                if not bm & CONT: break
+                if bm & HEAD: node = fc + bin(bm & BRANCH).count("1"); j += 1
+                else:
+                    m = 0
+                    while m < 32 and cls[j] == cls[j - 1] and (nodes[node] & CONT):
+                        node += 1; j += 1; m += 1
+                continue
+            c = cls[j]
+            if c < 29 and (bm >> c) & 1:
+                node = fc + bin(bm & ((1 << c) - 1)).count("1"); j += 1; continue
+            break
+        i = max(best_j, i + 1)
+tot = visits.sum()
+print("nodes", n, "visits", tot)
+cum = np.cumsum(visits)
+for K in (2048, 3072, 4096, 5120, 6144, 7168, 8192, 9216):
+    print("layout order: first", K, "nodes cover %.5f" % (cum[K - 1] / tot))
+sv = np.sort(visits)[::-1]; cs = np.cumsum(sv)
+for K in (1024, 2048, 3072, 4096, 5120, 6144):
+    print("frequency order: top", K, "cover %.5f" % (cs[K - 1] / tot))
+print("never visited:", int((visits == 0).sum()))

@@ -55,29 +55,75 @@ def _nodes(lib, h):
     return out
 
 
-def _walk_packed(nodes, byte_to_class, text):
-    """Greedy longest match over the packed device trie -- mirrors encode_kernel's step."""
+HEAD, CONT, BRANCH = 1 << 30, 1 << 31, (1 << 30) - 1
+OTHER = 29
+
+
+def _runbits(lib, h):
+    n = lib.ecgb_tokenizer_copy_runbits(h, None, 0)
+    out = np.empty(n, dtype=np.uint32)
+    lib.ecgb_tokenizer_copy_runbits(h, out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+    return out
+
+
+def _ctz32(x):
+    return 32 if x == 0 else (x & -x).bit_length() - 1
+
+
+def _walk_packed(nodes, byte_to_class, text, runbits=None):
+    """Greedy longest match over the packed device trie -- mirrors walk_chunk's step in encode.hip: a branch step by the
+    child bitmap, a continuation step when the symbol repeats the previous one, and (with `runbits`) the run step that
+    takes up to 32 equal symbols along a same-class chain at once."""
     out, i, n = [], 0, len(text)
     nodes = [int(v) for v in nodes]
+    cls = [byte_to_class.get(b, OTHER) for b in text] + [OTHER] * 40
+    diff = [1] + [int(cls[k] != cls[k - 1]) for k in range(1, len(cls))]     # the kernel's D bitmap
+    rb = [int(v) for v in runbits] if runbits is not None else None
     while i < n:
-        node, j, best_len, best_tok = 0, i, 0, None
+        node, j, best_j, best_node = 0, i, i, 0
         while True:
             rec = nodes[node]
-            tok = rec >> 48
-            if j != i and tok != 0xFFFF:
-                best_len, best_tok = j - i, tok
-            if j < n:
-                cls = byte_to_class.get(text[j], 255)
-                bm = rec & 0xFFFFFFFF
-                if cls < 31 and (bm >> cls) & 1:
-                    node = ((rec >> 32) & 0xFFFF) + bin(bm & ((1 << cls) - 1)).count("1")
+            bm, fc, tok = rec & 0xFFFFFFFF, (rec >> 32) & 0xFFFF, rec >> 48
+            if tok != 0xFFFF:
+                best_j, best_node = j, node
+            if node != 0 and diff[j] == 0:                      # the symbol repeats the one this node was entered by
+                if not bm & CONT:
+                    break
+                if bm & HEAD:
+                    node = fc + bin(bm & BRANCH).count("1")
                     j += 1
-                    continue
+                elif rb is None:
+                    node += 1
+                    j += 1
+                else:
+                    z = 0
+                    while z < 32 and diff[j + z] == 0:
+                        z += 1
+                    u = node + 1
+                    k, sh = u >> 5, u & 31
+                    cw = ((rb[2 * k] | (rb[2 * k + 2] << 32)) >> sh) & 0xFFFFFFFF
+                    tw = ((rb[2 * k + 1] | (rb[2 * k + 3] << 32)) >> sh) & 0xFFFFFFFF
+                    ones = _ctz32(~cw & 0xFFFFFFFF)
+                    m = min(z, 1 + ones, 32)
+                    passed = tw & ((1 << (m - 1)) - 1)
+                    if passed:
+                        q = passed.bit_length() - 1
+                        best_j, best_node = j + q + 1, node + 1 + q
+                    node += m
+                    j += m
+                continue
+            c = cls[j]
+            if j < n and c < OTHER and (bm >> c) & 1:
+                node = fc + bin(bm & ((1 << c) - 1)).count("1")
+                j += 1
+                continue
             break
-        if best_len == 0:
-            best_len, best_tok = 1, text[i]
-        out.append(best_tok)
-        i += best_len
+        if best_j == i:
+            out.append(text[i])
+            i += 1
+        else:
+            out.append(nodes[best_node] >> 48)
+            i = best_j
     return out
 
 
@@ -98,6 +144,10 @@ def test_packed_trie_reproduces_oracle(lib, seed):
     assert rc == 0
     try:
         nodes = _nodes(lib, h)
+        rb = _runbits(lib, h)
+        for u in range(nodes.size):       # the bit tables restate the node flags
+            assert (int(rb[2 * (u >> 5)]) >> (u & 31)) & 1 == (int(nodes[u]) >> 31) & 1
+            assert (int(rb[2 * (u >> 5) + 1]) >> (u & 31)) & 1 == int((int(nodes[u]) >> 48) != 0xFFFF)
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         assert lib.ecgb_tokenizer_info(h, C.byref(a), C.byref(b), C.byref(c)) == 0
         assert a.value == nodes.size and b.value == max(len(m[0]) for m in merges)
@@ -106,7 +156,11 @@ def test_packed_trie_reproduces_oracle(lib, seed):
         for _ in range(10):
             pool = np.frombuffer(alphabet + b"qz~", dtype=np.uint8)
             text = bytes(rng.choice(pool, size=int(rng.integers(0, 500))))
-            assert _walk_packed(nodes, b2c, text) == O.encode_text(text, merges)
+            want = O.encode_text(text, merges)
+            assert _walk_packed(nodes, b2c, text) == want
+            assert _walk_packed(nodes, b2c, text, rb) == want
+            runs = b"".join(bytes([rng.choice(pool)]) * int(rng.integers(1, 70)) for _ in range(40))   # long runs: the run step
+            assert _walk_packed(nodes, b2c, runs, rb) == O.encode_text(runs, merges)
     finally:
         lib.ecgb_tokenizer_destroy(h)
 
@@ -117,16 +171,18 @@ def test_packed_trie_fixture_tokenizer(lib):
     rc, h = _make_tok(lib, merges)
     assert rc == 0
     nodes = _nodes(lib, h)
+    rb = _runbits(lib, h)
     lib.ecgb_tokenizer_destroy(h)
     x = synth.synth_ecg(1, 1000, seed=0)
     text = O.symbols_to_text(O.quantize(x[0], pc["percentile_1"], pc["percentile_99"]))[:3000]
     assert _walk_packed(nodes, _classes(merges), text) == O.encode_text(text, merges)
+    assert _walk_packed(nodes, _classes(merges), text, rb) == O.encode_text(text, merges)
 
 
 def test_tokenizer_limits_are_reported(lib):
-    many = [([i, i + 1], 256 + i) for i in range(0, 80, 2)]          # > 31 symbol classes
+    many = [([i, i + 1], 256 + i) for i in range(0, 80, 2)]          # > 29 symbol classes
     rc, h = _make_tok(lib, many)
-    assert rc == -3 and b"31 distinct" in lib.ecgb_last_error()
+    assert rc == -3 and b"29 distinct" in lib.ecgb_last_error()
     rc, h = _make_tok(lib, [([97, 98], 70000)])                        # token id does not fit
     assert rc == -3
     rc, h = _make_tok(lib, [([97, 300], 256)])                         # not a byte
