@@ -330,7 +330,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic_bytes() if (B == 4096 and L == 5000) else None,
-                         "kernel": "encode_wave_kernel<64, INPUT_F64> (fused quantise+encode, one launch per step)",
+                         "kernel": "encode_flow_kernel<INPUT_F64> (fused quantise+encode, one launch per step)",
                          "kernel_ms": dev_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline:

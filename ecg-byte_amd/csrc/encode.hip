@@ -589,22 +589,29 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
 #ifdef ECGB_PROFILE
                     if (A.prof && c == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&A.prof[blockIdx.x * 8 + 5], 1ull);
 #endif
-                    uint32_t claimed = 0;
-                    if (node == 0) claimed = atomicOr(&marks[r >> 5], 1u << (r & 31));   // node == 0 <=> at a token start
+                    // every read of the trip is issued here, unconditionally, and waited for once
+                    const uint32_t rbit = 1u << (r & 31);
+                    const uint32_t claimed = atomicOr(&marks[r >> 5], node == 0 ? rbit : 0u);   // node == 0 <=> at a token start
                     const uint32_t s = sym[j];
                     uint64_t rec;
-                    if constexpr (ALL_LDS) rec = s_trie[node];
-                    else rec = (node < A.n_lds_nodes) ? s_trie[node] : A.trie[node];
+                    uint32_t btok;                                                       // token word of the best node so far
+                    if constexpr (ALL_LDS) {
+                        rec = s_trie[node];
+                        btok = reinterpret_cast<const uint32_t *>(s_trie)[2 * best_node + 1];
+                    } else {
+                        rec = (node < A.n_lds_nodes) ? s_trie[node] : A.trie[node];
+                        btok = (uint32_t)(((best_node < A.n_lds_nodes) ? s_trie[best_node] : A.trie[best_node]) >> 32);
+                    }
                     const uint32_t dk = j >> 5, u = node + 1, rk = (u >> 5) * 2;
                     const uint32_t d0 = dmap[dk], d1 = dmap[dk + 1];
                     const uint2 r0 = *reinterpret_cast<const uint2 *>(s_run + rk), r1 = *reinterpret_cast<const uint2 *>(s_run + rk + 2);
-                    if (node == 0 && ((claimed >> (r & 31)) & 1u)) {
+                    if (node == 0 && (claimed & rbit)) {
                         live = false;                                                    // joined a parse that got here first
                     } else {
                         const uint32_t dw = __builtin_amdgcn_alignbit(d1, d0, j & 31);   // bit t: position j + t starts a new run
                         const uint32_t bm = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
                         const uint32_t fc = hi & 0xFFFFu;
-                        if ((hi >> 16) != ecgb::kNoToken) { best_j = j; best_node = node; }   // the root carries none
+                        if ((hi >> 16) != ecgb::kNoToken) { best_j = j; best_node = node; btok = hi; }   // the root carries none
                         bool advanced = false;
                         if (node != 0 && !(dw & 1u)) {              // the symbol repeats the one this node was entered by
                             if (bm & ecgb::kContFlag) {
@@ -619,7 +626,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                                     const uint32_t ones = min((uint32_t)__ffs(~cw) - 1u, 32u);
                                     const uint32_t m = min(z, ones + 1u);
                                     const uint32_t passed = tw & ((1u << (m - 1u)) - 1u);
-                                    if (passed) {
+                                    if (passed) {                      // its token word is fetched by the next trip
                                         const uint32_t q = 31u - __clz(passed);
                                         best_j = j + q + 1u;
                                         best_node = u + q;
@@ -637,12 +644,9 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                             }
                         }
                         if (!advanced) {
-                            // emit the token [r, r + len): its id (the root's kNoToken for an unmatched or single symbol)
-                            uint64_t brec;
-                            if constexpr (ALL_LDS) brec = s_trie[best_node];
-                            else brec = (best_node < A.n_lds_nodes) ? s_trie[best_node] : A.trie[best_node];
+                            // emit the token [r, r + len): its id (kNoToken for an unmatched or single symbol)
                             const uint32_t len = max(best_j - r, 1u);   // unmatched byte: lib.rs:186-189
-                            ids_full[r] = (len >= 2) ? (uint16_t)(brec >> 48) : (uint16_t)ecgb::kNoToken;
+                            ids_full[r] = (len >= 2) ? (uint16_t)(btok >> 16) : (uint16_t)ecgb::kNoToken;
                             r += len; j = r; node = 0; best_j = r; best_node = 0;
                             live = r < seg_len;
                         }
