@@ -128,7 +128,9 @@ class ECGTokenDataset(torch.utils.data.Dataset):
             return text_label[1], (" ".join(answer) if isinstance(answer, list) else answer)
         raise KeyError(ds)
 
-    def __getitem__(self, index):
+    def load_host(self, index):
+        """The host half of __getitem__ (data_loader.py:55-80): read the .npy / .json pair, pick question and answer,
+        tokenize them.  Returns (signal float64 (12, L), question ids, answer ids, question, answer) or None."""
         try:
             signal = np.load(self.signal_path_list[index])
             with open(self.text_path_list[index]) as f:
@@ -140,7 +142,18 @@ class ECGTokenDataset(torch.utils.data.Dataset):
             question, answer = self._question_answer(text_label)
             tq = self.tokenizer([question], return_tensors="np", add_special_tokens=False).input_ids[0].tolist()
             ta = self.tokenizer([answer], return_tensors="np", add_special_tokens=False).input_ids[0].tolist()
-            x = torch.from_numpy(np.ascontiguousarray(signal, dtype=np.float64)[None]).cuda()
+        except Exception as e:
+            print(f"Error processing data at index {index}: {e}")
+            return None
+        return np.ascontiguousarray(signal, dtype=np.float64), tq, ta, question, answer
+
+    def __getitem__(self, index):
+        item = self.load_host(index)
+        if item is None:
+            return None
+        signal, tq, ta, question, answer = item
+        try:
+            x = torch.from_numpy(signal[None]).cuda()
             inference = bool(self.args.inference)
             ids, counts = self.assembler.encode(x, self.percentiles,
                                                 max_tokens=None if inference else self.args.pad_to_max)
@@ -157,3 +170,96 @@ class ECGTokenDataset(torch.utils.data.Dataset):
         return {"tokenized_signal": r["tokenized_signal"][0].cpu(), "attn_mask": r["attn_mask"][0].cpu(),
                 "quantized_signal_ids_input": r["quantized_signal_ids_input"][0].cpu(),
                 "position_ids": r["position_ids"][0].cpu(), "signal": signal}
+
+
+class DeviceBatchLoader:
+    """Replaces `DataLoader(ECGTokenDataset, batch_size, shuffle, sampler, pin_memory=True)` (main.py:245-257, which
+    runs with num_workers=0: every sample is read, quantised and encoded in the training process, one at a time).
+    Here a thread pool reads and tokenizes the next batches while the current one trains; a batch's signals are
+    stacked in pinned host memory, copied on a side stream, and quantise -> encode -> assemble run once per batch on
+    the device.  Yields the reference's batch dict with device tensors (training: tokenized_signal, attn_mask,
+    quantized_signal_ids_input, position_ids; inference, batch size 1: answer, question, tokenized_signal, attn_mask).
+    Samples that fail to load are dropped from their batch; a batch with no valid sample is yielded as None, which
+    the runners skip (train.py:17-19)."""
+
+    def __init__(self, dataset: ECGTokenDataset, batch_size=1, shuffle=False, sampler=None, drop_last=False, seed=0,
+                 workers=4, prefetch=2):
+        self.dataset, self.batch_size, self.shuffle, self.sampler = dataset, int(batch_size), shuffle, sampler
+        self.drop_last, self.seed, self.workers, self.prefetch = drop_last, seed, max(1, workers), max(1, prefetch)
+        self.epoch = 0
+        if bool(dataset.args.inference) and self.batch_size != 1:
+            raise ValueError("inference batches are single prompts (main.py:181-184 uses batch_size=1)")
+
+    def __len__(self):
+        n = len(self.sampler) if self.sampler is not None else len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def _order(self):
+        if self.sampler is not None:
+            return list(iter(self.sampler))
+        n = len(self.dataset)
+        if not self.shuffle:
+            return list(range(n))
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        return torch.randperm(n, generator=g).tolist()
+
+    def _host_batch(self, pool, idx):
+        items = [it for it in pool.map(self.dataset.load_host, idx) if it is not None]
+        if not items:
+            return None
+        sig = torch.from_numpy(np.stack([it[0] for it in items])).pin_memory()
+        return sig, [it[1] for it in items], [it[2] for it in items], [it[3] for it in items], [it[4] for it in items]
+
+    def __iter__(self):
+        from concurrent.futures import ThreadPoolExecutor
+        order = self._order()
+        self.epoch += 1
+        batches = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+        if self.drop_last and batches and len(batches[-1]) < self.batch_size:
+            batches.pop()
+        ds = self.dataset
+        inference = bool(ds.args.inference)
+        copy_stream = torch.cuda.Stream()
+        with ThreadPoolExecutor(self.workers) as pool, ThreadPoolExecutor(1) as feeder:
+            from collections import deque
+            futures, staged = deque(), deque()
+            nxt = 0
+
+            def submit():
+                nonlocal nxt
+                if nxt < len(batches):
+                    futures.append(feeder.submit(self._host_batch, pool, batches[nxt]))
+                    nxt += 1
+
+            def pump():                                       # one finished host batch -> pinned -> device (side stream)
+                host = futures.popleft().result()
+                submit()
+                if host is None:
+                    staged.append(None)
+                    return
+                sig, q, a, qs, ans = host
+                with torch.cuda.stream(copy_stream):
+                    dev = sig.cuda(non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                staged.append((dev, ev, q, a, qs, ans, sig))  # the pinned buffer stays alive until the batch is consumed
+
+            for _ in range(self.prefetch):
+                submit()
+            while futures or staged:
+                while futures and len(staged) < 2:            # the next batch's copy overlaps this batch's compute
+                    pump()
+                cur = staged.popleft()
+                if cur is None:
+                    yield None
+                    continue
+                dev, ev, q, a, qs, ans, _pin = cur
+                torch.cuda.current_stream().wait_event(ev)
+                if inference:
+                    ids, counts = ds.assembler.encode(dev, ds.percentiles)
+                    r = ds.assembler.assemble(ids, counts, q, inference=True)
+                    n = int(r["lengths"][0].item())
+                    yield {"answer": ans, "question": qs, "tokenized_signal": r["tokenized_signal"][:, :n],
+                           "attn_mask": r["attn_mask"][:, :n]}
+                else:
+                    yield ds.assembler(dev, ds.percentiles, q, a)

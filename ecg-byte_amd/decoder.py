@@ -190,6 +190,56 @@ class HipCausalLM(nn.Module):
     def device(self):
         return self.embed.device
 
+    @classmethod
+    def from_pretrained(cls, path, device="cuda", torch_dtype=None, **_):
+        """`AutoModelForCausalLM.from_pretrained(dir, torch_dtype=torch.bfloat16)` (ecg_byte/main.py:142) for a LOCAL
+        Llama checkpoint directory in the hub layout: config.json (LlamaConfig fields) + model.safetensors, or the
+        sharded model-0000x-of-0000y.safetensors with model.safetensors.index.json.  Weights are cast to bf16."""
+        import json
+        import os
+        from safetensors.torch import load_file
+        with open(os.path.join(path, "config.json")) as f:
+            hf = json.load(f)
+        arch = hf.get("model_type", "llama")
+        if arch != "llama":
+            raise NotImplementedError(f"from_pretrained: model_type {arch!r}: only the Llama block is built (DESIGN.md §8)")
+        keys = ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads",
+                "head_dim", "rms_norm_eps", "rope_theta", "rope_scaling", "tie_word_embeddings", "pad_token_id", "initializer_range")
+        kw = {k: hf[k] for k in keys if k in hf}
+        kw.setdefault("rope_scaling", None)
+        kw.setdefault("tie_word_embeddings", False)
+        if "num_key_value_heads" not in kw:
+            kw["num_key_value_heads"] = kw["num_attention_heads"]
+        model = cls(DecoderConfig(**kw), device=device)
+        index = os.path.join(path, "model.safetensors.index.json")
+        if os.path.exists(index):
+            with open(index) as f:
+                shards = sorted(set(json.load(f)["weight_map"].values()))
+        else:
+            shards = ["model.safetensors"]
+        sd = {}
+        for sh in shards:
+            sd.update(load_file(os.path.join(path, sh)))
+        model.load_state_dict(sd)
+        return model
+
+    def save_pretrained(self, path):
+        """config.json + model.safetensors in the hub layout (tied lm_head omitted, as transformers does)."""
+        import json
+        import os
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        c = self.cfg
+        cfg = {"architectures": ["LlamaForCausalLM"], "model_type": "llama", "torch_dtype": "bfloat16", "hidden_act": "silu",
+               "attention_bias": False, "mlp_bias": False,
+               **{k: getattr(c, k) for k in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+                                             "num_key_value_heads", "head_dim", "rms_norm_eps", "rope_theta", "rope_scaling",
+                                             "tie_word_embeddings", "pad_token_id", "initializer_range")}}
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(cfg, f, indent=1)
+        save_file({n: t.contiguous().cpu() for n, t in self.state_dict().items() if n != "lm_head.weight"},
+                  os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+
     def forward(self, input_ids=None, attention_mask=None, labels=None, position_ids=None, output_attentions=False, **_):
         if labels is None:   # inference forward: logits only (no autograd graph)
             with torch.no_grad():
@@ -197,6 +247,8 @@ class HipCausalLM(nn.Module):
                 hf = self._hidden_states(input_ids, attention_mask, position_ids)
                 logits = ops.gemm_nt(hf, self.embed.data)[:, :self.cfg.vocab_size].float().view(B, S, -1)
             return SimpleNamespace(loss=None, logits=logits, attentions=None)
+        if not torch.is_grad_enabled():   # validation: loss only, nothing kept for a backward
+            return SimpleNamespace(loss=self._eval_loss(input_ids, attention_mask, labels, position_ids), logits=None, attentions=None)
         anchor = self._anchor   # a parameter that requires grad, so autograd records the node
         loss = _LossFn.apply(anchor, self, input_ids, attention_mask, labels, position_ids)
         return SimpleNamespace(loss=loss, logits=None, attentions=None)
@@ -275,10 +327,22 @@ class HipCausalLM(nn.Module):
         yield "lm_head.weight", self.embed.data[: c.vocab_size]
 
     def state_dict(self, *a, **k):
-        return {n: t.clone() for n, t in self._hf_named()}
+        """HF parameter names; with LoRA enabled also the adapters under peft's names (`lora_named`)."""
+        sd = {n: t.clone() for n, t in self._hf_named()}
+        if self.lora is not None:
+            sd.update({n: t.clone() for n, t in self.lora_named()})
+        return sd
 
     def load_state_dict(self, sd, strict=True):
+        """Accepts HF names, and a peft checkpoint's spelling of them (`base_model.model.` prefix, `.base_layer.` infix)."""
+        def canon(n):
+            if "lora_" in n:
+                return n
+            return n.replace("base_model.model.", "", 1).replace(".base_layer.", ".") if n.startswith("base_model.model.") else n
+        sd = {canon(n): t for n, t in sd.items()}
         names = dict(self._hf_named())
+        if self.lora is not None:
+            names.update(dict(self.lora_named()))
         missing = [n for n in names if n not in sd and n != "lm_head.weight"]
         unexpected = [n for n in sd if n not in names and not n.endswith("rotary_emb.inv_freq")]
         if strict and (missing or unexpected):
@@ -434,6 +498,26 @@ class HipCausalLM(nn.Module):
                 self.lora[i]["down"].forward_add(hm, delta, False)
         hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta)
         return hf
+
+    def _eval_loss(self, input_ids, attention_mask, labels, position_ids):
+        """ForCausalLMLoss (loss_utils.py:24-47) without a backward: forward-only hidden states, lm_head + cross entropy
+        over the rows whose shifted label is not -100."""
+        c = self.cfg
+        dev = self.device
+        B, S = input_ids.shape
+        hf = self._hidden_states(input_ids, attention_mask, position_ids)
+        labels = labels.to(dev)
+        shifted = torch.full((B, S), -100, dtype=torch.int64, device=dev)
+        shifted[:, :-1] = labels[:, 1:]
+        shifted = shifted.view(-1)
+        inv_count = ops.count_labels(shifted, c.vocab_size)
+        rows = torch.nonzero(shifted != -100).view(-1)
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        for s0 in range(0, rows.numel(), 4096):
+            r = rows[s0:s0 + 4096]
+            logits = ops.gemm_nt(hf.index_select(0, r), self.embed.data)
+            ops.ce_fwd_bwd_(logits, shifted.index_select(0, r), inv_count, loss, c.vocab_size)
+        return loss.squeeze(0)
 
     def _decode_step(self, tokens, pos, mask, caches, n):
         """Hidden state [B, H] of one new token per sequence, written at cache row n-1 (n = keys valid after the update)."""

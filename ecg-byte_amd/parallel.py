@@ -10,14 +10,20 @@ import torch
 import torch.distributed as dist
 
 
-def shard_indices(n_records: int, rank: int, world: int) -> list[int]:
-    """Indices rank `rank` processes: torch's DistributedSampler(shuffle=False, drop_last=False)
-    rule -- pad by wrapping to a multiple of `world`, then stride."""
+def shard_indices(n_records: int, rank: int, world: int, shuffle: bool = False, seed: int = 0, epoch: int = 0) -> list[int]:
+    """Indices rank `rank` processes: torch's DistributedSampler(drop_last=False) rule (the reference's sampler,
+    ecg_byte/main.py:239-243) -- optionally a permutation seeded with seed + epoch, padded by wrapping to a
+    multiple of `world`, then strided."""
     if n_records == 0:
         return []
     per = math.ceil(n_records / world)
     total = per * world
-    idx = list(range(n_records))
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        idx = torch.randperm(n_records, generator=g).tolist()
+    else:
+        idx = list(range(n_records))
     pad = total - n_records
     if pad:
         idx += (idx * math.ceil(pad / len(idx)))[:pad]

@@ -47,6 +47,10 @@ def test_shard_indices_equals_distributed_sampler():
             for rank in range(world):
                 want = list(DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=False)) if n else []
                 assert parallel.shard_indices(n, rank, world) == want, (n, world, rank)
+                if n:   # the training sampler of main.py:239-243: shuffle=True, seed, set_epoch
+                    ds = DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=True, seed=7)
+                    ds.set_epoch(3)
+                    assert parallel.shard_indices(n, rank, world, shuffle=True, seed=7, epoch=3) == list(ds), (n, world, rank)
 
 
 @pytest.mark.timeout(300)

@@ -1,0 +1,190 @@
+"""GPU tests of the path around the kernels, on the reference's on-disk layout: files ->
+DeviceBatchLoader (threaded reads, pinned staging, one quantise+encode+assemble per batch) -> LLM wrapper ->
+trainer / validater / tester runners -> checkpoint files.  Token-level results are compared with the oracle pipeline."""
+import json
+import os
+import pickle
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from helpers import WordTokenizer, load_tokenizer
+from oracle import assemble as OA
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+REPORTS = ["sinus rhythm normal ecg", "atrial fibrillation with rapid ventricular response", "sinus bradycardia otherwise normal ecg",
+           "left bundle branch block", "sinus rhythm with premature ventricular complexes", "normal ecg"]
+
+
+@pytest.fixture()
+def ptb_dir(tmp_path):
+    """data/<dataset>/{ecg,text}/<split>/ in the reference's naming (preprocess_utils.py:215-226, file_utils.py:30-48)."""
+    from ecg_byte_amd import file_utils as F
+    from ecg_byte_amd import synth
+    vocab, merges, pc = load_tokenizer("c1")
+    x = synth.synth_ecg(11, 1000, seed=5)
+    for split, rng_ in (("train", range(0, 8)), ("val", range(8, 10)), ("test", range(10, 11))):
+        os.makedirs(tmp_path / "ecg" / split); os.makedirs(tmp_path / "text" / split)
+        for i in rng_:
+            np.save(tmp_path / "ecg" / split / f"ecg_{i}_0.npy", x[i])
+            (tmp_path / "text" / split / f"text_{i}_0.json").write_text(json.dumps(REPORTS[i % len(REPORTS)]))
+    F.save_percentiles(tmp_path / "percentiles.npy", pc["percentile_1"], pc["percentile_99"])
+    with open(tmp_path / "tok.pkl", "wb") as f:
+        pickle.dump((vocab, merges), f)
+    return tmp_path, x, pc
+
+
+def _tokenizer(vocab):
+    tok = WordTokenizer("Could you please help me explain my ECG?".split() + " ".join(REPORTS).split())
+    tok.add_tokens([f"signal_{k}" for k in vocab.keys()])             # main.py:144-150
+    tok.add_tokens(["<sig_start>"], special_tokens=True)
+    tok.add_tokens(["<sig_end>"], special_tokens=True)
+    tok.add_special_tokens({"pad_token": "<pad>"})
+    return tok
+
+
+def _dataset(root, split, inference=False, pad_to_max=124):
+    from ecg_byte_amd import file_utils as F
+    from ecg_byte_amd.data_loader import ECGTokenDataset
+    vocab, merges = F.load_vocab_and_merges(str(root / "tok.pkl"))
+    tok = _tokenizer(vocab)
+    sig, txt = F.align_signal_text_files(str(root / "ecg" / split), str(root / "text" / split))
+    args = SimpleNamespace(percentiles=str(root / "percentiles.npy"), dataset="ptb_500", inference=inference,
+                           pad_to_max=pad_to_max, dis=False, dev=False, toy=True, device="cuda")
+    return ECGTokenDataset(sig, txt, vocab, merges, tokenizer=tok, args=args), tok, args
+
+
+def test_loader_batches_equal_per_sample_items_and_the_oracle(ptb_dir):
+    from ecg_byte_amd.data_loader import DeviceBatchLoader
+    root, x, pc = ptb_dir
+    ds, tok, args = _dataset(root, "train")
+    os.remove(ds.signal_path_list[5])                                   # an unreadable sample is dropped from its batch
+    batches = list(DeviceBatchLoader(ds, batch_size=3, workers=3))
+    assert [b["tokenized_signal"].shape[0] for b in batches] == [3, 2, 2] and len(DeviceBatchLoader(ds, batch_size=3)) == 3
+    keep = [i for i in range(8) if i != 5]
+    rows = {k: torch.cat([b[k] for b in batches]).cpu().numpy() for k in batches[0]}
+    trie = O.Trie(ds.merges)
+    keys = list(ds.vocab.keys())
+    lut = {k: tok.convert_tokens_to_ids(f"signal_{k}") for k in keys}
+    for n, i in enumerate(keep):
+        item = ds[i]
+        for k in rows:
+            assert np.array_equal(rows[k][n], item[k].numpy()), (i, k)
+        sig = [lut[int(t)] for t in trie.quantize_encode(x[i], pc["percentile_1"], pc["percentile_99"])]
+        q = tok(["Could you please help me explain my ECG?"]).input_ids[0].tolist()
+        a = tok([REPORTS[i % len(REPORTS)]]).input_ids[0].tolist()
+        want = OA.prepare_training(sig, q, a, tok.pad_token_id, tok.convert_tokens_to_ids("<bos>"), tok.eos_token_id,
+                                   tok.convert_tokens_to_ids("<sig_start>"), tok.convert_tokens_to_ids("<sig_end>"), args.pad_to_max)
+        for k in want:
+            assert np.array_equal(rows[k][n], np.asarray(want[k])), (i, k)
+    assert ds[5] is None
+
+
+def _tiny_model(tok, seed=0):
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    cfg = DecoderConfig(vocab_size=len(tok), hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                        num_key_value_heads=1, rms_norm_eps=1e-5, rope_theta=10000.0, rope_scaling=None, pad_token_id=tok.pad_token_id)
+    return HipCausalLM(cfg, seed=seed)
+
+
+def test_runners_train_validate_checkpoint_and_generate(ptb_dir, tmp_path):
+    from ecg_byte_amd.data_loader import DeviceBatchLoader
+    from ecg_byte_amd.llm import LLM
+    from ecg_byte_amd.runners import tester, trainer, validater
+    root, x, pc = ptb_dir
+    train_ds, tok, args = _dataset(root, "train")
+    val_ds, _, _ = _dataset(root, "val")
+    model = LLM(_tiny_model(tok), args)
+    opt = model.llm.make_optimizer(lr=1e-4, warmup=4)
+    run_dir = tmp_path / "run"; os.makedirs(run_dir)
+    losses, vals = [], []
+    for epoch in range(6):
+        losses.append(trainer(model, DeviceBatchLoader(train_ds, batch_size=4, shuffle=True, seed=1), opt, args, epoch, str(run_dir),
+                              checkpoint_every=2 if epoch == 0 else 50000)["average_loss"])
+        vals.append(validater(model, DeviceBatchLoader(val_ds, batch_size=2), args, epoch)["average_loss"])
+    assert losses[-1] < 0.8 * losses[0] and vals[-1] < vals[0], (losses, vals)
+    assert not os.path.exists(run_dir / "best_train_model_0_1.pth")        # args.toy suppresses the step checkpoints (train.py:34)
+    # checkpoint format of main.py:299-306 and its reload (main.py:193-195)
+    torch.save({"model": model.state_dict(), "epoch": 5}, run_dir / "best_model.pth")
+    ck = torch.load(run_dir / "best_model.pth", map_location="cuda")
+    assert ck["epoch"] == 5 and all(k.startswith("llm.") for k in ck["model"]) and "llm.model.embed_tokens.weight" in ck["model"]
+    fresh = LLM(_tiny_model(tok, seed=9), args)
+    fresh.load_state_dict(ck["model"])
+    v2 = validater(fresh, DeviceBatchLoader(val_ds, batch_size=2), args, 0)["average_loss"]
+    assert abs(v2 - vals[-1]) < 1e-6 * max(1.0, abs(v2))
+    # the validation loss equals the training-path loss of the same batch (forward-only path vs autograd path)
+    b = next(iter(DeviceBatchLoader(val_ds, batch_size=2)))
+    with torch.no_grad():
+        l_eval = fresh(b).loss.item()
+    assert abs(fresh(b).loss.item() - l_eval) < 1e-5 * max(1.0, l_eval)
+    # inference: batch-1 prompts without padding, greedy generate, metrics averaged over the samples
+    test_ds, _, targs = _dataset(root, "test", inference=True)
+    out = tester(fresh, DeviceBatchLoader(test_ds, batch_size=1), tok, targs)
+    assert set(out["metrics"]) == {"BLEU"} and 0.0 <= out["metrics"]["BLEU"] <= 1.0
+    assert out["qa_results"]["questions"] == ["Could you please help me explain my ECG?"] and len(out["qa_results"]["gen_answers"]) == 1
+    p = next(iter(DeviceBatchLoader(test_ds, batch_size=1)))
+    item = test_ds[0]
+    assert torch.equal(p["tokenized_signal"][0].cpu(), item["tokenized_signal"]) and p["attn_mask"].shape == p["tokenized_signal"].shape
+
+
+def _write_model_dir(path, vocab_words):
+    """A local checkpoint directory in the hub layout: tiny Llama config + safetensors + a word-level fast tokenizer."""
+    from tokenizers import Tokenizer
+    from tokenizers.models import WordLevel
+    from tokenizers.pre_tokenizers import Whitespace
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    words = ["<unk>", "<bos>", "<eos>"] + sorted(set(vocab_words))
+    t = Tokenizer(WordLevel({w: i for i, w in enumerate(words)}, unk_token="<unk>"))
+    t.pre_tokenizer = Whitespace()
+    os.makedirs(path, exist_ok=True)
+    t.save(os.path.join(path, "tokenizer.json"))
+    with open(os.path.join(path, "tokenizer_config.json"), "w") as f:
+        json.dump({"tokenizer_class": "PreTrainedTokenizerFast", "bos_token": "<bos>", "eos_token": "<eos>", "unk_token": "<unk>"}, f)
+    cfg = DecoderConfig(vocab_size=len(words), hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                        num_key_value_heads=1, rms_norm_eps=1e-5, rope_theta=10000.0, rope_scaling=None)
+    m = HipCausalLM(cfg, seed=4)
+    m.save_pretrained(path)
+    return m
+
+
+def test_pretrained_directory_round_trip(tmp_path):
+    from ecg_byte_amd.decoder import HipCausalLM
+    m = _write_model_dir(str(tmp_path / "tiny"), ["a", "b"])
+    assert sorted(os.listdir(tmp_path / "tiny")) == ["config.json", "model.safetensors", "tokenizer.json", "tokenizer_config.json"]
+    cfg = json.load(open(tmp_path / "tiny" / "config.json"))
+    assert cfg["model_type"] == "llama" and cfg["num_key_value_heads"] == 1 and cfg["tie_word_embeddings"] is True
+    m2 = HipCausalLM.from_pretrained(str(tmp_path / "tiny"))
+    a, b = m.state_dict(), m2.state_dict()
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_main_cli_trains_then_infers_on_the_reference_layout(ptb_dir, tmp_path, monkeypatch):
+    """ecg_byte_amd.main with the reference's options on a data/ + runs/ tree: two epochs (--dev), best_model.pth in the
+    reference's run directory, then --inference over the five seeds with the per-seed and statistics files."""
+    pytest.importorskip("transformers")
+    from ecg_byte_amd import main as M
+    root, x, pc = ptb_dir
+    data = tmp_path / "data"
+    os.makedirs(data / "ptb_500")
+    os.rename(root / "ecg", data / "ptb_500" / "ecg")
+    os.rename(root / "text", data / "ptb_500" / "text")
+    os.rename(root / "tok.pkl", data / "tokenizer_c1.pkl")
+    model_dir = str(tmp_path / "tiny-llama")
+    _write_model_dir(model_dir, "Could you please help me explain my ECG ?".split() + " ".join(REPORTS).split())
+    common = ["--device", "cuda:0", "--model", model_dir, "--dataset", "ptb_500", "--tokenizer_check", "tokenizer_c1",
+              "--percentiles", str(root / "percentiles.npy"), "--pad_to_max", "124", "--batch_size", "4", "--warmup", "4",
+              "--data_root", str(data), "--runs_root", str(tmp_path / "runs"), "--num_merges", "1000", "--peft"]
+    out = M.main(common + ["--dev"])
+    assert len(out["train_loss"]) == 2 and all(np.isfinite(out["train_loss"])) and out["val_loss"][1] < out["val_loss"][0]
+    assert os.path.exists(os.path.join(out["directory"], "best_model.pth"))
+    ck = torch.load(os.path.join(out["directory"], "best_model.pth"), map_location="cpu")
+    assert ck["epoch"] in (0, 1) and any("lora_A" in k for k in ck["model"])          # --peft: adapters are in the checkpoint
+    rel = os.path.relpath(out["directory"], tmp_path / "runs" / "0")
+    stats = M.main(common + ["--inference", "--checkpoint", rel])
+    assert set(stats) == {"BLEU"} and len(stats["BLEU"]["raw_values"]) == 5
+    files = os.listdir(out["directory"])
+    assert "statistical_analysis_ptb_500.json" in files and sum(f.startswith("seed_") for f in files) == 5
