@@ -571,7 +571,6 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             const uint32_t stage_len = min(sym_cap, (n - seg_base + 16u) & ~15u);   // >= 1 sentinel past n
             stage_symbols<0, INPUT, VEC>(sym, stage_len, n - seg_base, A.signal + row + seg_base,
                                          A.raw + row + seg_base, c, 64, qa, qscale, s_thr, s_b2c);
-            for (uint32_t w = c; w < MARKW; w += 64) marks[w] = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             build_dmap<0>(sym, dmap, stage_len, c, 64);
@@ -579,10 +578,60 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             __builtin_amdgcn_wave_barrier();
             PROF_STAMP(0);
 
-            // ---- parse
+            // ---- chunk starts: equal numbers of RUNS per lane, not of symbols (a flat stretch costs a step per ~30
+            // symbols, a flickering one a step per symbol).  Lane l counts the run starts in positions [64l, 64l+64),
+            // a wave scan ranks them, and chunk k begins at the run start of rank k*R/64.  The claim bitmap is not in use
+            // yet and holds the 64 starts for a moment.  Any start is valid (claims make the parse exact whatever the
+            // starts are); the balance is what this buys.
             const uint32_t carry_rel = carry - seg_base;
+            uint32_t my_start = c * CH;
             {
-                uint32_t r = (c == 0) ? carry_rel : max(c * CH, carry_rel);   // chunks the carry token covers start at the carry
+                const uint32_t p0 = 64u * c;
+                uint32_t b0 = (p0 < seg_len) ? dmap[2 * c] : 0u, b1 = (p0 + 32 < seg_len) ? dmap[2 * c + 1] : 0u;
+                if (p0 < seg_len && seg_len - p0 < 32) b0 &= (1u << (seg_len - p0)) - 1u;
+                if (p0 + 32 < seg_len && seg_len - p0 - 32 < 32) b1 &= (1u << (seg_len - p0 - 32)) - 1u;
+                const uint32_t n_l = (uint32_t)(__popc(b0) + __popc(b1));
+                uint32_t incl = n_l;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t t = __shfl_up(incl, d, 64);
+                    if (c >= (uint32_t)d) incl += t;
+                }
+                const uint32_t R = __shfl(incl, 63, 64), P = incl - n_l;
+                marks[c] = my_start;                                            // fallback: equal symbol counts
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (n_l) {
+                    const float inv = 64.0f / (float)R;
+                    uint32_t k = max((uint32_t)ceilf((float)P * inv), 1u);
+                    const uint32_t k_hi = min((uint32_t)ceilf((float)(P + n_l) * inv), 64u);
+                    const uint32_t n_lo = (uint32_t)__popc(b0);
+                    for (; k < k_hi; ++k) {
+                        const uint32_t t = (k * R) >> 6;
+                        if (t < P || t >= P + n_l) continue;
+                        uint32_t want = t - P, w = b0, pos = 0;                 // the want-th (0-based) set bit of b1:b0
+                        if (want >= n_lo) { want -= n_lo; w = b1; pos = 32; }
+#pragma unroll
+                        for (int sh = 16; sh >= 1; sh >>= 1) {
+                            const uint32_t below = (uint32_t)__popc(w & ((1u << sh) - 1u));
+                            if (want >= below) { want -= below; w >>= sh; pos += sh; }
+                        }
+                        marks[k] = p0 + pos;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                my_start = marks[c];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            for (uint32_t w = c; w < MARKW; w += 64) marks[w] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- parse
+            {
+                uint32_t r = (c == 0) ? carry_rel : max(my_start, carry_rel);   // chunks the carry token covers start at the carry
                 uint32_t j = r, node = 0, best_j = r, best_node = 0;
                 bool live = r < seg_len;
                 while (live) {
@@ -663,10 +712,10 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             const uint32_t s_blk = min(pbase, seg_len), e_blk = min(pbase + 64u, seg_len);
             const uint32_t w0 = (2 * c < MARKW) ? marks[2 * c] : 0u, w1 = (2 * c + 1 < MARKW) ? marks[2 * c + 1] : 0u;
             const unsigned long long claimed_bits = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
-            for (unsigned long long rem = claimed_bits; rem;) {   // token lengths into the symbol bytes, four loads in flight
-                uint32_t p[4], idv[4];
+            for (unsigned long long rem = claimed_bits; rem;) {   // token lengths into the symbol bytes, eight loads in flight
+                uint32_t p[8], idv[8];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < 8; ++t) {
                     p[t] = 0xFFFFFFFFu;
                     if (rem) {
                         p[t] = pbase + (uint32_t)__ffsll((long long)rem) - 1u;
@@ -675,7 +724,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 8; ++t)
                     if (p[t] != 0xFFFFFFFFu && idv[t] != ecgb::kNoToken) sym[p[t]] = (uint8_t)(kLenBias + s_len[idv[t]]);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
