@@ -324,6 +324,13 @@ def main():
         del xd, ids
         torch.cuda.empty_cache()
         train = bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_train)
+        if not args.lora:   # SURVEY.md §8d asks for both: full fine-tune (BASELINE C3 wording) and LoRA r16 (what the reference's script runs)
+            import copy
+            largs = copy.copy(args)
+            largs.lora, largs.no_cpu_baseline, largs.train_steps = True, True, min(args.train_steps, 3)
+            lora = bench_train(largs, tk, vocab, merges, pc, world, rank, dev, x_train)
+            train["lora_r16"] = {k: lora[k] for k in ("value", "unit", "ms_per_step", "steps", "final_loss", "roofline")}
+            train["lora_r16"]["workload"] = lora["config"]["workload"]
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3

@@ -29,6 +29,8 @@ using bf16x4 = __attribute__((ext_vector_type(4))) short;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr float kLog2e = 1.4426950408889634f;
+// 2^x as one v_exp_f32 (results below 2^-126 flush to zero, which a softmax weight may)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
 
@@ -214,30 +216,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
                 for (int r = 0; r < 16; ++r) {
                     const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;       // key inside the tile
                     const bool vis = (k0 + kl <= qi) && (lds_mask[kl] != 0.f);
-                    const float v = vis ? s[r] * sc : -INFINITY;
+                    const float v = vis ? s[r] : -INFINITY;
                     p[kb][r] = v;
                     tmax = fmaxf(tmax, v);
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { const float v = s[r] * sc; p[kb][r] = v; tmax = fmaxf(tmax, v); }
+                for (int r = 0; r < 16; ++r) { const float v = s[r]; p[kb][r] = v; tmax = fmaxf(tmax, v); }
             }
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sc;      // p holds raw scores; sc > 0, so the maximum scales with them
         const float m_new = fmaxf(m, tmax);
         const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;   // no key visible yet: every p below is exp2(-inf) = 0
-        const float alpha = exp2f(m - m_safe);                     // m = -inf -> 0 (accumulators are still zero then)
+        const float alpha = fast_exp2(m - m_safe);                     // m = -inf -> 0 (accumulators are still zero then)
         float lsum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float e = exp2f(p[kb][r] - m_safe); p[kb][r] = e; lsum += e; }
+            for (int r = 0; r < 16; ++r) { const float e = fast_exp2(__builtin_fmaf(p[kb][r], sc, -m_safe)); p[kb][r] = e; lsum += e; }
         l = l * alpha + lsum;
         m = m_new;
+        if (__any(alpha != 1.f)) {   // once the running maxima have settled the accumulators need no rescale
 #pragma unroll
-        for (int db = 0; db < D / 32; ++db)
+            for (int db = 0; db < D / 32; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) accO[db][r] *= alpha;
+                for (int r = 0; r < 16; ++r) accO[db][r] *= alpha;
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -329,12 +333,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
                 for (int r = 0; r < 16; ++r) {
                     const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const bool vis = (k0 + kl <= qi) && (lds_mask[kl] != 0.f);
-                    const float pr = vis ? exp2f(s[r] * sc - lse) : 0.f;
+                    const float pr = vis ? fast_exp2(__builtin_fmaf(s[r], sc, -lse)) : 0.f;
                     ds[r] = pr * (dp[r] - delta) * A.scale;
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ds[r] = exp2f(s[r] * sc - lse) * (dp[r] - delta) * A.scale;
+                for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(__builtin_fmaf(s[r], sc, -lse)) * (dp[r] - delta) * A.scale;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs A)
             for (int r = 0; r < 16; ++r) {
                 const int ql = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;     // query inside the tile
                 const bool vis = kvis && (!diag || ki <= t0 + ql);
-                const float e = vis ? exp2f(s[r] * sc - lds_lse[ql]) : 0.f;
+                const float e = vis ? fast_exp2(__builtin_fmaf(s[r], sc, -lds_lse[ql])) : 0.f;
                 pr[r] = e;
                 ds[r] = e * (dp[r] - lds_delta[ql]) * A.scale;
             }
