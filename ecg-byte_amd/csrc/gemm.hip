@@ -210,6 +210,55 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel(GemmArgs G)
     }
 }
 
+// Epilogue of the 16x16x32 kernels: acc[i][j] holds D'[n = 4*lq + t][m = lm] of the 16x16 tile (i, j) of this wave.
+template <int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void store_tile_m16(const f32x4 (&acc)[TM][TN], const GemmArgs &G, int row0, int col0, int wr, int wc,
+                                               int lm, int lq, long long off_c)
+{
+    const float alpha = G.alpha;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = row0 + wr * WTM + i * 16 + lm;
+        if (r >= G.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = col0 + wc * WTN + j * 16 + lq * 4;
+            if (c + 3 < G.N && (G.ldc & 3) == 0) {
+                if (G.accumulate_f32 == 1) {
+                    float4 *p = reinterpret_cast<float4 *>(reinterpret_cast<float *>(G.C) + off_c + (long long)r * G.ldc + c);
+                    float4 v = *p;
+                    v.x += acc[i][j][0] * alpha; v.y += acc[i][j][1] * alpha; v.z += acc[i][j][2] * alpha; v.w += acc[i][j][3] * alpha;
+                    *p = v;
+                } else {
+                    using us4 = __attribute__((ext_vector_type(4))) unsigned short;
+                    us4 *p = reinterpret_cast<us4 *>(reinterpret_cast<unsigned short *>(G.C) + off_c + (long long)r * G.ldc + c);
+                    us4 v;
+                    if (G.accumulate_f32 == 2) {
+                        const us4 o = *p;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = f2bf_rn(__uint_as_float((unsigned)o[t] << 16) + acc[i][j][t] * alpha);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = f2bf_rn(acc[i][j][t] * alpha);
+                    }
+                    *p = v;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (c + t >= G.N) continue;
+                    const float v = acc[i][j][t] * alpha;
+                    if (G.accumulate_f32 == 1) reinterpret_cast<float *>(G.C)[off_c + (long long)r * G.ldc + c + t] += v;
+                    else {
+                        unsigned short *q = reinterpret_cast<unsigned short *>(G.C) + off_c + (long long)r * G.ldc + c + t;
+                        *q = f2bf_rn(G.accumulate_f32 == 2 ? __uint_as_float((unsigned)*q << 16) + v : v);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Same structure on `v_mfma_f32_16x16x32_bf16` (one MFMA = 16x16 outputs x K 32; the chip holds a higher
 // clock on this shape than on 32x32x16, MI355X_MICROARCH.md "DVFS give-back" item 7).  Operands swapped
 // as above: D'[n][m] with m = lane & 15 on the lane and n = 4*(lane >> 4) + reg in the registers.
@@ -290,48 +339,130 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16(GemmArgs G)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    const float alpha = G.alpha;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int r = row0 + wr * WTM + i * 16 + lm;
-        if (r >= G.M) continue;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int c = col0 + wc * WTN + j * 16 + lq * 4;
-            if (c + 3 < G.N && (G.ldc & 3) == 0) {
-                if (G.accumulate_f32 == 1) {
-                    float4 *p = reinterpret_cast<float4 *>(reinterpret_cast<float *>(G.C) + off_c + (long long)r * G.ldc + c);
-                    float4 v = *p;
-                    v.x += acc[i][j][0] * alpha; v.y += acc[i][j][1] * alpha; v.z += acc[i][j][2] * alpha; v.w += acc[i][j][3] * alpha;
-                    *p = v;
-                } else {
-                    using us4 = __attribute__((ext_vector_type(4))) unsigned short;
-                    us4 *p = reinterpret_cast<us4 *>(reinterpret_cast<unsigned short *>(G.C) + off_c + (long long)r * G.ldc + c);
-                    us4 v;
-                    if (G.accumulate_f32 == 2) {
-                        const us4 o = *p;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] = f2bf_rn(__uint_as_float((unsigned)o[t] << 16) + acc[i][j][t] * alpha);
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] = f2bf_rn(acc[i][j][t] * alpha);
-                    }
-                    *p = v;
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (c + t >= G.N) continue;
-                    const float v = acc[i][j][t] * alpha;
-                    if (G.accumulate_f32 == 1) reinterpret_cast<float *>(G.C)[off_c + (long long)r * G.ldc + c + t] += v;
-                    else {
-                        unsigned short *q = reinterpret_cast<unsigned short *>(G.C) + off_c + (long long)r * G.ldc + c + t;
-                        *q = f2bf_rn(G.accumulate_f32 == 2 ? __uint_as_float((unsigned)*q << 16) + v : v);
-                    }
-                }
-            }
-        }
+    store_tile_m16<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, off_c);
+}
+
+// The 256x256 tile in four PHASES per K-tile, the two wave rows staggered by one barrier.
+// A wave's 128x64 output is cut into quadrants (64 rows x 32 columns); a phase is
+//     [LDS reads of the operand halves the quadrant needs | LDS-DMA issue | counted waits]  barrier
+//     [16 MFMAs = one quadrant x K 64]                                                        barrier
+// and the waves of row 1 run one barrier behind those of row 0, so on every SIMD one wave reads LDS while the
+// other one issues MFMAs (cdna_hip_programming.md, "256^2 8-phase template": the per-phase interleave is the lever).
+// Quadrant order (A0,B0) (A0,B1) (A1,B1) (A1,B0): phase 1 reads A0 and B0, phase 2 B1, phase 3 A1, phase 4 nothing.
+// Reads are retired (lgkmcnt 0) before the phase's first barrier, so an LDS region may be restaged one phase after
+// its last read: the B region of the buffer is refilled for tile t+2 in phase 3 of tile t, the A region in phase 4
+// -- more than a whole K-tile ahead of their use.  Tile t+1 is waited for in phase 4 of tile t with the eight loads
+// of tile t+2 left in flight (vmcnt 8, never 0 inside the loop) and first read one barrier later.
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
+{
+    static_assert(BM == 256 && BN == 256 && WGM == 2 && WGN == 4, "phase schedule written for the 256x256 tile, 2x4 waves");
+    constexpr int NW = WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;                 // 8 x 4 MFMA tiles per wave
+    constexpr int kABytes = BM * BK * 2, kBBytes = BN * BK * 2, kBufBytes = kABytes + kBBytes;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nwg = G.tiles_m * G.tiles_n;
+    const int orig = blockIdx.x;
+    const int q = nwg / 8, rr = nwg % 8, xcd = orig % 8;
+    const int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
+    const int tm = wgid / G.tiles_n, tn = wgid % G.tiles_n;
+    const int row0 = tm * BM, col0 = tn * BN;
+    long long off_a, off_b, off_c;
+    if (G.inner) {
+        const int zo = blockIdx.z / G.inner, zi = blockIdx.z % G.inner;
+        off_a = zo * G.outer_a + (zi / G.div_a) * G.inner_a;
+        off_b = zo * G.outer_b + (zi / G.div_b) * G.inner_b;
+        off_c = zo * G.outer_c + zi * G.inner_c;
+    } else {
+        off_a = (long long)blockIdx.z * G.batch_a;
+        off_b = (long long)blockIdx.z * G.batch_b;
+        off_c = (long long)blockIdx.z * G.batch_c;
     }
+    const unsigned short *A = G.A + off_a;
+    const unsigned short *B = G.B + off_b;
+    const int wr = wave / WGN, wc = wave % WGN;
+    const int lm = lane & 15, lq = lane >> 4;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int KT = G.K / BK;
+
+    // prologue: tiles 0 and 1 in flight, tile 0 complete
+    stage_tile<BN, NW>(B, G.ldb, col0, G.N, 0, lds + kABytes, wave, lane);
+    stage_tile<BM, NW>(A, G.lda, row0, G.M, 0, lds, wave, lane);
+    if (KT > 1) {
+        stage_tile<BN, NW>(B, G.ldb, col0, G.N, BK, lds + kBufBytes + kABytes, wave, lane);
+        stage_tile<BM, NW>(A, G.lda, row0, G.M, BK, lds + kBufBytes, wave, lane);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // the stagger: row 1 runs one barrier behind row 0
+
+    bf16x8 a[2][4], b[2][4];                             // [k-step][tile]: one A half (4 row tiles), both B halves (4 column tiles)
+    for (int kt = 0; kt < KT; ++kt) {
+        const unsigned char *At = lds + (kt & 1) * kBufBytes, *Bt = At + kABytes;
+        unsigned char *nxt = lds + (kt & 1) * kBufBytes;  // tile kt+2 goes where tile kt lives
+        const bool more = kt + 2 < KT;
+        auto read_a = [&](int half) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ra = wr * WTM + (half * 4 + i) * 16 + lm, chunk = ks * 4 + lq;
+                    a[ks][i] = *reinterpret_cast<const bf16x8 *>(At + ra * 128 + ((chunk ^ ((ra >> 1) & 7)) << 4));
+                }
+        };
+        auto read_b = [&](int half) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int rb = wc * WTN + (half * 2 + j) * 16 + lm, chunk = ks * 4 + lq;
+                    b[ks][half * 2 + j] = *reinterpret_cast<const bf16x8 *>(Bt + rb * 128 + ((chunk ^ ((rb >> 1) & 7)) << 4));
+                }
+        };
+        auto mfma_quadrant = [&](int ah, int bh) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ah * 4 + i][bh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ks][bh * 2 + j], a[ks][i], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        // phase 1
+        read_b(0);
+        read_a(0);
+        mfma_quadrant(0, 0);
+        // phase 2
+        read_b(1);
+        mfma_quadrant(0, 1);
+        // phase 3: the B region of this buffer was last read in phase 2
+        read_a(1);
+        if (more) stage_tile<BN, NW>(B, G.ldb, col0, G.N, (kt + 2) * BK, nxt + kABytes, wave, lane);
+        mfma_quadrant(1, 1);
+        // phase 4: the A region was last read in phase 3; tile kt+1 must be complete one barrier from here
+        if (more) {
+            stage_tile<BM, NW>(A, G.lda, row0, G.M, (kt + 2) * BK, nxt, wave, lane);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        mfma_quadrant(1, 0);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();          // barrier counts of the two rows match again
+    store_tile_m16<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, off_c);
 }
 
 // ---- TN product for weight gradients: C[N,K] = A^T . B with A = dY [M,N] and B = X [M,K] (both ROW-major, the
@@ -449,7 +580,8 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_m16(GemmArgs G)
     }
 }
 
-int g_gemm_tile = 0;   // 0 auto; forced: 128 = 128x128 tile, 256 = 256x256 on 16x16x32 MFMA, 257 = 256x256 on 32x32x16 MFMA
+int g_gemm_tile = 0;   // 0 auto; forced: 128 = 128x128 tile, 256 = 256x256 phased on 16x16x32 MFMA (the default for big problems),
+                       // 257 = 256x256 on 32x32x16 MFMA, 258 = 256x256 on 16x16x32 with one barrier pair per K-tile (the earlier kernels, kept for A/B)
 
 int launch_gemm(GemmArgs &G, int batch, hipStream_t stream)
 {
@@ -457,7 +589,14 @@ int launch_gemm(GemmArgs &G, int batch, hipStream_t stream)
     const long long tiles256 = (long long)((G.M + 255) / 256) * ((G.N + 255) / 256) * batch;
     const bool big = g_gemm_tile >= 256 || (g_gemm_tile == 0 && tiles256 >= 192 && G.M >= 256 && G.N >= 256);
     hipError_t e;
-    if (big && g_gemm_tile != 257) {
+    if (big && g_gemm_tile != 257 && g_gemm_tile != 258) {
+        constexpr int lds = 2 * (256 + 256) * BK * 2;
+        auto kern = gemm_nt_kernel_m16p<256, 256, 2, 4>;
+        G.tiles_m = (G.M + 255) / 256; G.tiles_n = (G.N + 255) / 256;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess)
+            hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, (unsigned)batch), dim3(512), lds, stream, G);
+    } else if (big && g_gemm_tile == 258) {
         constexpr int lds = 2 * (256 + 256) * BK * 2;
         auto kern = gemm_nt_kernel_m16<256, 256, 2, 4>;
         G.tiles_m = (G.M + 255) / 256; G.tiles_n = (G.N + 255) / 256;
@@ -488,7 +627,7 @@ int launch_gemm(GemmArgs &G, int batch, hipStream_t stream)
 
 extern "C" int ecgb_set_gemm_tile(int tile)
 {
-    if (tile != 0 && tile != 128 && tile != 256 && tile != 257) { ecgb::set_error("ecgb_set_gemm_tile: 0, 128, 256 or 257"); return ECGB_ERR_INVALID; }
+    if (tile != 0 && tile != 128 && (tile < 256 || tile > 258)) { ecgb::set_error("ecgb_set_gemm_tile: 0, 128, 256, 257 or 258"); return ECGB_ERR_INVALID; }
     g_gemm_tile = tile;
     return ECGB_OK;
 }

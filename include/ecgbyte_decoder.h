@@ -75,7 +75,8 @@ int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b_dev, long 
 int ecgb_gemm_tn_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
                       int M, int N, int K, float alpha, int splits, void *stream);
 /* Output tile choice: 0 = automatic (256x256 tiles / 8 waves on v_mfma_f32_16x16x32_bf16 when they fill the chip,
- * else 128x128 / 4 waves on 32x32x16); forced: 128, 256, or 257 = 256x256 on 32x32x16 (tests, tuning). */
+ * else 128x128 / 4 waves on 32x32x16); forced: 128, 256, 257 = 256x256 on 32x32x16, 258 = 256x256 on 16x16x32
+ * without the four-phase schedule (tests, tuning). */
 int ecgb_set_gemm_tile(int tile);
 /* Same, with two-level batch addressing for attention heads: batch entry z = (zo, zi), zo = z / inner,
  * zi = z % inner; operand X starts at X + zo*outer_x + (zi / div_x)*inner_x  (div_b > 1 shares one KV head

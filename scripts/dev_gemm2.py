@@ -1,0 +1,22 @@
+"""Dev-only: A/B of the 256x256 GEMM kernels (tile 256 = one-barrier-pair per K-tile, 258 = phased + staggered), interleaved."""
+import sys, time
+sys.path.insert(0, '/root/repo')
+import torch
+from ecg_byte_amd import decoder_ops as ops
+shapes = [(32768, 3072, 2048), (32768, 16384, 2048), (32768, 2048, 8192), (32768, 2048, 2048), (8192, 8192, 8192), (4096, 4096, 4096)]
+for M, N, K in shapes:
+    a = torch.randn(M, K, device="cuda").to(torch.bfloat16); b = torch.randn(N, K, device="cuda").to(torch.bfloat16)
+    outs = {t: torch.empty(M, N, device="cuda", dtype=torch.bfloat16) for t in (256, 258)}
+    best = {256: 1e9, 258: 1e9}
+    for rep in range(6):
+        for tile in (256, 258):
+            ops.set_gemm_tile(tile)
+            ops.gemm_nt(a, b, out=outs[tile])
+            torch.cuda.synchronize(); t = time.perf_counter()
+            for _ in range(4): ops.gemm_nt(a, b, out=outs[tile])
+            torch.cuda.synchronize(); best[tile] = min(best[tile], (time.perf_counter() - t) / 4)
+    ops.set_gemm_tile(0)
+    same = torch.equal(outs[256], outs[258])
+    ref = (a[:256].float() @ b[:512].float().T)
+    err = (outs[258][:256, :512].float() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"M{M} N{N} K{K}: tile256 {2*M*N*K/best[256]/1e12:.0f}  phased {2*M*N*K/best[258]/1e12:.0f} TFLOP/s   identical={same} relerr={err:.2e}")

@@ -29,12 +29,37 @@ def _close(got, ref, atol, rtol=2 ** -7):
     assert bool((err <= tol).all()), f"max err {err.max().item():.4g} (tol {tol[err.argmax()].item():.4g})"
 
 
-@pytest.mark.parametrize("tile", [128, 256, 257])
+@pytest.mark.parametrize("tile", [128, 256, 257, 258])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 136, 128), (1024, 3072, 2048), (64, 512, 8192), (520, 300, 192)])
 def test_gemm_nt(ops, M, N, K, tile):
     ops.set_gemm_tile(tile)
     try:
         _gemm_checks(ops, M, N, K)
+    finally:
+        ops.set_gemm_tile(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 128), (300, 520, 192), (4096, 2048, 2048), (2048, 4096, 8192), (8192, 3072, 320)])
+def test_gemm_phased_schedule_is_bitwise_the_unphased_kernel(ops, M, N, K):
+    """The four-phase staggered 256x256 kernel (tile 256) issues the same MFMAs in the same order per accumulator as the
+    one-barrier-pair kernel (tile 258): results must be IDENTICAL, launch after launch -- an LDS race (a read ahead of
+    its LDS-DMA, a restage over a pending read) shows up as a rare differing tile, so the launch is repeated while other
+    kernels keep the memory system busy.  K-tile counts 1, 2, 3, odd and large; ragged M / N."""
+    a, b = _bf(M, K, seed=11), _bf(N, K, seed=12)
+    noise = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
+    ops.set_gemm_tile(258)
+    try:
+        want = ops.gemm_nt(a, b)
+        ops.set_gemm_tile(256)
+        for rep in range(25):
+            noise.random_()                      # concurrent traffic from the same stream's neighbours
+            got = ops.gemm_nt(a, b)
+            assert torch.equal(got, want), rep
+        acc_w = torch.ones((M, N), device="cuda")
+        acc_g = torch.ones((M, N), device="cuda")
+        ops.set_gemm_tile(258); ops.gemm_nt(a, b, out=acc_w, alpha=0.25, accumulate_f32=True)
+        ops.set_gemm_tile(256); ops.gemm_nt(a, b, out=acc_g, alpha=0.25, accumulate_f32=True)
+        assert torch.equal(acc_g, acc_w)
     finally:
         ops.set_gemm_tile(0)
 
