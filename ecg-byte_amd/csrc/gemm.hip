@@ -489,7 +489,11 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_m16(GemmArgs G)
     const int row0 = tm * BN_, col0 = tn * BK_;          // output row block (columns of A), output column block (columns of B)
     const unsigned short *A = G.A, *B = G.B;
     // staging item of this thread: columns c8*8 .. +7 of the operand's 256-column block, rows mg*4 .. +3 of the 64-row K-tile
-    const int c8 = tid & 31, mg = tid >> 5;               // 32 column chunks x 16 row groups = 512 items
+    // 32 column chunks x 16 row groups = 512 items.  The 16 row groups of a column chunk sit on consecutive lanes and a wave
+    // covers 4 column chunks, so that one transposing LDS write (below) touches 4 output rows x all 16 positions of a row
+    // instead of 32 rows x 2 positions: with the chunk-major assignment every write was a 16-way bank conflict
+    // (SQ_LDS_BANK_CONFLICT = 74 % of the LDS cycles).
+    const int c8 = wave * 4 + (lane >> 4), mg = lane & 15;
     const int wr = wave / WGN, wc = wave % WGN;
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -512,17 +516,29 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_m16(GemmArgs G)
         }
     };
     auto write_items = [&](unsigned char *buf) {
-        using bf16x4 = __attribute__((ext_vector_type(4))) short;
+        // Element pair (2k, 2k+1) of the four loaded rows is one 32-bit register each; a byte permute gathers the low or
+        // the high halves into the 8-byte transposed word.  Odd column chunks write their odd row first: a write
+        // instruction then covers two even and two odd output rows, i.e. both halves of the 64 LDS banks.
+        using u4 = __attribute__((ext_vector_type(4))) unsigned;
+        using u2 = __attribute__((ext_vector_type(2))) unsigned;
+        const unsigned odd = (unsigned)c8 & 1u;
+        const unsigned sel0 = odd ? 0x07060302u : 0x05040100u, sel1 = odd ? 0x05040100u : 0x07060302u;
+        u4 a4[4], b4[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = c8 * 8 + j;                     // output row inside the block = operand column
-            const int slot = (mg >> 1) ^ ((r >> 1) & 7);  // 16-byte slot of contraction elements 8*(mg>>1) .. +7
-            bf16x4 wa, wb;
-            wa[0] = ra[0][j]; wa[1] = ra[1][j]; wa[2] = ra[2][j]; wa[3] = ra[3][j];
-            wb[0] = rb[0][j]; wb[1] = rb[1][j]; wb[2] = rb[2][j]; wb[3] = rb[3][j];
-            *reinterpret_cast<bf16x4 *>(buf + r * 128 + (slot << 4) + (mg & 1) * 8) = wa;
-            *reinterpret_cast<bf16x4 *>(buf + kABytes + r * 128 + (slot << 4) + (mg & 1) * 8) = wb;
-        }
+        for (int t = 0; t < 4; ++t) { a4[t] = __builtin_bit_cast(u4, ra[t]); b4[t] = __builtin_bit_cast(u4, rb[t]); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const unsigned sel = pass ? sel1 : sel0;
+                const int r = c8 * 8 + 2 * k + (int)(pass ? 1u - odd : odd);   // output row inside the block = operand column
+                const int slot = (mg >> 1) ^ ((r >> 1) & 7);                    // 16-byte slot of contraction elements 8*(mg>>1) .. +7
+                u2 wa, wb;
+                wa[0] = __builtin_amdgcn_perm(a4[1][k], a4[0][k], sel); wa[1] = __builtin_amdgcn_perm(a4[3][k], a4[2][k], sel);
+                wb[0] = __builtin_amdgcn_perm(b4[1][k], b4[0][k], sel); wb[1] = __builtin_amdgcn_perm(b4[3][k], b4[2][k], sel);
+                *reinterpret_cast<u2 *>(buf + r * 128 + (slot << 4) + (mg & 1) * 8) = wa;
+                *reinterpret_cast<u2 *>(buf + kABytes + r * 128 + (slot << 4) + (mg & 1) * 8) = wb;
+            }
     };
     load_items(kt_begin);
     write_items(lds + (kt_begin & 1) * kBufBytes);
@@ -579,6 +595,7 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_m16(GemmArgs G)
         }
     }
 }
+
 
 int g_gemm_tile = 0;   // 0 auto; forced: 128 = 128x128 tile, 256 = 256x256 phased on 16x16x32 MFMA (the default for big problems),
                        // 257 = 256x256 on 32x32x16 MFMA, 258 = 256x256 on 16x16x32 with one barrier pair per K-tile (the earlier kernels, kept for A/B)
@@ -696,7 +713,7 @@ extern "C" int ecgb_gemm_tn_bf16(const void *a_dev, long long lda, const void *b
     G.accumulate_f32 = splits > 1 ? 1 : 0; G.alpha = alpha;      // splits > 1: c_dev is a ZEROED fp32 [N, ldc] buffer
     G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
     constexpr int lds = 2 * (256 + 256) * 64 * 2;
-    auto kern = gemm_tn_kernel_m16<256, 256, 2, 4>;
+    auto kern = gemm_tn_kernel_m16<256, 256, 2, 4>;   // (the four-phase staggered schedule of the NT kernel measured 4-6 % slower here)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), (unsigned)splits), dim3(512), lds, (hipStream_t)stream, G);

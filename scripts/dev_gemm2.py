@@ -20,3 +20,17 @@ for M, N, K in shapes:
     ref = (a[:256].float() @ b[:512].float().T)
     err = (outs[258][:256, :512].float() - ref).abs().max().item() / ref.abs().max().item()
     print(f"M{M} N{N} K{K}: tile256 {2*M*N*K/best[256]/1e12:.0f}  phased {2*M*N*K/best[258]/1e12:.0f} TFLOP/s   identical={same} relerr={err:.2e}")
+
+for M, N, K in [(32768, 3072, 2048), (32768, 16384, 2048), (32768, 2048, 8192), (32768, 2048, 2048), (4096, 132096, 2048)]:
+    dy = torch.randn(M, N, device="cuda").to(torch.bfloat16); x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    best = {256: 1e9, 258: 1e9}; outs = {}
+    for rep in range(5):
+        for tile in (258, 256):
+            ops.set_gemm_tile(tile)
+            outs[tile] = ops.gemm_tn(dy, x)
+            torch.cuda.synchronize(); t = time.perf_counter()
+            for _ in range(3): ops.gemm_tn(dy, x)
+            torch.cuda.synchronize(); best[tile] = min(best[tile], (time.perf_counter() - t) / 3)
+    ops.set_gemm_tile(0)
+    d = (outs[256].float() - outs[258].float()).abs().max().item()
+    print(f"TN dW[{N},{K}] over M={M}: unphased {2*M*N*K/best[258]/1e12:.0f}  phased {2*M*N*K/best[256]/1e12:.0f} TFLOP/s  maxdiff {d:.3g}")
