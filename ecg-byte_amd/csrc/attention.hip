@@ -158,10 +158,12 @@ __device__ __forceinline__ void store_accT(const f32x16 (&acc)[D / 32], unsigned
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_k[64 * D * 2];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_vt[D * 128];
-    __shared__ float lds_mask[64];
-    __shared__ int lds_flag;
+    // two K / V^T tile buffers: the tile after the one being multiplied is written while the others still compute,
+    // one barrier per tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds_k2[2][64 * D * 2];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_vt2[2][D * 128];
+    __shared__ float lds_mask2[2][64];
+    __shared__ int lds_flag2[2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, hq = blockIdx.y, g = hq / (A.Hq / A.Hkv);
     const int q0 = blockIdx.x * 128;
@@ -186,19 +188,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
     const unsigned short *src = first_half ? K + rowbase * A.ldk : V + rowbase * A.ldv;
     const long long src_ld = first_half ? A.ldk : A.ldv;
     Stage4 st;
-    stage_load<D>(st, src, src_ld, 0, A.S, item);
-    for (int k0 = 0; k0 < k_end; k0 += 64) {
-        __syncthreads();
-        if (first_half) stage_write_plain<D>(lds_k, st, item); else stage_write_transposed(lds_vt, st, item);
+    auto write_tile = [&](int buf, int k0) {
+        if (first_half) stage_write_plain<D>(lds_k2[buf], st, item); else stage_write_transposed(lds_vt2[buf], st, item);
         if (threadIdx.x < 64) {   // wave 0: key mask of the tile + "tile holds a padded / out-of-range key" flag
             const float mk = (k0 + (int)threadIdx.x < A.S) ? A.mask[rowbase + k0 + (int)threadIdx.x] : 0.f;
-            lds_mask[threadIdx.x] = mk;
+            lds_mask2[buf][threadIdx.x] = mk;
             const bool any0 = __any(mk == 0.f);
-            if (threadIdx.x == 0) lds_flag = any0 ? 1 : 0;
+            if (threadIdx.x == 0) lds_flag2[buf] = any0 ? 1 : 0;
         }
-        if (k0 + 64 < k_end) stage_load<D>(st, src, src_ld, k0 + 64, A.S, item);   // next tile in flight behind the MFMAs
-        __syncthreads();
-        if (k0 > wave_qmax) continue;
+    };
+    stage_load<D>(st, src, src_ld, 0, A.S, item);
+    write_tile(0, 0);
+    __syncthreads();
+    for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
+        const bool more = k0 + 64 < k_end;
+        if (more) stage_load<D>(st, src, src_ld, k0 + 64, A.S, item);   // next tile in flight behind the MFMAs
+        const unsigned char *lds_k = lds_k2[it & 1], *lds_vt = lds_vt2[it & 1];
+        const float *lds_mask = lds_mask2[it & 1];
+        const int lds_flag = lds_flag2[it & 1];
+        if (k0 <= wave_qmax) {
         // masks only matter on tiles that touch the diagonal of this wave's rows or hold padded keys
         const bool need_mask = (k0 + 63 > q0 + wave * 32) || lds_flag;
         float p[2][16];
@@ -251,6 +259,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
                 for (int db = 0; db < D / 32; ++db)
                     accO[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_vt, db * 32 + lr, kb, s2, h), pf, accO[db], 0, 0, 0);
             }
+        }
+        if (more) write_tile((it + 1) & 1, k0 + 64);   // its last readers passed the barrier that ended the previous trip
+        __syncthreads();
     }
     const float lt = l + __shfl_xor(l, 32, 64);
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
