@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
     // one barrier per tile
     __shared__ __attribute__((aligned(16))) unsigned char lds_k2[2][64 * D * 2];
     __shared__ __attribute__((aligned(16))) unsigned char lds_vt2[2][D * 128];
-    __shared__ float lds_mask2[2][64];
+    __shared__ __attribute__((aligned(16))) float lds_mask2[2][64];
     __shared__ int lds_flag2[2];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, hq = blockIdx.y, g = hq / (A.Hq / A.Hkv);
@@ -220,10 +220,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
             for (int ks = 0; ks < D / 16; ++ks)
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_k, kb * 32 + lr, ks, h), qf[ks], s, 0, 0, 0);
             if (need_mask) {
+                float4 mk4[4];                                                   // the lane's 16 keys are 4 runs of 4: four 16-byte reads,
+#pragma unroll   // (not sixteen dependent 4-byte reads behind a branch each)
+                for (int g4 = 0; g4 < 4; ++g4) mk4[g4] = *reinterpret_cast<const float4 *>(&lds_mask[kb * 32 + 8 * g4 + 4 * h]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;       // key inside the tile
-                    const bool vis = (k0 + kl <= qi) && (lds_mask[kl] != 0.f);
+                    const float mkv = (r & 3) == 0 ? mk4[r >> 2].x : (r & 3) == 1 ? mk4[r >> 2].y : (r & 3) == 2 ? mk4[r >> 2].z : mk4[r >> 2].w;
+                    const bool vis = (k0 + kl <= qi) & (mkv != 0.f);
                     const float v = vis ? s[r] : -INFINITY;
                     p[kb][r] = v;
                     tmax = fmaxf(tmax, v);
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
     __shared__ __attribute__((aligned(16))) unsigned char lds_k[64 * D * 2];
     __shared__ __attribute__((aligned(16))) unsigned char lds_v[64 * D * 2];
     __shared__ __attribute__((aligned(16))) unsigned char lds_kt[D * 128];
-    __shared__ float lds_mask[64];
+    __shared__ __attribute__((aligned(16))) float lds_mask[64];
     __shared__ int lds_flag;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, hq = blockIdx.y, g = hq / (A.Hq / A.Hkv);
@@ -340,10 +344,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
             }
             float ds[16];
             if (need_mask) {
+                float4 mk4[4];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) mk4[g4] = *reinterpret_cast<const float4 *>(&lds_mask[kb * 32 + 8 * g4 + 4 * h]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const bool vis = (k0 + kl <= qi) && (lds_mask[kl] != 0.f);
+                    const float mkv = (r & 3) == 0 ? mk4[r >> 2].x : (r & 3) == 1 ? mk4[r >> 2].y : (r & 3) == 2 ? mk4[r >> 2].z : mk4[r >> 2].w;
+                    const bool vis = (k0 + kl <= qi) & (mkv != 0.f);
                     const float pr = vis ? fast_exp2(__builtin_fmaf(s[r], sc, -lse)) : 0.f;
                     ds[r] = pr * (dp[r] - delta) * A.scale;
                 }
@@ -366,13 +374,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
 // =====================================================================================================
 // backward, dK and dV: grid (ceil(S/128), Hkv, B); lanes = keys; loops over the query heads of the group
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs A)
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs A)   // two waves per SIMD: at most 256 registers
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds_q[64 * D * 2];
     __shared__ __attribute__((aligned(16))) unsigned char lds_do[64 * D * 2];
     __shared__ __attribute__((aligned(16))) unsigned char lds_qt[D * 128];
     __shared__ __attribute__((aligned(16))) unsigned char lds_dot[D * 128];
-    __shared__ float lds_lse[64], lds_delta[64];
+    __shared__ __attribute__((aligned(16))) float lds_lse[64];
+    __shared__ __attribute__((aligned(16))) float lds_delta[64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, g = blockIdx.y, G = A.Hq / A.Hkv;
     const int kk0 = blockIdx.x * 128;
@@ -440,12 +449,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs A)
             float pr[16], ds[16];
             const bool diag = t0 + qb * 32 < wave_kmin + 32;              // some query of the block may precede some key of the wave
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ql = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;     // query inside the tile
-                const bool vis = kvis && (!diag || ki <= t0 + ql);
-                const float e = vis ? fast_exp2(__builtin_fmaf(s[r], sc, -lds_lse[ql])) : 0.f;
-                pr[r] = e;
-                ds[r] = e * (dp[r] - lds_delta[ql]) * A.scale;
+            for (int g4 = 0; g4 < 4; ++g4) {                                // the lane's 16 queries are 4 runs of 4: 16-byte reads
+                const float4 lse4 = *reinterpret_cast<const float4 *>(&lds_lse[qb * 32 + 8 * g4 + 4 * h]);
+                const float4 dl4 = *reinterpret_cast<const float4 *>(&lds_delta[qb * 32 + 8 * g4 + 4 * h]);
+                const float lse_t[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dl_t[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int r = 4 * g4 + t;
+                    const int ql = qb * 32 + t + 8 * g4 + 4 * h;             // query inside the tile
+                    const bool vis = kvis & (!diag | (ki <= t0 + ql));
+                    const float e = vis ? fast_exp2(__builtin_fmaf(s[r], sc, -lse_t[t])) : 0.f;
+                    pr[r] = e;
+                    ds[r] = e * (dp[r] - dl_t[t]) * A.scale;
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
