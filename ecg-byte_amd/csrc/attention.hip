@@ -56,17 +56,20 @@ struct AttnArgs {
 // after the barrier that retires the previous tile: plain image (row r at r*D*2 bytes, 16-byte slot c at
 // c ^ ((r >> 1) & 7)) and/or transposed image ([D][64]: row d at d*128 bytes, the 8-byte slot holding rows
 // 4*rg..4*rg+3 at rg ^ (d & 15)).
-struct Stage4 { bf16x8 v[4]; };
+struct Stage4 { bf16x8 v[4]; int nvalid; };   // nvalid: rows of the tile that exist (the others are zeroed when written to LDS)
 
 template <int D>
 __device__ __forceinline__ void stage_load(Stage4 &st, const unsigned short *g, long long ld, int row0, int rows_valid, int item)
 {
     const int rg = item % 16, c = item / 16;
+    // branch-free and unconditional: a conditional load is a basic block of its own and hipcc waits for it (vmcnt 0) before
+    // the next one; zeroing the out-of-range rows HERE would make the wait land right behind the loads.  Out-of-range rows
+    // read the last valid row; stage_write_* zeroes them.
+    st.nvalid = rows_valid - row0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int r = row0 + rg * 4 + t;
-        st.v[t] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (r < rows_valid) st.v[t] = *reinterpret_cast<const bf16x8 *>(g + (long long)r * ld + c * 8);
+        st.v[t] = *reinterpret_cast<const bf16x8 *>(g + (long long)min(r, rows_valid - 1) * ld + c * 8);
     }
 }
 template <int D>
@@ -76,7 +79,7 @@ __device__ __forceinline__ void stage_write_plain(unsigned char *lds, const Stag
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int r = rg * 4 + t;
-        *reinterpret_cast<bf16x8 *>(lds + r * (D * 2) + ((c ^ ((r >> 1) & 7)) << 4)) = st.v[t];
+        *reinterpret_cast<bf16x8 *>(lds + r * (D * 2) + ((c ^ ((r >> 1) & 7)) << 4)) = (r < st.nvalid) ? st.v[t] : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
 }
 __device__ __forceinline__ void stage_write_transposed(unsigned char *lds, const Stage4 &st, int item)
@@ -87,6 +90,8 @@ __device__ __forceinline__ void stage_write_transposed(unsigned char *lds, const
         const int d = c * 8 + j;
         bf16x4 w;
         w[0] = st.v[0][j]; w[1] = st.v[1][j]; w[2] = st.v[2][j]; w[3] = st.v[3][j];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) if (rg * 4 + t >= st.nvalid) w[t] = 0;
         *reinterpret_cast<bf16x4 *>(lds + d * 128 + ((rg ^ (d & 15)) << 3)) = w;
     }
 }
@@ -211,14 +216,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
         const bool need_mask = (k0 + 63 > q0 + wave * 32) || lds_flag;
         float p[2][16];
         float tmax = -INFINITY;
+        f32x16 sacc[2];                                         // the two key halves' chains interleaved: an MFMA never
+#pragma unroll                                                  // waits for the one issued just before it
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_k, kb * 32 + lr, ks, h), qf[ks], sacc[kb], 0, 0, 0);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < D / 16; ++ks)
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_k, kb * 32 + lr, ks, h), qf[ks], s, 0, 0, 0);
+            const f32x16 &s = sacc[kb];
             if (need_mask) {
                 float4 mk4[4];                                                   // the lane's 16 keys are 4 runs of 4: four 16-byte reads,
 #pragma unroll   // (not sixteen dependent 4-byte reads behind a branch each)
