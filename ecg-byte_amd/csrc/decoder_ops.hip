@@ -183,6 +183,67 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const unsigned short *
     for (int c = threadIdx.x; c < H; c += blockDim.x) atomicAdd(dw + c, s_dw[c]);
 }
 
+// The same for H = NC * 512 (2048, 4096): a lane owns NC runs of 8 columns, keeps the row's x and dy in registers (one
+// pass over memory) and its share of dw in fp32 registers across all the rows its wave processes; LDS and global atomics
+// happen once per wave / block instead of once per element (the kernel above spends its time in LDS atomics: 1.1 TB/s).
+template <bool GEMMA, int NC>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_rows_kernel(const unsigned short *x, const unsigned short *w,
+                                                               const float *rstd, const unsigned short *dy,
+                                                               const unsigned short *dres, unsigned short *dx, float *dw,
+                                                               size_t rows)
+{
+    constexpr int H = NC * 512;
+    __shared__ float s_dw[H];
+    for (int c = threadIdx.x; c < H; c += blockDim.x) s_dw[c] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    float wf[NC][8], acc[NC][8];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const bf16x8 vw = *reinterpret_cast<const bf16x8 *>(w + k * 512 + lane * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wf[k][j] = GEMMA ? 1.0f + bf2f(vw[j]) : bf2f(vw[j]); acc[k][j] = 0.f; }
+    }
+    for (size_t r = wave; r < rows; r += n_waves) {
+        const float rs = rstd[r];
+        bf16x8 vx[NC], vg[NC], vr[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            vx[k] = *reinterpret_cast<const bf16x8 *>(x + r * H + k * 512 + lane * 8);
+            vg[k] = *reinterpret_cast<const bf16x8 *>(dy + r * H + k * 512 + lane * 8);
+            if (dres) vr[k] = *reinterpret_cast<const bf16x8 *>(dres + r * H + k * 512 + lane * 8);
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += bf2f(vg[k][j]) * wf[k][j] * bf2f(vx[k][j]) * rs;
+        dot = wave_sum(dot) / (float)H;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = bf2f(vx[k][j]) * rs;
+                const float g = bf2f(vg[k][j]);
+                float d = rs * (g * wf[k][j] - xh * dot);
+                if (dres) d += bf2f(vr[k][j]);
+                o[j] = f2bf(d);
+                acc[k][j] += g * xh;
+            }
+            *reinterpret_cast<bf16x8 *>(dx + r * H + k * 512 + lane * 8) = o;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&s_dw[k * 512 + lane * 8 + j], acc[k][j]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += blockDim.x) atomicAdd(dw + c, s_dw[c]);
+}
+
 // ---- RoPE --------------------------------------------------------------------------------------
 // x: [T, n_heads, D] (token-major, heads contiguous); cos/sin: [T, D/2] fp32.  In place.
 // forward:  (x1, x2) -> (x1*c - x2*s, x2*c + x1*s);  backward (INVERSE): (g1*c + g2*s, g2*c - g1*s)
@@ -598,6 +659,15 @@ extern "C" int ecgb_rmsnorm_bwd(const void *x_dev, const void *w_dev, const floa
                                 const void *dres_dev, void *dx_dev, float *dw_dev, size_t rows, int hidden, int gemma, void *stream)
 {
     if (hidden % 8) { ecgb::set_error("ecgb_rmsnorm_bwd: hidden must be a multiple of 8"); return ECGB_ERR_INVALID; }
+    if (hidden == 2048 || hidden == 4096) {   // rows per wave ~16: enough to amortise the end-of-kernel reduction, enough waves to fill the chip
+        const dim3 g2((unsigned)std::min<size_t>(std::max<size_t>(1, rows / 64), 1024));
+#define ECGB_RMS_BWD_ROWS(G_, NC_) hipLaunchKernelGGL((rmsnorm_bwd_rows_kernel<G_, NC_>), g2, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x_dev, \
+        (const unsigned short *)w_dev, rstd_dev, (const unsigned short *)dy_dev, (const unsigned short *)dres_dev, (unsigned short *)dx_dev, dw_dev, rows)
+        if (hidden == 2048) { if (gemma) ECGB_RMS_BWD_ROWS(true, 4); else ECGB_RMS_BWD_ROWS(false, 4); }
+        else { if (gemma) ECGB_RMS_BWD_ROWS(true, 8); else ECGB_RMS_BWD_ROWS(false, 8); }
+#undef ECGB_RMS_BWD_ROWS
+        ECGB_CHECK_LAUNCH("rmsnorm_bwd");
+    }
     const dim3 grid((unsigned)std::min<size_t>(std::max<size_t>(1, rows / 4), 1024));
     const size_t lds = (size_t)hidden * 4;
     if (gemma)

@@ -89,9 +89,10 @@ def test_transpose_and_backward_products(ops):
     _close(ops.gemm_nt(ops.transpose(dy), ops.transpose(x)), dy.float().T @ x.float(), atol=0.3)   # dW = dY^T X
 
 
+@pytest.mark.parametrize("rows,H", [(300, 2048), (4100, 4096), (77, 640)], ids=["h2048", "h4096", "generic-h"])
 @pytest.mark.parametrize("gemma", [False, True])
-def test_rmsnorm(ops, gemma):
-    rows, H, eps = 300, 2048, 1e-5
+def test_rmsnorm(ops, gemma, rows, H):
+    eps = 1e-5
     x, r, w = _bf(rows, H, seed=7), _bf(rows, H, seed=8), _bf(H, scale=0.5, seed=9)
     y, rstd, xs = ops.rmsnorm_fwd(x, w, eps, residual=r, gemma=gemma)
     xsum = (x.float() + r.float()).to(torch.bfloat16)
@@ -110,7 +111,7 @@ def test_rmsnorm(ops, gemma):
     dw = torch.zeros(H, device="cuda")
     dx = ops.rmsnorm_bwd(xsum, w, rstd, dy, dw, dres=dres, gemma=gemma)
     _close(dx, xa.grad + dres.float(), atol=2e-2)
-    assert torch.allclose(dw, wa.grad, atol=0.15, rtol=2e-2)
+    assert torch.allclose(dw, wa.grad, atol=0.15 * math.sqrt(rows / 300), rtol=2e-2)
 
 
 def test_rope_forward_inverse(ops):
