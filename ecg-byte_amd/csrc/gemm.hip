@@ -465,6 +465,34 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
     store_tile_m16<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, off_c);
 }
 
+// Epilogue of the TN kernels: bf16 store, or fp32 atomics when the contraction is split over workgroups.
+template <int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void store_tile_tn(const f32x4 (&acc)[TM][TN], const GemmArgs &G, int row0, int col0, int wr, int wc, int lm, int lq)
+{
+    const float alpha = G.alpha;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = row0 + wr * WTM + i * 16 + lm;
+        if (r >= G.N) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = col0 + wc * WTN + j * 16 + lq * 4;
+            if (c + 3 >= G.K) continue;
+            if (G.accumulate_f32) {   // split over the contraction: fp32 partial sums meet in memory
+                float *p = reinterpret_cast<float *>(G.C) + (long long)r * G.ldc + c;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) atomicAdd(p + t, acc[i][j][t] * alpha);
+            } else {
+                using us4 = __attribute__((ext_vector_type(4))) unsigned short;
+                us4 v;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = f2bf_rn(acc[i][j][t] * alpha);
+                *reinterpret_cast<us4 *>(reinterpret_cast<unsigned short *>(G.C) + (long long)r * G.ldc + c) = v;
+            }
+        }
+    }
+}
+
 // ---- TN product for weight gradients: C[N,K] = A^T . B with A = dY [M,N] and B = X [M,K] (both ROW-major, the
 // contraction index m is the slow one).  Same MFMA / LDS-image / epilogue scheme as gemm_nt_kernel_m16; only the
 // staging differs: a thread loads 4 consecutive m-rows x 8 columns (four 16-byte loads, issued one K-tile ahead
@@ -572,28 +600,141 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_m16(GemmArgs G)
         }
         if (kt + 1 < KT) write_items(lds + ((kt + 1) & 1) * kBufBytes);   // the other buffer: its last reader finished before the barrier above
     }
-    const float alpha = G.alpha;
+    store_tile_tn<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq);
+}
+
+// C[N, K] = alpha * A[M, N]^T . B[M, K] with NO register staging: both operand tiles ([64 contraction rows] x [256
+// columns], 512-byte rows) go global -> LDS by LDS-DMA exactly as they lie in memory, and the MFMA fragments (8
+// consecutive contraction elements of one column) are gathered by gfx950's transposing LDS read `ds_read_b64_tr_b16`
+// (per 16 lanes: a block of 4 rows x 16 columns delivered column-major; lane 4q+p supplies the address of row q,
+// columns 4p..4p+3) -- two reads per fragment.  16-byte chunk c of row r sits at chunk c ^ 2(r & 7) ^ (r & 8) of its row (applied
+// on the global source address, the LDS side of the DMA is lane-linear), which spreads the 8 rows a 32-lane half reads
+// over all 64 banks.  Schedule: the four phases and the stagger of gemm_nt_kernel_m16p.
+template <int BN_, int BK_, int WGM, int WGN>
+__global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
+{
+    static_assert(BN_ == 256 && BK_ == 256 && WGM == 2 && WGN == 4, "phase schedule written for the 256x256 tile, 2x4 waves");
+    constexpr int WTM = BN_ / WGM, WTN = BK_ / WGN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int kABytes = 64 * BN_ * 2, kBBytes = 64 * BK_ * 2, kBufBytes = kABytes + kBBytes;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nwg = G.tiles_m * G.tiles_n;
+    const int orig = blockIdx.x;
+    const int q_ = nwg / 8, rr = nwg % 8, xcd = orig % 8;
+    const int wgid = (xcd < rr ? xcd * (q_ + 1) : rr * (q_ + 1) + (xcd - rr) * q_) + orig / 8;
+    const int tm = wgid / G.tiles_n, tn = wgid % G.tiles_n;
+    const int row0 = tm * BN_, col0 = tn * BK_;          // output row block (columns of A), output column block (columns of B)
+    const int wr = wave / WGN, wc = wave % WGN;
+    const int lm = lane & 15, lq = lane >> 4;
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int r = row0 + wr * WTM + i * 16 + lm;
-        if (r >= G.N) continue;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int c = col0 + wc * WTN + j * 16 + lq * 4;
-            if (c + 3 >= G.K) continue;
-            if (G.accumulate_f32) {   // split over the contraction: fp32 partial sums meet in memory
-                float *p = reinterpret_cast<float *>(G.C) + (long long)r * G.ldc + c;
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int KT_all = G.M / 64;
+    const int per = (KT_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kt_begin = (int)blockIdx.y * per;
+    const int KT = min(KT_all, kt_begin + per);
+    if (kt_begin >= KT) return;
+
+    // LDS-DMA of one operand tile: 32 instructions of 1 KiB (2 rows of 512 B), 4 per wave
+    auto stage = [&](const unsigned short *g, long long ld, int c0, int ncols, int kt, unsigned char *dst) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) atomicAdd(p + t, acc[i][j][t] * alpha);
-            } else {
-                using us4 = __attribute__((ext_vector_type(4))) unsigned short;
-                us4 v;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = f2bf_rn(acc[i][j][t] * alpha);
-                *reinterpret_cast<us4 *>(reinterpret_cast<unsigned short *>(G.C) + (long long)r * G.ldc + c) = v;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int inst = wave * 4 + i;
+            const int r = inst * 2 + (lane >> 5);                           // contraction row inside the tile
+            const int chunk = (lane & 31) ^ (((r & 7) << 1) ^ (r & 8));     // the global chunk this LDS slot holds
+            const int col = min(c0 + chunk * 8, ncols - 8);                 // clamped columns are never stored
+            const unsigned short *src = g + ((long long)kt * 64 + r) * ld + col;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + inst * 1024), 16, 0, 0);
         }
+    };
+    stage(G.B, G.ldb, col0, G.K, kt_begin, lds + kABytes);
+    stage(G.A, G.lda, row0, G.N, kt_begin, lds);
+    if (kt_begin + 1 < KT) {
+        stage(G.B, G.ldb, col0, G.K, kt_begin + 1, lds + kBufBytes + kABytes);
+        stage(G.A, G.lda, row0, G.N, kt_begin + 1, lds + kBufBytes);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    using s4 = __attribute__((ext_vector_type(4))) short;
+    const int tq = lm >> 2, tp = lm & 3;                                    // this lane's row / column group inside a 4 x 16 block
+    bf16x8 a[2][4], b[2][4];
+    for (int it = 0, kt = kt_begin; kt < KT; ++kt, ++it) {
+        const unsigned char *At = lds + (it & 1) * kBufBytes, *Bt = At + kABytes;
+        unsigned char *nxt = lds + (it & 1) * kBufBytes;
+        const bool more = kt + 2 < KT;
+        // lane constants of the fragment addresses, made opaque once per K-tile: hoisted out of the loop the 24 addresses
+        // per buffer cost more registers than the kernel has (it spilled, and a spill reload next to LDS-DMA makes hipcc
+        // wait vmcnt(0): the pipeline drained several times per tile)
+        int rbase = 8 * lq + tq, cbase = tp >> 1, hbase = (tp & 1) * 8;
+        asm volatile("" : "+v"(rbase), "+v"(cbase), "+v"(hbase));
+        // fragment of the 16 columns starting at c0 (multiple of 16), contraction rows ks*32 + 8*lq .. +7
+        auto frag = [&](const unsigned char *T, int c0, int ks) {
+            const int chunk = (c0 >> 3) + cbase;
+            const int r0 = ks * 32 + rbase, r1 = r0 + 4;
+            // inline asm: next to LDS-DMA hipcc puts a vmcnt(0) in front of a transposing read it can see (it would drain the
+            // two tiles in flight once per K-tile); ordering is by the explicit counted waits and barriers of the schedule
+            s4 lo, hi;
+            const unsigned tbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)const_cast<unsigned char *>(T);   // LDS byte address
+            const unsigned a0 = tbase + r0 * 512 + ((chunk ^ (((r0 & 7) << 1) ^ (r0 & 8))) << 4) + hbase;
+            const unsigned a1 = tbase + r1 * 512 + ((chunk ^ (((r1 & 7) << 1) ^ (r1 & 8))) << 4) + hbase;
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+            bf16x8 f;
+            f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+            return f;
+        };
+        auto read_a = [&](int half) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[ks][i] = frag(At, wr * WTM + (half * 4 + i) * 16, ks);
+        };
+        auto read_b = [&](int half) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[ks][half * 2 + j] = frag(Bt, wc * WTN + (half * 2 + j) * 16, ks);
+        };
+        auto mfma_quadrant = [&](int ah, int bh) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ah * 4 + i][bh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ks][bh * 2 + j], a[ks][i], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        read_b(0);
+        read_a(0);
+        mfma_quadrant(0, 0);
+        read_b(1);
+        mfma_quadrant(0, 1);
+        read_a(1);
+        if (more) stage(G.B, G.ldb, col0, G.K, kt + 2, nxt + kABytes);
+        mfma_quadrant(1, 1);
+        if (more) {
+            stage(G.A, G.lda, row0, G.N, kt + 2, nxt);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        mfma_quadrant(1, 0);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    store_tile_tn<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq);
 }
 
 
@@ -713,7 +854,7 @@ extern "C" int ecgb_gemm_tn_bf16(const void *a_dev, long long lda, const void *b
     G.accumulate_f32 = splits > 1 ? 1 : 0; G.alpha = alpha;      // splits > 1: c_dev is a ZEROED fp32 [N, ldc] buffer
     G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
     constexpr int lds = 2 * (256 + 256) * 64 * 2;
-    auto kern = gemm_tn_kernel_m16<256, 256, 2, 4>;   // (the four-phase staggered schedule of the NT kernel measured 4-6 % slower here)
+    auto kern = (g_gemm_tile == 258) ? gemm_tn_kernel_m16<256, 256, 2, 4> : gemm_tn_kernel_tr<256, 256, 2, 4>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), (unsigned)splits), dim3(512), lds, (hipStream_t)stream, G);

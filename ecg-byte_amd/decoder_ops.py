@@ -115,13 +115,15 @@ def dropout(x, p, seed, out=None):
     return out
 
 
-def gemm_tn(a, b, alpha=1.0):
-    """C[N,K] = alpha * A[M,N]^T @ B[M,K]  (weight gradient dW = dY^T X) without transposed copies."""
+def gemm_tn(a, b, alpha=1.0, splits=None):
+    """C[N,K] = alpha * A[M,N]^T @ B[M,K]  (weight gradient dW = dY^T X) without transposed copies.
+    splits: workgroups sharing one output tile's contraction (None: enough to fill the chip)."""
     M, N = a.shape
     K = b.shape[1]
     assert b.shape[0] == M and a.stride(1) == 1 and b.stride(1) == 1
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
-    splits = 1 if tiles >= 192 else max(1, min(8, 256 // tiles, M // 64))
+    if splits is None:
+        splits = 1 if tiles >= 192 else max(1, min(8, 256 // tiles, M // 64))
     if splits == 1:
         out = torch.empty((N, K), dtype=torch.bfloat16, device=a.device)
         _lib.check(_L().ecgb_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), K, M, N, K, float(alpha), 1, _st()))

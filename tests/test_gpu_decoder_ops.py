@@ -64,6 +64,28 @@ def test_gemm_phased_schedule_is_bitwise_the_unphased_kernel(ops, M, N, K):
         ops.set_gemm_tile(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 256, 256), (128, 512, 768), (192, 264, 520), (8192, 2048, 8192), (4096, 16384, 2048), (32768, 512, 512)])
+def test_gemm_tn_transposing_reads_are_bitwise_the_register_staged_kernel(ops, M, N, K):
+    """dW = dY^T X by LDS-DMA + ds_read_b64_tr_b16 on the four-phase schedule (default) against the register-staged kernel
+    (tile 258): identical bits (splits = 1: one workgroup sums a tile in one order), repeated under memory traffic to
+    screen the schedule for LDS races; contraction lengths of 1, 2, 3 and many K-tiles, ragged output columns."""
+    dy, x = _bf(M, N, seed=21), _bf(M, K, seed=22)
+    noise = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
+    ref = dy.float().T @ x.float()
+    ops.set_gemm_tile(258)
+    try:
+        want = ops.gemm_tn(dy, x, splits=1)
+        ops.set_gemm_tile(0)
+        for rep in range(15):
+            noise.random_()
+            got = ops.gemm_tn(dy, x, splits=1)
+            assert torch.equal(got, want), rep
+        _close(got, ref, atol=1e-2 * math.sqrt(M) / 8)
+        _close(ops.gemm_tn(dy, x), ref, atol=1e-2 * math.sqrt(M) / 8)      # automatic split over the contraction
+    finally:
+        ops.set_gemm_tile(0)
+
+
 def _gemm_checks(ops, M, N, K):
     a, b = _bf(M, K, seed=1), _bf(N, K, seed=2)
     ref = a.float() @ b.float().T
