@@ -233,7 +233,7 @@ unsigned long long *g_prof_dev = nullptr;
 
 constexpr int INPUT_F64 = 0, INPUT_BYTES = 1;
 constexpr uint32_t kLenBias = 30;          // flow kernel: a symbol byte >= kLenBias holds kLenBias + the length of the token that starts there
-constexpr size_t kFlowSlot = 4096;         // u16 id slots per resident wave of the flow kernel (one segment, full resolution)
+constexpr size_t kFlowSlot = 4096;         // token-list entries (u32: position | id << 16) per resident wave of the flow kernel: one segment
 
 // clear bits [lo, hi) of a lane-owned run of mark words (segment-relative bit indices)
 __device__ __forceinline__ void clear_bits(uint32_t *marks, uint32_t lo, uint32_t hi)
@@ -515,14 +515,16 @@ __device__ __forceinline__ uint32_t emit_word(uint32_t bits, uint32_t w_rel, con
 //            before has joined that parse and stops, otherwise it keeps going -- past its chunk,
 //            through later chunks, to the end of the segment.  Every position is therefore parsed at
 //            most once, nothing is ever re-walked, and a lane is idle only from its join to the end
-//            of the loop.  Each token's id goes to a full-resolution scratch array in global memory
-//            (0xFFFF for a single symbol).
+//            of the loop.  The tokens of a trip (position, id; 0xFFFF for a single symbol) are appended
+//            to the wave's token list in global memory: consecutive 4-byte entries, one coalesced
+//            store per trip, a few hundred entries per segment (dense, L2-resident).
 //   resolve  the claimed positions are the real chain plus the speculative prefixes that joined it.
-//            Token lengths of all claimed positions are pulled back (id -> length table) into the
-//            symbol bytes, then lane c follows the length pointers through positions [64c, 64c+64)
-//            from a guessed entry; entries are corrected from the left neighbour's exit until
-//            nothing changes (a few LDS hops per pass, no trie walking).
-//   emit     exclusive scan of the per-lane token counts, ids written in stream order.
+//            One sweep of the list puts the token lengths (id -> length table) into the symbol
+//            bytes, then lane c follows the length pointers through positions [64c, 64c+64) from a
+//            guessed entry; entries are corrected from the left neighbour's exit until nothing
+//            changes (a few LDS hops per pass, no trie walking).
+//   emit     the real chain's bitmap and its per-word prefix counts go to LDS; a second sweep of the
+//            list writes every entry that lies on the real chain to its output slot.
 template <int INPUT, bool ALL_LDS, bool VEC>
 __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
 {
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
     uint32_t *marks = s_marks_all + wave * MARKW;
     uint32_t *dmap = s_dmap_all + wave * dmap_words;
     const uint32_t gw = blockIdx.x * n_waves + wave, total_waves = gridDim.x * n_waves;
-    uint16_t *ids_full = A.ids_half + (size_t)gw * kFlowSlot;
+    uint32_t *tok_list = reinterpret_cast<uint32_t *>(A.ids_half) + (size_t)gw * kFlowSlot;
     const uint32_t n = A.n;
     const double qa = A.qp.a, qscale = A.qp.scale;
 #ifdef ECGB_PROFILE
@@ -630,11 +632,15 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             __builtin_amdgcn_wave_barrier();
 
             // ---- parse
+            uint32_t n_list = 0;                                            // tokens in the wave's list (real chain + speculative prefixes)
             {
                 uint32_t r = (c == 0) ? carry_rel : max(my_start, carry_rel);   // chunks the carry token covers start at the carry
                 uint32_t j = r, node = 0, best_j = r, best_node = 0;
                 bool live = r < seg_len;
+                n_list = 0;
                 while (live) {
+                    uint32_t emit_word = 0;
+                    bool emitting = false;
 #ifdef ECGB_PROFILE
                     if (A.prof && c == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&A.prof[blockIdx.x * 8 + 5], 1ull);
 #endif
@@ -695,15 +701,22 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                         if (!advanced) {
                             // emit the token [r, r + len): its id (kNoToken for an unmatched or single symbol)
                             const uint32_t len = max(best_j - r, 1u);   // unmatched byte: lib.rs:186-189
-                            ids_full[r] = (len >= 2) ? (uint16_t)(btok >> 16) : (uint16_t)ecgb::kNoToken;
+                            emit_word = r | (((len >= 2) ? (btok >> 16) : ecgb::kNoToken) << 16);
+                            emitting = true;
                             r += len; j = r; node = 0; best_j = r; best_node = 0;
                             live = r < seg_len;
                         }
                     }
+                    // the tokens of this trip are appended to the wave's list: consecutive 4-byte entries, one coalesced store
+                    const unsigned long long em = __ballot(emitting);
+                    if (emitting) tok_list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u))] = emit_word;
+                    n_list += (uint32_t)__popcll(em);
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the ids other lanes stored are read below (same CU, same L1)
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) n_list = max(n_list, (uint32_t)__shfl_xor(n_list, d, 64));   // lanes that left early counted less
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // list entries other lanes stored are read below (same CU, same L1)
             __builtin_amdgcn_wave_barrier();
             PROF_STAMP(1);
 
@@ -712,20 +725,9 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             const uint32_t s_blk = min(pbase, seg_len), e_blk = min(pbase + 64u, seg_len);
             const uint32_t w0 = (2 * c < MARKW) ? marks[2 * c] : 0u, w1 = (2 * c + 1 < MARKW) ? marks[2 * c + 1] : 0u;
             const unsigned long long claimed_bits = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
-            for (unsigned long long rem = claimed_bits; rem;) {   // token lengths into the symbol bytes, eight loads in flight
-                uint32_t p[8], idv[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    p[t] = 0xFFFFFFFFu;
-                    if (rem) {
-                        p[t] = pbase + (uint32_t)__ffsll((long long)rem) - 1u;
-                        rem &= rem - 1;
-                        idv[t] = ids_full[p[t]];
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    if (p[t] != 0xFFFFFFFFu && idv[t] != ecgb::kNoToken) sym[p[t]] = (uint8_t)(kLenBias + s_len[idv[t]]);
+            for (uint32_t i = c; i < n_list; i += 64) {   // token lengths into the symbol bytes: coalesced reads of the list
+                const uint32_t e = tok_list[i], id = e >> 16;
+                if (id != ecgb::kNoToken) sym[e & 0xFFFFu] = (uint8_t)(kLenBias + s_len[id]);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -758,7 +760,8 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             const uint32_t carry_out_rel = __shfl(my_exit, 63, 64);
             PROF_STAMP(2);
 
-            // ---- emit: lane c owns the tokens that start in its block
+            // ---- emit: the real chain's bitmap replaces the claim bitmap, its per-word prefix counts go where the change map
+            // was; then the list is swept once more and every entry on the real chain lands in its output slot
             const uint32_t cnt = (uint32_t)__popcll(chain);
             uint32_t incl = cnt;
 #pragma unroll
@@ -767,30 +770,23 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                 if (c >= (uint32_t)d) incl += t;
             }
             const uint32_t total = __shfl(incl, 63, 64);
-            uint32_t off = out_off + incl - cnt;
-            for (unsigned long long rem = chain; rem;) {
-                uint32_t p[4], idv[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    p[t] = 0xFFFFFFFFu;
-                    if (rem) {
-                        p[t] = pbase + (uint32_t)__ffsll((long long)rem) - 1u;
-                        rem &= rem - 1;
-                        idv[t] = ids_full[p[t]];
-                    }
+            const uint32_t off = out_off + incl - cnt;
+            if (2 * c < MARKW) { marks[2 * c] = (uint32_t)chain; dmap[2 * c] = off; }
+            if (2 * c + 1 < MARKW) { marks[2 * c + 1] = (uint32_t)(chain >> 32); dmap[2 * c + 1] = off + (uint32_t)__popc((uint32_t)chain); }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = c; i < n_list; i += 64) {
+                const uint32_t e = tok_list[i], pos = e & 0xFFFFu;
+                const uint32_t tb = marks[pos >> 5], bit = 1u << (pos & 31);
+                if (!(tb & bit)) continue;                                   // a speculative prefix, not on the real chain
+                const uint32_t slot = dmap[pos >> 5] + (uint32_t)__popc(tb & (bit - 1u));
+                uint32_t id = e >> 16;
+                if (id == ecgb::kNoToken) {                                  // single symbol: its byte still holds the class
+                    const uint32_t cls = sym[pos];
+                    if (INPUT == INPUT_BYTES && cls == ecgb::kOtherClass) id = A.raw[row + seg_base + pos];
+                    else id = s_single[cls];
                 }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (p[t] == 0xFFFFFFFFu) continue;
-                    uint32_t id = idv[t];
-                    if (id == ecgb::kNoToken) {                       // single symbol: its byte still holds the class
-                        const uint32_t cls = sym[p[t]];
-                        if (INPUT == INPUT_BYTES && cls == ecgb::kOtherClass) id = A.raw[row + seg_base + p[t]];
-                        else id = s_single[cls];
-                    }
-                    if (off < A.ids_stride) out[off] = id;
-                    ++off;
-                }
+                if (slot < A.ids_stride) out[slot] = id;
             }
             out_off += total;
             carry = seg_base + carry_out_rel;
@@ -1137,10 +1133,10 @@ extern "C" int ecgb_quantize_hip(const double *signal_dev, size_t n, double perc
 
 extern "C" size_t ecgb_encode_scratch_bytes(const ecgb_tokenizer *tok, size_t batch, size_t n_per_stream)
 {
-    // one id array of one segment per resident stream slot (reused, L2-resident): flow kernel: CUs x 16 waves x
-    // 4096 entries (full resolution); workgroup kernel: 2 x CUs x 16384 entries (half resolution)
+    // per resident stream slot (reused, L2-resident): flow kernel: CUs x 16 waves x a token list of up to 4096 4-byte
+    // entries (the first few hundred are used); workgroup kernel: 2 x CUs x 16384 half-resolution u16 ids
     const size_t cus = (tok && tok->n_cus > 0) ? (size_t)tok->n_cus : 256;
-    const size_t a = cus * kMaxWaves * kFlowSlot, b = 2 * cus * (size_t)kHalfPerSlot;
+    const size_t a = cus * kMaxWaves * kFlowSlot * 2, b = 2 * cus * (size_t)kHalfPerSlot;   // in u16 units
     return align_up(std::max(a, b) * sizeof(uint16_t)) + kAlign;
 }
 
