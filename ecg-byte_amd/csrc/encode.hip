@@ -233,7 +233,7 @@ unsigned long long *g_prof_dev = nullptr;
 
 constexpr int INPUT_F64 = 0, INPUT_BYTES = 1;
 constexpr uint32_t kLenBias = 30;          // flow kernel: a symbol byte >= kLenBias holds kLenBias + the length of the token that starts there
-constexpr size_t kFlowSlot = 4096;         // token-list entries (u32: position | id << 16) per resident wave of the flow kernel: one segment
+constexpr size_t kFlowSlot = 8192;         // token-list entries (u32: position | id << 16) per resident wave of the flow kernel: one segment
 
 // clear bits [lo, hi) of a lane-owned run of mark words (segment-relative bit indices)
 __device__ __forceinline__ void clear_bits(uint32_t *marks, uint32_t lo, uint32_t hi)
@@ -531,6 +531,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t n_waves = blockDim.x >> 6;
     const uint32_t CH = A.chunk, SEG = 64u * CH, MARKW = SEG / 32;            // SEG is a multiple of 64
+    const uint32_t WPL = (SEG > 4096) ? 4u : 2u, PW = 32u * WPL;               // bitmap words / positions a lane owns outside the parse
     const uint32_t sym_cap = SEG + A.margin;                                   // multiple of 16
     uint64_t *s_trie = reinterpret_cast<uint64_t *>(smem);
     double *s_thr = reinterpret_cast<double *>(s_trie + A.n_lds_nodes);        // 28
@@ -588,11 +589,17 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             const uint32_t carry_rel = carry - seg_base;
             uint32_t my_start = c * CH;
             {
-                const uint32_t p0 = 64u * c;
-                uint32_t b0 = (p0 < seg_len) ? dmap[2 * c] : 0u, b1 = (p0 + 32 < seg_len) ? dmap[2 * c + 1] : 0u;
-                if (p0 < seg_len && seg_len - p0 < 32) b0 &= (1u << (seg_len - p0)) - 1u;
-                if (p0 + 32 < seg_len && seg_len - p0 - 32 < 32) b1 &= (1u << (seg_len - p0 - 32)) - 1u;
-                const uint32_t n_l = (uint32_t)(__popc(b0) + __popc(b1));
+                const uint32_t p0 = PW * c;                                     // this lane's positions [p0, p0 + PW)
+                uint32_t bw[4], nw[4], n_l = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t q0 = p0 + 32 * k;
+                    uint32_t v = (k < WPL && q0 < seg_len) ? dmap[WPL * c + k] : 0u;
+                    if (k < WPL && q0 < seg_len && seg_len - q0 < 32) v &= (1u << (seg_len - q0)) - 1u;
+                    bw[k] = v;
+                    nw[k] = (uint32_t)__popc(v);
+                    n_l += nw[k];
+                }
                 uint32_t incl = n_l;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) {
@@ -607,12 +614,13 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                     const float inv = 64.0f / (float)R;
                     uint32_t k = max((uint32_t)ceilf((float)P * inv), 1u);
                     const uint32_t k_hi = min((uint32_t)ceilf((float)(P + n_l) * inv), 64u);
-                    const uint32_t n_lo = (uint32_t)__popc(b0);
                     for (; k < k_hi; ++k) {
                         const uint32_t t = (k * R) >> 6;
                         if (t < P || t >= P + n_l) continue;
-                        uint32_t want = t - P, w = b0, pos = 0;                 // the want-th (0-based) set bit of b1:b0
-                        if (want >= n_lo) { want -= n_lo; w = b1; pos = 32; }
+                        uint32_t want = t - P, w = bw[0], pos = 0;              // the want-th (0-based) set bit of the lane's words
+#pragma unroll
+                        for (uint32_t q = 0; q < 3; ++q)
+                            if (pos == 32 * q && want >= nw[q]) { want -= nw[q]; w = bw[q + 1]; pos = 32 * (q + 1); }
 #pragma unroll
                         for (int sh = 16; sh >= 1; sh >>= 1) {
                             const uint32_t below = (uint32_t)__popc(w & ((1u << sh) - 1u));
@@ -720,11 +728,15 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             __builtin_amdgcn_wave_barrier();
             PROF_STAMP(1);
 
-            // ---- resolve: lane c owns positions [64c, 64c + 64)
-            const uint32_t pbase = 64u * c;
-            const uint32_t s_blk = min(pbase, seg_len), e_blk = min(pbase + 64u, seg_len);
-            const uint32_t w0 = (2 * c < MARKW) ? marks[2 * c] : 0u, w1 = (2 * c + 1 < MARKW) ? marks[2 * c + 1] : 0u;
-            const unsigned long long claimed_bits = (unsigned long long)w0 | ((unsigned long long)w1 << 32);
+            // ---- resolve: lane c owns positions [PW*c, PW*c + PW)  (PW = 64, or 128 for segments longer than 4096)
+            const uint32_t pbase = PW * c;
+            const uint32_t s_blk = min(pbase, seg_len), e_blk = min(pbase + PW, seg_len);
+            uint32_t first_claimed = e_blk;
+#pragma unroll
+            for (uint32_t k = 4; k-- > 0;) {
+                const uint32_t v = (k < WPL && WPL * c + k < MARKW) ? marks[WPL * c + k] : 0u;
+                if (v) first_claimed = pbase + 32 * k + (uint32_t)__ffs(v) - 1u;
+            }
             for (uint32_t i = c; i < n_list; i += 64) {   // token lengths into the symbol bytes: coalesced reads of the list
                 const uint32_t e = tok_list[i], id = e >> 16;
                 if (id != ecgb::kNoToken) sym[e & 0xFFFFu] = (uint8_t)(kLenBias + s_len[id]);
@@ -732,19 +744,20 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 
-            auto follow = [&](uint32_t p, unsigned long long &on_chain) {   // length pointers through this lane's block
-                on_chain = 0;
+            auto follow = [&](uint32_t p, unsigned long long &lo, unsigned long long &hi) {   // length pointers through this lane's block
+                lo = 0; hi = 0;
                 while (p < e_blk) {
-                    on_chain |= 1ull << (p - pbase);
+                    const uint32_t rel = p - pbase;
+                    if (rel < 64) lo |= 1ull << rel; else hi |= 1ull << (rel - 64);
                     const uint32_t bb = sym[p];
                     p += (bb < kLenBias) ? 1u : bb - kLenBias;
                 }
                 return p;
             };
-            unsigned long long chain = 0;
-            uint32_t entry = (c == 0) ? carry_rel : (claimed_bits ? pbase + (uint32_t)__ffsll((long long)claimed_bits) - 1u : e_blk);
+            unsigned long long chain = 0, chain_hi = 0;
+            uint32_t entry = (c == 0) ? carry_rel : first_claimed;
             entry = max(entry, s_blk);
-            uint32_t my_exit = follow(entry, chain);
+            uint32_t my_exit = follow(entry, chain, chain_hi);
             for (;;) {
                 const uint32_t prev = __shfl_up(my_exit, 1, 64);
                 const uint32_t want = (c == 0) ? carry_rel : prev;
@@ -753,7 +766,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                 PROF_COUNT(4, 1);
                 if (changed) {
                     entry = want;
-                    my_exit = follow(entry, chain);
+                    my_exit = follow(entry, chain, chain_hi);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -762,7 +775,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
 
             // ---- emit: the real chain's bitmap replaces the claim bitmap, its per-word prefix counts go where the change map
             // was; then the list is swept once more and every entry on the real chain lands in its output slot
-            const uint32_t cnt = (uint32_t)__popcll(chain);
+            const uint32_t cnt = (uint32_t)(__popcll(chain) + __popcll(chain_hi));
             uint32_t incl = cnt;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -771,8 +784,15 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             }
             const uint32_t total = __shfl(incl, 63, 64);
             const uint32_t off = out_off + incl - cnt;
-            if (2 * c < MARKW) { marks[2 * c] = (uint32_t)chain; dmap[2 * c] = off; }
-            if (2 * c + 1 < MARKW) { marks[2 * c + 1] = (uint32_t)(chain >> 32); dmap[2 * c + 1] = off + (uint32_t)__popc((uint32_t)chain); }
+            {
+                const uint32_t cw[4] = {(uint32_t)chain, (uint32_t)(chain >> 32), (uint32_t)chain_hi, (uint32_t)(chain_hi >> 32)};
+                uint32_t run = off;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (k < WPL && WPL * c + k < MARKW) { marks[WPL * c + k] = cw[k]; dmap[WPL * c + k] = run; }
+                    run += (uint32_t)__popc(cw[k]);
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             for (uint32_t i = c; i < n_list; i += 64) {
@@ -922,9 +942,10 @@ inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 constexpr size_t kLdsCap = 160 * 1024;
 constexpr size_t kLdsTablesFixed = 28 * 8 + 64 + 256;
 constexpr size_t kMaxWaves = 16;
-constexpr uint32_t kFlowChunks[] = {62, 60, 58, 54, 52, 50, 46, 44, 42, 38, 36, 34};   // not multiples of 8: lanes at equal
+constexpr uint32_t kFlowChunks[] = {126, 124, 122, 118, 116, 114, 110, 108, 106, 102, 100, 98, 94, 92, 90, 86, 84, 82, 78, 76, 74, 70, 68, 66,
+                                    62, 60, 58, 54, 52, 50, 46, 44, 42, 38, 36, 34};   // not multiples of 8: lanes at equal
                                                                                        // chunk offsets land in different LDS banks
-int g_plan_mode = 0;   // 0 auto, 1 workgroup-per-stream, 2 wave-per-stream (tests / tuning)
+int g_plan_mode = 0;   // 0 auto, 1 workgroup-per-stream, 2 wave-per-stream, 3 wave-per-stream with 8 waves per CU and segments up to 8064 symbols (tests / tuning)
 
 struct Plan {
     uint32_t chunk;    // chunk length of the flow kernel
@@ -959,11 +980,21 @@ Plan make_plan(const ecgb_tokenizer *tok, size_t batch)
         size_t waves = 8;
         p.chunk = 34;
         bool found = false;
+        // 16 waves per CU with 3 456-symbol segments finish a round of records in ~1.0 time units, 8 waves per CU with
+        // segments twice as long in ~0.6 (measured on C2: fewer loop trips per record, but half the waves to hide
+        // latency): take whichever needs less time for this batch's rounds -- e.g. 8 waves when the batch holds at most
+        // 8 records per CU, 16 waves when it holds 9..16.
+        const size_t per_cu = (batch + cus - 1) / cus;
+        const double t16 = (double)((per_cu + 15) / 16) * 1.0, t8 = (double)((per_cu + 7) / 8) * 0.6;
+        const bool prefer8 = (g_plan_mode == 3) || (g_plan_mode == 0 && t8 < t16);
         for (size_t w : {(size_t)16, (size_t)12, (size_t)8}) {
+            if (prefer8 && w != 8) continue;
             if (tables + trie_bytes >= kLdsCap) break;
             const size_t per_wave_max = (kLdsCap - tables - trie_bytes) / w;
-            for (uint32_t ch : kFlowChunks)
+            for (uint32_t ch : kFlowChunks) {
+                if (ch > 62 && w != 8) continue;      // long segments only pay with few waves (and need a batch that fills two rounds)
                 if (flow_per_wave(ch, p.margin) <= per_wave_max) { waves = w; p.chunk = ch; found = true; break; }
+            }
             if (found) break;
         }
         const size_t per_wave = flow_per_wave(p.chunk, p.margin);
@@ -1096,7 +1127,7 @@ extern "C" void ecgb_debug_set_profile_buffer(unsigned long long *dev) { g_prof_
 
 extern "C" int ecgb_set_encode_plan(int mode)
 {
-    if (mode < 0 || mode > 2) { ecgb::set_error("ecgb_set_encode_plan: mode must be 0..2"); return ECGB_ERR_INVALID; }
+    if (mode < 0 || mode > 3) { ecgb::set_error("ecgb_set_encode_plan: mode must be 0..3"); return ECGB_ERR_INVALID; }
     g_plan_mode = mode;
     return ECGB_OK;
 }

@@ -24,7 +24,7 @@ def dev():
     return torch.device("cuda", 0)
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["plan-auto", "plan-workgroup", "plan-wave"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["plan-auto", "plan-workgroup", "plan-wave", "plan-wave-long-segments"])
 def plan(request, dev):
     """Runs a test under each encode kernel: automatic choice, workgroup-per-stream, wave-per-stream."""
     from ecg_byte_amd.tokenizer import set_encode_plan
