@@ -525,13 +525,13 @@ __device__ __forceinline__ uint32_t emit_word(uint32_t bits, uint32_t w_rel, con
 //            changes (a few LDS hops per pass, no trie walking).
 //   emit     the real chain's bitmap and its per-word prefix counts go to LDS; a second sweep of the
 //            list writes every entry that lies on the real chain to its output slot.
-template <int INPUT, bool ALL_LDS, bool VEC>
+template <int INPUT, bool ALL_LDS, bool VEC, bool WIDE>
 __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t n_waves = blockDim.x >> 6;
     const uint32_t CH = A.chunk, SEG = 64u * CH, MARKW = SEG / 32;            // SEG is a multiple of 64
-    const uint32_t WPL = (SEG > 4096) ? 4u : 2u, PW = 32u * WPL;               // bitmap words / positions a lane owns outside the parse
+    constexpr uint32_t WPL = WIDE ? 4u : 2u, PW = 32u * WPL;                  // bitmap words / positions a lane owns outside the parse (WIDE: segments > 4096)
     const uint32_t sym_cap = SEG + A.margin;                                   // multiple of 16
     uint64_t *s_trie = reinterpret_cast<uint64_t *>(smem);
     double *s_thr = reinterpret_cast<double *>(s_trie + A.n_lds_nodes);        // 28
@@ -590,12 +590,12 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             uint32_t my_start = c * CH;
             {
                 const uint32_t p0 = PW * c;                                     // this lane's positions [p0, p0 + PW)
-                uint32_t bw[4], nw[4], n_l = 0;
+                uint32_t bw[WPL], nw[WPL], n_l = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
+                for (uint32_t k = 0; k < WPL; ++k) {
                     const uint32_t q0 = p0 + 32 * k;
-                    uint32_t v = (k < WPL && q0 < seg_len) ? dmap[WPL * c + k] : 0u;
-                    if (k < WPL && q0 < seg_len && seg_len - q0 < 32) v &= (1u << (seg_len - q0)) - 1u;
+                    uint32_t v = (q0 < seg_len) ? dmap[WPL * c + k] : 0u;
+                    if (q0 < seg_len && seg_len - q0 < 32) v &= (1u << (seg_len - q0)) - 1u;
                     bw[k] = v;
                     nw[k] = (uint32_t)__popc(v);
                     n_l += nw[k];
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                         if (t < P || t >= P + n_l) continue;
                         uint32_t want = t - P, w = bw[0], pos = 0;              // the want-th (0-based) set bit of the lane's words
 #pragma unroll
-                        for (uint32_t q = 0; q < 3; ++q)
+                        for (uint32_t q = 0; q + 1 < WPL; ++q)
                             if (pos == 32 * q && want >= nw[q]) { want -= nw[q]; w = bw[q + 1]; pos = 32 * (q + 1); }
 #pragma unroll
                         for (int sh = 16; sh >= 1; sh >>= 1) {
@@ -733,8 +733,8 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             const uint32_t s_blk = min(pbase, seg_len), e_blk = min(pbase + PW, seg_len);
             uint32_t first_claimed = e_blk;
 #pragma unroll
-            for (uint32_t k = 4; k-- > 0;) {
-                const uint32_t v = (k < WPL && WPL * c + k < MARKW) ? marks[WPL * c + k] : 0u;
+            for (uint32_t k = WPL; k-- > 0;) {
+                const uint32_t v = (WPL * c + k < MARKW) ? marks[WPL * c + k] : 0u;
                 if (v) first_claimed = pbase + 32 * k + (uint32_t)__ffs(v) - 1u;
             }
             for (uint32_t i = c; i < n_list; i += 64) {   // token lengths into the symbol bytes: coalesced reads of the list
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                 lo = 0; hi = 0;
                 while (p < e_blk) {
                     const uint32_t rel = p - pbase;
-                    if (rel < 64) lo |= 1ull << rel; else hi |= 1ull << (rel - 64);
+                    if (!WIDE || rel < 64) lo |= 1ull << rel; else hi |= 1ull << (rel - 64);
                     const uint32_t bb = sym[p];
                     p += (bb < kLenBias) ? 1u : bb - kLenBias;
                 }
@@ -788,8 +788,8 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                 const uint32_t cw[4] = {(uint32_t)chain, (uint32_t)(chain >> 32), (uint32_t)chain_hi, (uint32_t)(chain_hi >> 32)};
                 uint32_t run = off;
 #pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    if (k < WPL && WPL * c + k < MARKW) { marks[WPL * c + k] = cw[k]; dmap[WPL * c + k] = run; }
+                for (uint32_t k = 0; k < WPL; ++k) {
+                    if (WPL * c + k < MARKW) { marks[WPL * c + k] = cw[k]; dmap[WPL * c + k] = run; }
                     run += (uint32_t)__popc(cw[k]);
                 }
             }
@@ -1052,9 +1052,12 @@ int launch_encode(const ecgb_tokenizer *tok, const double *signal, const uint8_t
     const bool all_lds = (pl.n_lds == A.n_nodes);
     const bool vec = (INPUT == INPUT_F64) && (n % 2 == 0) && ((reinterpret_cast<uintptr_t>(signal) & 15u) == 0);
     void (*kern)(EncodeArgs) = nullptr;
-    if (pl.wave)
-        kern = all_lds ? (vec ? encode_flow_kernel<INPUT, true, true> : encode_flow_kernel<INPUT, true, false>)
-                       : (vec ? encode_flow_kernel<INPUT, false, true> : encode_flow_kernel<INPUT, false, false>);
+    if (pl.wave && pl.chunk > 64)
+        kern = all_lds ? (vec ? encode_flow_kernel<INPUT, true, true, true> : encode_flow_kernel<INPUT, true, false, true>)
+                       : (vec ? encode_flow_kernel<INPUT, false, true, true> : encode_flow_kernel<INPUT, false, false, true>);
+    else if (pl.wave)
+        kern = all_lds ? (vec ? encode_flow_kernel<INPUT, true, true, false> : encode_flow_kernel<INPUT, true, false, false>)
+                       : (vec ? encode_flow_kernel<INPUT, false, true, false> : encode_flow_kernel<INPUT, false, false, false>);
     else
         kern = all_lds ? (vec ? encode_wg_kernel<INPUT, true, true> : encode_wg_kernel<INPUT, true, false>)
                        : (vec ? encode_wg_kernel<INPUT, false, true> : encode_wg_kernel<INPUT, false, false>);
