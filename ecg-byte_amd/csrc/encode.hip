@@ -939,7 +939,8 @@ int check_hip(hipError_t e, const char *what)
 
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
-constexpr size_t kLdsCap = 160 * 1024;
+constexpr size_t kLdsCap = 160 * 1024;        // static + dynamic LDS of a workgroup
+constexpr size_t kLdsStaticWg = 256;          // what hipcc allocates statically in encode_wg_kernel (__syncthreads_or)
 constexpr size_t kLdsTablesFixed = 28 * 8 + 64 + 256;
 constexpr size_t kMaxWaves = 16;
 constexpr uint32_t kFlowChunks[] = {126, 124, 122, 118, 116, 114, 110, 108, 106, 102, 100, 98, 94, 92, 90, 86, 84, 82, 78, 76, 74, 70, 68, 66,
@@ -1008,7 +1009,7 @@ Plan make_plan(const ecgb_tokenizer *tok, size_t batch)
         p.margin = (tok->max_depth + 1 + 255u) & ~255u;   // keeps the symbol buffer a whole number of swizzle blocks
         const size_t tables = kLdsTablesFixed + tok->runbits.size() * 4;
         const size_t fixed = tables + kSeg + p.margin + kMarkWords * 4 + kLanes * 4 + 16 + ((kSeg + p.margin) / 32 + 2) * 4;
-        p.n_lds = (fixed >= kLdsCap) ? 0u : (uint32_t)std::min<size_t>(n_nodes, (kLdsCap - fixed) / 8);
+        p.n_lds = (fixed >= kLdsCap - kLdsStaticWg) ? 0u : (uint32_t)std::min<size_t>(n_nodes, (kLdsCap - kLdsStaticWg - fixed) / 8);
         p.block = kLanes;
         p.grid = (unsigned)std::max<size_t>(1, std::min(batch, 2 * cus));
         p.lds = fixed + (size_t)p.n_lds * 8;
@@ -1063,7 +1064,7 @@ int launch_encode(const ecgb_tokenizer *tok, const double *signal, const uint8_t
                        : (vec ? encode_wg_kernel<INPUT, false, true> : encode_wg_kernel<INPUT, false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-    if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(encode kernel)");
+    if (e != hipSuccess) return check_hip(e, ("hipFuncSetAttribute(encode kernel, " + std::to_string(pl.lds) + " bytes of LDS)").c_str());
     hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(pl.block), pl.lds, stream, A);
     return check_hip(hipGetLastError(), "encode kernel launch");
 }

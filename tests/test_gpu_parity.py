@@ -327,3 +327,57 @@ def test_train_tokenizer_cli_end_to_end(dev, tmp_path):
     corpus = tu.process_large_file(str(tmp_path / "sampled.txt"), pc, 2)
     assert corpus == "".join(O.symbols_to_text(O.quantize(x[i], pc["percentile_1"], pc["percentile_99"])).decode() for i in range(12))
     assert (vocab, merges) == O.byte_pair_encoding(corpus, 50, fast=False)[1:]
+
+
+def test_trie_larger_than_lds(dev, plan):
+    """~30 000 trie nodes (240 KB) do not fit the 160 KB of LDS next to the per-wave buffers: nodes beyond `n_lds` are read
+    through L2 by both kernels (ALL_LDS = false instantiations)."""
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    rng = np.random.default_rng(77)
+    merges = random_merges(rng, 6500, alphabet=b"abcdefghijklmnopqrstuvwxyz", max_len=12, dup_frac=0.02)
+    tk = HipTokenizer(merges)
+    assert tk.n_nodes > 24000
+    pool = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", dtype=np.uint8)
+    texts = [bytes(rng.choice(pool, size=20011)) for _ in range(3)]
+    # plant expansions so that deep (non-LDS) nodes are actually reached
+    for t in range(3):
+        buf = bytearray(texts[t])
+        for k in range(300):
+            seq = bytes(merges[int(rng.integers(len(merges)))][0])
+            at = int(rng.integers(0, len(buf) - len(seq)))
+            buf[at:at + len(seq)] = seq
+        texts[t] = bytes(buf)
+    got, counts = _encode_bytes(tk, texts)
+    for b, t in enumerate(texts):
+        ref = O.encode_text(t, merges)
+        assert counts[b] == len(ref) and np.array_equal(got[b], ref), b
+
+
+def test_run_chains_with_branches_and_sparse_tokens(dev, plan):
+    """The run step: same-class chains up to 200 deep where only some depths carry a token (a^k for k in a sparse set),
+    branches hanging off the middle of a chain (a^k b, a^k c c), two interleaved run alphabets, runs longer than the
+    chain, runs that end exactly on / one short of / one past a token, and the 32-symbol cap of one step."""
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    rng = np.random.default_rng(5)
+    merges, tid = [], 256
+    for k in (2, 3, 4, 7, 8, 16, 31, 32, 33, 64, 100, 129, 200):
+        merges.append(([97] * k, tid)); tid += 1
+        if k in (3, 8, 33, 100):
+            merges.append(([97] * k + [98], tid)); tid += 1
+            merges.append(([97] * k + [99, 99], tid)); tid += 1
+    for k in (2, 5, 6, 40, 41, 150):
+        merges.append(([98] * k, tid)); tid += 1
+    merges.append(([98, 97], tid)); tid += 1
+    merges.append(([99, 98, 98, 98, 97], tid)); tid += 1
+    tk = HipTokenizer(merges)
+    texts = []
+    for _ in range(6):
+        parts = []
+        while sum(len(p) for p in parts) < 30000:
+            ch = bytes([int(rng.choice([97, 97, 97, 98, 98, 99]))])
+            parts.append(ch * int(rng.choice([1, 1, 2, 3, 7, 8, 9, 31, 32, 33, 34, 63, 64, 65, 99, 100, 101, 128, 199, 200, 201, 450])))
+        texts.append(b"".join(parts)[:30000])
+    got, counts = _encode_bytes(tk, texts)
+    for b, t in enumerate(texts):
+        ref = O.encode_text(t, merges)
+        assert counts[b] == len(ref) and np.array_equal(got[b], ref), b
