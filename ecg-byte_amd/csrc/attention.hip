@@ -490,20 +490,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs A)   // t
 }
 
 // =====================================================================================================
-// decode step: one query per (batch, head) against the KV cache.  grid (Hq, B), one wave per workgroup.
+// decode step: one query per (batch, head) against the KV cache.  grid (Hq, B), one wave per workgroup; head_dim 64 / 128 / 256.
 // q [B, Hq*D]; k/v cache rows [B, cap] with row stride ld (elements), kv head g at + g*D; len = keys in the cache
 // (incl. the new one); key j visible iff mask[b, j] != 0.  HBM-bound (reads the cache once).
+template <int D>
 __global__ __launch_bounds__(64) void attn_decode_kernel(const unsigned short *q, const unsigned short *kc, const unsigned short *vc,
                                                          long long ld, long long cap, const float *mask, long long mask_ld,
                                                          unsigned short *o, int len, int Hq, int Hkv, float scale)
 {
-    extern __shared__ float s_p[];                      // len scores / probabilities
-    constexpr int D = 64;
+    extern __shared__ float s_p[];                      // [len] scores / probabilities, then [D] the query in fp32
+    float *s_q = s_p + ((len + 3) & ~3);
     const int hq = blockIdx.x, b = blockIdx.y, g = hq / (Hq / Hkv), lane = threadIdx.x;
     const unsigned short *qp = q + ((long long)b * Hq + hq) * D;
-    float qf[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) qf[d] = bf2f(qp[d]);
+    for (int d = lane; d < D; d += 64) s_q[d] = bf2f(qp[d]);
+    __syncthreads();
     const unsigned short *K = kc + (long long)b * cap * ld + (long long)g * D;
     const unsigned short *V = vc + (long long)b * cap * ld + (long long)g * D;
     float m = -INFINITY;
@@ -512,11 +512,11 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const unsigned short *q
         if (mask[(long long)b * mask_ld + j] != 0.f) {
             const bf16x8 *kr = reinterpret_cast<const bf16x8 *>(K + (long long)j * ld);
             float acc = 0.f;
-#pragma unroll
+#pragma unroll 4
             for (int c = 0; c < D / 8; ++c) {
                 const bf16x8 kv = kr[c];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) acc += qf[c * 8 + t] * bf2f((unsigned short)kv[t]);
+                for (int t = 0; t < 8; ++t) acc += s_q[c * 8 + t] * bf2f((unsigned short)kv[t]);
             }
             sdot = acc * scale;
         }
@@ -535,12 +535,16 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const unsigned short *q
     for (int d = 32; d > 0; d >>= 1) l += __shfl_xor(l, d, 64);
     __syncthreads();
     const float inv = l > 0.f ? 1.f / l : 0.f;
-    float acc = 0.f;                                   // lane = output dimension d
+    float acc[D / 64];                                  // lane owns output dimensions lane, lane + 64, ...
+#pragma unroll
+    for (int t = 0; t < D / 64; ++t) acc[t] = 0.f;
     for (int j = 0; j < len; ++j) {
         const float pj = bf2f((unsigned short)(pack_bf16(s_p[j] * inv, 0.f) & 0xFFFFu));   // P is cast to bf16 before P.V, as SDPA does
-        acc += pj * bf2f(V[(long long)j * ld + lane]);
+#pragma unroll
+        for (int t = 0; t < D / 64; ++t) acc[t] += pj * bf2f(V[(long long)j * ld + lane + 64 * t]);
     }
-    o[((long long)b * Hq + hq) * D + lane] = (unsigned short)(pack_bf16(acc, 0.f) & 0xFFFFu);
+#pragma unroll
+    for (int t = 0; t < D / 64; ++t) o[((long long)b * Hq + hq) * D + lane + 64 * t] = (unsigned short)(pack_bf16(acc[t], 0.f) & 0xFFFFu);
 }
 
 int check_args(const AttnArgs &A, int D, const char *who)
@@ -612,11 +616,14 @@ extern "C" int ecgb_attn_decode(const void *q_dev, const void *k_cache_dev, cons
                                 const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, int n_q_heads,
                                 int n_kv_heads, int head_dim, float scale, void *stream)
 {
-    if (head_dim != 64) { ecgb::set_error("ecgb_attn_decode: head_dim must be 64 in this build"); return ECGB_ERR_UNSUPPORTED; }
+    if (head_dim != 64 && head_dim != 128 && head_dim != 256) { ecgb::set_error("ecgb_attn_decode: head_dim must be 64, 128 or 256"); return ECGB_ERR_UNSUPPORTED; }
     if (batch <= 0 || kv_len <= 0 || kv_len > capacity || n_q_heads % n_kv_heads || ld % 8) { ecgb::set_error("ecgb_attn_decode: bad shape"); return ECGB_ERR_INVALID; }
-    if ((size_t)kv_len * 4 > 64 * 1024) { ecgb::set_error("ecgb_attn_decode: cache longer than 16384 keys"); return ECGB_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(attn_decode_kernel, dim3((unsigned)n_q_heads, (unsigned)batch), dim3(64), (size_t)kv_len * 4, (hipStream_t)stream,
-                       (const unsigned short *)q_dev, (const unsigned short *)k_cache_dev, (const unsigned short *)v_cache_dev, ld, capacity,
-                       attn_mask_dev, mask_ld, (unsigned short *)o_dev, kv_len, n_q_heads, n_kv_heads, scale);
+    const size_t lds = ((size_t)((kv_len + 3) & ~3) + (size_t)head_dim) * 4;
+    if (lds > 64 * 1024) { ecgb::set_error("ecgb_attn_decode: cache longer than ~16000 keys"); return ECGB_ERR_UNSUPPORTED; }
+#define ECGB_DECODE(D_) hipLaunchKernelGGL(attn_decode_kernel<D_>, dim3((unsigned)n_q_heads, (unsigned)batch), dim3(64), lds, (hipStream_t)stream, \
+        (const unsigned short *)q_dev, (const unsigned short *)k_cache_dev, (const unsigned short *)v_cache_dev, ld, capacity, attn_mask_dev, mask_ld, \
+        (unsigned short *)o_dev, kv_len, n_q_heads, n_kv_heads, scale)
+    if (head_dim == 64) ECGB_DECODE(64); else if (head_dim == 128) ECGB_DECODE(128); else ECGB_DECODE(256);
+#undef ECGB_DECODE
     return launched("attn_decode_kernel");
 }

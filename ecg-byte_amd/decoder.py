@@ -47,10 +47,20 @@ class DecoderConfig:
     tie_word_embeddings: bool = True
     pad_token_id: int | None = None
     initializer_range: float = 0.02
+    model_type: str = "llama"      # "gemma": RMSNorm with (1 + w) in fp32 (modeling_gemma.py:60-65), gelu-tanh gate (140-149),
+                                   # embeddings scaled by sqrt(hidden) in the activation dtype (800-801), head_dim from the config
 
     def __post_init__(self):
         if self.head_dim is None:
             self.head_dim = self.hidden_size // self.num_attention_heads
+
+    @staticmethod
+    def gemma_2b(**kw):
+        """Published Gemma-2B dimensions (config C5): 18 layers, hidden 2048, 8 query heads / 1 KV head of 256, MLP 16384."""
+        base = dict(vocab_size=256000, hidden_size=2048, intermediate_size=16384, num_hidden_layers=18, num_attention_heads=8,
+                    num_key_value_heads=1, head_dim=256, rms_norm_eps=1e-6, rope_theta=10000.0, rope_scaling=None, model_type="gemma")
+        base.update(kw)
+        return DecoderConfig(**base)
 
     @staticmethod
     def llama_3_2_1b(**kw):
@@ -170,7 +180,12 @@ class HipCausalLM(nn.Module):
         self.wo = nn.ParameterList([nn.Parameter(init(H, Hq * D)) for _ in range(cfg.num_hidden_layers)])
         self.wgu = nn.ParameterList([nn.Parameter(init(2 * I, H)) for _ in range(cfg.num_hidden_layers)])
         self.wdown = nn.ParameterList([nn.Parameter(init(H, I)) for _ in range(cfg.num_hidden_layers)])
-        ones = lambda: nn.Parameter(torch.ones(H, dtype=torch.bfloat16, device=dev))
+        self.gemma = cfg.model_type == "gemma"
+        if cfg.model_type not in ("llama", "gemma"):
+            raise NotImplementedError(f"model_type {cfg.model_type!r}: the Llama and Gemma blocks are built")
+        # Gemma multiplies the embeddings by sqrt(hidden) held in the activation dtype (modeling_gemma.py:800-801)
+        self.embed_scale = float(torch.tensor(H ** 0.5, dtype=torch.bfloat16)) if self.gemma else 1.0
+        ones = lambda: nn.Parameter(torch.full((H,), 0.0 if self.gemma else 1.0, dtype=torch.bfloat16, device=dev))   # Gemma's norm weight is an offset from 1
         self.ln1 = nn.ParameterList([ones() for _ in range(cfg.num_hidden_layers)])
         self.ln2 = nn.ParameterList([ones() for _ in range(cfg.num_hidden_layers)])
         self.norm = ones()
@@ -201,13 +216,17 @@ class HipCausalLM(nn.Module):
         with open(os.path.join(path, "config.json")) as f:
             hf = json.load(f)
         arch = hf.get("model_type", "llama")
-        if arch != "llama":
-            raise NotImplementedError(f"from_pretrained: model_type {arch!r}: only the Llama block is built (DESIGN.md §8)")
+        if arch not in ("llama", "gemma"):
+            raise NotImplementedError(f"from_pretrained: model_type {arch!r}: the Llama and Gemma blocks are built (DESIGN.md §8)")
         keys = ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads",
                 "head_dim", "rms_norm_eps", "rope_theta", "rope_scaling", "tie_word_embeddings", "pad_token_id", "initializer_range")
         kw = {k: hf[k] for k in keys if k in hf}
+        kw["model_type"] = arch
         kw.setdefault("rope_scaling", None)
-        kw.setdefault("tie_word_embeddings", False)
+        kw.setdefault("tie_word_embeddings", arch == "gemma")   # GemmaConfig ties by default, LlamaConfig does not
+        if arch == "gemma":
+            kw.setdefault("rms_norm_eps", 1e-6)
+            kw.setdefault("rope_theta", 10000.0)
         if "num_key_value_heads" not in kw:
             kw["num_key_value_heads"] = kw["num_attention_heads"]
         model = cls(DecoderConfig(**kw), device=device)
@@ -230,7 +249,8 @@ class HipCausalLM(nn.Module):
         from safetensors.torch import save_file
         os.makedirs(path, exist_ok=True)
         c = self.cfg
-        cfg = {"architectures": ["LlamaForCausalLM"], "model_type": "llama", "torch_dtype": "bfloat16", "hidden_act": "silu",
+        cfg = {"architectures": ["GemmaForCausalLM" if self.gemma else "LlamaForCausalLM"], "model_type": c.model_type, "torch_dtype": "bfloat16",
+               **({"hidden_activation": "gelu_pytorch_tanh", "hidden_act": "gelu_pytorch_tanh"} if self.gemma else {"hidden_act": "silu"}),
                "attention_bias": False, "mlp_bias": False,
                **{k: getattr(c, k) for k in ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
                                              "num_key_value_heads", "head_dim", "rms_norm_eps", "rope_theta", "rope_scaling",
@@ -368,6 +388,24 @@ class HipCausalLM(nn.Module):
         fr = pos[:, None] * self.inv_freq[None, :].float()
         return fr.cos().contiguous(), fr.sin().contiguous()
 
+    def _attn_materialised(self, qkv, mask, B, S):
+        """Attention through the [B*Hq, S, S] score tensor (head-batched GEMMs + softmax kernel): any head_dim that is a
+        multiple of 64 (Gemma: 256); S must be a multiple of 64 (GEMM K-step).  Returns (output [B*S, Hq*D], probabilities)."""
+        c = self.cfg
+        D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        G, QKV, dev = Hq // Hkv, self.qkv, qkv.device
+        assert S % 64 == 0, "materialised attention needs a sequence length that is a multiple of 64"
+        P = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
+        ops.gemm_nt_heads((qkv, 0), QKV, (qkv, Hq * D), QKV, P, S, S, S, D, 1.0, B * Hq, Hq,
+                          S * QKV, D, 1, S * QKV, D, G, Hq * S * S, S * S)
+        ops.softmax_causal_fwd_(P, mask, Hq, 1.0 / math.sqrt(D))
+        vT = torch.empty((B, Hkv, D, S), dtype=torch.bfloat16, device=dev)
+        ops.transpose_strided(qkv, Hq * D + Hkv * D, vT, 0, S, D, QKV, S, B * Hkv, Hkv, S * QKV, D, Hkv * D * S, D * S)
+        ao = torch.empty((B * S, Hq * D), dtype=torch.bfloat16, device=dev)
+        ops.gemm_nt_heads(P, S, vT, S, ao, Hq * D, S, D, S, 1.0, B * Hq, Hq, Hq * S * S, S * S, 1,
+                          Hkv * D * S, D * S, G, S * Hq * D, D)
+        return ao, P
+
     # ---- forward ------------------------------------------------------------------------------
     def _forward_loss(self, input_ids, attention_mask, labels, position_ids):
         c = self.cfg
@@ -385,10 +423,10 @@ class HipCausalLM(nn.Module):
         QKV = self.qkv
         scale = 1.0 / math.sqrt(D)
         saved = []
-        x = ops.embed_fwd(input_ids.view(-1), self.embed.data)          # [T, H]
+        x = ops.embed_fwd(input_ids.view(-1), self.embed.data, self.embed_scale)          # [T, H]
         delta = None
         for i in range(c.num_hidden_layers):
-            h1, rstd1, x1 = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta)
+            h1, rstd1, x1 = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
             qkv = ops.gemm_nt(h1, self.wqkv[i].data)                    # [T, QKV]
             ls = [None] * 4
             if self.lora is not None:
@@ -398,29 +436,21 @@ class HipCausalLM(nn.Module):
             if self.fused_attention:
                 ao, P = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)       # P slot holds the row log-sum-exps
             else:
-                P = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
-                ops.gemm_nt_heads((qkv, 0), QKV, (qkv, Hq * D), QKV, P, S, S, S, D, 1.0, B * Hq, Hq,
-                                  S * QKV, D, 1, S * QKV, D, G, Hq * S * S, S * S)
-                ops.softmax_causal_fwd_(P, mask, Hq, scale)
-                vT = torch.empty((B, Hkv, D, S), dtype=torch.bfloat16, device=dev)
-                ops.transpose_strided(qkv, Hq * D + Hkv * D, vT, 0, S, D, QKV, S, B * Hkv, Hkv, S * QKV, D, Hkv * D * S, D * S)
-                ao = torch.empty((T, Hq * D), dtype=torch.bfloat16, device=dev)
-                ops.gemm_nt_heads(P, S, vT, S, ao, Hq * D, S, D, S, 1.0, B * Hq, Hq, Hq * S * S, S * S, 1,
-                                  Hkv * D * S, D * S, G, S * Hq * D, D)
+                ao, P = self._attn_materialised(qkv, mask, B, S)
             attn_delta = ops.gemm_nt(ao, self.wo[i].data)               # [T, H]
             if self.lora is not None:
                 ls[1] = self.lora[i]["o"].forward_add(ao, attn_delta, self.training)
-            h2, rstd2, x2 = ops.rmsnorm_fwd(x1, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta)
+            h2, rstd2, x2 = ops.rmsnorm_fwd(x1, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma)
             gu = ops.gemm_nt(h2, self.wgu[i].data)                      # [T, 2I]
             if self.lora is not None:
                 ls[2] = self.lora[i]["gu"].forward_add(h2, gu, self.training)
-            hm = ops.glu_fwd(gu)
+            hm = ops.glu_fwd(gu, gelu_tanh=self.gemma)
             delta = ops.gemm_nt(hm, self.wdown[i].data)
             if self.lora is not None:
                 ls[3] = self.lora[i]["down"].forward_add(hm, delta, self.training)
             saved.append((x1, rstd1, h1, qkv, P, ao, x2, rstd2, h2, gu, hm, ls))
             x = x2
-        hf, rstdf, xf = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta)
+        hf, rstdf, xf = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
 
         # ---- loss head: ForCausalLMLoss shifts (loss_utils.py:39-41): row t predicts labels[t+1]
         labels = labels.to(dev)
@@ -470,33 +500,46 @@ class HipCausalLM(nn.Module):
         mask = (attention_mask.to(dev).float() if attention_mask is not None else torch.ones(B, S, device=dev)).contiguous()
         if position_ids is None:
             position_ids = torch.arange(S, device=dev)[None].expand(B, S)
-        cos, sin = self._rope_tables(position_ids.to(dev))
+        position_ids = position_ids.to(dev)
+        lpad = 0
+        if not self.fused_attention and S % 64:   # the materialised path needs S % 64 == 0: masked positions on the LEFT change nothing
+            lpad = 64 - S % 64
+            input_ids = torch.cat([torch.zeros((B, lpad), dtype=input_ids.dtype, device=dev), input_ids], 1).contiguous()
+            mask = torch.cat([torch.zeros((B, lpad), device=dev), mask], 1).contiguous()
+            position_ids = torch.cat([torch.zeros((B, lpad), dtype=position_ids.dtype, device=dev), position_ids], 1)
+            S_out, S = S, S + lpad
+        cos, sin = self._rope_tables(position_ids)
         QKV = self.qkv
         scale = 1.0 / math.sqrt(D)
-        x = ops.embed_fwd(input_ids.view(-1), self.embed.data)
+        x = ops.embed_fwd(input_ids.view(-1), self.embed.data, self.embed_scale)
         delta = None
         for i in range(c.num_hidden_layers):
-            h1, _, x = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta)
+            h1, _, x = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
             qkv = ops.gemm_nt(h1, self.wqkv[i].data)
             if self.lora is not None:
                 self.lora[i]["qkv"].forward_add(h1, qkv, False)
             ops.rope_(qkv, cos, sin, Hq, D, QKV)
             _rope_offset(qkv, Hq * D, cos, sin, Hkv, D, QKV)
             if kv_out is not None:
-                kv_out[i][:, :S].copy_(qkv.view(B, S, QKV)[:, :, Hq * D:])
-            ao, _ = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)
+                kv_out[i][:, :S - lpad].copy_(qkv.view(B, S, QKV)[:, lpad:, Hq * D:])
+            if self.fused_attention:
+                ao, _ = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)
+            else:
+                ao, _ = self._attn_materialised(qkv, mask, B, S)
             attn_delta = ops.gemm_nt(ao, self.wo[i].data)
             if self.lora is not None:
                 self.lora[i]["o"].forward_add(ao, attn_delta, False)
-            h2, _, x = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta)
+            h2, _, x = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma)
             gu = ops.gemm_nt(h2, self.wgu[i].data)
             if self.lora is not None:
                 self.lora[i]["gu"].forward_add(h2, gu, False)
-            hm = ops.glu_fwd(gu)
+            hm = ops.glu_fwd(gu, gelu_tanh=self.gemma)
             delta = ops.gemm_nt(hm, self.wdown[i].data)
             if self.lora is not None:
                 self.lora[i]["down"].forward_add(hm, delta, False)
-        hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta)
+        hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
+        if lpad:
+            hf = hf.view(B, S, -1)[:, lpad:].reshape(B * S_out, -1)
         return hf
 
     def _eval_loss(self, input_ids, attention_mask, labels, position_ids):
@@ -526,10 +569,10 @@ class HipCausalLM(nn.Module):
         QKV = self.qkv
         scale = 1.0 / math.sqrt(D)
         cos, sin = self._rope_tables(pos)
-        x = ops.embed_fwd(tokens, self.embed.data)                       # [B, H]
+        x = ops.embed_fwd(tokens, self.embed.data, self.embed_scale)    # [B, H]
         delta = None
         for i in range(c.num_hidden_layers):
-            h1, _, x = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta)
+            h1, _, x = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
             qkv = ops.gemm_nt(h1, self.wqkv[i].data)                     # [B, QKV]
             if self.lora is not None:
                 self.lora[i]["qkv"].forward_add(h1, qkv, False)
@@ -540,15 +583,15 @@ class HipCausalLM(nn.Module):
             attn_delta = ops.gemm_nt(ao, self.wo[i].data)
             if self.lora is not None:
                 self.lora[i]["o"].forward_add(ao, attn_delta, False)
-            h2, _, x = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta)
+            h2, _, x = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma)
             gu = ops.gemm_nt(h2, self.wgu[i].data)
             if self.lora is not None:
                 self.lora[i]["gu"].forward_add(h2, gu, False)
-            hm = ops.glu_fwd(gu)
+            hm = ops.glu_fwd(gu, gelu_tanh=self.gemma)
             delta = ops.gemm_nt(hm, self.wdown[i].data)
             if self.lora is not None:
                 self.lora[i]["down"].forward_add(hm, delta, False)
-        hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta)
+        hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
         return hf
 
     @torch.no_grad()
@@ -635,7 +678,7 @@ class HipCausalLM(nn.Module):
             param.grad = g if param.grad is None else ops.add(param.grad, g)
 
         dw = torch.zeros(H, dtype=torch.float32, device=dev)
-        g = ops.rmsnorm_bwd(xf, self.norm.data, rstdf, dhf, dw)          # grad of the residual stream
+        g = ops.rmsnorm_bwd(xf, self.norm.data, rstdf, dhf, dw, gemma=self.gemma)          # grad of the residual stream
         lngrad(self.norm, dw)
         for i in reversed(range(c.num_hidden_layers)):
             x1, rstd1, h1, qkv, P, ao, x2, rstd2, h2, gu, hm, ls = saved.pop()
@@ -644,7 +687,7 @@ class HipCausalLM(nn.Module):
             d_hm = ops.gemm_nt(g, self._shadow(("wdown", i), self.wdown[i]))        # [T, I]
             if frozen:
                 d_hm = ops.add(d_hm, self.lora[i]["down"].backward(g, ls[3]))
-            d_gu = ops.glu_bwd(gu, d_hm)
+            d_gu = ops.glu_bwd(gu, d_hm, gelu_tanh=self.gemma)
             del d_hm, hm
             wgrad(d_gu, h2, self.wgu[i])
             d_h2 = ops.gemm_nt(d_gu, self._shadow(("wgu", i), self.wgu[i]))         # [T, H]
@@ -652,7 +695,7 @@ class HipCausalLM(nn.Module):
                 d_h2 = ops.add(d_h2, self.lora[i]["gu"].backward(d_gu, ls[2]))
             del d_gu, gu
             dw = torch.zeros(H, dtype=torch.float32, device=dev)
-            g2 = ops.rmsnorm_bwd(x2, self.ln2[i].data, rstd2, d_h2, dw, dres=g)
+            g2 = ops.rmsnorm_bwd(x2, self.ln2[i].data, rstd2, d_h2, dw, dres=g, gemma=self.gemma)
             lngrad(self.ln2[i], dw)
             # attention output projection
             wgrad(g2, ao, self.wo[i])
@@ -695,13 +738,13 @@ class HipCausalLM(nn.Module):
             if frozen:
                 d_h1 = ops.add(d_h1, self.lora[i]["qkv"].backward(d_qkv, ls[0]))
             dw = torch.zeros(H, dtype=torch.float32, device=dev)
-            g = ops.rmsnorm_bwd(x1, self.ln1[i].data, rstd1, d_h1, dw, dres=g2)
+            g = ops.rmsnorm_bwd(x1, self.ln1[i].data, rstd1, d_h1, dw, dres=g2, gemma=self.gemma)
             lngrad(self.ln1[i], dw)
             if self.grad_sync is not None:   # this layer's gradients are final: start their all-reduce now
                 ready = list(self.lora[i].parameters()) if frozen else [self.wqkv[i], self.wo[i], self.wgu[i], self.wdown[i], self.ln1[i], self.ln2[i]]
                 self.grad_sync.on_grads_ready(ready)
         if not frozen:
-            ops.embed_bwd(input_ids.view(-1), g, self.embed_grad32)
+            ops.embed_bwd(input_ids.view(-1), g, self.embed_grad32, self.embed_scale)
             eg = self.embed_grad32.to(torch.bfloat16)
             self.embed.grad = eg if self.embed.grad is None else ops.add(self.embed.grad, eg)
             self.embed_grad32.zero_()

@@ -4,6 +4,7 @@ scaling, left-padded batch, -100 labels.  Tolerances (bf16 compute vs the fp32 r
 loss within 1e-2 relative (the reference's own bf16 run differs from its fp32 run by ~1e-4 here);
 every parameter gradient within 3e-2 of the fp32 gradient in relative Frobenius norm and with
 cosine similarity > 0.999."""
+import json
 import os
 
 import numpy as np
@@ -47,16 +48,7 @@ def test_state_dict_roundtrip_hf_names():
     assert "lm_head.weight" in sd and torch.equal(sd["lm_head.weight"], sd["model.embed_tokens.weight"])
 
 
-@pytest.mark.parametrize("fused_attention", [True, False], ids=["fused-attn", "materialised-scores"])
-@pytest.mark.parametrize("full_logits", [False, True])
-def test_loss_and_gradients_vs_vendored_transformers(full_logits, fused_attention):
-    z, m = _load()
-    m.full_logits = full_logits
-    m.fused_attention = fused_attention
-    out = m(**_batch(z))
-    loss = out.loss
-    assert abs(loss.item() - float(z["loss_fp32"])) <= 1e-2 * float(z["loss_fp32"]), (loss.item(), float(z["loss_fp32"]))
-    loss.backward()
+def _compare_grads(z, m):
     c = m.cfg
     D, Hq, Hkv, I = c.head_dim, c.num_attention_heads, c.num_key_value_heads, c.intermediate_size
     grads = {"model.embed_tokens.weight": m.embed.grad[: c.vocab_size], "model.norm.weight": m.norm.grad}
@@ -78,6 +70,19 @@ def test_loss_and_gradients_vs_vendored_transformers(full_logits, fused_attentio
         rel = (g - ref).norm() / ref.norm().clamp_min(1e-12)
         cos = torch.nn.functional.cosine_similarity(g.flatten(), ref.flatten(), dim=0)
         assert rel.item() < 3e-2 and cos.item() > 0.999, (name, rel.item(), cos.item())
+
+
+@pytest.mark.parametrize("fused_attention", [True, False], ids=["fused-attn", "materialised-scores"])
+@pytest.mark.parametrize("full_logits", [False, True])
+def test_loss_and_gradients_vs_vendored_transformers(full_logits, fused_attention):
+    z, m = _load()
+    m.full_logits = full_logits
+    m.fused_attention = fused_attention
+    out = m(**_batch(z))
+    loss = out.loss
+    assert abs(loss.item() - float(z["loss_fp32"])) <= 1e-2 * float(z["loss_fp32"]), (loss.item(), float(z["loss_fp32"]))
+    loss.backward()
+    _compare_grads(z, m)
 
 
 def test_training_steps_reduce_loss_and_follow_torch_adam():
@@ -297,3 +302,59 @@ def test_generate_stops_when_every_sequence_finished():
     mask = torch.from_numpy(zg["attention_mask"]).cuda()[1:2]
     seq = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=24, pad_token_id=299, eos_token_id=int(zg["eos_token_id"]))
     assert seq.shape[1] == ids.shape[1] + 6 and int(seq[0, -1]) == int(zg["eos_token_id"])   # HF returns as soon as all are done
+
+
+# ---- Gemma block (config C5's family): goldens from the vendored GemmaForCausalLM, tests/golden/make_decoder_golden_gemma.py
+def _load_gemma():
+    z = np.load(os.path.join(GOLDEN, "decoder_gemma_tiny.npz"))
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    cfg = DecoderConfig(vocab_size=300, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                        num_key_value_heads=1, head_dim=128, rms_norm_eps=1e-6, rope_theta=10000.0, rope_scaling=None, pad_token_id=299,
+                        model_type="gemma")
+    m = HipCausalLM(cfg)
+    assert not m.fused_attention and m.gemma and m.embed_scale == float(torch.tensor(128 ** 0.5, dtype=torch.bfloat16))
+    m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")})
+    return z, m
+
+
+@pytest.mark.parametrize("full_logits", [False, True])
+def test_gemma_loss_and_gradients_vs_vendored_transformers(full_logits):
+    """(1 + w) RMSNorm in fp32, gelu-tanh gate, sqrt(hidden) embedding scale, MQA with head_dim 128 != hidden / heads
+    (materialised-scores attention): loss within 1e-2 relative of the fp32 reference run, every gradient within 3e-2."""
+    z, m = _load_gemma()
+    m.full_logits = full_logits
+    out = m(**_batch(z))
+    assert abs(out.loss.item() - float(z["loss_fp32"])) <= 1e-2 * float(z["loss_fp32"]), (out.loss.item(), float(z["loss_fp32"]))
+    out.loss.backward()
+    _compare_grads(z, m)
+
+
+@pytest.mark.parametrize("use_cache", [True, False], ids=["kv-cache", "recompute"])
+def test_gemma_generate_greedy_vs_vendored_transformers(use_cache):
+    """Greedy generate of the Gemma block: prompt length 45 (left-padded to 64 inside the materialised attention), head_dim 128
+    decode kernel."""
+    z, m = _load_gemma()
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    m.load_state_dict({k: (v * 4.0 if "proj" in k else v) for k, v in sd.items()})   # as make_decoder_golden_gemma.py does
+    m.eval()
+    ids = torch.from_numpy(z["gen_input_ids"]).cuda()
+    mask = torch.from_numpy(z["gen_attention_mask"]).cuda()
+    S0 = ids.shape[1]
+    seq, logits = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=16, pad_token_id=299, use_cache=use_cache, return_logits=True)
+    exact = _check_greedy(seq.cpu().numpy(), logits.cpu().numpy(), z["gen_sequences"], z["gen_scores"], S0,
+                          1.5 * float(z["gen_ref_bf16_deviation"].max()))
+    assert exact >= 24, exact
+
+
+def test_gemma_pretrained_directory(tmp_path):
+    z, m = _load_gemma()
+    from ecg_byte_amd.decoder import HipCausalLM
+    m.save_pretrained(str(tmp_path / "g"))
+    cfg = json.load(open(tmp_path / "g" / "config.json"))
+    assert cfg["model_type"] == "gemma" and cfg["head_dim"] == 128 and cfg["hidden_activation"] == "gelu_pytorch_tanh"
+    m2 = HipCausalLM.from_pretrained(str(tmp_path / "g"))
+    assert m2.gemma and not m2.fused_attention
+    a, b = m.state_dict(), m2.state_dict()
+    assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    out1, out2 = m(**_batch(z)).loss.item(), m2(**_batch(z)).loss.item()
+    assert abs(out1 - out2) < 1e-4 * out1          # the loss is summed with fp32 atomics: not bitwise repeatable
