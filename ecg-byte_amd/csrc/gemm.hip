@@ -738,6 +738,52 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
 }
 
 
+// C[M, N] = alpha * A[M, K] . B[N, K]^T for M <= 8 (the decode step of generate(): one new token per sequence).  No MFMA
+// tile to fill: the product is bound by reading B once.  One wave per output column n: the 64 lanes walk row n of B in
+// 16-byte pieces (1 KiB per step, coalesced), multiply with the matching pieces of the M rows of A (L2-resident), reduce
+// across the wave.  Same accumulate modes as the tiled kernels.
+template <int MR>
+__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs G)
+{
+    const int lane = threadIdx.x & 63;
+    const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= G.N) return;
+    const unsigned short *b = G.B + n * G.ldb;
+    float acc[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+    for (int k = lane * 8; k < G.K; k += 512) {
+        const bf16x8 vb = *reinterpret_cast<const bf16x8 *>(b + k);
+        float fb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fb[j] = __uint_as_float((unsigned)(unsigned short)vb[j] << 16);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m < G.M) {
+                const bf16x8 va = *reinterpret_cast<const bf16x8 *>(G.A + (long long)m * G.lda + k);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[m] += __uint_as_float((unsigned)(unsigned short)va[j] << 16) * fb[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc[m] += __shfl_xor(acc[m], d, 64);
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m >= G.M) break;
+            const float v = acc[m] * G.alpha;
+            if (G.accumulate_f32 == 1) reinterpret_cast<float *>(G.C)[(long long)m * G.ldc + n] += v;
+            else {
+                unsigned short *q = reinterpret_cast<unsigned short *>(G.C) + (long long)m * G.ldc + n;
+                *q = f2bf_rn(G.accumulate_f32 == 2 ? __uint_as_float((unsigned)*q << 16) + v : v);
+            }
+        }
+    }
+}
+
 int g_gemm_tile = 0;   // 0 auto; forced: 128 = 128x128 tile, 256 = 256x256 phased on 16x16x32 MFMA (the default for big problems),
                        // 257 = 256x256 on 32x32x16 MFMA, 258 = 256x256 on 16x16x32 with one barrier pair per K-tile (the earlier kernels, kept for A/B)
 
@@ -808,6 +854,14 @@ extern "C" int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b
     G.batch_a = batch_a; G.batch_b = batch_b; G.batch_c = batch_c;
     G.accumulate_f32 = accumulate_f32; G.alpha = alpha;
     G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
+    if (M <= 8 && batch == 1 && K % 8 == 0) {   // a few rows: bandwidth-bound column-per-wave kernel
+        const dim3 grid((unsigned)((N + 3) / 4));
+        if (M <= 2) hipLaunchKernelGGL(gemm_nt_skinny_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, G);
+        else hipLaunchKernelGGL(gemm_nt_skinny_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, G);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_skinny_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+        return ECGB_OK;
+    }
     return launch_gemm(G, batch, (hipStream_t)stream);
 }
 

@@ -30,7 +30,8 @@ def _close(got, ref, atol, rtol=2 ** -7):
 
 
 @pytest.mark.parametrize("tile", [128, 256, 257, 258])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 136, 128), (1024, 3072, 2048), (64, 512, 8192), (520, 300, 192)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 136, 128), (1024, 3072, 2048), (64, 512, 8192), (520, 300, 192),
+                                   (1, 4099, 2048), (2, 640, 64), (5, 1000, 8192), (8, 132, 4096)])   # the last four: the few-row (decode step) kernel
 def test_gemm_nt(ops, M, N, K, tile):
     ops.set_gemm_tile(tile)
     try:
@@ -101,6 +102,11 @@ def _gemm_checks(ops, M, N, K):
     # strided operand views (column slices of a wider buffer)
     wide = _bf(M, K + 64, seed=3)
     _close(ops.gemm_nt(wide[:, 64:], b), wide[:, 64:].float() @ b.float().T, atol=1e-2 * math.sqrt(K) / 8)
+    # bf16 accumulate mode (the LoRA branch adds into the base projection's output)
+    base = _bf(M, N, seed=4)
+    out = base.clone()
+    ops.gemm_nt(a, b, out=out, alpha=0.25, accumulate=True)
+    _close(out, base.float() + 0.25 * ref, atol=2e-2 * math.sqrt(K) / 8 + 2e-2 * base.float().abs().max().item())
 
 
 def test_transpose_and_backward_products(ops):
