@@ -104,6 +104,8 @@ def lib():
         "ecgb_softmax_bwd": [vp, vp, ci, ci, f32, vp],
         "ecgb_set_gemm_tile": [ci],
         "ecgb_attn_decode": [vp, vp, vp, ll, ll, vp, ll, vp, ci, ci, ci, ci, ci, f32, vp],
+        "ecgb_attn_decode_dyn": [vp, vp, vp, ll, ll, vp, ll, vp, ci, vp, ci, ci, ci, f32, vp],
+        "ecgb_kv_append": [vp, ll, ll, ci, vp, ll, ci, vp, vp],
         "ecgb_gemm_tn_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, vp],
         "ecgb_attn_fwd": [vp, ll, vp, ll, vp, ll, vp, vp, ll, vp, ci, ci, ci, ci, ci, f32, vp],
         "ecgb_attn_bwd": [vp, ll, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp, vp, ll, vp, ll, vp, ll, ci, ci, ci, ci, ci, f32, vp],

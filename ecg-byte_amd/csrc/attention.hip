@@ -496,10 +496,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs A)   // t
 template <int D>
 __global__ __launch_bounds__(64) void attn_decode_kernel(const unsigned short *q, const unsigned short *kc, const unsigned short *vc,
                                                          long long ld, long long cap, const float *mask, long long mask_ld,
-                                                         unsigned short *o, int len, int Hq, int Hkv, float scale)
+                                                         unsigned short *o, int len_arg, const int *len_dev, int Hq, int Hkv, float scale)
 {
     extern __shared__ float s_p[];                      // [len] scores / probabilities, then [D] the query in fp32
-    float *s_q = s_p + ((len + 3) & ~3);
+    const int len = len_dev ? *len_dev : len_arg;       // device-resident when the step is replayed from a captured graph
+    float *s_q = s_p + (len_dev ? (((int)cap + 3) & ~3) : ((len + 3) & ~3));
     const int hq = blockIdx.x, b = blockIdx.y, g = hq / (Hq / Hkv), lane = threadIdx.x;
     const unsigned short *qp = q + ((long long)b * Hq + hq) * D;
     for (int d = lane; d < D; d += 64) s_q[d] = bf2f(qp[d]);
@@ -612,18 +613,64 @@ extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev
     return launched("attn_bwd kernels");
 }
 
+namespace {
+int launch_attn_decode(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,
+                       const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, const int *kv_len_dev,
+                       int n_q_heads, int n_kv_heads, int head_dim, float scale, void *stream)
+{
+    if (head_dim != 64 && head_dim != 128 && head_dim != 256) { ecgb::set_error("ecgb_attn_decode: head_dim must be 64, 128 or 256"); return ECGB_ERR_UNSUPPORTED; }
+    if (batch <= 0 || (!kv_len_dev && (kv_len <= 0 || kv_len > capacity)) || n_q_heads % n_kv_heads || ld % 8) { ecgb::set_error("ecgb_attn_decode: bad shape"); return ECGB_ERR_INVALID; }
+    const long long rows = kv_len_dev ? capacity : (long long)kv_len;
+    const size_t lds = ((size_t)((rows + 3) & ~3ll) + (size_t)head_dim) * 4;
+    if (lds > 64 * 1024) { ecgb::set_error("ecgb_attn_decode: cache longer than ~16000 keys"); return ECGB_ERR_UNSUPPORTED; }
+#define ECGB_DECODE(D_) hipLaunchKernelGGL(attn_decode_kernel<D_>, dim3((unsigned)n_q_heads, (unsigned)batch), dim3(64), lds, (hipStream_t)stream, \
+        (const unsigned short *)q_dev, (const unsigned short *)k_cache_dev, (const unsigned short *)v_cache_dev, ld, capacity, attn_mask_dev, mask_ld, \
+        (unsigned short *)o_dev, kv_len, kv_len_dev, n_q_heads, n_kv_heads, scale)
+    if (head_dim == 64) ECGB_DECODE(64); else if (head_dim == 128) ECGB_DECODE(128); else ECGB_DECODE(256);
+#undef ECGB_DECODE
+    return launched("attn_decode_kernel");
+}
+
+// cache[b, *len - 1, :] = src[b, col_off : col_off + width]   (the new token's roped K | V, position from device memory)
+__global__ __launch_bounds__(256) void kv_append_kernel(const unsigned short *src, long long src_ld, long long col_off, int width,
+                                                        unsigned short *cache, long long cap, const int *len_dev, int batch)
+{
+    const long long row = *len_dev - 1;
+    const int per_row = width / 8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < batch * per_row; i += gridDim.x * blockDim.x) {
+        const int b = i / per_row, c = i % per_row;
+        *reinterpret_cast<bf16x8 *>(cache + ((long long)b * cap + row) * width + c * 8) =
+            *reinterpret_cast<const bf16x8 *>(src + (long long)b * src_ld + col_off + c * 8);
+    }
+}
+}  // namespace
+
 extern "C" int ecgb_attn_decode(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,
                                 const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, int n_q_heads,
                                 int n_kv_heads, int head_dim, float scale, void *stream)
 {
-    if (head_dim != 64 && head_dim != 128 && head_dim != 256) { ecgb::set_error("ecgb_attn_decode: head_dim must be 64, 128 or 256"); return ECGB_ERR_UNSUPPORTED; }
-    if (batch <= 0 || kv_len <= 0 || kv_len > capacity || n_q_heads % n_kv_heads || ld % 8) { ecgb::set_error("ecgb_attn_decode: bad shape"); return ECGB_ERR_INVALID; }
-    const size_t lds = ((size_t)((kv_len + 3) & ~3) + (size_t)head_dim) * 4;
-    if (lds > 64 * 1024) { ecgb::set_error("ecgb_attn_decode: cache longer than ~16000 keys"); return ECGB_ERR_UNSUPPORTED; }
-#define ECGB_DECODE(D_) hipLaunchKernelGGL(attn_decode_kernel<D_>, dim3((unsigned)n_q_heads, (unsigned)batch), dim3(64), lds, (hipStream_t)stream, \
-        (const unsigned short *)q_dev, (const unsigned short *)k_cache_dev, (const unsigned short *)v_cache_dev, ld, capacity, attn_mask_dev, mask_ld, \
-        (unsigned short *)o_dev, kv_len, n_q_heads, n_kv_heads, scale)
-    if (head_dim == 64) ECGB_DECODE(64); else if (head_dim == 128) ECGB_DECODE(128); else ECGB_DECODE(256);
-#undef ECGB_DECODE
-    return launched("attn_decode_kernel");
+    return launch_attn_decode(q_dev, k_cache_dev, v_cache_dev, ld, capacity, attn_mask_dev, mask_ld, o_dev, batch, kv_len, nullptr,
+                              n_q_heads, n_kv_heads, head_dim, scale, stream);
+}
+
+extern "C" int ecgb_attn_decode_dyn(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,
+                                    const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, const int *kv_len_dev,
+                                    int n_q_heads, int n_kv_heads, int head_dim, float scale, void *stream)
+{
+    if (!kv_len_dev) { ecgb::set_error("ecgb_attn_decode_dyn: NULL length pointer"); return ECGB_ERR_INVALID; }
+    return launch_attn_decode(q_dev, k_cache_dev, v_cache_dev, ld, capacity, attn_mask_dev, mask_ld, o_dev, batch, 0, kv_len_dev,
+                              n_q_heads, n_kv_heads, head_dim, scale, stream);
+}
+
+extern "C" int ecgb_kv_append(const void *src_dev, long long src_ld, long long col_off, int width, void *cache_dev, long long capacity,
+                              int batch, const int *kv_len_dev, void *stream)
+{
+    if (!src_dev || !cache_dev || !kv_len_dev || width <= 0 || width % 8 || src_ld % 8 || col_off % 8 || batch <= 0) {
+        ecgb::set_error("ecgb_kv_append: bad argument");
+        return ECGB_ERR_INVALID;
+    }
+    const int items = batch * (width / 8);
+    hipLaunchKernelGGL(kv_append_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short *)src_dev, src_ld, col_off, width, (unsigned short *)cache_dev, capacity, kv_len_dev, batch);
+    return launched("kv_append_kernel");
 }

@@ -562,8 +562,9 @@ class HipCausalLM(nn.Module):
             ops.ce_fwd_bwd_(logits, shifted.index_select(0, r), inv_count, loss, c.vocab_size)
         return loss.squeeze(0)
 
-    def _decode_step(self, tokens, pos, mask, caches, n):
-        """Hidden state [B, H] of one new token per sequence, written at cache row n-1 (n = keys valid after the update)."""
+    def _decode_step(self, tokens, pos, mask, caches, n, n_dev=None):
+        """Hidden state [B, H] of one new token per sequence, written at cache row n-1 (n = keys valid after the update).
+        n_dev: int32[1] device tensor holding n -- then nothing in the launches depends on the step (graph replay)."""
         c = self.cfg
         D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
         QKV = self.qkv
@@ -578,8 +579,12 @@ class HipCausalLM(nn.Module):
                 self.lora[i]["qkv"].forward_add(h1, qkv, False)
             ops.rope_(qkv, cos, sin, Hq, D, QKV)
             _rope_offset(qkv, Hq * D, cos, sin, Hkv, D, QKV)
-            caches[i][:, n - 1].copy_(qkv[:, Hq * D:])
-            ao = ops.attn_decode(qkv, caches[i], mask, n, Hq, Hkv, D, scale)
+            if n_dev is None:
+                caches[i][:, n - 1].copy_(qkv[:, Hq * D:])
+                ao = ops.attn_decode(qkv, caches[i], mask, n, Hq, Hkv, D, scale)
+            else:
+                ops.kv_append(qkv, Hq * D, caches[i], n_dev)
+                ao = ops.attn_decode_dyn(qkv, caches[i], mask, n_dev, Hq, Hkv, D, scale)
             attn_delta = ops.gemm_nt(ao, self.wo[i].data)
             if self.lora is not None:
                 self.lora[i]["o"].forward_add(ao, attn_delta, False)
@@ -596,7 +601,7 @@ class HipCausalLM(nn.Module):
 
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, max_new_tokens=128, pad_token_id=None, eos_token_id=None,
-                 use_cache=True, return_logits=False, **_):
+                 use_cache=True, return_logits=False, use_graph=False, **_):
         """Greedy search with the semantics of GenerationMixin.generate / _sample(do_sample=False)
         (generation/utils.py:1877, 3131-3250) as LLM.generate calls it (ecg_byte/models/llm.py:26-37): positions from the
         attention mask (utils.py:410-411), finished sequences keep emitting pad_token_id, stop when every sequence has
@@ -623,6 +628,8 @@ class HipCausalLM(nn.Module):
         seq = input_ids
         unfinished = torch.ones(B, dtype=torch.long, device=dev)
         step_logits = []
+        if use_cache and use_graph and not return_logits and max_new_tokens > 2:
+            return self._generate_graph(seq, mask, caches, S0, max_new_tokens, pad_token_id, eos, positions)
         for t in range(max_new_tokens):
             n = S0 + t                                                       # tokens in `seq`
             if t == 0 or not use_cache:
@@ -645,6 +652,74 @@ class HipCausalLM(nn.Module):
                 if int(unfinished.max()) == 0:
                     break
         return (seq, torch.stack(step_logits, 1)) if return_logits else seq
+
+    def _generate_graph(self, seq, mask, caches, S0, max_new_tokens, pad_token_id, eos, positions):
+        """The greedy loop with the decode step captured once in a HIP graph and replayed per token (`use_graph=True`).
+        Measured at Gemma-2B dims: 4.2 ms per token either way -- the step is bound by the GPU-side gaps between ~270
+        small dependent kernels, not by the host's launch calls, so the replay buys nothing yet (fewer, fused kernels
+        would); kept as an option.  Everything that changes from step to step lives in device memory: the
+        token, its position, the number of valid cache rows, the step counter; the host only replays and, when an eos id
+        is given, reads the `unfinished` flag."""
+        c = self.cfg
+        dev = self.device
+        B = seq.shape[0]
+        cap = S0 + max_new_tokens
+        # prefill + first token, eagerly
+        m0 = mask[:, :S0].contiguous()
+        hf = self._hidden_states(seq, m0, positions(m0), caches)
+        logits = ops.gemm_nt(hf.view(B, S0, -1)[:, -1].contiguous(), self.embed.data)[:, :c.vocab_size].float()
+        unfinished = torch.ones(B, dtype=torch.long, device=dev)
+        nxt = logits.argmax(-1)
+        if eos is not None:
+            unfinished = unfinished * (~torch.isin(nxt, eos)).long()
+        out = torch.full((B, cap), pad_token_id if pad_token_id is not None else 0, dtype=torch.long, device=dev)
+        out[:, :S0] = seq
+        out[:, S0] = nxt
+        mask[:, S0] = 1.0
+        if (eos is not None and int(unfinished.max()) == 0) or max_new_tokens == 1:
+            return out[:, :S0 + 1]
+        # static state of the captured step
+        tok = nxt.clone()
+        pos = positions(mask[:, :S0 + 1])[:, -1].contiguous()               # position of the token in `tok`
+        n_dev = torch.full((1,), S0 + 1, dtype=torch.int32, device=dev)     # cache rows valid once `tok` is appended
+        col = torch.full((B, 1), S0 + 1, dtype=torch.long, device=dev)      # where the token produced by the step goes
+        ones_col = torch.ones((B, 1), dtype=torch.float32, device=dev)
+        pad_t = torch.full((B,), pad_token_id if pad_token_id is not None else 0, dtype=torch.long, device=dev)
+
+        def step():
+            last = self._decode_step(tok, pos, mask, caches, None, n_dev)
+            lg = ops.gemm_nt(last, self.embed.data)[:, :c.vocab_size].float()
+            nx = lg.argmax(-1)
+            if eos is not None:
+                nx = nx * unfinished + pad_t * (1 - unfinished)
+                unfinished.mul_((nx[:, None] != eos[None, :]).all(1).long())
+            out.scatter_(1, col, nx[:, None])
+            mask.scatter_(1, col, ones_col)
+            tok.copy_(nx)
+            pos.add_(1)
+            n_dev.add_(1)
+            col.add_(1)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                      # warm-up outside the capture (allocations, lazy init)
+            snap = (tok.clone(), pos.clone(), n_dev.clone(), col.clone(), unfinished.clone(), out.clone(), mask.clone())
+            step()
+            for dst, src in zip((tok, pos, n_dev, col, unfinished, out, mask), snap):
+                dst.copy_(src)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        for dst, src in zip((tok, pos, n_dev, col, unfinished, out, mask), snap):   # capture does not execute, but keep the state explicit
+            dst.copy_(src)
+        produced = 1
+        for t in range(1, max_new_tokens):
+            graph.replay()
+            produced += 1
+            if eos is not None and int(unfinished.max()) == 0:
+                break
+        return out[:, :S0 + produced]
 
     # ---- backward -------------------------------------------------------------------------------
     def _backward(self, grad_out):

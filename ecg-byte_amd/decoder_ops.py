@@ -221,3 +221,19 @@ def attn_decode(qkv_new, cache, mask, kv_len, Hq, Hkv, D, scale):
     _lib.check(_L().ecgb_attn_decode(_p(q), _off(cache, 0), _off(cache, Hkv * D), W, cap, _p(mask), mask.stride(0), _p(o),
                                      B, int(kv_len), Hq, Hkv, D, float(scale), _st()))
     return o
+
+
+def attn_decode_dyn(qkv_new, cache, mask, kv_len_dev, Hq, Hkv, D, scale):
+    """attn_decode with the number of valid cache rows in device memory (int32[1]): replayable from a captured graph."""
+    B, cap, W = cache.shape
+    q = qkv_new[:, :Hq * D].contiguous()
+    o = torch.empty((B, Hq * D), dtype=torch.bfloat16, device=q.device)
+    _lib.check(_L().ecgb_attn_decode_dyn(_p(q), _off(cache, 0), _off(cache, Hkv * D), W, cap, _p(mask), mask.stride(0), _p(o),
+                                         B, _p(kv_len_dev), Hq, Hkv, D, float(scale), _st()))
+    return o
+
+
+def kv_append(qkv_new, col_off, cache, kv_len_dev):
+    """cache[:, *kv_len_dev - 1] = qkv_new[:, col_off : col_off + cache.shape[2]]"""
+    B, cap, W = cache.shape
+    _lib.check(_L().ecgb_kv_append(_p(qkv_new), qkv_new.stride(0), col_off, W, _p(cache), cap, B, _p(kv_len_dev), _st()))

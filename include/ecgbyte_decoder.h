@@ -135,6 +135,15 @@ int ecgb_attn_decode(const void *q_dev, const void *k_cache_dev, const void *v_c
                      const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, int n_q_heads,
                      int n_kv_heads, int head_dim, float scale, void *stream);
 
+/* The same with the number of valid cache rows read from device memory, and the append of the new token's K | V row at
+ * index *kv_len_dev - 1: nothing in the launch depends on the step, so one decode step captured in a HIP graph can be
+ * replayed for every token (the host only bumps the device counter). */
+int ecgb_attn_decode_dyn(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,
+                         const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, const int *kv_len_dev,
+                         int n_q_heads, int n_kv_heads, int head_dim, float scale, void *stream);
+int ecgb_kv_append(const void *src_dev, long long src_ld, long long col_off, int width, void *cache_dev, long long capacity,
+                   int batch, const int *kv_len_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

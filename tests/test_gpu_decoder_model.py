@@ -358,3 +358,25 @@ def test_gemma_pretrained_directory(tmp_path):
     assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
     out1, out2 = m(**_batch(z)).loss.item(), m2(**_batch(z)).loss.item()
     assert abs(out1 - out2) < 1e-4 * out1          # the loss is summed with fp32 atomics: not bitwise repeatable
+
+
+@pytest.mark.parametrize("family", ["llama", "gemma"])
+def test_generate_graph_replay_equals_eager_loop(family):
+    """The decode step captured in a HIP graph (device-resident token / position / cache length) and replayed per token
+    produces exactly the sequences of the eager loop, with and without an eos id (early stop, pad after eos)."""
+    if family == "llama":
+        zg, m = _load_generate()
+        ids, mask = torch.from_numpy(zg["input_ids"]).cuda(), torch.from_numpy(zg["attention_mask"]).cuda()
+        eos = int(zg["eos_token_id"])
+    else:
+        z, m = _load_gemma()
+        m.eval()
+        ids, mask = torch.from_numpy(z["gen_input_ids"]).cuda(), torch.from_numpy(z["gen_attention_mask"]).cuda()
+        eos = int(z["gen_sequences"][1, ids.shape[1] + 3])
+    for kw in (dict(), dict(eos_token_id=eos), dict(eos_token_id=[eos, 7])):
+        eager = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=20, pad_token_id=299, use_graph=False, **kw)
+        graph = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=20, pad_token_id=299, use_graph=True, **kw)
+        assert eager.shape == graph.shape and torch.equal(eager, graph), kw
+    one = m.generate(input_ids=ids[1:2], attention_mask=mask[1:2], max_new_tokens=20, pad_token_id=299, eos_token_id=eos)
+    ref = m.generate(input_ids=ids[1:2], attention_mask=mask[1:2], max_new_tokens=20, pad_token_id=299, eos_token_id=eos, use_graph=False)
+    assert torch.equal(one, ref)
