@@ -17,22 +17,22 @@
 // ---- Encoder ---------------------------------------------------------------------------
 // Greedy longest match is a sequential chain i -> i + len(i).  Walking the trie from EVERY
 // position would cost ~21 lookups per symbol on ECG streams; following only the chain costs
-// ~1.15.  One persistent workgroup per CU keeps the trie (8 B/node, breadth-first) in LDS and
-// works through its share of the batch, E streams at a time, in 32768-symbol segments:
-//   stage   256 lanes per stream read the float64 samples (coalesced 16-byte loads), classify
-//           them against the staircase and write the symbols straight into LDS -- the symbol
-//           stream never exists in HBM (for byte-stream input: LUT classify instead);
-//   pass 0  the segment is cut into 128-symbol chunks, one lane each; every lane parses its
-//           chunk speculatively from the chunk start, keeps one bit per token start in an LDS
-//           bitmap, stores ids of tokens longer than one symbol in a half-resolution id
-//           array (L2-resident per-workgroup scratch) and records where its chain leaves;
-//   stitch  lane c re-parses from the exit of chunk c-1 until it lands on a position its own
-//           speculative chain marked (greedy chains re-synchronise after ~40 symbols on
-//           ECG data) -- iterated to a fixed point, so the result is the true chain whatever
-//           the data (worst case: one iteration per chunk);
-//   emit    popcount + group scan of the bitmap gives every token its output slot.
-// Inner loop = two LDS reads (symbol byte, trie node) and ~20 VALU ops per symbol; no global
-// memory on the dependent path.  Trie nodes that do not fit LDS are read through L2.
+// ~1.15 -- and about 0.5 once a run of equal symbols is one step along a same-class chain of
+// consecutive trie nodes (tokenizer.hpp has the node layout, walk_chunk / encode_flow_kernel the
+// step).  One persistent workgroup per CU keeps the trie (8 B/node) and its bit tables in LDS:
+//   stage   lanes read the float64 samples (coalesced 16-byte loads), classify them against the
+//           staircase and write the symbol classes straight into LDS -- the symbol stream never
+//           exists in HBM (for byte-stream input: LUT classify instead); a change map (bit p =
+//           symbol p differs from p-1) gives the length of the run ahead with one find-first-set;
+//   parse   speculative: the segment is cut into chunks, one lane each, parsed from the chunk
+//           start before the true entry is known;
+//   resolve which of the parsed tokens lie on the real chain;
+//   emit    prefix sums give every real token its output slot.
+// Two kernels share stage / walk: encode_flow_kernel (large batches: one wave = one record,
+// claim-merge parse without re-walks, see its header) and encode_wg_kernel (small batches or
+// very long tokens: one 256-lane workgroup = one record, 32768-symbol segments, re-parse from
+// corrected entries to a fixed point).  No global memory on the dependent path of a step; trie
+// nodes that do not fit LDS are read through L2.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -821,7 +821,8 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
 // ==========================================================================================
 // Kernel 2 (small batches): ONE WORKGROUP OF 256 LANES = ONE STREAM, segments of 256 chunks of
 // 128 symbols, so a single record still spreads over 4 waves and few records over many CUs.
-// Same stage / walk / stitch / emit, with workgroup barriers between the phases.
+// Stage, speculative chunk parse, re-parse from corrected entries to a fixed point (the stitch), emit -- with workgroup
+// barriers between the phases.
 constexpr int kChunk = 128;                 // symbols per lane-chunk (multiple of 32)
 constexpr int kLanes = 256;                 // lanes (chunks) per stream per segment
 constexpr int kSeg = kChunk * kLanes;       // symbols per segment = 32768
