@@ -1,6 +1,8 @@
 """Dev-only: time the fused attention kernels at the Llama-3.2-1B shape (B=32, S=1024, 32/8 heads, D=64)."""
+import os as _os
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 import sys, time, math
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, _ROOT)
 import torch
 from ecg_byte_amd import decoder_ops as ops
 B, S, Hq, Hkv, D = 32, 1024, 32, 8, 64

@@ -1,6 +1,8 @@
 """Dev-only: TFLOP/s of ecgb_gemm_nt_bf16 at the Llama-3.2-1B projection shapes (random data)."""
+import os as _os
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 import sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, _ROOT)
 import torch
 from ecg_byte_amd import decoder_ops as ops
 shapes = [(32768, 3072, 2048), (32768, 16384, 2048), (32768, 2048, 8192), (32768, 2048, 2048), (4096, 132096, 2048), (2048, 8192, 32768)]

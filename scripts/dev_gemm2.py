@@ -1,6 +1,8 @@
 """Dev-only: A/B of the 256x256 GEMM kernels (tile 256 = one-barrier-pair per K-tile, 258 = phased + staggered), interleaved."""
+import os as _os
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 import sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, _ROOT)
 import torch
 from ecg_byte_amd import decoder_ops as ops
 shapes = [(32768, 3072, 2048), (32768, 16384, 2048), (32768, 2048, 8192), (32768, 2048, 2048), (8192, 8192, 8192), (4096, 4096, 4096)]

@@ -1,5 +1,7 @@
+import os as _os
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 import os, sys
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+sys.path.insert(0, _ROOT); sys.path.insert(0, _ROOT + '/tests')
 import numpy as np, torch
 import test_gpu_decoder_model as T
 z, m = T._load_gemma()

@@ -1,6 +1,8 @@
 """Dev-only: time the C5 workload shape -- Gemma-2B dims, seq 2048, LoRA r16 (what the reference's script runs) -- and greedy generate."""
+import os as _os
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 import sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, _ROOT)
 import torch
 from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8

@@ -1,5 +1,7 @@
+import os as _os
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+sys.path.insert(0, _ROOT); sys.path.insert(0, _ROOT + '/tests')
 import numpy as np, torch
 from helpers import load_tokenizer, oracle_batch
 from ecg_byte_amd import synth

@@ -1,5 +1,7 @@
+import os as _os
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 import sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, _ROOT)
 import torch
 from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
 V = 256000 + 256 + 3500 + 3

@@ -1,6 +1,8 @@
 """Dev-only: phase timers of encode_kernel from the -DECGB_PROFILE build."""
+import os as _os
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 import sys, os, ctypes as C
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+sys.path.insert(0, _ROOT); sys.path.insert(0, _ROOT + '/tests')
 import numpy as np, torch
 from ecg_byte_amd import _lib
 _lib.SO_PATH = os.path.join(os.path.dirname(_lib.SO_PATH), "libecgbyte_hip_prof.so")

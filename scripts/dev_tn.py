@@ -1,5 +1,7 @@
+import os as _os
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 import sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, _ROOT)
 import torch
 from ecg_byte_amd import decoder_ops as ops
 M, N, K = 32768, 16384, 2048

@@ -1,6 +1,8 @@
 """Dev-only: HIP trainer at fixture scale (2000 records of 12xL, seed 1) vs the committed tokenizer."""
+import os as _os
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+sys.path.insert(0, _ROOT); sys.path.insert(0, _ROOT + '/tests')
 import numpy as np, torch
 from helpers import load_tokenizer
 import bench

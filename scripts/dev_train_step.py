@@ -1,6 +1,8 @@
 """Dev-only: time the Llama-3.2-1B training step (B x 1024) on HipCausalLM."""
+import os as _os
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
 import sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, _ROOT)
 import torch
 from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
