@@ -99,6 +99,7 @@ def lib():
         "ecgb_count_labels": [vp, sz, ci, vp, vp],
         "ecgb_ce_fwd_bwd": [vp, vp, vp, vp, vp, sz, ci, sz, vp],
         "ecgb_sumsq": [vp, sz, ci, vp, vp],
+        "ecgb_sumsq_multi_bf16": [vp, vp, vp, vp, ci, vp, vp],
         "ecgb_adam_step": [vp, vp, ci, vp, vp, sz, vp, f32, f32, f32, f32, f32, f32, ci, vp],
         "ecgb_softmax_causal_fwd": [vp, vp, ci, ci, ci, f32, vp],
         "ecgb_softmax_bwd": [vp, vp, ci, ci, f32, vp],

@@ -470,6 +470,30 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const T *g, size_t n, float 
     if (threadIdx.x == 0) atomicAdd(acc, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
 }
 
+// The same over a LIST of bf16 tensors in one launch (one launch per parameter tensor is ~100 launches of mostly tiny
+// work per step): block b sums chunk b = elements [chunk_off[b], chunk_off[b] + 2^20) of tensor chunk_tensor[b].
+__global__ __launch_bounds__(256) void sumsq_multi_kernel(const unsigned short *const *ptrs, const unsigned long long *counts,
+                                                          const int *chunk_tensor, const unsigned long long *chunk_off, float *acc)
+{
+    __shared__ float s_red[4];
+    const int t = chunk_tensor[blockIdx.x];
+    const unsigned long long off = chunk_off[blockIdx.x];
+    const unsigned long long n = min((unsigned long long)(1u << 20), counts[t] - off);
+    const unsigned short *g = ptrs[t] + off;
+    float s = 0.f;
+    const unsigned long long n8 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? (n & ~7ull) : 0ull;
+    for (unsigned long long i = (unsigned long long)threadIdx.x * 8; i < n8; i += 256 * 8) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8 *>(g + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]); s += f * f; }
+    }
+    for (unsigned long long i = n8 + threadIdx.x; i < n; i += 256) { const float f = bf2f(g[i]); s += f * f; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+}
+
 // torch.optim.Adam with weight_decay as L2 (main.py:262-264), preceded by clip_grad_norm_(1.0)
 // (train.py:26): clip = min(1, max_norm / (sqrt(*sumsq) + 1e-6)).  Moments fp32, params bf16.
 template <typename G>
@@ -744,6 +768,16 @@ extern "C" int ecgb_sumsq(const void *g_dev, size_t n, int is_fp32, float *acc_d
     if (is_fp32) hipLaunchKernelGGL(sumsq_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)g_dev, n, acc_dev);
     else hipLaunchKernelGGL(sumsq_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)g_dev, n, acc_dev);
     ECGB_CHECK_LAUNCH("sumsq");
+}
+
+extern "C" int ecgb_sumsq_multi_bf16(const void *const *ptrs_dev, const unsigned long long *counts_dev, const int *chunk_tensor_dev,
+                                    const unsigned long long *chunk_off_dev, int n_chunks, float *acc_dev, void *stream)
+{
+    if (n_chunks <= 0) return ECGB_OK;
+    if (!ptrs_dev || !counts_dev || !chunk_tensor_dev || !chunk_off_dev || !acc_dev) { ecgb::set_error("ecgb_sumsq_multi_bf16: NULL argument"); return ECGB_ERR_INVALID; }
+    hipLaunchKernelGGL(sumsq_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short *const *)ptrs_dev, counts_dev, chunk_tensor_dev, chunk_off_dev, acc_dev);
+    ECGB_CHECK_LAUNCH("sumsq_multi");
 }
 
 extern "C" int ecgb_adam_step(void *param_dev, const void *grad_dev, int grad_is_fp32, float *m_dev, float *v_dev, size_t n,

@@ -853,6 +853,7 @@ class HipAdam:
         self.fixed_lr = None if warmup else lr
         self.t = 0
         self.state = {}
+        self._sumsq_plan = None
 
     def zero_grad(self):
         for p in self.model.parameters():
@@ -867,8 +868,15 @@ class HipAdam:
         self.t += 1
         params = [p for p in self.model.parameters() if p.grad is not None]
         acc = torch.zeros(1, dtype=torch.float32, device=self.model.device)
-        for p in params:
-            ops.sumsq(p.grad, acc)
+        grads = [p.grad for p in params]
+        if all(g.dtype == torch.bfloat16 and g.is_contiguous() for g in grads):
+            counts = [g.numel() for g in grads]
+            if self._sumsq_plan is None or self._sumsq_plan.counts_host != counts:
+                self._sumsq_plan = ops.SumsqPlan(counts, self.model.device)
+            ops.sumsq_multi(grads, acc, self._sumsq_plan)       # one launch for all gradients
+        else:
+            for g in grads:
+                ops.sumsq(g, acc)
         lr = self.lr(self.t)
         for p in params:
             st = self.state.get(id(p))

@@ -181,6 +181,28 @@ def sumsq(g, acc):
     _lib.check(_L().ecgb_sumsq(_p(g), g.numel(), int(g.dtype == torch.float32), _p(acc), _st()))
 
 
+class SumsqPlan:
+    """Chunk table of `sumsq_multi` for a fixed list of tensor sizes (built once, reused every step)."""
+
+    def __init__(self, counts, device):
+        ct, co = [], []
+        for t, n in enumerate(counts):
+            for off in range(0, n, 1 << 20):
+                ct.append(t)
+                co.append(off)
+        self.counts_host = list(counts)
+        self.counts = torch.tensor(counts, dtype=torch.int64, device=device)
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=device)
+        self.chunk_off = torch.tensor(co, dtype=torch.int64, device=device)
+        self.n_chunks = len(ct)
+
+
+def sumsq_multi(tensors, acc, plan):
+    """acc += sum over all (bf16, contiguous) tensors of their squared elements, one launch."""
+    ptrs = torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64).to(acc.device, non_blocking=True)
+    _lib.check(_L().ecgb_sumsq_multi_bf16(_p(ptrs), _p(plan.counts), _p(plan.chunk_tensor), _p(plan.chunk_off), plan.n_chunks, _p(acc), _st()))
+
+
 def adam_step_(p, g, m, v, sumsq_acc, max_norm, lr, beta1, beta2, eps, weight_decay, step):
     _lib.check(_L().ecgb_adam_step(_p(p), _p(g), int(g.dtype == torch.float32), _p(m), _p(v), p.numel(), _p(sumsq_acc),
                                    float(max_norm), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),

@@ -95,6 +95,10 @@ int ecgb_ce_fwd_bwd(void *logits_dev, const int64_t *labels_dev, float *row_loss
 
 /* acc_dev += sum(g^2) */
 int ecgb_sumsq(const void *g_dev, size_t n, int is_fp32, float *acc_dev, void *stream);
+/* The same over a list of bf16 tensors in ONE launch: ptrs_dev[t] / counts_dev[t] describe tensor t, and block b of the launch sums
+ * the (at most 2^20) elements of tensor chunk_tensor_dev[b] that start at chunk_off_dev[b].  *acc_dev += the total. */
+int ecgb_sumsq_multi_bf16(const void *const *ptrs_dev, const unsigned long long *counts_dev, const int *chunk_tensor_dev,
+                          const unsigned long long *chunk_off_dev, int n_chunks, float *acc_dev, void *stream);
 /* One Adam step (moments fp32, params bf16) with the gradient first scaled by min(1, max_norm/(sqrt(*sumsq)+1e-6))
  * and weight decay applied as L2 (grad += wd * param), as torch.optim.Adam does. */
 int ecgb_adam_step(void *param_dev, const void *grad_dev, int grad_is_fp32, float *m_dev, float *v_dev, size_t n,

@@ -286,3 +286,16 @@ def test_gemm_tn_weight_gradient(ops, M, N, K):
     ref = dy.float().T @ x.float()
     _close(ops.gemm_tn(dy, x), ref, atol=1e-2 * math.sqrt(M) / 4)
     _close(ops.gemm_tn(dy, x, alpha=0.25), 0.25 * ref, atol=1e-2 * math.sqrt(M) / 8)
+
+
+def test_sumsq_multi_equals_per_tensor_sum(ops):
+    """One launch over a list of gradient tensors (sizes from 8 elements to a few chunks of 2^20, an unaligned view among
+    them) against the fp32 sum of squares."""
+    sizes = [8, 2048, 1 << 20, (1 << 20) + 24, 3 * (1 << 20) + 5000, 77]
+    ts = [_bf(n, seed=30 + i) for i, n in enumerate(sizes)]
+    ts.append(_bf(4104, seed=40)[3:4099])                    # not 16-byte aligned: scalar path
+    plan = ops.SumsqPlan([t.numel() for t in ts], "cuda")
+    acc = torch.zeros(1, device="cuda")
+    ops.sumsq_multi(ts, acc, plan)
+    want = sum(float((t.float() ** 2).sum()) for t in ts)
+    assert abs(acc.item() - want) <= 1e-4 * want
