@@ -385,7 +385,7 @@ __device__ __forceinline__ uint32_t walk_chunk(const WalkCtx &W, uint32_t s_rel,
         if ((marks[start_rel >> 5] >> (start_rel & 31)) & 1u) return old_exit;   // already on the chain
     }
     uint32_t r = start_rel;        // token start
-    uint32_t j = r, node = 0, best_j = r, best_node = 0;
+    uint32_t j = r, node = 0, best_j = r;
     uint32_t result = 0;
     bool done = false;
     while (!done) {
@@ -396,13 +396,15 @@ __device__ __forceinline__ uint32_t walk_chunk(const WalkCtx &W, uint32_t s_rel,
         uint64_t rec;
         if constexpr (ALL_LDS) rec = W.s_trie[node];
         else rec = (node < W.n_lds) ? W.s_trie[node] : W.g_trie[node];
-        const uint32_t dk = j >> 5, u = node + 1, rk = (u >> 5) * 2;
+        const uint32_t dk = j >> 5, rk = (node >> 5) * 2;
         const uint32_t d0 = W.dmap[dk], d1 = W.dmap[dk + 1];
         const uint2 r0 = *reinterpret_cast<const uint2 *>(W.s_run + rk), r1 = *reinterpret_cast<const uint2 *>(W.s_run + rk + 2);
         const uint32_t dw = __builtin_amdgcn_alignbit(d1, d0, j & 31);        // bit t: position j + t starts a new run
+        const uint32_t cw = __builtin_amdgcn_alignbit(r1.x, r0.x, node & 31); // bit t: node + t has a continuation
+        const uint32_t tw = __builtin_amdgcn_alignbit(r1.y, r0.y, node & 31); // bit t: node + t carries a token itself
         const uint32_t bm = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
         const uint32_t fc = hi & 0xFFFFu;
-        if ((hi >> 16) != ecgb::kNoToken) { best_j = j; best_node = node; }   // the root carries none
+        if (tw & 1u) best_j = j;                                              // the root carries none
         bool advanced = false;
         if (node != 0 && !(dw & 1u)) {              // the symbol repeats the one this node was entered by
             if (bm & ecgb::kContFlag) {
@@ -411,17 +413,11 @@ __device__ __forceinline__ uint32_t walk_chunk(const WalkCtx &W, uint32_t s_rel,
                     node = fc + __popc(bm & ecgb::kBranchMask);
                     ++j;
                 } else {
-                    const uint32_t cw = __builtin_amdgcn_alignbit(r1.x, r0.x, u & 31);   // bit t: node u + t has a continuation
-                    const uint32_t tw = __builtin_amdgcn_alignbit(r1.y, r0.y, u & 31);   // bit t: node u + t carries a token
                     const uint32_t z = min((uint32_t)__ffs(dw) - 1u, 32u);               // symbols of this run ahead (>= 1)
-                    const uint32_t ones = min((uint32_t)__ffs(~cw) - 1u, 32u);
-                    const uint32_t m = min(z, ones + 1u);
-                    const uint32_t passed = tw & ((1u << (m - 1u)) - 1u);                // nodes u .. u + m - 2
-                    if (passed) {
-                        const uint32_t q = 31u - __clz(passed);
-                        best_j = j + q + 1u;
-                        best_node = u + q;
-                    }
+                    const uint32_t ones = min((uint32_t)__ffs(~cw) - 1u, 32u);           // chain nodes from this one on that continue (>= 1)
+                    const uint32_t m = min(z, ones);
+                    const uint32_t passed = tw & (0xFFFFFFFFu >> (32u - m)) & ~1u;       // nodes node + 1 .. node + m - 1
+                    if (passed) best_j = j + (31u - __clz(passed));
                     node += m;
                     j += m;
                 }
@@ -438,12 +434,7 @@ __device__ __forceinline__ uint32_t walk_chunk(const WalkCtx &W, uint32_t s_rel,
             // emit the token [r, r + len)
             const uint32_t len = max(best_j - r, 1u);   // unmatched byte: lib.rs:186-189
             atomicOr(&marks[r >> 5], 1u << (r & 31));
-            if (len >= 2) {
-                uint64_t brec;
-                if constexpr (ALL_LDS) brec = W.s_trie[best_node];
-                else brec = (best_node < W.n_lds) ? W.s_trie[best_node] : W.g_trie[best_node];
-                W.ids_half[r >> 1] = (uint16_t)(brec >> 48);
-            }
+            if (len >= 2) W.ids_half[r >> 1] = (uint16_t)(hi >> 16);   // the best token of the node the walk stopped at
             if constexpr (!FIRST) {   // drop marks of the old chain inside (r, r + len)
                 uint32_t lo = r + 1;
                 const uint32_t hi_pos = min(r + len, e_rel);
@@ -515,7 +506,7 @@ __device__ __forceinline__ uint32_t emit_word(uint32_t bits, uint32_t w_rel, con
 //            before has joined that parse and stops, otherwise it keeps going -- past its chunk,
 //            through later chunks, to the end of the segment.  Every position is therefore parsed at
 //            most once, nothing is ever re-walked, and a lane is idle only from its join to the end
-//            of the loop.  The tokens of a trip (position, id; 0xFFFF for a single symbol) are appended
+//            of the loop.  The tokens of a trip (position, id; 0xFFFF for an unmatched byte) are appended
 //            to the wave's token list in global memory: consecutive 4-byte entries, one coalesced
 //            store per trip, a few hundred entries per segment (dense, L2-resident).
 //   resolve  the claimed positions are the real chain plus the speculative prefixes that joined it.
@@ -640,79 +631,72 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             __builtin_amdgcn_wave_barrier();
 
             // ---- parse
+            // A trip is one trie step, or -- when the step fails -- the emission of the token the walk has matched: its id
+            // is the stopped-at node's best token (tokenizer.hpp), its length comes from the id -> length table, the next
+            // token start is claimed, and the first symbol of the next token is taken on the spot (the root's children are
+            // nodes 1 .. n_classes in class order), so the root is never visited and a token costs its steps past the
+            // first symbol plus one.  The step itself is branch-free: "the symbol repeats" selects the continuation flag
+            // instead of the symbol's class bit (kContFlag - 1 == kBranchMask makes the child formula the same), and inside
+            // a same-class chain the step length is the distance to the first position that starts a new run or the first
+            // chain node without a continuation.  All five LDS reads of a trip are issued together and waited for once.
             uint32_t n_list = 0;                                            // tokens in the wave's list (real chain + speculative prefixes)
             {
                 uint32_t r = (c == 0) ? carry_rel : max(my_start, carry_rel);   // chunks the carry token covers start at the carry
-                uint32_t j = r, node = 0, best_j = r, best_node = 0;
+                uint32_t j = r, node = 0;
                 bool live = r < seg_len;
-                n_list = 0;
+                if (live) {
+                    const uint32_t rbit = 1u << (r & 31);
+                    const uint32_t claimed = atomicOr(&marks[r >> 5], rbit);
+                    const uint32_t s0 = sym[r];
+                    live = !(claimed & rbit);                                   // two lanes at the carry: one of them goes
+                    if (INPUT == INPUT_F64 || s0 != ecgb::kOtherClass) { node = 1u + s0; j = r + 1u; }
+                }
                 while (live) {
                     uint32_t emit_word = 0;
                     bool emitting = false;
 #ifdef ECGB_PROFILE
                     if (A.prof && c == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&A.prof[blockIdx.x * 8 + 5], 1ull);
 #endif
-                    // every read of the trip is issued here, unconditionally, and waited for once
-                    const uint32_t rbit = 1u << (r & 31);
-                    const uint32_t claimed = atomicOr(&marks[r >> 5], node == 0 ? rbit : 0u);   // node == 0 <=> at a token start
-                    const uint32_t s = sym[j];
                     uint64_t rec;
-                    uint32_t btok;                                                       // token word of the best node so far
-                    if constexpr (ALL_LDS) {
-                        rec = s_trie[node];
-                        btok = reinterpret_cast<const uint32_t *>(s_trie)[2 * best_node + 1];
+                    if constexpr (ALL_LDS) rec = s_trie[node];
+                    else rec = (node < A.n_lds_nodes) ? s_trie[node] : A.trie[node];
+                    const uint32_t dk = j >> 5, ck = (node >> 5) * 2;
+                    uint32_t d0 = dmap[dk], d1 = dmap[dk + 1];
+                    uint32_t c0 = s_run[ck], c1 = s_run[ck + 2];
+                    uint32_t s = sym[j];
+                    asm volatile("" : "+v"(d0), "+v"(d1), "+v"(c0), "+v"(c1), "+v"(s));   // one wait for all of them, here
+                    const uint32_t dw = __builtin_amdgcn_alignbit(d1, d0, j & 31);       // bit t: position j + t starts a new run
+                    const uint32_t cw = __builtin_amdgcn_alignbit(c1, c0, node & 31);    // bit t: node + t has a continuation
+                    const uint32_t bm = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
+                    bool norep = dw & 1u;                                                // the symbol differs from the one this node was entered by
+                    if (INPUT != INPUT_F64) norep = norep || node == 0;                  // (the root: after an unmatched byte)
+                    const uint32_t bit = norep ? (1u << s) : ecgb::kContFlag;
+                    const bool ok = (bm & bit) != 0;
+                    const uint32_t child = (hi & 0xFFFFu) + (uint32_t)__popc(bm & (bit - 1u));
+                    const bool inchain = !norep && (int32_t)bm >= 0;                     // not the head of its chain: the continuation is node + 1
+                    const uint32_t stop = dw | ~cw;                                      // bit 0 is clear when the step is a chain step
+                    const uint32_t m = inchain ? min((uint32_t)__ffs(stop) - 1u, 32u) : 1u;
+                    const uint32_t nn = inchain ? node + m : child;
+                    if (ok) {
+                        node = nn;
+                        j += m;
                     } else {
-                        rec = (node < A.n_lds_nodes) ? s_trie[node] : A.trie[node];
-                        btok = (uint32_t)(((best_node < A.n_lds_nodes) ? s_trie[best_node] : A.trie[best_node]) >> 32);
-                    }
-                    const uint32_t dk = j >> 5, u = node + 1, rk = (u >> 5) * 2;
-                    const uint32_t d0 = dmap[dk], d1 = dmap[dk + 1];
-                    const uint2 r0 = *reinterpret_cast<const uint2 *>(s_run + rk), r1 = *reinterpret_cast<const uint2 *>(s_run + rk + 2);
-                    if (node == 0 && (claimed & rbit)) {
-                        live = false;                                                    // joined a parse that got here first
-                    } else {
-                        const uint32_t dw = __builtin_amdgcn_alignbit(d1, d0, j & 31);   // bit t: position j + t starts a new run
-                        const uint32_t bm = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
-                        const uint32_t fc = hi & 0xFFFFu;
-                        if ((hi >> 16) != ecgb::kNoToken) { best_j = j; best_node = node; btok = hi; }   // the root carries none
-                        bool advanced = false;
-                        if (node != 0 && !(dw & 1u)) {              // the symbol repeats the one this node was entered by
-                            if (bm & ecgb::kContFlag) {
-                                advanced = true;
-                                if (bm & ecgb::kHeadFlag) {
-                                    node = fc + __popc(bm & ecgb::kBranchMask);
-                                    ++j;
-                                } else {
-                                    const uint32_t cw = __builtin_amdgcn_alignbit(r1.x, r0.x, u & 31);
-                                    const uint32_t tw = __builtin_amdgcn_alignbit(r1.y, r0.y, u & 31);
-                                    const uint32_t z = min((uint32_t)__ffs(dw) - 1u, 32u);
-                                    const uint32_t ones = min((uint32_t)__ffs(~cw) - 1u, 32u);
-                                    const uint32_t m = min(z, ones + 1u);
-                                    const uint32_t passed = tw & ((1u << (m - 1u)) - 1u);
-                                    if (passed) {                      // its token word is fetched by the next trip
-                                        const uint32_t q = 31u - __clz(passed);
-                                        best_j = j + q + 1u;
-                                        best_node = u + q;
-                                    }
-                                    node += m;
-                                    j += m;
-                                }
-                            }
-                        } else {
-                            const uint32_t bit = 1u << s;
-                            if (bm & bit) {
-                                node = fc + __popc(bm & (bit - 1u));
-                                ++j;
-                                advanced = true;
-                            }
-                        }
-                        if (!advanced) {
-                            // emit the token [r, r + len): its id (kNoToken for an unmatched or single symbol)
-                            const uint32_t len = max(best_j - r, 1u);   // unmatched byte: lib.rs:186-189
-                            emit_word = r | (((len >= 2) ? (btok >> 16) : ecgb::kNoToken) << 16);
-                            emitting = true;
-                            r += len; j = r; node = 0; best_j = r; best_node = 0;
-                            live = r < seg_len;
+                        // emit the token that starts at r
+                        const uint32_t id = hi >> 16;
+                        uint32_t len;
+                        if (INPUT == INPUT_F64) len = s_len[id];                         // every stopped-at node has a best token
+                        else len = (id != ecgb::kNoToken) ? s_len[min(id, A.n_toklen - 1u)] : 1u;   // unmatched byte: lib.rs:186-189
+                        emit_word = r | (id << 16);
+                        emitting = true;
+                        r += len;
+                        live = r < seg_len;
+                        if (live) {
+                            const uint32_t rbit = 1u << (r & 31);
+                            const uint32_t claimed = atomicOr(&marks[r >> 5], rbit);
+                            const uint32_t s1 = sym[r];
+                            live = !(claimed & rbit);                                    // joined a parse that got here first
+                            node = 0; j = r;
+                            if (INPUT == INPUT_F64 || s1 != ecgb::kOtherClass) { node = 1u + s1; j = r + 1u; }
                         }
                     }
                     // the tokens of this trip are appended to the wave's list: consecutive 4-byte entries, one coalesced store
@@ -801,7 +785,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                 if (!(tb & bit)) continue;                                   // a speculative prefix, not on the real chain
                 const uint32_t slot = dmap[pos >> 5] + (uint32_t)__popc(tb & (bit - 1u));
                 uint32_t id = e >> 16;
-                if (id == ecgb::kNoToken) {                                  // single symbol: its byte still holds the class
+                if (id == ecgb::kNoToken) {                                  // unmatched byte: its byte still holds the class
                     const uint32_t cls = sym[pos];
                     if (INPUT == INPUT_BYTES && cls == ecgb::kOtherClass) id = A.raw[row + seg_base + pos];
                     else id = s_single[cls];

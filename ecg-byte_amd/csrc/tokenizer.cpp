@@ -4,7 +4,7 @@
 //
 // Layout choice (MI355X): the encode kernel walks the trie with one dependent lookup per
 // step, so a node must be ONE aligned 8-byte LDS/L2 read:
-//   branch-child bitmap (one bit per symbol class) + 2 flags | first-branch-child id | token id
+//   branch-child bitmap (one bit per symbol class) + 2 flags | first-branch-child id | best token id
 // Branch children (classes other than the one the node was entered by) are numbered
 // consecutively in class order:
 //   child(node, cls) = first + popcount(bitmap & ((1 << cls) - 1)).
@@ -152,6 +152,8 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
         }
         tok->nodes.resize(order.size());
         tok->runbits.assign(2 * (order.size() / 32 + 3), 0u);
+        std::vector<uint32_t> new_id(nb, 0), best(order.size(), kNoToken);   // best token on the path root..node, by new id
+        for (size_t i = 0; i < order.size(); ++i) new_id[order[i]] = (uint32_t)i;
         uint32_t max_depth = 0;
         for (size_t i = 0; i < order.size(); ++i) {
             const int32_t v = order[i];
@@ -174,7 +176,9 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
                 token = (uint32_t)n.token;
                 tok->runbits[2 * (i / 32) + 1] |= 1u << (i % 32);
             }
-            tok->nodes[i] = pack_node(bitmap, first_child[i], token);
+            // a parent is numbered before its children, so its best token is known
+            best[i] = (token != kNoToken || i == 0) ? token : best[new_id[parent[v]]];
+            tok->nodes[i] = pack_node(bitmap, first_child[i], best[i]);
             max_depth = std::max(max_depth, depth_old[v]);
         }
         tok->max_depth = max_depth;
@@ -184,10 +188,17 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
             for (size_t i = 0; i < n_merges; ++i) if (ids[i] < kNoToken) max_id = std::max(max_id, ids[i]);
             tok->tok_len.assign(((size_t)max_id + 1 + 7) & ~(size_t)7, 0);
             for (uint32_t b = 0; b < 256; ++b) tok->tok_len[b] = 1;
+            std::vector<uint8_t> seen(tok->tok_len.size(), 0);
+            bool ambiguous = false;   // one id on expansions of different lengths: the id does not tell the length
             for (size_t i = 0; i < order.size(); ++i) {
                 const int64_t t = bn[order[i]].token;
-                if (i != 0 && t >= 0) tok->tok_len[(size_t)t] = (uint8_t)depth_old[order[i]];
+                if (i == 0 || t < 0) continue;
+                const uint8_t d = (uint8_t)depth_old[order[i]];
+                if (seen[(size_t)t] && tok->tok_len[(size_t)t] != d) ambiguous = true;
+                seen[(size_t)t] = 1;
+                tok->tok_len[(size_t)t] = d;
             }
+            if (ambiguous) tok->tok_len.clear();   // the encoder then takes the kernel that does not use the table
         }
         // root children are nodes 1..n_classes in class order
         for (uint32_t c = 0; c < 32; ++c) { tok->single_id[c] = 0; if (c >= n_classes) tok->class_to_byte[c] = 0; }

@@ -12,15 +12,19 @@ constexpr uint32_t kMaxClasses = 29;      // usable symbol classes (bits 0..28 o
 constexpr uint32_t kOtherClass = 29;      // byte that occurs in no expansion and is not a..z; also the
                                           // end-of-stream sentinel: bit 29 is never set in any bitmap
 constexpr uint32_t kNoToken = 0xFFFFu;    // node carries no token id
-constexpr uint32_t kHeadFlag = 1u << 30;  // node was entered by a different class than its parent was (or from the root)
-constexpr uint32_t kContFlag = 1u << 31;  // node has a child of the class it was entered by (its "continuation")
+constexpr uint32_t kContFlag = 1u << 30;  // node has a child of the class it was entered by (its "continuation")
+constexpr uint32_t kHeadFlag = 1u << 31;  // node was entered by a different class than its parent was (or from the root)
 constexpr uint32_t kBranchMask = (1u << 30) - 1u;
 
 // Device trie node, 8 bytes:
 //   [28:0]  bitmap of the BRANCH children: classes other than the one the node was entered by
-//   [30]    kHeadFlag, [31] kContFlag
+//   [30]    kContFlag, [31] kHeadFlag   (kContFlag - 1 == kBranchMask: the continuation child of a head is "the child of
+//           class 30", after every branch child, by the same bitmap + popcount formula)
 //   [47:32] id of the first branch child (branch children are consecutive, in class order)
-//   [63:48] token id carried by the node (kNoToken if none)
+//   [63:48] BEST token of the node: the id carried by the deepest token-carrying node on the path root..node (the node
+//           itself if it carries one), kNoToken if there is none (the root).  This is what lib.rs:170-189 emits when its
+//           walk stops at this node, so a walk does not have to remember the last token it passed; which nodes carry a
+//           token THEMSELVES is the second bit table of `runbits`.
 // The continuation child of a head node sits right after its branch children
 // (first + popcount(bitmap)), followed by the rest of the same-class chain: for every other
 // node the continuation child is node + 1.  A run of equal symbols therefore walks consecutive
@@ -41,6 +45,7 @@ struct ecgb_tokenizer {
                                        // two zero pairs of padding (the kernel reads a 64-node window past any node)
     std::vector<uint8_t> tok_len;      // token id -> expansion length (1 for the byte tokens; 0 = id not in the vocabulary),
                                        // padded to a multiple of 8 entries; empty if some expansion is longer than 255
+                                       // or one id stands for expansions of different lengths
     uint8_t byte_to_class[256];        // raw byte -> symbol class (kOtherClass if none)
     uint16_t single_id[32];            // token id of the length-1 match of each class
     uint8_t class_to_byte[32];

@@ -55,7 +55,7 @@ def _nodes(lib, h):
     return out
 
 
-HEAD, CONT, BRANCH = 1 << 30, 1 << 31, (1 << 30) - 1
+CONT, HEAD, BRANCH = 1 << 30, 1 << 31, (1 << 30) - 1
 OTHER = 29
 
 
@@ -70,61 +70,54 @@ def _ctz32(x):
     return 32 if x == 0 else (x & -x).bit_length() - 1
 
 
-def _walk_packed(nodes, byte_to_class, text, runbits=None):
-    """Greedy longest match over the packed device trie -- mirrors walk_chunk's step in encode.hip: a branch step by the
-    child bitmap, a continuation step when the symbol repeats the previous one, and (with `runbits`) the run step that
-    takes up to 32 equal symbols along a same-class chain at once."""
+def _walk_packed(nodes, byte_to_class, text, lens, runbits=None):
+    """Greedy longest match over the packed device trie -- mirrors the step of encode_flow_kernel in encode.hip: "the
+    symbol repeats" selects the continuation flag instead of the class bit, the child comes from bitmap + popcount either
+    way, inside a same-class chain (with `runbits`) the step takes up to 32 equal symbols at once, and when the step fails
+    the token is the stopped-at node's BEST token (its length from the id -> length table `lens`)."""
     out, i, n = [], 0, len(text)
     nodes = [int(v) for v in nodes]
     cls = [byte_to_class.get(b, OTHER) for b in text] + [OTHER] * 40
-    diff = [1] + [int(cls[k] != cls[k - 1]) for k in range(1, len(cls))]     # the kernel's D bitmap
+    diff = [1] + [int(cls[k] != cls[k - 1]) for k in range(1, len(cls))]     # the kernel's change map
     rb = [int(v) for v in runbits] if runbits is not None else None
     while i < n:
-        node, j, best_j, best_node = 0, i, i, 0
+        node, j = 0, i
         while True:
             rec = nodes[node]
             bm, fc, tok = rec & 0xFFFFFFFF, (rec >> 32) & 0xFFFF, rec >> 48
-            if tok != 0xFFFF:
-                best_j, best_node = j, node
-            if node != 0 and diff[j] == 0:                      # the symbol repeats the one this node was entered by
-                if not bm & CONT:
-                    break
-                if bm & HEAD:
-                    node = fc + bin(bm & BRANCH).count("1")
-                    j += 1
-                elif rb is None:
-                    node += 1
-                    j += 1
-                else:
-                    z = 0
-                    while z < 32 and diff[j + z] == 0:
-                        z += 1
-                    u = node + 1
-                    k, sh = u >> 5, u & 31
-                    cw = ((rb[2 * k] | (rb[2 * k + 2] << 32)) >> sh) & 0xFFFFFFFF
-                    tw = ((rb[2 * k + 1] | (rb[2 * k + 3] << 32)) >> sh) & 0xFFFFFFFF
-                    ones = _ctz32(~cw & 0xFFFFFFFF)
-                    m = min(z, 1 + ones, 32)
-                    passed = tw & ((1 << (m - 1)) - 1)
-                    if passed:
-                        q = passed.bit_length() - 1
-                        best_j, best_node = j + q + 1, node + 1 + q
-                    node += m
-                    j += m
-                continue
-            c = cls[j]
-            if j < n and c < OTHER and (bm >> c) & 1:
-                node = fc + bin(bm & ((1 << c) - 1)).count("1")
+            norep = node == 0 or diff[j] == 1
+            bit = (1 << cls[j]) if norep else CONT
+            if not bm & bit:
+                break
+            inchain = not norep and not bm & HEAD
+            if not inchain:
+                node = fc + bin(bm & (bit - 1)).count("1")
                 j += 1
-                continue
-            break
-        if best_j == i:
+            elif rb is None:
+                node += 1
+                j += 1
+            else:
+                k, sh = node >> 5, node & 31
+                cw = ((rb[2 * k] | (rb[2 * k + 2] << 32)) >> sh) & 0xFFFFFFFF
+                dw = sum(diff[j + t] << t for t in range(32))
+                m = min(_ctz32((dw | ~cw) & 0xFFFFFFFF), 32)
+                assert m >= 1
+                node += m
+                j += m
+        if tok == 0xFFFF:                                       # only the root has no best token: unmatched byte
+            assert node == 0
             out.append(text[i])
             i += 1
         else:
-            out.append(nodes[best_node] >> 48)
-            i = best_j
+            out.append(tok)
+            i += lens[tok]
     return out
+
+
+def _lens(merges):
+    lens = {b: 1 for b in range(256)}
+    lens.update({tid: len(seq) for seq, tid in merges})
+    return lens
 
 
 def _classes(merges):
@@ -145,22 +138,38 @@ def test_packed_trie_reproduces_oracle(lib, seed):
     try:
         nodes = _nodes(lib, h)
         rb = _runbits(lib, h)
-        for u in range(nodes.size):       # the bit tables restate the node flags
-            assert (int(rb[2 * (u >> 5)]) >> (u & 31)) & 1 == (int(nodes[u]) >> 31) & 1
-            assert (int(rb[2 * (u >> 5) + 1]) >> (u & 31)) & 1 == int((int(nodes[u]) >> 48) != 0xFFFF)
+        own = [(int(rb[2 * (u >> 5) + 1]) >> (u & 31)) & 1 for u in range(nodes.size)]
+        for u in range(nodes.size):       # the first bit table restates the continuation flag
+            assert (int(rb[2 * (u >> 5)]) >> (u & 31)) & 1 == (int(nodes[u]) >> 30) & 1
+        # a node's token field is its own token if it carries one (second bit table), else its parent's field
+        assert int(nodes[0]) >> 48 == 0xFFFF and not own[0]
+        seen = 1
+        for u in range(nodes.size):
+            bm, fc = int(nodes[u]) & 0xFFFFFFFF, (int(nodes[u]) >> 32) & 0xFFFF
+            kids = [fc + k for k in range(bin(bm & BRANCH).count("1"))]
+            if bm & CONT:
+                kids.append(fc + len(kids) if (bm & HEAD) else u + 1)
+            for v in kids:
+                seen += 1
+                if not own[v]:
+                    assert int(nodes[v]) >> 48 == int(nodes[u]) >> 48
+        assert seen == nodes.size
+        ids_in_trie = {int(nodes[u]) >> 48 for u in range(nodes.size) if own[u]}
+        assert ids_in_trie <= set(_lens(merges))
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         assert lib.ecgb_tokenizer_info(h, C.byref(a), C.byref(b), C.byref(c)) == 0
         assert a.value == nodes.size and b.value == max(len(m[0]) for m in merges)
         b2c = _classes(merges)
+        lens = _lens(merges)
         assert c.value == len(b2c)
         for _ in range(10):
             pool = np.frombuffer(alphabet + b"qz~", dtype=np.uint8)
             text = bytes(rng.choice(pool, size=int(rng.integers(0, 500))))
             want = O.encode_text(text, merges)
-            assert _walk_packed(nodes, b2c, text) == want
-            assert _walk_packed(nodes, b2c, text, rb) == want
+            assert _walk_packed(nodes, b2c, text, lens) == want
+            assert _walk_packed(nodes, b2c, text, lens, rb) == want
             runs = b"".join(bytes([rng.choice(pool)]) * int(rng.integers(1, 70)) for _ in range(40))   # long runs: the run step
-            assert _walk_packed(nodes, b2c, runs, rb) == O.encode_text(runs, merges)
+            assert _walk_packed(nodes, b2c, runs, lens, rb) == O.encode_text(runs, merges)
     finally:
         lib.ecgb_tokenizer_destroy(h)
 
@@ -175,8 +184,8 @@ def test_packed_trie_fixture_tokenizer(lib):
     lib.ecgb_tokenizer_destroy(h)
     x = synth.synth_ecg(1, 1000, seed=0)
     text = O.symbols_to_text(O.quantize(x[0], pc["percentile_1"], pc["percentile_99"]))[:3000]
-    assert _walk_packed(nodes, _classes(merges), text) == O.encode_text(text, merges)
-    assert _walk_packed(nodes, _classes(merges), text, rb) == O.encode_text(text, merges)
+    assert _walk_packed(nodes, _classes(merges), text, _lens(merges)) == O.encode_text(text, merges)
+    assert _walk_packed(nodes, _classes(merges), text, _lens(merges), rb) == O.encode_text(text, merges)
 
 
 def test_tokenizer_limits_are_reported(lib):
