@@ -233,6 +233,7 @@ unsigned long long *g_prof_dev = nullptr;
 
 constexpr int INPUT_F64 = 0, INPUT_BYTES = 1;
 constexpr uint32_t kLenBias = 30;          // flow kernel: a symbol byte >= kLenBias holds kLenBias + the length of the token that starts there
+constexpr uint32_t kListRegs = 8;          // flow kernel: token-list entries a lane keeps in registers between its two sweeps
 constexpr size_t kFlowSlot = 8192;         // token-list entries (u32: position | id << 16) per resident wave of the flow kernel: one segment
 
 // clear bits [lo, hi) of a lane-owned run of mark words (segment-relative bit indices)
@@ -270,17 +271,18 @@ __device__ __forceinline__ void stage_symbols(uint8_t *sym, uint32_t stage_len, 
                                               const double *s_thr, const uint8_t *s_b2c)
 {
     if (INPUT == INPUT_F64) {
-        // whole groups of 4 samples inside the record: vector path, 4 groups (8 x 16-byte loads)
-        // in flight per lane before the first use
+        // whole groups of 4 samples inside the record: vector path, 4 groups (8 x 16-byte loads) in flight per lane
+        // before the first use.  The last, partial batch runs the same code: groups past the end re-read the last
+        // group and are not stored (one memory latency per batch of 4 * nlanes groups, none per leftover group).
         const uint32_t vec_len = VEC ? (min(stage_len, n_here) & ~3u) : 0u;
         const uint32_t step = nlanes * 4;
-        uint32_t k = lane * 4;
-        for (; k + 3 * step < vec_len; k += 4 * step) {
+        for (uint32_t k = lane * 4; k < vec_len; k += 4 * step) {
             double2 v[8];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                v[2 * u] = *reinterpret_cast<const double2 *>(x + k + u * step);
-                v[2 * u + 1] = *reinterpret_cast<const double2 *>(x + k + u * step + 2);
+                const uint32_t ku = min(k + u * step, vec_len - 4);
+                v[2 * u] = *reinterpret_cast<const double2 *>(x + ku);
+                v[2 * u + 1] = *reinterpret_cast<const double2 *>(x + ku + 2);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -288,17 +290,8 @@ __device__ __forceinline__ void stage_symbols(uint8_t *sym, uint32_t stage_len, 
                 w |= level_fast(v[2 * u].y, qa, qscale, s_thr) << 8;
                 w |= level_fast(v[2 * u + 1].x, qa, qscale, s_thr) << 16;
                 w |= level_fast(v[2 * u + 1].y, qa, qscale, s_thr) << 24;
-                *reinterpret_cast<uint32_t *>(sym + swz<CHUNK>(k + u * step)) = w;
+                if (k + u * step < vec_len) *reinterpret_cast<uint32_t *>(sym + swz<CHUNK>(k + u * step)) = w;
             }
-        }
-        for (; k < vec_len; k += step) {
-            const double2 v0 = *reinterpret_cast<const double2 *>(x + k);
-            const double2 v1 = *reinterpret_cast<const double2 *>(x + k + 2);
-            uint32_t w = level_fast(v0.x, qa, qscale, s_thr);
-            w |= level_fast(v0.y, qa, qscale, s_thr) << 8;
-            w |= level_fast(v1.x, qa, qscale, s_thr) << 16;
-            w |= level_fast(v1.y, qa, qscale, s_thr) << 24;
-            *reinterpret_cast<uint32_t *>(sym + swz<CHUNK>(k)) = w;
         }
         // the rest (record tail, odd/unaligned rows, sentinel padding) one sample at a time
         for (uint32_t kk = vec_len + lane * 4; kk < stage_len; kk += step) {
@@ -721,7 +714,17 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                 const uint32_t v = (WPL * c + k < MARKW) ? marks[WPL * c + k] : 0u;
                 if (v) first_claimed = pbase + 32 * k + (uint32_t)__ffs(v) - 1u;
             }
-            for (uint32_t i = c; i < n_list; i += 64) {   // token lengths into the symbol bytes: coalesced reads of the list
+            // the first kListRegs * 64 entries of the list (all of it unless the segment is mostly two-symbol tokens) are read
+            // once, all loads in flight together, and stay in registers for both sweeps
+            uint32_t ent[kListRegs];
+#pragma unroll
+            for (uint32_t k = 0; k < kListRegs; ++k) ent[k] = (c + 64 * k < n_list) ? tok_list[c + 64 * k] : 0xFFFFFFFFu;
+#pragma unroll
+            for (uint32_t k = 0; k < kListRegs; ++k) {   // token lengths into the symbol bytes
+                const uint32_t id = ent[k] >> 16;
+                if (id != ecgb::kNoToken) sym[ent[k] & 0xFFFFu] = (uint8_t)(kLenBias + s_len[id]);
+            }
+            for (uint32_t i = c + 64 * kListRegs; i < n_list; i += 64) {
                 const uint32_t e = tok_list[i], id = e >> 16;
                 if (id != ecgb::kNoToken) sym[e & 0xFFFFu] = (uint8_t)(kLenBias + s_len[id]);
             }
@@ -779,10 +782,10 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = c; i < n_list; i += 64) {
-                const uint32_t e = tok_list[i], pos = e & 0xFFFFu;
+            auto place = [&](uint32_t e) {
+                const uint32_t pos = e & 0xFFFFu;
                 const uint32_t tb = marks[pos >> 5], bit = 1u << (pos & 31);
-                if (!(tb & bit)) continue;                                   // a speculative prefix, not on the real chain
+                if (!(tb & bit)) return;                                     // a speculative prefix, not on the real chain
                 const uint32_t slot = dmap[pos >> 5] + (uint32_t)__popc(tb & (bit - 1u));
                 uint32_t id = e >> 16;
                 if (id == ecgb::kNoToken) {                                  // unmatched byte: its byte still holds the class
@@ -791,7 +794,11 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                     else id = s_single[cls];
                 }
                 if (slot < A.ids_stride) out[slot] = id;
-            }
+            };
+#pragma unroll
+            for (uint32_t k = 0; k < kListRegs; ++k)
+                if (c + 64 * k < n_list) place(ent[k]);
+            for (uint32_t i = c + 64 * kListRegs; i < n_list; i += 64) place(tok_list[i]);
             out_off += total;
             carry = seg_base + carry_out_rel;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
