@@ -233,8 +233,25 @@ unsigned long long *g_prof_dev = nullptr;
 
 constexpr int INPUT_F64 = 0, INPUT_BYTES = 1;
 constexpr uint32_t kLenBias = 30;          // flow kernel: a symbol byte >= kLenBias holds kLenBias + the length of the token that starts there
+constexpr int kStageGroups = 5;             // groups of 4 samples a lane loads before it classifies the first (C2: 3 batches per segment)
 constexpr uint32_t kListRegs = 8;          // flow kernel: token-list entries a lane keeps in registers between its two sweeps
 constexpr size_t kFlowSlot = 8192;         // token-list entries (u32: position | id << 16) per resident wave of the flow kernel: one segment
+
+// LDS byte address of word (i >> 5) of a table of 1 << SHIFT bytes per 32 entries: two instructions (the compiler's own
+// shift / mask / add sequence for the same expression is three; the parse loop of the flow kernel issues it twice a trip).
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+template <int SHIFT>
+__device__ __forceinline__ lds_cu32 *lds_word32(uint32_t i, uint32_t table_addr)
+{
+    uint32_t t, a;
+    asm("v_lshrrev_b32 %0, 5, %1" : "=v"(t) : "v"(i));
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(a) : "v"(t), "n"(SHIFT), "v"(table_addr));
+    return reinterpret_cast<lds_cu32 *>(a);
+}
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
 
 // clear bits [lo, hi) of a lane-owned run of mark words (segment-relative bit indices)
 __device__ __forceinline__ void clear_bits(uint32_t *marks, uint32_t lo, uint32_t hi)
@@ -271,21 +288,21 @@ __device__ __forceinline__ void stage_symbols(uint8_t *sym, uint32_t stage_len, 
                                               const double *s_thr, const uint8_t *s_b2c)
 {
     if (INPUT == INPUT_F64) {
-        // whole groups of 4 samples inside the record: vector path, 4 groups (8 x 16-byte loads) in flight per lane
+        // whole groups of 4 samples inside the record: vector path, kStageGroups groups (2 x 16-byte loads each) in flight per lane
         // before the first use.  The last, partial batch runs the same code: groups past the end re-read the last
-        // group and are not stored (one memory latency per batch of 4 * nlanes groups, none per leftover group).
+        // group and are not stored (one memory latency per batch of kStageGroups * nlanes groups, none per leftover group).
         const uint32_t vec_len = VEC ? (min(stage_len, n_here) & ~3u) : 0u;
         const uint32_t step = nlanes * 4;
-        for (uint32_t k = lane * 4; k < vec_len; k += 4 * step) {
-            double2 v[8];
+        for (uint32_t k = lane * 4; k < vec_len; k += kStageGroups * step) {
+            double2 v[2 * kStageGroups];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kStageGroups; ++u) {
                 const uint32_t ku = min(k + u * step, vec_len - 4);
                 v[2 * u] = *reinterpret_cast<const double2 *>(x + ku);
                 v[2 * u + 1] = *reinterpret_cast<const double2 *>(x + ku + 2);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kStageGroups; ++u) {
                 uint32_t w = level_fast(v[2 * u].x, qa, qscale, s_thr);
                 w |= level_fast(v[2 * u].y, qa, qscale, s_thr) << 8;
                 w |= level_fast(v[2 * u + 1].x, qa, qscale, s_thr) << 16;
@@ -637,6 +654,8 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                 uint32_t r = (c == 0) ? carry_rel : max(my_start, carry_rel);   // chunks the carry token covers start at the carry
                 uint32_t j = r, node = 0;
                 bool live = r < seg_len;
+                const uint32_t dmap_a = lds_addr(dmap), run_a = lds_addr(s_run), marks_a = lds_addr(marks);
+                uint32_t n_app = 0;                                             // entries appended so far (wave-uniform)
                 if (live) {
                     const uint32_t rbit = 1u << (r & 31);
                     const uint32_t claimed = atomicOr(&marks[r >> 5], rbit);
@@ -645,19 +664,17 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                     if (INPUT == INPUT_F64 || s0 != ecgb::kOtherClass) { node = 1u + s0; j = r + 1u; }
                 }
                 while (live) {
-                    uint32_t emit_word = 0;
-                    bool emitting = false;
 #ifdef ECGB_PROFILE
                     if (A.prof && c == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&A.prof[blockIdx.x * 8 + 5], 1ull);
 #endif
                     uint64_t rec;
                     if constexpr (ALL_LDS) rec = s_trie[node];
                     else rec = (node < A.n_lds_nodes) ? s_trie[node] : A.trie[node];
-                    const uint32_t dk = j >> 5, ck = (node >> 5) * 2;
-                    uint32_t d0 = dmap[dk], d1 = dmap[dk + 1];
-                    uint32_t c0 = s_run[ck], c1 = s_run[ck + 2];
-                    uint32_t s = sym[j];
-                    asm volatile("" : "+v"(d0), "+v"(d1), "+v"(c0), "+v"(c1), "+v"(s));   // one wait for all of them, here
+                    lds_cu32 *dp = lds_word32<2>(j, dmap_a), *cp = lds_word32<3>(node, run_a);
+                    const uint32_t d0 = dp[0], d1 = dp[1];
+                    const uint32_t c0 = cp[0], c1 = cp[2];
+                    const uint32_t s = sym[j];
+                    asm volatile("" :: "v"(d0), "v"(d1), "v"(c0), "v"(c1), "v"(s));   // one wait for all of them, here
                     const uint32_t dw = __builtin_amdgcn_alignbit(d1, d0, j & 31);       // bit t: position j + t starts a new run
                     const uint32_t cw = __builtin_amdgcn_alignbit(c1, c0, node & 31);    // bit t: node + t has a continuation
                     const uint32_t bm = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
@@ -665,6 +682,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                     if (INPUT != INPUT_F64) norep = norep || node == 0;                  // (the root: after an unmatched byte)
                     const uint32_t bit = norep ? (1u << s) : ecgb::kContFlag;
                     const bool ok = (bm & bit) != 0;
+                    const unsigned long long em = __ballot(!ok);                         // the lanes that emit a token in this trip
                     const uint32_t child = (hi & 0xFFFFu) + (uint32_t)__popc(bm & (bit - 1u));
                     const bool inchain = !norep && (int32_t)bm >= 0;                     // not the head of its chain: the continuation is node + 1
                     const uint32_t stop = dw | ~cw;                                      // bit 0 is clear when the step is a chain step
@@ -674,33 +692,28 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                         node = nn;
                         j += m;
                     } else {
-                        // emit the token that starts at r
+                        // emit the token that starts at r: appended to the wave's list (consecutive 4-byte entries, one
+                        // coalesced store per trip)
                         const uint32_t id = hi >> 16;
                         uint32_t len;
                         if (INPUT == INPUT_F64) len = s_len[id];                         // every stopped-at node has a best token
                         else len = (id != ecgb::kNoToken) ? s_len[min(id, A.n_toklen - 1u)] : 1u;   // unmatched byte: lib.rs:186-189
-                        emit_word = r | (id << 16);
-                        emitting = true;
+                        tok_list[n_app + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u))] = r | (id << 16);
                         r += len;
                         live = r < seg_len;
                         if (live) {
                             const uint32_t rbit = 1u << (r & 31);
-                            const uint32_t claimed = atomicOr(&marks[r >> 5], rbit);
+                            const uint32_t claimed = atomicOr(const_cast<uint32_t *>((const uint32_t *)lds_word32<2>(r, marks_a)), rbit);
                             const uint32_t s1 = sym[r];
                             live = !(claimed & rbit);                                    // joined a parse that got here first
                             node = 0; j = r;
                             if (INPUT == INPUT_F64 || s1 != ecgb::kOtherClass) { node = 1u + s1; j = r + 1u; }
                         }
                     }
-                    // the tokens of this trip are appended to the wave's list: consecutive 4-byte entries, one coalesced store
-                    const unsigned long long em = __ballot(emitting);
-                    if (emitting) tok_list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u))] = emit_word;
-                    n_list += (uint32_t)__popcll(em);
+                    n_app += (uint32_t)__popcll(em);
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) n_list = max(n_list, (uint32_t)__shfl_xor(n_list, d, 64));   // lanes that left early counted less
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // list entries other lanes stored are read below (same CU, same L1)
             __builtin_amdgcn_wave_barrier();
             PROF_STAMP(1);
@@ -713,7 +726,12 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             for (uint32_t k = WPL; k-- > 0;) {
                 const uint32_t v = (WPL * c + k < MARKW) ? marks[WPL * c + k] : 0u;
                 if (v) first_claimed = pbase + 32 * k + (uint32_t)__ffs(v) - 1u;
+                n_list += (uint32_t)__popc(v);
             }
+            // every claimed position got exactly one list entry (its claimant emitted the token that starts there), so the
+            // length of the list is the population of the claim bitmap -- the parse loop keeps its own count in a scalar
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) n_list += (uint32_t)__shfl_xor(n_list, d, 64);
             // the first kListRegs * 64 entries of the list (all of it unless the segment is mostly two-symbol tokens) are read
             // once, all loads in flight together, and stay in registers for both sweeps
             uint32_t ent[kListRegs];
