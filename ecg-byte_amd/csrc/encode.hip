@@ -674,10 +674,16 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                     const uint32_t d0 = dp[0], d1 = dp[1];
                     const uint32_t c0 = cp[0], c1 = cp[2];
                     const uint32_t s = sym[j];
-                    asm volatile("" :: "v"(d0), "v"(d1), "v"(c0), "v"(c1), "v"(s));   // one wait for all of them, here
+                    const uint32_t bm = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
+                    // the length of the node's best token is fetched for every lane as soon as the node record is in (it is
+                    // issued first and LDS answers in order): a trip that emits finds it there instead of waiting for it
+                    const uint32_t id = hi >> 16;
+                    uint32_t len;
+                    if (INPUT == INPUT_F64) len = s_len[id];                             // every node below the root has a best token
+                    else len = s_len[min(id, A.n_toklen - 1u)];
+                    asm volatile("" :: "v"(d0), "v"(d1), "v"(c0), "v"(c1), "v"(s));   // one wait for the rest, here
                     const uint32_t dw = __builtin_amdgcn_alignbit(d1, d0, j & 31);       // bit t: position j + t starts a new run
                     const uint32_t cw = __builtin_amdgcn_alignbit(c1, c0, node & 31);    // bit t: node + t has a continuation
-                    const uint32_t bm = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
                     bool norep = dw & 1u;                                                // the symbol differs from the one this node was entered by
                     if (INPUT != INPUT_F64) norep = norep || node == 0;                  // (the root: after an unmatched byte)
                     const uint32_t bit = norep ? (1u << s) : ecgb::kContFlag;
@@ -694,10 +700,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                     } else {
                         // emit the token that starts at r: appended to the wave's list (consecutive 4-byte entries, one
                         // coalesced store per trip)
-                        const uint32_t id = hi >> 16;
-                        uint32_t len;
-                        if (INPUT == INPUT_F64) len = s_len[id];                         // every stopped-at node has a best token
-                        else len = (id != ecgb::kNoToken) ? s_len[min(id, A.n_toklen - 1u)] : 1u;   // unmatched byte: lib.rs:186-189
+                        if (INPUT != INPUT_F64 && id == ecgb::kNoToken) len = 1u;       // unmatched byte: lib.rs:186-189
                         tok_list[n_app + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u))] = r | (id << 16);
                         r += len;
                         live = r < seg_len;
@@ -992,11 +995,11 @@ Plan make_plan(const ecgb_tokenizer *tok, size_t batch)
         p.chunk = 34;
         bool found = false;
         // 16 waves per CU with 3 456-symbol segments finish a round of records in ~1.0 time units, 8 waves per CU with
-        // segments twice as long in ~0.6 (measured on C2: fewer loop trips per record, but half the waves to hide
+        // segments twice as long in ~0.62 (measured on C2: fewer loop trips per record, but half the waves to hide
         // latency): take whichever needs less time for this batch's rounds -- e.g. 8 waves when the batch holds at most
         // 8 records per CU, 16 waves when it holds 9..16.
         const size_t per_cu = (batch + cus - 1) / cus;
-        const double t16 = (double)((per_cu + 15) / 16) * 1.0, t8 = (double)((per_cu + 7) / 8) * 0.6;
+        const double t16 = (double)((per_cu + 15) / 16) * 1.0, t8 = (double)((per_cu + 7) / 8) * 0.62;
         const bool prefer8 = (g_plan_mode == 3) || (g_plan_mode == 0 && t8 < t16);
         for (size_t w : {(size_t)16, (size_t)12, (size_t)8}) {
             if (prefer8 && w != 8) continue;
