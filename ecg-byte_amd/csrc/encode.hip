@@ -134,6 +134,35 @@ __device__ __forceinline__ uint32_t level_fast(double x, double a, double scale,
     return (uint32_t)b;
 }
 
+// Four levels at once, packed one per byte, for the staging loops of the encode kernels.  q is rounded to float first:
+// for 0 <= q < 26 the rounding moves it by < 2e-6, so unless its fraction lies within 1e-4 of an integer, floor(q) is the
+// same in float as in double and the argument of level_fast applies; clamping in float (NaN -> 0 by the IEEE max) and the
+// truncating convert replace the double-precision floor / compares.  The (rare) group with an ambiguous sample is redone
+// from the exact staircase: one branch per four samples.
+__device__ __forceinline__ uint32_t level_f32(double x, double a, double scale, bool &amb)
+{
+    const float qf = (float)((x - a) * scale);
+    const float t = __builtin_amdgcn_fractf(qf);
+    amb = amb || (fabsf(t - 0.5f) > 0.5f - 1e-4f);
+    return (uint32_t)(int)fminf(fmaxf(qf, 0.0f), 25.5f);
+}
+
+__device__ __forceinline__ uint32_t levels4(double2 v0, double2 v1, double a, double scale, const double *thr)
+{
+    bool amb = false;
+    uint32_t w = level_f32(v0.x, a, scale, amb);
+    w |= level_f32(v0.y, a, scale, amb) << 8;
+    w |= level_f32(v1.x, a, scale, amb) << 16;
+    w |= level_f32(v1.y, a, scale, amb) << 24;
+    if (amb) {
+        w = level_from_thresholds(v0.x, a, scale, thr);
+        w |= level_from_thresholds(v0.y, a, scale, thr) << 8;
+        w |= level_from_thresholds(v1.x, a, scale, thr) << 16;
+        w |= level_from_thresholds(v1.y, a, scale, thr) << 24;
+    }
+    return w;
+}
+
 // Records are rows: record r reads x + r*n and writes sym + r*sym_stride (blockIdx.y strides
 // over records, blockIdx.x/threads over the row).  Vector variant: n % 4 == 0 and 16-byte
 // aligned x, four samples per thread per iteration, one 4-byte store.
@@ -303,10 +332,7 @@ __device__ __forceinline__ void stage_symbols(uint8_t *sym, uint32_t stage_len, 
             }
 #pragma unroll
             for (int u = 0; u < kStageGroups; ++u) {
-                uint32_t w = level_fast(v[2 * u].x, qa, qscale, s_thr);
-                w |= level_fast(v[2 * u].y, qa, qscale, s_thr) << 8;
-                w |= level_fast(v[2 * u + 1].x, qa, qscale, s_thr) << 16;
-                w |= level_fast(v[2 * u + 1].y, qa, qscale, s_thr) << 24;
+                const uint32_t w = levels4(v[2 * u], v[2 * u + 1], qa, qscale, s_thr);
                 if (k + u * step < vec_len) *reinterpret_cast<uint32_t *>(sym + swz<CHUNK>(k + u * step)) = w;
             }
         }
@@ -751,6 +777,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            PROF_STAMP(6);
 
             auto follow = [&](uint32_t p, unsigned long long &lo, unsigned long long &hi) {   // length pointers through this lane's block
                 lo = 0; hi = 0;
@@ -766,6 +793,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             uint32_t entry = (c == 0) ? carry_rel : first_claimed;
             entry = max(entry, s_blk);
             uint32_t my_exit = follow(entry, chain, chain_hi);
+            PROF_STAMP(7);
             for (;;) {
                 const uint32_t prev = __shfl_up(my_exit, 1, 64);
                 const uint32_t want = (c == 0) ? carry_rel : prev;

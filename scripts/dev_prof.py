@@ -22,6 +22,6 @@ tk.quantize_encode(xd, pc); torch.cuda.synchronize()
 L.ecgb_debug_set_profile_buffer(C.c_void_p(prof.data_ptr()))
 tk.quantize_encode(xd, pc); torch.cuda.synchronize()
 p = prof.cpu().numpy().reshape(nwg, 8)
-names = ["stage", "pass0", "stitch", "emit", "passes", "it_first", "it_stitch"]
+names = ["stage", "parse", "resolve_passes", "emit", "passes", "trips", "resolve_sweep", "resolve_first_follow"]
 for k, nm in enumerate(names):
     print(f"{nm:12s} mean {p[:,k].mean():12.0f}  min {p[:,k].min():10d}  max {p[:,k].max():10d}")
