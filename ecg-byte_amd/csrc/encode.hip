@@ -277,6 +277,15 @@ __device__ __forceinline__ lds_cu32 *lds_word32(uint32_t i, uint32_t table_addr)
     asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(a) : "v"(t), "n"(SHIFT), "v"(table_addr));
     return reinterpret_cast<lds_cu32 *>(a);
 }
+// the same for a table every wave shares: its address is a scalar operand
+template <int SHIFT>
+__device__ __forceinline__ lds_cu32 *lds_word32_uniform(uint32_t i, uint32_t table_addr)
+{
+    uint32_t t, a;
+    asm("v_lshrrev_b32 %0, 5, %1" : "=v"(t) : "v"(i));
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(a) : "v"(t), "n"(SHIFT), "s"(table_addr));
+    return reinterpret_cast<lds_cu32 *>(a);
+}
 __device__ __forceinline__ uint32_t lds_addr(const void *p)
 {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
@@ -585,7 +594,8 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
     uint32_t *marks = s_marks_all + wave * MARKW;
     uint32_t *dmap = s_dmap_all + wave * dmap_words;
     const uint32_t gw = blockIdx.x * n_waves + wave, total_waves = gridDim.x * n_waves;
-    uint32_t *tok_list = reinterpret_cast<uint32_t *>(A.ids_half) + (size_t)gw * kFlowSlot;
+    // (the wave's list base as a scalar: list stores then take the base + 32-bit offset form)
+    uint32_t *tok_list = reinterpret_cast<uint32_t *>(A.ids_half) + (size_t)__builtin_amdgcn_readfirstlane(gw) * kFlowSlot;
     const uint32_t n = A.n;
     const double qa = A.qp.a, qscale = A.qp.scale;
 #ifdef ECGB_PROFILE
@@ -680,7 +690,9 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                 uint32_t r = (c == 0) ? carry_rel : max(my_start, carry_rel);   // chunks the carry token covers start at the carry
                 uint32_t j = r, node = 0;
                 bool live = r < seg_len;
-                const uint32_t dmap_a = lds_addr(dmap), run_a = lds_addr(s_run), marks_a = lds_addr(marks);
+                uint32_t dmap_a = lds_addr(dmap), marks_a = lds_addr(marks);
+                asm volatile("" : "+v"(dmap_a), "+v"(marks_a));             // (kept in registers, not recomputed every trip)
+                const uint32_t run_a = __builtin_amdgcn_readfirstlane(lds_addr(s_run));
                 uint32_t n_app = 0;                                             // entries appended so far (wave-uniform)
                 if (live) {
                     const uint32_t rbit = 1u << (r & 31);
@@ -696,7 +708,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                     uint64_t rec;
                     if constexpr (ALL_LDS) rec = s_trie[node];
                     else rec = (node < A.n_lds_nodes) ? s_trie[node] : A.trie[node];
-                    lds_cu32 *dp = lds_word32<2>(j, dmap_a), *cp = lds_word32<3>(node, run_a);
+                    lds_cu32 *dp = lds_word32<2>(j, dmap_a), *cp = lds_word32_uniform<3>(node, run_a);
                     const uint32_t d0 = dp[0], d1 = dp[1];
                     const uint32_t c0 = cp[0], c1 = cp[2];
                     const uint32_t s = sym[j];
@@ -714,7 +726,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                     if (INPUT != INPUT_F64) norep = norep || node == 0;                  // (the root: after an unmatched byte)
                     const uint32_t bit = norep ? (1u << s) : ecgb::kContFlag;
                     const bool ok = (bm & bit) != 0;
-                    const unsigned long long em = __ballot(!ok);                         // the lanes that emit a token in this trip
+                    const unsigned long long em = __ballot(1) & ~__ballot(ok);           // the lanes that emit a token in this trip
                     const uint32_t child = (hi & 0xFFFFu) + (uint32_t)__popc(bm & (bit - 1u));
                     const bool inchain = !norep && (int32_t)bm >= 0;                     // not the head of its chain: the continuation is node + 1
                     const uint32_t stop = dw | ~cw;                                      // bit 0 is clear when the step is a chain step
@@ -727,7 +739,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                         // emit the token that starts at r: appended to the wave's list (consecutive 4-byte entries, one
                         // coalesced store per trip)
                         if (INPUT != INPUT_F64 && id == ecgb::kNoToken) len = 1u;       // unmatched byte: lib.rs:186-189
-                        tok_list[n_app + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u))] = r | (id << 16);
+                        tok_list[__builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, n_app))] = r | (id << 16);
                         r += len;
                         live = r < seg_len;
                         if (live) {
