@@ -115,6 +115,42 @@ def test_quantize_encode_fixture_tokenizers(dev, plan, tag, L, B):
             assert np.array_equal(ids[b, : counts[b]], z[f"{tag}_ids_{b}"])   # committed anchor
 
 
+def test_fused_staging_on_the_quantiser_golden_inputs(dev, plan):
+    """The encode kernels classify samples while staging them (float fast path, exact staircase for a group with an
+    ambiguous sample): run them on the reference-generated quantiser inputs, which sit +-4 ulp around every bin edge."""
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    _, merges, _ = load_tokenizer("c1")
+    tk = HipTokenizer(merges)
+    trie = O.Trie(merges)
+    z = np.load(os.path.join(GOLDEN, "quantize_ref.npz"))
+    for i in range(int(z["n_cases"])):
+        p1, p99 = map(float, z[f"p_{i}"])
+        x = np.ascontiguousarray(z[f"x_{i}"].reshape(1, -1))
+        for n in (x.shape[1], x.shape[1] - 3):            # whole groups of four, and a ragged tail
+            if n <= 0:
+                continue
+            xs = np.ascontiguousarray(np.tile(x[:, :n], (5, 1)))          # 5 records: also the wave-per-record kernel's rows
+            ids, counts = tk.quantize_encode(torch.from_numpy(xs).cuda(), {"percentile_1": p1, "percentile_99": p99})
+            ids, counts = ids.cpu().numpy(), counts.cpu().numpy()
+            want = trie.encode_bytes(O.symbols_to_text(z[f"sym_{i}"].reshape(-1)[:n])).astype(np.uint32)
+            for b in range(5):
+                assert counts[b] == want.size, f"case {i} n {n}"
+                assert np.array_equal(ids[b, : counts[b]].astype(np.uint32), want), f"case {i} n {n}"
+
+
+def test_one_id_on_expansions_of_different_lengths(dev, plan):
+    """The id -> length table of the wave-per-record kernel cannot describe such a vocabulary: the handle must route
+    around it (lib.rs keeps whatever id the merges list gives a byte string)."""
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    merges = [([97, 98], 300), ([97, 98, 99], 300), ([98, 98], 301), ([97, 97, 97, 97], 301), ([99], 97)]
+    tk = HipTokenizer(merges)
+    rng = np.random.default_rng(0)
+    texts = [bytes(rng.choice(np.frombuffer(b"abc", dtype=np.uint8), size=700)) for _ in range(6)]
+    got, counts = _encode_bytes(tk, texts)
+    for t, g in zip(texts, got):
+        assert np.array_equal(g, np.asarray(O.encode_text(t, merges), dtype=np.uint32))
+
+
 def test_four_streams_per_workgroup_with_ragged_tail(dev):
     """batch >= 2 x CUs takes the wave-per-stream kernel; 1030 records leave a partly filled last workgroup."""
     from ecg_byte_amd import synth
