@@ -71,7 +71,8 @@ int ecgb_tokenizer_info(const ecgb_tokenizer *tok, uint32_t *n_nodes, uint32_t *
  * count.  Works on a host-only handle (no GPU present). */
 size_t ecgb_tokenizer_copy_nodes(const ecgb_tokenizer *tok, uint64_t *out, size_t cap);
 /* Copies up to `cap` words of the per-node bit tables the run step of the encoder uses (word pair k:
- * [2k] bit u = node 32k+u has a continuation child, [2k+1] bit u = node 32k+u carries a token; padded
+ * [2k] bit u = node 32k+u has a continuation child, [2k+1] bit u = node 32k+u carries a token ITSELF (a
+ * node's record holds the best token of its path); padded
  * with zero pairs) and returns the word count. */
 size_t ecgb_tokenizer_copy_runbits(const ecgb_tokenizer *tok, uint32_t *out, size_t cap);
 
