@@ -809,7 +809,8 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             for (;;) {
                 const uint32_t prev = __shfl_up(my_exit, 1, 64);
                 const uint32_t want = (c == 0) ? carry_rel : prev;
-                const bool changed = (want != entry);
+                const bool changed = (want != entry) && (pbase < seg_len);   // lanes past the segment own nothing: they must not
+                                                                             // pass the last exit along, one lane per pass
                 if (!__any(changed)) break;
                 PROF_COUNT(4, 1);
                 if (changed) {
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            const uint32_t carry_out_rel = __shfl(my_exit, 63, 64);
+            const uint32_t carry_out_rel = __shfl(my_exit, (int)((seg_len - 1u) / PW), 64);   // the exit of the last block of the segment
             PROF_STAMP(2);
 
             // ---- emit: the real chain's bitmap replaces the claim bitmap, its per-word prefix counts go where the change map
