@@ -693,7 +693,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                 uint32_t dmap_a = lds_addr(dmap), marks_a = lds_addr(marks);
                 asm volatile("" : "+v"(dmap_a), "+v"(marks_a));             // (kept in registers, not recomputed every trip)
                 const uint32_t run_a = __builtin_amdgcn_readfirstlane(lds_addr(s_run));
-                uint32_t n_app = 0;                                             // entries appended so far (wave-uniform)
+                uint32_t *tok_tail = tok_list;                                  // end of the list (wave-uniform)
                 if (live) {
                     const uint32_t rbit = 1u << (r & 31);
                     const uint32_t claimed = atomicOr(&marks[r >> 5], rbit);
@@ -724,10 +724,10 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                     const uint32_t cw = __builtin_amdgcn_alignbit(c1, c0, node & 31);    // bit t: node + t has a continuation
                     bool norep = dw & 1u;                                                // the symbol differs from the one this node was entered by
                     if (INPUT != INPUT_F64) norep = norep || node == 0;                  // (the root: after an unmatched byte)
-                    const uint32_t bit = norep ? (1u << s) : ecgb::kContFlag;
-                    const bool ok = (bm & bit) != 0;
+                    const uint32_t width = norep ? s : 30u;                              // the class bit, or the continuation flag: bit 30
+                    const bool ok = ((bm >> (width & 31u)) & 1u) != 0;
                     const unsigned long long em = __ballot(1) & ~__ballot(ok);           // the lanes that emit a token in this trip
-                    const uint32_t child = (hi & 0xFFFFu) + (uint32_t)__popc(bm & (bit - 1u));
+                    const uint32_t child = (hi & 0xFFFFu) + (uint32_t)__popc(__builtin_amdgcn_ubfe(bm, 0u, width));   // children of the classes below
                     const bool inchain = !norep && (int32_t)bm >= 0;                     // not the head of its chain: the continuation is node + 1
                     const uint32_t stop = dw | ~cw;                                      // bit 0 is clear when the step is a chain step
                     const uint32_t m = inchain ? min((uint32_t)__ffs(stop) - 1u, 32u) : 1u;
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                         // emit the token that starts at r: appended to the wave's list (consecutive 4-byte entries, one
                         // coalesced store per trip)
                         if (INPUT != INPUT_F64 && id == ecgb::kNoToken) len = 1u;       // unmatched byte: lib.rs:186-189
-                        tok_list[__builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, n_app))] = r | (id << 16);
+                        tok_tail[__builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u))] = r | (id << 16);
                         r += len;
                         live = r < seg_len;
                         if (live) {
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
                             if (INPUT == INPUT_F64 || s1 != ecgb::kOtherClass) { node = 1u + s1; j = r + 1u; }
                         }
                     }
-                    n_app += (uint32_t)__popcll(em);
+                    tok_tail += (uint32_t)__popcll(em);                                  // (a scalar pointer: the list grows by the tokens of this trip)
                     __builtin_amdgcn_wave_barrier();
                 }
             }
