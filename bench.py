@@ -186,7 +186,7 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
         opt.step_and_update_lr()
         return out.loss
 
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, min(args.warmup, 5))):   # a train step is 300x an encode step: a few warm-up steps are enough
         loss = step()
     torch.cuda.synchronize()
     if world > 1:
@@ -239,8 +239,8 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=4096, help="records per GPU")
     ap.add_argument("--L", type=int, default=5000, help="samples per lead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
