@@ -265,10 +265,18 @@ def main():
     x = make_signals(args.batch, args.L, seed=0, start=rank * args.batch, workers=workers)   # rank r owns records rB..rB+B-1
     x_train = None if args.no_train else make_signals(args.train_batch, args.L, seed=0,
                                                       start=10_000_000 + rank * args.train_batch, workers=workers)
+    # Test hooks (tests/test_gpu_pipeline.py runs the N = 2 path on a one-GPU box): ECGB_BENCH_BACKEND=gloo replaces RCCL,
+    # ECGB_BENCH_ONE_DEVICE=1 puts every rank on cuda:0.  Neither is set in a measured run.
+    backend = os.environ.get("ECGB_BENCH_BACKEND", "nccl")
+    if os.environ.get("ECGB_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"

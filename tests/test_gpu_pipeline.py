@@ -188,3 +188,30 @@ def test_main_cli_trains_then_infers_on_the_reference_layout(ptb_dir, tmp_path, 
     assert set(stats) == {"BLEU"} and len(stats["BLEU"]["raw_values"]) == 5
     files = os.listdir(out["directory"])
     assert "statistical_analysis_ptb_500.json" in files and sum(f.startswith("seed_") for f in files) == 5
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path (rank-sharded records, barrier + max-over-ranks timing, gradient all-reduce in the train
+    leg) end to end: two ranks on cuda:0 over gloo, through bench.py's test hooks -- a one-GPU box cannot run RCCL
+    between two ranks, the driver's 8-GPU run can."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ECGB_BENCH_BACKEND="gloo", ECGB_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "512", "--steps", "3",
+           "--warmup", "1", "--train-batch", "2", "--train-steps", "2", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3
+    assert out["config"]["records_per_gpu"] == 512
+    # both ranks' tokens are in the aggregate: twice one rank's records
+    assert abs(out["records_per_s"] * out["ms_per_step"] * 1e-3 - 2 * 512) < 1e-6 * 1024
+    assert out["value"] > 0 and out["roofline"]["achieved"] > 0
+    assert out["train"]["steps"] == 2 and np.isfinite(out["train"]["final_loss"]) and "dp2" in out["train"]["config"]["parallelism"]
+    assert np.isfinite(out["train"]["lora_r16"]["final_loss"])
