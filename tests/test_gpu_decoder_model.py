@@ -380,3 +380,35 @@ def test_generate_graph_replay_equals_eager_loop(family):
     one = m.generate(input_ids=ids[1:2], attention_mask=mask[1:2], max_new_tokens=20, pad_token_id=299, eos_token_id=eos)
     ref = m.generate(input_ids=ids[1:2], attention_mask=mask[1:2], max_new_tokens=20, pad_token_id=299, eos_token_id=eos, use_graph=False)
     assert torch.equal(one, ref)
+
+
+def test_data_parallel_gradients_two_ranks(tmp_path):
+    """two ranks, each with its own rows of the batch, exchange gradients layer by layer during the
+    backward pass (parallel.GradAllReduce); both must end with the mean of the two ranks' gradients, as
+    DistributedDataParallel gives the reference (main.py:165)."""
+    import subprocess
+    import sys
+    from ddp_worker import rank_rows
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = str(tmp_path / "grads")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(here, "ddp_worker.py"), out]
+    res = subprocess.run(cmd, cwd=os.path.dirname(here), env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    want = None
+    for rank in range(2):                                   # the same two backward passes, one after the other, no exchange
+        z, m = _load()
+        batch = {k: v[rank_rows(rank)] for k, v in _batch(z).items()}
+        m(**batch).loss.backward()
+        g = {n: p.grad.float() / 2 for n, p in m.named_parameters() if p.grad is not None}
+        want = g if want is None else {n: want[n] + g[n] for n in g}
+    for rank in range(2):
+        got = np.load(out + f".rank{rank}.npz")
+        assert set(got.files) == set(want)
+        for n in want:
+            a, b = torch.from_numpy(got[n]).cuda(), want[n]
+            rel = (a - b).norm() / b.norm().clamp_min(1e-12)
+            assert rel.item() < 2e-2, (rank, n, rel.item())
