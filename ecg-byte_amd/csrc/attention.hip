@@ -490,62 +490,128 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs A)   // t
 }
 
 // =====================================================================================================
-// decode step: one query per (batch, head) against the KV cache.  grid (Hq, B), one wave per workgroup; head_dim 64 / 128 / 256.
+// decode step: one query per (batch, head) against the KV cache.  grid (Hq, B), 16 waves per workgroup; head_dim 64 / 128 / 256.
 // q [B, Hq*D]; k/v cache rows [B, cap] with row stride ld (elements), kv head g at + g*D; len = keys in the cache
-// (incl. the new one); key j visible iff mask[b, j] != 0.  HBM-bound (reads the cache once).
+// (incl. the new one); key j visible iff mask[b, j] != 0.  Reads the cache once, every row as one coalesced D*2-byte piece:
+//   scores  a wave takes keys w, w+16, ...: its lanes read a key row together (D/64 elements each), multiply with the
+//           query (registers) and add up across the wave; eight keys in flight per wave;
+//   softmax max and sum over the workgroup, probabilities in LDS (fp32);
+//   P.V     thread t owns one 16-byte piece of the value rows of its key slice (interleaved keys); the slices' partial
+//           sums meet in LDS in a fixed order.  P is cast to bf16 before P.V, as SDPA does.
+constexpr int kDecodeThreads = 1024;
 template <int D>
-__global__ __launch_bounds__(64) void attn_decode_kernel(const unsigned short *q, const unsigned short *kc, const unsigned short *vc,
-                                                         long long ld, long long cap, const float *mask, long long mask_ld,
-                                                         unsigned short *o, int len_arg, const int *len_dev, int Hq, int Hkv, float scale)
+__global__ __launch_bounds__(kDecodeThreads) void attn_decode_kernel(const unsigned short *q, const unsigned short *kc, const unsigned short *vc,
+                                                                     long long ld, long long cap, const float *mask, long long mask_ld,
+                                                                     unsigned short *o, int len_arg, const int *len_dev, int Hq, int Hkv, float scale)
 {
-    extern __shared__ float s_p[];                      // [len] scores / probabilities, then [D] the query in fp32
+    constexpr int NW = kDecodeThreads / 64, EPL = D / 64;   // waves, elements per lane of a key row
+    constexpr int KU = 16, VU = 8;                      // key rows a wave / value rows a thread keeps in flight (memory latency, not bandwidth, is the cost)
+    extern __shared__ float s_p[];                      // [len] scores / probabilities, later [kDecodeThreads * 8] partial outputs; [2 * NW] reductions
     const int len = len_dev ? *len_dev : len_arg;       // device-resident when the step is replayed from a captured graph
-    float *s_q = s_p + (len_dev ? (((int)cap + 3) & ~3) : ((len + 3) & ~3));
-    const int hq = blockIdx.x, b = blockIdx.y, g = hq / (Hq / Hkv), lane = threadIdx.x;
+    const int rows_lds = len_dev ? (((int)cap + 3) & ~3) : ((len + 3) & ~3);
+    float *s_red = s_p + max(rows_lds, kDecodeThreads * 8);   // behind the scores / the P.V partial sums, whichever is longer
+    const int hq = blockIdx.x, b = blockIdx.y, g = hq / (Hq / Hkv), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned short *qp = q + ((long long)b * Hq + hq) * D;
-    for (int d = lane; d < D; d += 64) s_q[d] = bf2f(qp[d]);
-    __syncthreads();
+    float qf[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) qf[t] = bf2f(qp[lane * EPL + t]);
     const unsigned short *K = kc + (long long)b * cap * ld + (long long)g * D;
     const unsigned short *V = vc + (long long)b * cap * ld + (long long)g * D;
+    const float *mrow = mask + (long long)b * mask_ld;
+
+    // ---- scores
     float m = -INFINITY;
-    for (int j = lane; j < len; j += 64) {
-        float sdot = -INFINITY;
-        if (mask[(long long)b * mask_ld + j] != 0.f) {
-            const bf16x8 *kr = reinterpret_cast<const bf16x8 *>(K + (long long)j * ld);
-            float acc = 0.f;
-#pragma unroll 4
-            for (int c = 0; c < D / 8; ++c) {
-                const bf16x8 kv = kr[c];
+    for (int j0 = wave; j0 < len; j0 += KU * NW) {
+        float part[KU], mk[KU];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) acc += s_q[c * 8 + t] * bf2f((unsigned short)kv[t]);
+        for (int u = 0; u < KU; ++u) mk[u] = mrow[min(j0 + u * NW, len - 1)];   // in flight together with the key rows
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int j = j0 + u * NW;
+            part[u] = 0.f;
+            if (j < len) {
+                const unsigned short *kr = K + (long long)j * ld + lane * EPL;
+                if constexpr (EPL == 4) {
+                    const uint2 kv = *reinterpret_cast<const uint2 *>(kr);
+                    part[u] = qf[0] * __uint_as_float(kv.x << 16) + qf[1] * __uint_as_float(kv.x & 0xFFFF0000u) +
+                              qf[2] * __uint_as_float(kv.y << 16) + qf[3] * __uint_as_float(kv.y & 0xFFFF0000u);
+                } else if constexpr (EPL == 2) {
+                    const unsigned kv = *reinterpret_cast<const unsigned *>(kr);
+                    part[u] = qf[0] * __uint_as_float(kv << 16) + qf[1] * __uint_as_float(kv & 0xFFFF0000u);
+                } else {
+                    part[u] = qf[0] * bf2f(kr[0]);
+                }
             }
-            sdot = acc * scale;
         }
-        s_p[j] = sdot;
-        m = fmaxf(m, sdot);
-    }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+        for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+            for (int u = 0; u < KU; ++u) part[u] += __shfl_xor(part[u], d, 64);
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int j = j0 + u * NW;
+            if (j < len) {
+                const float sdot = (mk[u] != 0.f) ? part[u] * scale : -INFINITY;
+                if (lane == 0) s_p[j] = sdot;
+                m = fmaxf(m, sdot);
+            }
+        }
+    }
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = s_red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, s_red[w]);
+
+    // ---- softmax
     float l = 0.f;
-    for (int j = lane; j < len; j += 64) {
+    for (int j = tid; j < len; j += kDecodeThreads) {
         const float e = (m == -INFINITY) ? 0.f : __expf(s_p[j] - m);
         s_p[j] = e;
         l += e;
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) l += __shfl_xor(l, d, 64);
+    if (lane == 0) s_red[NW + wave] = l;
     __syncthreads();
+    l = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) l += s_red[NW + w];
     const float inv = l > 0.f ? 1.f / l : 0.f;
-    float acc[D / 64];                                  // lane owns output dimensions lane, lane + 64, ...
+
+    // ---- P.V: thread t owns 8 consecutive output dimensions (one 16-byte piece of a value row) and the keys of slice
+    // t / (D / 8), interleaved; all of a thread's rows of a batch are in flight together
+    constexpr int TPR = D / 8, NS = kDecodeThreads / TPR;      // threads per value row, key slices
+    const int piece = tid % TPR, slice = tid / TPR;
+    float acc[8];
 #pragma unroll
-    for (int t = 0; t < D / 64; ++t) acc[t] = 0.f;
-    for (int j = 0; j < len; ++j) {
-        const float pj = bf2f((unsigned short)(pack_bf16(s_p[j] * inv, 0.f) & 0xFFFFu));   // P is cast to bf16 before P.V, as SDPA does
+    for (int t = 0; t < 8; ++t) acc[t] = 0.f;
+    for (int j0 = slice; j0 < len; j0 += VU * NS) {
+        bf16x8 vv[VU];
 #pragma unroll
-        for (int t = 0; t < D / 64; ++t) acc[t] += pj * bf2f(V[(long long)j * ld + lane + 64 * t]);
+        for (int u = 0; u < VU; ++u) {
+            const int j = min(j0 + u * NS, len - 1);                    // past the end: a repeated row with probability 0
+            vv[u] = *reinterpret_cast<const bf16x8 *>(V + (long long)j * ld + piece * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int j = j0 + u * NS;
+            const float pj = (j < len) ? bf2f((unsigned short)(pack_bf16(s_p[j] * inv, 0.f) & 0xFFFFu)) : 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] += pj * bf2f((unsigned short)vv[u][t]);
+        }
     }
+    __syncthreads();                                            // s_p is dead: the slices' partial sums go there
+    float *s_part = s_p;                                        // [NS][D] floats (the launch sizes the buffer for it)
 #pragma unroll
-    for (int t = 0; t < D / 64; ++t) o[((long long)b * Hq + hq) * D + lane + 64 * t] = (unsigned short)(pack_bf16(acc[t], 0.f) & 0xFFFFu);
+    for (int t = 0; t < 8; ++t) s_part[slice * D + piece * 8 + t] = acc[t];
+    __syncthreads();
+    if (tid < D) {
+        float sum = 0.f;
+#pragma unroll 8
+        for (int sl = 0; sl < NS; ++sl) sum += s_part[sl * D + tid];
+        o[((long long)b * Hq + hq) * D + tid] = (unsigned short)(pack_bf16(sum, 0.f) & 0xFFFFu);
+    }
 }
 
 int check_args(const AttnArgs &A, int D, const char *who)
@@ -621,9 +687,9 @@ int launch_attn_decode(const void *q_dev, const void *k_cache_dev, const void *v
     if (head_dim != 64 && head_dim != 128 && head_dim != 256) { ecgb::set_error("ecgb_attn_decode: head_dim must be 64, 128 or 256"); return ECGB_ERR_UNSUPPORTED; }
     if (batch <= 0 || (!kv_len_dev && (kv_len <= 0 || kv_len > capacity)) || n_q_heads % n_kv_heads || ld % 8) { ecgb::set_error("ecgb_attn_decode: bad shape"); return ECGB_ERR_INVALID; }
     const long long rows = kv_len_dev ? capacity : (long long)kv_len;
-    const size_t lds = ((size_t)((rows + 3) & ~3ll) + (size_t)head_dim) * 4;
+    const size_t lds = (std::max<size_t>((size_t)((rows + 3) & ~3ll), (size_t)kDecodeThreads * 8) + 2 * (kDecodeThreads / 64)) * 4;
     if (lds > 64 * 1024) { ecgb::set_error("ecgb_attn_decode: cache longer than ~16000 keys"); return ECGB_ERR_UNSUPPORTED; }
-#define ECGB_DECODE(D_) hipLaunchKernelGGL(attn_decode_kernel<D_>, dim3((unsigned)n_q_heads, (unsigned)batch), dim3(64), lds, (hipStream_t)stream, \
+#define ECGB_DECODE(D_) hipLaunchKernelGGL(attn_decode_kernel<D_>, dim3((unsigned)n_q_heads, (unsigned)batch), dim3(kDecodeThreads), lds, (hipStream_t)stream, \
         (const unsigned short *)q_dev, (const unsigned short *)k_cache_dev, (const unsigned short *)v_cache_dev, ld, capacity, attn_mask_dev, mask_ld, \
         (unsigned short *)o_dev, kv_len, kv_len_dev, n_q_heads, n_kv_heads, scale)
     if (head_dim == 64) ECGB_DECODE(64); else if (head_dim == 128) ECGB_DECODE(128); else ECGB_DECODE(256);
