@@ -742,27 +742,42 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
 // tile to fill: the product is bound by reading B once.  One wave per output column n: the 64 lanes walk row n of B in
 // 16-byte pieces (1 KiB per step, coalesced), multiply with the matching pieces of the M rows of A (L2-resident), reduce
 // across the wave.  Same accumulate modes as the tiled kernels.
-template <int MR>
+// KS = waves that share one output column, each with a contiguous 1/KS of the contraction (long rows, few columns: more
+// waves in flight); their sums meet in LDS.
+template <int MR, int KS>
 __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs G)
 {
-    const int lane = threadIdx.x & 63;
-    const long long n = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= G.N) return;
-    const unsigned short *b = G.B + n * G.ldb;
+    __shared__ float s_part[4][MR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ks = wave % KS;
+    const long long n = (long long)blockIdx.x * (4 / KS) + wave / KS;
+    const bool live = n < G.N;
+    const unsigned short *b = G.B + (live ? n : 0) * G.ldb;
+    const int k_lo = ks * (G.K / KS), k_hi = k_lo + G.K / KS;      // G.K % (8 * KS) == 0 (checked by the launcher)
     float acc[MR];
 #pragma unroll
     for (int m = 0; m < MR; ++m) acc[m] = 0.f;
-    for (int k = lane * 8; k < G.K; k += 512) {
-        const bf16x8 vb = *reinterpret_cast<const bf16x8 *>(b + k);
-        float fb[8];
+    // four 16-byte pieces of the weight row in flight per lane: with one, a long row (K = 16 384: 32 pieces per lane) is a chain
+    // of 32 memory latencies
+    constexpr int U = 4;
+    for (int k0 = k_lo + lane * 8; k0 < k_hi; k0 += 512 * U) {
+        bf16x8 vb[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) fb[j] = __uint_as_float((unsigned)(unsigned short)vb[j] << 16);
+        for (int u = 0; u < U; ++u) vb[u] = *reinterpret_cast<const bf16x8 *>(b + min(k0 + 512 * u, k_hi - 8));   // past the end: re-read, not used
 #pragma unroll
-        for (int m = 0; m < MR; ++m) {
-            if (m < G.M) {
-                const bf16x8 va = *reinterpret_cast<const bf16x8 *>(G.A + (long long)m * G.lda + k);
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 512 * u;
+            if (k < k_hi) {
+                float fb[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[m] += __uint_as_float((unsigned)(unsigned short)va[j] << 16) * fb[j];
+                for (int j = 0; j < 8; ++j) fb[j] = __uint_as_float((unsigned)(unsigned short)vb[u][j] << 16);
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    if (m < G.M) {
+                        const bf16x8 va = *reinterpret_cast<const bf16x8 *>(G.A + (long long)m * G.lda + k);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[m] += __uint_as_float((unsigned)(unsigned short)va[j] << 16) * fb[j];
+                    }
+                }
             }
         }
     }
@@ -770,7 +785,20 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs G)
     for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) acc[m] += __shfl_xor(acc[m], d, 64);
-    if (lane == 0) {
+    if constexpr (KS > 1) {
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m) s_part[wave][m] = acc[m];
+        }
+        __syncthreads();
+        if (ks == 0 && lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int t = 1; t < KS; ++t) acc[m] += s_part[wave + t][m];
+        }
+    }
+    if (live && ks == 0 && lane == 0) {
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
             if (m >= G.M) break;
@@ -855,9 +883,15 @@ extern "C" int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b
     G.accumulate_f32 = accumulate_f32; G.alpha = alpha;
     G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
     if (M <= 8 && batch == 1 && K % 8 == 0) {   // a few rows: bandwidth-bound column-per-wave kernel
-        const dim3 grid((unsigned)((N + 3) / 4));
-        if (M <= 2) hipLaunchKernelGGL(gemm_nt_skinny_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, G);
-        else hipLaunchKernelGGL(gemm_nt_skinny_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, G);
+        const bool split = (K >= 8192 && K % 32 == 0 && N <= 8192);      // long rows, few columns: four waves per column
+        const dim3 grid(split ? (unsigned)N : (unsigned)((N + 3) / 4));
+        if (M <= 2) {
+            if (split) hipLaunchKernelGGL((gemm_nt_skinny_kernel<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, G);
+            else hipLaunchKernelGGL((gemm_nt_skinny_kernel<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, G);
+        } else {
+            if (split) hipLaunchKernelGGL((gemm_nt_skinny_kernel<8, 4>), grid, dim3(256), 0, (hipStream_t)stream, G);
+            else hipLaunchKernelGGL((gemm_nt_skinny_kernel<8, 1>), grid, dim3(256), 0, (hipStream_t)stream, G);
+        }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_skinny_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
         return ECGB_OK;

@@ -13,8 +13,9 @@ g = torch.Generator(device="cuda").manual_seed(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 p = torch.randint(1000, 100000, (B, 600), device="cuda", generator=g)
 pm = torch.ones_like(p, dtype=torch.float32)
-for it in range(3):
-    torch.cuda.synchronize(); t = time.perf_counter()
-    seq = m.generate(input_ids=p, attention_mask=pm, max_new_tokens=128, pad_token_id=V - 1)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t
-    print(f"B {B}: 600-token prompt + 128 new tokens: {1e3*dt:.0f} ms ({B*128/dt:.1f} tokens/s)")
+for use_graph in ((False, True) if len(sys.argv) > 2 else (False,)):
+    for it in range(3):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        seq = m.generate(input_ids=p, attention_mask=pm, max_new_tokens=128, pad_token_id=V - 1, use_graph=use_graph)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+        print(f"B {B} graph {int(use_graph)}: 600-token prompt + 128 new tokens: {1e3*dt:.0f} ms ({B*128/dt:.1f} tokens/s)")
