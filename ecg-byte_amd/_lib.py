@@ -106,6 +106,7 @@ def lib():
         "ecgb_set_gemm_tile": [ci],
         "ecgb_attn_decode": [vp, vp, vp, ll, ll, vp, ll, vp, ci, ci, ci, ci, ci, f32, vp],
         "ecgb_attn_decode_dyn": [vp, vp, vp, ll, ll, vp, ll, vp, ci, vp, ci, ci, ci, f32, vp],
+        "ecgb_attn_decode_split": [vp, vp, vp, ll, ll, vp, ll, vp, ci, ci, ci, ci, ci, f32, ci, vp, sz, vp],
         "ecgb_kv_append": [vp, ll, ll, ci, vp, ll, ci, vp, vp],
         "ecgb_gemm_tn_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, vp],
         "ecgb_attn_fwd": [vp, ll, vp, ll, vp, ll, vp, vp, ll, vp, ci, ci, ci, ci, ci, f32, vp],
@@ -115,6 +116,8 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    L.ecgb_attn_decode_split_scratch_bytes.argtypes = [ll, ci, ci, ci, ci]
+    L.ecgb_attn_decode_split_scratch_bytes.restype = sz
     _lib = L
     return L
 

@@ -614,6 +614,148 @@ __global__ __launch_bounds__(kDecodeThreads) void attn_decode_kernel(const unsig
     }
 }
 
+// ---- the same decode step with the keys of a head split over several workgroups (long caches, few heads: one CU
+// sustains only ~64 GB/s at the memory latency, the chip has 256).  Three small kernels:
+//   scores   grid (splits, Hq, B): the scores of the split's keys to scratch (fp32) + the split's max and sum of exponentials;
+//   values   grid (splits, Hq, B): global max / sum from the splits' statistics, p_j = bf16(exp(s_j - max) / sum) exactly as
+//            attn_decode_kernel forms it, partial P.V of the split's keys to scratch (fp32);
+//   combine  grid (Hq, B): the partial outputs added in split order, cast to bf16.
+// scratch (floats): scores [B, Hq, cap] | stats [B, Hq, splits, 2] | partial outputs [B, Hq, splits, D].
+constexpr int kSplitThreads = 256;
+template <int D>
+__global__ __launch_bounds__(kSplitThreads) void attn_decode_scores_kernel(const unsigned short *q, const unsigned short *kc, long long ld, long long cap,
+                                                                           const float *mask, long long mask_ld, float *scores, float *stats,
+                                                                           int len, int chunk, int Hq, int Hkv, float scale)
+{
+    constexpr int NW = kSplitThreads / 64, EPL = D / 64, KU = 8;
+    __shared__ float s_red[2 * NW];
+    const int sp = blockIdx.x, hq = blockIdx.y, b = blockIdx.z, g = hq / (Hq / Hkv), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k0 = sp * chunk, k1 = min(len, k0 + chunk);
+    const unsigned short *qp = q + ((long long)b * Hq + hq) * D;
+    float qf[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) qf[t] = bf2f(qp[lane * EPL + t]);
+    const unsigned short *K = kc + (long long)b * cap * ld + (long long)g * D;
+    const float *mrow = mask + (long long)b * mask_ld;
+    float *srow = scores + ((long long)b * Hq + hq) * cap;
+    float m = -INFINITY;
+    for (int j0 = k0 + wave; j0 < k1; j0 += KU * NW) {
+        float part[KU], mk[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) mk[u] = mrow[min(j0 + u * NW, k1 - 1)];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int j = j0 + u * NW;
+            part[u] = 0.f;
+            if (j < k1) {
+                const unsigned short *kr = K + (long long)j * ld + lane * EPL;
+                if constexpr (EPL == 4) {
+                    const uint2 kv = *reinterpret_cast<const uint2 *>(kr);
+                    part[u] = qf[0] * __uint_as_float(kv.x << 16) + qf[1] * __uint_as_float(kv.x & 0xFFFF0000u) +
+                              qf[2] * __uint_as_float(kv.y << 16) + qf[3] * __uint_as_float(kv.y & 0xFFFF0000u);
+                } else if constexpr (EPL == 2) {
+                    const unsigned kv = *reinterpret_cast<const unsigned *>(kr);
+                    part[u] = qf[0] * __uint_as_float(kv << 16) + qf[1] * __uint_as_float(kv & 0xFFFF0000u);
+                } else {
+                    part[u] = qf[0] * bf2f(kr[0]);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+            for (int u = 0; u < KU; ++u) part[u] += __shfl_xor(part[u], d, 64);
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int j = j0 + u * NW;
+            if (j < k1) {
+                const float sdot = (mk[u] != 0.f) ? part[u] * scale : -INFINITY;
+                if (lane == 0) srow[j] = sdot;
+                m = fmaxf(m, sdot);
+            }
+        }
+    }
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();                                     // (also orders the score stores before the reads below)
+    m = s_red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, s_red[w]);
+    float l = 0.f;
+    for (int j = k0 + tid; j < k1; j += kSplitThreads) l += (m == -INFINITY) ? 0.f : __expf(srow[j] - m);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) l += __shfl_xor(l, d, 64);
+    if (lane == 0) s_red[NW + wave] = l;
+    __syncthreads();
+    if (tid == 0) {
+        l = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) l += s_red[NW + w];
+        float *st = stats + (((long long)b * Hq + hq) * gridDim.x + sp) * 2;
+        st[0] = m;
+        st[1] = l;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kSplitThreads) void attn_decode_values_kernel(const unsigned short *vc, long long ld, long long cap, const float *scores,
+                                                                           const float *stats, float *partial, int len, int chunk, int Hq, int Hkv)
+{
+    constexpr int TPR = D / 8, NS = kSplitThreads / TPR, VU = 8;
+    __shared__ float s_part[NS * D];
+    const int sp = blockIdx.x, hq = blockIdx.y, b = blockIdx.z, g = hq / (Hq / Hkv), tid = threadIdx.x;
+    const int n_splits = gridDim.x;
+    const int k0 = sp * chunk, k1 = min(len, k0 + chunk);
+    const float *st = stats + ((long long)b * Hq + hq) * n_splits * 2;
+    float m = -INFINITY;
+    for (int t = 0; t < n_splits; ++t) m = fmaxf(m, st[2 * t]);
+    float l = 0.f;
+    for (int t = 0; t < n_splits; ++t) l += (st[2 * t] == -INFINITY) ? 0.f : st[2 * t + 1] * __expf(st[2 * t] - m);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const unsigned short *V = vc + (long long)b * cap * ld + (long long)g * D;
+    const float *srow = scores + ((long long)b * Hq + hq) * cap;
+    const int piece = tid % TPR, slice = tid / TPR;
+    float acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = 0.f;
+    for (int j0 = k0 + slice; j0 < k1; j0 += VU * NS) {
+        bf16x8 vv[VU];
+        float sc[VU];
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int j = min(j0 + u * NS, k1 - 1);
+            vv[u] = *reinterpret_cast<const bf16x8 *>(V + (long long)j * ld + piece * 8);
+            sc[u] = srow[j];
+        }
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int j = j0 + u * NS;
+            const float e = (m == -INFINITY) ? 0.f : __expf(sc[u] - m);
+            const float pj = (j < k1) ? bf2f((unsigned short)(pack_bf16(e * inv, 0.f) & 0xFFFFu)) : 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] += pj * bf2f((unsigned short)vv[u][t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s_part[slice * D + piece * 8 + t] = acc[t];
+    __syncthreads();
+    if (tid < D) {
+        float sum = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) sum += s_part[sl * D + tid];
+        partial[(((long long)b * Hq + hq) * n_splits + sp) * D + tid] = sum;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float *partial, unsigned short *o, int n_splits, int Hq)
+{
+    const int hq = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float *p = partial + ((long long)b * Hq + hq) * n_splits * D + tid;
+    float sum = 0.f;
+    for (int t = 0; t < n_splits; ++t) sum += p[(long long)t * D];
+    o[((long long)b * Hq + hq) * D + tid] = (unsigned short)(pack_bf16(sum, 0.f) & 0xFFFFu);
+}
+
 int check_args(const AttnArgs &A, int D, const char *who)
 {
     if (A.B <= 0 || A.S <= 0 || A.Hq <= 0 || A.Hkv <= 0 || A.Hq % A.Hkv) {
@@ -717,6 +859,44 @@ extern "C" int ecgb_attn_decode(const void *q_dev, const void *k_cache_dev, cons
 {
     return launch_attn_decode(q_dev, k_cache_dev, v_cache_dev, ld, capacity, attn_mask_dev, mask_ld, o_dev, batch, kv_len, nullptr,
                               n_q_heads, n_kv_heads, head_dim, scale, stream);
+}
+
+extern "C" size_t ecgb_attn_decode_split_scratch_bytes(long long capacity, int batch, int n_q_heads, int head_dim, int n_splits)
+{
+    if (capacity <= 0 || batch <= 0 || n_q_heads <= 0 || n_splits <= 0) return 0;
+    return (size_t)batch * n_q_heads * ((size_t)capacity + (size_t)n_splits * (2 + (size_t)head_dim)) * sizeof(float);
+}
+
+extern "C" int ecgb_attn_decode_split(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,
+                                      const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, int n_q_heads,
+                                      int n_kv_heads, int head_dim, float scale, int n_splits, void *scratch_dev, size_t scratch_bytes,
+                                      void *stream)
+{
+    if (head_dim != 64 && head_dim != 128 && head_dim != 256) { ecgb::set_error("ecgb_attn_decode_split: head_dim must be 64, 128 or 256"); return ECGB_ERR_UNSUPPORTED; }
+    if (!q_dev || !k_cache_dev || !v_cache_dev || !attn_mask_dev || !o_dev || !scratch_dev || batch <= 0 || kv_len <= 0 || kv_len > capacity ||
+        n_q_heads <= 0 || n_kv_heads <= 0 || n_q_heads % n_kv_heads || ld % 8 || n_splits <= 0 || n_splits > 1024) {
+        ecgb::set_error("ecgb_attn_decode_split: bad argument");
+        return ECGB_ERR_INVALID;
+    }
+    if (scratch_bytes < ecgb_attn_decode_split_scratch_bytes(capacity, batch, n_q_heads, head_dim, n_splits)) {
+        ecgb::set_error("ecgb_attn_decode_split: scratch too small (ecgb_attn_decode_split_scratch_bytes)");
+        return ECGB_ERR_INVALID;
+    }
+    float *scores = (float *)scratch_dev;
+    float *stats = scores + (size_t)batch * n_q_heads * (size_t)capacity;
+    float *partial = stats + (size_t)batch * n_q_heads * (size_t)n_splits * 2;
+    const int chunk = (kv_len + n_splits - 1) / n_splits;
+    const dim3 grid((unsigned)n_splits, (unsigned)n_q_heads, (unsigned)batch), gc((unsigned)n_q_heads, (unsigned)batch);
+#define ECGB_SPLIT(D_) do { \
+        hipLaunchKernelGGL(attn_decode_scores_kernel<D_>, grid, dim3(kSplitThreads), 0, (hipStream_t)stream, (const unsigned short *)q_dev, \
+            (const unsigned short *)k_cache_dev, ld, capacity, attn_mask_dev, mask_ld, scores, stats, kv_len, chunk, n_q_heads, n_kv_heads, scale); \
+        hipLaunchKernelGGL(attn_decode_values_kernel<D_>, grid, dim3(kSplitThreads), 0, (hipStream_t)stream, (const unsigned short *)v_cache_dev, \
+            ld, capacity, scores, stats, partial, kv_len, chunk, n_q_heads, n_kv_heads); \
+        hipLaunchKernelGGL(attn_decode_combine_kernel<D_>, gc, dim3(D_), 0, (hipStream_t)stream, partial, (unsigned short *)o_dev, n_splits, n_q_heads); \
+    } while (0)
+    if (head_dim == 64) ECGB_SPLIT(64); else if (head_dim == 128) ECGB_SPLIT(128); else ECGB_SPLIT(256);
+#undef ECGB_SPLIT
+    return launched("attn_decode_split kernels");
 }
 
 extern "C" int ecgb_attn_decode_dyn(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,

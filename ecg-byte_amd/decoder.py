@@ -581,7 +581,11 @@ class HipCausalLM(nn.Module):
             _rope_offset(qkv, Hq * D, cos, sin, Hkv, D, QKV)
             if n_dev is None:
                 caches[i][:, n - 1].copy_(qkv[:, Hq * D:])
-                ao = ops.attn_decode(qkv, caches[i], mask, n, Hq, Hkv, D, scale)
+                ns = ops.decode_splits(n, qkv.shape[0], Hq)
+                if ns > 1:
+                    ao = ops.attn_decode_split(qkv, caches[i], mask, n, Hq, Hkv, D, scale, ns)
+                else:
+                    ao = ops.attn_decode(qkv, caches[i], mask, n, Hq, Hkv, D, scale)
             else:
                 ops.kv_append(qkv, Hq * D, caches[i], n_dev)
                 ao = ops.attn_decode_dyn(qkv, caches[i], mask, n_dev, Hq, Hkv, D, scale)

@@ -245,6 +245,34 @@ def attn_decode(qkv_new, cache, mask, kv_len, Hq, Hkv, D, scale):
     return o
 
 
+_split_scratch = {}
+
+
+def decode_splits(kv_len, B, Hq):
+    """Workgroups a head's keys are split over in a decode step: about 128 keys each (a workgroup then needs one or two
+    batches of loads), at most 32 per head and 4096 in all; 1 = the single-workgroup kernel (short caches: three launches
+    cost more than they save)."""
+    if kv_len < 512:
+        return 1
+    return int(max(1, min(kv_len // 128, 32, max(1, 4096 // (B * Hq)))))
+
+
+def attn_decode_split(qkv_new, cache, mask, kv_len, Hq, Hkv, D, scale, n_splits):
+    """attn_decode with the keys of every head split over n_splits workgroups (ecgb_attn_decode_split)."""
+    B, cap, W = cache.shape
+    q = qkv_new[:, :Hq * D].contiguous()
+    o = torch.empty((B, Hq * D), dtype=torch.bfloat16, device=q.device)
+    need = _L().ecgb_attn_decode_split_scratch_bytes(cap, B, Hq, D, n_splits)
+    key = (q.device, need)
+    buf = _split_scratch.get(key)
+    if buf is None:
+        _split_scratch.clear()                       # one live buffer: the shapes of a generate() call do not change
+        buf = _split_scratch[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
+    _lib.check(_L().ecgb_attn_decode_split(_p(q), _off(cache, 0), _off(cache, Hkv * D), W, cap, _p(mask), mask.stride(0), _p(o),
+                                           B, int(kv_len), Hq, Hkv, D, float(scale), int(n_splits), _p(buf), need, _st()))
+    return o
+
+
 def attn_decode_dyn(qkv_new, cache, mask, kv_len_dev, Hq, Hkv, D, scale):
     """attn_decode with the number of valid cache rows in device memory (int32[1]): replayable from a captured graph."""
     B, cap, W = cache.shape

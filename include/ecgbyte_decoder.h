@@ -139,6 +139,16 @@ int ecgb_attn_decode(const void *q_dev, const void *k_cache_dev, const void *v_c
                      const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, int n_q_heads,
                      int n_kv_heads, int head_dim, float scale, void *stream);
 
+/* The same step with the keys of every head split over `n_splits` workgroups (long caches, few heads: one CU cannot pull a
+ * long cache fast enough, the chip has 256): scores + per-split statistics, then partial P.V with the global statistics,
+ * then the sum of the partial outputs -- three launches; same arithmetic per key as ecgb_attn_decode.  `scratch_dev` holds
+ * ecgb_attn_decode_split_scratch_bytes(...) bytes (fp32 scores, statistics and partial outputs). */
+size_t ecgb_attn_decode_split_scratch_bytes(long long capacity, int batch, int n_q_heads, int head_dim, int n_splits);
+int ecgb_attn_decode_split(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,
+                           const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, int n_q_heads,
+                           int n_kv_heads, int head_dim, float scale, int n_splits, void *scratch_dev, size_t scratch_bytes,
+                           void *stream);
+
 /* The same with the number of valid cache rows read from device memory, and the append of the new token's K | V row at
  * index *kv_len_dev - 1: nothing in the launch depends on the step, so one decode step captured in a HIP graph can be
  * replayed for every token (the host only bumps the device counter). */

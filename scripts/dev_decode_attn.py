@@ -15,4 +15,13 @@ for B in (1, 8):
         torch.cuda.synchronize(); e0.record()
         for _ in range(200): ops.attn_decode(qkv, cache, mask, L, Hq, Hkv, D, 0.0625)
         e1.record(); torch.cuda.synchronize()
-        print(f"B {B} len {L:5d}: {e0.elapsed_time(e1) / 200 * 1e3:7.1f} us per call (incl. the q copy)")
+        one = e0.elapsed_time(e1) / 200 * 1e3
+        ns = ops.decode_splits(L, B, Hq)
+        sp = float("nan")
+        if ns > 1:
+            for _ in range(10): ops.attn_decode_split(qkv, cache, mask, L, Hq, Hkv, D, 0.0625, ns)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(200): ops.attn_decode_split(qkv, cache, mask, L, Hq, Hkv, D, 0.0625, ns)
+            e1.record(); torch.cuda.synchronize()
+            sp = e0.elapsed_time(e1) / 200 * 1e3
+        print(f"B {B} len {L:5d}: one workgroup per head {one:7.1f} us   split over {ns:2d}: {sp:7.1f} us   (per call, incl. the q copy)")

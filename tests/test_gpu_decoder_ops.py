@@ -299,3 +299,32 @@ def test_sumsq_multi_equals_per_tensor_sum(ops):
     ops.sumsq_multi(ts, acc, plan)
     want = sum(float((t.float() ** 2).sum()) for t in ts)
     assert abs(acc.item() - want) <= 1e-4 * want
+
+
+@pytest.mark.parametrize("D,Hq,Hkv", [(64, 4, 2), (128, 4, 1), (256, 8, 1)])
+@pytest.mark.parametrize("B,n", [(1, 700), (3, 1500), (2, 37)])
+def test_decode_attention_single_and_split_kernels(ops, D, Hq, Hkv, B, n):
+    """One query per head against a KV cache with padded positions: the one-workgroup kernel and the kernel that splits a
+    head's keys over workgroups, against softmax(q.K^T * scale + mask) . V in fp32 with P cast to bf16 (as SDPA does)."""
+    torch.manual_seed(D + n)
+    cap = n + 11
+    cache = (torch.randn(B, cap, 2 * Hkv * D, device="cuda") * 0.7).to(torch.bfloat16)
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * D, device="cuda").to(torch.bfloat16)
+    mask = torch.ones(B, cap, device="cuda")
+    mask[:, :5] = 0                                             # left padding
+    mask[B - 1, 5:9] = 0
+    scale = D ** -0.5
+    q = qkv[:, :Hq * D].float().view(B, Hq, D)
+    k = cache[:, :n, :Hkv * D].float().view(B, n, Hkv, D).repeat_interleave(Hq // Hkv, dim=2)
+    v = cache[:, :n, Hkv * D:].float().view(B, n, Hkv, D).repeat_interleave(Hq // Hkv, dim=2)
+    s = torch.einsum("bhd,bnhd->bhn", q, k) * scale
+    s = s.masked_fill(mask[:, None, :n] == 0, float("-inf"))
+    p = torch.softmax(s, dim=-1).to(torch.bfloat16).float()
+    want = torch.einsum("bhn,bnhd->bhd", p, v).reshape(B, Hq * D)
+    one = ops.attn_decode(qkv, cache, mask, n, Hq, Hkv, D, scale).float()
+    assert (one - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-3
+    for ns in (2, 5, 16):
+        got = ops.attn_decode_split(qkv, cache, mask, n, Hq, Hkv, D, scale, ns).float()
+        assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-3, ns
+        assert (got - one).abs().max().item() <= 1e-2 * want.abs().max().item() + 1e-3, ns   # same arithmetic per key, other summation order
+    assert ops.decode_splits(100, 1, 8) == 1 and ops.decode_splits(2048, 1, 8) == 16 and ops.decode_splits(700, 8, 8) == 5
