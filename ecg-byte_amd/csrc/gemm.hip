@@ -812,6 +812,68 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs G)
     }
 }
 
+// More than two rows and many columns (the batched decode step's gate||up and output-head products): with one column per
+// wave every column re-reads the M activation pieces through L1 -- 8x the weight traffic at M = 8, and L1 bandwidth, not
+// HBM, is the limit (2 TB/s).  Here a wave takes COLS columns: the activation pieces are loaded and unpacked once per
+// K-step and used for all of them.
+template <int MR, int COLS>
+__global__ __launch_bounds__(256) void gemm_nt_skinny_cols_kernel(GemmArgs G)
+{
+    const int lane = threadIdx.x & 63;
+    const long long n0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * COLS;
+    if (n0 >= G.N) return;
+    float acc[COLS][MR];
+#pragma unroll
+    for (int c = 0; c < COLS; ++c)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) acc[c][m] = 0.f;
+    for (int k = lane * 8; k < G.K; k += 512) {
+        bf16x8 vb[COLS], va[MR];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) vb[c] = *reinterpret_cast<const bf16x8 *>(G.B + min(n0 + c, (long long)G.N - 1) * G.ldb + k);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) va[m] = *reinterpret_cast<const bf16x8 *>(G.A + (long long)min(m, G.M - 1) * G.lda + k);
+        float fa[MR][8];
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fa[m][j] = __uint_as_float((unsigned)(unsigned short)va[m][j] << 16);
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) {
+            float fb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fb[j] = __uint_as_float((unsigned)(unsigned short)vb[c][j] << 16);
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[c][m] += fa[m][j] * fb[j];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < COLS; ++c)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) acc[c][m] += __shfl_xor(acc[c][m], d, 64);
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) {
+            const long long n = n0 + c;
+            if (n >= G.N) break;
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                if (m >= G.M) break;
+                const float v = acc[c][m] * G.alpha;
+                if (G.accumulate_f32 == 1) reinterpret_cast<float *>(G.C)[(long long)m * G.ldc + n] += v;
+                else {
+                    unsigned short *q = reinterpret_cast<unsigned short *>(G.C) + (long long)m * G.ldc + n;
+                    *q = f2bf_rn(G.accumulate_f32 == 2 ? __uint_as_float((unsigned)*q << 16) + v : v);
+                }
+            }
+        }
+    }
+}
+
 int g_gemm_tile = 0;   // 0 auto; forced: 128 = 128x128 tile, 256 = 256x256 phased on 16x16x32 MFMA (the default for big problems),
                        // 257 = 256x256 on 32x32x16 MFMA, 258 = 256x256 on 16x16x32 with one barrier pair per K-tile (the earlier kernels, kept for A/B)
 
@@ -890,6 +952,7 @@ extern "C" int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b
             else hipLaunchKernelGGL((gemm_nt_skinny_kernel<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, G);
         } else {
             if (split) hipLaunchKernelGGL((gemm_nt_skinny_kernel<8, 4>), grid, dim3(256), 0, (hipStream_t)stream, G);
+            else if (N >= 8192) hipLaunchKernelGGL((gemm_nt_skinny_cols_kernel<8, 4>), dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, G);
             else hipLaunchKernelGGL((gemm_nt_skinny_kernel<8, 1>), grid, dim3(256), 0, (hipStream_t)stream, G);
         }
         const hipError_t e = hipGetLastError();

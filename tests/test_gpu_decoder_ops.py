@@ -31,7 +31,7 @@ def _close(got, ref, atol, rtol=2 ** -7):
 
 @pytest.mark.parametrize("tile", [128, 256, 257, 258])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 136, 128), (1024, 3072, 2048), (64, 512, 8192), (520, 300, 192),
-                                   (1, 4099, 2048), (2, 640, 64), (5, 1000, 8192), (8, 132, 4096), (1, 2048, 16384), (2, 36, 8256)])   # the last four: the few-row (decode step) kernel
+                                   (1, 4099, 2048), (2, 640, 64), (5, 1000, 8192), (8, 132, 4096), (1, 2048, 16384), (2, 36, 8256), (7, 8203, 256), (8, 16384, 2048)])   # the last eight: the few-row (decode step) kernel
 def test_gemm_nt(ops, M, N, K, tile):
     ops.set_gemm_tile(tile)
     try:
