@@ -88,6 +88,17 @@ def cpu_baseline(merges, pc, L, seed, budget_s=12.0):
         toks_f += len(O.encode_text(O.symbols_to_text(sym), merges))
         n_f += 1
     dt_f = time.perf_counter() - t0
+    # the quantiser alone: Python-level per-sample loop as the reference runs it, and the C restatement
+    t0 = time.perf_counter(); n_py = 0
+    while time.perf_counter() - t0 < 1.0:
+        O.quantize_python_style(x[n_py % 64], p1, p99)
+        n_py += 1
+    dt_py = time.perf_counter() - t0
+    t0 = time.perf_counter(); n_c = 0
+    while time.perf_counter() - t0 < 0.5:
+        O.quantize(x[n_c % 64], p1, p99)
+        n_c += 1
+    dt_c = time.perf_counter() - t0
     # all host cores, one record per thread at a time; the C calls release the GIL
     from concurrent.futures import ThreadPoolExecutor
     n_thr = max(1, min(os.cpu_count() or 1, 64))
@@ -109,6 +120,8 @@ def cpu_baseline(merges, pc, L, seed, budget_s=12.0):
         "records_per_s": n_f / dt_f,
         "value_trie_built_once": toks / dt_once,
         "records_per_s_trie_built_once": n_once / dt_once,
+        "quantiser_python_style_symbols_per_s": n_py * 12 * L / dt_py,      # np.vectorize + join, one core (tokenizer_utils.py:14-19)
+        "quantiser_c_symbols_per_s": n_c * 12 * L / dt_c,
         "host_cpus": os.cpu_count(),
     }
 

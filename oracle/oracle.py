@@ -93,6 +93,21 @@ def quantize(signal, p1, p99, want_clipped=False):
     return (clipped, sym) if want_clipped else sym
 
 
+def quantize_python_style(signal, p1, p99) -> str:
+    """normalize_all + the consumer's join, restated with the reference's COST structure (tokenizer_utils.py:14-19,
+    data_loader.py:75): numpy arithmetic, then one Python-level call per sample (np.vectorize) to build a '<U1' array,
+    then ''.join.  Only bench.py's cpu_baseline times it (the Python quantiser's cost is reported beside
+    the encoder's); the C restatement `quantize` is the checker."""
+    x = np.asarray(signal, dtype=np.float64)
+    lo, hi = p1 - 0.5, p99 + 0.5
+    norm = (x - lo) / ((hi - lo) + 1e-6)
+    clipped = np.clip(norm, 0, 1)
+    level = np.minimum(np.floor(clipped * 26), 25).astype(np.uint8)
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    sym = np.vectorize(lambda v: letters[v])(level)
+    return "".join(sym.flatten())
+
+
 def dequantize(sym, p1, p99):
     s = np.ascontiguousarray(sym, dtype=np.uint8)
     out = np.empty(s.shape, dtype=np.float64)
