@@ -78,6 +78,8 @@ struct QuantParams {
     double a;        // p1 - 0.5
     double d;        // ((p99 + 0.5) - (p1 - 0.5)) + 1e-6
     double scale;    // 26 / d, for the first guess of the level
+    double nas;      // -a * scale: q = fma(x, scale, nas) in the staging loops of the encode kernels
+    float amb_thr;   // a sample is ambiguous when |frac(q) - 0.5| exceeds this (staging loops of the encode kernels)
     double thr[28];  // thr[k] = smallest x whose level is >= k (k = 1..25); thr[0] = -inf, thr[26..27] = +inf
     int use_thresholds;
 };
@@ -88,8 +90,12 @@ QuantParams make_quant_params(double p1, double p99)
     q.a = p1 - 0.5;
     q.d = ((p99 + 0.5) - (p1 - 0.5)) + 1e-6;
     q.scale = 26.0 / q.d;
+    q.nas = -(q.a * q.scale);
     const double inf = std::numeric_limits<double>::infinity();
     q.use_thresholds = (q.d > 0.0) && std::isfinite(q.d) && std::isfinite(q.a) && std::isfinite(q.scale);
+    // beyond |a * scale| = 1e9 the rounding of fma(x, scale, nas) nears the 1e-4 band of level_f32: every group is then
+    // declared ambiguous and takes the exact staircase (slow, exact)
+    q.amb_thr = (std::fabs(q.a * q.scale) < 1e9) ? 0.5f - 1e-4f : -1.0f;
     q.thr[0] = -inf;
     q.thr[26] = q.thr[27] = inf;
     for (int k = 1; k <= 25; ++k) q.thr[k] = inf;
@@ -139,21 +145,21 @@ __device__ __forceinline__ uint32_t level_fast(double x, double a, double scale,
 // same in float as in double and the argument of level_fast applies; clamping in float (NaN -> 0 by the IEEE max) and the
 // truncating convert replace the double-precision floor / compares.  The (rare) group with an ambiguous sample is redone
 // from the exact staircase: one branch per four samples.
-__device__ __forceinline__ uint32_t level_f32(double x, double a, double scale, bool &amb)
+__device__ __forceinline__ uint32_t level_f32(double x, double scale, double nas, float amb_thr, bool &amb)
 {
-    const float qf = (float)((x - a) * scale);
+    const float qf = (float)__builtin_fma(x, scale, nas);   // (x - a) * scale in one operation: |a * scale| < 1e9 keeps it within 1e-7 of it
     const float t = __builtin_amdgcn_fractf(qf);
-    amb = amb || (fabsf(t - 0.5f) > 0.5f - 1e-4f);
+    amb = amb || (fabsf(t - 0.5f) > amb_thr);               // 0.5 - 1e-4 (make_quant_params)
     return (uint32_t)(int)fminf(fmaxf(qf, 0.0f), 25.5f);
 }
 
-__device__ __forceinline__ uint32_t levels4(double2 v0, double2 v1, double a, double scale, const double *thr)
+__device__ __forceinline__ uint32_t levels4(double2 v0, double2 v1, double a, double scale, double nas, float amb_thr, const double *thr)
 {
     bool amb = false;
-    uint32_t w = level_f32(v0.x, a, scale, amb);
-    w |= level_f32(v0.y, a, scale, amb) << 8;
-    w |= level_f32(v1.x, a, scale, amb) << 16;
-    w |= level_f32(v1.y, a, scale, amb) << 24;
+    uint32_t w = level_f32(v0.x, scale, nas, amb_thr, amb);
+    w |= level_f32(v0.y, scale, nas, amb_thr, amb) << 8;
+    w |= level_f32(v1.x, scale, nas, amb_thr, amb) << 16;
+    w |= level_f32(v1.y, scale, nas, amb_thr, amb) << 24;
     if (amb) {
         w = level_from_thresholds(v0.x, a, scale, thr);
         w |= level_from_thresholds(v0.y, a, scale, thr) << 8;
@@ -322,7 +328,7 @@ __device__ __forceinline__ uint32_t swz(uint32_t k)
 template <int CHUNK, int INPUT, bool VEC>
 __device__ __forceinline__ void stage_symbols(uint8_t *sym, uint32_t stage_len, uint32_t n_here,
                                               const double *x, const uint8_t *t8, uint32_t lane,
-                                              uint32_t nlanes, double qa, double qscale,
+                                              uint32_t nlanes, double qa, double qscale, double qnas, float qamb,
                                               const double *s_thr, const uint8_t *s_b2c)
 {
     if (INPUT == INPUT_F64) {
@@ -341,7 +347,7 @@ __device__ __forceinline__ void stage_symbols(uint8_t *sym, uint32_t stage_len, 
             }
 #pragma unroll
             for (int u = 0; u < kStageGroups; ++u) {
-                const uint32_t w = levels4(v[2 * u], v[2 * u + 1], qa, qscale, s_thr);
+                const uint32_t w = levels4(v[2 * u], v[2 * u + 1], qa, qscale, qnas, qamb, s_thr);
                 if (k + u * step < vec_len) *reinterpret_cast<uint32_t *>(sym + swz<CHUNK>(k + u * step)) = w;
             }
         }
@@ -597,7 +603,8 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
     // (the wave's list base as a scalar: list stores then take the base + 32-bit offset form)
     uint32_t *tok_list = reinterpret_cast<uint32_t *>(A.ids_half) + (size_t)__builtin_amdgcn_readfirstlane(gw) * kFlowSlot;
     const uint32_t n = A.n;
-    const double qa = A.qp.a, qscale = A.qp.scale;
+    const double qa = A.qp.a, qscale = A.qp.scale, qnas = A.qp.nas;
+    const float qamb = A.qp.amb_thr;
 #ifdef ECGB_PROFILE
     long long t_prof = clock64();
 #endif
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
             const uint32_t seg_len = min(SEG, n - seg_base);
             const uint32_t stage_len = min(sym_cap, (n - seg_base + 16u) & ~15u);   // >= 1 sentinel past n
             stage_symbols<0, INPUT, VEC>(sym, stage_len, n - seg_base, A.signal + row + seg_base,
-                                         A.raw + row + seg_base, c, 64, qa, qscale, s_thr, s_b2c);
+                                         A.raw + row + seg_base, c, 64, qa, qscale, qnas, qamb, s_thr, s_b2c);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             build_dmap<0>(sym, dmap, stage_len, c, 64);
@@ -915,7 +922,8 @@ __global__ __launch_bounds__(kLanes) void encode_wg_kernel(EncodeArgs A)
     const WalkCtx W{sym, marks, dmap, ids_half, s_trie, A.trie, s_run, A.n_lds_nodes};
 #endif
     const uint32_t n = A.n;
-    const double qa = A.qp.a, qscale = A.qp.scale;
+    const double qa = A.qp.a, qscale = A.qp.scale, qnas = A.qp.nas;
+    const float qamb = A.qp.amb_thr;
 
     for (uint32_t b = blockIdx.x; b < A.batch; b += gridDim.x) {
         const size_t row = (size_t)b * n;
@@ -927,7 +935,7 @@ __global__ __launch_bounds__(kLanes) void encode_wg_kernel(EncodeArgs A)
             __syncthreads();   // previous segment fully emitted; (first time) trie + tables staged
             const uint32_t stage_len = min(sym_cap, (n - seg_base + 16u) & ~15u);
             stage_symbols<kChunk, INPUT, VEC>(sym, stage_len, n - seg_base, A.signal + row + seg_base,
-                                      A.raw + row + seg_base, c, kLanes, qa, qscale, s_thr, s_b2c);
+                                      A.raw + row + seg_base, c, kLanes, qa, qscale, qnas, qamb, s_thr, s_b2c);
 #pragma unroll
             for (int w = 0; w < kWordsPerChunk; ++w) my[w] = 0;
             __syncthreads();

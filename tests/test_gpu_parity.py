@@ -138,6 +138,23 @@ def test_fused_staging_on_the_quantiser_golden_inputs(dev, plan):
                 assert np.array_equal(ids[b, : counts[b]].astype(np.uint32), want), f"case {i} n {n}"
 
 
+def test_fused_staging_with_a_huge_offset_takes_the_exact_route(dev, plan):
+    """Percentiles 1e9 away from zero: (x - a) * scale cannot be formed as one fma accurately enough, the handle must fall
+    back to the literal operation sequence -- the ids still equal the oracle's."""
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    _, merges, _ = load_tokenizer("c1")
+    tk = HipTokenizer(merges)
+    trie = O.Trie(merges)
+    rng = np.random.default_rng(5)
+    pc = {"percentile_1": 1e9, "percentile_99": 1e9 + 1.5}
+    x = 1e9 + rng.uniform(-0.7, 2.2, size=(4, 12, 250))
+    ids, counts = tk.quantize_encode(torch.from_numpy(x).cuda(), pc)
+    ids, counts = ids.cpu().numpy(), counts.cpu().numpy()
+    for b in range(4):
+        want = trie.quantize_encode(x[b], pc["percentile_1"], pc["percentile_99"])
+        assert counts[b] == want.size and np.array_equal(ids[b, : counts[b]].astype(np.uint32), want)
+
+
 def test_one_id_on_expansions_of_different_lengths(dev, plan):
     """The id -> length table of the wave-per-record kernel cannot describe such a vocabulary: the handle must route
     around it (lib.rs keeps whatever id the merges list gives a byte string)."""
