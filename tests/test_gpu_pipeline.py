@@ -215,3 +215,35 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0
     assert out["train"]["steps"] == 2 and np.isfinite(out["train"]["final_loss"]) and "dp2" in out["train"]["config"]["parallelism"]
     assert np.isfinite(out["train"]["lora_r16"]["final_loss"])
+
+
+def test_bench_line_contract_single_gpu():
+    """The one JSON line bench.py prints (N = 1, encode leg with its CPU baseline; the train leg is skipped here, the
+    two-rank test above runs it): every key the driver and SURVEY 8d ask for, with consistent values."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--no-train"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["metric"] == "ecg_tokens_per_sec_encode" and out["unit"] == "tokens/s" and out["n_gpus"] == 1
+    assert out["steps"] == 5 and out["warmup"] == 2 and out["higher_is_better"] is True and out["scaling"] == "weak"
+    assert out["vs_baseline"] is None and out["data"] == "synthetic" and "workload" in out["config"] and "model" not in out["config"]
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.9
+    # whole-job value = tokens of one launch / time of one launch
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - out["tokens_per_record"] * out["config"]["records_per_gpu"]) < 1e-6 * out["value"]
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "tokens/s" and c["value"] > 0 and "records" in c["sample"]
+    assert c["quantiser_python_style_symbols_per_s"] < c["quantiser_c_symbols_per_s"]
