@@ -1,42 +1,42 @@
-"""Mirror of ecg_byte/utils/file_utils.py (same names, arguments and return values): the on-disk layout the
-reference's preprocessing leaves behind and main.py consumes --
+"""Host-side helpers for the on-disk layout the reference's preprocessing leaves behind and its `main.py` consumes (the
+public names, arguments and return values of `ecg_byte/utils/file_utils.py`, so callers switch by changing the import):
   data/<dataset>/ecg/<split>/ecg_{i}_{j}.npy    float64 (12, seg_len) segment j of record i   (preprocess_utils.py:215-226)
   data/<dataset>/text/<split>/text_{i}_{j}.json the paired report / conversation / QA triple  (preprocess_utils.py:773-792)
   data/<tokenizer>.pkl                          pickle((vocab, merges))                       (tokenizer_utils.py:62-69)
   percentiles .npy                              pickled dict {'percentile_1', 'percentile_99'} (preprocess_utils.py:208-210)
-Host-side only (paths, json, pickle): nothing here touches the GPU."""
+Paths, json and pickle only: nothing here touches the GPU."""
 from __future__ import annotations
 
-import glob
 import json
-import os
 import pickle
 import random
 import re
+from pathlib import Path
 
 import numpy as np
 
+_RECORD_SEGMENT = re.compile(r"(\d+)_(\d+)")      # ecg_{record}_{segment}.npy / text_{record}_{segment}.json
+
 
 def ensure_directory_exists(directory_path):
-    """file_utils.py:10-15"""
+    """Creates the directory (and parents); reports instead of raising, like the reference (file_utils.py:10-15)."""
     try:
-        os.makedirs(directory_path, exist_ok=True)
-        print(f"Directory ensured: {directory_path}")
-    except Exception as e:
-        print(f"Error ensuring directory {directory_path}: {str(e)}")
+        Path(directory_path).mkdir(parents=True, exist_ok=True)
+    except OSError as err:
+        print(f"could not create {directory_path}: {err}")
+    else:
+        print(f"directory ready: {directory_path}")
 
 
 def load_vocab_and_merges(filename):
-    """file_utils.py:17-20"""
-    with open(filename, "rb") as f:
-        vocab, merges = pickle.load(f)
+    """pickle((vocab, merges)) as `tokenizer_utils.save_vocab_and_merges` writes it (file_utils.py:17-20)."""
+    vocab, merges = pickle.loads(Path(filename).read_bytes())
     return vocab, merges
 
 
 def open_json(path_to_file):
     """file_utils.py:22-24"""
-    with open(path_to_file) as json_file:
-        return json.load(json_file)
+    return json.loads(Path(path_to_file).read_text())
 
 
 def load_npy(file_path):
@@ -44,42 +44,43 @@ def load_npy(file_path):
     return np.load(file_path)
 
 
+def _by_record_segment(directory, pattern):
+    """{(record, segment): path} for the files of `directory` whose base name carries a `<digits>_<digits>` pair."""
+    found = {}
+    for path in Path(directory).glob(pattern):
+        m = _RECORD_SEGMENT.search(path.name)
+        if m:
+            found[(int(m.group(1)), int(m.group(2)))] = str(path)
+    return found
+
+
 def align_signal_text_files(signal_dir, text_dir):
-    """Pairs `*.npy` and `*.json` files by the first `(\\d+)_(\\d+)` in their base names and returns the two path lists
-    sorted by that (record, segment) index (file_utils.py:30-48).  Files without a partner are dropped."""
-    signal_files = glob.glob(os.path.join(signal_dir, "*.npy"))
-    text_files = glob.glob(os.path.join(text_dir, "*.json"))
-
-    def extract_indices(filename):
-        match = re.search(r"(\d+)_(\d+)", os.path.basename(filename))
-        return tuple(map(int, match.groups())) if match else None
-
-    signal_dict = {extract_indices(f): f for f in signal_files if extract_indices(f)}
-    text_dict = {extract_indices(f): f for f in text_files if extract_indices(f)}
-    common = sorted(set(signal_dict) & set(text_dict))
-    return [signal_dict[i] for i in common], [text_dict[i] for i in common]
+    """The `.npy` signals and `.json` texts that share a (record, segment) index, as two parallel path lists ordered
+    by that index; files without a partner are left out (file_utils.py:30-48)."""
+    signals = _by_record_segment(signal_dir, "*.npy")
+    texts = _by_record_segment(text_dir, "*.json")
+    keys = sorted(signals.keys() & texts.keys())
+    return [signals[k] for k in keys], [texts[k] for k in keys]
 
 
 def sample_N_percent_indices(length, N=0.1):
-    """file_utils.py:51-53 (uses the `random` module's global state, as the reference does)."""
-    sample_size = max(1, int(length * N))
-    return random.sample(range(length), sample_size)
+    """max(1, int(length * N)) distinct indices, drawn with the `random` module's global state as the reference does
+    (file_utils.py:51-53): seeding `random` reproduces the reference's subset."""
+    return random.sample(range(length), max(1, int(length * N)))
 
 
 def sample_N_percent_from_lists(list1, list2=None, N=0.05):
-    """file_utils.py:55-64"""
-    if list2 is not None and len(list1) != len(list2):
+    """The same random subset of one list or of two parallel lists (file_utils.py:55-64)."""
+    if list2 is not None and len(list2) != len(list1):
         raise ValueError("Both lists must have the same length")
-    idx = sample_N_percent_indices(len(list1), N)
-    s1 = [list1[i] for i in idx]
-    if list2 is None:
-        return s1
-    return s1, [list2[i] for i in idx]
+    picked = sample_N_percent_indices(len(list1), N)
+    first = [list1[i] for i in picked]
+    return first if list2 is None else (first, [list2[i] for i in picked])
 
 
 def save_percentiles(path, percentile_1, percentile_99):
-    """The writer side of `np.load(args.percentiles, allow_pickle=True).item()` (data_loader.py:47):
-    preprocess_utils.py:208-210 saves a dict with np.save."""
+    """Writer side of `np.load(args.percentiles, allow_pickle=True).item()` (data_loader.py:47): the reference's
+    preprocessing stores the dict with np.save (preprocess_utils.py:208-210)."""
     np.save(path, {"percentile_1": float(percentile_1), "percentile_99": float(percentile_99)})
 
 

@@ -1,71 +1,95 @@
-"""Mirror of the reference CLI ecg_byte/train_tokenizer.py (same flags, 8-16; same outputs, 19-66)
-with corpus building, BPE training and the self-check encode on the MI355X.
+"""Tokenizer training CLI: the flags of the reference's `ecg_byte/train_tokenizer.py` (8-16), on the MI355X path.
 
     python -m ecg_byte_amd.train_tokenizer --train --num_merges 3500 --sampled_files F --percentiles P
+
+Two stages, either of which can run alone:
+  train       corpus string from the sampled .npy records (quantise on the device) -> `rust_bpe.byte_pair_encoding`
+              (HIP trainer) -> pickle((vocab, merges))                                     [reference: 19-42]
+  self-check  one record: quantise, encode with the stored merges, decode, compare         [reference: 44-66]
+`main` returns True when the decoded text equals the quantised text -- the reference prints that comparison; the tests
+use it.
 """
 from __future__ import annotations
 
 import argparse
 import time
+from dataclasses import dataclass
 
 import numpy as np
 
 from . import rust_bpe
-from .tokenizer_utils import (decode_text, encode_text, load_vocab_and_merges, process_ecg,
-                              process_large_file, reverse_normalize_all, save_vocab_and_merges)
+from . import tokenizer_utils as tu
+
+# (flag, type / action, default, help) -- the reference's options, plus --check_ecg / --out for what it hard-codes
+_OPTIONS = (
+    ("--num_merges", int, 3500, "number of BPE merges (vocabulary size - 256)"),
+    ("--sampled_files", str, None, "text file listing the sampled .npy records, one path per line"),
+    ("--num_processes", int, 2, "accepted for compatibility; the device path does not fork workers"),
+    ("--percentiles", str, None, "pickled-dict .npy with percentile_1 / percentile_99"),
+    ("--train", "store_true", None, "train a tokenizer before the self-check"),
+    ("--loaded", str, None, "existing tokenizer .pkl to check instead of the one just trained"),
+    ("--check_ecg", str, "./data/seg_ecg_qa_ptb_500/ecg/train/ecg_10_1.npy", "record used by the self-check"),
+    ("--out", str, None, "where to write the tokenizer (default ./data/tokenizer_{num_merges}.pkl)"),
+)
 
 
 def get_args(argv=None):
-    parser = argparse.ArgumentParser(description=None)
-    parser.add_argument("--num_merges", type=int, default=3500, help="Please choose the vocabulary size")
-    parser.add_argument("--sampled_files", type=str, default=None, help="Path to the .txt file of sampled ecgs")
-    parser.add_argument("--num_processes", type=int, default=2, help="Accepted for compatibility (GPU path ignores it)")
-    parser.add_argument("--percentiles", type=str, default=None, help="Path to the calculated percentiles")
-    parser.add_argument("--train", action="store_true", default=None, help="Train the tokenizer")
-    parser.add_argument("--loaded", type=str, default=None, help="Path to an existing .pkl tokenizer")
-    parser.add_argument("--check_ecg", type=str, default="./data/seg_ecg_qa_ptb_500/ecg/train/ecg_10_1.npy",
-                        help="Record used for the encode/decode self-check (the reference hard-codes this path)")
-    parser.add_argument("--out", type=str, default=None, help="Output .pkl (default ./data/tokenizer_{num_merges}.pkl)")
-    return parser.parse_args(argv)
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    for flag, kind, default, text in _OPTIONS:
+        if kind == "store_true":
+            ap.add_argument(flag, action="store_true", default=default, help=text)
+        else:
+            ap.add_argument(flag, type=kind, default=default, help=text)
+    return ap.parse_args(argv)
 
 
-def main(args):
+@dataclass
+class TrainReport:
+    symbols: int
+    tokens: int
+    vocab_size: int
+    seconds: float
+
+    def lines(self):
+        ratio = self.symbols / max(1, self.tokens)
+        yield f"corpus: {self.symbols} symbols -> {self.tokens} tokens ({ratio:.2f}x), vocabulary {self.vocab_size}"
+        yield f"byte_pair_encoding: {self.seconds:.2f} s"
+
+
+def train(sampled_files, percentiles, num_merges, num_processes, out_path) -> TrainReport:
+    corpus = tu.process_large_file(sampled_files, percentiles, num_processes)
+    t0 = time.time()
+    ids, vocab, merges = rust_bpe.byte_pair_encoding(corpus, num_merges, num_processes)
+    dt = time.time() - t0
+    tu.save_vocab_and_merges(vocab, merges, out_path)
+    return TrainReport(symbols=len(corpus), tokens=len(ids), vocab_size=len(vocab), seconds=dt)
+
+
+def self_check(tokenizer_path, record_path, percentiles) -> bool:
+    """encode -> decode of one record must give its quantised text back (train_tokenizer.py:58-60)."""
+    vocab, merges = tu.load_vocab_and_merges(tokenizer_path)
+    signal = np.load(record_path)
+    text = tu.process_ecg(record_path, percentiles=percentiles)
+    ids = tu.encode_text(text, merges)
+    back = tu.decode_text(ids, vocab)
+    same = back == text
+    print(f"self-check on {record_path}: {len(text)} symbols -> {len(ids)} tokens ({len(text) / max(1, len(ids)):.2f}x); "
+          f"first ids {list(ids[:12])}; round trip {'ok' if same else 'MISMATCH'}")
+    if same:
+        rebuilt = tu.reverse_normalize_all(np.array(list(back)).reshape(signal.shape), percentiles)
+        print(f"largest |signal - dequantised| = {float(np.max(np.abs(signal - rebuilt))):.6g}")
+    return same
+
+
+def main(args) -> bool:
     percentiles = np.load(args.percentiles, allow_pickle=True).item()
-    tokenizer_file_name = args.out or f"./data/tokenizer_{args.num_merges}.pkl"
+    target = args.out or f"./data/tokenizer_{args.num_merges}.pkl"
     if args.train:
-        all_string_signals = process_large_file(args.sampled_files, percentiles, args.num_processes)
-        print(f"Total ECGs processed: {len(all_string_signals)}")
-        print(list(all_string_signals)[:100])
-        start_time = time.time()
-        ids, vocab, merges = rust_bpe.byte_pair_encoding(all_string_signals, args.num_merges, args.num_processes)
-        print(f"Byte pair encoding executed in {time.time() - start_time:.2f} seconds")
-        print("Shared vocabulary across all ECGs:")
-        print(f"Original length: {len(all_string_signals)}")
-        print(f"Encoded length: {len(ids)}")
-        print(f"Compression ratio: {len(all_string_signals) / max(1, len(ids)):.2f}X")
-        print(f"Vocabulary size: {len(vocab)}")
-        save_vocab_and_merges(vocab, merges, tokenizer_file_name)
-        print(f"Vocabulary and merges saved to {tokenizer_file_name}")
-    if args.loaded is None:
-        args.loaded = tokenizer_file_name
-    loaded_vocab, loaded_merges = load_vocab_and_merges(args.loaded)
-    print(f"Loaded vocabulary and merges from {args.loaded}")
-
-    new_ecg_signal = np.load(args.check_ecg)
-    new_ecg_text = process_ecg(args.check_ecg, percentiles=percentiles)
-    print(f"Processed ECG signal to text (first 100 characters): {new_ecg_text[:100]}...")
-    print(f"Total tokens: {len(new_ecg_text)}")
-    encoded_ecg = encode_text(new_ecg_text, loaded_merges)
-    print(f"Encoded ECG (first 20 tokens): {encoded_ecg[:20]}...")
-    print(f"Total tokens: {len(encoded_ecg)}")
-    print(f"Compression ratio: {len(new_ecg_text) / max(1, len(encoded_ecg)):.2f}X")
-    decoded_text = decode_text(encoded_ecg, loaded_vocab)
-    print(f"Decoded text (first 100 characters): {decoded_text[:100]}...")
-    print(decoded_text == new_ecg_text)
-    decoded_signal = reverse_normalize_all(np.array(list(decoded_text)).reshape(new_ecg_signal.shape), percentiles)
-    print(f"Maximum difference between original and decoded: {np.max(np.abs(new_ecg_signal - decoded_signal))}")
-    return decoded_text == new_ecg_text
+        for line in train(args.sampled_files, percentiles, args.num_merges, args.num_processes, target).lines():
+            print(line)
+        print(f"tokenizer written to {target}")
+    return self_check(args.loaded or target, args.check_ecg, percentiles)
 
 
 if __name__ == "__main__":
-    main(get_args())
+    raise SystemExit(0 if main(get_args()) else 1)
