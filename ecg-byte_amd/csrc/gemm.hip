@@ -816,18 +816,23 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs G)
 // wave every column re-reads the M activation pieces through L1 -- 8x the weight traffic at M = 8, and L1 bandwidth, not
 // HBM, is the limit (2 TB/s).  Here a wave takes COLS columns: the activation pieces are loaded and unpacked once per
 // K-step and used for all of them.
-template <int MR, int COLS>
+// KS = 4: the four waves of a workgroup share the same COLS columns and take a quarter of the contraction each (long rows,
+// few columns), their sums meet in LDS.
+template <int MR, int COLS, int KS>
 __global__ __launch_bounds__(256) void gemm_nt_skinny_cols_kernel(GemmArgs G)
 {
-    const int lane = threadIdx.x & 63;
-    const long long n0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * COLS;
-    if (n0 >= G.N) return;
+    static_assert(KS == 1 || KS == 4, "one wave per column group, or all four");
+    __shared__ float s_part[KS == 4 ? 4 : 1][COLS][MR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n0 = (KS == 4 ? (long long)blockIdx.x : (long long)blockIdx.x * 4 + wave) * COLS;
+    if (KS == 1 && n0 >= G.N) return;                       // (KS == 4: n0 is the same for the whole workgroup and < N by the grid size)
+    const int k_lo = (KS == 4 ? wave : 0) * (G.K / KS), k_hi = k_lo + G.K / KS;
     float acc[COLS][MR];
 #pragma unroll
     for (int c = 0; c < COLS; ++c)
 #pragma unroll
         for (int m = 0; m < MR; ++m) acc[c][m] = 0.f;
-    for (int k = lane * 8; k < G.K; k += 512) {
+    for (int k = k_lo + lane * 8; k < k_hi; k += 512) {
         bf16x8 vb[COLS], va[MR];
 #pragma unroll
         for (int c = 0; c < COLS; ++c) vb[c] = *reinterpret_cast<const bf16x8 *>(G.B + min(n0 + c, (long long)G.N - 1) * G.ldb + k);
@@ -855,6 +860,22 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_cols_kernel(GemmArgs G)
         for (int m = 0; m < MR; ++m)
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) acc[c][m] += __shfl_xor(acc[c][m], d, 64);
+    if constexpr (KS == 4) {
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < COLS; ++c)
+#pragma unroll
+                for (int m = 0; m < MR; ++m) s_part[wave][c][m] = acc[c][m];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < COLS; ++c)
+#pragma unroll
+                for (int m = 0; m < MR; ++m) acc[c][m] += s_part[1][c][m] + s_part[2][c][m] + s_part[3][c][m];
+        }
+    }
     if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < COLS; ++c) {
@@ -951,8 +972,8 @@ extern "C" int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b
             if (split) hipLaunchKernelGGL((gemm_nt_skinny_kernel<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, G);
             else hipLaunchKernelGGL((gemm_nt_skinny_kernel<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, G);
         } else {
-            if (split) hipLaunchKernelGGL((gemm_nt_skinny_kernel<8, 4>), grid, dim3(256), 0, (hipStream_t)stream, G);
-            else if (N >= 8192) hipLaunchKernelGGL((gemm_nt_skinny_cols_kernel<8, 4>), dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, G);
+            if (split) hipLaunchKernelGGL((gemm_nt_skinny_cols_kernel<8, 4, 4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, G);
+            else if (N >= 8192) hipLaunchKernelGGL((gemm_nt_skinny_cols_kernel<8, 4, 1>), dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, G);
             else hipLaunchKernelGGL((gemm_nt_skinny_kernel<8, 1>), grid, dim3(256), 0, (hipStream_t)stream, G);
         }
         const hipError_t e = hipGetLastError();
