@@ -255,6 +255,9 @@ class DeviceBatchLoader:
                     continue
                 dev, ev, q, a, qs, ans, _pin = cur
                 torch.cuda.current_stream().wait_event(ev)
+                # `dev` was allocated on the copy stream but is read by kernels of the consumer's stream: tell the caching
+                # allocator, or the block could be handed to the next batch's copy while the encoder still reads it
+                dev.record_stream(torch.cuda.current_stream())
                 if inference:
                     ids, counts = ds.assembler.encode(dev, ds.percentiles)
                     r = ds.assembler.assemble(ids, counts, q, inference=True)
