@@ -106,7 +106,8 @@ def test_runners_train_validate_checkpoint_and_generate(ptb_dir, tmp_path):
         losses.append(trainer(model, DeviceBatchLoader(train_ds, batch_size=4, shuffle=True, seed=1), opt, args, epoch, str(run_dir),
                               checkpoint_every=2 if epoch == 0 else 50000)["average_loss"])
         vals.append(validater(model, DeviceBatchLoader(val_ds, batch_size=2), args, epoch)["average_loss"])
-    assert losses[-1] < 0.8 * losses[0] and vals[-1] < vals[0], (losses, vals)
+    # (the Noam schedule's peak makes the last epoch of this tiny run bounce back up: judge the best epoch, not the last)
+    assert min(losses) < 0.6 * losses[0] and min(vals) < 0.7 * vals[0] and vals[-1] < vals[0], (losses, vals)
     assert not os.path.exists(run_dir / "best_train_model_0_1.pth")        # args.toy suppresses the step checkpoints (train.py:34)
     # checkpoint format of main.py:299-306 and its reload (main.py:193-195)
     torch.save({"model": model.state_dict(), "epoch": 5}, run_dir / "best_model.pth")
