@@ -116,7 +116,7 @@ def test_runners_train_validate_checkpoint_and_generate(ptb_dir, tmp_path):
     fresh = LLM(_tiny_model(tok, seed=9), args)
     fresh.load_state_dict(ck["model"])
     v2 = validater(fresh, DeviceBatchLoader(val_ds, batch_size=2), args, 0)["average_loss"]
-    assert abs(v2 - vals[-1]) < 1e-6 * max(1.0, abs(v2))
+    assert abs(v2 - vals[-1]) < 1e-5 * max(1.0, abs(v2))     # (the loss is summed with fp32 atomics)
     # the validation loss equals the training-path loss of the same batch (forward-only path vs autograd path)
     b = next(iter(DeviceBatchLoader(val_ds, batch_size=2)))
     with torch.no_grad():
