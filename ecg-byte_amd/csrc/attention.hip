@@ -622,13 +622,15 @@ __global__ __launch_bounds__(kDecodeThreads) void attn_decode_kernel(const unsig
 //   combine  grid (Hq, B): the partial outputs added in split order, cast to bf16.
 // scratch (floats): scores [B, Hq, cap] | stats [B, Hq, splits, 2] | partial outputs [B, Hq, splits, D].
 constexpr int kSplitThreads = 256;
+constexpr int kSplitMaxChunk = 2048;                     // keys per split the scores kernel can hold (the launcher raises n_splits to fit)
 template <int D>
 __global__ __launch_bounds__(kSplitThreads) void attn_decode_scores_kernel(const unsigned short *q, const unsigned short *kc, long long ld, long long cap,
                                                                            const float *mask, long long mask_ld, float *scores, float *stats,
                                                                            int len, int chunk, int Hq, int Hkv, float scale)
 {
-    constexpr int NW = kSplitThreads / 64, EPL = D / 64, KU = 8;
+    constexpr int NW = kSplitThreads / 64, EPL = D / 64, KU = 16;
     __shared__ float s_red[2 * NW];
+    __shared__ float s_sc[kSplitMaxChunk];                // the split's scores once more: the sum of exponentials reads them here
     const int sp = blockIdx.x, hq = blockIdx.y, b = blockIdx.z, g = hq / (Hq / Hkv), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k0 = sp * chunk, k1 = min(len, k0 + chunk);
     const unsigned short *qp = q + ((long long)b * Hq + hq) * D;
@@ -670,18 +672,18 @@ __global__ __launch_bounds__(kSplitThreads) void attn_decode_scores_kernel(const
             const int j = j0 + u * NW;
             if (j < k1) {
                 const float sdot = (mk[u] != 0.f) ? part[u] * scale : -INFINITY;
-                if (lane == 0) srow[j] = sdot;
+                if (lane == 0) { srow[j] = sdot; s_sc[j - k0] = sdot; }
                 m = fmaxf(m, sdot);
             }
         }
     }
     if (lane == 0) s_red[wave] = m;
-    __syncthreads();                                     // (also orders the score stores before the reads below)
+    __syncthreads();
     m = s_red[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) m = fmaxf(m, s_red[w]);
     float l = 0.f;
-    for (int j = k0 + tid; j < k1; j += kSplitThreads) l += (m == -INFINITY) ? 0.f : __expf(srow[j] - m);
+    for (int j = k0 + tid; j < k1; j += kSplitThreads) l += (m == -INFINITY) ? 0.f : __expf(s_sc[j - k0] - m);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) l += __shfl_xor(l, d, 64);
     if (lane == 0) s_red[NW + wave] = l;
@@ -885,6 +887,11 @@ extern "C" int ecgb_attn_decode_split(const void *q_dev, const void *k_cache_dev
     float *scores = (float *)scratch_dev;
     float *stats = scores + (size_t)batch * n_q_heads * (size_t)capacity;
     float *partial = stats + (size_t)batch * n_q_heads * (size_t)n_splits * 2;
+    if ((kv_len + n_splits - 1) / n_splits > kSplitMaxChunk) n_splits = (kv_len + kSplitMaxChunk - 1) / kSplitMaxChunk;
+    if (scratch_bytes < ecgb_attn_decode_split_scratch_bytes(capacity, batch, n_q_heads, head_dim, n_splits)) {
+        ecgb::set_error("ecgb_attn_decode_split: scratch too small for the splits a cache this long needs");
+        return ECGB_ERR_INVALID;
+    }
     const int chunk = (kv_len + n_splits - 1) / n_splits;
     const dim3 grid((unsigned)n_splits, (unsigned)n_q_heads, (unsigned)batch), gc((unsigned)n_q_heads, (unsigned)batch);
 #define ECGB_SPLIT(D_) do { \

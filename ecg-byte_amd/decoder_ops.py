@@ -249,12 +249,12 @@ _split_scratch = {}
 
 
 def decode_splits(kv_len, B, Hq):
-    """Workgroups a head's keys are split over in a decode step: about 128 keys each (a workgroup then needs one or two
-    batches of loads), at most 32 per head and 4096 in all; 1 = the single-workgroup kernel (short caches: three launches
-    cost more than they save)."""
+    """Workgroups a head's keys are split over in a decode step: about 64 keys each (a wave then needs one batch of key
+    rows), at most 32 per head and 1024 in all; 1 = the single-workgroup kernel (short caches: three launches cost more
+    than they save)."""
     if kv_len < 512:
         return 1
-    return int(max(1, min(kv_len // 128, 32, max(1, 4096 // (B * Hq)))))
+    return int(max(1, min(kv_len // 64, 32, max(1, 1024 // (B * Hq)))))
 
 
 def attn_decode_split(qkv_new, cache, mask, kv_len, Hq, Hkv, D, scale, n_splits):

@@ -327,4 +327,4 @@ def test_decode_attention_single_and_split_kernels(ops, D, Hq, Hkv, B, n):
         got = ops.attn_decode_split(qkv, cache, mask, n, Hq, Hkv, D, scale, ns).float()
         assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-3, ns
         assert (got - one).abs().max().item() <= 1e-2 * want.abs().max().item() + 1e-3, ns   # same arithmetic per key, other summation order
-    assert ops.decode_splits(100, 1, 8) == 1 and ops.decode_splits(2048, 1, 8) == 16 and ops.decode_splits(700, 8, 8) == 5
+    assert ops.decode_splits(100, 1, 8) == 1 and ops.decode_splits(2048, 1, 8) == 32 and ops.decode_splits(700, 8, 8) == 10
