@@ -239,7 +239,7 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_nt_kernel_m16p<256,256> + gemm_tn_kernel_tr<256,256> (bf16 MFMA 16x16x32)",
                         "algorithmic_flops_per_step": flops, "step_ms_hip_events": ev0.elapsed_time(ev1) / args.train_steps}}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baselines are an N = 1 item
         cfg_kw = dict(vocab_size=n_vocab, hidden_size=H, intermediate_size=I, num_hidden_layers=Lyr,
                       num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads,
                       head_dim=cfg.head_dim, rms_norm_eps=cfg.rms_norm_eps)
@@ -375,7 +375,7 @@ def main():
                          "kernel": "encode_flow_kernel<INPUT_F64> (fused quantise+encode, one launch per step)",
                          "kernel_ms": dev_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(merges, pc, L, seed=0)
         if train is not None:
             out["train"] = train
