@@ -431,8 +431,7 @@ class HipCausalLM(nn.Module):
             ls = [None] * 4
             if self.lora is not None:
                 ls[0] = self.lora[i]["qkv"].forward_add(h1, qkv, self.training)
-            ops.rope_(qkv, cos, sin, Hq, D, QKV)
-            _rope_offset(qkv, Hq * D, cos, sin, Hkv, D, QKV)
+            ops.rope_(qkv, cos, sin, Hq + Hkv, D, QKV)                   # the query heads and the key heads lie side by side: one launch
             if self.fused_attention:
                 ao, P = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)       # P slot holds the row log-sum-exps
             else:
@@ -518,8 +517,7 @@ class HipCausalLM(nn.Module):
             qkv = ops.gemm_nt(h1, self.wqkv[i].data)
             if self.lora is not None:
                 self.lora[i]["qkv"].forward_add(h1, qkv, False)
-            ops.rope_(qkv, cos, sin, Hq, D, QKV)
-            _rope_offset(qkv, Hq * D, cos, sin, Hkv, D, QKV)
+            ops.rope_(qkv, cos, sin, Hq + Hkv, D, QKV)                   # the query heads and the key heads lie side by side: one launch
             if kv_out is not None:
                 kv_out[i][:, :S - lpad].copy_(qkv.view(B, S, QKV)[:, lpad:, Hq * D:])
             if self.fused_attention:
@@ -577,8 +575,7 @@ class HipCausalLM(nn.Module):
             qkv = ops.gemm_nt(h1, self.wqkv[i].data)                     # [B, QKV]
             if self.lora is not None:
                 self.lora[i]["qkv"].forward_add(h1, qkv, False)
-            ops.rope_(qkv, cos, sin, Hq, D, QKV)
-            _rope_offset(qkv, Hq * D, cos, sin, Hkv, D, QKV)
+            ops.rope_(qkv, cos, sin, Hq + Hkv, D, QKV)                   # the query heads and the key heads lie side by side: one launch
             if n_dev is None:
                 caches[i][:, n - 1].copy_(qkv[:, Hq * D:])
                 ns = ops.decode_splits(n, qkv.shape[0], Hq)
@@ -810,8 +807,7 @@ class HipCausalLM(nn.Module):
                 d_qkv[:, Hq * D + Hkv * D:] = dkv32[1].view(T, Hkv * D).to(torch.bfloat16)
                 del dP, tmpT
             del P
-            ops.rope_(d_qkv, cos, sin, Hq, D, QKV, inverse=True)
-            _rope_offset(d_qkv, Hq * D, cos, sin, Hkv, D, QKV, inverse=True)
+            ops.rope_(d_qkv, cos, sin, Hq + Hkv, D, QKV, inverse=True)
             wgrad(d_qkv, h1, self.wqkv[i])
             d_h1 = ops.gemm_nt(d_qkv, self._shadow(("wqkv", i), self.wqkv[i]))      # [T, H]
             if frozen:
@@ -835,15 +831,6 @@ class HipCausalLM(nn.Module):
     # ---- fused optimizer (clip_grad_norm_(1.0) + Adam with L2, Noam schedule) -------------------------
     def make_optimizer(self, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2, warmup=500, max_norm=1.0):
         return HipAdam(self, lr, betas, eps, weight_decay, warmup, max_norm)
-
-
-def _rope_offset(buf, col_off, cos, sin, n_heads, D, row_stride, inverse=False):
-    """RoPE on the heads that start `col_off` elements into each row of a fused buffer."""
-    import ctypes as C
-    from . import _lib
-    _lib.check(_lib.lib().ecgb_rope(C.c_void_p(buf.data_ptr() + 2 * col_off), C.c_void_p(cos.data_ptr()),
-                                    C.c_void_p(sin.data_ptr()), cos.shape[0], n_heads, D, row_stride, int(inverse),
-                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
 
 class HipAdam:
