@@ -412,3 +412,32 @@ def test_data_parallel_gradients_two_ranks(tmp_path):
             a, b = torch.from_numpy(got[n]).cuda(), want[n]
             rel = (a - b).norm() / b.norm().clamp_min(1e-12)
             assert rel.item() < 2e-2, (rank, n, rel.item())
+
+
+def test_generate_long_prompt_takes_the_split_decode_attention(monkeypatch):
+    """Past 512 cached keys the decode step splits a head's keys over workgroups (ecgb_attn_decode_split): the KV-cache
+    path must still give the logits of the recompute-everything path (training kernels, no decode attention at all)."""
+    from ecg_byte_amd import decoder_ops as ops
+    zg, m = _load_generate()
+    g = torch.Generator().manual_seed(3)
+    B, S0, new = 2, 531, 6
+    ids = torch.randint(3, 290, (B, S0), generator=g).cuda()
+    mask = torch.ones(B, S0)
+    mask[1, :9] = 0                                              # left padding on one row
+    ids[1, :9] = 299
+    mask = mask.cuda()
+    calls = {"split": 0, "one": 0}
+    real_split, real_one = ops.attn_decode_split, ops.attn_decode
+    monkeypatch.setattr(ops, "attn_decode_split", lambda *a, **k: (calls.__setitem__("split", calls["split"] + 1), real_split(*a, **k))[1])
+    monkeypatch.setattr(ops, "attn_decode", lambda *a, **k: (calls.__setitem__("one", calls["one"] + 1), real_one(*a, **k))[1])
+    seq_c, lg_c = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=new, pad_token_id=299, use_cache=True, return_logits=True)
+    assert calls["split"] == (new - 1) * m.cfg.num_hidden_layers and calls["one"] == 0
+    seq_n, lg_n = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=new, pad_token_id=299, use_cache=False, return_logits=True)
+    lg_c, lg_n = lg_c.float(), lg_n.float()
+    tol = 1.5 * float(zg["ref_bf16_deviation"].max())
+    for t in range(new):                                        # compare while the two greedy paths agree
+        assert (lg_c[:, t] - lg_n[:, t]).abs().max().item() < tol, t
+        if not torch.equal(seq_c[:, S0 + t], seq_n[:, S0 + t]):
+            top2 = lg_n[:, t].topk(2, dim=-1).values
+            assert (top2[:, 0] - top2[:, 1]).min().item() < tol  # a tie at bf16 resolution
+            break
