@@ -181,8 +181,8 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
     model.full_logits = bool(args.full_logits)
     if args.lora:
         model.enable_lora(r=16, alpha=32, dropout=0.05)      # ecg_byte/main.py:131-138
-    if world > 1:
-        model.grad_sync = GradAllReduce()
+    if dist.is_initialized():
+        model.grad_sync = GradAllReduce(single_rank_collectives=True)
     opt = model.make_optimizer()                          # Adam(0.9, 0.99, 1e-8, wd 1e-2) + Noam(500) + clip 1.0
     asm = BatchAssembler(tk, lut, pad, bos, eos, sig_start, sig_end, S - 4, device=dev)
     rng = np.random.default_rng(2 + rank)
@@ -235,7 +235,7 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
                                   f"batch {B}/GPU, {'LoRA r16 on q,k,v,o,gate,up,down (frozen base)' if args.lora else 'full fine-tune'}, "
                                   f"random init; batches built by quantise+encode+assemble on device",
                       "loss_head_rows": "all" if model.full_logits else "labelled only (identical loss/gradients)",
-                      "parallelism": f"dp{world}" + (" (per-layer async all-reduce over RCCL)" if world > 1 else "")},
+                      "parallelism": f"dp{world}" + (f" (bucketed async all-reduce of the flat gradient buffer, backend {dist.get_backend()})" if dist.is_initialized() else "")},
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_nt_kernel_m16p<256,256> + gemm_tn_kernel_tr<256,256> (bf16 MFMA 16x16x32)",
                         "algorithmic_flops_per_step": flops, "step_ms_hip_events": ev0.elapsed_time(ev1) / args.train_steps}}
@@ -283,7 +283,10 @@ def main():
     backend = os.environ.get("ECGB_BENCH_BACKEND", "nccl")
     if os.environ.get("ECGB_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
-    if world > 1:
+    # started by torch.distributed.run (RANK in the environment): the process group is initialised even for ONE rank, and the
+    # train legs then send their gradient buckets through RCCL all the same -- the one-GPU check of the N > 1 code path
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if world > 1 or launched:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
@@ -380,7 +383,7 @@ def main():
         if train is not None:
             out["train"] = train
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

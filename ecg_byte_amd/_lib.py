@@ -25,7 +25,7 @@ class EcgbError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC]
+    cmd = ["make", "-j", str(min(8, os.cpu_count() or 1)), "-C", CSRC]
     if force:
         cmd.append("-B")
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
@@ -42,7 +42,7 @@ def lib():
     if not os.path.exists(SO_PATH):
         raise ImportError(
             f"{SO_PATH} not found: the HIP extension is not built. Run "
-            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C ecg-byte_amd/csrc`). "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C ecg_byte_amd/csrc`). "
             "There is no CPU fallback for the encode path.")
     L = C.CDLL(SO_PATH)
     vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
@@ -120,6 +120,17 @@ def lib():
     L.ecgb_attn_decode_split_scratch_bytes.restype = sz
     _lib = L
     return L
+
+
+def require_current(device) -> None:
+    """The C ABI takes raw pointers and launches on torch's current stream of the CURRENT device, so tensors on another
+    device would be touched by kernels running on the wrong GPU.  Fail loudly instead (ecg_byte/main.py's `--device cuda:N`
+    works because main() makes N current)."""
+    import torch
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if device.type != "cuda" or idx != torch.cuda.current_device():
+        raise RuntimeError(f"tensor on {device} but the current device is cuda:{torch.cuda.current_device()}: call "
+                           f"torch.cuda.set_device({device!s}) first (kernels launch on the current device's stream)")
 
 
 def check(rc: int) -> None:

@@ -866,6 +866,9 @@ extern "C" int ecgb_attn_decode(const void *q_dev, const void *k_cache_dev, cons
 extern "C" size_t ecgb_attn_decode_split_scratch_bytes(long long capacity, int batch, int n_q_heads, int head_dim, int n_splits)
 {
     if (capacity <= 0 || batch <= 0 || n_q_heads <= 0 || n_splits <= 0) return 0;
+    // a split never holds more than kSplitMaxChunk keys: size for the splits the longest cache (capacity keys) can need
+    const long long need_splits = (capacity + kSplitMaxChunk - 1) / kSplitMaxChunk;
+    if (need_splits > n_splits) n_splits = (int)need_splits;
     return (size_t)batch * n_q_heads * ((size_t)capacity + (size_t)n_splits * (2 + (size_t)head_dim)) * sizeof(float);
 }
 
@@ -884,14 +887,11 @@ extern "C" int ecgb_attn_decode_split(const void *q_dev, const void *k_cache_dev
         ecgb::set_error("ecgb_attn_decode_split: scratch too small (ecgb_attn_decode_split_scratch_bytes)");
         return ECGB_ERR_INVALID;
     }
+    // the split count is final BEFORE the scratch is laid out: stats and partial are indexed by gridDim.x
+    if ((kv_len + n_splits - 1) / n_splits > kSplitMaxChunk) n_splits = (kv_len + kSplitMaxChunk - 1) / kSplitMaxChunk;
     float *scores = (float *)scratch_dev;
     float *stats = scores + (size_t)batch * n_q_heads * (size_t)capacity;
     float *partial = stats + (size_t)batch * n_q_heads * (size_t)n_splits * 2;
-    if ((kv_len + n_splits - 1) / n_splits > kSplitMaxChunk) n_splits = (kv_len + kSplitMaxChunk - 1) / kSplitMaxChunk;
-    if (scratch_bytes < ecgb_attn_decode_split_scratch_bytes(capacity, batch, n_q_heads, head_dim, n_splits)) {
-        ecgb::set_error("ecgb_attn_decode_split: scratch too small for the splits a cache this long needs");
-        return ECGB_ERR_INVALID;
-    }
     const int chunk = (kv_len + n_splits - 1) / n_splits;
     const dim3 grid((unsigned)n_splits, (unsigned)n_q_heads, (unsigned)batch), gc((unsigned)n_q_heads, (unsigned)batch);
 #define ECGB_SPLIT(D_) do { \

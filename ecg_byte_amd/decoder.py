@@ -123,17 +123,15 @@ class LoraSite(nn.Module):
             ops.gemm_nt(t[:, 64 * b: 64 * b + 64], self.B[b].data, out=y[:, off: off + w], alpha=self.scale, accumulate=True)
         return xd, t, seed
 
-    def backward(self, dy, saved):
-        """Sets A.grad / B[b].grad and returns the adapters' contribution to d(input)."""
+    def backward(self, dy, saved, model):
+        """Sets A.grad / B[b].grad (slices of the model's flat gradient buffer) and returns the adapters' contribution to d(input)."""
         xd, t, seed = saved
         dt = torch.empty_like(t)
         for b, (off, w) in enumerate(self.blocks):
             dyb = dy[:, off: off + w]
-            gB = ops.gemm_tn(dyb, t[:, 64 * b: 64 * b + 64], alpha=self.scale)
-            self.B[b].grad = gB if self.B[b].grad is None else ops.add(self.B[b].grad, gB)
+            model._wgrad(self.B[b], dyb, t[:, 64 * b: 64 * b + 64], alpha=self.scale)
             ops.gemm_nt(dyb, ops.transpose(self.B[b].data), out=dt[:, 64 * b: 64 * b + 64], alpha=self.scale)
-        gA = ops.gemm_tn(dt, xd)
-        self.A.grad = gA if self.A.grad is None else ops.add(self.A.grad, gA)
+        model._wgrad(self.A, dt, xd)
         dx = ops.gemm_nt(dt, ops.transpose(self.A.data))
         if seed is not None:
             ops.dropout(dx, self.p, seed, out=dx)
@@ -198,6 +196,8 @@ class HipCausalLM(nn.Module):
         self.full_logits = False   # True: run the loss head over every row, as the reference materialises it
         self._saved = None
         self.grad_sync = None      # parallel.GradAllReduce: told as soon as a layer's gradients are final
+        self._gflat = None         # flat bf16 buffer holding every trainable gradient (see _grad_layout)
+        self._gflat_key = None
         self.fused_attention = cfg.head_dim == 64   # False: materialised scores (batched GEMM + softmax kernels)
 
     # ---- HF-style surface -------------------------------------------------------------------
@@ -257,7 +257,7 @@ class HipCausalLM(nn.Module):
                                              "tie_word_embeddings", "pad_token_id", "initializer_range")}}
         with open(os.path.join(path, "config.json"), "w") as f:
             json.dump(cfg, f, indent=1)
-        save_file({n: t.contiguous().cpu() for n, t in self.state_dict().items() if n != "lm_head.weight"},
+        save_file({n: t.contiguous().cpu() for n, t in self._hf_named() if n != "lm_head.weight"},
                   os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
 
     def forward(self, input_ids=None, attention_mask=None, labels=None, position_ids=None, output_attentions=False, **_):
@@ -348,9 +348,16 @@ class HipCausalLM(nn.Module):
 
     def state_dict(self, *a, **k):
         """HF parameter names; with LoRA enabled also the adapters under peft's names (`lora_named`)."""
-        sd = {n: t.clone() for n, t in self._hf_named()}
-        if self.lora is not None:
-            sd.update({n: t.clone() for n, t in self.lora_named()})
+        if self.lora is None:
+            return {n: t.clone() for n, t in self._hf_named()}
+        # peft's PeftModel.state_dict(): everything under `base_model.model.`, the wrapped projections' own weights under
+        # `.base_layer.` -- the names a reference run with --peft writes and reads back (ecg_byte/main.py:153-155,193-195)
+        def peft_name(n):
+            if n.endswith("_proj.weight"):
+                n = n[: -len("weight")] + "base_layer.weight"
+            return "base_model.model." + n
+        sd = {peft_name(n): t.clone() for n, t in self._hf_named()}
+        sd.update({n: t.clone() for n, t in self.lora_named()})
         return sd
 
     def load_state_dict(self, sd, strict=True):
@@ -406,20 +413,87 @@ class HipCausalLM(nn.Module):
                           Hkv * D * S, D * S, G, S * Hq * D, D)
         return ao, P
 
+    # ---- gradient storage ---------------------------------------------------------------------
+    def _grad_layout(self):
+        """Every trainable gradient lives in ONE flat bf16 buffer, laid out in the order backward finishes them: layer L-1's
+        tensors first, layer 0's last, then the embedding table and the final norm (full fine-tune) -- so "the gradients of
+        layers i..j are final" is one contiguous range, which parallel.GradAllReduce sends as one all-reduce per >= 25 MB
+        (the reference's DDP buckets, ecg_byte/main.py:165) instead of one per tensor, and the weight-gradient GEMMs write
+        straight into it.  `param.grad` is a view of its slice.  Slices start on 256-byte boundaries; the gaps stay zero."""
+        frozen = self.lora is not None
+        key = (frozen, self.v_pad, id(self.lora))
+        if self._gflat is not None and self._gflat_key == key:
+            return
+        L = self.cfg.num_hidden_layers
+        groups = []
+        for i in reversed(range(L)):
+            groups.append(list(self.lora[i].parameters()) if frozen else
+                          [self.wqkv[i], self.wo[i], self.wgu[i], self.wdown[i], self.ln1[i], self.ln2[i]])
+        if not frozen:
+            groups.append([self.embed, self.norm])
+        off, plan, ranges = 0, [], []
+        for ps in groups:
+            lo = off
+            for p in ps:
+                plan.append((p, off))
+                off += (p.numel() + 127) // 128 * 128
+            ranges.append((lo, off))
+        self._gflat = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
+        self._gview = {id(p): self._gflat[o: o + p.numel()].view(p.shape) for p, o in plan}
+        self._granges = ranges          # [L - 1 - i] = layer i's range; [L] = embed + final norm
+        self._gflat_key = key
+
+    def _grad_slot(self, param):
+        """(view, accumulate): the parameter's slice of the flat buffer, and whether it already holds a gradient this
+        backward must add to (gradient accumulation: `param.grad` survived since the last zero_grad)."""
+        view = self._gview[id(param)]
+        if param.grad is None:
+            return view, False
+        if param.grad.data_ptr() != view.data_ptr():
+            view.copy_(param.grad)
+        return view, True
+
+    def _wgrad(self, param, dy, xin, alpha=1.0):
+        """param.grad (+)= alpha * dy^T . xin, written by the TN GEMM into the flat buffer."""
+        view, acc = self._grad_slot(param)
+        if acc:
+            ops.add(view, ops.gemm_tn(dy, xin, alpha=alpha), out=view)
+        else:
+            ops.gemm_tn(dy, xin, alpha=alpha, out=view)
+        param.grad = view
+
+    def _vgrad(self, param, g):
+        """param.grad (+)= g (any float dtype, converted to bf16)."""
+        view, acc = self._grad_slot(param)
+        if acc:
+            ops.add(view, g.to(torch.bfloat16), out=view)
+        else:
+            view.copy_(g)
+        param.grad = view
+
     # ---- forward ------------------------------------------------------------------------------
     def _forward_loss(self, input_ids, attention_mask, labels, position_ids):
         c = self.cfg
         H, I, D, Hq, Hkv = c.hidden_size, c.intermediate_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
         G = Hq // Hkv
         dev = self.device
+        ops.require_current(dev)
         input_ids = input_ids.to(dev).contiguous()
         B, S = input_ids.shape
-        assert S % 64 == 0, "sequence length must be a multiple of 64 (GEMM K-step); the reference uses pad_to_max+4 = 1024"
-        T = B * S
         mask = (attention_mask.to(dev).float() if attention_mask is not None else torch.ones(B, S, device=dev)).contiguous()
         if position_ids is None:
             position_ids = torch.arange(S, device=dev)[None].expand(B, S)
-        cos, sin = self._rope_tables(position_ids.to(dev))
+        position_ids = position_ids.to(dev)
+        labels = labels.to(dev)
+        if S % 64:   # the GEMM K-step is 64 rows/columns: masked, unlabelled positions on the LEFT change neither the loss nor any
+            lpad = 64 - S % 64   # gradient (the reference's default --pad_to_max 1000 gives rows of 1004, data_loader.py:123)
+            input_ids = torch.cat([torch.zeros((B, lpad), dtype=input_ids.dtype, device=dev), input_ids], 1).contiguous()
+            mask = torch.cat([torch.zeros((B, lpad), device=dev), mask], 1).contiguous()
+            position_ids = torch.cat([torch.zeros((B, lpad), dtype=position_ids.dtype, device=dev), position_ids], 1)
+            labels = torch.cat([torch.full((B, lpad), -100, dtype=labels.dtype, device=dev), labels], 1)
+            S += lpad
+        T = B * S
+        cos, sin = self._rope_tables(position_ids)
         QKV = self.qkv
         scale = 1.0 / math.sqrt(D)
         saved = []
@@ -452,7 +526,6 @@ class HipCausalLM(nn.Module):
         hf, rstdf, xf = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
 
         # ---- loss head: ForCausalLMLoss shifts (loss_utils.py:39-41): row t predicts labels[t+1]
-        labels = labels.to(dev)
         shifted = torch.full((B, S), -100, dtype=torch.int64, device=dev)
         shifted[:, :-1] = labels[:, 1:]
         shifted = shifted.view(-1)
@@ -494,6 +567,7 @@ class HipCausalLM(nn.Module):
         c = self.cfg
         D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
         dev = self.device
+        ops.require_current(dev)
         input_ids = input_ids.to(dev).contiguous()
         B, S = input_ids.shape
         mask = (attention_mask.to(dev).float() if attention_mask is not None else torch.ones(B, S, device=dev)).contiguous()
@@ -739,19 +813,17 @@ class HipCausalLM(nn.Module):
             self.embed_grad32.mul_(go)
 
         frozen = self.lora is not None
+        self._grad_layout()
+        L = c.num_hidden_layers
 
         def wgrad(dy, xin, param):
-            """param.grad = dy^T . xin (bf16)"""
-            if frozen:
-                return
-            g = ops.gemm_tn(dy, xin)          # contraction over the token rows of both operands: no transposed copies
-            param.grad = g if param.grad is None else ops.add(param.grad, g)
+            """param.grad = dy^T . xin (bf16): contraction over the token rows of both operands, no transposed copies"""
+            if not frozen:
+                self._wgrad(param, dy, xin)
 
         def lngrad(param, dw32):
-            if frozen:
-                return
-            g = dw32.to(torch.bfloat16)
-            param.grad = g if param.grad is None else ops.add(param.grad, g)
+            if not frozen:
+                self._vgrad(param, dw32)
 
         dw = torch.zeros(H, dtype=torch.float32, device=dev)
         g = ops.rmsnorm_bwd(xf, self.norm.data, rstdf, dhf, dw, gemma=self.gemma)          # grad of the residual stream
@@ -762,13 +834,13 @@ class HipCausalLM(nn.Module):
             wgrad(g, hm, self.wdown[i])
             d_hm = ops.gemm_nt(g, self._shadow(("wdown", i), self.wdown[i]))        # [T, I]
             if frozen:
-                d_hm = ops.add(d_hm, self.lora[i]["down"].backward(g, ls[3]))
+                d_hm = ops.add(d_hm, self.lora[i]["down"].backward(g, ls[3], self))
             d_gu = ops.glu_bwd(gu, d_hm, gelu_tanh=self.gemma)
             del d_hm, hm
             wgrad(d_gu, h2, self.wgu[i])
             d_h2 = ops.gemm_nt(d_gu, self._shadow(("wgu", i), self.wgu[i]))         # [T, H]
             if frozen:
-                d_h2 = ops.add(d_h2, self.lora[i]["gu"].backward(d_gu, ls[2]))
+                d_h2 = ops.add(d_h2, self.lora[i]["gu"].backward(d_gu, ls[2], self))
             del d_gu, gu
             dw = torch.zeros(H, dtype=torch.float32, device=dev)
             g2 = ops.rmsnorm_bwd(x2, self.ln2[i].data, rstd2, d_h2, dw, dres=g, gemma=self.gemma)
@@ -777,7 +849,7 @@ class HipCausalLM(nn.Module):
             wgrad(g2, ao, self.wo[i])
             d_ao = ops.gemm_nt(g2, self._shadow(("wo", i), self.wo[i]))             # [T, Hq*D]
             if frozen:
-                d_ao = ops.add(d_ao, self.lora[i]["o"].backward(g2, ls[1]))
+                d_ao = ops.add(d_ao, self.lora[i]["o"].backward(g2, ls[1], self))
             # attention core
             if self.fused_attention:
                 d_qkv = ops.attn_bwd(qkv, mask, ao, d_ao, P, B, S, Hq, Hkv, D, scale)
@@ -811,21 +883,19 @@ class HipCausalLM(nn.Module):
             wgrad(d_qkv, h1, self.wqkv[i])
             d_h1 = ops.gemm_nt(d_qkv, self._shadow(("wqkv", i), self.wqkv[i]))      # [T, H]
             if frozen:
-                d_h1 = ops.add(d_h1, self.lora[i]["qkv"].backward(d_qkv, ls[0]))
+                d_h1 = ops.add(d_h1, self.lora[i]["qkv"].backward(d_qkv, ls[0], self))
             dw = torch.zeros(H, dtype=torch.float32, device=dev)
             g = ops.rmsnorm_bwd(x1, self.ln1[i].data, rstd1, d_h1, dw, dres=g2, gemma=self.gemma)
             lngrad(self.ln1[i], dw)
-            if self.grad_sync is not None:   # this layer's gradients are final: start their all-reduce now
-                ready = list(self.lora[i].parameters()) if frozen else [self.wqkv[i], self.wo[i], self.wgu[i], self.wdown[i], self.ln1[i], self.ln2[i]]
-                self.grad_sync.on_grads_ready(ready)
+            if self.grad_sync is not None:   # this layer's gradients are final: its range of the flat buffer may leave
+                self.grad_sync.on_flat_ready(self._gflat, *self._granges[L - 1 - i])
         if not frozen:
             ops.embed_bwd(input_ids.view(-1), g, self.embed_grad32, self.embed_scale)
-            eg = self.embed_grad32.to(torch.bfloat16)
-            self.embed.grad = eg if self.embed.grad is None else ops.add(self.embed.grad, eg)
+            self._vgrad(self.embed, self.embed_grad32)
             self.embed_grad32.zero_()
         if self.grad_sync is not None:
             if not frozen:
-                self.grad_sync.on_grads_ready([self.embed, self.norm])
+                self.grad_sync.on_flat_ready(self._gflat, *self._granges[L])
             self.grad_sync.finish()
 
     # ---- fused optimizer (clip_grad_norm_(1.0) + Adam with L2, Noam schedule) -------------------------

@@ -21,6 +21,9 @@ def _L():
     return _lib.lib()
 
 
+require_current = _lib.require_current
+
+
 def _bf(t):
     assert t.dtype == torch.bfloat16 and t.is_cuda and t.is_contiguous(), "expects contiguous CUDA bf16"
     return t
@@ -75,8 +78,9 @@ def glu_bwd(gate_up, dh, gelu_tanh=False):
     return d
 
 
-def add(a, b):
-    o = torch.empty_like(a)
+def add(a, b, out=None):
+    """out = a + b (out may be a or b: elementwise)."""
+    o = torch.empty_like(a) if out is None else out
     _lib.check(_L().ecgb_add_bf16(_p(_bf(a)), _p(_bf(b)), _p(o), a.numel(), _st()))
     return o
 
@@ -115,22 +119,24 @@ def dropout(x, p, seed, out=None):
     return out
 
 
-def gemm_tn(a, b, alpha=1.0, splits=None):
+def gemm_tn(a, b, alpha=1.0, splits=None, out=None):
     """C[N,K] = alpha * A[M,N]^T @ B[M,K]  (weight gradient dW = dY^T X) without transposed copies.
-    splits: workgroups sharing one output tile's contraction (None: enough to fill the chip)."""
+    splits: workgroups sharing one output tile's contraction (None: enough to fill the chip).
+    out: contiguous bf16 [N, K] destination (e.g. a parameter's slice of the flat gradient buffer)."""
     M, N = a.shape
     K = b.shape[1]
     assert b.shape[0] == M and a.stride(1) == 1 and b.stride(1) == 1
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
     if splits is None:
         splits = 1 if tiles >= 192 else max(1, min(8, 256 // tiles, M // 64))
-    if splits == 1:
+    if out is None:
         out = torch.empty((N, K), dtype=torch.bfloat16, device=a.device)
+    assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.shape == (N, K)
+    if splits == 1:
         _lib.check(_L().ecgb_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), K, M, N, K, float(alpha), 1, _st()))
         return out
     acc = torch.zeros((N, K), dtype=torch.float32, device=a.device)
     _lib.check(_L().ecgb_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(acc), K, M, N, K, float(alpha), splits, _st()))
-    out = torch.empty((N, K), dtype=torch.bfloat16, device=a.device)
     _lib.check(_L().ecgb_f32_to_bf16(_p(acc), _p(out), acc.numel(), _st()))
     return out
 

@@ -87,6 +87,37 @@ def build_model_and_tokenizer(args, vocab, device):
     return LLM(llm, args), tokenizer
 
 
+def _inference(args, model, tokenizer, vocab, merges, data, device):
+    """main.py:168-218: five seeded passes over the test split, per-seed result files, statistics over the seeds."""
+    from .data_loader import DeviceBatchLoader, ECGTokenDataset
+    from .file_utils import align_signal_text_files, sample_N_percent_from_lists
+    from .model_utils import run_statistical_analysis
+    from .runners import tester
+    test_signals, test_texts = align_signal_text_files(f"{data}/ecg/test", f"{data}/text/test")
+    if args.toy:
+        test_signals, test_texts = sample_N_percent_from_lists(test_signals, test_texts, 0.25)
+    test_data = ECGTokenDataset(test_signals, test_texts, vocab, merges, args=args, tokenizer=tokenizer)
+    ckpt_dir = f"{args.runs_root}/{args.seed}/{args.checkpoint}"
+    all_seed_results = []
+    for seed in [0, 42, 123, 456, 789]:                                 # main.py:185-205
+        random.seed(seed)
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        checkpoint = torch.load(f"{ckpt_dir}/best_model.pth", map_location=device)
+        model.load_state_dict(checkpoint["model"])
+        seed_results = tester(model, DeviceBatchLoader(test_data, batch_size=1, workers=args.workers), tokenizer, args)
+        all_seed_results.append(seed_results)
+        with open(f"{ckpt_dir}/seed_{seed}_results_{args.dataset}.json", "w") as f:
+            json.dump({"averages": seed_results["metrics"], "qa_results": seed_results["qa_results"]}, f)
+    stats_results = run_statistical_analysis(all_seed_results)
+    with open(f"{ckpt_dir}/statistical_analysis_{args.dataset}.json", "w") as f:
+        json.dump(stats_results, f)
+    for metric, st in stats_results.items():
+        print(f"\n{metric}:\nMean: {st['mean']:.2f}\nStd Dev: {st['std']:.2f}\n95% CI: [{st['conf_interval'][0]:.2f}, {st['conf_interval'][1]:.2f}]")
+    print("Inference Complete")
+    return stats_results
+
+
 def main(argv=None):
     from .data_loader import DeviceBatchLoader, ECGTokenDataset
     from .file_utils import align_signal_text_files, ensure_directory_exists, load_vocab_and_merges, sample_N_percent_from_lists
@@ -102,6 +133,10 @@ def main(argv=None):
         args.device = torch.device(f"cuda:{local_rank}")
         dist.init_process_group("nccl", rank=rank, world_size=world)      # RCCL
     device = torch.device(args.device or "cuda:0")
+    if device.type == "cuda":
+        # every ctypes-launched kernel goes to torch's CURRENT stream of the CURRENT device: `--device cuda:N` must make N current
+        # (the reference's .to(device) calls carry the device with the tensors, main.py:158; raw pointers do not)
+        torch.cuda.set_device(device)
     if args.dev:
         args.epochs = 2
     gc.collect()
@@ -115,29 +150,11 @@ def main(argv=None):
     data = f"{args.data_root}/{args.dataset}"
 
     if args.inference:
-        test_signals, test_texts = align_signal_text_files(f"{data}/ecg/test", f"{data}/text/test")
-        if args.toy:
-            test_signals, test_texts = sample_N_percent_from_lists(test_signals, test_texts, 0.25)
-        test_data = ECGTokenDataset(test_signals, test_texts, vocab, merges, args=args, tokenizer=tokenizer)
-        ckpt_dir = f"{args.runs_root}/{args.seed}/{args.checkpoint}"
-        all_seed_results = []
-        for seed in [0, 42, 123, 456, 789]:                                 # main.py:185-205
-            random.seed(seed)
-            torch.manual_seed(seed)
-            np.random.seed(seed)
-            checkpoint = torch.load(f"{ckpt_dir}/best_model.pth", map_location=device)
-            model.load_state_dict(checkpoint["model"])
-            seed_results = tester(model, DeviceBatchLoader(test_data, batch_size=1, workers=args.workers), tokenizer, args)
-            all_seed_results.append(seed_results)
-            with open(f"{ckpt_dir}/seed_{seed}_results_{args.dataset}.json", "w") as f:
-                json.dump({"averages": seed_results["metrics"], "qa_results": seed_results["qa_results"]}, f)
-        stats_results = run_statistical_analysis(all_seed_results)
-        with open(f"{ckpt_dir}/statistical_analysis_{args.dataset}.json", "w") as f:
-            json.dump(stats_results, f)
-        for metric, st in stats_results.items():
-            print(f"\n{metric}:\nMean: {st['mean']:.2f}\nStd Dev: {st['std']:.2f}\n95% CI: [{st['conf_interval'][0]:.2f}, {st['conf_interval'][1]:.2f}]")
-        print("Inference Complete")
-        return stats_results
+        try:
+            return _inference(args, model, tokenizer, vocab, merges, data, device)
+        finally:
+            if args.dis:
+                dist.destroy_process_group()
 
     train_signals, train_texts = align_signal_text_files(f"{data}/ecg/train", f"{data}/text/train")
     val_signals, val_texts = align_signal_text_files(f"{data}/ecg/val", f"{data}/text/val")
@@ -193,12 +210,17 @@ def main(argv=None):
             print("-----------------------------------------------------------")
     except Exception as e:                                                   # main.py:321-333
         print(f"An error occurred: {e}")
-        if checkpoint is not None and rank == 0:
-            torch.save(checkpoint, f"{directory_path}/crash_model.pth")
         raise
     finally:
-        if args.dis:
-            dist.destroy_process_group()
+        # main.py:336-346: the latest-epoch checkpoint is ALWAYS written at exit (normal end, early stop or exception), so the
+        # last epoch's weights survive when it was not the best one
+        try:
+            if checkpoint is not None and rank == 0:
+                torch.save(checkpoint, f"{directory_path}/crash_model.pth")
+                print("Final checkpoint saved as crash_model.pth")
+        finally:
+            if args.dis:
+                dist.destroy_process_group()
     return {"train_loss": train_loss, "val_loss": val_loss, "directory": directory_path}
 
 

@@ -47,6 +47,10 @@ def trainer(model, dataloader, optimizer, args, epoch, directory_path, checkpoin
                     break
         except Exception as e:
             print(f"Error during training at step {step}: {e}")
+            if getattr(args, "dis", False):
+                # train.py:59-61 swallows the error on every rank alike; with a collective inside backward a rank that skips a
+                # step leaves the others waiting in all-reduce forever, so a multi-rank run stops instead
+                raise
             continue
     if len_of_batch == 0:
         print("No valid batches for training.")
@@ -101,7 +105,12 @@ def tester(model, dataloader, tokenizer, args, extra_metrics=None):
             except Exception as e:
                 print("could not evaluate for some reason:", str(e))
                 print(f"Error type: {type(e).__name__}")
-                all_results.append({"BLEU": 0})
+                # inference.py:34-36: a failed sample scores zero in EVERY metric, so it pulls all the averages down alike
+                zero = {"BLEU": 0}
+                if extra_metrics is not None:
+                    zero.update({"METEOR": 0, "ROUGE": {"rouge-1": 0, "rouge-2": 0, "rouge-l": 0},
+                                 "BERTSCORE": {"hf-prec": [0], "hf-rec": [0], "hf-f1": [0]}})
+                all_results.append(zero)
             if getattr(args, "dev", False):
                 dev_count += 1
                 if dev_count == 10:

@@ -99,6 +99,7 @@ class HipTokenizer:
             raise TypeError("quantize_encode needs a CUDA tensor (no CPU fallback)")
         if signal.dtype != torch.float64:
             raise TypeError("signal must be float64 (the reference quantises in float64)")
+        _lib.require_current(signal.device)
         if not signal.is_contiguous():
             signal = signal.contiguous()
         B = signal.shape[0]
@@ -122,6 +123,7 @@ class HipTokenizer:
         """Encode a batch of raw byte streams: CUDA uint8 `(B, n)` -> `(ids, counts)`."""
         if not (isinstance(text, torch.Tensor) and text.is_cuda and text.dtype == torch.uint8):
             raise TypeError("encode_bytes needs a CUDA uint8 tensor (no CPU fallback)")
+        _lib.require_current(text.device)
         if text.dim() == 1:
             text = text[None]
         text = text.contiguous()
@@ -142,6 +144,7 @@ def quantize(signal: torch.Tensor, percentiles, want_clipped: bool = False):
     [and the clipped float64 tensor, the reference's first return value]."""
     if not (isinstance(signal, torch.Tensor) and signal.is_cuda and signal.dtype == torch.float64):
         raise TypeError("quantize needs a CUDA float64 tensor (no CPU fallback)")
+    _lib.require_current(signal.device)
     x = signal.contiguous()
     sym = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     clipped = torch.empty_like(x) if want_clipped else None

@@ -8,7 +8,11 @@ Follows the vendored transformers 4.46.0.dev0 under /root/reference/transformers
   LlamaMLP                models/llama/modeling_llama.py:238-258
   LlamaDecoderLayer       models/llama/modeling_llama.py:635-701
   ForCausalLMLoss         loss/loss_utils.py:24-47 (float upcast, shift, ignore_index -100, mean)
-Pinned against outputs of the reference itself: tests/golden/decoder_llama_tiny.npz
+Gemma (cfg["model_type"] == "gemma", config C5's family), models/gemma/modeling_gemma.py:
+  GemmaRMSNorm            51-68   (x_hat * (1 + w) in fp32, THEN cast)
+  GemmaMLP                131-152 (gelu-tanh gate)
+  embeddings * sqrt(hidden) held in the activation dtype, 800-801; attention as Llama's with head_dim from the config
+Pinned against outputs of the reference itself: tests/golden/decoder_llama_tiny.npz and decoder_gemma_tiny.npz
 (tests/test_oracle_decoder.py, fp32, 1e-5).
 """
 import math
@@ -17,10 +21,12 @@ import torch
 import torch.nn.functional as F
 
 
-def rms_norm(x, w, eps):
+def rms_norm(x, w, eps, gemma=False):
     dt = x.dtype
     xf = x.float()
     xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    if gemma:
+        return (xf * (1.0 + w.float())).to(dt)
     return w * xf.to(dt)
 
 
@@ -50,7 +56,10 @@ def llama_logits(params, cfg, input_ids, attention_mask, position_ids, inv_freq,
     B, S = input_ids.shape
     emb = params["model.embed_tokens.weight"]
     dt = emb.dtype
+    gemma = cfg.get("model_type", "llama") == "gemma"
     x = emb[input_ids]
+    if gemma:
+        x = x * torch.tensor(H ** 0.5, dtype=dt)
     freqs = position_ids[:, :, None].float() * inv_freq[None, None, :].float()
     e = torch.cat((freqs, freqs), -1)
     cos, sin = e.cos().to(dt)[:, None], e.sin().to(dt)[:, None]
@@ -59,7 +68,7 @@ def llama_logits(params, cfg, input_ids, attention_mask, position_ids, inv_freq,
     bias = torch.zeros(B, 1, S, S, dtype=dt, device=x.device).masked_fill(~visible, torch.finfo(dt).min)
     for i in range(cfg["num_hidden_layers"]):
         p = f"model.layers.{i}."
-        h = rms_norm(x, params[p + "input_layernorm.weight"], cfg["rms_norm_eps"])
+        h = rms_norm(x, params[p + "input_layernorm.weight"], cfg["rms_norm_eps"], gemma)
         q = _lin(params, p + "self_attn.q_proj", h, lora_scale).view(B, S, Hq, D).transpose(1, 2)
         k = _lin(params, p + "self_attn.k_proj", h, lora_scale).view(B, S, Hkv, D).transpose(1, 2)
         v = _lin(params, p + "self_attn.v_proj", h, lora_scale).view(B, S, Hkv, D).transpose(1, 2)
@@ -70,10 +79,11 @@ def llama_logits(params, cfg, input_ids, attention_mask, position_ids, inv_freq,
         a = F.scaled_dot_product_attention(q, k, v, attn_mask=bias)
         a = a.transpose(1, 2).reshape(B, S, Hq * D)
         x = x + _lin(params, p + "self_attn.o_proj", a, lora_scale)
-        h = rms_norm(x, params[p + "post_attention_layernorm.weight"], cfg["rms_norm_eps"])
-        g = F.silu(_lin(params, p + "mlp.gate_proj", h, lora_scale)) * _lin(params, p + "mlp.up_proj", h, lora_scale)
+        h = rms_norm(x, params[p + "post_attention_layernorm.weight"], cfg["rms_norm_eps"], gemma)
+        gate = _lin(params, p + "mlp.gate_proj", h, lora_scale)
+        g = (F.gelu(gate, approximate="tanh") if gemma else F.silu(gate)) * _lin(params, p + "mlp.up_proj", h, lora_scale)
         x = x + _lin(params, p + "mlp.down_proj", g, lora_scale)
-    x = rms_norm(x, params["model.norm.weight"], cfg["rms_norm_eps"])
+    x = rms_norm(x, params["model.norm.weight"], cfg["rms_norm_eps"], gemma)
     return F.linear(x, emb).float()
 
 
@@ -100,7 +110,9 @@ def random_params(cfg, seed=0, dtype=torch.float32, device="cpu", std=0.02):
     H, I, D = cfg["hidden_size"], cfg["intermediate_size"], cfg["head_dim"]
     Hq, Hkv, V = cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["vocab_size"]
     r = lambda *s: (torch.randn(*s, generator=g) * std).to(torch.bfloat16).to(dtype).to(device)
-    p = {"model.embed_tokens.weight": r(V, H), "model.norm.weight": torch.ones(H, dtype=dtype, device=device)}
+    gemma = cfg.get("model_type", "llama") == "gemma"      # Gemma's norm weights are offsets from 1
+    one = 0.0 if gemma else 1.0
+    p = {"model.embed_tokens.weight": r(V, H), "model.norm.weight": torch.full((H,), one, dtype=dtype, device=device)}
     for i in range(cfg["num_hidden_layers"]):
         q = f"model.layers.{i}."
         p[q + "self_attn.q_proj.weight"] = r(Hq * D, H)
@@ -110,8 +122,8 @@ def random_params(cfg, seed=0, dtype=torch.float32, device="cpu", std=0.02):
         p[q + "mlp.gate_proj.weight"] = r(I, H)
         p[q + "mlp.up_proj.weight"] = r(I, H)
         p[q + "mlp.down_proj.weight"] = r(H, I)
-        p[q + "input_layernorm.weight"] = (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16).to(dtype).to(device)
-        p[q + "post_attention_layernorm.weight"] = (1 + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16).to(dtype).to(device)
+        p[q + "input_layernorm.weight"] = (one + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16).to(dtype).to(device)
+        p[q + "post_attention_layernorm.weight"] = (one + 0.1 * torch.randn(H, generator=g)).to(torch.bfloat16).to(dtype).to(device)
     return p
 
 

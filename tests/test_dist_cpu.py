@@ -108,3 +108,40 @@ def test_grad_all_reduce_world_size_2_gloo():
         want = sum(per_rank) / world
         for r in range(world):
             assert torch.allclose(ret[r][i], want, atol=1e-6)
+
+
+def _flat_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ecg_byte_amd import parallel
+        g = torch.Generator().manual_seed(100 + rank)
+        sizes = [1000, 300, 5000, 64, 2000]                      # "layers", in the order backward finishes them
+        flat = torch.randn(sum(sizes), generator=g)
+        mine = flat.clone()
+        sync = parallel.GradAllReduce(bucket_bytes=4 * 1200)     # fp32 here: a bucket closes at >= 1200 elements
+        lo = 0
+        for n in sizes:
+            sync.on_flat_ready(flat, lo, lo + n)
+            lo += n
+        sent_before_finish = sync.collectives
+        sync.finish()
+        ret[rank] = (mine, flat.clone(), sent_before_finish, sync.collectives)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_gradient_buckets_world_size_2_gloo():
+    """The bucketed exchange of HipCausalLM's flat gradient buffer: adjacent ready ranges merge until a bucket is full
+    (DDP's 25 MB rule, ecg_byte/main.py:165, scaled down here), every element ends as the mean over the ranks, and the number of
+    collectives is the number of buckets, not the number of tensors."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_flat_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    want = (ret[0][0] + ret[1][0]) / 2
+    for r in range(world):
+        assert torch.allclose(ret[r][1], want, atol=1e-6)
+        # 1000 + 300 >= 1200 -> bucket 1; 5000 -> bucket 2; 64 + 2000 -> bucket 3 (closed by finish... it reaches 1200 with 2000)
+        assert ret[r][2] == 3 and ret[r][3] == 3

@@ -1,0 +1,206 @@
+"""Full-shape parity gates: the kernels at the dimensions BASELINE.json's configs C3 and C5 run them at,
+not at toy sizes -- 256x256 GEMM tiles inside a model, the split TN weight-gradient GEMM on o_proj, the loss head at
+V = 132 515 in 4 096-row chunks, fused attention with 32 query / 8 KV heads at S = 1024 and 2048 with left padding.
+
+Reference = oracle/llama_ref.py (the PyTorch restatement of the vendored LlamaForCausalLM / GemmaForCausalLM, pinned to
+goldens of the vendored transformers at 1e-5 in tests/test_oracle_decoder.py) run in FP32 ON THE SAME GPU with the same
+bf16-representable weights.  Tolerances (bf16 compute vs fp32 reference, the ones tests/test_gpu_decoder_model.py uses at
+tiny shapes): loss within 1e-2 relative, every parameter gradient within 3e-2 in relative Frobenius norm."""
+import math
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _bf(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(*shape, device="cuda", generator=g) * scale).to(torch.bfloat16)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (a) fused attention at the C3 / C5 head layouts
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,S,Hq,Hkv,D", [(2, 1024, 32, 8, 64), (2, 2048, 32, 8, 64), (2, 2048, 8, 1, 256), (2, 1024, 8, 2, 128)],
+                         ids=["llama1b-S1024", "llama1b-S2048", "gemma2b-S2048", "d128-S1024"])
+def test_fused_attention_full_shape(B, S, Hq, Hkv, D):
+    """ecgb_attn_fwd / ecgb_attn_bwd vs fp32 softmax attention with the reference's mask (causal AND key not padded,
+    modeling_llama.py:1047-1100); rows left-padded by different amounts, one of them not a multiple of the 64-row tile."""
+    from ecg_byte_amd import decoder_ops as ops
+    if D != 64 and not getattr(ops, "FUSED_HEAD_DIMS", (64,)).__contains__(D):
+        pytest.skip(f"fused attention for head_dim {D} not built")
+    QKV = Hq * D + 2 * Hkv * D
+    qkv = _bf(B * S, QKV, seed=30)
+    mask = torch.ones(B, S, device="cuda")
+    mask[0, : S // 3] = 0
+    mask[1, :37] = 0
+    scale = 1.0 / math.sqrt(D)
+    o, lse = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)
+    x = qkv.float().view(B, S, QKV).clone().requires_grad_(True)
+    q = x[..., : Hq * D].reshape(B, S, Hq, D).transpose(1, 2)
+    k = x[..., Hq * D: Hq * D + Hkv * D].reshape(B, S, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, 1)
+    v = x[..., Hq * D + Hkv * D:].reshape(B, S, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, 1)
+    vis = torch.tril(torch.ones(S, S, device="cuda", dtype=torch.bool))[None, None] & (mask[:, None, None, :] != 0)
+    sc = (q @ k.transpose(-1, -2)) * scale
+    p = torch.nan_to_num(torch.softmax(sc.masked_fill(~vis, float("-inf")), -1), nan=0.0)
+    ref = (p @ v).transpose(1, 2).reshape(B * S, Hq * D)
+    err = (o.float() - ref).abs()
+    assert err.max().item() <= 3e-2, err.max().item()
+    assert ((o.float() - ref).norm() / ref.norm()).item() < 1e-2
+    assert bool((o.view(B, S, -1)[0, : S // 3] == 0).all()) and bool((o.view(B, S, -1)[1, :37] == 0).all())   # pad rows -> zeros
+    do = _bf(B * S, Hq * D, seed=31)
+    ref.backward(do.float())
+    d_qkv = ops.attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale)
+    want = x.grad.view(B * S, QKV)
+    for name, lo, hi in (("dq", 0, Hq * D), ("dk", Hq * D, Hq * D + Hkv * D), ("dv", Hq * D + Hkv * D, QKV)):
+        g, w = d_qkv[:, lo:hi].float(), want[:, lo:hi]
+        rel = (g - w).norm() / w.norm()
+        assert rel.item() < 2e-2, (name, rel.item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (b) two layers at Llama-3.2-1B dimensions (C3): loss and EVERY gradient vs the fp32 oracle
+# ---------------------------------------------------------------------------------------------------------------------
+LLAMA_1B = dict(vocab_size=132515, hidden_size=2048, intermediate_size=8192, num_hidden_layers=2, num_attention_heads=32,
+                num_key_value_heads=8, head_dim=64, rms_norm_eps=1e-5)
+LLAMA3_SCALING = {"factor": 32.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 8192,
+                  "rope_type": "llama3"}
+
+
+def _batch(B, S, vocab, pad_id, seed, pads, n_labels=40):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    ids = torch.randint(0, vocab - 1, (B, S), device="cuda", generator=g)
+    mask = torch.ones(B, S, device="cuda")
+    for b, n in enumerate(pads):
+        mask[b % B, :n] = 0
+        ids[b % B, :n] = pad_id
+    pos = (torch.cumsum(mask, 1) - 1).clamp(min=0).long()
+    pos[mask == 0] = 0
+    labels = torch.full((B, S), -100, device="cuda")
+    labels[:, -n_labels:] = ids[:, -n_labels:]
+    labels[0, -n_labels: -n_labels + 7] = -100            # ragged label counts per row
+    return ids, mask, labels, pos
+
+
+def _oracle_grads(cfgd, inv_freq, batch, seed, std=0.02):
+    from oracle import llama_ref as R
+    params = R.random_params(cfgd, seed=seed, device="cuda", std=std)
+    ref_p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ids, mask, labels, pos = batch
+    loss = R.llama_loss(ref_p, cfgd, ids, mask, labels, pos, inv_freq)
+    loss.backward()
+    grads = {k: v.grad for k, v in ref_p.items()}
+    return params, float(loss), grads
+
+
+def _compare_all_grads(m, cfgd, grads, tol=3e-2):
+    V, L = cfgd["vocab_size"], cfgd["num_hidden_layers"]
+    I = cfgd["intermediate_size"]
+    Hq, Hkv, D = cfgd["num_attention_heads"], cfgd["num_key_value_heads"], cfgd["head_dim"]
+    worst = {}
+
+    def chk(name, got, want):
+        rel = ((got.float() - want).norm() / want.norm().clamp_min(1e-20)).item()
+        worst[name] = rel
+        assert rel < tol, (name, rel)
+
+    chk("embed", m.embed.grad[:V], grads["model.embed_tokens.weight"])
+    chk("norm", m.norm.grad, grads["model.norm.weight"])
+    for i in range(L):
+        p = f"model.layers.{i}."
+        w = m.wqkv[i].grad
+        chk(p + "q", w[: Hq * D], grads[p + "self_attn.q_proj.weight"])
+        chk(p + "k", w[Hq * D: Hq * D + Hkv * D], grads[p + "self_attn.k_proj.weight"])
+        chk(p + "v", w[Hq * D + Hkv * D:], grads[p + "self_attn.v_proj.weight"])
+        chk(p + "o", m.wo[i].grad, grads[p + "self_attn.o_proj.weight"])
+        chk(p + "gate", m.wgu[i].grad[:I], grads[p + "mlp.gate_proj.weight"])
+        chk(p + "up", m.wgu[i].grad[I:], grads[p + "mlp.up_proj.weight"])
+        chk(p + "down", m.wdown[i].grad, grads[p + "mlp.down_proj.weight"])
+        chk(p + "ln1", m.ln1[i].grad, grads[p + "input_layernorm.weight"])
+        chk(p + "ln2", m.ln2[i].grad, grads[p + "post_attention_layernorm.weight"])
+    return worst
+
+
+@pytest.fixture(scope="module")
+def llama_1b_reference():
+    from oracle import llama_ref as R
+    inv = R.llama3_inv_freq(64, 500000.0, LLAMA3_SCALING).cuda()
+    batch = _batch(4, 1024, LLAMA_1B["vocab_size"], LLAMA_1B["vocab_size"] - 1, seed=5, pads=[300, 0, 37, 777])
+    params, loss, grads = _oracle_grads(LLAMA_1B, inv, batch, seed=3)
+    torch.cuda.empty_cache()
+    return batch, params, loss, grads
+
+
+@pytest.mark.parametrize("fused_attention,full_logits", [(True, False), (True, True), (False, False)],
+                         ids=["fused-attn/labelled-rows", "fused-attn/full-logits", "materialised-scores/labelled-rows"])
+def test_llama_1b_dims_two_layers_vs_fp32_oracle(llama_1b_reference, fused_attention, full_logits):
+    """hidden 2048, inter 8192, 32/8 heads, vocab 132 515 (128 256 + 256 + 4 000 + 3), S 1024, B 4, left-padded rows of four
+    different lengths, -100 labels (modeling_llama.py:526-614,1135-1225, loss_utils.py:24-47)."""
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    batch, params, ref_loss, grads = llama_1b_reference
+    cfg = DecoderConfig(**{k: v for k, v in LLAMA_1B.items()}, rope_theta=500000.0, rope_scaling=dict(LLAMA3_SCALING),
+                        pad_token_id=LLAMA_1B["vocab_size"] - 1)
+    m = HipCausalLM(cfg)
+    m.load_state_dict(params)
+    m.fused_attention, m.full_logits = fused_attention, full_logits
+    ids, mask, labels, pos = batch
+    out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
+    out.loss.backward()
+    assert abs(out.loss.item() - ref_loss) <= 1e-2 * ref_loss, (out.loss.item(), ref_loss)
+    _compare_all_grads(m, LLAMA_1B, grads)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (c) one layer at Gemma-2B dimensions, S = 2048 (C5)
+# ---------------------------------------------------------------------------------------------------------------------
+GEMMA_2B = dict(vocab_size=256000 + 256 + 3500 + 3, hidden_size=2048, intermediate_size=16384, num_hidden_layers=1,
+                num_attention_heads=8, num_key_value_heads=1, head_dim=256, rms_norm_eps=1e-6, model_type="gemma")
+
+
+def test_gemma_2b_dims_one_layer_vs_fp32_oracle():
+    """hidden 2048, MLP 16 384, 8 query heads / 1 KV head of 256, vocab 259 759, S 2048, B 2 (modeling_gemma.py:51-68,131-152,
+    201-300,800-801): (1 + w) RMSNorm, gelu-tanh gate, sqrt(hidden) embedding scale, MQA."""
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    from oracle import llama_ref as R
+    inv = R.llama3_inv_freq(256, 10000.0, None).cuda()
+    V = GEMMA_2B["vocab_size"]
+    batch = _batch(2, 2048, V, V - 1, seed=6, pads=[901, 64])
+    params, ref_loss, grads = _oracle_grads(GEMMA_2B, inv, batch, seed=4)
+    torch.cuda.empty_cache()
+    cfg = DecoderConfig.gemma_2b(vocab_size=V, num_hidden_layers=1, pad_token_id=V - 1)
+    m = HipCausalLM(cfg)
+    m.load_state_dict(params)
+    ids, mask, labels, pos = batch
+    out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
+    out.loss.backward()
+    assert abs(out.loss.item() - ref_loss) <= 1e-2 * ref_loss, (out.loss.item(), ref_loss)
+    _compare_all_grads(m, GEMMA_2B, grads)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (d) the bench batch (B = 32): the labelled-rows loss head is the full-logits loss head
+# ---------------------------------------------------------------------------------------------------------------------
+def test_b32_labelled_rows_loss_equals_full_logits_loss():
+    """C3's batch: B 32, S 1024, Llama-3.2-1B dims (two layers).  The loss head over the rows whose shifted label is not -100
+    must give the loss and the gradients of the head over all 32 768 rows (what the reference materialises,
+    modeling_llama.py:1209-1213): unlabelled rows contribute exactly nothing."""
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    cfg = DecoderConfig(**{k: v for k, v in LLAMA_1B.items()}, rope_theta=500000.0, rope_scaling=dict(LLAMA3_SCALING),
+                        pad_token_id=LLAMA_1B["vocab_size"] - 1)
+    m = HipCausalLM(cfg, seed=7)
+    batch = _batch(32, 1024, cfg.vocab_size, cfg.vocab_size - 1, seed=8, pads=[(13 * b) % 700 for b in range(32)], n_labels=33)
+    ids, mask, labels, pos = batch
+    res = {}
+    for full in (False, True):
+        m.full_logits = full
+        for p in m.parameters():
+            p.grad = None
+        out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
+        out.loss.backward()
+        res[full] = (out.loss.item(), m.embed.grad.float().clone(), m.wdown[1].grad.float().clone(), m.wqkv[0].grad.float().clone())
+    (l0, e0, d0, q0), (l1, e1, d1, q1) = res[False], res[True]
+    assert abs(l0 - l1) <= 1e-5 * abs(l1), (l0, l1)
+    for name, a, b in (("embed", e0, e1), ("down", d0, d1), ("qkv", q0, q1)):
+        rel = ((a - b).norm() / b.norm()).item()
+        assert rel < 2e-3, (name, rel)          # same arithmetic per row; fp32 atomics and chunk boundaries reorder the sums

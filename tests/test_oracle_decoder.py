@@ -33,3 +33,20 @@ def test_decoder_oracle_bf16_close_to_reference_bf16():
     loss = R.llama_loss(params, CFG, torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]),
                         torch.from_numpy(z["labels"]), torch.from_numpy(z["position_ids"]), inv)
     assert abs(loss.item() - float(z["loss_bf16"])) < 2e-3
+
+
+def test_decoder_oracle_gemma_matches_vendored_transformers_fp32():
+    """The Gemma branch of the oracle (fp32 (1 + w) RMSNorm, gelu-tanh gate, sqrt(hidden) embedding scale, head_dim 128 !=
+    hidden / heads, MQA) against loss and every gradient of the vendored GemmaForCausalLM (make_decoder_golden_gemma.py)."""
+    z = np.load(os.path.join(GOLDEN, "decoder_gemma_tiny.npz"))
+    cfg = dict(vocab_size=300, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+               num_key_value_heads=1, head_dim=128, rms_norm_eps=1e-6, model_type="gemma")
+    inv = R.llama3_inv_freq(128, 10000.0, None)
+    params = {k[2:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("w:") and "lm_head" not in k}
+    loss = R.llama_loss(params, cfg, torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]),
+                        torch.from_numpy(z["labels"]), torch.from_numpy(z["position_ids"]), inv)
+    assert abs(loss.item() - float(z["loss_fp32"])) < 1e-5
+    loss.backward()
+    for k, p in params.items():
+        ref = torch.from_numpy(z["g:" + k])
+        assert torch.allclose(p.grad, ref, atol=2e-6, rtol=1e-4), k
