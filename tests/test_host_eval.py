@@ -97,6 +97,8 @@ def test_tester_aggregates_like_the_reference():
     extra = lambda refs, hyps: {"ROUGE": {"rouge-1": 0.5, "rouge-l": 0.25}, "BERTSCORE": {"hf-f1": [0.75]}}
     out = tester(Stub(), data + [None], None, SimpleNamespace(dev=False, device="cpu"), extra_metrics=extra)
     assert out["metrics"]["BLEU"] == pytest.approx((1.0 + 0 + 0) / 3)
-    assert out["metrics"]["rouge-1"] == pytest.approx(0.5) and out["metrics"]["hf-f1"] == pytest.approx(0.75)
+    # the failed sample scores zero in EVERY metric (inference.py:34-39), not only in BLEU
+    assert out["metrics"]["rouge-1"] == pytest.approx(2 * 0.5 / 3) and out["metrics"]["hf-f1"] == pytest.approx(2 * 0.75 / 3)
+    assert out["metrics"]["METEOR"] == 0 and out["metrics"]["rouge-2"] == 0
     assert out["qa_results"] == {"questions": ["q1", "q2"], "gt_answers": ["sinus rhythm normal ecg", "atrial fibrillation"],
                                  "gen_answers": ["sinus rhythm normal ecg", "nothing in common"]}
