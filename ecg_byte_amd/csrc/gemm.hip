@@ -42,6 +42,11 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int accumulate_f32;         // 0: C (bf16) = ..;  1: C is fp32 and C += ..;  2: C is bf16 and C += ..
     float alpha;
+    // K-concatenation (NT kernels, batch 1): C = alpha * ([A | A2] . [B | B2]^T) -- after the K / 64 tiles of (A, B) the loop runs
+    // K2 / 64 tiles of (A2 [M, K2], B2 [N, K2]).  The LoRA branch t . B_lora^T of a projection rides in the projection's own launch.
+    const unsigned short *A2, *B2;
+    long long lda2, ldb2;
+    int K2;
 };
 
 __device__ __forceinline__ unsigned short f2bf_rn(float f)
@@ -116,16 +121,24 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel(GemmArgs G)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int KT = G.K / BK;
-    stage_tile<BM, NW>(A, G.lda, row0, G.M, 0, lds, wave, lane);
-    stage_tile<BN, NW>(B, G.ldb, col0, G.N, 0, lds + kABytes, wave, lane);
+    const int KT1 = G.K / BK, KT = KT1 + G.K2 / BK;
+    auto stage_a = [&](int t, unsigned char *dst) {
+        if (t < KT1) stage_tile<BM, NW>(A, G.lda, row0, G.M, t * BK, dst, wave, lane);
+        else stage_tile<BM, NW>(G.A2, G.lda2, row0, G.M, (t - KT1) * BK, dst, wave, lane);
+    };
+    auto stage_b = [&](int t, unsigned char *dst) {
+        if (t < KT1) stage_tile<BN, NW>(B, G.ldb, col0, G.N, t * BK, dst, wave, lane);
+        else stage_tile<BN, NW>(G.B2, G.ldb2, col0, G.N, (t - KT1) * BK, dst, wave, lane);
+    };
+    stage_a(0, lds);
+    stage_b(0, lds + kABytes);
     const int lr = lane & 31, lh = lane >> 5;
     for (int kt = 0; kt < KT; ++kt) {
         unsigned char *cur = lds + (kt & 1) * kBufBytes;
         if (kt + 1 < KT) {
             unsigned char *nxt = lds + ((kt + 1) & 1) * kBufBytes;
-            stage_tile<BM, NW>(A, G.lda, row0, G.M, (kt + 1) * BK, nxt, wave, lane);
-            stage_tile<BN, NW>(B, G.ldb, col0, G.N, (kt + 1) * BK, nxt + kABytes, wave, lane);
+            stage_a(kt + 1, nxt);
+            stage_b(kt + 1, nxt + kABytes);
             // this wave's loads of tile kt have landed once only the kLoadsPerTile just issued are outstanding
             if constexpr (kLoadsPerTile == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (kLoadsPerTile == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -298,16 +311,24 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16(GemmArgs G)
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int KT = G.K / BK;
-    stage_tile<BM, NW>(A, G.lda, row0, G.M, 0, lds, wave, lane);
-    stage_tile<BN, NW>(B, G.ldb, col0, G.N, 0, lds + kABytes, wave, lane);
+    const int KT1 = G.K / BK, KT = KT1 + G.K2 / BK;
+    auto stage_a = [&](int t, unsigned char *dst) {
+        if (t < KT1) stage_tile<BM, NW>(A, G.lda, row0, G.M, t * BK, dst, wave, lane);
+        else stage_tile<BM, NW>(G.A2, G.lda2, row0, G.M, (t - KT1) * BK, dst, wave, lane);
+    };
+    auto stage_b = [&](int t, unsigned char *dst) {
+        if (t < KT1) stage_tile<BN, NW>(B, G.ldb, col0, G.N, t * BK, dst, wave, lane);
+        else stage_tile<BN, NW>(G.B2, G.ldb2, col0, G.N, (t - KT1) * BK, dst, wave, lane);
+    };
+    stage_a(0, lds);
+    stage_b(0, lds + kABytes);
     const int lm = lane & 15, lq = lane >> 4;
     for (int kt = 0; kt < KT; ++kt) {
         unsigned char *cur = lds + (kt & 1) * kBufBytes;
         if (kt + 1 < KT) {
             unsigned char *nxt = lds + ((kt + 1) & 1) * kBufBytes;
-            stage_tile<BM, NW>(A, G.lda, row0, G.M, (kt + 1) * BK, nxt, wave, lane);
-            stage_tile<BN, NW>(B, G.ldb, col0, G.N, (kt + 1) * BK, nxt + kABytes, wave, lane);
+            stage_a(kt + 1, nxt);
+            stage_b(kt + 1, nxt + kABytes);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -389,14 +410,22 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int KT = G.K / BK;
+    const int KT1 = G.K / BK, KT = KT1 + G.K2 / BK;
+    auto stage_a = [&](int t, unsigned char *dst) {
+        if (t < KT1) stage_tile<BM, NW>(A, G.lda, row0, G.M, t * BK, dst, wave, lane);
+        else stage_tile<BM, NW>(G.A2, G.lda2, row0, G.M, (t - KT1) * BK, dst, wave, lane);
+    };
+    auto stage_b = [&](int t, unsigned char *dst) {
+        if (t < KT1) stage_tile<BN, NW>(B, G.ldb, col0, G.N, t * BK, dst, wave, lane);
+        else stage_tile<BN, NW>(G.B2, G.ldb2, col0, G.N, (t - KT1) * BK, dst, wave, lane);
+    };
 
     // prologue: tiles 0 and 1 in flight, tile 0 complete
-    stage_tile<BN, NW>(B, G.ldb, col0, G.N, 0, lds + kABytes, wave, lane);
-    stage_tile<BM, NW>(A, G.lda, row0, G.M, 0, lds, wave, lane);
+    stage_b(0, lds + kABytes);
+    stage_a(0, lds);
     if (KT > 1) {
-        stage_tile<BN, NW>(B, G.ldb, col0, G.N, BK, lds + kBufBytes + kABytes, wave, lane);
-        stage_tile<BM, NW>(A, G.lda, row0, G.M, BK, lds + kBufBytes, wave, lane);
+        stage_b(1, lds + kBufBytes + kABytes);
+        stage_a(1, lds + kBufBytes);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -450,11 +479,11 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
         mfma_quadrant(0, 1);
         // phase 3: the B region of this buffer was last read in phase 2
         read_a(1);
-        if (more) stage_tile<BN, NW>(B, G.ldb, col0, G.N, (kt + 2) * BK, nxt + kABytes, wave, lane);
+        if (more) stage_b(kt + 2, nxt + kABytes);
         mfma_quadrant(1, 1);
         // phase 4: the A region was last read in phase 3; tile kt+1 must be complete one barrier from here
         if (more) {
-            stage_tile<BM, NW>(A, G.lda, row0, G.M, (kt + 2) * BK, nxt, wave, lane);
+            stage_a(kt + 2, nxt);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -964,6 +993,7 @@ extern "C" int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b
     G.M = M; G.N = N; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = ldc;
     G.batch_a = batch_a; G.batch_b = batch_b; G.batch_c = batch_c;
     G.accumulate_f32 = accumulate_f32; G.alpha = alpha;
+    G.A2 = G.B2 = nullptr; G.lda2 = G.ldb2 = 0; G.K2 = 0;
     G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
     if (M <= 8 && batch == 1 && K % 8 == 0) {   // a few rows: bandwidth-bound column-per-wave kernel
         const bool split = (K >= 8192 && K % 32 == 0 && N <= 8192);      // long rows, few columns: four waves per column
@@ -981,6 +1011,28 @@ extern "C" int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b
         return ECGB_OK;
     }
     return launch_gemm(G, batch, (hipStream_t)stream);
+}
+
+extern "C" int ecgb_gemm_nt_bf16_cat(const void *a_dev, long long lda, const void *b_dev, long long ldb, const void *a2_dev, long long lda2,
+                                     const void *b2_dev, long long ldb2, int K2, void *c_dev, long long ldc, int M, int N, int K, float alpha,
+                                     int accumulate_f32, void *stream)
+{
+    if (!a_dev || !b_dev || !a2_dev || !b2_dev || !c_dev || M <= 0 || N <= 0 || K <= 0 || K2 <= 0) {
+        ecgb::set_error("ecgb_gemm_nt_bf16_cat: bad argument");
+        return ECGB_ERR_INVALID;
+    }
+    if (K % BK || K2 % BK || lda % 8 || ldb % 8 || lda2 % 8 || ldb2 % 8 || (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)a2_dev | (uintptr_t)b2_dev) & 15)) {
+        ecgb::set_error("ecgb_gemm_nt_bf16_cat: K and K2 must be multiples of 64 and operands 16-byte aligned with strides % 8 == 0");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    GemmArgs G;
+    G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = c_dev;
+    G.M = M; G.N = N; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = ldc;
+    G.batch_a = G.batch_b = G.batch_c = 0;
+    G.accumulate_f32 = accumulate_f32; G.alpha = alpha;
+    G.A2 = (const unsigned short *)a2_dev; G.B2 = (const unsigned short *)b2_dev; G.lda2 = lda2; G.ldb2 = ldb2; G.K2 = K2;
+    G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
+    return launch_gemm(G, 1, (hipStream_t)stream);
 }
 
 extern "C" int ecgb_gemm_nt_bf16_heads(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev,
@@ -1002,6 +1054,7 @@ extern "C" int ecgb_gemm_nt_bf16_heads(const void *a_dev, long long lda, const v
     G.M = M; G.N = N; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = ldc;
     G.batch_a = G.batch_b = G.batch_c = 0;
     G.accumulate_f32 = accumulate_f32; G.alpha = alpha;
+    G.A2 = G.B2 = nullptr; G.lda2 = G.ldb2 = 0; G.K2 = 0;
     G.inner = inner; G.outer_a = outer_a; G.inner_a = inner_a; G.div_a = div_a;
     G.outer_b = outer_b; G.inner_b = inner_b; G.div_b = div_b; G.outer_c = outer_c; G.inner_c = inner_c;
     return launch_gemm(G, batch, (hipStream_t)stream);
@@ -1021,6 +1074,7 @@ extern "C" int ecgb_gemm_tn_bf16(const void *a_dev, long long lda, const void *b
     G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = c_dev;
     G.M = M; G.N = N; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = ldc;
     G.batch_a = G.batch_b = G.batch_c = 0;
+    G.A2 = G.B2 = nullptr; G.lda2 = G.ldb2 = 0; G.K2 = 0;
     G.tiles_m = (N + 255) / 256; G.tiles_n = (K + 255) / 256;
     if (splits < 1 || splits > 64) { ecgb::set_error("ecgb_gemm_tn_bf16: splits must be 1..64"); return ECGB_ERR_INVALID; }
     G.accumulate_f32 = splits > 1 ? 1 : 0; G.alpha = alpha;      // splits > 1: c_dev is a ZEROED fp32 [N, ldc] buffer

@@ -1,0 +1,233 @@
+// lora.hip -- the LoRA adapter branch of a projection on MI355X (gfx950).
+//
+// Reference: peft 0.13 LoraLayer as ecg_byte/main.py:131-155 configures it (r 16, alpha 32, dropout 0.05 on
+// q,k,v,o,gate,up,down; peft is neither vendored nor installed -- restated from its published formula):
+//     y = x W^T + (alpha / r) * B ( A dropout(x) )              one independent dropout mask PER MODULE
+// The adapters of a fused projection (q|k|v, gate|up) are stacked: A = [16-row sub-blocks, in], t = [T, 16 * n_sub], and every
+// module ("block") draws its own mask from its own 16-bit field of one counter-based hash of the element index -- q, k and v
+// see three independent masks of the same x for one hash evaluation.
+//
+// Both kernels are HBM-bound passes over a [T, in] activation with a rank-16 contraction on the matrix cores; they exist so
+// that dropout never costs a pass of its own:
+//   lora_down_kernel   t = scale/(1-p) * (mask_b . x) A_b^T   reads x ONCE: the MFMA operand fragments are loaded from global
+//                      memory straight in operand layout (lane = row, 8 consecutive k), masked in registers; also stores the
+//                      masked x of every block (what the backward's dA = dt^T (mask . x) contraction reads)
+//   lora_dx_kernel     dx += scale/(1-p) * sum_b mask_b . (dt_b A_b)   one read-modify-write of dx: the rank-16 products land in
+//                      MFMA accumulators whose lane holds four consecutive columns of one row, masked and added in place
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "tokenizer.hpp"
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using us4 = __attribute__((ext_vector_type(4))) unsigned short;
+
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// 32 hash bits of (seed, element index): two independent 16-bit fields (murmur3's finaliser over a Weyl step)
+__device__ __forceinline__ unsigned hash32(unsigned seed, unsigned idx)
+{
+    unsigned u = idx * 0x9E3779B1u + seed;
+    u ^= u >> 15; u *= 0x85EBCA77u;
+    u ^= u >> 13; u *= 0xC2B2AE3Du;
+    u ^= u >> 16;
+    return u;
+}
+
+constexpr int kLoraK = 64;        // row length of t / dt / A^T: up to four 16-wide sub-blocks, zero beyond the last one (the GEMM K-step)
+
+struct LoraArgs {
+    const unsigned short *x;      // [T, in]
+    const unsigned short *A;      // lora_down: [>= 16 * n_sub, in];  lora_dx: A^T = [in, 64]
+    const unsigned short *dt;     // lora_dx: [T, 64]
+    unsigned short *t;            // lora_down: [T, 64]
+    unsigned short *xd;           // lora_down: [n_fields, T, in] masked x per block, or NULL
+    unsigned short *dx;           // lora_dx: [T, in], += in place
+    int T, in;                    // (sub-block s belongs to block s * NF / NSUB: every block has the same number of sub-blocks)
+    float scale;                  // alpha / r / (1 - p)
+    unsigned thr;                 // keep iff field >= thr, thr = p * 65536 (0: no dropout)
+    unsigned seed;
+};
+
+// the masks of one element: bit f = field f keeps it
+template <int NF>
+__device__ __forceinline__ unsigned keep_bits(const LoraArgs &L, unsigned idx)
+{
+    if (L.thr == 0) return 0xFu;
+    const unsigned h0 = hash32(L.seed, idx);
+    unsigned k = ((h0 & 0xFFFFu) >= L.thr ? 1u : 0u) | ((h0 >> 16) >= L.thr ? 2u : 0u);
+    if constexpr (NF > 2) {
+        const unsigned h1 = hash32(L.seed ^ 0x68E31DA4u, idx);
+        k |= ((h1 & 0xFFFFu) >= L.thr ? 4u : 0u) | ((h1 >> 16) >= L.thr ? 8u : 0u);
+    }
+    return k;
+}
+
+// One wave = 16 rows of x; a workgroup = 4 waves = 64 rows.  K loop in steps of 32 (one v_mfma_f32_16x16x32_bf16 per sub-block).
+template <int NSUB, int NF>
+__global__ __launch_bounds__(256) void lora_down_kernel(LoraArgs L)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lm = lane & 15, lq = lane >> 4;
+    const int row = (blockIdx.x * 4 + wave) * 16 + lm;
+    const int rowc = row < L.T ? row : L.T - 1;                       // clamped: out-of-range rows are never stored
+    const unsigned short *xr = L.x + (size_t)rowc * L.in + 8 * lq;
+    f32x4 acc[NSUB];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const size_t plane = (size_t)L.T * L.in;
+    for (int k0 = 0; k0 < L.in; k0 += 64) {
+        bf16x8 xv[2], av[2][NSUB];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            xv[u] = *reinterpret_cast<const bf16x8 *>(xr + k0 + 32 * u);
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s)
+                av[u][s] = *reinterpret_cast<const bf16x8 *>(L.A + (size_t)(16 * s + lm) * L.in + k0 + 32 * u + 8 * lq);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            unsigned keep[8];
+            const unsigned idx0 = (unsigned)rowc * (unsigned)L.in + (unsigned)(k0 + 32 * u + 8 * lq);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) keep[e] = keep_bits<NF>(L, idx0 + e);
+            bf16x8 xm[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xm[f][e] = ((keep[e] >> f) & 1u) ? xv[u][e] : (short)0;
+                if (L.xd && row < L.T)
+                    *reinterpret_cast<bf16x8 *>(L.xd + f * plane + (size_t)row * L.in + k0 + 32 * u + 8 * lq) = xm[f];
+            }
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s)
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u][s], xm[s * NF / NSUB], acc[s], 0, 0, 0);   // D'[c][row]: lane = row, regs = 4 columns
+        }
+    }
+    if (row >= L.T) return;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {                                     // t is [T, 64]: the columns past the last sub-block are zero
+        us4 v = (us4){0, 0, 0, 0};
+        if (s < NSUB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = f2bf(acc[s < NSUB ? s : 0][r] * L.scale);
+        }
+        *reinterpret_cast<us4 *>(L.t + (size_t)row * kLoraK + 16 * s + 4 * lq) = v;
+    }
+}
+
+// One wave = 16 rows; it sweeps the columns of dx in tiles of 16.  The rank-16 product of a sub-block uses half the K of the
+// 16x16x32 MFMA (k-groups 2 and 3 of both fragments are zero).
+template <int NSUB, int NF>
+__global__ __launch_bounds__(256) void lora_dx_kernel(LoraArgs L)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lm = lane & 15, lq = lane >> 4;
+    const int row = (blockIdx.x * 4 + wave) * 16 + lm;
+    const int rowc = row < L.T ? row : L.T - 1;
+    constexpr int kp = kLoraK;
+    const bf16x8 zero = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 dtf[NSUB];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s)
+        dtf[s] = (lq < 2) ? *reinterpret_cast<const bf16x8 *>(L.dt + (size_t)rowc * kp + 16 * s + 8 * lq) : zero;
+    unsigned short *dxr = L.dx + (size_t)rowc * L.in + 4 * lq;
+    const int c_lo = blockIdx.y * (L.in / gridDim.y), c_hi = c_lo + L.in / gridDim.y;
+    for (int c0 = c_lo; c0 < c_hi; c0 += 16) {
+        const us4 old = *reinterpret_cast<const us4 *>(dxr + c0);
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+        unsigned keep[4];
+        const unsigned idx0 = (unsigned)rowc * (unsigned)L.in + (unsigned)(c0 + 4 * lq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep[e] = keep_bits<NF>(L, idx0 + e);
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const bf16x8 af = (lq < 2) ? *reinterpret_cast<const bf16x8 *>(L.A + (size_t)(c0 + lm) * kp + 16 * s + 8 * lq) : zero;
+            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, dtf[s], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // D'[col][row]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum[e] += ((keep[e] >> (s * NF / NSUB)) & 1u) ? d[e] : 0.f;
+        }
+        if (row < L.T) {
+            us4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = f2bf(bf2f(old[e]) + sum[e] * L.scale);
+            *reinterpret_cast<us4 *>(dxr + c0) = v;
+        }
+    }
+}
+
+int check_common(const char *who, int T, int in, int n_sub, int n_fields, float p)
+{
+    if (T <= 0 || in <= 0 || in % 64 || n_sub < 1 || n_sub > 4 || n_fields < 1 || n_fields > n_sub || n_sub % n_fields || !(p >= 0.f && p < 1.f)) {
+        ecgb::set_error(std::string(who) + ": T > 0, in % 64 == 0, 1..4 sub-blocks split evenly over 1..4 blocks, 0 <= p < 1 required");
+        return ECGB_ERR_INVALID;
+    }
+    return ECGB_OK;
+}
+
+void fill(LoraArgs &L, int T, int in, float scale, float p, uint64_t seed)
+{
+    L.T = T; L.in = in;
+    L.thr = (unsigned)(p * 65536.0f);
+    L.scale = scale / (1.0f - (float)L.thr / 65536.0f);            // the keep probability the 16-bit threshold really gives
+    L.seed = (unsigned)(seed ^ (seed >> 32));
+}
+
+#define ECGB_LORA_DISPATCH(KERNEL, GRID)                                                                                       \
+    do {                                                                                                                       \
+        const int key = n_sub * 8 + n_fields;                                                                                  \
+        if (key == 1 * 8 + 1) hipLaunchKernelGGL((KERNEL<1, 1>), GRID, dim3(256), 0, (hipStream_t)stream, L);                  \
+        else if (key == 2 * 8 + 1) hipLaunchKernelGGL((KERNEL<2, 1>), GRID, dim3(256), 0, (hipStream_t)stream, L);             \
+        else if (key == 2 * 8 + 2) hipLaunchKernelGGL((KERNEL<2, 2>), GRID, dim3(256), 0, (hipStream_t)stream, L);             \
+        else if (key == 3 * 8 + 1) hipLaunchKernelGGL((KERNEL<3, 1>), GRID, dim3(256), 0, (hipStream_t)stream, L);             \
+        else if (key == 3 * 8 + 3) hipLaunchKernelGGL((KERNEL<3, 3>), GRID, dim3(256), 0, (hipStream_t)stream, L);             \
+        else if (key == 4 * 8 + 1) hipLaunchKernelGGL((KERNEL<4, 1>), GRID, dim3(256), 0, (hipStream_t)stream, L);             \
+        else if (key == 4 * 8 + 2) hipLaunchKernelGGL((KERNEL<4, 2>), GRID, dim3(256), 0, (hipStream_t)stream, L);             \
+        else hipLaunchKernelGGL((KERNEL<4, 4>), GRID, dim3(256), 0, (hipStream_t)stream, L);                                   \
+    } while (0)
+
+}  // namespace
+
+extern "C" int ecgb_lora_down(const void *x_dev, const void *a_dev, void *t_dev, void *xd_dev, int T, int in, int n_sub, int n_fields,
+                              float scale, float p, uint64_t seed, void *stream)
+{
+    if (!x_dev || !a_dev || !t_dev) { ecgb::set_error("ecgb_lora_down: NULL argument"); return ECGB_ERR_INVALID; }
+    if (int rc = check_common("ecgb_lora_down", T, in, n_sub, n_fields, p)) return rc;
+    LoraArgs L{};
+    L.x = (const unsigned short *)x_dev; L.A = (const unsigned short *)a_dev; L.t = (unsigned short *)t_dev; L.xd = (unsigned short *)xd_dev;
+    fill(L, T, in, scale, p, seed);
+    const dim3 grid((unsigned)((T + 63) / 64));
+    ECGB_LORA_DISPATCH(lora_down_kernel, grid);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ecgb::set_error(std::string("lora_down_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
+}
+
+extern "C" int ecgb_lora_dx(const void *dt_dev, const void *at_dev, void *dx_dev, int T, int in, int n_sub, int n_fields,
+                            float scale, float p, uint64_t seed, void *stream)
+{
+    if (!dt_dev || !at_dev || !dx_dev) { ecgb::set_error("ecgb_lora_dx: NULL argument"); return ECGB_ERR_INVALID; }
+    if (int rc = check_common("ecgb_lora_dx", T, in, n_sub, n_fields, p)) return rc;
+    LoraArgs L{};
+    L.dt = (const unsigned short *)dt_dev; L.A = (const unsigned short *)at_dev; L.dx = (unsigned short *)dx_dev;
+    fill(L, T, in, scale, p, seed);
+    const unsigned row_blocks = (unsigned)((T + 63) / 64);
+    unsigned col_split = 1;                                          // few rows: split the columns over blockIdx.y to fill the chip
+    while (row_blocks * col_split < 1024 && (in / (int)(col_split * 2)) % 16 == 0 && col_split < 16) col_split *= 2;
+    const dim3 grid(row_blocks, col_split);
+    ECGB_LORA_DISPATCH(lora_dx_kernel, grid);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ecgb::set_error(std::string("lora_dx_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
+}

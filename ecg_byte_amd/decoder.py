@@ -91,50 +91,72 @@ def rope_inv_freq(cfg: DecoderConfig) -> torch.Tensor:
 class LoraSite(nn.Module):
     """LoRA adapters of one (possibly fused) projection, as peft's LoraLayer computes them
     (ecg_byte/main.py:131-155: r 16, alpha 32, dropout 0.05 on q,k,v,o,gate,up,down):
-        y[:, block b] += (alpha / r) * (dropout(x) A_b^T) B_b^T,   A_b: [r, in] kaiming-uniform, B_b: [out_b, r] zeros.
-    The rank is padded to the GEMM K-step (64): A rows / B columns r..63 are zero and stay zero (their
-    gradients are products with those zeros).  peft is neither vendored nor installed: parity unpinned."""
+        y[:, block b] = x W_b^T + (alpha / r) * (dropout_b(x) A_b^T) B_b^T,   A_b: [r, in] kaiming-uniform, B_b: [out_b, r] zeros,
+    with an independent dropout mask per module (q, k and v are three LoraLayers over the same input).
+    peft is neither vendored nor installed: parity unpinned, restated from the published formula.
+
+    MI355X layout: the adapters of the site are STACKED -- A is [64, in] (block b's rows start at 16 * spb * b, spb = ceil(r / 16)
+    sixteen-row sub-blocks per block; the rows past r and past the last block are zero and stay zero), B is [out, 64]
+    block-structured (block b's rows carry its r columns, zeros elsewhere: the gradient is masked to that pattern).  Then
+      forward   t = lora_down(x)  one pass over x (dropout inside, ecgb_lora_down);  y = [x | t] . [W | B]^T  ONE launch (K-concatenated
+                GEMM): the branch costs one extra K-step of the projection instead of a read-modify-write of y
+      backward  dt = dy . B;  dB = dy^T . t;  dA_b = dt_b^T . (mask_b . x);  dx += sum_b mask_b . (dt_b A_b)  (ecgb_lora_dx, in place)."""
 
     def __init__(self, in_dim, out_blocks, r, alpha, dropout, device, gen):
         super().__init__()
-        assert r <= 64
-        self.r, self.scale, self.p = r, alpha / r, dropout
+        self.r, self.alpha, self.p = r, alpha, dropout
         self.blocks = list(out_blocks)                       # (column offset, width) inside the fused output
         nb = len(self.blocks)
-        A = torch.zeros(64 * nb, in_dim)
+        self.spb = (r + 15) // 16                            # sub-blocks of 16 ranks per block
+        self.n_sub, self.n_fields = nb * self.spb, nb
+        if self.n_sub > 4:
+            raise NotImplementedError(f"LoRA rank {r} on a projection of {nb} fused modules needs {self.n_sub} > 4 sub-blocks of 16")
+        self.scale = alpha / r
+        A = torch.zeros(64, in_dim)
         bound = 1.0 / math.sqrt(in_dim)                      # kaiming_uniform_(a=sqrt(5)) on [r, in]
-        for b in range(nb):
-            A[64 * b: 64 * b + r] = (torch.rand(r, in_dim, generator=gen) * 2 - 1) * bound
+        n_out = sum(w for _, w in self.blocks)
+        bmask = torch.zeros(n_out, 64)
+        for b, (off, w) in enumerate(self.blocks):
+            lo = 16 * self.spb * b
+            A[lo: lo + r] = (torch.rand(r, in_dim, generator=gen) * 2 - 1) * bound
+            bmask[off: off + w, lo: lo + r] = 1.0
         self.A = nn.Parameter(A.to(torch.bfloat16).to(device))
-        self.B = nn.ParameterList([nn.Parameter(torch.zeros(w, 64, dtype=torch.bfloat16, device=device)) for _, w in self.blocks])
+        self.B = nn.Parameter(torch.zeros(n_out, 64, dtype=torch.bfloat16, device=device))
+        self.register_buffer("bmask", bmask.to(torch.bfloat16).to(device), persistent=False)
         self.seed = int(torch.randint(0, 2 ** 31, (1,), generator=gen))
         self.calls = 0
 
-    def forward_add(self, x, y, training):
-        """y (the base projection's output, [T, sum of widths]) += the adapter branches.  Returns what backward needs."""
-        seed = None
-        xd = x
+    def a_rows(self, b):
+        """Rows of A (= columns of B) that hold block b's rank-r adapter."""
+        lo = 16 * self.spb * b
+        return lo, lo + self.r
+
+    def project(self, x, w, training, keep=False):
+        """y = x W^T + the adapter branch, [T, out].  Returns (y, what backward needs)."""
+        p, seed = 0.0, 0
         if training and self.p > 0:
             self.calls += 1
-            seed = self.seed + 7919 * self.calls
-            xd = ops.dropout(x, self.p, seed)
-        t = ops.gemm_nt(xd, self.A.data)                     # [T, 64 * nb]
-        for b, (off, w) in enumerate(self.blocks):
-            ops.gemm_nt(t[:, 64 * b: 64 * b + 64], self.B[b].data, out=y[:, off: off + w], alpha=self.scale, accumulate=True)
-        return xd, t, seed
+            p, seed = self.p, self.seed + 7919 * self.calls
+        t, xd = ops.lora_down(x, self.A.data, self.n_sub, self.n_fields, self.scale, p, seed, keep_masked=keep)
+        y = ops.gemm_nt(x, w, a2=t, b2=self.B.data)
+        return y, (x, xd, t, p, seed)
 
-    def backward(self, dy, saved, model):
-        """Sets A.grad / B[b].grad (slices of the model's flat gradient buffer) and returns the adapters' contribution to d(input)."""
-        xd, t, seed = saved
-        dt = torch.empty_like(t)
-        for b, (off, w) in enumerate(self.blocks):
-            dyb = dy[:, off: off + w]
-            model._wgrad(self.B[b], dyb, t[:, 64 * b: 64 * b + 64], alpha=self.scale)
-            ops.gemm_nt(dyb, ops.transpose(self.B[b].data), out=dt[:, 64 * b: 64 * b + 64], alpha=self.scale)
-        model._wgrad(self.A, dt, xd)
-        dx = ops.gemm_nt(dt, ops.transpose(self.A.data))
-        if seed is not None:
-            ops.dropout(dx, self.p, seed, out=dx)
+    def backward(self, dy, saved, model, dx):
+        """Sets A.grad / B.grad (slices of the model's flat gradient buffer) and adds the adapters' contribution to `dx` in place
+        (dx already holds the base projection's dy . W)."""
+        x, xd, t, p, seed = saved
+        Bt = model._shadow(("lora_Bt", id(self)), self.B)                 # [64, out]
+        At = model._shadow(("lora_At", id(self)), self.A)                 # [in, 64]
+        dt = ops.gemm_nt(dy, Bt)                                         # [T, 64] = dy . B
+        model._wgrad(self.B, dy, t)                                      # dB = dy^T . t  (t carries alpha / r and 1 / (1 - p))
+        self.B.grad.mul_(self.bmask)                                     # every block's rows keep only its own columns
+        keep_scale = self.scale / (1.0 - int(p * 65536.0) / 65536.0)     # the keep probability ecgb_lora_down's 16-bit threshold gives
+        if xd is None:
+            model._wgrad(self.A, dt, x, alpha=keep_scale)                # no dropout: one product for all blocks
+        else:
+            w = 16 * self.spb                                            # dA_b = dt_b^T . (mask_b . x)
+            model._wgrad_rows(self.A, [(w * f, w * f + w, dt[:, w * f: w * f + w], xd[f]) for f in range(self.n_fields)], alpha=keep_scale)
+        ops.lora_dx_(dx, dt, At, self.n_sub, self.n_fields, self.scale, p, seed)
         return dx
 
 
@@ -323,8 +345,10 @@ class HipCausalLM(nn.Module):
                 site = layer[key]
                 for b, mod in enumerate(mods):
                     pre = f"base_model.model.model.layers.{i}.{mod}."
-                    yield pre + "lora_A.default.weight", site.A.data[64 * b: 64 * b + site.r]
-                    yield pre + "lora_B.default.weight", site.B[b].data[:, : site.r]
+                    lo, hi = site.a_rows(b)
+                    off, w = site.blocks[b]
+                    yield pre + "lora_A.default.weight", site.A.data[lo:hi]
+                    yield pre + "lora_B.default.weight", site.B.data[off: off + w, lo:hi]
 
     def _hf_named(self):
         """(HF name, tensor view) pairs, modeling_llama.py parameter names."""
@@ -383,12 +407,25 @@ class HipCausalLM(nn.Module):
 
     # ---- helpers --------------------------------------------------------------------------
     def _shadow(self, key, p):
-        """Transposed copy of a weight, refreshed when the parameter was updated in place."""
+        """Transposed copy of a weight.  The optimizer drops the copies of the parameters it updated (`_drop_shadows`): the frozen
+        base of a LoRA run is transposed once, not once per step."""
         ver = p._version
-        if self._t_version.get(key) != ver or key not in self._t:
-            self._t[key] = ops.transpose(p.data)
+        hit = self._t.get(key)
+        if hit is None or self._t_version.get(key) != ver:
+            hit = self._t[key] = (ops.transpose(p.data), id(p))
             self._t_version[key] = ver
-        return self._t[key]
+        return hit[0]
+
+    def _drop_shadows(self, param_ids):
+        for key in [k for k, (_, pid) in self._t.items() if pid in param_ids]:
+            del self._t[key]
+
+    def _proj(self, i, key, x, w, training=False, keep=False):
+        """One projection of layer i ("qkv", "o", "gu", "down"): x W^T, plus the LoRA branch of the site when adapters are on
+        (in the same launch).  Returns (y, what the adapter's backward needs or None)."""
+        if self.lora is None:
+            return ops.gemm_nt(x, w), None
+        return self.lora[i][key].project(x, w, training, keep)
 
     def _rope_tables(self, position_ids):
         pos = position_ids.reshape(-1).float()
@@ -455,11 +492,18 @@ class HipCausalLM(nn.Module):
 
     def _wgrad(self, param, dy, xin, alpha=1.0):
         """param.grad (+)= alpha * dy^T . xin, written by the TN GEMM into the flat buffer."""
+        self._wgrad_rows(param, [(0, param.shape[0], dy, xin)], alpha)
+
+    def _wgrad_rows(self, param, parts, alpha=1.0):
+        """parts = [(lo, hi, dy, xin)]: rows [lo, hi) of param.grad (+)= alpha * dy^T . xin (the stacked LoRA adapters: one product per
+        block; rows no part covers keep the zeros the flat buffer was created with)."""
         view, acc = self._grad_slot(param)
-        if acc:
-            ops.add(view, ops.gemm_tn(dy, xin, alpha=alpha), out=view)
-        else:
-            ops.gemm_tn(dy, xin, alpha=alpha, out=view)
+        for lo, hi, dy, xin in parts:
+            dst = view[lo:hi]
+            if acc:
+                ops.add(dst, ops.gemm_tn(dy, xin, alpha=alpha), out=dst)
+            else:
+                ops.gemm_tn(dy, xin, alpha=alpha, out=dst)
         param.grad = view
 
     def _vgrad(self, param, g):
@@ -501,26 +545,18 @@ class HipCausalLM(nn.Module):
         delta = None
         for i in range(c.num_hidden_layers):
             h1, rstd1, x1 = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
-            qkv = ops.gemm_nt(h1, self.wqkv[i].data)                    # [T, QKV]
             ls = [None] * 4
-            if self.lora is not None:
-                ls[0] = self.lora[i]["qkv"].forward_add(h1, qkv, self.training)
+            qkv, ls[0] = self._proj(i, "qkv", h1, self.wqkv[i].data, self.training, True)    # [T, QKV]
             ops.rope_(qkv, cos, sin, Hq + Hkv, D, QKV)                   # the query heads and the key heads lie side by side: one launch
             if self.fused_attention:
                 ao, P = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)       # P slot holds the row log-sum-exps
             else:
                 ao, P = self._attn_materialised(qkv, mask, B, S)
-            attn_delta = ops.gemm_nt(ao, self.wo[i].data)               # [T, H]
-            if self.lora is not None:
-                ls[1] = self.lora[i]["o"].forward_add(ao, attn_delta, self.training)
+            attn_delta, ls[1] = self._proj(i, "o", ao, self.wo[i].data, self.training, True)   # [T, H]
             h2, rstd2, x2 = ops.rmsnorm_fwd(x1, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma)
-            gu = ops.gemm_nt(h2, self.wgu[i].data)                      # [T, 2I]
-            if self.lora is not None:
-                ls[2] = self.lora[i]["gu"].forward_add(h2, gu, self.training)
+            gu, ls[2] = self._proj(i, "gu", h2, self.wgu[i].data, self.training, True)         # [T, 2I]
             hm = ops.glu_fwd(gu, gelu_tanh=self.gemma)
-            delta = ops.gemm_nt(hm, self.wdown[i].data)
-            if self.lora is not None:
-                ls[3] = self.lora[i]["down"].forward_add(hm, delta, self.training)
+            delta, ls[3] = self._proj(i, "down", hm, self.wdown[i].data, self.training, True)
             saved.append((x1, rstd1, h1, qkv, P, ao, x2, rstd2, h2, gu, hm, ls))
             x = x2
         hf, rstdf, xf = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
@@ -588,9 +624,7 @@ class HipCausalLM(nn.Module):
         delta = None
         for i in range(c.num_hidden_layers):
             h1, _, x = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
-            qkv = ops.gemm_nt(h1, self.wqkv[i].data)
-            if self.lora is not None:
-                self.lora[i]["qkv"].forward_add(h1, qkv, False)
+            qkv, _ = self._proj(i, "qkv", h1, self.wqkv[i].data)
             ops.rope_(qkv, cos, sin, Hq + Hkv, D, QKV)                   # the query heads and the key heads lie side by side: one launch
             if kv_out is not None:
                 kv_out[i][:, :S - lpad].copy_(qkv.view(B, S, QKV)[:, lpad:, Hq * D:])
@@ -598,17 +632,11 @@ class HipCausalLM(nn.Module):
                 ao, _ = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)
             else:
                 ao, _ = self._attn_materialised(qkv, mask, B, S)
-            attn_delta = ops.gemm_nt(ao, self.wo[i].data)
-            if self.lora is not None:
-                self.lora[i]["o"].forward_add(ao, attn_delta, False)
+            attn_delta, _ = self._proj(i, "o", ao, self.wo[i].data)
             h2, _, x = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma)
-            gu = ops.gemm_nt(h2, self.wgu[i].data)
-            if self.lora is not None:
-                self.lora[i]["gu"].forward_add(h2, gu, False)
+            gu, _ = self._proj(i, "gu", h2, self.wgu[i].data)
             hm = ops.glu_fwd(gu, gelu_tanh=self.gemma)
-            delta = ops.gemm_nt(hm, self.wdown[i].data)
-            if self.lora is not None:
-                self.lora[i]["down"].forward_add(hm, delta, False)
+            delta, _ = self._proj(i, "down", hm, self.wdown[i].data)
         hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
         if lpad:
             hf = hf.view(B, S, -1)[:, lpad:].reshape(B * S_out, -1)
@@ -646,9 +674,7 @@ class HipCausalLM(nn.Module):
         delta = None
         for i in range(c.num_hidden_layers):
             h1, _, x = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
-            qkv = ops.gemm_nt(h1, self.wqkv[i].data)                     # [B, QKV]
-            if self.lora is not None:
-                self.lora[i]["qkv"].forward_add(h1, qkv, False)
+            qkv, _ = self._proj(i, "qkv", h1, self.wqkv[i].data)         # [B, QKV]
             ops.rope_(qkv, cos, sin, Hq + Hkv, D, QKV)                   # the query heads and the key heads lie side by side: one launch
             if n_dev is None:
                 caches[i][:, n - 1].copy_(qkv[:, Hq * D:])
@@ -660,17 +686,11 @@ class HipCausalLM(nn.Module):
             else:
                 ops.kv_append(qkv, Hq * D, caches[i], n_dev)
                 ao = ops.attn_decode_dyn(qkv, caches[i], mask, n_dev, Hq, Hkv, D, scale)
-            attn_delta = ops.gemm_nt(ao, self.wo[i].data)
-            if self.lora is not None:
-                self.lora[i]["o"].forward_add(ao, attn_delta, False)
+            attn_delta, _ = self._proj(i, "o", ao, self.wo[i].data)
             h2, _, x = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma)
-            gu = ops.gemm_nt(h2, self.wgu[i].data)
-            if self.lora is not None:
-                self.lora[i]["gu"].forward_add(h2, gu, False)
+            gu, _ = self._proj(i, "gu", h2, self.wgu[i].data)
             hm = ops.glu_fwd(gu, gelu_tanh=self.gemma)
-            delta = ops.gemm_nt(hm, self.wdown[i].data)
-            if self.lora is not None:
-                self.lora[i]["down"].forward_add(hm, delta, False)
+            delta, _ = self._proj(i, "down", hm, self.wdown[i].data)
         hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
         return hf
 
@@ -834,13 +854,13 @@ class HipCausalLM(nn.Module):
             wgrad(g, hm, self.wdown[i])
             d_hm = ops.gemm_nt(g, self._shadow(("wdown", i), self.wdown[i]))        # [T, I]
             if frozen:
-                d_hm = ops.add(d_hm, self.lora[i]["down"].backward(g, ls[3], self))
+                self.lora[i]["down"].backward(g, ls[3], self, d_hm)
             d_gu = ops.glu_bwd(gu, d_hm, gelu_tanh=self.gemma)
             del d_hm, hm
             wgrad(d_gu, h2, self.wgu[i])
             d_h2 = ops.gemm_nt(d_gu, self._shadow(("wgu", i), self.wgu[i]))         # [T, H]
             if frozen:
-                d_h2 = ops.add(d_h2, self.lora[i]["gu"].backward(d_gu, ls[2], self))
+                self.lora[i]["gu"].backward(d_gu, ls[2], self, d_h2)
             del d_gu, gu
             dw = torch.zeros(H, dtype=torch.float32, device=dev)
             g2 = ops.rmsnorm_bwd(x2, self.ln2[i].data, rstd2, d_h2, dw, dres=g, gemma=self.gemma)
@@ -849,7 +869,7 @@ class HipCausalLM(nn.Module):
             wgrad(g2, ao, self.wo[i])
             d_ao = ops.gemm_nt(g2, self._shadow(("wo", i), self.wo[i]))             # [T, Hq*D]
             if frozen:
-                d_ao = ops.add(d_ao, self.lora[i]["o"].backward(g2, ls[1], self))
+                self.lora[i]["o"].backward(g2, ls[1], self, d_ao)
             # attention core
             if self.fused_attention:
                 d_qkv = ops.attn_bwd(qkv, mask, ao, d_ao, P, B, S, Hq, Hkv, D, scale)
@@ -883,7 +903,7 @@ class HipCausalLM(nn.Module):
             wgrad(d_qkv, h1, self.wqkv[i])
             d_h1 = ops.gemm_nt(d_qkv, self._shadow(("wqkv", i), self.wqkv[i]))      # [T, H]
             if frozen:
-                d_h1 = ops.add(d_h1, self.lora[i]["qkv"].backward(d_qkv, ls[0], self))
+                self.lora[i]["qkv"].backward(d_qkv, ls[0], self, d_h1)
             dw = torch.zeros(H, dtype=torch.float32, device=dev)
             g = ops.rmsnorm_bwd(x1, self.ln1[i].data, rstd1, d_h1, dw, dres=g2, gemma=self.gemma)
             lngrad(self.ln1[i], dw)
@@ -945,6 +965,6 @@ class HipAdam:
                 st = (torch.zeros(p.shape, dtype=torch.float32, device=p.device), torch.zeros(p.shape, dtype=torch.float32, device=p.device))
                 self.state[id(p)] = st
             ops.adam_step_(p.data, p.grad, st[0], st[1], acc, self.max_norm, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t)
-        self.model._t.clear()   # weights changed: transposed shadows are stale
+        self.model._drop_shadows({id(p) for p in params})   # updated weights: their transposed shadows are stale
 
     step = step_and_update_lr

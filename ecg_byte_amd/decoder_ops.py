@@ -97,15 +97,25 @@ def set_gemm_tile(tile: int):
     _lib.check(_L().ecgb_set_gemm_tile(int(tile)))
 
 
-def gemm_nt(a, b, out=None, alpha=1.0, accumulate_f32=False, accumulate=False):
+def gemm_nt(a, b, out=None, alpha=1.0, accumulate_f32=False, accumulate=False, a2=None, b2=None):
     """C[M,N] = alpha * A[M,K] @ B[N,K]^T.  a, b: 2-D bf16 (row stride = shape[1] or a column slice view).
-    accumulate_f32: `out` is fp32 and receives +=;  accumulate: `out` is bf16 and receives +=."""
+    accumulate_f32: `out` is fp32 and receives +=;  accumulate: `out` is bf16 and receives +=.
+    a2 [M,K2], b2 [N,K2]: a second operand pair contracted in the same launch, C = alpha * (A B^T + A2 B2^T)."""
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K and a.stride(1) == 1 and b.stride(1) == 1
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32 if accumulate_f32 else torch.bfloat16, device=a.device)
     mode = 1 if accumulate_f32 else (2 if accumulate else 0)
+    if a2 is not None:
+        K2 = a2.shape[1]
+        assert a2.shape[0] == M and b2.shape == (N, K2) and a2.stride(1) == 1 and b2.stride(1) == 1
+        if M > 8:
+            _lib.check(_L().ecgb_gemm_nt_bf16_cat(_p(a), a.stride(0), _p(b), b.stride(0), _p(a2), a2.stride(0), _p(b2), b2.stride(0), K2,
+                                                  _p(out), out.stride(0), M, N, K, float(alpha), mode, _st()))
+            return out
+        gemm_nt(a, b, out=out, alpha=alpha, accumulate_f32=accumulate_f32, accumulate=accumulate)      # few rows (a decode step):
+        return gemm_nt(a2, b2, out=out, alpha=alpha, accumulate_f32=accumulate_f32, accumulate=not accumulate_f32)   # two launches
     _lib.check(_L().ecgb_gemm_nt_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, float(alpha),
                                       mode, 1, 0, 0, 0, _st()))
     return out
@@ -117,6 +127,24 @@ def dropout(x, p, seed, out=None):
         out = torch.empty_like(x)
     _lib.check(_L().ecgb_dropout_bf16(_p(_bf(x)), _p(out), x.numel(), float(p), int(seed), _st()))
     return out
+
+
+def lora_down(x, A, n_sub, n_fields, scale, p=0.0, seed=0, keep_masked=False):
+    """t = scale / (1 - p) * (mask_f . x) A_f^T for the stacked adapters A [64, in] (n_sub 16-row sub-blocks) of n_fields modules, each
+    with its own dropout mask (ecgb_lora_down).  Returns (t [T, 64], masked copies of x [n_fields, T, in] or None)."""
+    T, K = x.shape
+    t = torch.empty((T, 64), dtype=torch.bfloat16, device=x.device)
+    xd = torch.empty((n_fields, T, K), dtype=torch.bfloat16, device=x.device) if keep_masked and p > 0 else None
+    _lib.check(_L().ecgb_lora_down(_p(_bf(x)), _p(_bf(A)), _p(t), _p(xd), T, K, n_sub, n_fields, float(scale), float(p), int(seed), _st()))
+    return t, xd
+
+
+def lora_dx_(dx, dt, At, n_sub, n_fields, scale, p=0.0, seed=0):
+    """dx += scale / (1 - p) * sum_f mask_f . (dt_f A_f), in place; dt [T, 64], At = A^T [in, 64] (ecgb_lora_dx)."""
+    T, K = dx.shape
+    assert dt.shape == (T, 64) and At.shape == (K, 64)
+    _lib.check(_L().ecgb_lora_dx(_p(_bf(dt)), _p(_bf(At)), _p(_bf(dx)), T, K, n_sub, n_fields, float(scale), float(p), int(seed), _st()))
+    return dx
 
 
 def gemm_tn(a, b, alpha=1.0, splits=None, out=None):

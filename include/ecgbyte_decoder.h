@@ -68,6 +68,26 @@ int ecgb_f32_to_bf16(const float *in_dev, void *out_dev, size_t n, void *stream)
 int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
                       int M, int N, int K, float alpha, int accumulate_f32, int batch, long long batch_a,
                       long long batch_b, long long batch_c, void *stream);
+/* K-concatenated product: C[M,N] = alpha * (A[M,K] . B[N,K]^T + A2[M,K2] . B2[N,K2]^T) in ONE launch (K, K2 multiples of 64;
+ * same accumulate modes).  A LoRA branch rides in its projection's launch: A2 = t = scale * dropout(x) lora_A^T [M, 64],
+ * B2 = lora_B [N, 64] (peft LoraLayer.forward, result = base(x) + lora_B(lora_A(dropout(x))) * scaling; ecg_byte/main.py:131-155). */
+int ecgb_gemm_nt_bf16_cat(const void *a_dev, long long lda, const void *b_dev, long long ldb, const void *a2_dev, long long lda2,
+                          const void *b2_dev, long long ldb2, int K2, void *c_dev, long long ldc, int M, int N, int K, float alpha,
+                          int accumulate_f32, void *stream);
+
+/* LoRA adapter branch (peft LoraLayer, ecg_byte/main.py:131-155), stacked adapters of a fused projection.  The stacked down-projection
+ * has n_sub 16-row sub-blocks (a_dev = [16 * n_sub, in]) split evenly over n_fields modules ("blocks": q | k | v share one x but each
+ * draws its OWN dropout mask); element (row, col) of x is kept for block f iff 16-bit field f of a counter-based hash of
+ * (seed, row * in + col) is >= p * 65536.  p = 0: no dropout.
+ * t and dt are [T, 64] (columns past 16 * n_sub zero: one K-step of ecgb_gemm_nt_bf16_cat), A^T is [in, 64].
+ *   ecgb_lora_down   t = scale / (1 - p) * (mask_f . x) A_f^T  (one pass over x);  xd_dev, if not NULL, receives the
+ *                    n_fields masked copies of x, [n_fields, T, in] (the backward's dA = dt^T . (mask . x) reads them)
+ *   ecgb_lora_dx     dx[T, in] += scale / (1 - p) * sum_f mask_f . (dt_f A_f), at_dev = A^T  (one read-modify-write of dx) */
+int ecgb_lora_down(const void *x_dev, const void *a_dev, void *t_dev, void *xd_dev, int T, int in, int n_sub, int n_fields,
+                   float scale, float p, uint64_t seed, void *stream);
+int ecgb_lora_dx(const void *dt_dev, const void *at_dev, void *dx_dev, int T, int in, int n_sub, int n_fields,
+                 float scale, float p, uint64_t seed, void *stream);
+
 /* Weight-gradient product without transposed copies: C[N,K] = alpha * A^T . B with A = [M,N] and B = [M,K]
  * row-major (dW = dY^T . X, the contraction index is the row index of both operands).  M % 64 == 0.
  * splits == 1: C is bf16.  splits > 1: the contraction is cut into `splits` slices run by separate workgroups

@@ -204,10 +204,12 @@ def test_lora_adapters_vs_oracle():
         for key, mods in names.items():
             site = layer[key]
             for b, mod in enumerate(mods):
-                grads[f"model.layers.{i}.{mod}.lora_A"] = site.A.grad[64 * b: 64 * b + 16]
-                grads[f"model.layers.{i}.{mod}.lora_B"] = site.B[b].grad[:, :16]
-                assert float(site.A.grad[64 * b + 16: 64 * b + 64].abs().max()) == 0.0      # rank padding stays inert
-                assert float(site.B[b].grad[:, 16:].abs().max()) == 0.0
+                lo, hi = site.a_rows(b)
+                off, w = site.blocks[b]
+                grads[f"model.layers.{i}.{mod}.lora_A"] = site.A.grad[lo:hi]
+                grads[f"model.layers.{i}.{mod}.lora_B"] = site.B.grad[off: off + w, lo:hi]
+            assert float(site.A.grad[16 * site.n_sub:].abs().max()) == 0.0              # the padding of the stacked layout stays inert
+            assert float((site.B.grad.float() * (1 - site.bmask.float())).abs().max()) == 0.0   # a block's rows only carry its own columns
     for k, gq in grads.items():
         want = ref_p[k].grad
         rel = (gq.float() - want).norm() / want.norm().clamp_min(1e-12)
@@ -222,6 +224,56 @@ def test_lora_adapters_vs_oracle():
     out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
     out.loss.backward()
     assert torch.isfinite(out.loss)
+
+
+def test_lora_dropout_masks_independent_per_module_and_replayed_in_backward():
+    """peft draws one dropout mask PER MODULE (q, k and v are three LoraLayers over the same input): the stacked site's three blocks
+    must see three different masks of x at the configured rate, and the backward must apply exactly the masks the forward drew
+    (checked against a torch restatement fed the masks the forward kernel stored)."""
+    from ecg_byte_amd import decoder_ops as ops
+    from ecg_byte_amd.decoder import LoraSite
+    T, K, p = 1024, 512, 0.25
+    g = torch.Generator().manual_seed(1)
+    site = LoraSite(K, [(0, 256), (256, 128), (384, 128)], r=16, alpha=32, dropout=p, device="cuda", gen=g)
+    x = torch.randn(T, K, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(512, K, device="cuda") * 0.05).to(torch.bfloat16)
+    with torch.no_grad():
+        site.B.copy_((torch.randn(512, 64, device="cuda") * 0.1).to(torch.bfloat16) * site.bmask)
+    y, saved = site.project(x, w, training=True, keep=True)
+    _, xd, t, p_used, seed = saved
+    keep = (xd != 0) | (x[None] == 0)
+    rate = 1.0 - keep.float().mean(dim=(1, 2))
+    assert all(abs(float(r) - p) < 0.01 for r in rate), rate                 # every block drops ~p of the elements
+    agree = (keep[0] == keep[1]).float().mean().item()                     # independent masks agree on (1-p)^2 + p^2 of them
+    assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 0.01, agree
+    assert torch.equal(xd, torch.where(keep, x[None].expand_as(xd), torch.zeros_like(xd)))   # masked copies are x or 0, unscaled
+    inv = 1.0 / (1.0 - int(p * 65536) / 65536)
+    A, B = site.A.data.float(), site.B.data.float()
+    t_ref = torch.cat([(xd[f].float() @ A[16 * f: 16 * f + 16].T) for f in range(3)], 1) * (2.0 * inv)
+    assert ((t[:, :48].float() - t_ref).norm() / t_ref.norm()).item() < 1e-2 and float(t[:, 48:].abs().max()) == 0.0
+    y_ref = x.float() @ w.float().T + t[:, :48].float() @ B[:, :48].T
+    assert ((y.float() - y_ref).norm() / y_ref.norm()).item() < 1e-2
+    # backward through a stand-in for the model's gradient plumbing
+    class _M:
+        _t = {}
+        def _shadow(self, key, prm): return ops.transpose(prm.data)
+        def _wgrad(self, prm, dy, xin, alpha=1.0): prm.grad = ops.gemm_tn(dy, xin, alpha=alpha)
+        def _wgrad_rows(self, prm, parts, alpha=1.0):
+            gr = torch.zeros_like(prm.data)
+            for lo, hi, dy, xin in parts: gr[lo:hi] = ops.gemm_tn(dy, xin, alpha=alpha)
+            prm.grad = gr
+    dy = torch.randn(T, 512, device="cuda").to(torch.bfloat16)
+    dx0 = torch.randn(T, K, device="cuda").to(torch.bfloat16)
+    dx = site.backward(dy, saved, _M(), dx0.clone())
+    dt = dy.float() @ B                                                   # [T, 64]
+    dB_ref = (dy.float().T @ t.float()) * site.bmask.float()
+    assert ((site.B.grad.float() - dB_ref).norm() / dB_ref.norm()).item() < 2e-2
+    dA_ref = torch.cat([dt[:, 16 * f: 16 * f + 16].T @ xd[f].float() for f in range(3)], 0) * (2.0 * inv)
+    assert ((site.A.grad[:48].float() - dA_ref).norm() / dA_ref.norm()).item() < 2e-2
+    dx_ref = dx0.float() + sum(keep[f].float() * (dt[:, 16 * f: 16 * f + 16] @ A[16 * f: 16 * f + 16]) for f in range(3)) * (2.0 * inv)
+    assert ((dx.float() - dx_ref).norm() / dx_ref.norm()).item() < 1e-2
+    y2, saved2 = site.project(x, w, training=True, keep=True)              # a new call draws new masks
+    assert not torch.equal(saved2[1], xd)
 
 
 def _load_generate():
