@@ -261,6 +261,7 @@ def main():
     ap.add_argument("--train-batch", type=int, default=32, help="samples per GPU per train step")
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--full-logits", action="store_true", help="loss head over every row, as the reference materialises it")
+    ap.add_argument("--no-lora-leg", action="store_true", help="full fine-tune leg only (profiling: one mode per kernel trace)")
     ap.add_argument("--lora", action="store_true", help="train LoRA adapters (r16, alpha 32, dropout 0.05; frozen base) as the reference's script does")
     args = ap.parse_args()
 
@@ -348,7 +349,7 @@ def main():
         del xd, ids
         torch.cuda.empty_cache()
         train = bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_train)
-        if not args.lora:   # SURVEY.md §8d asks for both: full fine-tune (BASELINE C3 wording) and LoRA r16 (what the reference's script runs)
+        if not args.lora and not args.no_lora_leg:   # SURVEY.md §8d asks for both: full fine-tune (BASELINE C3 wording) and LoRA r16 (what the reference's script runs)
             import copy
             largs = copy.copy(args)
             largs.lora, largs.no_cpu_baseline, largs.train_steps = True, True, min(args.train_steps, 3)

@@ -110,6 +110,11 @@ def lib():
         "ecgb_kv_append": [vp, ll, ll, ci, vp, ll, ci, vp, vp],
         "ecgb_gemm_tn_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, vp],
         "ecgb_gemm_nt_bf16_cat": [vp, ll, vp, ll, vp, ll, vp, ll, ci, vp, ll, ci, ci, ci, f32, ci, vp],
+        "ecgb_layernorm_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, f32, vp],
+        "ecgb_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp],
+        "ecgb_bias_act": [vp, vp, vp, sz, ci, ci, vp],
+        "ecgb_gelu_new_bwd": [vp, vp, vp, sz, vp],
+        "ecgb_colsum": [vp, vp, sz, ci, vp],
         "ecgb_lora_down": [vp, vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, vp],
         "ecgb_lora_dx": [vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, vp],
         "ecgb_attn_fwd": [vp, ll, vp, ll, vp, ll, vp, vp, ll, vp, ci, ci, ci, ci, ci, f32, vp],

@@ -127,7 +127,9 @@ __global__ __launch_bounds__(256) void lora_down_kernel(LoraArgs L)
     }
 }
 
-// One wave = 16 rows; it sweeps the columns of dx in tiles of 16.  The rank-16 product of a sub-block uses half the K of the
+// One wave = 16 rows; it sweeps the columns of dx 64 at a time: four MFMAs per sub-block whose operand rows are permuted so that
+// lane (row lm, quarter lq) ends with the 16 CONSECUTIVE columns c0 + 16 lq .. + 15 (MFMA q supplies columns 4q .. 4q + 3 of them):
+// two 16-byte loads and stores per lane instead of eight 8-byte ones.  The rank-16 product of a sub-block uses half the K of the
 // 16x16x32 MFMA (k-groups 2 and 3 of both fragments are zero).
 template <int NSUB, int NF>
 __global__ __launch_bounds__(256) void lora_dx_kernel(LoraArgs L)
@@ -142,27 +144,35 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraArgs L)
 #pragma unroll
     for (int s = 0; s < NSUB; ++s)
         dtf[s] = (lq < 2) ? *reinterpret_cast<const bf16x8 *>(L.dt + (size_t)rowc * kp + 16 * s + 8 * lq) : zero;
-    unsigned short *dxr = L.dx + (size_t)rowc * L.in + 4 * lq;
+    unsigned short *dxr = L.dx + (size_t)rowc * L.in + 16 * lq;
     const int c_lo = blockIdx.y * (L.in / gridDim.y), c_hi = c_lo + L.in / gridDim.y;
-    for (int c0 = c_lo; c0 < c_hi; c0 += 16) {
-        const us4 old = *reinterpret_cast<const us4 *>(dxr + c0);
-        float sum[4] = {0.f, 0.f, 0.f, 0.f};
-        unsigned keep[4];
-        const unsigned idx0 = (unsigned)rowc * (unsigned)L.in + (unsigned)(c0 + 4 * lq);
+    const int acol = 16 * (lm >> 2) + (lm & 3);                      // operand row lm of MFMA q stands for column c0 + acol + 4 q
+    for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
+        using us8 = __attribute__((ext_vector_type(8))) unsigned short;
+        const us8 old0 = *reinterpret_cast<const us8 *>(dxr + c0), old1 = *reinterpret_cast<const us8 *>(dxr + c0 + 8);
+        float sum[16];
+        unsigned keep[16];
+        const unsigned idx0 = (unsigned)rowc * (unsigned)L.in + (unsigned)(c0 + 16 * lq);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) keep[e] = keep_bits<NF>(L, idx0 + e);
+        for (int e = 0; e < 16; ++e) { keep[e] = keep_bits<NF>(L, idx0 + e); sum[e] = 0.f; }
 #pragma unroll
-        for (int s = 0; s < NSUB; ++s) {
-            const bf16x8 af = (lq < 2) ? *reinterpret_cast<const bf16x8 *>(L.A + (size_t)(c0 + lm) * kp + 16 * s + 8 * lq) : zero;
-            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, dtf[s], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // D'[col][row]
+        for (int s = 0; s < NSUB; ++s)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sum[e] += ((keep[e] >> (s * NF / NSUB)) & 1u) ? d[e] : 0.f;
-        }
+            for (int q = 0; q < 4; ++q) {
+                const bf16x8 af = (lq < 2) ? *reinterpret_cast<const bf16x8 *>(L.A + (size_t)(c0 + acol + 4 * q) * kp + 16 * s + 8 * lq) : zero;
+                const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, dtf[s], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);   // D'[col][row]
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[4 * q + e] += ((keep[4 * q + e] >> (s * NF / NSUB)) & 1u) ? d[e] : 0.f;
+            }
         if (row < L.T) {
-            us4 v;
+            us8 v0, v1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = f2bf(bf2f(old[e]) + sum[e] * L.scale);
-            *reinterpret_cast<us4 *>(dxr + c0) = v;
+            for (int e = 0; e < 8; ++e) {
+                v0[e] = f2bf(bf2f(old0[e]) + sum[e] * L.scale);
+                v1[e] = f2bf(bf2f(old1[e]) + sum[8 + e] * L.scale);
+            }
+            *reinterpret_cast<us8 *>(dxr + c0) = v0;
+            *reinterpret_cast<us8 *>(dxr + c0 + 8) = v1;
         }
     }
 }
@@ -224,7 +234,7 @@ extern "C" int ecgb_lora_dx(const void *dt_dev, const void *at_dev, void *dx_dev
     fill(L, T, in, scale, p, seed);
     const unsigned row_blocks = (unsigned)((T + 63) / 64);
     unsigned col_split = 1;                                          // few rows: split the columns over blockIdx.y to fill the chip
-    while (row_blocks * col_split < 1024 && (in / (int)(col_split * 2)) % 16 == 0 && col_split < 16) col_split *= 2;
+    while (row_blocks * col_split < 1024 && (in / (int)(col_split * 2)) % 64 == 0 && col_split < 16) col_split *= 2;
     const dim3 grid(row_blocks, col_split);
     ECGB_LORA_DISPATCH(lora_dx_kernel, grid);
     const hipError_t e = hipGetLastError();

@@ -57,6 +57,54 @@ def rmsnorm_bwd(x, w, rstd, dy, dw_f32, dres=None, gemma=False):
     return dx
 
 
+def layernorm_fwd(x, w, b, eps, residual=None):
+    """nn.LayerNorm.  Returns (y, mean, rstd, x_sum): x_sum = x + residual when residual is given (else x itself)."""
+    H = x.shape[-1]
+    rows = x.numel() // H
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    s = torch.empty_like(x) if residual is not None else None
+    _lib.check(_L().ecgb_layernorm_fwd(_p(_bf(x)), _p(residual), _p(_bf(w)), _p(_bf(b)), _p(y), _p(s), _p(mean), _p(rstd), rows, H, float(eps), _st()))
+    return y, mean, rstd, (s if residual is not None else x)
+
+
+def layernorm_bwd(x, w, mean, rstd, dy, dw_f32, db_f32, dres=None):
+    H = x.shape[-1]
+    dx = torch.empty_like(x)
+    _lib.check(_L().ecgb_layernorm_bwd(_p(_bf(x)), _p(_bf(w)), _p(mean), _p(rstd), _p(_bf(dy)), _p(dres), _p(dx), _p(dw_f32), _p(db_f32),
+                                       x.numel() // H, H, _st()))
+    return dx
+
+
+def bias_(u, bias):
+    """u += bias (broadcast over rows), in place."""
+    N = u.shape[-1]
+    _lib.check(_L().ecgb_bias_act(_p(_bf(u)), _p(_bf(bias)), None, u.numel() // N, N, 0, _st()))
+    return u
+
+
+def bias_gelu_new_(u, bias):
+    """u += bias in place (the pre-activation the backward needs); returns gelu_new(u)."""
+    N = u.shape[-1]
+    h = torch.empty_like(u)
+    _lib.check(_L().ecgb_bias_act(_p(_bf(u)), _p(_bf(bias)), _p(h), u.numel() // N, N, 1, _st()))
+    return h
+
+
+def gelu_new_bwd(pre, dh):
+    d = torch.empty_like(pre)
+    _lib.check(_L().ecgb_gelu_new_bwd(_p(_bf(pre)), _p(_bf(dh)), _p(d), pre.numel(), _st()))
+    return d
+
+
+def colsum(dy):
+    """fp32 column sums of a 2-D bf16 tensor (a bias gradient)."""
+    out = torch.zeros(dy.shape[-1], dtype=torch.float32, device=dy.device)
+    _lib.check(_L().ecgb_colsum(_p(_bf(dy)), _p(out), dy.numel() // dy.shape[-1], dy.shape[-1], _st()))
+    return out
+
+
 def rope_(x, cos, sin, n_heads, head_dim, row_stride, inverse=False):
     """In place on a [tokens, ...] view whose heads start at x.data_ptr(): x may be a slice of a fused qkv buffer."""
     tokens = cos.shape[0]
@@ -156,7 +204,8 @@ def gemm_tn(a, b, alpha=1.0, splits=None, out=None):
     assert b.shape[0] == M and a.stride(1) == 1 and b.stride(1) == 1
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
     if splits is None:
-        splits = 1 if tiles >= 192 else max(1, min(8, 256 // tiles, M // 64))
+        cap = 32 if min(N, K) <= 64 else 8          # a skinny output (LoRA adapter gradients) is a pass over the long operand:
+        splits = 1 if tiles >= 192 else max(1, min(cap, 256 // tiles, M // 64))   # enough workgroups to pull it at HBM speed
     if out is None:
         out = torch.empty((N, K), dtype=torch.bfloat16, device=a.device)
     assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.shape == (N, K)

@@ -88,6 +88,21 @@ int ecgb_lora_down(const void *x_dev, const void *a_dev, void *t_dev, void *xd_d
 int ecgb_lora_dx(const void *dt_dev, const void *at_dev, void *dx_dev, int T, int in, int n_sub, int n_fields,
                  float scale, float p, uint64_t seed, void *stream);
 
+/* GPT-2 block pieces (BASELINE config C1's model; transformers/src/transformers/models/gpt2/modeling_gpt2.py:565-661, pytorch_utils.py:87-113):
+ *   ecgb_layernorm_fwd   y = (x - mean) * rstd * w + b (nn.LayerNorm); residual_dev != NULL: x := x + residual first, written to sum_out_dev;
+ *                        mean_dev / rstd_dev (fp32 per row) are saved for the backward
+ *   ecgb_layernorm_bwd   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ dres], g = dy * w;  dw_dev / db_dev (fp32) += sum over rows of dy * xhat / dy
+ *   ecgb_bias_act        u += bias in place (Conv1D's bias);  gelu_new != 0: h = NewGELUActivation(u) as well (u keeps the pre-activation)
+ *   ecgb_gelu_new_bwd    dpre = dh * gelu_new'(pre)
+ *   ecgb_colsum          out (fp32) += sum over rows of dy: the gradient of a bias */
+int ecgb_layernorm_fwd(const void *x_dev, const void *residual_dev, const void *w_dev, const void *b_dev, void *y_dev, void *sum_out_dev,
+                       float *mean_dev, float *rstd_dev, size_t rows, int hidden, float eps, void *stream);
+int ecgb_layernorm_bwd(const void *x_dev, const void *w_dev, const float *mean_dev, const float *rstd_dev, const void *dy_dev,
+                       const void *dres_dev, void *dx_dev, float *dw_dev, float *db_dev, size_t rows, int hidden, void *stream);
+int ecgb_bias_act(void *u_dev, const void *bias_dev, void *h_dev, size_t rows, int n, int gelu_new, void *stream);
+int ecgb_gelu_new_bwd(const void *pre_dev, const void *dh_dev, void *dpre_dev, size_t n, void *stream);
+int ecgb_colsum(const void *dy_dev, float *out_dev, size_t rows, int n, void *stream);
+
 /* Weight-gradient product without transposed copies: C[N,K] = alpha * A^T . B with A = [M,N] and B = [M,K]
  * row-major (dW = dY^T . X, the contraction index is the row index of both operands).  M % 64 == 0.
  * splits == 1: C is bf16.  splits > 1: the contraction is cut into `splits` slices run by separate workgroups

@@ -50,3 +50,24 @@ def test_decoder_oracle_gemma_matches_vendored_transformers_fp32():
     for k, p in params.items():
         ref = torch.from_numpy(z["g:" + k])
         assert torch.allclose(p.grad, ref, atol=2e-6, rtol=1e-4), k
+
+
+def test_gpt2_oracle_matches_vendored_transformers_fp32():
+    """oracle/gpt2_ref.py (BASELINE config C1's model) against loss, logits and every gradient of the vendored GPT2LMHeadModel
+    (tests/golden/make_decoder_golden_gpt2.py): LayerNorm, learned positions, biased Conv1D projections, gelu_new, tied head."""
+    from oracle import gpt2_ref as G
+    z = np.load(os.path.join(GOLDEN, "decoder_gpt2_tiny.npz"))
+    cfg = dict(vocab_size=300, n_positions=128, n_embd=128, n_layer=2, n_head=2)
+    params = {k[2:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("w:")}
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    labels, pos = torch.from_numpy(z["labels"]), torch.from_numpy(z["position_ids"])
+    logits = G.gpt2_logits(params, cfg, ids, mask, pos)
+    assert torch.allclose(logits[:, -3:], torch.from_numpy(z["logits_fp32"]), atol=2e-5, rtol=1e-4)
+    loss = G.gpt2_loss(params, cfg, ids, mask, labels, pos)
+    assert abs(loss.item() - float(z["loss_fp32"])) < 1e-5
+    loss.backward()
+    for k, p in params.items():
+        assert torch.allclose(p.grad, torch.from_numpy(z["g:" + k]), atol=2e-6, rtol=1e-4), k
+    pb = {k: v.detach().to(torch.bfloat16) for k, v in params.items()}
+    lb = G.gpt2_loss(pb, cfg, ids, mask, labels, pos)                       # the bf16 run: loss computed on bf16 logits, no upcast
+    assert abs(lb.float().item() - float(z["loss_bf16"])) < 4e-2
