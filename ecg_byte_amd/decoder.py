@@ -238,8 +238,11 @@ class HipCausalLM(nn.Module):
         with open(os.path.join(path, "config.json")) as f:
             hf = json.load(f)
         arch = hf.get("model_type", "llama")
+        if arch == "gpt2":
+            from .gpt2 import HipGPT2LM
+            return HipGPT2LM.from_pretrained(path, device=device)
         if arch not in ("llama", "gemma"):
-            raise NotImplementedError(f"from_pretrained: model_type {arch!r}: the Llama and Gemma blocks are built (DESIGN.md §8)")
+            raise NotImplementedError(f"from_pretrained: model_type {arch!r}: the Llama, Gemma and GPT-2 blocks are built (DESIGN.md §8)")
         keys = ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "num_key_value_heads",
                 "head_dim", "rms_norm_eps", "rope_theta", "rope_scaling", "tie_word_embeddings", "pad_token_id", "initializer_range")
         kw = {k: hf[k] for k in keys if k in hf}
@@ -461,13 +464,7 @@ class HipCausalLM(nn.Module):
         key = (frozen, self.v_pad, id(self.lora))
         if self._gflat is not None and self._gflat_key == key:
             return
-        L = self.cfg.num_hidden_layers
-        groups = []
-        for i in reversed(range(L)):
-            groups.append(list(self.lora[i].parameters()) if frozen else
-                          [self.wqkv[i], self.wo[i], self.wgu[i], self.wdown[i], self.ln1[i], self.ln2[i]])
-        if not frozen:
-            groups.append([self.embed, self.norm])
+        groups = self._grad_groups(frozen)
         off, plan, ranges = 0, [], []
         for ps in groups:
             lo = off
@@ -479,6 +476,17 @@ class HipCausalLM(nn.Module):
         self._gview = {id(p): self._gflat[o: o + p.numel()].view(p.shape) for p, o in plan}
         self._granges = ranges          # [L - 1 - i] = layer i's range; [L] = embed + final norm
         self._gflat_key = key
+
+    def _grad_groups(self, frozen):
+        """Trainable parameters in the order backward finishes their gradients: one group per layer, last layer first, then the rest."""
+        L = self.cfg.num_hidden_layers
+        groups = []
+        for i in reversed(range(L)):
+            groups.append(list(self.lora[i].parameters()) if frozen else
+                          [self.wqkv[i], self.wo[i], self.wgu[i], self.wdown[i], self.ln1[i], self.ln2[i]])
+        if not frozen:
+            groups.append([self.embed, self.norm])
+        return groups
 
     def _grad_slot(self, param):
         """(view, accumulate): the parameter's slice of the flat buffer, and whether it already holds a gradient this
@@ -561,6 +569,17 @@ class HipCausalLM(nn.Module):
             x = x2
         hf, rstdf, xf = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
 
+        loss, dhf = self._loss_head(hf, labels, B, S)
+        self._saved = (saved, input_ids, mask, cos, sin, (xf, rstdf), dhf, (B, S))
+        return loss.squeeze(0)
+
+    def _loss_head(self, hf, labels, B, S):
+        """Tied lm_head + ForCausalLMLoss (loss_utils.py:24-47) over the final hidden states hf [B*S, H]: returns (loss, d loss / d hf)
+        and leaves d loss / d E of the head in self.embed_grad32 (unless the base is frozen)."""
+        c = self.cfg
+        H = c.hidden_size
+        dev = self.device
+        T = B * S
         # ---- loss head: ForCausalLMLoss shifts (loss_utils.py:39-41): row t predicts labels[t+1]
         shifted = torch.full((B, S), -100, dtype=torch.int64, device=dev)
         shifted[:, :-1] = labels[:, 1:]
@@ -592,8 +611,7 @@ class HipCausalLM(nn.Module):
             hrt = torch.zeros((H, npad), dtype=torch.bfloat16, device=dev)
             ops.transpose_strided(hr, 0, hrt, 0, n, H, H, npad, 1, 1, 0, 0, 0, 0)
             ops.gemm_nt(dlt, hrt, out=self.embed_grad32, accumulate_f32=True)   # dE += dlogits^T . h
-        self._saved = (saved, input_ids, mask, cos, sin, (xf, rstdf), dhf, (B, S))
-        return loss.squeeze(0)
+        return loss, dhf
 
     # ---- inference -----------------------------------------------------------------------------
     def _hidden_states(self, input_ids, attention_mask=None, position_ids=None, kv_out=None):
