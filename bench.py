@@ -34,17 +34,41 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def measured_traffic_bytes():
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r*/hbm_pmc.json; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for
-    16 B/lane coalesced reads).  None if no profile is committed."""
+def _latest_profile(name):
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_pmc.json")))
-    if not files:
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
+    return files[-1] if files else None
+
+
+def measured_traffic_bytes():
+    """(HBM bytes per launch, source) from the committed rocprofv3 PMC passes of this same workload (profiles/r*/hbm_pmc.json;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for 16 B/lane coalesced reads).  The counters need their own
+    rocprofv3 passes, so the figure is NOT measured by the run that prints it: `traffic_source` names the profile.  (None, None) if
+    no profile is committed."""
+    f = _latest_profile("hbm_pmc.json")
+    if not f:
+        return None, None
+    with open(f) as fh:
+        d = json.load(fh)
+    return (2.0 * d["FETCH_SIZE"]["per_launch_mean"] + d["WRITE_SIZE"]["per_launch_mean"]) * 1024.0, os.path.relpath(f, ROOT)
+
+
+def valu_roofline(kernel_ms):
+    """Secondary roofline of the encode kernel: it is bound by vector-instruction issue and LDS latency, not by HBM.
+    achieved = vector instructions per launch (SQ_INSTS_VALU of the committed counter pass, profiles/r*/sq_pmc.json) / the kernel
+    time measured by THIS run; peak = 256 CUs x 4 SIMDs x one wave64 VALU instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md,
+    wave scheduling).  None if no counter profile is committed."""
+    f = _latest_profile("sq_pmc.json")
+    if not f:
         return None
-    with open(files[-1]) as f:
-        d = json.load(f)
-    return (2.0 * d["FETCH_SIZE"]["per_launch_mean"] + d["WRITE_SIZE"]["per_launch_mean"]) * 1024.0
+    with open(f) as fh:
+        d = json.load(fh)
+    insts = d["counters"]["SQ_INSTS_VALU"]["per_launch_mean"]
+    peak = 256 * 4 * 2.4e9 / 2.0
+    ach = insts / (kernel_ms * 1e-3)
+    return {"bound": "valu_issue", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s", "frac": ach / peak,
+            "valu_insts_per_launch": insts, "valu_insts_per_record": d.get("derived", {}).get("valu_insts_per_record"),
+            "source": os.path.relpath(f, ROOT)}
 
 
 def _gen_chunk(args):
@@ -129,19 +153,17 @@ def cpu_baseline(merges, pc, L, seed, budget_s=12.0):
 MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
 
 
-def train_cpu_baseline(cfg_kw, S, threads=6):
-    """One forward+backward of the same architecture in plain PyTorch on the host CPU (the reference's
-    CPU path is HF transformers on ATen CPU kernels; torch.set_num_threads(6) is the reference's own
-    setting, ecg_byte/main.py:2).  fp32, batch 1, random weights of the published dimensions."""
+def _cpu_train_once(cfg_kw, S, threads, dtype, with_optimizer, base_params):
     import torch
     from oracle import llama_ref as R
     old = torch.get_num_threads()
     torch.set_num_threads(threads)
     try:
         cfgd = dict(cfg_kw)
-        params = R.random_params(cfgd, seed=0, dtype=torch.float32)
+        params = {k: v.detach().to(dtype).clone() for k, v in base_params.items()}
         for p in params.values():
             p.requires_grad_(True)
+        opt = torch.optim.Adam(list(params.values()), lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2) if with_optimizer else None
         g = torch.Generator().manual_seed(2)
         ids = torch.randint(1000, 100000, (1, S), generator=g)
         mask = torch.ones(1, S)
@@ -152,12 +174,173 @@ def train_cpu_baseline(cfg_kw, S, threads=6):
         t0 = time.perf_counter()
         loss = R.llama_loss(params, cfgd, ids, mask, labels, pos, inv)
         loss.backward()
-        dt = time.perf_counter() - t0
+        if opt is not None:
+            torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+            opt.step()
+        return time.perf_counter() - t0
     finally:
         torch.set_num_threads(old)
+
+
+def train_cpu_baseline(cfg_kw, S, threads=6):
+    """One train step of the same architecture in plain PyTorch on the host CPU (the reference's CPU path is HF transformers on ATen
+    CPU kernels).  `value`: fp32, batch 1, torch.set_num_threads(6) -- the reference's own setting, ecg_byte/main.py:2 -- forward +
+    backward.  `variants`: all host cores, with the clip + Adam step, and bf16 weights / activations."""
+    import torch
+    from oracle import llama_ref as R
+    base = R.random_params(dict(cfg_kw), seed=0, dtype=torch.float32)      # generated once: 1.24 G normal variates take longer than a step
+    dt = _cpu_train_once(cfg_kw, S, threads, torch.float32, False, base)
+    n_all = max(1, min(os.cpu_count() or 1, 64))
+    variants = []
+    for dtype, thr, opt in ((torch.float32, n_all, True), (torch.bfloat16, n_all, False), (torch.bfloat16, threads, False)):
+        t = _cpu_train_once(cfg_kw, S, thr, dtype, opt, base)
+        variants.append({"dtype": str(dtype).replace("torch.", ""), "threads": thr, "optimizer_step": opt, "samples_per_s": 1.0 / t, "seconds": t})
     return {"value": 1.0 / dt, "unit": "samples/s", "cores": threads, "kind": "port",
             "sample": f"1 sample (seq {S}) forward+backward, fp32, PyTorch CPU eager restatement of the decoder "
-                      f"(oracle/llama_ref.py) in {dt:.1f} s; optimizer step not included", "host_cpus": os.cpu_count()}
+                      f"(oracle/llama_ref.py) in {dt:.1f} s; optimizer step not included", "variants": variants, "host_cpus": os.cpu_count()}
+
+
+def hbm_kernel_report(dev, B, S, cfg, n_vocab, reps=10):
+    """HBM GB/s of the memory-bound kernels of the train step at its shapes (RMSNorm, RoPE, SwiGLU, CE, Adam report
+    GB/s against 8 TB/s instead of TFLOP/s).  Each kernel alone, `reps` launches between HIP events on the launch stream;
+    bytes = what the kernel must read and write once (bf16 activations, fp32 statistics / moments)."""
+    import torch
+    from ecg_byte_amd import decoder_ops as ops
+    T, H, I = B * S, cfg.hidden_size, cfg.intermediate_size
+    Hq, Hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    QKV = (Hq + 2 * Hkv) * D
+    bf = lambda *sh: torch.randn(*sh, device=dev).to(torch.bfloat16)
+    x, r, w = bf(T, H), bf(T, H), torch.ones(H, dtype=torch.bfloat16, device=dev)
+    y, rstd, xs = ops.rmsnorm_fwd(x, w, 1e-5, residual=r)
+    dwf = torch.zeros(H, dtype=torch.float32, device=dev)
+    qkv = bf(T, QKV)
+    pos = torch.arange(S, device=dev).repeat(B).float()
+    fr = pos[:, None] * torch.rand(D // 2, device=dev)[None]
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    gu, dh = bf(T, 2 * I), bf(T, I)
+    rows = 4096
+    logits = bf(rows, (n_vocab + 127) // 128 * 128)
+    labels = torch.randint(0, n_vocab, (rows,), device=dev)
+    inv, lsum = torch.ones(1, device=dev), torch.zeros(1, device=dev)
+    n_adam = 2 * I * H
+    p_, g_ = bf(n_adam), bf(n_adam)
+    m_, v_, acc = torch.zeros(n_adam, device=dev), torch.zeros(n_adam, device=dev), torch.ones(1, device=dev)
+    cases = [
+        ("rmsnorm_fwd (+ residual add)", lambda: ops.rmsnorm_fwd(x, w, 1e-5, residual=r), T * H * 2 * 4),          # read x, residual; write sum, y
+        ("rmsnorm_bwd (+ residual grad)", lambda: ops.rmsnorm_bwd(xs, w, rstd, y, dwf, dres=r), T * H * 2 * 4),   # read x, dy, dres; write dx
+        ("rope (q|k heads, in place)", lambda: ops.rope_(qkv, cos, sin, Hq + Hkv, D, QKV), T * (Hq + Hkv) * D * 2 * 2 + T * D * 4),
+        ("glu_fwd (SwiGLU)", lambda: ops.glu_fwd(gu), T * I * 2 * 3),
+        ("glu_bwd", lambda: ops.glu_bwd(gu, dh), T * I * 2 * 5),
+        ("ce_fwd_bwd (4096 rows x vocab, in place)", lambda: ops.ce_fwd_bwd_(logits, labels, inv, lsum, n_vocab), rows * logits.shape[1] * 2 * 2),
+        ("adam_step (bf16 param/grad, fp32 moments)", lambda: ops.adam_step_(p_, g_, m_, v_, acc, 1.0, 1e-4, 0.9, 0.99, 1e-8, 1e-2, 1), n_adam * (2 + 2 + 2 + 16)),
+    ]
+    out = []
+    for name, fn, nbytes in cases:
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out.append({"kernel": name, "algorithmic_bytes": nbytes, "ms": ms, "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS})
+    return out
+
+
+def bench_c1(args, dev, cpu=True):
+    """BASELINE config C1 beside the headline workload: PTB-XL 100 Hz records (12 x 1000), the 1 000-merge tokenizer, GPT-2-small,
+    batch 4.  HIP leg: quantise + encode + assemble on the device, then HipGPT2LM forward (loss only, eval mode) -- the reference's C1
+    is a FORWARD pass; CPU leg: the rust_bpe port (oracle/ecgb_oracle.c, trie rebuilt per record as the reference does) and the
+    PyTorch CPU forward of the same architecture (oracle/gpt2_ref.py) with the reference's 6 threads, with all host cores, and in bf16."""
+    import torch
+    from helpers import load_tokenizer
+    from ecg_byte_amd import synth
+    from ecg_byte_amd.data_loader import BatchAssembler
+    from ecg_byte_amd.gpt2 import GPT2Config, HipGPT2LM
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    vocab, merges, pc = load_tokenizer("c1")
+    B, L, S = 4, 1000, 1024
+    keys = list(vocab.keys())
+    base = 50257
+    n_vocab = base + len(keys) + 3
+    lut = np.zeros(max(keys) + 1, dtype=np.int32)
+    lut[keys] = base + np.arange(len(keys))
+    sig_start, sig_end, pad, bos, eos = n_vocab - 3, n_vocab - 2, n_vocab - 1, 50256, 50256
+    tk = HipTokenizer(merges)
+    asm = BatchAssembler(tk, lut, pad, bos, eos, sig_start, sig_end, S - 4, device=dev)
+    model = HipGPT2LM(GPT2Config(vocab_size=n_vocab, pad_token_id=pad), device=dev, seed=0).eval()
+    x_host = synth.synth_ecg(B, L, seed=0, start=20_000_000)
+    x = torch.from_numpy(x_host).to(dev)
+    rng = np.random.default_rng(3)
+    qs = [rng.integers(1000, 50000, size=int(rng.integers(8, 25))).tolist() for _ in range(B)]
+    ans = [rng.integers(1000, 50000, size=int(rng.integers(4, 33))).tolist() for _ in range(B)]
+
+    def step():
+        batch = asm(x, pc, qs, ans)
+        with torch.no_grad():
+            return model(input_ids=batch["tokenized_signal"], attention_mask=batch["attn_mask"],
+                         labels=batch["quantized_signal_ids_input"], position_ids=batch["position_ids"]).loss, batch
+
+    for _ in range(3):
+        loss, batch = step()
+    torch.cuda.synchronize()
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        asm(x, pc, qs, ans)
+    e1.record()
+    for _ in range(reps):
+        loss, batch = step()
+    e2.record()
+    torch.cuda.synchronize()
+    enc_ms, step_ms = e0.elapsed_time(e1) / reps, e1.elapsed_time(e2) / reps
+    out = {"workload": f"C1: 12x{L} float64 records (100 Hz x 10 s), {len(merges)} merges, GPT-2-small dims (12 layers, 768, 12 heads, vocab "
+                       f"{n_vocab}), seq {S}, batch {B}, forward (loss), random init",
+           "hip": {"quantise_encode_assemble_ms": enc_ms, "encode_plus_forward_ms": step_ms, "samples_per_s": B / (step_ms * 1e-3),
+                   "loss": float(loss.item())}}
+    if cpu:
+        from oracle import gpt2_ref as G
+        from oracle import oracle as O
+        p1, p99 = pc["percentile_1"], pc["percentile_99"]
+        t0 = time.perf_counter(); n_enc = 0
+        while time.perf_counter() - t0 < 2.0:
+            for b in range(B):
+                O.encode_text(O.symbols_to_text(O.quantize(x_host[b], p1, p99)), merges)
+            n_enc += 1
+        enc_cpu = (time.perf_counter() - t0) / n_enc
+        cfgd = dict(vocab_size=n_vocab, n_positions=1024, n_embd=768, n_layer=12, n_head=12)
+        ids, mask = batch["tokenized_signal"].cpu(), batch["attn_mask"].cpu()
+        labels, pos = batch["quantized_signal_ids_input"].cpu(), batch["position_ids"].cpu()
+        variants = []
+        n_all = max(1, min(os.cpu_count() or 1, 64))
+        old = torch.get_num_threads()
+        try:
+            for dtype, thr in ((torch.float32, 6), (torch.float32, n_all), (torch.bfloat16, n_all)):
+                torch.set_num_threads(thr)
+                params = G.random_params(cfgd, seed=0, dtype=dtype)
+                with torch.no_grad():
+                    G.gpt2_loss(params, cfgd, ids, mask, labels, pos)                     # warm-up
+                    t0 = time.perf_counter(); k = 0
+                    while time.perf_counter() - t0 < 4.0:
+                        G.gpt2_loss(params, cfgd, ids, mask, labels, pos)
+                        k += 1
+                    fwd = (time.perf_counter() - t0) / k
+                variants.append({"dtype": str(dtype).replace("torch.", ""), "threads": thr, "forward_s": fwd,
+                                 "samples_per_s": B / (enc_cpu + fwd)})
+        finally:
+            torch.set_num_threads(old)
+        out["cpu_baseline"] = {"value": variants[0]["samples_per_s"], "unit": "samples/s", "cores": 6, "kind": "port",
+                               "encode_s_per_batch_1_core": enc_cpu,
+                               "sample": f"batch of {B}: rust_bpe port (1 core, trie rebuilt per record) + GPT-2-small forward in PyTorch CPU eager "
+                                         f"(oracle/gpt2_ref.py), fp32, 6 threads (ecg_byte/main.py:2); ~4 s per variant",
+                               "variants": variants, "host_cpus": os.cpu_count()}
+        out["speedup_vs_cpu_6_threads"] = out["hip"]["samples_per_s"] / out["cpu_baseline"]["value"]
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
@@ -239,6 +422,11 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_nt_kernel_m16p<256,256> + gemm_tn_kernel_tr<256,256> (bf16 MFMA 16x16x32)",
                         "algorithmic_flops_per_step": flops, "step_ms_hip_events": ev0.elapsed_time(ev1) / args.train_steps}}
+    if rank == 0 and not args.lora:
+        del model, opt
+        model = opt = None
+        torch.cuda.empty_cache()
+        out["hbm_bound_kernels"] = hbm_kernel_report(dev, B, S, cfg, n_vocab)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baselines are an N = 1 item
         cfg_kw = dict(vocab_size=n_vocab, hidden_size=H, intermediate_size=I, num_hidden_layers=Lyr,
                       num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads,
@@ -261,6 +449,7 @@ def main():
     ap.add_argument("--train-batch", type=int, default=32, help="samples per GPU per train step")
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--full-logits", action="store_true", help="loss head over every row, as the reference materialises it")
+    ap.add_argument("--no-c1", action="store_true", help="skip the C1 object (12x1000 records + GPT-2-small forward, batch 4)")
     ap.add_argument("--no-lora-leg", action="store_true", help="full fine-tune leg only (profiling: one mode per kernel trace)")
     ap.add_argument("--lora", action="store_true", help="train LoRA adapters (r16, alpha 32, dropout 0.05; frozen base) as the reference's script does")
     args = ap.parse_args()
@@ -344,6 +533,9 @@ def main():
     else:
         tokens_total = tokens_rank
 
+    c1 = None
+    if rank == 0 and world == 1 and not args.no_c1:
+        c1 = bench_c1(args, dev, cpu=not args.no_cpu_baseline)
     train = None
     if not args.no_train:
         del xd, ids
@@ -362,6 +554,7 @@ def main():
         records_total = B * world
         alg_bytes = B * (8 * n) + 4 * tokens_rank          # per launch on one GPU
         achieved = alg_bytes / (dev_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic_bytes() if (B == 4096 and L == 5000) else (None, None)
         out = {
             "metric": "ecg_tokens_per_sec_encode", "value": tokens_total / (wall / args.steps),
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -375,12 +568,16 @@ def main():
             "tokens_per_record": tokens_total / records_total,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic_bytes() if (B == 4096 and L == 5000) else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "encode_flow_kernel<INPUT_F64> (fused quantise+encode, one launch per step)",
                          "kernel_ms": dev_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if B == 4096 and L == 5000:
+            out["roofline_valu"] = valu_roofline(dev_ms)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(merges, pc, L, seed=0)
+        if c1 is not None:
+            out["c1"] = c1
         if train is not None:
             out["train"] = train
         print(json.dumps(out), flush=True)
