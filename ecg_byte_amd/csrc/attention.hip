@@ -142,12 +142,12 @@ __device__ __forceinline__ void load_row_frags(bf16x8 (&f)[D / 16], const unsign
     }
 }
 // accumulator (lane = row index, registers = d) -> global [row][d]: 4 consecutive d per register group
-template <int D>
-__device__ __forceinline__ void store_accT(const f32x16 (&acc)[D / 32], unsigned short *g, long long ld, long long row, bool valid, int h, float mul)
+template <int NB>
+__device__ __forceinline__ void store_accT(const f32x16 (&acc)[NB], unsigned short *g, long long ld, long long row, bool valid, int h, float mul)
 {
     if (!valid) return;
 #pragma unroll
-    for (int db = 0; db < D / 32; ++db)
+    for (int db = 0; db < NB; ++db)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             using u2 = __attribute__((ext_vector_type(2))) unsigned;
@@ -164,11 +164,13 @@ template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
 {
     // two K / V^T tile buffers: the tile after the one being multiplied is written while the others still compute,
-    // one barrier per tile
-    __shared__ __attribute__((aligned(16))) unsigned char lds_k2[2][64 * D * 2];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_vt2[2][D * 128];
-    __shared__ __attribute__((aligned(16))) float lds_mask2[2][64];
-    __shared__ int lds_flag2[2];
+    // one barrier per tile.  Dynamic LDS (4 x 128 D bytes + 520: 33 KB at head_dim 64, 131 KB at 256).
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kTile = 128 * D;                           // bytes of a 64-row tile, plain or transposed
+    auto lds_k2 = [&](int i) { return smem + i * kTile; };
+    auto lds_vt2 = [&](int i) { return smem + (2 + i) * kTile; };
+    auto lds_mask2 = [&](int i) { return reinterpret_cast<float *>(smem + 4 * kTile) + 64 * i; };
+    int *lds_flag2 = reinterpret_cast<int *>(smem + 4 * kTile + 512);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, hq = blockIdx.y, g = hq / (A.Hq / A.Hkv);
     const int q0 = blockIdx.x * 128;
@@ -187,29 +189,36 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
     const float sc = A.scale * kLog2e;
     const int k_end = min(A.S, q0 + 128);
     const int wave_qmax = q0 + wave * 32 + 31;
-    static_assert(D == 64, "staging assumes 128 work items per tile");
+    constexpr int NI = D / 64;                               // staging items per thread: a tile is 16 row groups x D / 8 chunks
     const int item = threadIdx.x & 127;
     const bool first_half = threadIdx.x < 128;
     const unsigned short *src = first_half ? K + rowbase * A.ldk : V + rowbase * A.ldv;
     const long long src_ld = first_half ? A.ldk : A.ldv;
-    Stage4 st;
+    Stage4 st[NI];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) stage_load<D>(st[i], src, src_ld, k0, A.S, item + 128 * i);
+    };
     auto write_tile = [&](int buf, int k0) {
-        if (first_half) stage_write_plain<D>(lds_k2[buf], st, item); else stage_write_transposed(lds_vt2[buf], st, item);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (first_half) stage_write_plain<D>(lds_k2(buf), st[i], item + 128 * i); else stage_write_transposed(lds_vt2(buf), st[i], item + 128 * i);
+        }
         if (threadIdx.x < 64) {   // wave 0: key mask of the tile + "tile holds a padded / out-of-range key" flag
             const float mk = (k0 + (int)threadIdx.x < A.S) ? A.mask[rowbase + k0 + (int)threadIdx.x] : 0.f;
-            lds_mask2[buf][threadIdx.x] = mk;
+            lds_mask2(buf)[threadIdx.x] = mk;
             const bool any0 = __any(mk == 0.f);
             if (threadIdx.x == 0) lds_flag2[buf] = any0 ? 1 : 0;
         }
     };
-    stage_load<D>(st, src, src_ld, 0, A.S, item);
+    load_tile(0);
     write_tile(0, 0);
     __syncthreads();
     for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
         const bool more = k0 + 64 < k_end;
-        if (more) stage_load<D>(st, src, src_ld, k0 + 64, A.S, item);   // next tile in flight behind the MFMAs
-        const unsigned char *lds_k = lds_k2[it & 1], *lds_vt = lds_vt2[it & 1];
-        const float *lds_mask = lds_mask2[it & 1];
+        if (more) load_tile(k0 + 64);   // next tile in flight behind the MFMAs
+        const unsigned char *lds_k = lds_k2(it & 1), *lds_vt = lds_vt2(it & 1);
+        const float *lds_mask = lds_mask2(it & 1);
         const int lds_flag = lds_flag2[it & 1];
         if (k0 <= wave_qmax) {
         // masks only matter on tiles that touch the diagonal of this wave's rows or hold padded keys
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
     }
     const float lt = l + __shfl_xor(l, 32, 64);
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
-    store_accT<D>(accO, A.o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h, inv);
+    store_accT<D / 32>(accO, A.o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h, inv);
     if (qvalid && h == 0) A.lse[((long long)b * A.Hq + hq) * A.S + qi] = lt > 0.f ? m + log2f(lt) : INFINITY;
 }
 
@@ -288,11 +297,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_k[64 * D * 2];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_v[64 * D * 2];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_kt[D * 128];
-    __shared__ __attribute__((aligned(16))) float lds_mask[64];
-    __shared__ int lds_flag;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 x 128 D bytes + 260
+    constexpr int kTile = 128 * D;
+    unsigned char *lds_k = smem, *lds_v = smem + kTile, *lds_kt = smem + 2 * kTile;
+    float *lds_mask = reinterpret_cast<float *>(smem + 3 * kTile);
+    int &lds_flag = *reinterpret_cast<int *>(smem + 3 * kTile + 256);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, hq = blockIdx.y, g = hq / (A.Hq / A.Hkv);
     const int q0 = blockIdx.x * 128;
@@ -321,24 +330,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
     const float sc = A.scale * kLog2e;
     const int k_end = min(A.S, q0 + 128);
     const int wave_qmax = q0 + wave * 32 + 31;
-    static_assert(D == 64, "staging assumes 128 work items per tile");
+    constexpr int NI = D / 64;
     const int item = threadIdx.x & 127;
     const bool first_half = threadIdx.x < 128;
     const unsigned short *src = first_half ? K + rowbase * A.ldk : V + rowbase * A.ldv;
     const long long src_ld = first_half ? A.ldk : A.ldv;
-    Stage4 st;
-    stage_load<D>(st, src, src_ld, 0, A.S, item);
+    Stage4 st[NI];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) stage_load<D>(st[i], src, src_ld, k0, A.S, item + 128 * i);
+    };
+    load_tile(0);
     for (int k0 = 0; k0 < k_end; k0 += 64) {
         __syncthreads();
-        if (first_half) { stage_write_plain<D>(lds_k, st, item); stage_write_transposed(lds_kt, st, item); }
-        else stage_write_plain<D>(lds_v, st, item);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (first_half) { stage_write_plain<D>(lds_k, st[i], item + 128 * i); stage_write_transposed(lds_kt, st[i], item + 128 * i); }
+            else stage_write_plain<D>(lds_v, st[i], item + 128 * i);
+        }
         if (threadIdx.x < 64) {
             const float mk = (k0 + (int)threadIdx.x < A.S) ? A.mask[rowbase + k0 + (int)threadIdx.x] : 0.f;
             lds_mask[threadIdx.x] = mk;
             const bool any0 = __any(mk == 0.f);
             if (threadIdx.x == 0) lds_flag = any0 ? 1 : 0;
         }
-        if (k0 + 64 < k_end) stage_load<D>(st, src, src_ld, k0 + 64, A.S, item);
+        if (k0 + 64 < k_end) load_tile(k0 + 64);
         __syncthreads();
         if (k0 > wave_qmax) continue;
         const bool need_mask = (k0 + 63 > q0 + wave * 32) || lds_flag;
@@ -378,23 +394,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
             }
         }
     }
-    store_accT<D>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, 1.f);
+    store_accT<D / 32>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, 1.f);
 }
 
 // =====================================================================================================
 // backward, dK and dV: grid (ceil(S/128), Hkv, B); lanes = keys; loops over the query heads of the group
-template <int D>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs A)   // two waves per SIMD: at most 256 registers
+// DS > 1 (head_dim 256): the d range of the dK / dV accumulators is split over DS workgroups (blockIdx.x % DS): K, V fragments and
+// two full accumulator sets of head_dim 256 do not fit one wave's 512 registers; the S and dP products are recomputed per split.
+template <int D, int DS>
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(AttnArgs A)   // head_dim 64: two waves per SIMD (<= 256 registers)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_q[64 * D * 2];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_do[64 * D * 2];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_qt[D * 128];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_dot[D * 128];
-    __shared__ __attribute__((aligned(16))) float lds_lse[64];
-    __shared__ __attribute__((aligned(16))) float lds_delta[64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 4 x 128 D bytes + 512
+    constexpr int kTile = 128 * D;
+    unsigned char *lds_q = smem, *lds_do = smem + kTile, *lds_qt = smem + 2 * kTile, *lds_dot = smem + 3 * kTile;
+    float *lds_lse = reinterpret_cast<float *>(smem + 4 * kTile), *lds_delta = lds_lse + 64;
+    constexpr int NB = D / 32 / DS;                          // 32-wide d blocks this workgroup accumulates
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, g = blockIdx.y, G = A.Hq / A.Hkv;
-    const int kk0 = blockIdx.x * 128;
+    const int kk0 = (blockIdx.x / DS) * 128, db0 = (blockIdx.x % DS) * NB;
     const int ki = kk0 + wave * 32 + lr;
     const bool kvalid = ki < A.S;
     const long long rowbase = (long long)b * A.S;
@@ -402,14 +419,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs A)   // t
     load_row_frags<D>(kf, A.k + (long long)g * D, A.ldk, rowbase + ki, kvalid, h);
     load_row_frags<D>(vf, A.v + (long long)g * D, A.ldv, rowbase + ki, kvalid, h);
     const bool kvis = kvalid && A.mask[rowbase + (kvalid ? ki : 0)] != 0.f;
-    f32x16 accK[D / 32], accV[D / 32];
+    f32x16 accK[NB], accV[NB];
 #pragma unroll
-    for (int db = 0; db < D / 32; ++db)
+    for (int db = 0; db < NB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accK[db][r] = 0.f; accV[db][r] = 0.f; }
     const float sc = A.scale * kLog2e;
     const int wave_kmin = kk0 + wave * 32;
-    static_assert(D == 64, "staging assumes 128 work items per tile");
+    constexpr int NI = D / 64;
     const int item = threadIdx.x & 127;
     const bool first_half = threadIdx.x < 128;            // first half stages Q, second half dO
     const int t_begin = (kk0 / 64) * 64;                   // first query tile that can see this key block
@@ -422,18 +439,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs A)   // t
         return first_half ? A.q + (long long)hq * D + rowbase * A.ldq : A.d_o + (long long)hq * D + rowbase * A.ldo;
     };
     const long long src_ld = first_half ? A.ldq : A.ldo;
-    Stage4 st;
+    Stage4 st[NI];
     {
         int t0; long long stat;
         const unsigned short *src = src_of(0, t0, stat);
-        stage_load<D>(st, src, src_ld, t0, A.S, item);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) stage_load<D>(st[i], src, src_ld, t0, A.S, item + 128 * i);
     }
     for (int step = 0; step < n_steps; ++step) {
         int t0; long long stat;
         (void)src_of(step, t0, stat);
         __syncthreads();
-        if (first_half) { stage_write_plain<D>(lds_q, st, item); stage_write_transposed(lds_qt, st, item); }
-        else { stage_write_plain<D>(lds_do, st, item); stage_write_transposed(lds_dot, st, item); }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (first_half) { stage_write_plain<D>(lds_q, st[i], item + 128 * i); stage_write_transposed(lds_qt, st[i], item + 128 * i); }
+            else { stage_write_plain<D>(lds_do, st[i], item + 128 * i); stage_write_transposed(lds_dot, st[i], item + 128 * i); }
+        }
         if (threadIdx.x < 64) {
             const bool v = t0 + (int)threadIdx.x < A.S;
             lds_lse[threadIdx.x] = v ? A.lse[stat + t0 + threadIdx.x] : INFINITY;
@@ -442,7 +463,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs A)   // t
         if (step + 1 < n_steps) {
             int t1; long long stat1;
             const unsigned short *src = src_of(step + 1, t1, stat1);
-            stage_load<D>(st, src, src_ld, t1, A.S, item);   // next tile in flight behind the MFMAs
+#pragma unroll
+            for (int i = 0; i < NI; ++i) stage_load<D>(st[i], src, src_ld, t1, A.S, item + 128 * i);   // next tile in flight behind the MFMAs
         }
         __syncthreads();
         if (t0 + 63 < wave_kmin) continue;        // every query of the tile precedes every key of this wave
@@ -478,15 +500,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs A)   // t
                 const bf16x8 pf = frag_from_acc(&pr[8 * s2]);
                 const bf16x8 dsf = frag_from_acc(&ds[8 * s2]);
 #pragma unroll
-                for (int db = 0; db < D / 32; ++db) {
-                    accV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_dot, db * 32 + lr, qb, s2, h), pf, accV[db], 0, 0, 0);
-                    accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_qt, db * 32 + lr, qb, s2, h), dsf, accK[db], 0, 0, 0);
+                for (int db = 0; db < NB; ++db) {
+                    accV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_dot, (db0 + db) * 32 + lr, qb, s2, h), pf, accV[db], 0, 0, 0);
+                    accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_qt, (db0 + db) * 32 + lr, qb, s2, h), dsf, accK[db], 0, 0, 0);
                 }
             }
         }
     }
-    store_accT<D>(accK, A.dk + (long long)g * D, A.lddk, rowbase + ki, kvalid, h, 1.f);
-    store_accT<D>(accV, A.dv + (long long)g * D, A.lddv, rowbase + ki, kvalid, h, 1.f);
+    store_accT<NB>(accK, A.dk + (long long)g * D + db0 * 32, A.lddk, rowbase + ki, kvalid, h, 1.f);
+    store_accT<NB>(accV, A.dv + (long long)g * D + db0 * 32, A.lddv, rowbase + ki, kvalid, h, 1.f);
 }
 
 // =====================================================================================================
@@ -764,8 +786,8 @@ int check_args(const AttnArgs &A, int D, const char *who)
         ecgb::set_error(std::string(who) + ": bad shape");
         return ECGB_ERR_INVALID;
     }
-    if (D != 64) {
-        ecgb::set_error(std::string(who) + ": head_dim must be 64 in this build");
+    if (D != 64 && D != 128 && D != 256) {
+        ecgb::set_error(std::string(who) + ": head_dim must be 64, 128 or 256");
         return ECGB_ERR_UNSUPPORTED;
     }
     if (A.ldq % 8 || A.ldk % 8 || A.ldv % 8 || A.ldo % 8) {
@@ -796,7 +818,11 @@ extern "C" int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev
     int rc = check_args(A, head_dim, "ecgb_attn_fwd");
     if (rc) return rc;
     const dim3 grid((unsigned)((seq + 127) / 128), (unsigned)n_q_heads, (unsigned)batch);
-    hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, A);
+#define ECGB_FWD(D_) do { const int lds = 4 * 128 * D_ + 520; \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_kernel<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) break; \
+        hipLaunchKernelGGL(attn_fwd_kernel<D_>, grid, dim3(256), lds, (hipStream_t)stream, A); } while (0)
+    if (head_dim == 64) ECGB_FWD(64); else if (head_dim == 128) ECGB_FWD(128); else ECGB_FWD(256);
+#undef ECGB_FWD
     return launched("attn_fwd_kernel");
 }
 
@@ -818,8 +844,13 @@ extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev
     if (lddq % 4 || lddk % 4 || lddv % 4) { ecgb::set_error("ecgb_attn_bwd: gradient row strides must be multiples of 4"); return ECGB_ERR_UNSUPPORTED; }
     const dim3 gq((unsigned)((seq + 127) / 128), (unsigned)n_q_heads, (unsigned)batch);
     const dim3 gk((unsigned)((seq + 127) / 128), (unsigned)n_kv_heads, (unsigned)batch);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, (hipStream_t)stream, A);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gk, dim3(256), 0, (hipStream_t)stream, A);
+#define ECGB_BWD(D_, DS_) do { const int lq = 3 * 128 * D_ + 260, lk = 4 * 128 * D_ + 512; \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, lq) != hipSuccess) break; \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<D_, DS_>), hipFuncAttributeMaxDynamicSharedMemorySize, lk) != hipSuccess) break; \
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<D_>, gq, dim3(256), lq, (hipStream_t)stream, A); \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D_, DS_>), dim3(gk.x * DS_, gk.y, gk.z), dim3(256), lk, (hipStream_t)stream, A); } while (0)
+    if (head_dim == 64) ECGB_BWD(64, 1); else if (head_dim == 128) ECGB_BWD(128, 1); else ECGB_BWD(256, 4);
+#undef ECGB_BWD
     return launched("attn_bwd kernels");
 }
 

@@ -122,13 +122,14 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel(GemmArgs G)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int KT1 = G.K / BK, KT = KT1 + G.K2 / BK;
+    // (selects, not branches: LDS-DMA issued on two sides of a branch makes hipcc drain vmcnt(0) at the join)
     auto stage_a = [&](int t, unsigned char *dst) {
-        if (t < KT1) stage_tile<BM, NW>(A, G.lda, row0, G.M, t * BK, dst, wave, lane);
-        else stage_tile<BM, NW>(G.A2, G.lda2, row0, G.M, (t - KT1) * BK, dst, wave, lane);
+        const bool second = t >= KT1;
+        stage_tile<BM, NW>(second ? G.A2 : A, second ? G.lda2 : G.lda, row0, G.M, (second ? t - KT1 : t) * BK, dst, wave, lane);
     };
     auto stage_b = [&](int t, unsigned char *dst) {
-        if (t < KT1) stage_tile<BN, NW>(B, G.ldb, col0, G.N, t * BK, dst, wave, lane);
-        else stage_tile<BN, NW>(G.B2, G.ldb2, col0, G.N, (t - KT1) * BK, dst, wave, lane);
+        const bool second = t >= KT1;
+        stage_tile<BN, NW>(second ? G.B2 : B, second ? G.ldb2 : G.ldb, col0, G.N, (second ? t - KT1 : t) * BK, dst, wave, lane);
     };
     stage_a(0, lds);
     stage_b(0, lds + kABytes);
@@ -312,13 +313,14 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16(GemmArgs G)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int KT1 = G.K / BK, KT = KT1 + G.K2 / BK;
+    // (selects, not branches: LDS-DMA issued on two sides of a branch makes hipcc drain vmcnt(0) at the join)
     auto stage_a = [&](int t, unsigned char *dst) {
-        if (t < KT1) stage_tile<BM, NW>(A, G.lda, row0, G.M, t * BK, dst, wave, lane);
-        else stage_tile<BM, NW>(G.A2, G.lda2, row0, G.M, (t - KT1) * BK, dst, wave, lane);
+        const bool second = t >= KT1;
+        stage_tile<BM, NW>(second ? G.A2 : A, second ? G.lda2 : G.lda, row0, G.M, (second ? t - KT1 : t) * BK, dst, wave, lane);
     };
     auto stage_b = [&](int t, unsigned char *dst) {
-        if (t < KT1) stage_tile<BN, NW>(B, G.ldb, col0, G.N, t * BK, dst, wave, lane);
-        else stage_tile<BN, NW>(G.B2, G.ldb2, col0, G.N, (t - KT1) * BK, dst, wave, lane);
+        const bool second = t >= KT1;
+        stage_tile<BN, NW>(second ? G.B2 : B, second ? G.ldb2 : G.ldb, col0, G.N, (second ? t - KT1 : t) * BK, dst, wave, lane);
     };
     stage_a(0, lds);
     stage_b(0, lds + kABytes);
@@ -411,13 +413,14 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int KT1 = G.K / BK, KT = KT1 + G.K2 / BK;
+    // (selects, not branches: LDS-DMA issued on two sides of a branch makes hipcc drain vmcnt(0) at the join)
     auto stage_a = [&](int t, unsigned char *dst) {
-        if (t < KT1) stage_tile<BM, NW>(A, G.lda, row0, G.M, t * BK, dst, wave, lane);
-        else stage_tile<BM, NW>(G.A2, G.lda2, row0, G.M, (t - KT1) * BK, dst, wave, lane);
+        const bool second = t >= KT1;
+        stage_tile<BM, NW>(second ? G.A2 : A, second ? G.lda2 : G.lda, row0, G.M, (second ? t - KT1 : t) * BK, dst, wave, lane);
     };
     auto stage_b = [&](int t, unsigned char *dst) {
-        if (t < KT1) stage_tile<BN, NW>(B, G.ldb, col0, G.N, t * BK, dst, wave, lane);
-        else stage_tile<BN, NW>(G.B2, G.ldb2, col0, G.N, (t - KT1) * BK, dst, wave, lane);
+        const bool second = t >= KT1;
+        stage_tile<BN, NW>(second ? G.B2 : B, second ? G.ldb2 : G.ldb, col0, G.N, (second ? t - KT1 : t) * BK, dst, wave, lane);
     };
 
     // prologue: tiles 0 and 1 in flight, tile 0 complete

@@ -220,7 +220,7 @@ class HipCausalLM(nn.Module):
         self.grad_sync = None      # parallel.GradAllReduce: told as soon as a layer's gradients are final
         self._gflat = None         # flat bf16 buffer holding every trainable gradient (see _grad_layout)
         self._gflat_key = None
-        self.fused_attention = cfg.head_dim == 64   # False: materialised scores (batched GEMM + softmax kernels)
+        self.fused_attention = cfg.head_dim in ops.FUSED_HEAD_DIMS   # False: materialised scores (batched GEMM + softmax kernels)
 
     # ---- HF-style surface -------------------------------------------------------------------
     @property

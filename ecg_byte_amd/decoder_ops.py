@@ -292,6 +292,9 @@ def adam_step_(p, g, m, v, sumsq_acc, max_norm, lr, beta1, beta2, eps, weight_de
                                    int(step), _st()))
 
 
+FUSED_HEAD_DIMS = (64, 128, 256)     # head dims ecgb_attn_fwd / ecgb_attn_bwd take
+
+
 def _off(t, off):
     return C.c_void_p(t.data_ptr() + off * t.element_size())
 

@@ -154,7 +154,7 @@ int ecgb_softmax_bwd(const void *p_dev, void *dp_dev, int batch_heads, int seq, 
  * registers, MFMA for QK^T and PV.  q/k/v/o are [batch*seq] rows with the given row strides (elements);
  * query head hq starts at q + hq*head_dim, KV head g at k + g*head_dim (so slices of a fused qkv buffer work).
  * Key j is visible to query i iff j <= i and attn_mask[b, j] != 0; rows without a visible key give zeros.
- * lse_dev [batch, n_q_heads, seq] fp32 is saved for the backward.  head_dim == 64 in this build. */
+ * lse_dev [batch, n_q_heads, seq] fp32 is saved for the backward.  head_dim 64 (Llama, GPT-2), 128 or 256 (Gemma). */
 int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev, long long ldk, const void *v_dev, long long ldv,
                   const float *attn_mask_dev, void *o_dev, long long ldo, float *lse_dev, int batch, int seq,
                   int n_q_heads, int n_kv_heads, int head_dim, float scale, void *stream);

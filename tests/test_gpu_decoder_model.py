@@ -364,17 +364,20 @@ def _load_gemma():
                         num_key_value_heads=1, head_dim=128, rms_norm_eps=1e-6, rope_theta=10000.0, rope_scaling=None, pad_token_id=299,
                         model_type="gemma")
     m = HipCausalLM(cfg)
-    assert not m.fused_attention and m.gemma and m.embed_scale == float(torch.tensor(128 ** 0.5, dtype=torch.bfloat16))
+    assert m.fused_attention and m.gemma and m.embed_scale == float(torch.tensor(128 ** 0.5, dtype=torch.bfloat16))
     m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")})
     return z, m
 
 
+@pytest.mark.parametrize("fused_attention", [True, False], ids=["fused-attn", "materialised-scores"])
 @pytest.mark.parametrize("full_logits", [False, True])
-def test_gemma_loss_and_gradients_vs_vendored_transformers(full_logits):
-    """(1 + w) RMSNorm in fp32, gelu-tanh gate, sqrt(hidden) embedding scale, MQA with head_dim 128 != hidden / heads
-    (materialised-scores attention): loss within 1e-2 relative of the fp32 reference run, every gradient within 3e-2."""
+def test_gemma_loss_and_gradients_vs_vendored_transformers(full_logits, fused_attention):
+    """(1 + w) RMSNorm in fp32, gelu-tanh gate, sqrt(hidden) embedding scale, MQA with head_dim 128 != hidden / heads, through the
+    fused head_dim-128 attention kernels and through materialised scores: loss within 1e-2 relative of the fp32 reference run,
+    every gradient within 3e-2."""
     z, m = _load_gemma()
     m.full_logits = full_logits
+    m.fused_attention = fused_attention
     out = m(**_batch(z))
     assert abs(out.loss.item() - float(z["loss_fp32"])) <= 1e-2 * float(z["loss_fp32"]), (out.loss.item(), float(z["loss_fp32"]))
     out.loss.backward()
@@ -383,8 +386,8 @@ def test_gemma_loss_and_gradients_vs_vendored_transformers(full_logits):
 
 @pytest.mark.parametrize("use_cache", [True, False], ids=["kv-cache", "recompute"])
 def test_gemma_generate_greedy_vs_vendored_transformers(use_cache):
-    """Greedy generate of the Gemma block: prompt length 45 (left-padded to 64 inside the materialised attention), head_dim 128
-    decode kernel."""
+    """Greedy generate of the Gemma block: prompt length 45 (not a multiple of the 64-row tile) through the fused head_dim-128
+    attention, head_dim 128 decode kernel."""
     z, m = _load_gemma()
     sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
     m.load_state_dict({k: (v * 4.0 if "proj" in k else v) for k, v in sd.items()})   # as make_decoder_golden_gemma.py does
@@ -405,7 +408,7 @@ def test_gemma_pretrained_directory(tmp_path):
     cfg = json.load(open(tmp_path / "g" / "config.json"))
     assert cfg["model_type"] == "gemma" and cfg["head_dim"] == 128 and cfg["hidden_activation"] == "gelu_pytorch_tanh"
     m2 = HipCausalLM.from_pretrained(str(tmp_path / "g"))
-    assert m2.gemma and not m2.fused_attention
+    assert m2.gemma and m2.fused_attention
     a, b = m.state_dict(), m2.state_dict()
     assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
     out1, out2 = m(**_batch(z)).loss.item(), m2(**_batch(z)).loss.item()
