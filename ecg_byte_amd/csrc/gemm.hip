@@ -81,7 +81,7 @@ __device__ __forceinline__ void stage_tile(const unsigned short *g, long long ld
 // BM x BN output tile, WGM x WGN waves, each wave (BM/WGM) x (BN/WGN) = TM x TN MFMA tiles of 32x32.
 //   <128,128,2,2>: 4 waves, 64 KiB LDS, 2 workgroups per CU -- small grids and ragged shapes
 //   <256,256,2,4>: 8 waves, 128 KiB LDS, 1 workgroup per CU, half the L2->LDS bytes per FLOP -- the big projections
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool CAT = false>
 __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel(GemmArgs G)
 {
     constexpr int NW = WGM * WGN;
@@ -121,15 +121,25 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel(GemmArgs G)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int KT1 = G.K / BK, KT = KT1 + G.K2 / BK;
-    // (selects, not branches: LDS-DMA issued on two sides of a branch makes hipcc drain vmcnt(0) at the join)
+    const int KT1 = G.K / BK, KT = CAT ? KT1 + G.K2 / BK : KT1;
+    // CAT: the K loop continues into (A2, B2).  A template flag, not a run-time test: the plain kernel keeps the exact address
+    // arithmetic it had (the selects cost the 256x256 kernel 5 % when they sat in every launch).  Selects, not branches:
+    // LDS-DMA issued on two sides of a branch makes hipcc drain vmcnt(0) at the join.
     auto stage_a = [&](int t, unsigned char *dst) {
-        const bool second = t >= KT1;
-        stage_tile<BM, NW>(second ? G.A2 : A, second ? G.lda2 : G.lda, row0, G.M, (second ? t - KT1 : t) * BK, dst, wave, lane);
+        if constexpr (CAT) {
+            const bool second = t >= KT1;
+            stage_tile<BM, NW>(second ? G.A2 : A, second ? G.lda2 : G.lda, row0, G.M, (second ? t - KT1 : t) * BK, dst, wave, lane);
+        } else {
+            stage_tile<BM, NW>(A, G.lda, row0, G.M, t * BK, dst, wave, lane);
+        }
     };
     auto stage_b = [&](int t, unsigned char *dst) {
-        const bool second = t >= KT1;
-        stage_tile<BN, NW>(second ? G.B2 : B, second ? G.ldb2 : G.ldb, col0, G.N, (second ? t - KT1 : t) * BK, dst, wave, lane);
+        if constexpr (CAT) {
+            const bool second = t >= KT1;
+            stage_tile<BN, NW>(second ? G.B2 : B, second ? G.ldb2 : G.ldb, col0, G.N, (second ? t - KT1 : t) * BK, dst, wave, lane);
+        } else {
+            stage_tile<BN, NW>(B, G.ldb, col0, G.N, t * BK, dst, wave, lane);
+        }
     };
     stage_a(0, lds);
     stage_b(0, lds + kABytes);
@@ -276,7 +286,7 @@ __device__ __forceinline__ void store_tile_m16(const f32x4 (&acc)[TM][TN], const
 // Same structure on `v_mfma_f32_16x16x32_bf16` (one MFMA = 16x16 outputs x K 32; the chip holds a higher
 // clock on this shape than on 32x32x16, MI355X_MICROARCH.md "DVFS give-back" item 7).  Operands swapped
 // as above: D'[n][m] with m = lane & 15 on the lane and n = 4*(lane >> 4) + reg in the registers.
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool CAT = false>
 __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16(GemmArgs G)
 {
     constexpr int NW = WGM * WGN;
@@ -312,15 +322,25 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16(GemmArgs G)
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int KT1 = G.K / BK, KT = KT1 + G.K2 / BK;
-    // (selects, not branches: LDS-DMA issued on two sides of a branch makes hipcc drain vmcnt(0) at the join)
+    const int KT1 = G.K / BK, KT = CAT ? KT1 + G.K2 / BK : KT1;
+    // CAT: the K loop continues into (A2, B2).  A template flag, not a run-time test: the plain kernel keeps the exact address
+    // arithmetic it had (the selects cost the 256x256 kernel 5 % when they sat in every launch).  Selects, not branches:
+    // LDS-DMA issued on two sides of a branch makes hipcc drain vmcnt(0) at the join.
     auto stage_a = [&](int t, unsigned char *dst) {
-        const bool second = t >= KT1;
-        stage_tile<BM, NW>(second ? G.A2 : A, second ? G.lda2 : G.lda, row0, G.M, (second ? t - KT1 : t) * BK, dst, wave, lane);
+        if constexpr (CAT) {
+            const bool second = t >= KT1;
+            stage_tile<BM, NW>(second ? G.A2 : A, second ? G.lda2 : G.lda, row0, G.M, (second ? t - KT1 : t) * BK, dst, wave, lane);
+        } else {
+            stage_tile<BM, NW>(A, G.lda, row0, G.M, t * BK, dst, wave, lane);
+        }
     };
     auto stage_b = [&](int t, unsigned char *dst) {
-        const bool second = t >= KT1;
-        stage_tile<BN, NW>(second ? G.B2 : B, second ? G.ldb2 : G.ldb, col0, G.N, (second ? t - KT1 : t) * BK, dst, wave, lane);
+        if constexpr (CAT) {
+            const bool second = t >= KT1;
+            stage_tile<BN, NW>(second ? G.B2 : B, second ? G.ldb2 : G.ldb, col0, G.N, (second ? t - KT1 : t) * BK, dst, wave, lane);
+        } else {
+            stage_tile<BN, NW>(B, G.ldb, col0, G.N, t * BK, dst, wave, lane);
+        }
     };
     stage_a(0, lds);
     stage_b(0, lds + kABytes);
@@ -376,7 +396,7 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16(GemmArgs G)
 // its last read: the B region of the buffer is refilled for tile t+2 in phase 3 of tile t, the A region in phase 4
 // -- more than a whole K-tile ahead of their use.  Tile t+1 is waited for in phase 4 of tile t with the eight loads
 // of tile t+2 left in flight (vmcnt 8, never 0 inside the loop) and first read one barrier later.
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool CAT = false>
 __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
 {
     static_assert(BM == 256 && BN == 256 && WGM == 2 && WGN == 4, "phase schedule written for the 256x256 tile, 2x4 waves");
@@ -412,15 +432,25 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int KT1 = G.K / BK, KT = KT1 + G.K2 / BK;
-    // (selects, not branches: LDS-DMA issued on two sides of a branch makes hipcc drain vmcnt(0) at the join)
+    const int KT1 = G.K / BK, KT = CAT ? KT1 + G.K2 / BK : KT1;
+    // CAT: the K loop continues into (A2, B2).  A template flag, not a run-time test: the plain kernel keeps the exact address
+    // arithmetic it had (the selects cost the 256x256 kernel 5 % when they sat in every launch).  Selects, not branches:
+    // LDS-DMA issued on two sides of a branch makes hipcc drain vmcnt(0) at the join.
     auto stage_a = [&](int t, unsigned char *dst) {
-        const bool second = t >= KT1;
-        stage_tile<BM, NW>(second ? G.A2 : A, second ? G.lda2 : G.lda, row0, G.M, (second ? t - KT1 : t) * BK, dst, wave, lane);
+        if constexpr (CAT) {
+            const bool second = t >= KT1;
+            stage_tile<BM, NW>(second ? G.A2 : A, second ? G.lda2 : G.lda, row0, G.M, (second ? t - KT1 : t) * BK, dst, wave, lane);
+        } else {
+            stage_tile<BM, NW>(A, G.lda, row0, G.M, t * BK, dst, wave, lane);
+        }
     };
     auto stage_b = [&](int t, unsigned char *dst) {
-        const bool second = t >= KT1;
-        stage_tile<BN, NW>(second ? G.B2 : B, second ? G.ldb2 : G.ldb, col0, G.N, (second ? t - KT1 : t) * BK, dst, wave, lane);
+        if constexpr (CAT) {
+            const bool second = t >= KT1;
+            stage_tile<BN, NW>(second ? G.B2 : B, second ? G.ldb2 : G.ldb, col0, G.N, (second ? t - KT1 : t) * BK, dst, wave, lane);
+        } else {
+            stage_tile<BN, NW>(B, G.ldb, col0, G.N, t * BK, dst, wave, lane);
+        }
     };
 
     // prologue: tiles 0 and 1 in flight, tile 0 complete
@@ -938,28 +968,28 @@ int launch_gemm(GemmArgs &G, int batch, hipStream_t stream)
     hipError_t e;
     if (big && g_gemm_tile != 257 && g_gemm_tile != 258) {
         constexpr int lds = 2 * (256 + 256) * BK * 2;
-        auto kern = gemm_nt_kernel_m16p<256, 256, 2, 4>;
+        auto kern = G.K2 ? gemm_nt_kernel_m16p<256, 256, 2, 4, true> : gemm_nt_kernel_m16p<256, 256, 2, 4>;
         G.tiles_m = (G.M + 255) / 256; G.tiles_n = (G.N + 255) / 256;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess)
             hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, (unsigned)batch), dim3(512), lds, stream, G);
     } else if (big && g_gemm_tile == 258) {
         constexpr int lds = 2 * (256 + 256) * BK * 2;
-        auto kern = gemm_nt_kernel_m16<256, 256, 2, 4>;
+        auto kern = G.K2 ? gemm_nt_kernel_m16<256, 256, 2, 4, true> : gemm_nt_kernel_m16<256, 256, 2, 4>;
         G.tiles_m = (G.M + 255) / 256; G.tiles_n = (G.N + 255) / 256;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess)
             hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, (unsigned)batch), dim3(512), lds, stream, G);
     } else if (big) {
         constexpr int lds = 2 * (256 + 256) * BK * 2;
-        auto kern = gemm_nt_kernel<256, 256, 2, 4>;
+        auto kern = G.K2 ? gemm_nt_kernel<256, 256, 2, 4, true> : gemm_nt_kernel<256, 256, 2, 4>;
         G.tiles_m = (G.M + 255) / 256; G.tiles_n = (G.N + 255) / 256;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess)
             hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, (unsigned)batch), dim3(512), lds, stream, G);
     } else {
         constexpr int lds = 2 * (128 + 128) * BK * 2;
-        auto kern = gemm_nt_kernel<128, 128, 2, 2>;
+        auto kern = G.K2 ? gemm_nt_kernel<128, 128, 2, 2, true> : gemm_nt_kernel<128, 128, 2, 2>;
         G.tiles_m = (G.M + 127) / 128; G.tiles_n = (G.N + 127) / 128;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess)
