@@ -249,6 +249,67 @@ def hbm_kernel_report(dev, B, S, cfg, n_vocab, reps=10):
     return out
 
 
+def bench_c5(args, dev):
+    """BASELINE config C5's shapes on one GPU: Gemma-2B dims (18 layers, hidden 2048, 8 query heads / 1 KV head of 256, MLP 16 384,
+    vocab 256 000 + 256 + 3 500 + 3), seq 2048, batch 8, LoRA r16 (what the reference's script runs, ecg_byte/scripts/train_model.sh),
+    then greedy generate of 128 tokens after a 600-token prompt (ecg_byte/models/llm.py:26-37).  Random init, synthetic ids."""
+    import torch
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    B, S = 8, 2048
+    V = 256000 + 256 + 3500 + 3
+    cfg = DecoderConfig.gemma_2b(vocab_size=V, pad_token_id=V - 1)
+    m = HipCausalLM(cfg, device=dev, seed=0)
+    m.enable_lora(r=16, alpha=32, dropout=0.05)
+    opt = m.make_optimizer()
+    g = torch.Generator(device=dev).manual_seed(0)
+    ids = torch.randint(1000, 100000, (B, S), device=dev, generator=g)
+    mask = torch.ones(B, S, device=dev); mask[:, :100] = 0; ids[:, :100] = cfg.pad_token_id
+    pos = (torch.cumsum(mask, 1) - 1).clamp(min=0).long(); pos[mask == 0] = 0
+    labels = torch.full((B, S), -100, device=dev); labels[:, -24:] = ids[:, -24:]
+
+    def step():
+        opt.zero_grad()
+        out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
+        out.loss.backward()
+        opt.step_and_update_lr()
+        return out.loss
+
+    for _ in range(2):
+        loss = step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 3
+    e0.record()
+    for _ in range(n):
+        loss = step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    H, I, Lyr, D, Hq, Hkv = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads
+    per_layer = H * (Hq + 2 * Hkv) * D + Hq * D * H + 3 * H * I
+    tokens, head_rows = B * S, B * 24
+    flops = 2 * (2 * Lyr * per_layer * tokens + 2 * H * V * head_rows) + 3 * Lyr * 2 * S * Hq * D * tokens   # frozen base: forward + input gradients
+    out = {"workload": f"C5: Gemma-2B dims ({Lyr} layers, hidden {H}, {Hq}/{Hkv} heads of {D}, MLP {I}, vocab {V}), seq {S}, batch {B}, LoRA r16, "
+                       f"fused head_dim-256 attention, random init, synthetic ids",
+           "train": {"ms_per_step": ms, "samples_per_s": B / (ms * 1e-3), "tokens_per_s": tokens / (ms * 1e-3), "loss": float(loss.item()),
+                     "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "algorithmic_flops_per_step": flops},
+                     "max_memory_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}}
+    m.eval()
+    prompt = ids[:1, -600:].contiguous()
+    pm = torch.ones_like(prompt, dtype=torch.float32)
+    best = None
+    for _ in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        m.generate(input_ids=prompt, attention_mask=pm, max_new_tokens=128, pad_token_id=V - 1)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out["generate"] = {"prompt_tokens": 600, "new_tokens": 128, "batch": 1, "seconds": best, "tokens_per_s": 128 / best}
+    del m, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def bench_c1(args, dev, cpu=True):
     """BASELINE config C1 beside the headline workload: PTB-XL 100 Hz records (12 x 1000), the 1 000-merge tokenizer, GPT-2-small,
     batch 4.  HIP leg: quantise + encode + assemble on the device, then HipGPT2LM forward (loss only, eval mode) -- the reference's C1
@@ -449,6 +510,7 @@ def main():
     ap.add_argument("--train-batch", type=int, default=32, help="samples per GPU per train step")
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--full-logits", action="store_true", help="loss head over every row, as the reference materialises it")
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 object (Gemma-2B dims LoRA step + generate)")
     ap.add_argument("--no-c1", action="store_true", help="skip the C1 object (12x1000 records + GPT-2-small forward, batch 4)")
     ap.add_argument("--no-lora-leg", action="store_true", help="full fine-tune leg only (profiling: one mode per kernel trace)")
     ap.add_argument("--lora", action="store_true", help="train LoRA adapters (r16, alpha 32, dropout 0.05; frozen base) as the reference's script does")
@@ -549,6 +611,9 @@ def main():
             train["lora_r16"] = {k: lora[k] for k in ("value", "unit", "ms_per_step", "steps", "final_loss", "roofline")}
             train["lora_r16"]["workload"] = lora["config"]["workload"]
 
+    c5 = None
+    if rank == 0 and world == 1 and not args.no_c5 and not args.no_train:
+        c5 = bench_c5(args, dev)
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
         records_total = B * world
@@ -578,6 +643,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(merges, pc, L, seed=0)
         if c1 is not None:
             out["c1"] = c1
+        if c5 is not None:
+            out["c5"] = c5
         if train is not None:
             out["train"] = train
         print(json.dumps(out), flush=True)

@@ -137,7 +137,10 @@ class LoraSite(nn.Module):
         if training and self.p > 0:
             self.calls += 1
             p, seed = self.p, self.seed + 7919 * self.calls
-        t, xd = ops.lora_down(x, self.A.data, self.n_sub, self.n_fields, self.scale, p, seed, keep_masked=keep)
+        if x.shape[0] <= 8 and p == 0.0:            # a decode step: the few-row GEMM reads A once at HBM speed
+            t, xd = ops.gemm_nt(x, self.A.data, alpha=self.scale), None
+        else:
+            t, xd = ops.lora_down(x, self.A.data, self.n_sub, self.n_fields, self.scale, p, seed, keep_masked=keep)
         y = ops.gemm_nt(x, w, a2=t, b2=self.B.data)
         return y, (x, xd, t, p, seed)
 
