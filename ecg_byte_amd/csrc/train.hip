@@ -35,13 +35,12 @@ constexpr uint32_t kHashSlots = 2048;                 // per-workgroup LDS table
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 
 struct TrainState {
-    uint32_t n_cur;        // ids in the current buffer
-    uint32_t n_next;       // ids after the merge in flight
+    uint64_t n_cur;        // ids in the current buffer (64-bit: the reference's corpus is up to 6e9 symbols, tokenizer_utils.py:79-93)
+    uint64_t n_next;       // ids after the merge in flight
     uint32_t left, right;  // pair chosen for the merge in flight
     uint32_t new_id;
     uint32_t active;       // 0 once no pair is left (lib.rs:88-90) -- later merges are no-ops
     uint32_t done;         // merges performed
-    uint32_t pad;
 };
 
 struct TileInfo {
@@ -52,18 +51,23 @@ struct TileInfo {
 
 struct TrainArgs {
     TrainState *st;
-    uint32_t *table;       // V x V pair counts
+    uint64_t *table;       // V x V pair counts (64-bit: one pair can occur more than 2^32 times in a corpus that long)
     uint32_t V;
     uint32_t *buf[2];      // ping-pong id buffers
     TileInfo *tiles;       // per tile
-    uint32_t *tile_off;    // per tile: exclusive output offset; lead parity in the top bit
-    uint64_t *partial;     // kGrid arg-max partials: count << 32 | ~key
+    uint64_t *tile_off;    // per tile: exclusive output offset; lead parity in the top bit
+    uint64_t *partial;     // kGrid arg-max partials: 2 words each, count and ~key
     uint32_t *pairs_out;   // 2 x num_merges
-    uint32_t n0;           // initial length
+    uint64_t n0;           // initial length
 };
 
 // ---- LDS delta table --------------------------------------------------------------------
-__device__ __forceinline__ void delta_add(uint32_t *s_key, int *s_val, uint32_t *table, uint32_t key, int d)
+__device__ __forceinline__ void table_add(uint64_t *table, uint32_t key, int d)
+{
+    atomicAdd(reinterpret_cast<unsigned long long *>(&table[key]), (unsigned long long)(long long)d);   // two's complement: -1 adds 2^64 - 1
+}
+
+__device__ __forceinline__ void delta_add(uint32_t *s_key, int *s_val, uint64_t *table, uint32_t key, int d)
 {
     uint32_t h = (key * 2654435761u) >> 21;   // 11 bits
     for (int probe = 0; probe < 16; ++probe) {
@@ -71,16 +75,16 @@ __device__ __forceinline__ void delta_add(uint32_t *s_key, int *s_val, uint32_t 
         if (prev == kEmpty || prev == key) { atomicAdd(&s_val[h], d); return; }
         h = (h + 1) & (kHashSlots - 1);
     }
-    atomicAdd(&table[key], (uint32_t)d);      // table full around h: go to memory
+    table_add(table, key, d);                 // table full around h: go to memory
 }
 
-__device__ __forceinline__ void delta_flush(uint32_t *s_key, int *s_val, uint32_t *table)
+__device__ __forceinline__ void delta_flush(uint32_t *s_key, int *s_val, uint64_t *table)
 {
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < kHashSlots; i += kThreads) {
         const uint32_t k = s_key[i];
         const int v = s_val[i];
-        if (k != kEmpty && v != 0) atomicAdd(&table[k], (uint32_t)v);
+        if (k != kEmpty && v != 0) table_add(table, k, v);
         s_key[i] = kEmpty;
         s_val[i] = 0;
     }
@@ -94,12 +98,12 @@ __global__ __launch_bounds__(kThreads) void init_kernel(TrainArgs A, const uint8
     __shared__ int s_val[kHashSlots];
     for (uint32_t i = threadIdx.x; i < kHashSlots; i += kThreads) { s_key[i] = kEmpty; s_val[i] = 0; }
     __syncthreads();
-    const uint32_t n = A.n0;
-    const uint32_t n_tiles = (n + kTile - 1) / kTile;
+    const uint64_t n = A.n0;
+    const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint32_t base = t * kTile;
+        const uint64_t base = (uint64_t)t * kTile;
         for (uint32_t k = threadIdx.x; k < kTile; k += kThreads) {
-            const uint32_t i = base + k;
+            const uint64_t i = base + k;
             if (i < n) {
                 const uint32_t a = text[i];
                 A.buf[0][i] = a;                                    // lib.rs:72
@@ -115,53 +119,64 @@ __global__ __launch_bounds__(kThreads) void init_kernel(TrainArgs A, const uint8
 }
 
 // ---- 1. arg-max ------------------------------------------------------------------------------
-// key order: larger count first, then smaller (left,right): pack count<<32 | ~index and take max.
+// order: larger count first, then smaller (left, right) = larger ~index.  A zero count never wins.
+__device__ __forceinline__ bool better(unsigned long long c, uint32_t k, unsigned long long bc, uint32_t bk)
+{
+    return c > bc || (c == bc && c != 0 && k > bk);
+}
+
 __global__ __launch_bounds__(kThreads) void argmax_partial_kernel(TrainArgs A, uint32_t merge_index)
 {
-    __shared__ unsigned long long s_best[kThreads / 64];
+    __shared__ unsigned long long s_cnt[kThreads / 64];
+    __shared__ uint32_t s_key[kThreads / 64];
     const uint32_t v_cur = 256u + merge_index;            // ids that can exist so far
     const uint64_t total = (uint64_t)v_cur * A.V;
-    unsigned long long best = 0;
+    unsigned long long best = 0;                          // (count, ~index): larger count first, then smaller index
+    uint32_t bkey = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (uint64_t)gridDim.x * kThreads) {
-        const uint32_t c = A.table[i];
-        if (c) {
-            const unsigned long long cand = ((unsigned long long)c << 32) | (uint32_t)~(uint32_t)i;
-            best = cand > best ? cand : best;
-        }
+        const unsigned long long c = A.table[i];
+        const uint32_t k = ~(uint32_t)i;
+        if (better(c, k, best, bkey)) { best = c; bkey = k; }
     }
     for (int d = 32; d > 0; d >>= 1) {
-        const unsigned long long o = __shfl_down(best, d, 64);
-        best = o > best ? o : best;
+        const unsigned long long oc = __shfl_down(best, d, 64);
+        const uint32_t ok = __shfl_down(bkey, d, 64);
+        if (better(oc, ok, best, bkey)) { best = oc; bkey = ok; }
     }
-    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+    if ((threadIdx.x & 63) == 0) { s_cnt[threadIdx.x >> 6] = best; s_key[threadIdx.x >> 6] = bkey; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kThreads / 64; ++w) best = s_best[w] > best ? s_best[w] : best;
-        A.partial[blockIdx.x] = best;
+        for (int w = 1; w < kThreads / 64; ++w) if (better(s_cnt[w], s_key[w], best, bkey)) { best = s_cnt[w]; bkey = s_key[w]; }
+        A.partial[2 * blockIdx.x] = best;
+        A.partial[2 * blockIdx.x + 1] = bkey;
     }
 }
 
 // One workgroup: commit the previous merge (length, counter), pick the pair of this one.
 __global__ __launch_bounds__(kThreads) void argmax_final_kernel(TrainArgs A, uint32_t merge_index, uint32_t n_partials)
 {
-    __shared__ unsigned long long s_best[kThreads / 64];
+    __shared__ unsigned long long s_cnt[kThreads / 64];
+    __shared__ uint32_t s_key[kThreads / 64];
     unsigned long long best = 0;
+    uint32_t bkey = 0;
     for (uint32_t i = threadIdx.x; i < n_partials; i += kThreads) {
-        const unsigned long long o = A.partial[i];
-        best = o > best ? o : best;
+        const unsigned long long oc = A.partial[2 * i];
+        const uint32_t ok = (uint32_t)A.partial[2 * i + 1];
+        if (better(oc, ok, best, bkey)) { best = oc; bkey = ok; }
     }
     for (int d = 32; d > 0; d >>= 1) {
-        const unsigned long long o = __shfl_down(best, d, 64);
-        best = o > best ? o : best;
+        const unsigned long long oc = __shfl_down(best, d, 64);
+        const uint32_t ok = __shfl_down(bkey, d, 64);
+        if (better(oc, ok, best, bkey)) { best = oc; bkey = ok; }
     }
-    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+    if ((threadIdx.x & 63) == 0) { s_cnt[threadIdx.x >> 6] = best; s_key[threadIdx.x >> 6] = bkey; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kThreads / 64; ++w) best = s_best[w] > best ? s_best[w] : best;
+        for (int w = 1; w < kThreads / 64; ++w) if (better(s_cnt[w], s_key[w], best, bkey)) { best = s_cnt[w]; bkey = s_key[w]; }
         TrainState *st = A.st;
         if (st->active && merge_index > 0) { st->n_cur = st->n_next; }   // commit merge_index - 1
-        if (st->active && (best >> 32) != 0) {
-            const uint32_t idx = ~(uint32_t)best;
+        if (st->active && best != 0) {
+            const uint32_t idx = ~bkey;
             st->left = idx / A.V;
             st->right = idx % A.V;
             st->new_id = 256u + merge_index;                                // lib.rs:97
@@ -181,7 +196,7 @@ struct Span {
     uint32_t a[kPerThread + 3];   // a[0] = id before the span, a[1..16] the span, a[17], a[18] after
 };
 
-__device__ __forceinline__ void load_span(Span &s, const uint32_t *src, uint32_t i0, uint32_t n)
+__device__ __forceinline__ void load_span(Span &s, const uint32_t *src, uint64_t i0, uint64_t n)
 {
 #pragma unroll
     for (int k = 0; k < kPerThread + 3; ++k) {
@@ -267,11 +282,12 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
     const TrainState st = *A.st;
     if (!st.active) return;
     const uint32_t *src = A.buf[src_sel];
-    const uint32_t n = st.n_cur, l = st.left, r = st.right;
+    const uint64_t n = st.n_cur;
+    const uint32_t l = st.left, r = st.right;
     const bool same = (l == r);
-    const uint32_t n_tiles = (n + kTile - 1) / kTile;
+    const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint32_t i0 = t * kTile + threadIdx.x * kPerThread;
+        const uint64_t i0 = (uint64_t)t * kTile + threadIdx.x * kPerThread;
         Span s;
         load_span(s, src, i0, n);
         uint32_t dropped = 0, tail = 0;
@@ -320,7 +336,7 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
         if (threadIdx.x == 0) {
             uint32_t total = 0;
             for (int w = 0; w < kThreads / 64; ++w) total += s_cnt[w];
-            const uint32_t in_tile = min(kTile, n - t * kTile);
+            const uint32_t in_tile = (uint32_t)min((uint64_t)kTile, n - (uint64_t)t * kTile);
             A.tiles[t].count0 = in_tile - total;
             A.tiles[t].flags = flags;
         }
@@ -334,12 +350,13 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TrainArgs A)
     __shared__ uint32_t s_cnt[1024];
     __shared__ uint32_t s_par[1024];
     __shared__ uint32_t s_wsum[16];
-    __shared__ uint32_t s_carry, s_carry_par;
+    __shared__ uint64_t s_carry;
+    __shared__ uint32_t s_carry_par;
     TrainState *st = A.st;
     if (!st->active) return;
-    const uint32_t n = st->n_cur;
+    const uint64_t n = st->n_cur;
     const bool same = st->left == st->right;
-    const uint32_t n_tiles = (n + kTile - 1) / kTile;
+    const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
     if (threadIdx.x == 0) { s_carry = 0; s_carry_par = 0; }
     __syncthreads();
     for (uint32_t base = 0; base < n_tiles; base += 1024) {
@@ -370,9 +387,9 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TrainArgs A)
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
         if (lane == 63) s_wsum[wv] = incl;
         __syncthreads();
-        uint32_t before = s_carry;
+        uint64_t before = s_carry;
         for (uint32_t w = 0; w < wv; ++w) before += s_wsum[w];
-        if (t < n_tiles) A.tile_off[t] = (before + incl - v) | ((same ? s_par[threadIdx.x] : 0u) << 31);
+        if (t < n_tiles) A.tile_off[t] = (before + incl - v) | ((uint64_t)(same ? s_par[threadIdx.x] : 0u) << 63);
         __syncthreads();
         if (threadIdx.x == 0) { uint32_t tot = 0; for (int w = 0; w < 16; ++w) tot += s_wsum[w]; s_carry += tot; }
         __syncthreads();
@@ -393,12 +410,14 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
     __syncthreads();
     const uint32_t *src = A.buf[src_sel];
     uint32_t *dst = A.buf[src_sel ^ 1u];
-    const uint32_t n = st.n_cur, l = st.left, r = st.right, X = st.new_id, V = A.V;
-    const uint32_t n_tiles = (n + kTile - 1) / kTile;
+    const uint64_t n = st.n_cur;
+    const uint32_t l = st.left, r = st.right, X = st.new_id, V = A.V;
+    const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint32_t i0 = t * kTile + threadIdx.x * kPerThread;
-        const uint32_t off_word = A.tile_off[t];
-        const uint32_t tile_par = off_word >> 31, tile_off = off_word & 0x7FFFFFFFu;
+        const uint64_t i0 = (uint64_t)t * kTile + threadIdx.x * kPerThread;
+        const uint64_t off_word = A.tile_off[t];
+        const uint32_t tile_par = (uint32_t)(off_word >> 63);
+        const uint64_t tile_off = off_word & 0x7FFFFFFFFFFFFFFFull;
         Span s;
         load_span(s, src, i0, n);
         uint32_t lead_par = 0;
@@ -414,7 +433,7 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
         site_mask |= site0;                 // bit 0 = element before the span
         site_mask |= sa << (kPerThread + 1);
         // local survivors
-        const uint32_t valid = (i0 < n) ? min((uint32_t)kPerThread, n - i0) : 0u;
+        const uint32_t valid = (i0 < n) ? (uint32_t)min((uint64_t)kPerThread, n - i0) : 0u;
         uint32_t kept = 0;
 #pragma unroll
         for (int k = 1; k <= kPerThread; ++k) kept += ((uint32_t)k <= valid && !((second_mask >> k) & 1u)) ? 1u : 0u;
@@ -423,9 +442,9 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
         if (lane == 63) s_wsum[wv] = incl;
         __syncthreads();
-        uint32_t w_off = tile_off;
+        uint64_t w_off = tile_off;
         for (uint32_t w = 0; w < wv; ++w) w_off += s_wsum[w];
-        uint32_t o = w_off + incl - kept;
+        uint64_t o = w_off + incl - kept;
         // walk the span: write survivors, emit count deltas
 #pragma unroll
         for (int k = 1; k <= kPerThread; ++k) {
@@ -449,7 +468,7 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
                     else {
                         // kn == 18 (only when element 16 is a site): element 18 starts a site iff it and
                         // element 19 match; for l == r it sits at an even run offset (16 was even, 17 odd)
-                        const uint32_t i19 = i0 + kPerThread + 2;   // a[19] = src[i0 - 1 + 19]
+                        const uint64_t i19 = i0 + kPerThread + 2;   // a[19] = src[i0 - 1 + 19]
                         const uint32_t a19 = (i19 < n) ? src[i19] : kEmpty;
                         next_site = (an == l && a19 == r);
                     }
@@ -466,18 +485,19 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
 __global__ __launch_bounds__(kThreads) void finish_kernel(TrainArgs A, uint32_t num_merges, uint32_t *ids_out,
                                                           uint64_t *n_ids_out, uint32_t *n_done_out)
 {
-    __shared__ uint32_t s_n, s_sel;
+    __shared__ uint64_t s_n;
+    __shared__ uint32_t s_sel;
     if (threadIdx.x == 0) {
         const TrainState st = *A.st;
         // n_next of the last performed merge is committed here (no later argmax_final ran)
-        const uint32_t n = (st.done > 0 && st.active) ? st.n_next : st.n_cur;
+        const uint64_t n = (st.done > 0 && st.active) ? st.n_next : st.n_cur;
         s_n = n;
         s_sel = st.done & 1u;
         if (blockIdx.x == 0) { *n_ids_out = n; *n_done_out = st.done; }
     }
     __syncthreads();
     const uint32_t *src = A.buf[s_sel];
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < s_n; i += gridDim.x * kThreads) ids_out[i] = src[i];
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < s_n; i += (uint64_t)gridDim.x * kThreads) ids_out[i] = src[i];
 }
 
 int check_hip(hipError_t e, const char *what)
@@ -495,8 +515,8 @@ extern "C" size_t ecgb_bpe_train_scratch_bytes(size_t n, uint32_t num_merges)
 {
     const size_t V = 256 + (size_t)num_merges;
     const size_t tiles = (n + kTile - 1) / kTile + 1;
-    return align256(sizeof(TrainState)) + align256(V * V * 4) + 2 * align256(n * 4 + 64) + align256(tiles * sizeof(TileInfo)) +
-           align256(tiles * 4) + align256(kGrid * 8) + 1024;
+    return align256(sizeof(TrainState)) + align256(V * V * 8) + 2 * align256(n * 4 + 64) + align256(tiles * sizeof(TileInfo)) +
+           align256(tiles * 8) + align256(kGrid * 16) + 1024;
 }
 
 extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t num_merges, uint32_t *pairs_dev,
@@ -507,8 +527,8 @@ extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t nu
         ecgb::set_error("ecgb_bpe_train_hip: NULL argument");
         return ECGB_ERR_INVALID;
     }
-    if (n >= 0x7FFFFFFFull || num_merges > 65000u) {
-        ecgb::set_error("ecgb_bpe_train_hip: text longer than 2^31-1 bytes or more than 65000 merges");
+    if (n >= (1ull << 44) || num_merges > 65000u) {      // positions are 64-bit; 2^44 tiles-of-4096 still index with 32 bits
+        ecgb::set_error("ecgb_bpe_train_hip: text longer than 2^44 bytes or more than 65000 merges");
         return ECGB_ERR_UNSUPPORTED;
     }
     if (scratch_bytes < ecgb_bpe_train_scratch_bytes(n, num_merges)) {
@@ -521,16 +541,16 @@ extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t nu
     uint8_t *p = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(scratch_dev) + 255) / 256 * 256);
     TrainArgs A;
     A.st = reinterpret_cast<TrainState *>(p); p += align256(sizeof(TrainState));
-    A.table = reinterpret_cast<uint32_t *>(p); p += align256(V * V * 4);
+    A.table = reinterpret_cast<uint64_t *>(p); p += align256(V * V * 8);
     A.buf[0] = reinterpret_cast<uint32_t *>(p); p += align256(n * 4 + 64);
     A.buf[1] = reinterpret_cast<uint32_t *>(p); p += align256(n * 4 + 64);
     A.tiles = reinterpret_cast<TileInfo *>(p); p += align256(tiles * sizeof(TileInfo));
-    A.tile_off = reinterpret_cast<uint32_t *>(p); p += align256(tiles * 4);
-    A.partial = reinterpret_cast<uint64_t *>(p); p += align256(kGrid * 8);
+    A.tile_off = reinterpret_cast<uint64_t *>(p); p += align256(tiles * 8);
+    A.partial = reinterpret_cast<uint64_t *>(p); p += align256(kGrid * 16);
     A.V = (uint32_t)V;
     A.pairs_out = pairs_dev;
-    A.n0 = (uint32_t)n;
-    int rc = check_hip(hipMemsetAsync(A.table, 0, V * V * 4, st), "hipMemsetAsync(table)");
+    A.n0 = n;
+    int rc = check_hip(hipMemsetAsync(A.table, 0, V * V * 8, st), "hipMemsetAsync(table)");
     if (rc) return rc;
     const unsigned tile_grid = (unsigned)std::max<size_t>(1, std::min<size_t>(kGrid, (n + kTile - 1) / kTile));
     hipLaunchKernelGGL(init_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, text_dev);

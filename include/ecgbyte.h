@@ -151,7 +151,9 @@ int ecgb_assemble_hip(const uint32_t *ids_dev, size_t ids_stride, const uint32_t
  * text_dev: n bytes.  pairs_dev: 2*num_merges uint32, (left,right) of merge i at [2i],[2i+1]
  * (the caller derives vocab strings / byte expansions, lib.rs:101-110).  n_done_dev: merges
  * performed.  ids_out_dev: n uint32, the final ids; n_ids_dev: their number.  Everything is
- * enqueued on `stream`; no host synchronisation. */
+ * enqueued on `stream`; no host synchronisation.  Positions and pair counts are 64-bit: the corpus
+ * may be longer than 2^32 symbols (the reference concatenates up to 200 000 records x 30 000 symbols
+ * into one string, ecg_byte/utils/tokenizer_utils.py:79-93, ecg_byte/preprocess/sample_ecg.py:15). */
 size_t ecgb_bpe_train_scratch_bytes(size_t n, uint32_t num_merges);
 int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t num_merges, uint32_t *pairs_dev,
                        uint32_t *n_done_dev, uint32_t *ids_out_dev, uint64_t *n_ids_dev,

@@ -100,3 +100,47 @@ def test_trainer_reproduces_committed_tokenizers_at_full_size(tag, L, nm):
         lens[tid] = len(seq)
     got = ids[: int(n_ids)].cpu().numpy()
     assert int(lens[got].sum()) == text.numel()
+
+
+def test_trainer_past_2_pow_31_symbols():
+    """A corpus longer than 2^31 symbols (the reference's is up to 6e9, tokenizer_utils.py:79-93): positions, tile offsets and pair
+    counts are 64-bit.  The oracle cannot run at this size; checked through properties it guarantees: the first merge is the most
+    frequent pair of the text (smallest pair among equals), every later merge's ids are 256 + i, and expanding the final ids by the
+    merges gives the text back (train_tokenizer.py:58-60's round trip) -- on the device, at full length."""
+    from ecg_byte_amd.trainer import bpe_train_device
+    n = (1 << 31) + 12345
+    g = torch.Generator(device="cuda").manual_seed(7)
+    block = torch.randint(97, 101, (1 << 20,), device="cuda", generator=g, dtype=torch.uint8)
+    block[1000:300000] = 109                                              # a long flat run inside every block: run-parity merges ('mm')
+    text = block.repeat((n >> 20) + 1)[:n].contiguous()
+    n_merges = 6
+    ids, n_ids, pairs, n_done = bpe_train_device(text, n_merges)
+    torch.cuda.synchronize()
+    assert int(n_done) == n_merges
+    m = int(n_ids)
+    assert 0 < m < n
+    pairs = pairs.cpu().tolist()
+    # most frequent adjacent pair of the text, on the device in chunks (int64 keys of 2^31 positions do not fit one bincount comfortably)
+    counts = torch.zeros(65536, dtype=torch.int64, device="cuda")
+    step = 1 << 28
+    for lo in range(0, n - 1, step):
+        hi = min(n - 1, lo + step)
+        key = text[lo:hi].to(torch.int32) * 256 + text[lo + 1: hi + 1].to(torch.int32)
+        counts += torch.bincount(key, minlength=65536)
+    best = int(torch.argmax(counts))                                      # argmax returns the first (= smallest) index among equals
+    assert pairs[0] == [best // 256, best % 256], (pairs[0], best)
+    # round trip: expand the ids merge by merge, newest first
+    cur = ids[:m].to(torch.int32)
+    for i in reversed(range(n_merges)):
+        is_new = cur == 256 + i
+        reps = 1 + is_new.to(torch.int64)
+        out = torch.repeat_interleave(cur, reps)
+        first = torch.cumsum(reps, 0) - reps                              # position of every element's first copy
+        idx = first[is_new]
+        out[idx] = pairs[i][0]
+        out[idx + 1] = pairs[i][1]
+        cur = out
+        del out, reps, first, idx, is_new
+    assert cur.numel() == n
+    for lo in range(0, n, step):
+        assert torch.equal(cur[lo: lo + step].to(torch.uint8), text[lo: lo + step]), lo
