@@ -159,3 +159,40 @@ def test_random_merges_roundtrip():
             vocab[tid] = "".join(chr(b) for b in seq)
         text = bytes(rng.integers(97, 103, size=int(rng.integers(0, 2000))).astype(np.uint8))
         assert O.decode_text(O.encode_text(text, merges), vocab) == text.decode("ascii")
+
+
+# ---- the two restatements of lib.rs against each other ---------------------------------------------------------------------
+def test_second_restatement_agrees_on_the_known_answer_vectors():
+    from oracle import lib_rs_literal as R
+    assert R.encode_text("abc", [([98, 99], 256), ([97, 98], 257)]) == [257, 99]
+    assert R.encode_text("aaaa", [([97, 97], 256)]) == [256, 256] and R.encode_text("aaa", [([97, 97], 256)]) == [256, 97]
+    assert R.encode_text("abc", [([97, 98, 99], 256), ([97, 98, 99], 257)]) == [257]
+    assert R.encode_text("abcd", [([97, 98, 99, 100], 256)]) == [256] and R.encode_text("abcx", [([97, 98, 99, 100], 256)]) == [97, 98, 99, 120]
+    assert R.merge([97, 97, 97], (97, 97), 256) == [256, 97] and R.get_stats([97, 97, 97]) == {(97, 97): 2}
+    ids, vocab, merges = R.byte_pair_encoding("aaabdaaabac", 1)
+    assert ids == [256, 97, 98, 100, 256, 97, 98, 97, 99] and merges == [([97, 97], 256)] and vocab[256] == "aa"
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_differential_fuzz_c_oracle_vs_literal_python_restatement(seed):
+    """oracle/ecgb_oracle.c (the parity anchor of the HIP encoder and trainer) against oracle/lib_rs_literal.py, a statement-by-statement
+    Python transliteration of lib.rs:10-56,127-193 written independently of it: random vocabularies (duplicates, non-prefix-closed
+    sets, bytes outside every merge), random texts, trained tokenizers.  Encode ids, trainer ids / vocab / merges must be identical."""
+    from oracle import lib_rs_literal as R
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(25):
+        alphabet = bytes(rng.choice(np.arange(97, 123), size=int(rng.integers(1, 7)), replace=False).astype(np.uint8))
+        merges = random_merges(rng, int(rng.integers(0, 60)), alphabet=alphabet, max_len=int(rng.integers(2, 14)), dup_frac=0.1)
+        extra = alphabet + (b"" if rng.random() < 0.5 else bytes([200, 10]))
+        text = bytes(rng.choice(np.frombuffer(extra, dtype=np.uint8), size=int(rng.integers(0, 600))))
+        assert list(O.encode_text(text, merges)) == R.encode_text(text, merges)
+    for _ in range(6):
+        k = int(rng.choice([1, 2, 3, 5]))
+        text = bytes(rng.integers(97, 97 + k, size=int(rng.integers(0, 400))).astype(np.uint8))
+        nm = int(rng.integers(0, 40))
+        ids, vocab, merges = R.byte_pair_encoding(text, nm)
+        for fast in (False, True):
+            got = O.byte_pair_encoding(text, nm, fast=fast)
+            assert got[0] == ids and got[1] == vocab and got[2] == merges, (seed, k, nm, fast)
+        assert list(O.encode_text(text, merges)) == R.encode_text(text, merges)
+        assert "".join(vocab[i] for i in R.encode_text(text, merges)) == text.decode()
