@@ -268,6 +268,10 @@ class HipCausalLM(nn.Module):
         for sh in shards:
             sd.update(load_file(os.path.join(path, sh)))
         model.load_state_dict(sd)
+        gen = os.path.join(path, "generation_config.json")
+        if os.path.exists(gen):                                    # what HF's generate() falls back to when the caller passes no sampling arguments
+            with open(gen) as f:
+                model.generation_config = json.load(f)
         return model
 
     def save_pretrained(self, path):
@@ -716,12 +720,39 @@ class HipCausalLM(nn.Module):
         return hf
 
     @torch.no_grad()
+    def _next_token(self, logits, do_sample, temperature, top_k, top_p, generator):
+        """GenerationMixin._sample's token choice (generation/utils.py:3131-3250): argmax, or -- do_sample -- a draw from the
+        distribution after TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper (generation/logits_process.py), in that order.
+        [B, V] fp32 logits -> [B] int64.  (A few torch calls on a [B, V] tensor per token: bookkeeping, not the hot path.)"""
+        if not do_sample:
+            return logits.argmax(-1)
+        scores = logits / temperature if temperature != 1.0 else logits.clone()
+        if top_k and 0 < top_k < scores.shape[-1]:
+            kth = torch.topk(scores, top_k, dim=-1).values[..., -1, None]
+            scores = scores.masked_fill(scores < kth, float("-inf"))
+        if top_p is not None and top_p < 1.0:
+            srt, idx = torch.sort(scores, descending=False, dim=-1)
+            remove = srt.softmax(-1).cumsum(-1) <= (1.0 - top_p)
+            remove[..., -1:] = False                                       # min_tokens_to_keep = 1
+            scores = scores.masked_fill(remove.scatter(-1, idx, remove), float("-inf"))
+        return torch.multinomial(scores.softmax(-1), 1, generator=generator).squeeze(-1)
+
     def generate(self, input_ids=None, attention_mask=None, max_new_tokens=128, pad_token_id=None, eos_token_id=None,
-                 use_cache=True, return_logits=False, use_graph=False, **_):
-        """Greedy search with the semantics of GenerationMixin.generate / _sample(do_sample=False)
-        (generation/utils.py:1877, 3131-3250) as LLM.generate calls it (ecg_byte/models/llm.py:26-37): positions from the
-        attention mask (utils.py:410-411), finished sequences keep emitting pad_token_id, stop when every sequence has
-        produced eos_token_id or after max_new_tokens.  Returns [B, S0 + generated] int64 (prompt included)."""
+                 use_cache=True, return_logits=False, use_graph=False, do_sample=None, temperature=None, top_k=None, top_p=None,
+                 generator=None, **_):
+        """GenerationMixin.generate / _sample (generation/utils.py:1877, 3131-3250) as LLM.generate calls it
+        (ecg_byte/models/llm.py:26-37): positions from the attention mask (utils.py:410-411), finished sequences keep emitting
+        pad_token_id, stop when every sequence has produced eos_token_id or after max_new_tokens.  Greedy unless do_sample: the
+        reference's call passes no sampling arguments, so HF falls back to the checkpoint's generation_config.json -- which
+        the Llama-3.2 conversion writes with do_sample=True, temperature 0.6, top_p 0.9 (convert_llama_weights_to_hf.py:402-408);
+        `from_pretrained` reads that file into `self.generation_config` and the arguments default to it.
+        Returns [B, S0 + generated] int64 (prompt included)."""
+        gc = getattr(self, "generation_config", None) or {}
+        do_sample = bool(gc.get("do_sample", False)) if do_sample is None else bool(do_sample)
+        temperature = float(gc.get("temperature", 1.0)) if temperature is None else float(temperature)
+        top_k = int(gc.get("top_k", 50)) if top_k is None else int(top_k)                    # GenerationConfig's defaults
+        top_p = float(gc.get("top_p", 1.0)) if top_p is None else float(top_p)
+        pick = lambda lg: self._next_token(lg, do_sample, temperature, top_k, top_p, generator)
         c = self.cfg
         dev = self.device
         input_ids = input_ids.to(dev).long()
@@ -745,7 +776,7 @@ class HipCausalLM(nn.Module):
         unfinished = torch.ones(B, dtype=torch.long, device=dev)
         step_logits = []
         if use_cache and use_graph and not return_logits and max_new_tokens > 2:
-            return self._generate_graph(seq, mask, caches, S0, max_new_tokens, pad_token_id, eos, positions)
+            return self._generate_graph(seq, mask, caches, S0, max_new_tokens, pad_token_id, eos, positions, pick)
         for t in range(max_new_tokens):
             n = S0 + t                                                       # tokens in `seq`
             if t == 0 or not use_cache:
@@ -758,7 +789,7 @@ class HipCausalLM(nn.Module):
             logits = ops.gemm_nt(last, self.embed.data)[:, :c.vocab_size].float()
             if return_logits:
                 step_logits.append(logits)
-            nxt = logits.argmax(-1)
+            nxt = pick(logits)
             if eos is not None:
                 nxt = nxt * unfinished + pad_token_id * (1 - unfinished)
             seq = torch.cat([seq, nxt[:, None]], 1)
@@ -769,7 +800,7 @@ class HipCausalLM(nn.Module):
                     break
         return (seq, torch.stack(step_logits, 1)) if return_logits else seq
 
-    def _generate_graph(self, seq, mask, caches, S0, max_new_tokens, pad_token_id, eos, positions):
+    def _generate_graph(self, seq, mask, caches, S0, max_new_tokens, pad_token_id, eos, positions, pick=None):
         """The greedy loop with the decode step captured once in a HIP graph and replayed per token (`use_graph=True`).
         Measured at Gemma-2B dims: 4.2 ms per token either way -- the step is bound by the GPU-side gaps between ~270
         small dependent kernels, not by the host's launch calls, so the replay buys nothing yet (fewer, fused kernels
@@ -785,7 +816,8 @@ class HipCausalLM(nn.Module):
         hf = self._hidden_states(seq, m0, positions(m0), caches)
         logits = ops.gemm_nt(hf.view(B, S0, -1)[:, -1].contiguous(), self.embed.data)[:, :c.vocab_size].float()
         unfinished = torch.ones(B, dtype=torch.long, device=dev)
-        nxt = logits.argmax(-1)
+        pick = pick or (lambda lg: lg.argmax(-1))
+        nxt = pick(logits)
         if eos is not None:
             unfinished = unfinished * (~torch.isin(nxt, eos)).long()
         out = torch.full((B, cap), pad_token_id if pad_token_id is not None else 0, dtype=torch.long, device=dev)
@@ -805,7 +837,7 @@ class HipCausalLM(nn.Module):
         def step():
             last = self._decode_step(tok, pos, mask, caches, None, n_dev)
             lg = ops.gemm_nt(last, self.embed.data)[:, :c.vocab_size].float()
-            nx = lg.argmax(-1)
+            nx = pick(lg)
             if eos is not None:
                 nx = nx * unfinished + pad_t * (1 - unfinished)
                 unfinished.mul_((nx[:, None] != eos[None, :]).all(1).long())

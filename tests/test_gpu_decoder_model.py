@@ -526,3 +526,42 @@ def test_generate_long_prompt_takes_the_split_decode_attention(monkeypatch):
             top2 = lg_n[:, t].topk(2, dim=-1).values
             assert (top2[:, 0] - top2[:, 1]).min().item() < tol  # a tie at bf16 resolution
             break
+
+
+def test_generate_sampling_follows_the_warped_distribution(tmp_path):
+    """do_sample (what HF falls back to for a checkpoint whose generation_config.json says so -- the Llama-3.2 conversion writes
+    do_sample=True, temperature 0.6, top_p 0.9): top_k = 1 is greedy; the empirical distribution of the first sampled token follows
+    softmax(logits / T) restricted by top-k / top-p; generation_config.json is read by from_pretrained and sets the defaults."""
+    import json
+    zg, m = _load_generate()
+    ids = torch.from_numpy(zg["input_ids"]).cuda()[:1]
+    mask = torch.from_numpy(zg["attention_mask"]).cuda()[:1]
+    greedy = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=6, pad_token_id=299)
+    assert torch.equal(m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=6, pad_token_id=299, do_sample=True, top_k=1), greedy)
+    _, lg = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=1, pad_token_id=299, return_logits=True)
+    logits = lg[0, 0].float()
+    T, K, P = 0.7, 12, 0.8
+    sc = logits / T
+    kth = sc.topk(K).values[-1]
+    sc = sc.masked_fill(sc < kth, float("-inf"))
+    srt, idx = sc.sort()
+    rm = srt.softmax(-1).cumsum(-1) <= 1 - P
+    rm[-1] = False
+    sc[idx[rm]] = float("-inf")
+    want = sc.softmax(-1)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n = 4000
+    rep_ids, rep_mask = ids.repeat(n // 8, 1), mask.repeat(n // 8, 1)
+    draws = torch.cat([m.generate(input_ids=rep_ids, attention_mask=rep_mask, max_new_tokens=1, pad_token_id=299, do_sample=True,
+                                  temperature=T, top_k=K, top_p=P, generator=g)[:, -1] for _ in range(8)])
+    freq = torch.bincount(draws, minlength=want.numel()).float() / draws.numel()
+    assert float(freq[want == 0].sum()) == 0.0                              # nothing outside the nucleus is ever drawn
+    assert (freq - want).abs().max().item() < 0.04
+    m.save_pretrained(str(tmp_path / "m"))
+    with open(tmp_path / "m" / "generation_config.json", "w") as f:
+        json.dump({"do_sample": True, "temperature": 0.6, "top_p": 0.9}, f)
+    from ecg_byte_amd.decoder import HipCausalLM
+    m2 = HipCausalLM.from_pretrained(str(tmp_path / "m"))
+    assert m2.generation_config["do_sample"] is True
+    a = m2.generate(input_ids=rep_ids[:64], attention_mask=rep_mask[:64], max_new_tokens=3, pad_token_id=299, generator=g)
+    assert len({tuple(r.tolist()) for r in a[:, -3:]}) > 1                  # sampled by default now: the rows differ
