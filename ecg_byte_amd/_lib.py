@@ -75,6 +75,18 @@ def lib():
     L.ecgb_bpe_train_scratch_bytes.restype = sz
     L.ecgb_bpe_train_hip.argtypes = [vp, sz, u32, vp, vp, vp, vp, vp, sz, vp]
     L.ecgb_bpe_train_hip.restype = C.c_int
+    L.ecgb_bpe_shard_create.argtypes = [sz, u32, vp, sz]
+    L.ecgb_bpe_shard_create.restype = vp
+    L.ecgb_bpe_shard_destroy.argtypes = [vp]
+    L.ecgb_bpe_shard_destroy.restype = None
+    for name in ("ecgb_bpe_shard_table", "ecgb_bpe_shard_slab"):
+        getattr(L, name).argtypes = [vp, C.POINTER(sz)]
+        getattr(L, name).restype = vp
+    for name, args in {"ecgb_bpe_shard_begin": [vp, vp, vp, vp], "ecgb_bpe_shard_count": [vp, vp, C.c_int, C.c_int, vp],
+                       "ecgb_bpe_shard_pick": [vp, u32, vp, vp], "ecgb_bpe_shard_merge": [vp, u32, vp, C.c_int, C.c_int, vp],
+                       "ecgb_bpe_shard_apply": [vp, vp], "ecgb_bpe_shard_finish": [vp, vp, vp, vp, vp, vp]}.items():
+        getattr(L, name).argtypes = args
+        getattr(L, name).restype = C.c_int
     i32 = C.c_int32
     L.ecgb_assemble_hip.argtypes = [vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32,
                                     C.c_int, u32, vp, vp, vp, vp, vp, vp]

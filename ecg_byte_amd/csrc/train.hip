@@ -49,7 +49,19 @@ struct TileInfo {
                            // bit1: whole tile is `left` (l == r merges);  bit2: parity of trailing run of `left`
 };
 
+// What a shard of a corpus split over ranks knows about its neighbours for the merge in flight (ecgb_bpe_shard_*): the id before its
+// first element, the three ids after its last one, and -- for merges of a symbol with itself -- the parity of the run of `left` that
+// ends just before it.  A single-rank run has no neighbours: everything kEmpty / 0.
+struct Halo {
+    uint32_t prev;
+    uint32_t next[3];
+    uint32_t lead_par;
+    uint32_t pad[3];
+};
+
 struct TrainArgs {
+    const Halo *halo;      // never NULL
+    long long *slab;       // sharded: count deltas go to this [6][V] slab (all-reduced, then applied by every rank); NULL: straight into the table
     TrainState *st;
     uint64_t *table;       // V x V pair counts (64-bit: one pair can occur more than 2^32 times in a corpus that long)
     uint32_t V;
@@ -67,6 +79,20 @@ __device__ __forceinline__ void table_add(uint64_t *table, uint32_t key, int d)
     atomicAdd(reinterpret_cast<unsigned long long *>(&table[key]), (unsigned long long)(long long)d);   // two's complement: -1 adds 2^64 - 1
 }
 
+// Every count delta of a merge has `left`, `right` or the new id as one of its two ids (a pair disappears only next to a site, a
+// pair appears only next to a merged id), so the deltas of one merge fit six vectors of V: rows left / right / new, columns left /
+// right / new.  slab_index is the (first-match) place of pair (a, b); slab_pair its inverse.
+struct SlabKey { uint32_t l, r, x, V; };
+__device__ __forceinline__ uint32_t slab_index(const SlabKey &K, uint32_t a, uint32_t b)
+{
+    if (a == K.l) return b;
+    if (a == K.r) return K.V + b;
+    if (a == K.x) return 2 * K.V + b;
+    if (b == K.l) return 3 * K.V + a;
+    if (b == K.r) return 4 * K.V + a;
+    return 5 * K.V + a;                      // b == K.x
+}
+
 __device__ __forceinline__ void delta_add(uint32_t *s_key, int *s_val, uint64_t *table, uint32_t key, int d)
 {
     uint32_t h = (key * 2654435761u) >> 21;   // 11 bits
@@ -75,16 +101,32 @@ __device__ __forceinline__ void delta_add(uint32_t *s_key, int *s_val, uint64_t 
         if (prev == kEmpty || prev == key) { atomicAdd(&s_val[h], d); return; }
         h = (h + 1) & (kHashSlots - 1);
     }
-    table_add(table, key, d);                 // table full around h: go to memory
+    table_add(table, key, d);                 // table full around h: go to memory (sharded runs pass the slab here, see rewrite_kernel)
 }
 
-__device__ __forceinline__ void delta_flush(uint32_t *s_key, int *s_val, uint64_t *table)
+// the same with the overflow going to the slab when the run is sharded
+__device__ __forceinline__ void delta_add_s(uint32_t *s_key, int *s_val, uint64_t *table, long long *slab, const SlabKey &K, uint32_t key, int d)
+{
+    uint32_t h = (key * 2654435761u) >> 21;
+    for (int probe = 0; probe < 16; ++probe) {
+        const uint32_t prev = atomicCAS(&s_key[h], kEmpty, key);
+        if (prev == kEmpty || prev == key) { atomicAdd(&s_val[h], d); return; }
+        h = (h + 1) & (kHashSlots - 1);
+    }
+    if (slab) atomicAdd(reinterpret_cast<unsigned long long *>(&slab[slab_index(K, key / K.V, key % K.V)]), (unsigned long long)(long long)d);
+    else table_add(table, key, d);
+}
+
+__device__ __forceinline__ void delta_flush(uint32_t *s_key, int *s_val, uint64_t *table, long long *slab = nullptr, SlabKey K = SlabKey{0, 0, 0, 0})
 {
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < kHashSlots; i += kThreads) {
         const uint32_t k = s_key[i];
         const int v = s_val[i];
-        if (k != kEmpty && v != 0) table_add(table, k, v);
+        if (k != kEmpty && v != 0) {
+            if (slab) atomicAdd(reinterpret_cast<unsigned long long *>(&slab[slab_index(K, k / K.V, k % K.V)]), (unsigned long long)(long long)v);
+            else table_add(table, k, v);
+        }
         s_key[i] = kEmpty;
         s_val[i] = 0;
     }
@@ -196,12 +238,19 @@ struct Span {
     uint32_t a[kPerThread + 3];   // a[0] = id before the span, a[1..16] the span, a[17], a[18] after
 };
 
-__device__ __forceinline__ void load_span(Span &s, const uint32_t *src, uint64_t i0, uint64_t n)
+__device__ __forceinline__ uint32_t halo_at(const Halo &h, int64_t i, uint64_t n)   // id at position i outside [0, n)
+{
+    if (i < 0) return i == -1 ? h.prev : kEmpty;
+    const uint64_t d = (uint64_t)i - n;
+    return d < 3 ? h.next[d] : kEmpty;
+}
+
+__device__ __forceinline__ void load_span(Span &s, const uint32_t *src, uint64_t i0, uint64_t n, const Halo &h)
 {
 #pragma unroll
     for (int k = 0; k < kPerThread + 3; ++k) {
         const int64_t i = (int64_t)i0 + k - 1;
-        s.a[k] = (i >= 0 && i < (int64_t)n) ? src[i] : kEmpty;   // kEmpty never equals a real id
+        s.a[k] = (i >= 0 && i < (int64_t)n) ? src[i] : halo_at(h, i, n);   // kEmpty never equals a real id
     }
 }
 
@@ -289,7 +338,7 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t i0 = (uint64_t)t * kTile + threadIdx.x * kPerThread;
         Span s;
-        load_span(s, src, i0, n);
+        load_span(s, src, i0, n, Halo{kEmpty, {kEmpty, kEmpty, kEmpty}, 0, {0, 0, 0}});   // as if the shard stood alone: tile_scan adds what the neighbours change
         uint32_t dropped = 0, tail = 0;
         if (!same) {
 #pragma unroll
@@ -345,7 +394,7 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
 }
 
 // ---- 3. scan of tile counts (one workgroup) ---------------------------------------------------
-__global__ __launch_bounds__(1024) void tile_scan_kernel(TrainArgs A)
+__global__ __launch_bounds__(1024) void tile_scan_kernel(TrainArgs A, uint32_t src_sel)
 {
     __shared__ uint32_t s_cnt[1024];
     __shared__ uint32_t s_par[1024];
@@ -357,12 +406,15 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TrainArgs A)
     const uint64_t n = st->n_cur;
     const bool same = st->left == st->right;
     const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
-    if (threadIdx.x == 0) { s_carry = 0; s_carry_par = 0; }
+    const Halo halo = *A.halo;
+    if (threadIdx.x == 0) { s_carry = 0; s_carry_par = same ? halo.lead_par : 0u; }
     __syncthreads();
     for (uint32_t base = 0; base < n_tiles; base += 1024) {
         const uint32_t t = base + threadIdx.x;
         TileInfo ti = { 0, 0 };
         if (t < n_tiles) ti = A.tiles[t];
+        // a shard whose left neighbour ends in `left` while it starts with `right`: its first id is the second half of a site there
+        if (t == 0 && !same && n > 0 && halo.prev == st->left && A.buf[src_sel][0] == st->right) ti.count0 -= 1u;
         s_cnt[threadIdx.x] = ti.count0;
         s_par[threadIdx.x] = ti.flags;
         __syncthreads();
@@ -412,6 +464,8 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
     uint32_t *dst = A.buf[src_sel ^ 1u];
     const uint64_t n = st.n_cur;
     const uint32_t l = st.left, r = st.right, X = st.new_id, V = A.V;
+    const Halo halo = *A.halo;
+    const SlabKey SK{l, r, X, V};
     const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t i0 = (uint64_t)t * kTile + threadIdx.x * kPerThread;
@@ -419,7 +473,7 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
         const uint32_t tile_par = (uint32_t)(off_word >> 63);
         const uint64_t tile_off = off_word & 0x7FFFFFFFFFFFFFFFull;
         Span s;
-        load_span(s, src, i0, n);
+        load_span(s, src, i0, n, halo);
         uint32_t lead_par = 0;
         if (l == r) lead_par = thread_lead_parity(trailing_l(s, l), tile_par, s_wave);
         uint32_t site_mask, second_mask, sa;
@@ -455,7 +509,7 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
             const bool site_next = (site_mask >> (k + 1)) & 1u;
             // old pair (a[k], a[k+1]) disappears iff a site starts at k-1, k or k+1
             if (s.a[k + 1] != kEmpty && (site_prev || is_site || site_next))
-                delta_add(s_key, s_val, A.table, s.a[k] * V + s.a[k + 1], -1);
+                delta_add_s(s_key, s_val, A.table, A.slab, SK, s.a[k] * V + s.a[k + 1], -1);
             if (!is_second) {
                 const uint32_t val = is_site ? X : s.a[k];
                 dst[o++] = val;
@@ -469,15 +523,144 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
                         // kn == 18 (only when element 16 is a site): element 18 starts a site iff it and
                         // element 19 match; for l == r it sits at an even run offset (16 was even, 17 odd)
                         const uint64_t i19 = i0 + kPerThread + 2;   // a[19] = src[i0 - 1 + 19]
-                        const uint32_t a19 = (i19 < n) ? src[i19] : kEmpty;
+                        const uint32_t a19 = (i19 < n) ? src[i19] : halo_at(halo, (int64_t)i19, n);
                         next_site = (an == l && a19 == r);
                     }
                     const uint32_t next_val = next_site ? X : an;
-                    if (is_site || next_site) delta_add(s_key, s_val, A.table, val * V + next_val, 1);
+                    if (is_site || next_site) delta_add_s(s_key, s_val, A.table, A.slab, SK, val * V + next_val, 1);
                 }
             }
         }
+        delta_flush(s_key, s_val, A.table, A.slab, SK);
+    }
+}
+
+// =================================================================================================================
+// Sharded training: the corpus -- ONE string, tokenizer_utils.py:93, so merges do cross record joins --
+// is cut into contiguous slices, one per rank.  Every rank keeps the whole V x V table (identical everywhere: the arg-max needs no
+// exchange), rewrites its own slice, and per merge exchanges (1) an 8-word summary of its slice (all-gather: the ids at its ends
+// and, for merges of a symbol with itself, how a run of that symbol leaves it) and (2) the count deltas of the merge (all-reduce of
+// the 6 V-word slab).  The host only enqueues kernels and collectives; nothing is read back inside the loop.
+constexpr int kSummaryWords = 8;     // [0] n  [1..3] first three ids  [4] last id  [5] slice is all `left`  [6] parity of its trailing run of `left`
+
+__global__ __launch_bounds__(kThreads) void shard_convert_kernel(TrainArgs A, const uint8_t *text)
+{
+    const uint64_t n = A.n0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) A.buf[0][i] = text[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        A.st->n_cur = n; A.st->n_next = n; A.st->active = 1; A.st->done = 0;
+        A.st->left = A.st->right = A.st->new_id = kEmpty;
+    }
+}
+
+// initial histogram of the slice, the pair across its right end included (the LEFT rank of a pair counts it)
+__global__ __launch_bounds__(kThreads) void shard_count_kernel(TrainArgs A)
+{
+    __shared__ uint32_t s_key[kHashSlots];
+    __shared__ int s_val[kHashSlots];
+    for (uint32_t i = threadIdx.x; i < kHashSlots; i += kThreads) { s_key[i] = kEmpty; s_val[i] = 0; }
+    __syncthreads();
+    const uint64_t n = A.n0;
+    const Halo halo = *A.halo;
+    const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t base = (uint64_t)t * kTile;
+        for (uint32_t k = threadIdx.x; k < kTile; k += kThreads) {
+            const uint64_t i = base + k;
+            if (i < n) {
+                const uint32_t b = (i + 1 < n) ? A.buf[0][i + 1] : halo.next[0];
+                if (b != kEmpty) delta_add(s_key, s_val, A.table, A.buf[0][i] * A.V + b, 1);
+            }
+        }
         delta_flush(s_key, s_val, A.table);
+    }
+}
+
+// One workgroup: the slice's summary for the merge in flight (after tile_count_kernel: the per-tile run facts are in A.tiles).
+__global__ __launch_bounds__(kThreads) void shard_summary_kernel(TrainArgs A, uint32_t src_sel, long long *summary, int with_pair)
+{
+    __shared__ long long s_last_other[kThreads / 64];
+    const TrainState st = *A.st;
+    const uint64_t n = st.n_cur;
+    const uint32_t *src = A.buf[src_sel];
+    const uint32_t l = st.left;
+    const bool same = with_pair && st.active && st.left == st.right;
+    long long all_l = 0, tail_par = 0;
+    if (same && n > 0) {
+        const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
+        const uint64_t base = (uint64_t)(n_tiles - 1) * kTile;
+        const uint32_t sz = (uint32_t)(n - base);                       // the last tile may be partial (and odd-sized)
+        long long last_other = -1;                                      // last position of the last tile that is not `left`
+        for (uint32_t k = threadIdx.x; k < sz; k += kThreads) if (src[base + k] != l) last_other = k;
+        for (int d = 32; d > 0; d >>= 1) { const long long o = __shfl_down(last_other, d, 64); last_other = o > last_other ? o : last_other; }
+        if ((threadIdx.x & 63) == 0) s_last_other[threadIdx.x >> 6] = last_other;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kThreads / 64; ++w) last_other = s_last_other[w] > last_other ? s_last_other[w] : last_other;
+            if (last_other >= 0) tail_par = (sz - 1 - last_other) & 1;
+            else {
+                tail_par = sz & 1;                                      // the whole last tile is `left`: the run reaches further back
+                all_l = 1;
+                for (long long t = (long long)n_tiles - 2; t >= 0; --t) {
+                    const uint32_t f = A.tiles[t].flags;
+                    if (f & 2u) continue;                               // a full tile of `left`: 4096 ids, parity unchanged
+                    tail_par ^= (f >> 2) & 1u;                          // parity of the run that ends this tile
+                    all_l = 0;
+                    break;
+                }
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        summary[0] = (long long)n;
+        for (int k = 0; k < 3; ++k) summary[1 + k] = (uint64_t)k < n ? (long long)src[k] : (long long)kEmpty;
+        summary[4] = n > 0 ? (long long)src[n - 1] : (long long)kEmpty;
+        summary[5] = all_l;
+        summary[6] = tail_par;
+        summary[7] = 0;
+    }
+}
+
+// One thread: this rank's neighbours from the gathered summaries.
+__global__ void shard_halo_kernel(TrainArgs A, Halo *halo, const long long *gathered, int rank, int world, int with_pair)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const TrainState st = *A.st;
+    Halo h;
+    h.prev = kEmpty;
+    h.lead_par = 0;
+    h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    uint32_t par = 0;
+    for (int q = 0; q < rank; ++q) {
+        const long long *g = gathered + (size_t)q * kSummaryWords;
+        if (g[0] == 0) continue;                                        // an empty slice: invisible
+        h.prev = (uint32_t)g[4];
+        if (g[5]) par ^= (uint32_t)(g[0] & 1);                          // a slice of nothing but `left`: the run goes on through it
+        else par = (uint32_t)g[6];
+    }
+    if (with_pair && st.active && st.left == st.right && h.prev == st.left) h.lead_par = par;
+    int got = 0;
+    for (int q = rank + 1; q < world && got < 3; ++q) {
+        const long long *g = gathered + (size_t)q * kSummaryWords;
+        for (int k = 0; k < 3 && got < 3 && k < g[0]; ++k) h.next[got++] = (uint32_t)g[1 + k];
+    }
+    for (; got < 3; ++got) h.next[got] = kEmpty;
+    *halo = h;
+}
+
+// table += the all-reduced slab of the merge, slab = 0 for the next one
+__global__ __launch_bounds__(kThreads) void slab_apply_kernel(TrainArgs A)
+{
+    const TrainState st = *A.st;
+    const uint32_t V = A.V, l = st.left, r = st.right, x = st.new_id;
+    for (uint32_t j = blockIdx.x * kThreads + threadIdx.x; j < 6 * V; j += gridDim.x * kThreads) {
+        const long long v = A.slab[j];
+        if (v == 0) continue;
+        A.slab[j] = 0;
+        const uint32_t part = j / V, o = j % V;
+        const uint32_t fixed = (part % 3 == 0) ? l : (part % 3 == 1) ? r : x;
+        const uint32_t a = part < 3 ? fixed : o, b = part < 3 ? o : fixed;
+        if (st.active && fixed != kEmpty) atomicAdd(reinterpret_cast<unsigned long long *>(&A.table[(size_t)a * V + b]), (unsigned long long)v);
     }
 }
 
@@ -509,6 +692,29 @@ int check_hip(hipError_t e, const char *what)
 
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
+// carve the state of one trainer (or one shard) out of `scratch`
+TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w)
+{
+    const size_t V = 256 + (size_t)num_merges;
+    const size_t tiles = (n + kTile - 1) / kTile + 1;
+    uint8_t *p = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(scratch_dev) + 255) / 256 * 256);
+    TrainArgs A;
+    A.st = reinterpret_cast<TrainState *>(p); p += align256(sizeof(TrainState));
+    A.table = reinterpret_cast<uint64_t *>(p); p += align256(V * V * 8);
+    A.buf[0] = reinterpret_cast<uint32_t *>(p); p += align256(n * 4 + 64);
+    A.buf[1] = reinterpret_cast<uint32_t *>(p); p += align256(n * 4 + 64);
+    A.tiles = reinterpret_cast<TileInfo *>(p); p += align256(tiles * sizeof(TileInfo));
+    A.tile_off = reinterpret_cast<uint64_t *>(p); p += align256(tiles * 8);
+    A.partial = reinterpret_cast<uint64_t *>(p); p += align256(kGrid * 16);
+    *halo_w = reinterpret_cast<Halo *>(p); p += align256(sizeof(Halo));
+    A.halo = *halo_w;
+    A.slab = reinterpret_cast<long long *>(p); p += align256(6 * V * 8);
+    A.V = (uint32_t)V;
+    A.pairs_out = reinterpret_cast<uint32_t *>(p); p += align256(2 * (size_t)num_merges * 4 + 8);   // (sharded runs keep the pairs here)
+    A.n0 = n;
+    return A;
+}
+
 }  // namespace
 
 extern "C" size_t ecgb_bpe_train_scratch_bytes(size_t n, uint32_t num_merges)
@@ -516,7 +722,7 @@ extern "C" size_t ecgb_bpe_train_scratch_bytes(size_t n, uint32_t num_merges)
     const size_t V = 256 + (size_t)num_merges;
     const size_t tiles = (n + kTile - 1) / kTile + 1;
     return align256(sizeof(TrainState)) + align256(V * V * 8) + 2 * align256(n * 4 + 64) + align256(tiles * sizeof(TileInfo)) +
-           align256(tiles * 8) + align256(kGrid * 16) + 1024;
+           align256(tiles * 8) + align256(kGrid * 16) + align256(sizeof(Halo)) + align256(6 * V * 8) + align256(2 * (size_t)num_merges * 4 + 8) + 1024;
 }
 
 extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t num_merges, uint32_t *pairs_dev,
@@ -537,20 +743,15 @@ extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t nu
     }
     hipStream_t st = (hipStream_t)stream;
     const size_t V = 256 + (size_t)num_merges;
-    const size_t tiles = (n + kTile - 1) / kTile + 1;
-    uint8_t *p = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(scratch_dev) + 255) / 256 * 256);
-    TrainArgs A;
-    A.st = reinterpret_cast<TrainState *>(p); p += align256(sizeof(TrainState));
-    A.table = reinterpret_cast<uint64_t *>(p); p += align256(V * V * 8);
-    A.buf[0] = reinterpret_cast<uint32_t *>(p); p += align256(n * 4 + 64);
-    A.buf[1] = reinterpret_cast<uint32_t *>(p); p += align256(n * 4 + 64);
-    A.tiles = reinterpret_cast<TileInfo *>(p); p += align256(tiles * sizeof(TileInfo));
-    A.tile_off = reinterpret_cast<uint64_t *>(p); p += align256(tiles * 8);
-    A.partial = reinterpret_cast<uint64_t *>(p); p += align256(kGrid * 16);
-    A.V = (uint32_t)V;
+    Halo *halo_w;
+    TrainArgs A = layout(scratch_dev, n, num_merges, &halo_w);
     A.pairs_out = pairs_dev;
-    A.n0 = n;
+    A.slab = nullptr;                                                    // one rank: count deltas go straight into the table
     int rc = check_hip(hipMemsetAsync(A.table, 0, V * V * 8, st), "hipMemsetAsync(table)");
+    if (rc) return rc;
+    rc = check_hip(hipMemsetAsync(halo_w, 0xFF, 4 * sizeof(uint32_t), st), "hipMemsetAsync(halo)");   // prev, next[3] = kEmpty: no neighbours
+    if (rc) return rc;
+    rc = check_hip(hipMemsetAsync(reinterpret_cast<uint8_t *>(halo_w) + 16, 0, sizeof(Halo) - 16, st), "hipMemsetAsync(halo)");
     if (rc) return rc;
     const unsigned tile_grid = (unsigned)std::max<size_t>(1, std::min<size_t>(kGrid, (n + kTile - 1) / kTile));
     hipLaunchKernelGGL(init_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, text_dev);
@@ -560,10 +761,112 @@ extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t nu
         hipLaunchKernelGGL(argmax_partial_kernel, dim3(ag), dim3(kThreads), 0, st, A, i);
         hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(kThreads), 0, st, A, i, ag);
         hipLaunchKernelGGL(tile_count_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, i & 1u);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, A);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, A, i & 1u);
         hipLaunchKernelGGL(rewrite_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, i & 1u);
     }
     hipLaunchKernelGGL(finish_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, num_merges, ids_out_dev, n_ids_dev,
                        n_done_dev);
     return check_hip(hipGetLastError(), "bpe train launches");
+}
+
+// ---- sharded training: host handle + step-wise entry points (include/ecgbyte.h) ---------------------------------------------------
+struct ecgb_bpe_shard {
+    TrainArgs A;
+    Halo *halo_w;
+    size_t n;
+    uint32_t num_merges;
+    unsigned tile_grid;
+};
+
+extern "C" ecgb_bpe_shard *ecgb_bpe_shard_create(size_t n_local, uint32_t num_merges, void *scratch_dev, size_t scratch_bytes)
+{
+    if (!scratch_dev || n_local >= (1ull << 44) || num_merges > 65000u || scratch_bytes < ecgb_bpe_train_scratch_bytes(n_local, num_merges)) {
+        ecgb::set_error("ecgb_bpe_shard_create: bad argument or scratch smaller than ecgb_bpe_train_scratch_bytes()");
+        return nullptr;
+    }
+    ecgb_bpe_shard *h = new ecgb_bpe_shard;
+    h->A = layout(scratch_dev, n_local, num_merges, &h->halo_w);
+    h->n = n_local;
+    h->num_merges = num_merges;
+    h->tile_grid = (unsigned)std::max<size_t>(1, std::min<size_t>(kGrid, (n_local + kTile - 1) / kTile));
+    return h;
+}
+
+extern "C" void ecgb_bpe_shard_destroy(ecgb_bpe_shard *h) { delete h; }
+
+extern "C" void *ecgb_bpe_shard_table(ecgb_bpe_shard *h, size_t *n_words)
+{
+    if (n_words) *n_words = (size_t)h->A.V * h->A.V;
+    return h->A.table;
+}
+
+extern "C" void *ecgb_bpe_shard_slab(ecgb_bpe_shard *h, size_t *n_words)
+{
+    if (n_words) *n_words = 6 * (size_t)h->A.V;
+    return h->A.slab;
+}
+
+extern "C" int ecgb_bpe_shard_begin(ecgb_bpe_shard *h, const uint8_t *text_dev, long long *summary_dev, void *stream)
+{
+    if (!h || !summary_dev || (h->n && !text_dev)) { ecgb::set_error("ecgb_bpe_shard_begin: NULL argument"); return ECGB_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t V = h->A.V;
+    int rc = check_hip(hipMemsetAsync(h->A.table, 0, V * V * 8, st), "hipMemsetAsync(table)");
+    if (rc) return rc;
+    rc = check_hip(hipMemsetAsync(h->A.slab, 0, 6 * V * 8, st), "hipMemsetAsync(slab)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(shard_convert_kernel, dim3(h->tile_grid), dim3(kThreads), 0, st, h->A, text_dev);
+    hipLaunchKernelGGL(shard_summary_kernel, dim3(1), dim3(kThreads), 0, st, h->A, 0u, summary_dev, 0);
+    return check_hip(hipGetLastError(), "bpe shard begin");
+}
+
+extern "C" int ecgb_bpe_shard_count(ecgb_bpe_shard *h, const long long *gathered_dev, int rank, int world, void *stream)
+{
+    if (!h || !gathered_dev || rank < 0 || rank >= world) { ecgb::set_error("ecgb_bpe_shard_count: bad argument"); return ECGB_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(shard_halo_kernel, dim3(1), dim3(64), 0, st, h->A, h->halo_w, gathered_dev, rank, world, 0);
+    hipLaunchKernelGGL(shard_count_kernel, dim3(h->tile_grid), dim3(kThreads), 0, st, h->A);
+    return check_hip(hipGetLastError(), "bpe shard count");
+}
+
+extern "C" int ecgb_bpe_shard_pick(ecgb_bpe_shard *h, uint32_t merge_index, long long *summary_dev, void *stream)
+{
+    if (!h || !summary_dev || merge_index >= h->num_merges) { ecgb::set_error("ecgb_bpe_shard_pick: bad argument"); return ECGB_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t live = (size_t)(256 + merge_index) * h->A.V;
+    const unsigned ag = (unsigned)std::max<size_t>(1, std::min<size_t>(kGrid, (live + kThreads * 8 - 1) / (kThreads * 8)));
+    hipLaunchKernelGGL(argmax_partial_kernel, dim3(ag), dim3(kThreads), 0, st, h->A, merge_index);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(kThreads), 0, st, h->A, merge_index, ag);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(h->tile_grid), dim3(kThreads), 0, st, h->A, merge_index & 1u);
+    hipLaunchKernelGGL(shard_summary_kernel, dim3(1), dim3(kThreads), 0, st, h->A, merge_index & 1u, summary_dev, 1);
+    return check_hip(hipGetLastError(), "bpe shard pick");
+}
+
+extern "C" int ecgb_bpe_shard_merge(ecgb_bpe_shard *h, uint32_t merge_index, const long long *gathered_dev, int rank, int world, void *stream)
+{
+    if (!h || !gathered_dev || rank < 0 || rank >= world || merge_index >= h->num_merges) { ecgb::set_error("ecgb_bpe_shard_merge: bad argument"); return ECGB_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(shard_halo_kernel, dim3(1), dim3(64), 0, st, h->A, h->halo_w, gathered_dev, rank, world, 1);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, h->A, merge_index & 1u);
+    hipLaunchKernelGGL(rewrite_kernel, dim3(h->tile_grid), dim3(kThreads), 0, st, h->A, merge_index & 1u);
+    return check_hip(hipGetLastError(), "bpe shard merge");
+}
+
+extern "C" int ecgb_bpe_shard_apply(ecgb_bpe_shard *h, void *stream)
+{
+    if (!h) { ecgb::set_error("ecgb_bpe_shard_apply: NULL handle"); return ECGB_ERR_INVALID; }
+    hipLaunchKernelGGL(slab_apply_kernel, dim3((6 * h->A.V + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, h->A);
+    return check_hip(hipGetLastError(), "bpe shard apply");
+}
+
+extern "C" int ecgb_bpe_shard_finish(ecgb_bpe_shard *h, uint32_t *pairs_dev, uint32_t *n_done_dev, uint32_t *ids_out_dev, uint64_t *n_ids_dev, void *stream)
+{
+    if (!h || !pairs_dev || !n_done_dev || !ids_out_dev || !n_ids_dev) { ecgb::set_error("ecgb_bpe_shard_finish: NULL argument"); return ECGB_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(finish_kernel, dim3(h->tile_grid), dim3(kThreads), 0, st, h->A, h->num_merges, ids_out_dev, n_ids_dev, n_done_dev);
+    int rc = check_hip(hipGetLastError(), "bpe shard finish");
+    if (rc) return rc;
+    if (h->num_merges)
+        rc = check_hip(hipMemcpyAsync(pairs_dev, h->A.pairs_out, 2 * (size_t)h->num_merges * 4, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(pairs)");
+    return rc;
 }

@@ -159,6 +159,33 @@ int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t num_merges, u
                        uint32_t *n_done_dev, uint32_t *ids_out_dev, uint64_t *n_ids_dev,
                        void *scratch_dev, size_t scratch_bytes, void *stream);
 
+/* ---- tokenizer training on a corpus sharded over ranks (one process per GPU) ---------------------------
+ * The reference trains on ONE string, the concatenation of every sampled record (tokenizer_utils.py:79-93), so pairs -- and merges --
+ * straddle record joins.  Here rank r holds a contiguous slice of that string; the result (merges, and the concatenation of the
+ * ranks' final ids) is the single-device trainer's.  Every rank keeps the whole pair table (the arg-max needs no exchange) and per
+ * merge the host enqueues:
+ *     ecgb_bpe_shard_pick    arg-max, per-tile survivor counts, this slice's 8-word summary   -> all-gather the summaries (8 x world int64)
+ *     ecgb_bpe_shard_merge   neighbours from the gathered summaries (the id before the slice, the three after it, the parity of
+ *                            a run of `left` entering it), rewrite + compaction, count deltas into the 6 x V slab
+ *                                                                                             -> all-reduce (SUM) the slab (int64)
+ *     ecgb_bpe_shard_apply   table += slab, slab = 0
+ * after ecgb_bpe_shard_begin (bytes -> ids, first summary; all-gather) and ecgb_bpe_shard_count (initial histogram; all-reduce the
+ * table once).  Nothing is read back by the host inside the loop; the collectives are the caller's (RCCL through torch.distributed
+ * in ecg_byte_amd/trainer.py).  scratch: ecgb_bpe_train_scratch_bytes(n_local, num_merges) bytes of device memory, alive until
+ * ecgb_bpe_shard_destroy.  ecgb_bpe_shard_table / _slab return the device addresses (and word counts) of the two buffers to reduce. */
+typedef struct ecgb_bpe_shard ecgb_bpe_shard;
+ecgb_bpe_shard *ecgb_bpe_shard_create(size_t n_local, uint32_t num_merges, void *scratch_dev, size_t scratch_bytes);
+void ecgb_bpe_shard_destroy(ecgb_bpe_shard *h);
+void *ecgb_bpe_shard_table(ecgb_bpe_shard *h, size_t *n_words);
+void *ecgb_bpe_shard_slab(ecgb_bpe_shard *h, size_t *n_words);
+int ecgb_bpe_shard_begin(ecgb_bpe_shard *h, const uint8_t *text_dev, long long *summary_dev, void *stream);
+int ecgb_bpe_shard_count(ecgb_bpe_shard *h, const long long *gathered_dev, int rank, int world, void *stream);
+int ecgb_bpe_shard_pick(ecgb_bpe_shard *h, uint32_t merge_index, long long *summary_dev, void *stream);
+int ecgb_bpe_shard_merge(ecgb_bpe_shard *h, uint32_t merge_index, const long long *gathered_dev, int rank, int world, void *stream);
+int ecgb_bpe_shard_apply(ecgb_bpe_shard *h, void *stream);
+int ecgb_bpe_shard_finish(ecgb_bpe_shard *h, uint32_t *pairs_dev, uint32_t *n_done_dev, uint32_t *ids_out_dev, uint64_t *n_ids_dev,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

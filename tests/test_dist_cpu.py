@@ -145,3 +145,51 @@ def test_flat_gradient_buckets_world_size_2_gloo():
         assert torch.allclose(ret[r][1], want, atol=1e-6)
         # 1000 + 300 >= 1200 -> bucket 1; 5000 -> bucket 2; 64 + 2000 -> bucket 3 (closed by finish... it reaches 1200 with 2000)
         assert ret[r][2] == 3 and ret[r][3] == 3
+
+
+def _shard_worker(rank, world, port, cases, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ecg_byte_amd.trainer import bpe_train_sharded
+        from oracle.sharded_trainer import CpuShard
+        out = []
+        for text, cuts, nm in cases:
+            lo, hi = ([0] + cuts + [len(text)])[rank: rank + 2]
+            out.append(bpe_train_sharded(CpuShard(text[lo:hi], nm), nm))
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_bpe_trainer_protocol_equals_the_single_process_trainer(world):
+    """the corpus split into contiguous slices over ranks, one all-gather of 8-word summaries and one
+    all-reduce of the 6 x V delta slab per merge (ecg_byte_amd/trainer.py::bpe_train_sharded, the loop a multi-GPU run executes over
+    RCCL) -- here over gloo with a CPU model of one rank's kernels (oracle/sharded_trainer.py).  Merges and the concatenation of the
+    ranks' ids must equal the oracle trainer's on the whole text (lib.rs:58-125): random texts over small alphabets (many ties, many
+    self-merges), cuts inside runs, empty and one-symbol slices, runs longer than a slice."""
+    rng = np.random.default_rng(77 + world)
+    cases = []
+    for trial in range(24):
+        k = int(rng.choice([1, 2, 3, 5]))
+        n = int(rng.integers(0, 260))
+        text = bytes(rng.integers(97, 97 + k, size=n).astype(np.uint8))
+        if trial % 5 == 0:                                     # long runs that span the cuts
+            text = b"a" * int(rng.integers(0, 90)) + text[: n // 3] + b"b" * int(rng.integers(0, 70)) + b"a" * int(rng.integers(0, 50))
+        cuts = sorted(int(c) for c in rng.integers(0, len(text) + 1, size=world - 1))
+        if trial % 7 == 0:
+            cuts = [0] * (world - 1)                            # empty leading slices
+        cases.append((text, cuts, int(rng.integers(0, 50))))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_shard_worker, args=(world, _free_port(), cases, ret), nprocs=world, join=True)
+    from oracle import oracle as O
+    for c, (text, cuts, nm) in enumerate(cases):
+        want_ids, _, want_merges = O.byte_pair_encoding(text, nm, fast=False)
+        got_ids = sum((ret[r][c][0] for r in range(world)), [])
+        for r in range(world):
+            assert O.pairs_to_vocab_merges([tuple(p) for p in ret[r][c][1]])[1] == want_merges, (c, r, text, cuts, nm)
+        assert got_ids == want_ids, (c, text, cuts, nm)
+

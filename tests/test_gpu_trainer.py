@@ -144,3 +144,48 @@ def test_trainer_past_2_pow_31_symbols():
     assert cur.numel() == n
     for lo in range(0, n, step):
         assert torch.equal(cur[lo: lo + step].to(torch.uint8), text[lo: lo + step]), lo
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_trainer_ranks_on_one_gpu(tmp_path, world):
+    """SURVEY.md section 8e row 3 with the real kernels: the corpus cut into contiguous slices, one per rank (all on cuda:0 here, the
+    exchange over gloo), merges and concatenated ids equal to the oracle trainer's on the whole text -- small alphabets (ties, self
+    merges), cuts inside runs, empty slices, runs longer than a 4096-id tile, and a synthetic-ECG corpus of 240 000 symbols."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    from helpers import load_tokenizer
+    from ecg_byte_amd import synth
+    rng = np.random.default_rng(5 + world)
+    cases = []
+    for trial in range(14):
+        k = int(rng.choice([1, 2, 3, 5]))
+        n = int(rng.integers(0, 9000))
+        text = bytes(rng.integers(97, 97 + k, size=n).astype(np.uint8))
+        if trial % 4 == 0:
+            text = b"a" * int(rng.integers(0, 9000)) + text[: n // 3] + b"b" * int(rng.integers(0, 5000)) + b"a" * int(rng.integers(0, 6000))
+        cuts = sorted(int(c) for c in rng.integers(0, len(text) + 1, size=world - 1))
+        if trial % 6 == 0:
+            cuts = [0] * (world - 1)
+        cases.append((text, cuts, int(rng.integers(0, 60))))
+    _, _, pc = load_tokenizer("c1")
+    x = synth.synth_ecg(4, 5000, seed=9)
+    sym = b"".join(O.symbols_to_text(O.quantize(x[b], pc["percentile_1"], pc["percentile_99"])) for b in range(4))
+    cases.append((sym, [len(sym) * (r + 1) // world + 7 for r in range(world - 1)], 300))
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(tmp_path / "cases.pkl", "wb") as f:
+        pickle.dump(cases, f)
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29530 + world), os.path.join(here, "shard_worker.py"), str(tmp_path / "cases.pkl"), str(tmp_path / "out")]
+    res = subprocess.run(cmd, cwd=os.path.dirname(here), env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    outs = [pickle.load(open(str(tmp_path / "out") + f".rank{r}", "rb")) for r in range(world)]
+    for c, (text, cuts, nm) in enumerate(cases):
+        want_ids, _, want_merges = O.byte_pair_encoding(text, nm, fast=True)
+        for r in range(world):
+            assert O.pairs_to_vocab_merges([tuple(p) for p in outs[r][c][1]])[1] == want_merges, (c, r, len(text), cuts, nm)
+        assert sum((outs[r][c][0] for r in range(world)), []) == want_ids, (c, len(text), cuts, nm)
