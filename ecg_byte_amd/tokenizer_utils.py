@@ -85,6 +85,11 @@ def process_large_file(file_path, percentiles, num_processes=1, n=None):
             if n is not None and i >= n:
                 break
             paths.append(line.strip())
+    return process_paths(paths, percentiles).decode("ascii")
+
+
+def process_paths(paths, percentiles) -> bytes:
+    """Concatenated symbol bytes ('a'..'z') of the given .npy records, in order; records are quantised on the GPU in batches."""
     parts = []
     batch, shape = [], None
     def flush():
@@ -102,4 +107,4 @@ def process_large_file(file_path, percentiles, num_processes=1, n=None):
         if len(batch) >= 256:
             flush()
     flush()
-    return b"".join(parts).decode("ascii")
+    return b"".join(parts)

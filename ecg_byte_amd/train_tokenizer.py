@@ -30,6 +30,8 @@ _OPTIONS = (
     ("--loaded", str, None, "existing tokenizer .pkl to check instead of the one just trained"),
     ("--check_ecg", str, "./data/seg_ecg_qa_ptb_500/ecg/train/ecg_10_1.npy", "record used by the self-check"),
     ("--out", str, None, "where to write the tokenizer (default ./data/tokenizer_{num_merges}.pkl)"),
+    ("--dis", "store_true", None, "started by torch.distributed.run, one process per GPU: every rank quantises its contiguous share of "
+                                  "the listed records and trains on that slice of the corpus (RCCL; same merges as one GPU)"),
 )
 
 
@@ -65,6 +67,32 @@ def train(sampled_files, percentiles, num_merges, num_processes, out_path) -> Tr
     return TrainReport(symbols=len(corpus), tokens=len(ids), vocab_size=len(vocab), seconds=dt)
 
 
+def train_sharded(sampled_files, percentiles, num_merges, out_path) -> TrainReport:
+    """The same on a corpus split over the ranks of the default process group: the listed records are
+    dealt out in contiguous runs (the corpus is their concatenation IN FILE ORDER, tokenizer_utils.py:79-93), each rank quantises
+    its run and keeps the ids of its slice; rank 0 writes the pickle."""
+    import torch
+    import torch.distributed as dist
+    from .trainer import HipShard, bpe_train_sharded
+    rank, world = dist.get_rank(), dist.get_world_size()
+    with open(sampled_files) as f:
+        paths = [line.strip() for line in f if line.strip()]
+    lo, hi = len(paths) * rank // world, len(paths) * (rank + 1) // world
+    part = tu.process_paths(paths[lo:hi], percentiles)
+    text = torch.frombuffer(bytearray(part), dtype=torch.uint8).cuda() if part else torch.empty(0, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ids, pairs = bpe_train_sharded(HipShard(text, num_merges), num_merges)
+    dt = time.time() - t0
+    counts = torch.tensor([len(part), len(ids)], dtype=torch.int64, device="cuda")
+    dist.all_reduce(counts)
+    vocab, merges = rust_bpe.vocab_merges_from_pairs(pairs)
+    if rank == 0:
+        tu.save_vocab_and_merges(vocab, merges, out_path)
+    dist.barrier()
+    return TrainReport(symbols=int(counts[0]), tokens=int(counts[1]), vocab_size=len(vocab), seconds=dt)
+
+
 def self_check(tokenizer_path, record_path, percentiles) -> bool:
     """encode -> decode of one record must give its quantised text back (train_tokenizer.py:58-60)."""
     vocab, merges = tu.load_vocab_and_merges(tokenizer_path)
@@ -84,11 +112,27 @@ def self_check(tokenizer_path, record_path, percentiles) -> bool:
 def main(args) -> bool:
     percentiles = np.load(args.percentiles, allow_pickle=True).item()
     target = args.out or f"./data/tokenizer_{args.num_merges}.pkl"
-    if args.train:
-        for line in train(args.sampled_files, percentiles, args.num_merges, args.num_processes, target).lines():
-            print(line)
-        print(f"tokenizer written to {target}")
-    return self_check(args.loaded or target, args.check_ecg, percentiles)
+    rank = 0
+    if args.dis:
+        import os
+        import torch
+        import torch.distributed as dist
+        rank = int(os.environ["RANK"])
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+        dist.init_process_group("nccl")                                    # RCCL
+    try:
+        if args.train:
+            report = (train_sharded(args.sampled_files, percentiles, args.num_merges, target) if args.dis else
+                      train(args.sampled_files, percentiles, args.num_merges, args.num_processes, target))
+            if rank == 0:
+                for line in report.lines():
+                    print(line)
+                print(f"tokenizer written to {target}")
+        return self_check(args.loaded or target, args.check_ecg, percentiles) if rank == 0 else True
+    finally:
+        if args.dis:
+            import torch.distributed as dist
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
