@@ -442,9 +442,11 @@ class HipCausalLM(nn.Module):
         fr = pos[:, None] * self.inv_freq[None, :].float()
         return fr.cos().contiguous(), fr.sin().contiguous()
 
-    def _attn_materialised(self, qkv, mask, B, S):
+    def _attn_materialised(self, qkv, mask, B, S, drop=None):
         """Attention through the [B*Hq, S, S] score tensor (head-batched GEMMs + softmax kernel): any head_dim that is a
-        multiple of 64 (Gemma: 256); S must be a multiple of 64 (GEMM K-step).  Returns (output [B*S, Hq*D], probabilities)."""
+        multiple of 64 (Gemma: 256); S must be a multiple of 64 (GEMM K-step).  Returns (output [B*S, Hq*D], probabilities).
+        drop = (p, seed): dropout on the probabilities before P.V (GPT-2's attn_dropout, modeling_gpt2.py:214); then the second
+        return value is the pair (P, dropped P) the backward needs."""
         c = self.cfg
         D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
         G, QKV, dev = Hq // Hkv, self.qkv, qkv.device
@@ -456,9 +458,44 @@ class HipCausalLM(nn.Module):
         vT = torch.empty((B, Hkv, D, S), dtype=torch.bfloat16, device=dev)
         ops.transpose_strided(qkv, Hq * D + Hkv * D, vT, 0, S, D, QKV, S, B * Hkv, Hkv, S * QKV, D, Hkv * D * S, D * S)
         ao = torch.empty((B * S, Hq * D), dtype=torch.bfloat16, device=dev)
-        ops.gemm_nt_heads(P, S, vT, S, ao, Hq * D, S, D, S, 1.0, B * Hq, Hq, Hq * S * S, S * S, 1,
+        Pd = ops.dropout(P, drop[0], drop[1]) if drop else P
+        ops.gemm_nt_heads(Pd, S, vT, S, ao, Hq * D, S, D, S, 1.0, B * Hq, Hq, Hq * S * S, S * S, 1,
                           Hkv * D * S, D * S, G, S * Hq * D, D)
-        return ao, P
+        return ao, ((P, Pd) if drop else P)
+
+    def _attn_materialised_bwd(self, qkv, d_ao, P, B, S, drop=None):
+        """d_qkv of `_attn_materialised` (same layout as qkv).  P: its second return value."""
+        c = self.cfg
+        D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        G, QKV, dev = Hq // Hkv, self.qkv, qkv.device
+        T, scale = B * S, 1.0 / math.sqrt(D)
+        P, Pd = P if drop else (P, P)
+        d_qkv = torch.empty((T, QKV), dtype=torch.bfloat16, device=dev)
+        dP = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
+        ops.gemm_nt_heads(d_ao, Hq * D, (qkv, Hq * D + Hkv * D), QKV, dP, S, S, S, D, 1.0, B * Hq, Hq,
+                          S * Hq * D, D, 1, S * QKV, D, G, Hq * S * S, S * S)   # dP = dO . V^T
+        if drop:
+            ops.dropout(dP, drop[0], drop[1], out=dP)                            # the same mask, on the gradient
+        ops.softmax_bwd_(P, dP, scale)                                           # dP <- dS
+        kT = torch.empty((B, Hkv, D, S), dtype=torch.bfloat16, device=dev)
+        ops.transpose_strided(qkv, Hq * D, kT, 0, S, D, QKV, S, B * Hkv, Hkv, S * QKV, D, Hkv * D * S, D * S)
+        ops.gemm_nt_heads(dP, S, kT, S, (d_qkv, 0), QKV, S, D, S, 1.0, B * Hq, Hq, Hq * S * S, S * S, 1,
+                          Hkv * D * S, D * S, G, S * QKV, D)                     # dQ = dS . K
+        tmpT = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
+        qT = torch.empty((B, Hq, D, S), dtype=torch.bfloat16, device=dev)
+        ops.transpose_strided(qkv, 0, qT, 0, S, D, QKV, S, B * Hq, Hq, S * QKV, D, Hq * D * S, D * S)
+        doT = torch.empty((B, Hq, D, S), dtype=torch.bfloat16, device=dev)
+        ops.transpose_strided(d_ao, 0, doT, 0, S, D, Hq * D, S, B * Hq, Hq, S * Hq * D, D, Hq * D * S, D * S)
+        dkv32 = torch.zeros((2, B, S, Hkv * D), dtype=torch.float32, device=dev)
+        for which, (src, rhs) in enumerate(((dP, qT), (Pd, doT))):                # dK = dS^T . Q ; dV = P^T . dO
+            ops.transpose_strided(src, 0, tmpT, 0, S, S, S, S, B * Hq, 1, S * S, 0, S * S, 0)
+            for j in range(G):   # the G query heads of a KV head accumulate into the same fp32 tile
+                ops.gemm_nt_heads((tmpT, j * S * S), S, (rhs, j * D * S), S, dkv32[which], Hkv * D, S, D, S, 1.0,
+                                  B * Hkv, Hkv, Hq * S * S, G * S * S, 1, Hq * D * S, G * D * S, 1,
+                                  S * Hkv * D, D, accumulate_f32=True)
+        d_qkv[:, Hq * D: Hq * D + Hkv * D] = dkv32[0].view(T, Hkv * D).to(torch.bfloat16)
+        d_qkv[:, Hq * D + Hkv * D:] = dkv32[1].view(T, Hkv * D).to(torch.bfloat16)
+        return d_qkv
 
     # ---- gradient storage ---------------------------------------------------------------------
     def _grad_layout(self):
@@ -927,30 +964,7 @@ class HipCausalLM(nn.Module):
             if self.fused_attention:
                 d_qkv = ops.attn_bwd(qkv, mask, ao, d_ao, P, B, S, Hq, Hkv, D, scale)
             else:
-                d_qkv = torch.empty((T, QKV), dtype=torch.bfloat16, device=dev)
-                dP = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
-                ops.gemm_nt_heads(d_ao, Hq * D, (qkv, Hq * D + Hkv * D), QKV, dP, S, S, S, D, 1.0, B * Hq, Hq,
-                                  S * Hq * D, D, 1, S * QKV, D, G, Hq * S * S, S * S)   # dP = dO . V^T
-                ops.softmax_bwd_(P, dP, scale)                                           # dP <- dS
-                kT = torch.empty((B, Hkv, D, S), dtype=torch.bfloat16, device=dev)
-                ops.transpose_strided(qkv, Hq * D, kT, 0, S, D, QKV, S, B * Hkv, Hkv, S * QKV, D, Hkv * D * S, D * S)
-                ops.gemm_nt_heads(dP, S, kT, S, (d_qkv, 0), QKV, S, D, S, 1.0, B * Hq, Hq, Hq * S * S, S * S, 1,
-                                  Hkv * D * S, D * S, G, S * QKV, D)                     # dQ = dS . K
-                tmpT = torch.empty((B * Hq, S, S), dtype=torch.bfloat16, device=dev)
-                qT = torch.empty((B, Hq, D, S), dtype=torch.bfloat16, device=dev)
-                ops.transpose_strided(qkv, 0, qT, 0, S, D, QKV, S, B * Hq, Hq, S * QKV, D, Hq * D * S, D * S)
-                doT = torch.empty((B, Hq, D, S), dtype=torch.bfloat16, device=dev)
-                ops.transpose_strided(d_ao, 0, doT, 0, S, D, Hq * D, S, B * Hq, Hq, S * Hq * D, D, Hq * D * S, D * S)
-                dkv32 = torch.zeros((2, B, S, Hkv * D), dtype=torch.float32, device=dev)
-                for which, (src, rhs) in enumerate(((dP, qT), (P, doT))):                # dK = dS^T . Q ; dV = P^T . dO
-                    ops.transpose_strided(src, 0, tmpT, 0, S, S, S, S, B * Hq, 1, S * S, 0, S * S, 0)
-                    for j in range(G):   # the G query heads of a KV head accumulate into the same fp32 tile
-                        ops.gemm_nt_heads((tmpT, j * S * S), S, (rhs, j * D * S), S, dkv32[which], Hkv * D, S, D, S, 1.0,
-                                          B * Hkv, Hkv, Hq * S * S, G * S * S, 1, Hq * D * S, G * D * S, 1,
-                                          S * Hkv * D, D, accumulate_f32=True)
-                d_qkv[:, Hq * D: Hq * D + Hkv * D] = dkv32[0].view(T, Hkv * D).to(torch.bfloat16)
-                d_qkv[:, Hq * D + Hkv * D:] = dkv32[1].view(T, Hkv * D).to(torch.bfloat16)
-                del dP, tmpT
+                d_qkv = self._attn_materialised_bwd(qkv, d_ao, P, B, S)
             del P
             ops.rope_(d_qkv, cos, sin, Hq + Hkv, D, QKV, inverse=True)
             wgrad(d_qkv, h1, self.wqkv[i])

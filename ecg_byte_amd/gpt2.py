@@ -11,8 +11,10 @@ What differs from the Llama block: LayerNorm with bias (ecgb_layernorm_fwd/bwd),
 no RoPE, multi-head attention (Hkv = Hq) on the same fused causal + left-padding attention kernels (head_dim 64 in every GPT-2 size).
 The loss: the reference does NOT upcast GPT-2's logits (modeling_gpt2.py:1300-1304 vs loss_utils.py:36): its bf16 run rounds the
 log-probabilities to bf16; the kernel here accumulates the same bf16 logits in fp32 (the difference is inside the 1e-2 loss tolerance).
-Dropout: embd_pdrop / resid_pdrop are applied in training mode (counter-based masks, replayed in the backward); attention-probability
-dropout (attn_pdrop) is not built into the fused attention kernels -- training with attn_pdrop > 0 raises."""
+Dropout: embd_pdrop / resid_pdrop / attn_pdrop are applied in training mode (counter-based masks, replayed in the backward).  The
+fused attention kernels have no dropout on the probabilities, so a training step with attn_pdrop > 0 (GPT2Config's default 0.1)
+takes the materialised-scores attention (head-batched GEMMs + softmax kernel + dropout on P): slower, same semantics
+(modeling_gpt2.py:183-221); eval, generation and attn_pdrop = 0 run fused."""
 from __future__ import annotations
 
 import math
@@ -213,9 +215,6 @@ class HipGPT2LM(HipCausalLM):
         H, nh, D, eps = c.n_embd, c.n_head, c.head_dim, c.layer_norm_epsilon
         input_ids, mask, position_ids, B, S = self._prep(input_ids, attention_mask, position_ids)
         labels = labels.to(self.device)
-        if self.training and c.attn_pdrop > 0:
-            raise NotImplementedError("attention-probability dropout (attn_pdrop > 0) is not built into the fused attention kernels: "
-                                      "set attn_pdrop = 0 (or call .eval()) -- ecg_byte_amd/gpt2.py")
         if S % 64:   # as HipCausalLM._forward_loss: masked, unlabelled positions on the left change nothing
             lpad = 64 - S % 64
             dev = self.device
@@ -231,7 +230,13 @@ class HipGPT2LM(HipCausalLM):
         for i in range(c.n_layer):
             h1, mu1, rs1, x1 = ops.layernorm_fwd(x, self.ln1[i].data, self.ln1_b[i].data, eps, residual=delta)
             qkv = ops.bias_(ops.gemm_nt(h1, self.wqkv[i].data), self.bqkv[i].data)
-            ao, lse = ops.attn_fwd(qkv, mask, B, S, nh, nh, D, scale)
+            if self.training and c.attn_pdrop > 0:                         # dropout on the probabilities: materialised scores
+                self.drop_calls += 1
+                adrop = (c.attn_pdrop, self.drop_seed + 7919 * self.drop_calls + 4)
+                ao, lse = self._attn_materialised(qkv, mask, B, S, drop=adrop)
+                lse = (lse, adrop)
+            else:
+                ao, lse = ops.attn_fwd(qkv, mask, B, S, nh, nh, D, scale)
             attn_delta = ops.bias_(ops.gemm_nt(ao, self.wo[i].data), self.bo[i].data)
             attn_delta, seed_a = self._drop(attn_delta, c.resid_pdrop, 2)
             h2, mu2, rs2, x2 = ops.layernorm_fwd(x1, self.ln2[i].data, self.ln2_b[i].data, eps, residual=attn_delta)
@@ -288,7 +293,10 @@ class HipGPT2LM(HipCausalLM):
             self._vgrad(self.bo[i], ops.colsum(d_ad))
             self._wgrad(self.wo[i], d_ad, ao)
             d_ao = ops.gemm_nt(d_ad, self._shadow(("wo", i), self.wo[i]))
-            d_qkv = ops.attn_bwd(qkv, mask, ao, d_ao, lse, B, S, nh, nh, D, scale)
+            if isinstance(lse, tuple):
+                d_qkv = self._attn_materialised_bwd(qkv, d_ao, lse[0], B, S, drop=lse[1])
+            else:
+                d_qkv = ops.attn_bwd(qkv, mask, ao, d_ao, lse, B, S, nh, nh, D, scale)
             self._vgrad(self.bqkv[i], ops.colsum(d_qkv))
             self._wgrad(self.wqkv[i], d_qkv, h1)
             d_h1 = ops.gemm_nt(d_qkv, self._shadow(("wqkv", i), self.wqkv[i]))

@@ -116,10 +116,53 @@ def test_gpt2_residual_dropout_replayed_in_backward():
     out2 = m(**_batch(z))
     out2.loss.backward()
     assert ((m.wfc[0].grad.float() - g1).norm() / g1.norm()).item() > 1e-2
-    m.cfg.attn_pdrop = 0.1
+
+
+def test_gpt2_attention_dropout_matches_a_torch_restatement_with_the_same_masks():
+    """attn_pdrop > 0 in training mode (GPT2Config's default): dropout on the attention probabilities (modeling_gpt2.py:214) through the
+    materialised-scores path.  The masks the kernels drew are read back from the saved (P, dropped P) pairs and fed to the fp32 oracle
+    block with autograd: loss within 1e-2, every gradient within 4e-2 (bf16 probabilities in the product path)."""
+    from oracle import gpt2_ref as G
+    import torch.nn.functional as F
+    z, m = _load()
+    m.cfg.attn_pdrop = 0.2
     m.train()
-    with pytest.raises(NotImplementedError):
-        m(**_batch(z))
+    b = _batch(z)
+    out = m(**b)
+    saved = m._saved[0]
+    keeps = []
+    for layer in saved:
+        (P, Pd), (p, seed) = layer[5]
+        keeps.append(((Pd != 0) | (P == 0)).view(3, 2, 64, 64))
+        rate = 1 - ((Pd != 0).sum() / (P != 0).sum()).item()
+        assert abs(rate - 0.2) < 0.03, rate
+    out.loss.backward()
+    params = {k[2:]: torch.from_numpy(z[k]).cuda().requires_grad_(True) for k in z.files if k.startswith("w:")}
+    ids, mask, pos = b["input_ids"], b["attention_mask"], b["position_ids"]
+    H, nh, D, Bn, S = 128, 2, 64, 3, 64
+    x = params["transformer.wte.weight"][ids] + params["transformer.wpe.weight"][pos]
+    vis = torch.tril(torch.ones(S, S, dtype=torch.bool, device="cuda"))[None, None] & (mask[:, None, None, :] != 0)
+    for i in range(2):
+        pre = f"transformer.h.{i}."
+        h = F.layer_norm(x, (H,), params[pre + "ln_1.weight"], params[pre + "ln_1.bias"], 1e-5)
+        q, k, v = (h @ params[pre + "attn.c_attn.weight"] + params[pre + "attn.c_attn.bias"]).split(H, dim=2)
+        q, k, v = (t.view(Bn, S, nh, D).transpose(1, 2) for t in (q, k, v))
+        sc = (q @ k.transpose(-1, -2)) / 8.0
+        pr = torch.nan_to_num(torch.softmax(sc.masked_fill(~vis, float("-inf")), -1), nan=0.0)
+        pr = pr * keeps[i].float() / (1 - 0.2)
+        a = (pr @ v).transpose(1, 2).reshape(Bn, S, H)
+        x = x + a @ params[pre + "attn.c_proj.weight"] + params[pre + "attn.c_proj.bias"]
+        h = F.layer_norm(x, (H,), params[pre + "ln_2.weight"], params[pre + "ln_2.bias"], 1e-5)
+        x = x + G.gelu_new(h @ params[pre + "mlp.c_fc.weight"] + params[pre + "mlp.c_fc.bias"]) @ params[pre + "mlp.c_proj.weight"] + params[pre + "mlp.c_proj.bias"]
+    x = F.layer_norm(x, (H,), params["transformer.ln_f.weight"], params["transformer.ln_f.bias"], 1e-5)
+    logits = x @ params["transformer.wte.weight"].T
+    ref = F.cross_entropy(logits[:, :-1].reshape(-1, 300), b["labels"][:, 1:].reshape(-1), ignore_index=-100)
+    ref.backward()
+    assert abs(out.loss.item() - ref.item()) <= 1e-2 * ref.item(), (out.loss.item(), ref.item())
+    for name, g in _grads_hf(m).items():
+        want = params[name].grad
+        rel = ((g - want).norm() / want.norm().clamp_min(1e-12)).item()
+        assert rel < 4e-2, (name, rel)
 
 
 def test_gpt2_small_dims_two_layers_vs_fp32_oracle():
