@@ -401,9 +401,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
 // backward, dK and dV: grid (ceil(S/128), Hkv, B); lanes = keys; loops over the query heads of the group
 // DS > 1 (head_dim 256): the d range of the dK / dV accumulators is split over DS workgroups (blockIdx.x % DS): K, V fragments and
 // two full accumulator sets of head_dim 256 do not fit one wave's 512 registers; the S and dP products are recomputed per split.
-template <int D, int DS>
-__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(AttnArgs A)   // head_dim 64: two waves per SIMD (<= 256 registers)
+// WHICH: 0 = dK and dV in one pass (head_dim 64 / 128); 1 = dV only, 2 = dK only -- at head_dim 256 the two gradients are two launches,
+// each with full-width accumulators: the dV pass needs S alone (K fragments), the dK pass S and dP (K and V fragments), 1.25 x the MFMA
+// work of a single pass instead of the 2.5 x of splitting the d range four ways (DS = 4, the first head_dim-256 version: 3.3 ms per
+// layer at Gemma-2B's shape).
+template <int D, int DS, int WHICH>
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs &A, const int block_x)
 {
+    constexpr bool DO_V = WHICH != 2, DO_K = WHICH != 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 4 x 128 D bytes + 512
     constexpr int kTile = 128 * D;
     unsigned char *lds_q = smem, *lds_do = smem + kTile, *lds_qt = smem + 2 * kTile, *lds_dot = smem + 3 * kTile;
@@ -411,13 +416,13 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
     constexpr int NB = D / 32 / DS;                          // 32-wide d blocks this workgroup accumulates
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, g = blockIdx.y, G = A.Hq / A.Hkv;
-    const int kk0 = (blockIdx.x / DS) * 128, db0 = (blockIdx.x % DS) * NB;
+    const int kk0 = (block_x / DS) * 128, db0 = (block_x % DS) * NB;
     const int ki = kk0 + wave * 32 + lr;
     const bool kvalid = ki < A.S;
     const long long rowbase = (long long)b * A.S;
     bf16x8 kf[D / 16], vf[D / 16];
     load_row_frags<D>(kf, A.k + (long long)g * D, A.ldk, rowbase + ki, kvalid, h);
-    load_row_frags<D>(vf, A.v + (long long)g * D, A.ldv, rowbase + ki, kvalid, h);
+    if constexpr (DO_K) load_row_frags<D>(vf, A.v + (long long)g * D, A.ldv, rowbase + ki, kvalid, h);
     const bool kvis = kvalid && A.mask[rowbase + (kvalid ? ki : 0)] != 0.f;
     f32x16 accK[NB], accV[NB];
 #pragma unroll
@@ -452,8 +457,8 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            if (first_half) { stage_write_plain<D>(lds_q, st[i], item + 128 * i); stage_write_transposed(lds_qt, st[i], item + 128 * i); }
-            else { stage_write_plain<D>(lds_do, st[i], item + 128 * i); stage_write_transposed(lds_dot, st[i], item + 128 * i); }
+            if (first_half) { stage_write_plain<D>(lds_q, st[i], item + 128 * i); if constexpr (DO_K) stage_write_transposed(lds_qt, st[i], item + 128 * i); }
+            else { if constexpr (DO_K) stage_write_plain<D>(lds_do, st[i], item + 128 * i); if constexpr (DO_V) stage_write_transposed(lds_dot, st[i], item + 128 * i); }
         }
         if (threadIdx.x < 64) {
             const bool v = t0 + (int)threadIdx.x < A.S;
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
 #pragma unroll
             for (int ks = 0; ks < D / 16; ++ks) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_q, qb * 32 + lr, ks, h), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_do, qb * 32 + lr, ks, h), vf[ks], dp, 0, 0, 0);
+                if constexpr (DO_K) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_do, qb * 32 + lr, ks, h), vf[ks], dp, 0, 0, 0);
             }
             float pr[16], ds[16];
             const bool diag = t0 + qb * 32 < wave_kmin + 32;              // some query of the block may precede some key of the wave
@@ -501,14 +506,28 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
                 const bf16x8 dsf = frag_from_acc(&ds[8 * s2]);
 #pragma unroll
                 for (int db = 0; db < NB; ++db) {
-                    accV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_dot, (db0 + db) * 32 + lr, qb, s2, h), pf, accV[db], 0, 0, 0);
-                    accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_qt, (db0 + db) * 32 + lr, qb, s2, h), dsf, accK[db], 0, 0, 0);
+                    if constexpr (DO_V) accV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_dot, (db0 + db) * 32 + lr, qb, s2, h), pf, accV[db], 0, 0, 0);
+                    if constexpr (DO_K) accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_qt, (db0 + db) * 32 + lr, qb, s2, h), dsf, accK[db], 0, 0, 0);
                 }
             }
         }
     }
-    store_accT<NB>(accK, A.dk + (long long)g * D + db0 * 32, A.lddk, rowbase + ki, kvalid, h, 1.f);
-    store_accT<NB>(accV, A.dv + (long long)g * D + db0 * 32, A.lddv, rowbase + ki, kvalid, h, 1.f);
+    if constexpr (DO_K) store_accT<NB>(accK, A.dk + (long long)g * D + db0 * 32, A.lddk, rowbase + ki, kvalid, h, 1.f);
+    if constexpr (DO_V) store_accT<NB>(accV, A.dv + (long long)g * D + db0 * 32, A.lddv, rowbase + ki, kvalid, h, 1.f);
+}
+
+template <int D, int DS, int WHICH = 0>
+__global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(AttnArgs A)   // head_dim 64: two waves per SIMD (<= 256 registers)
+{
+    attn_bwd_dkv_body<D, DS, WHICH>(A, (int)blockIdx.x);
+}
+// head_dim 256: the dV pass and the dK pass of a key block as two workgroups of ONE launch (even / odd blockIdx.x) -- Gemma's single KV
+// head gives only S / 128 x batch key blocks, half a chip's worth at C5's shape
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pair_kernel(AttnArgs A)
+{
+    if (blockIdx.x & 1) attn_bwd_dkv_body<D, 1, 2>(A, (int)(blockIdx.x >> 1));
+    else attn_bwd_dkv_body<D, 1, 1>(A, (int)(blockIdx.x >> 1));
 }
 
 // =====================================================================================================
@@ -844,13 +863,23 @@ extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev
     if (lddq % 4 || lddk % 4 || lddv % 4) { ecgb::set_error("ecgb_attn_bwd: gradient row strides must be multiples of 4"); return ECGB_ERR_UNSUPPORTED; }
     const dim3 gq((unsigned)((seq + 127) / 128), (unsigned)n_q_heads, (unsigned)batch);
     const dim3 gk((unsigned)((seq + 127) / 128), (unsigned)n_kv_heads, (unsigned)batch);
-#define ECGB_BWD(D_, DS_) do { const int lq = 3 * 128 * D_ + 260, lk = 4 * 128 * D_ + 512; \
+#define ECGB_DKV(D_, DS_, W_) do { \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<D_, DS_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, lk) != hipSuccess) break; \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D_, DS_, W_>), dim3(gk.x * DS_, gk.y, gk.z), dim3(256), lk, (hipStream_t)stream, A); } while (0)
+#define ECGB_BWD(D_) do { const int lq = 3 * 128 * D_ + 260; \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, lq) != hipSuccess) break; \
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<D_, DS_>), hipFuncAttributeMaxDynamicSharedMemorySize, lk) != hipSuccess) break; \
         hipLaunchKernelGGL(attn_bwd_dq_kernel<D_>, gq, dim3(256), lq, (hipStream_t)stream, A); \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D_, DS_>), dim3(gk.x * DS_, gk.y, gk.z), dim3(256), lk, (hipStream_t)stream, A); } while (0)
-    if (head_dim == 64) ECGB_BWD(64, 1); else if (head_dim == 128) ECGB_BWD(128, 1); else ECGB_BWD(256, 4);
+        } while (0)
+    if (head_dim == 64) { ECGB_BWD(64); const int lk = 4 * 128 * 64 + 512; ECGB_DKV(64, 1, 0); }
+    else if (head_dim == 128) { ECGB_BWD(128); const int lk = 4 * 128 * 128 + 512; ECGB_DKV(128, 1, 0); }
+    else {
+        ECGB_BWD(256);
+        const int lk = 4 * 128 * 256 + 512;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_pair_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, lk) == hipSuccess)
+            hipLaunchKernelGGL(attn_bwd_dkv_pair_kernel<256>, dim3(gk.x * 2, gk.y, gk.z), dim3(256), lk, (hipStream_t)stream, A);
+    }
 #undef ECGB_BWD
+#undef ECGB_DKV
     return launched("attn_bwd kernels");
 }
 
