@@ -565,3 +565,40 @@ def test_generate_sampling_follows_the_warped_distribution(tmp_path):
     assert m2.generation_config["do_sample"] is True
     a = m2.generate(input_ids=rep_ids[:64], attention_mask=rep_mask[:64], max_new_tokens=3, pad_token_id=299, generator=g)
     assert len({tuple(r.tolist()) for r in a[:, -3:]}) > 1                  # sampled by default now: the rows differ
+
+
+@pytest.mark.parametrize("S", [100, 1004 % 256 + 64])
+def test_sequence_length_not_a_multiple_of_64(S):
+    """The reference's default --pad_to_max 1000 gives rows of 1004 tokens (data_loader.py:123): the training forward pads such rows on
+    the LEFT with masked, unlabelled positions up to the GEMM K-step; loss and gradients must be those of the unpadded rows (fp32 oracle),
+    and the eval loss the same number."""
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    from oracle import llama_ref as R
+    cfgd = dict(vocab_size=515, hidden_size=256, intermediate_size=448, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, head_dim=64, rms_norm_eps=1e-6)
+    params = R.random_params(cfgd, seed=11, device="cuda", std=0.05)
+    m = HipCausalLM(DecoderConfig(vocab_size=515, hidden_size=256, intermediate_size=448, num_hidden_layers=2, num_attention_heads=4,
+                                  num_key_value_heads=2, rms_norm_eps=1e-6, rope_theta=10000.0, rope_scaling=None, pad_token_id=514))
+    m.load_state_dict(params)
+    B = 3
+    g = torch.Generator(device="cuda").manual_seed(S)
+    ids = torch.randint(0, 514, (B, S), device="cuda", generator=g)
+    mask = torch.ones(B, S, device="cuda"); mask[1, :23] = 0; ids[1, :23] = 514
+    pos = (torch.cumsum(mask, 1) - 1).clamp(min=0).long(); pos[mask == 0] = 0
+    labels = torch.full((B, S), -100, device="cuda"); labels[:, -17:] = ids[:, -17:]
+    ref_p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = R.llama_loss(ref_p, cfgd, ids, mask, labels, pos, R.llama3_inv_freq(64, 10000.0, None).cuda())
+    ref.backward()
+    out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
+    out.loss.backward()
+    assert abs(out.loss.item() - ref.item()) <= 1e-2 * ref.item()
+    for i in range(2):
+        want = torch.cat([ref_p[f"model.layers.{i}.self_attn.{n}_proj.weight"].grad for n in "qkv"], 0)
+        assert ((m.wqkv[i].grad.float() - want).norm() / want.norm()).item() < 3e-2
+        want = ref_p[f"model.layers.{i}.mlp.down_proj.weight"].grad
+        assert ((m.wdown[i].grad.float() - want).norm() / want.norm()).item() < 3e-2
+    want = ref_p["model.embed_tokens.weight"].grad
+    assert ((m.embed.grad[:515].float() - want).norm() / want.norm()).item() < 3e-2
+    with torch.no_grad():
+        ev = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos).loss.item()
+    assert abs(ev - ref.item()) <= 1e-2 * ref.item()
