@@ -571,6 +571,31 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *in, unsig
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = f2bf(in[i]);
 }
 
+// out[i] = bf16(sum_s slabs[s * stride + i]) (+ out[i] when ACC): the K-slices of a split weight-gradient product, summed in slice
+// order.  Four elements per thread step: 16-byte loads per slab, one 8-byte store.
+template <bool ACC>
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float *slabs, long long stride, int n_slabs, unsigned short *out, size_t n4)
+{
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    using us4 = __attribute__((ext_vector_type(4))) unsigned short;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f4 v = *reinterpret_cast<const f4 *>(slabs + 4 * i);
+        for (int s = 1; s < n_slabs; ++s) {
+            const f4 w = *reinterpret_cast<const f4 *>(slabs + (long long)s * stride + 4 * i);
+            v += w;
+        }
+        us4 o;
+        if (ACC) {
+            o = *reinterpret_cast<const us4 *>(out + 4 * i);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] += bf2f(o[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = f2bf(v[t]);
+        *reinterpret_cast<us4 *>(out + 4 * i) = o;
+    }
+}
+
 // ---- attention softmax (scores materialised) -------------------------------------------------------
 // One wave per row i of one (batch, head): keys j <= i with mask[b, j] != 0.
 __global__ __launch_bounds__(256) void softmax_causal_fwd_kernel(unsigned short *scores, const float *mask, size_t rows_total,
@@ -807,6 +832,22 @@ extern "C" int ecgb_f32_to_bf16(const float *in_dev, void *out_dev, size_t n, vo
 {
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, in_dev, (unsigned short *)out_dev, n);
     ECGB_CHECK_LAUNCH("f32_to_bf16");
+}
+
+extern "C" int ecgb_sum_slabs_bf16(const float *slabs_dev, long long slab_stride, int n_slabs, void *out_dev, size_t n, int accumulate, void *stream)
+{
+    if (!slabs_dev || !out_dev || n_slabs < 1) { ecgb::set_error("ecgb_sum_slabs_bf16: bad argument"); return ECGB_ERR_INVALID; }
+    if (n % 4 || slab_stride % 4 || ((uintptr_t)slabs_dev & 15) || ((uintptr_t)out_dev & 7)) {
+        ecgb::set_error("ecgb_sum_slabs_bf16: n and slab_stride must be multiples of 4, slabs 16-byte and out 8-byte aligned");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    if (n == 0) return ECGB_OK;
+    const unsigned grid = grid_for(n / 4, 256);
+    if (accumulate)
+        hipLaunchKernelGGL(sum_slabs_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, slabs_dev, slab_stride, n_slabs, (unsigned short *)out_dev, n / 4);
+    else
+        hipLaunchKernelGGL(sum_slabs_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, slabs_dev, slab_stride, n_slabs, (unsigned short *)out_dev, n / 4);
+    ECGB_CHECK_LAUNCH("sum_slabs");
 }
 
 extern "C" int ecgb_softmax_causal_fwd(void *scores_dev, const float *attn_mask_dev, int batch_heads, int n_heads, int seq,

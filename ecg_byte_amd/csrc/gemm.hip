@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <type_traits>
 
 #include "tokenizer.hpp"
 
@@ -47,6 +48,10 @@ struct GemmArgs {
     const unsigned short *A2, *B2;
     long long lda2, ldb2;
     int K2;
+    // TN kernels with the contraction cut into K-slices: slice s stores its fp32 partial tile at C + s * split_stride (plain stores;
+    // the caller sums the slabs in slice order -- fp32 atomics into one buffer cost 0.15-0.2 ms per launch on the chip-wide L2
+    // miss path and made the weight gradients differ from run to run)
+    long long split_stride = 0;
 };
 
 __device__ __forceinline__ unsigned short f2bf_rn(float f)
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
 
 // Epilogue of the TN kernels: bf16 store, or fp32 atomics when the contraction is split over workgroups.
 template <int TM, int TN, int WTM, int WTN>
-__device__ __forceinline__ void store_tile_tn(const f32x4 (&acc)[TM][TN], const GemmArgs &G, int row0, int col0, int wr, int wc, int lm, int lq)
+__device__ __forceinline__ void store_tile_tn(const f32x4 (&acc)[TM][TN], const GemmArgs &G, int row0, int col0, int wr, int wc, int lm, int lq, int split)
 {
     const float alpha = G.alpha;
 #pragma unroll
@@ -540,10 +545,12 @@ __device__ __forceinline__ void store_tile_tn(const f32x4 (&acc)[TM][TN], const 
         for (int j = 0; j < TN; ++j) {
             const int c = col0 + wc * WTN + j * 16 + lq * 4;
             if (c + 3 >= G.K) continue;
-            if (G.accumulate_f32) {   // split over the contraction: fp32 partial sums meet in memory
-                float *p = reinterpret_cast<float *>(G.C) + (long long)r * G.ldc + c;
+            if (G.accumulate_f32) {   // split over the contraction: this slice's fp32 partial tile goes to its own slab
+                float *p = reinterpret_cast<float *>(G.C) + (long long)split * G.split_stride + (long long)r * G.ldc + c;
+                f32x4 v;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) atomicAdd(p + t, acc[i][j][t] * alpha);
+                for (int t = 0; t < 4; ++t) v[t] = acc[i][j][t] * alpha;
+                *reinterpret_cast<f32x4 *>(p) = v;
             } else {
                 using us4 = __attribute__((ext_vector_type(4))) unsigned short;
                 us4 v;
@@ -594,7 +601,10 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_m16(GemmArgs G)
     const int per = (KT_all + (int)gridDim.y - 1) / (int)gridDim.y;
     const int kt_begin = (int)blockIdx.y * per;
     const int KT = min(KT_all, kt_begin + per);
-    if (kt_begin >= KT) return;
+    if (kt_begin >= KT) {                                 // an empty K-slice still owns a slab: zeros
+        if (G.accumulate_f32) store_tile_tn<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lane & 15, lane >> 4, (int)blockIdx.y);
+        return;
+    }
     bf16x8 ra[4], rb[4];
     auto load_items = [&](int kt) {
 #pragma unroll
@@ -662,7 +672,7 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_m16(GemmArgs G)
         }
         if (kt + 1 < KT) write_items(lds + ((kt + 1) & 1) * kBufBytes);   // the other buffer: its last reader finished before the barrier above
     }
-    store_tile_tn<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq);
+    store_tile_tn<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, (int)blockIdx.y);
 }
 
 // C[N, K] = alpha * A[M, N]^T . B[M, K] with NO register staging: both operand tiles ([64 contraction rows] x [256
@@ -675,6 +685,7 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_m16(GemmArgs G)
 template <int BN_, int BK_, int WGM, int WGN>
 __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
 {
+    const int orig = blockIdx.x, split = blockIdx.y, n_splits = gridDim.y;
     static_assert(BN_ == 256 && BK_ == 256 && WGM == 2 && WGN == 4, "phase schedule written for the 256x256 tile, 2x4 waves");
     constexpr int WTM = BN_ / WGM, WTN = BK_ / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -682,7 +693,6 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nwg = G.tiles_m * G.tiles_n;
-    const int orig = blockIdx.x;
     const int q_ = nwg / 8, rr = nwg % 8, xcd = orig % 8;
     const int wgid = (xcd < rr ? xcd * (q_ + 1) : rr * (q_ + 1) + (xcd - rr) * q_) + orig / 8;
     const int tm = wgid / G.tiles_n, tn = wgid % G.tiles_n;
@@ -695,10 +705,13 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int KT_all = G.M / 64;
-    const int per = (KT_all + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int kt_begin = (int)blockIdx.y * per;
+    const int per = (KT_all + n_splits - 1) / n_splits;
+    const int kt_begin = split * per;
     const int KT = min(KT_all, kt_begin + per);
-    if (kt_begin >= KT) return;
+    if (kt_begin >= KT) {                                 // an empty K-slice still owns a slab: zeros
+        if (G.accumulate_f32) store_tile_tn<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, split);
+        return;
+    }
 
     // LDS-DMA of one operand tile: 32 instructions of 1 KiB (2 rows of 512 B), 4 per wave
     auto stage = [&](const unsigned short *g, long long ld, int c0, int ncols, int kt, unsigned char *dst) {
@@ -725,45 +738,59 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
 
-    using s4 = __attribute__((ext_vector_type(4))) short;
+    // Fragment addresses.  A fragment (8 contraction rows x 16 columns) is two transposing reads of 4 rows each; lane (16g + 4q + p)
+    // addresses row 8g + q (+4 for the second read), columns 4p..4p+3 of the fragment's 16: 16-byte chunk 2m + (p >> 1) of the row
+    // for the fragment at columns 16m.., stored at chunk ^ 2s with s = (row & 7) ^ ((row & 8) >> 1) -- a per-lane constant that only
+    // moves the low three bits of m.  So the byte address is  table[m & 7] + compile-time offset, with ONE table of 8 per-lane
+    // entries for the A operand (the second read, 4 rows down, has s ^ 4: entry m ^ 4) and 4 + 4 for B; K-half, second read, operand
+    // and nothing else go into the instruction's offset field, the buffer toggle (64 KiB: past the 16-bit field) is an XOR on the
+    // 16 entries once per K-tile.  The loop had ~190 address VALU + ~100 register moves per 64 MFMAs before; the moves came from
+    // assembling the 4-register operand out of two 2-register results element by element.
+    using i2 = __attribute__((ext_vector_type(2))) int;
+    using i4 = __attribute__((ext_vector_type(4))) int;
     const int tq = lm >> 2, tp = lm & 3;                                    // this lane's row / column group inside a 4 x 16 block
+    unsigned tabA[8], tabB0[4], tabB1[4];
+    {
+        const int rb = 8 * lq + tq;
+        const int sw = (rb & 7) ^ ((rb & 8) >> 1);
+        const unsigned lane_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds + rb * 512 + (tp & 1) * 8;
+        const int cb = tp >> 1;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) tabA[m] = lane_base + wr * 256 + (((2 * (m ^ sw)) + cb) << 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = (wc & 1) * 4 + j;
+            tabB0[j] = lane_base + (wc >> 1) * 256 + (((2 * (m ^ sw)) + cb) << 4);
+            tabB1[j] = lane_base + (wc >> 1) * 256 + (((2 * (m ^ 4 ^ sw)) + cb) << 4);
+        }
+    }
     bf16x8 a[2][4], b[2][4];
     for (int it = 0, kt = kt_begin; kt < KT; ++kt, ++it) {
-        const unsigned char *At = lds + (it & 1) * kBufBytes, *Bt = At + kABytes;
         unsigned char *nxt = lds + (it & 1) * kBufBytes;
         const bool more = kt + 2 < KT;
-        // lane constants of the fragment addresses, made opaque once per K-tile: hoisted out of the loop the 24 addresses
-        // per buffer cost more registers than the kernel has (it spilled, and a spill reload next to LDS-DMA makes hipcc
-        // wait vmcnt(0): the pipeline drained several times per tile)
-        int rbase = 8 * lq + tq, cbase = tp >> 1, hbase = (tp & 1) * 8;
-        asm volatile("" : "+v"(rbase), "+v"(cbase), "+v"(hbase));
-        // fragment of the 16 columns starting at c0 (multiple of 16), contraction rows ks*32 + 8*lq .. +7
-        auto frag = [&](const unsigned char *T, int c0, int ks) {
-            const int chunk = (c0 >> 3) + cbase;
-            const int r0 = ks * 32 + rbase, r1 = r0 + 4;
-            // inline asm: next to LDS-DMA hipcc puts a vmcnt(0) in front of a transposing read it can see (it would drain the
-            // two tiles in flight once per K-tile); ordering is by the explicit counted waits and barriers of the schedule
-            s4 lo, hi;
-            const unsigned tbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)const_cast<unsigned char *>(T);   // LDS byte address
-            const unsigned a0 = tbase + r0 * 512 + ((chunk ^ (((r0 & 7) << 1) ^ (r0 & 8))) << 4) + hbase;
-            const unsigned a1 = tbase + r1 * 512 + ((chunk ^ (((r1 & 7) << 1) ^ (r1 & 8))) << 4) + hbase;
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
-            bf16x8 f;
-            f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-            return f;
+        // inline asm: next to LDS-DMA hipcc puts a vmcnt(0) in front of a transposing read it can see (it would drain the two tiles
+        // in flight once per K-tile); ordering is by the explicit counted waits and barriers of the schedule
+        auto frag = [&](unsigned t0, unsigned t1, auto off) {
+            constexpr int OFF = decltype(off)::value;
+            i2 lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(t0), "n"(OFF));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(t1), "n"(OFF + 2048));
+            const i4 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+            return __builtin_bit_cast(bf16x8, f);
         };
         auto read_a = [&](int half) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[ks][i] = frag(At, wr * WTM + (half * 4 + i) * 16, ks);
+            for (int i = 0; i < 4; ++i) {
+                a[0][i] = frag(tabA[half * 4 + i], tabA[(half * 4 + i) ^ 4], std::integral_constant<int, 0>{});
+                a[1][i] = frag(tabA[half * 4 + i], tabA[(half * 4 + i) ^ 4], std::integral_constant<int, 32 * 512>{});
+            }
         };
         auto read_b = [&](int half) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) b[ks][half * 2 + j] = frag(Bt, wc * WTN + (half * 2 + j) * 16, ks);
+            for (int j = 0; j < 2; ++j) {
+                b[0][half * 2 + j] = frag(tabB0[half * 2 + j], tabB1[half * 2 + j], std::integral_constant<int, kABytes>{});
+                b[1][half * 2 + j] = frag(tabB0[half * 2 + j], tabB1[half * 2 + j], std::integral_constant<int, kABytes + 32 * 512>{});
+            }
         };
         auto mfma_quadrant = [&](int ah, int bh) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -794,9 +821,13 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         mfma_quadrant(1, 0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) tabA[m] ^= (unsigned)kBufBytes;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { tabB0[j] ^= (unsigned)kBufBytes; tabB1[j] ^= (unsigned)kBufBytes; }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
-    store_tile_tn<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq);
+    store_tile_tn<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, split);
 }
 
 
@@ -1099,7 +1130,7 @@ extern "C" int ecgb_gemm_tn_bf16(const void *a_dev, long long lda, const void *b
 {
     if (!a_dev || !b_dev || !c_dev || M <= 0 || N <= 0 || K <= 0) { ecgb::set_error("ecgb_gemm_tn_bf16: bad argument"); return ECGB_ERR_INVALID; }
     if (M % 64 || N % 8 || K % 8 || N < 8 || K < 8 || lda % 8 || ldb % 8 || ldc % 4 || ((uintptr_t)a_dev & 15) || ((uintptr_t)b_dev & 15) ||
-        ((uintptr_t)c_dev & 7)) {
+        ((uintptr_t)c_dev & (splits > 1 ? 15 : 7))) {
         ecgb::set_error("ecgb_gemm_tn_bf16: M % 64, N % 8, K % 8, 16-byte aligned operands required");
         return ECGB_ERR_UNSUPPORTED;
     }
@@ -1110,7 +1141,8 @@ extern "C" int ecgb_gemm_tn_bf16(const void *a_dev, long long lda, const void *b
     G.A2 = G.B2 = nullptr; G.lda2 = G.ldb2 = 0; G.K2 = 0;
     G.tiles_m = (N + 255) / 256; G.tiles_n = (K + 255) / 256;
     if (splits < 1 || splits > 64) { ecgb::set_error("ecgb_gemm_tn_bf16: splits must be 1..64"); return ECGB_ERR_INVALID; }
-    G.accumulate_f32 = splits > 1 ? 1 : 0; G.alpha = alpha;      // splits > 1: c_dev is a ZEROED fp32 [N, ldc] buffer
+    G.accumulate_f32 = splits > 1 ? 1 : 0; G.alpha = alpha;      // splits > 1: c_dev is fp32 [splits][N, ldc], one slab per K-slice
+    G.split_stride = (long long)N * ldc;
     G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
     constexpr int lds = 2 * (256 + 256) * 64 * 2;
     auto kern = (g_gemm_tile == 258) ? gemm_tn_kernel_m16<256, 256, 2, 4> : gemm_tn_kernel_tr<256, 256, 2, 4>;

@@ -552,10 +552,7 @@ class HipCausalLM(nn.Module):
         view, acc = self._grad_slot(param)
         for lo, hi, dy, xin in parts:
             dst = view[lo:hi]
-            if acc:
-                ops.add(dst, ops.gemm_tn(dy, xin, alpha=alpha), out=dst)
-            else:
-                ops.gemm_tn(dy, xin, alpha=alpha, out=dst)
+            ops.gemm_tn(dy, xin, alpha=alpha, out=dst, accumulate=acc)
         param.grad = view
 
     def _vgrad(self, param, g):

@@ -195,27 +195,56 @@ def lora_dx_(dx, dt, At, n_sub, n_fields, scale, p=0.0, seed=0):
     return dx
 
 
-def gemm_tn(a, b, alpha=1.0, splits=None, out=None):
+def tn_splits(N, K, M, n_cu=256):
+    """K-slices per 256x256 output tile of a weight-gradient product.  Skinny outputs (LoRA adapter gradients) are a pass over the long
+    operand: enough workgroups to pull it at HBM speed.  Otherwise the slice count that minimises the makespan in contraction steps when
+    tiles * s workgroups are dealt over the compute units one each (measured on dW of qkv [3072 x 2048] and o [2048 x 2048] at 32 768
+    rows: 5 and 4 slices, 0.49 and 0.31 ms against 0.99 and 0.96 unsplit), plus ~tiles / 20 steps per slice for writing and re-reading
+    its fp32 slab."""
+    tiles = ((N + 255) // 256) * ((K + 255) // 256)
+    kt = max(1, M // 64)
+    if min(N, K) <= 64:
+        return max(1, min(32, n_cu // tiles, kt))
+    best = None
+    for s in range(1, min(8, kt) + 1):
+        cost = -(-tiles * s // n_cu) * -(-kt // s) + s * tiles / 20.0
+        if best is None or cost < best[0] - 1e-9:
+            best = (cost, s)
+    return best[1]
+
+
+def sum_slabs(slabs, out, accumulate=False):
+    """out (bf16, contiguous) = [out +] sum over the leading axis of slabs (fp32 [n_slabs, out.numel()]), added in slab order."""
+    n_slabs = slabs.shape[0]
+    _lib.check(_L().ecgb_sum_slabs_bf16(_p(slabs), slabs.stride(0), n_slabs, _p(out), out.numel(), int(accumulate), _st()))
+    return out
+
+
+def gemm_tn(a, b, alpha=1.0, splits=None, out=None, accumulate=False):
     """C[N,K] = alpha * A[M,N]^T @ B[M,K]  (weight gradient dW = dY^T X) without transposed copies.
-    splits: workgroups sharing one output tile's contraction (None: enough to fill the chip).
-    out: contiguous bf16 [N, K] destination (e.g. a parameter's slice of the flat gradient buffer)."""
+    splits: workgroups sharing one output tile's contraction (None: enough to fill the chip); each writes its fp32 partial product to
+    its own slab and one pass sums them in slice order (deterministic).
+    out: contiguous bf16 [N, K] destination (e.g. a parameter's slice of the flat gradient buffer); accumulate: out += result."""
     M, N = a.shape
     K = b.shape[1]
     assert b.shape[0] == M and a.stride(1) == 1 and b.stride(1) == 1
     tiles = ((N + 255) // 256) * ((K + 255) // 256)
     if splits is None:
-        cap = 32 if min(N, K) <= 64 else 8          # a skinny output (LoRA adapter gradients) is a pass over the long operand:
-        splits = 1 if tiles >= 192 else max(1, min(cap, 256 // tiles, M // 64))   # enough workgroups to pull it at HBM speed
+        splits = tn_splits(N, K, M)
     if out is None:
+        assert not accumulate
         out = torch.empty((N, K), dtype=torch.bfloat16, device=a.device)
     assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.shape == (N, K)
-    if splits == 1:
+    if splits == 1 and not accumulate:
         _lib.check(_L().ecgb_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), K, M, N, K, float(alpha), 1, _st()))
         return out
-    acc = torch.zeros((N, K), dtype=torch.float32, device=a.device)
-    _lib.check(_L().ecgb_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(acc), K, M, N, K, float(alpha), splits, _st()))
-    _lib.check(_L().ecgb_f32_to_bf16(_p(acc), _p(out), acc.numel(), _st()))
-    return out
+    if splits == 1:
+        tmp = torch.empty((N, K), dtype=torch.bfloat16, device=a.device)
+        _lib.check(_L().ecgb_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(tmp), K, M, N, K, float(alpha), 1, _st()))
+        return add(out, tmp, out=out)
+    slabs = torch.empty((splits, N * K), dtype=torch.float32, device=a.device)
+    _lib.check(_L().ecgb_gemm_tn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(slabs), K, M, N, K, float(alpha), splits, _st()))
+    return sum_slabs(slabs, out, accumulate)
 
 
 def gemm_nt_heads(a, lda, b, ldb, c, ldc, M, N, K, alpha, batch, inner, outer_a, inner_a, div_a, outer_b, inner_b, div_b,

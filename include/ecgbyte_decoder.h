@@ -61,6 +61,9 @@ int ecgb_transpose_bf16_strided(const void *in_dev, void *out_dev, int rows, int
                                 int batch, int inner, long long outer_in, long long inner_in, long long outer_out,
                                 long long inner_out, void *stream);
 int ecgb_f32_to_bf16(const float *in_dev, void *out_dev, size_t n, void *stream);
+/* out[i] = bf16(sum_s slabs[s * slab_stride + i]) for i < n, summed in slab order; accumulate != 0: added to the bf16 already in out.
+ * The K-slices of ecgb_gemm_tn_bf16 (splits > 1) meet here.  n, slab_stride multiples of 4. */
+int ecgb_sum_slabs_bf16(const float *slabs_dev, long long slab_stride, int n_slabs, void *out_dev, size_t n, int accumulate, void *stream);
 
 /* C[M,N] = alpha * A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulation on the matrix cores.
  * accumulate_f32 = 0: C is bf16; 1: C is fp32 and C += result; 2: C is bf16 and C += result (LoRA branch added to
@@ -106,7 +109,8 @@ int ecgb_colsum(const void *dy_dev, float *out_dev, size_t rows, int n, void *st
 /* Weight-gradient product without transposed copies: C[N,K] = alpha * A^T . B with A = [M,N] and B = [M,K]
  * row-major (dW = dY^T . X, the contraction index is the row index of both operands).  M % 64 == 0.
  * splits == 1: C is bf16.  splits > 1: the contraction is cut into `splits` slices run by separate workgroups
- * (small outputs would otherwise leave most CUs idle) and C must be a ZEROED fp32 buffer that receives the sum. */
+ * (small outputs would otherwise leave most CUs idle) and C is fp32 [splits][N, ldc]: slice s stores its partial product
+ * in slab s (no zeroing needed, no atomics; ecgb_sum_slabs_bf16 adds the slabs in slice order). */
 int ecgb_gemm_tn_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
                       int M, int N, int K, float alpha, int splits, void *stream);
 /* Output tile choice: 0 = automatic (256x256 tiles / 8 waves on v_mfma_f32_16x16x32_bf16 when they fill the chip,

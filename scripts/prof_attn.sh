@@ -12,7 +12,8 @@ for f in glob.glob("gpurun_out/attn_pmc*/**/*counter_collection.csv", recursive=
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
         if "attn_" not in k: continue
-        name = k.split("::")[-1].split("(")[0] + " grid" + row["Grid_Size"]
+        import re
+        name = re.search(r"(attn_\w+<[^>]*>)", k).group(1) + " grid" + row["Grid_Size"]
         per[(name, row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"])
     for (name, d, c), v in per.items(): acc[name][c].append(v)
 for name in sorted(acc):

@@ -26,7 +26,7 @@ def _close(got, ref, atol, rtol=2 ** -7):
     got, ref = got.float(), ref.float()
     err = (got - ref).abs()
     tol = atol + rtol * ref.abs()
-    assert bool((err <= tol).all()), f"max err {err.max().item():.4g} (tol {tol[err.argmax()].item():.4g})"
+    assert bool((err <= tol).all()), f"max err {err.max().item():.4g} (tol {tol.flatten()[err.argmax()].item():.4g})"
 
 
 @pytest.mark.parametrize("tile", [128, 256, 257, 258])
@@ -286,6 +286,29 @@ def test_gemm_tn_weight_gradient(ops, M, N, K):
     ref = dy.float().T @ x.float()
     _close(ops.gemm_tn(dy, x), ref, atol=1e-2 * math.sqrt(M) / 4)
     _close(ops.gemm_tn(dy, x, alpha=0.25), 0.25 * ref, atol=1e-2 * math.sqrt(M) / 8)
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(128, 256, 512, 8), (1024, 520, 264, 3), (4096, 2048, 2048, 4), (2048, 64, 2048, 32)])
+def test_gemm_tn_k_slices_meet_in_slabs(ops, M, N, K, splits):
+    """The contraction cut into slices (more slices than K-tiles in the first case: the empty ones contribute zeros): each slice's
+    partial product is stored to its own fp32 slab and the slabs are summed in order, so the result is the same bits on every run;
+    accumulate adds to the bf16 already in the destination."""
+    dy, x = _bf(M, N, seed=42), _bf(M, K, seed=43)
+    ref = dy.float().T @ x.float()
+    out = torch.full((N, K), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.gemm_tn(dy, x, splits=splits, out=out)
+    _close(out, ref, atol=1e-2 * math.sqrt(M) / 4)
+    again = ops.gemm_tn(dy, x, splits=splits)
+    assert torch.equal(out, again)
+    base = _bf(N, K, seed=44)
+    acc = base.clone()
+    ops.gemm_tn(dy, x, splits=splits, out=acc, accumulate=True)
+    want = base.float() + ref
+    tol = 1e-2 * math.sqrt(M) / 4 + 2 ** -7 * (base.float().abs() + ref.abs())      # one bf16 rounding of the sum (two with splits=1)
+    assert bool(((acc.float() - want).abs() <= tol).all())
+    acc1 = base.clone()
+    ops.gemm_tn(dy, x, splits=1, out=acc1, accumulate=True)
+    assert bool(((acc1.float() - want).abs() <= tol).all())
 
 
 def test_sumsq_multi_equals_per_tensor_sum(ops):
