@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <type_traits>
 
 #include "tokenizer.hpp"
 
@@ -31,6 +32,14 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr float kLog2e = 1.4426950408889634f;
 // 2^x as one v_exp_f32 (results below 2^-126 flush to zero, which a softmax weight may)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// max(a, b, c) as ONE instruction: fmaxf on MFMA results costs a canonicalising v_max per operand on top
+__device__ __forceinline__ float max3(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 __device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
 
@@ -48,6 +57,33 @@ struct AttnArgs {
     int B, S, Hq, Hkv;
     float scale;
 };
+
+// ---- workgroup -> (block, head, batch) ------------------------------------------------------------------------------------------
+// Under the causal mask the work of a block grows with its index (query blocks) or shrinks with it (key blocks), and the hardware deals
+// consecutive workgroups to the 8 XCDs in turn: with the block index as blockIdx.x and 8 blocks per head (S = 1024), XCD k ran block k of
+// EVERY head -- XCD 7 had 16 K/V tiles per workgroup, XCD 0 two, and the kernel took as long as XCD 7 (1.8 x the balanced time; the
+// counters showed 1.1 resident waves per SIMD where 2 fit).  The grids are 1-D now:
+//   * (batch, KV head) groups a multiple of 8: group -> XCD group % 8, so a group's K and V stay in ONE L2; inside the XCD the groups run
+//     one after the other, each with its heaviest blocks first;
+//   * otherwise: the block index is rotated by the head index, so every XCD still sees every block size.
+// n_blk blocks, `heads` workgroups per block and group (the query heads of the group for forward / dQ, 1 for dK/dV, whose workgroups
+// loop over the heads themselves).
+__device__ __forceinline__ void map_block(int L, int n_blk, int heads, int n_groups, bool heavy_last, int &blk, int &head_in, int &group)
+{
+    const int per_group = n_blk * heads;
+    if ((n_groups & 7) == 0) {
+        const int xcd = L & 7, j = L >> 3;
+        group = (j / per_group) * 8 + xcd;
+        const int inner = j % per_group, rank = inner / heads;
+        head_in = inner % heads;
+        blk = heavy_last ? n_blk - 1 - rank : rank;
+    } else {
+        const int hl = L / n_blk, r = L % n_blk;
+        blk = (r + hl) % n_blk;
+        group = hl / heads;
+        head_in = hl % heads;
+    }
+}
 
 // ---- LDS tile helpers (tiles of 64 rows x D) -----------------------------------------------------------
 // Staging work item = 4 consecutive rows x one 16-byte chunk (8 d): 16 row groups x D/8 chunks per tile, i.e.
@@ -159,7 +195,7 @@ __device__ __forceinline__ void store_accT(const f32x16 (&acc)[NB], unsigned sho
 }
 
 // =====================================================================================================
-// forward: grid (ceil(S/128), Hq, B)
+// forward: 1-D grid of ceil(S/128) x Hq x B workgroups, dealt by map_block()
 template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
 {
@@ -172,8 +208,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
     auto lds_mask2 = [&](int i) { return reinterpret_cast<float *>(smem + 4 * kTile) + 64 * i; };
     int *lds_flag2 = reinterpret_cast<int *>(smem + 4 * kTile + 512);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, hq = blockIdx.y, g = hq / (A.Hq / A.Hkv);
-    const int q0 = blockIdx.x * 128;
+    int qblk, head_in, group;
+    map_block((int)blockIdx.x, (A.S + 127) / 128, A.Hq / A.Hkv, A.B * A.Hkv, true, qblk, head_in, group);
+    const int b = group / A.Hkv, g = group % A.Hkv, hq = g * (A.Hq / A.Hkv) + head_in;
+    const int q0 = qblk * 128;
     const int qi = q0 + wave * 32 + lr;
     const bool qvalid = qi < A.S;
     const long long rowbase = (long long)b * A.S;
@@ -221,67 +259,77 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
         const float *lds_mask = lds_mask2(it & 1);
         const int lds_flag = lds_flag2[it & 1];
         if (k0 <= wave_qmax) {
-        // masks only matter on tiles that touch the diagonal of this wave's rows or hold padded keys
-        const bool need_mask = (k0 + 63 > q0 + wave * 32) || lds_flag;
-        float p[2][16];
-        float tmax = -INFINITY;
-        f32x16 sacc[2];                                         // the two key halves' chains interleaved: an MFMA never
-#pragma unroll                                                  // waits for the one issued just before it
-        for (int kb = 0; kb < 2; ++kb)
+            // masks only matter on tiles that touch the diagonal of this wave's rows or hold padded keys: two code paths chosen per
+            // wave and tile (one `if` around the score loop alone is if-converted by hipcc: every tile then paid the ~130 compare /
+            // select instructions of the masked form, a third of the loop's vector instructions)
+            // (head_dim 128 / 256: one path with the choice inside -- two copies of the wider loop body cost more registers than a
+            // wave has, and the MFMA share of a tile is 2-4 x larger there)
+            const bool need_mask = (k0 + 63 > q0 + wave * 32) || lds_flag;
+            auto tile = [&](auto mode_tag) {
+                constexpr int MODE = decltype(mode_tag)::value;          // 0 = no masks, 1 = masks, 2 = decided here
+                float p[2][16];
+                float tmax = -INFINITY;
+                f32x16 sacc[2];                                     // the two key halves' chains interleaved: an MFMA never
+#pragma unroll                                                      // waits for the one issued just before it
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < D / 16; ++ks)
+                for (int ks = 0; ks < D / 16; ++ks)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_k, kb * 32 + lr, ks, h), qf[ks], sacc[kb], 0, 0, 0);
+                    for (int kb = 0; kb < 2; ++kb)
+                        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_k, kb * 32 + lr, ks, h), qf[ks], sacc[kb], 0, 0, 0);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const f32x16 &s = sacc[kb];
-            if (need_mask) {
-                float4 mk4[4];                                                   // the lane's 16 keys are 4 runs of 4: four 16-byte reads,
-#pragma unroll   // (not sixteen dependent 4-byte reads behind a branch each)
-                for (int g4 = 0; g4 < 4; ++g4) mk4[g4] = *reinterpret_cast<const float4 *>(&lds_mask[kb * 32 + 8 * g4 + 4 * h]);
+                for (int kb = 0; kb < 2; ++kb) {
+                    const f32x16 &s = sacc[kb];
+                    if (MODE == 1 || (MODE == 2 && need_mask)) {
+                        float4 mk4[4];                                           // the lane's 16 keys are 4 runs of 4: four 16-byte reads
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;       // key inside the tile
-                    const float mkv = (r & 3) == 0 ? mk4[r >> 2].x : (r & 3) == 1 ? mk4[r >> 2].y : (r & 3) == 2 ? mk4[r >> 2].z : mk4[r >> 2].w;
-                    const bool vis = (k0 + kl <= qi) & (mkv != 0.f);
-                    const float v = vis ? s[r] : -INFINITY;
-                    p[kb][r] = v;
-                    tmax = fmaxf(tmax, v);
+                        for (int g4 = 0; g4 < 4; ++g4) mk4[g4] = *reinterpret_cast<const float4 *>(&lds_mask[kb * 32 + 8 * g4 + 4 * h]);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;       // key inside the tile
+                            const float mkv = (r & 3) == 0 ? mk4[r >> 2].x : (r & 3) == 1 ? mk4[r >> 2].y : (r & 3) == 2 ? mk4[r >> 2].z : mk4[r >> 2].w;
+                            const bool vis = (k0 + kl <= qi) & (mkv != 0.f);
+                            const float v = vis ? s[r] : -INFINITY;
+                            p[kb][r] = v;
+                            tmax = fmaxf(tmax, v);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) { p[kb][r] = s[r]; p[kb][r + 1] = s[r + 1]; tmax = max3(s[r], s[r + 1], tmax); }
+                    }
                 }
-            } else {
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sc;      // p holds raw scores; sc > 0, so the maximum scales with them
+                const float m_new = fmaxf(m, tmax);
+                const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;   // no key visible yet: every p below is exp2(-inf) = 0
+                const float alpha = fast_exp2(m - m_safe);                     // m = -inf -> 0 (accumulators are still zero then)
+                float lsum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { const float v = s[r]; p[kb][r] = v; tmax = fmaxf(tmax, v); }
-            }
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sc;      // p holds raw scores; sc > 0, so the maximum scales with them
-        const float m_new = fmaxf(m, tmax);
-        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;   // no key visible yet: every p below is exp2(-inf) = 0
-        const float alpha = fast_exp2(m - m_safe);                     // m = -inf -> 0 (accumulators are still zero then)
-        float lsum = 0.f;
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+                    for (int r = 0; r < 16; ++r) { const float e = fast_exp2(__builtin_fmaf(p[kb][r], sc, -m_safe)); p[kb][r] = e; lsum += e; }
+                l = l * alpha + lsum;
+                m = m_new;
+                if (__any(alpha != 1.f)) {   // once the running maxima have settled the accumulators need no rescale
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float e = fast_exp2(__builtin_fmaf(p[kb][r], sc, -m_safe)); p[kb][r] = e; lsum += e; }
-        l = l * alpha + lsum;
-        m = m_new;
-        if (__any(alpha != 1.f)) {   // once the running maxima have settled the accumulators need no rescale
+                    for (int db = 0; db < D / 32; ++db)
 #pragma unroll
-            for (int db = 0; db < D / 32; ++db)
+                        for (int r = 0; r < 16; ++r) accO[db][r] *= alpha;
+                }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) accO[db][r] *= alpha;
-        }
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8 pf = frag_from_acc(&p[kb][8 * s2]);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pf = frag_from_acc(&p[kb][8 * s2]);
-#pragma unroll
-                for (int db = 0; db < D / 32; ++db)
-                    accO[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_vt, db * 32 + lr, kb, s2, h), pf, accO[db], 0, 0, 0);
-            }
+                        for (int db = 0; db < D / 32; ++db)
+                            accO[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_vt, db * 32 + lr, kb, s2, h), pf, accO[db], 0, 0, 0);
+                    }
+            };
+            if constexpr (D > 64) tile(std::integral_constant<int, 2>{});
+            else if (need_mask) tile(std::integral_constant<int, 1>{});
+            else tile(std::integral_constant<int, 0>{});
         }
         if (more) write_tile((it + 1) & 1, k0 + 64);   // its last readers passed the barrier that ended the previous trip
         __syncthreads();
@@ -293,7 +341,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
 }
 
 // =====================================================================================================
-// backward, dQ (and delta): grid (ceil(S/128), Hq, B); lanes = queries
+// backward, dQ (and delta): 1-D grid of ceil(S/128) x Hq x B workgroups (map_block); lanes = queries
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
 {
@@ -303,8 +351,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
     float *lds_mask = reinterpret_cast<float *>(smem + 3 * kTile);
     int &lds_flag = *reinterpret_cast<int *>(smem + 3 * kTile + 256);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, hq = blockIdx.y, g = hq / (A.Hq / A.Hkv);
-    const int q0 = blockIdx.x * 128;
+    int qblk, head_in, group;
+    map_block((int)blockIdx.x, (A.S + 127) / 128, A.Hq / A.Hkv, A.B * A.Hkv, true, qblk, head_in, group);
+    const int b = group / A.Hkv, g = group % A.Hkv, hq = g * (A.Hq / A.Hkv) + head_in;
+    const int q0 = qblk * 128;
     const int qi = q0 + wave * 32 + lr;
     const bool qvalid = qi < A.S;
     const long long rowbase = (long long)b * A.S;
@@ -398,7 +448,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
 }
 
 // =====================================================================================================
-// backward, dK and dV: grid (ceil(S/128), Hkv, B); lanes = keys; loops over the query heads of the group
+// backward, dK and dV: 1-D grid of ceil(S/128) x Hkv x B workgroups (map_block); lanes = keys; loops over the query heads of the group
 // DS > 1 (head_dim 256): the d range of the dK / dV accumulators is split over DS workgroups (blockIdx.x % DS): K, V fragments and
 // two full accumulator sets of head_dim 256 do not fit one wave's 512 registers; the S and dP products are recomputed per split.
 // WHICH: 0 = dK and dV in one pass (head_dim 64 / 128); 1 = dV only, 2 = dK only -- at head_dim 256 the two gradients are two launches,
@@ -406,7 +456,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
 // work of a single pass instead of the 2.5 x of splitting the d range four ways (DS = 4, the first head_dim-256 version: 3.3 ms per
 // layer at Gemma-2B's shape).
 template <int D, int DS, int WHICH>
-__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs &A, const int block_x)
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs &A, const int block_x, const int b, const int g)
 {
     constexpr bool DO_V = WHICH != 2, DO_K = WHICH != 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 4 x 128 D bytes + 512
@@ -415,7 +465,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs &A, const int b
     float *lds_lse = reinterpret_cast<float *>(smem + 4 * kTile), *lds_delta = lds_lse + 64;
     constexpr int NB = D / 32 / DS;                          // 32-wide d blocks this workgroup accumulates
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, g = blockIdx.y, G = A.Hq / A.Hkv;
+    const int G = A.Hq / A.Hkv;
     const int kk0 = (block_x / DS) * 128, db0 = (block_x % DS) * NB;
     const int ki = kk0 + wave * 32 + lr;
     const bool kvalid = ki < A.S;
@@ -519,15 +569,19 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs &A, const int b
 template <int D, int DS, int WHICH = 0>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(AttnArgs A)   // head_dim 64: two waves per SIMD (<= 256 registers)
 {
-    attn_bwd_dkv_body<D, DS, WHICH>(A, (int)blockIdx.x);
+    int blk, head_in, group;
+    map_block((int)blockIdx.x, ((A.S + 127) / 128) * DS, 1, A.B * A.Hkv, false, blk, head_in, group);   // key block 0 sees every query: first
+    attn_bwd_dkv_body<D, DS, WHICH>(A, blk, group / A.Hkv, group % A.Hkv);
 }
 // head_dim 256: the dV pass and the dK pass of a key block as two workgroups of ONE launch (even / odd blockIdx.x) -- Gemma's single KV
 // head gives only S / 128 x batch key blocks, half a chip's worth at C5's shape
 template <int D>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pair_kernel(AttnArgs A)
 {
-    if (blockIdx.x & 1) attn_bwd_dkv_body<D, 1, 2>(A, (int)(blockIdx.x >> 1));
-    else attn_bwd_dkv_body<D, 1, 1>(A, (int)(blockIdx.x >> 1));
+    int blk, head_in, group;
+    map_block((int)blockIdx.x, ((A.S + 127) / 128) * 2, 1, A.B * A.Hkv, false, blk, head_in, group);
+    if (blk & 1) attn_bwd_dkv_body<D, 1, 2>(A, blk >> 1, group / A.Hkv, group % A.Hkv);
+    else attn_bwd_dkv_body<D, 1, 1>(A, blk >> 1, group / A.Hkv, group % A.Hkv);
 }
 
 // =====================================================================================================
@@ -836,7 +890,7 @@ extern "C" int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev
     A.B = batch; A.S = seq; A.Hq = n_q_heads; A.Hkv = n_kv_heads; A.scale = scale;
     int rc = check_args(A, head_dim, "ecgb_attn_fwd");
     if (rc) return rc;
-    const dim3 grid((unsigned)((seq + 127) / 128), (unsigned)n_q_heads, (unsigned)batch);
+    const dim3 grid((unsigned)((seq + 127) / 128) * (unsigned)n_q_heads * (unsigned)batch);   // 1-D: map_block() deals blocks to XCDs
 #define ECGB_FWD(D_) do { const int lds = 4 * 128 * D_ + 520; \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_kernel<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) break; \
         hipLaunchKernelGGL(attn_fwd_kernel<D_>, grid, dim3(256), lds, (hipStream_t)stream, A); } while (0)
@@ -861,11 +915,12 @@ extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev
     int rc = check_args(A, head_dim, "ecgb_attn_bwd");
     if (rc) return rc;
     if (lddq % 4 || lddk % 4 || lddv % 4) { ecgb::set_error("ecgb_attn_bwd: gradient row strides must be multiples of 4"); return ECGB_ERR_UNSUPPORTED; }
-    const dim3 gq((unsigned)((seq + 127) / 128), (unsigned)n_q_heads, (unsigned)batch);
-    const dim3 gk((unsigned)((seq + 127) / 128), (unsigned)n_kv_heads, (unsigned)batch);
+    const unsigned nblk = (unsigned)((seq + 127) / 128);
+    const dim3 gq(nblk * (unsigned)n_q_heads * (unsigned)batch);          // 1-D: map_block() deals blocks to XCDs
+    const unsigned gk = nblk * (unsigned)n_kv_heads * (unsigned)batch;
 #define ECGB_DKV(D_, DS_, W_) do { \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<D_, DS_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, lk) != hipSuccess) break; \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D_, DS_, W_>), dim3(gk.x * DS_, gk.y, gk.z), dim3(256), lk, (hipStream_t)stream, A); } while (0)
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D_, DS_, W_>), dim3(gk * DS_), dim3(256), lk, (hipStream_t)stream, A); } while (0)
 #define ECGB_BWD(D_) do { const int lq = 3 * 128 * D_ + 260; \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, lq) != hipSuccess) break; \
         hipLaunchKernelGGL(attn_bwd_dq_kernel<D_>, gq, dim3(256), lq, (hipStream_t)stream, A); \
@@ -876,7 +931,7 @@ extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev
         ECGB_BWD(256);
         const int lk = 4 * 128 * 256 + 512;
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_pair_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, lk) == hipSuccess)
-            hipLaunchKernelGGL(attn_bwd_dkv_pair_kernel<256>, dim3(gk.x * 2, gk.y, gk.z), dim3(256), lk, (hipStream_t)stream, A);
+            hipLaunchKernelGGL(attn_bwd_dkv_pair_kernel<256>, dim3(gk * 2), dim3(256), lk, (hipStream_t)stream, A);
     }
 #undef ECGB_BWD
 #undef ECGB_DKV

@@ -2,8 +2,8 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d gpurun_out/attn_pmc1 -- python3 scripts/dev_attn_gemma.py > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/attn_pmc2 -- python3 scripts/dev_attn_gemma.py > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU --output-format csv -d gpurun_out/attn_pmc1 -- python3 ${ATTN_SCRIPT:-scripts/dev_attn_gemma.py} > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/attn_pmc2 -- python3 ${ATTN_SCRIPT:-scripts/dev_attn_gemma.py} > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
