@@ -33,7 +33,8 @@ constexpr float kLog2e = 1.4426950408889634f;
 // 2^x as one v_exp_f32 (results below 2^-126 flush to zero, which a softmax weight may)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// max(a, b, c) as ONE instruction: fmaxf on MFMA results costs a canonicalising v_max per operand on top
+// max(a, b, c) as ONE instruction: fmaxf on MFMA results costs a canonicalising v_max per operand on top.  The caller orders it behind
+// the MFMAs that produce its operands (see attn_fwd_kernel).
 __device__ __forceinline__ float max3(float a, float b, float c)
 {
     float r;
@@ -279,6 +280,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
                         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_k, kb * 32 + lr, ks, h), qf[ks], sacc[kb], 0, 0, 0);
+                // max3() below is inline asm: hipcc's hazard recogniser does not look inside it, and a vector instruction that reads an
+                // MFMA result needs 19 wait states after a 16-pass MFMA (nothing interlocks: the first version read stale registers now
+                // and then -- a slightly different running maximum, a softmax that differed in the last bits from run to run).  The
+                // accumulators pass through this statement, so everything after it is ordered behind the wait.
+                if constexpr (MODE == 0) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0]), "+v"(sacc[1]));
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     const f32x16 &s = sacc[kb];

@@ -13,6 +13,7 @@
 
 #include <string>
 
+#include "glu_math.hpp"
 #include "tokenizer.hpp"
 
 namespace {
@@ -278,22 +279,9 @@ __global__ __launch_bounds__(256) void rope_kernel(unsigned short *x, const floa
 // ---- SwiGLU / GeGLU ------------------------------------------------------------------------------
 // gu: [T, 2*I] with gate in [:, :I] and up in [:, I:]  (one fused gate|up projection);  h: [T, I]
 template <bool GELU_TANH>
-__device__ __forceinline__ float act(float g)
-{
-    if (GELU_TANH) { const float k = 0.7978845608028654f; return 0.5f * g * (1.f + tanhf(k * (g + 0.044715f * g * g * g))); }
-    return g / (1.f + __expf(-g));
-}
+__device__ __forceinline__ float act(float g) { return ecgb::glu_act<GELU_TANH>(g); }
 template <bool GELU_TANH>
-__device__ __forceinline__ float act_grad(float g)
-{
-    if (GELU_TANH) {
-        const float k = 0.7978845608028654f;
-        const float u = k * (g + 0.044715f * g * g * g), t = tanhf(u);
-        return 0.5f * (1.f + t) + 0.5f * g * (1.f - t * t) * k * (1.f + 3.f * 0.044715f * g * g);
-    }
-    const float s = 1.f / (1.f + __expf(-g));
-    return s * (1.f + g * (1.f - s));
-}
+__device__ __forceinline__ float act_grad(float g) { return ecgb::glu_act_grad<GELU_TANH>(g); }
 
 template <bool GELU_TANH>
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const unsigned short *gu, unsigned short *h, size_t T, int I)

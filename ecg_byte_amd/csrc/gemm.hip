@@ -19,6 +19,7 @@
 #include <string>
 #include <type_traits>
 
+#include "glu_math.hpp"
 #include "tokenizer.hpp"
 
 namespace {
@@ -52,6 +53,13 @@ struct GemmArgs {
     // the caller sums the slabs in slice order -- fp32 atomics into one buffer cost 0.15-0.2 ms per launch on the chip-wide L2
     // miss path and made the weight gradients differ from run to run)
     long long split_stride = 0;
+    // GLU epilogue (gemm_nt_kernel_m16p<.., EPI>): B is the fused gate|up weight [2 * glu_I, K] (gate rows, then up rows); an output
+    // tile takes 128 gate rows and the 128 up rows of the SAME columns, interleaved in blocks of 16 so that a lane holds gate[j] and
+    // up[j] side by side: H[M, glu_I] = act(gate) * up leaves in the epilogue, gate|up themselves go to C ([M, 2 * glu_I], or skipped
+    // when C is null: inference needs only H).
+    unsigned short *H = nullptr;
+    long long ldh = 0;
+    int glu_I = 0;
 };
 
 __device__ __forceinline__ unsigned short f2bf_rn(float f)
@@ -64,9 +72,11 @@ __device__ __forceinline__ unsigned short f2bf_rn(float f)
 
 // Issue the LDS-DMA loads of one ROWS x 64 operand tile: ROWS/8 wave-instructions of 1 KiB (8 rows each),
 // ROWS/8/NW per wave.  LDS image: row r at r*128 B, slot s (16 B) holds logical chunk s ^ ((r >> 1) & 7).
-template <int ROWS, int NW>
+// GLU_I > 0 (run-time value, compile-time switch GLU): tile row r is gate row row0/2 + 16*(r>>5) + (r&15) when (r>>4) is even, else the
+// up row GLU_I + the same.
+template <int ROWS, int NW, bool GLU = false>
 __device__ __forceinline__ void stage_tile(const unsigned short *g, long long ld, int row0, int rows_valid, int k0,
-                                           unsigned char *lds_tile, int wave, int lane)
+                                           unsigned char *lds_tile, int wave, int lane, int glu_I = 0)
 {
     constexpr int PER_WAVE = ROWS / 8 / NW;
 #pragma unroll
@@ -76,6 +86,7 @@ __device__ __forceinline__ void stage_tile(const unsigned short *g, long long ld
         const int slot = lane & 7;
         const int chunk = slot ^ ((r >> 1) & 7);
         int gr = row0 + r;
+        if constexpr (GLU) gr = (row0 >> 1) + ((r >> 5) << 4) + (r & 15) + (((r >> 4) & 1) ? glu_I : 0);
         gr = gr < rows_valid ? gr : rows_valid - 1;    // clamp: out-of-range rows are never stored
         const unsigned short *src = g + (long long)gr * ld + k0 + chunk * 8;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
@@ -401,7 +412,39 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16(GemmArgs G)
 // its last read: the B region of the buffer is refilled for tile t+2 in phase 3 of tile t, the A region in phase 4
 // -- more than a whole K-tile ahead of their use.  Tile t+1 is waited for in phase 4 of tile t with the eight loads
 // of tile t+2 left in flight (vmcnt 8, never 0 inside the loop) and first read one barrier later.
-template <int BM, int BN, int WGM, int WGN, bool CAT = false>
+// GLU epilogue of the 16x16x32 kernels (EPI 1 = SiLU, 2 = tanh-GELU): tile (i, 2p) is gate, (i, 2p + 1) up of the same 16 columns.
+// The arithmetic is glu_fwd_kernel's on the bf16-rounded projections (glu_math.hpp), so fused and unfused agree bit for bit.
+template <int EPI, int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void store_tile_glu(const f32x4 (&acc)[TM][TN], const GemmArgs &G, int row0, int col0, int wr, int wc, int lm, int lq)
+{
+    using us4 = __attribute__((ext_vector_type(4))) unsigned short;
+    const float alpha = G.alpha;
+    unsigned short *C = reinterpret_cast<unsigned short *>(G.C);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = row0 + wr * WTM + i * 16 + lm;
+        if (r >= G.M) continue;
+#pragma unroll
+        for (int p = 0; p < TN / 2; ++p) {
+            const int c = (col0 >> 1) + wc * (WTN / 2) + p * 16 + lq * 4;       // column of H = gate column of C
+            us4 g, u, h;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                g[t] = f2bf_rn(acc[i][2 * p][t] * alpha);
+                u[t] = f2bf_rn(acc[i][2 * p + 1][t] * alpha);
+                const float a = __uint_as_float((unsigned)f2bf_rn(ecgb::glu_act<EPI == 2>(__uint_as_float((unsigned)g[t] << 16))) << 16);
+                h[t] = f2bf_rn(a * __uint_as_float((unsigned)u[t] << 16));
+            }
+            if (C) {
+                *reinterpret_cast<us4 *>(C + (long long)r * G.ldc + c) = g;
+                *reinterpret_cast<us4 *>(C + (long long)r * G.ldc + G.glu_I + c) = u;
+            }
+            *reinterpret_cast<us4 *>(G.H + (long long)r * G.ldh + c) = h;
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, bool CAT = false, int EPI = 0>
 __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
 {
     static_assert(BM == 256 && BN == 256 && WGM == 2 && WGN == 4, "phase schedule written for the 256x256 tile, 2x4 waves");
@@ -452,9 +495,9 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
     auto stage_b = [&](int t, unsigned char *dst) {
         if constexpr (CAT) {
             const bool second = t >= KT1;
-            stage_tile<BN, NW>(second ? G.B2 : B, second ? G.ldb2 : G.ldb, col0, G.N, (second ? t - KT1 : t) * BK, dst, wave, lane);
+            stage_tile<BN, NW, EPI != 0>(second ? G.B2 : B, second ? G.ldb2 : G.ldb, col0, G.N, (second ? t - KT1 : t) * BK, dst, wave, lane, G.glu_I);
         } else {
-            stage_tile<BN, NW>(B, G.ldb, col0, G.N, t * BK, dst, wave, lane);
+            stage_tile<BN, NW, EPI != 0>(B, G.ldb, col0, G.N, t * BK, dst, wave, lane, G.glu_I);
         }
     };
 
@@ -529,7 +572,8 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
         mfma_quadrant(1, 0);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();          // barrier counts of the two rows match again
-    store_tile_m16<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, off_c);
+    if constexpr (EPI != 0) store_tile_glu<EPI, TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq);
+    else store_tile_m16<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, off_c);
 }
 
 // Epilogue of the TN kernels: bf16 store, or fp32 atomics when the contraction is split over workgroups.
@@ -1152,5 +1196,44 @@ extern "C" int ecgb_gemm_tn_bf16(const void *a_dev, long long lda, const void *b
         e = hipGetLastError();
     }
     if (e != hipSuccess) { ecgb::set_error(std::string("gemm_tn_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
+}
+
+// H[M, I] = act(gate) * up with gate | up = alpha * (A . B^T [+ A2 . B2^T]),  B = [2 I, K] (gate rows, then up rows): the gate|up
+// projection of the MLP with the GLU in its epilogue (modeling_llama.py:227-258 `down_proj(act_fn(gate_proj(x)) * up_proj(x))`,
+// modeling_gemma.py's GeGLU with gelu_tanh != 0).  c_dev ([M, 2 I] bf16, what the backward needs) may be null.  A2 / B2 ([M, K2],
+// [2 I, K2]) as in ecgb_gemm_nt_bf16_cat, or null.  M % 1 free, I % 128 == 0, K % 64 == 0.
+extern "C" int ecgb_gemm_nt_glu_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, const void *a2_dev, long long lda2,
+                                     const void *b2_dev, long long ldb2, int K2, void *c_dev, long long ldc, void *h_dev, long long ldh,
+                                     int M, int inter, int K, float alpha, int gelu_tanh, void *stream)
+{
+    if (!a_dev || !b_dev || !h_dev || M <= 0 || inter <= 0 || K <= 0 || (K2 > 0 && (!a2_dev || !b2_dev))) {
+        ecgb::set_error("ecgb_gemm_nt_glu_bf16: bad argument");
+        return ECGB_ERR_INVALID;
+    }
+    if (K % BK || K2 % BK || inter % 128 || lda % 8 || ldb % 8 || lda2 % 8 || ldb2 % 8 || ldc % 4 || ldh % 4 ||
+        (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)a2_dev | (uintptr_t)b2_dev) & 15) || (((uintptr_t)c_dev | (uintptr_t)h_dev) & 7)) {
+        ecgb::set_error("ecgb_gemm_nt_glu_bf16: K % 64, inter % 128, 16-byte aligned operands, strides % 8 (outputs % 4) required");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    GemmArgs G;
+    G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = c_dev;
+    G.M = M; G.N = 2 * inter; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = ldc;
+    G.batch_a = G.batch_b = G.batch_c = 0;
+    G.accumulate_f32 = 0; G.alpha = alpha;
+    G.A2 = (const unsigned short *)a2_dev; G.B2 = (const unsigned short *)b2_dev; G.lda2 = lda2; G.ldb2 = ldb2; G.K2 = K2 > 0 ? K2 : 0;
+    G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
+    G.H = (unsigned short *)h_dev; G.ldh = ldh; G.glu_I = inter;
+    G.tiles_m = (M + 255) / 256; G.tiles_n = (2 * inter) / 256;
+    constexpr int lds = 2 * (256 + 256) * BK * 2;
+    using Kern = void (*)(GemmArgs);
+    Kern kern = gelu_tanh ? (G.K2 ? (Kern)gemm_nt_kernel_m16p<256, 256, 2, 4, true, 2> : (Kern)gemm_nt_kernel_m16p<256, 256, 2, 4, false, 2>)
+                          : (G.K2 ? (Kern)gemm_nt_kernel_m16p<256, 256, 2, 4, true, 1> : (Kern)gemm_nt_kernel_m16p<256, 256, 2, 4, false, 1>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, 1), dim3(512), lds, (hipStream_t)stream, G);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_kernel (glu): ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
     return ECGB_OK;
 }

@@ -131,8 +131,10 @@ class LoraSite(nn.Module):
         lo = 16 * self.spb * b
         return lo, lo + self.r
 
-    def project(self, x, w, training, keep=False):
-        """y = x W^T + the adapter branch, [T, out].  Returns (y, what backward needs)."""
+    def project(self, x, w, training, keep=False, glu=None):
+        """y = x W^T + the adapter branch, [T, out].  Returns (y, what backward needs).
+        glu = (gelu_tanh, keep_gu): the site is the fused gate|up projection and the GLU runs in the GEMM's epilogue; y is then the pair
+        (gate|up or None, act(gate) * up)."""
         p, seed = 0.0, 0
         if training and self.p > 0:
             self.calls += 1
@@ -141,7 +143,12 @@ class LoraSite(nn.Module):
             t, xd = ops.gemm_nt(x, self.A.data, alpha=self.scale), None
         else:
             t, xd = ops.lora_down(x, self.A.data, self.n_sub, self.n_fields, self.scale, p, seed, keep_masked=keep)
-        y = ops.gemm_nt(x, w, a2=t, b2=self.B.data)
+        if glu is not None and ops.glu_fusable(x.shape[0], w.shape[0] // 2):
+            y = ops.gemm_nt_glu(x, w, gelu_tanh=glu[0], keep_gu=glu[1], a2=t, b2=self.B.data)
+        else:
+            y = ops.gemm_nt(x, w, a2=t, b2=self.B.data)
+            if glu is not None:
+                y = (y if glu[1] else None, ops.glu_fwd(y, gelu_tanh=glu[0]))
         return y, (x, xd, t, p, seed)
 
     def backward(self, dy, saved, model, dx):
@@ -437,6 +444,20 @@ class HipCausalLM(nn.Module):
             return ops.gemm_nt(x, w), None
         return self.lora[i][key].project(x, w, training, keep)
 
+    def _proj_glu(self, i, x, training=False, keep=False, keep_gu=True):
+        """The MLP's gate|up projection with the GLU in the GEMM's epilogue: returns (gate|up [T, 2I] or None, act(gate) * up [T, I],
+        adapter state).  gate|up is what the backward needs; inference passes keep_gu=False and the tensor is never written."""
+        w = self.wgu[i].data
+        if self.lora is not None:
+            (gu, hm), ls = self.lora[i]["gu"].project(x, w, training, keep, glu=(self.gemma, keep_gu))
+            return gu, hm, ls
+        if ops.glu_fusable(x.shape[0], w.shape[0] // 2):
+            gu, hm = ops.gemm_nt_glu(x, w, gelu_tanh=self.gemma, keep_gu=keep_gu)
+        else:
+            gu = ops.gemm_nt(x, w)
+            hm = ops.glu_fwd(gu, gelu_tanh=self.gemma)
+        return gu, hm, None
+
     def _rope_tables(self, position_ids):
         pos = position_ids.reshape(-1).float()
         fr = pos[:, None] * self.inv_freq[None, :].float()
@@ -603,8 +624,7 @@ class HipCausalLM(nn.Module):
                 ao, P = self._attn_materialised(qkv, mask, B, S)
             attn_delta, ls[1] = self._proj(i, "o", ao, self.wo[i].data, self.training, True)   # [T, H]
             h2, rstd2, x2 = ops.rmsnorm_fwd(x1, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma)
-            gu, ls[2] = self._proj(i, "gu", h2, self.wgu[i].data, self.training, True)         # [T, 2I]
-            hm = ops.glu_fwd(gu, gelu_tanh=self.gemma)
+            gu, hm, ls[2] = self._proj_glu(i, h2, self.training, True)                         # [T, 2I], [T, I]
             delta, ls[3] = self._proj(i, "down", hm, self.wdown[i].data, self.training, True)
             saved.append((x1, rstd1, h1, qkv, P, ao, x2, rstd2, h2, gu, hm, ls))
             x = x2
@@ -693,8 +713,7 @@ class HipCausalLM(nn.Module):
                 ao, _ = self._attn_materialised(qkv, mask, B, S)
             attn_delta, _ = self._proj(i, "o", ao, self.wo[i].data)
             h2, _, x = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma)
-            gu, _ = self._proj(i, "gu", h2, self.wgu[i].data)
-            hm = ops.glu_fwd(gu, gelu_tanh=self.gemma)
+            _, hm, _ = self._proj_glu(i, h2, keep_gu=False)
             delta, _ = self._proj(i, "down", hm, self.wdown[i].data)
         hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
         if lpad:
@@ -747,8 +766,7 @@ class HipCausalLM(nn.Module):
                 ao = ops.attn_decode_dyn(qkv, caches[i], mask, n_dev, Hq, Hkv, D, scale)
             attn_delta, _ = self._proj(i, "o", ao, self.wo[i].data)
             h2, _, x = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma)
-            gu, _ = self._proj(i, "gu", h2, self.wgu[i].data)
-            hm = ops.glu_fwd(gu, gelu_tanh=self.gemma)
+            _, hm, _ = self._proj_glu(i, h2, keep_gu=False)
             delta, _ = self._proj(i, "down", hm, self.wdown[i].data)
         hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
         return hf

@@ -169,6 +169,30 @@ def gemm_nt(a, b, out=None, alpha=1.0, accumulate_f32=False, accumulate=False, a
     return out
 
 
+def glu_fusable(M, inter):
+    """Shapes the GLU-epilogue GEMM takes: the 256x256 tile needs whole tiles of 128 gate + 128 up columns and enough of them to fill
+    the chip (a decode step's few rows go through the few-row kernel and the separate GLU)."""
+    return M >= 256 and inter % 128 == 0 and ((M + 255) // 256) * (2 * inter // 256) >= 192
+
+
+def gemm_nt_glu(a, b, gelu_tanh=False, keep_gu=True, a2=None, b2=None, alpha=1.0):
+    """(gate|up, h):  gate|up [M, 2I] = alpha * (A B^T [+ A2 B2^T]) with B = [2I, K] (gate rows, then up rows) and h [M, I] =
+    act(gate) * up computed in the GEMM's epilogue (ecgb_gemm_nt_glu_bf16); keep_gu=False: gate|up is not written (returns None)."""
+    M, K = a.shape
+    inter = b.shape[0] // 2
+    assert b.shape == (2 * inter, K) and a.stride(1) == 1 and b.stride(1) == 1
+    gu = torch.empty((M, 2 * inter), dtype=torch.bfloat16, device=a.device) if keep_gu else None
+    h = torch.empty((M, inter), dtype=torch.bfloat16, device=a.device)
+    K2 = 0
+    if a2 is not None:
+        K2 = a2.shape[1]
+        assert a2.shape[0] == M and b2.shape == (2 * inter, K2) and a2.stride(1) == 1 and b2.stride(1) == 1
+    _lib.check(_L().ecgb_gemm_nt_glu_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(a2), a2.stride(0) if K2 else 0, _p(b2),
+                                          b2.stride(0) if K2 else 0, K2, _p(gu), 2 * inter, _p(h), inter, M, inter, K, float(alpha),
+                                          int(gelu_tanh), _st()))
+    return gu, h
+
+
 def dropout(x, p, seed, out=None):
     """Inverted dropout; the same (p, seed) reproduces the mask (call it on the gradient for the backward)."""
     if out is None:

@@ -106,6 +106,14 @@ int ecgb_bias_act(void *u_dev, const void *bias_dev, void *h_dev, size_t rows, i
 int ecgb_gelu_new_bwd(const void *pre_dev, const void *dh_dev, void *dpre_dev, size_t n, void *stream);
 int ecgb_colsum(const void *dy_dev, float *out_dev, size_t rows, int n, void *stream);
 
+/* The MLP's gate|up projection with the GLU in the GEMM's epilogue (modeling_llama.py:227-258
+ * `down_proj(act_fn(gate_proj(x)) * up_proj(x))`; gelu_tanh != 0: Gemma's GeGLU):  gate|up [M, 2*inter] = alpha * (A . B^T
+ * [+ A2 . B2^T]) with B = [2*inter, K] (gate rows, then up rows), H [M, inter] = act(gate) * up on the bf16-rounded gate and up
+ * (bit for bit ecgb_glu_fwd of the stored projection).  c_dev may be null (inference: gate|up is never written).
+ * a2_dev / b2_dev ([M, K2], [2*inter, K2]) as in ecgb_gemm_nt_bf16_cat, or null with K2 = 0.  inter % 128 == 0, K, K2 % 64 == 0. */
+int ecgb_gemm_nt_glu_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, const void *a2_dev, long long lda2,
+                          const void *b2_dev, long long ldb2, int K2, void *c_dev, long long ldc, void *h_dev, long long ldh,
+                          int M, int inter, int K, float alpha, int gelu_tanh, void *stream);
 /* Weight-gradient product without transposed copies: C[N,K] = alpha * A^T . B with A = [M,N] and B = [M,K]
  * row-major (dW = dY^T . X, the contraction index is the row index of both operands).  M % 64 == 0.
  * splits == 1: C is bf16.  splits > 1: the contraction is cut into `splits` slices run by separate workgroups

@@ -311,6 +311,28 @@ def test_gemm_tn_k_slices_meet_in_slabs(ops, M, N, K, splits):
     assert bool(((acc1.float() - want).abs() <= tol).all())
 
 
+@pytest.mark.parametrize("gelu_tanh", [False, True])
+@pytest.mark.parametrize("M,inter,K,K2", [(4096, 8192, 2048, 0), (4000, 6144, 512, 64), (8192, 3072, 64, 0)])
+def test_gemm_glu_epilogue_is_bitwise_the_separate_kernels(ops, M, inter, K, K2, gelu_tanh):
+    """gate|up projection with the GLU in its epilogue (gate and up rows of the weight interleaved per tile) against the plain GEMM
+    followed by glu_fwd: the same bits in gate|up and in act(gate) * up; ragged row count, the LoRA K-concatenation, and the
+    inference form that never writes gate|up."""
+    assert ops.glu_fusable(M, inter)
+    a, b = _bf(M, K, seed=51), _bf(2 * inter, K, scale=K ** -0.5, seed=52)
+    a2 = _bf(M, K2, seed=53) if K2 else None
+    b2 = _bf(2 * inter, K2, scale=0.1, seed=54) if K2 else None
+    gu_ref = ops.gemm_nt(a, b, a2=a2, b2=b2)
+    h_ref = ops.glu_fwd(gu_ref, gelu_tanh=gelu_tanh)
+    gu, h = ops.gemm_nt_glu(a, b, gelu_tanh=gelu_tanh, a2=a2, b2=b2)
+    assert torch.equal(gu, gu_ref)
+    assert torch.equal(h, h_ref)
+    none, h2 = ops.gemm_nt_glu(a, b, gelu_tanh=gelu_tanh, keep_gu=False, a2=a2, b2=b2)
+    assert none is None and torch.equal(h2, h_ref)
+    g, u = gu_ref[:, :inter].float(), gu_ref[:, inter:].float()
+    act = torch.nn.functional.gelu(g, approximate="tanh") if gelu_tanh else torch.nn.functional.silu(g)
+    _close(h, act.to(torch.bfloat16).float() * u, atol=1e-3)
+
+
 def test_sumsq_multi_equals_per_tensor_sum(ops):
     """One launch over a list of gradient tensors (sizes from 8 elements to a few chunks of 2^20, an unaligned view among
     them) against the fp32 sum of squares."""
