@@ -59,6 +59,14 @@ struct AttnArgs {
     float scale;
 };
 
+#ifdef ECGB_PROFILE
+// dev builds only (`make prof`, scripts/dev_prof_attn.py): cycles per phase of the forward loop, summed over waves
+__device__ unsigned long long g_attn_prof[32];   // [wave of the workgroup][phase]
+#define APROF(k) do { const long long t_now = clock64(); prof_acc[k] += (unsigned long long)(t_now - t_prof); t_prof = clock64(); } while (0)
+#else
+#define APROF(k) do { } while (0)
+#endif
+
 // ---- workgroup -> (block, head, batch) ------------------------------------------------------------------------------------------
 // Under the causal mask the work of a block grows with its index (query blocks) or shrinks with it (key blocks), and the hardware deals
 // consecutive workgroups to the 8 XCDs in turn: with the block index as blockIdx.x and 8 blocks per head (S = 1024), XCD k ran block k of
@@ -113,6 +121,14 @@ template <int D>
 __device__ __forceinline__ void stage_write_plain(unsigned char *lds, const Stage4 &st, int item)
 {
     const int rg = item % 16, c = item / 16;
+    if (st.nvalid >= 64) {            // (uniform) nothing to zero
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = rg * 4 + t;
+            *reinterpret_cast<bf16x8 *>(lds + r * (D * 2) + ((c ^ ((r >> 1) & 7)) << 4)) = st.v[t];
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int r = rg * 4 + t;
@@ -122,13 +138,16 @@ __device__ __forceinline__ void stage_write_plain(unsigned char *lds, const Stag
 __device__ __forceinline__ void stage_write_transposed(unsigned char *lds, const Stage4 &st, int item)
 {
     const int rg = item % 16, c = item / 16;
+    const bool whole = st.nvalid >= 64;        // (uniform) nothing to zero
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int d = c * 8 + j;
         bf16x4 w;
         w[0] = st.v[0][j]; w[1] = st.v[1][j]; w[2] = st.v[2][j]; w[3] = st.v[3][j];
+        if (!whole) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) if (rg * 4 + t >= st.nvalid) w[t] = 0;
+            for (int t = 0; t < 4; ++t) if (rg * 4 + t >= st.nvalid) w[t] = 0;
+        }
         *reinterpret_cast<bf16x4 *>(lds + d * 128 + ((rg ^ (d & 15)) << 3)) = w;
     }
 }
@@ -201,13 +220,12 @@ template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
 {
     // two K / V^T tile buffers: the tile after the one being multiplied is written while the others still compute,
-    // one barrier per tile.  Dynamic LDS (4 x 128 D bytes + 520: 33 KB at head_dim 64, 131 KB at 256).
+    // one barrier per tile.  Dynamic LDS (4 x 128 D bytes + 4 bytes per key: 36 KB at head_dim 64 and S 1024, 139 KB at 256 / 2048).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kTile = 128 * D;                           // bytes of a 64-row tile, plain or transposed
     auto lds_k2 = [&](int i) { return smem + i * kTile; };
     auto lds_vt2 = [&](int i) { return smem + (2 + i) * kTile; };
-    auto lds_mask2 = [&](int i) { return reinterpret_cast<float *>(smem + 4 * kTile) + 64 * i; };
-    int *lds_flag2 = reinterpret_cast<int *>(smem + 4 * kTile + 512);
+    float *lds_maskrow = reinterpret_cast<float *>(smem + 4 * kTile);        // the batch row's key mask up to this block's last key
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     int qblk, head_in, group;
     map_block((int)blockIdx.x, (A.S + 127) / 128, A.Hq / A.Hkv, A.B * A.Hkv, true, qblk, head_in, group);
@@ -243,23 +261,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
         for (int i = 0; i < NI; ++i) {
             if (first_half) stage_write_plain<D>(lds_k2(buf), st[i], item + 128 * i); else stage_write_transposed(lds_vt2(buf), st[i], item + 128 * i);
         }
-        if (threadIdx.x < 64) {   // wave 0: key mask of the tile + "tile holds a padded / out-of-range key" flag
-            const float mk = (k0 + (int)threadIdx.x < A.S) ? A.mask[rowbase + k0 + (int)threadIdx.x] : 0.f;
-            lds_mask2(buf)[threadIdx.x] = mk;
-            const bool any0 = __any(mk == 0.f);
-            if (threadIdx.x == 0) lds_flag2[buf] = any0 ? 1 : 0;
-        }
     };
     load_tile(0);
+    // key mask: the whole row goes to LDS once (keys >= S read as padded).  Fetched per tile by wave 0 right where it was written, the
+    // load's memory latency (~1 700 cycles) sat in front of every tile's barrier: a quarter of the kernel.
+    for (int i = threadIdx.x; i < ((k_end + 63) & ~63); i += 256) lds_maskrow[i] = (i < A.S) ? A.mask[rowbase + i] : 0.f;
     write_tile(0, 0);
     __syncthreads();
+#ifdef ECGB_PROFILE
+    unsigned long long prof_acc[7] = {};
+    long long t_prof = clock64();
+#endif
     for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
         const bool more = k0 + 64 < k_end;
         if (more) load_tile(k0 + 64);   // next tile in flight behind the MFMAs
+        APROF(0);
         const unsigned char *lds_k = lds_k2(it & 1), *lds_vt = lds_vt2(it & 1);
-        const float *lds_mask = lds_mask2(it & 1);
-        const int lds_flag = lds_flag2[it & 1];
+        const float *lds_mask = lds_maskrow + k0;
         if (k0 <= wave_qmax) {
+            const bool lds_flag = __any(lds_mask[lane] == 0.f);          // the tile holds a padded / out-of-range key
             // masks only matter on tiles that touch the diagonal of this wave's rows or hold padded keys: two code paths chosen per
             // wave and tile (one `if` around the score loop alone is if-converted by hipcc: every tile then paid the ~130 compare /
             // select instructions of the masked form, a third of the loop's vector instructions)
@@ -307,6 +327,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
                     }
                 }
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sc;      // p holds raw scores; sc > 0, so the maximum scales with them
+                APROF(1);
                 const float m_new = fmaxf(m, tmax);
                 const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;   // no key visible yet: every p below is exp2(-inf) = 0
                 const float alpha = fast_exp2(m - m_safe);                     // m = -inf -> 0 (accumulators are still zero then)
@@ -323,6 +344,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) accO[db][r] *= alpha;
                 }
+                APROF(2);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -332,14 +354,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
                         for (int db = 0; db < D / 32; ++db)
                             accO[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_vt, db * 32 + lr, kb, s2, h), pf, accO[db], 0, 0, 0);
                     }
+                APROF(3);
             };
             if constexpr (D > 64) tile(std::integral_constant<int, 2>{});
             else if (need_mask) tile(std::integral_constant<int, 1>{});
             else tile(std::integral_constant<int, 0>{});
         }
         if (more) write_tile((it + 1) & 1, k0 + 64);   // its last readers passed the barrier that ended the previous trip
+        APROF(4);
         __syncthreads();
+        APROF(5);
+#ifdef ECGB_PROFILE
+        prof_acc[6] += 1;
+#endif
     }
+#ifdef ECGB_PROFILE
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 7; ++k) atomicAdd(&g_attn_prof[(threadIdx.x >> 6) * 8 + k], prof_acc[k]);
+#endif
     const float lt = l + __shfl_xor(l, 32, 64);
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
     store_accT<D / 32>(accO, A.o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h, inv);
@@ -351,11 +383,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 x 128 D bytes + 260
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 x 128 D bytes + 4 bytes per key
     constexpr int kTile = 128 * D;
     unsigned char *lds_k = smem, *lds_v = smem + kTile, *lds_kt = smem + 2 * kTile;
-    float *lds_mask = reinterpret_cast<float *>(smem + 3 * kTile);
-    int &lds_flag = *reinterpret_cast<int *>(smem + 3 * kTile + 256);
+    float *lds_maskrow = reinterpret_cast<float *>(smem + 3 * kTile);        // the batch row's key mask up to this block's last key
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     int qblk, head_in, group;
     map_block((int)blockIdx.x, (A.S + 127) / 128, A.Hq / A.Hkv, A.B * A.Hkv, true, qblk, head_in, group);
@@ -397,6 +428,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
         for (int i = 0; i < NI; ++i) stage_load<D>(st[i], src, src_ld, k0, A.S, item + 128 * i);
     };
     load_tile(0);
+    for (int i = threadIdx.x; i < ((k_end + 63) & ~63); i += 256) lds_maskrow[i] = (i < A.S) ? A.mask[rowbase + i] : 0.f;   // see attn_fwd_kernel
     for (int k0 = 0; k0 < k_end; k0 += 64) {
         __syncthreads();
 #pragma unroll
@@ -404,16 +436,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
             if (first_half) { stage_write_plain<D>(lds_k, st[i], item + 128 * i); stage_write_transposed(lds_kt, st[i], item + 128 * i); }
             else stage_write_plain<D>(lds_v, st[i], item + 128 * i);
         }
-        if (threadIdx.x < 64) {
-            const float mk = (k0 + (int)threadIdx.x < A.S) ? A.mask[rowbase + k0 + (int)threadIdx.x] : 0.f;
-            lds_mask[threadIdx.x] = mk;
-            const bool any0 = __any(mk == 0.f);
-            if (threadIdx.x == 0) lds_flag = any0 ? 1 : 0;
-        }
         if (k0 + 64 < k_end) load_tile(k0 + 64);
         __syncthreads();
         if (k0 > wave_qmax) continue;
-        const bool need_mask = (k0 + 63 > q0 + wave * 32) || lds_flag;
+        const float *lds_mask = lds_maskrow + k0;
+        const bool need_mask = (k0 + 63 > q0 + wave * 32) || __any(lds_mask[lane] == 0.f);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 s, dp;
@@ -501,12 +528,19 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs &A, const int b
     };
     const long long src_ld = first_half ? A.ldq : A.ldo;
     Stage4 st[NI];
-    {
+    float lse_n = INFINITY, delta_n = 0.f;      // wave 0: the tile's row statistics; head_dim 64: fetched with the tile, one tile ahead
+    auto load_step = [&](int step) {
         int t0; long long stat;
-        const unsigned short *src = src_of(0, t0, stat);
+        const unsigned short *src = src_of(step, t0, stat);
 #pragma unroll
         for (int i = 0; i < NI; ++i) stage_load<D>(st[i], src, src_ld, t0, A.S, item + 128 * i);
-    }
+        if (D == 64 && threadIdx.x < 64) {
+            const bool v = t0 + (int)threadIdx.x < A.S;
+            lse_n = v ? A.lse[stat + t0 + threadIdx.x] : INFINITY;
+            delta_n = v ? A.delta[stat + t0 + threadIdx.x] : 0.f;
+        }
+    };
+    load_step(0);
     for (int step = 0; step < n_steps; ++step) {
         int t0; long long stat;
         (void)src_of(step, t0, stat);
@@ -517,16 +551,15 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs &A, const int b
             else { if constexpr (DO_K) stage_write_plain<D>(lds_do, st[i], item + 128 * i); if constexpr (DO_V) stage_write_transposed(lds_dot, st[i], item + 128 * i); }
         }
         if (threadIdx.x < 64) {
-            const bool v = t0 + (int)threadIdx.x < A.S;
-            lds_lse[threadIdx.x] = v ? A.lse[stat + t0 + threadIdx.x] : INFINITY;
-            lds_delta[threadIdx.x] = v ? A.delta[stat + t0 + threadIdx.x] : 0.f;
+            if (D != 64) {                             // wider heads: measured slower a tile ahead (registers)
+                const bool v = t0 + (int)threadIdx.x < A.S;
+                lse_n = v ? A.lse[stat + t0 + threadIdx.x] : INFINITY;
+                delta_n = v ? A.delta[stat + t0 + threadIdx.x] : 0.f;
+            }
+            lds_lse[threadIdx.x] = lse_n;
+            lds_delta[threadIdx.x] = delta_n;
         }
-        if (step + 1 < n_steps) {
-            int t1; long long stat1;
-            const unsigned short *src = src_of(step + 1, t1, stat1);
-#pragma unroll
-            for (int i = 0; i < NI; ++i) stage_load<D>(st[i], src, src_ld, t1, A.S, item + 128 * i);   // next tile in flight behind the MFMAs
-        }
+        if (step + 1 < n_steps) load_step(step + 1);      // next tile in flight behind the MFMAs
         __syncthreads();
         if (t0 + 63 < wave_kmin) continue;        // every query of the tile precedes every key of this wave
 #pragma unroll
@@ -873,6 +906,10 @@ int check_args(const AttnArgs &A, int D, const char *who)
         ecgb::set_error(std::string(who) + ": row strides must be multiples of 8 elements");
         return ECGB_ERR_UNSUPPORTED;
     }
+    if (4 * 128 * D + 4 * (((long long)A.S + 63) & ~63ll) > 160 * 1024) {      // tile buffers + the row's key mask in LDS
+        ecgb::set_error(std::string(who) + ": sequence too long for the key mask in LDS (head_dim 256: 8 192 keys, 64: 32 768)");
+        return ECGB_ERR_UNSUPPORTED;
+    }
     return ECGB_OK;
 }
 
@@ -897,7 +934,7 @@ extern "C" int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev
     int rc = check_args(A, head_dim, "ecgb_attn_fwd");
     if (rc) return rc;
     const dim3 grid((unsigned)((seq + 127) / 128) * (unsigned)n_q_heads * (unsigned)batch);   // 1-D: map_block() deals blocks to XCDs
-#define ECGB_FWD(D_) do { const int lds = 4 * 128 * D_ + 520; \
+#define ECGB_FWD(D_) do { const int lds = 4 * 128 * D_ + 4 * ((seq + 63) & ~63); \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_kernel<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) break; \
         hipLaunchKernelGGL(attn_fwd_kernel<D_>, grid, dim3(256), lds, (hipStream_t)stream, A); } while (0)
     if (head_dim == 64) ECGB_FWD(64); else if (head_dim == 128) ECGB_FWD(128); else ECGB_FWD(256);
@@ -927,7 +964,7 @@ extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev
 #define ECGB_DKV(D_, DS_, W_) do { \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<D_, DS_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, lk) != hipSuccess) break; \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<D_, DS_, W_>), dim3(gk * DS_), dim3(256), lk, (hipStream_t)stream, A); } while (0)
-#define ECGB_BWD(D_) do { const int lq = 3 * 128 * D_ + 260; \
+#define ECGB_BWD(D_) do { const int lq = 3 * 128 * D_ + 4 * ((seq + 63) & ~63); \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, lq) != hipSuccess) break; \
         hipLaunchKernelGGL(attn_bwd_dq_kernel<D_>, gq, dim3(256), lq, (hipStream_t)stream, A); \
         } while (0)
@@ -1048,3 +1085,11 @@ extern "C" int ecgb_kv_append(const void *src_dev, long long src_ld, long long c
                        (const unsigned short *)src_dev, src_ld, col_off, width, (unsigned short *)cache_dev, capacity, kv_len_dev, batch);
     return launched("kv_append_kernel");
 }
+
+#ifdef ECGB_PROFILE
+extern "C" void ecgb_debug_attn_profile(unsigned long long *out8, int reset)
+{
+    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_attn_prof), 32 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[32] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), z, sizeof z); }
+}
+#endif

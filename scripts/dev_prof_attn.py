@@ -1,0 +1,25 @@
+"""Dev-only: phase timers of attn_fwd_kernel<64> from the -DECGB_PROFILE build (make -C ecg_byte_amd/csrc prof)."""
+import os, sys, math, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from ecg_byte_amd import _lib
+_lib.SO_PATH = os.path.join(os.path.dirname(_lib.SO_PATH), "libecgbyte_hip_prof.so")
+from ecg_byte_amd import decoder_ops as ops
+B, S, Hq, Hkv, D = 32, 1024, 32, 8, 64
+qkv = torch.randn(B * S, (Hq + 2 * Hkv) * D, device="cuda").to(torch.bfloat16)
+mask = torch.ones(B, S, device="cuda")
+L = _lib.lib()
+L.ecgb_debug_attn_profile.argtypes = [C.c_void_p, C.c_int]
+for _ in range(2): ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, 1 / math.sqrt(D))
+torch.cuda.synchronize()
+L.ecgb_debug_attn_profile(None, 1)
+ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, 1 / math.sqrt(D)); torch.cuda.synchronize()
+out = (C.c_ulonglong * 32)()
+L.ecgb_debug_attn_profile(out, 0)
+names = ["top: issue next tile's loads", "S: K reads + MFMA + max", "softmax", "PV: V reads + MFMA issue", "write next tile to LDS (waits for its loads)", "barrier"]
+for w in range(4):
+    o = out[8 * w: 8 * w + 8]
+    trips = o[6]
+    tot = sum(o[k] for k in range(6))
+    print(f"wave {w}: trips {trips}, cycles per trip {tot / trips:.0f}: " + "  ".join(f"{n.split(':')[0]} {o[k] / trips:.0f}" for k, n in enumerate(names)))
