@@ -74,20 +74,24 @@ __device__ __forceinline__ unsigned keep_bits(const LoraArgs &L, unsigned idx)
     return k;
 }
 
-// One wave = 16 rows of x; a workgroup = 4 waves = 64 rows.  K loop in steps of 32 (one v_mfma_f32_16x16x32_bf16 per sub-block).
-template <int NSUB, int NF>
+// One wave = 16 rows of x over 1 / KW of the columns; a workgroup = 4 waves = 64 / KW rows.  K loop in steps of 32 (one
+// v_mfma_f32_16x16x32_bf16 per sub-block).  KW = 4 (in % 256 == 0): the four waves of a workgroup share 16 rows and take a quarter of the
+// contraction each, their partial sums meet in LDS -- 32 768 rows are only 2 048 row groups, 8 waves per CU with two 16-byte loads in
+// flight each: the pass ran at half the HBM rate.
+template <int NSUB, int NF, int KW>
 __global__ __launch_bounds__(256) void lora_down_kernel(LoraArgs L)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lm = lane & 15, lq = lane >> 4;
-    const int row = (blockIdx.x * 4 + wave) * 16 + lm;
+    const int row = (blockIdx.x * (4 / KW) + wave / KW) * 16 + lm;
     const int rowc = row < L.T ? row : L.T - 1;                       // clamped: out-of-range rows are never stored
     const unsigned short *xr = L.x + (size_t)rowc * L.in + 8 * lq;
     f32x4 acc[NSUB];
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const size_t plane = (size_t)L.T * L.in;
-    for (int k0 = 0; k0 < L.in; k0 += 64) {
+    const int k_lo = (wave % KW) * (L.in / KW), k_hi = k_lo + L.in / KW;
+    for (int k0 = k_lo; k0 < k_hi; k0 += 64) {
         bf16x8 xv[2], av[2][NSUB];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -114,6 +118,19 @@ __global__ __launch_bounds__(256) void lora_down_kernel(LoraArgs L)
             for (int s = 0; s < NSUB; ++s)
                 acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u][s], xm[s * NF / NSUB], acc[s], 0, 0, 0);   // D'[c][row]: lane = row, regs = 4 columns
         }
+    }
+    if constexpr (KW > 1) {                                           // wave 0 of the row group adds the other waves' partial sums
+        __shared__ f32x4 red[4][NSUB][64];
+        if (wave % KW) {
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) red[wave][s][lane] = acc[s];
+        }
+        __syncthreads();
+        if (wave % KW) return;
+#pragma unroll
+        for (int w = 1; w < KW; ++w)
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) acc[s] += red[wave + w][s][lane];
     }
     if (row >= L.T) return;
 #pragma unroll
@@ -194,18 +211,19 @@ void fill(LoraArgs &L, int T, int in, float scale, float p, uint64_t seed)
     L.seed = (unsigned)(seed ^ (seed >> 32));
 }
 
-#define ECGB_LORA_DISPATCH(KERNEL, GRID)                                                                                       \
+#define ECGB_LORA_DISPATCH(KERNEL, GRID, ...)                                                                                  \
     do {                                                                                                                       \
         const int key = n_sub * 8 + n_fields;                                                                                  \
-        if (key == 1 * 8 + 1) hipLaunchKernelGGL((KERNEL<1, 1>), GRID, dim3(256), 0, (hipStream_t)stream, L);                  \
-        else if (key == 2 * 8 + 1) hipLaunchKernelGGL((KERNEL<2, 1>), GRID, dim3(256), 0, (hipStream_t)stream, L);             \
-        else if (key == 2 * 8 + 2) hipLaunchKernelGGL((KERNEL<2, 2>), GRID, dim3(256), 0, (hipStream_t)stream, L);             \
-        else if (key == 3 * 8 + 1) hipLaunchKernelGGL((KERNEL<3, 1>), GRID, dim3(256), 0, (hipStream_t)stream, L);             \
-        else if (key == 3 * 8 + 3) hipLaunchKernelGGL((KERNEL<3, 3>), GRID, dim3(256), 0, (hipStream_t)stream, L);             \
-        else if (key == 4 * 8 + 1) hipLaunchKernelGGL((KERNEL<4, 1>), GRID, dim3(256), 0, (hipStream_t)stream, L);             \
-        else if (key == 4 * 8 + 2) hipLaunchKernelGGL((KERNEL<4, 2>), GRID, dim3(256), 0, (hipStream_t)stream, L);             \
-        else hipLaunchKernelGGL((KERNEL<4, 4>), GRID, dim3(256), 0, (hipStream_t)stream, L);                                   \
+        if (key == 1 * 8 + 1) hipLaunchKernelGGL((KERNEL<1, 1 __VA_ARGS__>), GRID, dim3(256), 0, (hipStream_t)stream, L);      \
+        else if (key == 2 * 8 + 1) hipLaunchKernelGGL((KERNEL<2, 1 __VA_ARGS__>), GRID, dim3(256), 0, (hipStream_t)stream, L); \
+        else if (key == 2 * 8 + 2) hipLaunchKernelGGL((KERNEL<2, 2 __VA_ARGS__>), GRID, dim3(256), 0, (hipStream_t)stream, L); \
+        else if (key == 3 * 8 + 1) hipLaunchKernelGGL((KERNEL<3, 1 __VA_ARGS__>), GRID, dim3(256), 0, (hipStream_t)stream, L); \
+        else if (key == 3 * 8 + 3) hipLaunchKernelGGL((KERNEL<3, 3 __VA_ARGS__>), GRID, dim3(256), 0, (hipStream_t)stream, L); \
+        else if (key == 4 * 8 + 1) hipLaunchKernelGGL((KERNEL<4, 1 __VA_ARGS__>), GRID, dim3(256), 0, (hipStream_t)stream, L); \
+        else if (key == 4 * 8 + 2) hipLaunchKernelGGL((KERNEL<4, 2 __VA_ARGS__>), GRID, dim3(256), 0, (hipStream_t)stream, L); \
+        else hipLaunchKernelGGL((KERNEL<4, 4 __VA_ARGS__>), GRID, dim3(256), 0, (hipStream_t)stream, L);                       \
     } while (0)
+#define ECGB_COMMA ,
 
 }  // namespace
 
@@ -217,8 +235,13 @@ extern "C" int ecgb_lora_down(const void *x_dev, const void *a_dev, void *t_dev,
     LoraArgs L{};
     L.x = (const unsigned short *)x_dev; L.A = (const unsigned short *)a_dev; L.t = (unsigned short *)t_dev; L.xd = (unsigned short *)xd_dev;
     fill(L, T, in, scale, p, seed);
-    const dim3 grid((unsigned)((T + 63) / 64));
-    ECGB_LORA_DISPATCH(lora_down_kernel, grid);
+    if (in % 256 == 0 && T >= 1024) {                                // row groups of 16 with the contraction split over the four waves
+        const dim3 grid((unsigned)((T + 15) / 16));
+        ECGB_LORA_DISPATCH(lora_down_kernel, grid, ECGB_COMMA 4);
+    } else {
+        const dim3 grid((unsigned)((T + 63) / 64));
+        ECGB_LORA_DISPATCH(lora_down_kernel, grid, ECGB_COMMA 1);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ecgb::set_error(std::string("lora_down_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
     return ECGB_OK;
@@ -234,7 +257,7 @@ extern "C" int ecgb_lora_dx(const void *dt_dev, const void *at_dev, void *dx_dev
     fill(L, T, in, scale, p, seed);
     const unsigned row_blocks = (unsigned)((T + 63) / 64);
     unsigned col_split = 1;                                          // few rows: split the columns over blockIdx.y to fill the chip
-    while (row_blocks * col_split < 1024 && (in / (int)(col_split * 2)) % 64 == 0 && col_split < 16) col_split *= 2;
+    while (row_blocks * col_split < 4096 && (in / (int)(col_split * 2)) % 64 == 0 && col_split < 16) col_split *= 2;   // 16 workgroups per CU
     const dim3 grid(row_blocks, col_split);
     ECGB_LORA_DISPATCH(lora_dx_kernel, grid);
     const hipError_t e = hipGetLastError();
