@@ -757,24 +757,32 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
         return;
     }
 
-    // LDS-DMA of one operand tile: 32 instructions of 1 KiB (2 rows of 512 B), 4 per wave
-    auto stage = [&](const unsigned short *g, long long ld, int c0, int ncols, int kt, unsigned char *dst) {
+    // LDS-DMA of one operand tile: 32 instructions of 1 KiB (2 rows of 512 B), 4 per wave.  Address = wave-uniform running pointer to
+    // the next K-tile of the operand (tiles are staged in order: one scalar add per tile) + a per-lane 32-bit byte offset that never
+    // changes (row inside the tile, swizzled chunk): no multiplies in the loop.
+    unsigned offA[4], offB[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int inst = wave * 4 + i;
-            const int r = inst * 2 + (lane >> 5);                           // contraction row inside the tile
-            const int chunk = (lane & 31) ^ (((r & 7) << 1) ^ (r & 8));     // the global chunk this LDS slot holds
-            const int col = min(c0 + chunk * 8, ncols - 8);                 // clamped columns are never stored
-            const unsigned short *src = g + ((long long)kt * 64 + r) * ld + col;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(dst + inst * 1024), 16, 0, 0);
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int inst = wave * 4 + i;
+        const int r = inst * 2 + (lane >> 5);                               // contraction row inside the tile
+        const int chunk = (lane & 31) ^ (((r & 7) << 1) ^ (r & 8));         // the global chunk this LDS slot holds
+        offA[i] = (unsigned)(((long long)r * G.lda + min(row0 + chunk * 8, G.N - 8)) * 2);     // clamped columns are never stored
+        offB[i] = (unsigned)(((long long)r * G.ldb + min(col0 + chunk * 8, G.K - 8)) * 2);
+    }
+    const unsigned char *nextA = reinterpret_cast<const unsigned char *>(G.A) + (long long)kt_begin * 64 * G.lda * 2;
+    const unsigned char *nextB = reinterpret_cast<const unsigned char *>(G.B) + (long long)kt_begin * 64 * G.ldb * 2;
+    auto stage = [&](const unsigned char *&next, long long ld, const unsigned (&off)[4], unsigned char *dst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(next + off[i]),
+                                             (__attribute__((address_space(3))) void *)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
+        next += 64 * ld * 2;
     };
-    stage(G.B, G.ldb, col0, G.K, kt_begin, lds + kABytes);
-    stage(G.A, G.lda, row0, G.N, kt_begin, lds);
+    stage(nextB, G.ldb, offB, lds + kABytes);
+    stage(nextA, G.lda, offA, lds);
     if (kt_begin + 1 < KT) {
-        stage(G.B, G.ldb, col0, G.K, kt_begin + 1, lds + kBufBytes + kABytes);
-        stage(G.A, G.lda, row0, G.N, kt_begin + 1, lds + kBufBytes);
+        stage(nextB, G.ldb, offB, lds + kBufBytes + kABytes);
+        stage(nextA, G.lda, offA, lds + kBufBytes);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -856,10 +864,10 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
         read_b(1);
         mfma_quadrant(0, 1);
         read_a(1);
-        if (more) stage(G.B, G.ldb, col0, G.K, kt + 2, nxt + kABytes);
+        if (more) stage(nextB, G.ldb, offB, nxt + kABytes);
         mfma_quadrant(1, 1);
         if (more) {
-            stage(G.A, G.lda, row0, G.N, kt + 2, nxt);
+            stage(nextA, G.lda, offA, nxt);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1185,6 +1193,10 @@ extern "C" int ecgb_gemm_tn_bf16(const void *a_dev, long long lda, const void *b
     G.A2 = G.B2 = nullptr; G.lda2 = G.ldb2 = 0; G.K2 = 0;
     G.tiles_m = (N + 255) / 256; G.tiles_n = (K + 255) / 256;
     if (splits < 1 || splits > 64) { ecgb::set_error("ecgb_gemm_tn_bf16: splits must be 1..64"); return ECGB_ERR_INVALID; }
+    if ((64 * lda + N) * 2 >= (1ll << 32) || (64 * ldb + K) * 2 >= (1ll << 32)) {      // per-lane byte offsets inside a K-tile are 32-bit
+        ecgb::set_error("ecgb_gemm_tn_bf16: row strides above 2^24 elements are not supported");
+        return ECGB_ERR_UNSUPPORTED;
+    }
     G.accumulate_f32 = splits > 1 ? 1 : 0; G.alpha = alpha;      // splits > 1: c_dev is fp32 [splits][N, ldc], one slab per K-slice
     G.split_stride = (long long)N * ldc;
     G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
