@@ -448,12 +448,11 @@ template <int BM, int BN, int WGM, int WGN, bool CAT = false, int EPI = 0>
 __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
 {
     static_assert(BM == 256 && BN == 256 && WGM == 2 && WGN == 4, "phase schedule written for the 256x256 tile, 2x4 waves");
-    constexpr int NW = WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;                 // 8 x 4 MFMA tiles per wave
     constexpr int kABytes = BM * BK * 2, kBBytes = BN * BK * 2, kBufBytes = kABytes + kBBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave index in a scalar register: the LDS-DMA destinations (M0) are scalar arithmetic
     const int nwg = G.tiles_m * G.tiles_n;
     const int orig = blockIdx.x;
     const int q = nwg / 8, rr = nwg % 8, xcd = orig % 8;
@@ -484,21 +483,47 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
     // CAT: the K loop continues into (A2, B2).  A template flag, not a run-time test: the plain kernel keeps the exact address
     // arithmetic it had (the selects cost the 256x256 kernel 5 % when they sat in every launch).  Selects, not branches:
     // LDS-DMA issued on two sides of a branch makes hipcc drain vmcnt(0) at the join.
-    auto stage_a = [&](int t, unsigned char *dst) {
+    // The tiles of an operand are staged in K order, so the LDS-DMA address is a wave-uniform running pointer (scalar registers, + 128
+    // bytes per tile) plus a per-lane byte offset fixed for the whole launch (row of the tile, swizzled chunk): the loop carries no
+    // vector address arithmetic (global_load_lds v_off, s[base]).  CAT: a second pointer / offset set for (A2, B2), chosen per tile by
+    // a wave-uniform select (no branch: LDS-DMA issued on two sides of a branch makes hipcc drain vmcnt(0) at the join).
+    unsigned offA[4], offB[4], offA2[CAT ? 4 : 1], offB2[CAT ? 4 : 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        const int ra = min(row0 + r, G.M - 1) - row0;                                  // clamped: out-of-range rows are never stored
+        int rb = min(col0 + r, G.N - 1) - col0;
+        if constexpr (EPI != 0) rb = ((r >> 5) << 4) + (r & 15) + (((r >> 4) & 1) ? G.glu_I : 0);   // gate / up rows interleaved by 16
+        offA[i] = (unsigned)(((long long)ra * G.lda + chunk * 8) * 2);
+        offB[i] = (unsigned)(((long long)rb * G.ldb + chunk * 8) * 2);
         if constexpr (CAT) {
-            const bool second = t >= KT1;
-            stage_tile<BM, NW>(second ? G.A2 : A, second ? G.lda2 : G.lda, row0, G.M, (second ? t - KT1 : t) * BK, dst, wave, lane);
-        } else {
-            stage_tile<BM, NW>(A, G.lda, row0, G.M, t * BK, dst, wave, lane);
+            offA2[i] = (unsigned)(((long long)ra * G.lda2 + chunk * 8) * 2);
+            offB2[i] = (unsigned)(((long long)rb * G.ldb2 + chunk * 8) * 2);
         }
+    }
+    const int brow0 = EPI != 0 ? (col0 >> 1) : col0;
+    const unsigned char *nextA = reinterpret_cast<const unsigned char *>(A + (long long)row0 * G.lda);
+    const unsigned char *nextB = reinterpret_cast<const unsigned char *>(B + (long long)brow0 * G.ldb);
+    const unsigned char *nextA2 = CAT ? reinterpret_cast<const unsigned char *>(G.A2 + (long long)row0 * G.lda2) : nullptr;
+    const unsigned char *nextB2 = CAT ? reinterpret_cast<const unsigned char *>(G.B2 + (long long)brow0 * G.ldb2) : nullptr;
+    auto stage_a = [&](int t, unsigned char *dst) {
+        const bool second = CAT && t >= KT1;
+        const unsigned char *base = second ? nextA2 : nextA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (second ? offA2[CAT ? i : 0] : offA[i])),
+                                             (__attribute__((address_space(3))) void *)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
+        if (second) nextA2 += BK * 2; else nextA += BK * 2;
     };
     auto stage_b = [&](int t, unsigned char *dst) {
-        if constexpr (CAT) {
-            const bool second = t >= KT1;
-            stage_tile<BN, NW, EPI != 0>(second ? G.B2 : B, second ? G.ldb2 : G.ldb, col0, G.N, (second ? t - KT1 : t) * BK, dst, wave, lane, G.glu_I);
-        } else {
-            stage_tile<BN, NW, EPI != 0>(B, G.ldb, col0, G.N, t * BK, dst, wave, lane, G.glu_I);
-        }
+        const bool second = CAT && t >= KT1;
+        const unsigned char *base = second ? nextB2 : nextB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (second ? offB2[CAT ? i : 0] : offB[i])),
+                                             (__attribute__((address_space(3))) void *)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
+        if (second) nextB2 += BK * 2; else nextB += BK * 2;
     };
 
     // prologue: tiles 0 and 1 in flight, tile 0 complete
@@ -735,7 +760,7 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int kABytes = 64 * BN_ * 2, kBBytes = 64 * BK_ * 2, kBufBytes = kABytes + kBBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int nwg = G.tiles_m * G.tiles_n;
     const int q_ = nwg / 8, rr = nwg % 8, xcd = orig % 8;
     const int wgid = (xcd < rr ? xcd * (q_ + 1) : rr * (q_ + 1) + (xcd - rr) * q_) + orig / 8;
