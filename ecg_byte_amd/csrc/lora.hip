@@ -18,6 +18,7 @@
 
 #include <string>
 
+#include "glu_math.hpp"
 #include "tokenizer.hpp"
 
 namespace {
@@ -54,6 +55,8 @@ struct LoraArgs {
     unsigned short *t;            // lora_down: [T, 64]
     unsigned short *xd;           // lora_down: [n_fields, T, in] masked x per block, or NULL
     unsigned short *dx;           // lora_dx: [T, in], += in place
+    const unsigned short *gu;     // lora_dx with the GLU backward behind it: gate|up [T, 2 in] of the forward ...
+    unsigned short *dgu;          // ... and d(gate|up) [T, 2 in]: dx is then only read
     int T, in;                    // (sub-block s belongs to block s * NF / NSUB: every block has the same number of sub-blocks)
     float scale;                  // alpha / r / (1 - p)
     unsigned thr;                 // keep iff field >= thr, thr = p * 65536 (0: no dropout)
@@ -148,7 +151,10 @@ __global__ __launch_bounds__(256) void lora_down_kernel(LoraArgs L)
 // lane (row lm, quarter lq) ends with the 16 CONSECUTIVE columns c0 + 16 lq .. + 15 (MFMA q supplies columns 4q .. 4q + 3 of them):
 // two 16-byte loads and stores per lane instead of eight 8-byte ones.  The rank-16 product of a sub-block uses half the K of the
 // 16x16x32 MFMA (k-groups 2 and 3 of both fragments are zero).
-template <int NSUB, int NF>
+// GLU != 0 (1 = SiLU, 2 = tanh-GELU; the down-projection site): dx is d(act(gate) * up) and nothing else reads it, so instead of writing
+// the sum back the kernel goes on to d gate = dx * up * act'(gate), d up = dx * act(gate) (glu_bwd_kernel's arithmetic on the bf16-rounded sum:
+// the same bits as the two separate kernels) and writes those: one read-modify-write pass over [T, in] less per layer.
+template <int NSUB, int NF, int GLU = 0>
 __global__ __launch_bounds__(256) void lora_dx_kernel(LoraArgs L)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -188,8 +194,26 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraArgs L)
                 v0[e] = f2bf(bf2f(old0[e]) + sum[e] * L.scale);
                 v1[e] = f2bf(bf2f(old1[e]) + sum[8 + e] * L.scale);
             }
-            *reinterpret_cast<us8 *>(dxr + c0) = v0;
-            *reinterpret_cast<us8 *>(dxr + c0 + 8) = v1;
+            if constexpr (GLU == 0) {
+                *reinterpret_cast<us8 *>(dxr + c0) = v0;
+                *reinterpret_cast<us8 *>(dxr + c0 + 8) = v1;
+            } else {
+                const size_t o = (size_t)row * 2 * L.in + c0 + 16 * lq;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const us8 g = *reinterpret_cast<const us8 *>(L.gu + o + 8 * half), u = *reinterpret_cast<const us8 *>(L.gu + o + L.in + 8 * half);
+                    const us8 d = half ? v1 : v0;
+                    us8 og, ou;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float gf = bf2f(g[e]), uf = bf2f(u[e]), df = bf2f(d[e]);
+                        og[e] = f2bf(df * uf * ecgb::glu_act_grad<GLU == 2>(gf));
+                        ou[e] = f2bf(df * ecgb::glu_act<GLU == 2>(gf));
+                    }
+                    *reinterpret_cast<us8 *>(L.dgu + o + 8 * half) = og;
+                    *reinterpret_cast<us8 *>(L.dgu + o + L.in + 8 * half) = ou;
+                }
+            }
         }
     }
 }
@@ -262,5 +286,28 @@ extern "C" int ecgb_lora_dx(const void *dt_dev, const void *at_dev, void *dx_dev
     ECGB_LORA_DISPATCH(lora_dx_kernel, grid);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ecgb::set_error(std::string("lora_dx_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
+}
+
+// ecgb_lora_dx followed by the GLU backward in one pass (the down-projection site: dx = d(act(gate) * up) [T, inter]):
+//   d(gate|up) = glu_bwd(gate|up, dx + scale/(1-p) * sum_b mask_b . (dt_b A_b));  dx itself is only read.
+extern "C" int ecgb_lora_dx_glu(const void *dt_dev, const void *at_dev, const void *dx_dev, const void *gate_up_dev, void *d_gate_up_dev, int T,
+                                int inter, int n_sub, int n_fields, float scale, float p, uint64_t seed, int gelu_tanh, void *stream)
+{
+    if (!dt_dev || !at_dev || !dx_dev || !gate_up_dev || !d_gate_up_dev) { ecgb::set_error("ecgb_lora_dx_glu: NULL argument"); return ECGB_ERR_INVALID; }
+    if (int rc = check_common("ecgb_lora_dx_glu", T, inter, n_sub, n_fields, p)) return rc;
+    if (n_sub != 1 || n_fields != 1) { ecgb::set_error("ecgb_lora_dx_glu: one adapter block (the down projection)"); return ECGB_ERR_UNSUPPORTED; }
+    LoraArgs L{};
+    L.dt = (const unsigned short *)dt_dev; L.A = (const unsigned short *)at_dev; L.dx = (unsigned short *)const_cast<void *>(dx_dev);
+    L.gu = (const unsigned short *)gate_up_dev; L.dgu = (unsigned short *)d_gate_up_dev;
+    fill(L, T, inter, scale, p, seed);
+    const unsigned row_blocks = (unsigned)((T + 63) / 64);
+    unsigned col_split = 1;
+    while (row_blocks * col_split < 4096 && (inter / (int)(col_split * 2)) % 64 == 0 && col_split < 16) col_split *= 2;
+    const dim3 grid(row_blocks, col_split);
+    if (gelu_tanh) hipLaunchKernelGGL((lora_dx_kernel<1, 1, 2>), grid, dim3(256), 0, (hipStream_t)stream, L);
+    else hipLaunchKernelGGL((lora_dx_kernel<1, 1, 1>), grid, dim3(256), 0, (hipStream_t)stream, L);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ecgb::set_error(std::string("lora_dx_kernel (glu): ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
     return ECGB_OK;
 }

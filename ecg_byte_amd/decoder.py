@@ -151,9 +151,10 @@ class LoraSite(nn.Module):
                 y = (y if glu[1] else None, ops.glu_fwd(y, gelu_tanh=glu[0]))
         return y, (x, xd, t, p, seed)
 
-    def backward(self, dy, saved, model, dx):
+    def backward(self, dy, saved, model, dx, glu=None):
         """Sets A.grad / B.grad (slices of the model's flat gradient buffer) and adds the adapters' contribution to `dx` in place
-        (dx already holds the base projection's dy . W)."""
+        (dx already holds the base projection's dy . W).  glu = (gate|up, gelu_tanh) on the down-projection site: dx is d(act(gate) * up);
+        returns d(gate|up) from the same pass instead of writing dx back (ecgb_lora_dx_glu)."""
         x, xd, t, p, seed = saved
         Bt = model._shadow(("lora_Bt", id(self)), self.B)                 # [64, out]
         At = model._shadow(("lora_At", id(self)), self.A)                 # [in, 64]
@@ -166,8 +167,10 @@ class LoraSite(nn.Module):
         else:
             w = 16 * self.spb                                            # dA_b = dt_b^T . (mask_b . x)
             model._wgrad_rows(self.A, [(w * f, w * f + w, dt[:, w * f: w * f + w], xd[f]) for f in range(self.n_fields)], alpha=keep_scale)
+        if glu is not None and self.n_sub == 1:
+            return ops.lora_dx_glu(dx, dt, At, glu[0], self.scale, p, seed, gelu_tanh=glu[1])
         ops.lora_dx_(dx, dt, At, self.n_sub, self.n_fields, self.scale, p, seed)
-        return dx
+        return dx if glu is None else ops.glu_bwd(glu[0], dx, gelu_tanh=glu[1])
 
 
 class _LossFn(torch.autograd.Function):
@@ -959,8 +962,9 @@ class HipCausalLM(nn.Module):
             wgrad(g, hm, self.wdown[i])
             d_hm = ops.gemm_nt(g, self._shadow(("wdown", i), self.wdown[i]))        # [T, I]
             if frozen:
-                self.lora[i]["down"].backward(g, ls[3], self, d_hm)
-            d_gu = ops.glu_bwd(gu, d_hm, gelu_tanh=self.gemma)
+                d_gu = self.lora[i]["down"].backward(g, ls[3], self, d_hm, glu=(gu, self.gemma))   # adapters + GLU backward in one pass
+            else:
+                d_gu = ops.glu_bwd(gu, d_hm, gelu_tanh=self.gemma)
             del d_hm, hm
             wgrad(d_gu, h2, self.wgu[i])
             d_h2 = ops.gemm_nt(d_gu, self._shadow(("wgu", i), self.wgu[i]))         # [T, H]

@@ -219,6 +219,17 @@ def lora_dx_(dx, dt, At, n_sub, n_fields, scale, p=0.0, seed=0):
     return dx
 
 
+def lora_dx_glu(dx, dt, At, gate_up, scale, p=0.0, seed=0, gelu_tanh=False):
+    """d(gate|up) = glu_bwd(gate|up, dx + scale / (1 - p) * mask . (dt A)) in one pass (ecgb_lora_dx_glu: the down-projection site, one
+    adapter block); dx [T, I] is only read."""
+    T, inter = dx.shape
+    assert dt.shape == (T, 64) and At.shape == (inter, 64) and gate_up.shape == (T, 2 * inter)
+    d = torch.empty_like(gate_up)
+    _lib.check(_L().ecgb_lora_dx_glu(_p(_bf(dt)), _p(_bf(At)), _p(_bf(dx)), _p(_bf(gate_up)), _p(d), T, inter, 1, 1, float(scale), float(p), int(seed),
+                                     int(gelu_tanh), _st()))
+    return d
+
+
 def tn_splits(N, K, M, n_cu=256):
     """K-slices per 256x256 output tile of a weight-gradient product.  Skinny outputs (LoRA adapter gradients) are a pass over the long
     operand: enough workgroups to pull it at HBM speed.  Otherwise the slice count that minimises the makespan in contraction steps when

@@ -90,6 +90,11 @@ int ecgb_lora_down(const void *x_dev, const void *a_dev, void *t_dev, void *xd_d
                    float scale, float p, uint64_t seed, void *stream);
 int ecgb_lora_dx(const void *dt_dev, const void *at_dev, void *dx_dev, int T, int in, int n_sub, int n_fields,
                  float scale, float p, uint64_t seed, void *stream);
+/* ecgb_lora_dx with the GLU backward behind it (the down-projection site, one adapter block): dx [T, inter] = d(act(gate) * up) of the
+ * frozen base is READ, the adapters' contribution added, and d(gate|up) [T, 2*inter] = ecgb_glu_bwd(gate|up, that sum) written -- the same
+ * bits as ecgb_lora_dx followed by ecgb_glu_bwd, one read-modify-write pass over [T, inter] less. */
+int ecgb_lora_dx_glu(const void *dt_dev, const void *at_dev, const void *dx_dev, const void *gate_up_dev, void *d_gate_up_dev, int T,
+                     int inter, int n_sub, int n_fields, float scale, float p, uint64_t seed, int gelu_tanh, void *stream);
 
 /* GPT-2 block pieces (BASELINE config C1's model; transformers/src/transformers/models/gpt2/modeling_gpt2.py:565-661, pytorch_utils.py:87-113):
  *   ecgb_layernorm_fwd   y = (x - mean) * rstd * w + b (nn.LayerNorm); residual_dev != NULL: x := x + residual first, written to sum_out_dev;

@@ -333,6 +333,24 @@ def test_gemm_glu_epilogue_is_bitwise_the_separate_kernels(ops, M, inter, K, K2,
     _close(h, act.to(torch.bfloat16).float() * u, atol=1e-3)
 
 
+@pytest.mark.parametrize("gelu_tanh", [False, True])
+@pytest.mark.parametrize("p", [0.0, 0.05])
+def test_lora_dx_with_glu_backward_is_bitwise_the_two_kernels(ops, p, gelu_tanh):
+    """The down-projection site's adapter contribution to d(act(gate) * up) and the GLU backward in one pass: the same bits as
+    ecgb_lora_dx followed by ecgb_glu_bwd, and the input gradient itself is left untouched."""
+    T, inter = 1000, 2048
+    dx, gu = _bf(T, inter, seed=71), _bf(T, 2 * inter, seed=72)
+    dt = _bf(T, 64, scale=0.5, seed=73)
+    dt[:, 16:] = 0
+    At = _bf(inter, 64, scale=0.05, seed=74)
+    want_dx = ops.lora_dx_(dx.clone(), dt, At, 1, 1, 2.0, p, 4321)
+    want = ops.glu_bwd(gu, want_dx, gelu_tanh=gelu_tanh)
+    keep = dx.clone()
+    got = ops.lora_dx_glu(dx, dt, At, gu, 2.0, p, 4321, gelu_tanh=gelu_tanh)
+    assert torch.equal(got, want)
+    assert torch.equal(dx, keep)
+
+
 def test_sumsq_multi_equals_per_tensor_sum(ops):
     """One launch over a list of gradient tensors (sizes from 8 elements to a few chunks of 2^20, an unaligned view among
     them) against the fp32 sum of squares."""
