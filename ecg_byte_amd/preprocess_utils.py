@@ -1,0 +1,104 @@
+"""Host mirror of the offline conditioning in ecg_byte/utils/preprocess_utils.py:26-113 on top of csrc/preprocess.hip.
+
+Same function names and argument meaning as the reference; the arrays are float64 CUDA tensors and every function takes one record
+`[n, leads]` (the reference's shape) or a batch `[records, n, leads]` -- the batch is what the kernels are built for (one lane per
+(record, lead) series).  Filter design stays on the host with scipy.signal, the library the reference calls (`iirnotch`, `butter`,
+`lfilter_zi`: a few dozen coefficients); everything that touches samples runs on the device.  No CPU fallback: without the HIP
+library these functions raise.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_MAX_TAPS = 9
+
+
+def _L():
+    return _lib.lib()
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _batch(x):
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float64):
+        raise TypeError("expected a float64 CUDA tensor [n, leads] or [records, n, leads]")
+    _lib.require_current(x.device)
+    return (x[None] if x.dim() == 2 else x).contiguous(), x.dim() == 2
+
+
+def check_nan_inf(data, step_name):
+    """preprocess_utils.py:26-33: NaN / inf -> 0 (with the reference's warning)."""
+    if not bool(torch.isfinite(data).all()):
+        print(f"Warning: NaN or inf values detected after {step_name}")
+        data = torch.nan_to_num(data, nan=0.0, posinf=0.0, neginf=0.0)
+    return data
+
+
+def reorder_indices(signals):
+    """preprocess_utils.py:35-40: MIMIC lead order (I, II, III, aVR, aVF, aVL, V1-6) -> (I, II, III, aVL, aVR, aVF, V1-6)."""
+    current_order = ['I', 'II', 'III', 'aVR', 'aVF', 'aVL', 'V1', 'V2', 'V3', 'V4', 'V5', 'V6']
+    desired_order = ['I', 'II', 'III', 'aVL', 'aVR', 'aVF', 'V1', 'V2', 'V3', 'V4', 'V5', 'V6']
+    order_mapping = {lead: index for index, lead in enumerate(current_order)}
+    new_indices = [order_mapping[lead] for lead in desired_order]
+    return signals[..., new_indices]
+
+
+def design_filters(fs=500, notch_freqs=(50, 60), highcut=100.0):
+    """The four (b, a) pairs of advanced_ecg_filter, preprocess_utils.py:69-86, from the same scipy.signal calls."""
+    from scipy import signal
+    out = [signal.iirnotch(f, 30.0, fs) for f in notch_freqs]
+    nyquist = 0.5 * fs
+    out.append(signal.butter(4, [0.5 / nyquist, highcut / nyquist], btype='band'))
+    out.append(signal.butter(4, 0.05 / nyquist, btype='high'))
+    return out
+
+
+def filtfilt(filters, x):
+    """scipy.signal.filtfilt(b, a, x, axis=-2) for each (b, a) of `filters` in turn, on the device (ecgb_filtfilt_f64; at most four per
+    launch, longer chains are cut)."""
+    from scipy import signal
+    xb, single = _batch(x)
+    R, n, leads = xb.shape
+    y = xb
+    for s0 in range(0, len(filters), 4):
+        chunk = filters[s0:s0 + 4]
+        taps = (C.c_int * len(chunk))()
+        b = np.zeros((len(chunk), _MAX_TAPS)); a = np.zeros((len(chunk), _MAX_TAPS)); zi = np.zeros((len(chunk), _MAX_TAPS - 1))
+        for k, (bk, ak) in enumerate(chunk):
+            bk, ak = np.atleast_1d(np.asarray(bk, np.float64)), np.atleast_1d(np.asarray(ak, np.float64))
+            nt = max(len(bk), len(ak))
+            if nt > _MAX_TAPS or nt < 2:
+                raise ValueError("filters of 2..9 coefficients")
+            taps[k] = nt
+            b[k, :len(bk)] = bk; a[k, :len(ak)] = ak
+            zi[k, :nt - 1] = signal.lfilter_zi(bk, ak)
+        edge = 3 * max(taps)
+        nbytes = _L().ecgb_filtfilt_scratch_bytes(R, n, leads, edge)
+        scratch = torch.empty(nbytes // 8, dtype=torch.float64, device=xb.device)
+        out = torch.empty_like(xb)
+        _lib.check(_L().ecgb_filtfilt_f64(C.c_void_p(y.data_ptr()), C.c_void_p(out.data_ptr()), R, n, leads, len(chunk), taps,
+                                          b.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), zi.ctypes.data_as(C.c_void_p),
+                                          C.c_void_p(scratch.data_ptr()), nbytes, _st()))
+        y = out
+    return y[0] if single else y
+
+
+def advanced_ecg_filter(ecg_data, fs=500, notch_freqs=[50, 60], highcut=100.0):
+    """preprocess_utils.py:66-88: notch filters, Butterworth band-pass 0.5 Hz..highcut (order 4), high-pass 0.05 Hz (order 4), each
+    applied forward and backward (filtfilt)."""
+    return filtfilt(design_filters(fs, tuple(notch_freqs), highcut), ecg_data)
+
+
+def segment_ecg(ecg_data, text_data, seg_len):
+    """preprocess_utils.py:103-116: whole segments of seg_len samples, the tail dropped; the text repeated per segment.  One record
+    [n, leads] -> ([segments, seg_len, leads], [text] * segments); a batch -> [records, segments, seg_len, leads]."""
+    n = ecg_data.shape[-2]
+    num_segments = n // seg_len
+    seg = ecg_data[..., : num_segments * seg_len, :]
+    seg = seg.reshape(*ecg_data.shape[:-2], num_segments, seg_len, ecg_data.shape[-1])
+    return seg, [text_data] * num_segments

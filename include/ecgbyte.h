@@ -186,6 +186,17 @@ int ecgb_bpe_shard_apply(ecgb_bpe_shard *h, void *stream);
 int ecgb_bpe_shard_finish(ecgb_bpe_shard *h, uint32_t *pairs_dev, uint32_t *n_done_dev, uint32_t *ids_out_dev, uint64_t *n_ids_dev,
                           void *stream);
 
+/* ---- offline conditioning of raw records (float64, a whole batch per call) -------------------------------
+ * ecg_byte/utils/preprocess_utils.py:66-88 advanced_ecg_filter: scipy.signal.filtfilt(b, a, x, axis=0) -- method 'pad', padtype 'odd',
+ * padlen 3 * max(len a, len b), initial state lfilter_zi * edge sample, direct form II transposed both ways -- for up to four filters
+ * applied one after the other (the reference: notch 50 Hz, notch 60 Hz, Butterworth band-pass 0.5-100 Hz order 4, high-pass 0.05 Hz
+ * order 4).  x_dev, y_dev: [records, n, leads] as wfdb.rdsamp returns them (preprocess_utils.py:126); may alias.
+ * n_taps[k] = coefficients of filter k (2..9, len b == len a); b, a: [n_filters][9] host arrays, zi: [n_filters][8] =
+ * scipy.signal.lfilter_zi(b, a).  Scratch: ecgb_filtfilt_scratch_bytes(records, n, leads, 3 * max taps). */
+size_t ecgb_filtfilt_scratch_bytes(int records, int n, int leads, int max_edge);
+int ecgb_filtfilt_f64(const double *x_dev, double *y_dev, int records, int n, int leads, int n_filters, const int *n_taps,
+                      const double *b, const double *a, const double *zi, double *scratch_dev, size_t scratch_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,71 @@
+"""GPU parity of the offline conditioning kernels (csrc/preprocess.hip) against the oracle / scipy on the same inputs and against the
+committed golden vectors.  float64: the filter chain is compared bit for bit with the written-out recursion of the oracle and within
+1e-11 of its maximum with scipy's compiled loop (the recursion amplifies a last-bit difference of the two builds)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+scipy = pytest.importorskip("scipy")
+
+from oracle import preprocess_ref as P  # noqa: E402
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "preprocess_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def pp():
+    assert torch.cuda.is_available()
+    from ecg_byte_amd import preprocess_utils
+    return preprocess_utils
+
+
+def _records(R, n, seed):
+    from ecg_byte_amd import synth
+    rng = np.random.default_rng(seed)
+    x = np.ascontiguousarray(synth.synth_ecg(R, n, seed=seed).transpose(0, 2, 1))
+    return x + 0.02 * rng.standard_normal(x.shape) + 0.05 * np.sin(2 * np.pi * 60.0 * np.arange(n) / 500.0)[None, :, None] + rng.uniform(-1, 1, (R, 1, 12))
+
+
+def test_filter_chain_golden(pp):
+    got = pp.advanced_ecg_filter(torch.from_numpy(G["raw"][0]).cuda()).cpu().numpy()
+    want = G["filtered"][0]
+    assert np.abs(got - want).max() <= 1e-11 * np.abs(want).max()
+
+
+def test_each_filter_is_the_written_out_recursion_bit_for_bit(pp):
+    """One filter at a time, three leads: the kernel against oracle.filtfilt_literal (the same operations in the same order)."""
+    x = _records(1, 700, seed=3)[0][:, :3]
+    xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    for b, a in pp.design_filters():
+        got = pp.filtfilt([(b, a)], xd).cpu().numpy()
+        for lead in range(3):
+            assert np.array_equal(got[:, lead], P.filtfilt_literal(b, a, x[:, lead])), lead
+
+
+@pytest.mark.parametrize("R,n", [(1, 5000), (37, 5000), (5, 28), (3, 1237)])
+def test_filter_chain_batches_against_scipy(pp, R, n):
+    """Full-length records (5000 samples at 500 Hz), a ragged batch, the shortest signal scipy accepts (padlen 27 < n)."""
+    x = _records(R, n, seed=R)
+    got = pp.advanced_ecg_filter(torch.from_numpy(x).cuda()).cpu().numpy()
+    for r in range(R):
+        want = P.advanced_ecg_filter(x[r])
+        assert np.abs(got[r] - want).max() <= 1e-10 * max(np.abs(want).max(), 1e-3), r
+
+
+def test_short_signals_are_refused_like_scipy(pp):
+    from ecg_byte_amd._lib import EcgbError
+    with pytest.raises(EcgbError):
+        pp.advanced_ecg_filter(torch.zeros(27, 12, dtype=torch.float64, device="cuda"))
+
+
+def test_segment_reorder_nan(pp):
+    x = torch.arange(2500 * 12, dtype=torch.float64, device="cuda").reshape(2500, 12)
+    seg, txt = pp.segment_ecg(x, "q", 1000)
+    ref, _ = P.segment_ecg(x.cpu().numpy(), "q", 1000)
+    assert txt == ["q", "q"] and np.array_equal(seg.cpu().numpy(), ref)
+    assert np.array_equal(pp.reorder_indices(x).cpu().numpy(), P.reorder_indices(x.cpu().numpy()))
+    bad = x.clone(); bad[3, 2] = float("nan"); bad[4, 1] = float("inf")
+    assert np.array_equal(pp.check_nan_inf(bad, "t").cpu().numpy(), P.check_nan_inf(bad.cpu().numpy()))
