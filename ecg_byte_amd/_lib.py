@@ -91,6 +91,12 @@ def lib():
     L.ecgb_filtfilt_scratch_bytes.restype = sz
     L.ecgb_filtfilt_f64.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), vp, vp, vp, vp, sz, vp]
     L.ecgb_filtfilt_f64.restype = C.c_int
+    L.ecgb_resample_cubic_f64.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, sz, vp]
+    L.ecgb_resample_cubic_f64.restype = C.c_int
+    L.ecgb_wavelet_denoise_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.ecgb_wavelet_denoise_scratch_bytes.restype = sz
+    L.ecgb_wavelet_denoise_f64.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, vp, sz, vp]
+    L.ecgb_wavelet_denoise_f64.restype = C.c_int
     i32 = C.c_int32
     L.ecgb_assemble_hip.argtypes = [vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32,
                                     C.c_int, u32, vp, vp, vp, vp, vp, vp]

@@ -111,7 +111,226 @@ __global__ __launch_bounds__(64) void filtfilt_kernel(FiltfiltArgs A)
     }
 }
 
+// ---- cubic-spline resampling -----------------------------------------------------------------------------------------------------------
+// scipy.interpolate.interp1d(t, y, kind='cubic') is the not-a-knot cubic spline through all n samples (make_interp_spline, k = 3, default
+// boundary conditions), evaluated at m equally spaced targets over the same span (preprocess_utils.py:90-101).  The interpolant does not
+// depend on how it is computed, so instead of scipy's banded B-spline solve this is the classic second-derivative form on the unit grid:
+//   M[i-1] + 4 M[i] + M[i+1] = 6 (y[i+1] - 2 y[i] + y[i-1])            1 <= i <= n-2
+//   not-a-knot:  M[0] = 2 M[1] - M[2],  M[n-1] = 2 M[n-2] - M[n-3]      => rows 1 and n-2 collapse to 6 M[1] = r[1], 6 M[n-2] = r[n-2]
+// one Thomas sweep per sequence over rows 2 .. n-3 (the pivots 1 / (4 - c') are the same for every sequence and reach their fixed point
+// 2 - sqrt(3) in double precision within ~20 rows), then  S(i + u) = y[i] + u (dy - (2 M[i] + M[i+1]) / 6) + u^2 M[i] / 2 + u^3 (M[i+1] - M[i]) / 6.
+// Agreement with scipy: the two solves differ by rounding only (1e-13 of the signal's range measured, tests/test_gpu_preprocess.py).
+struct ResampleArgs {
+    const double *x;                 // [R, n, L]
+    double *y;                       // [R, m, L]
+    double *M;                       // scratch [n][S]
+    int R, n, L, m;
+};
+
+__global__ __launch_bounds__(64) void resample_cubic_kernel(ResampleArgs A)
+{
+    const size_t S = (size_t)A.R * A.L;
+    const size_t seq = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= S) return;
+    const size_t r = seq / A.L, l = seq % A.L;
+    const int n = A.n, m = A.m, L = A.L;
+    const double *x = A.x + (r * n) * L + l;
+    double *out = A.y + (r * m) * L + l;
+    double *M = A.M + seq;
+    auto Y = [&](int i) -> double { return x[(size_t)i * L]; };
+    auto rhs = [&](int i) -> double { return 6.0 * (Y(i + 1) - 2.0 * Y(i) + Y(i - 1)); };
+    constexpr int kTab = 32;
+    double cp[kTab];                                         // c'[2 + k]; c'[2 + k] = c'[2 + kTab - 1] beyond the table (fixed point)
+    cp[0] = 0.25;
+#pragma unroll
+    for (int k = 1; k < kTab; ++k) cp[k] = 1.0 / (4.0 - cp[k - 1]);
+    auto cprime = [&](int i) -> double { const int k = i - 2; return cp[k < kTab ? k : kTab - 1]; };
+    const double M1 = rhs(1) / 6.0, Mn2 = rhs(n - 2) / 6.0;
+    M[(size_t)1 * S] = M1;
+    M[(size_t)(n - 2) * S] = Mn2;
+    if (n >= 6) {                                            // rows 2 .. n-3
+        double dprev = (rhs(2) - M1) * cprime(2);
+        M[(size_t)2 * S] = dprev;
+        for (int i = 3; i <= n - 3; ++i) {
+            double ri = rhs(i);
+            if (i == n - 3) ri -= Mn2;
+            dprev = (ri - dprev) * cprime(i);                // cprime(i) = 1 / (4 - c'[i-1])
+            M[(size_t)i * S] = dprev;
+        }
+        double Mnext = dprev;                                // M[n-3]
+        for (int i = n - 4; i >= 2; --i) {
+            Mnext = M[(size_t)i * S] - cprime(i) * Mnext;
+            M[(size_t)i * S] = Mnext;
+        }
+    } else if (n == 5) {
+        M[(size_t)2 * S] = (rhs(2) - M1 - Mn2) / 4.0;
+    }
+    M[0] = 2.0 * M[(size_t)1 * S] - M[(size_t)2 * S];
+    M[(size_t)(n - 1) * S] = 2.0 * M[(size_t)(n - 2) * S] - M[(size_t)(n - 3) * S];
+    for (int j = 0; j < m; ++j) {
+        const double s = m > 1 ? (double)j * (double)(n - 1) / (double)(m - 1) : 0.0;
+        int i = (int)s;
+        if (i > n - 2) i = n - 2;
+        const double u = s - (double)i;
+        const double y0 = Y(i), y1 = Y(i + 1), m0 = M[(size_t)i * S], m1 = M[(size_t)(i + 1) * S];
+        const double c1 = (y1 - y0) - (2.0 * m0 + m1) / 6.0, c2 = 0.5 * m0, c3 = (m1 - m0) / 6.0;
+        out[(size_t)j * L] = y0 + u * (c1 + u * (c2 + u * c3));
+    }
+}
+
+// ---- wavelet denoising ---------------------------------------------------------------------------------------------------------------------
+// preprocess_utils.py:43-64: coeffs = pywt.wavedec(x, 'db6', level=4) (mode 'symmetric'); threshold = median(|cD4|) / 0.6745 (0 when the
+// median is 0); every detail band soft-thresholded (pywt.threshold: c * max(0, 1 - thr / |c|)) and zeroed where not finite or |c| <= 1e-10;
+// pywt.waverec; NaN / inf -> 0.  PyWavelets is not installed anywhere this code runs: restated from its published algorithm, PARITY UNPINNED
+// (tests compare with oracle/preprocess_ref.py, an independent numpy restatement, and check the transform's own identities).
+//   analysis   cA[o] = sum_j dec_lo[j] xe[2 o + 1 - j],  cD likewise with dec_hi,  o < (N + 11) / 2;  xe = half-point symmetric extension
+//   synthesis  x[t]  = sum_o cA[o] dec_lo[2 o + 1 - t] + sum_o cD[o] dec_hi[2 o + 1 - t],  t < 2 Nc - 10; a band one sample longer than its
+//              detail band loses its last sample first (waverec)
+__constant__ double kDb6Lo[12] = {-0.00107730108499558, 0.004777257511010651, 0.0005538422009938016, -0.031582039318031156,
+                                  0.02752286553001629, 0.09750160558707936, -0.12976686756709563, -0.22626469396516913,
+                                  0.3152503517092432, 0.7511339080215775, 0.4946238903983854, 0.11154074335008017};
+constexpr int kWF = 12, kLevels = 4;
+
+struct WaveletArgs {
+    const double *x;                 // [R, n, L]
+    double *y;                       // [R, n, L]
+    double *work;                    // scratch, time-major: per level l (1..4) bands A_l and D_l of len[l] + 2 rows
+    int R, n, L;
+    int len[kLevels + 1];            // len[0] = n, len[l] = (len[l-1] + 11) / 2
+    long long offA[kLevels + 1], offD[kLevels + 1];   // row offsets into `work`
+    double epsilon;
+};
+
+__global__ __launch_bounds__(64) void wavelet_denoise_kernel(WaveletArgs A)
+{
+    const size_t S = (size_t)A.R * A.L;
+    const size_t seq = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (seq >= S) return;
+    const size_t r = seq / A.L, l0 = seq % A.L;
+    const int L = A.L, n = A.n;
+    const double *x = A.x + (r * n) * L + l0;
+    double *out = A.y + (r * n) * L + l0;
+    double *W = A.work + seq;
+    auto band = [&](long long off, int i) -> double & { return W[(size_t)(off + i) * S]; };
+    double lo[kWF], hi[kWF];
+#pragma unroll
+    for (int k = 0; k < kWF; ++k) { lo[k] = kDb6Lo[k]; hi[k] = ((k & 1) ? 1.0 : -1.0) * kDb6Lo[kWF - 1 - k]; }
+    // ---- wavedec
+    for (int lev = 1; lev <= kLevels; ++lev) {
+        const int N = A.len[lev - 1], Nc = A.len[lev];
+        auto in_at = [&](int i) -> double {                  // symmetric extension: ... x1 x0 | x0 x1 ... x[N-1] | x[N-1] x[N-2] ...
+            if (i < 0) i = -1 - i;
+            else if (i >= N) i = 2 * N - 1 - i;
+            return lev == 1 ? x[(size_t)i * L] : band(A.offA[lev - 1], i);
+        };
+        for (int o = 0; o < Nc; ++o) {
+            double sa = 0.0, sd = 0.0;
+#pragma unroll
+            for (int j = 0; j < kWF; ++j) {
+                const double v = in_at(2 * o + 1 - j);
+                sa += lo[j] * v;
+                sd += hi[j] * v;
+            }
+            band(A.offA[lev], o) = sa;
+            band(A.offD[lev], o) = sd;
+        }
+    }
+    // ---- threshold from the median of |cD4|: the two middle order statistics by a radix select on the bit patterns (monotone for x >= 0)
+    const int n4 = A.len[kLevels];
+    auto kth = [&](int k) -> double {
+        unsigned long long prefix = 0;
+        for (int bit = 62; bit >= 0; --bit) {
+            const unsigned long long mask = ~((1ull << bit) - 1);       // bits above and including `bit`
+            int zeros = 0;
+            for (int i = 0; i < n4; ++i) {
+                const unsigned long long u = (unsigned long long)__double_as_longlong(fabs(band(A.offD[kLevels], i)));
+                if ((u & mask) == prefix) ++zeros;                          // matches the prefix with this bit 0
+            }
+            if (k >= zeros) { k -= zeros; prefix |= 1ull << bit; }
+        }
+        return __longlong_as_double((long long)prefix);
+    };
+    bool any_nan = false;                                    // np.median of a band that holds a NaN is NaN
+    for (int i = 0; i < n4; ++i) any_nan |= isnan(band(A.offD[kLevels], i));
+    const double med = any_nan ? __longlong_as_double(0x7ff8000000000000ll) : (n4 & 1) ? kth(n4 / 2) : 0.5 * (kth(n4 / 2 - 1) + kth(n4 / 2));
+    const double thr = med == 0.0 ? 0.0 : med / 0.6745;
+    for (int lev = 1; lev <= kLevels; ++lev)
+        for (int i = 0; i < A.len[lev]; ++i) {
+            double &c = band(A.offD[lev], i);
+            const double mag = fabs(c);
+            double f = 1.0 - thr / mag;                      // pywt.threshold 'soft': data * clip(1 - value / |data|, 0)
+            f = f < 0.0 ? 0.0 : f;                           // (NaN, from 0 / 0, stays NaN and is zeroed by the test below)
+            const double t = c * f;
+            c = (isfinite(t) && mag > A.epsilon) ? t : 0.0;
+        }
+    // ---- waverec
+    int cur = A.len[kLevels];                                // length of the running approximation band (stored in A_lev)
+    for (int lev = kLevels; lev >= 1; --lev) {
+        const int Nd = A.len[lev];
+        if (cur == Nd + 1) cur = Nd;                         // waverec drops the extra sample
+        const int No = 2 * Nd - kWF + 2;
+        for (int t = 0; t < No; ++t) {
+            double sa = 0.0, sd = 0.0;
+            for (int o = t / 2; o < Nd && 2 * o + 1 - t < kWF; ++o) {       // t / 2 = smallest o with 2 o + 1 - t >= 0
+                const int k = 2 * o + 1 - t;
+                sa += band(A.offA[lev], o) * lo[k];
+                sd += band(A.offD[lev], o) * hi[k];
+            }
+            const double v = sa + sd;
+            if (lev > 1) band(A.offA[lev - 1], t) = v;
+            else if (t < n) out[(size_t)t * L] = isfinite(v) ? v : 0.0;
+        }
+        cur = No;
+    }
+}
+
 }  // namespace
+
+extern "C" size_t ecgb_wavelet_denoise_scratch_bytes(int records, int n, int leads)
+{
+    if (records <= 0 || n <= 0 || leads <= 0) return 0;
+    size_t rows = 0;
+    int len = n;
+    for (int lev = 1; lev <= kLevels; ++lev) { len = (len + kWF - 1) / 2; rows += 2 * ((size_t)len + 2); }
+    return (size_t)records * leads * rows * sizeof(double);
+}
+
+extern "C" int ecgb_wavelet_denoise_f64(const double *x_dev, double *y_dev, int records, int n, int leads, double epsilon, double *scratch_dev,
+                                        size_t scratch_bytes, void *stream)
+{
+    if (!x_dev || !y_dev || !scratch_dev || records <= 0 || n <= 0 || leads <= 0) { ecgb::set_error("ecgb_wavelet_denoise_f64: bad argument"); return ECGB_ERR_INVALID; }
+    if (n % 2) { ecgb::set_error("ecgb_wavelet_denoise_f64: odd lengths reconstruct one sample long (the reference's assignment raises)"); return ECGB_ERR_UNSUPPORTED; }
+    WaveletArgs A{};
+    A.x = x_dev; A.y = y_dev; A.work = scratch_dev; A.R = records; A.n = n; A.L = leads; A.epsilon = epsilon;
+    A.len[0] = n;
+    long long row = 0;
+    for (int lev = 1; lev <= kLevels; ++lev) {
+        if (A.len[lev - 1] < kWF - 1) { ecgb::set_error("ecgb_wavelet_denoise_f64: signal too short for four db6 levels"); return ECGB_ERR_UNSUPPORTED; }
+        A.len[lev] = (A.len[lev - 1] + kWF - 1) / 2;
+        A.offA[lev] = row; row += A.len[lev] + 2;
+        A.offD[lev] = row; row += A.len[lev] + 2;
+    }
+    if (scratch_bytes < ecgb_wavelet_denoise_scratch_bytes(records, n, leads)) { ecgb::set_error("ecgb_wavelet_denoise_f64: scratch too small"); return ECGB_ERR_INVALID; }
+    const size_t S = (size_t)records * leads;
+    hipLaunchKernelGGL(wavelet_denoise_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, (hipStream_t)stream, A);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ecgb::set_error(std::string("wavelet_denoise_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
+}
+
+extern "C" int ecgb_resample_cubic_f64(const double *x_dev, double *y_dev, int records, int n, int leads, int m, double *scratch_dev,
+                                       size_t scratch_bytes, void *stream)
+{
+    if (!x_dev || !y_dev || !scratch_dev || records <= 0 || leads <= 0 || m <= 0) { ecgb::set_error("ecgb_resample_cubic_f64: bad argument"); return ECGB_ERR_INVALID; }
+    if (n < 4) { ecgb::set_error("ecgb_resample_cubic_f64: a cubic spline needs at least 4 samples (scipy raises too)"); return ECGB_ERR_INVALID; }
+    const size_t S = (size_t)records * leads;
+    if (scratch_bytes < S * (size_t)n * sizeof(double)) { ecgb::set_error("ecgb_resample_cubic_f64: scratch too small (records * leads * n doubles)"); return ECGB_ERR_INVALID; }
+    ResampleArgs A{x_dev, y_dev, scratch_dev, records, n, leads, m};
+    hipLaunchKernelGGL(resample_cubic_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, (hipStream_t)stream, A);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ecgb::set_error(std::string("resample_cubic_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
+}
 
 extern "C" size_t ecgb_filtfilt_scratch_bytes(int records, int n, int leads, int max_edge)
 {

@@ -94,6 +94,49 @@ def advanced_ecg_filter(ecg_data, fs=500, notch_freqs=[50, 60], highcut=100.0):
     return filtfilt(design_filters(fs, tuple(notch_freqs), highcut), ecg_data)
 
 
+def wavelet_denoise(ecg_data, wavelet='db6', level=4, epsilon=1e-10):
+    """preprocess_utils.py:43-64: db6 / level 4 wavelet shrinkage with the threshold median(|cD4|) / 0.6745 (ecgb_wavelet_denoise_f64;
+    PyWavelets is absent: restated from its published algorithm, parity unpinned).  Only the reference's wavelet and level are built."""
+    if wavelet != 'db6' or level != 4:
+        raise NotImplementedError("the reference calls wavelet_denoise with its defaults (db6, level 4): only those are built")
+    xb, single = _batch(ecg_data)
+    R, n, leads = xb.shape
+    out = torch.empty_like(xb)
+    nbytes = _L().ecgb_wavelet_denoise_scratch_bytes(R, n, leads)
+    scratch = torch.empty(nbytes // 8, dtype=torch.float64, device=xb.device)
+    _lib.check(_L().ecgb_wavelet_denoise_f64(C.c_void_p(xb.data_ptr()), C.c_void_p(out.data_ptr()), R, n, leads, float(epsilon),
+                                             C.c_void_p(scratch.data_ptr()), nbytes, _st()))
+    return out[0] if single else out
+
+
+def condition_records(signals, reorder=True, seg_len=1250, orig_fs=500, target_fs=250):
+    """process_instance, preprocess_utils.py:118-160, for a BATCH of raw records [records, n, 12] already on the device (reading wfdb
+    files stays with the caller): NaN/inf -> 0, MIMIC lead order, the filter chain, wavelet shrinkage, resampling to target_fs, whole
+    segments of seg_len samples.  Returns [records, segments, seg_len, 12]; records that still hold NaN / inf are the caller's to drop
+    (`torch.isfinite(out).all(dim=(1, 2, 3))`), as the reference skips them."""
+    x = check_nan_inf(signals, "reading")
+    if reorder:
+        x = check_nan_inf(reorder_indices(x).contiguous(), "reordering")
+    x = check_nan_inf(advanced_ecg_filter(x, fs=orig_fs), "advanced filtering")
+    x = check_nan_inf(wavelet_denoise(x), "wavelet denoising")
+    x = check_nan_inf(nsample_ecg(x, orig_fs, target_fs), "resampling")
+    seg, _ = segment_ecg(x, None, seg_len)
+    return check_nan_inf(seg, "segmentation")
+
+
+def nsample_ecg(ecg_data, orig_fs, target_fs):
+    """preprocess_utils.py:90-101: cubic-spline resampling (scipy interp1d kind='cubic' = not-a-knot spline through every sample) to
+    int(n * target_fs / orig_fs) equally spaced instants over the same span (ecgb_resample_cubic_f64)."""
+    xb, single = _batch(ecg_data)
+    R, n, leads = xb.shape
+    m = int(n * target_fs / orig_fs)
+    out = torch.empty((R, m, leads), dtype=torch.float64, device=xb.device)
+    scratch = torch.empty(R * leads * n, dtype=torch.float64, device=xb.device)
+    _lib.check(_L().ecgb_resample_cubic_f64(C.c_void_p(xb.data_ptr()), C.c_void_p(out.data_ptr()), R, n, leads, m,
+                                            C.c_void_p(scratch.data_ptr()), scratch.numel() * 8, _st()))
+    return out[0] if single else out
+
+
 def segment_ecg(ecg_data, text_data, seg_len):
     """preprocess_utils.py:103-116: whole segments of seg_len samples, the tail dropped; the text repeated per segment.  One record
     [n, leads] -> ([segments, seg_len, leads], [text] * segments); a batch -> [records, segments, seg_len, leads]."""

@@ -197,6 +197,20 @@ size_t ecgb_filtfilt_scratch_bytes(int records, int n, int leads, int max_edge);
 int ecgb_filtfilt_f64(const double *x_dev, double *y_dev, int records, int n, int leads, int n_filters, const int *n_taps,
                       const double *b, const double *a, const double *zi, double *scratch_dev, size_t scratch_bytes, void *stream);
 
+/* ecg_byte/utils/preprocess_utils.py:90-101 nsample_ecg: scipy.interpolate.interp1d(t, y, kind='cubic') -- the not-a-knot cubic spline
+ * through all n samples -- evaluated at m equally spaced instants over the same span (the reference: 5000 samples at 500 Hz -> 2500 at
+ * 250 Hz).  x_dev [records, n, leads] -> y_dev [records, m, leads], float64; n >= 4.  Scratch: records * leads * n doubles. */
+int ecgb_resample_cubic_f64(const double *x_dev, double *y_dev, int records, int n, int leads, int m, double *scratch_dev,
+                            size_t scratch_bytes, void *stream);
+
+/* ecg_byte/utils/preprocess_utils.py:43-64 wavelet_denoise: four-level db6 decomposition (pywt.wavedec, mode 'symmetric'), threshold =
+ * median(|cD4|) / 0.6745, soft threshold of every detail band (zero where |c| <= epsilon, the reference passes 1e-10), pywt.waverec,
+ * NaN / inf -> 0.  PyWavelets is not installed here: restated from its published algorithm, parity UNPINNED.
+ * x_dev, y_dev: [records, n, leads] float64, n even and >= 96; may alias.  Scratch: ecgb_wavelet_denoise_scratch_bytes. */
+size_t ecgb_wavelet_denoise_scratch_bytes(int records, int n, int leads);
+int ecgb_wavelet_denoise_f64(const double *x_dev, double *y_dev, int records, int n, int leads, double epsilon, double *scratch_dev,
+                             size_t scratch_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

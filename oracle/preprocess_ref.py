@@ -66,6 +66,73 @@ def filtfilt_literal(b, a, x):
     return y[e:-e]
 
 
+def nsample_ecg(ecg_data, orig_fs, target_fs):               # preprocess_utils.py:90-101
+    from scipy import interpolate
+    num_samples, num_leads = ecg_data.shape
+    duration = num_samples / orig_fs
+    t_original = np.linspace(0, duration, num_samples, endpoint=True)
+    t_target = np.linspace(0, duration, int(num_samples * target_fs / orig_fs), endpoint=True)
+    downsampled_data = np.zeros((len(t_target), num_leads))
+    for lead in range(num_leads):
+        f = interpolate.interp1d(t_original, ecg_data[:, lead], kind='cubic', bounds_error=False, fill_value="extrapolate")
+        downsampled_data[:, lead] = f(t_target)
+    return downsampled_data
+
+
 def segment_ecg(ecg_data, text_data, seg_len):               # preprocess_utils.py:103-116
     num_segments = ecg_data.shape[0] // seg_len
     return (np.array([ecg_data[i * seg_len:(i + 1) * seg_len, :] for i in range(num_segments)]), [text_data] * num_segments)
+
+
+# ---- wavelet_denoise: PyWavelets restated (PARITY UNPINNED: pywt is not installed; conventions from its documentation and C sources) --------
+DB6_DEC_LO = np.array([-0.00107730108499558, 0.004777257511010651, 0.0005538422009938016, -0.031582039318031156, 0.02752286553001629,
+                       0.09750160558707936, -0.12976686756709563, -0.22626469396516913, 0.3152503517092432, 0.7511339080215775,
+                       0.4946238903983854, 0.11154074335008017])
+DB6_DEC_HI = np.array([(-1.0) ** (k + 1) * DB6_DEC_LO[11 - k] for k in range(12)])      # quadrature mirror of the low-pass
+
+
+def dwt_symmetric(x):
+    """pywt.dwt(x, 'db6', mode='symmetric'): full convolution of the half-point symmetric extension with the decomposition filters,
+    every second sample starting at index 1: (len(x) + 11) // 2 coefficients per band."""
+    F = 12
+    ext = np.concatenate([x[F - 2::-1] if len(x) >= F - 1 else None, x, x[:-F:-1]])      # x[10..0] | x | x[-1..-11]
+    full_lo = np.convolve(ext, DB6_DEC_LO)[F - 1:]           # index i of the un-padded convolution = index i + (F - 1) here
+    full_hi = np.convolve(ext, DB6_DEC_HI)[F - 1:]
+    nc = (len(x) + F - 1) // 2
+    return full_lo[1:2 * nc:2], full_hi[1:2 * nc:2]
+
+
+def idwt_symmetric(ca, cd):
+    """pywt.idwt(ca, cd, 'db6'): 2 len(ca) - 10 samples, x[t] = sum_o ca[o] dec_lo[2o + 1 - t] + cd[o] dec_hi[2o + 1 - t]."""
+    n = 2 * len(ca) - 10
+    x = np.zeros(n)
+    for t in range(n):
+        o = np.arange(t // 2, min(len(ca), (t + 12) // 2))
+        k = 2 * o + 1 - t
+        x[t] = (ca[o] * DB6_DEC_LO[k]).sum() + (cd[o] * DB6_DEC_HI[k]).sum()
+    return x
+
+
+def wavelet_denoise(ecg_data, level=4, epsilon=1e-10):       # preprocess_utils.py:43-64
+    denoised = np.zeros_like(ecg_data)
+    for i in range(ecg_data.shape[1]):
+        a, details = ecg_data[:, i], []
+        for _ in range(level):                                # wavedec
+            a, d = dwt_symmetric(a)
+            details.append(d)
+        coeffs = [a] + details[::-1]                          # [cA4, cD4, cD3, cD2, cD1]
+        median_abs = np.median(np.abs(coeffs[-level]))
+        threshold = 0 if median_abs == 0 else median_abs / 0.6745
+
+        def safe_threshold(c):
+            with np.errstate(divide='ignore', invalid='ignore'):
+                thresholded = c * np.clip(1 - threshold / np.abs(c), 0, None)           # pywt.threshold(c, threshold, mode='soft')
+            return np.where(np.isfinite(thresholded) & (np.abs(c) > epsilon), thresholded, 0)
+        new = [coeffs[0]] + [safe_threshold(c) for c in coeffs[1:]]
+        a = new[0]
+        for d in new[1:]:                                     # waverec
+            if len(a) == len(d) + 1:
+                a = a[:-1]
+            a = idwt_symmetric(a, d)
+        denoised[:, i] = a
+    return np.nan_to_num(denoised, nan=0.0, posinf=0.0, neginf=0.0)

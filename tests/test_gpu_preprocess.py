@@ -55,6 +55,60 @@ def test_filter_chain_batches_against_scipy(pp, R, n):
         assert np.abs(got[r] - want).max() <= 1e-10 * max(np.abs(want).max(), 1e-3), r
 
 
+def test_resample_golden_and_batches(pp):
+    """The not-a-knot spline in second-derivative form against scipy's B-spline solve: the same interpolant, rounding apart (1e-11 of
+    the signal's range allowed; 1e-13 typical).  Golden record, the reference's 5000 -> 2500, an odd ratio, the shortest inputs."""
+    got = pp.nsample_ecg(torch.from_numpy(G["filtered"][0]).cuda(), 500, 250).cpu().numpy()
+    want = G["resampled"][0]
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-11 * np.abs(want).max()
+    for R, n, fs_in, fs_out in [(3, 5000, 500, 250), (2, 1001, 500, 360), (2, 4, 500, 1000), (1, 5, 500, 250), (2, 6, 100, 250), (1, 7, 500, 500)]:
+        x = _records(R, n, seed=n)
+        got = pp.nsample_ecg(torch.from_numpy(x).cuda(), fs_in, fs_out).cpu().numpy()
+        for r in range(R):
+            want = P.nsample_ecg(x[r], fs_in, fs_out)
+            assert got[r].shape == want.shape
+            assert np.abs(got[r] - want).max() <= 1e-11 * max(np.abs(want).max(), 1e-3), (n, r, np.abs(got[r] - want).max())
+
+
+@pytest.mark.parametrize("R,n", [(1, 5000), (9, 5000), (2, 640), (3, 98)])
+def test_wavelet_denoise_against_the_restatement(pp, R, n):
+    """csrc/preprocess.hip against oracle.wavelet_denoise (an independent numpy restatement; PyWavelets itself is not available: parity
+    unpinned) -- same decomposition, same median / threshold, same reconstruction to 1e-11 of the signal's range."""
+    x = _records(R, n, seed=7 * R + n)
+    got = pp.wavelet_denoise(torch.from_numpy(x).cuda()).cpu().numpy()
+    for r in range(R):
+        want = P.wavelet_denoise(x[r])
+        assert np.abs(got[r] - want).max() <= 1e-11 * max(np.abs(want).max(), 1e-3), (r, np.abs(got[r] - want).max())
+
+
+def test_wavelet_denoise_edge_cases(pp):
+    z = torch.zeros(2, 640, 12, dtype=torch.float64, device="cuda")
+    assert bool((pp.wavelet_denoise(z) == 0).all())                                     # median 0 -> threshold 0 -> 0 / 0 guarded
+    c = torch.full((640, 12), 0.25, dtype=torch.float64, device="cuda")
+    assert float((pp.wavelet_denoise(c) - 0.25).abs().max()) < 1e-10
+    xb = _records(1, 640, seed=2)[0]
+    xb[100, 3] = np.nan                                                                 # np.median is NaN then: every detail of the lead is
+    out = pp.wavelet_denoise(torch.from_numpy(xb).cuda()).cpu().numpy()                 # zeroed, the NaN's neighbourhood becomes 0
+    want = P.wavelet_denoise(xb)
+    assert np.isfinite(out).all() and np.abs(out - want).max() <= 1e-11 * np.abs(want).max()
+    assert (out[95:106, 3] == 0).all() and (want[95:106, 3] == 0).all()
+    from ecg_byte_amd._lib import EcgbError
+    with pytest.raises(EcgbError):
+        pp.wavelet_denoise(torch.zeros(641, 12, dtype=torch.float64, device="cuda"))
+
+
+def test_condition_records_is_the_reference_pipeline(pp):
+    """process_instance's order of operations on a batch: reorder, filter chain, wavelet shrinkage, 500 -> 250 Hz, segments."""
+    x = _records(3, 5000, seed=4)
+    got = pp.condition_records(torch.from_numpy(x).cuda(), reorder=True, seg_len=1250).cpu().numpy()
+    assert got.shape == (3, 2, 1250, 12)
+    for r in range(3):
+        y = P.reorder_indices(x[r])
+        y = P.nsample_ecg(P.wavelet_denoise(P.advanced_ecg_filter(y)), 500, 250)
+        want, _ = P.segment_ecg(y, None, 1250)
+        assert np.abs(got[r] - want).max() <= 1e-9 * np.abs(want).max()
+
+
 def test_short_signals_are_refused_like_scipy(pp):
     from ecg_byte_amd._lib import EcgbError
     with pytest.raises(EcgbError):
