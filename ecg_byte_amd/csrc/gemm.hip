@@ -908,6 +908,156 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
 }
 
 
+// ---- NN product for input gradients: C[M, N] = alpha * A[M, K] . B[K, N] with B ROW-major (dX = dY . W with W = [out, in] as nn.Linear
+// stores it): no transposed shadow copy of the weight.  The A side is gemm_nt_kernel_m16p's (rows of 64 contraction elements, LDS image
+// [256 rows][128 B], ds_read_b128 fragments), the B side is gemm_tn_kernel_tr's ([64 contraction rows] x [256 columns] as it lies in memory,
+// fragments by ds_read_b64_tr_b16 from the per-lane address tables), on the same four-phase staggered schedule.  Lane for lane the MFMAs see
+// the operands of the NT kernel run on a transposed copy of B, so the results are the same bits (tests).
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM *WGN * 64) void gemm_nn_kernel_m16p(GemmArgs G)
+{
+    static_assert(BM == 256 && BN == 256 && WGM == 2 && WGN == 4, "phase schedule written for the 256x256 tile, 2x4 waves");
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int kABytes = BM * BK * 2, kBBytes = BN * BK * 2, kBufBytes = kABytes + kBBytes;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nwg = G.tiles_m * G.tiles_n;
+    const int orig = blockIdx.x;
+    const int q = nwg / 8, rr = nwg % 8, xcd = orig % 8;
+    const int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
+    const int tm = wgid / G.tiles_n, tn = wgid % G.tiles_n;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int wr = wave / WGN, wc = wave % WGN;
+    const int lm = lane & 15, lq = lane >> 4;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int KT = G.K / BK;
+    // LDS-DMA addresses: scalar running pointers + constant per-lane byte offsets (see gemm_nt_kernel_m16p / gemm_tn_kernel_tr)
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);                                // A: tile row, 8 rows of 128 B per instruction
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        const int ra = min(row0 + r, G.M - 1) - row0;
+        offA[i] = (unsigned)(((long long)ra * G.lda + chunk * 8) * 2);
+        const int rk = (wave * 4 + i) * 2 + (lane >> 5);                               // B: contraction row inside the tile, 2 rows of 512 B
+        const int chunkb = (lane & 31) ^ (((rk & 7) << 1) ^ (rk & 8));
+        offB[i] = (unsigned)(((long long)rk * G.ldb + min(col0 + chunkb * 8, G.N - 8)) * 2);      // clamped columns are never stored
+    }
+    const unsigned char *nextA = reinterpret_cast<const unsigned char *>(G.A + (long long)row0 * G.lda);
+    const unsigned char *nextB = reinterpret_cast<const unsigned char *>(G.B);
+    auto stage_a = [&](unsigned char *dst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nextA + offA[i]),
+                                             (__attribute__((address_space(3))) void *)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
+        nextA += BK * 2;
+    };
+    auto stage_b = [&](unsigned char *dst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nextB + offB[i]),
+                                             (__attribute__((address_space(3))) void *)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
+        nextB += (long long)BK * G.ldb * 2;
+    };
+    stage_b(lds + kABytes);
+    stage_a(lds);
+    if (KT > 1) {
+        stage_b(lds + kBufBytes + kABytes);
+        stage_a(lds + kBufBytes);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    // B fragment addresses: the tables of gemm_tn_kernel_tr (entry m & 7 of the fragment at columns 16 m.., + offset field)
+    using i2 = __attribute__((ext_vector_type(2))) int;
+    using i4 = __attribute__((ext_vector_type(4))) int;
+    const int tq = lm >> 2, tp = lm & 3;
+    unsigned tabB0[4], tabB1[4];
+    {
+        const int rb = 8 * lq + tq;
+        const int sw = (rb & 7) ^ ((rb & 8) >> 1);
+        const unsigned lane_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds + rb * 512 + (tp & 1) * 8;
+        const int cb = tp >> 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = (wc & 1) * 4 + j;
+            tabB0[j] = lane_base + (wc >> 1) * 256 + (((2 * (m ^ sw)) + cb) << 4);
+            tabB1[j] = lane_base + (wc >> 1) * 256 + (((2 * (m ^ 4 ^ sw)) + cb) << 4);
+        }
+    }
+    bf16x8 a[2][4], b[2][4];
+    for (int kt = 0; kt < KT; ++kt) {
+        const unsigned char *At = lds + (kt & 1) * kBufBytes;
+        unsigned char *nxt = lds + (kt & 1) * kBufBytes;
+        const bool more = kt + 2 < KT;
+        auto read_a = [&](int half) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ra = wr * WTM + (half * 4 + i) * 16 + lm, chunk = ks * 4 + lq;
+                    a[ks][i] = *reinterpret_cast<const bf16x8 *>(At + ra * 128 + ((chunk ^ ((ra >> 1) & 7)) << 4));
+                }
+        };
+        auto fragb = [&](unsigned t0, unsigned t1, auto off) {
+            constexpr int OFF = decltype(off)::value;
+            i2 lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(t0), "n"(OFF));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(t1), "n"(OFF + 2048));
+            const i4 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+            return __builtin_bit_cast(bf16x8, f);
+        };
+        auto read_b = [&](int half) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                b[0][half * 2 + j] = fragb(tabB0[half * 2 + j], tabB1[half * 2 + j], std::integral_constant<int, kABytes>{});
+                b[1][half * 2 + j] = fragb(tabB0[half * 2 + j], tabB1[half * 2 + j], std::integral_constant<int, kABytes + 32 * 512>{});
+            }
+        };
+        auto mfma_quadrant = [&](int ah, int bh) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ah * 4 + i][bh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ks][bh * 2 + j], a[ks][i], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        read_b(0);
+        read_a(0);
+        mfma_quadrant(0, 0);
+        read_b(1);
+        mfma_quadrant(0, 1);
+        read_a(1);
+        if (more) stage_b(nxt + kABytes);
+        mfma_quadrant(1, 1);
+        if (more) {
+            stage_a(nxt);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        mfma_quadrant(1, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { tabB0[j] ^= (unsigned)kBufBytes; tabB1[j] ^= (unsigned)kBufBytes; }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    store_tile_m16<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, 0);
+}
+
 // C[M, N] = alpha * A[M, K] . B[N, K]^T for M <= 8 (the decode step of generate(): one new token per sequence).  No MFMA
 // tile to fill: the product is bound by reading B once.  One wave per output column n: the 64 lanes walk row n of B in
 // 16-byte pieces (1 KiB per step, coalesced), multiply with the matching pieces of the M rows of A (L2-resident), reduce
@@ -1272,5 +1422,35 @@ extern "C" int ecgb_gemm_nt_glu_bf16(const void *a_dev, long long lda, const voi
         e = hipGetLastError();
     }
     if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_kernel (glu): ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
+}
+
+// C[M, N] = alpha * A[M, K] . B[K, N], B row-major (the input gradient dX = dY . W against the weight as nn.Linear stores it, [out, in]):
+// what ecgb_gemm_nt_bf16 computes on a transposed copy of B, without the copy.  accumulate as in ecgb_gemm_nt_bf16.
+extern "C" int ecgb_gemm_nn_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N,
+                                 int K, float alpha, int accumulate_f32, void *stream)
+{
+    if (!a_dev || !b_dev || !c_dev || M <= 0 || N <= 0 || K <= 0) { ecgb::set_error("ecgb_gemm_nn_bf16: bad argument"); return ECGB_ERR_INVALID; }
+    if (K % BK || N % 8 || N < 8 || lda % 8 || ldb % 8 || ((uintptr_t)a_dev & 15) || ((uintptr_t)b_dev & 15) ||
+        (64 * ldb + N) * 2 >= (1ll << 32) || (256 * lda + K) * 2 >= (1ll << 32)) {
+        ecgb::set_error("ecgb_gemm_nn_bf16: K % 64, N % 8, 16-byte aligned operands with strides % 8 (below 2^24) required");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    GemmArgs G;
+    G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = c_dev;
+    G.M = M; G.N = N; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = ldc;
+    G.batch_a = G.batch_b = G.batch_c = 0;
+    G.accumulate_f32 = accumulate_f32; G.alpha = alpha;
+    G.A2 = G.B2 = nullptr; G.lda2 = G.ldb2 = 0; G.K2 = 0;
+    G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
+    G.tiles_m = (M + 255) / 256; G.tiles_n = (N + 255) / 256;
+    constexpr int lds = 2 * (256 + 256) * BK * 2;
+    auto kern = gemm_nn_kernel_m16p<256, 256, 2, 4>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, 1), dim3(512), lds, (hipStream_t)stream, G);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nn_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
     return ECGB_OK;
 }

@@ -440,6 +440,13 @@ class HipCausalLM(nn.Module):
         for key in [k for k, (_, pid) in self._t.items() if pid in param_ids]:
             del self._t[key]
 
+    def _dx(self, dy, key, p):
+        """dx = dy . W for a weight stored [out, in] (the input gradient of y = x W^T): the NN kernel reads W as it lies; shapes below its
+        256x256 tile go through the NT kernel on a transposed shadow copy (`_shadow`)."""
+        if ops.nn_eligible(dy.shape[0], p.shape[1], p.shape[0]):
+            return ops.gemm_nn(dy, p.data)
+        return ops.gemm_nt(dy, self._shadow(key, p))
+
     def _proj(self, i, key, x, w, training=False, keep=False):
         """One projection of layer i ("qkv", "o", "gu", "down"): x W^T, plus the LoRA branch of the site when adapters are on
         (in the same launch).  Returns (y, what the adapter's backward needs or None)."""
@@ -656,7 +663,7 @@ class HipCausalLM(nn.Module):
         else:
             self.embed_grad32.zero_()
         dhf = torch.zeros((T, H), dtype=torch.bfloat16, device=dev)
-        embed_t = self._shadow("embed", self.embed)                      # [H, v_pad]
+
         chunk = 4096
         for s0 in range(0, rows.numel(), chunk):
             r = rows[s0:s0 + chunk]
@@ -664,7 +671,7 @@ class HipCausalLM(nn.Module):
             lab = shifted.index_select(0, r)
             logits = ops.gemm_nt(hr, self.embed.data)                    # [n, v_pad]
             ops.ce_fwd_bwd_(logits, lab, inv_count, loss, c.vocab_size)  # logits <- dlogits
-            dhr = ops.gemm_nt(logits, embed_t)                           # [n, H] = dlogits . E
+            dhr = self._dx(logits, "embed", self.embed)                  # [n, H] = dlogits . E
             dhf.index_copy_(0, r, dhr)
             if self.lora is not None:
                 continue                                                 # frozen base: no embedding / lm_head gradient
@@ -960,14 +967,14 @@ class HipCausalLM(nn.Module):
             x1, rstd1, h1, qkv, P, ao, x2, rstd2, h2, gu, hm, ls = saved.pop()
             # MLP
             wgrad(g, hm, self.wdown[i])
-            d_hm = ops.gemm_nt(g, self._shadow(("wdown", i), self.wdown[i]))        # [T, I]
+            d_hm = self._dx(g, ("wdown", i), self.wdown[i])        # [T, I]
             if frozen:
                 d_gu = self.lora[i]["down"].backward(g, ls[3], self, d_hm, glu=(gu, self.gemma))   # adapters + GLU backward in one pass
             else:
                 d_gu = ops.glu_bwd(gu, d_hm, gelu_tanh=self.gemma)
             del d_hm, hm
             wgrad(d_gu, h2, self.wgu[i])
-            d_h2 = ops.gemm_nt(d_gu, self._shadow(("wgu", i), self.wgu[i]))         # [T, H]
+            d_h2 = self._dx(d_gu, ("wgu", i), self.wgu[i])         # [T, H]
             if frozen:
                 self.lora[i]["gu"].backward(d_gu, ls[2], self, d_h2)
             del d_gu, gu
@@ -976,7 +983,7 @@ class HipCausalLM(nn.Module):
             lngrad(self.ln2[i], dw)
             # attention output projection
             wgrad(g2, ao, self.wo[i])
-            d_ao = ops.gemm_nt(g2, self._shadow(("wo", i), self.wo[i]))             # [T, Hq*D]
+            d_ao = self._dx(g2, ("wo", i), self.wo[i])             # [T, Hq*D]
             if frozen:
                 self.lora[i]["o"].backward(g2, ls[1], self, d_ao)
             # attention core
@@ -987,7 +994,7 @@ class HipCausalLM(nn.Module):
             del P
             ops.rope_(d_qkv, cos, sin, Hq + Hkv, D, QKV, inverse=True)
             wgrad(d_qkv, h1, self.wqkv[i])
-            d_h1 = ops.gemm_nt(d_qkv, self._shadow(("wqkv", i), self.wqkv[i]))      # [T, H]
+            d_h1 = self._dx(d_qkv, ("wqkv", i), self.wqkv[i])      # [T, H]
             if frozen:
                 self.lora[i]["qkv"].backward(d_qkv, ls[0], self, d_h1)
             dw = torch.zeros(H, dtype=torch.float32, device=dev)

@@ -169,6 +169,24 @@ def gemm_nt(a, b, out=None, alpha=1.0, accumulate_f32=False, accumulate=False, a
     return out
 
 
+def nn_eligible(M, N, K):
+    """Shapes the NN kernel (256x256 tiles only) takes; smaller or ragged-K problems go through gemm_nt on a transposed copy."""
+    return M >= 256 and N >= 256 and N % 8 == 0 and K % 64 == 0 and ((M + 255) // 256) * ((N + 255) // 256) >= 192
+
+
+def gemm_nn(a, b, out=None, alpha=1.0, accumulate_f32=False, accumulate=False):
+    """C[M,N] = alpha * A[M,K] @ B[K,N], B row-major (dX = dY W against the weight as stored, [out, in]): no transposed copy of B
+    (ecgb_gemm_nn_bf16; the same bits as gemm_nt(a, b.T.contiguous()))."""
+    M, K = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == K and a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if accumulate_f32 else torch.bfloat16, device=a.device)
+    mode = 1 if accumulate_f32 else (2 if accumulate else 0)
+    _lib.check(_L().ecgb_gemm_nn_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, float(alpha), mode, _st()))
+    return out
+
+
 def glu_fusable(M, inter):
     """Shapes the GLU-epilogue GEMM takes: the 256x256 tile needs whole tiles of 128 gate + 128 up columns and enough of them to fill
     the chip (a decode step's few rows go through the few-row kernel and the separate GLU)."""

@@ -278,12 +278,12 @@ class HipGPT2LM(HipCausalLM):
             d_delta = undrop(g, c.resid_pdrop, seed_m)
             self._vgrad(self.bproj[i], ops.colsum(d_delta))
             self._wgrad(self.wproj[i], d_delta, hm)
-            d_hm = ops.gemm_nt(d_delta, self._shadow(("wproj", i), self.wproj[i]))
+            d_hm = self._dx(d_delta, ("wproj", i), self.wproj[i])
             d_u = ops.gelu_new_bwd(u, d_hm)
             del d_hm, hm, u
             self._vgrad(self.bfc[i], ops.colsum(d_u))
             self._wgrad(self.wfc[i], d_u, h2)
-            d_h2 = ops.gemm_nt(d_u, self._shadow(("wfc", i), self.wfc[i]))
+            d_h2 = self._dx(d_u, ("wfc", i), self.wfc[i])
             del d_u
             dw, db = z(H), z(H)
             g2 = ops.layernorm_bwd(x2, self.ln2[i].data, mu2, rs2, d_h2, dw, db, dres=g)
@@ -292,14 +292,14 @@ class HipGPT2LM(HipCausalLM):
             d_ad = undrop(g2, c.resid_pdrop, seed_a)
             self._vgrad(self.bo[i], ops.colsum(d_ad))
             self._wgrad(self.wo[i], d_ad, ao)
-            d_ao = ops.gemm_nt(d_ad, self._shadow(("wo", i), self.wo[i]))
+            d_ao = self._dx(d_ad, ("wo", i), self.wo[i])
             if isinstance(lse, tuple):
                 d_qkv = self._attn_materialised_bwd(qkv, d_ao, lse[0], B, S, drop=lse[1])
             else:
                 d_qkv = ops.attn_bwd(qkv, mask, ao, d_ao, lse, B, S, nh, nh, D, scale)
             self._vgrad(self.bqkv[i], ops.colsum(d_qkv))
             self._wgrad(self.wqkv[i], d_qkv, h1)
-            d_h1 = ops.gemm_nt(d_qkv, self._shadow(("wqkv", i), self.wqkv[i]))
+            d_h1 = self._dx(d_qkv, ("wqkv", i), self.wqkv[i])
             dw, db = z(H), z(H)
             g = ops.layernorm_bwd(x1, self.ln1[i].data, mu1, rs1, d_h1, dw, db, dres=g2)
             self._vgrad(self.ln1[i], dw)

@@ -111,6 +111,11 @@ int ecgb_bias_act(void *u_dev, const void *bias_dev, void *h_dev, size_t rows, i
 int ecgb_gelu_new_bwd(const void *pre_dev, const void *dh_dev, void *dpre_dev, size_t n, void *stream);
 int ecgb_colsum(const void *dy_dev, float *out_dev, size_t rows, int n, void *stream);
 
+/* C[M,N] = alpha * A[M,K] . B[K,N] with B ROW-major: the input gradient dX = dY . W against the weight as nn.Linear stores it
+ * ([out, in], modeling_llama.py:227-258,273-395) -- what ecgb_gemm_nt_bf16 computes on a transposed copy of B, without the copy (the
+ * same bits).  accumulate_f32 as in ecgb_gemm_nt_bf16.  K % 64 == 0, N % 8 == 0. */
+int ecgb_gemm_nn_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N,
+                      int K, float alpha, int accumulate_f32, void *stream);
 /* The MLP's gate|up projection with the GLU in the GEMM's epilogue (modeling_llama.py:227-258
  * `down_proj(act_fn(gate_proj(x)) * up_proj(x))`; gelu_tanh != 0: Gemma's GeGLU):  gate|up [M, 2*inter] = alpha * (A . B^T
  * [+ A2 . B2^T]) with B = [2*inter, K] (gate rows, then up rows), H [M, inter] = act(gate) * up on the bf16-rounded gate and up

@@ -351,6 +351,30 @@ def test_lora_dx_with_glu_backward_is_bitwise_the_two_kernels(ops, p, gelu_tanh)
     assert torch.equal(dx, keep)
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 2048, 3072), (4000, 2048, 64), (32768, 2048, 128), (8192, 8192, 2048), (3000, 2056, 192)])
+def test_gemm_nn_is_bitwise_the_nt_kernel_on_a_transposed_copy(ops, M, N, K):
+    """dX = dY . W against the weight as stored ([out, in] row-major): the NN kernel (A side of the NT kernel, B side by transposing LDS
+    reads) against gemm_nt on W^T -- identical bits, repeated under memory traffic (LDS race screen); 1, 2, 3 and many K-tiles, ragged
+    rows and columns; the accumulate modes."""
+    assert ops.nn_eligible(32768, 2048, 3072) and not ops.nn_eligible(8, 2048, 3072) and not ops.nn_eligible(4096, 2048, 40)
+    a, w = _bf(M, K, seed=81), _bf(K, N, scale=K ** -0.5, seed=82)
+    want = ops.gemm_nt(a, ops.transpose(w))
+    noise = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
+    for rep in range(8):
+        noise.random_()
+        assert torch.equal(ops.gemm_nn(a, w), want), rep
+    _close(want, a.float() @ w.float(), atol=1e-2 * math.sqrt(K) / 8)
+    base = _bf(M, N, seed=83)
+    o1, o2 = base.clone(), base.clone()
+    ops.gemm_nt(a, ops.transpose(w), out=o1, alpha=0.5, accumulate=True)
+    ops.gemm_nn(a, w, out=o2, alpha=0.5, accumulate=True)
+    assert torch.equal(o1, o2)
+    f1, f2 = torch.ones((M, N), device="cuda"), torch.ones((M, N), device="cuda")
+    ops.gemm_nt(a, ops.transpose(w), out=f1, accumulate_f32=True)
+    ops.gemm_nn(a, w, out=f2, accumulate_f32=True)
+    assert torch.equal(f1, f2)
+
+
 def test_sumsq_multi_equals_per_tensor_sum(ops):
     """One launch over a list of gradient tensors (sizes from 8 elements to a few chunks of 2^20, an unaligned view among
     them) against the fp32 sum of squares."""
