@@ -144,12 +144,14 @@ def lib():
         "ecgb_lora_dx": [vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, vp],
         "ecgb_lora_dx_glu": [vp, vp, vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, ci, vp],
         "ecgb_attn_fwd": [vp, ll, vp, ll, vp, ll, vp, vp, ll, vp, ci, ci, ci, ci, ci, f32, vp],
-        "ecgb_attn_bwd": [vp, ll, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp, vp, ll, vp, ll, vp, ll, ci, ci, ci, ci, ci, f32, vp],
+        "ecgb_attn_bwd": [vp, ll, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp, vp, ll, vp, ll, vp, ll, ci, ci, ci, ci, ci, f32, vp, sz, vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    L.ecgb_attn_bwd_scratch_bytes.argtypes = [ci, ci, ci, ci, ci]
+    L.ecgb_attn_bwd_scratch_bytes.restype = sz
     L.ecgb_attn_decode_split_scratch_bytes.argtypes = [ll, ci, ci, ci, ci]
     L.ecgb_attn_decode_split_scratch_bytes.restype = sz
     _lib = L

@@ -57,6 +57,10 @@ struct AttnArgs {
     long long lddq, lddk, lddv;
     int B, S, Hq, Hkv;
     float scale;
+    // dK/dV with the query heads of a KV group split over `head_splits` workgroups (few key blocks, one KV head: Gemma): split h writes its
+    // fp32 partial sums to slab [which (0 = dK, 1 = dV)][h][B * S][D]; attn_dkv_reduce_kernel adds the slabs in order
+    float *slab;
+    int head_splits;
 };
 
 #ifdef ECGB_PROFILE
@@ -211,6 +215,22 @@ __device__ __forceinline__ void store_accT(const f32x16 (&acc)[NB], unsigned sho
             v[0] = pack_bf16(acc[db][gq * 4 + 0] * mul, acc[db][gq * 4 + 1] * mul);
             v[1] = pack_bf16(acc[db][gq * 4 + 2] * mul, acc[db][gq * 4 + 3] * mul);
             *reinterpret_cast<u2 *>(g + row * ld + db * 32 + gq * 8 + 4 * h) = v;
+        }
+}
+
+// the same into a contiguous fp32 [row][D] slab
+template <int NB>
+__device__ __forceinline__ void store_accT_f32(const f32x16 (&acc)[NB], float *g, long long ld, long long row, bool valid, int h)
+{
+    if (!valid) return;
+#pragma unroll
+    for (int db = 0; db < NB; ++db)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            using f4 = __attribute__((ext_vector_type(4))) float;
+            f4 v;
+            v[0] = acc[db][gq * 4 + 0]; v[1] = acc[db][gq * 4 + 1]; v[2] = acc[db][gq * 4 + 2]; v[3] = acc[db][gq * 4 + 3];
+            *reinterpret_cast<f4 *>(g + row * ld + db * 32 + gq * 8 + 4 * h) = v;
         }
 }
 
@@ -489,7 +509,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
 // work of a single pass instead of the 2.5 x of splitting the d range four ways (DS = 4, the first head_dim-256 version: 3.3 ms per
 // layer at Gemma-2B's shape).
 template <int D, int DS, int WHICH>
-__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs &A, const int block_x, const int b, const int g)
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs &A, const int block_x, const int b, const int g, const int hsplit = 0)
 {
     constexpr bool DO_V = WHICH != 2, DO_K = WHICH != 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 4 x 128 D bytes + 512
@@ -519,9 +539,10 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs &A, const int b
     const bool first_half = threadIdx.x < 128;            // first half stages Q, second half dO
     const int t_begin = (kk0 / 64) * 64;                   // first query tile that can see this key block
     const int tiles_per_head = (A.S - t_begin + 63) / 64;
-    const int n_steps = G * tiles_per_head;
+    const int heads_here = G / (A.head_splits > 1 ? A.head_splits : 1), head_lo = hsplit * heads_here;   // this workgroup's query heads of the group
+    const int n_steps = heads_here * tiles_per_head;
     auto src_of = [&](int step, int &t0, long long &stat) -> const unsigned short * {
-        const int hq = g * G + step / tiles_per_head;
+        const int hq = g * G + head_lo + step / tiles_per_head;
         t0 = t_begin + (step % tiles_per_head) * 64;
         stat = ((long long)b * A.Hq + hq) * A.S;
         return first_half ? A.q + (long long)hq * D + rowbase * A.ldq : A.d_o + (long long)hq * D + rowbase * A.ldo;
@@ -601,6 +622,13 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs &A, const int b
             }
         }
     }
+    if (A.head_splits > 1) {                                 // partial sums over this workgroup's heads: fp32 slabs, reduced in order afterwards
+        const long long rows_all = (long long)A.B * A.S, slab = rows_all * A.Hkv * D;
+        float *base = A.slab + (long long)hsplit * slab + ((long long)g * rows_all) * D + db0 * 32;
+        if constexpr (DO_K) store_accT_f32<NB>(accK, base, D, rowbase + ki, kvalid, h);
+        if constexpr (DO_V) store_accT_f32<NB>(accV, base + (long long)A.head_splits * slab, D, rowbase + ki, kvalid, h);
+        return;
+    }
     if constexpr (DO_K) store_accT<NB>(accK, A.dk + (long long)g * D + db0 * 32, A.lddk, rowbase + ki, kvalid, h, 1.f);
     if constexpr (DO_V) store_accT<NB>(accV, A.dv + (long long)g * D + db0 * 32, A.lddv, rowbase + ki, kvalid, h, 1.f);
 }
@@ -617,10 +645,35 @@ __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(Attn
 template <int D>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pair_kernel(AttnArgs A)
 {
+    // blocks of a (batch, KV head) group: (key block, head split, pass) with the key block slowest -- heaviest first
+    const int hs = A.head_splits > 1 ? A.head_splits : 1;
     int blk, head_in, group;
-    map_block((int)blockIdx.x, ((A.S + 127) / 128) * 2, 1, A.B * A.Hkv, false, blk, head_in, group);
-    if (blk & 1) attn_bwd_dkv_body<D, 1, 2>(A, blk >> 1, group / A.Hkv, group % A.Hkv);
-    else attn_bwd_dkv_body<D, 1, 1>(A, blk >> 1, group / A.Hkv, group % A.Hkv);
+    map_block((int)blockIdx.x, ((A.S + 127) / 128) * 2 * hs, 1, A.B * A.Hkv, false, blk, head_in, group);
+    const int pass = blk & 1, hsplit = (blk >> 1) % hs, kblk = (blk >> 1) / hs;
+    if (pass) attn_bwd_dkv_body<D, 1, 2>(A, kblk, group / A.Hkv, group % A.Hkv, hsplit);
+    else attn_bwd_dkv_body<D, 1, 1>(A, kblk, group / A.Hkv, group % A.Hkv, hsplit);
+}
+
+// dk / dv [row][g * D + d] (bf16, row strides lddk / lddv) = sum over the head splits of the fp32 slabs, in split order
+template <int D>
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnArgs A)
+{
+    const long long rows_all = (long long)A.B * A.S, slab = rows_all * A.Hkv * D;
+    const long long n4 = slab / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n4; i += (long long)gridDim.x * blockDim.x) {
+        const int which = i >= n4;                           // 0 = dK, 1 = dV
+        const long long e = (i - which * n4) * 4;            // element inside a slab: [g][row][d]
+        const long long g = e / (rows_all * D), row = (e / D) % rows_all;
+        const int d = (int)(e % D);
+        using f4 = __attribute__((ext_vector_type(4))) float;
+        f4 v = *reinterpret_cast<const f4 *>(A.slab + (long long)which * A.head_splits * slab + e);
+        for (int hsp = 1; hsp < A.head_splits; ++hsp) v += *reinterpret_cast<const f4 *>(A.slab + ((long long)which * A.head_splits + hsp) * slab + e);
+        using u2 = __attribute__((ext_vector_type(2))) unsigned;
+        u2 o;
+        o[0] = pack_bf16(v[0], v[1]); o[1] = pack_bf16(v[2], v[3]);
+        unsigned short *dst = which ? A.dv + row * A.lddv : A.dk + row * A.lddk;
+        *reinterpret_cast<u2 *>(dst + g * D + d) = o;
+    }
 }
 
 // =====================================================================================================
@@ -942,11 +995,33 @@ extern "C" int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev
     return launched("attn_fwd_kernel");
 }
 
+namespace {
+// head_dim 256 with few (batch, KV head, key block) workgroups: the causal key blocks differ 16-fold in work and one launch of <= 256
+// workgroups takes as long as its heaviest one (key block 0).  Splitting a group's query heads over 2..4 workgroups gives the scheduler
+// pieces to balance with (heaviest first); the price is fp32 partial slabs and a small ordered reduction.
+int dkv_head_splits(int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim)
+{
+    if (head_dim != 256) return 1;
+    const int G = n_q_heads / n_kv_heads;
+    const long long wgs = (long long)((seq + 127) / 128) * n_kv_heads * batch * 2;
+    int hs = 1;
+    while (wgs * hs < 1024 && hs * 2 <= 4 && G % (hs * 2) == 0) hs *= 2;
+    return hs;
+}
+}  // namespace
+
+extern "C" size_t ecgb_attn_bwd_scratch_bytes(int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim)
+{
+    if (batch <= 0 || seq <= 0 || n_q_heads <= 0 || n_kv_heads <= 0 || n_q_heads % n_kv_heads) return 0;
+    const int hs = dkv_head_splits(batch, seq, n_q_heads, n_kv_heads, head_dim);
+    return hs > 1 ? (size_t)2 * hs * batch * seq * n_kv_heads * head_dim * sizeof(float) : 0;
+}
+
 extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev, long long ldk, const void *v_dev, long long ldv,
                              const float *attn_mask_dev, const void *o_dev, const void *do_dev, long long ldo,
                              const float *lse_dev, float *delta_dev, void *dq_dev, long long lddq, void *dk_dev, long long lddk,
                              void *dv_dev, long long lddv, int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim,
-                             float scale, void *stream)
+                             float scale, void *scratch_dev, size_t scratch_bytes, void *stream)
 {
     AttnArgs A = {};
     A.q = (const unsigned short *)q_dev; A.k = (const unsigned short *)k_dev; A.v = (const unsigned short *)v_dev;
@@ -958,6 +1033,13 @@ extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev
     int rc = check_args(A, head_dim, "ecgb_attn_bwd");
     if (rc) return rc;
     if (lddq % 4 || lddk % 4 || lddv % 4) { ecgb::set_error("ecgb_attn_bwd: gradient row strides must be multiples of 4"); return ECGB_ERR_UNSUPPORTED; }
+    A.head_splits = dkv_head_splits(batch, seq, n_q_heads, n_kv_heads, head_dim);
+    A.slab = (float *)scratch_dev;
+    if (A.head_splits > 1 && (!scratch_dev || ((uintptr_t)scratch_dev & 15) ||
+                              scratch_bytes < ecgb_attn_bwd_scratch_bytes(batch, seq, n_q_heads, n_kv_heads, head_dim))) {
+        ecgb::set_error("ecgb_attn_bwd: scratch of ecgb_attn_bwd_scratch_bytes() bytes (16-byte aligned) required for this shape");
+        return ECGB_ERR_INVALID;
+    }
     const unsigned nblk = (unsigned)((seq + 127) / 128);
     const dim3 gq(nblk * (unsigned)n_q_heads * (unsigned)batch);          // 1-D: map_block() deals blocks to XCDs
     const unsigned gk = nblk * (unsigned)n_kv_heads * (unsigned)batch;
@@ -973,8 +1055,10 @@ extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev
     else {
         ECGB_BWD(256);
         const int lk = 4 * 128 * 256 + 512;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_pair_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, lk) == hipSuccess)
-            hipLaunchKernelGGL(attn_bwd_dkv_pair_kernel<256>, dim3(gk * 2), dim3(256), lk, (hipStream_t)stream, A);
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_pair_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, lk) == hipSuccess) {
+            hipLaunchKernelGGL(attn_bwd_dkv_pair_kernel<256>, dim3(gk * 2 * (unsigned)A.head_splits), dim3(256), lk, (hipStream_t)stream, A);
+            if (A.head_splits > 1) hipLaunchKernelGGL(attn_dkv_reduce_kernel<256>, dim3(2048), dim3(256), 0, (hipStream_t)stream, A);
+        }
     }
 #undef ECGB_BWD
 #undef ECGB_DKV

@@ -396,9 +396,11 @@ def attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale):
     QKV = qkv.shape[1]
     d_qkv = torch.empty_like(qkv)
     delta = torch.empty((B, Hq, S), dtype=torch.float32, device=qkv.device)
+    nbytes = _L().ecgb_attn_bwd_scratch_bytes(B, S, Hq, Hkv, D)          # partial dK / dV slabs (head_dim 256 with few key blocks), else 0
+    scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device) if nbytes else None
     _lib.check(_L().ecgb_attn_bwd(_off(qkv, 0), QKV, _off(qkv, Hq * D), QKV, _off(qkv, Hq * D + Hkv * D), QKV, _p(mask),
                                   _p(o), _p(_bf(do)), Hq * D, _p(lse), _p(delta), _off(d_qkv, 0), QKV, _off(d_qkv, Hq * D), QKV,
-                                  _off(d_qkv, Hq * D + Hkv * D), QKV, B, S, Hq, Hkv, D, float(scale), _st()))
+                                  _off(d_qkv, Hq * D + Hkv * D), QKV, B, S, Hq, Hkv, D, float(scale), _p(scratch), nbytes, _st()))
     return d_qkv
 
 

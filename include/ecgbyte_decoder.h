@@ -182,10 +182,13 @@ int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev, long long
                   int n_q_heads, int n_kv_heads, int head_dim, float scale, void *stream);
 /* dq/dk/dv from dO (same layout as o).  delta_dev [batch, n_q_heads, seq] fp32 is scratch (rowsum(dO*O)).
  * dK/dV sum over the query heads of each KV group inside the kernel (no atomics). */
+/* scratch of ecgb_attn_bwd: fp32 partial dK / dV slabs when the query heads of a KV group are split over workgroups (head_dim 256 with
+ * few key blocks: Gemma); 0 for every other shape (scratch_dev may then be null). */
+size_t ecgb_attn_bwd_scratch_bytes(int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim);
 int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev, long long ldk, const void *v_dev, long long ldv,
                   const float *attn_mask_dev, const void *o_dev, const void *do_dev, long long ldo, const float *lse_dev,
                   float *delta_dev, void *dq_dev, long long lddq, void *dk_dev, long long lddk, void *dv_dev,
-                  long long lddv, int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim, float scale, void *stream);
+                  long long lddv, int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim, float scale, void *scratch_dev, size_t scratch_bytes, void *stream);
 
 /* One decode step of generate(): q [batch, n_q_heads*head_dim] against a KV cache whose rows (one per position) are
  * `ld` elements apart, `capacity` rows per batch entry, KV head g at + g*head_dim; the first kv_len rows are valid
