@@ -107,7 +107,7 @@ def lib():
         "ecgb_embed_fwd": [vp, vp, vp, sz, ci, f32, vp],
         "ecgb_embed_bwd": [vp, vp, vp, sz, ci, f32, vp],
         "ecgb_rmsnorm_fwd": [vp, vp, vp, vp, vp, vp, sz, ci, f32, ci, vp],
-        "ecgb_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, sz, ci, ci, vp],
+        "ecgb_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, sz, ci, ci, vp, vp],
         "ecgb_rope": [vp, vp, vp, sz, ci, ci, sz, ci, vp],
         "ecgb_glu_fwd": [vp, vp, sz, ci, ci, vp],
         "ecgb_glu_bwd": [vp, vp, vp, sz, ci, ci, vp],
@@ -121,7 +121,7 @@ def lib():
         "ecgb_count_labels": [vp, sz, ci, vp, vp],
         "ecgb_ce_fwd_bwd": [vp, vp, vp, vp, vp, sz, ci, sz, vp],
         "ecgb_sumsq": [vp, sz, ci, vp, vp],
-        "ecgb_sumsq_multi_bf16": [vp, vp, vp, vp, ci, vp, vp],
+        "ecgb_sumsq_multi_bf16": [vp, vp, vp, vp, ci, vp, vp, vp],
         "ecgb_adam_step": [vp, vp, ci, vp, vp, sz, vp, f32, f32, f32, f32, f32, f32, ci, vp],
         "ecgb_softmax_causal_fwd": [vp, vp, ci, ci, ci, f32, vp],
         "ecgb_softmax_bwd": [vp, vp, ci, ci, f32, vp],
@@ -150,6 +150,8 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    L.ecgb_rmsnorm_bwd_scratch_floats.argtypes = [sz, ci]
+    L.ecgb_rmsnorm_bwd_scratch_floats.restype = sz
     L.ecgb_attn_bwd_scratch_bytes.argtypes = [ci, ci, ci, ci, ci]
     L.ecgb_attn_bwd_scratch_bytes.restype = sz
     L.ecgb_attn_decode_split_scratch_bytes.argtypes = [ll, ci, ci, ci, ci]

@@ -191,7 +191,7 @@ template <bool GEMMA, int NC>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_rows_kernel(const unsigned short *x, const unsigned short *w,
                                                                const float *rstd, const unsigned short *dy,
                                                                const unsigned short *dres, unsigned short *dx, float *dw,
-                                                               size_t rows)
+                                                               size_t rows, float *partials)
 {
     constexpr int H = NC * 512;
     __shared__ float s_dw[H];
@@ -236,6 +236,19 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_rows_kernel(const unsigned sh
             }
             *reinterpret_cast<bf16x8 *>(dx + r * H + k * 512 + lane * 8) = o;
         }
+    }
+    if (partials) {                                          // the four waves add in wave order, the block's row goes to partials[block]
+        for (int w = 0; w < 4; ++w) {
+            if ((int)(threadIdx.x >> 6) == w) {
+#pragma unroll
+                for (int k = 0; k < NC; ++k)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s_dw[k * 512 + lane * 8 + j] += acc[k][j];
+            }
+            __syncthreads();
+        }
+        for (int c = threadIdx.x; c < H; c += blockDim.x) partials[(size_t)blockIdx.x * H + c] = s_dw[c];
+        return;
     }
 #pragma unroll
     for (int k = 0; k < NC; ++k)
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(unsigned short *logits,
         if (threadIdx.x == 0) {
             const float l = valid ? lse - bf2f(p[lab]) : 0.f;
             row_loss[r] = l;
-            if (valid) atomicAdd(sum_loss, l * inv_count);
+            if (valid && sum_loss) atomicAdd(sum_loss, l * inv_count);      // (null: the caller sums row_loss in order)
         }
         __syncthreads();
         const float scale = valid ? inv_count : 0.f;
@@ -461,7 +474,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const T *g, size_t n, float 
 // The same over a LIST of bf16 tensors in one launch (one launch per parameter tensor is ~100 launches of mostly tiny
 // work per step): block b sums chunk b = elements [chunk_off[b], chunk_off[b] + 2^20) of tensor chunk_tensor[b].
 __global__ __launch_bounds__(256) void sumsq_multi_kernel(const unsigned short *const *ptrs, const unsigned long long *counts,
-                                                          const int *chunk_tensor, const unsigned long long *chunk_off, float *acc)
+                                                          const int *chunk_tensor, const unsigned long long *chunk_off, float *acc,
+                                                          float *partials)
 {
     __shared__ float s_red[4];
     const int t = chunk_tensor[blockIdx.x];
@@ -479,7 +493,34 @@ __global__ __launch_bounds__(256) void sumsq_multi_kernel(const unsigned short *
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+    if (threadIdx.x == 0) {
+        const float b = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        if (partials) partials[blockIdx.x] = b;              // summed in chunk order by ordered_sum_kernel: the same bits every step
+        else atomicAdd(acc, b);
+    }
+}
+
+// *acc += sum of v[0..n) in a fixed order (one workgroup: strided partial sums, then the usual tree): the gradient norm must not depend
+// on the order in which workgroups happened to finish -- the clip factor multiplies every gradient.
+__global__ __launch_bounds__(256) void ordered_sum_kernel(const float *v, int n, float *acc)
+{
+    __shared__ float s_red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *acc += (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// dw[c] += sum over b < n_blocks of partials[b][c], in block order (the weight gradients of the norms: per-workgroup partial rows)
+__global__ __launch_bounds__(256) void partial_rows_sum_kernel(const float *partials, int n_blocks, int H, float *dw)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H) return;
+    float s = 0.f;
+    for (int b = 0; b < n_blocks; ++b) s += partials[(size_t)b * H + c];
+    dw[c] += s;
 }
 
 // torch.optim.Adam with weight_decay as L2 (main.py:262-264), preceded by clip_grad_norm_(1.0)
@@ -692,17 +733,26 @@ extern "C" int ecgb_rmsnorm_fwd(const void *x_dev, const void *residual_dev, con
     ECGB_CHECK_LAUNCH("rmsnorm_fwd");
 }
 
+extern "C" size_t ecgb_rmsnorm_bwd_scratch_floats(size_t rows, int hidden)
+{
+    if (hidden != 2048 && hidden != 4096) return 0;          // other widths: LDS + global atomics (order of arrival)
+    return std::min<size_t>(std::max<size_t>(1, rows / 64), 1024) * (size_t)hidden;
+}
+
 extern "C" int ecgb_rmsnorm_bwd(const void *x_dev, const void *w_dev, const float *rstd_dev, const void *dy_dev,
-                                const void *dres_dev, void *dx_dev, float *dw_dev, size_t rows, int hidden, int gemma, void *stream)
+                                const void *dres_dev, void *dx_dev, float *dw_dev, size_t rows, int hidden, int gemma, float *scratch_dev,
+                                void *stream)
 {
     if (hidden % 8) { ecgb::set_error("ecgb_rmsnorm_bwd: hidden must be a multiple of 8"); return ECGB_ERR_INVALID; }
     if (hidden == 2048 || hidden == 4096) {   // rows per wave ~16: enough to amortise the end-of-kernel reduction, enough waves to fill the chip
         const dim3 g2((unsigned)std::min<size_t>(std::max<size_t>(1, rows / 64), 1024));
 #define ECGB_RMS_BWD_ROWS(G_, NC_) hipLaunchKernelGGL((rmsnorm_bwd_rows_kernel<G_, NC_>), g2, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x_dev, \
-        (const unsigned short *)w_dev, rstd_dev, (const unsigned short *)dy_dev, (const unsigned short *)dres_dev, (unsigned short *)dx_dev, dw_dev, rows)
+        (const unsigned short *)w_dev, rstd_dev, (const unsigned short *)dy_dev, (const unsigned short *)dres_dev, (unsigned short *)dx_dev, dw_dev, rows, scratch_dev)
         if (hidden == 2048) { if (gemma) ECGB_RMS_BWD_ROWS(true, 4); else ECGB_RMS_BWD_ROWS(false, 4); }
         else { if (gemma) ECGB_RMS_BWD_ROWS(true, 8); else ECGB_RMS_BWD_ROWS(false, 8); }
 #undef ECGB_RMS_BWD_ROWS
+        if (scratch_dev)      // per-block partial rows -> dw, in block order (scratch: ecgb_rmsnorm_bwd_scratch_floats; null: atomics)
+            hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((unsigned)((hidden + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scratch_dev, (int)g2.x, hidden, dw_dev);
         ECGB_CHECK_LAUNCH("rmsnorm_bwd");
     }
     const dim3 grid((unsigned)std::min<size_t>(std::max<size_t>(1, rows / 4), 1024));
@@ -784,12 +834,13 @@ extern "C" int ecgb_sumsq(const void *g_dev, size_t n, int is_fp32, float *acc_d
 }
 
 extern "C" int ecgb_sumsq_multi_bf16(const void *const *ptrs_dev, const unsigned long long *counts_dev, const int *chunk_tensor_dev,
-                                    const unsigned long long *chunk_off_dev, int n_chunks, float *acc_dev, void *stream)
+                                    const unsigned long long *chunk_off_dev, int n_chunks, float *acc_dev, float *partials_dev, void *stream)
 {
     if (n_chunks <= 0) return ECGB_OK;
     if (!ptrs_dev || !counts_dev || !chunk_tensor_dev || !chunk_off_dev || !acc_dev) { ecgb::set_error("ecgb_sumsq_multi_bf16: NULL argument"); return ECGB_ERR_INVALID; }
     hipLaunchKernelGGL(sumsq_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short *const *)ptrs_dev, counts_dev, chunk_tensor_dev, chunk_off_dev, acc_dev);
+                       (const unsigned short *const *)ptrs_dev, counts_dev, chunk_tensor_dev, chunk_off_dev, acc_dev, partials_dev);
+    if (partials_dev) hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials_dev, n_chunks, acc_dev);
     ECGB_CHECK_LAUNCH("sumsq_multi");
 }
 

@@ -53,7 +53,10 @@ def rmsnorm_fwd(x, w, eps, residual=None, gemma=False):
 def rmsnorm_bwd(x, w, rstd, dy, dw_f32, dres=None, gemma=False):
     H = x.shape[-1]
     dx = torch.empty_like(x)
-    _lib.check(_L().ecgb_rmsnorm_bwd(_p(_bf(x)), _p(_bf(w)), _p(rstd), _p(_bf(dy)), _p(dres), _p(dx), _p(dw_f32), x.numel() // H, H, int(gemma), _st()))
+    rows = x.numel() // H
+    nf = _L().ecgb_rmsnorm_bwd_scratch_floats(rows, H)      # per-workgroup partial rows of dw, added in order (the same bits every launch)
+    scratch = torch.empty(nf, dtype=torch.float32, device=x.device) if nf else None
+    _lib.check(_L().ecgb_rmsnorm_bwd(_p(_bf(x)), _p(_bf(w)), _p(rstd), _p(_bf(dy)), _p(dres), _p(dx), _p(dw_f32), rows, H, int(gemma), _p(scratch), _st()))
     return dx
 
 
@@ -338,7 +341,8 @@ def ce_fwd_bwd_(logits, labels, inv_count, sum_loss, vocab):
     """logits [rows, ld] bf16 overwritten with dlogits; returns per-row losses (fp32)."""
     rows, ld = logits.shape
     row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
-    _lib.check(_L().ecgb_ce_fwd_bwd(_p(_bf(logits)), _p(labels), _p(row_loss), _p(sum_loss), _p(inv_count), rows, vocab, ld, _st()))
+    _lib.check(_L().ecgb_ce_fwd_bwd(_p(_bf(logits)), _p(labels), _p(row_loss), None, _p(inv_count), rows, vocab, ld, _st()))
+    sum_loss.add_(row_loss.sum() * inv_count)               # in a fixed order (the kernel's own float atomics add in order of arrival)
     return row_loss
 
 
@@ -360,12 +364,14 @@ class SumsqPlan:
         self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=device)
         self.chunk_off = torch.tensor(co, dtype=torch.int64, device=device)
         self.n_chunks = len(ct)
+        self.partials = torch.empty(len(ct), dtype=torch.float32, device=device)       # per-chunk sums, added in chunk order
 
 
 def sumsq_multi(tensors, acc, plan):
     """acc += sum over all (bf16, contiguous) tensors of their squared elements, one launch."""
     ptrs = torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64).to(acc.device, non_blocking=True)
-    _lib.check(_L().ecgb_sumsq_multi_bf16(_p(ptrs), _p(plan.counts), _p(plan.chunk_tensor), _p(plan.chunk_off), plan.n_chunks, _p(acc), _st()))
+    _lib.check(_L().ecgb_sumsq_multi_bf16(_p(ptrs), _p(plan.counts), _p(plan.chunk_tensor), _p(plan.chunk_off), plan.n_chunks, _p(acc),
+                                          _p(plan.partials), _st()))
 
 
 def adam_step_(p, g, m, v, sumsq_acc, max_norm, lr, beta1, beta2, eps, weight_decay, step):

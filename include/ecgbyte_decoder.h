@@ -38,8 +38,11 @@ int ecgb_embed_bwd(const int64_t *ids_dev, const void *dout_dev, float *grad_tab
 int ecgb_rmsnorm_fwd(const void *x_dev, const void *residual_dev, const void *w_dev, void *y_dev, void *sum_out_dev,
                      float *rstd_dev, size_t rows, int hidden, float eps, int gemma, void *stream);
 /* dx = rstd * (dy*w - xhat * mean(dy*w*xhat)) [+ dres];  dw_dev (fp32) += sum over rows of dy * xhat */
+/* scratch_dev (ecgb_rmsnorm_bwd_scratch_floats floats, or null): with it the weight gradient is summed in a fixed order (per-workgroup partial
+ * rows added in workgroup order: the same bits every launch; hidden 2048 / 4096), without it by LDS + global float atomics. */
+size_t ecgb_rmsnorm_bwd_scratch_floats(size_t rows, int hidden);
 int ecgb_rmsnorm_bwd(const void *x_dev, const void *w_dev, const float *rstd_dev, const void *dy_dev,
-                     const void *dres_dev, void *dx_dev, float *dw_dev, size_t rows, int hidden, int gemma, void *stream);
+                     const void *dres_dev, void *dx_dev, float *dw_dev, size_t rows, int hidden, int gemma, float *scratch_dev, void *stream);
 
 /* In-place rotary embedding of x [tokens, n_heads, head_dim] (row stride in elements), half-split
  * layout; cos/sin fp32 [tokens, head_dim/2].  inverse=1 applies the transpose rotation (backward). */
@@ -154,8 +157,9 @@ int ecgb_ce_fwd_bwd(void *logits_dev, const int64_t *labels_dev, float *row_loss
 int ecgb_sumsq(const void *g_dev, size_t n, int is_fp32, float *acc_dev, void *stream);
 /* The same over a list of bf16 tensors in ONE launch: ptrs_dev[t] / counts_dev[t] describe tensor t, and block b of the launch sums
  * the (at most 2^20) elements of tensor chunk_tensor_dev[b] that start at chunk_off_dev[b].  *acc_dev += the total. */
+/* partials_dev (n_chunks floats, or null): per-chunk sums stored and added in chunk order -- the same gradient norm bits every step; null: atomics. */
 int ecgb_sumsq_multi_bf16(const void *const *ptrs_dev, const unsigned long long *counts_dev, const int *chunk_tensor_dev,
-                          const unsigned long long *chunk_off_dev, int n_chunks, float *acc_dev, void *stream);
+                          const unsigned long long *chunk_off_dev, int n_chunks, float *acc_dev, float *partials_dev, void *stream);
 /* One Adam step (moments fp32, params bf16) with the gradient first scaled by min(1, max_norm/(sqrt(*sumsq)+1e-6))
  * and weight decay applied as L2 (grad += wd * param), as torch.optim.Adam does. */
 int ecgb_adam_step(void *param_dev, const void *grad_dev, int grad_is_fp32, float *m_dev, float *v_dev, size_t n,

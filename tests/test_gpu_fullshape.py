@@ -224,3 +224,50 @@ def test_b32_labelled_rows_loss_equals_full_logits_loss():
     for name, a, b in (("embed", e0, e1), ("down", d0, d1), ("qkv", q0, q1)):
         rel = ((a - b).norm() / b.norm()).item()
         assert rel < 2e-3, (name, rel)          # same arithmetic per row; fp32 atomics and chunk boundaries reorder the sums
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (e) run-to-run reproducibility of a whole step
+# ---------------------------------------------------------------------------------------------------------------------
+def _one_step(lora, seed):
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    cfg = DecoderConfig(**{**LLAMA_1B, "vocab_size": 4099}, rope_theta=500000.0, rope_scaling=dict(LLAMA3_SCALING), pad_token_id=4098)
+    m = HipCausalLM(cfg, seed=seed)
+    if lora:
+        m.enable_lora(r=16, alpha=32, dropout=0.05)
+    opt = m.make_optimizer()
+    ids, mask, labels, pos = _batch(8, 1024, cfg.vocab_size, cfg.vocab_size - 1, seed=21, pads=[0, 5, 300, 64, 0, 130, 17, 700], n_labels=60)
+    out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
+    out.loss.backward()
+    grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    opt.step_and_update_lr()
+    params = {n: p.data.clone() for n, p in m.named_parameters() if p.requires_grad}
+    return out.loss.detach().clone(), grads, params
+
+
+def test_lora_step_is_the_same_bits_twice():
+    """The reference's launch mode (LoRA r16, dropout 0.05) at Llama-3.2-1B widths, two layers, B 8 x S 1024, left padding: two models built
+    from the same seed take one step each -- loss, every adapter gradient and every updated adapter must be IDENTICAL.  Every kernel
+    of that step adds in a fixed order (K-slice slabs, per-chunk gradient-norm partials, row losses summed in order, no float atomics),
+    so a differing bit is a race or an uninitialised read."""
+    l1, g1, p1 = _one_step(True, seed=11)
+    l2, g2, p2 = _one_step(True, seed=11)
+    assert torch.equal(l1, l2)
+    assert g1.keys() == g2.keys() and len(g1) > 0
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    for k in p1:
+        assert torch.equal(p1[k], p2[k]), k
+
+
+def test_full_finetune_step_repeats_except_the_embedding_scatter():
+    """Full fine-tune: the loss and every gradient but the tied embedding's repeat bit for bit (the embedding scatter still adds its rows
+    with float atomics, in order of arrival; through the gradient norm that reaches the updated weights, which are therefore not compared)."""
+    l1, g1, _ = _one_step(False, seed=12)
+    l2, g2, _ = _one_step(False, seed=12)
+    assert torch.equal(l1, l2)
+    for k in g1:
+        if "embed" in k:
+            assert torch.allclose(g1[k].float(), g2[k].float(), atol=1e-3, rtol=1e-2), k
+        else:
+            assert torch.equal(g1[k], g2[k]), k
