@@ -89,6 +89,44 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long *ids, co
     }
 }
 
+// table(bf16)[id, :] += scale * sum of dout[t, :] over the tokens t with ids[t] == id, WITHOUT atomics and without an fp32 table: the tokens
+// arrive sorted by id (ids_sorted, order = the stable argsort), workgroup i owns the run of equal ids that STARTS at sorted position i (the
+// others return at once) and adds the run's rows in sorted order, in fp32, on top of what the table row already holds (the tied lm_head's
+// gradient) -- the same bits every launch.  skip_id: nn.Embedding's padding_idx, whose row takes no gradient from the lookup
+// (modeling_llama.py:889); it is also by far the longest run of a left-padded batch.
+__global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const long long *ids_sorted, const long long *order, const unsigned short *dout,
+                                                               unsigned short *table, size_t T, int H, float scale, long long skip_id)
+{
+    const size_t i = blockIdx.x;
+    const long long id = ids_sorted[i];
+    if (id == skip_id || (i > 0 && ids_sorted[i - 1] == id)) return;
+    size_t end = i + 1;
+    while (end < T && ids_sorted[end] == id) ++end;
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        size_t j = i;
+        for (; j + 4 <= end; j += 4) {                       // four rows in flight
+            bf16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8 *>(dout + (size_t)order[j + u] * H + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += bf2f(v[u][k]);
+        }
+        for (; j < end; ++j) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(dout + (size_t)order[j] * H + c);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += bf2f(v[k]);
+        }
+        unsigned short *dst = table + (size_t)id * H + c;
+        bf16x8 o = *reinterpret_cast<const bf16x8 *>(dst);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = f2bf(bf2f(o[k]) + acc[k] * scale);
+        *reinterpret_cast<bf16x8 *>(dst) = o;
+    }
+}
+
 // ---- RMSNorm ---------------------------------------------------------------------------------
 // One wave per row.  y = w * bf16(x * rsqrt(mean(x^2) + eps))  (Llama; gemma: (1 + w), fp32 product)
 // Optionally fuses the residual add that precedes it: x = a + b is written to `sum_out`.
@@ -715,6 +753,17 @@ extern "C" int ecgb_embed_bwd(const int64_t *ids_dev, const void *dout_dev, floa
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(tokens * (hidden / 8), 256)), dim3(256), 0, (hipStream_t)stream,
                        (const long long *)ids_dev, (const unsigned short *)dout_dev, grad_table_dev, tokens, hidden, scale);
     ECGB_CHECK_LAUNCH("embed_bwd");
+}
+
+extern "C" int ecgb_embed_bwd_sorted(const int64_t *ids_sorted_dev, const int64_t *order_dev, const void *dout_dev, void *grad_table_dev,
+                                    size_t tokens, int hidden, float scale, int64_t skip_id, void *stream)
+{
+    if (!ids_sorted_dev || !order_dev || !dout_dev || !grad_table_dev || hidden % 8) { ecgb::set_error("ecgb_embed_bwd_sorted: bad argument (hidden % 8)"); return ECGB_ERR_INVALID; }
+    if (tokens == 0) return ECGB_OK;
+    hipLaunchKernelGGL(embed_bwd_sorted_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (const long long *)ids_sorted_dev,
+                       (const long long *)order_dev, (const unsigned short *)dout_dev, (unsigned short *)grad_table_dev, tokens, hidden, scale,
+                       (long long)skip_id);
+    ECGB_CHECK_LAUNCH("embed_bwd_sorted");
 }
 
 extern "C" int ecgb_rmsnorm_fwd(const void *x_dev, const void *residual_dev, const void *w_dev, void *y_dev, void *sum_out_dev,

@@ -227,7 +227,7 @@ class HipCausalLM(nn.Module):
         self.lora = None        # nn.ModuleDict of LoraSite per layer once enable_lora() ran
         self._t = {}            # transposed shadow weights
         self._t_version = {}    # parameter version each shadow was made from
-        self.embed_grad32 = None
+        self.embed_grad_head = None
         self.full_logits = False   # True: run the loss head over every row, as the reference materialises it
         self._saved = None
         self.grad_sync = None      # parallel.GradAllReduce: told as soon as a layer's gradients are final
@@ -333,7 +333,7 @@ class HipCausalLM(nn.Module):
         self.cfg.vocab_size = n
         self.config.vocab_size = n
         self.v_pad = v_pad
-        self.embed_grad32 = None
+        self.embed_grad_head = None
         self._t.pop("embed", None)
 
     def enable_lora(self, r=16, alpha=32, dropout=0.05, seed=0):
@@ -646,7 +646,7 @@ class HipCausalLM(nn.Module):
 
     def _loss_head(self, hf, labels, B, S):
         """Tied lm_head + ForCausalLMLoss (loss_utils.py:24-47) over the final hidden states hf [B*S, H]: returns (loss, d loss / d hf)
-        and leaves d loss / d E of the head in self.embed_grad32 (unless the base is frozen)."""
+        and leaves d loss / d E of the head in self.embed_grad_head (bf16 [v_pad, H]; unless the base is frozen)."""
         c = self.cfg
         H = c.hidden_size
         dev = self.device
@@ -658,31 +658,46 @@ class HipCausalLM(nn.Module):
         inv_count = ops.count_labels(shifted, c.vocab_size)
         rows = torch.arange(T, device=dev) if self.full_logits else torch.nonzero(shifted != -100).view(-1)
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        if self.embed_grad32 is None:
-            self.embed_grad32 = torch.zeros((self.v_pad, H), dtype=torch.float32, device=dev)
-        else:
-            self.embed_grad32.zero_()
+        frozen = self.lora is not None
+        if not frozen and self.embed_grad_head is None:
+            self.embed_grad_head = torch.empty((self.v_pad, H), dtype=torch.bfloat16, device=dev)
         dhf = torch.zeros((T, H), dtype=torch.bfloat16, device=dev)
 
         chunk = 4096
+        first = True
         for s0 in range(0, rows.numel(), chunk):
             r = rows[s0:s0 + chunk]
-            hr = hf.index_select(0, r)                                   # gather (plumbing)
-            lab = shifted.index_select(0, r)
-            logits = ops.gemm_nt(hr, self.embed.data)                    # [n, v_pad]
-            ops.ce_fwd_bwd_(logits, lab, inv_count, loss, c.vocab_size)  # logits <- dlogits
-            dhr = self._dx(logits, "embed", self.embed)                  # [n, H] = dlogits . E
-            dhf.index_copy_(0, r, dhr)
-            if self.lora is not None:
-                continue                                                 # frozen base: no embedding / lm_head gradient
             n = r.numel()
-            npad = (n + 63) // 64 * 64                                   # contraction over rows: K-step 64
-            dlt = torch.zeros((self.v_pad, npad), dtype=torch.bfloat16, device=dev)
-            ops.transpose_strided(logits, 0, dlt, 0, n, self.v_pad, self.v_pad, npad, 1, 1, 0, 0, 0, 0)
-            hrt = torch.zeros((H, npad), dtype=torch.bfloat16, device=dev)
-            ops.transpose_strided(hr, 0, hrt, 0, n, H, H, npad, 1, 1, 0, 0, 0, 0)
-            ops.gemm_nt(dlt, hrt, out=self.embed_grad32, accumulate_f32=True)   # dE += dlogits^T . h
+            npad = (n + 63) // 64 * 64                                   # the weight-gradient product contracts over the rows: K-step 64
+            hr = torch.zeros((npad, H), dtype=torch.bfloat16, device=dev)     # rows past n: zero states, label -100 -> zero logits, zero dlogits
+            hr[:n] = hf.index_select(0, r)                               # gather (plumbing)
+            lab = torch.full((npad,), -100, dtype=torch.int64, device=dev)
+            lab[:n] = shifted.index_select(0, r)
+            logits = ops.gemm_nt(hr, self.embed.data)                    # [npad, v_pad]
+            ops.ce_fwd_bwd_(logits, lab, inv_count, loss, c.vocab_size)  # logits <- dlogits
+            dhr = self._dx(logits, "embed", self.embed)                  # [npad, H] = dlogits . E
+            dhf.index_copy_(0, r, dhr[:n])
+            if frozen:
+                continue                                                 # frozen base: no embedding / lm_head gradient
+            ops.gemm_tn(logits, hr, out=self.embed_grad_head, accumulate=not first)    # dE (+)= dlogits^T . h, straight from the row-major operands
+            first = False
+        if not frozen and first:                                         # no labelled row at all
+            self.embed_grad_head.zero_()
         return loss, dhf
+
+    def _embedding_grad(self, param, head, ids, g, scale, skip_id):
+        """param.grad (+)= head (the tied lm_head's share, or None) + the scatter of the rows of g by ids -- in the flat gradient buffer,
+        without atomics (ecgb_embed_bwd_sorted)."""
+        view, acc = self._grad_slot(param)
+        if head is not None:
+            if acc:
+                ops.add(view, head, out=view)
+            else:
+                view.copy_(head)
+        elif not acc:
+            view.zero_()
+        ops.embed_bwd_sorted_(ids, g, view, scale, skip_id)
+        param.grad = view
 
     # ---- inference -----------------------------------------------------------------------------
     def _hidden_states(self, input_ids, attention_mask=None, position_ids=None, kv_out=None):
@@ -943,11 +958,12 @@ class HipCausalLM(nn.Module):
         T = B * S
         scale = 1.0 / math.sqrt(D)
         go = float(grad_out)   # d(final)/d(loss); 1.0 for loss.backward()
+        frozen = self.lora is not None
         if go != 1.0:
             dhf = (dhf.float() * go).to(torch.bfloat16)
-            self.embed_grad32.mul_(go)
+            if not frozen:
+                self.embed_grad_head.copy_((self.embed_grad_head.float() * go).to(torch.bfloat16))
 
-        frozen = self.lora is not None
         self._grad_layout()
         L = c.num_hidden_layers
 
@@ -1003,9 +1019,8 @@ class HipCausalLM(nn.Module):
             if self.grad_sync is not None:   # this layer's gradients are final: its range of the flat buffer may leave
                 self.grad_sync.on_flat_ready(self._gflat, *self._granges[L - 1 - i])
         if not frozen:
-            ops.embed_bwd(input_ids.view(-1), g, self.embed_grad32, self.embed_scale)
-            self._vgrad(self.embed, self.embed_grad32)
-            self.embed_grad32.zero_()
+            pad = c.pad_token_id if c.pad_token_id is not None else -1       # nn.Embedding(padding_idx): no lookup gradient for that row
+            self._embedding_grad(self.embed, self.embed_grad_head, input_ids.view(-1), g, self.embed_scale, pad)
         if self.grad_sync is not None:
             if not frozen:
                 self.grad_sync.on_flat_ready(self._gflat, *self._granges[L])

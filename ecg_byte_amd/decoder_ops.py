@@ -35,6 +35,16 @@ def embed_fwd(ids, table, scale=1.0):
     return out
 
 
+def embed_bwd_sorted_(ids, dout, grad_table_bf16, scale=1.0, skip_id=-1):
+    """grad_table_bf16[id] += scale * sum of dout rows with that id, in place, no atomics (ecgb_embed_bwd_sorted): the same bits every call."""
+    flat = ids.reshape(-1)
+    ids_sorted, order = torch.sort(flat, stable=True)
+    assert grad_table_bf16.dtype == torch.bfloat16 and grad_table_bf16.is_contiguous()
+    _lib.check(_L().ecgb_embed_bwd_sorted(_p(ids_sorted), _p(order), _p(_bf(dout)), _p(grad_table_bf16), flat.numel(), dout.shape[-1], float(scale),
+                                          int(skip_id), _st()))
+    return grad_table_bf16
+
+
 def embed_bwd(ids, dout, grad_table_f32, scale=1.0):
     _lib.check(_L().ecgb_embed_bwd(_p(ids.contiguous()), _p(_bf(dout)), _p(grad_table_f32), ids.numel(), dout.shape[-1], float(scale), _st()))
 

@@ -96,8 +96,7 @@ class HipGPT2LM(HipCausalLM):
         self.qkv = 3 * H
         self.lora = None
         self._t, self._t_version = {}, {}
-        self.embed_grad32 = None
-        self.wpe_grad32 = None
+        self.embed_grad_head = None
         self.full_logits = False
         self._saved = None
         self.grad_sync = None
@@ -261,7 +260,7 @@ class HipGPT2LM(HipCausalLM):
         go = float(grad_out)
         if go != 1.0:
             dhf = (dhf.float() * go).to(torch.bfloat16)
-            self.embed_grad32.mul_(go)
+            self.embed_grad_head.copy_((self.embed_grad_head.float() * go).to(torch.bfloat16))
         self._grad_layout()
         L = c.n_layer
         z = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
@@ -307,14 +306,8 @@ class HipGPT2LM(HipCausalLM):
             if self.grad_sync is not None:
                 self.grad_sync.on_flat_ready(self._gflat, *self._granges[L - 1 - i])
         g = undrop(g, c.embd_pdrop, seed_e)
-        ops.embed_bwd(input_ids.view(-1), g, self.embed_grad32, 1.0)
-        self._vgrad(self.embed, self.embed_grad32)
-        self.embed_grad32.zero_()
-        if self.wpe_grad32 is None:
-            self.wpe_grad32 = torch.zeros(self.wpe.shape, dtype=torch.float32, device=dev)
-        ops.embed_bwd(position_ids.reshape(-1).contiguous(), g, self.wpe_grad32, 1.0)
-        self._vgrad(self.wpe, self.wpe_grad32)
-        self.wpe_grad32.zero_()
+        self._embedding_grad(self.embed, self.embed_grad_head, input_ids.view(-1), g, 1.0, -1)     # GPT-2's wte has no padding_idx
+        self._embedding_grad(self.wpe, None, position_ids.reshape(-1).contiguous(), g, 1.0, -1)
         if self.grad_sync is not None:
             self.grad_sync.on_flat_ready(self._gflat, *self._granges[L])
             self.grad_sync.finish()
@@ -385,6 +378,6 @@ class HipGPT2LM(HipCausalLM):
         self.embed = nn.Parameter(emb)
         self.cfg.vocab_size = self.config.vocab_size = n
         self.v_pad = v_pad
-        self.embed_grad32 = None
+        self.embed_grad_head = None
         self._t.pop("embed", None)
         self._gflat = None

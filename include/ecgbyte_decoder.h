@@ -32,6 +32,11 @@ int ecgb_embed_fwd(const int64_t *ids_dev, const void *table_dev, void *out_dev,
                    float scale, void *stream);
 int ecgb_embed_bwd(const int64_t *ids_dev, const void *dout_dev, float *grad_table_dev, size_t tokens, int hidden,
                    float scale, void *stream);
+/* The same scatter-add into a BF16 table without atomics: tokens sorted by id (ids_sorted_dev, order_dev = the stable argsort of ids); every
+ * run of equal ids is added in sorted order, in fp32, on top of what the row holds (the tied lm_head's gradient) -- the same bits every
+ * launch, no fp32 copy of the table.  skip_id: the padding_idx row (no gradient from the lookup, modeling_llama.py:889), or -1. */
+int ecgb_embed_bwd_sorted(const int64_t *ids_sorted_dev, const int64_t *order_dev, const void *dout_dev, void *grad_table_dev,
+                          size_t tokens, int hidden, float scale, int64_t skip_id, void *stream);
 
 /* y = w * bf16(x * rsqrt(mean(x^2)+eps)).  If residual_dev != NULL: x := x + residual first, written to
  * sum_out_dev.  rstd_dev (fp32 per row) is saved for the backward. */

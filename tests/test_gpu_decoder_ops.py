@@ -375,6 +375,28 @@ def test_gemm_nn_is_bitwise_the_nt_kernel_on_a_transposed_copy(ops, M, N, K):
     assert torch.equal(f1, f2)
 
 
+def test_embedding_scatter_sorted_is_exact_and_repeatable(ops):
+    """Rows scattered into a bf16 table in sorted order (no atomics): against an fp64 index_add on top of the table's previous contents,
+    heavy repeats of a few ids, a skipped padding id, and the same bits on every call."""
+    T, H, V = 5000, 1024, 700
+    g = torch.Generator(device="cuda").manual_seed(91)
+    ids = torch.randint(0, V, (T,), device="cuda", generator=g)
+    ids[:1500] = 7
+    ids[1500:1900] = 699
+    ids[1900:2400] = 3                                       # the padding id: skipped
+    dout = _bf(T, H, seed=92)
+    base = _bf(V, H, seed=93)
+    want = base.double()
+    keep = ids != 3
+    want.index_add_(0, ids[keep], dout[keep].double() * 0.5)
+    got = ops.embed_bwd_sorted_(ids, dout, base.clone(), scale=0.5, skip_id=3)
+    assert torch.equal(got[3], base[3])
+    err = (got.double() - want).abs()
+    assert bool((err <= 2 ** -8 * want.abs() + 1e-6).all()), err.max().item()
+    for _ in range(3):
+        assert torch.equal(ops.embed_bwd_sorted_(ids, dout, base.clone(), scale=0.5, skip_id=3), got)
+
+
 def test_sumsq_multi_equals_per_tensor_sum(ops):
     """One launch over a list of gradient tensors (sizes from 8 elements to a few chunks of 2^20, an unaligned view among
     them) against the fp32 sum of squares."""

@@ -260,14 +260,13 @@ def test_lora_step_is_the_same_bits_twice():
         assert torch.equal(p1[k], p2[k]), k
 
 
-def test_full_finetune_step_repeats_except_the_embedding_scatter():
-    """Full fine-tune: the loss and every gradient but the tied embedding's repeat bit for bit (the embedding scatter still adds its rows
-    with float atomics, in order of arrival; through the gradient norm that reaches the updated weights, which are therefore not compared)."""
-    l1, g1, _ = _one_step(False, seed=12)
-    l2, g2, _ = _one_step(False, seed=12)
+def test_full_finetune_step_is_the_same_bits_twice():
+    """Full fine-tune: loss, every gradient (the tied embedding's too: its rows are scattered in sorted order, no atomics) and every
+    updated weight repeat bit for bit."""
+    l1, g1, p1 = _one_step(False, seed=12)
+    l2, g2, p2 = _one_step(False, seed=12)
     assert torch.equal(l1, l2)
     for k in g1:
-        if "embed" in k:
-            assert torch.allclose(g1[k].float(), g2[k].float(), atol=1e-3, rtol=1e-2), k
-        else:
-            assert torch.equal(g1[k], g2[k]), k
+        assert torch.equal(g1[k], g2[k]), k
+    for k in p1:
+        assert torch.equal(p1[k], p2[k]), k
