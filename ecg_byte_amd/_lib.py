@@ -137,10 +137,10 @@ def lib():
         "ecgb_gemm_nt_glu_bf16": [vp, ll, vp, ll, vp, ll, vp, ll, ci, vp, ll, vp, ll, ci, ci, ci, f32, ci, vp],
         "ecgb_gemm_nt_bf16_cat": [vp, ll, vp, ll, vp, ll, vp, ll, ci, vp, ll, ci, ci, ci, f32, ci, vp],
         "ecgb_layernorm_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, f32, vp],
-        "ecgb_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp],
+        "ecgb_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp, vp],
         "ecgb_bias_act": [vp, vp, vp, sz, ci, ci, vp],
         "ecgb_gelu_new_bwd": [vp, vp, vp, sz, vp],
-        "ecgb_colsum": [vp, vp, sz, ci, vp],
+        "ecgb_colsum": [vp, vp, sz, ci, vp, vp],
         "ecgb_lora_down": [vp, vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, vp],
         "ecgb_lora_dx": [vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, vp],
         "ecgb_lora_dx_glu": [vp, vp, vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, ci, vp],
@@ -151,6 +151,11 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    for name in ("ecgb_layernorm_bwd_scratch_floats", "ecgb_colsum_scratch_floats"):
+        getattr(L, name).argtypes = [sz, ci]
+        getattr(L, name).restype = sz
+    L.ecgb_partial_rows_sum_f32.argtypes = [vp, ci, ci, ll, vp, vp]
+    L.ecgb_partial_rows_sum_f32.restype = C.c_int
     L.ecgb_rmsnorm_bwd_scratch_floats.argtypes = [sz, ci]
     L.ecgb_rmsnorm_bwd_scratch_floats.restype = sz
     L.ecgb_attn_bwd_scratch_bytes.argtypes = [ci, ci, ci, ci, ci]

@@ -176,7 +176,7 @@ template <bool GEMMA>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const unsigned short *x, const unsigned short *w,
                                                           const float *rstd, const unsigned short *dy,
                                                           const unsigned short *dres, unsigned short *dx, float *dw,
-                                                          size_t rows, int H)
+                                                          size_t rows, int H, float *partials)
 {
     extern __shared__ float s_dw[];   // H floats
     for (int c = threadIdx.x; c < H; c += blockDim.x) s_dw[c] = 0.f;
@@ -219,6 +219,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const unsigned short *
         }
     }
     __syncthreads();
+    if (partials) {   // launched with ONE wave per workgroup then: the LDS adds above happened in program order; the block's row is added in block order
+        for (int c = threadIdx.x; c < H; c += blockDim.x) partials[(size_t)blockIdx.x * H + c] = s_dw[c];
+        return;
+    }
     for (int c = threadIdx.x; c < H; c += blockDim.x) atomicAdd(dw + c, s_dw[c]);
 }
 
@@ -552,12 +556,12 @@ __global__ __launch_bounds__(256) void ordered_sum_kernel(const float *v, int n,
 }
 
 // dw[c] += sum over b < n_blocks of partials[b][c], in block order (the weight gradients of the norms: per-workgroup partial rows)
-__global__ __launch_bounds__(256) void partial_rows_sum_kernel(const float *partials, int n_blocks, int H, float *dw)
+__global__ __launch_bounds__(256) void partial_rows_sum_kernel(const float *partials, int n_blocks, int H, long long ld, float *dw)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= H) return;
     float s = 0.f;
-    for (int b = 0; b < n_blocks; ++b) s += partials[(size_t)b * H + c];
+    for (int b = 0; b < n_blocks; ++b) s += partials[(size_t)b * ld + c];
     dw[c] += s;
 }
 
@@ -784,8 +788,16 @@ extern "C" int ecgb_rmsnorm_fwd(const void *x_dev, const void *residual_dev, con
 
 extern "C" size_t ecgb_rmsnorm_bwd_scratch_floats(size_t rows, int hidden)
 {
-    if (hidden != 2048 && hidden != 4096) return 0;          // other widths: LDS + global atomics (order of arrival)
+    if (hidden != 2048 && hidden != 4096) return std::min<size_t>(std::max<size_t>(1, rows), 4096) * (size_t)hidden;   // one-wave workgroups
     return std::min<size_t>(std::max<size_t>(1, rows / 64), 1024) * (size_t)hidden;
+}
+
+// dst[c] += sum over b < n_rows of partials[b * ld + c], c < n, in row order (per-workgroup partial sums of a weight / bias gradient)
+extern "C" int ecgb_partial_rows_sum_f32(const float *partials_dev, int n_rows, int n, long long ld, float *dst_dev, void *stream)
+{
+    if (!partials_dev || !dst_dev || n_rows < 0 || n <= 0) { ecgb::set_error("ecgb_partial_rows_sum_f32: bad argument"); return ECGB_ERR_INVALID; }
+    hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials_dev, n_rows, n, ld, dst_dev);
+    ECGB_CHECK_LAUNCH("partial_rows_sum");
 }
 
 extern "C" int ecgb_rmsnorm_bwd(const void *x_dev, const void *w_dev, const float *rstd_dev, const void *dy_dev,
@@ -801,19 +813,23 @@ extern "C" int ecgb_rmsnorm_bwd(const void *x_dev, const void *w_dev, const floa
         else { if (gemma) ECGB_RMS_BWD_ROWS(true, 8); else ECGB_RMS_BWD_ROWS(false, 8); }
 #undef ECGB_RMS_BWD_ROWS
         if (scratch_dev)      // per-block partial rows -> dw, in block order (scratch: ecgb_rmsnorm_bwd_scratch_floats; null: atomics)
-            hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((unsigned)((hidden + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scratch_dev, (int)g2.x, hidden, dw_dev);
+            hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((unsigned)((hidden + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scratch_dev, (int)g2.x, hidden, (long long)hidden, dw_dev);
         ECGB_CHECK_LAUNCH("rmsnorm_bwd");
     }
-    const dim3 grid((unsigned)std::min<size_t>(std::max<size_t>(1, rows / 4), 1024));
+    // scratch: one wave per workgroup (its LDS adds are then in program order) and per-workgroup rows added in order; without: four waves and atomics
+    const dim3 grid(scratch_dev ? (unsigned)std::min<size_t>(std::max<size_t>(1, rows), 4096) : (unsigned)std::min<size_t>(std::max<size_t>(1, rows / 4), 1024));
+    const dim3 block(scratch_dev ? 64 : 256);
     const size_t lds = (size_t)hidden * 4;
     if (gemma)
-        hipLaunchKernelGGL(rmsnorm_bwd_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short *)x_dev,
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel<true>, grid, block, lds, (hipStream_t)stream, (const unsigned short *)x_dev,
                            (const unsigned short *)w_dev, rstd_dev, (const unsigned short *)dy_dev, (const unsigned short *)dres_dev,
-                           (unsigned short *)dx_dev, dw_dev, rows, hidden);
+                           (unsigned short *)dx_dev, dw_dev, rows, hidden, scratch_dev);
     else
-        hipLaunchKernelGGL(rmsnorm_bwd_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short *)x_dev,
+        hipLaunchKernelGGL(rmsnorm_bwd_kernel<false>, grid, block, lds, (hipStream_t)stream, (const unsigned short *)x_dev,
                            (const unsigned short *)w_dev, rstd_dev, (const unsigned short *)dy_dev, (const unsigned short *)dres_dev,
-                           (unsigned short *)dx_dev, dw_dev, rows, hidden);
+                           (unsigned short *)dx_dev, dw_dev, rows, hidden, scratch_dev);
+    if (scratch_dev)
+        hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((unsigned)((hidden + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scratch_dev, (int)grid.x, hidden, (long long)hidden, dw_dev);
     ECGB_CHECK_LAUNCH("rmsnorm_bwd");
 }
 

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const unsigned short
 template <int NC>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short *x, const unsigned short *w, const float *mean, const float *rstd,
                                                             const unsigned short *dy, const unsigned short *dres, unsigned short *dx,
-                                                            float *dw, float *db, size_t rows, int H)
+                                                            float *dw, float *db, size_t rows, int H, float *partials)
 {
     extern __shared__ float s_acc[];   // 2 * H floats
     for (int c = threadIdx.x; c < 2 * H; c += blockDim.x) s_acc[c] = 0.f;
@@ -140,6 +140,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const unsigned short
                 *reinterpret_cast<bf16x8 *>(dx + r * H + c) = o;
             }
         }
+    }
+    if (partials) {   // the four waves add in wave order; the block's [dw | db] row goes to partials[block], added in block order by the caller
+        for (int wv = 0; wv < 4; ++wv) {
+            if ((int)(threadIdx.x >> 6) == wv) {
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    const int c = k * 512 + lane * 8;
+                    if (c < H) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { s_acc[c + j] += aw[k][j]; s_acc[H + c + j] += ab[k][j]; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        for (int c = threadIdx.x; c < 2 * H; c += blockDim.x) partials[(size_t)blockIdx.x * 2 * H + c] = s_acc[c];
+        return;
     }
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
@@ -198,7 +215,7 @@ __global__ __launch_bounds__(256) void gelu_new_bwd_kernel(const unsigned short 
 }
 
 // out[c] (fp32) += sum over rows of dy[r, c]: a bias gradient.  Block b takes a slab of rows; thread t the 8 columns t*8 + 2048 k.
-__global__ __launch_bounds__(256) void colsum_kernel(const unsigned short *dy, float *out, size_t rows, int N, size_t rows_per_block)
+__global__ __launch_bounds__(256) void colsum_kernel(const unsigned short *dy, float *out, size_t rows, int N, size_t rows_per_block, float *partials)
 {
     const size_t r0 = (size_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
     for (int c = threadIdx.x * 8; c < N; c += 256 * 8) {
@@ -208,8 +225,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short *dy, f
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[j]);
         }
+        if (partials) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(out + c + j, acc[j]);
+            for (int j = 0; j < 8; ++j) partials[(size_t)blockIdx.x * N + c + j] = acc[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) atomicAdd(out + c + j, acc[j]);
+        }
     }
 }
 
@@ -237,8 +259,16 @@ extern "C" int ecgb_layernorm_fwd(const void *x_dev, const void *residual_dev, c
     return launched("layernorm_fwd_kernel");
 }
 
+extern "C" int ecgb_partial_rows_sum_f32(const float *partials_dev, int n_rows, int n, long long ld, float *dst_dev, void *stream);
+
+extern "C" size_t ecgb_layernorm_bwd_scratch_floats(size_t rows, int hidden)
+{
+    return (size_t)std::min<unsigned>(grid_for(rows, 16), 1024) * 2 * (size_t)hidden;
+}
+
 extern "C" int ecgb_layernorm_bwd(const void *x_dev, const void *w_dev, const float *mean_dev, const float *rstd_dev, const void *dy_dev,
-                                  const void *dres_dev, void *dx_dev, float *dw_dev, float *db_dev, size_t rows, int hidden, void *stream)
+                                  const void *dres_dev, void *dx_dev, float *dw_dev, float *db_dev, size_t rows, int hidden, float *scratch_dev,
+                                  void *stream)
 {
     if (!x_dev || !w_dev || !mean_dev || !rstd_dev || !dy_dev || !dx_dev || !dw_dev || !db_dev || hidden <= 0 || hidden % 8 || hidden > 4096) {
         ecgb::set_error("ecgb_layernorm_bwd: bad argument (hidden % 8 == 0, hidden <= 4096)");
@@ -249,9 +279,13 @@ extern "C" int ecgb_layernorm_bwd(const void *x_dev, const void *w_dev, const fl
     const size_t lds = 2 * (size_t)hidden * sizeof(float);
 #define ECGB_LN(NC_) hipLaunchKernelGGL(layernorm_bwd_kernel<NC_>, grid, dim3(256), lds, (hipStream_t)stream, (const unsigned short *)x_dev, \
         (const unsigned short *)w_dev, mean_dev, rstd_dev, (const unsigned short *)dy_dev, (const unsigned short *)dres_dev, (unsigned short *)dx_dev, \
-        dw_dev, db_dev, rows, hidden)
+        dw_dev, db_dev, rows, hidden, scratch_dev)
     if (hidden <= 1024) ECGB_LN(2); else if (hidden <= 2048) ECGB_LN(4); else ECGB_LN(8);
 #undef ECGB_LN
+    if (scratch_dev) {        // per-workgroup [dw | db] rows, added in workgroup order (the same bits every launch); null: atomics
+        if (int rc = ecgb_partial_rows_sum_f32(scratch_dev, (int)grid.x, hidden, 2ll * hidden, dw_dev, stream)) return rc;
+        if (int rc = ecgb_partial_rows_sum_f32(scratch_dev + hidden, (int)grid.x, hidden, 2ll * hidden, db_dev, stream)) return rc;
+    }
     return launched("layernorm_bwd_kernel");
 }
 
@@ -274,11 +308,19 @@ extern "C" int ecgb_gelu_new_bwd(const void *pre_dev, const void *dh_dev, void *
     return launched("gelu_new_bwd_kernel");
 }
 
-extern "C" int ecgb_colsum(const void *dy_dev, float *out_dev, size_t rows, int n, void *stream)
+extern "C" size_t ecgb_colsum_scratch_floats(size_t rows, int n)
+{
+    return std::min<size_t>(1024, (rows + 31) / 32) * (size_t)n;
+}
+
+extern "C" int ecgb_colsum(const void *dy_dev, float *out_dev, size_t rows, int n, float *scratch_dev, void *stream)
 {
     if (!dy_dev || !out_dev || n <= 0 || n % 8) { ecgb::set_error("ecgb_colsum: bad argument (n % 8 == 0)"); return ECGB_ERR_INVALID; }
     if (rows == 0) return ECGB_OK;
     const size_t blocks = std::min<size_t>(1024, (rows + 31) / 32), rpb = (rows + blocks - 1) / blocks;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)dy_dev, out_dev, rows, n, rpb);
+    const unsigned grid = (unsigned)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)dy_dev, out_dev, rows, n, rpb, scratch_dev);
+    if (scratch_dev)          // per-workgroup partial rows added in workgroup order; null: atomics
+        if (int rc = ecgb_partial_rows_sum_f32(scratch_dev, (int)grid, n, (long long)n, out_dev, stream)) return rc;
     return launched("colsum_kernel");
 }

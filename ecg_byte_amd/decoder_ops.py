@@ -85,8 +85,10 @@ def layernorm_fwd(x, w, b, eps, residual=None):
 def layernorm_bwd(x, w, mean, rstd, dy, dw_f32, db_f32, dres=None):
     H = x.shape[-1]
     dx = torch.empty_like(x)
+    rows = x.numel() // H
+    scratch = torch.empty(_L().ecgb_layernorm_bwd_scratch_floats(rows, H), dtype=torch.float32, device=x.device)    # ordered dw / db sums
     _lib.check(_L().ecgb_layernorm_bwd(_p(_bf(x)), _p(_bf(w)), _p(mean), _p(rstd), _p(_bf(dy)), _p(dres), _p(dx), _p(dw_f32), _p(db_f32),
-                                       x.numel() // H, H, _st()))
+                                       rows, H, _p(scratch), _st()))
     return dx
 
 
@@ -114,7 +116,9 @@ def gelu_new_bwd(pre, dh):
 def colsum(dy):
     """fp32 column sums of a 2-D bf16 tensor (a bias gradient)."""
     out = torch.zeros(dy.shape[-1], dtype=torch.float32, device=dy.device)
-    _lib.check(_L().ecgb_colsum(_p(_bf(dy)), _p(out), dy.numel() // dy.shape[-1], dy.shape[-1], _st()))
+    rows, n = dy.numel() // dy.shape[-1], dy.shape[-1]
+    scratch = torch.empty(_L().ecgb_colsum_scratch_floats(rows, n), dtype=torch.float32, device=dy.device)          # ordered partial rows
+    _lib.check(_L().ecgb_colsum(_p(_bf(dy)), _p(out), rows, n, _p(scratch), _st()))
     return out
 
 

@@ -113,11 +113,16 @@ int ecgb_lora_dx_glu(const void *dt_dev, const void *at_dev, const void *dx_dev,
  *   ecgb_colsum          out (fp32) += sum over rows of dy: the gradient of a bias */
 int ecgb_layernorm_fwd(const void *x_dev, const void *residual_dev, const void *w_dev, const void *b_dev, void *y_dev, void *sum_out_dev,
                        float *mean_dev, float *rstd_dev, size_t rows, int hidden, float eps, void *stream);
+/* scratch_dev of ecgb_layernorm_bwd / ecgb_colsum (…_scratch_floats floats, or null): per-workgroup partial rows added in workgroup order -- the same
+ * bits every launch; null: float atomics. */
+size_t ecgb_layernorm_bwd_scratch_floats(size_t rows, int hidden);
+size_t ecgb_colsum_scratch_floats(size_t rows, int n);
+int ecgb_partial_rows_sum_f32(const float *partials_dev, int n_rows, int n, long long ld, float *dst_dev, void *stream);
 int ecgb_layernorm_bwd(const void *x_dev, const void *w_dev, const float *mean_dev, const float *rstd_dev, const void *dy_dev,
-                       const void *dres_dev, void *dx_dev, float *dw_dev, float *db_dev, size_t rows, int hidden, void *stream);
+                       const void *dres_dev, void *dx_dev, float *dw_dev, float *db_dev, size_t rows, int hidden, float *scratch_dev, void *stream);
 int ecgb_bias_act(void *u_dev, const void *bias_dev, void *h_dev, size_t rows, int n, int gelu_new, void *stream);
 int ecgb_gelu_new_bwd(const void *pre_dev, const void *dh_dev, void *dpre_dev, size_t n, void *stream);
-int ecgb_colsum(const void *dy_dev, float *out_dev, size_t rows, int n, void *stream);
+int ecgb_colsum(const void *dy_dev, float *out_dev, size_t rows, int n, float *scratch_dev, void *stream);
 
 /* C[M,N] = alpha * A[M,K] . B[K,N] with B ROW-major: the input gradient dX = dY . W against the weight as nn.Linear stores it
  * ([out, in], modeling_llama.py:227-258,273-395) -- what ecgb_gemm_nt_bf16 computes on a transposed copy of B, without the copy (the

@@ -602,3 +602,34 @@ def test_sequence_length_not_a_multiple_of_64(S):
     with torch.no_grad():
         ev = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos).loss.item()
     assert abs(ev - ref.item()) <= 1e-2 * ref.item()
+
+
+@pytest.mark.parametrize("family", ["llama", "gemma"])
+def test_small_width_step_is_the_same_bits_twice(family):
+    """Widths that take the generic RMSNorm backward (one wave per workgroup, per-workgroup partial rows added in order), split-K weight
+    gradients over slabs, the sorted embedding scatter: two models from one seed, one step each, identical loss / gradients / weights."""
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+
+    def step():
+        cfg = DecoderConfig(vocab_size=700, hidden_size=192, intermediate_size=448, num_hidden_layers=2, num_attention_heads=3,
+                            num_key_value_heads=1, head_dim=64, rms_norm_eps=1e-5, rope_theta=10000.0, rope_scaling=None, pad_token_id=699,
+                            model_type=family)
+        m = HipCausalLM(cfg, seed=9)
+        opt = m.make_optimizer(warmup=10)
+        g = torch.Generator(device="cuda").manual_seed(4)
+        ids = torch.randint(0, 699, (3, 192), device="cuda", generator=g)
+        mask = torch.ones(3, 192, device="cuda"); mask[0, :50] = 0; ids[0, :50] = 699
+        pos = (torch.cumsum(mask, 1) - 1).clamp(min=0).long()
+        labels = torch.full((3, 192), -100, device="cuda"); labels[:, -30:] = ids[:, -30:]
+        out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
+        out.loss.backward()
+        grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        opt.step_and_update_lr()
+        return out.loss.detach().clone(), grads, {n: p.data.clone() for n, p in m.named_parameters()}
+    l1, g1, p1 = step()
+    l2, g2, p2 = step()
+    assert torch.equal(l1, l2) and len(g1) > 0
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    for k in p1:
+        assert torch.equal(p1[k], p2[k]), k

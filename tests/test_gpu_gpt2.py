@@ -199,3 +199,33 @@ def test_gpt2_small_dims_two_layers_vs_fp32_oracle():
         want = ref_p[name].grad
         rel = ((gq - want).norm() / want.norm().clamp_min(1e-12)).item()
         assert rel < 3e-2, (name, rel)
+
+
+def test_gpt2_step_is_the_same_bits_twice():
+    """GPT-2-small widths, two layers, dropout on (counter-based masks: the same seeds draw the same masks): two models from one seed take
+    one step each -- loss, every gradient (LayerNorm weights / biases and the projection biases are summed over per-workgroup partial rows in
+    order, the embeddings by the sorted scatter) and every updated weight identical."""
+    from ecg_byte_amd.gpt2 import GPT2Config, HipGPT2LM
+
+    def step():
+        cfg = GPT2Config(vocab_size=4099, n_layer=2)
+        m = HipGPT2LM(cfg, seed=5)
+        m.train()
+        opt = m.make_optimizer()
+        g = torch.Generator(device="cuda").manual_seed(3)
+        ids = torch.randint(0, 4098, (4, 1024), device="cuda", generator=g)
+        mask = torch.ones(4, 1024, device="cuda"); mask[1, :200] = 0; mask[3, :17] = 0
+        pos = (torch.cumsum(mask, 1) - 1).clamp(min=0).long()
+        labels = torch.full((4, 1024), -100, device="cuda"); labels[:, -50:] = ids[:, -50:]
+        out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
+        out.loss.backward()
+        grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        opt.step_and_update_lr()
+        return out.loss.detach().clone(), grads, {n: p.data.clone() for n, p in m.named_parameters()}
+    l1, g1, p1 = step()
+    l2, g2, p2 = step()
+    assert torch.equal(l1, l2) and len(g1) > 0
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    for k in p1:
+        assert torch.equal(p1[k], p2[k]), k
