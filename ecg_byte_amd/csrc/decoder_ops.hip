@@ -620,6 +620,35 @@ __global__ __launch_bounds__(256) void transpose_kernel(const unsigned short *in
     }
 }
 
+// many small matrices in ONE launch (the LoRA adapters' transposed copies: 2 per site, 128 of a few KB each per step -- launch-bound as single
+// calls): block b transposes 64x64 tile b - tile_off[t] of matrix t, t found by bisection in the tile prefix sums.
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const unsigned short *const *src, unsigned short *const *dst, const int *rows,
+                                                              const int *cols, const int *tile_off, int n)
+{
+    __shared__ unsigned short tile[64][66];
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tile_off[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int t = lo, R = rows[t], Cc = cols[t];
+    const unsigned short *in = src[t];
+    unsigned short *out = dst[t];
+    const int local = (int)blockIdx.x - tile_off[t], tiles_c = (Cc + 63) / 64;
+    const int tr = local / tiles_c, tc = local % tiles_c;
+    for (int k = threadIdx.x; k < 64 * 64; k += 256) {
+        const int r = k / 64, c = k % 64;
+        const int gr = tr * 64 + r, gc = tc * 64 + c;
+        tile[r][c] = (gr < R && gc < Cc) ? in[(size_t)gr * Cc + gc] : 0;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 64 * 64; k += 256) {
+        const int c = k / 64, r = k % 64;
+        const int gr = tr * 64 + r, gc = tc * 64 + c;
+        if (gr < R && gc < Cc) out[(size_t)gc * R + gr] = tile[r][c];
+    }
+}
+
 // batched, strided variant: matrix z = (zo, zi) of R x Cc elements, input rows ld_in apart, output rows ld_out apart
 __global__ __launch_bounds__(256) void transpose_strided_kernel(const unsigned short *in, unsigned short *out, int R, int Cc,
                                                                 long long ld_in, long long ld_out, int inner,
@@ -941,6 +970,16 @@ extern "C" int ecgb_transpose_bf16(const void *in_dev, void *out_dev, int rows, 
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)std::min<size_t>(std::max<size_t>(tiles, 1), 256 * 16)), dim3(256), 0,
                        (hipStream_t)stream, (const unsigned short *)in_dev, (unsigned short *)out_dev, rows, cols);
     ECGB_CHECK_LAUNCH("transpose_bf16");
+}
+
+extern "C" int ecgb_transpose_multi_bf16(const void *const *src_dev, void *const *dst_dev, const int *rows_dev, const int *cols_dev,
+                                         const int *tile_off_dev, int n, int total_tiles, void *stream)
+{
+    if (n <= 0 || total_tiles <= 0) return ECGB_OK;
+    if (!src_dev || !dst_dev || !rows_dev || !cols_dev || !tile_off_dev) { ecgb::set_error("ecgb_transpose_multi_bf16: NULL argument"); return ECGB_ERR_INVALID; }
+    hipLaunchKernelGGL(transpose_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const unsigned short *const *)src_dev,
+                       (unsigned short *const *)dst_dev, rows_dev, cols_dev, tile_off_dev, n);
+    ECGB_CHECK_LAUNCH("transpose_multi");
 }
 
 extern "C" int ecgb_f32_to_bf16(const float *in_dev, void *out_dev, size_t n, void *stream)

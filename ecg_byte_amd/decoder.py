@@ -436,6 +436,22 @@ class HipCausalLM(nn.Module):
             self._t_version[key] = ver
         return hit[0]
 
+    def _refresh_lora_shadows(self):
+        """The transposed copies of every adapter (A^T for lora_dx, B^T for dt = dy B) in ONE launch: 2 per site and layer, a few KB each --
+        as 224 single transposes per step they were launch-bound (1.5 ms)."""
+        sites = [(i, k, s) for i, layer in enumerate(self.lora) for k, s in layer.items()]
+        tensors = [t for _, _, s in sites for t in (s.A.data, s.B.data)]
+        plan = getattr(self, "_lora_tplan", None)
+        if plan is None or not plan.valid_for(tensors):
+            plan = self._lora_tplan = ops.TransposePlan(tensors)
+        if all(self._t_version.get(("lora_At", id(s))) == s.A._version and ("lora_At", id(s)) in self._t and
+               self._t_version.get(("lora_Bt", id(s))) == s.B._version and ("lora_Bt", id(s)) in self._t for _, _, s in sites):
+            return                                                       # nothing was updated since the copies were made
+        dst = ops.transpose_multi(plan)
+        for n, (_, _, s) in enumerate(sites):
+            self._t[("lora_At", id(s))] = (dst[2 * n], id(s.A)); self._t_version[("lora_At", id(s))] = s.A._version
+            self._t[("lora_Bt", id(s))] = (dst[2 * n + 1], id(s.B)); self._t_version[("lora_Bt", id(s))] = s.B._version
+
     def _drop_shadows(self, param_ids):
         for key in [k for k, (_, pid) in self._t.items() if pid in param_ids]:
             del self._t[key]
@@ -959,6 +975,8 @@ class HipCausalLM(nn.Module):
         scale = 1.0 / math.sqrt(D)
         go = float(grad_out)   # d(final)/d(loss); 1.0 for loss.backward()
         frozen = self.lora is not None
+        if frozen:
+            self._refresh_lora_shadows()
         if go != 1.0:
             dhf = (dhf.float() * go).to(torch.bfloat16)
             if not frozen:

@@ -157,6 +157,37 @@ def transpose(x2d):
     return o
 
 
+class TransposePlan:
+    """Pointer / shape tables of `transpose_multi` for a fixed list of 2-D bf16 tensors (built once: the tensors and their transposed
+    destinations are persistent buffers updated in place)."""
+
+    def __init__(self, tensors):
+        dev = tensors[0].device
+        self.src = list(tensors)
+        self.dst = [torch.empty((t.shape[1], t.shape[0]), dtype=torch.bfloat16, device=dev) for t in tensors]
+        tiles = [((t.shape[0] + 63) // 64) * ((t.shape[1] + 63) // 64) for t in tensors]
+        off = [0]
+        for n in tiles:
+            off.append(off[-1] + n)
+        self.total = off[-1]
+        self.n = len(tensors)
+        self.src_ptrs = torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64, device=dev)
+        self.dst_ptrs = torch.tensor([t.data_ptr() for t in self.dst], dtype=torch.int64, device=dev)
+        self.rows = torch.tensor([t.shape[0] for t in tensors], dtype=torch.int32, device=dev)
+        self.cols = torch.tensor([t.shape[1] for t in tensors], dtype=torch.int32, device=dev)
+        self.tile_off = torch.tensor(off[:-1], dtype=torch.int32, device=dev)
+
+    def valid_for(self, tensors):
+        return len(tensors) == self.n and all(a.data_ptr() == b.data_ptr() and a.shape == b.shape for a, b in zip(tensors, self.src))
+
+
+def transpose_multi(plan):
+    """plan.dst[t] = plan.src[t]^T for every tensor of the plan, one launch."""
+    _lib.check(_L().ecgb_transpose_multi_bf16(_p(plan.src_ptrs), _p(plan.dst_ptrs), _p(plan.rows), _p(plan.cols), _p(plan.tile_off), plan.n,
+                                              plan.total, _st()))
+    return plan.dst
+
+
 def set_gemm_tile(tile: int):
     """0 = automatic, 128 / 256 = force that output tile (tests, tuning)."""
     _lib.check(_L().ecgb_set_gemm_tile(int(tile)))

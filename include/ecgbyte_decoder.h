@@ -68,6 +68,10 @@ int ecgb_transpose_bf16(const void *in_dev, void *out_dev, int rows, int cols, v
 int ecgb_transpose_bf16_strided(const void *in_dev, void *out_dev, int rows, int cols, long long ld_in, long long ld_out,
                                 int batch, int inner, long long outer_in, long long inner_in, long long outer_out,
                                 long long inner_out, void *stream);
+/* n row-major matrices transposed in ONE launch (dst[t] = src[t]^T, src[t] is rows[t] x cols[t]); tile_off_dev[t] = number of 64x64 tiles of the
+ * matrices before t, total_tiles = their sum over all n.  The LoRA adapters' transposed copies after an optimizer step. */
+int ecgb_transpose_multi_bf16(const void *const *src_dev, void *const *dst_dev, const int *rows_dev, const int *cols_dev,
+                              const int *tile_off_dev, int n, int total_tiles, void *stream);
 int ecgb_f32_to_bf16(const float *in_dev, void *out_dev, size_t n, void *stream);
 /* out[i] = bf16(sum_s slabs[s * slab_stride + i]) for i < n, summed in slab order; accumulate != 0: added to the bf16 already in out.
  * The K-slices of ecgb_gemm_tn_bf16 (splits > 1) meet here.  n, slab_stride multiples of 4. */
