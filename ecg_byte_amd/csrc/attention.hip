@@ -173,6 +173,25 @@ __device__ __forceinline__ bf16x8 frag_transposed(const unsigned char *lds, int 
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
     return f;
 }
+// The same fragment from a PLAIN V tile ([key][64 d], chunk c of key row r stored at c ^ 4 ((r >> 1) & 1)) by two transposing reads: per 16
+// lanes a block of 4 keys x 16 d comes back column-major, lane 4 q + p supplying the address of key q, d 4 p .. 4 p + 3 (inline asm: a
+// transposing read hipcc can see next to LDS-DMA gets a vmcnt(0) in front of it)
+__device__ __forceinline__ bf16x8 frag_v_tr(const unsigned char *lds, int db, int lr, int kb, int s2, int h)
+{
+    using i2 = __attribute__((ext_vector_type(2))) int;
+    using i4 = __attribute__((ext_vector_type(4))) int;
+    const int a = lr >> 4, q = (lr & 15) >> 2, p = lr & 3;
+    const int key0 = kb * 32 + 16 * s2 + 4 * h + q, key1 = key0 + 8;
+    const int chunk = db * 4 + 2 * a + (p >> 1);
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)const_cast<unsigned char *>(lds) + (p & 1) * 8;
+    const unsigned a0 = base + key0 * 128 + ((chunk ^ (((key0 >> 1) & 1) << 2)) << 4);
+    const unsigned a1 = base + key1 * 128 + ((chunk ^ (((key1 >> 1) & 1) << 2)) << 4);
+    i2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+    const i4 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+    return __builtin_bit_cast(bf16x8, f);
+}
 // two fp32 -> packed bf16 pair, one v_cvt_pk_bf16_f32 (round to nearest even)
 using bf2_t = __attribute__((ext_vector_type(2))) __bf16;
 __device__ __forceinline__ unsigned pack_bf16(float a, float b)
@@ -236,17 +255,22 @@ __device__ __forceinline__ void store_accT_f32(const f32x16 (&acc)[NB], float *g
 
 // =====================================================================================================
 // forward: 1-D grid of ceil(S/128) x Hq x B workgroups, dealt by map_block()
-template <int D>
+// DMA (head_dim 64): K and V tiles go global -> LDS by LDS-DMA (global_load_lds, no register round trip, no LDS write instructions), two
+// tiles ahead into a ring of three buffers; V stays as it lies in memory ([key][d], 16-byte chunk c of key row r at c ^ 4 ((r >> 1) & 1)) and
+// the P.V operand (V^T rows in accumulator order) is gathered by transposing LDS reads.  The register-staged form spent 60 % of a wave's
+// time per tile issuing loads, waiting for them and writing both images (scripts/dev_prof_attn.py).
+template <int D, bool DMA = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
 {
+    static_assert(!DMA || D == 64, "the LDS-DMA staging is written for 128-byte rows");
     // two K / V^T tile buffers: the tile after the one being multiplied is written while the others still compute,
     // one barrier per tile.  Dynamic LDS (4 x 128 D bytes + 4 bytes per key: 36 KB at head_dim 64 and S 1024, 139 KB at 256 / 2048).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kTile = 128 * D;                           // bytes of a 64-row tile, plain or transposed
-    auto lds_k2 = [&](int i) { return smem + i * kTile; };
-    auto lds_vt2 = [&](int i) { return smem + (2 + i) * kTile; };
-    float *lds_maskrow = reinterpret_cast<float *>(smem + 4 * kTile);        // the batch row's key mask up to this block's last key
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
+    auto lds_k2 = [&](int i) { return smem + i * (DMA ? 2 * kTile : kTile); };
+    auto lds_vt2 = [&](int i) { return DMA ? smem + i * 2 * kTile + kTile : smem + (2 + i) * kTile; };
+    float *lds_maskrow = reinterpret_cast<float *>(smem + (DMA ? 6 : 4) * kTile);        // the batch row's key mask up to this block's last key
+    const int wave = DMA ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     int qblk, head_in, group;
     map_block((int)blockIdx.x, (A.S + 127) / 128, A.Hq / A.Hkv, A.B * A.Hkv, true, qblk, head_in, group);
     const int b = group / A.Hkv, g = group % A.Hkv, hq = g * (A.Hq / A.Hkv) + head_in;
@@ -282,21 +306,56 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
             if (first_half) stage_write_plain<D>(lds_k2(buf), st[i], item + 128 * i); else stage_write_transposed(lds_vt2(buf), st[i], item + 128 * i);
         }
     };
-    load_tile(0);
+    // DMA: a tile is 8 instructions of 1 KiB (8 rows of 128 B) per operand, two of each per wave; per-lane byte offsets inside a tile are
+    // constants (whole tiles) or clamped to the last key (the one partial tile a sequence can end with); the tile's base is scalar
+    const int last_tile = (k_end - 1) / 64;
+    unsigned offK[2], offV[2], offKt[2], offVt[2];
+    if constexpr (DMA) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (wave * 2 + i) * 8 + (lane >> 3), slot = lane & 7;
+            const int ck = slot ^ ((r >> 1) & 7), cv = slot ^ (((r >> 1) & 1) << 2);
+            const int rt = min(r, A.S - 1 - last_tile * 64);                 // tail tile: rows past the last key re-read it (masked: keys >= S)
+            offK[i] = (unsigned)(((long long)r * A.ldk + ck * 8) * 2);  offKt[i] = (unsigned)(((long long)rt * A.ldk + ck * 8) * 2);
+            offV[i] = (unsigned)(((long long)r * A.ldv + cv * 8) * 2);  offVt[i] = (unsigned)(((long long)rt * A.ldv + cv * 8) * 2);
+        }
+    }
+    auto issue_tile = [&](int t, int buf) {                  // UNCONDITIONAL (the caller clamps t): the waits below stay counted
+        const bool tail = (t + 1) * 64 > A.S;
+        const unsigned char *kb = reinterpret_cast<const unsigned char *>(K + (rowbase + (long long)t * 64) * A.ldk);
+        const unsigned char *vb = reinterpret_cast<const unsigned char *>(V + (rowbase + (long long)t * 64) * A.ldv);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb + (tail ? offKt[i] : offK[i])),
+                                             (__attribute__((address_space(3))) void *)(lds_k2(buf) + (wave * 2 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb + (tail ? offVt[i] : offV[i])),
+                                             (__attribute__((address_space(3))) void *)(lds_vt2(buf) + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+    };
     // key mask: the whole row goes to LDS once (keys >= S read as padded).  Fetched per tile by wave 0 right where it was written, the
     // load's memory latency (~1 700 cycles) sat in front of every tile's barrier: a quarter of the kernel.
-    for (int i = threadIdx.x; i < ((k_end + 63) & ~63); i += 256) lds_maskrow[i] = (i < A.S) ? A.mask[rowbase + i] : 0.f;
-    write_tile(0, 0);
-    __syncthreads();
+    if constexpr (DMA) {
+        issue_tile(0, 0);
+        issue_tile(min(1, last_tile), 1);
+        for (int i = threadIdx.x; i < ((k_end + 63) & ~63); i += 256) lds_maskrow[i] = (i < A.S) ? A.mask[rowbase + i] : 0.f;
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // tile 0 (and Q) landed; tile 1 may still be in flight
+        __syncthreads();                                     // (drains: the price of one barrier with full waits, once per workgroup)
+    } else {
+        load_tile(0);
+        for (int i = threadIdx.x; i < ((k_end + 63) & ~63); i += 256) lds_maskrow[i] = (i < A.S) ? A.mask[rowbase + i] : 0.f;
+        write_tile(0, 0);
+        __syncthreads();
+    }
 #ifdef ECGB_PROFILE
     unsigned long long prof_acc[7] = {};
     long long t_prof = clock64();
 #endif
     for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
         const bool more = k0 + 64 < k_end;
-        if (more) load_tile(k0 + 64);   // next tile in flight behind the MFMAs
+        if constexpr (DMA) issue_tile(min(it + 2, last_tile), (it + 2) % 3);      // two tiles ahead, into the buffer tile it - 1 left at the last barrier
+        else if (more) load_tile(k0 + 64);   // next tile in flight behind the MFMAs
         APROF(0);
-        const unsigned char *lds_k = lds_k2(it & 1), *lds_vt = lds_vt2(it & 1);
+        const unsigned char *lds_k = lds_k2(DMA ? it % 3 : it & 1), *lds_vt = lds_vt2(DMA ? it % 3 : it & 1);
         const float *lds_mask = lds_maskrow + k0;
         if (k0 <= wave_qmax) {
             const bool lds_flag = __any(lds_mask[lane] == 0.f);          // the tile holds a padded / out-of-range key
@@ -320,6 +379,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
                         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_k, kb * 32 + lr, ks, h), qf[ks], sacc[kb], 0, 0, 0);
+                // DMA: the eight V^T fragments of the tile are requested now, behind the S products, and arrive under the softmax
+                bf16x8 vfr[2][2][DMA ? D / 32 : 1];
+                if constexpr (DMA) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                            for (int db = 0; db < D / 32; ++db) vfr[kb][s2][db] = frag_v_tr(lds_vt, db, lr, kb, s2, h);
+                }
                 // max3() below is inline asm: hipcc's hazard recogniser does not look inside it, and a vector instruction that reads an
                 // MFMA result needs 19 wait states after a 16-pass MFMA (nothing interlocks: the first version read stale registers now
                 // and then -- a slightly different running maximum, a softmax that differed in the last bits from run to run).  The
@@ -330,8 +399,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
                     const f32x16 &s = sacc[kb];
                     if (MODE == 1 || (MODE == 2 && need_mask)) {
                         float4 mk4[4];                                           // the lane's 16 keys are 4 runs of 4: four 16-byte reads
+                        if constexpr (DMA) {
+                            using f4v = __attribute__((ext_vector_type(4))) float;
+                            f4v mv[4];
+                            // inline asm: a mask read hipcc can see behind LDS-DMA gets vmcnt(0) in front of it (both tiles in flight drained on
+                            // every masked tile).  LDS returns in order: once only the 16 V reads requested above are outstanding, these are in.
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) mk4[g4] = *reinterpret_cast<const float4 *>(&lds_mask[kb * 32 + 8 * g4 + 4 * h]);
+                            for (int g4 = 0; g4 < 4; ++g4) {
+                                const unsigned ma = (unsigned)(size_t)(__attribute__((address_space(3))) float *)const_cast<float *>(&lds_mask[kb * 32 + 8 * g4 + 4 * h]);
+                                f4v t;
+                                asm volatile("ds_read_b128 %0, %1" : "=v"(t) : "v"(ma));
+                                mv[g4] = t;
+                            }
+                            // the registers pass THROUGH the wait: a bare waitcnt statement does not stop hipcc from scheduling the compares on
+                            // them ahead of it (it believes an asm's outputs are ready when the asm is)
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mv[0]), "+v"(mv[1]), "+v"(mv[2]), "+v"(mv[3]));
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) mk4[g4] = make_float4(mv[g4][0], mv[g4][1], mv[g4][2], mv[g4][3]);
+                        } else {
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) mk4[g4] = *reinterpret_cast<const float4 *>(&lds_mask[kb * 32 + 8 * g4 + 4 * h]);
+                        }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;       // key inside the tile
@@ -365,6 +453,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
                         for (int r = 0; r < 16; ++r) accO[db][r] *= alpha;
                 }
                 APROF(2);
+                if constexpr (DMA)       // the V fragments requested above (inline-asm reads: hipcc does not count them); the registers pass through the wait
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vfr[0][0][0]), "+v"(vfr[0][0][DMA ? 1 : 0]), "+v"(vfr[0][1][0]), "+v"(vfr[0][1][DMA ? 1 : 0]),
+                                 "+v"(vfr[1][0][0]), "+v"(vfr[1][0][DMA ? 1 : 0]), "+v"(vfr[1][1][0]), "+v"(vfr[1][1][DMA ? 1 : 0]));
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -372,7 +463,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
                         const bf16x8 pf = frag_from_acc(&p[kb][8 * s2]);
 #pragma unroll
                         for (int db = 0; db < D / 32; ++db)
-                            accO[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_vt, db * 32 + lr, kb, s2, h), pf, accO[db], 0, 0, 0);
+                            accO[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(DMA ? vfr[kb][s2][DMA ? db : 0] : frag_transposed(lds_vt, db * 32 + lr, kb, s2, h),
+                                                                               pf, accO[db], 0, 0, 0);
                     }
                 APROF(3);
             };
@@ -380,9 +472,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
             else if (need_mask) tile(std::integral_constant<int, 1>{});
             else tile(std::integral_constant<int, 0>{});
         }
-        if (more) write_tile((it + 1) & 1, k0 + 64);   // its last readers passed the barrier that ended the previous trip
-        APROF(4);
-        __syncthreads();
+        if constexpr (DMA) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // this wave's pieces of tile it + 1 have landed (tile it + 2's four may still fly)
+            APROF(4);
+            __builtin_amdgcn_s_barrier();                      // ... and everybody else's; all reads of tile it are done
+        } else {
+            if (more) write_tile((it + 1) & 1, k0 + 64);   // its last readers passed the barrier that ended the previous trip
+            APROF(4);
+            __syncthreads();
+        }
         APROF(5);
 #ifdef ECGB_PROFILE
         prof_acc[6] += 1;
@@ -945,6 +1043,8 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float *par
     o[((long long)b * Hq + hq) * D + tid] = (unsigned short)(pack_bf16(sum, 0.f) & 0xFFFFu);
 }
 
+int g_attn_fwd_dma = 1;       // head_dim 64 forward: LDS-DMA staging (1) or the register-staged kernel (0; tests / A-B)
+
 int check_args(const AttnArgs &A, int D, const char *who)
 {
     if (A.B <= 0 || A.S <= 0 || A.Hq <= 0 || A.Hkv <= 0 || A.Hq % A.Hkv) {
@@ -990,7 +1090,13 @@ extern "C" int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev
 #define ECGB_FWD(D_) do { const int lds = 4 * 128 * D_ + 4 * ((seq + 63) & ~63); \
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_kernel<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) break; \
         hipLaunchKernelGGL(attn_fwd_kernel<D_>, grid, dim3(256), lds, (hipStream_t)stream, A); } while (0)
-    if (head_dim == 64) ECGB_FWD(64); else if (head_dim == 128) ECGB_FWD(128); else ECGB_FWD(256);
+    if (head_dim == 64) {
+        const int lds = 6 * 128 * 64 + 4 * ((seq + 63) & ~63);
+        if (g_attn_fwd_dma) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess)
+                hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), lds, (hipStream_t)stream, A);
+        } else ECGB_FWD(64);
+    } else if (head_dim == 128) ECGB_FWD(128); else ECGB_FWD(256);
 #undef ECGB_FWD
     return launched("attn_fwd_kernel");
 }
@@ -1177,3 +1283,10 @@ extern "C" void ecgb_debug_attn_profile(unsigned long long *out8, int reset)
     if (reset) { unsigned long long z[32] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), z, sizeof z); }
 }
 #endif
+
+// head_dim 64 forward: 1 = K / V tiles by LDS-DMA two tiles ahead (default), 0 = the register-staged kernel (tests, A/B)
+extern "C" int ecgb_set_attn_fwd_staging(int dma)
+{
+    g_attn_fwd_dma = dma ? 1 : 0;
+    return ECGB_OK;
+}

@@ -442,6 +442,11 @@ def attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale):
     return o, lse
 
 
+def set_attn_fwd_staging(dma: bool):
+    """head_dim 64 forward: LDS-DMA staging (default) or the register-staged kernel (tests, A/B)."""
+    _lib.check(_L().ecgb_set_attn_fwd_staging(int(bool(dma))))
+
+
 def attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale):
     """Returns d_qkv with the same fused layout as qkv."""
     QKV = qkv.shape[1]

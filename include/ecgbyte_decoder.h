@@ -200,6 +200,9 @@ int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev, long long
                   int n_q_heads, int n_kv_heads, int head_dim, float scale, void *stream);
 /* dq/dk/dv from dO (same layout as o).  delta_dev [batch, n_q_heads, seq] fp32 is scratch (rowsum(dO*O)).
  * dK/dV sum over the query heads of each KV group inside the kernel (no atomics). */
+/* head_dim 64 forward: 1 = K / V tiles by LDS-DMA two tiles ahead into a ring of three buffers, V gathered by transposing LDS reads (default);
+ * 0 = the register-staged kernel (kept for A/B and as the cross-check in the tests). */
+int ecgb_set_attn_fwd_staging(int dma);
 /* scratch of ecgb_attn_bwd: fp32 partial dK / dV slabs when the query heads of a KV group are split over workgroups (head_dim 256 with
  * few key blocks: Gemma); 0 for every other shape (scratch_dev may then be null). */
 size_t ecgb_attn_bwd_scratch_bytes(int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim);
