@@ -145,6 +145,7 @@ def lib():
         "ecgb_colsum": [vp, vp, sz, ci, vp, vp],
         "ecgb_lora_down": [vp, vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, vp],
         "ecgb_lora_dx": [vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, vp],
+        "ecgb_lora_da": [vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, ci, vp, C.c_size_t, vp],
         "ecgb_lora_dx_glu": [vp, vp, vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, ci, vp],
         "ecgb_attn_fwd": [vp, ll, vp, ll, vp, ll, vp, vp, ll, vp, ci, ci, ci, ci, ci, f32, vp],
         "ecgb_attn_bwd": [vp, ll, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp, vp, ll, vp, ll, vp, ll, ci, ci, ci, ci, ci, f32, vp, sz, vp],
@@ -160,6 +161,8 @@ def lib():
     L.ecgb_partial_rows_sum_f32.restype = C.c_int
     L.ecgb_rmsnorm_bwd_scratch_floats.argtypes = [sz, ci]
     L.ecgb_rmsnorm_bwd_scratch_floats.restype = sz
+    L.ecgb_lora_da_scratch_bytes.argtypes = [ci, ci, ci]
+    L.ecgb_lora_da_scratch_bytes.restype = sz
     L.ecgb_attn_bwd_scratch_bytes.argtypes = [ci, ci, ci, ci, ci]
     L.ecgb_attn_bwd_scratch_bytes.restype = sz
     L.ecgb_attn_decode_split_scratch_bytes.argtypes = [ll, ci, ci, ci, ci]

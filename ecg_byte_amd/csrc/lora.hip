@@ -57,6 +57,8 @@ struct LoraArgs {
     unsigned short *dx;           // lora_dx: [T, in], += in place
     const unsigned short *gu;     // lora_dx with the GLU backward behind it: gate|up [T, 2 in] of the forward ...
     unsigned short *dgu;          // ... and d(gate|up) [T, 2 in]: dx is then only read
+    float *slab;                  // lora_da: [n_chunks, 16 * n_sub, in] fp32 partial products, one slab per chunk of rows
+    int chunk_rows;               // lora_da: rows of x per chunk (a multiple of 64)
     int T, in;                    // (sub-block s belongs to block s * NF / NSUB: every block has the same number of sub-blocks)
     float scale;                  // alpha / r / (1 - p)
     unsigned thr;                 // keep iff field >= thr, thr = p * 65536 (0: no dropout)
@@ -241,6 +243,193 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraArgs L)
     }
 }
 
+// dA_b = scale/(1-p) * dt_b^T . (mask_b . x) for the stacked adapters of a site, from x itself: the masks are the hash lora_down drew,
+// evaluated again on the operand fragments, so the forward keeps no masked copy of x per module (1.3 GB a layer at Llama-3.2-1B / batch 32,
+// written once and read once) and the contraction reads x ONCE for all modules of the site.
+// A workgroup = 256 columns of x over one chunk of rows; K-tiles of 64 rows.  x ([64 rows] x [256 columns], 512-byte rows) and dt ([64] x
+// [64], 128-byte rows) go global -> LDS by LDS-DMA as they lie in memory (ring of two buffers, the next tile in flight under the hashing
+// of this one); both MFMA operands are "8 consecutive rows of one column", gathered by ds_read_b64_tr_b16 (x: gemm_tn_kernel_tr's layout and
+// swizzle; dt: 16-byte chunk c of row r at c ^ 2 f(r), f = bit 1 of r | bit 3 of r << 1, which spreads the 8 rows a 32-lane half addresses over all
+// 64 banks).  Wave w owns columns 64 w .. 64 w + 63.  Each chunk's product goes to its own fp32 slab; the slabs are summed in chunk order
+// afterwards (ecgb_sum_slabs_bf16): the gradient is the same bits every time.
+template <int NSUB, int NF>
+__global__ __launch_bounds__(256, 2) void lora_da_kernel(LoraArgs L)
+{
+    constexpr int kXBytes = 64 * 512, kDtBytes = 64 * 128, kBuf = kXBytes + kDtBytes;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // 2 x 40 KB
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int lm = lane & 15, lq = lane >> 4;
+    const int col0 = blockIdx.x * 256;
+    const int row_lo = blockIdx.y * L.chunk_rows, row_hi = min(L.T, row_lo + L.chunk_rows);
+    const int KT = (row_hi - row_lo + 63) / 64;
+    const int last_rows = row_hi - (row_lo + (KT - 1) * 64);               // rows of the chunk's last tile that exist (1..64)
+    // LDS-DMA: scalar running pointer to the tile + constant per-lane byte offsets (a second set for the one partial tile x can end with:
+    // rows past the end re-read the last row; their dt elements are zeroed below)
+    unsigned offX[8], offXt[8], offD[2], offDt[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = (wave * 8 + i) * 2 + (lane >> 5);
+        const int chunk = (lane & 31) ^ (((r & 7) << 1) ^ (r & 8));
+        const long long c = min(col0 + chunk * 8, L.in - 8);                // clamped columns are never stored
+        offX[i] = (unsigned)(((long long)r * L.in + c) * 2);
+        offXt[i] = (unsigned)(((long long)min(r, last_rows - 1) * L.in + c) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1);
+        offD[i] = (unsigned)((r * kLoraK + chunk * 8) * 2);
+        offDt[i] = (unsigned)((min(r, last_rows - 1) * kLoraK + chunk * 8) * 2);
+    }
+    const unsigned char *nextX = reinterpret_cast<const unsigned char *>(L.x) + (long long)row_lo * L.in * 2;
+    const unsigned char *nextD = reinterpret_cast<const unsigned char *>(L.dt) + (long long)row_lo * kLoraK * 2;
+    auto stage = [&](int kt, unsigned char *dst) {
+        const bool tail = kt == KT - 1 && last_rows < 64;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nextX + (tail ? offXt[i] : offX[i])),
+                                             (__attribute__((address_space(3))) void *)(dst + (wave * 8 + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nextD + (tail ? offDt[i] : offD[i])),
+                                             (__attribute__((address_space(3))) void *)(dst + kXBytes + (wave * 2 + i) * 1024), 16, 0, 0);
+        nextX += (long long)64 * L.in * 2;
+        nextD += 64 * kLoraK * 2;
+    };
+    stage(0, lds);
+    if (KT > 1) { stage(1, lds + kBuf); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // fragment addresses (see gemm_tn_kernel_tr): lane 16 g + 4 q + p addresses row 8 g + q (+ 4: second read), columns 4 p .. 4 p + 3
+    using i2 = __attribute__((ext_vector_type(2))) int;
+    using i4 = __attribute__((ext_vector_type(4))) int;
+    const int tq = lm >> 2, tp = lm & 3;
+    const int rb = 8 * lq + tq;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    unsigned tabX0[4], tabX1[4], tabD[NSUB];
+    {
+        const int sw = (rb & 7) ^ ((rb & 8) >> 1);
+        const unsigned base = lds0 + rb * 512 + (tp & 1) * 8 + (wave >> 1) * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = (wave & 1) * 4 + j;
+            tabX0[j] = base + (((2 * (m ^ sw)) + (tp >> 1)) << 4);
+            tabX1[j] = base + (((2 * (m ^ 4 ^ sw)) + (tp >> 1)) << 4);
+        }
+        const int f = ((rb >> 1) & 1) | (((rb >> 3) & 1) << 1);
+#pragma unroll
+        for (int sb = 0; sb < NSUB; ++sb) tabD[sb] = lds0 + kXBytes + rb * 128 + (tp & 1) * 8 + ((((2 * sb) + (tp >> 1)) ^ (f << 1)) << 4);
+    }
+    f32x4 acc[NSUB][4];
+#pragma unroll
+    for (int sb = 0; sb < NSUB; ++sb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[sb][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < KT; ++kt) {
+        // inline asm reads: hipcc would drain the tile in flight (vmcnt 0) in front of an LDS read it can see next to LDS-DMA, and it neither
+        // counts asm reads nor keeps their consumers behind a bare wait -- the registers pass through the wait statement
+        i4 xv[2][4], dv[2][NSUB];
+        auto frag = [&](unsigned a0, unsigned a1, auto off) {
+            constexpr int OFF = decltype(off)::value;
+            i2 lo, hi;
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(OFF));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(OFF));
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xv[0][j] = frag(tabX0[j], tabX1[j] + 4 * 512, std::integral_constant<int, 0>{});
+            xv[1][j] = frag(tabX0[j], tabX1[j] + 4 * 512, std::integral_constant<int, 32 * 512>{});
+        }
+#pragma unroll
+        for (int sb = 0; sb < NSUB; ++sb) {
+            dv[0][sb] = frag(tabD[sb], tabD[sb] + 4 * 128, std::integral_constant<int, 0>{});
+            dv[1][sb] = frag(tabD[sb], tabD[sb] + 4 * 128, std::integral_constant<int, 32 * 128>{});
+        }
+        if constexpr (NSUB == 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xv[0][0]), "+v"(xv[0][1]), "+v"(xv[0][2]), "+v"(xv[0][3]), "+v"(xv[1][0]), "+v"(xv[1][1]),
+                         "+v"(xv[1][2]), "+v"(xv[1][3]), "+v"(dv[0][0]), "+v"(dv[1][0]));
+        else if constexpr (NSUB == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xv[0][0]), "+v"(xv[0][1]), "+v"(xv[0][2]), "+v"(xv[0][3]), "+v"(xv[1][0]), "+v"(xv[1][1]),
+                         "+v"(xv[1][2]), "+v"(xv[1][3]), "+v"(dv[0][0]), "+v"(dv[1][0]), "+v"(dv[0][NSUB > 1 ? 1 : 0]), "+v"(dv[1][NSUB > 1 ? 1 : 0]));
+        else if constexpr (NSUB == 3)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xv[0][0]), "+v"(xv[0][1]), "+v"(xv[0][2]), "+v"(xv[0][3]), "+v"(xv[1][0]), "+v"(xv[1][1]),
+                         "+v"(xv[1][2]), "+v"(xv[1][3]), "+v"(dv[0][0]), "+v"(dv[1][0]), "+v"(dv[0][NSUB > 1 ? 1 : 0]), "+v"(dv[1][NSUB > 1 ? 1 : 0]),
+                         "+v"(dv[0][NSUB > 2 ? 2 : 0]), "+v"(dv[1][NSUB > 2 ? 2 : 0]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xv[0][0]), "+v"(xv[0][1]), "+v"(xv[0][2]), "+v"(xv[0][3]), "+v"(xv[1][0]), "+v"(xv[1][1]),
+                         "+v"(xv[1][2]), "+v"(xv[1][3]), "+v"(dv[0][0]), "+v"(dv[1][0]), "+v"(dv[0][NSUB > 1 ? 1 : 0]), "+v"(dv[1][NSUB > 1 ? 1 : 0]),
+                         "+v"(dv[0][NSUB > 2 ? 2 : 0]), "+v"(dv[1][NSUB > 2 ? 2 : 0]), "+v"(dv[0][NSUB > 3 ? 3 : 0]), "+v"(dv[1][NSUB > 3 ? 3 : 0]));
+        __builtin_amdgcn_s_barrier();                                   // every wave holds its fragments: the buffer is free
+        if (kt + 2 < KT) stage(kt + 2, lds + (kt & 1) * kBuf);
+        const int trow0 = row_lo + kt * 64;
+        if (kt == KT - 1 && last_rows < 64) {                           // (uniform) dt rows past the end contribute nothing
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int sb = 0; sb < NSUB; ++sb)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int r = 32 * ks + 8 * lq + 2 * w;
+                        unsigned v = (unsigned)dv[ks][sb][w];
+                        if (r >= last_rows) v &= 0xFFFF0000u;
+                        if (r + 1 >= last_rows) v &= 0x0000FFFFu;
+                        dv[ks][sb][w] = (int)v;
+                    }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned col = (unsigned)(col0 + wave * 64 + 16 * j + lm);
+                const unsigned idx0 = (unsigned)(trow0 + 32 * ks + 8 * lq) * (unsigned)L.in + col;
+                i4 xm[NF];
+                if (L.thr == 0) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) xm[f] = xv[ks][j];
+                } else {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) xm[f] = (i4){0, 0, 0, 0};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const unsigned k0 = keep_bits<NF>(L, idx0 + (unsigned)(2 * w) * (unsigned)L.in);
+                        const unsigned k1 = keep_bits<NF>(L, idx0 + (unsigned)(2 * w + 1) * (unsigned)L.in);
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+                            const unsigned m = (((k0 >> f) & 1u) ? 0x0000FFFFu : 0u) | (((k1 >> f) & 1u) ? 0xFFFF0000u : 0u);
+                            xm[f][w] = (int)((unsigned)xv[ks][j][w] & m);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int sb = 0; sb < NSUB; ++sb)
+                    acc[sb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xm[sb * NF / NSUB]), __builtin_bit_cast(bf16x8, dv[ks][sb]),
+                                                                         acc[sb][j], 0, 0, 0);
+            }
+        if (kt + 1 < KT) {                                              // the next tile has landed (the one after it may still fly)
+            if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned step = (kt & 1) ? (unsigned)-kBuf : (unsigned)kBuf;      // (40 KB is not a power of two: add, not xor)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { tabX0[j] += step; tabX1[j] += step; }
+#pragma unroll
+            for (int sb = 0; sb < NSUB; ++sb) tabD[sb] += step;
+        }
+    }
+    // lane (lm, lq) of acc[sb][j]: adapter row 16 sb + lm, columns col0 + 64 wave + 16 j + 4 lq .. + 3
+    float *out = L.slab + ((size_t)blockIdx.y * (16 * NSUB)) * L.in;
+#pragma unroll
+    for (int sb = 0; sb < NSUB; ++sb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = col0 + wave * 64 + 16 * j + 4 * lq;
+            if (c < L.in) *reinterpret_cast<f32x4 *>(out + (size_t)(16 * sb + lm) * L.in + c) = acc[sb][j] * L.scale;
+        }
+}
+
 int check_common(const char *who, int T, int in, int n_sub, int n_fields, float p)
 {
     if (T <= 0 || in <= 0 || in % 64 || n_sub < 1 || n_sub > 4 || n_fields < 1 || n_fields > n_sub || n_sub % n_fields || !(p >= 0.f && p < 1.f)) {
@@ -333,4 +522,54 @@ extern "C" int ecgb_lora_dx_glu(const void *dt_dev, const void *at_dev, const vo
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ecgb::set_error(std::string("lora_dx_kernel (glu): ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
     return ECGB_OK;
+}
+
+namespace {
+// rows of x per chunk: about 512 workgroups (two per CU), never fewer than four K-tiles of 64 rows
+int lora_da_chunk_rows(int T, int in)
+{
+    const int col_tiles = (in + 255) / 256;
+    int n_chunks = 512 / col_tiles;                                  // (256 .. 1024 workgroups measured: 512 is best or within 5 % of it at in = 2048 and 8192)
+    if (n_chunks < 1) n_chunks = 1;
+    int rows = ((T + n_chunks - 1) / n_chunks + 63) / 64 * 64;
+    if (rows < 256) rows = 256;
+    return rows;
+}
+}  // namespace
+
+extern "C" int ecgb_sum_slabs_bf16(const float *slabs_dev, long long slab_stride, int n_slabs, void *out_dev, size_t n, int accumulate, void *stream);
+
+extern "C" size_t ecgb_lora_da_scratch_bytes(int T, int in, int n_sub)
+{
+    if (T <= 0 || in <= 0 || n_sub < 1 || n_sub > 4) return 0;
+    const int rows = lora_da_chunk_rows(T, in);
+    return (size_t)((T + rows - 1) / rows) * 16 * n_sub * in * sizeof(float);
+}
+
+// dA [16 n_sub, in] (bf16, the first rows of the stacked A's gradient) (+)= scale / (1 - p) * dt[:, :16 n_sub]^T . (mask . x)
+extern "C" int ecgb_lora_da(const void *x_dev, const void *dt_dev, void *da_dev, int T, int in, int n_sub, int n_fields, float scale, float p,
+                            uint64_t seed, int accumulate, void *scratch_dev, size_t scratch_bytes, void *stream)
+{
+    if (!x_dev || !dt_dev || !da_dev || !scratch_dev) { ecgb::set_error("ecgb_lora_da: NULL argument"); return ECGB_ERR_INVALID; }
+    if (int rc = check_common("ecgb_lora_da", T, in, n_sub, n_fields, p)) return rc;
+    if (scratch_bytes < ecgb_lora_da_scratch_bytes(T, in, n_sub)) { ecgb::set_error("ecgb_lora_da: scratch smaller than ecgb_lora_da_scratch_bytes()"); return ECGB_ERR_INVALID; }
+    LoraArgs L{};
+    L.x = (const unsigned short *)x_dev; L.dt = (const unsigned short *)dt_dev; L.slab = (float *)scratch_dev;
+    fill(L, T, in, scale, p, seed);
+    L.chunk_rows = lora_da_chunk_rows(T, in);
+    const int n_chunks = (T + L.chunk_rows - 1) / L.chunk_rows;
+    const dim3 grid((unsigned)((in + 255) / 256), (unsigned)n_chunks);
+    constexpr unsigned kLds = 2 * (64 * 512 + 64 * 128);
+    const int key = n_sub * 8 + n_fields;
+#define ECGB_DA_CASE(NS, NFI)                                                                                                    \
+    if (key == NS * 8 + NFI) {                                                                                                   \
+        (void)hipFuncSetAttribute((const void *)lora_da_kernel<NS, NFI>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);                  \
+        hipLaunchKernelGGL((lora_da_kernel<NS, NFI>), grid, dim3(256), kLds, (hipStream_t)stream, L);                            \
+    }
+    ECGB_DA_CASE(1, 1) else ECGB_DA_CASE(2, 1) else ECGB_DA_CASE(2, 2) else ECGB_DA_CASE(3, 1) else ECGB_DA_CASE(3, 3)
+    else ECGB_DA_CASE(4, 1) else ECGB_DA_CASE(4, 2) else ECGB_DA_CASE(4, 4)
+#undef ECGB_DA_CASE
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ecgb::set_error(std::string("lora_da_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ecgb_sum_slabs_bf16((const float *)scratch_dev, (long long)16 * n_sub * in, n_chunks, da_dev, (size_t)16 * n_sub * in, accumulate, stream);
 }

@@ -162,11 +162,10 @@ class LoraSite(nn.Module):
         model._wgrad(self.B, dy, t)                                      # dB = dy^T . t  (t carries alpha / r and 1 / (1 - p))
         self.B.grad.mul_(self.bmask)                                     # every block's rows keep only its own columns
         keep_scale = self.scale / (1.0 - int(p * 65536.0) / 65536.0)     # the keep probability ecgb_lora_down's 16-bit threshold gives
-        if xd is None:
+        if p == 0.0:
             model._wgrad(self.A, dt, x, alpha=keep_scale)                # no dropout: one product for all blocks
-        else:
-            w = 16 * self.spb                                            # dA_b = dt_b^T . (mask_b . x)
-            model._wgrad_rows(self.A, [(w * f, w * f + w, dt[:, w * f: w * f + w], xd[f]) for f in range(self.n_fields)], alpha=keep_scale)
+        else:                                                            # dA_b = dt_b^T . (mask_b . x), the masks replayed from the seed
+            model._lora_agrad(self.A, x, dt, self.n_sub, self.n_fields, self.scale, p, seed)
         if glu is not None and self.n_sub == 1:
             return ops.lora_dx_glu(dx, dt, At, glu[0], self.scale, p, seed, gelu_tanh=glu[1])
         ops.lora_dx_(dx, dt, At, self.n_sub, self.n_fields, self.scale, p, seed)
@@ -602,6 +601,13 @@ class HipCausalLM(nn.Module):
             ops.gemm_tn(dy, xin, alpha=alpha, out=dst, accumulate=acc)
         param.grad = view
 
+    def _lora_agrad(self, param, x, dt, n_sub, n_fields, scale, p, seed):
+        """Rows [0, 16 n_sub) of a stacked LoRA A's gradient (+)= scale / (1 - p) * dt^T . (mask . x) (ecgb_lora_da); the rows past them keep
+        the zeros the flat buffer was created with."""
+        view, acc = self._grad_slot(param)
+        ops.lora_da(x, dt, view[: 16 * n_sub], n_sub, n_fields, scale, p, seed, accumulate=acc)
+        param.grad = view
+
     def _vgrad(self, param, g):
         """param.grad (+)= g (any float dtype, converted to bf16)."""
         view, acc = self._grad_slot(param)
@@ -642,16 +648,16 @@ class HipCausalLM(nn.Module):
         for i in range(c.num_hidden_layers):
             h1, rstd1, x1 = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
             ls = [None] * 4
-            qkv, ls[0] = self._proj(i, "qkv", h1, self.wqkv[i].data, self.training, True)    # [T, QKV]
+            qkv, ls[0] = self._proj(i, "qkv", h1, self.wqkv[i].data, self.training)    # [T, QKV]
             ops.rope_(qkv, cos, sin, Hq + Hkv, D, QKV)                   # the query heads and the key heads lie side by side: one launch
             if self.fused_attention:
                 ao, P = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)       # P slot holds the row log-sum-exps
             else:
                 ao, P = self._attn_materialised(qkv, mask, B, S)
-            attn_delta, ls[1] = self._proj(i, "o", ao, self.wo[i].data, self.training, True)   # [T, H]
+            attn_delta, ls[1] = self._proj(i, "o", ao, self.wo[i].data, self.training)   # [T, H]
             h2, rstd2, x2 = ops.rmsnorm_fwd(x1, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma)
-            gu, hm, ls[2] = self._proj_glu(i, h2, self.training, True)                         # [T, 2I], [T, I]
-            delta, ls[3] = self._proj(i, "down", hm, self.wdown[i].data, self.training, True)
+            gu, hm, ls[2] = self._proj_glu(i, h2, self.training)                         # [T, 2I], [T, I]
+            delta, ls[3] = self._proj(i, "down", hm, self.wdown[i].data, self.training)
             saved.append((x1, rstd1, h1, qkv, P, ao, x2, rstd2, h2, gu, hm, ls))
             x = x2
         hf, rstdf, xf = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)

@@ -285,6 +285,19 @@ def lora_dx_(dx, dt, At, n_sub, n_fields, scale, p=0.0, seed=0):
     return dx
 
 
+def lora_da(x, dt, out, n_sub, n_fields, scale, p=0.0, seed=0, accumulate=False):
+    """out [16 * n_sub, in] (bf16, contiguous: the first rows of the stacked A's gradient) (+)= scale / (1 - p) * dt[:, :16 n_sub]^T . (mask_f . x),
+    the dropout masks of ecgb_lora_down evaluated again from (seed, element index) (ecgb_lora_da): one pass over x for all modules of the site,
+    no masked copies of x kept by the forward; row chunks meet in fp32 slabs added in order."""
+    T, K = x.shape
+    assert dt.shape == (T, 64) and out.shape == (16 * n_sub, K) and out.dtype == torch.bfloat16 and out.is_contiguous()
+    nbytes = _L().ecgb_lora_da_scratch_bytes(T, K, n_sub)
+    scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    _lib.check(_L().ecgb_lora_da(_p(_bf(x)), _p(_bf(dt)), _p(out), T, K, n_sub, n_fields, float(scale), float(p), int(seed), int(accumulate),
+                                 _p(scratch), nbytes, _st()))
+    return out
+
+
 def lora_dx_glu(dx, dt, At, gate_up, scale, p=0.0, seed=0, gelu_tanh=False):
     """d(gate|up) = glu_bwd(gate|up, dx + scale / (1 - p) * mask . (dt A)) in one pass (ecgb_lora_dx_glu: the down-projection site, one
     adapter block); dx [T, I] is only read."""

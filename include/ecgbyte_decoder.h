@@ -96,12 +96,19 @@ int ecgb_gemm_nt_bf16_cat(const void *a_dev, long long lda, const void *b_dev, l
  * (seed, row * in + col) is >= p * 65536.  p = 0: no dropout.
  * t and dt are [T, 64] (columns past 16 * n_sub zero: one K-step of ecgb_gemm_nt_bf16_cat), A^T is [in, 64].
  *   ecgb_lora_down   t = scale / (1 - p) * (mask_f . x) A_f^T  (one pass over x);  xd_dev, if not NULL, receives the
- *                    n_fields masked copies of x, [n_fields, T, in] (the backward's dA = dt^T . (mask . x) reads them)
+ *                    n_fields masked copies of x, [n_fields, T, in] (tests compare them with the masks the backward kernels replay)
  *   ecgb_lora_dx     dx[T, in] += scale / (1 - p) * sum_f mask_f . (dt_f A_f), at_dev = A^T  (one read-modify-write of dx) */
 int ecgb_lora_down(const void *x_dev, const void *a_dev, void *t_dev, void *xd_dev, int T, int in, int n_sub, int n_fields,
                    float scale, float p, uint64_t seed, void *stream);
 int ecgb_lora_dx(const void *dt_dev, const void *at_dev, void *dx_dev, int T, int in, int n_sub, int n_fields,
                  float scale, float p, uint64_t seed, void *stream);
+/* The adapters' own weight gradient from x itself: da_dev [16 * n_sub, in] (bf16: the first rows of the stacked A's gradient) (+)=
+ * scale / (1 - p) * dt[:, :16 * n_sub]^T . (mask_f . x), the masks evaluated again from (seed, row * in + col) -- the forward keeps no masked
+ * copy of x (peft's autograd saves dropout(x) per module; the model here saves x once per site).  One pass over x for all modules of the
+ * site; chunks of rows meet in fp32 slabs (scratch_dev, ecgb_lora_da_scratch_bytes) summed in chunk order: no atomics, the same bits every time. */
+size_t ecgb_lora_da_scratch_bytes(int T, int in, int n_sub);
+int ecgb_lora_da(const void *x_dev, const void *dt_dev, void *da_dev, int T, int in, int n_sub, int n_fields, float scale, float p,
+                 uint64_t seed, int accumulate, void *scratch_dev, size_t scratch_bytes, void *stream);
 /* ecgb_lora_dx with the GLU backward behind it (the down-projection site, one adapter block): dx [T, inter] = d(act(gate) * up) of the
  * frozen base is READ, the adapters' contribution added, and d(gate|up) [T, 2*inter] = ecgb_glu_bwd(gate|up, that sum) written -- the same
  * bits as ecgb_lora_dx followed by ecgb_glu_bwd, one read-modify-write pass over [T, inter] less. */

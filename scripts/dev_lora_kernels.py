@@ -19,8 +19,13 @@ for name, K, n_sub, n_fields in (("o", 2048, 1, 1), ("down", 8192, 1, 1), ("qkv"
     At = A.T.contiguous()
     dt = torch.randn(T, 64, device="cuda").to(torch.bfloat16)
     for p in (0.0, 0.05):
-        t0 = timed(lambda: ops.lora_down(x, A, n_sub, n_fields, 2.0, p, 1234, keep_masked=True))
-        by = T * K * 2 * (1 + (n_fields if p > 0 else 0))
+        t0 = timed(lambda: ops.lora_down(x, A, n_sub, n_fields, 2.0, p, 1234))
+        by = T * K * 2
         dx = torch.zeros(T, K, device="cuda", dtype=torch.bfloat16)
         t1 = timed(lambda: ops.lora_dx_(dx, dt, At, n_sub, n_fields, 2.0, p, 1234))
-        print(f"{name:5s} p={p}: lora_down {t0:.3f} ms ({by / t0 / 1e9:.2f} TB/s)   lora_dx {t1:.3f} ms ({T * K * 4 / t1 / 1e9:.2f} TB/s)")
+        da = torch.zeros(16 * n_sub, K, device="cuda", dtype=torch.bfloat16)
+        t2 = timed(lambda: ops.lora_da(x, dt, da, n_sub, n_fields, 2.0, p, 1234))
+        w = 16 * n_sub // n_fields
+        t3 = timed(lambda: [ops.gemm_tn(dt[:, w * f: w * f + w], x, alpha=2.0, out=da[w * f: w * f + w]) for f in range(n_fields)])   # the TN GEMMs on masked copies it replaces (x stands in for xd)
+        print(f"{name:5s} p={p}: lora_down {t0:.3f} ms ({by / t0 / 1e9:.2f} TB/s)   lora_dx {t1:.3f} ms ({T * K * 4 / t1 / 1e9:.2f} TB/s)"
+              f"   lora_da {t2:.3f} ms ({by / t2 / 1e9:.2f} TB/s; per-module TN GEMMs {t3:.3f} ms)")

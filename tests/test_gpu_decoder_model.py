@@ -262,6 +262,10 @@ def test_lora_dropout_masks_independent_per_module_and_replayed_in_backward():
             gr = torch.zeros_like(prm.data)
             for lo, hi, dy, xin in parts: gr[lo:hi] = ops.gemm_tn(dy, xin, alpha=alpha)
             prm.grad = gr
+        def _lora_agrad(self, prm, x, dt, n_sub, n_fields, scale, p, seed):
+            gr = torch.zeros_like(prm.data)
+            ops.lora_da(x, dt, gr[: 16 * n_sub], n_sub, n_fields, scale, p, seed)
+            prm.grad = gr
     dy = torch.randn(T, 512, device="cuda").to(torch.bfloat16)
     dx0 = torch.randn(T, K, device="cuda").to(torch.bfloat16)
     dx = site.backward(dy, saved, _M(), dx0.clone())

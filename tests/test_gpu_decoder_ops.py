@@ -351,6 +351,35 @@ def test_lora_dx_with_glu_backward_is_bitwise_the_two_kernels(ops, p, gelu_tanh)
     assert torch.equal(dx, keep)
 
 
+@pytest.mark.parametrize("T,K,n_sub,n_fields,p", [(1024, 512, 3, 3, 0.25), (1000, 2048, 1, 1, 0.05), (4096, 2048, 2, 2, 0.05), (700, 128, 4, 2, 0.1),
+                                                  (2048, 8192, 1, 1, 0.05), (32768, 2048, 3, 3, 0.05), (333, 320, 4, 4, 0.5), (640, 2048, 2, 1, 0.0)])
+def test_lora_da_replays_the_forward_masks(ops, T, K, n_sub, n_fields, p):
+    """The adapters' weight gradient from x itself (ecgb_lora_da: the dropout masks evaluated again from the seed, one pass over x for all
+    modules of the site) against dt_f^T . xd_f on the masked copies ecgb_lora_down stores when asked: every mask bit must be the forward's.
+    Ragged rows (a last tile of 8 / 40 / 13 rows), columns that are not a multiple of the 256-column tile, 1..4 sub-blocks over 1..4
+    modules, no dropout, accumulation into an existing gradient; the same bits on every launch (ordered slabs, no atomics)."""
+    x, A = _bf(T, K, seed=91), _bf(64, K, scale=0.05, seed=92)
+    dt = _bf(T, 64, scale=0.5, seed=93)
+    dt[:, 16 * n_sub:] = 0
+    _, xd = ops.lora_down(x, A, n_sub, n_fields, 2.0, p, 777, keep_masked=True)
+    inv = 2.0 / (1.0 - int(p * 65536) / 65536)
+    w = 16 * n_sub // n_fields
+    want = torch.cat([dt[:, w * f: w * f + w].float().T @ (xd[f] if xd is not None else x).float() for f in range(n_fields)], 0) * inv
+    got = torch.zeros(16 * n_sub, K, dtype=torch.bfloat16, device="cuda")
+    ops.lora_da(x, dt, got, n_sub, n_fields, 2.0, p, 777)
+    _close(got, want, atol=2e-2 * float(want.abs().max()), rtol=1e-2)
+    noise = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
+    for rep in range(4):
+        noise.random_()
+        again = torch.zeros_like(got)
+        assert torch.equal(ops.lora_da(x, dt, again, n_sub, n_fields, 2.0, p, 777), got), rep
+    other = ops.lora_da(x, dt, torch.zeros_like(got), n_sub, n_fields, 2.0, p, 778)
+    assert p == 0.0 or not torch.equal(other, got)                          # another seed, other masks
+    base = _bf(16 * n_sub, K, seed=94)
+    acc = ops.lora_da(x, dt, base.clone(), n_sub, n_fields, 2.0, p, 777, accumulate=True)
+    _close(acc, base.float() + want, atol=2e-2 * float(want.abs().max()) + 2e-2, rtol=1e-2)
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 2048, 3072), (4000, 2048, 64), (32768, 2048, 128), (8192, 8192, 2048), (3000, 2056, 192)])
 def test_gemm_nn_is_bitwise_the_nt_kernel_on_a_transposed_copy(ops, M, N, K):
     """dX = dY . W against the weight as stored ([out, in] row-major): the NN kernel (A side of the NT kernel, B side by transposing LDS
