@@ -27,7 +27,6 @@ using bf16x8 = __attribute__((ext_vector_type(8))) short;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using us4 = __attribute__((ext_vector_type(4))) unsigned short;
 
-__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f)
 {
     unsigned u = __float_as_uint(f);
@@ -44,6 +43,15 @@ __device__ __forceinline__ unsigned hash32(unsigned seed, unsigned idx)
     u ^= u >> 13; u *= 0xC2B2AE3Du;
     u ^= u >> 16;
     return u;
+}
+
+// two fp32 -> packed bf16 pair, one v_cvt_pk_bf16_f32 (round to nearest even)
+using bf2_t = __attribute__((ext_vector_type(2))) __bf16;
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+{
+    bf2_t v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
 }
 
 constexpr int kLoraK = 64;        // row length of t / dt / A^T: up to four 16-wide sub-blocks, zero beyond the last one (the GEMM K-step)
@@ -196,6 +204,17 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraArgs L)
         fetch_at(more ? c0 + 64 : c0);                               // unconditional: the waits stay counted
         const unsigned short *at = s_at[it & 1];
         const us8 old0 = *reinterpret_cast<const us8 *>(dxr + c0), old1 = *reinterpret_cast<const us8 *>(dxr + c0 + 8);
+        // GLU: gate / up of the same elements, requested here with dx (clamped row: unconditional, so that all six loads are in flight
+        // under the hashing and the MFMAs -- behind the `row < T` test below they were issued after them, their latency exposed every step)
+        us8 gv[2], uv[2];
+        if constexpr (GLU != 0) {
+            const size_t oc = (size_t)rowc * 2 * L.in + c0 + 16 * lq;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                gv[half] = *reinterpret_cast<const us8 *>(L.gu + oc + 8 * half);
+                uv[half] = *reinterpret_cast<const us8 *>(L.gu + oc + L.in + 8 * half);
+            }
+        }
         float sum[16];
         unsigned keep[16];
         const unsigned idx0 = (unsigned)rowc * (unsigned)L.in + (unsigned)(c0 + 16 * lq);
@@ -211,30 +230,41 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraArgs L)
                 for (int e = 0; e < 4; ++e) sum[4 * q + e] += ((keep[4 * q + e] >> (s * NF / NSUB)) & 1u) ? d[e] : 0.f;
             }
         if (row < L.T) {
-            us8 v0, v1;
+            // element pairs stay packed: word j of a half holds columns 2 j, 2 j + 1; one v_cvt_pk_bf16_f32 per pair (round to nearest even,
+            // as every other kernel of the library converts) instead of an integer rounding sequence per element
+            using u4 = __attribute__((ext_vector_type(4))) unsigned;
+            const u4 oldw[2] = {__builtin_bit_cast(u4, old0), __builtin_bit_cast(u4, old1)};
+            u4 v[2];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v0[e] = f2bf(bf2f(old0[e]) + sum[e] * L.scale);
-                v1[e] = f2bf(bf2f(old1[e]) + sum[8 + e] * L.scale);
-            }
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[half][j] = pack_bf16(__uint_as_float(oldw[half][j] << 16) + sum[8 * half + 2 * j] * L.scale,
+                                           __uint_as_float(oldw[half][j] & 0xFFFF0000u) + sum[8 * half + 2 * j + 1] * L.scale);
             if constexpr (GLU == 0) {
-                *reinterpret_cast<us8 *>(dxr + c0) = v0;
-                *reinterpret_cast<us8 *>(dxr + c0 + 8) = v1;
+                *reinterpret_cast<u4 *>(dxr + c0) = v[0];
+                *reinterpret_cast<u4 *>(dxr + c0 + 8) = v[1];
             } else {
                 const size_t o = (size_t)row * 2 * L.in + c0 + 16 * lq;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    const us8 g = *reinterpret_cast<const us8 *>(L.gu + o + 8 * half), u = *reinterpret_cast<const us8 *>(L.gu + o + L.in + 8 * half);
-                    const us8 d = half ? v1 : v0;
-                    us8 og, ou;
+                    const u4 g = __builtin_bit_cast(u4, gv[half]), u = __builtin_bit_cast(u4, uv[half]);
+                    u4 og, ou;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float gf = bf2f(g[e]), uf = bf2f(u[e]), df = bf2f(d[e]);
-                        og[e] = f2bf(df * uf * ecgb::glu_act_grad<GLU == 2>(gf));
-                        ou[e] = f2bf(df * ecgb::glu_act<GLU == 2>(gf));
+                    for (int j = 0; j < 4; ++j) {
+                        float dg[2], du[2];
+#pragma unroll
+                        for (int hl = 0; hl < 2; ++hl) {
+                            const float gf = __uint_as_float(hl ? g[j] & 0xFFFF0000u : g[j] << 16), uf = __uint_as_float(hl ? u[j] & 0xFFFF0000u : u[j] << 16);
+                            const float df = __uint_as_float(hl ? v[half][j] & 0xFFFF0000u : v[half][j] << 16);
+                            dg[hl] = df * uf * ecgb::glu_act_grad<GLU == 2>(gf);
+                            du[hl] = df * ecgb::glu_act<GLU == 2>(gf);
+                        }
+                        og[j] = pack_bf16(dg[0], dg[1]);
+                        ou[j] = pack_bf16(du[0], du[1]);
                     }
-                    *reinterpret_cast<us8 *>(L.dgu + o + 8 * half) = og;
-                    *reinterpret_cast<us8 *>(L.dgu + o + L.in + 8 * half) = ou;
+                    *reinterpret_cast<u4 *>(L.dgu + o + 8 * half) = og;
+                    *reinterpret_cast<u4 *>(L.dgu + o + L.in + 8 * half) = ou;
                 }
             }
         }
