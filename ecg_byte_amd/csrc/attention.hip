@@ -173,24 +173,69 @@ __device__ __forceinline__ bf16x8 frag_transposed(const unsigned char *lds, int 
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
     return f;
 }
-// The same fragment from a PLAIN V tile ([key][64 d], chunk c of key row r stored at c ^ 4 ((r >> 1) & 1)) by two transposing reads: per 16
-// lanes a block of 4 keys x 16 d comes back column-major, lane 4 q + p supplying the address of key q, d 4 p .. 4 p + 3 (inline asm: a
-// transposing read hipcc can see next to LDS-DMA gets a vmcnt(0) in front of it)
-__device__ __forceinline__ bf16x8 frag_v_tr(const unsigned char *lds, int db, int lr, int kb, int s2, int h)
+// ---- LDS-DMA staging of the backward kernels (head_dim 64) ---------------------------------------------------------------------------
+// A tile of 64 rows x 128 bytes lands as it lies in memory, 16-byte chunk c of row r at c ^ u(r), u(r) = bit 1 of r << 2 | bits 2-3 of r: one image
+// serves BOTH kinds of read conflict-free -- the row fragments (ds_read_b128: the 8 row pairs 16 lanes address land on 8 different chunk positions, u
+// is a bijection of bits 1-3 of r) and the transposing reads (ds_read_b64_tr_b16: the 4 rows x 64 bytes 32 lanes address cover rows 0,1 in one
+// 64-byte half of the row and rows 2,3 in the other).  The swizzle is applied on the global address of the DMA (its LDS side is lane-linear).
+__device__ __forceinline__ int swz_u(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+__device__ __forceinline__ bf16x8 frag_plain_u(const unsigned char *lds, int r, int ks, int h)
 {
-    using i2 = __attribute__((ext_vector_type(2))) int;
-    using i4 = __attribute__((ext_vector_type(4))) int;
+    return *reinterpret_cast<const bf16x8 *>(lds + r * 128 + (((ks * 2 + h) ^ swz_u(r)) << 4));
+}
+// Inline-asm LDS reads next to LDS-DMA (a read hipcc can see there gets a vmcnt(0) in front of it: every tile in flight drained).  hipcc neither counts
+// such reads in lgkmcnt nor knows their results are pending: it may copy a destination register the moment the asm statement is over (and it did --
+// v_mov of registers still in flight, stale data on a busy chip), and passing the registers through a later wait statement does not help: the
+// copy is made BEFORE that statement.  So a group of reads and its wait are ONE asm statement, and the results exist when it ends.  Placed right
+// behind the issue of a tile's first MFMAs, the wait runs under them.
+using i2v = __attribute__((ext_vector_type(2))) int;
+using i4v = __attribute__((ext_vector_type(4))) int;
+using f4v = __attribute__((ext_vector_type(4))) float;
+// the four transposed fragments f[s2][db] (rows = d 32 db .., k = 32 tile rows in accumulator order) of one half of a tile image: (a0, b0) / (a1, b1)
+// are the lane's first / second read address for db = 0 / 1, OFF0 / OFF1 the byte offsets of the s2 = 0 / 1 row groups
+template <int OFF0, int OFF1>
+__device__ __forceinline__ void tr_frags4_wait(bf16x8 (&f)[2][2], unsigned a0, unsigned b0, unsigned a1, unsigned b1)
+{
+    i2v r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+                 "ds_read_b64_tr_b16 %1, %9 offset:%12\n\t"
+                 "ds_read_b64_tr_b16 %2, %10 offset:%12\n\t"
+                 "ds_read_b64_tr_b16 %3, %11 offset:%12\n\t"
+                 "ds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+                 "ds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
+                 "ds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+                 "ds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                 : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "n"(OFF0), "n"(OFF1)
+                 : "memory");
+    f[0][0] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(r0, r1, 0, 1, 2, 3));
+    f[0][1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(r2, r3, 0, 1, 2, 3));
+    f[1][0] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(r4, r5, 0, 1, 2, 3));
+    f[1][1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(r6, r7, 0, 1, 2, 3));
+}
+// four 16-byte reads 32 bytes apart (a lane's four runs of four keys / queries in a row of floats), from byte offset OFF
+template <int OFF>
+__device__ __forceinline__ void lds_rows4_wait(f4v (&m)[4], unsigned a)
+{
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\t"
+                 "ds_read_b128 %1, %4 offset:%6\n\t"
+                 "ds_read_b128 %2, %4 offset:%7\n\t"
+                 "ds_read_b128 %3, %4 offset:%8\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3])
+                 : "v"(a), "n"(OFF), "n"(OFF + 32), "n"(OFF + 64), "n"(OFF + 96)
+                 : "memory");
+}
+// byte offset inside a tile image of this lane's transposing read for fragment (db, kb = 0, s2 = 0): row_add = 0 for the first read, 8 for the second
+// (bit 3 of the row enters u, so the two are computed separately); the other (kb, s2) are 32 kb + 16 s2 rows further down, which leaves u alone: they go
+// into the instruction's offset field
+__device__ __forceinline__ unsigned tr_off_u(int db, int lr, int h, int row_add)
+{
     const int a = lr >> 4, q = (lr & 15) >> 2, p = lr & 3;
-    const int key0 = kb * 32 + 16 * s2 + 4 * h + q, key1 = key0 + 8;
+    const int key = 4 * h + q + row_add;
     const int chunk = db * 4 + 2 * a + (p >> 1);
-    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)const_cast<unsigned char *>(lds) + (p & 1) * 8;
-    const unsigned a0 = base + key0 * 128 + ((chunk ^ (((key0 >> 1) & 1) << 2)) << 4);
-    const unsigned a1 = base + key1 * 128 + ((chunk ^ (((key1 >> 1) & 1) << 2)) << 4);
-    i2 lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
-    const i4 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
-    return __builtin_bit_cast(bf16x8, f);
+    return (unsigned)(key * 128 + ((chunk ^ swz_u(key)) << 4) + (p & 1) * 8);
 }
 // two fp32 -> packed bf16 pair, one v_cvt_pk_bf16_f32 (round to nearest even)
 using bf2_t = __attribute__((ext_vector_type(2))) __bf16;
@@ -346,12 +391,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
         write_tile(0, 0);
         __syncthreads();
     }
+    // DMA: this lane's transposing-read address inside a V image for d block 0 / 1 (first read; the second is 8 keys = 1 KiB further down; the other
+    // (kb, s2) row groups go into the instruction's offset field): 16-byte chunk c of key row r lies at c ^ 4 ((r >> 1) & 1)
+    unsigned vtr[2] = {0, 0};
+    if constexpr (DMA) {
+        const int a = lr >> 4, q = (lr & 15) >> 2, p = lr & 3;
+        const int key = 4 * h + q;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+            vtr[db] = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem + kTile + key * 128 +
+                      (((db * 4 + 2 * a + (p >> 1)) ^ (((key >> 1) & 1) << 2)) << 4) + (p & 1) * 8;
+    }
 #ifdef ECGB_PROFILE
     unsigned long long prof_acc[7] = {};
     long long t_prof = clock64();
 #endif
     for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
         const bool more = k0 + 64 < k_end;
+        const unsigned vimg = DMA ? (unsigned)((it % 3) * 2 * kTile) : 0u;
         if constexpr (DMA) issue_tile(min(it + 2, last_tile), (it + 2) % 3);      // two tiles ahead, into the buffer tile it - 1 left at the last barrier
         else if (more) load_tile(k0 + 64);   // next tile in flight behind the MFMAs
         APROF(0);
@@ -379,15 +436,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
                         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain<D>(lds_k, kb * 32 + lr, ks, h), qf[ks], sacc[kb], 0, 0, 0);
-                // DMA: the eight V^T fragments of the tile are requested now, behind the S products, and arrive under the softmax
-                bf16x8 vfr[2][2][DMA ? D / 32 : 1];
+                // DMA: the eight V^T fragments of the tile are read now, behind the issue of the S products (the wait inside runs under them)
+                bf16x8 vfr[2][2][2];                                // [kb][s2][db]
                 if constexpr (DMA) {
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                            for (int db = 0; db < D / 32; ++db) vfr[kb][s2][db] = frag_v_tr(lds_vt, db, lr, kb, s2, h);
+                    tr_frags4_wait<0, 16 * 128>(vfr[0], vtr[0] + vimg, vtr[0] + vimg + 1024, vtr[1] + vimg, vtr[1] + vimg + 1024);
+                    tr_frags4_wait<32 * 128, 48 * 128>(vfr[1], vtr[0] + vimg, vtr[0] + vimg + 1024, vtr[1] + vimg, vtr[1] + vimg + 1024);
                 }
                 // max3() below is inline asm: hipcc's hazard recogniser does not look inside it, and a vector instruction that reads an
                 // MFMA result needs 19 wait states after a 16-pass MFMA (nothing interlocks: the first version read stale registers now
@@ -400,20 +453,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
                     if (MODE == 1 || (MODE == 2 && need_mask)) {
                         float4 mk4[4];                                           // the lane's 16 keys are 4 runs of 4: four 16-byte reads
                         if constexpr (DMA) {
-                            using f4v = __attribute__((ext_vector_type(4))) float;
                             f4v mv[4];
-                            // inline asm: a mask read hipcc can see behind LDS-DMA gets vmcnt(0) in front of it (both tiles in flight drained on
-                            // every masked tile).  LDS returns in order: once only the 16 V reads requested above are outstanding, these are in.
-#pragma unroll
-                            for (int g4 = 0; g4 < 4; ++g4) {
-                                const unsigned ma = (unsigned)(size_t)(__attribute__((address_space(3))) float *)const_cast<float *>(&lds_mask[kb * 32 + 8 * g4 + 4 * h]);
-                                f4v t;
-                                asm volatile("ds_read_b128 %0, %1" : "=v"(t) : "v"(ma));
-                                mv[g4] = t;
-                            }
-                            // the registers pass THROUGH the wait: a bare waitcnt statement does not stop hipcc from scheduling the compares on
-                            // them ahead of it (it believes an asm's outputs are ready when the asm is)
-                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mv[0]), "+v"(mv[1]), "+v"(mv[2]), "+v"(mv[3]));
+                            const unsigned ma = (unsigned)(size_t)(__attribute__((address_space(3))) float *)const_cast<float *>(lds_mask) + 16 * h;
+                            if (kb == 0) lds_rows4_wait<0>(mv, ma); else lds_rows4_wait<128>(mv, ma);
 #pragma unroll
                             for (int g4 = 0; g4 < 4; ++g4) mk4[g4] = make_float4(mv[g4][0], mv[g4][1], mv[g4][2], mv[g4][3]);
                         } else {
@@ -453,9 +495,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
                         for (int r = 0; r < 16; ++r) accO[db][r] *= alpha;
                 }
                 APROF(2);
-                if constexpr (DMA)       // the V fragments requested above (inline-asm reads: hipcc does not count them); the registers pass through the wait
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vfr[0][0][0]), "+v"(vfr[0][0][DMA ? 1 : 0]), "+v"(vfr[0][1][0]), "+v"(vfr[0][1][DMA ? 1 : 0]),
-                                 "+v"(vfr[1][0][0]), "+v"(vfr[1][0][DMA ? 1 : 0]), "+v"(vfr[1][1][0]), "+v"(vfr[1][1][DMA ? 1 : 0]));
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -463,7 +502,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
                         const bf16x8 pf = frag_from_acc(&p[kb][8 * s2]);
 #pragma unroll
                         for (int db = 0; db < D / 32; ++db)
-                            accO[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(DMA ? vfr[kb][s2][DMA ? db : 0] : frag_transposed(lds_vt, db * 32 + lr, kb, s2, h),
+                            accO[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(DMA ? vfr[kb][s2][db & 1] : frag_transposed(lds_vt, db * 32 + lr, kb, s2, h),
                                                                                pf, accO[db], 0, 0, 0);
                     }
                 APROF(3);
@@ -594,6 +633,129 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
                     accQ[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(lds_kt, db * 32 + lr, kb, s2, h), dsf, accQ[db], 0, 0, 0);
             }
         }
+    }
+    store_accT<D / 32>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, 1.f);
+}
+
+// dQ with LDS-DMA staging (head_dim 64): K and V tiles through a ring of three buffers, two tiles ahead, counted waits (see attn_fwd_kernel<64, true>);
+// K is read both ways from one image (row fragments for S, transposing reads for dS . K).  Same arithmetic in the same order as attn_bwd_dq_kernel<64>:
+// the same bits.
+__global__ __launch_bounds__(256) void attn_bwd_dq_dma_kernel(AttnArgs A)
+{
+    constexpr int D = 64, kTile = 128 * D;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 x (K, V) + 4 bytes per key
+    auto lds_k3 = [&](int i) { return smem + i * 2 * kTile; };
+    auto lds_v3 = [&](int i) { return smem + i * 2 * kTile + kTile; };
+    float *lds_maskrow = reinterpret_cast<float *>(smem + 6 * kTile);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
+    int qblk, head_in, group;
+    map_block((int)blockIdx.x, (A.S + 127) / 128, A.Hq / A.Hkv, A.B * A.Hkv, true, qblk, head_in, group);
+    const int b = group / A.Hkv, g = group % A.Hkv, hq = g * (A.Hq / A.Hkv) + head_in;
+    const int q0 = qblk * 128;
+    const int qi = q0 + wave * 32 + lr;
+    const bool qvalid = qi < A.S;
+    const long long rowbase = (long long)b * A.S;
+    const unsigned short *Q = A.q + (long long)hq * D, *K = A.k + (long long)g * D, *V = A.v + (long long)g * D;
+    bf16x8 qf[D / 16], dof[D / 16], of[D / 16];
+    load_row_frags<D>(qf, Q, A.ldq, rowbase + qi, qvalid, h);
+    load_row_frags<D>(dof, A.d_o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h);
+    load_row_frags<D>(of, A.o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h);
+    float delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += bf2f((unsigned short)dof[ks][j]) * bf2f((unsigned short)of[ks][j]);
+    delta += __shfl_xor(delta, 32, 64);
+    const long long stat = ((long long)b * A.Hq + hq) * A.S + qi;
+    if (qvalid && h == 0) A.delta[stat] = delta;
+    const float lse = qvalid ? A.lse[stat] : INFINITY;
+    f32x16 accQ[D / 32];
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accQ[db][r] = 0.f;
+    const float sc = A.scale * kLog2e;
+    const int k_end = min(A.S, q0 + 128);
+    const int wave_qmax = q0 + wave * 32 + 31;
+    const int last_tile = (k_end - 1) / 64;
+    unsigned offK[2], offV[2], offKt[2], offVt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + (lane >> 3), c = (lane & 7) ^ swz_u(r);
+        const int rt = min(r, A.S - 1 - last_tile * 64);                 // tail tile: rows past the last key re-read it (masked: keys >= S)
+        offK[i] = (unsigned)(((long long)r * A.ldk + c * 8) * 2);  offKt[i] = (unsigned)(((long long)rt * A.ldk + c * 8) * 2);
+        offV[i] = (unsigned)(((long long)r * A.ldv + c * 8) * 2);  offVt[i] = (unsigned)(((long long)rt * A.ldv + c * 8) * 2);
+    }
+    auto issue_tile = [&](int t, int buf) {                  // UNCONDITIONAL (the caller clamps t): the waits below stay counted
+        const bool tail = (t + 1) * 64 > A.S;
+        const unsigned char *kb = reinterpret_cast<const unsigned char *>(K + (rowbase + (long long)t * 64) * A.ldk);
+        const unsigned char *vb = reinterpret_cast<const unsigned char *>(V + (rowbase + (long long)t * 64) * A.ldv);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb + (tail ? offKt[i] : offK[i])),
+                                             (__attribute__((address_space(3))) void *)(lds_k3(buf) + (wave * 2 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb + (tail ? offVt[i] : offV[i])),
+                                             (__attribute__((address_space(3))) void *)(lds_v3(buf) + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+    };
+    issue_tile(0, 0);
+    issue_tile(min(1, last_tile), 1);
+    for (int i = threadIdx.x; i < ((k_end + 63) & ~63); i += 256) lds_maskrow[i] = (i < A.S) ? A.mask[rowbase + i] : 0.f;   // see attn_fwd_kernel
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    unsigned trA[D / 32], trB[D / 32];                       // this lane's transposing-read offsets inside a K image (first / second read)
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db) { trA[db] = lds0 + tr_off_u(db, lr, h, 0); trB[db] = lds0 + tr_off_u(db, lr, h, 8); }
+    for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
+        issue_tile(min(it + 2, last_tile), (it + 2) % 3);
+        const int buf = it % 3;
+        const unsigned char *lds_k = lds_k3(buf), *lds_v = lds_v3(buf);
+        const unsigned kimg = (unsigned)(buf * 2 * kTile);
+        if (k0 <= wave_qmax) {
+            const float *lds_mask = lds_maskrow + k0;
+            const bool need_mask = (k0 + 63 > q0 + wave * 32) || __any(lds_mask[lane] == 0.f);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < D / 16; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain_u(lds_k, kb * 32 + lr, ks, h), qf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain_u(lds_v, kb * 32 + lr, ks, h), dof[ks], dp, 0, 0, 0);
+                }
+                bf16x8 ktf[2][2];                            // K^T fragments of this key half [s2][db]: read (and waited for) under the products above
+                if (kb == 0) tr_frags4_wait<0, 16 * 128>(ktf, trA[0] + kimg, trB[0] + kimg, trA[1] + kimg, trB[1] + kimg);
+                else tr_frags4_wait<32 * 128, 48 * 128>(ktf, trA[0] + kimg, trB[0] + kimg, trA[1] + kimg, trB[1] + kimg);
+                float ds[16];
+                if (need_mask) {
+                    f4v mv[4];
+                    const unsigned ma = (unsigned)(size_t)(__attribute__((address_space(3))) float *)const_cast<float *>(lds_mask) + 16 * h;
+                    if (kb == 0) lds_rows4_wait<0>(mv, ma); else lds_rows4_wait<128>(mv, ma);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const float mkv = mv[r >> 2][r & 3];
+                        const bool vis = (k0 + kl <= qi) & (mkv != 0.f);
+                        const float pr = vis ? fast_exp2(__builtin_fmaf(s[r], sc, -lse)) : 0.f;
+                        ds[r] = pr * (dp[r] - delta) * A.scale;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(__builtin_fmaf(s[r], sc, -lse)) * (dp[r] - delta) * A.scale;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 dsf = frag_from_acc(&ds[8 * s2]);
+#pragma unroll
+                    for (int db = 0; db < D / 32; ++db)
+                        accQ[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[s2][db], dsf, accQ[db], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // this wave's pieces of tile it + 1 have landed (tile it + 2's four may still fly)
+        __builtin_amdgcn_s_barrier();                        // ... and everybody else's; all reads of tile it are done
     }
     store_accT<D / 32>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, 1.f);
 }
@@ -729,6 +891,140 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs &A, const int b
     }
     if constexpr (DO_K) store_accT<NB>(accK, A.dk + (long long)g * D + db0 * 32, A.lddk, rowbase + ki, kvalid, h, 1.f);
     if constexpr (DO_V) store_accT<NB>(accV, A.dv + (long long)g * D + db0 * 32, A.lddv, rowbase + ki, kvalid, h, 1.f);
+}
+
+// dK and dV with LDS-DMA staging (head_dim 64): the Q and dO tiles of a step (one query head, 64 queries) and the tile's row statistics (log-sum-exp,
+// delta: 256 bytes each, 4 bytes a lane) go global -> LDS through a ring of three buffers, two steps ahead; every wave issues the same five
+// instructions per step (two Q pieces, two dO pieces, one statistics row: waves 0 / 1 bring lse / delta, 2 / 3 a copy nobody reads), so one counted
+// wait serves all.  Each tile is read both ways from its one image.  A tile that ends past the sequence re-reads the last row (DMA cannot zero):
+// those queries are switched off in the visibility test.  Same arithmetic in the same order as attn_bwd_dkv_kernel<64, 1, 0>: the same bits.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(AttnArgs A)
+{
+    constexpr int D = 64, kTile = 128 * D, kStep = 2 * kTile + 1024;      // Q image, dO image, four statistics rows
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 x kStep
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
+    int blk, head_in, group;
+    map_block((int)blockIdx.x, (A.S + 127) / 128, 1, A.B * A.Hkv, false, blk, head_in, group);   // key block 0 sees every query: first
+    const int b = group / A.Hkv, g = group % A.Hkv;
+    const int G = A.Hq / A.Hkv;
+    const int kk0 = blk * 128;
+    const int ki = kk0 + wave * 32 + lr;
+    const bool kvalid = ki < A.S;
+    const long long rowbase = (long long)b * A.S;
+    bf16x8 kf[D / 16], vf[D / 16];
+    load_row_frags<D>(kf, A.k + (long long)g * D, A.ldk, rowbase + ki, kvalid, h);
+    load_row_frags<D>(vf, A.v + (long long)g * D, A.ldv, rowbase + ki, kvalid, h);
+    const bool kvis = kvalid && A.mask[rowbase + (kvalid ? ki : 0)] != 0.f;
+    f32x16 accK[D / 32], accV[D / 32];
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accK[db][r] = 0.f; accV[db][r] = 0.f; }
+    const float sc = A.scale * kLog2e;
+    const int wave_kmin = kk0 + wave * 32;
+    const int t_begin = (kk0 / 64) * 64;                   // first query tile that can see this key block
+    const int tiles_per_head = (A.S - t_begin + 63) / 64;
+    const int n_steps = G * tiles_per_head;
+    const int tail_rows = A.S - (t_begin + (tiles_per_head - 1) * 64);    // rows of a head's last tile that exist (1..64)
+    unsigned offQ[2], offO[2], offQt[2], offOt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + (lane >> 3), c = (lane & 7) ^ swz_u(r);
+        const int rt = min(r, tail_rows - 1);
+        offQ[i] = (unsigned)(((long long)r * A.ldq + c * 8) * 2);  offQt[i] = (unsigned)(((long long)rt * A.ldq + c * 8) * 2);
+        offO[i] = (unsigned)(((long long)r * A.ldo + c * 8) * 2);  offOt[i] = (unsigned)(((long long)rt * A.ldo + c * 8) * 2);
+    }
+    const unsigned offS = (unsigned)lane * 4u, offSt = (unsigned)min(lane, tail_rows - 1) * 4u;
+    const float *stat_src = (wave & 1) ? A.delta : A.lse;
+    auto issue_step = [&](int step, int buf) {               // UNCONDITIONAL (the caller clamps step): the waits below stay counted
+        const int hq = g * G + step / tiles_per_head;
+        const int ti = step % tiles_per_head;
+        const int t0 = t_begin + ti * 64;
+        const bool tail = ti == tiles_per_head - 1 && tail_rows < 64;
+        const unsigned char *qb = reinterpret_cast<const unsigned char *>(A.q + (long long)hq * D + (rowbase + t0) * A.ldq);
+        const unsigned char *ob = reinterpret_cast<const unsigned char *>(A.d_o + (long long)hq * D + (rowbase + t0) * A.ldo);
+        const unsigned char *sb = reinterpret_cast<const unsigned char *>(stat_src + ((long long)b * A.Hq + hq) * A.S + t0);
+        unsigned char *dst = smem + buf * kStep;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + (tail ? offQt[i] : offQ[i])),
+                                             (__attribute__((address_space(3))) void *)(dst + (wave * 2 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ob + (tail ? offOt[i] : offO[i])),
+                                             (__attribute__((address_space(3))) void *)(dst + kTile + (wave * 2 + i) * 1024), 16, 0, 0);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sb + (tail ? offSt : offS)),
+                                         (__attribute__((address_space(3))) void *)(dst + 2 * kTile + wave * 256), 4, 0, 0);
+    };
+    issue_step(0, 0);
+    issue_step(min(1, n_steps - 1), 1);
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    unsigned trA[D / 32], trB[D / 32];
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db) { trA[db] = lds0 + tr_off_u(db, lr, h, 0); trB[db] = lds0 + tr_off_u(db, lr, h, 8); }
+    const unsigned statA = lds0 + 2 * kTile + 16 * h;        // + 32 g4 + 128 qb: the lane's four runs of four queries
+    for (int step = 0; step < n_steps; ++step) {
+        issue_step(min(step + 2, n_steps - 1), (step + 2) % 3);
+        const int buf = step % 3;
+        const unsigned char *lds_q = smem + buf * kStep, *lds_do = lds_q + kTile;
+        const unsigned img = (unsigned)(buf * kStep);
+        const int t0 = t_begin + (step % tiles_per_head) * 64;
+        if (t0 + 63 >= wave_kmin) {                            // else: every query of the tile precedes every key of this wave
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < D / 16; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain_u(lds_q, qb * 32 + lr, ks, h), kf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain_u(lds_do, qb * 32 + lr, ks, h), vf[ks], dp, 0, 0, 0);
+                }
+                // statistics and the transposed fragments of this query half: read (and waited for) under the products above
+                f4v lse4[4], dl4[4];
+                bf16x8 qtf[2][2], dotf[2][2];                // [s2][db]
+                if (qb == 0) {
+                    lds_rows4_wait<0>(lse4, statA + img);
+                    lds_rows4_wait<256>(dl4, statA + img);
+                    tr_frags4_wait<kTile, kTile + 16 * 128>(dotf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
+                    tr_frags4_wait<0, 16 * 128>(qtf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
+                } else {
+                    lds_rows4_wait<128>(lse4, statA + img);
+                    lds_rows4_wait<256 + 128>(dl4, statA + img);
+                    tr_frags4_wait<kTile + 32 * 128, kTile + 48 * 128>(dotf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
+                    tr_frags4_wait<32 * 128, 48 * 128>(qtf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
+                }
+                float pr[16], ds[16];
+                const bool diag = t0 + qb * 32 < wave_kmin + 32;              // some query of the block may precede some key of the wave
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int r = 4 * g4 + t;
+                        const int ql = qb * 32 + t + 8 * g4 + 4 * h;             // query inside the tile
+                        const bool vis = kvis & (!diag | (ki <= t0 + ql)) & (t0 + ql < A.S);
+                        const float e = vis ? fast_exp2(__builtin_fmaf(s[r], sc, -lse4[g4][t])) : 0.f;
+                        pr[r] = e;
+                        ds[r] = e * (dp[r] - dl4[g4][t]) * A.scale;
+                    }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 pf = frag_from_acc(&pr[8 * s2]);
+                    const bf16x8 dsf = frag_from_acc(&ds[8 * s2]);
+#pragma unroll
+                    for (int db = 0; db < D / 32; ++db) {
+                        accV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[s2][db], pf, accV[db], 0, 0, 0);
+                        accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s2][db], dsf, accK[db], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // this wave's pieces of step + 1 have landed (step + 2's five may still fly)
+        __builtin_amdgcn_s_barrier();                        // ... and everybody else's; all reads of this step's images are done
+    }
+    store_accT<D / 32>(accK, A.dk + (long long)g * D, A.lddk, rowbase + ki, kvalid, h, 1.f);
+    store_accT<D / 32>(accV, A.dv + (long long)g * D, A.lddv, rowbase + ki, kvalid, h, 1.f);
 }
 
 template <int D, int DS, int WHICH = 0>
@@ -1043,7 +1339,7 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float *par
     o[((long long)b * Hq + hq) * D + tid] = (unsigned short)(pack_bf16(sum, 0.f) & 0xFFFFu);
 }
 
-int g_attn_fwd_dma = 1;       // head_dim 64 forward: LDS-DMA staging (1) or the register-staged kernel (0; tests / A-B)
+int g_attn_dma = 1;       // head_dim 64 forward and backward: LDS-DMA staging (1) or the register-staged kernels (0; tests / A-B)
 
 int check_args(const AttnArgs &A, int D, const char *who)
 {
@@ -1059,8 +1355,8 @@ int check_args(const AttnArgs &A, int D, const char *who)
         ecgb::set_error(std::string(who) + ": row strides must be multiples of 8 elements");
         return ECGB_ERR_UNSUPPORTED;
     }
-    if (4 * 128 * D + 4 * (((long long)A.S + 63) & ~63ll) > 160 * 1024) {      // tile buffers + the row's key mask in LDS
-        ecgb::set_error(std::string(who) + ": sequence too long for the key mask in LDS (head_dim 256: 8 192 keys, 64: 32 768)");
+    if ((D == 64 ? 6 : 4) * 128 * D + 4 * (((long long)A.S + 63) & ~63ll) > 160 * 1024) {      // tile buffers + the row's key mask in LDS
+        ecgb::set_error(std::string(who) + ": sequence too long for the key mask in LDS (head_dim 256: 8 192 keys, 64: 28 672)");
         return ECGB_ERR_UNSUPPORTED;
     }
     return ECGB_OK;
@@ -1092,7 +1388,7 @@ extern "C" int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev
         hipLaunchKernelGGL(attn_fwd_kernel<D_>, grid, dim3(256), lds, (hipStream_t)stream, A); } while (0)
     if (head_dim == 64) {
         const int lds = 6 * 128 * 64 + 4 * ((seq + 63) & ~63);
-        if (g_attn_fwd_dma) {
+        if (g_attn_dma) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess)
                 hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), lds, (hipStream_t)stream, A);
         } else ECGB_FWD(64);
@@ -1156,7 +1452,22 @@ extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, lq) != hipSuccess) break; \
         hipLaunchKernelGGL(attn_bwd_dq_kernel<D_>, gq, dim3(256), lq, (hipStream_t)stream, A); \
         } while (0)
-    if (head_dim == 64) { ECGB_BWD(64); const int lk = 4 * 128 * 64 + 512; ECGB_DKV(64, 1, 0); }
+    if (head_dim == 64) {
+        if (g_attn_dma) {
+            const int lq = 6 * 128 * 64 + 4 * ((seq + 63) & ~63);
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lq) == hipSuccess)
+                hipLaunchKernelGGL(attn_bwd_dq_dma_kernel, gq, dim3(256), lq, (hipStream_t)stream, A);
+        } else {
+            ECGB_BWD(64);
+        }
+        if (g_attn_dma) {
+            const int lk = 3 * (2 * 128 * 64 + 1024);
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lk) == hipSuccess)
+                hipLaunchKernelGGL(attn_bwd_dkv_dma_kernel, dim3(gk), dim3(256), lk, (hipStream_t)stream, A);
+        } else {
+            const int lk = 4 * 128 * 64 + 512; ECGB_DKV(64, 1, 0);
+        }
+    }
     else if (head_dim == 128) { ECGB_BWD(128); const int lk = 4 * 128 * 128 + 512; ECGB_DKV(128, 1, 0); }
     else {
         ECGB_BWD(256);
@@ -1284,9 +1595,9 @@ extern "C" void ecgb_debug_attn_profile(unsigned long long *out8, int reset)
 }
 #endif
 
-// head_dim 64 forward: 1 = K / V tiles by LDS-DMA two tiles ahead (default), 0 = the register-staged kernel (tests, A/B)
+// head_dim 64, forward and backward: 1 = tiles by LDS-DMA two tiles ahead (default), 0 = the register-staged kernels (tests, A/B)
 extern "C" int ecgb_set_attn_fwd_staging(int dma)
 {
-    g_attn_fwd_dma = dma ? 1 : 0;
+    g_attn_dma = dma ? 1 : 0;
     return ECGB_OK;
 }

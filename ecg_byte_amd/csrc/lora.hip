@@ -358,40 +358,45 @@ __global__ __launch_bounds__(256, 2) void lora_da_kernel(LoraArgs L)
         for (int j = 0; j < 4; ++j) acc[sb][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < KT; ++kt) {
-        // inline asm reads: hipcc would drain the tile in flight (vmcnt 0) in front of an LDS read it can see next to LDS-DMA, and it neither
-        // counts asm reads nor keeps their consumers behind a bare wait -- the registers pass through the wait statement
+        // inline asm reads: hipcc would drain the tile in flight (vmcnt 0) in front of an LDS read it can see next to LDS-DMA.  It neither counts asm
+        // reads in lgkmcnt nor knows their results are pending (it may copy a destination register as soon as the statement is over): a group of
+        // reads and its wait are ONE asm statement, the results exist when it ends
         i4 xv[2][4], dv[2][NSUB];
-        auto frag = [&](unsigned a0, unsigned a1, auto off) {
+        auto frags4 = [&](i4 (&f)[4], auto off) {
+            constexpr int OFF = decltype(off)::value;
+            i2 r0, r1, r2, r3, r4, r5, r6, r7;
+            asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%16\n\t"
+                         "ds_read_b64_tr_b16 %1, %9 offset:%17\n\t"
+                         "ds_read_b64_tr_b16 %2, %10 offset:%16\n\t"
+                         "ds_read_b64_tr_b16 %3, %11 offset:%17\n\t"
+                         "ds_read_b64_tr_b16 %4, %12 offset:%16\n\t"
+                         "ds_read_b64_tr_b16 %5, %13 offset:%17\n\t"
+                         "ds_read_b64_tr_b16 %6, %14 offset:%16\n\t"
+                         "ds_read_b64_tr_b16 %7, %15 offset:%17\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                         : "v"(tabX0[0]), "v"(tabX1[0]), "v"(tabX0[1]), "v"(tabX1[1]), "v"(tabX0[2]), "v"(tabX1[2]), "v"(tabX0[3]), "v"(tabX1[3]),
+                           "n"(OFF), "n"(OFF + 4 * 512)
+                         : "memory");
+            f[0] = __builtin_shufflevector(r0, r1, 0, 1, 2, 3); f[1] = __builtin_shufflevector(r2, r3, 0, 1, 2, 3);
+            f[2] = __builtin_shufflevector(r4, r5, 0, 1, 2, 3); f[3] = __builtin_shufflevector(r6, r7, 0, 1, 2, 3);
+        };
+        auto frag1 = [&](unsigned a, auto off) {
             constexpr int OFF = decltype(off)::value;
             i2 lo, hi;
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(OFF));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(OFF));
+            asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\t"
+                         "ds_read_b64_tr_b16 %1, %2 offset:%4\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(lo), "=&v"(hi) : "v"(a), "n"(OFF), "n"(OFF + 4 * 128) : "memory");
             return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
         };
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            xv[0][j] = frag(tabX0[j], tabX1[j] + 4 * 512, std::integral_constant<int, 0>{});
-            xv[1][j] = frag(tabX0[j], tabX1[j] + 4 * 512, std::integral_constant<int, 32 * 512>{});
-        }
+        frags4(xv[0], std::integral_constant<int, 0>{});
+        frags4(xv[1], std::integral_constant<int, 32 * 512>{});
 #pragma unroll
         for (int sb = 0; sb < NSUB; ++sb) {
-            dv[0][sb] = frag(tabD[sb], tabD[sb] + 4 * 128, std::integral_constant<int, 0>{});
-            dv[1][sb] = frag(tabD[sb], tabD[sb] + 4 * 128, std::integral_constant<int, 32 * 128>{});
+            dv[0][sb] = frag1(tabD[sb], std::integral_constant<int, 0>{});
+            dv[1][sb] = frag1(tabD[sb], std::integral_constant<int, 32 * 128>{});
         }
-        if constexpr (NSUB == 1)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xv[0][0]), "+v"(xv[0][1]), "+v"(xv[0][2]), "+v"(xv[0][3]), "+v"(xv[1][0]), "+v"(xv[1][1]),
-                         "+v"(xv[1][2]), "+v"(xv[1][3]), "+v"(dv[0][0]), "+v"(dv[1][0]));
-        else if constexpr (NSUB == 2)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xv[0][0]), "+v"(xv[0][1]), "+v"(xv[0][2]), "+v"(xv[0][3]), "+v"(xv[1][0]), "+v"(xv[1][1]),
-                         "+v"(xv[1][2]), "+v"(xv[1][3]), "+v"(dv[0][0]), "+v"(dv[1][0]), "+v"(dv[0][NSUB > 1 ? 1 : 0]), "+v"(dv[1][NSUB > 1 ? 1 : 0]));
-        else if constexpr (NSUB == 3)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xv[0][0]), "+v"(xv[0][1]), "+v"(xv[0][2]), "+v"(xv[0][3]), "+v"(xv[1][0]), "+v"(xv[1][1]),
-                         "+v"(xv[1][2]), "+v"(xv[1][3]), "+v"(dv[0][0]), "+v"(dv[1][0]), "+v"(dv[0][NSUB > 1 ? 1 : 0]), "+v"(dv[1][NSUB > 1 ? 1 : 0]),
-                         "+v"(dv[0][NSUB > 2 ? 2 : 0]), "+v"(dv[1][NSUB > 2 ? 2 : 0]));
-        else
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xv[0][0]), "+v"(xv[0][1]), "+v"(xv[0][2]), "+v"(xv[0][3]), "+v"(xv[1][0]), "+v"(xv[1][1]),
-                         "+v"(xv[1][2]), "+v"(xv[1][3]), "+v"(dv[0][0]), "+v"(dv[1][0]), "+v"(dv[0][NSUB > 1 ? 1 : 0]), "+v"(dv[1][NSUB > 1 ? 1 : 0]),
-                         "+v"(dv[0][NSUB > 2 ? 2 : 0]), "+v"(dv[1][NSUB > 2 ? 2 : 0]), "+v"(dv[0][NSUB > 3 ? 3 : 0]), "+v"(dv[1][NSUB > 3 ? 3 : 0]));
         __builtin_amdgcn_s_barrier();                                   // every wave holds its fragments: the buffer is free
         if (kt + 2 < KT) stage(kt + 2, lds + (kt & 1) * kBuf);
         const int trow0 = row_lo + kt * 64;

@@ -79,15 +79,15 @@ def test_fused_attention_is_the_same_bits_every_launch(B, S, Hq, Hkv, D):
         assert torch.equal(d, ops.attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale)), rep
 
 
-@pytest.mark.parametrize("B,S,Hq,Hkv,pads", [(32, 1024, 32, 8, True), (32, 1024, 32, 8, False), (3, 1000, 8, 2, True), (5, 70, 4, 4, True)],
-                         ids=["c3-pads", "c3", "ragged", "short"])
-def test_attention_forward_dma_staging_is_bitwise_the_register_staging(B, S, Hq, Hkv, pads):
-    """The head_dim-64 forward has two ways of getting K/V tiles into LDS (LDS-DMA through a three-buffer ring, the default; registers
-    + ds_write, kept as the check): same arithmetic in the same order, so the same bits — on a full chip too, where a read of an LDS
-    tile that has not landed yet would show."""
+@pytest.mark.parametrize("B,S,Hq,Hkv,pads", [(32, 1024, 32, 8, True), (32, 1024, 32, 8, False), (3, 1000, 8, 2, True), (5, 70, 4, 4, True), (2, 2048, 4, 1, True)],
+                         ids=["c3-pads", "c3", "ragged", "short", "long"])
+def test_attention_dma_staging_is_bitwise_the_register_staging(B, S, Hq, Hkv, pads):
+    """The head_dim-64 kernels (forward, dQ, dK/dV) have two ways of getting their tiles into LDS (LDS-DMA through a three-buffer ring, the
+    default; registers + ds_write, kept as the check): same arithmetic in the same order, so the same bits -- on a full chip too, where a
+    read of an LDS tile that has not landed yet would show.  Ragged sequence ends exercise the tiles DMA cannot zero-fill."""
     from ecg_byte_amd import decoder_ops as ops
     D = 64
-    qkv = _bf(B * S, (Hq + 2 * Hkv) * D, seed=62)
+    qkv, do = _bf(B * S, (Hq + 2 * Hkv) * D, seed=62), _bf(B * S, Hq * D, seed=63)
     mask = torch.ones(B, S, device="cuda")
     if pads:
         for b in range(B):
@@ -95,10 +95,13 @@ def test_attention_forward_dma_staging_is_bitwise_the_register_staging(B, S, Hq,
     try:
         ops.set_attn_fwd_staging(0)
         o0, l0 = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, 0.125)
+        d0 = ops.attn_bwd(qkv, mask, o0, do, l0, B, S, Hq, Hkv, D, 0.125)
         ops.set_attn_fwd_staging(1)
         for rep in range(4):
             o1, l1 = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, 0.125)
             assert torch.equal(o0, o1) and torch.equal(l0, l1), rep
+            d1 = ops.attn_bwd(qkv, mask, o0, do, l0, B, S, Hq, Hkv, D, 0.125)
+            assert torch.equal(d0, d1), (rep, (d0.float() - d1.float()).abs().max().item())
     finally:
         ops.set_attn_fwd_staging(1)
 
