@@ -255,3 +255,29 @@ def test_tokenizer_pickle_format_roundtrip(tmp_path):
     sym = np.array([["a", "z"], ["m", "b"]])
     back = tu.reverse_normalize_all(sym, {"percentile_1": -1.0, "percentile_99": 1.0})
     assert np.array_equal(back, O.dequantize(np.array([[0, 25], [12, 1]], dtype=np.uint8), -1.0, 1.0))
+
+
+def test_inline_asm_lds_reads_are_not_used_before_their_wait():
+    """gemm.hip's transposing LDS reads are inline asm whose wait is a later statement (the phase schedule puts the LDS-DMA issue between them):
+    hipcc may use or copy a destination register before that wait -- it did so in an attention kernel, stale data only on a busy chip.
+    scripts/check_asm_lds_reads.py screens the compiled assembly for that; here: the screen itself on two hand-written snippets, then on
+    the real file (hipcc cross-compiles gfx950 without a GPU)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_asm_lds_reads", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "check_asm_lds_reads.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    good = """_Zkernel:
+	;;#ASMSTART
+	ds_read_b64_tr_b16 v[10:11], v3 offset:0
+	;;#ASMEND
+	v_add_u32_e32 v5, v6, v7
+	;;#ASMSTART
+	s_waitcnt lgkmcnt(0)
+	;;#ASMEND
+	v_mfma_f32_16x16x32_bf16 v[20:23], v[8:11], v[12:15], v[20:23]
+"""
+    bad = good.replace("v_add_u32_e32 v5, v6, v7", "v_mov_b64_e32 v[40:41], v[10:11]")
+    assert chk.check(good) == []
+    hits = chk.check(bad)
+    assert len(hits) == 1 and hits[0][3] == [10, 11]
+    assert chk.main() == 0
