@@ -91,69 +91,88 @@ __device__ __forceinline__ unsigned keep_bits(const LoraArgs &L, unsigned idx)
 // v_mfma_f32_16x16x32_bf16 per sub-block).  KW = 4 (in % 256 == 0): the four waves of a workgroup share 16 rows and take a quarter of the
 // contraction each, their partial sums meet in LDS -- 32 768 rows are only 2 048 row groups, 8 waves per CU with two 16-byte loads in
 // flight each: the pass ran at half the HBM rate.
-template <int NSUB, int NF, int KW>
+// RG = 2: a wave takes two row groups (32 rows) against ONE load of the A fragments -- on the fused sites (q|k|v: three sub-blocks) the A
+// fragments were three of every four 16-byte loads of the loop (L2 hits, but they are what the load pipe was busy with: 1.8 TB/s on x).
+template <int NSUB, int NF, int KW, int RG = 1>
 __global__ __launch_bounds__(256) void lora_down_kernel(LoraArgs L)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lm = lane & 15, lq = lane >> 4;
-    const int row = (blockIdx.x * (4 / KW) + wave / KW) * 16 + lm;
-    const int rowc = row < L.T ? row : L.T - 1;                       // clamped: out-of-range rows are never stored
-    const unsigned short *xr = L.x + (size_t)rowc * L.in + 8 * lq;
-    f32x4 acc[NSUB];
+    int row[RG], rowc[RG];
+    const unsigned short *xr[RG];
 #pragma unroll
-    for (int s = 0; s < NSUB; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < RG; ++g) {
+        row[g] = ((blockIdx.x * (4 / KW) + wave / KW) * RG + g) * 16 + lm;
+        rowc[g] = row[g] < L.T ? row[g] : L.T - 1;                    // clamped: out-of-range rows are never stored
+        xr[g] = L.x + (size_t)rowc[g] * L.in + 8 * lq;
+    }
+    f32x4 acc[RG][NSUB];
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) acc[g][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const size_t plane = (size_t)L.T * L.in;
     const int k_lo = (wave % KW) * (L.in / KW), k_hi = k_lo + L.in / KW;
     for (int k0 = k_lo; k0 < k_hi; k0 += 64) {
-        bf16x8 xv[2], av[2][NSUB];
+        bf16x8 xv[RG][2], av[2][NSUB];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            xv[u] = *reinterpret_cast<const bf16x8 *>(xr + k0 + 32 * u);
+#pragma unroll
+            for (int g = 0; g < RG; ++g) xv[g][u] = *reinterpret_cast<const bf16x8 *>(xr[g] + k0 + 32 * u);
 #pragma unroll
             for (int s = 0; s < NSUB; ++s)
                 av[u][s] = *reinterpret_cast<const bf16x8 *>(L.A + (size_t)(16 * s + lm) * L.in + k0 + 32 * u + 8 * lq);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            unsigned keep[8];
-            const unsigned idx0 = (unsigned)rowc * (unsigned)L.in + (unsigned)(k0 + 32 * u + 8 * lq);
+        for (int g = 0; g < RG; ++g)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) keep[e] = keep_bits<NF>(L, idx0 + e);
-            bf16x8 xm[NF];
+            for (int u = 0; u < 2; ++u) {
+                unsigned keep[8];
+                const unsigned idx0 = (unsigned)rowc[g] * (unsigned)L.in + (unsigned)(k0 + 32 * u + 8 * lq);
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
+                for (int e = 0; e < 8; ++e) keep[e] = keep_bits<NF>(L, idx0 + e);
+                bf16x8 xm[NF];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xm[f][e] = ((keep[e] >> f) & 1u) ? xv[u][e] : (short)0;
-                if (L.xd && row < L.T)
-                    *reinterpret_cast<bf16x8 *>(L.xd + f * plane + (size_t)row * L.in + k0 + 32 * u + 8 * lq) = xm[f];
+                for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xm[f][e] = ((keep[e] >> f) & 1u) ? xv[g][u][e] : (short)0;
+                    if (L.xd && row[g] < L.T)
+                        *reinterpret_cast<bf16x8 *>(L.xd + f * plane + (size_t)row[g] * L.in + k0 + 32 * u + 8 * lq) = xm[f];
+                }
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s)
+                    acc[g][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u][s], xm[s * NF / NSUB], acc[g][s], 0, 0, 0);   // D'[c][row]: lane = row, regs = 4 columns
             }
-#pragma unroll
-            for (int s = 0; s < NSUB; ++s)
-                acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u][s], xm[s * NF / NSUB], acc[s], 0, 0, 0);   // D'[c][row]: lane = row, regs = 4 columns
-        }
     }
     if constexpr (KW > 1) {                                           // wave 0 of the row group adds the other waves' partial sums
-        __shared__ f32x4 red[4][NSUB][64];
+        __shared__ f32x4 red[4][RG][NSUB][64];
         if (wave % KW) {
 #pragma unroll
-            for (int s = 0; s < NSUB; ++s) red[wave][s][lane] = acc[s];
+            for (int g = 0; g < RG; ++g)
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s) red[wave][g][s][lane] = acc[g][s];
         }
         __syncthreads();
         if (wave % KW) return;
 #pragma unroll
         for (int w = 1; w < KW; ++w)
 #pragma unroll
-            for (int s = 0; s < NSUB; ++s) acc[s] += red[wave + w][s][lane];
+            for (int g = 0; g < RG; ++g)
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s) acc[g][s] += red[wave + w][g][s][lane];
     }
-    if (row >= L.T) return;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {                                     // t is [T, 64]: the columns past the last sub-block are zero
-        us4 v = (us4){0, 0, 0, 0};
-        if (s < NSUB) {
+    for (int g = 0; g < RG; ++g) {
+        if (row[g] >= L.T) continue;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = f2bf(acc[s < NSUB ? s : 0][r] * L.scale);
+        for (int s = 0; s < 4; ++s) {                                 // t is [T, 64]: the columns past the last sub-block are zero
+            us4 v = (us4){0, 0, 0, 0};
+            if (s < NSUB) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = f2bf(acc[g][s < NSUB ? s : 0][r] * L.scale);
+            }
+            *reinterpret_cast<us4 *>(L.t + (size_t)row[g] * kLoraK + 16 * s + 4 * lq) = v;
         }
-        *reinterpret_cast<us4 *>(L.t + (size_t)row * kLoraK + 16 * s + 4 * lq) = v;
     }
 }
 
@@ -506,7 +525,10 @@ extern "C" int ecgb_lora_down(const void *x_dev, const void *a_dev, void *t_dev,
     LoraArgs L{};
     L.x = (const unsigned short *)x_dev; L.A = (const unsigned short *)a_dev; L.t = (unsigned short *)t_dev; L.xd = (unsigned short *)xd_dev;
     fill(L, T, in, scale, p, seed);
-    if (in % 256 == 0 && T >= 1024) {                                // row groups of 16 with the contraction split over the four waves
+    if (in % 256 == 0 && T >= 8192 && n_sub > 1) {                   // fused sites: two row groups per wave share the A fragments
+        const dim3 grid((unsigned)((T + 31) / 32));
+        ECGB_LORA_DISPATCH(lora_down_kernel, grid, ECGB_COMMA 4 ECGB_COMMA 2);
+    } else if (in % 256 == 0 && T >= 1024) {                         // row groups of 16 with the contraction split over the four waves
         const dim3 grid((unsigned)((T + 15) / 16));
         ECGB_LORA_DISPATCH(lora_down_kernel, grid, ECGB_COMMA 4);
     } else {
