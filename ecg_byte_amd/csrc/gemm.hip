@@ -251,11 +251,47 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel(GemmArgs G)
 }
 
 // Epilogue of the 16x16x32 kernels: acc[i][j] holds D'[n = 4*lq + t][m = lm] of the 16x16 tile (i, j) of this wave.
+// `stage` (the 256x256 kernels, whole interior tiles, plain bf16 store): the wave's 128 x 64 block goes through ITS OWN 16 KB of the operand
+// buffers (all reads of them are over: every wave has passed its last lgkmcnt(0) + barrier) and leaves as sixteen 16-byte stores per lane, each
+// instruction eight whole 128-byte lines -- registers-to-memory it was thirty-two 8-byte stores per lane, each instruction 32-byte pieces of
+// sixteen different lines: the in-kernel timers (scripts/dev_prof_gemm.py) put the epilogue at 18 000 of a K = 2048 tile's 107 000 cycles,
+// store-issue bound.  Row r of the block lies at r * 128 bytes, its 16-byte chunk c at c ^ ((r >> 1) & 7): the 8-byte writes of a 16-row MFMA
+// tile and the row reads both run conflict-free.  Same values, same rounding (round to nearest even) as the direct path.
 template <int TM, int TN, int WTM, int WTN>
 __device__ __forceinline__ void store_tile_m16(const f32x4 (&acc)[TM][TN], const GemmArgs &G, int row0, int col0, int wr, int wc,
-                                               int lm, int lq, long long off_c)
+                                               int lm, int lq, long long off_c, unsigned char *stage = nullptr)
 {
     const float alpha = G.alpha;
+    if constexpr (WTM == 128 && WTN == 64) {
+        if (stage && G.accumulate_f32 == 0 && row0 + 256 <= G.M && col0 + 256 <= G.N && (G.ldc & 7) == 0 && (off_c & 7) == 0) {   // (uniform)
+            using u2 = __attribute__((ext_vector_type(2))) unsigned;
+            using u4 = __attribute__((ext_vector_type(4))) unsigned;
+            using bf2 = __attribute__((ext_vector_type(2))) __bf16;
+            unsigned char *blk = stage + (wr * 4 + wc) * (128 * 128);
+            const int sw = (lm >> 1) & 7;                               // (row >> 1) & 7 of every row this lane writes (rows i * 16 + lm)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bf2 lo, hi;
+                    lo[0] = (__bf16)(acc[i][j][0] * alpha); lo[1] = (__bf16)(acc[i][j][1] * alpha);
+                    hi[0] = (__bf16)(acc[i][j][2] * alpha); hi[1] = (__bf16)(acc[i][j][3] * alpha);
+                    u2 v;
+                    v[0] = __builtin_bit_cast(unsigned, lo); v[1] = __builtin_bit_cast(unsigned, hi);
+                    const int slot = j * 4 + lq;                        // 8-byte slot of the row
+                    *reinterpret_cast<u2 *>(blk + (i * 16 + lm) * 128 + ((((slot >> 1) ^ sw)) << 4) + (slot & 1) * 8) = v;
+                }
+            const int lane = lq * 16 + lm, rr = lane >> 3, c16 = lane & 7;
+            unsigned short *dst = reinterpret_cast<unsigned short *>(G.C) + off_c + (long long)(row0 + wr * WTM + rr) * G.ldc + col0 + wc * WTN + c16 * 8;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int r = it * 8 + rr;
+                const u4 v = *reinterpret_cast<const u4 *>(blk + r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4));
+                *reinterpret_cast<u4 *>(dst + (long long)it * 8 * G.ldc) = v;
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = row0 + wr * WTM + i * 16 + lm;
@@ -415,11 +451,62 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16(GemmArgs G)
 // GLU epilogue of the 16x16x32 kernels (EPI 1 = SiLU, 2 = tanh-GELU): tile (i, 2p) is gate, (i, 2p + 1) up of the same 16 columns.
 // The arithmetic is glu_fwd_kernel's on the bf16-rounded projections (glu_math.hpp), so fused and unfused agree bit for bit.
 template <int EPI, int TM, int TN, int WTM, int WTN>
-__device__ __forceinline__ void store_tile_glu(const f32x4 (&acc)[TM][TN], const GemmArgs &G, int row0, int col0, int wr, int wc, int lm, int lq)
+__device__ __forceinline__ void store_tile_glu(const f32x4 (&acc)[TM][TN], const GemmArgs &G, int row0, int col0, int wr, int wc, int lm, int lq,
+                                               unsigned char *stage = nullptr)
 {
     using us4 = __attribute__((ext_vector_type(4))) unsigned short;
     const float alpha = G.alpha;
     unsigned short *C = reinterpret_cast<unsigned short *>(G.C);
+    if constexpr (WTM == 128 && WTN == 64) {
+        // whole interior tiles: gate, up and act(gate) * up of the wave's 128 rows x 32 columns leave through its own 16 KB of the operand buffers
+        // (see store_tile_m16), 64 rows at a time: three arrays of 64 rows x 64 bytes, 16-byte chunk c of row r at c ^ ((r >> 2) & 3); twelve 16-byte
+        // stores per lane and half instead of forty-eight 8-byte ones.  Same values, same rounding points as the direct path below.
+        if (stage && row0 + 256 <= G.M && col0 + 256 <= G.N && (G.ldc & 7) == 0 && (G.ldh & 7) == 0 && (G.glu_I & 7) == 0) {   // (uniform)
+            using u2 = __attribute__((ext_vector_type(2))) unsigned;
+            using u4 = __attribute__((ext_vector_type(4))) unsigned;
+            using bf2 = __attribute__((ext_vector_type(2))) __bf16;
+            auto pack = [](float a, float b) { bf2 v; v[0] = (__bf16)a; v[1] = (__bf16)b; return __builtin_bit_cast(unsigned, v); };
+            auto lo_f = [](unsigned w) { return __uint_as_float(w << 16); };
+            auto hi_f = [](unsigned w) { return __uint_as_float(w & 0xFFFF0000u); };
+            unsigned char *blk = stage + (wr * 4 + wc) * (128 * 128);
+            const int sw = (lm >> 2) & 3;
+            const int lane = lq * 16 + lm, rr = lane >> 2, c16 = lane & 3;
+            const long long hcol = (col0 >> 1) + wc * (WTN / 2) + c16 * 8;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                    for (int p = 0; p < TN / 2; ++p) {
+                        const int i = half * 4 + i4;
+                        u2 g, u, h;
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            g[w] = pack(acc[i][2 * p][2 * w] * alpha, acc[i][2 * p][2 * w + 1] * alpha);
+                            u[w] = pack(acc[i][2 * p + 1][2 * w] * alpha, acc[i][2 * p + 1][2 * w + 1] * alpha);
+                            const unsigned a = pack(ecgb::glu_act<EPI == 2>(lo_f(g[w])), ecgb::glu_act<EPI == 2>(hi_f(g[w])));
+                            h[w] = pack(lo_f(a) * lo_f(u[w]), hi_f(a) * hi_f(u[w]));
+                        }
+                        const int slot = p * 4 + lq;
+                        unsigned char *dst = blk + (i4 * 16 + lm) * 64 + (((slot >> 1) ^ sw) << 4) + (slot & 1) * 8;
+                        if (C) { *reinterpret_cast<u2 *>(dst) = g; *reinterpret_cast<u2 *>(dst + 4096) = u; }
+                        *reinterpret_cast<u2 *>(dst + 8192) = h;
+                    }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = it * 16 + rr;
+                    const unsigned char *src = blk + r * 64 + ((c16 ^ ((r >> 2) & 3)) << 4);
+                    const long long grow = row0 + wr * WTM + half * 64 + r;
+                    if (C) {
+                        *reinterpret_cast<u4 *>(C + grow * G.ldc + hcol) = *reinterpret_cast<const u4 *>(src);
+                        *reinterpret_cast<u4 *>(C + grow * G.ldc + G.glu_I + hcol) = *reinterpret_cast<const u4 *>(src + 4096);
+                    }
+                    *reinterpret_cast<u4 *>(G.H + grow * G.ldh + hcol) = *reinterpret_cast<const u4 *>(src + 8192);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = row0 + wr * WTM + i * 16 + lm;
@@ -444,10 +531,16 @@ __device__ __forceinline__ void store_tile_glu(const f32x4 (&acc)[TM][TN], const
     }
 }
 
+#ifdef ECGB_PROFILE
+__device__ unsigned long long g_gemm_prof[8];    // [prologue, K loop, epilogue, tiles] cycles summed over the workgroups of gemm_nt_kernel_m16p (wave 0)
+#endif
 template <int BM, int BN, int WGM, int WGN, bool CAT = false, int EPI = 0>
 __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
 {
     static_assert(BM == 256 && BN == 256 && WGM == 2 && WGN == 4, "phase schedule written for the 256x256 tile, 2x4 waves");
+#ifdef ECGB_PROFILE
+    const long long tp0 = clock64();
+#endif
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;                 // 8 x 4 MFMA tiles per wave
     constexpr int kABytes = BM * BK * 2, kBBytes = BN * BK * 2, kBufBytes = kABytes + kBBytes;
@@ -539,6 +632,9 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();          // the stagger: row 1 runs one barrier behind row 0
 
+#ifdef ECGB_PROFILE
+    const long long tp1 = clock64();
+#endif
     bf16x8 a[2][4], b[2][4];                             // [k-step][tile]: one A half (4 row tiles), both B halves (4 column tiles)
     for (int kt = 0; kt < KT; ++kt) {
         const unsigned char *At = lds + (kt & 1) * kBufBytes, *Bt = At + kABytes;
@@ -597,8 +693,19 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
         mfma_quadrant(1, 0);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();          // barrier counts of the two rows match again
-    if constexpr (EPI != 0) store_tile_glu<EPI, TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq);
-    else store_tile_m16<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, off_c);
+#ifdef ECGB_PROFILE
+    const long long tp2 = clock64();
+#endif
+    if constexpr (EPI != 0) store_tile_glu<EPI, TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, lds);
+    else store_tile_m16<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, off_c, lds);
+#ifdef ECGB_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long tp3 = clock64();
+    if (tid == 0) {
+        atomicAdd(&g_gemm_prof[0], (unsigned long long)(tp1 - tp0)); atomicAdd(&g_gemm_prof[1], (unsigned long long)(tp2 - tp1));
+        atomicAdd(&g_gemm_prof[2], (unsigned long long)(tp3 - tp2)); atomicAdd(&g_gemm_prof[3], 1ull);
+    }
+#endif
 }
 
 // Epilogue of the TN kernels: bf16 store, or fp32 atomics when the contraction is split over workgroups.
@@ -1055,7 +1162,7 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nn_kernel_m16p(GemmArgs G)
         for (int j = 0; j < 4; ++j) { tabB0[j] ^= (unsigned)kBufBytes; tabB1[j] ^= (unsigned)kBufBytes; }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
-    store_tile_m16<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, 0);
+    store_tile_m16<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, 0, lds);
 }
 
 // C[M, N] = alpha * A[M, K] . B[N, K]^T for M <= 8 (the decode step of generate(): one new token per sequence).  No MFMA
@@ -1454,3 +1561,11 @@ extern "C" int ecgb_gemm_nn_bf16(const void *a_dev, long long lda, const void *b
     if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nn_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
     return ECGB_OK;
 }
+
+#ifdef ECGB_PROFILE
+extern "C" void ecgb_debug_gemm_profile(unsigned long long *out8, int reset)
+{
+    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gemm_prof), 8 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof z); }
+}
+#endif
