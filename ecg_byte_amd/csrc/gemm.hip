@@ -60,6 +60,10 @@ struct GemmArgs {
     unsigned short *H = nullptr;
     long long ldh = 0;
     int glu_I = 0;
+    // GLU backward in the NN kernel's epilogue (GB != 0): C is d(gate|up) [M, 2 glu_I], the product itself (d of act(gate) * up, [M, glu_I]) is never
+    // written; GU = gate|up of the forward, row stride ldgu
+    const unsigned short *GU = nullptr;
+    long long ldgu = 0;
 };
 
 __device__ __forceinline__ unsigned short f2bf_rn(float f)
@@ -257,13 +261,17 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel(GemmArgs G)
 // sixteen different lines: the in-kernel timers (scripts/dev_prof_gemm.py) put the epilogue at 18 000 of a K = 2048 tile's 107 000 cycles,
 // store-issue bound.  Row r of the block lies at r * 128 bytes, its 16-byte chunk c at c ^ ((r >> 1) & 7): the 8-byte writes of a 16-row MFMA
 // tile and the row reads both run conflict-free.  Same values, same rounding (round to nearest even) as the direct path.
-template <int TM, int TN, int WTM, int WTN>
+// GB != 0 (1 = SiLU, 2 = tanh-GELU; the down projection's input gradient in a full fine-tune): the block is d(act(gate) * up); instead of storing it
+// the read phase fetches gate and up of the same elements and stores d gate = d * up * act'(gate), d up = d * act(gate) -- ecgb_glu_bwd's arithmetic on
+// the bf16-rounded product (the same bits as the two kernels), one write and one read of [M, glu_I] less and no second launch.  Whole tiles only (the
+// entry point checks).
+template <int TM, int TN, int WTM, int WTN, int GB = 0>
 __device__ __forceinline__ void store_tile_m16(const f32x4 (&acc)[TM][TN], const GemmArgs &G, int row0, int col0, int wr, int wc,
                                                int lm, int lq, long long off_c, unsigned char *stage = nullptr)
 {
     const float alpha = G.alpha;
     if constexpr (WTM == 128 && WTN == 64) {
-        if (stage && G.accumulate_f32 == 0 && row0 + 256 <= G.M && col0 + 256 <= G.N && (G.ldc & 7) == 0 && (off_c & 7) == 0) {   // (uniform)
+        if (GB != 0 || (stage && G.accumulate_f32 == 0 && row0 + 256 <= G.M && col0 + 256 <= G.N && (G.ldc & 7) == 0 && (off_c & 7) == 0)) {   // (uniform)
             using u2 = __attribute__((ext_vector_type(2))) unsigned;
             using u4 = __attribute__((ext_vector_type(4))) unsigned;
             using bf2 = __attribute__((ext_vector_type(2))) __bf16;
@@ -283,6 +291,38 @@ __device__ __forceinline__ void store_tile_m16(const f32x4 (&acc)[TM][TN], const
                 }
             const int lane = lq * 16 + lm, rr = lane >> 3, c16 = lane & 7;
             unsigned short *dst = reinterpret_cast<unsigned short *>(G.C) + off_c + (long long)(row0 + wr * WTM + rr) * G.ldc + col0 + wc * WTN + c16 * 8;
+            if constexpr (GB != 0) {
+                const unsigned short *gsrc = G.GU + (long long)(row0 + wr * WTM + rr) * G.ldgu + col0 + wc * WTN + c16 * 8;
+                auto pack = [](float a, float b) { bf2 v; v[0] = (__bf16)a; v[1] = (__bf16)b; return __builtin_bit_cast(unsigned, v); };
+#pragma unroll
+                for (int grp = 0; grp < 2; ++grp) {                     // eight rows' gate / up loads in flight at a time (the accumulators are dead by now)
+                    u4 g[8], u[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const long long ro = (long long)(grp * 8 + k) * 8 * G.ldgu;
+                        g[k] = *reinterpret_cast<const u4 *>(gsrc + ro);
+                        u[k] = *reinterpret_cast<const u4 *>(gsrc + ro + G.glu_I);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = (grp * 8 + k) * 8 + rr;
+                        const u4 d = *reinterpret_cast<const u4 *>(blk + r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4));
+                        u4 og, ou;
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) {
+                            const float g0 = __uint_as_float(g[k][w] << 16), g1 = __uint_as_float(g[k][w] & 0xFFFF0000u);
+                            const float u0 = __uint_as_float(u[k][w] << 16), u1 = __uint_as_float(u[k][w] & 0xFFFF0000u);
+                            const float d0 = __uint_as_float(d[w] << 16), d1 = __uint_as_float(d[w] & 0xFFFF0000u);
+                            og[w] = pack(d0 * u0 * ecgb::glu_act_grad<GB == 2>(g0), d1 * u1 * ecgb::glu_act_grad<GB == 2>(g1));
+                            ou[w] = pack(d0 * ecgb::glu_act<GB == 2>(g0), d1 * ecgb::glu_act<GB == 2>(g1));
+                        }
+                        unsigned short *o = dst + (long long)(grp * 8 + k) * 8 * G.ldc;
+                        *reinterpret_cast<u4 *>(o) = og;
+                        *reinterpret_cast<u4 *>(o + G.glu_I) = ou;
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 const int r = it * 8 + rr;
@@ -1020,7 +1060,7 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
 // [256 rows][128 B], ds_read_b128 fragments), the B side is gemm_tn_kernel_tr's ([64 contraction rows] x [256 columns] as it lies in memory,
 // fragments by ds_read_b64_tr_b16 from the per-lane address tables), on the same four-phase staggered schedule.  Lane for lane the MFMAs see
 // the operands of the NT kernel run on a transposed copy of B, so the results are the same bits (tests).
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int GB = 0>
 __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nn_kernel_m16p(GemmArgs G)
 {
     static_assert(BM == 256 && BN == 256 && WGM == 2 && WGN == 4, "phase schedule written for the 256x256 tile, 2x4 waves");
@@ -1162,7 +1202,7 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nn_kernel_m16p(GemmArgs G)
         for (int j = 0; j < 4; ++j) { tabB0[j] ^= (unsigned)kBufBytes; tabB1[j] ^= (unsigned)kBufBytes; }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
-    store_tile_m16<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, 0, lds);
+    store_tile_m16<TM, TN, WTM, WTN, GB>(acc, G, row0, col0, wr, wc, lm, lq, 0, lds);
 }
 
 // C[M, N] = alpha * A[M, K] . B[N, K]^T for M <= 8 (the decode step of generate(): one new token per sequence).  No MFMA
@@ -1559,6 +1599,37 @@ extern "C" int ecgb_gemm_nn_bf16(const void *a_dev, long long lda, const void *b
         e = hipGetLastError();
     }
     if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nn_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
+}
+
+// d(gate|up) [M, 2 inter] = ecgb_glu_bwd(gate|up, dY . W) with W = the down projection as stored ([hidden, inter] row-major): ecgb_gemm_nn_bf16 with the
+// GLU backward in its epilogue (the product [M, inter] is never written).  Whole 256x256 tiles only: M % 256 == 0, inter % 256 == 0.
+extern "C" int ecgb_gemm_nn_glu_bwd_bf16(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *gate_up_dev, long long ldgu,
+                                         void *d_gate_up_dev, long long ldd, int M, int inter, int K, int gelu_tanh, void *stream)
+{
+    if (!dy_dev || !w_dev || !gate_up_dev || !d_gate_up_dev || M <= 0 || inter <= 0 || K <= 0) { ecgb::set_error("ecgb_gemm_nn_glu_bwd_bf16: bad argument"); return ECGB_ERR_INVALID; }
+    if (K % BK || M % 256 || inter % 256 || lddy % 8 || ldw % 8 || ldgu % 8 || ldd % 8 || ((uintptr_t)dy_dev & 15) || ((uintptr_t)w_dev & 15) ||
+        ((uintptr_t)gate_up_dev & 15) || ((uintptr_t)d_gate_up_dev & 15) || (64 * ldw + inter) * 2 >= (1ll << 32) || (256 * lddy + K) * 2 >= (1ll << 32)) {
+        ecgb::set_error("ecgb_gemm_nn_glu_bwd_bf16: K % 64, M % 256, inter % 256, 16-byte aligned operands with strides % 8 required");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    GemmArgs G;
+    G.A = (const unsigned short *)dy_dev; G.B = (const unsigned short *)w_dev; G.C = d_gate_up_dev;
+    G.M = M; G.N = inter; G.K = K; G.lda = lddy; G.ldb = ldw; G.ldc = ldd;
+    G.batch_a = G.batch_b = G.batch_c = 0;
+    G.accumulate_f32 = 0; G.alpha = 1.0f;
+    G.A2 = G.B2 = nullptr; G.lda2 = G.ldb2 = 0; G.K2 = 0;
+    G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
+    G.tiles_m = M / 256; G.tiles_n = inter / 256;
+    G.glu_I = inter; G.GU = (const unsigned short *)gate_up_dev; G.ldgu = ldgu;
+    constexpr int lds = 2 * (256 + 256) * BK * 2;
+    auto kern = gelu_tanh ? gemm_nn_kernel_m16p<256, 256, 2, 4, 2> : gemm_nn_kernel_m16p<256, 256, 2, 4, 1>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, 1), dim3(512), lds, (hipStream_t)stream, G);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nn_kernel (GLU backward): ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
     return ECGB_OK;
 }
 

@@ -1007,12 +1007,16 @@ class HipCausalLM(nn.Module):
             x1, rstd1, h1, qkv, P, ao, x2, rstd2, h2, gu, hm, ls = saved.pop()
             # MLP
             wgrad(g, hm, self.wdown[i])
-            d_hm = self._dx(g, ("wdown", i), self.wdown[i])        # [T, I]
-            if frozen:
-                d_gu = self.lora[i]["down"].backward(g, ls[3], self, d_hm, glu=(gu, self.gemma))   # adapters + GLU backward in one pass
+            if not frozen and ops.nn_glu_bwd_eligible(g.shape[0], I, H):
+                d_gu = ops.gemm_nn_glu_bwd(g, self.wdown[i].data, gu, gelu_tanh=self.gemma)       # dX of the down projection + GLU backward, one launch
             else:
-                d_gu = ops.glu_bwd(gu, d_hm, gelu_tanh=self.gemma)
-            del d_hm, hm
+                d_hm = self._dx(g, ("wdown", i), self.wdown[i])    # [T, I]
+                if frozen:
+                    d_gu = self.lora[i]["down"].backward(g, ls[3], self, d_hm, glu=(gu, self.gemma))   # adapters + GLU backward in one pass
+                else:
+                    d_gu = ops.glu_bwd(gu, d_hm, gelu_tanh=self.gemma)
+                del d_hm
+            del hm
             wgrad(d_gu, h2, self.wgu[i])
             d_h2 = self._dx(d_gu, ("wgu", i), self.wgu[i])         # [T, H]
             if frozen:

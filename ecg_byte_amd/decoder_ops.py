@@ -235,6 +235,24 @@ def gemm_nn(a, b, out=None, alpha=1.0, accumulate_f32=False, accumulate=False):
     return out
 
 
+def nn_glu_bwd_eligible(M, inter, K):
+    """Shapes the NN kernel with the GLU backward in its epilogue takes: whole 256x256 tiles (the epilogue pairs every element of the product with
+    its gate / up), enough of them to fill the chip."""
+    return M % 256 == 0 and inter % 256 == 0 and K % 64 == 0 and (M // 256) * (inter // 256) >= 192
+
+
+def gemm_nn_glu_bwd(dy, w, gate_up, gelu_tanh=False):
+    """d(gate|up) [M, 2I] = glu_bwd(gate|up, dy @ w) with w = [K, I] (the down projection as stored): the input gradient of the down projection and the
+    GLU backward in one launch (ecgb_gemm_nn_glu_bwd_bf16; the same bits as gemm_nn followed by glu_bwd, d(act(gate) * up) is never written)."""
+    M, K = dy.shape
+    inter = w.shape[1]
+    assert w.shape[0] == K and gate_up.shape == (M, 2 * inter) and dy.stride(1) == 1 and w.stride(1) == 1 and gate_up.stride(1) == 1
+    d = torch.empty_like(gate_up)
+    _lib.check(_L().ecgb_gemm_nn_glu_bwd_bf16(_p(_bf(dy)), dy.stride(0), _p(_bf(w)), w.stride(0), _p(_bf(gate_up)), gate_up.stride(0), _p(d), d.stride(0),
+                                              M, inter, K, int(gelu_tanh), _st()))
+    return d
+
+
 def glu_fusable(M, inter):
     """Shapes the GLU-epilogue GEMM takes: the 256x256 tile needs whole tiles of 128 gate + 128 up columns and enough of them to fill
     the chip (a decode step's few rows go through the few-row kernel and the separate GLU)."""

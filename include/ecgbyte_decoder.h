@@ -140,6 +140,11 @@ int ecgb_colsum(const void *dy_dev, float *out_dev, size_t rows, int n, float *s
  * same bits).  accumulate_f32 as in ecgb_gemm_nt_bf16.  K % 64 == 0, N % 8 == 0. */
 int ecgb_gemm_nn_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N,
                       int K, float alpha, int accumulate_f32, void *stream);
+/* ecgb_gemm_nn_bf16 with the GLU backward in its epilogue (full fine-tune, the MLP's down projection): d_gate_up [M, 2 * inter] =
+ * ecgb_glu_bwd(gate_up, dY . W), W = [K, inter] row-major as nn.Linear stores the down projection; the product [M, inter] is never written.
+ * The same bits as the two calls.  Whole 256x256 tiles only: M % 256 == 0 and inter % 256 == 0, else ECGB_ERR_UNSUPPORTED (callers take the two calls). */
+int ecgb_gemm_nn_glu_bwd_bf16(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *gate_up_dev, long long ldgu,
+                              void *d_gate_up_dev, long long ldd, int M, int inter, int K, int gelu_tanh, void *stream);
 /* The MLP's gate|up projection with the GLU in the GEMM's epilogue (modeling_llama.py:227-258
  * `down_proj(act_fn(gate_proj(x)) * up_proj(x))`; gelu_tanh != 0: Gemma's GeGLU):  gate|up [M, 2*inter] = alpha * (A . B^T
  * [+ A2 . B2^T]) with B = [2*inter, K] (gate rows, then up rows), H [M, inter] = act(gate) * up on the bf16-rounded gate and up

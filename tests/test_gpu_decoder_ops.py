@@ -404,6 +404,23 @@ def test_gemm_nn_is_bitwise_the_nt_kernel_on_a_transposed_copy(ops, M, N, K):
     assert torch.equal(f1, f2)
 
 
+@pytest.mark.parametrize("gelu_tanh", [False, True])
+@pytest.mark.parametrize("M,I,K", [(4096, 8192, 2048), (16384, 3072, 512), (8192, 2048, 192)])
+def test_gemm_nn_with_glu_backward_is_bitwise_the_two_kernels(ops, M, I, K, gelu_tanh):
+    """The down projection's input gradient with the GLU backward in the GEMM's epilogue (full fine-tune): d(gate|up) must be the bits of
+    gemm_nn followed by glu_bwd, on every launch; shapes outside whole 256x256 tiles are refused (the model takes the two kernels there)."""
+    assert ops.nn_glu_bwd_eligible(32768, 8192, 2048) and not ops.nn_glu_bwd_eligible(1000, 8192, 2048) and not ops.nn_glu_bwd_eligible(4096, 8320, 2048)
+    dy, w = _bf(M, K, seed=101), _bf(K, I, scale=K ** -0.5, seed=102)
+    gu = _bf(M, 2 * I, seed=103)
+    want = ops.glu_bwd(gu, ops.gemm_nn(dy, w), gelu_tanh=gelu_tanh)
+    noise = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
+    for rep in range(4):
+        noise.random_()
+        assert torch.equal(ops.gemm_nn_glu_bwd(dy, w, gu, gelu_tanh=gelu_tanh), want), rep
+    with pytest.raises(Exception):
+        ops.gemm_nn_glu_bwd(dy[:1000], w, gu[:1000], gelu_tanh=gelu_tanh)
+
+
 def test_embedding_scatter_sorted_is_exact_and_repeatable(ops):
     """Rows scattered into a bf16 table in sorted order (no atomics): against an fp64 index_add on top of the table's previous contents,
     heavy repeats of a few ids, a skipped padding id, and the same bits on every call."""
