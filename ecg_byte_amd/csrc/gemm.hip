@@ -572,7 +572,7 @@ __device__ __forceinline__ void store_tile_glu(const f32x4 (&acc)[TM][TN], const
 }
 
 #ifdef ECGB_PROFILE
-__device__ unsigned long long g_gemm_prof[8];    // [prologue, K loop, epilogue, tiles] cycles summed over the workgroups of gemm_nt_kernel_m16p (wave 0)
+__device__ unsigned long long g_gemm_prof[8];    // [prologue, K loop, epilogue, tiles] cycles summed over the workgroups (wave 0) of gemm_nt_kernel_m16p; [4..7]: gemm_nn_kernel_m16p
 #endif
 template <int BM, int BN, int WGM, int WGN, bool CAT = false, int EPI = 0>
 __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
@@ -1064,6 +1064,9 @@ template <int BM, int BN, int WGM, int WGN, int GB = 0>
 __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nn_kernel_m16p(GemmArgs G)
 {
     static_assert(BM == 256 && BN == 256 && WGM == 2 && WGN == 4, "phase schedule written for the 256x256 tile, 2x4 waves");
+#ifdef ECGB_PROFILE
+    const long long tp0 = clock64();
+#endif
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int kABytes = BM * BK * 2, kBBytes = BN * BK * 2, kBufBytes = kABytes + kBBytes;
@@ -1140,6 +1143,9 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nn_kernel_m16p(GemmArgs G)
             tabB1[j] = lane_base + (wc >> 1) * 256 + (((2 * (m ^ 4 ^ sw)) + cb) << 4);
         }
     }
+#ifdef ECGB_PROFILE
+    const long long tp1 = clock64();
+#endif
     bf16x8 a[2][4], b[2][4];
     for (int kt = 0; kt < KT; ++kt) {
         const unsigned char *At = lds + (kt & 1) * kBufBytes;
@@ -1202,7 +1208,18 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nn_kernel_m16p(GemmArgs G)
         for (int j = 0; j < 4; ++j) { tabB0[j] ^= (unsigned)kBufBytes; tabB1[j] ^= (unsigned)kBufBytes; }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
+#ifdef ECGB_PROFILE
+    const long long tp2 = clock64();
+#endif
     store_tile_m16<TM, TN, WTM, WTN, GB>(acc, G, row0, col0, wr, wc, lm, lq, 0, lds);
+#ifdef ECGB_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long tp3 = clock64();
+    if (threadIdx.x == 0) {
+        atomicAdd(&g_gemm_prof[4], (unsigned long long)(tp1 - tp0)); atomicAdd(&g_gemm_prof[5], (unsigned long long)(tp2 - tp1));
+        atomicAdd(&g_gemm_prof[6], (unsigned long long)(tp3 - tp2)); atomicAdd(&g_gemm_prof[7], 1ull);
+    }
+#endif
 }
 
 // C[M, N] = alpha * A[M, K] . B[N, K]^T for M <= 8 (the decode step of generate(): one new token per sequence).  No MFMA
