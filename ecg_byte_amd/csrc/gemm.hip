@@ -572,7 +572,7 @@ __device__ __forceinline__ void store_tile_glu(const f32x4 (&acc)[TM][TN], const
 }
 
 #ifdef ECGB_PROFILE
-__device__ unsigned long long g_gemm_prof[8];    // [prologue, K loop, epilogue, tiles] cycles summed over the workgroups (wave 0) of gemm_nt_kernel_m16p; [4..7]: gemm_nn_kernel_m16p
+__device__ unsigned long long g_gemm_prof[12];    // [prologue, K loop, epilogue, tiles] cycles summed over the workgroups (wave 0) of gemm_nt_kernel_m16p; [4..7]: gemm_nn_kernel_m16p, [8..11]: gemm_tn_kernel_tr (K-tiles instead of tiles in [11])
 #endif
 template <int BM, int BN, int WGM, int WGN, bool CAT = false, int EPI = 0>
 __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nt_kernel_m16p(GemmArgs G)
@@ -901,6 +901,9 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_m16(GemmArgs G)
 template <int BN_, int BK_, int WGM, int WGN>
 __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
 {
+#ifdef ECGB_PROFILE
+    const long long tp0 = clock64();
+#endif
     const int orig = blockIdx.x, split = blockIdx.y, n_splits = gridDim.y;
     static_assert(BN_ == 256 && BK_ == 256 && WGM == 2 && WGN == 4, "phase schedule written for the 256x256 tile, 2x4 waves");
     constexpr int WTM = BN_ / WGM, WTN = BK_ / WGN;
@@ -988,6 +991,9 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
             tabB1[j] = lane_base + (wc >> 1) * 256 + (((2 * (m ^ 4 ^ sw)) + cb) << 4);
         }
     }
+#ifdef ECGB_PROFILE
+    const long long tp1 = clock64();
+#endif
     bf16x8 a[2][4], b[2][4];
     for (int it = 0, kt = kt_begin; kt < KT; ++kt, ++it) {
         unsigned char *nxt = lds + (it & 1) * kBufBytes;
@@ -1051,7 +1057,18 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_tn_kernel_tr(GemmArgs G)
         for (int j = 0; j < 4; ++j) { tabB0[j] ^= (unsigned)kBufBytes; tabB1[j] ^= (unsigned)kBufBytes; }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
+#ifdef ECGB_PROFILE
+    const long long tp2 = clock64();
+#endif
     store_tile_tn<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, split);
+#ifdef ECGB_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long tp3 = clock64();
+    if (threadIdx.x == 0) {
+        atomicAdd(&g_gemm_prof[8], (unsigned long long)(tp1 - tp0)); atomicAdd(&g_gemm_prof[9], (unsigned long long)(tp2 - tp1));
+        atomicAdd(&g_gemm_prof[10], (unsigned long long)(tp3 - tp2)); atomicAdd(&g_gemm_prof[11], (unsigned long long)(KT - kt_begin));
+    }
+#endif
 }
 
 
@@ -1651,9 +1668,9 @@ extern "C" int ecgb_gemm_nn_glu_bwd_bf16(const void *dy_dev, long long lddy, con
 }
 
 #ifdef ECGB_PROFILE
-extern "C" void ecgb_debug_gemm_profile(unsigned long long *out8, int reset)
+extern "C" void ecgb_debug_gemm_profile(unsigned long long *out8, int reset)   // out8: 12 counters
 {
-    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gemm_prof), 8 * sizeof(unsigned long long));
-    if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof z); }
+    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gemm_prof), 12 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[12] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof z); }
 }
 #endif
