@@ -778,6 +778,239 @@ __device__ __forceinline__ void store_tile_tn(const f32x4 (&acc)[TM][TN], const 
     }
 }
 
+// ---- persistent form of gemm_nt_kernel_m16p -------------------------------------------------------------------------------------------
+// One workgroup per CU walks output tiles blockIdx.x, blockIdx.x + gridDim.x, ... (same tile -> XCD deal as the one-tile kernel).  A tile of the
+// K = 2048 projections is 83 000 cycles of K loop between 4 800 of prologue (address set-up + the flight of the first K-tile) and 4 800 of
+// epilogue, and with one workgroup per CU nothing overlaps them (scripts/dev_prof_gemm.py).  Here the K-tile stream runs on into the next
+// tile: its first K-tile is staged during the last-but-one K-tile of this one (the ring position that would take K-tile KT), lands under the
+// last K-tile and the epilogue, and the second one is issued right behind the epilogue; the epilogue stages through the OTHER buffer
+// (8 KB per wave: half a block at a time).  Whole interior tiles only, no batch, plain bf16 store or the GLU epilogue (the launcher checks).
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void store_block_half_staged(const f32x4 (&acc)[TM][TN], const GemmArgs &G, unsigned char *blk, int row0, int col0, int wr, int wc, int lm, int lq)
+{
+    using u2 = __attribute__((ext_vector_type(2))) unsigned;
+    using u4 = __attribute__((ext_vector_type(4))) unsigned;
+    using bf2 = __attribute__((ext_vector_type(2))) __bf16;
+    auto pack = [](float a, float b) { bf2 v; v[0] = (__bf16)a; v[1] = (__bf16)b; return __builtin_bit_cast(unsigned, v); };
+    const float alpha = G.alpha;
+    const int lane = lq * 16 + lm;
+    if constexpr (EPI == 0) {                                           // two passes of 64 rows x 128 bytes (layout of store_tile_m16)
+        const int sw = (lm >> 1) & 7, rr = lane >> 3, c16 = lane & 7;
+        unsigned short *dst = reinterpret_cast<unsigned short *>(G.C) + (long long)(row0 + wr * 128 + rr) * G.ldc + col0 + wc * 64 + c16 * 8;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int i = half * 4 + i4;
+                    u2 v;
+                    v[0] = pack(acc[i][j][0] * alpha, acc[i][j][1] * alpha); v[1] = pack(acc[i][j][2] * alpha, acc[i][j][3] * alpha);
+                    const int slot = j * 4 + lq;
+                    *reinterpret_cast<u2 *>(blk + (i4 * 16 + lm) * 128 + ((((slot >> 1) ^ sw)) << 4) + (slot & 1) * 8) = v;
+                }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = it * 8 + rr;
+                const u4 v = *reinterpret_cast<const u4 *>(blk + r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4));
+                *reinterpret_cast<u4 *>(dst + (long long)(half * 64 + it * 8) * G.ldc) = v;
+            }
+        }
+    } else {                                                            // four passes of 32 rows: gate, up, act(gate) * up, 64 bytes a row each (layout of store_tile_glu)
+        auto lo_f = [](unsigned w) { return __uint_as_float(w << 16); };
+        auto hi_f = [](unsigned w) { return __uint_as_float(w & 0xFFFF0000u); };
+        unsigned short *C = reinterpret_cast<unsigned short *>(G.C);
+        const int sw = (lm >> 2) & 3, rr = lane >> 2, c16 = lane & 3;
+        const long long hcol = (col0 >> 1) + wc * 32 + c16 * 8;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                for (int p = 0; p < TN / 2; ++p) {
+                    const int i = q4 * 2 + i2;
+                    u2 g, u, h;
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        g[w] = pack(acc[i][2 * p][2 * w] * alpha, acc[i][2 * p][2 * w + 1] * alpha);
+                        u[w] = pack(acc[i][2 * p + 1][2 * w] * alpha, acc[i][2 * p + 1][2 * w + 1] * alpha);
+                        const unsigned a = pack(ecgb::glu_act<EPI == 2>(lo_f(g[w])), ecgb::glu_act<EPI == 2>(hi_f(g[w])));
+                        h[w] = pack(lo_f(a) * lo_f(u[w]), hi_f(a) * hi_f(u[w]));
+                    }
+                    const int slot = p * 4 + lq;
+                    unsigned char *d = blk + (i2 * 16 + lm) * 64 + (((slot >> 1) ^ sw) << 4) + (slot & 1) * 8;
+                    if (C) { *reinterpret_cast<u2 *>(d) = g; *reinterpret_cast<u2 *>(d + 2048) = u; }
+                    *reinterpret_cast<u2 *>(d + 4096) = h;
+                }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int r = it * 16 + rr;
+                const unsigned char *src = blk + r * 64 + ((c16 ^ ((r >> 2) & 3)) << 4);
+                const long long grow = row0 + wr * 128 + q4 * 32 + r;
+                if (C) {
+                    *reinterpret_cast<u4 *>(C + grow * G.ldc + hcol) = *reinterpret_cast<const u4 *>(src);
+                    *reinterpret_cast<u4 *>(C + grow * G.ldc + G.glu_I + hcol) = *reinterpret_cast<const u4 *>(src + 2048);
+                }
+                *reinterpret_cast<u4 *>(G.H + grow * G.ldh + hcol) = *reinterpret_cast<const u4 *>(src + 4096);
+            }
+        }
+    }
+}
+
+template <bool CAT, int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_kernel_m16pp(GemmArgs G)
+{
+    constexpr int BM = 256, BN = 256, WGN = 4, WTM = 128, WTN = 64, TM = 8, TN = 4;
+    constexpr int kABytes = BM * BK * 2, kBBytes = BN * BK * 2, kBufBytes = kABytes + kBBytes;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nwg = G.tiles_m * G.tiles_n;
+    const int q = nwg / 8, rr8 = nwg % 8;
+    auto tile_origin = [&](int t, int &row0, int &col0) {              // the one-tile kernel's blockIdx.x -> tile map (XCD t % 8 owns a contiguous range)
+        const int xcd = t % 8;
+        const int wgid = (xcd < rr8 ? xcd * (q + 1) : rr8 * (q + 1) + (xcd - rr8) * q) + t / 8;
+        row0 = (wgid / G.tiles_n) * BM; col0 = (wgid % G.tiles_n) * BN;
+    };
+    const int wr = wave / WGN, wc = wave % WGN;
+    const int lm = lane & 15, lq = lane >> 4;
+    const int KT1 = G.K / BK, KT = CAT ? KT1 + G.K2 / BK : KT1;
+    unsigned offA[4], offB[4], offA2[CAT ? 4 : 1], offB2[CAT ? 4 : 1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        int rb = r;
+        if constexpr (EPI != 0) rb = ((r >> 5) << 4) + (r & 15) + (((r >> 4) & 1) ? G.glu_I : 0);   // gate / up rows interleaved by 16
+        offA[i] = (unsigned)(((long long)r * G.lda + chunk * 8) * 2);
+        offB[i] = (unsigned)(((long long)rb * G.ldb + chunk * 8) * 2);
+        if constexpr (CAT) {
+            offA2[i] = (unsigned)(((long long)r * G.lda2 + chunk * 8) * 2);
+            offB2[i] = (unsigned)(((long long)rb * G.ldb2 + chunk * 8) * 2);
+        }
+    }
+    const unsigned char *nextA = nullptr, *nextB = nullptr, *nextA2 = nullptr, *nextB2 = nullptr;
+    auto point_a = [&](int row0) {
+        nextA = reinterpret_cast<const unsigned char *>(G.A + (long long)row0 * G.lda);
+        if constexpr (CAT) nextA2 = reinterpret_cast<const unsigned char *>(G.A2 + (long long)row0 * G.lda2);
+    };
+    auto point_b = [&](int col0) {
+        const int brow0 = EPI != 0 ? (col0 >> 1) : col0;
+        nextB = reinterpret_cast<const unsigned char *>(G.B + (long long)brow0 * G.ldb);
+        if constexpr (CAT) nextB2 = reinterpret_cast<const unsigned char *>(G.B2 + (long long)brow0 * G.ldb2);
+    };
+    auto stage_a = [&](int t, unsigned char *dst) {
+        const bool second = CAT && t >= KT1;
+        const unsigned char *base = second ? nextA2 : nextA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (second ? offA2[CAT ? i : 0] : offA[i])),
+                                             (__attribute__((address_space(3))) void *)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
+        if (second) nextA2 += BK * 2; else nextA += BK * 2;
+    };
+    auto stage_b = [&](int t, unsigned char *dst) {
+        const bool second = CAT && t >= KT1;
+        const unsigned char *base = second ? nextB2 : nextB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (second ? offB2[CAT ? i : 0] : offB[i])),
+                                             (__attribute__((address_space(3))) void *)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
+        if (second) nextB2 += BK * 2; else nextB += BK * 2;
+    };
+
+    int tile = blockIdx.x, row0, col0;
+    tile_origin(tile, row0, col0);
+    point_a(row0); point_b(col0);
+    int par = 0;                                                        // K-tile kt of the current tile lives in buffer (kt + par) & 1
+    stage_b(0, lds + kABytes);
+    stage_a(0, lds);
+    stage_b(1, lds + kBufBytes + kABytes);                              // (KT >= 2: the launcher checks)
+    stage_a(1, lds + kBufBytes);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (;;) {
+        const int ntile = tile + gridDim.x;
+        const bool has_next = ntile < nwg;
+        int nrow0 = 0, ncol0 = 0;
+        if (has_next) tile_origin(ntile, nrow0, ncol0);
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (wr == 1) __builtin_amdgcn_s_barrier();          // the stagger: row 1 runs one barrier behind row 0
+        bf16x8 a[2][4], b[2][4];
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = (kt + par) & 1;
+            const unsigned char *At = lds + cur * kBufBytes, *Bt = At + kABytes;
+            unsigned char *nxt = lds + cur * kBufBytes;      // K-tile kt + 2 of the stream goes where K-tile kt lives
+            const bool own = kt + 2 < KT;                    // the stream's next K-tile belongs to this output tile ...
+            const bool more = own || (kt + 2 == KT && has_next);   // ... or is the first one of the next (its second follows the epilogue)
+            const int tnext = own ? kt + 2 : 0;
+            auto read_a = [&](int half) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int ra = wr * WTM + (half * 4 + i) * 16 + lm, chunk = ks * 4 + lq;
+                        a[ks][i] = *reinterpret_cast<const bf16x8 *>(At + ra * 128 + ((chunk ^ ((ra >> 1) & 7)) << 4));
+                    }
+            };
+            auto read_b = [&](int half) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int rb = wc * WTN + (half * 2 + j) * 16 + lm, chunk = ks * 4 + lq;
+                        b[ks][half * 2 + j] = *reinterpret_cast<const bf16x8 *>(Bt + rb * 128 + ((chunk ^ ((rb >> 1) & 7)) << 4));
+                    }
+            };
+            auto mfma_quadrant = [&](int ah, int bh) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[ah * 4 + i][bh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ks][bh * 2 + j], a[ks][i], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_barrier();
+            };
+            read_b(0);
+            read_a(0);
+            mfma_quadrant(0, 0);
+            read_b(1);
+            mfma_quadrant(0, 1);
+            read_a(1);
+            if (more) {
+                if (!own) point_b(ncol0);
+                stage_b(tnext, nxt + kABytes);
+            }
+            mfma_quadrant(1, 1);
+            if (more) {
+                if (!own) point_a(nrow0);
+                stage_a(tnext, nxt);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            mfma_quadrant(1, 0);
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();          // barrier counts of the two rows match again; every read of the operand buffers is over
+        // the buffer of this tile's last K-tile is free (the other one holds or awaits the next tile's first K-tile)
+        store_block_half_staged<EPI, TM, TN>(acc, G, lds + ((KT - 1 + par) & 1) * kBufBytes + wave * 8192, row0, col0, wr, wc, lm, lq);
+        if (!has_next) break;
+        par = (KT + par) & 1;                                // the next tile's K-tile 0 sits where this tile's K-tile KT - 2 was
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // every wave is through with the staging buffer: it takes the next tile's second K-tile
+        stage_b(1, lds + ((1 + par) & 1) * kBufBytes + kABytes);
+        stage_a(1, lds + ((1 + par) & 1) * kBufBytes);
+        tile = ntile; row0 = nrow0; col0 = ncol0;
+    }
+}
+
 // ---- TN product for weight gradients: C[N,K] = A^T . B with A = dY [M,N] and B = X [M,K] (both ROW-major, the
 // contraction index m is the slow one).  Same MFMA / LDS-image / epilogue scheme as gemm_nt_kernel_m16; only the
 // staging differs: a thread loads 4 consecutive m-rows x 8 columns (four 16-byte loads, issued one K-tile ahead
@@ -1396,8 +1629,26 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_cols_kernel(GemmArgs G)
     }
 }
 
-int g_gemm_tile = 0;   // 0 auto; forced: 128 = 128x128 tile, 256 = 256x256 phased on 16x16x32 MFMA (the default for big problems),
+int g_gemm_tile = 0;   // 0 auto; 259 = 256x256 phased, one tile per workgroup (no persistent tile loop: A/B); forced: 128 = 128x128 tile, 256 = 256x256 phased on 16x16x32 MFMA (the default for big problems),
                        // 257 = 256x256 on 32x32x16 MFMA, 258 = 256x256 on 16x16x32 with one barrier pair per K-tile (the earlier kernels, kept for A/B)
+// persistent tile loop (gemm_nt_kernel_m16pp): whole interior tiles, no batch, plain bf16 store, at least two rounds of tiles per CU
+int n_cus()
+{
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+bool persist_ok(const GemmArgs &G, int batch, bool glu)
+{
+    const int KT = G.K / BK + (G.K2 > 0 ? G.K2 / BK : 0);
+    const long long tiles = (long long)(G.M / 256) * (G.N / 256);
+    return g_gemm_tile != 259 && batch == 1 && !G.inner && G.M % 256 == 0 && G.N % 256 == 0 && KT >= 2 && G.accumulate_f32 == 0 && (G.ldc & 7) == 0 &&
+           (!glu || ((G.ldh & 7) == 0 && (G.glu_I & 7) == 0)) && tiles >= 2 * n_cus();
+}
+
 
 int launch_gemm(GemmArgs &G, int batch, hipStream_t stream)
 {
@@ -1407,11 +1658,17 @@ int launch_gemm(GemmArgs &G, int batch, hipStream_t stream)
     hipError_t e;
     if (big && g_gemm_tile != 257 && g_gemm_tile != 258) {
         constexpr int lds = 2 * (256 + 256) * BK * 2;
-        auto kern = G.K2 ? gemm_nt_kernel_m16p<256, 256, 2, 4, true> : gemm_nt_kernel_m16p<256, 256, 2, 4>;
         G.tiles_m = (G.M + 255) / 256; G.tiles_n = (G.N + 255) / 256;
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess)
-            hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, (unsigned)batch), dim3(512), lds, stream, G);
+        if (persist_ok(G, batch, false)) {
+            auto kern = G.K2 ? gemm_nt_kernel_m16pp<true, 0> : gemm_nt_kernel_m16pp<false, 0>;
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3((unsigned)n_cus(), 1, 1), dim3(512), lds, stream, G);
+        } else {
+            auto kern = G.K2 ? gemm_nt_kernel_m16p<256, 256, 2, 4, true> : gemm_nt_kernel_m16p<256, 256, 2, 4>;
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess)
+                hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, (unsigned)batch), dim3(512), lds, stream, G);
+        }
     } else if (big && g_gemm_tile == 258) {
         constexpr int lds = 2 * (256 + 256) * BK * 2;
         auto kern = G.K2 ? gemm_nt_kernel_m16<256, 256, 2, 4, true> : gemm_nt_kernel_m16<256, 256, 2, 4>;
@@ -1443,7 +1700,7 @@ int launch_gemm(GemmArgs &G, int batch, hipStream_t stream)
 
 extern "C" int ecgb_set_gemm_tile(int tile)
 {
-    if (tile != 0 && tile != 128 && (tile < 256 || tile > 258)) { ecgb::set_error("ecgb_set_gemm_tile: 0, 128, 256, 257 or 258"); return ECGB_ERR_INVALID; }
+    if (tile != 0 && tile != 128 && (tile < 256 || tile > 259)) { ecgb::set_error("ecgb_set_gemm_tile: 0, 128, 256, 257, 258 or 259"); return ECGB_ERR_INVALID; }
     g_gemm_tile = tile;
     return ECGB_OK;
 }
@@ -1597,9 +1854,15 @@ extern "C" int ecgb_gemm_nt_glu_bf16(const void *a_dev, long long lda, const voi
     using Kern = void (*)(GemmArgs);
     Kern kern = gelu_tanh ? (G.K2 ? (Kern)gemm_nt_kernel_m16p<256, 256, 2, 4, true, 2> : (Kern)gemm_nt_kernel_m16p<256, 256, 2, 4, false, 2>)
                           : (G.K2 ? (Kern)gemm_nt_kernel_m16p<256, 256, 2, 4, true, 1> : (Kern)gemm_nt_kernel_m16p<256, 256, 2, 4, false, 1>);
+    unsigned grid = (unsigned)(G.tiles_m * G.tiles_n);
+    if (persist_ok(G, 1, true)) {
+        kern = gelu_tanh ? (G.K2 ? (Kern)gemm_nt_kernel_m16pp<true, 2> : (Kern)gemm_nt_kernel_m16pp<false, 2>)
+                         : (G.K2 ? (Kern)gemm_nt_kernel_m16pp<true, 1> : (Kern)gemm_nt_kernel_m16pp<false, 1>);
+        grid = (unsigned)n_cus();
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, 1), dim3(512), lds, (hipStream_t)stream, G);
+        hipLaunchKernelGGL(kern, dim3(grid, 1, 1), dim3(512), lds, (hipStream_t)stream, G);
         e = hipGetLastError();
     }
     if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_kernel (glu): ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
