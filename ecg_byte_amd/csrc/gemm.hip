@@ -785,7 +785,7 @@ __device__ __forceinline__ void store_tile_tn(const f32x4 (&acc)[TM][TN], const 
 // tile: its first K-tile is staged during the last-but-one K-tile of this one (the ring position that would take K-tile KT), lands under the
 // last K-tile and the epilogue, and the second one is issued right behind the epilogue; the epilogue stages through the OTHER buffer
 // (8 KB per wave: half a block at a time).  Whole interior tiles only, no batch, plain bf16 store or the GLU epilogue (the launcher checks).
-template <int EPI, int TM, int TN>
+template <int EPI, int TM, int TN, int GB = 0>
 __device__ __forceinline__ void store_block_half_staged(const f32x4 (&acc)[TM][TN], const GemmArgs &G, unsigned char *blk, int row0, int col0, int wr, int wc, int lm, int lq)
 {
     using u2 = __attribute__((ext_vector_type(2))) unsigned;
@@ -809,11 +809,38 @@ __device__ __forceinline__ void store_block_half_staged(const f32x4 (&acc)[TM][T
                     const int slot = j * 4 + lq;
                     *reinterpret_cast<u2 *>(blk + (i4 * 16 + lm) * 128 + ((((slot >> 1) ^ sw)) << 4) + (slot & 1) * 8) = v;
                 }
+            if constexpr (GB != 0) {                                    // GLU backward on the staged product (see store_tile_m16): gate / up of the 64 rows in flight together
+                const unsigned short *gsrc = G.GU + (long long)(row0 + wr * 128 + half * 64 + rr) * G.ldgu + col0 + wc * 64 + c16 * 8;
+                u4 g[8], u[8];
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int r = it * 8 + rr;
-                const u4 v = *reinterpret_cast<const u4 *>(blk + r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4));
-                *reinterpret_cast<u4 *>(dst + (long long)(half * 64 + it * 8) * G.ldc) = v;
+                for (int k = 0; k < 8; ++k) {
+                    g[k] = *reinterpret_cast<const u4 *>(gsrc + (long long)k * 8 * G.ldgu);
+                    u[k] = *reinterpret_cast<const u4 *>(gsrc + (long long)k * 8 * G.ldgu + G.glu_I);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = k * 8 + rr;
+                    const u4 d = *reinterpret_cast<const u4 *>(blk + r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4));
+                    u4 og, ou;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float g0 = __uint_as_float(g[k][w] << 16), g1 = __uint_as_float(g[k][w] & 0xFFFF0000u);
+                        const float u0 = __uint_as_float(u[k][w] << 16), u1 = __uint_as_float(u[k][w] & 0xFFFF0000u);
+                        const float d0 = __uint_as_float(d[w] << 16), d1 = __uint_as_float(d[w] & 0xFFFF0000u);
+                        og[w] = pack(d0 * u0 * ecgb::glu_act_grad<GB == 2>(g0), d1 * u1 * ecgb::glu_act_grad<GB == 2>(g1));
+                        ou[w] = pack(d0 * ecgb::glu_act<GB == 2>(g0), d1 * ecgb::glu_act<GB == 2>(g1));
+                    }
+                    unsigned short *o = dst + (long long)(half * 64 + k * 8) * G.ldc;
+                    *reinterpret_cast<u4 *>(o) = og;
+                    *reinterpret_cast<u4 *>(o + G.glu_I) = ou;
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int r = it * 8 + rr;
+                    const u4 v = *reinterpret_cast<const u4 *>(blk + r * 128 + ((c16 ^ ((r >> 1) & 7)) << 4));
+                    *reinterpret_cast<u4 *>(dst + (long long)(half * 64 + it * 8) * G.ldc) = v;
+                }
             }
         }
     } else {                                                            // four passes of 32 rows: gate, up, act(gate) * up, 64 bytes a row each (layout of store_tile_glu)
@@ -1472,6 +1499,167 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nn_kernel_m16p(GemmArgs G)
 #endif
 }
 
+// Persistent form of gemm_nn_kernel_m16p (see gemm_nt_kernel_m16pp): whole interior tiles only, plain bf16 store or the GLU backward (GB).
+// The B-side fragment tables toggle buffers once per K-tile, so they follow the K-tile stream across tiles by themselves.
+template <int GB>
+__global__ __launch_bounds__(512) void gemm_nn_kernel_m16pp(GemmArgs G)
+{
+    constexpr int BM = 256, BN = 256, WGN = 4, WTM = 128, TM = 8, TN = 4;
+    constexpr int kABytes = BM * BK * 2, kBBytes = BN * BK * 2, kBufBytes = kABytes + kBBytes;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nwg = G.tiles_m * G.tiles_n;
+    const int q = nwg / 8, rr8 = nwg % 8;
+    auto tile_origin = [&](int t, int &row0, int &col0) {
+        const int xcd = t % 8;
+        const int wgid = (xcd < rr8 ? xcd * (q + 1) : rr8 * (q + 1) + (xcd - rr8) * q) + t / 8;
+        row0 = (wgid / G.tiles_n) * BM; col0 = (wgid % G.tiles_n) * BN;
+    };
+    const int wr = wave / WGN, wc = wave % WGN;
+    const int lm = lane & 15, lq = lane >> 4;
+    const int KT = G.K / BK;
+    unsigned offA[4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        offA[i] = (unsigned)(((long long)r * G.lda + chunk * 8) * 2);
+        const int rk = (wave * 4 + i) * 2 + (lane >> 5);
+        const int chunkb = (lane & 31) ^ (((rk & 7) << 1) ^ (rk & 8));
+        offB[i] = (unsigned)(((long long)rk * G.ldb + chunkb * 8) * 2);              // the tile's first column goes into the base pointer
+    }
+    const unsigned char *nextA = nullptr, *nextB = nullptr;
+    auto stage_a = [&](unsigned char *dst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nextA + offA[i]),
+                                             (__attribute__((address_space(3))) void *)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
+        nextA += BK * 2;
+    };
+    auto stage_b = [&](unsigned char *dst) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nextB + offB[i]),
+                                             (__attribute__((address_space(3))) void *)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
+        nextB += (long long)BK * G.ldb * 2;
+    };
+    int tile = blockIdx.x, row0, col0;
+    tile_origin(tile, row0, col0);
+    nextA = reinterpret_cast<const unsigned char *>(G.A + (long long)row0 * G.lda);
+    nextB = reinterpret_cast<const unsigned char *>(G.B + col0);
+    int par = 0;
+    stage_b(lds + kABytes);
+    stage_a(lds);
+    stage_b(lds + kBufBytes + kABytes);                                 // (KT >= 2: the launcher checks)
+    stage_a(lds + kBufBytes);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    using i2 = __attribute__((ext_vector_type(2))) int;
+    using i4 = __attribute__((ext_vector_type(4))) int;
+    const int tq = lm >> 2, tp = lm & 3;
+    unsigned tabB0[4], tabB1[4];
+    {
+        const int rb = 8 * lq + tq;
+        const int sw = (rb & 7) ^ ((rb & 8) >> 1);
+        const unsigned lane_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds + rb * 512 + (tp & 1) * 8;
+        const int cb = tp >> 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = (wc & 1) * 4 + j;
+            tabB0[j] = lane_base + (wc >> 1) * 256 + (((2 * (m ^ sw)) + cb) << 4);
+            tabB1[j] = lane_base + (wc >> 1) * 256 + (((2 * (m ^ 4 ^ sw)) + cb) << 4);
+        }
+    }
+    for (;;) {
+        const int ntile = tile + gridDim.x;
+        const bool has_next = ntile < nwg;
+        int nrow0 = 0, ncol0 = 0;
+        if (has_next) tile_origin(ntile, nrow0, ncol0);
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+        bf16x8 a[2][4], b[2][4];
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = (kt + par) & 1;
+            const unsigned char *At = lds + cur * kBufBytes;
+            unsigned char *nxt = lds + cur * kBufBytes;
+            const bool own = kt + 2 < KT;
+            const bool more = own || (kt + 2 == KT && has_next);
+            auto read_a = [&](int half) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int ra = wr * WTM + (half * 4 + i) * 16 + lm, chunk = ks * 4 + lq;
+                        a[ks][i] = *reinterpret_cast<const bf16x8 *>(At + ra * 128 + ((chunk ^ ((ra >> 1) & 7)) << 4));
+                    }
+            };
+            auto fragb = [&](unsigned t0, unsigned t1, auto off) {
+                constexpr int OFF = decltype(off)::value;
+                i2 lo, hi;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(t0), "n"(OFF));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(t1), "n"(OFF + 2048));
+                const i4 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+                return __builtin_bit_cast(bf16x8, f);
+            };
+            auto read_b = [&](int half) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    b[0][half * 2 + j] = fragb(tabB0[half * 2 + j], tabB1[half * 2 + j], std::integral_constant<int, kABytes>{});
+                    b[1][half * 2 + j] = fragb(tabB0[half * 2 + j], tabB1[half * 2 + j], std::integral_constant<int, kABytes + 32 * 512>{});
+                }
+            };
+            auto mfma_quadrant = [&](int ah, int bh) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[ah * 4 + i][bh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ks][bh * 2 + j], a[ks][i], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_barrier();
+            };
+            read_b(0);
+            read_a(0);
+            mfma_quadrant(0, 0);
+            read_b(1);
+            mfma_quadrant(0, 1);
+            read_a(1);
+            if (more) {
+                if (!own) nextB = reinterpret_cast<const unsigned char *>(G.B + ncol0);
+                stage_b(nxt + kABytes);
+            }
+            mfma_quadrant(1, 1);
+            if (more) {
+                if (!own) nextA = reinterpret_cast<const unsigned char *>(G.A + (long long)nrow0 * G.lda);
+                stage_a(nxt);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            mfma_quadrant(1, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { tabB0[j] ^= (unsigned)kBufBytes; tabB1[j] ^= (unsigned)kBufBytes; }
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        store_block_half_staged<0, TM, TN, GB>(acc, G, lds + ((KT - 1 + par) & 1) * kBufBytes + wave * 8192, row0, col0, wr, wc, lm, lq);
+        if (!has_next) break;
+        par = (KT + par) & 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stage_b(lds + ((1 + par) & 1) * kBufBytes + kABytes);
+        stage_a(lds + ((1 + par) & 1) * kBufBytes);
+        tile = ntile; row0 = nrow0; col0 = ncol0;
+    }
+}
+
 // C[M, N] = alpha * A[M, K] . B[N, K]^T for M <= 8 (the decode step of generate(): one new token per sequence).  No MFMA
 // tile to fill: the product is bound by reading B once.  One wave per output column n: the 64 lanes walk row n of B in
 // 16-byte pieces (1 KiB per step, coalesced), multiply with the matching pieces of the M rows of A (L2-resident), reduce
@@ -1645,7 +1833,8 @@ bool persist_ok(const GemmArgs &G, int batch, bool glu)
 {
     const int KT = G.K / BK + (G.K2 > 0 ? G.K2 / BK : 0);
     const long long tiles = (long long)(G.M / 256) * (G.N / 256);
-    return g_gemm_tile != 259 && batch == 1 && !G.inner && G.M % 256 == 0 && G.N % 256 == 0 && KT >= 2 && G.accumulate_f32 == 0 && (G.ldc & 7) == 0 &&
+    // (long contractions gain nothing -- the prologue is 0.5 % of a K = 16 384 tile -- and lose the dynamic dispatch's load balancing: measured +1.5 %)
+    return g_gemm_tile != 259 && batch == 1 && !G.inner && G.M % 256 == 0 && G.N % 256 == 0 && KT >= 2 && KT <= 64 && G.accumulate_f32 == 0 && (G.ldc & 7) == 0 &&
            (!glu || ((G.ldh & 7) == 0 && (G.glu_I & 7) == 0)) && tiles >= 2 * n_cus();
 }
 
@@ -1889,10 +2078,13 @@ extern "C" int ecgb_gemm_nn_bf16(const void *a_dev, long long lda, const void *b
     G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
     G.tiles_m = (M + 255) / 256; G.tiles_n = (N + 255) / 256;
     constexpr int lds = 2 * (256 + 256) * BK * 2;
-    auto kern = gemm_nn_kernel_m16p<256, 256, 2, 4>;
+    using Kern = void (*)(GemmArgs);
+    Kern kern = gemm_nn_kernel_m16p<256, 256, 2, 4>;
+    unsigned grid = (unsigned)(G.tiles_m * G.tiles_n);
+    if (persist_ok(G, 1, false)) { kern = gemm_nn_kernel_m16pp<0>; grid = (unsigned)n_cus(); }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, 1), dim3(512), lds, (hipStream_t)stream, G);
+        hipLaunchKernelGGL(kern, dim3(grid, 1, 1), dim3(512), lds, (hipStream_t)stream, G);
         e = hipGetLastError();
     }
     if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nn_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
@@ -1920,10 +2112,13 @@ extern "C" int ecgb_gemm_nn_glu_bwd_bf16(const void *dy_dev, long long lddy, con
     G.tiles_m = M / 256; G.tiles_n = inter / 256;
     G.glu_I = inter; G.GU = (const unsigned short *)gate_up_dev; G.ldgu = ldgu;
     constexpr int lds = 2 * (256 + 256) * BK * 2;
-    auto kern = gelu_tanh ? gemm_nn_kernel_m16p<256, 256, 2, 4, 2> : gemm_nn_kernel_m16p<256, 256, 2, 4, 1>;
+    using Kern = void (*)(GemmArgs);
+    Kern kern = gelu_tanh ? (Kern)gemm_nn_kernel_m16p<256, 256, 2, 4, 2> : (Kern)gemm_nn_kernel_m16p<256, 256, 2, 4, 1>;
+    unsigned grid = (unsigned)(G.tiles_m * G.tiles_n);
+    if (persist_ok(G, 1, false) && (ldgu & 7) == 0) { kern = gelu_tanh ? (Kern)gemm_nn_kernel_m16pp<2> : (Kern)gemm_nn_kernel_m16pp<1>; grid = (unsigned)n_cus(); }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), 1, 1), dim3(512), lds, (hipStream_t)stream, G);
+        hipLaunchKernelGGL(kern, dim3(grid, 1, 1), dim3(512), lds, (hipStream_t)stream, G);
         e = hipGetLastError();
     }
     if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nn_kernel (GLU backward): ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }

@@ -35,3 +35,14 @@ for name, M, I, K, gelu in (("llama", 32768, 8192, 2048, False), ("gemma", 16384
         for _ in range(3):
             r_gu, r_h = ops.gemm_nt_glu(a, b, gelu_tanh=gelu, **kw); same = same and torch.equal(r_gu, w_gu) and torch.equal(r_h, w_h)
         print(f"GLU {name} cat={cat}: one tile {t0:.3f} ms  persistent {t1:.3f} ms  same bits {same}")
+for M, N, K in [(32768, 2048, 3072), (32768, 2048, 2048), (32768, 2048, 16384), (32768, 8192, 2048)]:
+    a = torch.randn(M, K, device="cuda").to(torch.bfloat16); b = (torch.randn(K, N, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    ops.set_gemm_tile(259); want = ops.gemm_nn(a, b); t0 = timed(lambda: ops.gemm_nn(a, b))
+    ops.set_gemm_tile(0); got = ops.gemm_nn(a, b); t1 = timed(lambda: ops.gemm_nn(a, b))
+    same = all(torch.equal(ops.gemm_nn(a, b), want) for _ in range(3)) and torch.equal(got, want)
+    print(f"NN M{M} N{N} K{K}: one tile {t0:.3f} ms ({2*M*N*K/t0/1e9:.0f} TFLOP/s)  persistent {t1:.3f} ms ({2*M*N*K/t1/1e9:.0f})  same bits {same}")
+M, I, K = 32768, 8192, 2048
+dy = torch.randn(M, K, device="cuda").to(torch.bfloat16); w = (torch.randn(K, I, device="cuda") * K ** -0.5).to(torch.bfloat16); gu = torch.randn(M, 2 * I, device="cuda").to(torch.bfloat16)
+ops.set_gemm_tile(259); want = ops.gemm_nn_glu_bwd(dy, w, gu); t0 = timed(lambda: ops.gemm_nn_glu_bwd(dy, w, gu))
+ops.set_gemm_tile(0); got = ops.gemm_nn_glu_bwd(dy, w, gu); t1 = timed(lambda: ops.gemm_nn_glu_bwd(dy, w, gu))
+print(f"NN + GLU backward: one tile {t0:.3f} ms  persistent {t1:.3f} ms  same bits {torch.equal(got, want) and all(torch.equal(ops.gemm_nn_glu_bwd(dy, w, gu), want) for _ in range(3))}")

@@ -407,16 +407,20 @@ def test_gemm_nn_is_bitwise_the_nt_kernel_on_a_transposed_copy(ops, M, N, K):
 @pytest.mark.parametrize("M,N,K,cat", [(32768, 3072, 2048, False), (8192, 16384, 128, True), (16384, 8192, 192, False), (32768, 2048, 2112, True),
                                        (4096, 132608, 256, False)])
 def test_gemm_nt_persistent_tile_loop_is_bitwise_the_one_tile_kernel(ops, M, N, K, cat):
-    """Big problems of whole 256x256 tiles run the persistent form of the NT kernel (a workgroup per CU walks the tiles, the next tile's first
+    """Big problems of whole 256x256 tiles run the persistent form of the NT (and NN) kernel (a workgroup per CU walks the tiles, the next tile's first
     K-tiles land under the epilogue): the same MFMA sequence per tile, so the same bits as the one-tile-per-workgroup kernel (tile code 259) --
     even and odd K-tile counts (the ring position of a tile's first K-tile alternates), 2 and many K-tiles, the K-concatenated second operand
     pair, the GLU epilogue; repeated under memory traffic (a tile reading LDS that the next tile's DMA has already overwritten would show)."""
     a, b = _bf(M, K, seed=111), _bf(N, K, scale=K ** -0.5, seed=112)
     kw = dict(a2=_bf(M, 64, seed=113), b2=_bf(N, 64, scale=0.1, seed=114)) if cat else {}
     try:
+        bn = _bf(K, N, scale=K ** -0.5, seed=115)                            # the NN kernel's operand ([K, N] as stored)
+        gu_in = _bf(M, 2 * N, seed=116) if ops.nn_glu_bwd_eligible(M, N, K) and M * N <= 1 << 28 else None
         ops.set_gemm_tile(259)
         want = ops.gemm_nt(a, b, **kw)
         want_glu = ops.gemm_nt_glu(a, b, **kw) if N % 256 == 0 and ops.glu_fusable(M, N // 2) else None
+        want_nn = ops.gemm_nn(a, bn)
+        want_gb = ops.gemm_nn_glu_bwd(a, bn, gu_in) if gu_in is not None else None
         ops.set_gemm_tile(0)
         noise = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
         for rep in range(4):
@@ -425,6 +429,9 @@ def test_gemm_nt_persistent_tile_loop_is_bitwise_the_one_tile_kernel(ops, M, N, 
             if want_glu is not None:
                 gu, h = ops.gemm_nt_glu(a, b, **kw)
                 assert torch.equal(gu, want_glu[0]) and torch.equal(h, want_glu[1]), rep
+            assert torch.equal(ops.gemm_nn(a, bn), want_nn), rep
+            if want_gb is not None:
+                assert torch.equal(ops.gemm_nn_glu_bwd(a, bn, gu_in), want_gb), rep
     finally:
         ops.set_gemm_tile(0)
 
