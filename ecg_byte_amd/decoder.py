@@ -166,6 +166,8 @@ class LoraSite(nn.Module):
             model._wgrad(self.A, dt, x, alpha=keep_scale)                # no dropout: one product for all blocks
         else:                                                            # dA_b = dt_b^T . (mask_b . x), the masks replayed from the seed
             model._lora_agrad(self.A, x, dt, self.n_sub, self.n_fields, self.scale, p, seed)
+        if dx is None:                                                   # the caller needs no input gradient (the bottom layer over frozen embeddings)
+            return None
         if glu is not None and self.n_sub == 1:
             return ops.lora_dx_glu(dx, dt, At, glu[0], self.scale, p, seed, gelu_tanh=glu[1])
         ops.lora_dx_(dx, dt, At, self.n_sub, self.n_fields, self.scale, p, seed)
@@ -1038,12 +1040,14 @@ class HipCausalLM(nn.Module):
             del P
             ops.rope_(d_qkv, cos, sin, Hq + Hkv, D, QKV, inverse=True)
             wgrad(d_qkv, h1, self.wqkv[i])
-            d_h1 = self._dx(d_qkv, ("wqkv", i), self.wqkv[i])      # [T, H]
+            bottom = frozen and i == 0                             # frozen embeddings below: nobody needs the gradient of the first layer's input
+            d_h1 = None if bottom else self._dx(d_qkv, ("wqkv", i), self.wqkv[i])      # [T, H]   (autograd would not compute it either)
             if frozen:
                 self.lora[i]["qkv"].backward(d_qkv, ls[0], self, d_h1)
-            dw = torch.zeros(H, dtype=torch.float32, device=dev)
-            g = ops.rmsnorm_bwd(x1, self.ln1[i].data, rstd1, d_h1, dw, dres=g2, gemma=self.gemma)
-            lngrad(self.ln1[i], dw)
+            if not bottom:
+                dw = torch.zeros(H, dtype=torch.float32, device=dev)
+                g = ops.rmsnorm_bwd(x1, self.ln1[i].data, rstd1, d_h1, dw, dres=g2, gemma=self.gemma)
+                lngrad(self.ln1[i], dw)
             if self.grad_sync is not None:   # this layer's gradients are final: its range of the flat buffer may leave
                 self.grad_sync.on_flat_ready(self._gflat, *self._granges[L - 1 - i])
         if not frozen:
