@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const unsigned short *
         }
     }
     __syncthreads();
+    if (!dw) return;   // frozen norm weights: only the input gradient was wanted
     if (partials) {   // launched with ONE wave per workgroup then: the LDS adds above happened in program order; the block's row is added in block order
         for (int c = threadIdx.x; c < H; c += blockDim.x) partials[(size_t)blockIdx.x * H + c] = s_dw[c];
         return;
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_rows_kernel(const unsigned sh
             *reinterpret_cast<bf16x8 *>(dx + r * H + k * 512 + lane * 8) = o;
         }
     }
+    if (!dw) return;                                         // frozen norm weights (LoRA): only the input gradient was wanted
     if (partials) {                                          // the four waves add in wave order, the block's row goes to partials[block]
         for (int w = 0; w < 4; ++w) {
             if ((int)(threadIdx.x >> 6) == w) {
@@ -852,7 +854,7 @@ extern "C" int ecgb_rmsnorm_bwd(const void *x_dev, const void *w_dev, const floa
         if (hidden == 2048) { if (gemma) ECGB_RMS_BWD_ROWS(true, 4); else ECGB_RMS_BWD_ROWS(false, 4); }
         else { if (gemma) ECGB_RMS_BWD_ROWS(true, 8); else ECGB_RMS_BWD_ROWS(false, 8); }
 #undef ECGB_RMS_BWD_ROWS
-        if (scratch_dev)      // per-block partial rows -> dw, in block order (scratch: ecgb_rmsnorm_bwd_scratch_floats; null: atomics)
+        if (scratch_dev && dw_dev)      // per-block partial rows -> dw, in block order (scratch: ecgb_rmsnorm_bwd_scratch_floats; null: atomics)
             hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((unsigned)((hidden + 15) / 16)), dim3(256), 0, (hipStream_t)stream, scratch_dev, (int)g2.x, hidden, (long long)hidden, dw_dev);
         ECGB_CHECK_LAUNCH("rmsnorm_bwd");
     }
@@ -868,7 +870,7 @@ extern "C" int ecgb_rmsnorm_bwd(const void *x_dev, const void *w_dev, const floa
         hipLaunchKernelGGL(rmsnorm_bwd_kernel<false>, grid, block, lds, (hipStream_t)stream, (const unsigned short *)x_dev,
                            (const unsigned short *)w_dev, rstd_dev, (const unsigned short *)dy_dev, (const unsigned short *)dres_dev,
                            (unsigned short *)dx_dev, dw_dev, rows, hidden, scratch_dev);
-    if (scratch_dev)
+    if (scratch_dev && dw_dev)
         hipLaunchKernelGGL(partial_rows_sum_kernel, dim3((unsigned)((hidden + 15) / 16)), dim3(256), 0, (hipStream_t)stream, scratch_dev, (int)grid.x, hidden, (long long)hidden, dw_dev);
     ECGB_CHECK_LAUNCH("rmsnorm_bwd");
 }

@@ -1002,7 +1002,7 @@ class HipCausalLM(nn.Module):
             if not frozen:
                 self._vgrad(param, dw32)
 
-        dw = torch.zeros(H, dtype=torch.float32, device=dev)
+        dw = None if frozen else torch.zeros(H, dtype=torch.float32, device=dev)        # frozen norm weights (LoRA): no weight gradient is computed
         g = ops.rmsnorm_bwd(xf, self.norm.data, rstdf, dhf, dw, gemma=self.gemma)          # grad of the residual stream
         lngrad(self.norm, dw)
         for i in reversed(range(c.num_hidden_layers)):
@@ -1024,7 +1024,7 @@ class HipCausalLM(nn.Module):
             if frozen:
                 self.lora[i]["gu"].backward(d_gu, ls[2], self, d_h2)
             del d_gu, gu
-            dw = torch.zeros(H, dtype=torch.float32, device=dev)
+            dw = None if frozen else torch.zeros(H, dtype=torch.float32, device=dev)
             g2 = ops.rmsnorm_bwd(x2, self.ln2[i].data, rstd2, d_h2, dw, dres=g, gemma=self.gemma)
             lngrad(self.ln2[i], dw)
             # attention output projection
@@ -1045,7 +1045,7 @@ class HipCausalLM(nn.Module):
             if frozen:
                 self.lora[i]["qkv"].backward(d_qkv, ls[0], self, d_h1)
             if not bottom:
-                dw = torch.zeros(H, dtype=torch.float32, device=dev)
+                dw = None if frozen else torch.zeros(H, dtype=torch.float32, device=dev)
                 g = ops.rmsnorm_bwd(x1, self.ln1[i].data, rstd1, d_h1, dw, dres=g2, gemma=self.gemma)
                 lngrad(self.ln1[i], dw)
             if self.grad_sync is not None:   # this layer's gradients are final: its range of the flat buffer may leave

@@ -61,10 +61,11 @@ def rmsnorm_fwd(x, w, eps, residual=None, gemma=False):
 
 
 def rmsnorm_bwd(x, w, rstd, dy, dw_f32, dres=None, gemma=False):
+    """dx (+ dres) of RMSNorm; dw_f32 [H] receives += the weight gradient, or None: frozen norm weights (LoRA), nothing is computed for them."""
     H = x.shape[-1]
     dx = torch.empty_like(x)
     rows = x.numel() // H
-    nf = _L().ecgb_rmsnorm_bwd_scratch_floats(rows, H)      # per-workgroup partial rows of dw, added in order (the same bits every launch)
+    nf = _L().ecgb_rmsnorm_bwd_scratch_floats(rows, H) if dw_f32 is not None else 0     # per-workgroup partial rows of dw, added in order (the same bits every launch)
     scratch = torch.empty(nf, dtype=torch.float32, device=x.device) if nf else None
     _lib.check(_L().ecgb_rmsnorm_bwd(_p(_bf(x)), _p(_bf(w)), _p(rstd), _p(_bf(dy)), _p(dres), _p(dx), _p(dw_f32), rows, H, int(gemma), _p(scratch), _st()))
     return dx

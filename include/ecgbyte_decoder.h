@@ -42,7 +42,7 @@ int ecgb_embed_bwd_sorted(const int64_t *ids_sorted_dev, const int64_t *order_de
  * sum_out_dev.  rstd_dev (fp32 per row) is saved for the backward. */
 int ecgb_rmsnorm_fwd(const void *x_dev, const void *residual_dev, const void *w_dev, void *y_dev, void *sum_out_dev,
                      float *rstd_dev, size_t rows, int hidden, float eps, int gemma, void *stream);
-/* dx = rstd * (dy*w - xhat * mean(dy*w*xhat)) [+ dres];  dw_dev (fp32) += sum over rows of dy * xhat */
+/* dx = rstd * (dy*w - xhat * mean(dy*w*xhat)) [+ dres];  dw_dev (fp32) += sum over rows of dy * xhat; dw_dev NULL: frozen norm weights, no weight gradient */
 /* scratch_dev (ecgb_rmsnorm_bwd_scratch_floats floats, or null): with it the weight gradient is summed in a fixed order (per-workgroup partial
  * rows added in workgroup order: the same bits every launch; hidden 2048 / 4096), without it by LDS + global float atomics. */
 size_t ecgb_rmsnorm_bwd_scratch_floats(size_t rows, int hidden);

@@ -140,6 +140,7 @@ def test_rmsnorm(ops, gemma, rows, H):
     dx = ops.rmsnorm_bwd(xsum, w, rstd, dy, dw, dres=dres, gemma=gemma)
     _close(dx, xa.grad + dres.float(), atol=2e-2)
     assert torch.allclose(dw, wa.grad, atol=0.15 * math.sqrt(rows / 300), rtol=2e-2)
+    assert torch.equal(ops.rmsnorm_bwd(xsum, w, rstd, dy, None, dres=dres, gemma=gemma), dx)     # frozen norm weights (LoRA): the same input gradient, no dw
 
 
 def test_rope_forward_inverse(ops):
