@@ -638,8 +638,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs A)
 }
 
 // dQ with LDS-DMA staging (head_dim 64): K and V tiles through a ring of three buffers, two tiles ahead, counted waits (see attn_fwd_kernel<64, true>);
-// K is read both ways from one image (row fragments for S, transposing reads for dS . K).  Same arithmetic in the same order as attn_bwd_dq_kernel<64>:
-// the same bits.
+// K is read both ways from one image (row fragments for S, transposing reads for dS . K).  The arithmetic of attn_bwd_dq_kernel<64> except that the softmax scale
+// multiplies dQ once at the store instead of every dS element: the same bits for head_dim 64's scale of 1/8 (a power of two commutes with the bf16 rounding of dS).
 __global__ __launch_bounds__(256) void attn_bwd_dq_dma_kernel(AttnArgs A)
 {
     constexpr int D = 64, kTile = 128 * D;
@@ -739,11 +739,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_dma_kernel(AttnArgs A)
                         const float mkv = mv[r >> 2][r & 3];
                         const bool vis = (k0 + kl <= qi) & (mkv != 0.f);
                         const float pr = vis ? fast_exp2(__builtin_fmaf(s[r], sc, -lse)) : 0.f;
-                        ds[r] = pr * (dp[r] - delta) * A.scale;
+                        ds[r] = pr * (dp[r] - delta);                                // the softmax scale multiplies dQ once, at the store
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(__builtin_fmaf(s[r], sc, -lse)) * (dp[r] - delta) * A.scale;
+                    for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(__builtin_fmaf(s[r], sc, -lse)) * (dp[r] - delta);
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_dma_kernel(AttnArgs A)
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // this wave's pieces of tile it + 1 have landed (tile it + 2's four may still fly)
         __builtin_amdgcn_s_barrier();                        // ... and everybody else's; all reads of tile it are done
     }
-    store_accT<D / 32>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, 1.f);
+    store_accT<D / 32>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, A.scale);
 }
 
 // =====================================================================================================
@@ -897,7 +897,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs &A, const int b
 // delta: 256 bytes each, 4 bytes a lane) go global -> LDS through a ring of three buffers, two steps ahead; every wave issues the same five
 // instructions per step (two Q pieces, two dO pieces, one statistics row: waves 0 / 1 bring lse / delta, 2 / 3 a copy nobody reads), so one counted
 // wait serves all.  Each tile is read both ways from its one image.  A tile that ends past the sequence re-reads the last row (DMA cannot zero):
-// those queries are switched off in the visibility test.  Same arithmetic in the same order as attn_bwd_dkv_kernel<64, 1, 0>: the same bits.
+// those queries are switched off in the visibility test.  The arithmetic of attn_bwd_dkv_kernel<64, 1, 0> except that the softmax scale multiplies dK once at the
+// store: the same bits for head_dim 64's scale of 1/8.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(AttnArgs A)
 {
     constexpr int D = 64, kTile = 128 * D, kStep = 2 * kTile + 1024;      // Q image, dO image, four statistics rows
@@ -915,6 +916,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(AttnArgs A)
     load_row_frags<D>(kf, A.k + (long long)g * D, A.ldk, rowbase + ki, kvalid, h);
     load_row_frags<D>(vf, A.v + (long long)g * D, A.ldv, rowbase + ki, kvalid, h);
     const bool kvis = kvalid && A.mask[rowbase + (kvalid ? ki : 0)] != 0.f;
+    // query q sees this lane's key iff the key is real and ki <= q < S: one unsigned compare, (q - vis_lo) < vis_n with vis_lo = ki (S for a padded /
+    // out-of-range key: vis_n = 0, never true).  (Causal test, key padding and the clamped rows of a tile past the end were two compares, an or and
+    // scalar mask arithmetic per element: 133 of a step's 344 vector instructions.)
+    const int vis_lo = kvis ? ki : A.S;
+    const unsigned vis_n = (unsigned)(A.S - vis_lo);
     f32x16 accK[D / 32], accV[D / 32];
 #pragma unroll
     for (int db = 0; db < D / 32; ++db)
@@ -996,17 +1002,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(AttnArgs A)
                     tr_frags4_wait<32 * 128, 48 * 128>(qtf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
                 }
                 float pr[16], ds[16];
-                const bool diag = t0 + qb * 32 < wave_kmin + 32;              // some query of the block may precede some key of the wave
+                const int qrel = t0 + 4 * h - vis_lo;                            // (query of element (g4, t)) - vis_lo = qrel + 32 qb + 8 g4 + t
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int r = 4 * g4 + t;
-                        const int ql = qb * 32 + t + 8 * g4 + 4 * h;             // query inside the tile
-                        const bool vis = kvis & (!diag | (ki <= t0 + ql)) & (t0 + ql < A.S);
+                        const bool vis = (unsigned)(qrel + (qb * 32 + 8 * g4 + t)) < vis_n;
                         const float e = vis ? fast_exp2(__builtin_fmaf(s[r], sc, -lse4[g4][t])) : 0.f;
                         pr[r] = e;
-                        ds[r] = e * (dp[r] - dl4[g4][t]) * A.scale;
+                        ds[r] = e * (dp[r] - dl4[g4][t]);                        // the softmax scale multiplies dK once, at the store
                     }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -1023,7 +1028,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(AttnArgs A)
         asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // this wave's pieces of step + 1 have landed (step + 2's five may still fly)
         __builtin_amdgcn_s_barrier();                        // ... and everybody else's; all reads of this step's images are done
     }
-    store_accT<D / 32>(accK, A.dk + (long long)g * D, A.lddk, rowbase + ki, kvalid, h, 1.f);
+    store_accT<D / 32>(accK, A.dk + (long long)g * D, A.lddk, rowbase + ki, kvalid, h, A.scale);
     store_accT<D / 32>(accV, A.dv + (long long)g * D, A.lddv, rowbase + ki, kvalid, h, 1.f);
 }
 
