@@ -1703,6 +1703,19 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs G)
             }
         }
     }
+    if (G.K2 > 0 && ks == 0) {                               // second operand pair (the LoRA branch of a decode step: K2 = 64, one piece for eight lanes)
+        for (int k = lane * 8; k < G.K2; k += 512) {
+            const bf16x8 vb = *reinterpret_cast<const bf16x8 *>(G.B2 + (live ? n : 0) * G.ldb2 + k);
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                if (m < G.M) {
+                    const bf16x8 va = *reinterpret_cast<const bf16x8 *>(G.A2 + (long long)m * G.lda2 + k);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[m] += __uint_as_float((unsigned)(unsigned short)va[j] << 16) * __uint_as_float((unsigned)(unsigned short)vb[j] << 16);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -1774,6 +1787,20 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_cols_kernel(GemmArgs G)
             for (int m = 0; m < MR; ++m)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[c][m] += fa[m][j] * fb[j];
+        }
+    }
+    if (G.K2 > 0 && (KS == 1 || wave == 0)) {               // second operand pair (see gemm_nt_skinny_kernel)
+        for (int k = lane * 8; k < G.K2; k += 512) {
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) {
+                const bf16x8 vb = *reinterpret_cast<const bf16x8 *>(G.B2 + min(n0 + c, (long long)G.N - 1) * G.ldb2 + k);
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    const bf16x8 va = *reinterpret_cast<const bf16x8 *>(G.A2 + (long long)min(m, G.M - 1) * G.lda2 + k);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[c][m] += __uint_as_float((unsigned)(unsigned short)va[j] << 16) * __uint_as_float((unsigned)(unsigned short)vb[j] << 16);
+                }
+            }
         }
     }
 #pragma unroll
@@ -1913,7 +1940,7 @@ extern "C" int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b
     G.accumulate_f32 = accumulate_f32; G.alpha = alpha;
     G.A2 = G.B2 = nullptr; G.lda2 = G.ldb2 = 0; G.K2 = 0;
     G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
-    if (M <= 8 && batch == 1 && K % 8 == 0) {   // a few rows: bandwidth-bound column-per-wave kernel
+    if (M <= 8 && batch == 1 && K % 8 == 0) {   // a few rows: bandwidth-bound column-per-wave kernel (ecgb_gemm_nt_bf16_cat has the same dispatch)
         const bool split = (K >= 8192 && K % 32 == 0 && N <= 8192);      // long rows, few columns: four waves per column
         const dim3 grid(split ? (unsigned)N : (unsigned)((N + 3) / 4));
         if (M <= 2) {
@@ -1950,6 +1977,21 @@ extern "C" int ecgb_gemm_nt_bf16_cat(const void *a_dev, long long lda, const voi
     G.accumulate_f32 = accumulate_f32; G.alpha = alpha;
     G.A2 = (const unsigned short *)a2_dev; G.B2 = (const unsigned short *)b2_dev; G.lda2 = lda2; G.ldb2 = ldb2; G.K2 = K2;
     G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
+    if (M <= 8) {   // a few rows (a decode step with adapters): the column-per-wave kernels take the second pair behind the first, one launch
+        const bool split = (K >= 8192 && K % 32 == 0 && N <= 8192);
+        const dim3 grid(split ? (unsigned)N : (unsigned)((N + 3) / 4));
+        if (M <= 2) {
+            if (split) hipLaunchKernelGGL((gemm_nt_skinny_kernel<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, G);
+            else hipLaunchKernelGGL((gemm_nt_skinny_kernel<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, G);
+        } else {
+            if (split) hipLaunchKernelGGL((gemm_nt_skinny_cols_kernel<8, 4, 4>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, G);
+            else if (N >= 8192) hipLaunchKernelGGL((gemm_nt_skinny_cols_kernel<8, 4, 1>), dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, G);
+            else hipLaunchKernelGGL((gemm_nt_skinny_kernel<8, 1>), grid, dim3(256), 0, (hipStream_t)stream, G);
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_skinny_kernel (cat): ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+        return ECGB_OK;
+    }
     return launch_gemm(G, 1, (hipStream_t)stream);
 }
 

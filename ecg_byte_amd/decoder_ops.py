@@ -207,12 +207,9 @@ def gemm_nt(a, b, out=None, alpha=1.0, accumulate_f32=False, accumulate=False, a
     if a2 is not None:
         K2 = a2.shape[1]
         assert a2.shape[0] == M and b2.shape == (N, K2) and a2.stride(1) == 1 and b2.stride(1) == 1
-        if M > 8:
-            _lib.check(_L().ecgb_gemm_nt_bf16_cat(_p(a), a.stride(0), _p(b), b.stride(0), _p(a2), a2.stride(0), _p(b2), b2.stride(0), K2,
-                                                  _p(out), out.stride(0), M, N, K, float(alpha), mode, _st()))
-            return out
-        gemm_nt(a, b, out=out, alpha=alpha, accumulate_f32=accumulate_f32, accumulate=accumulate)      # few rows (a decode step):
-        return gemm_nt(a2, b2, out=out, alpha=alpha, accumulate_f32=accumulate_f32, accumulate=not accumulate_f32)   # two launches
+        _lib.check(_L().ecgb_gemm_nt_bf16_cat(_p(a), a.stride(0), _p(b), b.stride(0), _p(a2), a2.stride(0), _p(b2), b2.stride(0), K2,
+                                              _p(out), out.stride(0), M, N, K, float(alpha), mode, _st()))      # (few rows: the decode step's kernels, one launch too)
+        return out
     _lib.check(_L().ecgb_gemm_nt_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, float(alpha),
                                       mode, 1, 0, 0, 0, _st()))
     return out

@@ -40,6 +40,24 @@ def test_gemm_nt(ops, M, N, K, tile):
         ops.set_gemm_tile(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 2560, 2048), (2, 2048, 16384), (5, 1000, 2048), (8, 16384, 2048), (8, 2048, 8192), (3, 36, 128)])
+def test_gemm_nt_few_rows_with_second_operand_pair(ops, M, N, K):
+    """A decode step with LoRA adapters: y = x W^T + t B^T for 1..8 rows is ONE launch of the column-per-wave kernels (the second pair is
+    contracted behind the first), every dispatch variant (one / four waves per column, four columns per wave), plain and accumulating."""
+    a, b = _bf(M, K, seed=121), _bf(N, K, scale=K ** -0.5, seed=122)
+    a2, b2 = _bf(M, 64, seed=123), _bf(N, 64, scale=0.1, seed=124)
+    want = a.float() @ b.float().T + a2.float() @ b2.float().T
+    got = ops.gemm_nt(a, b, a2=a2, b2=b2)
+    _close(got, want, atol=2e-2)
+    assert torch.equal(ops.gemm_nt(a, b, a2=a2, b2=b2), got)
+    base = _bf(M, N, seed=125)
+    acc = ops.gemm_nt(a, b, a2=a2, b2=b2, out=base.clone(), alpha=0.5, accumulate=True)
+    _close(acc, base.float() + 0.5 * want, atol=3e-2)
+    f32 = torch.ones((M, N), device="cuda")
+    ops.gemm_nt(a, b, a2=a2, b2=b2, out=f32, accumulate_f32=True)
+    _close(f32, 1.0 + want, atol=1e-3 * math.sqrt(K))
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 128), (300, 520, 192), (4096, 2048, 2048), (2048, 4096, 8192), (8192, 3072, 320)])
 def test_gemm_phased_schedule_is_bitwise_the_unphased_kernel(ops, M, N, K):
     """The four-phase staggered 256x256 kernel (tile 256) issues the same MFMAs in the same order per accumulator as the
