@@ -266,10 +266,29 @@ __device__ __forceinline__ void load_row_frags(bf16x8 (&f)[D / 16], const unsign
     }
 }
 // accumulator (lane = row index, registers = d) -> global [row][d]: 4 consecutive d per register group
+// 16-byte stores: a row's 8 consecutive columns are split over the two half-waves (lane i: columns 8 k .. + 3, lane i + 32: + 4 .. + 7); one
+// v_permlane32_swap per dword on the register pair of column groups (2 k, 2 k + 1) leaves lane i with group 2 k whole and lane i + 32 with group
+// 2 k + 1 whole -- half the store instructions for the same bytes (the store tail is issue-bound: cdna_hip_programming.md T21).
 template <int NB>
 __device__ __forceinline__ void store_accT(const f32x16 (&acc)[NB], unsigned short *g, long long ld, long long row, bool valid, int h, float mul)
 {
     if (!valid) return;
+    if ((ld & 7) == 0 && ((size_t)g & 15) == 0) {            // (uniform)
+        using u4 = __attribute__((ext_vector_type(4))) unsigned;
+#pragma unroll
+        for (int db = 0; db < NB; ++db)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                unsigned a0 = pack_bf16(acc[db][8 * k + 0] * mul, acc[db][8 * k + 1] * mul), a1 = pack_bf16(acc[db][8 * k + 2] * mul, acc[db][8 * k + 3] * mul);
+                unsigned b0 = pack_bf16(acc[db][8 * k + 4] * mul, acc[db][8 * k + 5] * mul), b1 = pack_bf16(acc[db][8 * k + 6] * mul, acc[db][8 * k + 7] * mul);
+                const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                u4 v;
+                v[0] = r0[0]; v[1] = r1[0]; v[2] = r0[1]; v[3] = r1[1];
+                *reinterpret_cast<u4 *>(g + row * ld + db * 32 + 16 * k + 8 * h) = v;
+            }
+        return;
+    }
 #pragma unroll
     for (int db = 0; db < NB; ++db)
 #pragma unroll
