@@ -1856,6 +1856,11 @@ int n_cus()
     }
     return n;
 }
+// Persistent workgroups own a STATIC share of the tiles and fill every CU: a kernel of another stream that holds CUs while one runs (an RCCL
+// collective under the backward of a data-parallel step) would leave the late-starting workgroups' shares to run after all the others.  The
+// input-gradient GEMMs are the ones that run beside the gradient exchange: ecgb_set_gemm_backward_persistent(0) sends them to the one-tile kernels
+// (parallel.GradAllReduce does so when it is active with more than one rank); the forward GEMMs never overlap a collective.
+int g_nn_persist = 1;
 bool persist_ok(const GemmArgs &G, int batch, bool glu)
 {
     const int KT = G.K / BK + (G.K2 > 0 ? G.K2 / BK : 0);
@@ -1913,6 +1918,12 @@ int launch_gemm(GemmArgs &G, int batch, hipStream_t stream)
 }
 
 }  // namespace
+
+extern "C" int ecgb_set_gemm_backward_persistent(int on)
+{
+    g_nn_persist = on ? 1 : 0;
+    return ECGB_OK;
+}
 
 extern "C" int ecgb_set_gemm_tile(int tile)
 {
@@ -2123,7 +2134,7 @@ extern "C" int ecgb_gemm_nn_bf16(const void *a_dev, long long lda, const void *b
     using Kern = void (*)(GemmArgs);
     Kern kern = gemm_nn_kernel_m16p<256, 256, 2, 4>;
     unsigned grid = (unsigned)(G.tiles_m * G.tiles_n);
-    if (persist_ok(G, 1, false)) { kern = gemm_nn_kernel_m16pp<0>; grid = (unsigned)n_cus(); }
+    if (g_nn_persist && persist_ok(G, 1, false)) { kern = gemm_nn_kernel_m16pp<0>; grid = (unsigned)n_cus(); }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(kern, dim3(grid, 1, 1), dim3(512), lds, (hipStream_t)stream, G);
@@ -2157,7 +2168,7 @@ extern "C" int ecgb_gemm_nn_glu_bwd_bf16(const void *dy_dev, long long lddy, con
     using Kern = void (*)(GemmArgs);
     Kern kern = gelu_tanh ? (Kern)gemm_nn_kernel_m16p<256, 256, 2, 4, 2> : (Kern)gemm_nn_kernel_m16p<256, 256, 2, 4, 1>;
     unsigned grid = (unsigned)(G.tiles_m * G.tiles_n);
-    if (persist_ok(G, 1, false) && (ldgu & 7) == 0) { kern = gelu_tanh ? (Kern)gemm_nn_kernel_m16pp<2> : (Kern)gemm_nn_kernel_m16pp<1>; grid = (unsigned)n_cus(); }
+    if (g_nn_persist && persist_ok(G, 1, false) && (ldgu & 7) == 0) { kern = gelu_tanh ? (Kern)gemm_nn_kernel_m16pp<2> : (Kern)gemm_nn_kernel_m16pp<1>; grid = (unsigned)n_cus(); }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(kern, dim3(grid, 1, 1), dim3(512), lds, (hipStream_t)stream, G);

@@ -194,6 +194,12 @@ def set_gemm_tile(tile: int):
     _lib.check(_L().ecgb_set_gemm_tile(int(tile)))
 
 
+def set_gemm_backward_persistent(on: bool):
+    """Input-gradient GEMMs with the persistent tile loop (default) or one tile per workgroup: the latter beside a gradient exchange that
+    occupies CUs (parallel.GradAllReduce turns it off for world size > 1; ecgb_set_gemm_backward_persistent)."""
+    _lib.check(_L().ecgb_set_gemm_backward_persistent(int(bool(on))))
+
+
 def gemm_nt(a, b, out=None, alpha=1.0, accumulate_f32=False, accumulate=False, a2=None, b2=None):
     """C[M,N] = alpha * A[M,K] @ B[N,K]^T.  a, b: 2-D bf16 (row stride = shape[1] or a column slice view).
     accumulate_f32: `out` is fp32 and receives +=;  accumulate: `out` is bf16 and receives +=.

@@ -77,6 +77,11 @@ class GradAllReduce:
         # world size 1 needs no exchange; `single_rank_collectives` issues the collectives anyway (the one-GPU box's test of the
         # RCCL path: communicator, async all-reduce, stream ordering against the ctypes-launched kernels)
         self.active = ok and (self.world > 1 or single_rank_collectives)
+        if self.active and self.world > 1 and torch.cuda.is_available():
+            # the collectives run beside the backward's input-gradient GEMMs and hold CUs: persistent workgroups with a static share of the tiles
+            # would wait for the late starters; one tile per workgroup degrades gracefully (include/ecgbyte_decoder.h)
+            from . import decoder_ops as _ops
+            _ops.set_gemm_backward_persistent(False)
 
     def _send(self, t):
         op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM

@@ -164,6 +164,10 @@ int ecgb_gemm_tn_bf16(const void *a_dev, long long lda, const void *b_dev, long 
  * else 128x128 / 4 waves on 32x32x16); forced: 128, 256, 257 = 256x256 on 32x32x16, 258 = 256x256 on 16x16x32
  * without the four-phase schedule (tests, tuning). */
 int ecgb_set_gemm_tile(int tile);
+/* The input-gradient GEMMs (ecgb_gemm_nn_bf16, ecgb_gemm_nn_glu_bwd_bf16) with a persistent tile loop (default, 1) or one tile per workgroup (0).
+ * Persistent workgroups hold a static share of the tiles on every CU; beside a collective that occupies CUs (the gradient exchange of a
+ * data-parallel backward) the one-tile kernels degrade gracefully where a static share would not.  parallel.GradAllReduce sets 0 for world > 1. */
+int ecgb_set_gemm_backward_persistent(int on);
 /* Same, with two-level batch addressing for attention heads: batch entry z = (zo, zi), zo = z / inner,
  * zi = z % inner; operand X starts at X + zo*outer_x + (zi / div_x)*inner_x  (div_b > 1 shares one KV head
  * among div_b query heads). */

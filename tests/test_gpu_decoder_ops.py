@@ -451,8 +451,13 @@ def test_gemm_nt_persistent_tile_loop_is_bitwise_the_one_tile_kernel(ops, M, N, 
             assert torch.equal(ops.gemm_nn(a, bn), want_nn), rep
             if want_gb is not None:
                 assert torch.equal(ops.gemm_nn_glu_bwd(a, bn, gu_in), want_gb), rep
+        ops.set_gemm_backward_persistent(False)                 # what a data-parallel run selects: the same bits from the one-tile kernels
+        assert torch.equal(ops.gemm_nn(a, bn), want_nn)
+        if want_gb is not None:
+            assert torch.equal(ops.gemm_nn_glu_bwd(a, bn, gu_in), want_gb)
     finally:
         ops.set_gemm_tile(0)
+        ops.set_gemm_backward_persistent(True)
 
 
 @pytest.mark.parametrize("gelu_tanh", [False, True])
