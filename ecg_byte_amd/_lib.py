@@ -138,6 +138,7 @@ def lib():
         "ecgb_sum_slabs_bf16": [vp, ll, ci, vp, sz, ci, vp],
         "ecgb_gemm_nn_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, vp],
         "ecgb_gemm_nn_glu_bwd_bf16": [vp, ll, vp, ll, vp, ll, vp, ll, ci, ci, ci, ci, vp],
+        "ecgb_gemm_nn_splitk_bf16": [vp, ll, vp, ll, vp, vp, ci, ci, ci, ci, f32, vp],
         "ecgb_gemm_nt_glu_bf16": [vp, ll, vp, ll, vp, ll, vp, ll, ci, vp, ll, vp, ll, ci, ci, ci, f32, ci, vp],
         "ecgb_gemm_nt_bf16_cat": [vp, ll, vp, ll, vp, ll, vp, ll, ci, vp, ll, ci, ci, ci, f32, ci, vp],
         "ecgb_layernorm_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, f32, vp],

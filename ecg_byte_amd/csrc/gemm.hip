@@ -340,7 +340,11 @@ __device__ __forceinline__ void store_tile_m16(const f32x4 (&acc)[TM][TN], const
         for (int j = 0; j < TN; ++j) {
             const int c = col0 + wc * WTN + j * 16 + lq * 4;
             if (c + 3 < G.N && (G.ldc & 3) == 0) {
-                if (G.accumulate_f32 == 1) {
+                if (G.accumulate_f32 == 3) {                      // a K-slice's fp32 partial tile, stored to its own slab (summed in slice order afterwards)
+                    float4 v;
+                    v.x = acc[i][j][0] * alpha; v.y = acc[i][j][1] * alpha; v.z = acc[i][j][2] * alpha; v.w = acc[i][j][3] * alpha;
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(G.C) + off_c + (long long)r * G.ldc + c) = v;
+                } else if (G.accumulate_f32 == 1) {
                     float4 *p = reinterpret_cast<float4 *>(reinterpret_cast<float *>(G.C) + off_c + (long long)r * G.ldc + c);
                     float4 v = *p;
                     v.x += acc[i][j][0] * alpha; v.y += acc[i][j][1] * alpha; v.z += acc[i][j][2] * alpha; v.w += acc[i][j][3] * alpha;
@@ -364,7 +368,8 @@ __device__ __forceinline__ void store_tile_m16(const f32x4 (&acc)[TM][TN], const
                 for (int t = 0; t < 4; ++t) {
                     if (c + t >= G.N) continue;
                     const float v = acc[i][j][t] * alpha;
-                    if (G.accumulate_f32 == 1) reinterpret_cast<float *>(G.C)[off_c + (long long)r * G.ldc + c + t] += v;
+                    if (G.accumulate_f32 == 3) reinterpret_cast<float *>(G.C)[off_c + (long long)r * G.ldc + c + t] = v;
+                    else if (G.accumulate_f32 == 1) reinterpret_cast<float *>(G.C)[off_c + (long long)r * G.ldc + c + t] += v;
                     else {
                         unsigned short *q = reinterpret_cast<unsigned short *>(G.C) + off_c + (long long)r * G.ldc + c + t;
                         *q = f2bf_rn(G.accumulate_f32 == 2 ? __uint_as_float((unsigned)*q << 16) + v : v);
@@ -1362,7 +1367,15 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nn_kernel_m16p(GemmArgs G)
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int KT = G.K / BK;
+    // gridDim.y > 1: the contraction is cut into K-slices (few output tiles, a long contraction: the loss head's input gradient), each workgroup stores its
+    // fp32 partial tile to its own slab (accumulate_f32 == 3), ecgb_sum_slabs_bf16 adds them in slice order
+    const int KT_all = G.K / BK, n_splits = gridDim.y, split = blockIdx.y;
+    const int kt_per = (KT_all + n_splits - 1) / n_splits, kt0 = split * kt_per;
+    const int KT = min(KT_all, kt0 + kt_per) - kt0;
+    if (KT <= 0) {                                         // an empty K-slice still owns a slab: zeros
+        store_tile_m16<TM, TN, WTM, WTN>(acc, G, row0, col0, wr, wc, lm, lq, (long long)split * G.split_stride);
+        return;
+    }
     // LDS-DMA addresses: scalar running pointers + constant per-lane byte offsets (see gemm_nt_kernel_m16p / gemm_tn_kernel_tr)
     unsigned offA[4], offB[4];
 #pragma unroll
@@ -1375,8 +1388,8 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nn_kernel_m16p(GemmArgs G)
         const int chunkb = (lane & 31) ^ (((rk & 7) << 1) ^ (rk & 8));
         offB[i] = (unsigned)(((long long)rk * G.ldb + min(col0 + chunkb * 8, G.N - 8)) * 2);      // clamped columns are never stored
     }
-    const unsigned char *nextA = reinterpret_cast<const unsigned char *>(G.A + (long long)row0 * G.lda);
-    const unsigned char *nextB = reinterpret_cast<const unsigned char *>(G.B);
+    const unsigned char *nextA = reinterpret_cast<const unsigned char *>(G.A + (long long)row0 * G.lda + (long long)kt0 * BK);
+    const unsigned char *nextB = reinterpret_cast<const unsigned char *>(G.B + (long long)kt0 * BK * G.ldb);
     auto stage_a = [&](unsigned char *dst) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1488,7 +1501,7 @@ __global__ __launch_bounds__(WGM *WGN * 64) void gemm_nn_kernel_m16p(GemmArgs G)
 #ifdef ECGB_PROFILE
     const long long tp2 = clock64();
 #endif
-    store_tile_m16<TM, TN, WTM, WTN, GB>(acc, G, row0, col0, wr, wc, lm, lq, 0, lds);
+    store_tile_m16<TM, TN, WTM, WTN, GB>(acc, G, row0, col0, wr, wc, lm, lq, (long long)split * G.split_stride, lds);
 #ifdef ECGB_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const long long tp3 = clock64();
@@ -2142,6 +2155,38 @@ extern "C" int ecgb_gemm_nn_bf16(const void *a_dev, long long lda, const void *b
     }
     if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nn_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
     return ECGB_OK;
+}
+
+// ecgb_gemm_nn_bf16 for few output tiles and a long contraction (the loss head's input gradient: 1 280 labelled rows x hidden 2048 over a vocabulary of
+// 132 608): n_splits K-slices per output tile, each into its own fp32 slab [M, N] (slabs_dev: n_splits x M x N floats, 16-byte aligned), added in slice
+// order into c_dev (bf16 [M, ldc]) -- no atomics, the same bits every launch.
+extern "C" int ecgb_sum_slabs_bf16(const float *slabs_dev, long long slab_stride, int n_slabs, void *out_dev, size_t n, int accumulate, void *stream);
+extern "C" int ecgb_gemm_nn_splitk_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, float *slabs_dev, int M, int N,
+                                        int K, int n_splits, float alpha, void *stream)
+{
+    if (!a_dev || !b_dev || !c_dev || !slabs_dev || M <= 0 || N <= 0 || K <= 0 || n_splits < 1 || n_splits > 64) { ecgb::set_error("ecgb_gemm_nn_splitk_bf16: bad argument"); return ECGB_ERR_INVALID; }
+    if (K % BK || N % 8 || N < 8 || lda % 8 || ldb % 8 || ((uintptr_t)a_dev & 15) || ((uintptr_t)b_dev & 15) || ((uintptr_t)slabs_dev & 15) ||
+        (64 * ldb + N) * 2 >= (1ll << 32) || (256 * lda + K) * 2 >= (1ll << 32)) {
+        ecgb::set_error("ecgb_gemm_nn_splitk_bf16: K % 64, N % 8, 16-byte aligned operands with strides % 8 required");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    GemmArgs G;
+    G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = slabs_dev;
+    G.M = M; G.N = N; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = N;
+    G.batch_a = G.batch_b = G.batch_c = 0;
+    G.accumulate_f32 = 3; G.alpha = alpha; G.split_stride = (long long)M * N;
+    G.A2 = G.B2 = nullptr; G.lda2 = G.ldb2 = 0; G.K2 = 0;
+    G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
+    G.tiles_m = (M + 255) / 256; G.tiles_n = (N + 255) / 256;
+    constexpr int lds = 2 * (256 + 256) * BK * 2;
+    auto kern = gemm_nn_kernel_m16p<256, 256, 2, 4>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)(G.tiles_m * G.tiles_n), (unsigned)n_splits, 1), dim3(512), lds, (hipStream_t)stream, G);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nn_kernel (K-slices): ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ecgb_sum_slabs_bf16(slabs_dev, (long long)M * N, n_splits, c_dev, (size_t)M * N, 0, stream);
 }
 
 // d(gate|up) [M, 2 inter] = ecgb_glu_bwd(gate|up, dY . W) with W = the down projection as stored ([hidden, inter] row-major): ecgb_gemm_nn_bf16 with the

@@ -458,10 +458,13 @@ class HipCausalLM(nn.Module):
             del self._t[key]
 
     def _dx(self, dy, key, p):
-        """dx = dy . W for a weight stored [out, in] (the input gradient of y = x W^T): the NN kernel reads W as it lies; shapes below its
-        256x256 tile go through the NT kernel on a transposed shadow copy (`_shadow`)."""
+        """dx = dy . W for a weight stored [out, in] (the input gradient of y = x W^T): the NN kernel reads W as it lies (K-sliced when the output has
+        few tiles and the contraction is long); shapes below its 256x256 tile go through the NT kernel on a transposed shadow copy (`_shadow`)."""
         if ops.nn_eligible(dy.shape[0], p.shape[1], p.shape[0]):
             return ops.gemm_nn(dy, p.data)
+        splits = ops.nn_splitk_plan(dy.shape[0], p.shape[1], p.shape[0])
+        if splits:                                                       # few tiles, a long contraction (the loss head: dlogits . E over the vocabulary)
+            return ops.gemm_nn_splitk(dy, p.data, splits)
         return ops.gemm_nt(dy, self._shadow(key, p))
 
     def _proj(self, i, key, x, w, training=False, keep=False):

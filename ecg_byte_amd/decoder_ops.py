@@ -239,6 +239,30 @@ def gemm_nn(a, b, out=None, alpha=1.0, accumulate_f32=False, accumulate=False):
     return out
 
 
+def nn_splitk_plan(M, N, K, n_cu=256):
+    """K-slices for gemm_nn_splitk, or 0: few 256x256 output tiles and a long contraction (the loss head's input gradient: ~1 300 labelled rows x hidden
+    over the vocabulary)."""
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if M < 256 or N < 256 or N % 8 or K % 64 or tiles >= 192:
+        return 0
+    # the slice count depends on the contraction length ALONE (about 384 K-tiles a slice: 6 slices over a 132 608-entry vocabulary): a row's sum is
+    # then formed in the same order whatever the number of rows -- the labelled-rows loss head and the full-logits one give the same bits
+    splits = min(-(-(K // 64) // 384), 64)
+    return splits if splits >= 2 else 0
+
+
+def gemm_nn_splitk(a, b, splits, alpha=1.0):
+    """C[M,N] = alpha * A[M,K] @ B[K,N] (B row-major) with the contraction in `splits` K-slices: fp32 slabs summed in slice order (ecgb_gemm_nn_splitk_bf16;
+    deterministic)."""
+    M, K = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == K and a.stride(1) == 1 and b.stride(1) == 1
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    slabs = torch.empty((splits, M, N), dtype=torch.float32, device=a.device)
+    _lib.check(_L().ecgb_gemm_nn_splitk_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), _p(slabs), M, N, K, int(splits), float(alpha), _st()))
+    return out
+
+
 def nn_glu_bwd_eligible(M, inter, K):
     """Shapes the NN kernel with the GLU backward in its epilogue takes: whole 256x256 tiles (the epilogue pairs every element of the product with
     its gate / up), enough of them to fill the chip."""

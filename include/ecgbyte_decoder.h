@@ -145,6 +145,11 @@ int ecgb_gemm_nn_bf16(const void *a_dev, long long lda, const void *b_dev, long 
  * The same bits as the two calls.  Whole 256x256 tiles only: M % 256 == 0 and inter % 256 == 0, else ECGB_ERR_UNSUPPORTED (callers take the two calls). */
 int ecgb_gemm_nn_glu_bwd_bf16(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *gate_up_dev, long long ldgu,
                               void *d_gate_up_dev, long long ldd, int M, int inter, int K, int gelu_tanh, void *stream);
+/* ecgb_gemm_nn_bf16 with the contraction cut into n_splits K-slices (few output tiles, a long contraction: the loss head's input gradient dlogits . E over the
+ * vocabulary): slice s writes its fp32 partial product to slab s of slabs_dev (n_splits x M x N floats, 16-byte aligned), the slabs are added in slice
+ * order into c_dev (bf16, contiguous [M, N]).  No atomics: the same bits every launch. */
+int ecgb_gemm_nn_splitk_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, float *slabs_dev, int M, int N, int K,
+                             int n_splits, float alpha, void *stream);
 /* The MLP's gate|up projection with the GLU in the GEMM's epilogue (modeling_llama.py:227-258
  * `down_proj(act_fn(gate_proj(x)) * up_proj(x))`; gelu_tanh != 0: Gemma's GeGLU):  gate|up [M, 2*inter] = alpha * (A . B^T
  * [+ A2 . B2^T]) with B = [2*inter, K] (gate rows, then up rows), H [M, inter] = act(gate) * up on the bf16-rounded gate and up

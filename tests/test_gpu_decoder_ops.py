@@ -477,6 +477,22 @@ def test_gemm_nn_with_glu_backward_is_bitwise_the_two_kernels(ops, M, I, K, gelu
         ops.gemm_nn_glu_bwd(dy[:1000], w, gu[:1000], gelu_tanh=gelu_tanh)
 
 
+@pytest.mark.parametrize("M,N,K", [(1280, 2048, 132608), (320, 768, 51584), (1000, 2048, 49152), (4096, 2048, 132608)])
+def test_gemm_nn_k_slices(ops, M, N, K):
+    """The input gradient of the loss head (few labelled rows x hidden, contraction over the vocabulary): K-slices into fp32 slabs, summed in slice
+    order -- against the fp32 product, the same bits every launch, ragged rows and a last slice shorter than the others."""
+    splits = ops.nn_splitk_plan(M, N, K)
+    assert splits >= 2 and ops.nn_splitk_plan(32768, 2048, 2048) == 0 and ops.nn_splitk_plan(8, 2048, 132608) == 0
+    a, b = _bf(M, K, seed=131), _bf(K, N, scale=K ** -0.5, seed=132)
+    got = ops.gemm_nn_splitk(a, b, splits)
+    _close(got, a.float() @ b.float(), atol=2e-2)
+    assert splits == ops.nn_splitk_plan(256, N, K)                     # the slicing depends on the contraction alone
+    for s in (2, 3, splits):
+        again = ops.gemm_nn_splitk(a, b, s)
+        _close(again, a.float() @ b.float(), atol=2e-2)
+        assert torch.equal(ops.gemm_nn_splitk(a, b, s), again)
+
+
 def test_embedding_scatter_sorted_is_exact_and_repeatable(ops):
     """Rows scattered into a bf16 table in sorted order (no atomics): against an fp64 index_add on top of the table's previous contents,
     heavy repeats of a few ids, a skipped padding id, and the same bits on every call."""
