@@ -513,6 +513,7 @@ def main():
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 object (Gemma-2B dims LoRA step + generate)")
     ap.add_argument("--no-c1", action="store_true", help="skip the C1 object (12x1000 records + GPT-2-small forward, batch 4)")
     ap.add_argument("--no-lora-leg", action="store_true", help="full fine-tune leg only (profiling: one mode per kernel trace)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra objects of the line (batch sweep, tokenizer trainer, offline conditioning, full-logits leg)")
     ap.add_argument("--lora", action="store_true", help="train LoRA adapters (r16, alpha 32, dropout 0.05; frozen base) as the reference's script does")
     args = ap.parse_args()
 

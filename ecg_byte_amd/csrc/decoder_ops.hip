@@ -93,13 +93,15 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const long long *ids, co
 // arrive sorted by id (ids_sorted, order = the stable argsort), workgroup i owns the run of equal ids that STARTS at sorted position i (the
 // others return at once) and adds the run's rows in sorted order, in fp32, on top of what the table row already holds (the tied lm_head's
 // gradient) -- the same bits every launch.  skip_id: nn.Embedding's padding_idx, whose row takes no gradient from the lookup
-// (modeling_llama.py:889); it is also by far the longest run of a left-padded batch.
+// (modeling_llama.py:889); it is also by far the longest run of a left-padded batch.  Negative ids are skipped too: the callers replace the
+// id of every position whose attention mask is 0 by -1 (the gradient of such a row is exactly zero), so that the padding run -- thousands of
+// rows that ONE workgroup would sum serially at the tail of the backward -- costs nothing whether or not the model declares a padding_idx.
 __global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const long long *ids_sorted, const long long *order, const unsigned short *dout,
                                                                unsigned short *table, size_t T, int H, float scale, long long skip_id)
 {
     const size_t i = blockIdx.x;
     const long long id = ids_sorted[i];
-    if (id == skip_id || (i > 0 && ids_sorted[i - 1] == id)) return;
+    if (id == skip_id || id < 0 || (i > 0 && ids_sorted[i - 1] == id)) return;   // id < 0: a row the caller masked out (attention mask 0: its gradient is exactly zero)
     size_t end = i + 1;
     while (end < T && ids_sorted[end] == id) ++end;
     for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {

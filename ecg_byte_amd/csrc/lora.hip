@@ -618,14 +618,19 @@ extern "C" int ecgb_lora_da(const void *x_dev, const void *dt_dev, void *da_dev,
     const dim3 grid((unsigned)((in + 255) / 256), (unsigned)n_chunks);
     constexpr unsigned kLds = 2 * (64 * 512 + 64 * 128);
     const int key = n_sub * 8 + n_fields;
+    bool launched = false;
 #define ECGB_DA_CASE(NS, NFI)                                                                                                    \
     if (key == NS * 8 + NFI) {                                                                                                   \
-        (void)hipFuncSetAttribute((const void *)lora_da_kernel<NS, NFI>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);                  \
+        const hipError_t ea = hipFuncSetAttribute((const void *)lora_da_kernel<NS, NFI>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); \
+        if (ea != hipSuccess) { ecgb::set_error(std::string("lora_da_kernel: hipFuncSetAttribute: ") + hipGetErrorString(ea)); return ECGB_ERR_HIP; } \
         hipLaunchKernelGGL((lora_da_kernel<NS, NFI>), grid, dim3(256), kLds, (hipStream_t)stream, L);                            \
+        launched = true;                                                                                                         \
     }
     ECGB_DA_CASE(1, 1) else ECGB_DA_CASE(2, 1) else ECGB_DA_CASE(2, 2) else ECGB_DA_CASE(3, 1) else ECGB_DA_CASE(3, 3)
     else ECGB_DA_CASE(4, 1) else ECGB_DA_CASE(4, 2) else ECGB_DA_CASE(4, 4)
 #undef ECGB_DA_CASE
+    // no template case for this (n_sub, n_fields): nothing was launched, and summing the slabs would reduce uninitialised memory into A.grad
+    if (!launched) { ecgb::set_error("ecgb_lora_da: unsupported (n_sub, n_fields) combination"); return ECGB_ERR_UNSUPPORTED; }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ecgb::set_error(std::string("lora_da_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
     return ecgb_sum_slabs_bf16((const float *)scratch_dev, (long long)16 * n_sub * in, n_chunks, da_dev, (size_t)16 * n_sub * in, accumulate, stream);

@@ -69,10 +69,10 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
         bool used[256] = { false };
         for (size_t i = 0; i < n_merges; ++i) {
             if (offsets[i + 1] < offsets[i]) { delete tok; set_error("ecgb_tokenizer_create: offsets not monotone"); return ECGB_ERR_INVALID; }
-            for (uint32_t k = offsets[i]; k < offsets[i + 1]; ++k) {
-                if (flat_bytes[k] > 255u) { delete tok; set_error("ecgb_tokenizer_create: expansion element > 255"); return ECGB_ERR_INVALID; }
-                used[flat_bytes[k]] = true;
-            }
+            // An element > 255 is accepted as the reference accepts it (lib.rs:140-146 keys children by u32): no input byte
+            // ever follows that edge, so everything from it on -- the entry's token included -- is unreachable.  Only the
+            // prefix in front of it adds (token-less) nodes.
+            for (uint32_t k = offsets[i]; k < offsets[i + 1] && flat_bytes[k] <= 255u; ++k) used[flat_bytes[k]] = true;
         }
         for (uint32_t b = 0; b < 256; ++b) {
             if (!used[b] || tok->byte_to_class[b] != kOtherClass) continue;
@@ -108,8 +108,23 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
             uint32_t b = tok->class_to_byte[c];
             insert(&b, 1, b);
         }
-        for (size_t i = 0; i < n_merges; ++i)
-            insert(flat_bytes + offsets[i], offsets[i + 1] - offsets[i], ids[i]);
+        auto walk_only = [&](const uint32_t *seq, size_t len) {   // the reachable prefix of an entry with an element > 255
+            int32_t node = 0;
+            for (size_t k = 0; k < len; ++k) {
+                const uint8_t cls = tok->byte_to_class[seq[k]];
+                int32_t ch = bn[node].child[cls];
+                if (ch < 0) { ch = (int32_t)bn.size(); bn[node].child[cls] = ch; bn.emplace_back(); }
+                node = ch;
+            }
+        };
+        for (size_t i = 0; i < n_merges; ++i) {
+            const uint32_t *seq = flat_bytes + offsets[i];
+            const size_t len = offsets[i + 1] - offsets[i];
+            size_t reach = 0;
+            while (reach < len && seq[reach] <= 255u) ++reach;
+            if (reach == len) insert(seq, len, ids[i]);
+            else walk_only(seq, reach);
+        }
 
         if (bn.size() >= 65535) {
             delete tok;

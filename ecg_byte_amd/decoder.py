@@ -88,6 +88,11 @@ def rope_inv_freq(cfg: DecoderConfig) -> torch.Tensor:
     return torch.where(is_medium, smoothed, inv_freq_llama)
 
 
+def _dp_rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 class LoraSite(nn.Module):
     """LoRA adapters of one (possibly fused) projection, as peft's LoraLayer computes them
     (ecg_byte/main.py:131-155: r 16, alpha 32, dropout 0.05 on q,k,v,o,gate,up,down):
@@ -137,8 +142,11 @@ class LoraSite(nn.Module):
         (gate|up or None, act(gate) * up)."""
         p, seed = 0.0, 0
         if training and self.p > 0:
+            # One mask stream per (site, rank, call): data-parallel ranks draw DIFFERENT masks (torch's per-process generators give the
+            # reference's DDP ranks different dropout too); `calls` restarts at 0 with a new process -- the reference never resumes
+            # training (SURVEY.md section 5) -- and HipCausalLM.lora_rng_state() / set_lora_rng_state() carry it across a checkpoint.
             self.calls += 1
-            p, seed = self.p, self.seed + 7919 * self.calls
+            p, seed = self.p, (self.seed + 7919 * self.calls + 104729 * _dp_rank()) & 0x7FFFFFFF
         if x.shape[0] <= 8 and p == 0.0:            # a decode step: the few-row GEMM reads A once at HBM speed
             t, xd = ops.gemm_nt(x, self.A.data, alpha=self.scale), None
         else:
@@ -356,6 +364,16 @@ class HipCausalLM(nn.Module):
             }))
         self.lora = sites
         return self
+
+    def lora_rng_state(self):
+        """Dropout stream positions of every adapter site (save beside a checkpoint to continue an interrupted run with the mask sequence
+        it would have drawn; the reference has no training resume, so its checkpoint format has no slot for this)."""
+        return [[layer[k].calls for k in ("qkv", "o", "gu", "down")] for layer in self.lora] if self.lora is not None else None
+
+    def set_lora_rng_state(self, state):
+        for layer, row in zip(self.lora, state):
+            for k, n in zip(("qkv", "o", "gu", "down"), row):
+                layer[k].calls = int(n)
 
     def lora_named(self):
         """(peft-style name, tensor) pairs of the adapter weights: lora_A [r, in], lora_B [out, r]."""
@@ -975,6 +993,12 @@ class HipCausalLM(nn.Module):
 
     # ---- backward -------------------------------------------------------------------------------
     def _backward(self, grad_out):
+        if self.grad_sync is not None and hasattr(self.grad_sync, "backward_kernels"):
+            with self.grad_sync.backward_kernels():     # one-tile input-gradient GEMMs only while a gradient exchange can be in flight
+                return self._backward_impl(grad_out)
+        return self._backward_impl(grad_out)
+
+    def _backward_impl(self, grad_out):
         c = self.cfg
         H, I, D, Hq, Hkv = c.hidden_size, c.intermediate_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
         G = Hq // Hkv
@@ -1055,7 +1079,8 @@ class HipCausalLM(nn.Module):
                 self.grad_sync.on_flat_ready(self._gflat, *self._granges[L - 1 - i])
         if not frozen:
             pad = c.pad_token_id if c.pad_token_id is not None else -1       # nn.Embedding(padding_idx): no lookup gradient for that row
-            self._embedding_grad(self.embed, self.embed_grad_head, input_ids.view(-1), g, self.embed_scale, pad)
+            live_ids = input_ids.view(-1).masked_fill(mask.reshape(-1) == 0, -1)   # masked positions: gradient exactly zero, skipped as one run
+            self._embedding_grad(self.embed, self.embed_grad_head, live_ids, g, self.embed_scale, pad)
         if self.grad_sync is not None:
             if not frozen:
                 self.grad_sync.on_flat_ready(self._gflat, *self._granges[L])

@@ -251,6 +251,12 @@ class HipGPT2LM(HipCausalLM):
         return loss.squeeze(0)
 
     def _backward(self, grad_out):
+        if self.grad_sync is not None and hasattr(self.grad_sync, "backward_kernels"):
+            with self.grad_sync.backward_kernels():     # one-tile input-gradient GEMMs only while a gradient exchange can be in flight
+                return self._backward_impl(grad_out)
+        return self._backward_impl(grad_out)
+
+    def _backward_impl(self, grad_out):
         c = self.cfg
         H, nh, D = c.n_embd, c.n_head, c.head_dim
         saved, input_ids, position_ids, mask, (xf, muf, rsf), dhf, (B, S), seed_e = self._saved
@@ -306,8 +312,9 @@ class HipGPT2LM(HipCausalLM):
             if self.grad_sync is not None:
                 self.grad_sync.on_flat_ready(self._gflat, *self._granges[L - 1 - i])
         g = undrop(g, c.embd_pdrop, seed_e)
-        self._embedding_grad(self.embed, self.embed_grad_head, input_ids.view(-1), g, 1.0, -1)     # GPT-2's wte has no padding_idx
-        self._embedding_grad(self.wpe, None, position_ids.reshape(-1).contiguous(), g, 1.0, -1)
+        dead = mask.reshape(-1) == 0     # masked positions: gradient exactly zero -- skipped instead of summed by one workgroup as one long run
+        self._embedding_grad(self.embed, self.embed_grad_head, input_ids.view(-1).masked_fill(dead, -1), g, 1.0, -1)     # GPT-2's wte has no padding_idx
+        self._embedding_grad(self.wpe, None, position_ids.reshape(-1).masked_fill(dead, -1).contiguous(), g, 1.0, -1)
         if self.grad_sync is not None:
             self.grad_sync.on_flat_ready(self._gflat, *self._granges[L])
             self.grad_sync.finish()

@@ -1,14 +1,17 @@
 """Mirror of ecg_byte/main.py (the trainer / inference CLI of the end-to-end path): same options, same
 directory conventions, same checkpoint and result files, with the hot path on the MI355X:
 
+    python -m ecg_byte_amd.main --dis --gpus 0,1,2,3 --ports 12359 --model <dir> --dataset ptb_500 ...      (the reference's launch)
     python -m torch.distributed.run --nproc-per-node N -m ecg_byte_amd.main --dis --model <dir> --dataset ptb_500 ...
     python -m ecg_byte_amd.main --device cuda:0 --model <dir> --dataset ptb_500 --tokenizer_check tokenizer_3500_300000 ...
 
 Differences from the reference, all deliberate:
   * `--model` is a LOCAL directory in the hub layout (config.json, model.safetensors, tokenizer files); nothing is
     downloaded and no API key is read (main.py:82-87 logs in to the hub);
-  * distributed runs are one process per GPU started by torchrun (RANK / LOCAL_RANK / WORLD_SIZE), RCCL backend,
-    rendezvous from the environment, instead of mp.spawn with --gpus/--ports (main.py:57-63, 338-345);
+  * distributed runs are one process per GPU over RCCL, started EITHER way: by torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the
+    environment), or -- with no RANK in the environment -- by this module itself exactly as the reference does it
+    (`--dis --gpus 0,1,2,3 --ports P`: mp.spawn of one child per listed GPU before any GPU call, main.py:57-63, 356-360), so
+    scripts/train_model.sh runs with only the module name changed;
   * `--data_root` / `--runs_root` (defaults: the reference's ./data and ./runs) say where the files live;
   * the decoder is decoder.HipCausalLM (Llama family only), LoRA is decoder.LoraSite, the optimizer decoder.HipAdam
     (Adam + L2 + Noam schedule + clip 1.0 in one kernel), batches come from data_loader.DeviceBatchLoader;
@@ -118,6 +121,58 @@ def _inference(args, model, tokenizer, vocab, merges, data, device):
     return stats_results
 
 
+def init_distributed(args):
+    """setup(), main.py:57-60 + 68-73: this process is rank RANK of WORLD_SIZE on GPU LOCAL_RANK; RCCL (backend "nccl") process group with
+    the rendezvous of the environment.  Both launchers end here: torchrun sets the variables itself, `spawn_ranks` sets them per child."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    backend = os.environ.get("ECGB_MAIN_BACKEND", "nccl")                   # "gloo": the CPU tests of the launch path
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")               # this pool's driver supports dmabuf IPC only
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        args.device = torch.device(f"cuda:{local_rank}")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=args.device)      # RCCL
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def _probe(rank, world, local_rank):
+    """Test hook: one all-reduce over the group just built, then a JSON record of what this rank saw."""
+    t = torch.tensor([float(rank + 1)])
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t)
+    rec = {"rank": rank, "world": world, "local_rank": local_rank, "master_port": os.environ.get("MASTER_PORT"),
+           "master_addr": os.environ.get("MASTER_ADDR"), "sum": float(t.item()), "pid": os.getpid(), "ppid": os.getppid()}
+    with open(f"{os.environ['ECGB_MAIN_PROBE']}_{rank}.json", "w") as f:
+        json.dump(rec, f)
+    dist.destroy_process_group()
+    return rec
+
+
+def _spawned(rank, world, gpu_ids, port, argv):
+    """Child of spawn_ranks: rank `rank` drives GPU gpu_ids[rank] (main.py:68-69) and meets the others on `port` (main.py:57-59)."""
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+    os.environ["LOCAL_RANK"] = str(gpu_ids[rank])
+    os.environ["MASTER_ADDR"] = "127.0.0.1"          # the reference says 'localhost'; the loopback address needs no resolver
+    os.environ["MASTER_PORT"] = str(port)
+    main(argv)
+
+
+def spawn_ranks(args, argv=None):
+    """mp.spawn(main, args=(world_size,), nprocs=world_size, join=True) of main.py:356-360: world size = number of ids in --gpus, start
+    method "spawn", one child per listed GPU.  The parent has made no GPU call when it gets here (argument parsing only), so the
+    children initialise HIP / RCCL in fresh processes; it waits for all of them and re-raises the first failure."""
+    import sys
+    import torch.multiprocessing as mp
+    gpu_ids = [int(i) for i in args.gpus.split(",")]
+    world = len(gpu_ids)
+    child_argv = list(sys.argv[1:] if argv is None else argv)
+    mp.spawn(_spawned, args=(world, gpu_ids, args.ports, child_argv), nprocs=world, join=True)
+    return {"spawned": world, "gpus": gpu_ids, "port": args.ports}
+
+
 def main(argv=None):
     from .data_loader import DeviceBatchLoader, ECGTokenDataset
     from .file_utils import align_signal_text_files, ensure_directory_exists, load_vocab_and_merges, sample_N_percent_from_lists
@@ -127,11 +182,12 @@ def main(argv=None):
     args = get_args(argv)
     rank, world = 0, 1
     if args.dis:
-        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-        local_rank = int(os.environ.get("LOCAL_RANK", rank))
-        torch.cuda.set_device(local_rank)
-        args.device = torch.device(f"cuda:{local_rank}")
-        dist.init_process_group("nccl", rank=rank, world_size=world)      # RCCL
+        if "RANK" not in os.environ:
+            # the reference's own launch (main.py:356-360): `python main.py --dis --gpus 0,1,2,3 --ports P` spawns one process per listed GPU
+            return spawn_ranks(args, argv)
+        rank, world, local_rank = init_distributed(args)
+        if os.environ.get("ECGB_MAIN_PROBE"):                               # test hook (tests/test_dist_cpu.py): rendezvous only
+            return _probe(rank, world, local_rank)
     device = torch.device(args.device or "cuda:0")
     if device.type == "cuda":
         # every ctypes-launched kernel goes to torch's CURRENT stream of the CURRENT device: `--device cuda:N` must make N current

@@ -77,11 +77,29 @@ class GradAllReduce:
         # world size 1 needs no exchange; `single_rank_collectives` issues the collectives anyway (the one-GPU box's test of the
         # RCCL path: communicator, async all-reduce, stream ordering against the ctypes-launched kernels)
         self.active = ok and (self.world > 1 or single_rank_collectives)
-        if self.active and self.world > 1 and torch.cuda.is_available():
-            # the collectives run beside the backward's input-gradient GEMMs and hold CUs: persistent workgroups with a static share of the tiles
-            # would wait for the late starters; one tile per workgroup degrades gracefully (include/ecgbyte_decoder.h)
+        # The collectives run beside the backward's input-gradient GEMMs and hold CUs: persistent workgroups with a static share of the
+        # tiles would wait for the late starters; one tile per workgroup degrades gracefully (include/ecgbyte_decoder.h).  The switch is
+        # process-global in the C library, so it is NOT set here: the model's backward turns it off for the duration of a backward pass
+        # with an active exchange and restores it (`backward_kernels()`), and later models / evaluation in the process keep the
+        # persistent kernels.  The one-rank RCCL leg (`single_rank_collectives`) makes the same choice as world > 1.
+        self.one_tile_backward = bool(self.active and torch.cuda.is_available())
+
+    def backward_kernels(self):
+        """Context manager for one backward pass: one-tile input-gradient GEMMs while an exchange can be in flight."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            if not self.one_tile_backward:
+                yield
+                return
             from . import decoder_ops as _ops
             _ops.set_gemm_backward_persistent(False)
+            try:
+                yield
+            finally:
+                _ops.set_gemm_backward_persistent(True)
+        return scope()
 
     def _send(self, t):
         op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM

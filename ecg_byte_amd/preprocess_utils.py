@@ -109,11 +109,27 @@ def wavelet_denoise(ecg_data, wavelet='db6', level=4, epsilon=1e-10):
     return out[0] if single else out
 
 
-def condition_records(signals, reorder=True, seg_len=1250, orig_fs=500, target_fs=250):
+def condition_records(signals, reorder=True, seg_len=1250, orig_fs=500, target_fs=250, return_kept=False):
     """process_instance, preprocess_utils.py:118-160, for a BATCH of raw records [records, n, 12] already on the device (reading wfdb
-    files stays with the caller): NaN/inf -> 0, MIMIC lead order, the filter chain, wavelet shrinkage, resampling to target_fs, whole
-    segments of seg_len samples.  Returns [records, segments, seg_len, 12]; records that still hold NaN / inf are the caller's to drop
-    (`torch.isfinite(out).all(dim=(1, 2, 3))`), as the reference skips them."""
+    files stays with the caller): MIMIC lead order, the filter chain, wavelet shrinkage, resampling to target_fs, whole segments of
+    seg_len samples, NaN/inf -> 0 after every stage (check_nan_inf).
+
+    A record whose RAW signal holds a NaN or an infinity is skipped, as the reference skips it (preprocess_utils.py:134-136 returns
+    None before the first check_nan_inf can zero-fill it): it is not in the output.  The reference's second test, after the last
+    check_nan_inf (157-159), can never fire -- the array has just been made finite -- and is reproduced by construction.
+    Returns [kept records, segments, seg_len, 12]; with return_kept=True also the bool mask [records] of the records kept, so the
+    caller can drop the matching text entries."""
+    if signals.dim() != 3:
+        raise ValueError("condition_records takes a batch [records, n, leads]")
+    kept = torch.isfinite(signals).all(dim=2).all(dim=1)
+    n_bad = int((~kept).sum().item())
+    if n_bad:
+        print(f"Warning: NaN values detected in {n_bad} record(s). Skipping these instances.")
+        signals = signals[kept]
+    if signals.shape[0] == 0:
+        n_out = int(signals.shape[1] * target_fs / orig_fs)
+        seg = signals.new_zeros((0, n_out // seg_len, seg_len, signals.shape[2]))
+        return (seg, kept) if return_kept else seg
     x = check_nan_inf(signals, "reading")
     if reorder:
         x = check_nan_inf(reorder_indices(x).contiguous(), "reordering")
@@ -121,7 +137,8 @@ def condition_records(signals, reorder=True, seg_len=1250, orig_fs=500, target_f
     x = check_nan_inf(wavelet_denoise(x), "wavelet denoising")
     x = check_nan_inf(nsample_ecg(x, orig_fs, target_fs), "resampling")
     seg, _ = segment_ecg(x, None, seg_len)
-    return check_nan_inf(seg, "segmentation")
+    seg = check_nan_inf(seg, "segmentation")
+    return (seg, kept) if return_kept else seg
 
 
 def nsample_ecg(ecg_data, orig_fs, target_fs):

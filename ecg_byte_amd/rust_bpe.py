@@ -18,25 +18,32 @@ _CACHE: dict = {}
 _CACHE_MAX = 8
 
 
-def _fingerprint(merges):
-    n = len(merges)
-    if n == 0:
-        return (0,)
-    return (n, merges[0][1], merges[-1][1], len(merges[0][0]), len(merges[-1][0]), merges[n // 2][1])
+def _content_key(merges) -> bytes:
+    """Digest of the WHOLE list (every expansion element and id).  The reference rebuilds its trie from `merges` on every call
+    (lib.rs:153-161), so any mutation -- a replaced entry, an inner list edited in place -- is honoured there; a cache keyed on the
+    object's identity or on a few sampled fields would keep serving the stale trie.  Serialising 4 000 entries and hashing them takes
+    ~1.5 ms, less than the reference's own per-call rebuild."""
+    import hashlib
+    import marshal
+    try:
+        blob = marshal.dumps(merges)
+    except ValueError:           # numpy integers and other non-marshallable element types
+        import pickle
+        blob = pickle.dumps([(list(map(int, seq)), int(tid)) for seq, tid in merges], protocol=5)
+    return hashlib.blake2b(blob, digest_size=16).digest()
 
 
 def tokenizer_for(merges) -> HipTokenizer:
-    """The reference rebuilds the trie on every encode_text call (lib.rs:153-161); here the
-    device handle is cached per merges object."""
-    key = id(merges)
-    hit = _CACHE.get(key)
-    fp = _fingerprint(merges)
-    if hit is not None and hit[0] is merges and hit[1] == fp:
-        return hit[2]
+    """The reference rebuilds the trie on every encode_text call (lib.rs:153-161); here the device handle is cached per CONTENT of
+    the merges list."""
+    key = _content_key(merges)
+    tk = _CACHE.get(key)
+    if tk is not None:
+        return tk
     tk = HipTokenizer(merges)
     if len(_CACHE) >= _CACHE_MAX:
         _CACHE.pop(next(iter(_CACHE)))
-    _CACHE[key] = (merges, fp, tk)   # holding `merges` keeps id() from being recycled
+    _CACHE[key] = tk
     return tk
 
 

@@ -212,7 +212,8 @@ uint32_t ecgb_oracle_bpe_train(uint32_t *ids_io, size_t *n_io, uint32_t num_merg
  *             token_id, emit it and advance by its length; no match -> emit the raw id.
  * ---------------------------------------------------------------------------------- */
 typedef struct {
-    uint64_t *ekeys;    /* (node<<8)|byte, UINT64_MAX empty */
+    uint64_t *ekeys;    /* (node<<32)|element: the reference keys children by u32 (lib.rs:128), so an expansion element
+                           > 255 is its own edge -- a node no input byte reaches -- and never aliases a byte edge; UINT64_MAX empty */
     uint32_t *echild;
     size_t ecap, elen;
     int64_t *token;     /* per node, -1 = None */
@@ -235,7 +236,7 @@ static void trie_free(trie *t) { free(t->ekeys); free(t->echild); free(t->token)
 
 static int64_t trie_child(const trie *t, uint32_t node, uint32_t byte)
 {
-    uint64_t key = ((uint64_t)node << 8) | byte;
+    uint64_t key = ((uint64_t)node << 32) | byte;
     size_t h = (size_t)mix64(key) & (t->ecap - 1);
     while (t->ekeys[h] != UINT64_MAX) {
         if (t->ekeys[h] == key) return t->echild[h];
@@ -275,7 +276,7 @@ static int trie_insert(trie *t, const uint32_t *seq, size_t len, uint32_t token_
                 if (!nt) return -1;
                 t->token = nt; t->ncap = nc;
             }
-            uint64_t key = ((uint64_t)node << 8) | seq[i];
+            uint64_t key = ((uint64_t)node << 32) | seq[i];
             size_t h = (size_t)mix64(key) & (t->ecap - 1);
             while (t->ekeys[h] != UINT64_MAX) h = (h + 1) & (t->ecap - 1);
             t->ekeys[h] = key; t->echild[h] = (uint32_t)t->n_nodes; t->elen++;

@@ -13,6 +13,8 @@ import torch.multiprocessing as mp
 
 from helpers import load_tokenizer
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     with socket.socket() as s:
@@ -193,3 +195,49 @@ def test_sharded_bpe_trainer_protocol_equals_the_single_process_trainer(world):
             assert O.pairs_to_vocab_merges([tuple(p) for p in ret[r][c][1]])[1] == want_merges, (c, r, text, cuts, nm)
         assert got_ids == want_ids, (c, text, cuts, nm)
 
+
+
+@pytest.mark.timeout(300)
+def test_main_dis_without_rank_spawns_one_child_per_listed_gpu(tmp_path):
+    """The reference's own launch (ecg_byte/main.py:356-360, scripts/train_model.sh:6-18): `main --dis --gpus 0,1,2 --ports P` with no RANK
+    in the environment must mp.spawn one child per listed GPU -- rank r on GPU gpus[r], rendezvous on port P -- from a parent that has
+    made no GPU call.  The children run the gloo hook (ECGB_MAIN_BACKEND / ECGB_MAIN_PROBE): rendezvous + one all-reduce, no model."""
+    import json
+    import subprocess
+    import sys
+    port = _free_port()
+    probe = str(tmp_path / "probe")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ECGB_MAIN_BACKEND="gloo", ECGB_MAIN_PROBE=probe, PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "ecg_byte_amd.main", "--dis", "--gpus", "2,0,3", "--ports", str(port), "--model", "none",
+           "--tokenizer_check", "none", "--peft", "--batch_size", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    recs = [json.load(open(f"{probe}_{k}.json")) for k in range(3)]
+    assert [x["rank"] for x in recs] == [0, 1, 2] and all(x["world"] == 3 for x in recs)
+    assert [x["local_rank"] for x in recs] == [2, 0, 3]                    # local_rank = gpu_ids[rank], main.py:68-69
+    assert all(x["master_port"] == str(port) for x in recs)
+    assert all(x["sum"] == 6.0 for x in recs)                             # 1 + 2 + 3: the three children really met
+    assert len({x["pid"] for x in recs}) == 3 and len({x["ppid"] for x in recs}) == 1
+
+
+@pytest.mark.timeout(300)
+def test_main_dis_under_torchrun_environment_still_initialises_from_it(tmp_path):
+    """The torchrun path: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* already in the environment -> no spawn, the process IS the rank."""
+    import json
+    import subprocess
+    import sys
+    port = _free_port()
+    probe = str(tmp_path / "probe")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, ECGB_MAIN_BACKEND="gloo", ECGB_MAIN_PROBE=probe, PYTHONPATH=ROOT, RANK=str(rank), WORLD_SIZE="2",
+                   LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-m", "ecg_byte_amd.main", "--dis", "--model", "none", "--tokenizer_check", "none"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(tmp_path)))
+    for p in procs:
+        out, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-2000:]
+    recs = [json.load(open(f"{probe}_{k}.json")) for k in range(2)]
+    assert [x["local_rank"] for x in recs] == [0, 1] and all(x["sum"] == 3.0 and x["world"] == 2 for x in recs)
+    assert len({x["ppid"] for x in recs}) == 1 and recs[0]["ppid"] == os.getpid()       # no intermediate spawner

@@ -109,6 +109,21 @@ def test_condition_records_is_the_reference_pipeline(pp):
         assert np.abs(got[r] - want).max() <= 1e-9 * np.abs(want).max()
 
 
+def test_records_with_nan_or_inf_in_the_raw_signal_are_skipped_like_the_reference(pp):
+    """preprocess_utils.py:134-136: an instance whose raw signal holds NaN / inf is skipped before check_nan_inf could zero-fill it."""
+    x = _records(4, 5000, seed=5)
+    bad = x.copy()
+    bad[1, 17, 3] = np.nan
+    bad[3, 4000, 11] = np.inf
+    clean = pp.condition_records(torch.from_numpy(x).cuda(), reorder=True, seg_len=1250)
+    got, kept = pp.condition_records(torch.from_numpy(bad).cuda(), reorder=True, seg_len=1250, return_kept=True)
+    assert kept.cpu().tolist() == [True, False, True, False]
+    assert got.shape == (2, 2, 1250, 12) and bool(torch.isfinite(got).all())
+    assert torch.equal(got, clean[[0, 2]])                                  # the kept records are untouched by their neighbours
+    none, kept = pp.condition_records(torch.from_numpy(bad[[1, 3]]).cuda(), return_kept=True)
+    assert none.shape == (0, 2, 1250, 12) and not bool(kept.any())
+
+
 def test_short_signals_are_refused_like_scipy(pp):
     from ecg_byte_amd._lib import EcgbError
     with pytest.raises(EcgbError):

@@ -194,8 +194,46 @@ def test_tokenizer_limits_are_reported(lib):
     assert rc == -3 and b"29 distinct" in lib.ecgb_last_error()
     rc, h = _make_tok(lib, [([97, 98], 70000)])                        # token id does not fit
     assert rc == -3
-    rc, h = _make_tok(lib, [([97, 300], 256)])                         # not a byte
-    assert rc == -1
+
+
+def test_expansion_elements_above_255_are_unreachable_nodes_like_the_reference(lib):
+    """lib.rs:140-146 keys trie children by u32: an expansion element > 255 is an edge no input byte follows, so the entry's
+    token can never be emitted, but the prefix in front of it still adds (token-less) interior nodes.  The handle accepts such a
+    list and parses exactly like the oracle, whose edge key is (node << 32) | element (no aliasing with byte edges: with the old
+    (node << 8) | byte key, element 300 = 0x12C under node n aliased byte 0x2C under node n + 1)."""
+    merges = [([97, 98], 256), ([97, 300], 257), ([97, 98, 99, 400, 100], 258), ([98, 99], 259), ([97, 98, 99], 260),
+              ([0x12C], 261), ([97, 0x161], 262)]
+    rc, h = _make_tok(lib, merges)
+    assert rc == 0, lib.ecgb_last_error()
+    nodes = _nodes(lib, h)
+    lib.ecgb_tokenizer_destroy(h)
+    lens = _lens([m for m in merges if max(m[0]) <= 255])
+    b2c = _classes([m for m in merges if max(m[0]) <= 255])
+    from oracle import lib_rs_literal as R
+    for text in ("abcabd", "aabbcc", "abc,abc", "a,bca", "ab" * 9 + "c", "abca"):
+        ref = O.encode_text(text, merges)
+        assert ref == R.encode_text(text, merges)
+        assert 257 not in ref and 258 not in ref and 261 not in ref and 262 not in ref
+        assert _walk_packed(nodes, b2c, text.encode(), lens) == ref, text
+
+
+def test_rust_bpe_cache_honours_in_place_edits_of_the_merges_list():
+    """The reference rebuilds its trie from `merges` on every call (lib.rs:153-161): an edit of a middle entry -- even of an inner
+    list, in place -- must not be served from a stale handle."""
+    from ecg_byte_amd import rust_bpe
+    merges = [([97, 97], 256), ([97, 98], 257), ([98, 98], 258), ([97, 97, 98], 259), ([99, 99], 260), ([98, 99], 261), ([100, 100], 262)]
+    t0 = rust_bpe.tokenizer_for(merges)
+    assert rust_bpe.tokenizer_for(merges) is t0                       # unchanged content: cached
+    assert rust_bpe.tokenizer_for([(list(s), i) for s, i in merges]) is t0   # an equal copy too
+    n0 = t0.nodes().copy()
+    merges[3][0][2] = 97                                              # inner list of a middle entry, in place: aab -> aaa
+    t1 = rust_bpe.tokenizer_for(merges)
+    assert t1 is not t0 and not np.array_equal(t1.nodes(), n0)
+    merges[2] = ([98, 98, 98], 258)                                   # a replaced middle entry
+    t2 = rust_bpe.tokenizer_for(merges)
+    assert t2 is not t1 and t2.n_nodes == t1.n_nodes + 1
+    npm = [(np.array(s, dtype=np.uint32), np.int64(i)) for s, i in merges]   # numpy element types take the pickle path
+    assert rust_bpe.tokenizer_for(npm).n_nodes == t2.n_nodes
 
 
 def test_device_entry_points_fail_loudly_without_gpu(lib):
