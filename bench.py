@@ -249,6 +249,110 @@ def hbm_kernel_report(dev, B, S, cfg, n_vocab, reps=10):
     return out
 
 
+def bench_batch_sweep(tk, pc, xd, L, sizes=(1, 64, 1024, 4096), reps=20):
+    """the fused quantise + encode launch over B in {1, 64, 1024, 4096} records (inputs resident, HIP events on the launch stream)."""
+    import torch
+    n = 12 * L
+    out = []
+    for B in sizes:
+        if B > xd.shape[0]:
+            continue
+        x = xd[:B]
+        ids = torch.empty((B, n), dtype=torch.int32, device=xd.device)
+        counts = torch.empty((B,), dtype=torch.int32, device=xd.device)
+        for _ in range(3):
+            tk.quantize_encode(x, pc, ids_stride=n, out=(ids, counts))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            tk.quantize_encode(x, pc, ids_stride=n, out=(ids, counts))
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        toks = int(counts.sum().item())
+        alg = B * 8 * n + 4 * toks
+        out.append({"records": B, "ms_per_launch": ms, "tokens_per_s": toks / (ms * 1e-3), "symbols_per_s": B * n / (ms * 1e-3),
+                    "GB/s": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    return out
+
+
+def bench_trainer(pc, L, x, num_merges=4000):
+    """rust_bpe.byte_pair_encoding on the device for the C2 tokenizer's own corpus (2 000 synthetic records, seed 1).
+    Algorithmic bytes per merge i: 4 N_i (count) + 4 N_i + 4 N_{i+1} (rewrite); the N_i are recovered exactly from the result (undoing merge
+    i splits every token 256 + i into its two children)."""
+    import torch
+    from ecg_byte_amd.tokenizer import quantize
+    from ecg_byte_amd.trainer import bpe_train_device
+    n_records = x.shape[0]
+    sym = quantize(torch.from_numpy(x).cuda(), pc).view(-1)
+    text = (sym + 97).contiguous()
+    del x, sym
+    best = None
+    for _ in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ids, n_ids, pairs, n_done = bpe_train_device(text, num_merges)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    k, m = int(n_done.item()), int(n_ids.item())
+    cnt = torch.bincount(ids[:m].long(), minlength=256 + k).cpu().numpy().astype(np.int64)
+    pr = pairs[:k].cpu().numpy()
+    N = [0] * (k + 1)
+    N[k] = m
+    for i in range(k - 1, -1, -1):
+        c = int(cnt[256 + i])
+        cnt[pr[i, 0]] += c
+        cnt[pr[i, 1]] += c
+        N[i] = N[i + 1] + c
+    assert N[0] == text.numel(), (N[0], text.numel())
+    alg = sum(8 * N[i] + 4 * N[i + 1] for i in range(k))
+    return {"workload": f"{n_records} records of 12x{L} (seed 1) = {text.numel()} symbols, {num_merges} merges: the corpus of tests/golden/tokenizer_c2.pkl",
+            "seconds": best, "merges_done": k, "final_ids": m, "compression": text.numel() / max(m, 1),
+            "algorithmic_bytes": alg, "GB/s": alg / best / 1e9, "frac_of_hbm_peak": alg / best / 1e9 / HBM_PEAK_GBS,
+            "merges_per_s": k / best}
+
+
+def bench_preprocess(dev, n_records=1024):
+    """the offline conditioning (filter chain, wavelet shrinkage, 500 -> 250 Hz, segments) of raw 12 x 5000 float64 records on
+    the device.  Algorithmic bytes: 480 KB read + 240 KB written per record."""
+    import torch
+    from ecg_byte_amd import preprocess_utils as pp, synth
+    base = np.ascontiguousarray(synth.synth_ecg(64, 5000, seed=0).transpose(0, 2, 1))
+    x = np.concatenate([base] * (n_records // 64)) + 0.01 * np.random.default_rng(0).standard_normal((n_records, 5000, 12))
+    xd = torch.from_numpy(x).to(dev)
+    out = pp.condition_records(xd, reorder=True, seg_len=1250)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
+    e0.record()
+    for _ in range(reps):
+        out = pp.condition_records(xd, reorder=True, seg_len=1250)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    alg = n_records * (5000 * 12 * 8 + 2500 * 12 * 8)
+    return {"workload": f"{n_records} raw records of 5000 x 12 float64: notch 50/60 Hz, band-pass, high-pass (filtfilt), db6 wavelet shrinkage, cubic resample to 250 Hz, 1250-sample segments",
+            "ms": ms, "records_per_s": n_records / (ms * 1e-3), "GB/s": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "segments_out": list(out.shape)}
+
+
+def mfma_busy_from_profile():
+    """Per-kernel MFMA-pipe busy fraction and held clock of the train step's GEMM / attention kernels from the committed counter passes
+    (profiles/r*/train_pmc.json: SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over SQ_BUSY_CYCLES / 32 shader engines).  Counters need their own rocprofv3
+    passes, so the figures are NOT measured by the run that prints them; `source` names the profile."""
+    f = _latest_profile("train_pmc.json")
+    if not f:
+        return None
+    with open(f) as fh:
+        d = json.load(fh)
+    rows = []
+    for name, c in d.items():
+        if ("gemm_" in name or "attn_" in name) and c.get("mfma_busy") is not None:
+            rows.append({"kernel": name, "mfma_busy": c["mfma_busy"], "valu_per_mfma": c.get("valu_per_mfma"), "clock_ghz": c.get("clock_ghz_pmc_pass"),
+                         "avg_us": c.get("trace_avg_us") or c.get("pmc_pass_avg_us")})
+    rows.sort(key=lambda r: -(r["avg_us"] or 0))
+    return {"source": os.path.relpath(f, ROOT), "kernels": rows}
+
+
 def bench_c5(args, dev):
     """BASELINE config C5's shapes on one GPU: Gemma-2B dims (18 layers, hidden 2048, 8 query heads / 1 KV head of 256, MLP 16 384,
     vocab 256 000 + 256 + 3 500 + 3), seq 2048, batch 8, LoRA r16 (what the reference's script runs, ecg_byte/scripts/train_model.sh),
@@ -426,7 +530,7 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
     if args.lora:
         model.enable_lora(r=16, alpha=32, dropout=0.05)      # ecg_byte/main.py:131-138
     if dist.is_initialized():
-        model.grad_sync = GradAllReduce(single_rank_collectives=True)
+        model.grad_sync = GradAllReduce(single_rank_collectives=True, time_exposed=True)
     opt = model.make_optimizer()                          # Adam(0.9, 0.99, 1e-8, wd 1e-2) + Noam(500) + clip 1.0
     asm = BatchAssembler(tk, lut, pad, bos, eos, sig_start, sig_end, S - 4, device=dev)
     rng = np.random.default_rng(2 + rank)
@@ -464,6 +568,12 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     sec = wall / args.train_steps
+    comm = None
+    if dist.is_initialized() and model.grad_sync is not None:
+        gs = model.grad_sync
+        comm = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "collectives_per_step": gs.collectives / max(1, gs.steps),
+                "exposed_ms_per_step": gs.exposed_ms() / max(1, gs.steps),
+                "note": "exposed = time the compute stream waits in GradAllReduce.finish() for buckets still in flight (HIP events around the waits)"}
     # algorithmic FLOPs: 3 x (2 x matmul params x tokens + causal attention), loss head over the rows it runs on
     H, I, Lyr = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
     per_layer = H * (cfg.num_attention_heads * cfg.head_dim + 2 * cfg.num_key_value_heads * cfg.head_dim) + cfg.num_attention_heads * cfg.head_dim * H + 3 * H * I
@@ -483,7 +593,9 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_nt_kernel_m16pp + gemm_nn_kernel_m16pp (persistent tile loops; m16p for long contractions) + gemm_tn_kernel_tr, 256x256 tiles (bf16 MFMA 16x16x32)",
                         "algorithmic_flops_per_step": flops, "step_ms_hip_events": ev0.elapsed_time(ev1) / args.train_steps}}
-    if rank == 0 and not args.lora:
+    if comm is not None:
+        out["gradient_exchange"] = comm
+    if rank == 0 and not args.lora and not getattr(args, "no_hbm_report", False):
         del model, opt
         model = opt = None
         torch.cuda.empty_cache()
@@ -527,10 +639,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # host-side synthetic data first: the generator forks worker processes, which must happen before
     # this process initialises HIP / RCCL
-    workers = max(1, min(8, (os.cpu_count() or 1) // max(1, world)))
+    workers = int(os.environ.get("ECGB_BENCH_WORKERS", max(1, min(8, (os.cpu_count() or 1) // max(1, world)))))   # 1: no fork pool (profiler runs)
     x = make_signals(args.batch, args.L, seed=0, start=rank * args.batch, workers=workers)   # rank r owns records rB..rB+B-1
     x_train = None if args.no_train else make_signals(args.train_batch, args.L, seed=0,
                                                       start=10_000_000 + rank * args.train_batch, workers=workers)
+    # the tokenizer trainer's corpus (2 000 records, seed 1: what tests/golden/tokenizer_c2.pkl was trained on) -- generated here, before HIP is up, like the rest
+    x_corpus = make_signals(2000, args.L, seed=1, start=0, workers=workers) if (rank == 0 and world == 1 and not args.no_extras and args.L == 5000) else None
     # Test hooks (tests/test_gpu_pipeline.py runs the N = 2 path on a one-GPU box): ECGB_BENCH_BACKEND=gloo replaces RCCL,
     # ECGB_BENCH_ONE_DEVICE=1 puts every rank on cuda:0.  Neither is set in a measured run.
     backend = os.environ.get("ECGB_BENCH_BACKEND", "nccl")
@@ -596,6 +710,9 @@ def main():
     else:
         tokens_total = tokens_rank
 
+    sweep = None
+    if rank == 0 and world == 1 and not args.no_extras and L == 5000:
+        sweep = bench_batch_sweep(tk, pc, xd, L)
     c1 = None
     if rank == 0 and world == 1 and not args.no_c1:
         c1 = bench_c1(args, dev, cpu=not args.no_cpu_baseline)
@@ -612,9 +729,26 @@ def main():
             train["lora_r16"] = {k: lora[k] for k in ("value", "unit", "ms_per_step", "steps", "final_loss", "roofline")}
             train["lora_r16"]["workload"] = lora["config"]["workload"]
 
+    if train is not None and not args.lora and not args.full_logits and not args.no_extras:
+        # the reference-equivalent loss head (modeling_llama.py:1209-1213 materialises every row's logits): the same step with the head over all B x S rows
+        import copy
+        fargs = copy.copy(args)
+        fargs.full_logits, fargs.no_cpu_baseline, fargs.train_steps, fargs.no_hbm_report = True, True, min(args.train_steps, 2), True
+        full = bench_train(fargs, tk, vocab, merges, pc, world, rank, dev, x_train)
+        train["full_logits"] = {k: full[k] for k in ("value", "unit", "ms_per_step", "steps", "final_loss", "roofline")}
+        train["full_logits"]["workload"] = full["config"]["workload"] + "; loss head over all rows, as the reference materialises them"
+    if train is not None:
+        mb = mfma_busy_from_profile()
+        if mb is not None:
+            train["roofline"]["mfma_busy"] = mb
     c5 = None
     if rank == 0 and world == 1 and not args.no_c5 and not args.no_train:
         c5 = bench_c5(args, dev)
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras and L == 5000:
+        extras["trainer"] = bench_trainer(pc, L, x_corpus)
+        del x_corpus
+        extras["preprocess"] = bench_preprocess(dev)
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
         records_total = B * world
@@ -642,6 +776,9 @@ def main():
             out["roofline_valu"] = valu_roofline(dev_ms)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(merges, pc, L, seed=0)
+        if sweep is not None:
+            out["batch_sweep"] = sweep
+        out.update(extras)
         if c1 is not None:
             out["c1"] = c1
         if c5 is not None:

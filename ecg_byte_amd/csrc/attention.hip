@@ -61,11 +61,12 @@ struct AttnArgs {
     // fp32 partial sums to slab [which (0 = dK, 1 = dV)][h][B * S][D]; attn_dkv_reduce_kernel adds the slabs in order
     float *slab;
     int head_splits;
+    int lean_hw_log2;                     // lean forward / dQ kernels: log2 of the query heads of a KV group that share a workgroup's K / V tiles
 };
 
 #ifdef ECGB_PROFILE
 // dev builds only (`make prof`, scripts/dev_prof_attn.py): cycles per phase of the forward loop, summed over waves
-__device__ unsigned long long g_attn_prof[32];   // [wave of the workgroup][phase]
+__device__ unsigned long long g_attn_prof[64];   // [wave of the workgroup (up to 8)][phase]
 #define APROF(k) do { const long long t_now = clock64(); prof_acc[k] += (unsigned long long)(t_now - t_prof); t_prof = clock64(); } while (0)
 #else
 #define APROF(k) do { } while (0)
@@ -226,6 +227,24 @@ __device__ __forceinline__ void lds_rows4_wait(f4v (&m)[4], unsigned a)
                  : "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3])
                  : "v"(a), "n"(OFF), "n"(OFF + 32), "n"(OFF + 64), "n"(OFF + 96)
                  : "memory");
+}
+// four row fragments -- two lane addresses x two byte offsets -- and their wait as one statement (see above); issued right behind a group of MFMAs, the
+// wait runs under them.  (Compiler-visible ds_read_b128 are issued one pair at a time just ahead of the MFMAs that use them: every pair then exposes an
+// LDS round trip -- ~650 cycles for the eight MFMAs of a score product instead of 256.)
+template <int OFF0, int OFF1>
+__device__ __forceinline__ void lds_frags2x2_wait(bf16x8 &f00, bf16x8 &f01, bf16x8 &f10, bf16x8 &f11, unsigned a0, unsigned a1)
+{
+    i4v r0, r1, r2, r3;
+    asm volatile("ds_read_b128 %0, %4 offset:%6\n\t"
+                 "ds_read_b128 %1, %4 offset:%7\n\t"
+                 "ds_read_b128 %2, %5 offset:%6\n\t"
+                 "ds_read_b128 %3, %5 offset:%7\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                 : "v"(a0), "v"(a1), "n"(OFF0), "n"(OFF1)
+                 : "memory");
+    f00 = __builtin_bit_cast(bf16x8, r0); f01 = __builtin_bit_cast(bf16x8, r1);
+    f10 = __builtin_bit_cast(bf16x8, r2); f11 = __builtin_bit_cast(bf16x8, r3);
 }
 // byte offset inside a tile image of this lane's transposing read for fragment (db, kb = 0, s2 = 0): row_add = 0 for the first read, 8 for the second
 // (bit 3 of the row enters u, so the two are computed separately); the other (kb, s2) are 32 kb + 16 s2 rows further down, which leaves u alone: they go
@@ -1051,6 +1070,536 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(AttnArgs A)
     store_accT<D / 32>(accV, A.dv + (long long)g * D, A.lddv, rowbase + ki, kvalid, h, 1.f);
 }
 
+// =====================================================================================================
+// Round 3: the head_dim-64 kernels again, with the softmax arithmetic moved into the MFMA accumulators ("lean" kernels, g_attn_dma == 2).
+// The LDS-DMA kernels above are vector-issue bound, not MFMA bound (ISA count of attn_fwd_kernel<64, true>: ~200 vector instructions beside 16
+// MFMAs per 32 x 64 tile = ~930 issue cycles against 512 of MFMA; dK/dV 211 beside 32).  What a score costs besides its exp is removed:
+//   * the row operand held in registers is PRE-SCALED by scale * log2(e) (rounded to bf16 once per row, as the persistent-workgroup attention of the
+//     CDNA guide does): the products are log2-domain scores, no multiply per score;
+//   * the row constant of the softmax is the INITIAL ACCUMULATOR of the score product (MFMA takes C != D): forward -- minus the row's running
+//     maximum, so p = exp2(acc) with no subtraction; backward -- the row's log-sum-exp with the register operand negated, acc = lse - s, p = exp2(-acc)
+//     (the negation is the instruction's source modifier); dP starts from delta the same way: acc = delta - dP, and ds = -(p * acc): one multiply, the
+//     sign goes into the scale applied once at the store;
+//   * forward: the running maximum is DEFERRED (T13 of the guide).  A tile takes the fast path -- no maximum at all, 32 exp + 32 adds + 16 packs --
+//     unless some row has not seen a key yet or some lane's tile sum exceeds 2^10 (a score more than ~2^5..2^10 above the row's reference);
+//     then the exact path: row maximum, rescale of l and O, new reference.  Tiles that need the causal / padding mask always take the exact path.
+// The bf16 rounding points of P and dS are the ones of the kernels above; what changes is the rounding of the pre-scaled operand (half an ulp
+// of bf16 on q resp. k: the size of the input's own quantisation) and the order of the fp32 sums inside the MFMA.  lse / delta keep their meaning
+// and layout, so every lean kernel can be mixed with the others (tests A/B each one alone).
+// =====================================================================================================
+
+// row operand fragments, pre-scaled: bf16(x * mul) (mul = +-scale * log2 e, or -1 for a sign flip, which is exact)
+__device__ __forceinline__ void scale_row_frags(bf16x8 (&f)[4], float mul)
+{
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        using u4 = __attribute__((ext_vector_type(4))) unsigned;
+        u4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            w[j] = pack_bf16(bf2f((unsigned short)f[ks][2 * j]) * mul, bf2f((unsigned short)f[ks][2 * j + 1]) * mul);
+        f[ks] = __builtin_bit_cast(bf16x8, w);
+    }
+}
+__device__ __forceinline__ f32x16 splat16(float v)
+{
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = v;
+    return r;
+}
+
+constexpr int kLeanRing = 3;      // LDS ring depth of the lean kernels: tiles (kRing - 1) ahead (4 measured the same as 3: the flight time is not what a wave waits for)
+template <int N> __device__ __forceinline__ void lean_wait_tiles() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// NW waves per workgroup (4 or 8) share every K / V tile.  Measured with the phase timers (scripts/dev_prof_attn.py, 4 waves x 32 rows, two workgroups per CU):
+// 2 030 of a tile's 4 700 cycles went into ISSUING its four LDS-DMA pieces -- the vector memory path of a CU takes about 16 bytes per cycle, 32 KB per pair of
+// workgroup tiles against 1 024 cycles of MFMA: the kernel was bound by the tile traffic, not by arithmetic.  So a tile serves twice the rows: eight waves,
+// and -- grouped-query attention -- the waves of a workgroup are the HW = gcd(G, 8) query heads of the KV group times 8 / HW blocks of 32 rows (Llama: 4 heads
+// x 64 rows, where both row blocks need exactly the same tiles: no wave idles at a barrier under the causal mask; one head: 256 rows).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_lean_kernel(AttnArgs A)
+{
+    constexpr int D = 64, kTile = 128 * D, PPW = 8 / NW;      // PPW: 1 KiB pieces of a tile per wave and operand
+    // Ring of kRing (K, V) tile pairs, kAhead = kRing - 1 tiles in flight, issued FIRST thing in a tile.  Measured (scripts/dev_attn_lean.py, C3 shape):
+    // issuing tile it + 2 in the middle of tile it (in the vector-only stretch, where the guide prices an LDS-DMA issue lowest) cost 15 % of the kernel; a ring of
+    // four (three tiles ahead) measured the same as three.
+    constexpr int kRing = kLeanRing, kAhead = kRing - 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // kRing x (K, V) tiles + the row's key mask
+    auto lds_k2 = [&](int i) { return smem + i * 2 * kTile; };
+    auto lds_vt2 = [&](int i) { return smem + i * 2 * kTile + kTile; };
+    float *lds_maskrow = reinterpret_cast<float *>(smem + 2 * kRing * kTile);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
+    const int hw_log2 = A.lean_hw_log2, R = (NW >> hw_log2) * 32;          // heads per workgroup (log2), query rows per workgroup
+    int qblk, head_in, group;
+    map_block((int)blockIdx.x, (A.S + R - 1) / R, (A.Hq / A.Hkv) >> hw_log2, A.B * A.Hkv, true, qblk, head_in, group);
+    const int b = group / A.Hkv, g = group % A.Hkv, hq = g * (A.Hq / A.Hkv) + (head_in << hw_log2) + (wave & ((1 << hw_log2) - 1));
+    const int q0 = qblk * R, qw0 = q0 + (wave >> hw_log2) * 32;            // first row of the workgroup / of this wave
+    const int qi = qw0 + lr;
+    const bool qvalid = qi < A.S;
+    const long long rowbase = (long long)b * A.S;
+    const unsigned short *Q = A.q + (long long)hq * D, *K = A.k + (long long)g * D, *V = A.v + (long long)g * D;
+    const int k_end = min(A.S, q0 + R);
+    const int wave_qmax = qw0 + 31;
+    const int last_tile = (k_end - 1) / 64;
+    unsigned offK[PPW], offV[PPW], offKt[PPW], offVt[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int r = (wave * PPW + i) * 8 + (lane >> 3), slot = lane & 7;
+        const int ck = slot ^ ((r >> 1) & 7), cv = slot ^ (((r >> 1) & 1) << 2);
+        const int rt = min(r, A.S - 1 - last_tile * 64);
+        offK[i] = (unsigned)(((long long)r * A.ldk + ck * 8) * 2);  offKt[i] = (unsigned)(((long long)rt * A.ldk + ck * 8) * 2);
+        offV[i] = (unsigned)(((long long)r * A.ldv + cv * 8) * 2);  offVt[i] = (unsigned)(((long long)rt * A.ldv + cv * 8) * 2);
+    }
+    auto issue_tile = [&](int t, int buf) {                  // UNCONDITIONAL (the caller clamps t): the waits below stay counted
+        const bool tail = (t + 1) * 64 > A.S;
+        const unsigned char *kb = reinterpret_cast<const unsigned char *>(K + (rowbase + (long long)t * 64) * A.ldk);
+        const unsigned char *vb = reinterpret_cast<const unsigned char *>(V + (rowbase + (long long)t * 64) * A.ldv);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb + (tail ? offKt[i] : offK[i])),
+                                             (__attribute__((address_space(3))) void *)(lds_k2(buf) + (wave * PPW + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb + (tail ? offVt[i] : offV[i])),
+                                             (__attribute__((address_space(3))) void *)(lds_vt2(buf) + (wave * PPW + i) * 1024), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < kAhead; ++t) issue_tile(min(t, last_tile), t);
+    bf16x8 qf[4];
+    load_row_frags<D>(qf, Q, A.ldq, rowbase + qi, qvalid, h);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // Q's fragments (younger than the tiles' pieces) are in: from here on the waits are counted
+    scale_row_frags(qf, A.scale * kLog2e);                   // log2-domain scores straight out of the MFMA
+    for (int i = threadIdx.x; i < ((k_end + 63) & ~63); i += NW * 64) lds_maskrow[i] = (i < A.S) ? A.mask[rowbase + i] : 0.f;
+    f32x16 accO[2] = {splat16(0.f), splat16(0.f)};
+    float m = -INFINITY, l = 0.f;                            // m: the row's reference (a deferred running maximum); -inf = no key seen yet
+    f32x16 cinit = splat16(0.f);                             // -m in all sixteen registers: the initial accumulator of the score products
+    __syncthreads();
+    unsigned vtr[2];
+    {
+        const int a = lr >> 4, q = (lr & 15) >> 2, p = lr & 3;
+        const int key = 4 * h + q;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+            vtr[db] = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem + kTile + key * 128 +
+                      (((db * 4 + 2 * a + (p >> 1)) ^ (((key >> 1) & 1) << 2)) << 4) + (p & 1) * 8;
+    }
+    unsigned kbase[4];                                       // this lane's K row fragment (key lr, k-step ks) inside a K image; key 32 + lr is 4 KiB further
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        kbase[ks] = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem + lr * 128 + (((ks * 2 + h) ^ ((lr >> 1) & 7)) << 4);
+#ifdef ECGB_PROFILE
+    unsigned long long prof_acc[7] = {};
+    long long t_prof = clock64();
+#endif
+    for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
+        const unsigned vimg = (unsigned)((it % kRing) * 2 * kTile);
+        const float *lds_mask = lds_maskrow + k0;
+        issue_tile(min(it + kAhead, last_tile), (it + kAhead) % kRing);      // FIRST thing in the tile: the pieces need their whole flight time (see kRing)
+        APROF(0);
+        if (k0 <= wave_qmax) {
+            const bool need_mask = (k0 + 63 > qw0) || __any(lds_mask[lane] == 0.f);
+            f32x16 sacc[2];
+            bf16x8 kfr[2][4];                                   // [kb][ks]: K row fragments, four per batch; the second batch and the V^T fragments land under MFMAs
+            lds_frags2x2_wait<0, 4096>(kfr[0][0], kfr[1][0], kfr[0][1], kfr[1][1], kbase[0] + vimg, kbase[1] + vimg);
+            sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][0], qf[0], cinit, 0, 0, 0);
+            sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[1][0], qf[0], cinit, 0, 0, 0);
+            sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][1], qf[1], sacc[0], 0, 0, 0);
+            sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[1][1], qf[1], sacc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            lds_frags2x2_wait<0, 4096>(kfr[0][2], kfr[1][2], kfr[0][3], kfr[1][3], kbase[2] + vimg, kbase[3] + vimg);
+#pragma unroll
+            for (int ks = 2; ks < 4; ++ks)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][ks], qf[ks], sacc[kb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 vfr[2][2][2];                                // [kb][s2][db]: the tile's eight V^T fragments, read (and waited for) under the products above
+            tr_frags4_wait<0, 16 * 128>(vfr[0], vtr[0] + vimg, vtr[0] + vimg + 1024, vtr[1] + vimg, vtr[1] + vimg + 1024);
+            tr_frags4_wait<32 * 128, 48 * 128>(vfr[1], vtr[0] + vimg, vtr[0] + vimg + 1024, vtr[1] + vimg, vtr[1] + vimg + 1024);
+            APROF(1);
+            bf16x8 pf[2][2];                                    // [kb][s2]: P as the B operand of P.V, packed as it is produced (the fp32 values are not kept)
+            using u4 = __attribute__((ext_vector_type(4))) unsigned;
+            bool exact = need_mask;
+            if (!need_mask) {                                   // (uniform) fast path: p = exp2(score - reference) is the accumulator's exp2
+                float lsum = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        u4 w;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float e0 = fast_exp2(sacc[kb][8 * s2 + 2 * j]), e1 = fast_exp2(sacc[kb][8 * s2 + 2 * j + 1]);
+                            lsum += e0; lsum += e1;
+                            w[j] = pack_bf16(e0, e1);
+                        }
+                        pf[kb][s2] = __builtin_bit_cast(bf16x8, w);
+                    }
+                // not (lsum <= 2^10) also catches +inf; a row that has seen no key yet has no reference: exact path
+                exact = __any(!(lsum <= 1024.f) || m == -INFINITY);
+                if (!exact) l += lsum;
+            }
+            if (exact) {
+                float t = -INFINITY;
+                if (need_mask) {
+                    f4v mv[2][4];
+                    const unsigned ma = (unsigned)(size_t)(__attribute__((address_space(3))) float *)const_cast<float *>(lds_mask) + 16 * h;
+                    lds_rows4_wait<0>(mv[0], ma);
+                    lds_rows4_wait<128>(mv[1], ma);
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;       // key inside the tile
+                            const bool vis = (k0 + kl <= qi) & (mv[kb][r >> 2][r & 3] != 0.f);
+                            const float v = vis ? sacc[kb][r] : -INFINITY;
+                            sacc[kb][r] = v;
+                            t = fmaxf(t, v);
+                        }
+                } else {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) t = fmaxf(t, sacc[kb][r]);
+                }
+                t = fmaxf(t, __shfl_xor(t, 32, 64));            // the row's maximum of (score - reference); -inf: no visible key in this tile
+                // unseen row: the reference becomes the tile's maximum itself (if there is one); seen row: it only ever moves up
+                const bool unseen = m == -INFINITY;
+                const float d = (t == -INFINITY) ? 0.f : (unseen ? t : fmaxf(t, 0.f));
+                const float alpha = unseen ? 1.f : fast_exp2(-d);   // (an unseen row's l and O are still zero)
+                float lsum = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        u4 w;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float e0 = fast_exp2(sacc[kb][8 * s2 + 2 * j] - d), e1 = fast_exp2(sacc[kb][8 * s2 + 2 * j + 1] - d);
+                            lsum += e0; lsum += e1;
+                            w[j] = pack_bf16(e0, e1);
+                        }
+                        pf[kb][s2] = __builtin_bit_cast(bf16x8, w);
+                    }
+                l = l * alpha + lsum;
+                if (t != -INFINITY) m = unseen ? t : m + d;
+                if (__any(alpha != 1.f)) {
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) accO[db][r] *= alpha;
+                }
+                if (__any(d != 0.f)) cinit = splat16(m == -INFINITY ? 0.f : -m);
+            }
+            APROF(2);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+                        accO[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb][s2][db], pf[kb][s2], accO[db], 0, 0, 0);
+            APROF(3);
+        }
+        lean_wait_tiles<2 * PPW * (kAhead - 1)>();         // this wave's pieces of tile it + 1 have landed (the younger tiles' may still fly)
+        APROF(4);
+        __builtin_amdgcn_s_barrier();                      // ... and everybody else's; all reads of tile it are done
+        APROF(5);
+#ifdef ECGB_PROFILE
+        prof_acc[6] += 1;
+#endif
+    }
+#ifdef ECGB_PROFILE
+    if ((threadIdx.x & 63) == 0)
+        for (int kk = 0; kk < 7; ++kk) atomicAdd(&g_attn_prof[(threadIdx.x >> 6) * 8 + kk], prof_acc[kk]);
+#endif
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    store_accT<2>(accO, A.o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h, inv);
+    if (qvalid && h == 0) A.lse[((long long)b * A.Hq + hq) * A.S + qi] = lt > 0.f ? m + log2f(lt) : INFINITY;
+}
+
+// dQ, lean form: lanes = queries.  Register operands: -Q * scale * log2 e and -dO; initial accumulators: the row's lse and delta.
+//   acc_s = lse - s,  p = exp2(-acc_s);   acc_dp = delta - dP;   dsn = p * acc_dp = -dS;   accQ += K^T . dsn  ->  dQ = -scale * accQ
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_lean_kernel(AttnArgs A)
+{
+    constexpr int D = 64, kTile = 128 * D, PPW = 8 / NW;      // (waves, heads and rows of a workgroup: see attn_fwd_lean_kernel)
+    constexpr int kRing = kLeanRing, kAhead = kRing - 1;   // (see attn_fwd_lean_kernel)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kRing x (K, V) + 4 bytes per key
+    auto lds_k3 = [&](int i) { return smem + i * 2 * kTile; };
+    auto lds_v3 = [&](int i) { return smem + i * 2 * kTile + kTile; };
+    float *lds_maskrow = reinterpret_cast<float *>(smem + 2 * kRing * kTile);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
+    const int hw_log2 = A.lean_hw_log2, R = (NW >> hw_log2) * 32;
+    int qblk, head_in, group;
+    map_block((int)blockIdx.x, (A.S + R - 1) / R, (A.Hq / A.Hkv) >> hw_log2, A.B * A.Hkv, true, qblk, head_in, group);
+    const int b = group / A.Hkv, g = group % A.Hkv, hq = g * (A.Hq / A.Hkv) + (head_in << hw_log2) + (wave & ((1 << hw_log2) - 1));
+    const int q0 = qblk * R, qw0 = q0 + (wave >> hw_log2) * 32;
+    const int qi = qw0 + lr;
+    const bool qvalid = qi < A.S;
+    const long long rowbase = (long long)b * A.S;
+    const unsigned short *Q = A.q + (long long)hq * D, *K = A.k + (long long)g * D, *V = A.v + (long long)g * D;
+    const int k_end = min(A.S, q0 + R);
+    const int wave_qmax = qw0 + 31;
+    const int last_tile = (k_end - 1) / 64;
+    unsigned offK[PPW], offV[PPW], offKt[PPW], offVt[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int r = (wave * PPW + i) * 8 + (lane >> 3), c = (lane & 7) ^ swz_u(r);
+        const int rt = min(r, A.S - 1 - last_tile * 64);
+        offK[i] = (unsigned)(((long long)r * A.ldk + c * 8) * 2);  offKt[i] = (unsigned)(((long long)rt * A.ldk + c * 8) * 2);
+        offV[i] = (unsigned)(((long long)r * A.ldv + c * 8) * 2);  offVt[i] = (unsigned)(((long long)rt * A.ldv + c * 8) * 2);
+    }
+    auto issue_tile = [&](int t, int buf) {
+        const bool tail = (t + 1) * 64 > A.S;
+        const unsigned char *kb = reinterpret_cast<const unsigned char *>(K + (rowbase + (long long)t * 64) * A.ldk);
+        const unsigned char *vb = reinterpret_cast<const unsigned char *>(V + (rowbase + (long long)t * 64) * A.ldv);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb + (tail ? offKt[i] : offK[i])),
+                                             (__attribute__((address_space(3))) void *)(lds_k3(buf) + (wave * PPW + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb + (tail ? offVt[i] : offV[i])),
+                                             (__attribute__((address_space(3))) void *)(lds_v3(buf) + (wave * PPW + i) * 1024), 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < kAhead; ++t) issue_tile(min(t, last_tile), t);
+    bf16x8 qf[4], dof[4], of[4];
+    load_row_frags<D>(qf, Q, A.ldq, rowbase + qi, qvalid, h);
+    load_row_frags<D>(dof, A.d_o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h);
+    load_row_frags<D>(of, A.o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h);
+    float delta = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += bf2f((unsigned short)dof[ks][j]) * bf2f((unsigned short)of[ks][j]);
+    delta += __shfl_xor(delta, 32, 64);
+    const long long stat = ((long long)b * A.Hq + hq) * A.S + qi;
+    if (qvalid && h == 0) A.delta[stat] = delta;
+    const float lse = qvalid ? A.lse[stat] : INFINITY;
+    scale_row_frags(qf, -A.scale * kLog2e);
+    scale_row_frags(dof, -1.f);
+    const f32x16 lseC = splat16(lse), delC = splat16(delta);
+    f32x16 accQ[2] = {splat16(0.f), splat16(0.f)};
+    for (int i = threadIdx.x; i < ((k_end + 63) & ~63); i += NW * 64) lds_maskrow[i] = (i < A.S) ? A.mask[rowbase + i] : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the row loads above are younger than the tiles' pieces: one full wait, once)
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    unsigned trA[2], trB[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) { trA[db] = lds0 + tr_off_u(db, lr, h, 0); trB[db] = lds0 + tr_off_u(db, lr, h, 8); }
+    unsigned rbase[4];                                       // this lane's row fragment (row lr, k-step ks) inside an image; row 32 + lr is 4 KiB further
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rbase[ks] = lds0 + lr * 128 + (((ks * 2 + h) ^ swz_u(lr)) << 4);
+    for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
+        issue_tile(min(it + kAhead, last_tile), (it + kAhead) % kRing);
+        const int buf = it % kRing;
+        const unsigned kimg = (unsigned)(buf * 2 * kTile);
+        if (k0 <= wave_qmax) {
+            const float *lds_mask = lds_maskrow + k0;
+            const bool need_mask = (k0 + 63 > qw0) || __any(lds_mask[lane] == 0.f);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8 kfr[4], vfr[4];                        // row fragments of this key half: K and V images side by side (+ kTile), two k-steps per batch
+                if (kb == 0) lds_frags2x2_wait<0, kTile>(kfr[0], vfr[0], kfr[1], vfr[1], rbase[0] + kimg, rbase[1] + kimg);
+                else lds_frags2x2_wait<4096, kTile + 4096>(kfr[0], vfr[0], kfr[1], vfr[1], rbase[0] + kimg, rbase[1] + kimg);
+                f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0], qf[0], lseC, 0, 0, 0);
+                f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[0], dof[0], delC, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[1], qf[1], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[1], dof[1], dp, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kb == 0) lds_frags2x2_wait<0, kTile>(kfr[2], vfr[2], kfr[3], vfr[3], rbase[2] + kimg, rbase[3] + kimg);
+                else lds_frags2x2_wait<4096, kTile + 4096>(kfr[2], vfr[2], kfr[3], vfr[3], rbase[2] + kimg, rbase[3] + kimg);
+#pragma unroll
+                for (int ks = 2; ks < 4; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ks], dof[ks], dp, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 ktf[2][2];
+                if (kb == 0) tr_frags4_wait<0, 16 * 128>(ktf, trA[0] + kimg, trB[0] + kimg, trA[1] + kimg, trB[1] + kimg);
+                else tr_frags4_wait<32 * 128, 48 * 128>(ktf, trA[0] + kimg, trB[0] + kimg, trA[1] + kimg, trB[1] + kimg);
+                float ds[16];
+                if (need_mask) {
+                    f4v mv[4];
+                    const unsigned ma = (unsigned)(size_t)(__attribute__((address_space(3))) float *)const_cast<float *>(lds_mask) + 16 * h;
+                    if (kb == 0) lds_rows4_wait<0>(mv, ma); else lds_rows4_wait<128>(mv, ma);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const bool vis = (k0 + kl <= qi) & (mv[r >> 2][r & 3] != 0.f);
+                        ds[r] = vis ? fast_exp2(-s[r]) * dp[r] : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(-s[r]) * dp[r];
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 dsf = frag_from_acc(&ds[8 * s2]);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+                        accQ[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[s2][db], dsf, accQ[db], 0, 0, 0);
+                }
+            }
+        }
+        lean_wait_tiles<2 * PPW * (kAhead - 1)>();
+        __builtin_amdgcn_s_barrier();
+    }
+    store_accT<2>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, -A.scale);
+}
+
+// dK / dV, lean form: lanes = keys.  Register operands: -K * scale * log2 e and -V; initial accumulators: the tile's lse / delta rows as they lie in LDS
+// (the lane's sixteen queries are four runs of four floats: four 16-byte reads ARE the sixteen accumulator registers).
+//   acc_s = lse_q - s,  p = exp2(-acc_s);  acc_dp = delta_q - dP;  dsn = p * acc_dp = -dS;  accV += dO^T . p;  accK += Q^T . dsn  ->  dK = -scale * accK
+// NW waves = NW x 32 keys per workgroup share every (Q, dO) tile (see attn_fwd_lean_kernel: the tile traffic, not the arithmetic, bounds the 4-wave kernel).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_lean_kernel(AttnArgs A)
+{
+    constexpr int D = 64, kTile = 128 * D, PPW = 8 / NW, kStep = 2 * kTile + NW * 256;      // Q image, dO image, one 256-byte statistics row per wave
+    constexpr int kRing = kLeanRing, kAhead = kRing - 1;   // (see attn_fwd_lean_kernel)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kRing x kStep
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
+    int blk, head_in, group;
+    map_block((int)blockIdx.x, (A.S + NW * 32 - 1) / (NW * 32), 1, A.B * A.Hkv, false, blk, head_in, group);
+    const int b = group / A.Hkv, g = group % A.Hkv;
+    const int G = A.Hq / A.Hkv;
+    const int kk0 = blk * (NW * 32);
+    const int ki = kk0 + wave * 32 + lr;
+    const bool kvalid = ki < A.S;
+    const long long rowbase = (long long)b * A.S;
+    const int wave_kmin = kk0 + wave * 32;
+    const int t_begin = (kk0 / 64) * 64;
+    const int tiles_per_head = (A.S - t_begin + 63) / 64;
+    const int n_steps = G * tiles_per_head;
+    const int tail_rows = A.S - (t_begin + (tiles_per_head - 1) * 64);
+    unsigned offQ[PPW], offO[PPW], offQt[PPW], offOt[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int r = (wave * PPW + i) * 8 + (lane >> 3), c = (lane & 7) ^ swz_u(r);
+        const int rt = min(r, tail_rows - 1);
+        offQ[i] = (unsigned)(((long long)r * A.ldq + c * 8) * 2);  offQt[i] = (unsigned)(((long long)rt * A.ldq + c * 8) * 2);
+        offO[i] = (unsigned)(((long long)r * A.ldo + c * 8) * 2);  offOt[i] = (unsigned)(((long long)rt * A.ldo + c * 8) * 2);
+    }
+    const unsigned offS = (unsigned)lane * 4u, offSt = (unsigned)min(lane, tail_rows - 1) * 4u;
+    const float *stat_src = (wave & 1) ? A.delta : A.lse;
+    auto issue_step = [&](int step, int buf) {
+        const int hq = g * G + step / tiles_per_head;
+        const int ti = step % tiles_per_head;
+        const int t0 = t_begin + ti * 64;
+        const bool tail = ti == tiles_per_head - 1 && tail_rows < 64;
+        const unsigned char *qb = reinterpret_cast<const unsigned char *>(A.q + (long long)hq * D + (rowbase + t0) * A.ldq);
+        const unsigned char *ob = reinterpret_cast<const unsigned char *>(A.d_o + (long long)hq * D + (rowbase + t0) * A.ldo);
+        const unsigned char *sb = reinterpret_cast<const unsigned char *>(stat_src + ((long long)b * A.Hq + hq) * A.S + t0);
+        unsigned char *dst = smem + buf * kStep;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + (tail ? offQt[i] : offQ[i])),
+                                             (__attribute__((address_space(3))) void *)(dst + (wave * PPW + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ob + (tail ? offOt[i] : offO[i])),
+                                             (__attribute__((address_space(3))) void *)(dst + kTile + (wave * PPW + i) * 1024), 16, 0, 0);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sb + (tail ? offSt : offS)),
+                                         (__attribute__((address_space(3))) void *)(dst + 2 * kTile + wave * 256), 4, 0, 0);
+    };
+#pragma unroll
+    for (int t = 0; t < kAhead; ++t) issue_step(min(t, n_steps - 1), t);
+    bf16x8 kf[4], vf[4];
+    load_row_frags<D>(kf, A.k + (long long)g * D, A.ldk, rowbase + ki, kvalid, h);
+    load_row_frags<D>(vf, A.v + (long long)g * D, A.ldv, rowbase + ki, kvalid, h);
+    const bool kvis = kvalid && A.mask[rowbase + (kvalid ? ki : 0)] != 0.f;
+    scale_row_frags(kf, -A.scale * kLog2e);
+    scale_row_frags(vf, -1.f);
+    const int vis_lo = kvis ? ki : A.S;
+    const unsigned vis_n = (unsigned)(A.S - vis_lo);
+    const bool wave_all_keys = __all(kvis);                  // (uniform) no padded / out-of-range key among this wave's 32
+    f32x16 accK[2] = {splat16(0.f), splat16(0.f)}, accV[2] = {splat16(0.f), splat16(0.f)};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the row loads above are younger than the steps' pieces: one full wait, once)
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    unsigned trA[2], trB[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) { trA[db] = lds0 + tr_off_u(db, lr, h, 0); trB[db] = lds0 + tr_off_u(db, lr, h, 8); }
+    const unsigned statA = lds0 + 2 * kTile + 16 * h;        // + 32 g4 + 128 qb: the lane's four runs of four queries
+    unsigned rbase[4];                                       // this lane's row fragment (row lr, k-step ks) inside an image; row 32 + lr is 4 KiB further
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rbase[ks] = lds0 + lr * 128 + (((ks * 2 + h) ^ swz_u(lr)) << 4);
+    for (int step = 0; step < n_steps; ++step) {
+        issue_step(min(step + kAhead, n_steps - 1), (step + kAhead) % kRing);
+        const int buf = step % kRing;
+        const unsigned img = (unsigned)(buf * kStep);
+        const int t0 = t_begin + (step % tiles_per_head) * 64;
+        if (t0 + 63 >= wave_kmin) {                            // else: every query of the tile precedes every key of this wave
+            // (uniform) every (query, key) pair of this wave's 64 x 32 block is visible: queries all real and none before a key, keys all real
+            const bool all_vis = wave_all_keys && t0 >= wave_kmin + 31 && t0 + 64 <= A.S;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f4v lse4[4], dl4[4];
+                if (qb == 0) { lds_rows4_wait<0>(lse4, statA + img); lds_rows4_wait<256>(dl4, statA + img); }
+                else { lds_rows4_wait<128>(lse4, statA + img); lds_rows4_wait<256 + 128>(dl4, statA + img); }
+                f32x16 c_s = __builtin_shufflevector(__builtin_shufflevector(lse4[0], lse4[1], 0, 1, 2, 3, 4, 5, 6, 7),
+                                                     __builtin_shufflevector(lse4[2], lse4[3], 0, 1, 2, 3, 4, 5, 6, 7),
+                                                     0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                const f32x16 c_dp = __builtin_shufflevector(__builtin_shufflevector(dl4[0], dl4[1], 0, 1, 2, 3, 4, 5, 6, 7),
+                                                            __builtin_shufflevector(dl4[2], dl4[3], 0, 1, 2, 3, 4, 5, 6, 7),
+                                                            0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+                if (!all_vis) {                               // an invisible pair starts from +inf: p = exp2(-inf) = 0 exactly
+                    const int qrel = t0 + 4 * h - vis_lo;     // (query of element r) - vis_lo = qrel + 32 qb + 8 (r >> 2) + (r & 3)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        c_s[r] = ((unsigned)(qrel + (qb * 32 + 8 * (r >> 2) + (r & 3))) < vis_n) ? c_s[r] : INFINITY;
+                }
+                bf16x8 qfr[4], ofr[4];                        // row fragments of this query half: Q and dO images side by side (+ kTile), two k-steps per batch
+                if (qb == 0) lds_frags2x2_wait<0, kTile>(qfr[0], ofr[0], qfr[1], ofr[1], rbase[0] + img, rbase[1] + img);
+                else lds_frags2x2_wait<4096, kTile + 4096>(qfr[0], ofr[0], qfr[1], ofr[1], rbase[0] + img, rbase[1] + img);
+                f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[0], kf[0], c_s, 0, 0, 0);
+                f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr[0], vf[0], c_dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[1], kf[1], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr[1], vf[1], dp, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (qb == 0) lds_frags2x2_wait<0, kTile>(qfr[2], ofr[2], qfr[3], ofr[3], rbase[2] + img, rbase[3] + img);
+                else lds_frags2x2_wait<4096, kTile + 4096>(qfr[2], ofr[2], qfr[3], ofr[3], rbase[2] + img, rbase[3] + img);
+#pragma unroll
+                for (int ks = 2; ks < 4; ++ks) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[ks], kf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr[ks], vf[ks], dp, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 qtf[2][2], dotf[2][2];                // [s2][db]: transposed fragments of this query half, read under the products above
+                if (qb == 0) {
+                    tr_frags4_wait<kTile, kTile + 16 * 128>(dotf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
+                    tr_frags4_wait<0, 16 * 128>(qtf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
+                } else {
+                    tr_frags4_wait<kTile + 32 * 128, kTile + 48 * 128>(dotf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
+                    tr_frags4_wait<32 * 128, 48 * 128>(qtf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
+                }
+                float pr[16], ds[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = fast_exp2(-s[r]);
+                    pr[r] = e;
+                    ds[r] = e * dp[r];
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 pf = frag_from_acc(&pr[8 * s2]);
+                    const bf16x8 dsf = frag_from_acc(&ds[8 * s2]);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        accV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[s2][db], pf, accV[db], 0, 0, 0);
+                        accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s2][db], dsf, accK[db], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        lean_wait_tiles<(2 * PPW + 1) * (kAhead - 1)>();
+        __builtin_amdgcn_s_barrier();
+    }
+    store_accT<2>(accK, A.dk + (long long)g * D, A.lddk, rowbase + ki, kvalid, h, -A.scale);
+    store_accT<2>(accV, A.dv + (long long)g * D, A.lddv, rowbase + ki, kvalid, h, 1.f);
+}
+
 template <int D, int DS, int WHICH = 0>
 __global__ __launch_bounds__(256, D == 64 ? 2 : 1) void attn_bwd_dkv_kernel(AttnArgs A)   // head_dim 64: two waves per SIMD (<= 256 registers)
 {
@@ -1363,7 +1912,23 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float *par
     o[((long long)b * Hq + hq) * D + tid] = (unsigned short)(pack_bf16(sum, 0.f) & 0xFFFFu);
 }
 
-int g_attn_dma = 1;       // head_dim 64 forward and backward: LDS-DMA staging (1) or the register-staged kernels (0; tests / A-B)
+// head_dim 64 forward and backward: 2 = the lean kernels (LDS-DMA staging, softmax constants in the MFMA accumulators: the default), 1 = the round-2 LDS-DMA
+// kernels, 0 = the register-staged kernels (tests / A-B).  Bits 8 / 9 / 10 send the forward / dQ / dK-dV kernel alone back to mode 1 (A-B of one kernel).
+int g_attn_dma = 2;
+
+// waves per workgroup of the lean kernels: 4 (default; two workgroups per CU) or 8 (one workgroup per CU, a K / V tile serves twice the rows: measured 15 %
+// slower end to end at the C3 shape although its tile loop is faster -- scripts/experiments/r03_attn_fwd_pingpong.hip.txt; kept for A-B: ecgb_set_attn_lean_waves)
+int g_lean_waves = 4;
+// forward / dQ lean kernels: HW = gcd(G, waves) query heads of a KV group per workgroup (a power of two), waves / HW blocks of 32 rows
+struct LeanGeom { int hw_log2; unsigned grid; };
+LeanGeom lean_geom(int seq, int n_q_heads, int n_kv_heads, int batch)
+{
+    const int G = n_q_heads / n_kv_heads;
+    int l2 = 0;
+    while ((2 << l2) <= g_lean_waves && G % (2 << l2) == 0) ++l2;
+    const int rows = (g_lean_waves >> l2) * 32;
+    return {l2, (unsigned)((seq + rows - 1) / rows) * (unsigned)(n_q_heads >> l2) * (unsigned)batch};
+}
 
 int check_args(const AttnArgs &A, int D, const char *who)
 {
@@ -1412,7 +1977,14 @@ extern "C" int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev
         hipLaunchKernelGGL(attn_fwd_kernel<D_>, grid, dim3(256), lds, (hipStream_t)stream, A); } while (0)
     if (head_dim == 64) {
         const int lds = 6 * 128 * 64 + 4 * ((seq + 63) & ~63);
-        if (g_attn_dma) {
+        if ((g_attn_dma & 3) == 2 && !(g_attn_dma & 0x100)) {
+            const int ldl = 2 * kLeanRing * 128 * 64 + 4 * ((seq + 63) & ~63);
+            const LeanGeom lg = lean_geom(seq, n_q_heads, n_kv_heads, batch);
+            A.lean_hw_log2 = lg.hw_log2;
+            auto kf = g_lean_waves == 8 ? attn_fwd_lean_kernel<8> : attn_fwd_lean_kernel<4>;
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, ldl) == hipSuccess)
+                hipLaunchKernelGGL(kf, dim3(lg.grid), dim3(g_lean_waves * 64), ldl, (hipStream_t)stream, A);
+        } else if (g_attn_dma & 3) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess)
                 hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), lds, (hipStream_t)stream, A);
         } else ECGB_FWD(64);
@@ -1477,17 +2049,25 @@ extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev
         hipLaunchKernelGGL(attn_bwd_dq_kernel<D_>, gq, dim3(256), lq, (hipStream_t)stream, A); \
         } while (0)
     if (head_dim == 64) {
-        if (g_attn_dma) {
-            const int lq = 6 * 128 * 64 + 4 * ((seq + 63) & ~63);
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lq) == hipSuccess)
-                hipLaunchKernelGGL(attn_bwd_dq_dma_kernel, gq, dim3(256), lq, (hipStream_t)stream, A);
+        const bool lean = (g_attn_dma & 3) == 2;
+        if (g_attn_dma & 3) {
+            const bool lq_lean = lean && !(g_attn_dma & 0x200);
+            const int lq = (lq_lean ? 2 * kLeanRing : 6) * 128 * 64 + 4 * ((seq + 63) & ~63);
+            const LeanGeom lg = lean_geom(seq, n_q_heads, n_kv_heads, batch);
+            A.lean_hw_log2 = lg.hw_log2;
+            auto kq = !lq_lean ? attn_bwd_dq_dma_kernel : g_lean_waves == 8 ? attn_bwd_dq_lean_kernel<8> : attn_bwd_dq_lean_kernel<4>;
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, lq) == hipSuccess)
+                hipLaunchKernelGGL(kq, lq_lean ? dim3(lg.grid) : gq, dim3(lq_lean ? g_lean_waves * 64 : 256), lq, (hipStream_t)stream, A);
         } else {
             ECGB_BWD(64);
         }
-        if (g_attn_dma) {
-            const int lk = 3 * (2 * 128 * 64 + 1024);
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lk) == hipSuccess)
-                hipLaunchKernelGGL(attn_bwd_dkv_dma_kernel, dim3(gk), dim3(256), lk, (hipStream_t)stream, A);
+        if (g_attn_dma & 3) {
+            const bool lk_lean = lean && !(g_attn_dma & 0x400);
+            const int lk = lk_lean ? kLeanRing * (2 * 128 * 64 + g_lean_waves * 256) : 3 * (2 * 128 * 64 + 1024);
+            auto kk = !lk_lean ? attn_bwd_dkv_dma_kernel : g_lean_waves == 8 ? attn_bwd_dkv_lean_kernel<8> : attn_bwd_dkv_lean_kernel<4>;
+            const unsigned gkl = (unsigned)((seq + g_lean_waves * 32 - 1) / (g_lean_waves * 32)) * (unsigned)n_kv_heads * (unsigned)batch;
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, lk) == hipSuccess)
+                hipLaunchKernelGGL(kk, dim3(lk_lean ? gkl : gk), dim3(lk_lean ? g_lean_waves * 64 : 256), lk, (hipStream_t)stream, A);
         } else {
             const int lk = 4 * 128 * 64 + 512; ECGB_DKV(64, 1, 0);
         }
@@ -1614,14 +2194,22 @@ extern "C" int ecgb_kv_append(const void *src_dev, long long src_ld, long long c
 #ifdef ECGB_PROFILE
 extern "C" void ecgb_debug_attn_profile(unsigned long long *out8, int reset)
 {
-    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_attn_prof), 32 * sizeof(unsigned long long));
-    if (reset) { unsigned long long z[32] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), z, sizeof z); }
+    if (out8) (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_attn_prof), 64 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[64] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), z, sizeof z); }
 }
 #endif
 
-// head_dim 64, forward and backward: 1 = tiles by LDS-DMA two tiles ahead (default), 0 = the register-staged kernels (tests, A/B)
-extern "C" int ecgb_set_attn_fwd_staging(int dma)
+// head_dim 64, forward and backward: 2 = the lean LDS-DMA kernels (default), 1 = the round-2 LDS-DMA kernels, 0 = the register-staged kernels (tests, A/B);
+// | 0x100 / 0x200 / 0x400 with mode 2: the forward / dQ / dK-dV kernel alone stays on mode 1
+extern "C" int ecgb_set_attn_lean_waves(int waves)
 {
-    g_attn_dma = dma ? 1 : 0;
+    if (waves != 4 && waves != 8) { ecgb::set_error("ecgb_set_attn_lean_waves: 4 or 8"); return ECGB_ERR_INVALID; }
+    g_lean_waves = waves;
+    return ECGB_OK;
+}
+extern "C" int ecgb_set_attn_fwd_staging(int mode)
+{
+    if ((mode & 3) == 3 || (mode & ~0x703)) { ecgb::set_error("ecgb_set_attn_fwd_staging: mode 0, 1 or 2 (| 0x100 | 0x200 | 0x400)"); return ECGB_ERR_INVALID; }
+    g_attn_dma = mode;
     return ECGB_OK;
 }

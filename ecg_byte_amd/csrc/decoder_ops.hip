@@ -486,6 +486,112 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(unsigned short *logits,
     }
 }
 
+// The same with the row held in REGISTERS: one read of the logits and one write of the gradient, the algorithmic minimum (the kernel above
+// reads a 265 KB row three times -- maximum, sum, gradient; the second and third come from L2, but the three dependent sweeps with two exp passes
+// ran at 0.31 of the HBM rate).  512 threads per row, thread t owns the 16-byte chunks t, t + 512, ... (MAXC of them: 40 cover 163 840
+// columns -- Llama's 132 608 --: 160 packed registers of the 256 a thread has at two waves per SIMD; with 1 024 threads x 20 chunks and a 128-register
+// budget hipcc spilled 100-600 registers whatever the sweeps looked like.  Wider vocabularies (Gemma) stay on the kernel above).  Statistics as
+// before: block maximum, then the sum of exp(v - max) in a fixed order (wave shuffles, then the eight wave sums in wave order): the same bits every launch.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi)     // one v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN)
+{
+    using bf2_t = __attribute__((ext_vector_type(2))) __bf16;
+    bf2_t v;
+    v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+template <int MAXC>
+__global__ __launch_bounds__(512) void ce_fwd_bwd_reg_kernel(unsigned short *logits, const long long *labels, float *row_loss,
+                                                             float *sum_loss, const float *inv_count_ptr, size_t rows, int V, size_t ld)
+{
+    __shared__ float s_red[2][8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float inv_count = *inv_count_ptr;
+    for (size_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        // per row, everything below is derived from values hipcc cannot see through: hoisted out of this loop, the forty chunk offsets, their
+        // range tests and address pairs lived across the whole row and spilled (660 scalar, 170 vector registers)
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid), "+s"(V), "+s"(ld));
+        tid &= 511;                                           // (range known again: 32-bit offsets from the row's scalar base, no 64-bit address pair per chunk)
+        unsigned short *p = logits + r * ld;
+        const long long lab = labels[r];
+        const bool valid = lab >= 0 && lab < V;
+        u32x4 v[MAXC];                                        // packed pairs stay packed: element-wise edits of a bf16x8 made hipcc keep every 16-bit lane in a register of its own
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {                      // every load issued before the first use; chunks past the row's end re-read its first chunk
+            const int c = (i * 512 + tid) * 8;
+            v[i] = *reinterpret_cast<const u32x4 *>(p + (c < (int)ld ? c : 0));
+        }
+        // columns >= V (the padded vocabulary, chunks past the row) become -inf ONCE, in the packed registers: they then drop out of the maximum, add
+        // exp(-inf) = 0 to the sum and get the gradient 0 with no per-element test in the sweeps (only the chunk that holds column V is partial)
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            if ((i + 1) * 4096 <= V) continue;                // (uniform) every lane's chunk of this round is whole
+            const int lim = V - (i * 512 + tid) * 8;
+            if (lim < 8) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    v[i][d] = (2 * d < lim ? v[i][d] & 0xFFFFu : 0xFF80u) | (2 * d + 1 < lim ? v[i][d] & 0xFFFF0000u : 0xFF800000u);
+            }
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) m = fmaxf(m, fmaxf(__uint_as_float(v[i][d] << 16), __uint_as_float(v[i][d] & 0xFFFF0000u)));
+        }
+        m = wave_max(m);
+        if (lane == 0) s_red[0][wv] = m;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 8; ++w) m = fmaxf(m, s_red[0][w]);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { s += __expf(__uint_as_float(v[i][d] << 16) - m); s += __expf(__uint_as_float(v[i][d] & 0xFFFF0000u) - m); }
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // bounds how many expansions hipcc keeps in flight (registers)
+        }
+        s = wave_sum(s);
+        if (lane == 0) s_red[1][wv] = s;
+        __syncthreads();
+        s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += s_red[1][w];
+        const float lse = m + logf(s);
+        if (tid == 0) {
+            const float l = valid ? lse - bf2f(p[lab]) : 0.f;        // p[lab] is read before any thread has stored: the stores follow the barrier below
+            row_loss[r] = l;
+            if (valid && sum_loss) atomicAdd(sum_loss, l * inv_count);
+        }
+        __syncthreads();
+        const float scale = valid ? inv_count : 0.f;
+        const int lab_c = valid ? (int)lab : -1;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = (i * 512 + tid) * 8;
+            u32x4 o;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                o[d] = pack2_bf16(__expf(__uint_as_float(v[i][d] << 16) - lse) * scale, __expf(__uint_as_float(v[i][d] & 0xFFFF0000u) - lse) * scale);
+            if ((unsigned)(lab_c - i * 4096) < 4096u) {              // (uniform) the label column lies in this round of chunks: one lane owns it
+                const int j = lab_c - c;
+                if ((unsigned)j < 8u) {
+                    const unsigned w = v[i][j >> 1];
+                    const float x = (j & 1) ? __uint_as_float(w & 0xFFFF0000u) : __uint_as_float(w << 16);
+                    const unsigned g = pack2_bf16((__expf(x - lse) - 1.f) * scale, 0.f) & 0xFFFFu;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        if (d == (j >> 1)) o[d] = (j & 1) ? (o[d] & 0xFFFFu) | (g << 16) : (o[d] & 0xFFFF0000u) | g;
+                }
+            }
+            if ((i + 1) * 4096 <= (int)ld) *reinterpret_cast<u32x4 *>(p + c) = o;      // (uniform) whole round inside the row
+            else if (c < (int)ld) *reinterpret_cast<u32x4 *>(p + c) = o;
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // number of labels != -100 -> *inv_count = 1 / max(count, 1)   (mean reduction, loss_utils.py:24-29)
 __global__ __launch_bounds__(256) void count_labels_kernel(const long long *labels, size_t n, int V, float *inv_count)
 {
@@ -785,6 +891,9 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const unsigned short *
 
 #define ECGB_CHECK_LAUNCH(name) return ok_or(hipGetLastError(), name)
 
+int g_ce_in_registers = 1;   // ecgb_ce_fwd_bwd: rows that fit (ld <= 163 840) are held in registers (one read, one write); 0 = the three-sweep kernel (A/B, tests)
+extern "C" int ecgb_set_ce_in_registers(int on) { g_ce_in_registers = on ? 1 : 0; return ECGB_OK; }
+
 extern "C" int ecgb_embed_fwd(const int64_t *ids_dev, const void *table_dev, void *out_dev, size_t tokens, int hidden,
                               float scale, void *stream)
 {
@@ -928,6 +1037,12 @@ extern "C" int ecgb_ce_fwd_bwd(void *logits_dev, const int64_t *labels_dev, floa
                                const float *inv_count_dev, size_t rows, int vocab, size_t ld, void *stream)
 {
     if (ld % 8) { ecgb::set_error("ecgb_ce_fwd_bwd: leading dimension must be a multiple of 8"); return ECGB_ERR_INVALID; }
+    if (g_ce_in_registers && ld <= (size_t)40 * 512 * 8) {           // the row fits 512 threads x 40 chunks of 8: one read, one write
+        hipLaunchKernelGGL(ce_fwd_bwd_reg_kernel<40>, dim3((unsigned)std::min<size_t>(std::max<size_t>(rows, 1), 4096)), dim3(512), 0,
+                           (hipStream_t)stream, (unsigned short *)logits_dev, (const long long *)labels_dev, row_loss_dev, sum_loss_dev,
+                           inv_count_dev, rows, vocab, ld);
+        ECGB_CHECK_LAUNCH("ce_fwd_bwd (registers)");
+    }
     hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3((unsigned)std::min<size_t>(std::max<size_t>(rows, 1), 4096)), dim3(256), 0,
                        (hipStream_t)stream, (unsigned short *)logits_dev, (const long long *)labels_dev, row_loss_dev, sum_loss_dev,
                        inv_count_dev, rows, vocab, ld);

@@ -616,8 +616,22 @@ __global__ __launch_bounds__(1024) void encode_flow_kernel(EncodeArgs A)
         for (uint32_t seg_base = 0; seg_base < n; seg_base += SEG) {
             const uint32_t seg_len = min(SEG, n - seg_base);
             const uint32_t stage_len = min(sym_cap, (n - seg_base + 16u) & ~15u);   // >= 1 sentinel past n
-            stage_symbols<0, INPUT, VEC>(sym, stage_len, n - seg_base, A.signal + row + seg_base,
-                                         A.raw + row + seg_base, c, 64, qa, qscale, qnas, qamb, s_thr, s_b2c);
+            // The look-ahead margin of the previous segment IS the head of this one: its symbol bytes are still in LDS, untouched (the resolve phase
+            // writes lengths only at token starts < seg_len), so they move down inside LDS instead of being fetched and classified again -- the margin
+            // was staged twice per segment: 6.5 % of the signal traffic at C2's 3 456-symbol segments (profiles/r02/hbm_pmc.json: 2.36 GB against 2.04).
+            // Both stagings end at the same absolute position (SEG is a multiple of 16), so every sentinel this segment needs is in the moved bytes too.
+            const uint32_t pre = (seg_base == 0) ? 0u : min(A.margin, stage_len);
+            if (pre) {
+                for (uint32_t k = c * 4; k < pre; k += 256) {
+                    const uint32_t v = *reinterpret_cast<const uint32_t *>(sym + SEG + k);
+                    *reinterpret_cast<uint32_t *>(sym + k) = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const uint32_t n_rest = n - seg_base;
+            stage_symbols<0, INPUT, VEC>(sym + pre, stage_len - pre, n_rest > pre ? n_rest - pre : 0u, A.signal + row + seg_base + pre,
+                                         A.raw + row + seg_base + pre, c, 64, qa, qscale, qnas, qamb, s_thr, s_b2c);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             build_dmap<0>(sym, dmap, stage_len, c, 64);

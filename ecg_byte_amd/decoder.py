@@ -744,6 +744,34 @@ class HipCausalLM(nn.Module):
         ops.embed_bwd_sorted_(ids, g, view, scale, skip_id)
         param.grad = view
 
+    def _embedding_grad_sparse(self, live_ids, g, skip_id):
+        """Data-parallel form of _embedding_grad: the table's slice of the flat buffer already holds the MEAN over the ranks of the tied head's dE (its
+        all-reduce left when backward started and is waited for here); every rank reduces the rows of g by id into a compact [distinct ids, H] table
+        (ecgb_embed_bwd_sorted on the ranks of the ids), the ranks exchange (ids, rows) (GradAllReduce.exchange_rows) and each adds all of them, divided
+        by the world size, in rank order: avg(head) + sum_r scatter_r / W = avg(head + scatter), the same gradient the dense exchange produces (up to
+        one more bf16 rounding of the sparse rows), with a tail of a few MB after the last layer instead of the 0.54 GB table."""
+        gs = self.grad_sync
+        view = self._gview[id(self.embed)]
+        ids = live_ids if skip_id < 0 else live_ids.masked_fill(live_ids == skip_id, -1)
+        uniq, inv = torch.unique(ids, sorted=True, return_inverse=True)
+        if uniq.numel() and int(uniq[0]) < 0:                                 # -1: masked / padding rows, no gradient
+            uniq, inv = uniq[1:], inv - 1
+        rows = torch.zeros((max(int(uniq.numel()), 1), view.shape[1]), dtype=torch.bfloat16, device=view.device)
+        ops.embed_bwd_sorted_(inv, g, rows, self.embed_scale, -1)             # compact: row j = the sum over the tokens whose id is uniq[j]
+        parts = gs.exchange_rows(uniq, rows[: uniq.numel()])
+        v_lo, v_hi = view.data_ptr(), view.data_ptr() + view.numel() * 2
+        overlaps = lambda t: t.data_ptr() < v_hi and t.data_ptr() + t.numel() * t.element_size() > v_lo
+        for t, work, divide in gs.pending:                                    # the dense part (issued first) has landed
+            if overlaps(t):
+                work.wait()
+                if divide and gs.world > 1:
+                    t.div_(gs.world)
+        gs.pending = [(t, w, dv) for t, w, dv in gs.pending if not overlaps(t)]
+        W = float(max(1, len(parts)))
+        for ids_r, rows_r in parts:                                           # rank order: the same bits on every rank
+            if ids_r.numel():
+                ops.embed_bwd_sorted_(ids_r, rows_r, view, 1.0 / W, -1)
+
     # ---- inference -----------------------------------------------------------------------------
     def _hidden_states(self, input_ids, attention_mask=None, position_ids=None, kv_out=None):
         """Final-normed hidden states [B*S, H] of a whole (left-padded) batch, nothing saved for backward.  kv_out: optional
@@ -1019,6 +1047,17 @@ class HipCausalLM(nn.Module):
 
         self._grad_layout()
         L = c.num_hidden_layers
+        # Data parallel: the tied head's share of the embedding gradient (dense, 0.54 GB at Llama-3.2-1B's vocabulary) was finished by the loss head in
+        # the forward pass -- it leaves NOW, under the whole backward; what the input rows add at the very end travels as (ids, rows) (see _embedding_grad_sparse)
+        sparse_embed = (not frozen and self.grad_sync is not None and getattr(self.grad_sync, "sparse_embedding", False)
+                        and self.embed.grad is None)
+        if sparse_embed:
+            view, _ = self._grad_slot(self.embed)
+            view.copy_(self.embed_grad_head)
+            self.embed.grad = view
+            off = (view.data_ptr() - self._gflat.data_ptr()) // 2
+            self.grad_sync.on_flat_ready(self._gflat, off, off + view.numel())
+            self.grad_sync._flush()
 
         def wgrad(dy, xin, param):
             """param.grad = dy^T . xin (bf16): contraction over the token rows of both operands, no transposed copies"""
@@ -1080,10 +1119,16 @@ class HipCausalLM(nn.Module):
         if not frozen:
             pad = c.pad_token_id if c.pad_token_id is not None else -1       # nn.Embedding(padding_idx): no lookup gradient for that row
             live_ids = input_ids.view(-1).masked_fill(mask.reshape(-1) == 0, -1)   # masked positions: gradient exactly zero, skipped as one run
-            self._embedding_grad(self.embed, self.embed_grad_head, live_ids, g, self.embed_scale, pad)
+            if sparse_embed:
+                self._embedding_grad_sparse(live_ids, g, pad)
+            else:
+                self._embedding_grad(self.embed, self.embed_grad_head, live_ids, g, self.embed_scale, pad)
         if self.grad_sync is not None:
             if not frozen:
-                self.grad_sync.on_flat_ready(self._gflat, *self._granges[L])
+                lo, hi = self._granges[L]
+                if sparse_embed:                                  # the table's slice has been exchanged already: only what lies behind it (the final norm)
+                    lo = (self._gview[id(self.embed)].data_ptr() - self._gflat.data_ptr()) // 2 + (self.embed.numel() + 127) // 128 * 128
+                self.grad_sync.on_flat_ready(self._gflat, lo, hi)
             self.grad_sync.finish()
 
     # ---- fused optimizer (clip_grad_norm_(1.0) + Adam with L2, Noam schedule) -------------------------

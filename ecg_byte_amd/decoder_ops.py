@@ -501,9 +501,21 @@ def attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale):
     return o, lse
 
 
-def set_attn_fwd_staging(dma: bool):
-    """head_dim 64 forward: LDS-DMA staging (default) or the register-staged kernel (tests, A/B)."""
-    _lib.check(_L().ecgb_set_attn_fwd_staging(int(bool(dma))))
+def set_ce_in_registers(on: bool = True):
+    """ecgb_ce_fwd_bwd: hold each row of logits in registers (one read, one write; default) or run the three-sweep kernel (A/B, tests)."""
+    _lib.check(_L().ecgb_set_ce_in_registers(int(bool(on))))
+
+
+def set_attn_lean_waves(waves: int = 4):
+    """Waves per workgroup of the lean head_dim-64 attention kernels (4: default, 8: A/B)."""
+    _lib.check(_L().ecgb_set_attn_lean_waves(int(waves)))
+
+
+def set_attn_fwd_staging(mode: int = 2):
+    """head_dim 64 forward / backward kernels: 2 = lean LDS-DMA kernels (default: softmax constants in the MFMA accumulators, deferred running
+    maximum), 1 = the round-2 LDS-DMA kernels, 0 = the register-staged kernels (tests, A/B).  With 2: | 0x100 / 0x200 / 0x400 keeps the forward /
+    dQ / dK-dV kernel alone on mode 1."""
+    _lib.check(_L().ecgb_set_attn_fwd_staging(int(mode)))
 
 
 def attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale):

@@ -65,8 +65,12 @@ class GradAllReduce:
     in-place scale per bucket.  `on_grads_ready(params)` is the per-tensor path for gradients that are not part of
     a flat buffer.  `finish()` sends what is left and waits for everything."""
 
-    def __init__(self, process_group=None, bucket_bytes: int = 25 << 20, single_rank_collectives: bool = False):
+    def __init__(self, process_group=None, bucket_bytes: int = 25 << 20, single_rank_collectives: bool = False, time_exposed: bool = False,
+                 rsag_mb=None, sparse_embedding=None):
         self.pg = process_group
+        self.steps = 0             # finish() calls
+        self._time_exposed = bool(time_exposed) and torch.cuda.is_available()
+        self._exposed = []         # (event before the waits, event after them) per step
         self.bucket_bytes = int(bucket_bytes)
         self.pending = []          # (tensor, work, needs_divide)
         self.open = None           # (flat, lo, hi): ready, not yet sent
@@ -83,6 +87,17 @@ class GradAllReduce:
         # with an active exchange and restores it (`backward_kernels()`), and later models / evaluation in the process keep the
         # persistent kernels.  The one-rank RCCL leg (`single_rank_collectives`) makes the same choice as world > 1.
         self.one_tile_backward = bool(self.active and torch.cuda.is_available())
+        # buckets of at least this many bytes leave as reduce-scatter + all-gather (0 = never): ECGB_GRAD_EXCHANGE=rsag (64 MB) or rsag:<MB>
+        import os
+        mode = os.environ.get("ECGB_GRAD_EXCHANGE", "") if rsag_mb is None else f"rsag:{rsag_mb}"
+        self.rsag_bytes = 0
+        if mode.startswith("rsag"):
+            self.rsag_bytes = int(float(mode.split(":")[1]) * (1 << 20)) if ":" in mode else 64 << 20
+        self.rsag_buckets = 0
+        # the embedding table's gradient = tied head's dE (dense, final when backward STARTS) + the scatter of the input rows (sparse, final when it
+        # ends): with `sparse_embedding` the model sends the dense part first and the sparse part as (ids, rows) -- the exposed tail of a step is
+        # then a few MB instead of the 0.54 GB table
+        self.sparse_embedding = bool(sparse_embedding) if sparse_embedding is not None else (self.active and self.world > 1)
 
     def backward_kernels(self):
         """Context manager for one backward pass: one-tile input-gradient GEMMs while an exchange can be in flight."""
@@ -103,8 +118,66 @@ class GradAllReduce:
 
     def _send(self, t):
         op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
+        if self.rsag_bytes and t.numel() * t.element_size() >= self.rsag_bytes and self.world > 1:
+            return self._send_rsag(t, op)
         self.pending.append((t, dist.all_reduce(t, op=op, group=self.pg, async_op=True), not self.avg))
         self.collectives += 1
+
+    def _send_rsag(self, t, op):
+        """Explicit reduce-scatter + all-gather of one large bucket (2.49 GB of full fine-tune gradients; a reduce-scatter
+        followed by an all-gather moves 2 (W-1)/W of the bytes like a ring all-reduce but lets RCCL run each half as a direct exchange over all seven
+        xGMI links).  Selected by ECGB_GRAD_EXCHANGE=rsag[:min_mb] or rsag_mb=...; unmeasured on hardware (no multi-GPU node this round): both forms are
+        here so that they can be timed the day one exists.  The bucket is cut at a multiple of the world size; the remainder (< world elements) goes
+        through a plain all-reduce.  RCCL orders the two collectives on its stream; gloo (CPU tests) has no reduce-scatter: there the shard is cut from
+        an all-reduce, which exercises the same bookkeeping."""
+        W = self.world
+        n = (t.numel() // W) * W
+        body, rest = t[:n], t[n:]
+        r = dist.get_rank(self.pg)
+        shard = body.view(W, -1)[r]
+        if self.avg:
+            w1 = dist.reduce_scatter_tensor(shard, body, op=op, group=self.pg, async_op=True)
+            w2 = dist.all_gather_into_tensor(body, shard, group=self.pg, async_op=True)
+            self.pending.append((body, w1, False))
+            self.pending.append((body, w2, False))
+        else:
+            w1 = dist.all_reduce(body, op=op, group=self.pg, async_op=True)       # gloo: stands in for the reduce-scatter
+            w1.wait()
+            body.div_(W)
+            full = [torch.empty_like(shard) for _ in range(W)]
+            w2 = dist.all_gather(full, shard.contiguous(), group=self.pg, async_op=True)
+            w2.wait()
+            for k in range(W):
+                body.view(W, -1)[k].copy_(full[k])
+        self.collectives += 2
+        self.rsag_buckets += 1
+        if rest.numel():
+            self.pending.append((rest, dist.all_reduce(rest, op=op, group=self.pg, async_op=True), not self.avg))
+            self.collectives += 1
+
+    def exchange_rows(self, ids, rows):
+        """Sparse part of an embedding gradient: every rank contributes (ids [n] int64, unique and sorted; rows [n, H]) -- the per-id sums of its own
+        batch -- and gets back the list [(ids_r, rows_r)] of all ranks in rank order (its own included).  One all-gather of the counts (host
+        sync: a few bytes), then padded all-gathers of the ids and the rows: W x max_n x H elements instead of the whole table (0.54 GB for
+        Llama-3.2-1B's 132 k x 2048 embedding; a batch touches a few thousand distinct ids).  The caller adds rows_r / W to its table in rank order."""
+        if not self.active or self.world == 1:
+            return [(ids, rows)]
+        W = self.world
+        n = torch.tensor([ids.numel()], dtype=torch.int64, device=ids.device)
+        counts = [torch.zeros_like(n) for _ in range(W)]
+        dist.all_gather(counts, n, group=self.pg)
+        counts = [int(c.item()) for c in counts]
+        cap = max(max(counts), 1)
+        pid = torch.full((cap,), -1, dtype=torch.int64, device=ids.device)
+        pid[: ids.numel()] = ids
+        prow = torch.zeros((cap, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        prow[: rows.shape[0]] = rows
+        gid = [torch.empty_like(pid) for _ in range(W)]
+        grow = [torch.empty_like(prow) for _ in range(W)]
+        dist.all_gather(gid, pid, group=self.pg)
+        dist.all_gather(grow, prow, group=self.pg)
+        self.collectives += 3
+        return [(gid[k][: counts[k]], grow[k][: counts[k]]) for k in range(W)]
 
     def _flush(self):
         if self.open is not None:
@@ -133,8 +206,23 @@ class GradAllReduce:
 
     def finish(self):
         self._flush()
+        self.steps += 1
+        ev = None
+        if self._time_exposed and self.active:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for t, work, divide in self.pending:
             work.wait()
             if divide and self.world > 1:
                 t.div_(self.world)
+        if ev is not None:
+            ev[1].record()
+            self._exposed.append(ev)
         self.pending = []
+
+    def exposed_ms(self) -> float:
+        """Total time the compute stream spent waiting in finish() for buckets still in flight (needs time_exposed=True; synchronises)."""
+        if not self._exposed:
+            return 0.0
+        torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in self._exposed))

@@ -187,6 +187,9 @@ int ecgb_count_labels(const int64_t *labels_dev, size_t n, int vocab, float *inv
  * ignored); sum_loss_dev += sum(row losses) * inv_count; logits are overwritten with d(loss)/d(logits). */
 int ecgb_ce_fwd_bwd(void *logits_dev, const int64_t *labels_dev, float *row_loss_dev, float *sum_loss_dev,
                     const float *inv_count_dev, size_t rows, int vocab, size_t ld, void *stream);
+/* 1 (default): rows with ld <= 163 840 are held in registers by 1 024-thread workgroups -- one read of the logits, one write of the gradient;
+ * 0: the three-sweep kernel (maximum, sum, gradient), which wider vocabularies always take.  Same loss and gradients up to the order of the fp32 sums. */
+int ecgb_set_ce_in_registers(int on);
 
 /* acc_dev += sum(g^2) */
 int ecgb_sumsq(const void *g_dev, size_t n, int is_fp32, float *acc_dev, void *stream);
@@ -221,9 +224,13 @@ int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev, long long
                   int n_q_heads, int n_kv_heads, int head_dim, float scale, void *stream);
 /* dq/dk/dv from dO (same layout as o).  delta_dev [batch, n_q_heads, seq] fp32 is scratch (rowsum(dO*O)).
  * dK/dV sum over the query heads of each KV group inside the kernel (no atomics). */
-/* head_dim 64 forward: 1 = K / V tiles by LDS-DMA two tiles ahead into a ring of three buffers, V gathered by transposing LDS reads (default);
- * 0 = the register-staged kernel (kept for A/B and as the cross-check in the tests). */
-int ecgb_set_attn_fwd_staging(int dma);
+/* head_dim 64 forward and backward: 2 = the lean kernels (default): tiles by LDS-DMA two tiles ahead into a ring of three buffers, the register operand
+ * pre-scaled by scale * log2 e, the softmax row constants (running maximum / log-sum-exp / delta) as the initial accumulators of the score products,
+ * forward running maximum deferred; 1 = the round-2 LDS-DMA kernels; 0 = the register-staged kernels (1 and 0 are bit-identical to each other and kept
+ * for A/B and as cross-checks).  With 2, | 0x100 / 0x200 / 0x400 keeps the forward / dQ / dK-dV kernel alone on mode 1.  ECGB_ERR_INVALID otherwise. */
+int ecgb_set_attn_fwd_staging(int mode);
+/* waves per workgroup of the lean kernels: 4 (default) or 8 (a K / V tile serves gcd(G, 8) query heads x 256 / gcd rows; A/B). */
+int ecgb_set_attn_lean_waves(int waves);
 /* scratch of ecgb_attn_bwd: fp32 partial dK / dV slabs when the query heads of a KV group are split over workgroups (head_dim 256 with
  * few key blocks: Gemma); 0 for every other shape (scratch_dev may then be null). */
 size_t ecgb_attn_bwd_scratch_bytes(int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim);

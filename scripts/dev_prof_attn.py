@@ -7,6 +7,8 @@ from ecg_byte_amd import _lib
 _lib.SO_PATH = os.path.join(os.path.dirname(_lib.SO_PATH), "libecgbyte_hip_prof.so")
 from ecg_byte_amd import decoder_ops as ops
 B, S, Hq, Hkv, D = 32, 1024, 32, 8, 64
+NWAVES = int(os.environ.get("LEAN_WAVES", "8"))
+ops.set_attn_lean_waves(NWAVES)
 qkv = torch.randn(B * S, (Hq + 2 * Hkv) * D, device="cuda").to(torch.bfloat16)
 mask = torch.ones(B, S, device="cuda")
 L = _lib.lib()
@@ -15,10 +17,10 @@ for _ in range(2): ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, 1 / math.sqrt(D))
 torch.cuda.synchronize()
 L.ecgb_debug_attn_profile(None, 1)
 ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, 1 / math.sqrt(D)); torch.cuda.synchronize()
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 64)()
 L.ecgb_debug_attn_profile(out, 0)
-names = ["top: issue next tile's loads", "S: K reads + MFMA + max", "softmax", "PV: V reads + MFMA issue", "write next tile to LDS (waits for its loads)", "barrier"]
-for w in range(4):
+names = ["issue: DMA of a later tile", "S: K reads + 8 MFMA + V^T reads", "softmax: exp sweep (+ exact path)", "PV: 8 MFMA issue", "wait: vmcnt of the next tile", "barrier"]
+for w in range(NWAVES):
     o = out[8 * w: 8 * w + 8]
     trips = o[6]
     tot = sum(o[k] for k in range(6))

@@ -241,3 +241,62 @@ def test_main_dis_under_torchrun_environment_still_initialises_from_it(tmp_path)
     recs = [json.load(open(f"{probe}_{k}.json")) for k in range(2)]
     assert [x["local_rank"] for x in recs] == [0, 1] and all(x["sum"] == 3.0 and x["world"] == 2 for x in recs)
     assert len({x["ppid"] for x in recs}) == 1 and recs[0]["ppid"] == os.getpid()       # no intermediate spawner
+
+
+def _lora_bucket_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ecg_byte_amd import parallel
+        # LoRA r16 on Llama-3.2-1B widths, the stacked layout of decoder.LoraSite: per layer A [64, in] + B [out, 64] for the four sites
+        # (qkv 2048 -> 3072, o 2048 -> 2048, gate|up 2048 -> 16384, down 8192 -> 2048), every slice padded to 128 elements; 16 layers, last first
+        per_layer = sum((64 * i + 127) // 128 * 128 + (o * 64 + 127) // 128 * 128 for i, o in ((2048, 3072), (2048, 2048), (2048, 16384), (8192, 2048)))
+        layers = 16
+        g = torch.Generator().manual_seed(200 + rank)
+        flat = torch.randn(layers * per_layer, generator=g).to(torch.bfloat16)
+        mine = flat.clone()
+        sync = parallel.GradAllReduce()                                  # DDP's 25 MB buckets
+        for i in range(layers):
+            sync.on_flat_ready(flat, i * per_layer, (i + 1) * per_layer)
+        before = sync.collectives
+        sync.finish()
+        # the same exchange as reduce-scatter + all-gather for buckets of >= 1 MB (the gloo stand-in exercises cut, remainder and order)
+        flat2 = mine.clone()[: layers * per_layer - 3]                   # a length the world size does not divide
+        sync2 = parallel.GradAllReduce(bucket_bytes=8 << 20, rsag_mb=1)
+        step = 3 * per_layer
+        for lo in range(0, flat2.numel(), step):
+            sync2.on_flat_ready(flat2, lo, min(lo + step, flat2.numel()))
+        sync2.finish()
+        # the sparse rows of an embedding gradient
+        ids = torch.arange(rank, 40 + 3 * rank, 2 + rank)
+        rows = torch.full((ids.numel(), 8), float(rank + 1))
+        parts = parallel.GradAllReduce(sparse_embedding=True).exchange_rows(ids, rows)
+        ret[rank] = (mine, flat.clone(), before, sync.collectives, per_layer, flat2.clone(), sync2.collectives, sync2.rsag_buckets,
+                     [(a.tolist(), b[:, 0].tolist()) for a, b in parts])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_lora_buckets_rsag_and_sparse_rows_world_size_4_gloo():
+    """World size 4 (the reference's own launch, scripts/train_model.sh: four GPUs) over the LoRA adapters' flat gradient buffer: layers of
+    4.6 MiB merge into 25 MB buckets in backward order (4 collectives for 16 layers, not 128 tensors), every element ends as the mean; the
+    reduce-scatter + all-gather form gives the same means; exchange_rows hands every rank every rank's (ids, rows) in rank order."""
+    world = 4
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_lora_bucket_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    per_layer = ret[0][4]
+    assert 4.0 < per_layer * 2 / 2 ** 20 < 6.0                          # MiB of bf16 per layer: several layers per 25 MB bucket
+    want = sum(ret[r][0].float() for r in range(world)) / world
+    per_bucket = -(-(25 << 20) // (per_layer * 2))                        # layers until a bucket holds 25 MB
+    n_buckets = -(-16 // per_bucket)
+    for r in range(world):
+        assert torch.allclose(ret[r][1].float(), want, atol=2e-2, rtol=2e-2)
+        assert ret[r][3] == n_buckets and ret[r][2] in (n_buckets - 1, n_buckets)      # the last bucket may only close in finish()
+        want2 = want[: ret[r][5].numel()]
+        assert torch.allclose(ret[r][5].float(), want2, atol=2e-2, rtol=2e-2)
+        assert ret[r][7] >= 1 and ret[r][6] > ret[r][7]
+        assert ret[r][8] == ret[0][8]
+        for k, (ids, vals) in enumerate(ret[r][8]):
+            assert ids == list(range(k, 40 + 3 * k, 2 + k)) and all(v == k + 1 for v in vals)

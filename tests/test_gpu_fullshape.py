@@ -96,14 +96,87 @@ def test_attention_dma_staging_is_bitwise_the_register_staging(B, S, Hq, Hkv, pa
         ops.set_attn_fwd_staging(0)
         o0, l0 = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, 0.125)
         d0 = ops.attn_bwd(qkv, mask, o0, do, l0, B, S, Hq, Hkv, D, 0.125)
-        ops.set_attn_fwd_staging(1)
+        ops.set_attn_fwd_staging(1)                      # the round-2 LDS-DMA kernels (the default is 2: the lean kernels, tested below)
         for rep in range(4):
             o1, l1 = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, 0.125)
             assert torch.equal(o0, o1) and torch.equal(l0, l1), rep
             d1 = ops.attn_bwd(qkv, mask, o0, do, l0, B, S, Hq, Hkv, D, 0.125)
             assert torch.equal(d0, d1), (rep, (d0.float() - d1.float()).abs().max().item())
     finally:
+        ops.set_attn_fwd_staging(2)
+
+
+def _attn_ref_fp64(qkv, do, mask, B, S, Hq, Hkv, D, scale):
+    """softmax(q k^T * scale + causal / padding mask) v and its gradients in float64 on the device, one batch row at a time."""
+    q, k, v = qkv.view(B, S, Hq + 2 * Hkv, D).double().split([Hq, Hkv, Hkv], dim=2)
+    G = Hq // Hkv
+    o = torch.empty(B, S, Hq, D, dtype=torch.float64, device="cuda")
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    causal = torch.tril(torch.ones(S, S, dtype=torch.bool, device="cuda"))
+    for b in range(B):
+        qb, kb, vb = (t[b].transpose(0, 1).clone().requires_grad_(True) for t in (q, k, v))             # [H, S, D]
+        vis = causal & (mask[b] != 0)[None, :]
+        s = torch.einsum("hqd,hkd->hqk", qb, kb.repeat_interleave(G, 0)) * scale
+        s = s.masked_fill(~vis[None], float("-inf"))
+        p = torch.softmax(s, -1).nan_to_num(0.0)                                                         # rows without a visible key: zeros
+        ob = torch.einsum("hqk,hkd->hqd", p, vb.repeat_interleave(G, 0))
+        ob.backward(do.view(B, S, Hq, D)[b].double().transpose(0, 1))
+        o[b] = ob.detach().transpose(0, 1)
+        dq[b], dk[b], dv[b] = qb.grad.transpose(0, 1), kb.grad.transpose(0, 1), vb.grad.transpose(0, 1)
+    return o, torch.cat([dq, dk, dv], 2).reshape(B * S, -1)
+
+
+@pytest.mark.parametrize("B,S,Hq,Hkv,pads", [(4, 1024, 32, 8, True), (2, 1024, 32, 8, False), (3, 1000, 8, 2, True), (5, 70, 4, 4, True), (2, 2048, 4, 1, True)],
+                         ids=["c3-pads", "c3", "ragged", "short", "long"])
+def test_lean_attention_kernels_against_float64_and_the_round2_kernels(B, S, Hq, Hkv, pads):
+    """The lean head_dim-64 kernels (the default) pre-scale the register operand and keep the softmax constants in the MFMA accumulators:
+    not the bits of the round-2 kernels, so they are held to (a) a float64 reference of the op, as close to it as the round-2 kernels are
+    (the rounding of q * scale * log2 e to bf16 is the one new error source), (b) each kernel ALONE against its round-2 counterpart on
+    the same inputs, (c) the same bits every launch."""
+    from ecg_byte_amd import decoder_ops as ops
+    D, scale = 64, 0.125
+    qkv, do = _bf(B * S, (Hq + 2 * Hkv) * D, seed=72), _bf(B * S, Hq * D, seed=73)
+    mask = torch.ones(B, S, device="cuda")
+    if pads:
+        for b in range(B):
+            mask[b, : (37 * b + 5) % (S // 2)] = 0
+    live = (mask.view(-1) != 0)
+    o_ref, d_ref = _attn_ref_fp64(qkv, do, mask, B, S, Hq, Hkv, D, scale)
+
+    def err(x, ref):
+        x, ref = x.double().reshape(-1), ref.double().reshape(-1)
+        return ((x - ref).norm() / ref.norm()).item()
+
+    try:
         ops.set_attn_fwd_staging(1)
+        o1, l1 = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)
+        d1 = ops.attn_bwd(qkv, mask, o1, do, l1, B, S, Hq, Hkv, D, scale)
+        ops.set_attn_fwd_staging(2)
+        o2, l2 = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)
+        d2 = ops.attn_bwd(qkv, mask, o2, do, l2, B, S, Hq, Hkv, D, scale)
+        o2b, l2b = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)
+        assert torch.equal(o2, o2b) and torch.equal(l2, l2b)
+        assert torch.equal(d2, ops.attn_bwd(qkv, mask, o2, do, l2, B, S, Hq, Hkv, D, scale))
+        # (a) float64: outputs of live rows, gradients of every element
+        of = o_ref.reshape(B * S, -1)[live]
+        e1, e2 = err(o1.view(B * S, -1)[live], of), err(o2.view(B * S, -1)[live], of)
+        assert e2 < 6e-3 and e2 < 1.5 * e1 + 1e-4, (e1, e2)
+        g1, g2 = err(d1, d_ref), err(d2, d_ref)
+        assert g2 < 1.2e-2 and g2 < 1.5 * g1 + 1e-4, (g1, g2)
+        fin = torch.isfinite(l1)
+        assert torch.equal(fin, torch.isfinite(l2)) and (l1[fin] - l2[fin]).abs().max().item() < 2e-2       # log2 units
+        # (b) one lean kernel at a time on the round-2 forward's o / lse
+        for bit, name in ((0x200 | 0x400, "fwd"), (0x100 | 0x400, "dq"), (0x100 | 0x200, "dkv")):
+            ops.set_attn_fwd_staging(2 | bit)
+            if name == "fwd":
+                ox, lx = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)
+                assert torch.equal(ox, o2) and torch.equal(lx, l2)
+            else:
+                dx = ops.attn_bwd(qkv, mask, o1, do, l1, B, S, Hq, Hkv, D, scale)
+                e = err(dx, d1.double())
+                assert e < 8e-3, (name, e)
+    finally:
+        ops.set_attn_fwd_staging(2)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
