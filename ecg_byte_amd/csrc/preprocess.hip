@@ -40,6 +40,11 @@ struct FiltfiltArgs {
 //   ext = [2 x[0] - x[e..1], x, 2 x[n-1] - x[n-2..n-1-e]];  y1 = lfilter(ext, z = zi * ext[0]);  y2 = lfilter(reverse(y1), z = zi * y1[-1]);
 //   result = reverse(y2)[e : e + n]
 // lfilter step:  y = z[0] + b[0] x;  z[k] = z[k+1] + x b[k+1] - y a[k+1]  (k < nb - 2);  z[nb-2] = x b[nb-1] - y a[nb-1].
+// Round 3: the loop is the same recursion sample by sample (the same bits), but the SAMPLES move in blocks of kBlk: the next block's kBlk loads are issued
+// (independent of each other and of the recursion) before the current block is filtered, and a block's results are stored together.  The first version loaded
+// one sample, filtered it and stored it: hipcc cannot move a load above the previous store (`ext`, `mid` and the record may alias for all it knows), so every
+// step paid a memory round trip -- 560 cycles per step against ~60 of arithmetic, one wave per SIMD (22.6 ms for 4 096 records).
+constexpr int kBlk = 16;
 template <int NB, typename SRC, typename DST>
 __device__ __forceinline__ void filtfilt_one(const Filt &F, int n, SRC src, double *ext, size_t S, size_t seq, DST dst)
 {
@@ -61,14 +66,41 @@ __device__ __forceinline__ void filtfilt_one(const Filt &F, int n, SRC src, doub
     const double x0 = ext_at(0);
 #pragma unroll
     for (int k = 0; k < NB - 1; ++k) z[k] = F.zi[k] * x0;
-    for (int i = 0; i < N; ++i) ext[(size_t)i * S + seq] = step(ext_at(i));
+    double cur[kBlk], nxt[kBlk];
+    // ---- forward over the extended signal -> ext
+#pragma unroll
+    for (int u = 0; u < kBlk; ++u) cur[u] = ext_at(min(u, N - 1));
+    for (int i0 = 0; i0 < N; i0 += kBlk) {
+#pragma unroll
+        for (int u = 0; u < kBlk; ++u) nxt[u] = ext_at(min(i0 + kBlk + u, N - 1));      // the next block's loads fly while this one is filtered
+        double out[kBlk];
+#pragma unroll
+        for (int u = 0; u < kBlk; ++u) if (i0 + u < N) out[u] = step(cur[u]);
+#pragma unroll
+        for (int u = 0; u < kBlk; ++u) if (i0 + u < N) ext[(size_t)(i0 + u) * S + seq] = out[u];
+#pragma unroll
+        for (int u = 0; u < kBlk; ++u) cur[u] = nxt[u];
+    }
+    // ---- backward over ext -> dst (the middle n samples)
     const double y0 = ext[(size_t)(N - 1) * S + seq];
 #pragma unroll
     for (int k = 0; k < NB - 1; ++k) z[k] = F.zi[k] * y0;
-    for (int i = 0; i < N; ++i) {
-        const double w = step(ext[(size_t)(N - 1 - i) * S + seq]);
-        const int pos = N - 1 - i - e;
-        if (pos >= 0 && pos < n) dst(pos, w);
+    auto rev_at = [&](int i) -> double { return ext[(size_t)(N - 1 - min(i, N - 1)) * S + seq]; };
+#pragma unroll
+    for (int u = 0; u < kBlk; ++u) cur[u] = rev_at(u);
+    for (int i0 = 0; i0 < N; i0 += kBlk) {
+#pragma unroll
+        for (int u = 0; u < kBlk; ++u) nxt[u] = rev_at(i0 + kBlk + u);
+        double out[kBlk];
+#pragma unroll
+        for (int u = 0; u < kBlk; ++u) if (i0 + u < N) out[u] = step(cur[u]);
+#pragma unroll
+        for (int u = 0; u < kBlk; ++u) {
+            const int pos = N - 1 - (i0 + u) - e;
+            if (i0 + u < N && pos >= 0 && pos < n) dst(pos, out[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kBlk; ++u) cur[u] = nxt[u];
     }
 }
 
@@ -148,33 +180,75 @@ __global__ __launch_bounds__(64) void resample_cubic_kernel(ResampleArgs A)
     const double M1 = rhs(1) / 6.0, Mn2 = rhs(n - 2) / 6.0;
     M[(size_t)1 * S] = M1;
     M[(size_t)(n - 2) * S] = Mn2;
+    // Round 3: the sweeps and the evaluation move their samples in blocks of kBlk (loads of a block issued together, results stored together, the next
+    // block's loads in flight meanwhile): same arithmetic in the same order, no memory round trip per step (see filtfilt_one).
     if (n >= 6) {                                            // rows 2 .. n-3
         double dprev = (rhs(2) - M1) * cprime(2);
         M[(size_t)2 * S] = dprev;
-        for (int i = 3; i <= n - 3; ++i) {
-            double ri = rhs(i);
-            if (i == n - 3) ri -= Mn2;
-            dprev = (ri - dprev) * cprime(i);                // cprime(i) = 1 / (4 - c'[i-1])
-            M[(size_t)i * S] = dprev;
+        auto ycl = [&](int i) -> double { return Y(min(max(i, 0), n - 1)); };
+        double yc[kBlk + 2], yn[kBlk + 2];
+#pragma unroll
+        for (int u = 0; u < kBlk + 2; ++u) yc[u] = ycl(3 - 1 + u);          // rows 3 .. 3 + kBlk - 1 need Y(2) .. Y(3 + kBlk)
+        for (int i0 = 3; i0 <= n - 3; i0 += kBlk) {
+#pragma unroll
+            for (int u = 0; u < kBlk + 2; ++u) yn[u] = ycl(i0 + kBlk - 1 + u);
+            double out[kBlk];
+#pragma unroll
+            for (int u = 0; u < kBlk; ++u) {
+                const int i = i0 + u;
+                if (i <= n - 3) {
+                    double ri = 6.0 * (yc[u + 2] - 2.0 * yc[u + 1] + yc[u]);
+                    if (i == n - 3) ri -= Mn2;
+                    dprev = (ri - dprev) * cprime(i);        // cprime(i) = 1 / (4 - c'[i-1])
+                    out[u] = dprev;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kBlk; ++u) if (i0 + u <= n - 3) M[(size_t)(i0 + u) * S] = out[u];
+#pragma unroll
+            for (int u = 0; u < kBlk + 2; ++u) yc[u] = yn[u];
         }
         double Mnext = dprev;                                // M[n-3]
-        for (int i = n - 4; i >= 2; --i) {
-            Mnext = M[(size_t)i * S] - cprime(i) * Mnext;
-            M[(size_t)i * S] = Mnext;
+        double mc[kBlk], mn[kBlk];
+        auto mcl = [&](int i) -> double { return M[(size_t)max(i, 2) * S]; };
+#pragma unroll
+        for (int u = 0; u < kBlk; ++u) mc[u] = mcl(n - 4 - u);
+        for (int i0 = n - 4; i0 >= 2; i0 -= kBlk) {
+#pragma unroll
+            for (int u = 0; u < kBlk; ++u) mn[u] = mcl(i0 - kBlk - u);     // rows below this block: not written by it
+            double out[kBlk];
+#pragma unroll
+            for (int u = 0; u < kBlk; ++u) {
+                const int i = i0 - u;
+                if (i >= 2) { Mnext = mc[u] - cprime(i) * Mnext; out[u] = Mnext; }
+            }
+#pragma unroll
+            for (int u = 0; u < kBlk; ++u) if (i0 - u >= 2) M[(size_t)(i0 - u) * S] = out[u];
+#pragma unroll
+            for (int u = 0; u < kBlk; ++u) mc[u] = mn[u];
         }
     } else if (n == 5) {
         M[(size_t)2 * S] = (rhs(2) - M1 - Mn2) / 4.0;
     }
     M[0] = 2.0 * M[(size_t)1 * S] - M[(size_t)2 * S];
     M[(size_t)(n - 1) * S] = 2.0 * M[(size_t)(n - 2) * S] - M[(size_t)(n - 3) * S];
-    for (int j = 0; j < m; ++j) {
-        const double s = m > 1 ? (double)j * (double)(n - 1) / (double)(m - 1) : 0.0;
-        int i = (int)s;
-        if (i > n - 2) i = n - 2;
-        const double u = s - (double)i;
-        const double y0 = Y(i), y1 = Y(i + 1), m0 = M[(size_t)i * S], m1 = M[(size_t)(i + 1) * S];
-        const double c1 = (y1 - y0) - (2.0 * m0 + m1) / 6.0, c2 = 0.5 * m0, c3 = (m1 - m0) / 6.0;
-        out[(size_t)j * L] = y0 + u * (c1 + u * (c2 + u * c3));
+    for (int j0 = 0; j0 < m; j0 += kBlk) {
+        double y0[kBlk], y1[kBlk], m0[kBlk], m1[kBlk], uu[kBlk];
+#pragma unroll
+        for (int u = 0; u < kBlk; ++u) {
+            const int j = min(j0 + u, m - 1);
+            const double sx = m > 1 ? (double)j * (double)(n - 1) / (double)(m - 1) : 0.0;
+            int i = (int)sx;
+            if (i > n - 2) i = n - 2;
+            uu[u] = sx - (double)i;
+            y0[u] = Y(i); y1[u] = Y(i + 1); m0[u] = M[(size_t)i * S]; m1[u] = M[(size_t)(i + 1) * S];
+        }
+#pragma unroll
+        for (int u = 0; u < kBlk; ++u) {
+            if (j0 + u >= m) continue;
+            const double c1 = (y1[u] - y0[u]) - (2.0 * m0[u] + m1[u]) / 6.0, c2 = 0.5 * m0[u], c3 = (m1[u] - m0[u]) / 6.0;
+            out[(size_t)(j0 + u) * L] = y0[u] + uu[u] * (c1 + uu[u] * (c2 + uu[u] * c3));
+        }
     }
 }
 
@@ -215,70 +289,139 @@ __global__ __launch_bounds__(64) void wavelet_denoise_kernel(WaveletArgs A)
     double lo[kWF], hi[kWF];
 #pragma unroll
     for (int k = 0; k < kWF; ++k) { lo[k] = kDb6Lo[k]; hi[k] = ((k & 1) ? 1.0 : -1.0) * kDb6Lo[kWF - 1 - k]; }
-    // ---- wavedec
+    // Round 3: every loop below moves its samples in blocks (the loads of a block together, its results stored together): the sums are formed in the
+    // order they had, so the values are the first version's; what is gone is one memory round trip per coefficient (see filtfilt_one) and three quarters of
+    // the median's selection passes.
+    constexpr int kOB = 8;                                   // outputs per block
+    // ---- wavedec: cA[o], cD[o] = sum_j f[j] xe[2 o + 1 - j]: a block of kOB outputs reads xe[2 o0 - 10 .. 2 (o0 + kOB - 1) + 1]
     for (int lev = 1; lev <= kLevels; ++lev) {
         const int N = A.len[lev - 1], Nc = A.len[lev];
         auto in_at = [&](int i) -> double {                  // symmetric extension: ... x1 x0 | x0 x1 ... x[N-1] | x[N-1] x[N-2] ...
             if (i < 0) i = -1 - i;
             else if (i >= N) i = 2 * N - 1 - i;
+            i = min(max(i, 0), N - 1);                       // (blocks past the band's end read a valid sample and drop the result)
             return lev == 1 ? x[(size_t)i * L] : band(A.offA[lev - 1], i);
         };
-        for (int o = 0; o < Nc; ++o) {
-            double sa = 0.0, sd = 0.0;
+        for (int o0 = 0; o0 < Nc; o0 += kOB) {
+            double w[2 * kOB + kWF - 2];
 #pragma unroll
-            for (int j = 0; j < kWF; ++j) {
-                const double v = in_at(2 * o + 1 - j);
-                sa += lo[j] * v;
-                sd += hi[j] * v;
+            for (int u = 0; u < 2 * kOB + kWF - 2; ++u) w[u] = in_at(2 * o0 - (kWF - 2) + u);      // w[u] = xe[2 o0 - 10 + u]
+            double sa[kOB], sd[kOB];
+#pragma unroll
+            for (int q = 0; q < kOB; ++q) {
+                double a = 0.0, d = 0.0;
+#pragma unroll
+                for (int j = 0; j < kWF; ++j) {
+                    const double v = w[2 * q + (kWF - 1) - j];                                       // xe[2 (o0 + q) + 1 - j]
+                    a += lo[j] * v;
+                    d += hi[j] * v;
+                }
+                sa[q] = a; sd[q] = d;
             }
-            band(A.offA[lev], o) = sa;
-            band(A.offD[lev], o) = sd;
+#pragma unroll
+            for (int q = 0; q < kOB; ++q)
+                if (o0 + q < Nc) { band(A.offA[lev], o0 + q) = sa[q]; band(A.offD[lev], o0 + q) = sd[q]; }
         }
     }
-    // ---- threshold from the median of |cD4|: the two middle order statistics by a radix select on the bit patterns (monotone for x >= 0)
+    // ---- threshold from the median of |cD4|: the two middle order statistics by a radix select on the bit patterns (monotone for x >= 0), four bits a pass
+    // (sixteen counters in registers: one sweep of the band settles four bits instead of one -- 16 sweeps per statistic instead of 63)
     const int n4 = A.len[kLevels];
     auto kth = [&](int k) -> double {
         unsigned long long prefix = 0;
-        for (int bit = 62; bit >= 0; --bit) {
-            const unsigned long long mask = ~((1ull << bit) - 1);       // bits above and including `bit`
-            int zeros = 0;
-            for (int i = 0; i < n4; ++i) {
-                const unsigned long long u = (unsigned long long)__double_as_longlong(fabs(band(A.offD[kLevels], i)));
-                if ((u & mask) == prefix) ++zeros;                          // matches the prefix with this bit 0
+        for (int shift = 60; shift >= 0; shift -= 4) {
+            const unsigned long long mask = shift == 60 ? 0ull : ~((1ull << (shift + 4)) - 1);       // the bits already settled
+            int cnt[16];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) cnt[d] = 0;
+            for (int i0 = 0; i0 < n4; i0 += kOB) {
+                unsigned long long u8[kOB];
+#pragma unroll
+                for (int q = 0; q < kOB; ++q) u8[q] = (unsigned long long)__double_as_longlong(fabs(band(A.offD[kLevels], min(i0 + q, n4 - 1))));
+#pragma unroll
+                for (int q = 0; q < kOB; ++q) {
+                    const bool in = (i0 + q < n4) && ((u8[q] & mask) == prefix);
+                    const int dig = (int)((u8[q] >> shift) & 15ull);
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) cnt[d] += (in && dig == d) ? 1 : 0;
+                }
             }
-            if (k >= zeros) { k -= zeros; prefix |= 1ull << bit; }
+            int dsel = 15;
+            bool found = false;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                if (!found) {
+                    if (k < cnt[d]) { dsel = d; found = true; }
+                    else k -= cnt[d];
+                }
+            }
+            prefix |= (unsigned long long)dsel << shift;
         }
         return __longlong_as_double((long long)prefix);
     };
     bool any_nan = false;                                    // np.median of a band that holds a NaN is NaN
-    for (int i = 0; i < n4; ++i) any_nan |= isnan(band(A.offD[kLevels], i));
+    for (int i0 = 0; i0 < n4; i0 += kOB) {
+        double v[kOB];
+#pragma unroll
+        for (int q = 0; q < kOB; ++q) v[q] = band(A.offD[kLevels], min(i0 + q, n4 - 1));
+#pragma unroll
+        for (int q = 0; q < kOB; ++q) any_nan |= isnan(v[q]);
+    }
     const double med = any_nan ? __longlong_as_double(0x7ff8000000000000ll) : (n4 & 1) ? kth(n4 / 2) : 0.5 * (kth(n4 / 2 - 1) + kth(n4 / 2));
     const double thr = med == 0.0 ? 0.0 : med / 0.6745;
     for (int lev = 1; lev <= kLevels; ++lev)
-        for (int i = 0; i < A.len[lev]; ++i) {
-            double &c = band(A.offD[lev], i);
-            const double mag = fabs(c);
-            double f = 1.0 - thr / mag;                      // pywt.threshold 'soft': data * clip(1 - value / |data|, 0)
-            f = f < 0.0 ? 0.0 : f;                           // (NaN, from 0 / 0, stays NaN and is zeroed by the test below)
-            const double t = c * f;
-            c = (isfinite(t) && mag > A.epsilon) ? t : 0.0;
+        for (int i0 = 0; i0 < A.len[lev]; i0 += kOB) {
+            double c[kOB];
+#pragma unroll
+            for (int q = 0; q < kOB; ++q) c[q] = band(A.offD[lev], min(i0 + q, A.len[lev] - 1));
+#pragma unroll
+            for (int q = 0; q < kOB; ++q) {
+                const double mag = fabs(c[q]);
+                double f = 1.0 - thr / mag;                  // pywt.threshold 'soft': data * clip(1 - value / |data|, 0)
+                f = f < 0.0 ? 0.0 : f;                       // (NaN, from 0 / 0, stays NaN and is zeroed by the test below)
+                const double t = c[q] * f;
+                c[q] = (isfinite(t) && mag > A.epsilon) ? t : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < kOB; ++q) if (i0 + q < A.len[lev]) band(A.offD[lev], i0 + q) = c[q];
         }
-    // ---- waverec
+    // ---- waverec: x[t] = sum_o cA[o] lo[2 o + 1 - t] + cD[o] hi[2 o + 1 - t], o from t / 2 while 2 o + 1 - t < 12: a block of 2 kOB outputs (t0 even)
+    // reads bands [t0 / 2 .. t0 / 2 + kOB + 4]
     int cur = A.len[kLevels];                                // length of the running approximation band (stored in A_lev)
     for (int lev = kLevels; lev >= 1; --lev) {
         const int Nd = A.len[lev];
         if (cur == Nd + 1) cur = Nd;                         // waverec drops the extra sample
         const int No = 2 * Nd - kWF + 2;
-        for (int t = 0; t < No; ++t) {
-            double sa = 0.0, sd = 0.0;
-            for (int o = t / 2; o < Nd && 2 * o + 1 - t < kWF; ++o) {       // t / 2 = smallest o with 2 o + 1 - t >= 0
-                const int k = 2 * o + 1 - t;
-                sa += band(A.offA[lev], o) * lo[k];
-                sd += band(A.offD[lev], o) * hi[k];
+        for (int t0 = 0; t0 < No; t0 += 2 * kOB) {
+            const int ob = t0 / 2;
+            double ba[kOB + 5], bd[kOB + 5];
+#pragma unroll
+            for (int u = 0; u < kOB + 5; ++u) {
+                const int o = min(ob + u, Nd - 1);
+                ba[u] = band(A.offA[lev], o);
+                bd[u] = band(A.offD[lev], o);
             }
-            const double v = sa + sd;
-            if (lev > 1) band(A.offA[lev - 1], t) = v;
-            else if (t < n) out[(size_t)t * L] = isfinite(v) ? v : 0.0;
+            double res[2 * kOB];
+#pragma unroll
+            for (int q = 0; q < 2 * kOB; ++q) {
+                const int t = t0 + q;
+                double sa = 0.0, sd = 0.0;
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {                // o = t / 2 + u, k = 2 o + 1 - t = 2 u + 1 - (t & 1) < 12
+                    const int o = t / 2 + u, kk = 2 * u + 1 - (q & 1);
+                    if (o < Nd) {
+                        sa += ba[q / 2 + u] * lo[kk];
+                        sd += bd[q / 2 + u] * hi[kk];
+                    }
+                }
+                res[q] = sa + sd;
+            }
+#pragma unroll
+            for (int q = 0; q < 2 * kOB; ++q) {
+                const int t = t0 + q;
+                if (t >= No) continue;
+                if (lev > 1) band(A.offA[lev - 1], t) = res[q];
+                else if (t < n) out[(size_t)t * L] = isfinite(res[q]) ? res[q] : 0.0;
+            }
         }
         cur = No;
     }

@@ -130,6 +130,19 @@ def condition_records(signals, reorder=True, seg_len=1250, orig_fs=500, target_f
         n_out = int(signals.shape[1] * target_fs / orig_fs)
         seg = signals.new_zeros((0, n_out // seg_len, seg_len, signals.shape[2]))
         return (seg, kept) if return_kept else seg
+    # Fast path: the stages run back to back with no host synchronisation; every stage's "all finite" test stays a device scalar and is read ONCE at the end.
+    # A non-finite value anywhere (overflow of a filter: not seen on real records) sends the batch through the literal sequence below, check_nan_inf after
+    # every stage as the reference has it.  The lead permutation commutes with every per-lead stage: it is applied last, to the resampled half-size data.
+    x = signals
+    flags = []
+    x = advanced_ecg_filter(x, fs=orig_fs); flags.append(torch.isfinite(x).all())
+    x = wavelet_denoise(x); flags.append(torch.isfinite(x).all())
+    x = nsample_ecg(x, orig_fs, target_fs); flags.append(torch.isfinite(x).all())
+    if bool(torch.stack(flags).all()):
+        if reorder:
+            x = reorder_indices(x).contiguous()
+        seg, _ = segment_ecg(x, None, seg_len)
+        return (seg, kept) if return_kept else seg
     x = check_nan_inf(signals, "reading")
     if reorder:
         x = check_nan_inf(reorder_indices(x).contiguous(), "reordering")
