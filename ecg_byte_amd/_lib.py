@@ -132,6 +132,7 @@ def lib():
         "ecgb_softmax_bwd": [vp, vp, ci, ci, f32, vp],
         "ecgb_set_gemm_tile": [ci],
         "ecgb_set_gemm_backward_persistent": [ci],
+        "ecgb_set_gemm_group_m": [ci],
         "ecgb_attn_decode": [vp, vp, vp, ll, ll, vp, ll, vp, ci, ci, ci, ci, ci, f32, vp],
         "ecgb_attn_decode_dyn": [vp, vp, vp, ll, ll, vp, ll, vp, ci, vp, ci, ci, ci, f32, vp],
         "ecgb_attn_decode_split": [vp, vp, vp, ll, ll, vp, ll, vp, ci, ci, ci, ci, ci, f32, ci, vp, sz, vp],

@@ -194,6 +194,11 @@ def set_gemm_tile(tile: int):
     _lib.check(_L().ecgb_set_gemm_tile(int(tile)))
 
 
+def set_gemm_group_m(group_m: int = 0):
+    """Tile order of the big GEMM kernels inside an XCD's range: 0 = row by row (default), g = blocks of g tile rows (A/B; measured slower).  Same results."""
+    _lib.check(_L().ecgb_set_gemm_group_m(int(group_m)))
+
+
 def set_gemm_backward_persistent(on: bool):
     """Input-gradient GEMMs with the persistent tile loop (default) or one tile per workgroup: the latter beside a gradient exchange that
     occupies CUs (parallel.GradAllReduce turns it off for world size > 1; ecgb_set_gemm_backward_persistent)."""

@@ -173,6 +173,9 @@ int ecgb_set_gemm_tile(int tile);
  * Persistent workgroups hold a static share of the tiles on every CU; beside a collective that occupies CUs (the gradient exchange of a
  * data-parallel backward) the one-tile kernels degrade gracefully where a static share would not.  parallel.GradAllReduce sets 0 for world > 1. */
 int ecgb_set_gemm_backward_persistent(int on);
+/* Order in which an XCD's workgroups walk its range of output tiles: 0 or 1 = row by row (default); g > 1 = blocks of g tile rows, column by column (the ~32
+ * tiles an XCD runs at a time are then g x 32 / g, both operand panels shared in its L2: measured 1-9 % slower at the C3 shapes, kept for A/B).  Same results. */
+int ecgb_set_gemm_group_m(int group_m);
 /* Same, with two-level batch addressing for attention heads: batch entry z = (zo, zi), zo = z / inner,
  * zi = z % inner; operand X starts at X + zo*outer_x + (zi / div_x)*inner_x  (div_b > 1 shares one KV head
  * among div_b query heads). */

@@ -4,8 +4,9 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
+export ECGB_BENCH_WORKERS=1   # no fork pool under the profiler
 P=${1:-r2}
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${P}_stats -o enc -- python3 bench.py --no-cpu-baseline --no-train --no-c1 > gpurun_out/${P}_bench_encode.txt 2> gpurun_out/${P}_bench_encode.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${P}_stats -o enc -- python3 bench.py --no-cpu-baseline --no-train --no-c1 --no-extras > gpurun_out/${P}_bench_encode.txt 2> gpurun_out/${P}_bench_encode.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${P}_FETCH_SIZE -- python3 scripts/dev_encode_only.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${P}_WRITE_SIZE -- python3 scripts/dev_encode_only.py > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d gpurun_out/${P}_sq1 -- python3 scripts/dev_encode_only.py > /dev/null 2>&1
