@@ -240,6 +240,8 @@ class HipCausalLM(nn.Module):
         self.full_logits = False   # True: run the loss head over every row, as the reference materialises it
         self._saved = None
         self.grad_sync = None      # parallel.GradAllReduce: told as soon as a layer's gradients are final
+        self._opt_ready = {}       # HipAdam(overlap=True): parameter group -> event recorded behind its update on the optimizer's side stream
+        self._opt_done = None      # ... and behind the last one
         self._gflat = None         # flat bf16 buffer holding every trainable gradient (see _grad_layout)
         self._gflat_key = None
         self.fused_attention = cfg.head_dim in ops.FUSED_HEAD_DIMS   # False: materialised scores (batched GEMM + softmax kernels)
@@ -410,6 +412,7 @@ class HipCausalLM(nn.Module):
         yield "lm_head.weight", self.embed.data[: c.vocab_size]
 
     def state_dict(self, *a, **k):
+        self.sync_optimizer()
         """HF parameter names; with LoRA enabled also the adapters under peft's names (`lora_named`)."""
         if self.lora is None:
             return {n: t.clone() for n, t in self._hf_named()}
@@ -424,6 +427,7 @@ class HipCausalLM(nn.Module):
         return sd
 
     def load_state_dict(self, sd, strict=True):
+        self.sync_optimizer()
         """Accepts HF names, and a peft checkpoint's spelling of them (`base_model.model.` prefix, `.base_layer.` infix)."""
         def canon(n):
             if "lora_" in n:
@@ -567,6 +571,30 @@ class HipCausalLM(nn.Module):
         return d_qkv
 
     # ---- gradient storage ---------------------------------------------------------------------
+    # ---- optimizer step overlapped with the next forward (HipAdam(overlap=True)) ---------------------------------------------------
+    def _opt_groups(self):
+        """Trainable parameters in the order the FORWARD pass first reads them: ("embed", ...), (0, layer 0), ..., ("norm", ...)."""
+        if self.lora is not None:
+            return [(i, list(self.lora[i].parameters())) for i in range(self.cfg.num_hidden_layers)]
+        L = self.cfg.num_hidden_layers
+        return ([("embed", [self.embed])] +
+                [(i, [self.ln1[i], self.wqkv[i], self.wo[i], self.ln2[i], self.wgu[i], self.wdown[i]]) for i in range(L)] +
+                [("norm", [self.norm])])
+
+    def _wait_group(self, key):
+        """The current stream waits until the optimizer has updated parameter group `key` (no-op without an overlapped step in flight)."""
+        ev = self._opt_ready.pop(key, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def sync_optimizer(self):
+        """The current stream waits for the whole optimizer step (everything that reads or writes parameters or gradients outside the training
+        forward calls this first)."""
+        if self._opt_done is not None:
+            torch.cuda.current_stream().wait_event(self._opt_done)
+            self._opt_done = None
+            self._opt_ready.clear()
+
     def _grad_layout(self):
         """Every trainable gradient lives in ONE flat bf16 buffer, laid out in the order backward finishes them: layer L-1's
         tensors first, layer 0's last, then the embedding table and the final norm (full fine-tune) -- so "the gradients of
@@ -666,9 +694,11 @@ class HipCausalLM(nn.Module):
         QKV = self.qkv
         scale = 1.0 / math.sqrt(D)
         saved = []
+        self._wait_group("embed")                                    # (an overlapped optimizer step: this group's update has landed)
         x = ops.embed_fwd(input_ids.view(-1), self.embed.data, self.embed_scale)          # [T, H]
         delta = None
         for i in range(c.num_hidden_layers):
+            self._wait_group(i)
             h1, rstd1, x1 = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
             ls = [None] * 4
             qkv, ls[0] = self._proj(i, "qkv", h1, self.wqkv[i].data, self.training)    # [T, QKV]
@@ -683,6 +713,7 @@ class HipCausalLM(nn.Module):
             delta, ls[3] = self._proj(i, "down", hm, self.wdown[i].data, self.training)
             saved.append((x1, rstd1, h1, qkv, P, ao, x2, rstd2, h2, gu, hm, ls))
             x = x2
+        self._wait_group("norm")
         hf, rstdf, xf = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
 
         loss, dhf = self._loss_head(hf, labels, B, S)
@@ -774,6 +805,7 @@ class HipCausalLM(nn.Module):
 
     # ---- inference -----------------------------------------------------------------------------
     def _hidden_states(self, input_ids, attention_mask=None, position_ids=None, kv_out=None):
+        self.sync_optimizer()
         """Final-normed hidden states [B*S, H] of a whole (left-padded) batch, nothing saved for backward.  kv_out: optional
         list of per-layer caches [B, cap, 2*Hkv*D]; rows [:S] receive the roped keys and the values (DynamicCache.update,
         cache_utils.py:408-470)."""
@@ -1027,6 +1059,7 @@ class HipCausalLM(nn.Module):
         return self._backward_impl(grad_out)
 
     def _backward_impl(self, grad_out):
+        self.sync_optimizer()                                        # gradients are about to be overwritten; the adapters' shadows are rebuilt from the updated weights
         c = self.cfg
         H, I, D, Hq, Hkv = c.hidden_size, c.intermediate_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
         G = Hq // Hkv
@@ -1132,8 +1165,8 @@ class HipCausalLM(nn.Module):
             self.grad_sync.finish()
 
     # ---- fused optimizer (clip_grad_norm_(1.0) + Adam with L2, Noam schedule) -------------------------
-    def make_optimizer(self, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2, warmup=500, max_norm=1.0):
-        return HipAdam(self, lr, betas, eps, weight_decay, warmup, max_norm)
+    def make_optimizer(self, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2, warmup=500, max_norm=1.0, overlap=False):
+        return HipAdam(self, lr, betas, eps, weight_decay, warmup, max_norm, overlap=overlap)
 
 
 class HipAdam:
@@ -1141,8 +1174,16 @@ class HipAdam:
     global-norm clip to 1.0, Adam (weight decay as L2), lr = d_model^-0.5 * min(t^-0.5, t * warmup^-1.5).
     Moments are fp32 (the reference's follow the bf16 parameter dtype)."""
 
-    def __init__(self, model: HipCausalLM, lr, betas, eps, weight_decay, warmup, max_norm):
+    def __init__(self, model: HipCausalLM, lr, betas, eps, weight_decay, warmup, max_norm, overlap=False):
         self.model, self.betas, self.eps, self.wd, self.warmup, self.max_norm = model, betas, eps, weight_decay, warmup, max_norm
+        # overlap=True: the parameter updates run on a side HIP stream, group by group in the order the forward pass reads them, and the NEXT forward
+        # waits per group (an event each): the step's 27 GB of moment / weight traffic (5.7 ms at the HBM rate) hides under the next forward's GEMMs,
+        # which leave the memory system idle.  The gradient norm (needs every gradient) stays in front.  Same arithmetic, same bits.  Anything that
+        # touches parameters through the model (backward, inference, state_dict, generate) waits for the whole step first (`sync_optimizer`); code
+        # that reads `p.data` directly right after `step()` must call `model.sync_optimizer()` itself -- hence opt-in (bench.py, main.py).
+        self.overlap = bool(overlap) and hasattr(model, "_opt_groups") and torch.cuda.is_available()
+        self._side = None
+        self._acc = None
         self.init_lr = model.cfg.hidden_size ** -0.5
         self.fixed_lr = None if warmup else lr
         self.t = 0
@@ -1172,12 +1213,47 @@ class HipAdam:
             for g in grads:
                 ops.sumsq(g, acc)
         lr = self.lr(self.t)
-        for p in params:
+
+        def update(p):
             st = self.state.get(id(p))
             if st is None or st[0].shape != p.shape:
                 st = (torch.zeros(p.shape, dtype=torch.float32, device=p.device), torch.zeros(p.shape, dtype=torch.float32, device=p.device))
                 self.state[id(p)] = st
             ops.adam_step_(p.data, p.grad, st[0], st[1], acc, self.max_norm, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t)
+
+        if not self.overlap:
+            for p in params:
+                update(p)
+        else:
+            model = self.model
+            model.sync_optimizer()                                   # (a previous overlapped step nobody waited for)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=model.device)
+            main = torch.cuda.current_stream()
+            for p in params:                                         # moments are created on the main stream, before the fork
+                if id(p) not in self.state or self.state[id(p)][0].shape != p.shape:
+                    self.state[id(p)] = (torch.zeros(p.shape, dtype=torch.float32, device=p.device), torch.zeros(p.shape, dtype=torch.float32, device=p.device))
+            acc.record_stream(self._side)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            self._side.wait_event(fork)
+            have = {id(p) for p in params}
+            with torch.cuda.stream(self._side):
+                seen = set()
+                for key, group in model._opt_groups():
+                    for p in group:
+                        if id(p) in have:
+                            update(p)
+                            seen.add(id(p))
+                    ev = torch.cuda.Event()
+                    ev.record(self._side)
+                    model._opt_ready[key] = ev
+                for p in params:                                     # anything the groups do not name
+                    if id(p) not in seen:
+                        update(p)
+                done = torch.cuda.Event()
+                done.record(self._side)
+                model._opt_done = done
         self.model._drop_shadows({id(p) for p in params})   # updated weights: their transposed shadows are stale
 
     step = step_and_update_lr

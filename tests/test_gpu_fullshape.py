@@ -370,3 +370,35 @@ def test_full_finetune_step_is_the_same_bits_twice():
         assert torch.equal(g1[k], g2[k]), k
     for k in p1:
         assert torch.equal(p1[k], p2[k]), k
+
+
+def _three_steps(lora, overlap, seed=13):
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    cfg = DecoderConfig(**{**LLAMA_1B, "vocab_size": 4099}, rope_theta=500000.0, rope_scaling=dict(LLAMA3_SCALING), pad_token_id=4098)
+    m = HipCausalLM(cfg, seed=seed)
+    if lora:
+        m.enable_lora(r=16, alpha=32, dropout=0.05)
+    opt = m.make_optimizer(warmup=2, overlap=overlap)
+    losses = []
+    for step in range(3):
+        ids, mask, labels, pos = _batch(4, 1024, cfg.vocab_size, cfg.vocab_size - 1, seed=31 + step, pads=[0, 5, 300, 64], n_labels=60)
+        opt.zero_grad()
+        out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
+        out.loss.backward()
+        opt.step_and_update_lr()                      # overlap: returns with the updates still running on the side stream
+        losses.append(out.loss.detach().clone())
+    m.sync_optimizer()
+    torch.cuda.synchronize()
+    return torch.stack(losses), {n: p.data.clone() for n, p in m.named_parameters() if p.requires_grad}
+
+
+@pytest.mark.parametrize("lora", [False, True], ids=["full", "lora"])
+def test_overlapped_optimizer_step_is_the_plain_step_bit_for_bit(lora):
+    """HipAdam(overlap=True) runs the parameter updates on a side stream under the next forward (one event per layer group): three steps must
+    leave the losses and every trained tensor with the bits of three plain steps -- a forward that read a weight before its update landed, or
+    a backward that overwrote a gradient the optimizer was still reading, shows here."""
+    l0, p0 = _three_steps(lora, False)
+    l1, p1 = _three_steps(lora, True)
+    assert torch.equal(l0, l1), (l0, l1)
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
