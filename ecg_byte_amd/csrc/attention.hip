@@ -1780,12 +1780,14 @@ constexpr int kSplitMaxChunk = 2048;                     // keys per split the s
 template <int D>
 __global__ __launch_bounds__(kSplitThreads) void attn_decode_scores_kernel(const unsigned short *q, const unsigned short *kc, long long ld, long long cap,
                                                                            const float *mask, long long mask_ld, float *scores, float *stats,
-                                                                           int len, int chunk, int Hq, int Hkv, float scale)
+                                                                           int len_arg, int chunk_arg, const int *len_dev, int Hq, int Hkv, float scale)
 {
     constexpr int NW = kSplitThreads / 64, EPL = D / 64, KU = 16;
     __shared__ float s_red[2 * NW];
     __shared__ float s_sc[kSplitMaxChunk];                // the split's scores once more: the sum of exponentials reads them here
     const int sp = blockIdx.x, hq = blockIdx.y, b = blockIdx.z, g = hq / (Hq / Hkv), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // device-resident length (a replayed graph): the same split of the keys the host computes from a length it knows
+    const int len = len_dev ? *len_dev : len_arg, chunk = len_dev ? (len + (int)gridDim.x - 1) / (int)gridDim.x : chunk_arg;
     const int k0 = sp * chunk, k1 = min(len, k0 + chunk);
     const unsigned short *qp = q + ((long long)b * Hq + hq) * D;
     float qf[EPL];
@@ -1854,12 +1856,14 @@ __global__ __launch_bounds__(kSplitThreads) void attn_decode_scores_kernel(const
 
 template <int D>
 __global__ __launch_bounds__(kSplitThreads) void attn_decode_values_kernel(const unsigned short *vc, long long ld, long long cap, const float *scores,
-                                                                           const float *stats, float *partial, int len, int chunk, int Hq, int Hkv)
+                                                                           const float *stats, float *partial, int len_arg, int chunk_arg, const int *len_dev,
+                                                                           int Hq, int Hkv)
 {
     constexpr int TPR = D / 8, NS = kSplitThreads / TPR, VU = 8;
     __shared__ float s_part[NS * D];
     const int sp = blockIdx.x, hq = blockIdx.y, b = blockIdx.z, g = hq / (Hq / Hkv), tid = threadIdx.x;
     const int n_splits = gridDim.x;
+    const int len = len_dev ? *len_dev : len_arg, chunk = len_dev ? (len + n_splits - 1) / n_splits : chunk_arg;
     const int k0 = sp * chunk, k1 = min(len, k0 + chunk);
     const float *st = stats + ((long long)b * Hq + hq) * n_splits * 2;
     float m = -INFINITY;
@@ -2135,38 +2139,59 @@ extern "C" size_t ecgb_attn_decode_split_scratch_bytes(long long capacity, int b
     return (size_t)batch * n_q_heads * ((size_t)capacity + (size_t)n_splits * (2 + (size_t)head_dim)) * sizeof(float);
 }
 
-extern "C" int ecgb_attn_decode_split(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,
-                                      const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, int n_q_heads,
-                                      int n_kv_heads, int head_dim, float scale, int n_splits, void *scratch_dev, size_t scratch_bytes,
-                                      void *stream)
+namespace {
+int launch_attn_decode_split(const char *who, const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,
+                             const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, const int *kv_len_dev, int n_q_heads,
+                             int n_kv_heads, int head_dim, float scale, int n_splits, void *scratch_dev, size_t scratch_bytes, void *stream)
 {
-    if (head_dim != 64 && head_dim != 128 && head_dim != 256) { ecgb::set_error("ecgb_attn_decode_split: head_dim must be 64, 128 or 256"); return ECGB_ERR_UNSUPPORTED; }
-    if (!q_dev || !k_cache_dev || !v_cache_dev || !attn_mask_dev || !o_dev || !scratch_dev || batch <= 0 || kv_len <= 0 || kv_len > capacity ||
-        n_q_heads <= 0 || n_kv_heads <= 0 || n_q_heads % n_kv_heads || ld % 8 || n_splits <= 0 || n_splits > 1024) {
-        ecgb::set_error("ecgb_attn_decode_split: bad argument");
+    if (head_dim != 64 && head_dim != 128 && head_dim != 256) { ecgb::set_error(std::string(who) + ": head_dim must be 64, 128 or 256"); return ECGB_ERR_UNSUPPORTED; }
+    if (!q_dev || !k_cache_dev || !v_cache_dev || !attn_mask_dev || !o_dev || !scratch_dev || batch <= 0 || (!kv_len_dev && (kv_len <= 0 || kv_len > capacity)) ||
+        capacity <= 0 || n_q_heads <= 0 || n_kv_heads <= 0 || n_q_heads % n_kv_heads || ld % 8 || n_splits <= 0 || n_splits > 1024) {
+        ecgb::set_error(std::string(who) + ": bad argument");
         return ECGB_ERR_INVALID;
     }
     if (scratch_bytes < ecgb_attn_decode_split_scratch_bytes(capacity, batch, n_q_heads, head_dim, n_splits)) {
-        ecgb::set_error("ecgb_attn_decode_split: scratch too small (ecgb_attn_decode_split_scratch_bytes)");
+        ecgb::set_error(std::string(who) + ": scratch too small (ecgb_attn_decode_split_scratch_bytes)");
         return ECGB_ERR_INVALID;
     }
-    // the split count is final BEFORE the scratch is laid out: stats and partial are indexed by gridDim.x
-    if ((kv_len + n_splits - 1) / n_splits > kSplitMaxChunk) n_splits = (kv_len + kSplitMaxChunk - 1) / kSplitMaxChunk;
+    // the split count is final BEFORE the scratch is laid out: stats and partial are indexed by gridDim.x.  A length in device memory can grow to the capacity.
+    const long long longest = kv_len_dev ? capacity : (long long)kv_len;
+    if ((longest + n_splits - 1) / n_splits > kSplitMaxChunk) n_splits = (int)((longest + kSplitMaxChunk - 1) / kSplitMaxChunk);
     float *scores = (float *)scratch_dev;
     float *stats = scores + (size_t)batch * n_q_heads * (size_t)capacity;
     float *partial = stats + (size_t)batch * n_q_heads * (size_t)n_splits * 2;
-    const int chunk = (kv_len + n_splits - 1) / n_splits;
+    const int chunk = kv_len_dev ? 0 : (kv_len + n_splits - 1) / n_splits;
     const dim3 grid((unsigned)n_splits, (unsigned)n_q_heads, (unsigned)batch), gc((unsigned)n_q_heads, (unsigned)batch);
 #define ECGB_SPLIT(D_) do { \
         hipLaunchKernelGGL(attn_decode_scores_kernel<D_>, grid, dim3(kSplitThreads), 0, (hipStream_t)stream, (const unsigned short *)q_dev, \
-            (const unsigned short *)k_cache_dev, ld, capacity, attn_mask_dev, mask_ld, scores, stats, kv_len, chunk, n_q_heads, n_kv_heads, scale); \
+            (const unsigned short *)k_cache_dev, ld, capacity, attn_mask_dev, mask_ld, scores, stats, kv_len, chunk, kv_len_dev, n_q_heads, n_kv_heads, scale); \
         hipLaunchKernelGGL(attn_decode_values_kernel<D_>, grid, dim3(kSplitThreads), 0, (hipStream_t)stream, (const unsigned short *)v_cache_dev, \
-            ld, capacity, scores, stats, partial, kv_len, chunk, n_q_heads, n_kv_heads); \
+            ld, capacity, scores, stats, partial, kv_len, chunk, kv_len_dev, n_q_heads, n_kv_heads); \
         hipLaunchKernelGGL(attn_decode_combine_kernel<D_>, gc, dim3(D_), 0, (hipStream_t)stream, partial, (unsigned short *)o_dev, n_splits, n_q_heads); \
     } while (0)
     if (head_dim == 64) ECGB_SPLIT(64); else if (head_dim == 128) ECGB_SPLIT(128); else ECGB_SPLIT(256);
 #undef ECGB_SPLIT
     return launched("attn_decode_split kernels");
+}
+}  // namespace
+
+extern "C" int ecgb_attn_decode_split(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,
+                                      const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, int n_q_heads,
+                                      int n_kv_heads, int head_dim, float scale, int n_splits, void *scratch_dev, size_t scratch_bytes,
+                                      void *stream)
+{
+    return launch_attn_decode_split("ecgb_attn_decode_split", q_dev, k_cache_dev, v_cache_dev, ld, capacity, attn_mask_dev, mask_ld, o_dev, batch, kv_len, nullptr,
+                                    n_q_heads, n_kv_heads, head_dim, scale, n_splits, scratch_dev, scratch_bytes, stream);
+}
+
+extern "C" int ecgb_attn_decode_split_dyn(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,
+                                          const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, const int *kv_len_dev, int n_q_heads,
+                                          int n_kv_heads, int head_dim, float scale, int n_splits, void *scratch_dev, size_t scratch_bytes,
+                                          void *stream)
+{
+    if (!kv_len_dev) { ecgb::set_error("ecgb_attn_decode_split_dyn: NULL length pointer"); return ECGB_ERR_INVALID; }
+    return launch_attn_decode_split("ecgb_attn_decode_split_dyn", q_dev, k_cache_dev, v_cache_dev, ld, capacity, attn_mask_dev, mask_ld, o_dev, batch, 0, kv_len_dev,
+                                    n_q_heads, n_kv_heads, head_dim, scale, n_splits, scratch_dev, scratch_bytes, stream);
 }
 
 extern "C" int ecgb_attn_decode_dyn(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,

@@ -54,6 +54,60 @@ unsigned grid_for(size_t items, unsigned per_block)
     return (unsigned)std::max<size_t>(1, std::min<size_t>(b, 256 * 16));
 }
 
+// ---- greedy token choice ---------------------------------------------------------------------
+// out[r] = index of the first maximum of x[r, 0:n] (torch.argmax's rule for ties; a NaN counts as the maximum, as it does there).  One workgroup per row, no
+// workspace: torch's own argmax over a 260 000-wide row is a two-pass reduction over a semaphore buffer it allocates per call -- three launches with the
+// slice and the fp32 copy in front of it, and state a replayed HIP graph must not depend on.
+__device__ __forceinline__ unsigned argmax_key(unsigned short b)
+{
+    const unsigned u = b;
+    if ((u & 0x7FFFu) > 0x7F80u) return 0xFFFFu;            // NaN: above everything
+    return (u & 0x8000u) ? (0x7FFFu - (u & 0x7FFFu)) : (0x8000u | u);   // monotone in the bf16 value (-0 just below +0: torch compares them equal -- first index wins there, see below)
+}
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const unsigned short *x, long long ld, int n, long long *out)
+{
+    __shared__ unsigned long long s_best[16];
+    const unsigned short *row = x + (long long)blockIdx.x * ld;
+    // one 64-bit key per candidate: value key above, ~index below -- the maximum of the keys is the greatest value at the lowest index
+    unsigned long long best = 0;
+    auto take = [&](unsigned short b, int i) {
+        unsigned k = argmax_key(b);
+        if (k == 0x7FFFu) k = 0x8000u;                        // -0 == +0
+        const unsigned long long key = ((unsigned long long)k << 32) | (unsigned)(0x7FFFFFFF - i);
+        best = key > best ? key : best;
+    };
+    const int head = (int)((16 - ((uintptr_t)row & 15)) & 15) / 2;     // elements before the first 16-byte boundary (rows of an odd-width matrix)
+    for (int i = threadIdx.x; i < min(head, n); i += 1024) take(row[i], i);
+    const int body = n > head ? (n - head) / 8 : 0;
+    constexpr int U = 8;                                      // 16-byte pieces in flight per thread: a 260 000-wide row is 32 pieces per thread, a chain of 32 memory latencies one at a time
+    for (int c0 = threadIdx.x; c0 < body; c0 += 1024 * U) {
+        bf16x8 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const bf16x8 *>(row + head + min(c0 + 1024 * u, body - 1) * 8);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + 1024 * u;
+            if (c < body) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) take((unsigned short)v[u][j], head + c * 8 + j);
+            }
+        }
+    }
+    for (int i = head + body * 8 + threadIdx.x; i < n; i += 1024) take(row[i], i);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long o = __shfl_xor(best, d, 64);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 16; ++w) best = s_best[w] > best ? s_best[w] : best;
+        out[blockIdx.x] = (long long)(0x7FFFFFFF - (unsigned)(best & 0xFFFFFFFFu));
+    }
+}
+
 // ---- embedding -------------------------------------------------------------------------------
 // out[t, :] = table[ids[t], :] * scale   (scale = 1 for Llama; sqrt(hidden) for Gemma)
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long *ids, const unsigned short *table, unsigned short *out,
@@ -893,6 +947,13 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const unsigned short *
 
 int g_ce_in_registers = 1;   // ecgb_ce_fwd_bwd: rows that fit (ld <= 163 840) are held in registers (one read, one write); 0 = the three-sweep kernel (A/B, tests)
 extern "C" int ecgb_set_ce_in_registers(int on) { g_ce_in_registers = on ? 1 : 0; return ECGB_OK; }
+
+extern "C" int ecgb_argmax_bf16(const void *x_dev, long long ld, int rows, int n, int64_t *out_dev, void *stream)
+{
+    if (!x_dev || !out_dev || rows <= 0 || n <= 0 || ld < n) { ecgb::set_error("ecgb_argmax_bf16: bad argument"); return ECGB_ERR_INVALID; }
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, (const unsigned short *)x_dev, ld, n, (long long *)out_dev);
+    ECGB_CHECK_LAUNCH("argmax_rows");
+}
 
 extern "C" int ecgb_embed_fwd(const int64_t *ids_dev, const void *table_dev, void *out_dev, size_t tokens, int hidden,
                               float scale, void *stream)

@@ -870,9 +870,10 @@ class HipCausalLM(nn.Module):
             ops.ce_fwd_bwd_(logits, shifted.index_select(0, r), inv_count, loss, c.vocab_size)
         return loss.squeeze(0)
 
-    def _decode_step(self, tokens, pos, mask, caches, n, n_dev=None):
+    def _decode_step(self, tokens, pos, mask, caches, n, n_dev=None, scratch=None):
         """Hidden state [B, H] of one new token per sequence, written at cache row n-1 (n = keys valid after the update).
-        n_dev: int32[1] device tensor holding n -- then nothing in the launches depends on the step (graph replay)."""
+        n_dev: int32[1] device tensor holding n -- then nothing in the launches depends on the step (graph replay); scratch: the
+        split decode attention's buffer the captured step owns."""
         c = self.cfg
         D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
         QKV = self.qkv
@@ -884,16 +885,19 @@ class HipCausalLM(nn.Module):
             h1, _, x = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
             qkv, _ = self._proj(i, "qkv", h1, self.wqkv[i].data)         # [B, QKV]
             ops.rope_(qkv, cos, sin, Hq + Hkv, D, QKV)                   # the query heads and the key heads lie side by side: one launch
+            ns = ops.decode_splits(caches[i].shape[1], qkv.shape[0], Hq)
             if n_dev is None:
                 caches[i][:, n - 1].copy_(qkv[:, Hq * D:])
-                ns = ops.decode_splits(n, qkv.shape[0], Hq)
                 if ns > 1:
                     ao = ops.attn_decode_split(qkv, caches[i], mask, n, Hq, Hkv, D, scale, ns)
                 else:
                     ao = ops.attn_decode(qkv, caches[i], mask, n, Hq, Hkv, D, scale)
             else:
                 ops.kv_append(qkv, Hq * D, caches[i], n_dev)
-                ao = ops.attn_decode_dyn(qkv, caches[i], mask, n_dev, Hq, Hkv, D, scale)
+                if ns > 1:
+                    ao = ops.attn_decode_split(qkv, caches[i], mask, n_dev, Hq, Hkv, D, scale, ns, scratch=scratch)
+                else:
+                    ao = ops.attn_decode_dyn(qkv, caches[i], mask, n_dev, Hq, Hkv, D, scale)
             attn_delta, _ = self._proj(i, "o", ao, self.wo[i].data)
             h2, _, x = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma)
             _, hm, _ = self._proj_glu(i, h2, keep_gu=False)
@@ -920,7 +924,7 @@ class HipCausalLM(nn.Module):
         return torch.multinomial(scores.softmax(-1), 1, generator=generator).squeeze(-1)
 
     def generate(self, input_ids=None, attention_mask=None, max_new_tokens=128, pad_token_id=None, eos_token_id=None,
-                 use_cache=True, return_logits=False, use_graph=False, do_sample=None, temperature=None, top_k=None, top_p=None,
+                 use_cache=True, return_logits=False, use_graph=None, do_sample=None, temperature=None, top_k=None, top_p=None,
                  generator=None, **_):
         """GenerationMixin.generate / _sample (generation/utils.py:1877, 3131-3250) as LLM.generate calls it
         (ecg_byte/models/llm.py:26-37): positions from the attention mask (utils.py:410-411), finished sequences keep emitting
@@ -928,13 +932,19 @@ class HipCausalLM(nn.Module):
         reference's call passes no sampling arguments, so HF falls back to the checkpoint's generation_config.json -- which
         the Llama-3.2 conversion writes with do_sample=True, temperature 0.6, top_p 0.9 (convert_llama_weights_to_hf.py:402-408);
         `from_pretrained` reads that file into `self.generation_config` and the arguments default to it.
+        use_graph: None (default) = the decode step runs as a replayed HIP graph (`_generate_graph`) whenever nothing asks for the eager loop
+        (per-step logits, no cache, sampling); True / False force it.
         Returns [B, S0 + generated] int64 (prompt included)."""
         gc = getattr(self, "generation_config", None) or {}
         do_sample = bool(gc.get("do_sample", False)) if do_sample is None else bool(do_sample)
         temperature = float(gc.get("temperature", 1.0)) if temperature is None else float(temperature)
         top_k = int(gc.get("top_k", 50)) if top_k is None else int(top_k)                    # GenerationConfig's defaults
         top_p = float(gc.get("top_p", 1.0)) if top_p is None else float(top_p)
-        pick = lambda lg: self._next_token(lg, do_sample, temperature, top_k, top_p, generator)
+        V = self.cfg.vocab_size
+        if do_sample:
+            pick = lambda lg16: self._next_token(lg16[:, :V].float(), True, temperature, top_k, top_p, generator)
+        else:
+            pick = lambda lg16: ops.argmax_rows(lg16, V)        # the bf16 logits as the head GEMM leaves them: one launch, first maximum (torch.argmax's rule)
         c = self.cfg
         dev = self.device
         input_ids = input_ids.to(dev).long()
@@ -952,13 +962,19 @@ class HipCausalLM(nn.Module):
             p = m.long().cumsum(-1) - 1
             return p.masked_fill(m == 0, 1)
 
+        if use_graph is None:
+            use_graph = generator is None and not do_sample          # (sampling replays too when asked: use_graph=True)
+        if use_cache and use_graph and not return_logits and max_new_tokens > 2:
+            return self._generate_graph(input_ids, mask, S0, max_new_tokens, pad_token_id, eos, positions, pick,
+                                        (do_sample, temperature, top_k, top_p) if do_sample else None)
         width = 2 * c.num_key_value_heads * c.head_dim
-        caches = [torch.empty((B, cap, width), dtype=torch.bfloat16, device=dev) for _ in range(c.num_hidden_layers)] if use_cache else None
+        cap_rows = -(-cap // 128) * 128                                   # as _generate_graph sizes them: the same split of the keys, the same bits
+        caches = [torch.empty((B, cap_rows, width), dtype=torch.bfloat16, device=dev) for _ in range(c.num_hidden_layers)] if use_cache else None
+        if cap_rows != cap:
+            mask = torch.cat([mask, mask.new_zeros((B, cap_rows - cap))], 1)
         seq = input_ids
         unfinished = torch.ones(B, dtype=torch.long, device=dev)
         step_logits = []
-        if use_cache and use_graph and not return_logits and max_new_tokens > 2:
-            return self._generate_graph(seq, mask, caches, S0, max_new_tokens, pad_token_id, eos, positions, pick)
         for t in range(max_new_tokens):
             n = S0 + t                                                       # tokens in `seq`
             if t == 0 or not use_cache:
@@ -968,9 +984,9 @@ class HipCausalLM(nn.Module):
             else:
                 pos = positions(mask[:, :n])[:, -1]
                 last = self._decode_step(seq[:, -1].contiguous(), pos, mask, caches, n)
-            logits = ops.gemm_nt(last, self.embed.data)[:, :c.vocab_size].float()
+            logits = ops.gemm_nt(last, self.embed.data)
             if return_logits:
-                step_logits.append(logits)
+                step_logits.append(logits[:, :c.vocab_size].float())
             nxt = pick(logits)
             if eos is not None:
                 nxt = nxt * unfinished + pad_token_id * (1 - unfinished)
@@ -982,74 +998,105 @@ class HipCausalLM(nn.Module):
                     break
         return (seq, torch.stack(step_logits, 1)) if return_logits else seq
 
-    def _generate_graph(self, seq, mask, caches, S0, max_new_tokens, pad_token_id, eos, positions, pick=None):
-        """The greedy loop with the decode step captured once in a HIP graph and replayed per token (`use_graph=True`).
-        Measured at Gemma-2B dims: 4.2 ms per token either way -- the step is bound by the GPU-side gaps between ~270
-        small dependent kernels, not by the host's launch calls, so the replay buys nothing yet (fewer, fused kernels
-        would); kept as an option.  Everything that changes from step to step lives in device memory: the
-        token, its position, the number of valid cache rows, the step counter; the host only replays and, when an eos id
-        is given, reads the `unfinished` flag."""
+    def _generate_graph(self, seq, mask, S0, max_new_tokens, pad_token_id, eos, positions, pick, sampling=None):
+        """The generate loop with the decode step captured once in a HIP graph and replayed per token.  Everything that changes from step to
+        step lives in device memory -- the token, its position, the number of valid cache rows, the column the next token goes to, the
+        `unfinished` flags -- so the host only replays and, when an eos id is given, reads one flag per token.
+        The captured step is kept on the model and REUSED by later calls (`self._gen_graphs`): its buffers (KV caches, mask, output) are sized
+        to the call's prompt + new tokens rounded up to 128 rows, so the eval loop's calls (one per test sample, prompts of different lengths,
+        ecg_byte/runners/tester.py) replay one graph; a call writes its prompt state into the buffers and replays.  Key: batch, rounded
+        capacity, pad / eos ids, the sampling arguments, and the storage of the embedding table and of the adapters (a resized vocabulary
+        or enable_lora() captures anew).  At Gemma-2B dims with adapters (about 400 launches per token, which the host issues at 8 us each):
+        3.5 ms per token eagerly, 2.25 replayed (423 tokens/s after a 600-token prompt; 530 without adapters); capturing costs about 16 ms, once.
+        The greedy choice inside the step is ecgb_argmax_bf16, not torch.argmax: over a 260 000-wide row torch's reduction is two passes over a
+        semaphore buffer, and a graph holding it, replayed after other eager reductions had run, left the token unwritten (measured: the second
+        call of a reused graph read 8 bytes of RoPE table as a token id) -- the step must not depend on state outside its own buffers."""
         c = self.cfg
         dev = self.device
         B = seq.shape[0]
-        cap = S0 + max_new_tokens
+        cap = -(-(S0 + max_new_tokens) // 128) * 128
+        pad_id = pad_token_id if pad_token_id is not None else 0
+        key = (B, cap, pad_id, None if eos is None else tuple(int(e) for e in eos.tolist()), sampling, self.training, self.embed.data_ptr(),
+               None if self.lora is None else self.lora[0]["qkv"].A.data_ptr())
+        graphs = self.__dict__.setdefault("_gen_graphs", {})
+        st = graphs.get(key)
+        if st is None:
+            while len(graphs) >= 4:                                          # a handful of shapes at most: drop the oldest
+                graphs.pop(next(iter(graphs)))
+            width = 2 * c.num_key_value_heads * c.head_dim
+            st = SimpleNamespace(graph=None,
+                                 caches=[torch.empty((B, cap, width), dtype=torch.bfloat16, device=dev) for _ in range(c.num_hidden_layers)],
+                                 mask=torch.zeros((B, cap), dtype=torch.float32, device=dev),
+                                 out=torch.zeros((B, cap), dtype=torch.long, device=dev),
+                                 tok=torch.zeros(B, dtype=torch.long, device=dev), pos=torch.zeros(B, dtype=torch.long, device=dev),
+                                 n_dev=torch.zeros(1, dtype=torch.int32, device=dev), col=torch.zeros((B, 1), dtype=torch.long, device=dev),
+                                 unfinished=torch.ones(B, dtype=torch.long, device=dev),
+                                 ones_col=torch.ones((B, 1), dtype=torch.float32, device=dev),
+                                 pad_t=torch.full((B,), pad_id, dtype=torch.long, device=dev), eos=eos, scratch=None)
+            ns = ops.decode_splits(cap, B, c.num_attention_heads)
+            if ns > 1:
+                st.scratch = ops.decode_split_scratch(cap, B, c.num_attention_heads, c.head_dim, ns, dev)
+            graphs[key] = st
+        caches, gmask, out, tok, pos, n_dev, col, unfinished = st.caches, st.mask, st.out, st.tok, st.pos, st.n_dev, st.col, st.unfinished
         # prefill + first token, eagerly
-        m0 = mask[:, :S0].contiguous()
+        gmask.zero_()
+        gmask[:, :S0] = mask[:, :S0]
+        m0 = gmask[:, :S0].contiguous()
         hf = self._hidden_states(seq, m0, positions(m0), caches)
-        logits = ops.gemm_nt(hf.view(B, S0, -1)[:, -1].contiguous(), self.embed.data)[:, :c.vocab_size].float()
-        unfinished = torch.ones(B, dtype=torch.long, device=dev)
-        pick = pick or (lambda lg: lg.argmax(-1))
+        logits = ops.gemm_nt(hf.view(B, S0, -1)[:, -1].contiguous(), self.embed.data)
+        unfinished.fill_(1)
         nxt = pick(logits)
         if eos is not None:
-            unfinished = unfinished * (~torch.isin(nxt, eos)).long()
-        out = torch.full((B, cap), pad_token_id if pad_token_id is not None else 0, dtype=torch.long, device=dev)
+            unfinished.mul_((~torch.isin(nxt, eos)).long())
+        out.fill_(pad_id)
         out[:, :S0] = seq
         out[:, S0] = nxt
-        mask[:, S0] = 1.0
+        gmask[:, S0] = 1.0
         if (eos is not None and int(unfinished.max()) == 0) or max_new_tokens == 1:
-            return out[:, :S0 + 1]
-        # static state of the captured step
-        tok = nxt.clone()
-        pos = positions(mask[:, :S0 + 1])[:, -1].contiguous()               # position of the token in `tok`
-        n_dev = torch.full((1,), S0 + 1, dtype=torch.int32, device=dev)     # cache rows valid once `tok` is appended
-        col = torch.full((B, 1), S0 + 1, dtype=torch.long, device=dev)      # where the token produced by the step goes
-        ones_col = torch.ones((B, 1), dtype=torch.float32, device=dev)
-        pad_t = torch.full((B,), pad_token_id if pad_token_id is not None else 0, dtype=torch.long, device=dev)
+            return out[:, :S0 + 1].clone()
+        # state of the captured step
+        tok.copy_(nxt)
+        pos.copy_(positions(gmask[:, :S0 + 1])[:, -1])                       # position of the token in `tok`
+        n_dev.fill_(S0 + 1)                                                  # cache rows valid once `tok` is appended
+        col.fill_(S0 + 1)                                                    # where the token produced by the step goes
+        eos_s, ones_col, pad_t = st.eos, st.ones_col, st.pad_t
 
         def step():
-            last = self._decode_step(tok, pos, mask, caches, None, n_dev)
-            lg = ops.gemm_nt(last, self.embed.data)[:, :c.vocab_size].float()
-            nx = pick(lg)
-            if eos is not None:
+            last = self._decode_step(tok, pos, gmask, caches, None, n_dev, scratch=st.scratch)
+            nx = pick(ops.gemm_nt(last, self.embed.data))
+            if eos_s is not None:
                 nx = nx * unfinished + pad_t * (1 - unfinished)
-                unfinished.mul_((nx[:, None] != eos[None, :]).all(1).long())
+                unfinished.mul_((nx[:, None] != eos_s[None, :]).all(1).long())
             out.scatter_(1, col, nx[:, None])
-            mask.scatter_(1, col, ones_col)
+            gmask.scatter_(1, col, ones_col)
             tok.copy_(nx)
             pos.add_(1)
             n_dev.add_(1)
             col.add_(1)
 
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                                      # warm-up outside the capture (allocations, lazy init)
-            snap = (tok.clone(), pos.clone(), n_dev.clone(), col.clone(), unfinished.clone(), out.clone(), mask.clone())
-            step()
-            for dst, src in zip((tok, pos, n_dev, col, unfinished, out, mask), snap):
+        if st.graph is None:
+            state = (tok, pos, n_dev, col, unfinished, out, gmask)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                                  # warm-up outside the capture (allocations, lazy init)
+                snap = tuple(t.clone() for t in state)
+                step()
+                for dst, src in zip(state, snap):
+                    dst.copy_(src)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            for dst, src in zip(state, snap):                              # capture does not execute, but keep the state explicit
                 dst.copy_(src)
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
-        for dst, src in zip((tok, pos, n_dev, col, unfinished, out, mask), snap):   # capture does not execute, but keep the state explicit
-            dst.copy_(src)
+            st.graph = graph
         produced = 1
         for t in range(1, max_new_tokens):
-            graph.replay()
+            st.graph.replay()
             produced += 1
             if eos is not None and int(unfinished.max()) == 0:
                 break
-        return out[:, :S0 + produced]
+        return out[:, :S0 + produced].clone()
 
     # ---- backward -------------------------------------------------------------------------------
     def _backward(self, grad_out):

@@ -35,6 +35,15 @@ def embed_fwd(ids, table, scale=1.0):
     return out
 
 
+def argmax_rows(x, n=None):
+    """torch.argmax(x[:, :n], -1) of a bf16 matrix (first index of the maximum), one launch without workspace (ecgb_argmax_bf16)."""
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    n = x.shape[1] if n is None else int(n)
+    out = torch.empty(x.shape[0], dtype=torch.int64, device=x.device)
+    _lib.check(_L().ecgb_argmax_bf16(_p(x), x.stride(0), x.shape[0], n, _p(out), _st()))
+    return out
+
+
 def embed_bwd_sorted_(ids, dout, grad_table_bf16, scale=1.0, skip_id=-1):
     """grad_table_bf16[id] += scale * sum of dout rows with that id, in place, no atomics (ecgb_embed_bwd_sorted): the same bits every call."""
     flat = ids.reshape(-1)
@@ -553,25 +562,40 @@ _split_scratch = {}
 def decode_splits(kv_len, B, Hq):
     """Workgroups a head's keys are split over in a decode step: about 64 keys each (a wave then needs one batch of key
     rows), at most 32 per head and 1024 in all; 1 = the single-workgroup kernel (short caches: three launches cost more
-    than they save)."""
+    than they save).  generate() passes the CAPACITY of its caches (prompt + new tokens, rounded up to 128 rows), not the keys valid
+    at a step: one split count for the whole call, the same in the eager loop and in the replayed graph -- the same bits."""
     if kv_len < 512:
         return 1
     return int(max(1, min(kv_len // 64, 32, max(1, 1024 // (B * Hq)))))
 
 
-def attn_decode_split(qkv_new, cache, mask, kv_len, Hq, Hkv, D, scale, n_splits):
-    """attn_decode with the keys of every head split over n_splits workgroups (ecgb_attn_decode_split)."""
+def decode_split_scratch(cap, B, Hq, D, n_splits, device):
+    """The fp32 scratch of attn_decode_split for a cache of `cap` rows (scores, per-split statistics, partial outputs)."""
+    return torch.empty(_L().ecgb_attn_decode_split_scratch_bytes(cap, B, Hq, D, n_splits), dtype=torch.uint8, device=device)
+
+
+def attn_decode_split(qkv_new, cache, mask, kv_len, Hq, Hkv, D, scale, n_splits, scratch=None):
+    """attn_decode with the keys of every head split over n_splits workgroups (ecgb_attn_decode_split).  kv_len: an int, or an int32[1] device
+    tensor (ecgb_attn_decode_split_dyn: replayable from a captured graph; the same bits for the same n_splits).  scratch: a caller-owned buffer
+    (decode_split_scratch) -- a captured graph must own the one it was captured with; otherwise one cached buffer per shape."""
     B, cap, W = cache.shape
     q = qkv_new[:, :Hq * D].contiguous()
     o = torch.empty((B, Hq * D), dtype=torch.bfloat16, device=q.device)
     need = _L().ecgb_attn_decode_split_scratch_bytes(cap, B, Hq, D, n_splits)
-    key = (q.device, need)
-    buf = _split_scratch.get(key)
+    buf = scratch
     if buf is None:
-        _split_scratch.clear()                       # one live buffer: the shapes of a generate() call do not change
-        buf = _split_scratch[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
-    _lib.check(_L().ecgb_attn_decode_split(_p(q), _off(cache, 0), _off(cache, Hkv * D), W, cap, _p(mask), mask.stride(0), _p(o),
-                                           B, int(kv_len), Hq, Hkv, D, float(scale), int(n_splits), _p(buf), need, _st()))
+        key = (q.device, need)
+        buf = _split_scratch.get(key)
+        if buf is None:
+            _split_scratch.clear()                       # one live buffer: the shapes of a generate() call do not change
+            buf = _split_scratch[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
+    assert buf.numel() >= need
+    if torch.is_tensor(kv_len):
+        _lib.check(_L().ecgb_attn_decode_split_dyn(_p(q), _off(cache, 0), _off(cache, Hkv * D), W, cap, _p(mask), mask.stride(0), _p(o),
+                                                   B, _p(kv_len), Hq, Hkv, D, float(scale), int(n_splits), _p(buf), buf.numel(), _st()))
+    else:
+        _lib.check(_L().ecgb_attn_decode_split(_p(q), _off(cache, 0), _off(cache, Hkv * D), W, cap, _p(mask), mask.stride(0), _p(o),
+                                               B, int(kv_len), Hq, Hkv, D, float(scale), int(n_splits), _p(buf), buf.numel(), _st()))
     return o
 
 

@@ -347,19 +347,21 @@ class HipGPT2LM(HipCausalLM):
             x, delta = self._layer_infer(i, x, delta, attend)
         return ops.layernorm_fwd(x, self.norm.data, self.norm_b.data, c.layer_norm_epsilon, residual=delta)[0]
 
-    def _decode_step(self, tokens, pos, mask, caches, n, n_dev=None):
+    def _decode_step(self, tokens, pos, mask, caches, n, n_dev=None, scratch=None):
         c = self.cfg
         H, nh, D = c.n_embd, c.n_head, c.head_dim
         scale = 1.0 / math.sqrt(D)
 
         def attend(i, qkv):
+            ns = ops.decode_splits(caches[i].shape[1], qkv.shape[0], nh)      # by the caches' capacity: see HipCausalLM._decode_step
             if n_dev is None:
                 caches[i][:, n - 1].copy_(qkv[:, H:])
-                ns = ops.decode_splits(n, qkv.shape[0], nh)
                 if ns > 1:
                     return ops.attn_decode_split(qkv, caches[i], mask, n, nh, nh, D, scale, ns)
                 return ops.attn_decode(qkv, caches[i], mask, n, nh, nh, D, scale)
             ops.kv_append(qkv, H, caches[i], n_dev)
+            if ns > 1:
+                return ops.attn_decode_split(qkv, caches[i], mask, n_dev, nh, nh, D, scale, ns, scratch=scratch)
             return ops.attn_decode_dyn(qkv, caches[i], mask, n_dev, nh, nh, D, scale)
 
         x, delta = self._embed(tokens[:, None], pos[:, None]), None

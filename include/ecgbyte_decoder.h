@@ -269,6 +269,15 @@ int ecgb_attn_decode_dyn(const void *q_dev, const void *k_cache_dev, const void 
                          int n_q_heads, int n_kv_heads, int head_dim, float scale, void *stream);
 int ecgb_kv_append(const void *src_dev, long long src_ld, long long col_off, int width, void *cache_dev, long long capacity,
                    int batch, const int *kv_len_dev, void *stream);
+/* ecgb_attn_decode_split with the number of valid cache rows in device memory: the same three launches, each split's key range computed on the
+ * device as the host computes it (chunk = ceil(len / n_splits)) -- the same bits as ecgb_attn_decode_split with the same n_splits. */
+int ecgb_attn_decode_split_dyn(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,
+                               const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, const int *kv_len_dev, int n_q_heads,
+                               int n_kv_heads, int head_dim, float scale, int n_splits, void *scratch_dev, size_t scratch_bytes, void *stream);
+
+/* Greedy token choice of generate() (GenerationMixin._sample, generation/utils.py:3205: `next_tokens = torch.argmax(next_token_scores, dim=-1)`):
+ * out[r] = index of the first maximum of the bf16 row x[r, 0:n] (rows `ld` elements apart).  One launch, no workspace. */
+int ecgb_argmax_bf16(const void *x_dev, long long ld, int rows, int n, int64_t *out_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,11 @@ from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
 V = 256000 + 256 + 3500 + 3
 cfg = DecoderConfig.gemma_2b(vocab_size=V, pad_token_id=V - 1)
 m = HipCausalLM(cfg)
+if _os.environ.get("LORA"):
+    m.enable_lora(16, 32, 0.05)
+    for n_, p_ in m.named_parameters():
+        if "lora_B" in n_ or n_.endswith(".B"):
+            p_.data.normal_(0, 0.01)
 m.eval()
 g = torch.Generator(device="cuda").manual_seed(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1

@@ -439,6 +439,12 @@ def test_generate_graph_replay_equals_eager_loop(family):
     one = m.generate(input_ids=ids[1:2], attention_mask=mask[1:2], max_new_tokens=20, pad_token_id=299, eos_token_id=eos)
     ref = m.generate(input_ids=ids[1:2], attention_mask=mask[1:2], max_new_tokens=20, pad_token_id=299, eos_token_id=eos, use_graph=False)
     assert torch.equal(one, ref)
+    # a captured step is reused by later calls of the same batch size whose prompt + new tokens fit its buffers: other prompt lengths, other token counts
+    m._gen_graphs.clear()
+    for cut, new in ((0, 20), (3, 17), (1, 9), (0, 20)):
+        kw = dict(input_ids=ids[:, cut:], attention_mask=mask[:, cut:], max_new_tokens=new, pad_token_id=299, eos_token_id=eos)
+        assert torch.equal(m.generate(**kw), m.generate(use_graph=False, **kw)), (cut, new)
+    assert len(m._gen_graphs) == 1
 
 
 def test_data_parallel_gradients_two_ranks(tmp_path):
@@ -530,6 +536,24 @@ def test_generate_long_prompt_takes_the_split_decode_attention(monkeypatch):
             top2 = lg_n[:, t].topk(2, dim=-1).values
             assert (top2[:, 0] - top2[:, 1]).min().item() < tol  # a tie at bf16 resolution
             break
+
+
+def test_generate_long_prompt_graph_replay_equals_eager_loop():
+    """Caches of 512 rows and more: the replayed step runs the split decode attention with the length in device memory (ecgb_attn_decode_split_dyn), the
+    eager loop the same kernels with the length as an argument and the same split count (by the caches' capacity): the same sequences, call after call."""
+    zg, m = _load_generate()
+    g = torch.Generator().manual_seed(5)
+    B, S0 = 2, 540
+    ids = torch.randint(3, 290, (B, S0), generator=g).cuda()
+    mask = torch.ones(B, S0)
+    mask[0, :17] = 0
+    ids[0, :17] = 299
+    mask = mask.cuda()
+    m._gen_graphs = {}
+    for cut, new in ((0, 30), (40, 70), (3, 12)):
+        kw = dict(input_ids=ids[:, cut:], attention_mask=mask[:, cut:], max_new_tokens=new, pad_token_id=299)
+        assert torch.equal(m.generate(use_graph=True, **kw), m.generate(use_graph=False, **kw)), (cut, new)
+    assert len(m._gen_graphs) == 1 and next(iter(m._gen_graphs.values())).scratch is not None
 
 
 def test_generate_sampling_follows_the_warped_distribution(tmp_path):

@@ -586,4 +586,30 @@ def test_decode_attention_single_and_split_kernels(ops, D, Hq, Hkv, B, n):
         got = ops.attn_decode_split(qkv, cache, mask, n, Hq, Hkv, D, scale, ns).float()
         assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-3, ns
         assert (got - one).abs().max().item() <= 1e-2 * want.abs().max().item() + 1e-3, ns   # same arithmetic per key, other summation order
+        # the length in device memory (a replayed graph's step), a caller-owned scratch: the same bits
+        n_dev = torch.full((1,), n, dtype=torch.int32, device="cuda")
+        own = ops.decode_split_scratch(cap, B, Hq, D, ns, "cuda")
+        assert torch.equal(ops.attn_decode_split(qkv, cache, mask, n_dev, Hq, Hkv, D, scale, ns, scratch=own).float(), got), ns
     assert ops.decode_splits(100, 1, 8) == 1 and ops.decode_splits(2048, 1, 8) == 32 and ops.decode_splits(700, 8, 8) == 10
+
+
+@pytest.mark.parametrize("rows,n,ld", [(1, 259759, 259776), (3, 1000, 1000), (8, 4099, 4103), (2, 7, 9), (5, 300, 304)])
+def test_argmax_rows_is_torch_argmax(ops, rows, n, ld):
+    """ecgb_argmax_bf16 (the greedy token choice of generate()) = torch.argmax over the first n columns: the FIRST index of the maximum with ties
+    (bf16 logits tie often), -0 == +0, a NaN counts as the maximum; rows that start off a 16-byte boundary (odd widths)."""
+    g = torch.Generator(device="cuda").manual_seed(rows * 1000 + n)
+    x = (torch.randn(rows, ld, device="cuda", generator=g) * 3).to(torch.bfloat16)
+    x[:, n:] = 100.0                                               # past the end: never chosen
+    assert torch.equal(ops.argmax_rows(x, n), x[:, :n].float().argmax(-1))
+    # ties: few distinct values
+    y = torch.randint(-2, 3, (rows, ld), device="cuda", generator=g).to(torch.bfloat16)
+    assert torch.equal(ops.argmax_rows(y, n), y[:, :n].float().argmax(-1))
+    # all negative, zeros of both signs
+    z = -x.abs()
+    z[:, n // 2] = -0.0
+    z[:, n - 1] = 0.0
+    assert torch.equal(ops.argmax_rows(z, n), torch.full((rows,), n // 2, device="cuda"))
+    z[0, n // 3] = float("nan")
+    assert int(ops.argmax_rows(z, n)[0]) == n // 3
+    w = torch.full((rows, ld), float("-inf"), device="cuda").to(torch.bfloat16)
+    assert torch.equal(ops.argmax_rows(w, n), torch.zeros(rows, dtype=torch.long, device="cuda"))
