@@ -1019,7 +1019,7 @@ class HipCausalLM(nn.Module):
         key = (B, cap, pad_id, None if eos is None else tuple(int(e) for e in eos.tolist()), sampling, self.training, self.embed.data_ptr(),
                None if self.lora is None else self.lora[0]["qkv"].A.data_ptr())
         graphs = self.__dict__.setdefault("_gen_graphs", {})
-        st = graphs.get(key)
+        st = graphs.get(key) if sampling is None else None                   # (a sampling step holds torch's sort / cumsum / multinomial: captured per call, see below)
         if st is None:
             while len(graphs) >= 4:                                          # a handful of shapes at most: drop the oldest
                 graphs.pop(next(iter(graphs)))
@@ -1036,7 +1036,8 @@ class HipCausalLM(nn.Module):
             ns = ops.decode_splits(cap, B, c.num_attention_heads)
             if ns > 1:
                 st.scratch = ops.decode_split_scratch(cap, B, c.num_attention_heads, c.head_dim, ns, dev)
-            graphs[key] = st
+            if sampling is None:
+                graphs[key] = st
         caches, gmask, out, tok, pos, n_dev, col, unfinished = st.caches, st.mask, st.out, st.tok, st.pos, st.n_dev, st.col, st.unfinished
         # prefill + first token, eagerly
         gmask.zero_()
