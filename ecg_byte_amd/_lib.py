@@ -138,6 +138,9 @@ def lib():
         "ecgb_attn_decode_split": [vp, vp, vp, ll, ll, vp, ll, vp, ci, ci, ci, ci, ci, f32, ci, vp, sz, vp],
         "ecgb_kv_append": [vp, ll, ll, ci, vp, ll, ci, vp, vp],
         "ecgb_argmax_bf16": [vp, ll, ci, ci, vp, vp],
+        "ecgb_gemm_nt_w4_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, vp],
+        "ecgb_set_gemm_w4": [ci],
+        "ecgb_set_gemm_w4_group_m": [ci],
         "ecgb_attn_decode_split_dyn": [vp, vp, vp, ll, ll, vp, ll, vp, ci, vp, ci, ci, ci, f32, ci, vp, sz, vp],
         "ecgb_gemm_tn_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, vp],
         "ecgb_sum_slabs_bf16": [vp, ll, ci, vp, sz, ci, vp],

@@ -1,0 +1,301 @@
+// C[M, N] = alpha * A[M, K] . B[N, K]^T (bf16 in, fp32 accumulate, bf16 out) on FOUR waves per workgroup, each owning a 128x128 quarter of a
+// 256x256 tile -- one wave per SIMD, its 256 accumulators in the accumulation half of the register file.
+//
+// Why a second NT kernel (round 3).  The 8-wave kernels of gemm.hip (wave tile 128x64, two waves per SIMD) keep the MFMA pipes 0.61-0.70 busy at about
+// 1.7 GHz; hipBLASLt's kernel for the same shapes (MT256x256x64, MIWT8_8, 256 threads; `scripts/prof_blas.sh`, `scripts/prof_gemm_pmc.sh`) keeps them 0.91
+// busy at 1.65 GHz -- the clock does not pay for the idle cycles, so the gap is schedule, not power.  A 128x128 wave tile reads 32 LDS fragments per 128 MFMAs
+// where a 128x64 one reads 24 per 64: a third less LDS traffic per FLOP, half the waves' worth of address arithmetic, ONE workgroup barrier per K-tile
+// instead of eight.  Measured on the forward shapes of the C3 step (`scripts/dev_gemm_w4.py`): 1-6 % faster than the 8-wave kernels, 5-12 % behind
+// hipBLASLt; what is left is the one rendezvous per K-tile (the four waves wait for the slowest wave's LDS-DMA: 8 % at K = 8192) -- see DESIGN.md section 7.
+//
+// This file is compiled WITHOUT -amdgpu-mfma-vgpr-form (Makefile): 256 accumulators + 128 fragment registers need both halves of the file.
+//
+// Persistent: one workgroup per CU, each walks its share of the tiles as ONE flat sequence of K-tiles, so the first two K-tiles of the next output tile are
+// already in flight (and its first fragments in registers) while the finished tile is stored.  Per K-tile and wave: 16 LDS-DMA pieces (global_load_lds,
+// 1 KiB each), 32 ds_read_b128, 128 MFMA 16x16x32, one s_barrier.  Same MFMA, same order over K as the 8-wave kernels: the same bits
+// (tests/test_gpu_decoder_ops.py::test_gemm_nt_four_wave_kernel_same_bits).
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "tokenizer.hpp"
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int BK = 64;
+constexpr int kTileBytes = 256 * BK * 2;                 // one operand's K-tile: 256 rows of 128 bytes
+constexpr int kBufBytes = 2 * kTileBytes;                // A then B
+constexpr int kStageBytes = 4096;                        // per wave: one MFMA row (16 x 128 bf16) of the finished tile on its way out
+constexpr int kLdsBytes = 2 * kBufBytes + 4 * kStageBytes;
+
+struct W4Args {
+    const unsigned short *A, *B;
+    unsigned short *C;
+    long long lda, ldb, ldc;
+    int M, N, K;
+    int tiles_m, tiles_n;
+    int group_m;            // tile order: 0 / 1 row by row; g: blocks of g tile rows, column by column inside a block
+    float alpha;
+};
+
+__device__ __forceinline__ unsigned pack2(float a, float b)
+{
+    using bf2 = __attribute__((ext_vector_type(2))) __bf16;
+    bf2 v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// Tile of workgroup w in round `it`: the workgroups of a round take consecutive tiles of the tile order, the 32 workgroups of an XCD (w % 8) a contiguous run
+// of them -- with the order in blocks of 16 tile rows (tile_rc) an XCD's 32 concurrent tiles are a 16 x 2 patch: 18 panels of A and B for 32 tiles instead of
+// 33 (measured, [32768, 16384] x K 2048: 2.07 ms row by row, 1.87 / 1.70 / 1.62 / 1.60 ms with blocks of 2 / 4 / 8 / 16 -- the LDS-DMA of a K-tile has one K-tile
+// of time to land, and the rendezvous waits for the slowest of 64 pieces: it is the L2 hit rate that decides how long).
+__device__ __forceinline__ int tile_of_round(int w, int it, int nwg) { return it * nwg + (w & 7) * (nwg >> 3) + (w >> 3); }
+__device__ __forceinline__ void tile_rc(const W4Args &G, int tile, int &tm, int &tn)
+{
+    if (G.group_m > 1) {
+        const int per = G.group_m * G.tiles_n, blk = tile / per, in = tile - blk * per;
+        const int rows = min(G.group_m, G.tiles_m - blk * G.group_m);           // the last block may be shorter
+        tn = in / rows;
+        tm = blk * G.group_m + (in - tn * rows);
+    } else {
+        tm = tile / G.tiles_n;
+        tn = tile - tm * G.tiles_n;
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_w4_kernel(W4Args G)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lm = lane & 15, lq = lane >> 4;
+    const int nwg = gridDim.x, w = blockIdx.x;
+    const int n_tiles = G.tiles_m * G.tiles_n;
+    const int KT = G.K / BK;
+    // my tiles: rounds it = 0, 1, ... while tile_of_round(w, it) < n_tiles
+    int my_tiles = 0;
+    for (int it = 0; tile_of_round(w, it, nwg) < n_tiles; ++it) ++my_tiles;
+    if (my_tiles == 0) return;
+    const long long total = (long long)my_tiles * KT;      // K-tiles of the flat sequence
+
+    // ---- LDS-DMA: piece p = wave * 8 + i (i = 0..7) of an operand's K-tile is rows p*8 .. p*8+7; lane L brings the 16-byte chunk
+    // (L & 7) ^ ((row >> 1) & 7) of row p*8 + (L >> 3) -- the swizzle sits on the global side, the LDS side of the DMA is linear.
+    // (row >> 1) & 7 = ((L >> 4) + 4 * (i & 1)) & 7.  One piece = two instructions: M0 <- where the piece lands, then
+    // `global_load_lds_dwordx4 v_offset, s[base]`: the scalar base is the K-tile's, the per-lane offset (row of the piece, swizzled chunk) is fixed for the
+    // whole launch -- no address arithmetic in the loop.  (asm: through the builtin hipcc forms a 64-bit vector address per piece, four more instructions
+    // between two MFMAs: 3 % of the kernel.)
+    unsigned voffA[8], voffB[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int chunk = (lane & 7) ^ (((lane >> 4) + 4 * (i & 1)) & 7);
+        voffA[i] = (unsigned)(((long long)(i * 8 + (lane >> 3)) * G.lda + chunk * 8) * 2);
+        voffB[i] = (unsigned)(((long long)(i * 8 + (lane >> 3)) * G.ldb + chunk * 8) * 2);
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    const unsigned dma_base = lds_base + (unsigned)wave * 8192u;                 // this wave's eight pieces of an operand tile
+    // the K-tile the next stage brings: (round, K-tile) of the flat sequence and where its pieces start.  Past the end of the sequence the pointers stay on the
+    // last K-tile: the loop body stages unconditionally (no branch inside the interleaved stretch), a repeated tile lands in a buffer nobody reads again.
+    int st_kt = 0, st_it = 0;
+    const unsigned char *st_a = nullptr, *st_b = nullptr;
+    auto stage_first = [&]() {                                                  // start of round st_it's tile
+        int tm, tn;
+        tile_rc(G, tile_of_round(w, st_it, nwg), tm, tn);
+        st_a = reinterpret_cast<const unsigned char *>(G.A + ((long long)tm * 256 + wave * 64) * G.lda);
+        st_b = reinterpret_cast<const unsigned char *>(G.B + ((long long)tn * 256 + wave * 64) * G.ldb);
+    };
+    auto stage_advance = [&]() {
+        if (++st_kt == KT) {
+            st_kt = 0;
+            if (++st_it < my_tiles) stage_first();
+        } else {
+            st_a += BK * 2; st_b += BK * 2;
+        }
+    };
+    auto dma_a = [&](unsigned buf_off, int i) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dma_base + buf_off + (unsigned)i * 1024u), "v"(voffA[i]), "s"(st_a) : "memory");
+    };
+    auto dma_b = [&](unsigned buf_off, int i) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dma_base + buf_off + (unsigned)kTileBytes + (unsigned)i * 1024u), "v"(voffB[i]), "s"(st_b) : "memory");
+    };
+
+    // ---- fragments: MFMA 16x16x32 operand = 16 rows x 32 k; lane (lm, lq) reads the 16-byte chunk ks*4 + lq of row (tile row) * 16 + lm.
+    // (row >> 1) & 7 = (lm >> 1) & 7 for every row this lane reads: one swizzled offset per k-slice.
+    const int sw = (lm >> 1) & 7;
+    const unsigned fragA = (unsigned)((wr * 128 + lm) * 128 + ((lq ^ sw) << 4));
+    const unsigned fragB = (unsigned)(kTileBytes + (wc * 128 + lm) * 128 + ((lq ^ sw) << 4));
+    auto frag_a = [&](const unsigned char *buf, int ks, int i) { return *reinterpret_cast<const bf16x8 *>(buf + (fragA ^ (ks ? 64u : 0u)) + i * 2048); };
+    auto frag_b = [&](const unsigned char *buf, int ks, int j) { return *reinterpret_cast<const bf16x8 *>(buf + (fragB ^ (ks ? 64u : 0u)) + j * 2048); };
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // (asm: the accumulators stay in a0..a255 by constraint, the fragments in architectural registers -- as builtins hipcc put fragments into the accumulation
+    // file and spilled 176 registers; the 64 MFMAs between two uses of one accumulator cover the dependent-issue distance the assembler does not see.  The empty
+    // asm with a memory clobber pins the loads between the MFMAs where they are written.)
+#define W4_MFMA(i, j, fa, fb) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fb[j]), "v"(fa[i]))
+#define W4_FENCE() asm volatile("" ::: "memory")
+
+    // prologue: K-tiles 0 and 1 of the sequence in flight, 0 complete
+    stage_first();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dma_a(0u, i); dma_b(0u, i); }
+    if (total > 1) {
+        stage_advance();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { dma_a((unsigned)kBufBytes, i); dma_b((unsigned)kBufBytes, i); }
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (total > 2) stage_advance();
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fb0[j] = frag_b(lds, 0, j);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa0[i] = frag_a(lds, 0, i);
+
+    long long g = 0;
+    for (int it = 0; it < my_tiles; ++it) {
+        // (two nested loops, not one flat one with the store under a test: with the store inside the K loop hipcc spilled the loop-carried fragments on every K-tile)
+        for (int kt = 0; kt < KT; ++kt, ++g) {
+            unsigned char *cur = lds + (g & 1) * kBufBytes, *nxt = lds + ((g + 1) & 1) * kBufBytes;
+            const unsigned cur_off = (unsigned)(g & 1) * (unsigned)kBufBytes;
+            // ---- k-slice 0 of K-tile g (fragments read a block ago), the fragments of k-slice 1 read underneath: one ds_read per four MFMAs
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    W4_MFMA(i, j, fa0, fb0);
+                    if ((j & 3) == 3) {
+                        const int r = i * 2 + (j >> 2);                       // 0..15: B fragments first (the first row of MFMAs needs them all)
+                        W4_FENCE();
+                        if (r < 8) fb1[r] = frag_b(cur, 1, r); else fa1[r - 8] = frag_a(cur, 1, r - 8);
+                        W4_FENCE();
+                    }
+                }
+            // every read of `cur` by this wave has returned; this wave's pieces of K-tile g + 1 have landed; then everyone's
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ---- k-slice 1; underneath, K-tile g + 2 starts into `cur` (16 pieces) and the fragments of K-tile g + 1's k-slice 0 are read (the last K-tile of a
+            // tile reads the first fragments of the next tile): one of the 32 per two MFMAs, DMA pieces and reads alternating (all DMA first: 5-9 % slower)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    W4_MFMA(i, j, fa1, fb1);
+                    if (j & 1) {
+                        const int slot = i * 4 + (j >> 1), r = slot >> 1;     // 32 slots: even = fragment read r, odd = DMA piece r (0..15)
+                        W4_FENCE();
+                        if (slot & 1) { if (r < 8) dma_a(cur_off, r); else dma_b(cur_off, r - 8); }
+                        else { if (r < 8) fb0[r] = frag_b(nxt, 0, r); else fa0[r - 8] = frag_a(nxt, 0, r - 8); }
+                        W4_FENCE();
+                    }
+                }
+            if (g + 3 < total) stage_advance();
+        }
+        // ---- the tile is complete (the next tile's first two K-tiles are in flight, its first fragments in registers).  The wave's 128x128 block leaves through
+        // 4 KiB of LDS of its own, one MFMA row of 16 x 128 at a time: a lane holds four consecutive columns of sixteen different rows, memory wants whole rows --
+        // 8-byte writes in (row r at r * 256 bytes, its 16-byte chunk c at c ^ r: the writes of a 16 x 16 tile and the row reads both run at full LDS width), 16-byte
+        // reads out, each store instruction four full 256-byte rows.  (Direct 8-byte stores from the accumulator layout: 12 us per tile, a quarter of a K = 2048 tile.)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                    // the last MFMAs' results before the accumulators are read
+        int tm, tn;
+        tile_rc(G, tile_of_round(w, it, nwg), tm, tn);
+        using u2 = __attribute__((ext_vector_type(2))) unsigned;
+        using u4 = __attribute__((ext_vector_type(4))) unsigned;
+        unsigned char *stg = lds + 2 * kBufBytes + wave * kStageBytes;
+        const int rr = lane >> 4, cc = lane & 15;                              // read side: row (of four per pass) and 16-byte chunk
+        unsigned short *cdst = G.C + ((long long)tm * 256 + wr * 128 + rr) * G.ldc + (long long)tn * 256 + wc * 128 + cc * 8;
+        const float alpha = G.alpha;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                u2 v;
+                v[0] = pack2(acc[i][j][0] * alpha, acc[i][j][1] * alpha);
+                v[1] = pack2(acc[i][j][2] * alpha, acc[i][j][3] * alpha);
+                const int c = j * 2 + (lq >> 1);
+                *reinterpret_cast<u2 *>(stg + lm * 256 + ((c ^ lm) << 4) + (lq & 1) * 8) = v;
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int r = ps * 4 + rr;
+                *reinterpret_cast<u4 *>(cdst + (long long)(i * 16 + ps * 4) * G.ldc) = *reinterpret_cast<const u4 *>(stg + r * 256 + ((cc ^ r) << 4));
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+#undef W4_MFMA
+#undef W4_FENCE
+}
+
+int g_w4_group_m = 16;
+int g_w4_cus = 0;
+
+}  // namespace
+
+namespace ecgb {
+// For gemm.hip's dispatch: does the four-wave kernel take this problem?  Whole 256x256 tiles, operands 16-byte aligned, per-lane DMA offsets within 32 bits, and
+// at least 256 K-tiles per workgroup (one persistent workgroup per CU with a static share of the tiles): measured on the step's shapes, the kernel gains 4-6 %
+// where a workgroup has 512 K-tiles and more ([32768, 8192] -> 2048, the loss head, gate|up) and loses 0-3 % at 128-192 (qkv, o: the eight-wave kernels'
+// second wave per SIMD hides the tile hand-over better).
+bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long long ldb, const void *c_dev, long long ldc, int M, int N, int K)
+{
+    if (!g_w4_cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_w4_cus = (n & ~7) > 0 ? (n & ~7) : 8;                            // a multiple of the 8 XCDs
+    }
+    return M > 0 && N > 0 && K > 0 && M % 256 == 0 && N % 256 == 0 && K % BK == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
+           (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)c_dev) & 15) == 0 && (long long)63 * lda * 2 + 128 <= 0xFFFFFFFFll && (long long)63 * ldb * 2 + 128 <= 0xFFFFFFFFll &&
+           (long long)(M / 256) * (N / 256) / g_w4_cus * (K / BK) >= 256;
+}
+
+int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream)
+{
+    W4Args G;
+    G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = (unsigned short *)c_dev;
+    G.lda = lda; G.ldb = ldb; G.ldc = ldc; G.M = M; G.N = N; G.K = K; G.tiles_m = M / 256; G.tiles_n = N / 256; G.alpha = alpha; G.group_m = g_w4_group_m;
+    static bool attr_set = false;
+    hipError_t e = hipSuccess;
+    if (!attr_set) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_w4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        attr_set = (e == hipSuccess);
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3((unsigned)g_w4_cus), dim3(256), kLdsBytes, (hipStream_t)stream, G);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_w4_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
+}
+}  // namespace ecgb
+
+extern "C" int ecgb_set_gemm_w4_group_m(int g)
+{
+    if (g < 0 || g > 1024) { ecgb::set_error("ecgb_set_gemm_w4_group_m: 0..1024"); return ECGB_ERR_INVALID; }
+    g_w4_group_m = g;
+    return ECGB_OK;
+}
+
+// The four-wave kernel by name (tests, A/B): ECGB_ERR_UNSUPPORTED where ecgb_gemm_nt_bf16 would fall back to the 8-wave kernels.
+extern "C" int ecgb_gemm_nt_w4_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
+                                    int M, int N, int K, float alpha, void *stream)
+{
+    if (!a_dev || !b_dev || !c_dev || M <= 0 || N <= 0 || K <= 0) { ecgb::set_error("ecgb_gemm_nt_w4_bf16: bad argument"); return ECGB_ERR_INVALID; }
+    (void)ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K);          // (device properties)
+    if (M % 256 || N % 256 || K % BK || lda % 8 || ldb % 8 || ldc % 8 || (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)c_dev) & 15) ||
+        (long long)63 * lda * 2 + 128 > 0xFFFFFFFFll || (long long)63 * ldb * 2 + 128 > 0xFFFFFFFFll) {
+        ecgb::set_error("ecgb_gemm_nt_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream);
+}

@@ -35,6 +35,25 @@ def embed_fwd(ids, table, scale=1.0):
     return out
 
 
+def set_gemm_w4(on=True):
+    """A/B switch: plain NT products of whole 256x256 tiles on the four-wave kernel (default) or on the eight-wave kernels."""
+    _lib.check(_L().ecgb_set_gemm_w4(1 if on else 0))
+
+
+def set_gemm_w4_group_m(g=16):
+    """Tile order of the four-wave kernel: blocks of g tile rows (0: row by row)."""
+    _lib.check(_L().ecgb_set_gemm_w4_group_m(int(g)))
+
+
+def gemm_nt_w4(a, b, alpha=1.0, out=None):
+    """a [M, K] . b [N, K]^T on the four-wave kernel (ecgb_gemm_nt_w4_bf16): M, N multiples of 256, K of 64."""
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device) if out is None else out
+    _lib.check(_L().ecgb_gemm_nt_w4_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, float(alpha), _st()))
+    return out
+
+
 def argmax_rows(x, n=None):
     """torch.argmax(x[:, :n], -1) of a bf16 matrix (first index of the maximum), one launch without workspace (ecgb_argmax_bf16)."""
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1

@@ -275,6 +275,14 @@ int ecgb_attn_decode_split_dyn(const void *q_dev, const void *k_cache_dev, const
                                const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, const int *kv_len_dev, int n_q_heads,
                                int n_kv_heads, int head_dim, float scale, int n_splits, void *scratch_dev, size_t scratch_bytes, void *stream);
 
+/* C = alpha * A . B^T like ecgb_gemm_nt_bf16 (plain bf16 store, one problem), on four waves per workgroup with 128x128 wave tiles (csrc/gemm_w4.hip).
+ * Whole 256x256 tiles only: M and N multiples of 256, K of 64, 16-byte aligned operands; ECGB_ERR_UNSUPPORTED otherwise.  ecgb_gemm_nt_bf16 dispatches here
+ * when the problem also has at least two tiles per CU (batch 1, plain store); the same bits as the eight-wave kernels. */
+int ecgb_gemm_nt_w4_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
+                         int M, int N, int K, float alpha, void *stream);
+int ecgb_set_gemm_w4(int on);              /* 1 (default): ecgb_gemm_nt_bf16 sends eligible problems to the four-wave kernel; 0: never (A/B, tests) */
+int ecgb_set_gemm_w4_group_m(int group_m);  /* its tile order: blocks of group_m tile rows (default 16; 0 = row by row) */
+
 /* Greedy token choice of generate() (GenerationMixin._sample, generation/utils.py:3205: `next_tokens = torch.argmax(next_token_scores, dim=-1)`):
  * out[r] = index of the first maximum of the bf16 row x[r, 0:n] (rows `ld` elements apart).  One launch, no workspace. */
 int ecgb_argmax_bf16(const void *x_dev, long long ld, int rows, int n, int64_t *out_dev, void *stream);

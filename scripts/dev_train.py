@@ -12,7 +12,7 @@ from ecg_byte_amd import rust_bpe
 tag = sys.argv[1] if len(sys.argv) > 1 else "c2"
 L, nm = (5000, 4000) if tag == "c2" else (1000, 1000)
 vocab, merges, pc = load_tokenizer(tag)
-x = bench.make_signals(2000, L, seed=1, start=0, workers=16)
+x = bench.make_signals(2000, L, seed=1, start=0, workers=int(_os.environ.get("ECGB_BENCH_WORKERS", "16")))   # 1 under rocprofv3: a fork pool under the profiler hangs
 sym = quantize(torch.from_numpy(x).cuda(), pc).view(-1)
 text = (sym + 97).contiguous()
 torch.cuda.synchronize()

@@ -613,3 +613,33 @@ def test_argmax_rows_is_torch_argmax(ops, rows, n, ld):
     assert int(ops.argmax_rows(z, n)[0]) == n // 3
     w = torch.full((rows, ld), float("-inf"), device="cuda").to(torch.bfloat16)
     assert torch.equal(ops.argmax_rows(w, n), torch.zeros(rows, dtype=torch.long, device="cuda"))
+
+
+@pytest.mark.parametrize("M,N,K,pad", [(512, 512, 64, 0), (768, 256, 192, 8), (4096, 8192, 256, 0), (8192, 8192, 1024, 64)])
+def test_gemm_nt_four_wave_kernel_same_bits(ops, M, N, K, pad):
+    """csrc/gemm_w4.hip (four waves per workgroup, 128x128 wave tiles, persistent) = the eight-wave kernels bit for bit (same MFMA, same order over K), for
+    every tile order, with padded row strides and a scale; ecgb_gemm_nt_bf16 dispatches to it from 256 K-tiles per CU on and stays on the eight-wave kernels
+    when the switch is off; shapes off whole tiles are refused by name."""
+    a = _bf(M, K + pad, seed=51)[:, :K]
+    b = _bf(N, K + pad, seed=52)[:, :K]
+    ops.set_gemm_w4(False)
+    try:
+        ref = ops.gemm_nt(a, b)
+        ref_s = ops.gemm_nt(a, b, alpha=0.37)
+    finally:
+        ops.set_gemm_w4(True)
+    want = a.float() @ b.float().T
+    assert (ref.float() - want).abs().max().item() <= 2e-2 * want.abs().max().item()
+    for g in (0, 3, 16, 1000):
+        ops.set_gemm_w4_group_m(g)
+        try:
+            assert torch.equal(ops.gemm_nt_w4(a, b), ref), g
+        finally:
+            ops.set_gemm_w4_group_m(16)
+    assert torch.equal(ops.gemm_nt_w4(a, b, alpha=0.37), ref_s)
+    out = torch.full((M, N + 24), 7.0, device="cuda", dtype=torch.bfloat16)       # into a wider buffer: the columns past N stay
+    ops.gemm_nt_w4(a, b, out=out[:, :N])
+    assert torch.equal(out[:, :N], ref) and bool((out[:, N:] == 7.0).all())
+    assert torch.equal(ops.gemm_nt(a, b), ref)                                   # the dispatch, whatever it picks (the last shape: four-wave)
+    with pytest.raises(Exception):
+        ops.gemm_nt_w4(a[:-16], b)
