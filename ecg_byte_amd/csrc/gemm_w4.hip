@@ -18,6 +18,7 @@
 
 #include <string>
 
+#include "glu_math.hpp"
 #include "tokenizer.hpp"
 
 namespace {
@@ -28,7 +29,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int BK = 64;
 constexpr int kTileBytes = 256 * BK * 2;                 // one operand's K-tile: 256 rows of 128 bytes
 constexpr int kBufBytes = 2 * kTileBytes;                // A then B
-constexpr int kStageBytes = 4096;                        // per wave: one MFMA row (16 x 128 bf16) of the finished tile on its way out
+constexpr int kStageBytes = 6144;                        // per wave: one MFMA row of the finished tile on its way out (16 x 128 bf16; GLU: gate, up and act(gate) * up, 16 x 64 each)
 constexpr int kLdsBytes = 2 * kBufBytes + 4 * kStageBytes;
 
 struct W4Args {
@@ -39,6 +40,9 @@ struct W4Args {
     int tiles_m, tiles_n;
     int group_m;            // tile order: 0 / 1 row by row; g: blocks of g tile rows, column by column inside a block
     float alpha;
+    unsigned short *H;      // GLU epilogue (EPI != 0): act(gate) * up [M, glu_I]; B is [2 * glu_I, K], gate rows then up rows; C (gate|up, [M, 2 * glu_I]) may be null
+    long long ldh;
+    int glu_I;
 };
 
 __device__ __forceinline__ unsigned pack2(float a, float b)
@@ -67,6 +71,10 @@ __device__ __forceinline__ void tile_rc(const W4Args &G, int tile, int &tm, int 
     }
 }
 
+// EPI 0: plain bf16 store.  EPI 1 (SiLU) / 2 (tanh-GELU): the MLP's gate|up projection with the GLU in the epilogue, as gemm.hip's EPI kernels do it -- a tile's 256
+// columns are 8 groups of 16 gate columns and the 16 up columns of the same outputs (the B rows are fetched in that order), MFMA tile (i, 2p) is gate and
+// (i, 2p + 1) up of the same 16 columns; glu_fwd_kernel's arithmetic on the bf16-rounded projections: the same bits fused and unfused, four-wave and eight-wave.
+template <int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_w4_kernel(W4Args G)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -93,7 +101,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < 8; ++i) {
         const int chunk = (lane & 7) ^ (((lane >> 4) + 4 * (i & 1)) & 7);
         voffA[i] = (unsigned)(((long long)(i * 8 + (lane >> 3)) * G.lda + chunk * 8) * 2);
-        voffB[i] = (unsigned)(((long long)(i * 8 + (lane >> 3)) * G.ldb + chunk * 8) * 2);
+        if constexpr (EPI == 0) voffB[i] = (unsigned)(((long long)(i * 8 + (lane >> 3)) * G.ldb + chunk * 8) * 2);
+        else                                             // tile row r = (wave * 8 + i) * 8 + (lane >> 3) is weight row 16 * (r >> 5) + (r & 15) (+ glu_I: an up row)
+            voffB[i] = (unsigned)(((long long)(16 * (i >> 2) + (i & 1) * 8 + (lane >> 3) + ((i >> 1) & 1) * (long long)G.glu_I) * G.ldb + chunk * 8) * 2);
     }
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
     const unsigned dma_base = lds_base + (unsigned)wave * 8192u;                 // this wave's eight pieces of an operand tile
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         int tm, tn;
         tile_rc(G, tile_of_round(w, st_it, nwg), tm, tn);
         st_a = reinterpret_cast<const unsigned char *>(G.A + ((long long)tm * 256 + wave * 64) * G.lda);
-        st_b = reinterpret_cast<const unsigned char *>(G.B + ((long long)tn * 256 + wave * 64) * G.ldb);
+        st_b = reinterpret_cast<const unsigned char *>(G.B + (EPI == 0 ? (long long)tn * 256 + wave * 64 : (long long)tn * 128 + wave * 32) * G.ldb);
     };
     auto stage_advance = [&]() {
         if (++st_kt == KT) {
@@ -210,27 +220,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         using u2 = __attribute__((ext_vector_type(2))) unsigned;
         using u4 = __attribute__((ext_vector_type(4))) unsigned;
         unsigned char *stg = lds + 2 * kBufBytes + wave * kStageBytes;
-        const int rr = lane >> 4, cc = lane & 15;                              // read side: row (of four per pass) and 16-byte chunk
-        unsigned short *cdst = G.C + ((long long)tm * 256 + wr * 128 + rr) * G.ldc + (long long)tn * 256 + wc * 128 + cc * 8;
         const float alpha = G.alpha;
+        if constexpr (EPI == 0) {
+            const int rr = lane >> 4, cc = lane & 15;                          // read side: row (of four per pass) and 16-byte chunk
+            unsigned short *cdst = G.C + ((long long)tm * 256 + wr * 128 + rr) * G.ldc + (long long)tn * 256 + wc * 128 + cc * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 8; ++i) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                u2 v;
-                v[0] = pack2(acc[i][j][0] * alpha, acc[i][j][1] * alpha);
-                v[1] = pack2(acc[i][j][2] * alpha, acc[i][j][3] * alpha);
-                const int c = j * 2 + (lq >> 1);
-                *reinterpret_cast<u2 *>(stg + lm * 256 + ((c ^ lm) << 4) + (lq & 1) * 8) = v;
-                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 8; ++j) {
+                    u2 v;
+                    v[0] = pack2(acc[i][j][0] * alpha, acc[i][j][1] * alpha);
+                    v[1] = pack2(acc[i][j][2] * alpha, acc[i][j][3] * alpha);
+                    const int c = j * 2 + (lq >> 1);
+                    *reinterpret_cast<u2 *>(stg + lm * 256 + ((c ^ lm) << 4) + (lq & 1) * 8) = v;
+                    acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int r = ps * 4 + rr;
+                    *reinterpret_cast<u4 *>(cdst + (long long)(i * 16 + ps * 4) * G.ldc) = *reinterpret_cast<const u4 *>(stg + r * 256 + ((cc ^ r) << 4));
+                }
+                asm volatile("" ::: "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            // three arrays of 16 rows x 64 columns (gate, up, act(gate) * up: 2 KiB each), row r at r * 128 bytes, its 16-byte chunk c at c ^ (r & 7); out in whole
+            // 128-byte rows, eight rows per store instruction
+            auto lo_f = [](unsigned x) { return __uint_as_float(x << 16); };
+            auto hi_f = [](unsigned x) { return __uint_as_float(x & 0xFFFF0000u); };
+            const int rr = lane >> 3, cc = lane & 7;
+            const long long hcol = (long long)tn * 128 + wc * 64 + cc * 8;       // column of H = gate column of C
+            const long long grow0 = (long long)tm * 256 + wr * 128 + rr;
 #pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const int r = ps * 4 + rr;
-                *reinterpret_cast<u4 *>(cdst + (long long)(i * 16 + ps * 4) * G.ldc) = *reinterpret_cast<const u4 *>(stg + r * 256 + ((cc ^ r) << 4));
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    u2 gt, up, h;
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) {
+                        gt[x] = pack2(acc[i][2 * p][2 * x] * alpha, acc[i][2 * p][2 * x + 1] * alpha);
+                        up[x] = pack2(acc[i][2 * p + 1][2 * x] * alpha, acc[i][2 * p + 1][2 * x + 1] * alpha);
+                        const unsigned a = pack2(ecgb::glu_act<EPI == 2>(lo_f(gt[x])), ecgb::glu_act<EPI == 2>(hi_f(gt[x])));
+                        h[x] = pack2(lo_f(a) * lo_f(up[x]), hi_f(a) * hi_f(up[x]));
+                    }
+                    acc[i][2 * p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    acc[i][2 * p + 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const int c = p * 2 + (lq >> 1);
+                    unsigned char *dst = stg + lm * 128 + ((c ^ (lm & 7)) << 4) + (lq & 1) * 8;
+                    if (G.C) { *reinterpret_cast<u2 *>(dst) = gt; *reinterpret_cast<u2 *>(dst + 2048) = up; }
+                    *reinterpret_cast<u2 *>(dst + 4096) = h;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int r = ps * 8 + rr;
+                    const unsigned char *src = stg + r * 128 + ((cc ^ (r & 7)) << 4);
+                    const long long grow = grow0 + i * 16 + ps * 8;
+                    if (G.C) {
+                        *reinterpret_cast<u4 *>(G.C + grow * G.ldc + hcol) = *reinterpret_cast<const u4 *>(src);
+                        *reinterpret_cast<u4 *>(G.C + grow * G.ldc + G.glu_I + hcol) = *reinterpret_cast<const u4 *>(src + 2048);
+                    }
+                    *reinterpret_cast<u4 *>(G.H + grow * G.ldh + hcol) = *reinterpret_cast<const u4 *>(src + 4096);
+                }
+                asm volatile("" ::: "memory");
             }
-            asm volatile("" ::: "memory");
         }
     }
 #undef W4_MFMA
@@ -259,19 +312,23 @@ bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long l
            (long long)(M / 256) * (N / 256) / g_w4_cus * (K / BK) >= 256;
 }
 
-int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream)
+// epi 0: C [M, N] plain.  epi 1 / 2 (SiLU / tanh-GELU): N = 2 * inter, B = [gate rows; up rows], H [M, inter] = act(gate) * up, C (gate|up) may be null.
+int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream,
+                   int epi, void *h_dev, long long ldh)
 {
     W4Args G;
     G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = (unsigned short *)c_dev;
     G.lda = lda; G.ldb = ldb; G.ldc = ldc; G.M = M; G.N = N; G.K = K; G.tiles_m = M / 256; G.tiles_n = N / 256; G.alpha = alpha; G.group_m = g_w4_group_m;
-    static bool attr_set = false;
+    G.H = (unsigned short *)h_dev; G.ldh = ldh; G.glu_I = N / 2;
+    void (*kern)(W4Args) = epi == 0 ? gemm_nt_w4_kernel<0> : epi == 1 ? gemm_nt_w4_kernel<1> : gemm_nt_w4_kernel<2>;
+    static bool attr_set[3] = {false, false, false};
     hipError_t e = hipSuccess;
-    if (!attr_set) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_nt_w4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        attr_set = (e == hipSuccess);
+    if (!attr_set[epi]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        attr_set[epi] = (e == hipSuccess);
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(gemm_nt_w4_kernel, dim3((unsigned)g_w4_cus), dim3(256), kLdsBytes, (hipStream_t)stream, G);
+        hipLaunchKernelGGL(kern, dim3((unsigned)g_w4_cus), dim3(256), kLdsBytes, (hipStream_t)stream, G);
         e = hipGetLastError();
     }
     if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_w4_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
@@ -297,5 +354,5 @@ extern "C" int ecgb_gemm_nt_w4_bf16(const void *a_dev, long long lda, const void
         ecgb::set_error("ecgb_gemm_nt_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
         return ECGB_ERR_UNSUPPORTED;
     }
-    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream);
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0);
 }

@@ -643,3 +643,23 @@ def test_gemm_nt_four_wave_kernel_same_bits(ops, M, N, K, pad):
     assert torch.equal(ops.gemm_nt(a, b), ref)                                   # the dispatch, whatever it picks (the last shape: four-wave)
     with pytest.raises(Exception):
         ops.gemm_nt_w4(a[:-16], b)
+
+
+@pytest.mark.parametrize("gelu", [False, True])
+def test_gemm_nt_glu_four_wave_kernel_same_bits(ops, gelu):
+    """The gate|up projection with the GLU in the epilogue on the four-wave kernel (a shape ecgb_gemm_nt_glu_bf16 dispatches there: 256 K-tiles per CU) = the
+    eight-wave kernel bit for bit: gate|up, act(gate) * up, and the inference form that never writes gate|up."""
+    M, I, K = 8192, 8192, 2048
+    x, w = _bf(M, K, seed=61), _bf(2 * I, K, seed=62) * 0.05
+    ops.set_gemm_w4(False)
+    try:
+        gu8, h8 = ops.gemm_nt_glu(x, w, gelu_tanh=gelu, keep_gu=True)
+    finally:
+        ops.set_gemm_w4(True)
+    gu4, h4 = ops.gemm_nt_glu(x, w, gelu_tanh=gelu, keep_gu=True)
+    assert torch.equal(gu4, gu8) and torch.equal(h4, h8)
+    none, h4n = ops.gemm_nt_glu(x, w, gelu_tanh=gelu, keep_gu=False)
+    assert none is None and torch.equal(h4n, h8)
+    assert torch.equal(ops.glu_fwd(gu4, gelu_tanh=gelu), h4)                      # and the unfused kernel on the stored projection
+    want = x[:64].float() @ w.float().T
+    assert (gu4[:64].float() - want).abs().max().item() <= 2e-2 * want.abs().max().item()
