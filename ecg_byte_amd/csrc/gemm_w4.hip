@@ -40,6 +40,9 @@ struct W4Args {
     int tiles_m, tiles_n;
     int group_m;            // tile order: 0 / 1 row by row; g: blocks of g tile rows, column by column inside a block
     float alpha;
+    const unsigned short *A2, *B2;   // CAT: a second operand pair contracted behind the first, C = alpha * (A B^T + A2 B2^T) (the LoRA branch: A2 = x A_lora^T, B2 = B_lora)
+    long long lda2, ldb2;
+    int K2;
     unsigned short *H;      // GLU epilogue (EPI != 0): act(gate) * up [M, glu_I]; B is [2 * glu_I, K], gate rows then up rows; C (gate|up, [M, 2 * glu_I]) may be null
     long long ldh;
     int glu_I;
@@ -74,7 +77,9 @@ __device__ __forceinline__ void tile_rc(const W4Args &G, int tile, int &tm, int 
 // EPI 0: plain bf16 store.  EPI 1 (SiLU) / 2 (tanh-GELU): the MLP's gate|up projection with the GLU in the epilogue, as gemm.hip's EPI kernels do it -- a tile's 256
 // columns are 8 groups of 16 gate columns and the 16 up columns of the same outputs (the B rows are fetched in that order), MFMA tile (i, 2p) is gate and
 // (i, 2p + 1) up of the same 16 columns; glu_fwd_kernel's arithmetic on the bf16-rounded projections: the same bits fused and unfused, four-wave and eight-wave.
-template <int EPI>
+// CAT: the K loop continues into (A2, B2) -- K-tiles KT1 .. KT - 1 of every output tile come from the second pair (another scalar base, another set of per-lane
+// offsets chosen by a wave-uniform select: one v_cndmask per DMA piece).
+template <int EPI, bool CAT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_w4_kernel(W4Args G)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lm = lane & 15, lq = lane >> 4;
     const int nwg = gridDim.x, w = blockIdx.x;
     const int n_tiles = G.tiles_m * G.tiles_n;
-    const int KT = G.K / BK;
+    const int KT1 = G.K / BK, KT = CAT ? KT1 + G.K2 / BK : KT1;
     // my tiles: rounds it = 0, 1, ... while tile_of_round(w, it) < n_tiles
     int my_tiles = 0;
     for (int it = 0; tile_of_round(w, it, nwg) < n_tiles; ++it) ++my_tiles;
@@ -96,40 +101,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // `global_load_lds_dwordx4 v_offset, s[base]`: the scalar base is the K-tile's, the per-lane offset (row of the piece, swizzled chunk) is fixed for the
     // whole launch -- no address arithmetic in the loop.  (asm: through the builtin hipcc forms a 64-bit vector address per piece, four more instructions
     // between two MFMAs: 3 % of the kernel.)
-    unsigned voffA[8], voffB[8];
+    unsigned voffA[8], voffB[8], voffA2[CAT ? 8 : 1], voffB2[CAT ? 8 : 1];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int chunk = (lane & 7) ^ (((lane >> 4) + 4 * (i & 1)) & 7);
+        // B: tile row r = (wave * 8 + i) * 8 + (lane >> 3); GLU: that is weight row 16 * (r >> 5) + (r & 15) (+ glu_I: an up row)
+        const long long rb = EPI == 0 ? (long long)(i * 8 + (lane >> 3)) : 16 * (i >> 2) + (i & 1) * 8 + (lane >> 3) + ((i >> 1) & 1) * (long long)G.glu_I;
         voffA[i] = (unsigned)(((long long)(i * 8 + (lane >> 3)) * G.lda + chunk * 8) * 2);
-        if constexpr (EPI == 0) voffB[i] = (unsigned)(((long long)(i * 8 + (lane >> 3)) * G.ldb + chunk * 8) * 2);
-        else                                             // tile row r = (wave * 8 + i) * 8 + (lane >> 3) is weight row 16 * (r >> 5) + (r & 15) (+ glu_I: an up row)
-            voffB[i] = (unsigned)(((long long)(16 * (i >> 2) + (i & 1) * 8 + (lane >> 3) + ((i >> 1) & 1) * (long long)G.glu_I) * G.ldb + chunk * 8) * 2);
+        voffB[i] = (unsigned)((rb * G.ldb + chunk * 8) * 2);
+        if constexpr (CAT) {
+            voffA2[i] = (unsigned)(((long long)(i * 8 + (lane >> 3)) * G.lda2 + chunk * 8) * 2);
+            voffB2[i] = (unsigned)((rb * G.ldb2 + chunk * 8) * 2);
+        }
     }
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
     const unsigned dma_base = lds_base + (unsigned)wave * 8192u;                 // this wave's eight pieces of an operand tile
     // the K-tile the next stage brings: (round, K-tile) of the flat sequence and where its pieces start.  Past the end of the sequence the pointers stay on the
     // last K-tile: the loop body stages unconditionally (no branch inside the interleaved stretch), a repeated tile lands in a buffer nobody reads again.
     int st_kt = 0, st_it = 0;
-    const unsigned char *st_a = nullptr, *st_b = nullptr;
+    bool st_second = false;                                                     // (CAT) the K-tile to stage comes from (A2, B2)
+    const unsigned char *st_a = nullptr, *st_b = nullptr, *st_a2 = nullptr, *st_b2 = nullptr;
     auto stage_first = [&]() {                                                  // start of round st_it's tile
         int tm, tn;
         tile_rc(G, tile_of_round(w, st_it, nwg), tm, tn);
-        st_a = reinterpret_cast<const unsigned char *>(G.A + ((long long)tm * 256 + wave * 64) * G.lda);
-        st_b = reinterpret_cast<const unsigned char *>(G.B + (EPI == 0 ? (long long)tn * 256 + wave * 64 : (long long)tn * 128 + wave * 32) * G.ldb);
+        const long long ra = (long long)tm * 256 + wave * 64, rb = EPI == 0 ? (long long)tn * 256 + wave * 64 : (long long)tn * 128 + wave * 32;
+        st_a = reinterpret_cast<const unsigned char *>(G.A + ra * G.lda);
+        st_b = reinterpret_cast<const unsigned char *>(G.B + rb * G.ldb);
+        if constexpr (CAT) {
+            st_a2 = reinterpret_cast<const unsigned char *>(G.A2 + ra * G.lda2);
+            st_b2 = reinterpret_cast<const unsigned char *>(G.B2 + rb * G.ldb2);
+            st_second = false;
+        }
     };
     auto stage_advance = [&]() {
         if (++st_kt == KT) {
             st_kt = 0;
             if (++st_it < my_tiles) stage_first();
+        } else if (CAT && st_kt == KT1) {
+            st_a = st_a2; st_b = st_b2; st_second = true;
         } else {
             st_a += BK * 2; st_b += BK * 2;
         }
     };
     auto dma_a = [&](unsigned buf_off, int i) {
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dma_base + buf_off + (unsigned)i * 1024u), "v"(voffA[i]), "s"(st_a) : "memory");
+        const unsigned vo = CAT ? (st_second ? voffA2[CAT ? i : 0] : voffA[i]) : voffA[i];
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dma_base + buf_off + (unsigned)i * 1024u), "v"(vo), "s"(st_a) : "memory");
     };
     auto dma_b = [&](unsigned buf_off, int i) {
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dma_base + buf_off + (unsigned)kTileBytes + (unsigned)i * 1024u), "v"(voffB[i]), "s"(st_b) : "memory");
+        const unsigned vo = CAT ? (st_second ? voffB2[CAT ? i : 0] : voffB[i]) : voffB[i];
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dma_base + buf_off + (unsigned)kTileBytes + (unsigned)i * 1024u), "v"(vo), "s"(st_b) : "memory");
     };
 
     // ---- fragments: MFMA 16x16x32 operand = 16 rows x 32 k; lane (lm, lq) reads the 16-byte chunk ks*4 + lq of row (tile row) * 16 + lm.
@@ -314,18 +334,22 @@ bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long l
 
 // epi 0: C [M, N] plain.  epi 1 / 2 (SiLU / tanh-GELU): N = 2 * inter, B = [gate rows; up rows], H [M, inter] = act(gate) * up, C (gate|up) may be null.
 int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream,
-                   int epi, void *h_dev, long long ldh)
+                   int epi, void *h_dev, long long ldh, const void *a2_dev, long long lda2, const void *b2_dev, long long ldb2, int K2)
 {
     W4Args G;
+    G.A2 = (const unsigned short *)a2_dev; G.B2 = (const unsigned short *)b2_dev; G.lda2 = lda2; G.ldb2 = ldb2; G.K2 = K2 > 0 ? K2 : 0;
     G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = (unsigned short *)c_dev;
     G.lda = lda; G.ldb = ldb; G.ldc = ldc; G.M = M; G.N = N; G.K = K; G.tiles_m = M / 256; G.tiles_n = N / 256; G.alpha = alpha; G.group_m = g_w4_group_m;
     G.H = (unsigned short *)h_dev; G.ldh = ldh; G.glu_I = N / 2;
-    void (*kern)(W4Args) = epi == 0 ? gemm_nt_w4_kernel<0> : epi == 1 ? gemm_nt_w4_kernel<1> : gemm_nt_w4_kernel<2>;
-    static bool attr_set[3] = {false, false, false};
+    const int which = epi + (G.K2 ? 3 : 0);
+    void (*const kerns[6])(W4Args) = {gemm_nt_w4_kernel<0, false>, gemm_nt_w4_kernel<1, false>, gemm_nt_w4_kernel<2, false>,
+                                      gemm_nt_w4_kernel<0, true>, gemm_nt_w4_kernel<1, true>, gemm_nt_w4_kernel<2, true>};
+    void (*kern)(W4Args) = kerns[which];
+    static bool attr_set[6] = {false, false, false, false, false, false};
     hipError_t e = hipSuccess;
-    if (!attr_set[epi]) {
+    if (!attr_set[which]) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        attr_set[epi] = (e == hipSuccess);
+        attr_set[which] = (e == hipSuccess);
     }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(kern, dim3((unsigned)g_w4_cus), dim3(256), kLdsBytes, (hipStream_t)stream, G);
@@ -354,5 +378,5 @@ extern "C" int ecgb_gemm_nt_w4_bf16(const void *a_dev, long long lda, const void
         ecgb::set_error("ecgb_gemm_nt_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
         return ECGB_ERR_UNSUPPORTED;
     }
-    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0);
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0);
 }

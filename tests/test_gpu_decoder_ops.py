@@ -663,3 +663,24 @@ def test_gemm_nt_glu_four_wave_kernel_same_bits(ops, gelu):
     assert torch.equal(ops.glu_fwd(gu4, gelu_tanh=gelu), h4)                      # and the unfused kernel on the stored projection
     want = x[:64].float() @ w.float().T
     assert (gu4[:64].float() - want).abs().max().item() <= 2e-2 * want.abs().max().item()
+
+
+def test_gemm_nt_cat_four_wave_kernel_same_bits(ops):
+    """A second operand pair behind the first (the LoRA branch inside the projection's launch) on the four-wave kernel, plain and with the GLU epilogue, at a
+    shape the entry points dispatch there: the eight-wave kernels bit for bit; K2 = 64 and 128."""
+    M, N, K = 8192, 16384, 2048
+    x, w = _bf(M, K, seed=71), _bf(N, K, seed=72) * 0.05
+    for K2 in (64, 128):
+        t, bl = _bf(M, K2, seed=73), _bf(N, K2, seed=74) * 0.1
+        ops.set_gemm_w4(False)
+        try:
+            y8 = ops.gemm_nt(x, w, a2=t, b2=bl)
+            gu8, h8 = ops.gemm_nt_glu(x, w, a2=t, b2=bl)
+        finally:
+            ops.set_gemm_w4(True)
+        assert torch.equal(ops.gemm_nt(x, w, a2=t, b2=bl), y8), K2
+        gu4, h4 = ops.gemm_nt_glu(x, w, a2=t, b2=bl)
+        assert torch.equal(gu4, gu8) and torch.equal(h4, h8), K2
+        want = x[:32].float() @ w.float().T + t[:32].float() @ bl.float().T
+        assert (y8[:32].float() - want).abs().max().item() <= 2e-2 * want.abs().max().item()
+    assert not torch.equal(y8, ops.gemm_nt(x, w))                                 # (the branch is there)
