@@ -1973,7 +1973,7 @@ int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long lon
 namespace { int g_gemm_w4 = 1; }
 extern "C" int ecgb_set_gemm_w4(int on)
 {
-    g_gemm_w4 = on ? 1 : 0;
+    g_gemm_w4 = on < 0 ? 0 : on > 2 ? 2 : on;           // 2: every form the four-wave kernel has, also where the eight-wave one measured faster (tests)
     return ECGB_OK;
 }
 
@@ -2158,8 +2158,10 @@ extern "C" int ecgb_gemm_nt_glu_bf16(const void *a_dev, long long lda, const voi
         ecgb::set_error("ecgb_gemm_nt_glu_bf16: K % 64, inter % 128, 16-byte aligned operands, strides % 8 (outputs % 4) required");
         return ECGB_ERR_UNSUPPORTED;
     }
-    // whole tiles: the four-wave kernel with the same epilogue (the same bits)
-    if (g_gemm_w4 && g_gemm_tile == 0 && (K2 <= 0 || (long long)(inter + 63) * ldb2 * 2 + 128 <= 0xFFFFFFFFll) && (ldh & 7) == 0 && ((uintptr_t)h_dev & 15) == 0 && (!c_dev || ((ldc & 7) == 0 && ((uintptr_t)c_dev & 15) == 0)) &&
+    // whole tiles, no second operand pair: the four-wave kernel with the same epilogue (the same bits).  Measured at [32768, 2048] -> 2 x 8192: 1.853 against 1.863 ms, h only
+    // 1.669 against 1.703 -- the activation is vector work that a wave alone on its SIMD cannot hide (under the profiler its MFMA pipes are 0.57 busy, the plain kernel's
+    // 0.65); with a LoRA pair behind it 1.952 against 1.935, so that form stays on the eight-wave kernel (g_gemm_w4 == 2 sends it to the four-wave one: tests).
+    if (g_gemm_w4 && g_gemm_tile == 0 && (K2 <= 0 || (g_gemm_w4 == 2 && (long long)(inter + 63) * ldb2 * 2 + 128 <= 0xFFFFFFFFll)) && (ldh & 7) == 0 && ((uintptr_t)h_dev & 15) == 0 && (!c_dev || ((ldc & 7) == 0 && ((uintptr_t)c_dev & 15) == 0)) &&
         (long long)(inter + 63) * ldb * 2 + 128 <= 0xFFFFFFFFll && ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, h_dev, ldh, M, 2 * inter, K))
         return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, 2 * inter, K, alpha, stream, gelu_tanh ? 2 : 1, h_dev, ldh, a2_dev, lda2, b2_dev, ldb2, K2);
     GemmArgs G{};

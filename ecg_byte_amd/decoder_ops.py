@@ -36,8 +36,9 @@ def embed_fwd(ids, table, scale=1.0):
 
 
 def set_gemm_w4(on=True):
-    """A/B switch: plain NT products of whole 256x256 tiles on the four-wave kernel (default) or on the eight-wave kernels."""
-    _lib.check(_L().ecgb_set_gemm_w4(1 if on else 0))
+    """A/B switch: plain NT products of whole 256x256 tiles on the four-wave kernel (default) or on the eight-wave kernels; on=2 also sends the forms there
+    that measured faster on eight waves (gate|up + GLU with a LoRA pair)."""
+    _lib.check(_L().ecgb_set_gemm_w4(int(on)))
 
 
 def set_gemm_w4_group_m(g=16):

@@ -280,7 +280,7 @@ int ecgb_attn_decode_split_dyn(const void *q_dev, const void *k_cache_dev, const
  * when the problem also has at least two tiles per CU (batch 1, plain store); the same bits as the eight-wave kernels. */
 int ecgb_gemm_nt_w4_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
                          int M, int N, int K, float alpha, void *stream);
-int ecgb_set_gemm_w4(int on);              /* 1 (default): ecgb_gemm_nt_bf16 sends eligible problems to the four-wave kernel; 0: never (A/B, tests) */
+int ecgb_set_gemm_w4(int on);              /* 1 (default): ecgb_gemm_nt_bf16 / _cat / _glu send eligible problems to the four-wave kernel; 0: never; 2: every form it has (A/B, tests) */
 int ecgb_set_gemm_w4_group_m(int group_m);  /* its tile order: blocks of group_m tile rows (default 16; 0 = row by row) */
 
 /* Greedy token choice of generate() (GenerationMixin._sample, generation/utils.py:3205: `next_tokens = torch.argmax(next_token_scores, dim=-1)`):

@@ -38,3 +38,16 @@ for M, N, K in [(32768, 16384, 2048), (32768, 2048, 8192), (32768, 3072, 2048), 
     ops.set_gemm_w4_group_m(16)
     print(f"M{M} N{N} K{K}: equal {same}  8-wave {min(res['w8']):.3f} ms {fl / min(res['w8']) / 1e9:.0f} TF/s   4-wave {min(res['w4']):.3f} ms {fl / min(res['w4']) / 1e9:.0f} TF/s   "
           f"hipBLASLt {min(res['blas']):.3f} ms {fl / min(res['blas']) / 1e9:.0f} TF/s     tile order (ms): " + "  ".join(f"g{k}: {t:.3f}" for k, t in grp.items()), flush=True)
+
+# the gate|up projection with the GLU epilogue, and with a LoRA pair behind it
+M, I, K = 32768, 8192, 2048
+x = torch.randn(M, K, device="cuda").to(torch.bfloat16); wgu = (torch.randn(2 * I, K, device="cuda") * 0.05).to(torch.bfloat16)
+t = torch.randn(M, 64, device="cuda").to(torch.bfloat16); bl = (torch.randn(2 * I, 64, device="cuda") * 0.05).to(torch.bfloat16)
+for name, kw in (("gate|up + GLU (SiLU)", {}), ("gate|up + GLU + LoRA pair", dict(a2=t, b2=bl)), ("gate|up + GLU (inference: h only)", dict(keep_gu=False))):
+    res = {False: [], True: []}
+    for rnd in range(3):
+        for on in (False, True):
+            ops.set_gemm_w4(on)
+            res[on].append(timed(lambda: ops.gemm_nt_glu(x, wgu, **kw)))
+    ops.set_gemm_w4(True)
+    print(f"{name}: 8-wave {min(res[False]):.3f} ms   4-wave {min(res[True]):.3f} ms", flush=True)

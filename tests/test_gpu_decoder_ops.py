@@ -679,7 +679,11 @@ def test_gemm_nt_cat_four_wave_kernel_same_bits(ops):
         finally:
             ops.set_gemm_w4(True)
         assert torch.equal(ops.gemm_nt(x, w, a2=t, b2=bl), y8), K2
-        gu4, h4 = ops.gemm_nt_glu(x, w, a2=t, b2=bl)
+        ops.set_gemm_w4(2)                                                       # (the GLU form with a pair stays on eight waves by default)
+        try:
+            gu4, h4 = ops.gemm_nt_glu(x, w, a2=t, b2=bl)
+        finally:
+            ops.set_gemm_w4(True)
         assert torch.equal(gu4, gu8) and torch.equal(h4, h8), K2
         want = x[:32].float() @ w.float().T + t[:32].float() @ bl.float().T
         assert (y8[:32].float() - want).abs().max().item() <= 2e-2 * want.abs().max().item()
