@@ -9,7 +9,7 @@ import csv, sys, collections
 seen = collections.OrderedDict()
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    if k.startswith("Cijk") or "gemm" in k.lower():
+    if "Cijk" in k or "gemm" in k.lower():
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         e = seen.setdefault(k, dict(n=0, t=0.0, r=r))
         e["n"] += 1; e["t"] += d
