@@ -97,6 +97,8 @@ def lib():
     L.ecgb_wavelet_denoise_scratch_bytes.restype = sz
     L.ecgb_wavelet_denoise_f64.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, vp, sz, vp]
     L.ecgb_wavelet_denoise_f64.restype = C.c_int
+    L.ecgb_nonfinite_records_f64.argtypes = [vp, C.c_int, sz, vp, vp]
+    L.ecgb_nonfinite_records_f64.restype = C.c_int
     i32 = C.c_int32
     L.ecgb_assemble_hip.argtypes = [vp, sz, vp, sz, vp, sz, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32,
                                     C.c_int, u32, vp, vp, vp, vp, vp, vp]

@@ -31,6 +31,17 @@ def _batch(x):
     return (x[None] if x.dim() == 2 else x).contiguous(), x.dim() == 2
 
 
+def nonfinite_records(x, records=None):
+    """uint8 [records]: 1 where a record of the float64 batch x (records consecutive, equal-sized pieces of it; default: its first dimension) holds a NaN or an
+    infinity (ecgb_nonfinite_records_f64: one pass at memory speed, no temporaries)."""
+    assert x.dtype == torch.float64 and x.is_contiguous()
+    R = x.shape[0] if records is None else int(records)
+    flags = torch.zeros(R, dtype=torch.uint8, device=x.device)
+    if x.numel():
+        _lib.check(_L().ecgb_nonfinite_records_f64(C.c_void_p(x.data_ptr()), R, x.numel() // R, C.c_void_p(flags.data_ptr()), _st()))
+    return flags
+
+
 def check_nan_inf(data, step_name):
     """preprocess_utils.py:26-33: NaN / inf -> 0 (with the reference's warning)."""
     if not bool(torch.isfinite(data).all()):
@@ -121,7 +132,8 @@ def condition_records(signals, reorder=True, seg_len=1250, orig_fs=500, target_f
     caller can drop the matching text entries."""
     if signals.dim() != 3:
         raise ValueError("condition_records takes a batch [records, n, leads]")
-    kept = torch.isfinite(signals).all(dim=2).all(dim=1)
+    signals = signals.contiguous()
+    kept = nonfinite_records(signals) == 0
     n_bad = int((~kept).sum().item())
     if n_bad:
         print(f"Warning: NaN values detected in {n_bad} record(s). Skipping these instances.")
@@ -135,10 +147,10 @@ def condition_records(signals, reorder=True, seg_len=1250, orig_fs=500, target_f
     # every stage as the reference has it.  The lead permutation commutes with every per-lead stage: it is applied last, to the resampled half-size data.
     x = signals
     flags = []
-    x = advanced_ecg_filter(x, fs=orig_fs); flags.append(torch.isfinite(x).all())
-    x = wavelet_denoise(x); flags.append(torch.isfinite(x).all())
-    x = nsample_ecg(x, orig_fs, target_fs); flags.append(torch.isfinite(x).all())
-    if bool(torch.stack(flags).all()):
+    x = advanced_ecg_filter(x, fs=orig_fs); flags.append(nonfinite_records(x, 1))
+    x = wavelet_denoise(x); flags.append(nonfinite_records(x, 1))
+    x = nsample_ecg(x, orig_fs, target_fs); flags.append(nonfinite_records(x, 1))
+    if not bool(torch.cat(flags).any()):
         if reorder:
             x = reorder_indices(x).contiguous()
         seg, _ = segment_ecg(x, None, seg_len)

@@ -211,6 +211,10 @@ size_t ecgb_wavelet_denoise_scratch_bytes(int records, int n, int leads);
 int ecgb_wavelet_denoise_f64(const double *x_dev, double *y_dev, int records, int n, int leads, double epsilon, double *scratch_dev,
                              size_t scratch_bytes, void *stream);
 
+/* ecg_byte/utils/preprocess_utils.py:26-33 check_nan_inf's test `np.isfinite(data).all()` and process_instance's test of the raw record (134-136), for a batch:
+ * flags_dev[r] = 1 if record r (per_record consecutive doubles) holds a NaN or an infinity; flags_dev must be zero on entry.  One pass at memory speed. */
+int ecgb_nonfinite_records_f64(const double *x_dev, int records, size_t per_record, unsigned char *flags_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

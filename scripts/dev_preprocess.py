@@ -29,3 +29,11 @@ print(f"{R} records of 5000 x 12 float64 ({x.nbytes / 1e9:.2f} GB): filter chain
 t = time.perf_counter(); f = P.advanced_ecg_filter(x[0]); t1 = time.perf_counter() - t
 t = time.perf_counter(); P.nsample_ecg(f, 500, 250); t2 = time.perf_counter() - t
 print(f"CPU (scipy, 1 core, one record): filter chain {t1 * 1e3:.1f} ms, resample {t2 * 1e3:.1f} ms  -> {1 / (t1 + t2):.0f} records/s without the wavelet stage")
+
+# the glue of condition_records, piece by piece
+tk, _ = timed(lambda: torch.isfinite(xd).all(dim=2).all(dim=1).sum().item())
+t1f, _ = timed(lambda: torch.isfinite(yf).all())
+t1r, _ = timed(lambda: torch.isfinite(yr).all())
+tro, _ = timed(lambda: pp.reorder_indices(yr).contiguous())
+print(f"glue: raw-record finite test {tk * 1e3:.2f} ms, finite test of a stage's output {t1f * 1e3:.2f} ms (full size) / {t1r * 1e3:.2f} ms (resampled), lead reorder {tro * 1e3:.2f} ms; "
+      f"stages {1e3 * (tf + tw + tr):.1f} ms + glue {1e3 * (tk + 2 * t1f + t1r + tro):.1f} ms against {tall * 1e3:.1f} ms measured")

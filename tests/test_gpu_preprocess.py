@@ -138,3 +138,19 @@ def test_segment_reorder_nan(pp):
     assert np.array_equal(pp.reorder_indices(x).cpu().numpy(), P.reorder_indices(x.cpu().numpy()))
     bad = x.clone(); bad[3, 2] = float("nan"); bad[4, 1] = float("inf")
     assert np.array_equal(pp.check_nan_inf(bad, "t").cpu().numpy(), P.check_nan_inf(bad.cpu().numpy()))
+
+
+def test_nonfinite_records_is_isfinite_all():
+    """ecgb_nonfinite_records_f64 (the finite tests of condition_records in one pass each) = ~torch.isfinite(x).all() per record: NaN of either sign, both infinities,
+    denormals and huge finite values, at the ends of a record and of a chunk; one flag for a whole tensor."""
+    from ecg_byte_amd import preprocess_utils as pp
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn(37, 5000, 12, device="cuda", dtype=torch.float64, generator=g)
+    x[3, 0, 0] = float("nan"); x[5, 4999, 11] = float("inf"); x[9, 2500, 7] = float("-inf"); x[11, 683, 3] = -float("nan")
+    x[20, 1, 1] = 1.7e308; x[21, 2, 2] = 5e-324; x[22, 8191 // 12, 8191 % 12] = float("inf")
+    want = ~torch.isfinite(x).reshape(37, -1).all(dim=1)
+    assert torch.equal(pp.nonfinite_records(x) != 0, want)
+    assert int(pp.nonfinite_records(x, 1)) == 1 and int(pp.nonfinite_records(x[12:20].contiguous(), 1)) == 0
+    y = torch.randn(3, 7, device="cuda", dtype=torch.float64)                    # records shorter than a wave
+    y[2, 6] = float("nan")
+    assert pp.nonfinite_records(y).tolist() == [0, 0, 1]
