@@ -245,13 +245,24 @@ __device__ __forceinline__ uint32_t halo_at(const Halo &h, int64_t i, uint64_t n
     return d < 3 ? h.next[d] : kEmpty;
 }
 
-__device__ __forceinline__ void load_span(Span &s, const uint32_t *src, uint64_t i0, uint64_t n, const Halo &h)
+// A lane's span out of LDS.  A lane's 19 ids lie 64 bytes apart from its neighbour's: read straight from memory, every one of the 19 loads of a wave touches 64
+// separate 64-byte segments (tile_count 40 us and rewrite 64 us per merge whatever the length: 1 TB/s).  So the workgroup brings the tile -- 4096 ids and the three
+// around it -- with consecutive lanes on consecutive words, parks it in LDS with one pad word per 16 (lane t's ids start at word 17 t: the lanes' reads hit 64
+// different banks), and every lane picks its span from there.  stage_tile ends with a barrier; callers put one before the next stage_tile (or re-use of s_ids).
+constexpr uint32_t kStageWords = kTile + 3 + (kTile + 3) / 16 + 1;
+__device__ __forceinline__ void stage_tile(uint32_t *s_ids, const uint32_t *src, uint64_t base, uint64_t n, const Halo &h)
 {
-#pragma unroll
-    for (int k = 0; k < kPerThread + 3; ++k) {
-        const int64_t i = (int64_t)i0 + k - 1;
-        s.a[k] = (i >= 0 && i < (int64_t)n) ? src[i] : halo_at(h, i, n);   // kEmpty never equals a real id
+    for (uint32_t j = threadIdx.x; j < kTile + 3; j += kThreads) {
+        const int64_t i = (int64_t)base + j - 1;
+        s_ids[j + (j >> 4)] = (i >= 0 && i < (int64_t)n) ? src[i] : halo_at(h, i, n);
     }
+    __syncthreads();
+}
+__device__ __forceinline__ void span_from_lds(Span &s, const uint32_t *s_ids)
+{
+    const uint32_t t17 = threadIdx.x * 17u;
+#pragma unroll
+    for (int k = 0; k < kPerThread + 3; ++k) s.a[k] = s_ids[t17 + k + (k >> 4)];
 }
 
 // number of trailing `l` ids of the span (0..16)
@@ -328,6 +339,7 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
     __shared__ uint32_t s_first[kThreads / 64];
     __shared__ uint32_t s_last[kThreads / 64];
     __shared__ uint32_t s_lead_extra;
+    __shared__ uint32_t s_ids[kStageWords];
     const TrainState st = *A.st;
     if (!st.active) return;
     const uint32_t *src = A.buf[src_sel];
@@ -336,9 +348,9 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
     const bool same = (l == r);
     const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint64_t i0 = (uint64_t)t * kTile + threadIdx.x * kPerThread;
         Span s;
-        load_span(s, src, i0, n, Halo{kEmpty, {kEmpty, kEmpty, kEmpty}, 0, {0, 0, 0}});   // as if the shard stood alone: tile_scan adds what the neighbours change
+        stage_tile(s_ids, src, (uint64_t)t * kTile, n, Halo{kEmpty, {kEmpty, kEmpty, kEmpty}, 0, {0, 0, 0}});   // as if the shard stood alone: tile_scan adds what the neighbours change
+        span_from_lds(s, s_ids);
         uint32_t dropped = 0, tail = 0;
         if (!same) {
 #pragma unroll
@@ -456,6 +468,7 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
     __shared__ int s_val[kHashSlots];
     __shared__ uint32_t s_wave[kThreads / 64];
     __shared__ uint32_t s_wsum[kThreads / 64];
+    __shared__ uint32_t s_ids[kStageWords];               // the tile on its way in (stage_tile), then its survivors on their way out
     const TrainState st = *A.st;
     if (!st.active) return;
     for (uint32_t i = threadIdx.x; i < kHashSlots; i += kThreads) { s_key[i] = kEmpty; s_val[i] = 0; }
@@ -473,7 +486,8 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
         const uint32_t tile_par = (uint32_t)(off_word >> 63);
         const uint64_t tile_off = off_word & 0x7FFFFFFFFFFFFFFFull;
         Span s;
-        load_span(s, src, i0, n, halo);
+        stage_tile(s_ids, src, (uint64_t)t * kTile, n, halo);
+        span_from_lds(s, s_ids);
         uint32_t lead_par = 0;
         if (l == r) lead_par = thread_lead_parity(trailing_l(s, l), tile_par, s_wave);
         uint32_t site_mask, second_mask, sa;
@@ -495,10 +509,10 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
         const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
         if (lane == 63) s_wsum[wv] = incl;
-        __syncthreads();
-        uint64_t w_off = tile_off;
-        for (uint32_t w = 0; w < wv; ++w) w_off += s_wsum[w];
-        uint64_t o = w_off + incl - kept;
+        __syncthreads();                                     // (every lane has its span in registers: s_ids is free for the survivors)
+        uint32_t w_off = 0, tile_kept = 0;
+        for (uint32_t w = 0; w < kThreads / 64; ++w) { if (w < wv) w_off += s_wsum[w]; tile_kept += s_wsum[w]; }
+        uint32_t o = w_off + incl - kept;                    // inside the tile's output; it leaves LDS in one coalesced copy below
         // walk the span: write survivors, emit count deltas
 #pragma unroll
         for (int k = 1; k <= kPerThread; ++k) {
@@ -512,7 +526,7 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
                 delta_add_s(s_key, s_val, A.table, A.slab, SK, s.a[k] * V + s.a[k + 1], -1);
             if (!is_second) {
                 const uint32_t val = is_site ? X : s.a[k];
-                dst[o++] = val;
+                s_ids[o++] = val;
                 // new pair (val, next kept value) counts iff this or the next kept element is a merged id
                 const int kn = is_site ? k + 2 : k + 1;             // next kept element
                 const uint32_t an = (kn <= kPerThread + 2) ? s.a[kn] : kEmpty;
@@ -531,7 +545,9 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
                 }
             }
         }
-        delta_flush(s_key, s_val, A.table, A.slab, SK);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < tile_kept; i += kThreads) dst[tile_off + i] = s_ids[i];
+        delta_flush(s_key, s_val, A.table, A.slab, SK);      // (its barriers also fence s_ids before the next tile is staged)
     }
 }
 
