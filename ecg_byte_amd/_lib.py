@@ -162,6 +162,7 @@ def lib():
         "ecgb_lora_dx_glu": [vp, vp, vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, ci, vp],
         "ecgb_attn_fwd": [vp, ll, vp, ll, vp, ll, vp, vp, ll, vp, ci, ci, ci, ci, ci, f32, vp],
         "ecgb_attn_bwd": [vp, ll, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp, vp, ll, vp, ll, vp, ll, ci, ci, ci, ci, ci, f32, vp, sz, vp],
+        "ecgb_attn_bwd_rope": [vp, ll, vp, ll, vp, ll, vp, vp, vp, ll, vp, vp, vp, ll, vp, ll, vp, ll, vp, vp, ci, ci, ci, ci, ci, f32, vp, sz, vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)

@@ -62,6 +62,7 @@ struct AttnArgs {
     float *slab;
     int head_splits;
     int lean_hw_log2;                     // lean forward / dQ kernels: log2 of the query heads of a KV group that share a workgroup's K / V tiles
+    const float *rope_cos, *rope_sin;     // lean backward kernels, optional ([B * S, 32] fp32): dQ and dK leave with RoPE's inverse rotation applied (store_accT_rope_inv)
 };
 
 #ifdef ECGB_PROFILE
@@ -318,6 +319,46 @@ __device__ __forceinline__ void store_accT(const f32x16 (&acc)[NB], unsigned sho
             v[1] = pack_bf16(acc[db][gq * 4 + 2] * mul, acc[db][gq * 4 + 3] * mul);
             *reinterpret_cast<u2 *>(g + row * ld + db * 32 + gq * 8 + 4 * h) = v;
         }
+}
+
+// store_accT<2> with RoPE's backward folded in (head_dim 64: the gradient with respect to the UNROTATED q / k).  The separate pass (ecgb_rope inverse, in place on d_qkv)
+// reads the bf16 gradient back, rotates in fp32 with cos / sin rounded to bf16 and rounds once more: exactly that happens here on the packed values before they
+// leave -- the same bits, one read and one write of the q|k gradient less (1.0 ms of a C3 step).  After the group swap a lane holds columns 16 k + 8 h + j of both
+// 32-column halves: the pairs (d, d + 32) a rotation mixes are in one lane.  cs / sn: this row's 32 cosines / sines.
+__device__ __forceinline__ void store_accT_rope_inv(const f32x16 (&acc)[2], unsigned short *g, long long ld, long long row, bool valid, int h, float mul,
+                                                    const float *cs, const float *sn)
+{
+    if (!valid) return;
+    using u4 = __attribute__((ext_vector_type(4))) unsigned;
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    auto lo_f = [](unsigned x) { return __uint_as_float(x << 16); };
+    auto hi_f = [](unsigned x) { return __uint_as_float(x & 0xFFFF0000u); };
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        u4 v[2];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            unsigned a0 = pack_bf16(acc[db][8 * k + 0] * mul, acc[db][8 * k + 1] * mul), a1 = pack_bf16(acc[db][8 * k + 2] * mul, acc[db][8 * k + 3] * mul);
+            unsigned b0 = pack_bf16(acc[db][8 * k + 4] * mul, acc[db][8 * k + 5] * mul), b1 = pack_bf16(acc[db][8 * k + 6] * mul, acc[db][8 * k + 7] * mul);
+            const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            v[db][0] = r0[0]; v[db][1] = r1[0]; v[db][2] = r0[1]; v[db][3] = r1[1];
+        }
+        const f4 c0 = *reinterpret_cast<const f4 *>(cs + 16 * k + 8 * h), c1 = *reinterpret_cast<const f4 *>(cs + 16 * k + 8 * h + 4);
+        const f4 s0 = *reinterpret_cast<const f4 *>(sn + 16 * k + 8 * h), s1 = *reinterpret_cast<const f4 *>(sn + 16 * k + 8 * h + 4);
+        u4 o1, o2;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float ca = w < 2 ? c0[2 * w] : c1[2 * w - 4], cb = w < 2 ? c0[2 * w + 1] : c1[2 * w - 3];
+            const float sa = w < 2 ? s0[2 * w] : s1[2 * w - 4], sb = w < 2 ? s0[2 * w + 1] : s1[2 * w - 3];
+            const unsigned cc = pack_bf16(ca, cb), ss = pack_bf16(sa, sb);          // HF holds cos / sin in the activation dtype
+            const float x1a = lo_f(v[0][w]), x1b = hi_f(v[0][w]), x2a = lo_f(v[1][w]), x2b = hi_f(v[1][w]);
+            o1[w] = pack_bf16(x1a * lo_f(cc) + x2a * lo_f(ss), x1b * hi_f(cc) + x2b * hi_f(ss));
+            o2[w] = pack_bf16(x2a * lo_f(cc) - x1a * lo_f(ss), x2b * hi_f(cc) - x1b * hi_f(ss));
+        }
+        *reinterpret_cast<u4 *>(g + row * ld + 16 * k + 8 * h) = o1;
+        *reinterpret_cast<u4 *>(g + row * ld + 32 + 16 * k + 8 * h) = o2;
+    }
 }
 
 // the same into a contiguous fp32 [row][D] slab
@@ -1447,7 +1488,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_lean_kernel(AttnArgs A
         lean_wait_tiles<2 * PPW * (kAhead - 1)>();
         __builtin_amdgcn_s_barrier();
     }
-    store_accT<2>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, -A.scale);
+    if (A.rope_cos) store_accT_rope_inv(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, -A.scale, A.rope_cos + (rowbase + qi) * 32, A.rope_sin + (rowbase + qi) * 32);
+    else store_accT<2>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, -A.scale);
 }
 
 // dK / dV, lean form: lanes = keys.  Register operands: -K * scale * log2 e and -V; initial accumulators: the tile's lse / delta rows as they lie in LDS
@@ -1596,7 +1638,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_lean_kernel(AttnArgs 
         lean_wait_tiles<(2 * PPW + 1) * (kAhead - 1)>();
         __builtin_amdgcn_s_barrier();
     }
-    store_accT<2>(accK, A.dk + (long long)g * D, A.lddk, rowbase + ki, kvalid, h, -A.scale);
+    if (A.rope_cos) store_accT_rope_inv(accK, A.dk + (long long)g * D, A.lddk, rowbase + ki, kvalid, h, -A.scale, A.rope_cos + (rowbase + ki) * 32, A.rope_sin + (rowbase + ki) * 32);
+    else store_accT<2>(accK, A.dk + (long long)g * D, A.lddk, rowbase + ki, kvalid, h, -A.scale);
     store_accT<2>(accV, A.dv + (long long)g * D, A.lddv, rowbase + ki, kvalid, h, 1.f);
 }
 
@@ -2019,13 +2062,15 @@ extern "C" size_t ecgb_attn_bwd_scratch_bytes(int batch, int seq, int n_q_heads,
     return hs > 1 ? (size_t)2 * hs * batch * seq * n_kv_heads * head_dim * sizeof(float) : 0;
 }
 
-extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev, long long ldk, const void *v_dev, long long ldv,
-                             const float *attn_mask_dev, const void *o_dev, const void *do_dev, long long ldo,
-                             const float *lse_dev, float *delta_dev, void *dq_dev, long long lddq, void *dk_dev, long long lddk,
-                             void *dv_dev, long long lddv, int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim,
-                             float scale, void *scratch_dev, size_t scratch_bytes, void *stream)
+namespace {
+int attn_bwd_impl(const void *q_dev, long long ldq, const void *k_dev, long long ldk, const void *v_dev, long long ldv,
+                  const float *attn_mask_dev, const void *o_dev, const void *do_dev, long long ldo,
+                  const float *lse_dev, float *delta_dev, void *dq_dev, long long lddq, void *dk_dev, long long lddk,
+                  void *dv_dev, long long lddv, int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim,
+                  float scale, void *scratch_dev, size_t scratch_bytes, void *stream, const float *rope_cos, const float *rope_sin)
 {
     AttnArgs A = {};
+    A.rope_cos = rope_cos; A.rope_sin = rope_sin;
     A.q = (const unsigned short *)q_dev; A.k = (const unsigned short *)k_dev; A.v = (const unsigned short *)v_dev;
     A.ldq = ldq; A.ldk = ldk; A.ldv = ldv; A.mask = attn_mask_dev; A.o = (unsigned short *)const_cast<void *>(o_dev); A.ldo = ldo;
     A.lse = const_cast<float *>(lse_dev); A.d_o = (const unsigned short *)do_dev; A.delta = delta_dev;
@@ -2088,6 +2133,35 @@ extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev
 #undef ECGB_BWD
 #undef ECGB_DKV
     return launched("attn_bwd kernels");
+}
+}  // namespace
+
+extern "C" int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev, long long ldk, const void *v_dev, long long ldv,
+                             const float *attn_mask_dev, const void *o_dev, const void *do_dev, long long ldo,
+                             const float *lse_dev, float *delta_dev, void *dq_dev, long long lddq, void *dk_dev, long long lddk,
+                             void *dv_dev, long long lddv, int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim,
+                             float scale, void *scratch_dev, size_t scratch_bytes, void *stream)
+{
+    return attn_bwd_impl(q_dev, ldq, k_dev, ldk, v_dev, ldv, attn_mask_dev, o_dev, do_dev, ldo, lse_dev, delta_dev, dq_dev, lddq, dk_dev, lddk, dv_dev, lddv,
+                         batch, seq, n_q_heads, n_kv_heads, head_dim, scale, scratch_dev, scratch_bytes, stream, nullptr, nullptr);
+}
+
+// ecgb_attn_bwd followed by RoPE's backward on dQ and dK (ecgb_rope, inverse), in the attention kernels' own stores: q and k are the ROTATED projections the forward
+// saw, dq / dk come out as gradients of the unrotated ones.  rope_cos_dev / rope_sin_dev: [batch * seq, 32] fp32, the tables ecgb_rope takes.  head_dim 64 on the
+// lean kernels with 16-byte aligned dq / dk rows only: ECGB_ERR_UNSUPPORTED otherwise, and the caller runs the two steps apart (the same bits either way).
+extern "C" int ecgb_attn_bwd_rope(const void *q_dev, long long ldq, const void *k_dev, long long ldk, const void *v_dev, long long ldv,
+                                  const float *attn_mask_dev, const void *o_dev, const void *do_dev, long long ldo,
+                                  const float *lse_dev, float *delta_dev, void *dq_dev, long long lddq, void *dk_dev, long long lddk,
+                                  void *dv_dev, long long lddv, const float *rope_cos_dev, const float *rope_sin_dev, int batch, int seq, int n_q_heads,
+                                  int n_kv_heads, int head_dim, float scale, void *scratch_dev, size_t scratch_bytes, void *stream)
+{
+    if (!rope_cos_dev || !rope_sin_dev) { ecgb::set_error("ecgb_attn_bwd_rope: NULL table"); return ECGB_ERR_INVALID; }
+    if (head_dim != 64 || (g_attn_dma & 0x703) != 2 || (lddq & 7) || (lddk & 7) || (((uintptr_t)dq_dev | (uintptr_t)dk_dev | (uintptr_t)rope_cos_dev | (uintptr_t)rope_sin_dev) & 15)) {
+        ecgb::set_error("ecgb_attn_bwd_rope: head_dim 64 on the lean kernels with 16-byte aligned gradient rows only");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    return attn_bwd_impl(q_dev, ldq, k_dev, ldk, v_dev, ldv, attn_mask_dev, o_dev, do_dev, ldo, lse_dev, delta_dev, dq_dev, lddq, dk_dev, lddk, dv_dev, lddv,
+                         batch, seq, n_q_heads, n_kv_heads, head_dim, scale, scratch_dev, scratch_bytes, stream, rope_cos_dev, rope_sin_dev);
 }
 
 namespace {

@@ -1181,11 +1181,11 @@ class HipCausalLM(nn.Module):
                 self.lora[i]["o"].backward(g2, ls[1], self, d_ao)
             # attention core
             if self.fused_attention:
-                d_qkv = ops.attn_bwd(qkv, mask, ao, d_ao, P, B, S, Hq, Hkv, D, scale)
+                d_qkv = ops.attn_bwd(qkv, mask, ao, d_ao, P, B, S, Hq, Hkv, D, scale, rope=(cos, sin))   # RoPE's backward inside (head_dim 64) or behind it
             else:
                 d_qkv = self._attn_materialised_bwd(qkv, d_ao, P, B, S)
+                ops.rope_(d_qkv, cos, sin, Hq + Hkv, D, QKV, inverse=True)
             del P
-            ops.rope_(d_qkv, cos, sin, Hq + Hkv, D, QKV, inverse=True)
             wgrad(d_qkv, h1, self.wqkv[i])
             bottom = frozen and i == 0                             # frozen embeddings below: nobody needs the gradient of the first layer's input
             d_h1 = None if bottom else self._dx(d_qkv, ("wqkv", i), self.wqkv[i])      # [T, H]   (autograd would not compute it either)

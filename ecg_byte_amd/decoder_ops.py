@@ -552,16 +552,38 @@ def set_attn_fwd_staging(mode: int = 2):
     _lib.check(_L().ecgb_set_attn_fwd_staging(int(mode)))
 
 
-def attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale):
-    """Returns d_qkv with the same fused layout as qkv."""
+_fuse_rope_bwd = True
+
+
+def set_attn_bwd_rope_fusion(on=True):
+    """A/B switch: RoPE's backward inside the attention backward kernels' stores (default, where they can: ecgb_attn_bwd_rope) or as its own pass."""
+    global _fuse_rope_bwd
+    _fuse_rope_bwd = bool(on)
+
+
+def attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale, rope=None):
+    """Returns d_qkv with the same fused layout as qkv.  rope = (cos, sin) [B * S, D / 2] fp32: qkv holds the ROTATED q and k and d_qkv comes back as the
+    gradient of the unrotated projection -- RoPE's backward in the attention kernels' own stores where they can (ecgb_attn_bwd_rope: head_dim 64, lean kernels),
+    otherwise as the separate pass it replaces (ecgb_rope, inverse); the same bits either way."""
     QKV = qkv.shape[1]
     d_qkv = torch.empty_like(qkv)
     delta = torch.empty((B, Hq, S), dtype=torch.float32, device=qkv.device)
     nbytes = _L().ecgb_attn_bwd_scratch_bytes(B, S, Hq, Hkv, D)          # partial dK / dV slabs (head_dim 256 with few key blocks), else 0
     scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device) if nbytes else None
+    if rope is not None and _fuse_rope_bwd and D == 64:
+        cos, sin = rope
+        rc = _L().ecgb_attn_bwd_rope(_off(qkv, 0), QKV, _off(qkv, Hq * D), QKV, _off(qkv, Hq * D + Hkv * D), QKV, _p(mask),
+                                     _p(o), _p(_bf(do)), Hq * D, _p(lse), _p(delta), _off(d_qkv, 0), QKV, _off(d_qkv, Hq * D), QKV,
+                                     _off(d_qkv, Hq * D + Hkv * D), QKV, _p(cos), _p(sin), B, S, Hq, Hkv, D, float(scale), _p(scratch), nbytes, _st())
+        if rc == 0:
+            return d_qkv
+        if rc != -3:                                                     # ECGB_ERR_UNSUPPORTED: the two steps apart, below
+            _lib.check(rc)
     _lib.check(_L().ecgb_attn_bwd(_off(qkv, 0), QKV, _off(qkv, Hq * D), QKV, _off(qkv, Hq * D + Hkv * D), QKV, _p(mask),
                                   _p(o), _p(_bf(do)), Hq * D, _p(lse), _p(delta), _off(d_qkv, 0), QKV, _off(d_qkv, Hq * D), QKV,
                                   _off(d_qkv, Hq * D + Hkv * D), QKV, B, S, Hq, Hkv, D, float(scale), _p(scratch), nbytes, _st()))
+    if rope is not None:
+        rope_(d_qkv, rope[0], rope[1], Hq + Hkv, D, QKV, inverse=True)
     return d_qkv
 
 

@@ -241,6 +241,15 @@ int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev, long long
                   const float *attn_mask_dev, const void *o_dev, const void *do_dev, long long ldo, const float *lse_dev,
                   float *delta_dev, void *dq_dev, long long lddq, void *dk_dev, long long lddk, void *dv_dev,
                   long long lddv, int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim, float scale, void *scratch_dev, size_t scratch_bytes, void *stream);
+/* ecgb_attn_bwd followed by RoPE's backward on dQ and dK (ecgb_rope with inverse != 0: modeling_llama.py:151-176 apply_rotary_pos_emb, transposed), inside the
+ * attention kernels' own stores: q and k are the ROTATED projections the forward saw, dq / dk come out as gradients of the unrotated ones -- the same bits as the two
+ * calls, one read and one write of the q|k gradient less.  rope_cos_dev / rope_sin_dev: [batch * seq, 32] fp32, the tables ecgb_rope takes.  head_dim 64 on the lean
+ * kernels with 16-byte aligned dq / dk rows only: ECGB_ERR_UNSUPPORTED otherwise (the caller then runs the two steps apart). */
+int ecgb_attn_bwd_rope(const void *q_dev, long long ldq, const void *k_dev, long long ldk, const void *v_dev, long long ldv,
+                       const float *attn_mask_dev, const void *o_dev, const void *do_dev, long long ldo,
+                       const float *lse_dev, float *delta_dev, void *dq_dev, long long lddq, void *dk_dev, long long lddk,
+                       void *dv_dev, long long lddv, const float *rope_cos_dev, const float *rope_sin_dev, int batch, int seq, int n_q_heads,
+                       int n_kv_heads, int head_dim, float scale, void *scratch_dev, size_t scratch_bytes, void *stream);
 
 /* One decode step of generate(): q [batch, n_q_heads*head_dim] against a KV cache whose rows (one per position) are
  * `ld` elements apart, `capacity` rows per batch entry, KV head g at + g*head_dim; the first kv_len rows are valid

@@ -402,3 +402,38 @@ def test_overlapped_optimizer_step_is_the_plain_step_bit_for_bit(lora):
     assert torch.equal(l0, l1), (l0, l1)
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k
+
+
+@pytest.mark.parametrize("B,S,Hq,Hkv,pads", [(4, 1024, 32, 8, True), (3, 1000, 8, 2, True), (5, 70, 4, 4, False), (2, 2048, 4, 1, True)], ids=["c3-pads", "ragged", "short", "long"])
+def test_rope_backward_inside_the_attention_backward_is_the_separate_pass_bit_for_bit(B, S, Hq, Hkv, pads):
+    """ecgb_attn_bwd_rope (RoPE's backward applied by the lean dQ / dK-dV kernels as they store) = ecgb_attn_bwd followed by ecgb_rope(inverse) on d_qkv: the same
+    bits, v untouched by the rotation; where the fused entry does not apply (kernels other than the lean ones) attn_bwd falls back to the two steps by itself."""
+    from ecg_byte_amd import decoder_ops as ops
+    D, scale = 64, 0.125
+    qkv, do = _bf(B * S, (Hq + 2 * Hkv) * D, seed=81), _bf(B * S, Hq * D, seed=82)
+    mask = torch.ones(B, S, device="cuda")
+    if pads:
+        for b in range(B):
+            mask[b, : (29 * b + 3) % (S // 2)] = 0
+    pos = (mask.long().cumsum(-1) - 1).clamp_min(0).view(-1).float()
+    inv_freq = 1.0 / (500000.0 ** (torch.arange(0, D, 2, device="cuda").float() / D))
+    fr = pos[:, None] * inv_freq[None, :]
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    o, lse = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)
+    ops.set_attn_bwd_rope_fusion(False)
+    try:
+        apart = ops.attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale, rope=(cos, sin))
+        plain = ops.attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale)
+    finally:
+        ops.set_attn_bwd_rope_fusion(True)
+    fused = ops.attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale, rope=(cos, sin))
+    assert torch.equal(fused, apart)
+    assert torch.equal(fused[:, (Hq + Hkv) * D:], plain[:, (Hq + Hkv) * D:]) and not torch.equal(fused[:, : Hq * D], plain[:, : Hq * D])
+    ops.set_attn_fwd_staging(1)                                                   # the round-2 kernels: no fused form, the same result through the fallback
+    try:
+        o1, l1 = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)
+        a = ops.attn_bwd(qkv, mask, o1, do, l1, B, S, Hq, Hkv, D, scale, rope=(cos, sin))
+        b = ops.rope_(ops.attn_bwd(qkv, mask, o1, do, l1, B, S, Hq, Hkv, D, scale), cos, sin, Hq + Hkv, D, qkv.shape[1], inverse=True)
+        assert torch.equal(a, b)
+    finally:
+        ops.set_attn_fwd_staging(2)
