@@ -43,6 +43,8 @@ struct W4Args {
     const unsigned short *A2, *B2;   // CAT: a second operand pair contracted behind the first, C = alpha * (A B^T + A2 B2^T) (the LoRA branch: A2 = x A_lora^T, B2 = B_lora)
     long long lda2, ldb2;
     int K2;
+    const float *rope_cos, *rope_sin;   // EPI 3: columns below rope_cols are heads of 64 that leave rotated (RoPE forward), row t with row t of the [M, 32] fp32 tables
+    int rope_cols;
     unsigned short *H;      // GLU epilogue (EPI != 0): act(gate) * up [M, glu_I]; B is [2 * glu_I, K], gate rows then up rows; C (gate|up, [M, 2 * glu_I]) may be null
     long long ldh;
     int glu_I;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < 8; ++i) {
         const int chunk = (lane & 7) ^ (((lane >> 4) + 4 * (i & 1)) & 7);
         // B: tile row r = (wave * 8 + i) * 8 + (lane >> 3); GLU: that is weight row 16 * (r >> 5) + (r & 15) (+ glu_I: an up row)
-        const long long rb = EPI == 0 ? (long long)(i * 8 + (lane >> 3)) : 16 * (i >> 2) + (i & 1) * 8 + (lane >> 3) + ((i >> 1) & 1) * (long long)G.glu_I;
+        const long long rb = (EPI == 0 || EPI == 3) ? (long long)(i * 8 + (lane >> 3)) : 16 * (i >> 2) + (i & 1) * 8 + (lane >> 3) + ((i >> 1) & 1) * (long long)G.glu_I;
         voffA[i] = (unsigned)(((long long)(i * 8 + (lane >> 3)) * G.lda + chunk * 8) * 2);
         voffB[i] = (unsigned)((rb * G.ldb + chunk * 8) * 2);
         if constexpr (CAT) {
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto stage_first = [&]() {                                                  // start of round st_it's tile
         int tm, tn;
         tile_rc(G, tile_of_round(w, st_it, nwg), tm, tn);
-        const long long ra = (long long)tm * 256 + wave * 64, rb = EPI == 0 ? (long long)tn * 256 + wave * 64 : (long long)tn * 128 + wave * 32;
+        const long long ra = (long long)tm * 256 + wave * 64, rb = (EPI == 0 || EPI == 3) ? (long long)tn * 256 + wave * 64 : (long long)tn * 128 + wave * 32;
         st_a = reinterpret_cast<const unsigned char *>(G.A + ra * G.lda);
         st_b = reinterpret_cast<const unsigned char *>(G.B + rb * G.ldb);
         if constexpr (CAT) {
@@ -263,6 +265,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
                 asm volatile("" ::: "memory");
             }
+        } else if constexpr (EPI == 3) {
+            // the q|k|v projection with RoPE's forward in the epilogue (modeling_llama.py:151-176: q_embed = q * cos + rotate_half(q) * sin, in the activation dtype).  Staged as
+            // EPI 0; on the way out a lane takes its own 16-byte chunk and the chunk 32 columns away in the same head of 64, and writes
+            //     bf16(x1 * c - x2 * s)  (first half of the head)   /   bf16(x2 * c + x1 * s)  (second half)
+            // from the bf16-rounded projection with cos / sin rounded to bf16 -- ecgb_rope's arithmetic on the stored tensor, the same bits, without storing and re-reading it.
+            auto lo_f = [](unsigned x) { return __uint_as_float(x << 16); };
+            auto hi_f = [](unsigned x) { return __uint_as_float(x & 0xFFFF0000u); };
+            using f4 = __attribute__((ext_vector_type(4))) float;
+            const int rr = lane >> 4, cc = lane & 15;
+            const long long col = (long long)tn * 256 + wc * 128 + cc * 8;
+            const bool rot = col < G.rope_cols, second = (cc & 4) != 0;
+            unsigned short *cdst = G.C + ((long long)tm * 256 + wr * 128 + rr) * G.ldc + col;
+            const long long trow0 = (long long)tm * 256 + wr * 128 + rr;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    u2 v;
+                    v[0] = pack2(acc[i][j][0] * alpha, acc[i][j][1] * alpha);
+                    v[1] = pack2(acc[i][j][2] * alpha, acc[i][j][3] * alpha);
+                    const int c = j * 2 + (lq >> 1);
+                    *reinterpret_cast<u2 *>(stg + lm * 256 + ((c ^ lm) << 4) + (lq & 1) * 8) = v;
+                    acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int r = ps * 4 + rr;
+                    u4 own = *reinterpret_cast<const u4 *>(stg + r * 256 + ((cc ^ r) << 4));
+                    if (rot) {
+                        const u4 oth = *reinterpret_cast<const u4 *>(stg + r * 256 + (((cc ^ 4) ^ r) << 4));
+                        const float *pc = G.rope_cos + (trow0 + i * 16 + ps * 4) * 32 + (cc & 3) * 8, *ps_ = G.rope_sin + (trow0 + i * 16 + ps * 4) * 32 + (cc & 3) * 8;
+                        const f4 c0 = *reinterpret_cast<const f4 *>(pc), c1 = *reinterpret_cast<const f4 *>(pc + 4);
+                        const f4 s0 = *reinterpret_cast<const f4 *>(ps_), s1 = *reinterpret_cast<const f4 *>(ps_ + 4);
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const unsigned cw = pack2(x < 2 ? c0[2 * x] : c1[2 * x - 4], x < 2 ? c0[2 * x + 1] : c1[2 * x - 3]);
+                            const unsigned sw = pack2(x < 2 ? s0[2 * x] : s1[2 * x - 4], x < 2 ? s0[2 * x + 1] : s1[2 * x - 3]);
+                            const float pa = lo_f(oth[x]) * lo_f(sw), pb = hi_f(oth[x]) * hi_f(sw);
+                            own[x] = pack2(lo_f(own[x]) * lo_f(cw) + (second ? pa : -pa), hi_f(own[x]) * hi_f(cw) + (second ? pb : -pb));
+                        }
+                    }
+                    *reinterpret_cast<u4 *>(cdst + (long long)(i * 16 + ps * 4) * G.ldc) = own;
+                }
+                asm volatile("" ::: "memory");
+            }
         } else {
             // three arrays of 16 rows x 64 columns (gate, up, act(gate) * up: 2 KiB each), row r at r * 128 bytes, its 16-byte chunk c at c ^ (r & 7); out in whole
             // 128-byte rows, eight rows per store instruction
@@ -334,18 +382,20 @@ bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long l
 
 // epi 0: C [M, N] plain.  epi 1 / 2 (SiLU / tanh-GELU): N = 2 * inter, B = [gate rows; up rows], H [M, inter] = act(gate) * up, C (gate|up) may be null.
 int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream,
-                   int epi, void *h_dev, long long ldh, const void *a2_dev, long long lda2, const void *b2_dev, long long ldb2, int K2)
+                   int epi, void *h_dev, long long ldh, const void *a2_dev, long long lda2, const void *b2_dev, long long ldb2, int K2,
+                   const float *rope_cos, const float *rope_sin, int rope_cols)
 {
     W4Args G;
+    G.rope_cos = rope_cos; G.rope_sin = rope_sin; G.rope_cols = rope_cols;
     G.A2 = (const unsigned short *)a2_dev; G.B2 = (const unsigned short *)b2_dev; G.lda2 = lda2; G.ldb2 = ldb2; G.K2 = K2 > 0 ? K2 : 0;
     G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = (unsigned short *)c_dev;
     G.lda = lda; G.ldb = ldb; G.ldc = ldc; G.M = M; G.N = N; G.K = K; G.tiles_m = M / 256; G.tiles_n = N / 256; G.alpha = alpha; G.group_m = g_w4_group_m;
     G.H = (unsigned short *)h_dev; G.ldh = ldh; G.glu_I = N / 2;
-    const int which = epi + (G.K2 ? 3 : 0);
-    void (*const kerns[6])(W4Args) = {gemm_nt_w4_kernel<0, false>, gemm_nt_w4_kernel<1, false>, gemm_nt_w4_kernel<2, false>,
-                                      gemm_nt_w4_kernel<0, true>, gemm_nt_w4_kernel<1, true>, gemm_nt_w4_kernel<2, true>};
+    const int which = epi + (G.K2 ? 4 : 0);
+    void (*const kerns[8])(W4Args) = {gemm_nt_w4_kernel<0, false>, gemm_nt_w4_kernel<1, false>, gemm_nt_w4_kernel<2, false>, gemm_nt_w4_kernel<3, false>,
+                                      gemm_nt_w4_kernel<0, true>, gemm_nt_w4_kernel<1, true>, gemm_nt_w4_kernel<2, true>, gemm_nt_w4_kernel<3, true>};
     void (*kern)(W4Args) = kerns[which];
-    static bool attr_set[6] = {false, false, false, false, false, false};
+    static bool attr_set[8] = {};
     hipError_t e = hipSuccess;
     if (!attr_set[which]) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
@@ -378,5 +428,27 @@ extern "C" int ecgb_gemm_nt_w4_bf16(const void *a_dev, long long lda, const void
         ecgb::set_error("ecgb_gemm_nt_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
         return ECGB_ERR_UNSUPPORTED;
     }
-    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0);
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0);
+}
+
+// The q|k|v projection with RoPE's forward in the epilogue: C = alpha * (A B^T [+ A2 B2^T]), then every head of 64 columns below rope_cols rotated with row t of the
+// [M, 32] fp32 tables (ecgb_rope's arithmetic on the bf16-rounded projection: the same bits as the two calls).  Whole 256x256 tiles and one tile per CU at least;
+// ECGB_ERR_UNSUPPORTED otherwise (the caller runs ecgb_gemm_nt_bf16[_cat] and ecgb_rope).
+extern "C" int ecgb_gemm_nt_bf16_rope(const void *a_dev, long long lda, const void *b_dev, long long ldb, const void *a2_dev, long long lda2,
+                                      const void *b2_dev, long long ldb2, int K2, void *c_dev, long long ldc, int M, int N, int K, float alpha,
+                                      const float *rope_cos_dev, const float *rope_sin_dev, int rope_cols, void *stream)
+{
+    if (!a_dev || !b_dev || !c_dev || !rope_cos_dev || !rope_sin_dev || M <= 0 || N <= 0 || K <= 0 || (K2 > 0 && (!a2_dev || !b2_dev))) {
+        ecgb::set_error("ecgb_gemm_nt_bf16_rope: bad argument");
+        return ECGB_ERR_INVALID;
+    }
+    (void)ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K);          // (device properties)
+    if (M % 256 || N % 256 || K % BK || K2 % BK || rope_cols % 64 || rope_cols < 0 || rope_cols > N || lda % 8 || ldb % 8 || ldc % 8 || (K2 > 0 && (lda2 % 8 || ldb2 % 8)) ||
+        (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)c_dev | (uintptr_t)a2_dev | (uintptr_t)b2_dev | (uintptr_t)rope_cos_dev | (uintptr_t)rope_sin_dev) & 15) ||
+        (long long)63 * lda * 2 + 128 > 0xFFFFFFFFll || (long long)63 * ldb * 2 + 128 > 0xFFFFFFFFll ||
+        (K2 > 0 && ((long long)63 * lda2 * 2 + 128 > 0xFFFFFFFFll || (long long)63 * ldb2 * 2 + 128 > 0xFFFFFFFFll)) || (long long)(M / 256) * (N / 256) < g_w4_cus) {
+        ecgb::set_error("ecgb_gemm_nt_bf16_rope: whole 256x256 tiles (one per CU at least), K % 64, 16-byte aligned operands required");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 3, nullptr, 0, a2_dev, lda2, b2_dev, ldb2, K2 > 0 ? K2 : 0, rope_cos_dev, rope_sin_dev, rope_cols);
 }

@@ -136,7 +136,7 @@ class LoraSite(nn.Module):
         lo = 16 * self.spb * b
         return lo, lo + self.r
 
-    def project(self, x, w, training, keep=False, glu=None):
+    def project(self, x, w, training, keep=False, glu=None, rope=None):
         """y = x W^T + the adapter branch, [T, out].  Returns (y, what backward needs).
         glu = (gelu_tanh, keep_gu): the site is the fused gate|up projection and the GLU runs in the GEMM's epilogue; y is then the pair
         (gate|up or None, act(gate) * up)."""
@@ -153,6 +153,8 @@ class LoraSite(nn.Module):
             t, xd = ops.lora_down(x, self.A.data, self.n_sub, self.n_fields, self.scale, p, seed, keep_masked=keep)
         if glu is not None and ops.glu_fusable(x.shape[0], w.shape[0] // 2):
             y = ops.gemm_nt_glu(x, w, gelu_tanh=glu[0], keep_gu=glu[1], a2=t, b2=self.B.data)
+        elif rope is not None:                              # the q|k|v site: RoPE in the projection's epilogue (or behind it: ops.gemm_nt_rope decides)
+            y = ops.gemm_nt_rope(x, w, rope[0], rope[1], rope[2], a2=t, b2=self.B.data)
         else:
             y = ops.gemm_nt(x, w, a2=t, b2=self.B.data)
             if glu is not None:
@@ -489,12 +491,15 @@ class HipCausalLM(nn.Module):
             return ops.gemm_nn_splitk(dy, p.data, splits)
         return ops.gemm_nt(dy, self._shadow(key, p))
 
-    def _proj(self, i, key, x, w, training=False, keep=False):
+    def _proj(self, i, key, x, w, training=False, keep=False, rope=None):
         """One projection of layer i ("qkv", "o", "gu", "down"): x W^T, plus the LoRA branch of the site when adapters are on
-        (in the same launch).  Returns (y, what the adapter's backward needs or None)."""
+        (in the same launch).  rope = (cos, sin, columns): the q|k|v projection leaves with its q and k heads rotated (apply_rotary_pos_emb in the GEMM's
+        epilogue where the kernel takes the shape, else as the separate pass).  Returns (y, what the adapter's backward needs or None)."""
         if self.lora is None:
+            if rope is not None:
+                return ops.gemm_nt_rope(x, w, rope[0], rope[1], rope[2]), None
             return ops.gemm_nt(x, w), None
-        return self.lora[i][key].project(x, w, training, keep)
+        return self.lora[i][key].project(x, w, training, keep, rope=rope)
 
     def _proj_glu(self, i, x, training=False, keep=False, keep_gu=True):
         """The MLP's gate|up projection with the GLU in the GEMM's epilogue: returns (gate|up [T, 2I] or None, act(gate) * up [T, I],
@@ -691,6 +696,7 @@ class HipCausalLM(nn.Module):
             S += lpad
         T = B * S
         cos, sin = self._rope_tables(position_ids)
+        rope = (cos, sin, (Hq + Hkv) * D)                                 # what the q|k|v projection rotates on its way out
         QKV = self.qkv
         scale = 1.0 / math.sqrt(D)
         saved = []
@@ -701,8 +707,7 @@ class HipCausalLM(nn.Module):
             self._wait_group(i)
             h1, rstd1, x1 = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
             ls = [None] * 4
-            qkv, ls[0] = self._proj(i, "qkv", h1, self.wqkv[i].data, self.training)    # [T, QKV]
-            ops.rope_(qkv, cos, sin, Hq + Hkv, D, QKV)                   # the query heads and the key heads lie side by side: one launch
+            qkv, ls[0] = self._proj(i, "qkv", h1, self.wqkv[i].data, self.training, rope=rope)    # [T, QKV], q and k heads rotated
             if self.fused_attention:
                 ao, P = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale)       # P slot holds the row log-sum-exps
             else:
@@ -827,14 +832,14 @@ class HipCausalLM(nn.Module):
             position_ids = torch.cat([torch.zeros((B, lpad), dtype=position_ids.dtype, device=dev), position_ids], 1)
             S_out, S = S, S + lpad
         cos, sin = self._rope_tables(position_ids)
+        rope = (cos, sin, (Hq + Hkv) * D)                                 # what the q|k|v projection rotates on its way out
         QKV = self.qkv
         scale = 1.0 / math.sqrt(D)
         x = ops.embed_fwd(input_ids.view(-1), self.embed.data, self.embed_scale)
         delta = None
         for i in range(c.num_hidden_layers):
             h1, _, x = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
-            qkv, _ = self._proj(i, "qkv", h1, self.wqkv[i].data)
-            ops.rope_(qkv, cos, sin, Hq + Hkv, D, QKV)                   # the query heads and the key heads lie side by side: one launch
+            qkv, _ = self._proj(i, "qkv", h1, self.wqkv[i].data, rope=rope)
             if kv_out is not None:
                 kv_out[i][:, :S - lpad].copy_(qkv.view(B, S, QKV)[:, lpad:, Hq * D:])
             if self.fused_attention:

@@ -35,6 +35,34 @@ def embed_fwd(ids, table, scale=1.0):
     return out
 
 
+_fuse_rope_fwd = False        # measured at the C3 shape (scripts/dev_rope_fusion.py): 0.382 ms fused against 0.362 ms apart (0.396 / 0.376 with a LoRA pair) -- the
+                              # four-wave kernel is slower than the eight-wave one on this short contraction and its epilogue is exposed: off
+
+
+def set_gemm_rope_fusion(on=True):
+    """A/B switch: RoPE's forward in the q|k|v projection's epilogue (ecgb_gemm_nt_bf16_rope, where it can) or as its own pass (default: faster, see above)."""
+    global _fuse_rope_fwd
+    _fuse_rope_fwd = bool(on)
+
+
+def gemm_nt_rope(a, b, cos, sin, rope_cols, a2=None, b2=None, alpha=1.0):
+    """C = alpha * (A B^T [+ A2 B2^T]) with every head of 64 columns below rope_cols rotated by RoPE (row t with row t of cos / sin [M, 32] fp32): the q|k|v projection
+    and ecgb_rope in one launch (ecgb_gemm_nt_bf16_rope), the same bits; where that kernel does not take the shape, the two calls."""
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    if _fuse_rope_fwd and cos.shape[1] == 32:
+        K2 = a2.shape[1] if a2 is not None else 0
+        rc = _L().ecgb_gemm_nt_bf16_rope(_p(a), a.stride(0), _p(b), b.stride(0), _p(a2), a2.stride(0) if K2 else 0, _p(b2), b2.stride(0) if K2 else 0, K2,
+                                         _p(out), out.stride(0), M, N, K, float(alpha), _p(cos), _p(sin), int(rope_cols), _st())
+        if rc == 0:
+            return out
+        if rc != -3:                                                     # ECGB_ERR_UNSUPPORTED: the two steps apart, below
+            _lib.check(rc)
+    gemm_nt(a, b, out=out, alpha=alpha, a2=a2, b2=b2)
+    return rope_(out, cos, sin, rope_cols // (2 * cos.shape[1]), 2 * cos.shape[1], N)
+
+
 def set_gemm_w4(on=True):
     """A/B switch: plain NT products of whole 256x256 tiles on the four-wave kernel (default) or on the eight-wave kernels; on=2 also sends the forms there
     that measured faster on eight waves (gate|up + GLU with a LoRA pair)."""

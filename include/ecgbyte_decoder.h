@@ -289,6 +289,13 @@ int ecgb_attn_decode_split_dyn(const void *q_dev, const void *k_cache_dev, const
  * when the problem also has at least two tiles per CU (batch 1, plain store); the same bits as the eight-wave kernels. */
 int ecgb_gemm_nt_w4_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
                          int M, int N, int K, float alpha, void *stream);
+/* The q|k|v projection with RoPE's forward in its epilogue (modeling_llama.py:151-176 apply_rotary_pos_emb on the projection's output): C = alpha * (A . B^T
+ * [+ A2 . B2^T, K2 > 0: the LoRA pair of ecgb_gemm_nt_bf16_cat]), then every head of 64 columns below rope_cols rotated with row t of the [M, 32] fp32 tables --
+ * ecgb_rope's arithmetic on the bf16-rounded projection: the same bits as the two calls, one write and one read of q|k less.  Whole 256x256 tiles, at least one per
+ * CU, 16-byte aligned operands; ECGB_ERR_UNSUPPORTED otherwise (the caller runs ecgb_gemm_nt_bf16[_cat] and ecgb_rope). */
+int ecgb_gemm_nt_bf16_rope(const void *a_dev, long long lda, const void *b_dev, long long ldb, const void *a2_dev, long long lda2,
+                           const void *b2_dev, long long ldb2, int K2, void *c_dev, long long ldc, int M, int N, int K, float alpha,
+                           const float *rope_cos_dev, const float *rope_sin_dev, int rope_cols, void *stream);
 int ecgb_set_gemm_w4(int on);              /* 1 (default): ecgb_gemm_nt_bf16 / _cat / _glu send eligible problems to the four-wave kernel; 0: never; 2: every form it has (A/B, tests) */
 int ecgb_set_gemm_w4_group_m(int group_m);  /* its tile order: blocks of group_m tile rows (default 16; 0 = row by row) */
 

@@ -25,3 +25,16 @@ for rnd in range(4):
         res[on].append(timed(lambda: ops.attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale, rope=(cos, sin))))
 ops.set_attn_bwd_rope_fusion(True)
 print(f"attention backward + RoPE backward per layer: apart {min(res[False]):.3f} ms, fused {min(res[True]):.3f} ms")
+
+# forward: the q|k|v projection + RoPE, apart (eight-wave GEMM, then ecgb_rope) against ecgb_gemm_nt_bf16_rope (four-wave kernel, rotation in the epilogue)
+H = 2048
+x = torch.randn(B * S, H, device="cuda").to(torch.bfloat16); wqkv = (torch.randn((Hq + 2 * Hkv) * D, H, device="cuda") * 0.05).to(torch.bfloat16)
+t = torch.randn(B * S, 64, device="cuda").to(torch.bfloat16); bl = (torch.randn((Hq + 2 * Hkv) * D, 64, device="cuda") * 0.05).to(torch.bfloat16)
+for name, kw in (("q|k|v projection + RoPE", {}), ("the same with a LoRA pair", dict(a2=t, b2=bl))):
+    res = {True: [], False: []}
+    for rnd in range(4):
+        for on in (False, True):
+            ops.set_gemm_rope_fusion(on)
+            res[on].append(timed(lambda: ops.gemm_nt_rope(x, wqkv, cos, sin, (Hq + Hkv) * D, **kw)))
+    ops.set_gemm_rope_fusion(False)
+    print(f"{name}: apart {min(res[False]):.3f} ms, fused {min(res[True]):.3f} ms")

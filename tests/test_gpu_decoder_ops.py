@@ -688,3 +688,28 @@ def test_gemm_nt_cat_four_wave_kernel_same_bits(ops):
         want = x[:32].float() @ w.float().T + t[:32].float() @ bl.float().T
         assert (y8[:32].float() - want).abs().max().item() <= 2e-2 * want.abs().max().item()
     assert not torch.equal(y8, ops.gemm_nt(x, w))                                 # (the branch is there)
+
+
+@pytest.mark.parametrize("with_pair", [False, True])
+def test_gemm_nt_rope_epilogue_is_gemm_then_rope_bit_for_bit(ops, with_pair):
+    """ecgb_gemm_nt_bf16_rope (the q|k|v projection with RoPE's forward in the four-wave kernel's epilogue) = ecgb_gemm_nt_bf16[_cat] followed by ecgb_rope on the
+    q and k heads: the same bits, the v columns untouched; a shape the kernel does not take goes through the two calls by itself."""
+    M, K, Hq, Hkv, D = 8192, 512, 32, 8, 64
+    N, cols = (Hq + 2 * Hkv) * D, (Hq + Hkv) * D
+    x, w = _bf(M, K, seed=91), _bf(N, K, seed=92) * 0.1
+    kw = dict(a2=_bf(M, 64, seed=93), b2=_bf(N, 64, seed=94) * 0.1) if with_pair else {}
+    pos = (torch.arange(M, device="cuda") % 1024).float()
+    fr = pos[:, None] * (1.0 / (500000.0 ** (torch.arange(0, D, 2, device="cuda").float() / D)))[None, :]
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    plain = ops.gemm_nt(x, w, **kw)
+    apart = ops.rope_(plain.clone(), cos, sin, Hq + Hkv, D, N)
+    assert torch.equal(ops.gemm_nt_rope(x, w, cos, sin, cols, **kw), apart)      # the default: the two calls (faster at the step's shape)
+    ops.set_gemm_rope_fusion(True)
+    try:
+        fused = ops.gemm_nt_rope(x, w, cos, sin, cols, **kw)
+        small = ops.gemm_nt_rope(x[:300], w, cos[:300].contiguous(), sin[:300].contiguous(), cols, **({k: v[:300] if k == "a2" else v for k, v in kw.items()}))
+    finally:
+        ops.set_gemm_rope_fusion(False)
+    assert torch.equal(fused, apart)
+    assert torch.equal(fused[:, cols:], plain[:, cols:]) and not torch.equal(fused[:, :cols], plain[:, :cols])
+    assert torch.equal(small, apart[:300])                                        # 300 rows: not whole tiles, the fallback
