@@ -141,6 +141,7 @@ def lib():
         "ecgb_kv_append": [vp, ll, ll, ci, vp, ll, ci, vp, vp],
         "ecgb_argmax_bf16": [vp, ll, ci, ci, vp, vp],
         "ecgb_gemm_nt_w4_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, vp],
+        "ecgb_gemm_nn_w4_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, vp],
         "ecgb_gemm_nt_bf16_rope": [vp, ll, vp, ll, vp, ll, vp, ll, ci, vp, ll, ci, ci, ci, f32, vp, vp, ci, vp],
         "ecgb_set_gemm_w4": [ci],
         "ecgb_set_gemm_w4_group_m": [ci],

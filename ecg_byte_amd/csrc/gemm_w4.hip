@@ -59,9 +59,10 @@ __device__ __forceinline__ unsigned pack2(float a, float b)
 }
 
 // Tile of workgroup w in round `it`: the workgroups of a round take consecutive tiles of the tile order, the 32 workgroups of an XCD (w % 8) a contiguous run
-// of them -- with the order in blocks of 16 tile rows (tile_rc) an XCD's 32 concurrent tiles are a 16 x 2 patch: 18 panels of A and B for 32 tiles instead of
+// of them -- with the order in blocks of 8 tile rows (tile_rc) an XCD's 32 concurrent tiles are an 8 x 4 patch: 12 panels of A and B for 32 tiles instead of
 // 33 (measured, [32768, 16384] x K 2048: 2.07 ms row by row, 1.87 / 1.70 / 1.62 / 1.60 ms with blocks of 2 / 4 / 8 / 16 -- the LDS-DMA of a K-tile has one K-tile
-// of time to land, and the rendezvous waits for the slowest of 64 pieces: it is the L2 hit rate that decides how long).
+// of time to land, and the rendezvous waits for the slowest of 64 pieces: it is the L2 hit rate that decides how long).  8, not 16: level with 16 on the NT shapes
+// over three boxes, and the NN product [32768, 16384] . [16384, 2048] (8 tile columns) takes 1.63 ms with blocks of 0 .. 8 and 2.31 with 16.
 __device__ __forceinline__ int tile_of_round(int w, int it, int nwg) { return it * nwg + (w & 7) * (nwg >> 3) + (w >> 3); }
 __device__ __forceinline__ void tile_rc(const W4Args &G, int tile, int &tm, int &tn)
 {
@@ -81,9 +82,13 @@ __device__ __forceinline__ void tile_rc(const W4Args &G, int tile, int &tm, int 
 // (i, 2p + 1) up of the same 16 columns; glu_fwd_kernel's arithmetic on the bf16-rounded projections: the same bits fused and unfused, four-wave and eight-wave.
 // CAT: the K loop continues into (A2, B2) -- K-tiles KT1 .. KT - 1 of every output tile come from the second pair (another scalar base, another set of per-lane
 // offsets chosen by a wave-uniform select: one v_cndmask per DMA piece).
-template <int EPI, bool CAT>
+// NN: B is [K, N] row-major (the input gradient dX = dY . W against the weight as nn.Linear stores it): its K-tile lies in LDS as 64 contraction rows of 512 bytes, staged
+// two rows per DMA piece, and the MFMA fragments (eight consecutive contraction elements of one column) are gathered by gfx950's transposing LDS read -- the layout, swizzle
+// and fragment addresses of gemm_nn_kernel_m16p (gemm.hip), through the compiler's builtin so that hipcc carries the waits.  Plain store, no second pair.
+template <int EPI, bool CAT, bool NN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_w4_kernel(W4Args G)
 {
+    static_assert(!NN || (EPI == 0 && !CAT), "the NN form is the plain product");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1;
@@ -110,6 +115,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // B: tile row r = (wave * 8 + i) * 8 + (lane >> 3); GLU: that is weight row 16 * (r >> 5) + (r & 15) (+ glu_I: an up row)
         const long long rb = (EPI == 0 || EPI == 3) ? (long long)(i * 8 + (lane >> 3)) : 16 * (i >> 2) + (i & 1) * 8 + (lane >> 3) + ((i >> 1) & 1) * (long long)G.glu_I;
         voffA[i] = (unsigned)(((long long)(i * 8 + (lane >> 3)) * G.lda + chunk * 8) * 2);
+        if constexpr (NN) {                                  // piece i: contraction rows rk, rk + 1 of the tile (512 bytes each), 16-byte chunk c of row rk at c ^ ((rk & 7) << 1 ^ (rk & 8))
+            const int rk = i * 2 + (lane >> 5), rkt = wave * 16 + rk;
+            const int chunkb = (lane & 31) ^ (((rkt & 7) << 1) ^ (rkt & 8));
+            voffB[i] = (unsigned)(((long long)rk * G.ldb + chunkb * 8) * 2);
+        } else
         voffB[i] = (unsigned)((rb * G.ldb + chunk * 8) * 2);
         if constexpr (CAT) {
             voffA2[i] = (unsigned)(((long long)(i * 8 + (lane >> 3)) * G.lda2 + chunk * 8) * 2);
@@ -128,7 +138,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         tile_rc(G, tile_of_round(w, st_it, nwg), tm, tn);
         const long long ra = (long long)tm * 256 + wave * 64, rb = (EPI == 0 || EPI == 3) ? (long long)tn * 256 + wave * 64 : (long long)tn * 128 + wave * 32;
         st_a = reinterpret_cast<const unsigned char *>(G.A + ra * G.lda);
-        st_b = reinterpret_cast<const unsigned char *>(G.B + rb * G.ldb);
+        st_b = NN ? reinterpret_cast<const unsigned char *>(G.B + (long long)wave * 16 * G.ldb + (long long)tn * 256)       // this wave's 16 contraction rows of K-tile 0, the tile's columns
+                  : reinterpret_cast<const unsigned char *>(G.B + rb * G.ldb);
         if constexpr (CAT) {
             st_a2 = reinterpret_cast<const unsigned char *>(G.A2 + ra * G.lda2);
             st_b2 = reinterpret_cast<const unsigned char *>(G.B2 + rb * G.ldb2);
@@ -142,7 +153,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         } else if (CAT && st_kt == KT1) {
             st_a = st_a2; st_b = st_b2; st_second = true;
         } else {
-            st_a += BK * 2; st_b += BK * 2;
+            st_a += BK * 2;
+            st_b += NN ? (long long)BK * G.ldb * 2 : (long long)BK * 2;
         }
     };
     auto dma_a = [&](unsigned buf_off, int i) {
@@ -160,7 +172,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned fragA = (unsigned)((wr * 128 + lm) * 128 + ((lq ^ sw) << 4));
     const unsigned fragB = (unsigned)(kTileBytes + (wc * 128 + lm) * 128 + ((lq ^ sw) << 4));
     auto frag_a = [&](const unsigned char *buf, int ks, int i) { return *reinterpret_cast<const bf16x8 *>(buf + (fragA ^ (ks ? 64u : 0u)) + i * 2048); };
-    auto frag_b = [&](const unsigned char *buf, int ks, int j) { return *reinterpret_cast<const bf16x8 *>(buf + (fragB ^ (ks ? 64u : 0u)) + j * 2048); };
+    unsigned tabB0[NN ? 8 : 1], tabB1[NN ? 8 : 1];           // NN: this lane's two transposing reads of the fragment at columns 16 j .. (k-slice 0; k-slice 1 is 32 rows further)
+    if constexpr (NN) {
+        const int tq = lm >> 2, tp = lm & 3, rbk = 8 * lq + tq, swb = (rbk & 7) ^ ((rbk & 8) >> 1), cb = tp >> 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            tabB0[j] = (unsigned)(kTileBytes + rbk * 512 + (tp & 1) * 8 + wc * 256 + (((2 * (j ^ swb)) + cb) << 4));
+            tabB1[j] = (unsigned)(kTileBytes + rbk * 512 + (tp & 1) * 8 + wc * 256 + (((2 * (j ^ 4 ^ swb)) + cb) << 4) + 2048);
+        }
+    }
+    auto frag_b = [&](const unsigned char *buf, int ks, int j) {
+        if constexpr (NN) {
+            using s4 = __attribute__((ext_vector_type(4))) short;
+            using s8 = __attribute__((ext_vector_type(8))) short;
+            const unsigned char *p0 = buf + tabB0[j] + (ks ? 32 * 512 : 0), *p1 = buf + tabB1[j] + (ks ? 32 * 512 : 0);
+            const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)(size_t)(unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char *)p0);
+            const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)(size_t)(unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char *)p1);
+            const s8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            return __builtin_bit_cast(bf16x8, f);
+        } else {
+            return *reinterpret_cast<const bf16x8 *>(buf + (fragB ^ (ks ? 64u : 0u)) + j * 2048);
+        }
+    };
 
     f32x4 acc[8][8];
 #pragma unroll
@@ -358,7 +391,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef W4_FENCE
 }
 
-int g_w4_group_m = 16;
+int g_w4_group_m = 8;
 int g_w4_cus = 0;
 
 }  // namespace
@@ -383,7 +416,7 @@ bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long l
 // epi 0: C [M, N] plain.  epi 1 / 2 (SiLU / tanh-GELU): N = 2 * inter, B = [gate rows; up rows], H [M, inter] = act(gate) * up, C (gate|up) may be null.
 int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream,
                    int epi, void *h_dev, long long ldh, const void *a2_dev, long long lda2, const void *b2_dev, long long ldb2, int K2,
-                   const float *rope_cos, const float *rope_sin, int rope_cols)
+                   const float *rope_cos, const float *rope_sin, int rope_cols, bool nn)
 {
     W4Args G;
     G.rope_cos = rope_cos; G.rope_sin = rope_sin; G.rope_cols = rope_cols;
@@ -391,11 +424,12 @@ int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long lon
     G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = (unsigned short *)c_dev;
     G.lda = lda; G.ldb = ldb; G.ldc = ldc; G.M = M; G.N = N; G.K = K; G.tiles_m = M / 256; G.tiles_n = N / 256; G.alpha = alpha; G.group_m = g_w4_group_m;
     G.H = (unsigned short *)h_dev; G.ldh = ldh; G.glu_I = N / 2;
-    const int which = epi + (G.K2 ? 4 : 0);
-    void (*const kerns[8])(W4Args) = {gemm_nt_w4_kernel<0, false>, gemm_nt_w4_kernel<1, false>, gemm_nt_w4_kernel<2, false>, gemm_nt_w4_kernel<3, false>,
-                                      gemm_nt_w4_kernel<0, true>, gemm_nt_w4_kernel<1, true>, gemm_nt_w4_kernel<2, true>, gemm_nt_w4_kernel<3, true>};
+    const int which = nn ? 8 : epi + (G.K2 ? 4 : 0);
+    void (*const kerns[9])(W4Args) = {gemm_nt_w4_kernel<0, false>, gemm_nt_w4_kernel<1, false>, gemm_nt_w4_kernel<2, false>, gemm_nt_w4_kernel<3, false>,
+                                      gemm_nt_w4_kernel<0, true>, gemm_nt_w4_kernel<1, true>, gemm_nt_w4_kernel<2, true>, gemm_nt_w4_kernel<3, true>,
+                                      gemm_nt_w4_kernel<0, false, true>};
     void (*kern)(W4Args) = kerns[which];
-    static bool attr_set[8] = {};
+    static bool attr_set[9] = {};
     hipError_t e = hipSuccess;
     if (!attr_set[which]) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
@@ -428,7 +462,7 @@ extern "C" int ecgb_gemm_nt_w4_bf16(const void *a_dev, long long lda, const void
         ecgb::set_error("ecgb_gemm_nt_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
         return ECGB_ERR_UNSUPPORTED;
     }
-    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0);
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, false);
 }
 
 // The q|k|v projection with RoPE's forward in the epilogue: C = alpha * (A B^T [+ A2 B2^T]), then every head of 64 columns below rope_cols rotated with row t of the
@@ -450,5 +484,19 @@ extern "C" int ecgb_gemm_nt_bf16_rope(const void *a_dev, long long lda, const vo
         ecgb::set_error("ecgb_gemm_nt_bf16_rope: whole 256x256 tiles (one per CU at least), K % 64, 16-byte aligned operands required");
         return ECGB_ERR_UNSUPPORTED;
     }
-    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 3, nullptr, 0, a2_dev, lda2, b2_dev, ldb2, K2 > 0 ? K2 : 0, rope_cos_dev, rope_sin_dev, rope_cols);
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 3, nullptr, 0, a2_dev, lda2, b2_dev, ldb2, K2 > 0 ? K2 : 0, rope_cos_dev, rope_sin_dev, rope_cols, false);
+}
+
+// C = alpha * A . B with B [K, N] row-major on the four-wave kernel (tests, A/B; ecgb_gemm_nn_bf16 dispatches here for long contractions): whole tiles only.
+extern "C" int ecgb_gemm_nn_w4_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
+                                    int M, int N, int K, float alpha, void *stream)
+{
+    if (!a_dev || !b_dev || !c_dev || M <= 0 || N <= 0 || K <= 0) { ecgb::set_error("ecgb_gemm_nn_w4_bf16: bad argument"); return ECGB_ERR_INVALID; }
+    (void)ecgb::gemm_w4_applies(a_dev, lda, a_dev, lda, c_dev, ldc, M, N, K);          // (device properties)
+    if (M % 256 || N % 256 || K % BK || lda % 8 || ldb % 8 || ldc % 8 || (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)c_dev) & 15) ||
+        (long long)63 * lda * 2 + 128 > 0xFFFFFFFFll || ((long long)15 * ldb + 256) * 2 > 0xFFFFFFFFll) {
+        ecgb::set_error("ecgb_gemm_nn_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, true);
 }

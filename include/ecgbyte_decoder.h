@@ -296,8 +296,12 @@ int ecgb_gemm_nt_w4_bf16(const void *a_dev, long long lda, const void *b_dev, lo
 int ecgb_gemm_nt_bf16_rope(const void *a_dev, long long lda, const void *b_dev, long long ldb, const void *a2_dev, long long lda2,
                            const void *b2_dev, long long ldb2, int K2, void *c_dev, long long ldc, int M, int N, int K, float alpha,
                            const float *rope_cos_dev, const float *rope_sin_dev, int rope_cols, void *stream);
+/* ecgb_gemm_nn_bf16's product (B [K, N] row-major) on the four-wave kernel, by name: whole 256x256 tiles, plain bf16 store; ECGB_ERR_UNSUPPORTED otherwise.  The same bits
+ * as the eight-wave NN kernels; ecgb_gemm_nn_bf16 dispatches here from 256 K-tiles per CU on while persistent backward kernels are allowed. */
+int ecgb_gemm_nn_w4_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
+                         int M, int N, int K, float alpha, void *stream);
 int ecgb_set_gemm_w4(int on);              /* 1 (default): ecgb_gemm_nt_bf16 / _cat / _glu send eligible problems to the four-wave kernel; 0: never; 2: every form it has (A/B, tests) */
-int ecgb_set_gemm_w4_group_m(int group_m);  /* its tile order: blocks of group_m tile rows (default 16; 0 = row by row) */
+int ecgb_set_gemm_w4_group_m(int group_m);  /* its tile order: blocks of group_m tile rows (default 8; 0 = row by row) */
 
 /* Greedy token choice of generate() (GenerationMixin._sample, generation/utils.py:3205: `next_tokens = torch.argmax(next_token_scores, dim=-1)`):
  * out[r] = index of the first maximum of the bf16 row x[r, 0:n] (rows `ld` elements apart).  One launch, no workspace. */

@@ -35,7 +35,7 @@ for M, N, K in [(32768, 16384, 2048), (32768, 2048, 8192), (32768, 3072, 2048), 
         ops.set_gemm_w4_group_m(gm)
         assert torch.equal(ops.gemm_nt_w4(a, b), ref)
         grp[gm] = min(timed(lambda: ops.gemm_nt_w4(a, b)) for _ in range(2))
-    ops.set_gemm_w4_group_m(16)
+    ops.set_gemm_w4_group_m(8)
     print(f"M{M} N{N} K{K}: equal {same}  8-wave {min(res['w8']):.3f} ms {fl / min(res['w8']) / 1e9:.0f} TF/s   4-wave {min(res['w4']):.3f} ms {fl / min(res['w4']) / 1e9:.0f} TF/s   "
           f"hipBLASLt {min(res['blas']):.3f} ms {fl / min(res['blas']) / 1e9:.0f} TF/s     tile order (ms): " + "  ".join(f"g{k}: {t:.3f}" for k, t in grp.items()), flush=True)
 

@@ -635,7 +635,7 @@ def test_gemm_nt_four_wave_kernel_same_bits(ops, M, N, K, pad):
         try:
             assert torch.equal(ops.gemm_nt_w4(a, b), ref), g
         finally:
-            ops.set_gemm_w4_group_m(16)
+            ops.set_gemm_w4_group_m(8)
     assert torch.equal(ops.gemm_nt_w4(a, b, alpha=0.37), ref_s)
     out = torch.full((M, N + 24), 7.0, device="cuda", dtype=torch.bfloat16)       # into a wider buffer: the columns past N stay
     ops.gemm_nt_w4(a, b, out=out[:, :N])
@@ -713,3 +713,27 @@ def test_gemm_nt_rope_epilogue_is_gemm_then_rope_bit_for_bit(ops, with_pair):
     assert torch.equal(fused, apart)
     assert torch.equal(fused[:, cols:], plain[:, cols:]) and not torch.equal(fused[:, :cols], plain[:, :cols])
     assert torch.equal(small, apart[:300])                                        # 300 rows: not whole tiles, the fallback
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 512, 128), (768, 256, 192), (8192, 2048, 4096)])
+def test_gemm_nn_four_wave_kernel_same_bits(ops, M, N, K):
+    """The four-wave kernel on the NN layout (B [K, N] row-major: dX = dY . W, the fragments of B by transposing LDS reads) = the eight-wave NN kernels bit for bit;
+    the last shape is one ecgb_gemm_nn_bf16 dispatches there (256 K-tiles per CU); padded strides; refused off whole tiles."""
+    a = _bf(M, K + 8, seed=95)[:, :K]
+    b = (_bf(K, N + 16, seed=96) * 0.1)[:, :N]
+    ops.set_gemm_w4(False)
+    try:
+        ref = ops.gemm_nn(a, b)
+    finally:
+        ops.set_gemm_w4(True)
+    want = a.float() @ b.float()
+    assert (ref.float() - want).abs().max().item() <= 2e-2 * want.abs().max().item()
+    for g in (0, 3, 8):
+        ops.set_gemm_w4_group_m(g)
+        try:
+            assert torch.equal(ops.gemm_nn_w4(a, b), ref), g
+        finally:
+            ops.set_gemm_w4_group_m(8)
+    assert torch.equal(ops.gemm_nn(a, b), ref)                                   # the dispatch, whatever it picks
+    with pytest.raises(Exception):
+        ops.gemm_nn_w4(a, b[:, :-16])
