@@ -142,6 +142,7 @@ def lib():
         "ecgb_argmax_bf16": [vp, ll, ci, ci, vp, vp],
         "ecgb_gemm_nt_w4_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, vp],
         "ecgb_gemm_nn_w4_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, vp],
+        "ecgb_gemm_tn_w4_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, vp],
         "ecgb_gemm_nt_bf16_rope": [vp, ll, vp, ll, vp, ll, vp, ll, ci, vp, ll, ci, ci, ci, f32, vp, vp, ci, vp],
         "ecgb_set_gemm_w4": [ci],
         "ecgb_set_gemm_w4_group_m": [ci],

@@ -1969,7 +1969,7 @@ namespace ecgb {
 bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long long ldb, const void *c_dev, long long ldc, int M, int N, int K);
 int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream,
                    int epi, void *h_dev, long long ldh, const void *a2_dev, long long lda2, const void *b2_dev, long long ldb2, int K2,
-                   const float *rope_cos, const float *rope_sin, int rope_cols, bool nn);
+                   const float *rope_cos, const float *rope_sin, int rope_cols, int lay);
 }
 namespace { int g_gemm_w4 = 1; }
 extern "C" int ecgb_set_gemm_w4(int on)
@@ -2035,7 +2035,7 @@ extern "C" int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b
     }
     // whole 256x256 tiles, plain bf16 store, one problem, at least two tiles per CU: the four-wave kernel (the same bits; 1-6 % faster on the step's forward shapes)
     if (g_gemm_w4 && g_gemm_tile == 0 && batch == 1 && accumulate_f32 == 0 && ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K))
-        return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, false);
+        return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 0);
     return launch_gemm(G, batch, (hipStream_t)stream);
 }
 
@@ -2076,7 +2076,7 @@ extern "C" int ecgb_gemm_nt_bf16_cat(const void *a_dev, long long lda, const voi
     }
     if (g_gemm_w4 && g_gemm_tile == 0 && accumulate_f32 == 0 && (long long)63 * lda2 * 2 + 128 <= 0xFFFFFFFFll && (long long)63 * ldb2 * 2 + 128 <= 0xFFFFFFFFll &&
         ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K))
-        return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, a2_dev, lda2, b2_dev, ldb2, K2, nullptr, nullptr, 0, false);
+        return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, a2_dev, lda2, b2_dev, ldb2, K2, nullptr, nullptr, 0, 0);
     return launch_gemm(G, 1, (hipStream_t)stream);
 }
 
@@ -2128,6 +2128,11 @@ extern "C" int ecgb_gemm_tn_bf16(const void *a_dev, long long lda, const void *b
         ecgb::set_error("ecgb_gemm_tn_bf16: row strides above 2^24 elements are not supported");
         return ECGB_ERR_UNSUPPORTED;
     }
+    // one K-slice, whole tiles, a long contraction: the four-wave kernel on the TN layout (the same bits; dW of the down projection 0.836 -> 0.785 ms, of gate|up 1.589 -> 1.574);
+    // persistent, so not while a gradient exchange may hold CUs (g_nn_persist)
+    if (splits == 1 && g_gemm_w4 && g_nn_persist && g_gemm_tile == 0 && N % 256 == 0 && K % 256 == 0 && (ldc & 7) == 0 && ((uintptr_t)c_dev & 15) == 0 &&
+        ((long long)15 * lda + 256) * 2 <= 0xFFFFFFFFll && ((long long)15 * ldb + 256) * 2 <= 0xFFFFFFFFll && ecgb::gemm_w4_applies(a_dev, 8, b_dev, 8, c_dev, ldc, N, K, M))
+        return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, N, K, M, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 2);
     G.accumulate_f32 = splits > 1 ? 1 : 0; G.alpha = alpha;      // splits > 1: c_dev is fp32 [splits][N, ldc], one slab per K-slice
     G.split_stride = (long long)N * ldc;
     G.inner = 0; G.outer_a = G.inner_a = G.outer_b = G.inner_b = G.outer_c = G.inner_c = 0; G.div_a = G.div_b = 1;
@@ -2164,7 +2169,7 @@ extern "C" int ecgb_gemm_nt_glu_bf16(const void *a_dev, long long lda, const voi
     // 0.65); with a LoRA pair behind it 1.952 against 1.935, so that form stays on the eight-wave kernel (g_gemm_w4 == 2 sends it to the four-wave one: tests).
     if (g_gemm_w4 && g_gemm_tile == 0 && (K2 <= 0 || (g_gemm_w4 == 2 && (long long)(inter + 63) * ldb2 * 2 + 128 <= 0xFFFFFFFFll)) && (ldh & 7) == 0 && ((uintptr_t)h_dev & 15) == 0 && (!c_dev || ((ldc & 7) == 0 && ((uintptr_t)c_dev & 15) == 0)) &&
         (long long)(inter + 63) * ldb * 2 + 128 <= 0xFFFFFFFFll && ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, h_dev, ldh, M, 2 * inter, K))
-        return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, 2 * inter, K, alpha, stream, gelu_tanh ? 2 : 1, h_dev, ldh, a2_dev, lda2, b2_dev, ldb2, K2, nullptr, nullptr, 0, false);
+        return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, 2 * inter, K, alpha, stream, gelu_tanh ? 2 : 1, h_dev, ldh, a2_dev, lda2, b2_dev, ldb2, K2, nullptr, nullptr, 0, 0);
     GemmArgs G{};
     G.group_m = g_gemm_group_m;
     G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = c_dev;
@@ -2209,7 +2214,7 @@ extern "C" int ecgb_gemm_nn_bf16(const void *a_dev, long long lda, const void *b
     // persistent: not while a gradient exchange may hold CUs (g_nn_persist, see above).
     if (g_gemm_w4 && g_nn_persist && g_gemm_tile == 0 && accumulate_f32 == 0 && (((uintptr_t)c_dev & 15) == 0) && (ldc & 7) == 0 && N % 256 == 0 &&
         ((long long)15 * ldb + 256) * 2 <= 0xFFFFFFFFll && ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K))
-        return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, true);
+        return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1);
     GemmArgs G{};
     G.group_m = g_gemm_group_m;
     G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = c_dev;

@@ -85,10 +85,13 @@ __device__ __forceinline__ void tile_rc(const W4Args &G, int tile, int &tm, int 
 // NN: B is [K, N] row-major (the input gradient dX = dY . W against the weight as nn.Linear stores it): its K-tile lies in LDS as 64 contraction rows of 512 bytes, staged
 // two rows per DMA piece, and the MFMA fragments (eight consecutive contraction elements of one column) are gathered by gfx950's transposing LDS read -- the layout, swizzle
 // and fragment addresses of gemm_nn_kernel_m16p (gemm.hip), through the compiler's builtin so that hipcc carries the waits.  Plain store, no second pair.
-template <int EPI, bool CAT, bool NN = false>
+// LAY 2 (TN: the weight gradient dW = dY^T . X): A is [K, M] row-major as well -- both operands staged as contraction rows and gathered by transposing reads
+// (gemm_tn_kernel_tr's layout).  LAY 0: NT, LAY 1: NN.
+template <int EPI, bool CAT, int LAY = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_w4_kernel(W4Args G)
 {
-    static_assert(!NN || (EPI == 0 && !CAT), "the NN form is the plain product");
+    constexpr bool NN = LAY >= 1, TA = LAY == 2;              // B, A stored with the contraction index as the row
+    static_assert(!NN || (EPI == 0 && !CAT), "the NN / TN forms are the plain product");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1;
@@ -115,6 +118,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // B: tile row r = (wave * 8 + i) * 8 + (lane >> 3); GLU: that is weight row 16 * (r >> 5) + (r & 15) (+ glu_I: an up row)
         const long long rb = (EPI == 0 || EPI == 3) ? (long long)(i * 8 + (lane >> 3)) : 16 * (i >> 2) + (i & 1) * 8 + (lane >> 3) + ((i >> 1) & 1) * (long long)G.glu_I;
         voffA[i] = (unsigned)(((long long)(i * 8 + (lane >> 3)) * G.lda + chunk * 8) * 2);
+        if constexpr (TA) {
+            const int rk = i * 2 + (lane >> 5), rkt = wave * 16 + rk;
+            voffA[i] = (unsigned)(((long long)rk * G.lda + ((lane & 31) ^ (((rkt & 7) << 1) ^ (rkt & 8))) * 8) * 2);
+        }
         if constexpr (NN) {                                  // piece i: contraction rows rk, rk + 1 of the tile (512 bytes each), 16-byte chunk c of row rk at c ^ ((rk & 7) << 1 ^ (rk & 8))
             const int rk = i * 2 + (lane >> 5), rkt = wave * 16 + rk;
             const int chunkb = (lane & 31) ^ (((rkt & 7) << 1) ^ (rkt & 8));
@@ -137,7 +144,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         int tm, tn;
         tile_rc(G, tile_of_round(w, st_it, nwg), tm, tn);
         const long long ra = (long long)tm * 256 + wave * 64, rb = (EPI == 0 || EPI == 3) ? (long long)tn * 256 + wave * 64 : (long long)tn * 128 + wave * 32;
-        st_a = reinterpret_cast<const unsigned char *>(G.A + ra * G.lda);
+        st_a = TA ? reinterpret_cast<const unsigned char *>(G.A + (long long)wave * 16 * G.lda + (long long)tm * 256)
+                  : reinterpret_cast<const unsigned char *>(G.A + ra * G.lda);
         st_b = NN ? reinterpret_cast<const unsigned char *>(G.B + (long long)wave * 16 * G.ldb + (long long)tn * 256)       // this wave's 16 contraction rows of K-tile 0, the tile's columns
                   : reinterpret_cast<const unsigned char *>(G.B + rb * G.ldb);
         if constexpr (CAT) {
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         } else if (CAT && st_kt == KT1) {
             st_a = st_a2; st_b = st_b2; st_second = true;
         } else {
-            st_a += BK * 2;
+            st_a += TA ? (long long)BK * G.lda * 2 : (long long)BK * 2;
             st_b += NN ? (long long)BK * G.ldb * 2 : (long long)BK * 2;
         }
     };
@@ -171,28 +179,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int sw = (lm >> 1) & 7;
     const unsigned fragA = (unsigned)((wr * 128 + lm) * 128 + ((lq ^ sw) << 4));
     const unsigned fragB = (unsigned)(kTileBytes + (wc * 128 + lm) * 128 + ((lq ^ sw) << 4));
-    auto frag_a = [&](const unsigned char *buf, int ks, int i) { return *reinterpret_cast<const bf16x8 *>(buf + (fragA ^ (ks ? 64u : 0u)) + i * 2048); };
-    unsigned tabB0[NN ? 8 : 1], tabB1[NN ? 8 : 1];           // NN: this lane's two transposing reads of the fragment at columns 16 j .. (k-slice 0; k-slice 1 is 32 rows further)
+    // NN / TN: a lane's transposing reads of the fragment at columns 16 m .. of a tile stored as contraction rows (k-slice 0; k-slice 1 is 32 rows further): lane
+    // (16 g + 4 q + p) addresses row 8 g + q, chunk 2 m + (p >> 1) of the row, stored at chunk ^ 2 s with s = (row & 7) ^ ((row & 8) >> 1); the second read, 4 rows
+    // down, has s ^ 4: the entry of fragment m ^ 4, 2048 bytes further (gemm_tn_kernel_tr has the derivation).
+    unsigned tabA[TA ? 8 : 1], tabB[NN ? 8 : 1];
     if constexpr (NN) {
         const int tq = lm >> 2, tp = lm & 3, rbk = 8 * lq + tq, swb = (rbk & 7) ^ ((rbk & 8) >> 1), cb = tp >> 1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            tabB0[j] = (unsigned)(kTileBytes + rbk * 512 + (tp & 1) * 8 + wc * 256 + (((2 * (j ^ swb)) + cb) << 4));
-            tabB1[j] = (unsigned)(kTileBytes + rbk * 512 + (tp & 1) * 8 + wc * 256 + (((2 * (j ^ 4 ^ swb)) + cb) << 4) + 2048);
+        for (int m = 0; m < 8; ++m) {
+            tabB[m] = (unsigned)(kTileBytes + rbk * 512 + (tp & 1) * 8 + wc * 256 + (((2 * (m ^ swb)) + cb) << 4));
+            if constexpr (TA) tabA[m] = (unsigned)(rbk * 512 + (tp & 1) * 8 + wr * 256 + (((2 * (m ^ swb)) + cb) << 4));
         }
     }
+    using s4 = __attribute__((ext_vector_type(4))) short;
+    using s8 = __attribute__((ext_vector_type(8))) short;
+    auto tr_frag = [&](const unsigned char *buf, unsigned t0, unsigned t1, int ks) {
+        const unsigned char *p0 = buf + t0 + (ks ? 32 * 512 : 0), *p1 = buf + t1 + 2048 + (ks ? 32 * 512 : 0);
+        const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)(size_t)(unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char *)p0);
+        const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)(size_t)(unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char *)p1);
+        const s8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, f);
+    };
+    auto frag_a = [&](const unsigned char *buf, int ks, int i) {
+        if constexpr (TA) return tr_frag(buf, tabA[i], tabA[i ^ 4], ks);
+        else return *reinterpret_cast<const bf16x8 *>(buf + (fragA ^ (ks ? 64u : 0u)) + i * 2048);
+    };
     auto frag_b = [&](const unsigned char *buf, int ks, int j) {
-        if constexpr (NN) {
-            using s4 = __attribute__((ext_vector_type(4))) short;
-            using s8 = __attribute__((ext_vector_type(8))) short;
-            const unsigned char *p0 = buf + tabB0[j] + (ks ? 32 * 512 : 0), *p1 = buf + tabB1[j] + (ks ? 32 * 512 : 0);
-            const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)(size_t)(unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char *)p0);
-            const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)(size_t)(unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char *)p1);
-            const s8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            return __builtin_bit_cast(bf16x8, f);
-        } else {
-            return *reinterpret_cast<const bf16x8 *>(buf + (fragB ^ (ks ? 64u : 0u)) + j * 2048);
-        }
+        if constexpr (NN) return tr_frag(buf, tabB[j], tabB[j ^ 4], ks);
+        else return *reinterpret_cast<const bf16x8 *>(buf + (fragB ^ (ks ? 64u : 0u)) + j * 2048);
     };
 
     f32x4 acc[8][8];
@@ -416,7 +430,7 @@ bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long l
 // epi 0: C [M, N] plain.  epi 1 / 2 (SiLU / tanh-GELU): N = 2 * inter, B = [gate rows; up rows], H [M, inter] = act(gate) * up, C (gate|up) may be null.
 int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream,
                    int epi, void *h_dev, long long ldh, const void *a2_dev, long long lda2, const void *b2_dev, long long ldb2, int K2,
-                   const float *rope_cos, const float *rope_sin, int rope_cols, bool nn)
+                   const float *rope_cos, const float *rope_sin, int rope_cols, int lay)
 {
     W4Args G;
     G.rope_cos = rope_cos; G.rope_sin = rope_sin; G.rope_cols = rope_cols;
@@ -424,12 +438,12 @@ int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long lon
     G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = (unsigned short *)c_dev;
     G.lda = lda; G.ldb = ldb; G.ldc = ldc; G.M = M; G.N = N; G.K = K; G.tiles_m = M / 256; G.tiles_n = N / 256; G.alpha = alpha; G.group_m = g_w4_group_m;
     G.H = (unsigned short *)h_dev; G.ldh = ldh; G.glu_I = N / 2;
-    const int which = nn ? 8 : epi + (G.K2 ? 4 : 0);
-    void (*const kerns[9])(W4Args) = {gemm_nt_w4_kernel<0, false>, gemm_nt_w4_kernel<1, false>, gemm_nt_w4_kernel<2, false>, gemm_nt_w4_kernel<3, false>,
-                                      gemm_nt_w4_kernel<0, true>, gemm_nt_w4_kernel<1, true>, gemm_nt_w4_kernel<2, true>, gemm_nt_w4_kernel<3, true>,
-                                      gemm_nt_w4_kernel<0, false, true>};
+    const int which = lay ? 7 + lay : epi + (G.K2 ? 4 : 0);
+    void (*const kerns[10])(W4Args) = {gemm_nt_w4_kernel<0, false>, gemm_nt_w4_kernel<1, false>, gemm_nt_w4_kernel<2, false>, gemm_nt_w4_kernel<3, false>,
+                                       gemm_nt_w4_kernel<0, true>, gemm_nt_w4_kernel<1, true>, gemm_nt_w4_kernel<2, true>, gemm_nt_w4_kernel<3, true>,
+                                       gemm_nt_w4_kernel<0, false, 1>, gemm_nt_w4_kernel<0, false, 2>};
     void (*kern)(W4Args) = kerns[which];
-    static bool attr_set[9] = {};
+    static bool attr_set[10] = {};
     hipError_t e = hipSuccess;
     if (!attr_set[which]) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
@@ -462,7 +476,7 @@ extern "C" int ecgb_gemm_nt_w4_bf16(const void *a_dev, long long lda, const void
         ecgb::set_error("ecgb_gemm_nt_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
         return ECGB_ERR_UNSUPPORTED;
     }
-    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, false);
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 0);
 }
 
 // The q|k|v projection with RoPE's forward in the epilogue: C = alpha * (A B^T [+ A2 B2^T]), then every head of 64 columns below rope_cols rotated with row t of the
@@ -484,7 +498,7 @@ extern "C" int ecgb_gemm_nt_bf16_rope(const void *a_dev, long long lda, const vo
         ecgb::set_error("ecgb_gemm_nt_bf16_rope: whole 256x256 tiles (one per CU at least), K % 64, 16-byte aligned operands required");
         return ECGB_ERR_UNSUPPORTED;
     }
-    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 3, nullptr, 0, a2_dev, lda2, b2_dev, ldb2, K2 > 0 ? K2 : 0, rope_cos_dev, rope_sin_dev, rope_cols, false);
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 3, nullptr, 0, a2_dev, lda2, b2_dev, ldb2, K2 > 0 ? K2 : 0, rope_cos_dev, rope_sin_dev, rope_cols, 0);
 }
 
 // C = alpha * A . B with B [K, N] row-major on the four-wave kernel (tests, A/B; ecgb_gemm_nn_bf16 dispatches here for long contractions): whole tiles only.
@@ -498,5 +512,20 @@ extern "C" int ecgb_gemm_nn_w4_bf16(const void *a_dev, long long lda, const void
         ecgb::set_error("ecgb_gemm_nn_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
         return ECGB_ERR_UNSUPPORTED;
     }
-    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, true);
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1);
+}
+
+// C[M, N] = alpha * A^T . B with A [K, M] and B [K, N] row-major (ecgb_gemm_tn_bf16's product: C = its [N, K] output, K here = its M) on the four-wave kernel, by name:
+// whole 256x256 tiles, plain bf16 store.
+extern "C" int ecgb_gemm_tn_w4_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
+                                    int M, int N, int K, float alpha, void *stream)
+{
+    if (!a_dev || !b_dev || !c_dev || M <= 0 || N <= 0 || K <= 0) { ecgb::set_error("ecgb_gemm_tn_w4_bf16: bad argument"); return ECGB_ERR_INVALID; }
+    (void)ecgb::gemm_w4_applies(a_dev, 8, a_dev, 8, c_dev, ldc, M, N, K);              // (device properties)
+    if (M % 256 || N % 256 || K % BK || lda % 8 || ldb % 8 || ldc % 8 || (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)c_dev) & 15) ||
+        ((long long)15 * lda + 256) * 2 > 0xFFFFFFFFll || ((long long)15 * ldb + 256) * 2 > 0xFFFFFFFFll) {
+        ecgb::set_error("ecgb_gemm_tn_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 2);
 }

@@ -74,6 +74,15 @@ def set_gemm_w4_group_m(g=8):
     _lib.check(_L().ecgb_set_gemm_w4_group_m(int(g)))
 
 
+def gemm_tn_w4(a, b, alpha=1.0, out=None):
+    """a [K, M]^T . b [K, N] (both row-major: the weight gradient dY^T . X) on the four-wave kernel (ecgb_gemm_tn_w4_bf16): M, N multiples of 256, K of 64."""
+    K, M = a.shape
+    N = b.shape[1]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device) if out is None else out
+    _lib.check(_L().ecgb_gemm_tn_w4_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, float(alpha), _st()))
+    return out
+
+
 def gemm_nn_w4(a, b, alpha=1.0, out=None):
     """a [M, K] . b [K, N] (b row-major) on the four-wave kernel (ecgb_gemm_nn_w4_bf16): M, N multiples of 256, K of 64."""
     M, K = a.shape

@@ -300,6 +300,10 @@ int ecgb_gemm_nt_bf16_rope(const void *a_dev, long long lda, const void *b_dev, 
  * as the eight-wave NN kernels; ecgb_gemm_nn_bf16 dispatches here from 256 K-tiles per CU on while persistent backward kernels are allowed. */
 int ecgb_gemm_nn_w4_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
                          int M, int N, int K, float alpha, void *stream);
+/* ecgb_gemm_tn_bf16's product with one K-slice (C [M, N] = A^T . B, A [K, M] and B [K, N] row-major: the weight gradient dY^T . X) on the four-wave kernel, by name;
+ * whole 256x256 tiles, plain bf16 store, the same bits; ecgb_gemm_tn_bf16 dispatches here under the same conditions as ecgb_gemm_nn_bf16. */
+int ecgb_gemm_tn_w4_bf16(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc,
+                         int M, int N, int K, float alpha, void *stream);
 int ecgb_set_gemm_w4(int on);              /* 1 (default): ecgb_gemm_nt_bf16 / _cat / _glu send eligible problems to the four-wave kernel; 0: never; 2: every form it has (A/B, tests) */
 int ecgb_set_gemm_w4_group_m(int group_m);  /* its tile order: blocks of group_m tile rows (default 8; 0 = row by row) */
 

@@ -737,3 +737,27 @@ def test_gemm_nn_four_wave_kernel_same_bits(ops, M, N, K):
     assert torch.equal(ops.gemm_nn(a, b), ref)                                   # the dispatch, whatever it picks
     with pytest.raises(Exception):
         ops.gemm_nn_w4(a, b[:, :-16])
+
+
+@pytest.mark.parametrize("Kc,M,N", [(128, 512, 512), (192, 768, 256), (16384, 2048, 2048)])
+def test_gemm_tn_four_wave_kernel_same_bits(ops, Kc, M, N):
+    """The four-wave kernel on the TN layout (dW = dY^T . X: both operands staged as contraction rows, fragments by transposing LDS reads) = the eight-wave TN kernel with
+    one K-slice bit for bit; the last shape is one ecgb_gemm_tn_bf16 dispatches there; padded strides; refused off whole tiles."""
+    a = _bf(Kc, M + 8, seed=97)[:, :M]
+    b = (_bf(Kc, N + 16, seed=98) * 0.1)[:, :N]
+    ops.set_gemm_w4(False)
+    try:
+        ref = ops.gemm_tn(a, b, splits=1)
+    finally:
+        ops.set_gemm_w4(True)
+    want = a.float().T @ b.float()
+    assert (ref.float() - want).abs().max().item() <= 2e-2 * want.abs().max().item()
+    for g in (0, 8):
+        ops.set_gemm_w4_group_m(g)
+        try:
+            assert torch.equal(ops.gemm_tn_w4(a, b), ref), g
+        finally:
+            ops.set_gemm_w4_group_m(8)
+    assert torch.equal(ops.gemm_tn(a, b, splits=1), ref)                          # the dispatch, whatever it picks
+    with pytest.raises(Exception):
+        ops.gemm_tn_w4(a[:, :-16], b)
