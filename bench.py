@@ -605,7 +605,7 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
                       "loss_head_rows": "all" if model.full_logits else "labelled only (identical loss/gradients)",
                       "parallelism": f"dp{world}" + (f" (bucketed async all-reduce of the flat gradient buffer, backend {dist.get_backend()})" if dist.is_initialized() else "")},
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_nt_kernel_m16pp + gemm_nn_kernel_m16pp (persistent tile loops; m16p for long contractions) + gemm_tn_kernel_tr, 256x256 tiles (bf16 MFMA 16x16x32)",
+                        "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_nt_w4_kernel (four waves, 128x128 wave tiles: NT / NN / TN products with 256+ K-tiles per CU) + gemm_nt_kernel_m16pp / gemm_nn_kernel_m16pp (eight waves, persistent tile loops) + gemm_tn_kernel_tr, 256x256 tiles (bf16 MFMA 16x16x32)",
                         "algorithmic_flops_per_step": flops, "step_ms_hip_events": ev0.elapsed_time(ev1) / args.train_steps}}
     if comm is not None:
         out["gradient_exchange"] = comm
