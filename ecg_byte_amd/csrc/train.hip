@@ -25,10 +25,14 @@
 
 #include "tokenizer.hpp"
 
+#ifndef ECGB_TRAIN_PER_THREAD
+#define ECGB_TRAIN_PER_THREAD 16
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kPerThread = 16;                        // even: a span of one repeated symbol keeps run parity
+constexpr int kPerThread = ECGB_TRAIN_PER_THREAD;       // even: a span of one repeated symbol keeps run parity
 constexpr uint32_t kTile = kThreads * kPerThread;     // 4096 ids per tile
 constexpr uint32_t kGrid = 2048;                      // persistent grid (8 workgroups per CU)
 constexpr uint32_t kHashSlots = 2048;                 // per-workgroup LDS table of count deltas
@@ -249,20 +253,20 @@ __device__ __forceinline__ uint32_t halo_at(const Halo &h, int64_t i, uint64_t n
 // separate 64-byte segments (tile_count 40 us and rewrite 64 us per merge whatever the length: 1 TB/s).  So the workgroup brings the tile -- 4096 ids and the three
 // around it -- with consecutive lanes on consecutive words, parks it in LDS with one pad word per 16 (lane t's ids start at word 17 t: the lanes' reads hit 64
 // different banks), and every lane picks its span from there.  stage_tile ends with a barrier; callers put one before the next stage_tile (or re-use of s_ids).
-constexpr uint32_t kStageWords = kTile + 3 + (kTile + 3) / 16 + 1;
+constexpr uint32_t kStageWords = kTile + 3 + (kTile + 3) / kPerThread + 1;
 __device__ __forceinline__ void stage_tile(uint32_t *s_ids, const uint32_t *src, uint64_t base, uint64_t n, const Halo &h)
 {
     for (uint32_t j = threadIdx.x; j < kTile + 3; j += kThreads) {
         const int64_t i = (int64_t)base + j - 1;
-        s_ids[j + (j >> 4)] = (i >= 0 && i < (int64_t)n) ? src[i] : halo_at(h, i, n);
+        s_ids[j + j / kPerThread] = (i >= 0 && i < (int64_t)n) ? src[i] : halo_at(h, i, n);
     }
     __syncthreads();
 }
 __device__ __forceinline__ void span_from_lds(Span &s, const uint32_t *s_ids)
 {
-    const uint32_t t17 = threadIdx.x * 17u;
+    const uint32_t t17 = threadIdx.x * (uint32_t)(kPerThread + 1);      // one pad word per span: the lanes' reads hit different banks
 #pragma unroll
-    for (int k = 0; k < kPerThread + 3; ++k) s.a[k] = s_ids[t17 + k + (k >> 4)];
+    for (int k = 0; k < kPerThread + 3; ++k) s.a[k] = s_ids[t17 + k + k / kPerThread];
 }
 
 // number of trailing `l` ids of the span (0..16)
