@@ -644,6 +644,12 @@ def main():
     ap.add_argument("--lora", action="store_true", help="train LoRA adapters (r16, alpha 32, dropout 0.05; frozen base) as the reference's script does")
     args = ap.parse_args()
 
+    # ONE line on stdout: libraries print there too (RCCL's version banner at the first collective under torch.distributed.run lands on file descriptor 1, in front of
+    # the line).  Everything this process and its children write to stdout goes to stderr from here on; the JSON line is written to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from helpers import load_tokenizer
@@ -800,7 +806,8 @@ def main():
             out["c5"] = c5
         if train is not None:
             out["train"] = train
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if dist.is_initialized():
         dist.destroy_process_group()
 
