@@ -1788,6 +1788,78 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs G)
     }
 }
 
+// The gate|up projection of a decode step with the GLU folded in: one wave per column n of H computes the gate column n and the up column n + glu_I (both weight rows
+// stream by once, as in gemm_nt_skinny_kernel), rounds them to bf16 as the stored projection would be, and writes act(gate) * up -- store_tile_glu's arithmetic: the same
+// bits as the few-row GEMM followed by ecgb_glu_fwd, one launch and one write / read of gate|up less per layer and token.  G.C (gate|up) may be null.
+template <int MR, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_skinny_glu_kernel(GemmArgs G)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long n = (long long)blockIdx.x * 4 + wave;
+    const bool live = n < G.glu_I;
+    const unsigned short *bg = G.B + (live ? n : 0) * G.ldb, *bu = bg + (long long)G.glu_I * G.ldb;
+    float ag[MR], au[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) { ag[m] = 0.f; au[m] = 0.f; }
+    constexpr int U = 2;                                   // 16-byte pieces of each of the two weight rows in flight per lane
+    auto fma8 = [&](const bf16x8 &va, const bf16x8 &vb, float &acc) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += __uint_as_float((unsigned)(unsigned short)va[j] << 16) * __uint_as_float((unsigned)(unsigned short)vb[j] << 16);
+    };
+    for (int k0 = lane * 8; k0 < G.K; k0 += 512 * U) {
+        bf16x8 vg[U], vu[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = min(k0 + 512 * u, G.K - 8);
+            vg[u] = *reinterpret_cast<const bf16x8 *>(bg + k);
+            vu[u] = *reinterpret_cast<const bf16x8 *>(bu + k);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 512 * u;
+            if (k < G.K) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    if (m < G.M) {
+                        const bf16x8 va = *reinterpret_cast<const bf16x8 *>(G.A + (long long)m * G.lda + k);
+                        fma8(va, vg[u], ag[m]);
+                        fma8(va, vu[u], au[m]);
+                    }
+                }
+            }
+        }
+    }
+    if (G.K2 > 0) {                                         // the LoRA pair behind the first, as in gemm_nt_skinny_kernel
+        for (int k = lane * 8; k < G.K2; k += 512) {
+            const bf16x8 vg = *reinterpret_cast<const bf16x8 *>(G.B2 + (live ? n : 0) * G.ldb2 + k);
+            const bf16x8 vu = *reinterpret_cast<const bf16x8 *>(G.B2 + ((live ? n : 0) + (long long)G.glu_I) * G.ldb2 + k);
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                if (m < G.M) {
+                    const bf16x8 va = *reinterpret_cast<const bf16x8 *>(G.A2 + (long long)m * G.lda2 + k);
+                    fma8(va, vg, ag[m]);
+                    fma8(va, vu, au[m]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { ag[m] += __shfl_xor(ag[m], d, 64); au[m] += __shfl_xor(au[m], d, 64); }
+    if (live && lane == 0) {
+        unsigned short *C = reinterpret_cast<unsigned short *>(G.C);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (m >= G.M) break;
+            const unsigned short g16 = f2bf_rn(ag[m] * G.alpha), u16 = f2bf_rn(au[m] * G.alpha);
+            const float a = __uint_as_float((unsigned)f2bf_rn(ecgb::glu_act<EPI == 2>(__uint_as_float((unsigned)g16 << 16))) << 16);
+            G.H[(long long)m * G.ldh + n] = f2bf_rn(a * __uint_as_float((unsigned)u16 << 16));
+            if (C) { C[(long long)m * G.ldc + n] = g16; C[(long long)m * G.ldc + G.glu_I + n] = u16; }
+        }
+    }
+}
+
 // More than two rows and many columns (the batched decode step's gate||up and output-head products): with one column per
 // wave every column re-reads the M activation pieces through L1 -- 8x the weight traffic at M = 8, and L1 bandwidth, not
 // HBM, is the limit (2 TB/s).  Here a wave takes COLS columns: the activation pieces are loaded and unpacked once per
@@ -2163,6 +2235,24 @@ extern "C" int ecgb_gemm_nt_glu_bf16(const void *a_dev, long long lda, const voi
         (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)a2_dev | (uintptr_t)b2_dev) & 15) || (((uintptr_t)c_dev | (uintptr_t)h_dev) & 7)) {
         ecgb::set_error("ecgb_gemm_nt_glu_bf16: K % 64, inter % 128, 16-byte aligned operands, strides % 8 (outputs % 4) required");
         return ECGB_ERR_UNSUPPORTED;
+    }
+    if (M <= 8 && K % 8 == 0 && (K2 <= 0 || K2 % 8 == 0)) {       // a decode step: the few-row kernel with the GLU folded in (bound by reading the two weight rows once)
+        GemmArgs G{};
+        G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = c_dev;
+        G.M = M; G.N = 2 * inter; G.K = K; G.lda = lda; G.ldb = ldb; G.ldc = ldc; G.alpha = alpha;
+        G.A2 = (const unsigned short *)a2_dev; G.B2 = (const unsigned short *)b2_dev; G.lda2 = lda2; G.ldb2 = ldb2; G.K2 = K2 > 0 ? K2 : 0;
+        G.H = (unsigned short *)h_dev; G.ldh = ldh; G.glu_I = inter;
+        const dim3 grid((unsigned)((inter + 3) / 4));
+        if (M <= 2) {
+            if (gelu_tanh) hipLaunchKernelGGL((gemm_nt_skinny_glu_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, G);
+            else hipLaunchKernelGGL((gemm_nt_skinny_glu_kernel<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, G);
+        } else {
+            if (gelu_tanh) hipLaunchKernelGGL((gemm_nt_skinny_glu_kernel<8, 2>), grid, dim3(256), 0, (hipStream_t)stream, G);
+            else hipLaunchKernelGGL((gemm_nt_skinny_glu_kernel<8, 1>), grid, dim3(256), 0, (hipStream_t)stream, G);
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_skinny_glu_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+        return ECGB_OK;
     }
     // whole tiles, no second operand pair: the four-wave kernel with the same epilogue (the same bits).  Measured at [32768, 2048] -> 2 x 8192: 1.853 against 1.863 ms, h only
     // 1.669 against 1.703 -- the activation is vector work that a wave alone on its SIMD cannot hide (under the profiler its MFMA pipes are 0.57 busy, the plain kernel's

@@ -363,7 +363,9 @@ def gemm_nn_glu_bwd(dy, w, gate_up, gelu_tanh=False):
 
 def glu_fusable(M, inter):
     """Shapes the GLU-epilogue GEMM takes: the 256x256 tile needs whole tiles of 128 gate + 128 up columns and enough of them to fill
-    the chip (a decode step's few rows go through the few-row kernel and the separate GLU)."""
+    the chip; up to eight rows (a decode step) go through the few-row kernel with the GLU folded in."""
+    if M <= 8:
+        return inter % 128 == 0                              # a decode step: the few-row kernel with the GLU folded in (gemm_nt_skinny_glu_kernel)
     return M >= 256 and inter % 128 == 0 and ((M + 255) // 256) * (2 * inter // 256) >= 192
 
 

@@ -761,3 +761,20 @@ def test_gemm_tn_four_wave_kernel_same_bits(ops, Kc, M, N):
     assert torch.equal(ops.gemm_tn(a, b, splits=1), ref)                          # the dispatch, whatever it picks
     with pytest.raises(Exception):
         ops.gemm_tn_w4(a[:, :-16], b)
+
+
+@pytest.mark.parametrize("M", [1, 2, 5, 8])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_few_row_glu_projection_is_gemm_then_glu_bit_for_bit(ops, M, gelu):
+    """A decode step's gate|up projection with the GLU folded into the few-row kernel (gemm_nt_skinny_glu_kernel) = the few-row GEMM followed by ecgb_glu_fwd: the same
+    bits for act(gate) * up and for gate|up when it is kept, with and without the LoRA pair."""
+    I, K = 1024, 2048
+    x, w = _bf(M, K, seed=101), _bf(2 * I, K, seed=102) * 0.05
+    t, bl = _bf(M, 64, seed=103), _bf(2 * I, 64, seed=104) * 0.05
+    for kw in ({}, dict(a2=t, b2=bl)):
+        gu = ops.gemm_nt(x, w, **kw)
+        h = ops.glu_fwd(gu, gelu_tanh=gelu)
+        gu2, h2 = ops.gemm_nt_glu(x, w, gelu_tanh=gelu, keep_gu=True, **kw)
+        assert torch.equal(gu2, gu) and torch.equal(h2, h)
+        none, h3 = ops.gemm_nt_glu(x, w, gelu_tanh=gelu, keep_gu=False, **kw)
+        assert none is None and torch.equal(h3, h)
