@@ -116,6 +116,7 @@ def lib():
         "ecgb_rmsnorm_fwd": [vp, vp, vp, vp, vp, vp, sz, ci, f32, ci, vp],
         "ecgb_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, sz, ci, ci, vp, vp],
         "ecgb_rope": [vp, vp, vp, sz, ci, ci, sz, ci, vp],
+        "ecgb_rope_append": [vp, vp, vp, ci, ci, ci, ci, sz, vp, ll, ci, vp, vp],
         "ecgb_glu_fwd": [vp, vp, sz, ci, ci, vp],
         "ecgb_glu_bwd": [vp, vp, vp, sz, ci, ci, vp],
         "ecgb_add_bf16": [vp, vp, vp, sz, vp],

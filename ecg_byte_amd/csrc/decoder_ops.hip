@@ -389,6 +389,43 @@ __global__ __launch_bounds__(256) void rope_kernel(unsigned short *x, const floa
     }
 }
 
+// A decode step's RoPE and KV-cache append in one launch: the new token's q and k heads are rotated in place in qkv (rope_kernel's arithmetic), and its rotated k and its v
+// go to row len - 1 of the cache (k | v, row stride `width` = 2 * n_kv * D) -- ecgb_rope followed by the cache copy / ecgb_kv_append, the same bits.
+// qkv [B, (n_q + 2 n_kv) * D]; len: *len_dev when given (a replayed graph), else len_arg.
+__global__ __launch_bounds__(256) void rope_append_kernel(unsigned short *qkv, const float *cs, const float *sn, int B, int n_q, int n_kv, int D, size_t row_stride,
+                                                          unsigned short *cache, long long cap, int len_arg, const int *len_dev)
+{
+    const int half = D / 2, per_head = half / 8;
+    const long long row = (len_dev ? *len_dev : len_arg) - 1;
+    const int width = 2 * n_kv * D;
+    const int n_rope = B * (n_q + n_kv) * per_head, n_v = B * (n_kv * D / 8);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rope + n_v; i += gridDim.x * blockDim.x) {
+        if (i < n_rope) {
+            const int c = i % per_head, th = i / per_head, h = th % (n_q + n_kv), t = th / (n_q + n_kv);
+            unsigned short *p = qkv + (size_t)t * row_stride + (size_t)h * D + c * 8;
+            bf16x8 a = *reinterpret_cast<bf16x8 *>(p), b = *reinterpret_cast<bf16x8 *>(p + half);
+            const float *pc = cs + (size_t)t * half + c * 8, *ps = sn + (size_t)t * half + c * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float cc = bf2f(f2bf(pc[j])), ss = bf2f(f2bf(ps[j]));
+                const float x1 = bf2f(a[j]), x2 = bf2f(b[j]);
+                a[j] = f2bf(x1 * cc - x2 * ss); b[j] = f2bf(x2 * cc + x1 * ss);
+            }
+            *reinterpret_cast<bf16x8 *>(p) = a;
+            *reinterpret_cast<bf16x8 *>(p + half) = b;
+            if (h >= n_q) {
+                unsigned short *kc = cache + ((long long)t * cap + row) * width + (size_t)(h - n_q) * D + c * 8;
+                *reinterpret_cast<bf16x8 *>(kc) = a;
+                *reinterpret_cast<bf16x8 *>(kc + half) = b;
+            }
+        } else {
+            const int j = i - n_rope, per_row = n_kv * D / 8, t = j / per_row, c = j % per_row;
+            *reinterpret_cast<bf16x8 *>(cache + ((long long)t * cap + row) * width + n_kv * D + c * 8) =
+                *reinterpret_cast<const bf16x8 *>(qkv + (size_t)t * row_stride + (size_t)(n_q + n_kv) * D + c * 8);
+        }
+    }
+}
+
 // ---- SwiGLU / GeGLU ------------------------------------------------------------------------------
 // gu: [T, 2*I] with gate in [:, :I] and up in [:, I:]  (one fused gate|up projection);  h: [T, I]
 template <bool GELU_TANH>
@@ -1059,6 +1096,20 @@ extern "C" int ecgb_rope(void *x_dev, const float *cos_dev, const float *sin_dev
         hipLaunchKernelGGL(rope_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (unsigned short *)x_dev, cos_dev, sin_dev,
                            tokens, n_heads, head_dim, row_stride);
     ECGB_CHECK_LAUNCH("rope");
+}
+
+extern "C" int ecgb_rope_append(void *qkv_dev, const float *cos_dev, const float *sin_dev, int batch, int n_q_heads, int n_kv_heads, int head_dim, size_t row_stride,
+                                void *cache_dev, long long capacity, int kv_len, const int *kv_len_dev, void *stream)
+{
+    if (!qkv_dev || !cos_dev || !sin_dev || !cache_dev || batch <= 0 || n_q_heads <= 0 || n_kv_heads <= 0 || head_dim % 16 || capacity <= 0 ||
+        (!kv_len_dev && (kv_len <= 0 || kv_len > capacity)) || row_stride % 8) {
+        ecgb::set_error("ecgb_rope_append: bad argument");
+        return ECGB_ERR_INVALID;
+    }
+    const size_t items = (size_t)batch * ((size_t)(n_q_heads + n_kv_heads) * (head_dim / 16) + (size_t)n_kv_heads * head_dim / 8);
+    hipLaunchKernelGGL(rope_append_kernel, dim3(grid_for(items, 256)), dim3(256), 0, (hipStream_t)stream, (unsigned short *)qkv_dev, cos_dev, sin_dev, batch, n_q_heads,
+                       n_kv_heads, head_dim, row_stride, (unsigned short *)cache_dev, capacity, kv_len, kv_len_dev);
+    ECGB_CHECK_LAUNCH("rope_append");
 }
 
 extern "C" int ecgb_glu_fwd(const void *gate_up_dev, void *h_dev, size_t tokens, int inter, int gelu_tanh, void *stream)

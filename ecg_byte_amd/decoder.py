@@ -889,16 +889,14 @@ class HipCausalLM(nn.Module):
         for i in range(c.num_hidden_layers):
             h1, _, x = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
             qkv, _ = self._proj(i, "qkv", h1, self.wqkv[i].data)         # [B, QKV]
-            ops.rope_(qkv, cos, sin, Hq + Hkv, D, QKV)                   # the query heads and the key heads lie side by side: one launch
+            ops.rope_append_(qkv, cos, sin, Hq, Hkv, D, caches[i], n if n_dev is None else n_dev)   # RoPE on q and k, the rotated k and v into the cache: one launch
             ns = ops.decode_splits(caches[i].shape[1], qkv.shape[0], Hq)
             if n_dev is None:
-                caches[i][:, n - 1].copy_(qkv[:, Hq * D:])
                 if ns > 1:
                     ao = ops.attn_decode_split(qkv, caches[i], mask, n, Hq, Hkv, D, scale, ns)
                 else:
                     ao = ops.attn_decode(qkv, caches[i], mask, n, Hq, Hkv, D, scale)
             else:
-                ops.kv_append(qkv, Hq * D, caches[i], n_dev)
                 if ns > 1:
                     ao = ops.attn_decode_split(qkv, caches[i], mask, n_dev, Hq, Hkv, D, scale, ns, scratch=scratch)
                 else:

@@ -205,6 +205,17 @@ def rope_(x, cos, sin, n_heads, head_dim, row_stride, inverse=False):
     return x
 
 
+def rope_append_(qkv, cos, sin, Hq, Hkv, D, cache, kv_len):
+    """A decode step's rope_ on the q and k heads of qkv [B, (Hq + 2 Hkv) * D] (in place) and the append of the rotated k and of v at row kv_len - 1 of cache
+    [B, cap, 2 * Hkv * D], one launch (ecgb_rope_append).  kv_len: an int, or an int32[1] device tensor (a replayed graph)."""
+    B, cap, W = cache.shape
+    assert W == 2 * Hkv * D and cache.is_contiguous()
+    dyn = torch.is_tensor(kv_len)
+    _lib.check(_L().ecgb_rope_append(_p(qkv), _p(cos), _p(sin), B, Hq, Hkv, D, qkv.stride(0), _p(cache), cap, 0 if dyn else int(kv_len),
+                                     _p(kv_len) if dyn else None, _st()))
+    return qkv
+
+
 def glu_fwd(gate_up, gelu_tanh=False):
     inter = gate_up.shape[-1] // 2
     h = torch.empty(gate_up.shape[:-1] + (inter,), dtype=torch.bfloat16, device=gate_up.device)

@@ -307,6 +307,12 @@ int ecgb_gemm_tn_w4_bf16(const void *a_dev, long long lda, const void *b_dev, lo
 int ecgb_set_gemm_w4(int on);              /* 1 (default): ecgb_gemm_nt_bf16 / _cat / _glu send eligible problems to the four-wave kernel; 0: never; 2: every form it has (A/B, tests) */
 int ecgb_set_gemm_w4_group_m(int group_m);  /* its tile order: blocks of group_m tile rows (default 8; 0 = row by row) */
 
+/* A decode step's ecgb_rope (forward, on the new token's q and k heads) and its KV-cache append in one launch: qkv_dev [batch, (n_q + 2 n_kv) * head_dim] is rotated in
+ * place, the rotated k and the v of every sequence go to row kv_len - 1 of cache_dev [batch, capacity, 2 * n_kv * head_dim] (k | v).  kv_len_dev (int32[1] in device
+ * memory) replaces kv_len when given (a replayed graph).  The same bits as ecgb_rope followed by the copy / ecgb_kv_append. */
+int ecgb_rope_append(void *qkv_dev, const float *cos_dev, const float *sin_dev, int batch, int n_q_heads, int n_kv_heads, int head_dim, size_t row_stride,
+                     void *cache_dev, long long capacity, int kv_len, const int *kv_len_dev, void *stream);
+
 /* Greedy token choice of generate() (GenerationMixin._sample, generation/utils.py:3205: `next_tokens = torch.argmax(next_token_scores, dim=-1)`):
  * out[r] = index of the first maximum of the bf16 row x[r, 0:n] (rows `ld` elements apart).  One launch, no workspace. */
 int ecgb_argmax_bf16(const void *x_dev, long long ld, int rows, int n, int64_t *out_dev, void *stream);

@@ -778,3 +778,22 @@ def test_few_row_glu_projection_is_gemm_then_glu_bit_for_bit(ops, M, gelu):
         assert torch.equal(gu2, gu) and torch.equal(h2, h)
         none, h3 = ops.gemm_nt_glu(x, w, gelu_tanh=gelu, keep_gu=False, **kw)
         assert none is None and torch.equal(h3, h)
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,D", [(1, 8, 1, 256), (3, 32, 8, 64), (2, 4, 4, 128)])
+def test_rope_append_is_rope_then_cache_copy(ops, B, Hq, Hkv, D):
+    """ecgb_rope_append (a decode step's RoPE on q and k and the KV-cache append in one launch) = ecgb_rope followed by the copy of k | v into the cache row, with the
+    length as an argument and in device memory; the other cache rows stay."""
+    QKV, cap, n = (Hq + 2 * Hkv) * D, 37, 20
+    qkv = _bf(B, QKV, seed=111)
+    pos = torch.arange(B, device="cuda").float() * 7 + 3
+    fr = pos[:, None] * (1.0 / (10000.0 ** (torch.arange(0, D, 2, device="cuda").float() / D)))[None, :]
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    cache0 = _bf(B * cap, 2 * Hkv * D, seed=112).view(B, cap, 2 * Hkv * D).contiguous()
+    want_q = ops.rope_(qkv.clone(), cos, sin, Hq + Hkv, D, QKV)
+    want_c = cache0.clone()
+    want_c[:, n - 1] = want_q[:, Hq * D:]
+    for dyn in (False, True):
+        q2, c2 = qkv.clone(), cache0.clone()
+        ops.rope_append_(q2, cos, sin, Hq, Hkv, D, c2, torch.full((1,), n, dtype=torch.int32, device="cuda") if dyn else n)
+        assert torch.equal(q2, want_q) and torch.equal(c2, want_c), dyn
