@@ -114,6 +114,7 @@ def lib():
         "ecgb_transpose_multi_bf16": [vp, vp, vp, vp, vp, ci, ci, vp],
         "ecgb_embed_bwd_sorted": [vp, vp, vp, vp, sz, ci, f32, C.c_int64, vp],
         "ecgb_rmsnorm_fwd": [vp, vp, vp, vp, vp, vp, sz, ci, f32, ci, vp],
+        "ecgb_rmsnorm_lora_fwd": [vp, vp, vp, vp, vp, vp, sz, ci, f32, ci, vp, ll, ci, f32, vp, ll, vp],
         "ecgb_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, sz, ci, ci, vp, vp],
         "ecgb_rope": [vp, vp, vp, sz, ci, ci, sz, ci, vp],
         "ecgb_rope_append": [vp, vp, vp, ci, ci, ci, ci, sz, vp, ll, ci, vp, vp],

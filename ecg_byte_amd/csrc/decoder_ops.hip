@@ -226,6 +226,68 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const unsigned short *
     }
 }
 
+// rmsnorm_fwd_kernel for a decode step with adapters: n_a / 4 workgroups per row, each redoes the norm (4 KiB) and takes four rows of A; after the normalised row y is in LDS, its product with the site's stacked LoRA
+// down-projection follows in the same launch -- t[r] = bf16(scale * y . A[r, :]) for the n_a rows of A ([n_a, H] bf16).  The lanes walk y and A[r] in the pieces
+// and the order of the few-row GEMM (gemm_nt_skinny_kernel: lane l takes the 16-byte pieces at 8 l + 512 u, sums them in ascending k, then the butterfly), so t is
+// bit for bit what ecgb_gemm_nt_bf16(y, A, alpha = scale) returns: one launch less per adapter site and token.
+template <bool GEMMA>
+__global__ __launch_bounds__(256) void rmsnorm_lora_fwd_kernel(const unsigned short *a, const unsigned short *b, const unsigned short *w, unsigned short *y,
+                                                               unsigned short *sum_out, float *rstd, int H, float eps, const unsigned short *lora_a,
+                                                               long long lda, int n_a, float lora_scale, unsigned short *t_out, long long ldt)
+{
+    extern __shared__ __align__(16) unsigned short s_y[];     // the normalised row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t r = blockIdx.x;
+    const bool first = blockIdx.y == 0;                        // the workgroup that also writes y, the residual sum and rstd
+    if (wave == 0) {                                           // (rmsnorm_fwd_kernel's arithmetic)
+        const unsigned short *pa = a + r * H;
+        float ss = 0.f;
+        for (int c = lane * 8; c < H; c += 64 * 8) {
+            bf16x8 v = *reinterpret_cast<const bf16x8 *>(pa + c);
+            if (b) {
+                const bf16x8 u = *reinterpret_cast<const bf16x8 *>(b + r * H + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = f2bf(bf2f(v[j]) + bf2f(u[j]));
+                if (first) *reinterpret_cast<bf16x8 *>(sum_out + r * H + c) = v;
+                *reinterpret_cast<bf16x8 *>(s_y + c) = v;     // (the summed row waits here for the second sweep)
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = bf2f(v[j]); ss += f * f; }
+        }
+        ss = wave_sum(ss);
+        const float rs = rsqrtf(ss / (float)H + eps);
+        if (first && lane == 0 && rstd) rstd[r] = rs;
+        for (int c = lane * 8; c < H; c += 64 * 8) {
+            const bf16x8 v = b ? *reinterpret_cast<const bf16x8 *>(s_y + c) : *reinterpret_cast<const bf16x8 *>(pa + c);
+            const bf16x8 g = *reinterpret_cast<const bf16x8 *>(w + c);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (GEMMA) o[j] = f2bf(bf2f(v[j]) * rs * (1.0f + bf2f(g[j])));
+                else o[j] = f2bf(bf2f(f2bf(bf2f(v[j]) * rs)) * bf2f(g[j]));
+            }
+            if (first) *reinterpret_cast<bf16x8 *>(y + r * H + c) = o;
+            *reinterpret_cast<bf16x8 *>(s_y + c) = o;
+        }
+    }
+    __syncthreads();
+    {
+        const int ra = blockIdx.y * 4 + wave;               // one row of A per wave: the workgroups of a row (grid.y) redo the norm and share out the rows of A
+        if (ra >= n_a) return;
+        const unsigned short *pa = lora_a + (long long)ra * lda;
+        float acc = 0.f;
+        for (int k = lane * 8; k < H; k += 512) {
+            const bf16x8 vb = *reinterpret_cast<const bf16x8 *>(pa + k);
+            const bf16x8 va = *reinterpret_cast<const bf16x8 *>(s_y + k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += bf2f(va[j]) * bf2f(vb[j]);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if (lane == 0) t_out[r * ldt + ra] = f2bf(acc * lora_scale);
+    }
+}
+
 // dx = rs * (dy*w' - xhat * mean(dy*w'*xhat)) [+ dres];   dw(fp32) += sum_rows dy * xhat
 // w' = w (Llama) or 1 + w (Gemma).  One wave per row; dw accumulated per block in LDS then atomics.
 template <bool GEMMA>
@@ -1035,6 +1097,26 @@ extern "C" int ecgb_rmsnorm_fwd(const void *x_dev, const void *residual_dev, con
                            (const unsigned short *)residual_dev, (const unsigned short *)w_dev, (unsigned short *)y_dev,
                            (unsigned short *)sum_out_dev, rstd_dev, rows, hidden, eps);
     ECGB_CHECK_LAUNCH("rmsnorm_fwd");
+}
+
+extern "C" int ecgb_rmsnorm_lora_fwd(const void *x_dev, const void *residual_dev, const void *w_dev, void *y_dev, void *sum_out_dev, float *rstd_dev, size_t rows,
+                                     int hidden, float eps, int gemma, const void *lora_a_dev, long long lda, int n_a, float lora_scale, void *t_dev, long long ldt,
+                                     void *stream)
+{
+    if (hidden % 512 || (residual_dev && !sum_out_dev) || !lora_a_dev || !t_dev || n_a <= 0 || lda % 8 || rows == 0 || rows > 65535 || ((uintptr_t)lora_a_dev & 15)) {
+        ecgb::set_error("ecgb_rmsnorm_lora_fwd: bad arguments (hidden % 512, 16-byte aligned A)");
+        return ECGB_ERR_INVALID;
+    }
+    const size_t lds = (size_t)hidden * 2;
+    if (gemma)
+        hipLaunchKernelGGL(rmsnorm_lora_fwd_kernel<true>, dim3((unsigned)rows, (unsigned)((n_a + 3) / 4)), dim3(256), lds, (hipStream_t)stream, (const unsigned short *)x_dev,
+                           (const unsigned short *)residual_dev, (const unsigned short *)w_dev, (unsigned short *)y_dev, (unsigned short *)sum_out_dev, rstd_dev, hidden, eps,
+                           (const unsigned short *)lora_a_dev, lda, n_a, lora_scale, (unsigned short *)t_dev, ldt);
+    else
+        hipLaunchKernelGGL(rmsnorm_lora_fwd_kernel<false>, dim3((unsigned)rows, (unsigned)((n_a + 3) / 4)), dim3(256), lds, (hipStream_t)stream, (const unsigned short *)x_dev,
+                           (const unsigned short *)residual_dev, (const unsigned short *)w_dev, (unsigned short *)y_dev, (unsigned short *)sum_out_dev, rstd_dev, hidden, eps,
+                           (const unsigned short *)lora_a_dev, lda, n_a, lora_scale, (unsigned short *)t_dev, ldt);
+    ECGB_CHECK_LAUNCH("rmsnorm_lora_fwd");
 }
 
 extern "C" size_t ecgb_rmsnorm_bwd_scratch_floats(size_t rows, int hidden)

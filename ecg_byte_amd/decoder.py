@@ -136,7 +136,7 @@ class LoraSite(nn.Module):
         lo = 16 * self.spb * b
         return lo, lo + self.r
 
-    def project(self, x, w, training, keep=False, glu=None, rope=None):
+    def project(self, x, w, training, keep=False, glu=None, rope=None, t_pre=None):
         """y = x W^T + the adapter branch, [T, out].  Returns (y, what backward needs).
         glu = (gelu_tanh, keep_gu): the site is the fused gate|up projection and the GLU runs in the GEMM's epilogue; y is then the pair
         (gate|up or None, act(gate) * up)."""
@@ -147,7 +147,9 @@ class LoraSite(nn.Module):
             # training -- and HipCausalLM.lora_rng_state() / set_lora_rng_state() carry it across a checkpoint.
             self.calls += 1
             p, seed = self.p, (self.seed + 7919 * self.calls + 104729 * _dp_rank()) & 0x7FFFFFFF
-        if x.shape[0] <= 8 and p == 0.0:            # a decode step: the few-row GEMM reads A once at HBM speed
+        if t_pre is not None and p == 0.0:          # a decode step whose norm kernel already formed t = scale * x A^T (ops.rmsnorm_fwd(lora=...))
+            t, xd = t_pre, None
+        elif x.shape[0] <= 8 and p == 0.0:          # a decode step: the few-row GEMM reads A once at HBM speed
             t, xd = ops.gemm_nt(x, self.A.data, alpha=self.scale), None
         else:
             t, xd = ops.lora_down(x, self.A.data, self.n_sub, self.n_fields, self.scale, p, seed, keep_masked=keep)
@@ -491,7 +493,7 @@ class HipCausalLM(nn.Module):
             return ops.gemm_nn_splitk(dy, p.data, splits)
         return ops.gemm_nt(dy, self._shadow(key, p))
 
-    def _proj(self, i, key, x, w, training=False, keep=False, rope=None):
+    def _proj(self, i, key, x, w, training=False, keep=False, rope=None, t_pre=None):
         """One projection of layer i ("qkv", "o", "gu", "down"): x W^T, plus the LoRA branch of the site when adapters are on
         (in the same launch).  rope = (cos, sin, columns): the q|k|v projection leaves with its q and k heads rotated (apply_rotary_pos_emb in the GEMM's
         epilogue where the kernel takes the shape, else as the separate pass).  Returns (y, what the adapter's backward needs or None)."""
@@ -499,14 +501,14 @@ class HipCausalLM(nn.Module):
             if rope is not None:
                 return ops.gemm_nt_rope(x, w, rope[0], rope[1], rope[2]), None
             return ops.gemm_nt(x, w), None
-        return self.lora[i][key].project(x, w, training, keep, rope=rope)
+        return self.lora[i][key].project(x, w, training, keep, rope=rope, t_pre=t_pre)
 
-    def _proj_glu(self, i, x, training=False, keep=False, keep_gu=True):
+    def _proj_glu(self, i, x, training=False, keep=False, keep_gu=True, t_pre=None):
         """The MLP's gate|up projection with the GLU in the GEMM's epilogue: returns (gate|up [T, 2I] or None, act(gate) * up [T, I],
         adapter state).  gate|up is what the backward needs; inference passes keep_gu=False and the tensor is never written."""
         w = self.wgu[i].data
         if self.lora is not None:
-            (gu, hm), ls = self.lora[i]["gu"].project(x, w, training, keep, glu=(self.gemma, keep_gu))
+            (gu, hm), ls = self.lora[i]["gu"].project(x, w, training, keep, glu=(self.gemma, keep_gu), t_pre=t_pre)
             return gu, hm, ls
         if ops.glu_fusable(x.shape[0], w.shape[0] // 2):
             gu, hm = ops.gemm_nt_glu(x, w, gelu_tanh=self.gemma, keep_gu=keep_gu)
@@ -847,8 +849,12 @@ class HipCausalLM(nn.Module):
             else:
                 ao, _ = self._attn_materialised(qkv, mask, B, S)
             attn_delta, _ = self._proj(i, "o", ao, self.wo[i].data)
-            h2, _, x = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma)
-            _, hm, _ = self._proj_glu(i, h2, keep_gu=False)
+            if self.lora is not None and not self.training:
+                site = self.lora[i]["gu"]
+                h2, _, x, t2 = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma, lora=(site.A.data, site.scale))
+            else:
+                (h2, _, x), t2 = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma), None
+            _, hm, _ = self._proj_glu(i, h2, keep_gu=False, t_pre=t2)
             delta, _ = self._proj(i, "down", hm, self.wdown[i].data)
         hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
         if lpad:
@@ -887,8 +893,12 @@ class HipCausalLM(nn.Module):
         x = ops.embed_fwd(tokens, self.embed.data, self.embed_scale)    # [B, H]
         delta = None
         for i in range(c.num_hidden_layers):
-            h1, _, x = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
-            qkv, _ = self._proj(i, "qkv", h1, self.wqkv[i].data)         # [B, QKV]
+            if self.lora is not None and not self.training:             # adapters: the norm kernel forms the site's t = scale * h A^T on its way out
+                site = self.lora[i]["qkv"]
+                h1, _, x, t1 = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma, lora=(site.A.data, site.scale))
+            else:
+                (h1, _, x), t1 = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma), None
+            qkv, _ = self._proj(i, "qkv", h1, self.wqkv[i].data, t_pre=t1)         # [B, QKV]
             ops.rope_append_(qkv, cos, sin, Hq, Hkv, D, caches[i], n if n_dev is None else n_dev)   # RoPE on q and k, the rotated k and v into the cache: one launch
             ns = ops.decode_splits(caches[i].shape[1], qkv.shape[0], Hq)
             if n_dev is None:

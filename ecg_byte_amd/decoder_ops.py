@@ -124,13 +124,24 @@ def embed_bwd(ids, dout, grad_table_f32, scale=1.0):
     _lib.check(_L().ecgb_embed_bwd(_p(ids.contiguous()), _p(_bf(dout)), _p(grad_table_f32), ids.numel(), dout.shape[-1], float(scale), _st()))
 
 
-def rmsnorm_fwd(x, w, eps, residual=None, gemma=False):
-    """Returns (y, rstd, x_sum): x_sum = x + residual when residual is given (else x itself)."""
+def rmsnorm_fwd(x, w, eps, residual=None, gemma=False, lora=None):
+    """Returns (y, rstd, x_sum): x_sum = x + residual when residual is given (else x itself).
+    lora = (A [n, H] bf16, scale), up to eight rows (a decode step with adapters): also returns t = gemm_nt(y, A, alpha=scale) as a fourth value, computed in the
+    same launch (ecgb_rmsnorm_lora_fwd; the same bits as the few-row GEMM)."""
     H = x.shape[-1]
     rows = x.numel() // H
     y = torch.empty_like(x)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     s = torch.empty_like(x) if residual is not None else None
+    if lora is not None:
+        A, scale = lora
+        if rows <= 8 and H % 512 == 0 and A.stride(1) == 1:
+            t = torch.empty((rows, A.shape[0]), dtype=torch.bfloat16, device=x.device)
+            _lib.check(_L().ecgb_rmsnorm_lora_fwd(_p(_bf(x)), _p(residual), _p(_bf(w)), _p(y), _p(s), _p(rstd), rows, H, float(eps), int(gemma),
+                                                  _p(A), A.stride(0), A.shape[0], float(scale), _p(t), t.stride(0), _st()))
+            return y, rstd, (s if residual is not None else x), t
+        _lib.check(_L().ecgb_rmsnorm_fwd(_p(_bf(x)), _p(residual), _p(_bf(w)), _p(y), _p(s), _p(rstd), rows, H, float(eps), int(gemma), _st()))
+        return y, rstd, (s if residual is not None else x), gemm_nt(y.view(rows, H), A, alpha=scale)
     _lib.check(_L().ecgb_rmsnorm_fwd(_p(_bf(x)), _p(residual), _p(_bf(w)), _p(y), _p(s), _p(rstd), rows, H, float(eps), int(gemma), _st()))
     return y, rstd, (s if residual is not None else x)
 

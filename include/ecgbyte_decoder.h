@@ -307,6 +307,13 @@ int ecgb_gemm_tn_w4_bf16(const void *a_dev, long long lda, const void *b_dev, lo
 int ecgb_set_gemm_w4(int on);              /* 1 (default): ecgb_gemm_nt_bf16 / _cat / _glu send eligible problems to the four-wave kernel; 0: never; 2: every form it has (A/B, tests) */
 int ecgb_set_gemm_w4_group_m(int group_m);  /* its tile order: blocks of group_m tile rows (default 8; 0 = row by row) */
 
+/* ecgb_rmsnorm_fwd for the few rows of a decode step with adapters, followed in the same launch by the site's stacked LoRA down-projection of the normalised row:
+ * t_dev [rows, ldt] (bf16) = lora_scale * y . A^T for the n_a rows of lora_a_dev [n_a, lda] -- bit for bit ecgb_gemm_nt_bf16(y, A, alpha = lora_scale) on the few-row
+ * kernel (the same pieces in the same order).  hidden % 512 == 0; one workgroup per row. */
+int ecgb_rmsnorm_lora_fwd(const void *x_dev, const void *residual_dev, const void *w_dev, void *y_dev, void *sum_out_dev, float *rstd_dev, size_t rows,
+                          int hidden, float eps, int gemma, const void *lora_a_dev, long long lda, int n_a, float lora_scale, void *t_dev, long long ldt,
+                          void *stream);
+
 /* A decode step's ecgb_rope (forward, on the new token's q and k heads) and its KV-cache append in one launch: qkv_dev [batch, (n_q + 2 n_kv) * head_dim] is rotated in
  * place, the rotated k and the v of every sequence go to row kv_len - 1 of cache_dev [batch, capacity, 2 * n_kv * head_dim] (k | v).  kv_len_dev (int32[1] in device
  * memory) replaces kv_len when given (a replayed graph).  The same bits as ecgb_rope followed by the copy / ecgb_kv_append. */

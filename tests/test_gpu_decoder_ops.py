@@ -797,3 +797,19 @@ def test_rope_append_is_rope_then_cache_copy(ops, B, Hq, Hkv, D):
         q2, c2 = qkv.clone(), cache0.clone()
         ops.rope_append_(q2, cos, sin, Hq, Hkv, D, c2, torch.full((1,), n, dtype=torch.int32, device="cuda") if dyn else n)
         assert torch.equal(q2, want_q) and torch.equal(c2, want_c), dyn
+
+
+@pytest.mark.parametrize("rows", [1, 2, 5, 8])
+@pytest.mark.parametrize("gemma", [False, True])
+def test_rmsnorm_with_lora_down_projection_is_the_two_launches(ops, rows, gemma):
+    """ecgb_rmsnorm_lora_fwd (a decode step's RMSNorm with the adapter site's t = scale * y A^T formed in the same launch) = ecgb_rmsnorm_fwd followed by the few-row
+    GEMM: y, rstd, the residual sum and t, bit for bit."""
+    H = 2048
+    x, res, w = _bf(rows, H, seed=121), _bf(rows, H, seed=122), _bf(H, seed=123) * 0.1 + 1.0
+    A = _bf(64, H, seed=124) * 0.05
+    A[40:] = 0
+    for residual in (None, res):
+        y0, r0, s0 = ops.rmsnorm_fwd(x, w, 1e-5, residual=residual, gemma=gemma)
+        t0 = ops.gemm_nt(y0, A, alpha=2.0)
+        y1, r1, s1, t1 = ops.rmsnorm_fwd(x, w, 1e-5, residual=residual, gemma=gemma, lora=(A, 2.0))
+        assert torch.equal(y1, y0) and torch.equal(r1, r0) and torch.equal(s1, s0) and torch.equal(t1, t0)
