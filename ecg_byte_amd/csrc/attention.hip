@@ -247,6 +247,34 @@ __device__ __forceinline__ void lds_frags2x2_wait(bf16x8 &f00, bf16x8 &f01, bf16
     f00 = __builtin_bit_cast(bf16x8, r0); f01 = __builtin_bit_cast(bf16x8, r1);
     f10 = __builtin_bit_cast(bf16x8, r2); f11 = __builtin_bit_cast(bf16x8, r3);
 }
+// the dK/dV kernel's reads in front of a query half's first products -- the lane's lse and delta runs (2 x four 16-byte reads 32 bytes apart, from byte offsets
+// SOFF and SOFF + 256 of the statistics) and the first batch of row fragments (two lane addresses x two byte offsets) -- as ONE statement with one wait: apart they
+// were three LDS round trips in a row (~150 cycles each) before the first MFMA of every query half could issue
+template <int SOFF, int OFF0, int OFF1>
+__device__ __forceinline__ void lds_stats_frags_wait(f4v (&m0)[4], f4v (&m1)[4], bf16x8 &f00, bf16x8 &f01, bf16x8 &f10, bf16x8 &f11, unsigned sa, unsigned a0, unsigned a1)
+{
+    i4v r0, r1, r2, r3;
+    asm volatile("ds_read_b128 %0, %12 offset:%15\n\t"
+                 "ds_read_b128 %1, %12 offset:%16\n\t"
+                 "ds_read_b128 %2, %12 offset:%17\n\t"
+                 "ds_read_b128 %3, %12 offset:%18\n\t"
+                 "ds_read_b128 %4, %12 offset:%19\n\t"
+                 "ds_read_b128 %5, %12 offset:%20\n\t"
+                 "ds_read_b128 %6, %12 offset:%21\n\t"
+                 "ds_read_b128 %7, %12 offset:%22\n\t"
+                 "ds_read_b128 %8, %13 offset:%23\n\t"
+                 "ds_read_b128 %9, %13 offset:%24\n\t"
+                 "ds_read_b128 %10, %14 offset:%23\n\t"
+                 "ds_read_b128 %11, %14 offset:%24\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(m0[0]), "=&v"(m0[1]), "=&v"(m0[2]), "=&v"(m0[3]), "=&v"(m1[0]), "=&v"(m1[1]), "=&v"(m1[2]), "=&v"(m1[3]),
+                   "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                 : "v"(sa), "v"(a0), "v"(a1), "n"(SOFF), "n"(SOFF + 32), "n"(SOFF + 64), "n"(SOFF + 96), "n"(SOFF + 256), "n"(SOFF + 256 + 32), "n"(SOFF + 256 + 64),
+                   "n"(SOFF + 256 + 96), "n"(OFF0), "n"(OFF1)
+                 : "memory");
+    f00 = __builtin_bit_cast(bf16x8, r0); f01 = __builtin_bit_cast(bf16x8, r1);
+    f10 = __builtin_bit_cast(bf16x8, r2); f11 = __builtin_bit_cast(bf16x8, r3);
+}
 // byte offset inside a tile image of this lane's transposing read for fragment (db, kb = 0, s2 = 0): row_add = 0 for the first read, 8 for the second
 // (bit 3 of the row enters u, so the two are computed separately); the other (kb, s2) are 32 kb + 16 s2 rows further down, which leaves u alone: they go
 // into the instruction's offset field
@@ -1578,8 +1606,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_lean_kernel(AttnArgs 
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 f4v lse4[4], dl4[4];
-                if (qb == 0) { lds_rows4_wait<0>(lse4, statA + img); lds_rows4_wait<256>(dl4, statA + img); }
-                else { lds_rows4_wait<128>(lse4, statA + img); lds_rows4_wait<256 + 128>(dl4, statA + img); }
+                bf16x8 qfr[4], ofr[4];                        // row fragments of this query half: Q and dO images side by side (+ kTile), two k-steps per batch
+                if (qb == 0) lds_stats_frags_wait<0, 0, kTile>(lse4, dl4, qfr[0], ofr[0], qfr[1], ofr[1], statA + img, rbase[0] + img, rbase[1] + img);
+                else lds_stats_frags_wait<128, 4096, kTile + 4096>(lse4, dl4, qfr[0], ofr[0], qfr[1], ofr[1], statA + img, rbase[0] + img, rbase[1] + img);
                 f32x16 c_s = __builtin_shufflevector(__builtin_shufflevector(lse4[0], lse4[1], 0, 1, 2, 3, 4, 5, 6, 7),
                                                      __builtin_shufflevector(lse4[2], lse4[3], 0, 1, 2, 3, 4, 5, 6, 7),
                                                      0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
@@ -1592,9 +1621,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_lean_kernel(AttnArgs 
                     for (int r = 0; r < 16; ++r)
                         c_s[r] = ((unsigned)(qrel + (qb * 32 + 8 * (r >> 2) + (r & 3))) < vis_n) ? c_s[r] : INFINITY;
                 }
-                bf16x8 qfr[4], ofr[4];                        // row fragments of this query half: Q and dO images side by side (+ kTile), two k-steps per batch
-                if (qb == 0) lds_frags2x2_wait<0, kTile>(qfr[0], ofr[0], qfr[1], ofr[1], rbase[0] + img, rbase[1] + img);
-                else lds_frags2x2_wait<4096, kTile + 4096>(qfr[0], ofr[0], qfr[1], ofr[1], rbase[0] + img, rbase[1] + img);
                 f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[0], kf[0], c_s, 0, 0, 0);
                 f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr[0], vf[0], c_dp, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[1], kf[1], s, 0, 0, 0);
