@@ -1531,10 +1531,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_lean_kernel(AttnArgs 
     constexpr int kRing = kLeanRing, kAhead = kRing - 1;   // (see attn_fwd_lean_kernel)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kRing x kStep
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
-    int blk, head_in, group;
-    map_block((int)blockIdx.x, (A.S + NW * 32 - 1) / (NW * 32), 1, A.B * A.Hkv, false, blk, head_in, group);
+    // Under the causal mask key block j of a sequence has (n_blk - j) x as many query tiles as the last one: with one block per workgroup the 2 048 workgroups of the C3
+    // shape carry 8 .. 64 steps each and the 512 slots of the chip were 58 % used (phase timers: 3 680 cycles per step and wave, 73 728 steps, 453 us).  A workgroup takes
+    // the PAIR (j, n_blk - 1 - j): every workgroup the same work.
+    const int n_blk = (A.S + NW * 32 - 1) / (NW * 32);
+    int pair, head_in, group;
+    map_block((int)blockIdx.x, (n_blk + 1) / 2, 1, A.B * A.Hkv, false, pair, head_in, group);
     const int b = group / A.Hkv, g = group % A.Hkv;
     const int G = A.Hq / A.Hkv;
+    for (int half = 0; half < 2; ++half) {
+    const int blk = half == 0 ? pair : n_blk - 1 - pair;
+    if (half == 1) {
+        if (blk == pair) break;                              // an odd number of blocks: the middle one once
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the clamped re-issues of the last step may still be landing in the ring
+        __syncthreads();
+    }
     const int kk0 = blk * (NW * 32);
     const int ki = kk0 + wave * 32 + lr;
     const bool kvalid = ki < A.S;
@@ -1595,8 +1606,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_lean_kernel(AttnArgs 
     unsigned rbase[4];                                       // this lane's row fragment (row lr, k-step ks) inside an image; row 32 + lr is 4 KiB further
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) rbase[ks] = lds0 + lr * 128 + (((ks * 2 + h) ^ swz_u(lr)) << 4);
+#ifdef ECGB_PROFILE
+    unsigned long long prof_acc[8] = {};
+    long long t_prof = clock64();
+#endif
     for (int step = 0; step < n_steps; ++step) {
         issue_step(min(step + kAhead, n_steps - 1), (step + kAhead) % kRing);
+        APROF(0);
         const int buf = step % kRing;
         const unsigned img = (unsigned)(buf * kStep);
         const int t0 = t_begin + (step % tiles_per_head) * 64;
@@ -1609,6 +1625,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_lean_kernel(AttnArgs 
                 bf16x8 qfr[4], ofr[4];                        // row fragments of this query half: Q and dO images side by side (+ kTile), two k-steps per batch
                 if (qb == 0) lds_stats_frags_wait<0, 0, kTile>(lse4, dl4, qfr[0], ofr[0], qfr[1], ofr[1], statA + img, rbase[0] + img, rbase[1] + img);
                 else lds_stats_frags_wait<128, 4096, kTile + 4096>(lse4, dl4, qfr[0], ofr[0], qfr[1], ofr[1], statA + img, rbase[0] + img, rbase[1] + img);
+                APROF(1);
                 f32x16 c_s = __builtin_shufflevector(__builtin_shufflevector(lse4[0], lse4[1], 0, 1, 2, 3, 4, 5, 6, 7),
                                                      __builtin_shufflevector(lse4[2], lse4[3], 0, 1, 2, 3, 4, 5, 6, 7),
                                                      0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
@@ -1642,6 +1659,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_lean_kernel(AttnArgs 
                     tr_frags4_wait<kTile + 32 * 128, kTile + 48 * 128>(dotf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
                     tr_frags4_wait<32 * 128, 48 * 128>(qtf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
                 }
+                APROF(2);
                 float pr[16], ds[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1659,14 +1677,25 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_lean_kernel(AttnArgs 
                         accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s2][db], dsf, accK[db], 0, 0, 0);
                     }
                 }
+                APROF(3);
             }
         }
         lean_wait_tiles<(2 * PPW + 1) * (kAhead - 1)>();
+        APROF(4);
         __builtin_amdgcn_s_barrier();
+        APROF(5);
+#ifdef ECGB_PROFILE
+        prof_acc[6] += 1;
+#endif
     }
+#ifdef ECGB_PROFILE
+    if ((threadIdx.x & 63) == 0)
+        for (int kk = 0; kk < 7; ++kk) atomicAdd(&g_attn_prof[(threadIdx.x >> 6) * 8 + kk], prof_acc[kk]);
+#endif
     if (A.rope_cos) store_accT_rope_inv(accK, A.dk + (long long)g * D, A.lddk, rowbase + ki, kvalid, h, -A.scale, A.rope_cos + (rowbase + ki) * 32, A.rope_sin + (rowbase + ki) * 32);
     else store_accT<2>(accK, A.dk + (long long)g * D, A.lddk, rowbase + ki, kvalid, h, -A.scale);
     store_accT<2>(accV, A.dv + (long long)g * D, A.lddv, rowbase + ki, kvalid, h, 1.f);
+    }
 }
 
 template <int D, int DS, int WHICH = 0>
@@ -2140,7 +2169,7 @@ int attn_bwd_impl(const void *q_dev, long long ldq, const void *k_dev, long long
             const bool lk_lean = lean && !(g_attn_dma & 0x400);
             const int lk = lk_lean ? kLeanRing * (2 * 128 * 64 + g_lean_waves * 256) : 3 * (2 * 128 * 64 + 1024);
             auto kk = !lk_lean ? attn_bwd_dkv_dma_kernel : g_lean_waves == 8 ? attn_bwd_dkv_lean_kernel<8> : attn_bwd_dkv_lean_kernel<4>;
-            const unsigned gkl = (unsigned)((seq + g_lean_waves * 32 - 1) / (g_lean_waves * 32)) * (unsigned)n_kv_heads * (unsigned)batch;
+            const unsigned gkl = (unsigned)(((seq + g_lean_waves * 32 - 1) / (g_lean_waves * 32) + 1) / 2) * (unsigned)n_kv_heads * (unsigned)batch;   // key blocks in pairs (j, n - 1 - j)
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, lk) == hipSuccess)
                 hipLaunchKernelGGL(kk, dim3(lk_lean ? gkl : gk), dim3(lk_lean ? g_lean_waves * 64 : 256), lk, (hipStream_t)stream, A);
         } else {
