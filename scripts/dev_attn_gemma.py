@@ -1,6 +1,9 @@
 """Dev-only: fused attention forward / backward at C5's shape (Gemma-2B: 8 query heads, 1 KV head of 256, S 2048, B 8) and C3's."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ecg_byte_amd import _lib
+if os.environ.get("OLD"):
+    _lib.SO_PATH = os.path.join(os.path.dirname(_lib.SO_PATH), "libecgbyte_hip_old.so")   # A/B against a second build
 import torch
 from ecg_byte_amd import decoder_ops as ops
 for B, S, Hq, Hkv, D in [(8, 2048, 8, 1, 256), (32, 1024, 32, 8, 64), (8, 2048, 16, 4, 128)]:
