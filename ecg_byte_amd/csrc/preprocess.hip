@@ -6,8 +6,9 @@
 //
 // Every stage is a recursion along time (IIR state, tridiagonal sweep, nothing to tile), so the parallel axis is the SEQUENCE: one lane =
 // one (record, lead) time series, 49 152 lanes for 4 096 twelve-lead records.  The records arrive as [record][time][lead] (what
-// wfdb.rdsamp returns, preprocess_utils.py:126); intermediates live TIME-MAJOR, [time][sequence], so that the 64 lanes of a wave touch
-// 512 contiguous bytes at every step.  Arithmetic follows the reference's libraries operation by operation where that is what fixes
+// wfdb.rdsamp returns, preprocess_utils.py:126); intermediates live TIME-MAJOR PER WAVE, [wave][time][64 lanes]: the 64 lanes of a wave touch
+// 512 contiguous bytes at every step and a wave's consecutive steps are consecutive 512-byte rows (one stream per wave for DRAM pages and the TLB;
+// the first layout, [time][all sequences], put a wave's consecutive steps 393 KB apart).  Arithmetic follows the reference's libraries operation by operation where that is what fixes
 // the bits (scipy's direct-form-II-transposed loop, its odd extension and initial conditions); -ffp-contract=off keeps a*b+c two roundings.
 #include <hip/hip_runtime.h>
 
@@ -30,9 +31,10 @@ struct Filt {
 struct FiltfiltArgs {
     const double *x;                 // [R, n, L]
     double *y;                       // [R, n, L]
-    double *ext;                     // scratch [n + 2 * max edge][S]: the forward pass's output over the extended signal
-    double *mid;                     // scratch [n][S]: a filter's result, the next filter's input
-    int R, n, L, n_filters;
+    double *ext;                     // scratch [wave][n + 2 * max edge][64]: the forward pass's output over the extended signal
+    double *mid;                     // scratch [wave][n][64]: a filter's result, the next filter's input
+    int R, n, L, n_filters, ext_rows;   // ext_rows = n + 2 * max edge
+    unsigned char *flags;            // optional [R]: set to 1 where a record's result holds a value that is not finite
     Filt f[kMaxFilters];
 };
 
@@ -44,9 +46,12 @@ struct FiltfiltArgs {
 // (independent of each other and of the recursion) before the current block is filtered, and a block's results are stored together.  The first version loaded
 // one sample, filtered it and stored it: hipcc cannot move a load above the previous store (`ext`, `mid` and the record may alias for all it knows), so every
 // step paid a memory round trip -- 560 cycles per step against ~60 of arithmetic, one wave per SIMD (22.6 ms for 4 096 records).
-constexpr int kBlk = 16;
-template <int NB, typename SRC, typename DST>
-__device__ __forceinline__ void filtfilt_one(const Filt &F, int n, SRC src, double *ext, size_t S, size_t seq, DST dst)
+#ifndef ECGB_PRE_BLK
+#define ECGB_PRE_BLK 32
+#endif
+constexpr int kBlk = ECGB_PRE_BLK;
+template <int NB, typename SRC, typename DST, typename FLUSH>
+__device__ __forceinline__ void filtfilt_one(const Filt &F, int n, SRC src, double *ext, size_t S, size_t seq, DST dst, FLUSH flush)
 {
     const int e = F.edge, N = n + 2 * e;
     double z[NB - 1];
@@ -97,50 +102,82 @@ __device__ __forceinline__ void filtfilt_one(const Filt &F, int n, SRC src, doub
 #pragma unroll
         for (int u = 0; u < kBlk; ++u) {
             const int pos = N - 1 - (i0 + u) - e;
-            if (i0 + u < N && pos >= 0 && pos < n) dst(pos, out[u]);
+            dst(pos, out[u], u, i0 + u < N && pos >= 0 && pos < n);
         }
+        flush(N - 1 - i0 - e);                               // the block's positions: this one downwards
 #pragma unroll
         for (int u = 0; u < kBlk; ++u) cur[u] = nxt[u];
     }
 }
 
-template <typename SRC, typename DST>
-__device__ __forceinline__ void filtfilt_dispatch(const Filt &F, int n, SRC src, double *ext, size_t S, size_t seq, DST dst)
+template <typename SRC, typename DST, typename FLUSH>
+__device__ __forceinline__ void filtfilt_dispatch(const Filt &F, int n, SRC src, double *ext, size_t S, size_t seq, DST dst, FLUSH flush)
 {
     switch (F.nb) {
-    case 2: filtfilt_one<2>(F, n, src, ext, S, seq, dst); break;
-    case 3: filtfilt_one<3>(F, n, src, ext, S, seq, dst); break;
-    case 4: filtfilt_one<4>(F, n, src, ext, S, seq, dst); break;
-    case 5: filtfilt_one<5>(F, n, src, ext, S, seq, dst); break;
-    case 6: filtfilt_one<6>(F, n, src, ext, S, seq, dst); break;
-    case 7: filtfilt_one<7>(F, n, src, ext, S, seq, dst); break;
-    case 8: filtfilt_one<8>(F, n, src, ext, S, seq, dst); break;
-    default: filtfilt_one<9>(F, n, src, ext, S, seq, dst); break;
+    case 2: filtfilt_one<2>(F, n, src, ext, S, seq, dst, flush); break;
+    case 3: filtfilt_one<3>(F, n, src, ext, S, seq, dst, flush); break;
+    case 4: filtfilt_one<4>(F, n, src, ext, S, seq, dst, flush); break;
+    case 5: filtfilt_one<5>(F, n, src, ext, S, seq, dst, flush); break;
+    case 6: filtfilt_one<6>(F, n, src, ext, S, seq, dst, flush); break;
+    case 7: filtfilt_one<7>(F, n, src, ext, S, seq, dst, flush); break;
+    case 8: filtfilt_one<8>(F, n, src, ext, S, seq, dst, flush); break;
+    default: filtfilt_one<9>(F, n, src, ext, S, seq, dst, flush); break;
     }
 }
 
+// PLANAR: the last filter's result goes out sequence by sequence, y[sequence][time] -- the layout the workgroup-per-sequence wavelet kernel reads with whole
+// lines.  A lane's results are consecutive in time, 8 bytes a step; written lane by lane they would be 64 partial lines per store instruction, so a block of
+// kBlk steps x 64 lanes crosses LDS and leaves as rows of kBlk consecutive doubles per sequence (whole lines).
+template <bool PLANAR>
 __global__ __launch_bounds__(64) void filtfilt_kernel(FiltfiltArgs A)
 {
+    __shared__ double tile[PLANAR ? kBlk * 65 : 1];
     const size_t S = (size_t)A.R * A.L;
     const size_t seq = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (seq >= S) return;
+    const bool full_wave = ((size_t)blockIdx.x + 1) * 64 <= S;                    // (a partial last wave stores lane by lane)
+    const int lane = threadIdx.x;
     const size_t r = seq / A.L, l = seq % A.L;
     const double *xin = A.x + (r * A.n) * A.L + l;
-    double *yout = A.y + (r * A.n) * A.L + l;
-    const int L = A.L;
+    double *yout = PLANAR ? A.y + seq * (size_t)A.n : A.y + (r * A.n) * A.L + l;
+    const int L = A.L, n = A.n;
+    double *ext = A.ext + (size_t)blockIdx.x * A.ext_rows * 64 + threadIdx.x;     // this wave's rows, this lane's column
+    double *mid = A.mid + (size_t)blockIdx.x * A.n * 64 + threadIdx.x;
+    bool bad = false;                                                             // a value that is not finite went out (flags: check_nan_inf's test)
     for (int k = 0; k < A.n_filters; ++k) {
         const bool first = k == 0, lastf = k == A.n_filters - 1;
         auto src_x = [&](int t) -> double { return xin[(size_t)t * L]; };
-        auto src_m = [&](int t) -> double { return A.mid[(size_t)t * S + seq]; };
-        auto dst_y = [&](int t, double v) { yout[(size_t)t * L] = v; };
-        auto dst_m = [&](int t, double v) { A.mid[(size_t)t * S + seq] = v; };
+        auto src_m = [&](int t) -> double { return mid[(size_t)t * 64]; };
+        auto dst_y = [&](int t, double v, int u, bool ok) {
+            if (ok) bad |= !isfinite(v);
+            if (PLANAR) {
+                if (full_wave) tile[u * 65 + lane] = v;
+                else if (ok) yout[t] = v;
+            } else if (ok) yout[(size_t)t * L] = v;
+        };
+        auto dst_m = [&](int t, double v, int, bool ok) { if (ok) mid[(size_t)t * 64] = v; };
+        auto no_flush = [](int) {};
+        auto flush_y = [&](int top) {                                             // the tile holds steps u = 0 .. kBlk - 1 of every lane: positions top - u
+            if (!PLANAR || !full_wave) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            double *y0 = A.y + ((size_t)blockIdx.x * 64) * (size_t)n;
+#pragma unroll 4
+            for (int q = 0; q < kBlk; ++q) {
+                const int idx = q * 64 + lane, sq = idx / kBlk, u = idx % kBlk, pos = top - u;
+                if (pos >= 0 && pos < n) y0[(size_t)sq * n + pos] = tile[u * 65 + sq];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
         // a filter reads all of its input before the backward pass writes the first output sample, so `mid` can be source and
         // destination of the same filter
-        if (first && lastf) filtfilt_dispatch(A.f[k], A.n, src_x, A.ext, S, seq, dst_y);
-        else if (first) filtfilt_dispatch(A.f[k], A.n, src_x, A.ext, S, seq, dst_m);
-        else if (lastf) filtfilt_dispatch(A.f[k], A.n, src_m, A.ext, S, seq, dst_y);
-        else filtfilt_dispatch(A.f[k], A.n, src_m, A.ext, S, seq, dst_m);
+        if (first && lastf) filtfilt_dispatch(A.f[k], A.n, src_x, ext, 64, 0, dst_y, flush_y);
+        else if (first) filtfilt_dispatch(A.f[k], A.n, src_x, ext, 64, 0, dst_m, no_flush);
+        else if (lastf) filtfilt_dispatch(A.f[k], A.n, src_m, ext, 64, 0, dst_y, flush_y);
+        else filtfilt_dispatch(A.f[k], A.n, src_m, ext, 64, 0, dst_m, no_flush);
     }
+    if (A.flags && bad) A.flags[r] = 1;
 }
 
 // ---- cubic-spline resampling -----------------------------------------------------------------------------------------------------------
@@ -152,13 +189,18 @@ __global__ __launch_bounds__(64) void filtfilt_kernel(FiltfiltArgs A)
 // one Thomas sweep per sequence over rows 2 .. n-3 (the pivots 1 / (4 - c') are the same for every sequence and reach their fixed point
 // 2 - sqrt(3) in double precision within ~20 rows), then  S(i + u) = y[i] + u (dy - (2 M[i] + M[i+1]) / 6) + u^2 M[i] / 2 + u^3 (M[i+1] - M[i]) / 6.
 // Agreement with scipy: the two solves differ by rounding only (1e-13 of the signal's range measured, tests/test_gpu_preprocess.py).
+constexpr int kMaxLeadMap = 32;
 struct ResampleArgs {
-    const double *x;                 // [R, n, L]
+    const double *x;                 // [R, n, L], or [R * L][n] (PLANAR_IN)
     double *y;                       // [R, m, L]
-    double *M;                       // scratch [n][S]
+    double *M;                       // scratch [wave][n][64]
     int R, n, L, m;
+    unsigned char *flags;            // optional [R]: 1 where a record's result holds a value that is not finite
+    int use_map;
+    unsigned char out_lead[kMaxLeadMap];   // use_map: lead l of the input is lead out_lead[l] of the output (the MIMIC reorder, preprocess_utils.py:35-40)
 };
 
+template <bool PLANAR_IN>
 __global__ __launch_bounds__(64) void resample_cubic_kernel(ResampleArgs A)
 {
     const size_t S = (size_t)A.R * A.L;
@@ -166,10 +208,11 @@ __global__ __launch_bounds__(64) void resample_cubic_kernel(ResampleArgs A)
     if (seq >= S) return;
     const size_t r = seq / A.L, l = seq % A.L;
     const int n = A.n, m = A.m, L = A.L;
-    const double *x = A.x + (r * n) * L + l;
-    double *out = A.y + (r * m) * L + l;
-    double *M = A.M + seq;
-    auto Y = [&](int i) -> double { return x[(size_t)i * L]; };
+    const double *x = PLANAR_IN ? A.x + seq * (size_t)n : A.x + (r * n) * L + l;
+    double *out = A.y + (r * m) * L + (A.use_map ? (size_t)A.out_lead[l] : l);
+    double *M = A.M + (size_t)blockIdx.x * n * 64 + threadIdx.x;
+    auto Y = [&](int i) -> double { return PLANAR_IN ? x[i] : x[(size_t)i * L]; };
+    bool bad = false;
     auto rhs = [&](int i) -> double { return 6.0 * (Y(i + 1) - 2.0 * Y(i) + Y(i - 1)); };
     constexpr int kTab = 32;
     double cp[kTab];                                         // c'[2 + k]; c'[2 + k] = c'[2 + kTab - 1] beyond the table (fixed point)
@@ -178,13 +221,13 @@ __global__ __launch_bounds__(64) void resample_cubic_kernel(ResampleArgs A)
     for (int k = 1; k < kTab; ++k) cp[k] = 1.0 / (4.0 - cp[k - 1]);
     auto cprime = [&](int i) -> double { const int k = i - 2; return cp[k < kTab ? k : kTab - 1]; };
     const double M1 = rhs(1) / 6.0, Mn2 = rhs(n - 2) / 6.0;
-    M[(size_t)1 * S] = M1;
-    M[(size_t)(n - 2) * S] = Mn2;
+    M[(size_t)1 * 64] = M1;
+    M[(size_t)(n - 2) * 64] = Mn2;
     // Round 3: the sweeps and the evaluation move their samples in blocks of kBlk (loads of a block issued together, results stored together, the next
     // block's loads in flight meanwhile): same arithmetic in the same order, no memory round trip per step (see filtfilt_one).
     if (n >= 6) {                                            // rows 2 .. n-3
         double dprev = (rhs(2) - M1) * cprime(2);
-        M[(size_t)2 * S] = dprev;
+        M[(size_t)2 * 64] = dprev;
         auto ycl = [&](int i) -> double { return Y(min(max(i, 0), n - 1)); };
         double yc[kBlk + 2], yn[kBlk + 2];
 #pragma unroll
@@ -204,13 +247,13 @@ __global__ __launch_bounds__(64) void resample_cubic_kernel(ResampleArgs A)
                 }
             }
 #pragma unroll
-            for (int u = 0; u < kBlk; ++u) if (i0 + u <= n - 3) M[(size_t)(i0 + u) * S] = out[u];
+            for (int u = 0; u < kBlk; ++u) if (i0 + u <= n - 3) M[(size_t)(i0 + u) * 64] = out[u];
 #pragma unroll
             for (int u = 0; u < kBlk + 2; ++u) yc[u] = yn[u];
         }
         double Mnext = dprev;                                // M[n-3]
         double mc[kBlk], mn[kBlk];
-        auto mcl = [&](int i) -> double { return M[(size_t)max(i, 2) * S]; };
+        auto mcl = [&](int i) -> double { return M[(size_t)max(i, 2) * 64]; };
 #pragma unroll
         for (int u = 0; u < kBlk; ++u) mc[u] = mcl(n - 4 - u);
         for (int i0 = n - 4; i0 >= 2; i0 -= kBlk) {
@@ -223,15 +266,15 @@ __global__ __launch_bounds__(64) void resample_cubic_kernel(ResampleArgs A)
                 if (i >= 2) { Mnext = mc[u] - cprime(i) * Mnext; out[u] = Mnext; }
             }
 #pragma unroll
-            for (int u = 0; u < kBlk; ++u) if (i0 - u >= 2) M[(size_t)(i0 - u) * S] = out[u];
+            for (int u = 0; u < kBlk; ++u) if (i0 - u >= 2) M[(size_t)(i0 - u) * 64] = out[u];
 #pragma unroll
             for (int u = 0; u < kBlk; ++u) mc[u] = mn[u];
         }
     } else if (n == 5) {
-        M[(size_t)2 * S] = (rhs(2) - M1 - Mn2) / 4.0;
+        M[(size_t)2 * 64] = (rhs(2) - M1 - Mn2) / 4.0;
     }
-    M[0] = 2.0 * M[(size_t)1 * S] - M[(size_t)2 * S];
-    M[(size_t)(n - 1) * S] = 2.0 * M[(size_t)(n - 2) * S] - M[(size_t)(n - 3) * S];
+    M[0] = 2.0 * M[(size_t)1 * 64] - M[(size_t)2 * 64];
+    M[(size_t)(n - 1) * 64] = 2.0 * M[(size_t)(n - 2) * 64] - M[(size_t)(n - 3) * 64];
     for (int j0 = 0; j0 < m; j0 += kBlk) {
         double y0[kBlk], y1[kBlk], m0[kBlk], m1[kBlk], uu[kBlk];
 #pragma unroll
@@ -241,15 +284,18 @@ __global__ __launch_bounds__(64) void resample_cubic_kernel(ResampleArgs A)
             int i = (int)sx;
             if (i > n - 2) i = n - 2;
             uu[u] = sx - (double)i;
-            y0[u] = Y(i); y1[u] = Y(i + 1); m0[u] = M[(size_t)i * S]; m1[u] = M[(size_t)(i + 1) * S];
+            y0[u] = Y(i); y1[u] = Y(i + 1); m0[u] = M[(size_t)i * 64]; m1[u] = M[(size_t)(i + 1) * 64];
         }
 #pragma unroll
         for (int u = 0; u < kBlk; ++u) {
             if (j0 + u >= m) continue;
             const double c1 = (y1[u] - y0[u]) - (2.0 * m0[u] + m1[u]) / 6.0, c2 = 0.5 * m0[u], c3 = (m1[u] - m0[u]) / 6.0;
-            out[(size_t)(j0 + u) * L] = y0[u] + uu[u] * (c1 + uu[u] * (c2 + uu[u] * c3));
+            const double v = y0[u] + uu[u] * (c1 + uu[u] * (c2 + uu[u] * c3));
+            bad |= !isfinite(v);
+            out[(size_t)(j0 + u) * L] = v;
         }
     }
+    if (A.flags && bad) A.flags[r] = 1;
 }
 
 // ---- wavelet denoising ---------------------------------------------------------------------------------------------------------------------
@@ -268,7 +314,8 @@ constexpr int kWF = 12, kLevels = 4;
 struct WaveletArgs {
     const double *x;                 // [R, n, L]
     double *y;                       // [R, n, L]
-    double *work;                    // scratch, time-major: per level l (1..4) bands A_l and D_l of len[l] + 2 rows
+    double *work;                    // scratch [wave][rows][64]: per level l (1..4) bands A_l and D_l of len[l] + 2 rows
+    long long rows;                  // rows per wave
     int R, n, L;
     int len[kLevels + 1];            // len[0] = n, len[l] = (len[l-1] + 11) / 2
     long long offA[kLevels + 1], offD[kLevels + 1];   // row offsets into `work`
@@ -284,15 +331,18 @@ __global__ __launch_bounds__(64) void wavelet_denoise_kernel(WaveletArgs A)
     const int L = A.L, n = A.n;
     const double *x = A.x + (r * n) * L + l0;
     double *out = A.y + (r * n) * L + l0;
-    double *W = A.work + seq;
-    auto band = [&](long long off, int i) -> double & { return W[(size_t)(off + i) * S]; };
+    double *W = A.work + (size_t)blockIdx.x * A.rows * 64 + threadIdx.x;
+    auto band = [&](long long off, int i) -> double & { return W[(size_t)(off + i) * 64]; };
     double lo[kWF], hi[kWF];
 #pragma unroll
     for (int k = 0; k < kWF; ++k) { lo[k] = kDb6Lo[k]; hi[k] = ((k & 1) ? 1.0 : -1.0) * kDb6Lo[kWF - 1 - k]; }
     // Round 3: every loop below moves its samples in blocks (the loads of a block together, its results stored together): the sums are formed in the
     // order they had, so the values are the first version's; what is gone is one memory round trip per coefficient (see filtfilt_one) and three quarters of
     // the median's selection passes.
-    constexpr int kOB = 8;                                   // outputs per block
+#ifndef ECGB_PRE_OB
+#define ECGB_PRE_OB 8
+#endif
+    constexpr int kOB = ECGB_PRE_OB;                         // outputs per block
     // ---- wavedec: cA[o], cD[o] = sum_j f[j] xe[2 o + 1 - j]: a block of kOB outputs reads xe[2 o0 - 10 .. 2 (o0 + kOB - 1) + 1]
     for (int lev = 1; lev <= kLevels; ++lev) {
         const int N = A.len[lev - 1], Nc = A.len[lev];
@@ -427,6 +477,172 @@ __global__ __launch_bounds__(64) void wavelet_denoise_kernel(WaveletArgs A)
     }
 }
 
+// ---- the same stage with ONE WORKGROUP PER SEQUENCE (the path ecgb_wavelet_denoise_f64 takes whenever a sequence's bands fit in LDS) ------------------------
+// The transform is a pair of FIR filters, not a recursion: every coefficient of a level is independent of its neighbours, so the parallel axis can be TIME and the
+// sequence can stay on chip.  256 lanes share one sequence: the samples are read once into LDS, the four analysis levels, the median, the shrinkage and three of the
+// four synthesis levels run LDS to LDS, and the last synthesis level writes the result -- 16 bytes of HBM traffic per sample where the lane-per-sequence kernel above
+// moves ~92 (every band written and read back through its time-major scratch, the median's sweeps).  Each coefficient is the sum the kernel above forms, term by term
+// in the same order, and the median is the same order statistic: the results are the same bits (tests/test_gpu_preprocess.py compares the two kernels).
+// LDS: [x, later A2 D2 A3 D3 A4 D4 | A1 | D1] -- level 1 reads x and writes A1, D1; from level 2 on x is dead and the small bands take its place; synthesis writes
+// A3', A2', A1' where A3, A2, A1 were.  80.1 KB at n = 5000: two workgroups per CU.
+// The records arrive [record][time][lead]: a sequence's samples are 8 bytes every 96.  XCD k takes the k-th eighth of the sequences in order, so the twelve leads of a
+// record run side by side on one XCD and share the record's lines in its L2 (HBM sees each line once; the 12-fold line traffic is L2 -> CU).
+struct WaveletWgArgs {
+    const double *x;
+    double *y;
+    int R, n, L;
+    int len[kLevels + 1];
+    int offA[kLevels + 1], offD[kLevels + 1];   // LDS offsets in doubles (offA[0] = x)
+    double epsilon;
+};
+
+constexpr int kWgLanes = 256;
+
+// PLANAR: x and y are [sequence][time] (what ecgb_filtfilt_planar_f64 writes): the workgroup's loads and stores are whole lines
+template <bool PLANAR>
+__global__ __launch_bounds__(kWgLanes) void wavelet_denoise_wg_kernel(WaveletWgArgs A)
+{
+    extern __shared__ __align__(16) double s_w[];
+    __shared__ unsigned long long s_key[2];
+    __shared__ int s_nan;
+    const size_t S = (size_t)A.R * A.L;
+    const size_t per_xcd = (S + 7) / 8;
+    const size_t seq = (size_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((size_t)(blockIdx.x >> 3) >= per_xcd || seq >= S) return;
+    const size_t r = seq / A.L, l0 = seq % A.L;
+    const int L = A.L, n = A.n, tid = threadIdx.x;
+    const double *x = PLANAR ? A.x + seq * (size_t)n : A.x + (r * n) * L + l0;
+    double *out = PLANAR ? A.y + seq * (size_t)n : A.y + (r * n) * L + l0;
+    const size_t stride = PLANAR ? 1 : (size_t)L;
+    double lo[kWF], hi[kWF];
+#pragma unroll
+    for (int k = 0; k < kWF; ++k) { lo[k] = kDb6Lo[k]; hi[k] = ((k & 1) ? 1.0 : -1.0) * kDb6Lo[kWF - 1 - k]; }
+    if (tid == 0) s_nan = 0;
+    // the samples: kLoadBatch loads per lane in flight before the first is used (n = 5000: one memory round trip for the sequence)
+    constexpr int kLoadBatch = 20;
+    for (int i0 = tid; i0 < n; i0 += kLoadBatch * kWgLanes) {
+        double v[kLoadBatch];
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; ++u) v[u] = x[(size_t)min(i0 + u * kWgLanes, n - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < kLoadBatch; ++u) if (i0 + u * kWgLanes < n) s_w[i0 + u * kWgLanes] = v[u];
+    }
+    __syncthreads();
+    // ---- wavedec
+    for (int lev = 1; lev <= kLevels; ++lev) {
+        const int N = A.len[lev - 1], Nc = A.len[lev];
+        const double *in = s_w + A.offA[lev - 1];
+        double *ca = s_w + A.offA[lev], *cd = s_w + A.offD[lev];
+        for (int o = tid; o < Nc; o += kWgLanes) {
+            double a = 0.0, d = 0.0;
+            if (2 * o - (kWF - 2) >= 0 && 2 * o + 1 < N) {  // the window lies inside the band: twelve reads at constant offsets, no index arithmetic
+                const double *pw = in + 2 * o + 1;
+#pragma unroll
+                for (int j = 0; j < kWF; ++j) {
+                    const double v = pw[-j];
+                    a += lo[j] * v;
+                    d += hi[j] * v;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < kWF; ++j) {
+                    int i = 2 * o + 1 - j;                   // symmetric extension: ... x1 x0 | x0 x1 ... x[N-1] | x[N-1] x[N-2] ...
+                    if (i < 0) i = -1 - i;
+                    else if (i >= N) i = 2 * N - 1 - i;
+                    i = min(max(i, 0), N - 1);
+                    const double v = in[i];
+                    a += lo[j] * v;
+                    d += hi[j] * v;
+                }
+            }
+            ca[o] = a; cd[o] = d;
+        }
+        __syncthreads();
+    }
+    // ---- median of |cD4|: the k-th order statistic is the largest value with at most k values below it.  |cD4| goes to LDS once (where A1 was: dead until the
+    // synthesis rewrites it), every lane counts the values below its own (n4 broadcast reads) and the candidates meet in an LDS maximum on the bit patterns
+    // (monotone for x >= 0).  The same order statistics as the radix select of the kernel above.
+    const int n4 = A.len[kLevels];
+    const double *d4 = s_w + A.offD[kLevels];
+    double *mag4 = s_w + A.offA[1];
+    {
+        bool nan_here = false;
+        for (int i = tid; i < n4; i += kWgLanes) { const double v = d4[i]; nan_here |= isnan(v); mag4[i] = fabs(v); }
+        if (nan_here) s_nan = 1;
+        if (tid < 2) s_key[tid] = 0ull;
+    }
+    __syncthreads();
+    const bool any_nan = s_nan != 0;
+    if (!any_nan) {
+        const int k_lo = (n4 & 1) ? n4 / 2 : n4 / 2 - 1, k_hi = n4 / 2;
+        for (int i = tid; i < n4; i += kWgLanes) {
+            const double v = mag4[i];
+            int below = 0;
+            int j = 0;
+            for (; j + 4 <= n4; j += 4) {
+                const double u0 = mag4[j], u1 = mag4[j + 1], u2 = mag4[j + 2], u3 = mag4[j + 3];
+                below += (u0 < v ? 1 : 0) + (u1 < v ? 1 : 0) + (u2 < v ? 1 : 0) + (u3 < v ? 1 : 0);
+            }
+            for (; j < n4; ++j) below += mag4[j] < v ? 1 : 0;
+            const unsigned long long key = (unsigned long long)__double_as_longlong(v);
+            if (below <= k_lo) atomicMax(&s_key[0], key);
+            if (below <= k_hi) atomicMax(&s_key[1], key);
+        }
+    }
+    __syncthreads();
+    const double med_lo = __longlong_as_double((long long)s_key[0]), med_hi = __longlong_as_double((long long)s_key[1]);
+    const double med = any_nan ? __longlong_as_double(0x7ff8000000000000ll) : (n4 & 1) ? med_lo : 0.5 * (med_lo + med_hi);
+    const double thr = med == 0.0 ? 0.0 : med / 0.6745;
+    for (int lev = 1; lev <= kLevels; ++lev) {
+        double *cd = s_w + A.offD[lev];
+        for (int i = tid; i < A.len[lev]; i += kWgLanes) {
+            const double c = cd[i], mag = fabs(c);
+            double f = 1.0 - thr / mag;                      // pywt.threshold 'soft': data * clip(1 - value / |data|, 0)
+            f = f < 0.0 ? 0.0 : f;
+            const double t = c * f;
+            cd[i] = (isfinite(t) && mag > A.epsilon) ? t : 0.0;
+        }
+    }
+    __syncthreads();
+    // ---- waverec
+    for (int lev = kLevels; lev >= 1; --lev) {
+        const int Nd = A.len[lev];
+        const int No = 2 * Nd - kWF + 2;
+        const double *ca = s_w + A.offA[lev], *cd = s_w + A.offD[lev];
+        double *dst = s_w + A.offA[lev - 1];
+        // outputs 2 q and 2 q + 1 read the same six coefficients of each band (o = q + u; k = 2 u + 1 for the even output, 2 u for the odd one): a lane takes the pair
+        for (int q = tid; 2 * q < No; q += kWgLanes) {
+            double sa0 = 0.0, sd0 = 0.0, sa1 = 0.0, sd1 = 0.0;
+            if (q + 5 < Nd) {
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const double a = ca[q + u], d = cd[q + u];
+                    sa0 += a * lo[2 * u + 1]; sd0 += d * hi[2 * u + 1];
+                    sa1 += a * lo[2 * u];     sd1 += d * hi[2 * u];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    if (q + u < Nd) {
+                        const double a = ca[q + u], d = cd[q + u];
+                        sa0 += a * lo[2 * u + 1]; sd0 += d * hi[2 * u + 1];
+                        sa1 += a * lo[2 * u];     sd1 += d * hi[2 * u];
+                    }
+                }
+            }
+            const double res[2] = {sa0 + sd0, sa1 + sd1};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = 2 * q + h;
+                if (t >= No) continue;
+                if (lev > 1) dst[t] = res[h];
+                else if (t < n) out[(size_t)t * stride] = isfinite(res[h]) ? res[h] : 0.0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- NaN / inf test of whole records (check_nan_inf's `np.isfinite(x).all()`, preprocess_utils.py:26-33, and process_instance's np.isnan(signal).any() on the raw
 // record): flags[r] = 1 if record r holds a value that is not finite.  One pass at memory speed (torch.isfinite(x).all() on float64 writes a byte per value and reads
 // it back: 1.8 ms per 2 GB here, 2.8 ms per record-wise test).  flags must be zero on entry.
@@ -453,6 +669,9 @@ __global__ __launch_bounds__(256) void nonfinite_records_kernel(const double *x,
     if (__any(bad) && (threadIdx.x & 63) == 0) flags[rec] = 1;
 }
 
+int g_wavelet_wg = 1;                                      // 0: the lane-per-sequence kernel on every shape (tests compare the two)
+static inline size_t waves_of(size_t sequences) { return (sequences + 63) / 64; }   // scratch is laid out per wave of 64 sequences
+
 }  // namespace
 
 extern "C" size_t ecgb_wavelet_denoise_scratch_bytes(int records, int n, int leads)
@@ -461,55 +680,123 @@ extern "C" size_t ecgb_wavelet_denoise_scratch_bytes(int records, int n, int lea
     size_t rows = 0;
     int len = n;
     for (int lev = 1; lev <= kLevels; ++lev) { len = (len + kWF - 1) / 2; rows += 2 * ((size_t)len + 2); }
-    return (size_t)records * leads * rows * sizeof(double);
+    return waves_of((size_t)records * leads) * 64 * rows * sizeof(double);
 }
 
-extern "C" int ecgb_wavelet_denoise_f64(const double *x_dev, double *y_dev, int records, int n, int leads, double epsilon, double *scratch_dev,
-                                        size_t scratch_bytes, void *stream)
+// planar: x, y are [records * leads][n]; only the workgroup kernel reads that layout (scratch unused)
+static int wavelet_denoise_impl(const double *x_dev, double *y_dev, int records, int n, int leads, double epsilon, double *scratch_dev, size_t scratch_bytes,
+                                bool planar, void *stream)
 {
-    if (!x_dev || !y_dev || !scratch_dev || records <= 0 || n <= 0 || leads <= 0) { ecgb::set_error("ecgb_wavelet_denoise_f64: bad argument"); return ECGB_ERR_INVALID; }
-    if (n % 2) { ecgb::set_error("ecgb_wavelet_denoise_f64: odd lengths reconstruct one sample long (the reference's assignment raises)"); return ECGB_ERR_UNSUPPORTED; }
+    const char *fn = planar ? "ecgb_wavelet_denoise_planar_f64" : "ecgb_wavelet_denoise_f64";
+    if (!x_dev || !y_dev || (!planar && !scratch_dev) || records <= 0 || n <= 0 || leads <= 0) { ecgb::set_error(std::string(fn) + ": bad argument"); return ECGB_ERR_INVALID; }
+    if (n % 2) { ecgb::set_error(std::string(fn) + ": odd lengths reconstruct one sample long (the reference's assignment raises)"); return ECGB_ERR_UNSUPPORTED; }
     WaveletArgs A{};
     A.x = x_dev; A.y = y_dev; A.work = scratch_dev; A.R = records; A.n = n; A.L = leads; A.epsilon = epsilon;
     A.len[0] = n;
     long long row = 0;
     for (int lev = 1; lev <= kLevels; ++lev) {
-        if (A.len[lev - 1] < kWF - 1) { ecgb::set_error("ecgb_wavelet_denoise_f64: signal too short for four db6 levels"); return ECGB_ERR_UNSUPPORTED; }
+        if (A.len[lev - 1] < kWF - 1) { ecgb::set_error(std::string(fn) + ": signal too short for four db6 levels"); return ECGB_ERR_UNSUPPORTED; }
         A.len[lev] = (A.len[lev - 1] + kWF - 1) / 2;
         A.offA[lev] = row; row += A.len[lev] + 2;
         A.offD[lev] = row; row += A.len[lev] + 2;
     }
-    if (scratch_bytes < ecgb_wavelet_denoise_scratch_bytes(records, n, leads)) { ecgb::set_error("ecgb_wavelet_denoise_f64: scratch too small"); return ECGB_ERR_INVALID; }
+    A.rows = row;
+    if (!planar && scratch_bytes < ecgb_wavelet_denoise_scratch_bytes(records, n, leads)) { ecgb::set_error(std::string(fn) + ": scratch too small"); return ECGB_ERR_INVALID; }
     const size_t S = (size_t)records * leads;
-    hipLaunchKernelGGL(wavelet_denoise_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, (hipStream_t)stream, A);
+    // one workgroup per sequence, bands in LDS, when they fit (n <= ~10 200); else one lane per sequence through the scratch
+    WaveletWgArgs G{};
+    G.x = x_dev; G.y = y_dev; G.R = records; G.n = n; G.L = leads; G.epsilon = epsilon;
+    int small = 0;                                           // A2 D2 A3 D3 A4 D4 live where x was
+    for (int lev = 0; lev <= kLevels; ++lev) G.len[lev] = A.len[lev];
+    for (int lev = 2; lev <= kLevels; ++lev) { G.offA[lev] = small; small += A.len[lev] + 2; G.offD[lev] = small; small += A.len[lev] + 2; }
+    const int region0 = std::max(n, small);
+    G.offA[0] = 0;
+    G.offA[1] = region0;
+    G.offD[1] = region0 + A.len[1] + 2;
+    const size_t lds = (size_t)(region0 + 2 * (A.len[1] + 2)) * sizeof(double);
+    const size_t wgs = ((S + 7) / 8) * 8;
+    const bool fits = lds <= 160 * 1024 - 64 && wgs <= 0x7FFFFFFFull;
+    if (planar && !fits) { ecgb::set_error(std::string(fn) + ": the sequence's bands do not fit in LDS (n <= ~10 200)"); return ECGB_ERR_UNSUPPORTED; }
+    if (planar || (g_wavelet_wg && fits)) {
+        const void *kern = planar ? reinterpret_cast<const void *>(wavelet_denoise_wg_kernel<true>) : reinterpret_cast<const void *>(wavelet_denoise_wg_kernel<false>);
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            ecgb::set_error(std::string(fn) + ": cannot size the workgroup's LDS");
+            return ECGB_ERR_HIP;
+        }
+        if (planar) hipLaunchKernelGGL(wavelet_denoise_wg_kernel<true>, dim3((unsigned)wgs), dim3(kWgLanes), lds, (hipStream_t)stream, G);
+        else hipLaunchKernelGGL(wavelet_denoise_wg_kernel<false>, dim3((unsigned)wgs), dim3(kWgLanes), lds, (hipStream_t)stream, G);
+    } else {
+        hipLaunchKernelGGL(wavelet_denoise_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, (hipStream_t)stream, A);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ecgb::set_error(std::string("wavelet_denoise_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
+}
+
+extern "C" int ecgb_wavelet_denoise_f64(const double *x_dev, double *y_dev, int records, int n, int leads, double epsilon, double *scratch_dev,
+                                        size_t scratch_bytes, void *stream)
+{
+    return wavelet_denoise_impl(x_dev, y_dev, records, n, leads, epsilon, scratch_dev, scratch_bytes, false, stream);
+}
+
+extern "C" int ecgb_wavelet_denoise_planar_f64(const double *x_dev, double *y_dev, int records, int n, int leads, double epsilon, void *stream)
+{
+    return wavelet_denoise_impl(x_dev, y_dev, records, n, leads, epsilon, nullptr, 0, true, stream);
+}
+
+extern "C" size_t ecgb_resample_cubic_scratch_bytes(int records, int n, int leads)
+{
+    if (records <= 0 || n <= 0 || leads <= 0) return 0;
+    return waves_of((size_t)records * leads) * 64 * (size_t)n * sizeof(double);
+}
+
+static int resample_cubic_impl(const double *x_dev, double *y_dev, int records, int n, int leads, int m, const int *out_lead, double *scratch_dev,
+                               size_t scratch_bytes, unsigned char *flags_dev, bool planar_in, void *stream)
+{
+    const char *fn = planar_in ? "ecgb_resample_cubic_planar_f64" : "ecgb_resample_cubic_f64";
+    if (!x_dev || !y_dev || !scratch_dev || records <= 0 || leads <= 0 || m <= 0) { ecgb::set_error(std::string(fn) + ": bad argument"); return ECGB_ERR_INVALID; }
+    if (n < 4) { ecgb::set_error(std::string(fn) + ": a cubic spline needs at least 4 samples (scipy raises too)"); return ECGB_ERR_INVALID; }
+    const size_t S = (size_t)records * leads;
+    if (scratch_bytes < ecgb_resample_cubic_scratch_bytes(records, n, leads)) { ecgb::set_error(std::string(fn) + ": scratch too small (ecgb_resample_cubic_scratch_bytes)"); return ECGB_ERR_INVALID; }
+    ResampleArgs A{};
+    A.x = x_dev; A.y = y_dev; A.M = scratch_dev; A.R = records; A.n = n; A.L = leads; A.m = m; A.flags = flags_dev;
+    if (out_lead) {
+        if (leads > kMaxLeadMap) { ecgb::set_error(std::string(fn) + ": a lead map covers at most 32 leads"); return ECGB_ERR_UNSUPPORTED; }
+        unsigned seen = 0;
+        for (int l = 0; l < leads; ++l) {
+            if (out_lead[l] < 0 || out_lead[l] >= leads || (seen >> out_lead[l] & 1u)) { ecgb::set_error(std::string(fn) + ": the lead map is not a permutation"); return ECGB_ERR_INVALID; }
+            seen |= 1u << out_lead[l];
+            A.out_lead[l] = (unsigned char)out_lead[l];
+        }
+        A.use_map = 1;
+    }
+    if (planar_in) hipLaunchKernelGGL(resample_cubic_kernel<true>, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(resample_cubic_kernel<false>, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, (hipStream_t)stream, A);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ecgb::set_error(std::string("resample_cubic_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
     return ECGB_OK;
 }
 
 extern "C" int ecgb_resample_cubic_f64(const double *x_dev, double *y_dev, int records, int n, int leads, int m, double *scratch_dev,
                                        size_t scratch_bytes, void *stream)
 {
-    if (!x_dev || !y_dev || !scratch_dev || records <= 0 || leads <= 0 || m <= 0) { ecgb::set_error("ecgb_resample_cubic_f64: bad argument"); return ECGB_ERR_INVALID; }
-    if (n < 4) { ecgb::set_error("ecgb_resample_cubic_f64: a cubic spline needs at least 4 samples (scipy raises too)"); return ECGB_ERR_INVALID; }
-    const size_t S = (size_t)records * leads;
-    if (scratch_bytes < S * (size_t)n * sizeof(double)) { ecgb::set_error("ecgb_resample_cubic_f64: scratch too small (records * leads * n doubles)"); return ECGB_ERR_INVALID; }
-    ResampleArgs A{x_dev, y_dev, scratch_dev, records, n, leads, m};
-    hipLaunchKernelGGL(resample_cubic_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, (hipStream_t)stream, A);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { ecgb::set_error(std::string("resample_cubic_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
-    return ECGB_OK;
+    return resample_cubic_impl(x_dev, y_dev, records, n, leads, m, nullptr, scratch_dev, scratch_bytes, nullptr, false, stream);
+}
+
+extern "C" int ecgb_resample_cubic_planar_f64(const double *x_dev, double *y_dev, int records, int n, int leads, int m, const int *out_lead,
+                                              double *scratch_dev, size_t scratch_bytes, unsigned char *flags_dev, void *stream)
+{
+    return resample_cubic_impl(x_dev, y_dev, records, n, leads, m, out_lead, scratch_dev, scratch_bytes, flags_dev, true, stream);
 }
 
 extern "C" size_t ecgb_filtfilt_scratch_bytes(int records, int n, int leads, int max_edge)
 {
     if (records <= 0 || n <= 0 || leads <= 0 || max_edge < 0) return 0;
-    return (size_t)records * leads * ((size_t)n + 2 * (size_t)max_edge + (size_t)n) * sizeof(double);
+    return waves_of((size_t)records * leads) * 64 * ((size_t)n + 2 * (size_t)max_edge + (size_t)n) * sizeof(double);
 }
 
-extern "C" int ecgb_filtfilt_f64(const double *x_dev, double *y_dev, int records, int n, int leads, int n_filters, const int *n_taps,
-                                 const double *b, const double *a, const double *zi, double *scratch_dev, size_t scratch_bytes,
-                                 void *stream)
+static int filtfilt_impl(const double *x_dev, double *y_dev, int records, int n, int leads, int n_filters, const int *n_taps, const double *b, const double *a,
+                         const double *zi, double *scratch_dev, size_t scratch_bytes, unsigned char *flags_dev, bool planar, void *stream)
 {
     if (!x_dev || !y_dev || !n_taps || !b || !a || !zi || !scratch_dev || records <= 0 || n <= 0 || leads <= 0) {
         ecgb::set_error("ecgb_filtfilt_f64: bad argument");
@@ -517,7 +804,7 @@ extern "C" int ecgb_filtfilt_f64(const double *x_dev, double *y_dev, int records
     }
     if (n_filters < 1 || n_filters > kMaxFilters) { ecgb::set_error("ecgb_filtfilt_f64: 1..4 filters per call"); return ECGB_ERR_UNSUPPORTED; }
     FiltfiltArgs A{};
-    A.x = x_dev; A.y = y_dev; A.R = records; A.n = n; A.L = leads; A.n_filters = n_filters;
+    A.x = x_dev; A.y = y_dev; A.R = records; A.n = n; A.L = leads; A.n_filters = n_filters; A.flags = flags_dev;
     int max_edge = 0;
     for (int k = 0; k < n_filters; ++k) {
         const int nb = n_taps[k];
@@ -534,12 +821,31 @@ extern "C" int ecgb_filtfilt_f64(const double *x_dev, double *y_dev, int records
     if (scratch_bytes < ecgb_filtfilt_scratch_bytes(records, n, leads, max_edge)) { ecgb::set_error("ecgb_filtfilt_f64: scratch too small"); return ECGB_ERR_INVALID; }
     const size_t S = (size_t)records * leads;
     A.ext = scratch_dev;
-    A.mid = scratch_dev + S * ((size_t)n + 2 * (size_t)max_edge);
-    hipLaunchKernelGGL(filtfilt_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, (hipStream_t)stream, A);
+    A.ext_rows = n + 2 * max_edge;
+    A.mid = scratch_dev + waves_of(S) * 64 * (size_t)A.ext_rows;
+    if (planar) hipLaunchKernelGGL(filtfilt_kernel<true>, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(filtfilt_kernel<false>, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, (hipStream_t)stream, A);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ecgb::set_error(std::string("filtfilt_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
     return ECGB_OK;
 }
+
+extern "C" int ecgb_filtfilt_f64(const double *x_dev, double *y_dev, int records, int n, int leads, int n_filters, const int *n_taps,
+                                 const double *b, const double *a, const double *zi, double *scratch_dev, size_t scratch_bytes,
+                                 void *stream)
+{
+    return filtfilt_impl(x_dev, y_dev, records, n, leads, n_filters, n_taps, b, a, zi, scratch_dev, scratch_bytes, nullptr, false, stream);
+}
+
+extern "C" int ecgb_filtfilt_planar_f64(const double *x_dev, double *y_dev, int records, int n, int leads, int n_filters, const int *n_taps,
+                                        const double *b, const double *a, const double *zi, double *scratch_dev, size_t scratch_bytes,
+                                        unsigned char *flags_dev, void *stream)
+{
+    if (x_dev == y_dev) { ecgb::set_error("ecgb_filtfilt_planar_f64: input and output have different layouts and must not alias"); return ECGB_ERR_INVALID; }
+    return filtfilt_impl(x_dev, y_dev, records, n, leads, n_filters, n_taps, b, a, zi, scratch_dev, scratch_bytes, flags_dev, true, stream);
+}
+
+extern "C" void ecgb_set_wavelet_workgroup_kernel(int on) { g_wavelet_wg = on ? 1 : 0; }
 
 extern "C" int ecgb_nonfinite_records_f64(const double *x_dev, int records, size_t per_record, unsigned char *flags_dev, void *stream)
 {

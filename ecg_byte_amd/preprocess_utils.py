@@ -69,25 +69,31 @@ def design_filters(fs=500, notch_freqs=(50, 60), highcut=100.0):
     return out
 
 
+def _pack_filters(chunk):
+    """(n_taps, b, a, zi) as ecgb_filtfilt_f64 takes them: [filters][9] coefficient rows, zi = scipy.signal.lfilter_zi(b, a)."""
+    from scipy import signal
+    taps = (C.c_int * len(chunk))()
+    b = np.zeros((len(chunk), _MAX_TAPS)); a = np.zeros((len(chunk), _MAX_TAPS)); zi = np.zeros((len(chunk), _MAX_TAPS - 1))
+    for k, (bk, ak) in enumerate(chunk):
+        bk, ak = np.atleast_1d(np.asarray(bk, np.float64)), np.atleast_1d(np.asarray(ak, np.float64))
+        nt = max(len(bk), len(ak))
+        if nt > _MAX_TAPS or nt < 2:
+            raise ValueError("filters of 2..9 coefficients")
+        taps[k] = nt
+        b[k, :len(bk)] = bk; a[k, :len(ak)] = ak
+        zi[k, :nt - 1] = signal.lfilter_zi(bk, ak)
+    return taps, b, a, zi
+
+
 def filtfilt(filters, x):
     """scipy.signal.filtfilt(b, a, x, axis=-2) for each (b, a) of `filters` in turn, on the device (ecgb_filtfilt_f64; at most four per
     launch, longer chains are cut)."""
-    from scipy import signal
     xb, single = _batch(x)
     R, n, leads = xb.shape
     y = xb
     for s0 in range(0, len(filters), 4):
         chunk = filters[s0:s0 + 4]
-        taps = (C.c_int * len(chunk))()
-        b = np.zeros((len(chunk), _MAX_TAPS)); a = np.zeros((len(chunk), _MAX_TAPS)); zi = np.zeros((len(chunk), _MAX_TAPS - 1))
-        for k, (bk, ak) in enumerate(chunk):
-            bk, ak = np.atleast_1d(np.asarray(bk, np.float64)), np.atleast_1d(np.asarray(ak, np.float64))
-            nt = max(len(bk), len(ak))
-            if nt > _MAX_TAPS or nt < 2:
-                raise ValueError("filters of 2..9 coefficients")
-            taps[k] = nt
-            b[k, :len(bk)] = bk; a[k, :len(ak)] = ak
-            zi[k, :nt - 1] = signal.lfilter_zi(bk, ak)
+        taps, b, a, zi = _pack_filters(chunk)
         edge = 3 * max(taps)
         nbytes = _L().ecgb_filtfilt_scratch_bytes(R, n, leads, edge)
         scratch = torch.empty(nbytes // 8, dtype=torch.float64, device=xb.device)
@@ -99,10 +105,55 @@ def filtfilt(filters, x):
     return y[0] if single else y
 
 
+_PLANAR_MAX_N = 10000       # the bands of a sequence live in LDS (ecgb_wavelet_denoise_planar_f64)
+
+
+def _condition_planar(x, orig_fs, target_fs, out_lead):
+    """The filter chain, the wavelet shrinkage and the resampling of condition_records' fast path with the intermediates sequence-major
+    ([records * leads][n]; include/ecgbyte.h): the same three stages, the same bits as advanced_ecg_filter -> wavelet_denoise -> nsample_ecg, the lead
+    reorder folded into the last store and the stages' "not finite" tests into the kernels.  Returns ([records, m, leads], flags [records] uint8)."""
+    R, n, leads = x.shape
+    filters = design_filters(orig_fs)
+    taps, b, a, zi = _pack_filters(filters)
+    nbytes = _L().ecgb_filtfilt_scratch_bytes(R, n, leads, 3 * max(taps))
+    nres = _L().ecgb_resample_cubic_scratch_bytes(R, n, leads)
+    scratch = torch.empty(max(nbytes, nres) // 8, dtype=torch.float64, device=x.device)
+    flags = torch.zeros(R, dtype=torch.uint8, device=x.device)
+    planar = torch.empty(R * leads * n, dtype=torch.float64, device=x.device)
+    _lib.check(_L().ecgb_filtfilt_planar_f64(C.c_void_p(x.data_ptr()), C.c_void_p(planar.data_ptr()), R, n, leads, len(filters), taps,
+                                             b.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), zi.ctypes.data_as(C.c_void_p),
+                                             C.c_void_p(scratch.data_ptr()), nbytes, C.c_void_p(flags.data_ptr()), _st()))
+    _lib.check(_L().ecgb_wavelet_denoise_planar_f64(C.c_void_p(planar.data_ptr()), C.c_void_p(planar.data_ptr()), R, n, leads, 1e-10, _st()))
+    m = int(n * target_fs / orig_fs)
+    out = torch.empty((R, m, leads), dtype=torch.float64, device=x.device)
+    lead_map = None
+    if out_lead is not None:
+        lead_map = (C.c_int * leads)(*out_lead)
+    _lib.check(_L().ecgb_resample_cubic_planar_f64(C.c_void_p(planar.data_ptr()), C.c_void_p(out.data_ptr()), R, n, leads, m, lead_map,
+                                                   C.c_void_p(scratch.data_ptr()), nres, C.c_void_p(flags.data_ptr()), _st()))
+    return out, flags
+
+
 def advanced_ecg_filter(ecg_data, fs=500, notch_freqs=[50, 60], highcut=100.0):
     """preprocess_utils.py:66-88: notch filters, Butterworth band-pass 0.5 Hz..highcut (order 4), high-pass 0.05 Hz (order 4), each
     applied forward and backward (filtfilt)."""
     return filtfilt(design_filters(fs, tuple(notch_freqs), highcut), ecg_data)
+
+
+_planar_pipeline = True
+
+
+def set_planar_pipeline(on=True):
+    """Dev / tests: False sends condition_records through the three per-stage calls ([records, n, leads] between the stages) instead of the
+    sequence-major pipeline (same bits)."""
+    global _planar_pipeline
+    _planar_pipeline = bool(on)
+
+
+def set_wavelet_workgroup_kernel(on=True):
+    """Dev / tests: False forms the wavelet stage with the lane-per-sequence kernel on every shape (default: one workgroup per sequence with the bands in LDS
+    whenever they fit; same bits)."""
+    _L().ecgb_set_wavelet_workgroup_kernel(1 if on else 0)
 
 
 def wavelet_denoise(ecg_data, wavelet='db6', level=4, epsilon=1e-10):
@@ -146,15 +197,29 @@ def condition_records(signals, reorder=True, seg_len=1250, orig_fs=500, target_f
     # A non-finite value anywhere (overflow of a filter: not seen on real records) sends the batch through the literal sequence below, check_nan_inf after
     # every stage as the reference has it.  The lead permutation commutes with every per-lead stage: it is applied last, to the resampled half-size data.
     x = signals
-    flags = []
-    x = advanced_ecg_filter(x, fs=orig_fs); flags.append(nonfinite_records(x, 1))
-    x = wavelet_denoise(x); flags.append(nonfinite_records(x, 1))
-    x = nsample_ecg(x, orig_fs, target_fs); flags.append(nonfinite_records(x, 1))
-    if not bool(torch.cat(flags).any()):
+    n, leads = x.shape[1], x.shape[2]
+    if _planar_pipeline and n % 2 == 0 and 96 <= n <= _PLANAR_MAX_N and leads <= 32 and (not reorder or leads == 12):
+        # sequence-major intermediates, the reorder in the last store, the tests in the kernels (see _condition_planar)
+        out_lead = None
         if reorder:
-            x = reorder_indices(x).contiguous()
-        seg, _ = segment_ecg(x, None, seg_len)
-        return (seg, kept) if return_kept else seg
+            new_indices = reorder_indices(torch.arange(12))        # output lead c = input lead new_indices[c]
+            out_lead = [0] * 12
+            for c, l in enumerate(new_indices.tolist()):
+                out_lead[l] = c
+        x, flags = _condition_planar(x, orig_fs, target_fs, out_lead)
+        if not bool(flags.any()):
+            seg, _ = segment_ecg(x, None, seg_len)
+            return (seg, kept) if return_kept else seg
+    else:
+        flags = []
+        x = advanced_ecg_filter(x, fs=orig_fs); flags.append(nonfinite_records(x, 1))
+        x = wavelet_denoise(x); flags.append(nonfinite_records(x, 1))
+        x = nsample_ecg(x, orig_fs, target_fs); flags.append(nonfinite_records(x, 1))
+        if not bool(torch.cat(flags).any()):
+            if reorder:
+                x = reorder_indices(x).contiguous()
+            seg, _ = segment_ecg(x, None, seg_len)
+            return (seg, kept) if return_kept else seg
     x = check_nan_inf(signals, "reading")
     if reorder:
         x = check_nan_inf(reorder_indices(x).contiguous(), "reordering")
@@ -173,7 +238,7 @@ def nsample_ecg(ecg_data, orig_fs, target_fs):
     R, n, leads = xb.shape
     m = int(n * target_fs / orig_fs)
     out = torch.empty((R, m, leads), dtype=torch.float64, device=xb.device)
-    scratch = torch.empty(R * leads * n, dtype=torch.float64, device=xb.device)
+    scratch = torch.empty(_L().ecgb_resample_cubic_scratch_bytes(R, n, leads) // 8, dtype=torch.float64, device=xb.device)
     _lib.check(_L().ecgb_resample_cubic_f64(C.c_void_p(xb.data_ptr()), C.c_void_p(out.data_ptr()), R, n, leads, m,
                                             C.c_void_p(scratch.data_ptr()), scratch.numel() * 8, _st()))
     return out[0] if single else out

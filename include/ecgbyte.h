@@ -199,7 +199,9 @@ int ecgb_filtfilt_f64(const double *x_dev, double *y_dev, int records, int n, in
 
 /* ecg_byte/utils/preprocess_utils.py:90-101 nsample_ecg: scipy.interpolate.interp1d(t, y, kind='cubic') -- the not-a-knot cubic spline
  * through all n samples -- evaluated at m equally spaced instants over the same span (the reference: 5000 samples at 500 Hz -> 2500 at
- * 250 Hz).  x_dev [records, n, leads] -> y_dev [records, m, leads], float64; n >= 4.  Scratch: records * leads * n doubles. */
+ * 250 Hz).  x_dev [records, n, leads] -> y_dev [records, m, leads], float64; n >= 4.  Scratch: ecgb_resample_cubic_scratch_bytes (n doubles per
+ * sequence, sequences rounded up to whole waves of 64). */
+size_t ecgb_resample_cubic_scratch_bytes(int records, int n, int leads);
 int ecgb_resample_cubic_f64(const double *x_dev, double *y_dev, int records, int n, int leads, int m, double *scratch_dev,
                             size_t scratch_bytes, void *stream);
 
@@ -210,6 +212,25 @@ int ecgb_resample_cubic_f64(const double *x_dev, double *y_dev, int records, int
 size_t ecgb_wavelet_denoise_scratch_bytes(int records, int n, int leads);
 int ecgb_wavelet_denoise_f64(const double *x_dev, double *y_dev, int records, int n, int leads, double epsilon, double *scratch_dev,
                              size_t scratch_bytes, void *stream);
+/* Two kernels form this stage with the same bits: one workgroup per sequence with the bands in LDS (default, n up to ~10 200) and one lane per sequence through
+ * the scratch (longer sequences).  on = 0 takes the second on every shape (tests compare them). */
+void ecgb_set_wavelet_workgroup_kernel(int on);
+
+/* The three stages back to back (process_instance, preprocess_utils.py:142-151) with the intermediates SEQUENCE-MAJOR, [records * leads][n]: the layout the
+ * workgroup-per-sequence wavelet kernel reads and writes with whole lines (a sequence of [records][n][leads] is 8 bytes every 8 * leads).  Same arithmetic, same bits
+ * as the three calls above; only where the intermediates lie differs.
+ *   ecgb_filtfilt_planar_f64        x [records, n, leads] -> y [records * leads][n]   (x and y must not alias)
+ *   ecgb_wavelet_denoise_planar_f64 x, y [records * leads][n] (may alias); n even, 96 <= n <= ~10 200 (the bands of a sequence live in LDS), else ECGB_ERR_UNSUPPORTED
+ *   ecgb_resample_cubic_planar_f64  x [records * leads][n] -> y [records, m, leads]; out_lead (host, may be NULL): lead l of the input becomes lead out_lead[l] of
+ *                                   the output -- the MIMIC lead reorder (preprocess_utils.py:35-40) folded into the store; a permutation of 0 .. leads-1, leads <= 32
+ * flags_dev (may be NULL): [records] bytes, zeroed by the caller; set to 1 where the stage wrote a value that is not finite (check_nan_inf's test,
+ * preprocess_utils.py:26-33, without another pass over the data; the wavelet stage zeroes such values itself, line 62). */
+int ecgb_filtfilt_planar_f64(const double *x_dev, double *y_dev, int records, int n, int leads, int n_filters, const int *n_taps,
+                             const double *b, const double *a, const double *zi, double *scratch_dev, size_t scratch_bytes,
+                             unsigned char *flags_dev, void *stream);
+int ecgb_wavelet_denoise_planar_f64(const double *x_dev, double *y_dev, int records, int n, int leads, double epsilon, void *stream);
+int ecgb_resample_cubic_planar_f64(const double *x_dev, double *y_dev, int records, int n, int leads, int m, const int *out_lead,
+                                   double *scratch_dev, size_t scratch_bytes, unsigned char *flags_dev, void *stream);
 
 /* ecg_byte/utils/preprocess_utils.py:26-33 check_nan_inf's test `np.isfinite(data).all()` and process_instance's test of the raw record (134-136), for a batch:
  * flags_dev[r] = 1 if record r (per_record consecutive doubles) holds a NaN or an infinity; flags_dev must be zero on entry.  One pass at memory speed. */

@@ -81,6 +81,36 @@ def test_wavelet_denoise_against_the_restatement(pp, R, n):
         assert np.abs(got[r] - want).max() <= 1e-11 * max(np.abs(want).max(), 1e-3), (r, np.abs(got[r] - want).max())
 
 
+@pytest.mark.parametrize("R,n,L", [(9, 5000, 12), (70, 640, 12), (3, 98, 12), (5, 1000, 3), (2, 10000, 12), (1, 12000, 2)])
+def test_wavelet_workgroup_kernel_is_the_lane_kernel_bit_for_bit(pp, R, n, L):
+    """The stage has two kernels -- one workgroup per sequence with the bands in LDS, one lane per sequence through scratch memory (the only one for sequences
+    too long for LDS: n = 12 000 takes it either way).  Same sums in the same order, the same order statistics: the same bits, NaN / constant / zero leads included."""
+    x = _records(R, n, seed=R + n)[:, :, :L].copy()
+    x[0, :, 0] = 0.0
+    if L > 1:
+        x[0, :, 1] = 0.5
+    if R > 1:
+        x[1, n // 3, L - 1] = np.nan
+    xd = torch.from_numpy(x).cuda()
+    try:
+        pp.set_wavelet_workgroup_kernel(False)
+        lane = pp.wavelet_denoise(xd).clone()
+    finally:
+        pp.set_wavelet_workgroup_kernel(True)
+    wg = pp.wavelet_denoise(xd)
+    assert torch.equal(lane.view(torch.int64), wg.view(torch.int64))
+    buf = xd.clone()                                                                    # in place: x_dev == y_dev
+    from ecg_byte_amd import _lib
+    import ctypes as C
+    lib = _lib.lib()
+    nbytes = lib.ecgb_wavelet_denoise_scratch_bytes(R, n, L)
+    scratch = torch.empty(nbytes // 8, dtype=torch.float64, device="cuda")
+    _lib.check(lib.ecgb_wavelet_denoise_f64(C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()), R, n, L, 1e-10, C.c_void_p(scratch.data_ptr()), nbytes,
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert torch.equal(buf.view(torch.int64), wg.view(torch.int64))
+
+
 def test_wavelet_denoise_edge_cases(pp):
     z = torch.zeros(2, 640, 12, dtype=torch.float64, device="cuda")
     assert bool((pp.wavelet_denoise(z) == 0).all())                                     # median 0 -> threshold 0 -> 0 / 0 guarded
@@ -95,6 +125,43 @@ def test_wavelet_denoise_edge_cases(pp):
     from ecg_byte_amd._lib import EcgbError
     with pytest.raises(EcgbError):
         pp.wavelet_denoise(torch.zeros(641, 12, dtype=torch.float64, device="cuda"))
+
+
+@pytest.mark.parametrize("R,n,reorder", [(16, 5000, True), (9, 5000, False), (7, 1000, True), (64, 640, True)])
+def test_sequence_major_pipeline_is_the_three_stage_calls_bit_for_bit(pp, R, n, reorder):
+    """condition_records' fast path keeps its intermediates [records * leads][n] (ecgb_filtfilt_planar_f64 -> ecgb_wavelet_denoise_planar_f64 ->
+    ecgb_resample_cubic_planar_f64, lead reorder in the last store): the same bits as the per-stage calls with [records, n, leads] between them, whole and
+    partial last waves of sequences."""
+    x = torch.from_numpy(_records(R, n, seed=3 * R + n)).cuda()
+    try:
+        pp.set_planar_pipeline(False)
+        want = pp.condition_records(x, reorder=reorder, seg_len=n // 4)
+    finally:
+        pp.set_planar_pipeline(True)
+    got = pp.condition_records(x, reorder=reorder, seg_len=n // 4)
+    assert got.shape == want.shape and torch.equal(got.view(torch.int64), want.view(torch.int64))
+    # the stages one by one against the public per-stage functions
+    planar_out, flags = pp._condition_planar(x, 500, 250, None)
+    ref = pp.nsample_ecg(pp.wavelet_denoise(pp.advanced_ecg_filter(x)), 500, 250)
+    assert torch.equal(planar_out.view(torch.int64), ref.view(torch.int64)) and not bool(flags.any())
+
+
+def test_sequence_major_pipeline_flags_records_that_leave_a_stage_not_finite(pp):
+    """The kernels of the fast path raise a record's flag where check_nan_inf's test (preprocess_utils.py:26-33) would have fired: condition_records then runs the
+    literal stage-by-stage sequence and returns what the per-stage path returns."""
+    x = _records(4, 1000, seed=11)
+    x[2, 500, 4] = 1e308                                                                # finite on entry; the filter chain overflows around it
+    xd = torch.from_numpy(x).cuda()
+    _, flags = pp._condition_planar(xd, 500, 250, None)
+    per_stage = pp.advanced_ecg_filter(xd)
+    assert flags.cpu().tolist() == [0, 0, int(not bool(torch.isfinite(per_stage[2]).all())), 0]
+    try:
+        pp.set_planar_pipeline(False)
+        want = pp.condition_records(xd, seg_len=250)
+    finally:
+        pp.set_planar_pipeline(True)
+    got = pp.condition_records(xd, seg_len=250)
+    assert torch.equal(got.view(torch.int64), want.view(torch.int64))
 
 
 def test_condition_records_is_the_reference_pipeline(pp):
