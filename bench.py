@@ -316,7 +316,7 @@ def bench_preprocess(dev, n_records=4096):
     the device.  Algorithmic bytes: 480 KB read + 240 KB written per record.  The stages are recursions along time, one sequence (record, lead) per lane:
     4 096 records are 768 waves -- one per SIMD; fewer records take the same time (1 024: the same 20 ms), so the batch is what an offline pass over a corpus
     of 200 000 records would use.  `stage_traffic` is what the stages move as they are written (every filtfilt is a forward and a backward sweep through HBM,
-    the wavelet transform six sweeps, the spline three): the bound the kernels run against, not the algorithmic bytes."""
+    the wavelet transform one, the spline two and a half), not the algorithmic bytes; `bound` says what the kernels actually run against."""
     import torch
     from ecg_byte_amd import preprocess_utils as pp, synth
     base = np.ascontiguousarray(synth.synth_ecg(64, 5000, seed=0).transpose(0, 2, 1))
@@ -334,15 +334,17 @@ def bench_preprocess(dev, n_records=4096):
     ms = e0.elapsed_time(e1) / reps
     alg = n_records * (5000 * 12 * 8 + 2500 * 12 * 8)
     samples = n_records * 5000 * 12
-    # sweeps through HBM as the stages are written, 8 bytes read + 8 written per sample and sweep: 4 filters x (forward, backward); wavelet: 4 levels down
-    # (1 + 1/2 + 1/4 + 1/8 of the samples) and up again + the threshold pass ~ 5; spline: tridiagonal forward, back substitution, evaluation (half-size output) ~ 2.5;
-    # the four finite tests read 3.5 x 8 bytes
-    sweeps = {"filter_chain": 8.0, "wavelet": 5.0, "resample": 2.5}
-    traffic = sum(sweeps.values()) * 16 * samples + 3.5 * 8 * samples
+    # sweeps through HBM as the stages are written, 8 bytes read + 8 written per sample and sweep: 4 filters x (forward, backward); wavelet: ONE (round 3: a
+    # workgroup per sequence keeps the bands in LDS -- the samples are read once and the result written once; the lane-per-sequence kernel moved ~5);
+    # spline: tridiagonal forward, back substitution, evaluation (half-size output) ~ 2.5; the raw-record finite test reads 8 bytes (the stages' tests are in the kernels)
+    sweeps = {"filter_chain": 8.0, "wavelet": 1.0, "resample": 2.5}
+    traffic = sum(sweeps.values()) * 16 * samples + 1.0 * 8 * samples
     return {"workload": f"{n_records} raw records of 5000 x 12 float64: notch 50/60 Hz, band-pass, high-pass (filtfilt), db6 wavelet shrinkage, cubic resample to 250 Hz, 1250-sample segments",
             "ms": ms, "records_per_s": n_records / (ms * 1e-3), "GB/s": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "stage_traffic": {"sweeps_of_16_bytes_per_sample": sweeps, "bytes": traffic, "GB/s": traffic / (ms * 1e-3) / 1e9,
                               "frac_of_hbm_peak": traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "bound": "recursion latency and vector-f64 issue, not HBM: 49 152 sequences are 768 waves (one per SIMD), a dependent f64 operation returns after ~38 cycles and "
+                     "a lone wave issues one f64 instruction per ~10 cycles (scripts/experiments/f64_rate.hip); profiles/r03/conditioning_pmc.txt",
             "segments_out": list(out.shape)}
 
 

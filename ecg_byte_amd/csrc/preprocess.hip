@@ -47,7 +47,7 @@ struct FiltfiltArgs {
 // one sample, filtered it and stored it: hipcc cannot move a load above the previous store (`ext`, `mid` and the record may alias for all it knows), so every
 // step paid a memory round trip -- 560 cycles per step against ~60 of arithmetic, one wave per SIMD (22.6 ms for 4 096 records).
 #ifndef ECGB_PRE_BLK
-#define ECGB_PRE_BLK 32
+#define ECGB_PRE_BLK 16
 #endif
 constexpr int kBlk = ECGB_PRE_BLK;
 template <int NB, typename SRC, typename DST, typename FLUSH>
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64) void filtfilt_kernel(FiltfiltArgs A)
 // one Thomas sweep per sequence over rows 2 .. n-3 (the pivots 1 / (4 - c') are the same for every sequence and reach their fixed point
 // 2 - sqrt(3) in double precision within ~20 rows), then  S(i + u) = y[i] + u (dy - (2 M[i] + M[i+1]) / 6) + u^2 M[i] / 2 + u^3 (M[i+1] - M[i]) / 6.
 // Agreement with scipy: the two solves differ by rounding only (1e-13 of the signal's range measured, tests/test_gpu_preprocess.py).
-constexpr int kMaxLeadMap = 32;
+constexpr int kMaxLeadMap = 32, kResampleTab = 32;
 struct ResampleArgs {
     const double *x;                 // [R, n, L], or [R * L][n] (PLANAR_IN)
     double *y;                       // [R, m, L]
@@ -197,6 +197,7 @@ struct ResampleArgs {
     int R, n, L, m;
     unsigned char *flags;            // optional [R]: 1 where a record's result holds a value that is not finite
     int use_map;
+    double cp[kResampleTab];         // the Thomas sweep's pivots 1 / (4 - c'): the same for every sequence
     unsigned char out_lead[kMaxLeadMap];   // use_map: lead l of the input is lead out_lead[l] of the output (the MIMIC reorder, preprocess_utils.py:35-40)
 };
 
@@ -214,12 +215,9 @@ __global__ __launch_bounds__(64) void resample_cubic_kernel(ResampleArgs A)
     auto Y = [&](int i) -> double { return PLANAR_IN ? x[i] : x[(size_t)i * L]; };
     bool bad = false;
     auto rhs = [&](int i) -> double { return 6.0 * (Y(i + 1) - 2.0 * Y(i) + Y(i - 1)); };
-    constexpr int kTab = 32;
-    double cp[kTab];                                         // c'[2 + k]; c'[2 + k] = c'[2 + kTab - 1] beyond the table (fixed point)
-    cp[0] = 0.25;
-#pragma unroll
-    for (int k = 1; k < kTab; ++k) cp[k] = 1.0 / (4.0 - cp[k - 1]);
-    auto cprime = [&](int i) -> double { const int k = i - 2; return cp[k < kTab ? k : kTab - 1]; };
+    // c'[2 + k] = A.cp[k] (from the host: the same IEEE divisions; a row index is the same in every lane, so the pivot is one scalar load -- a table built in the
+    // kernel and indexed by the row lived in scratch memory); c'[2 + k] = c'[2 + kTab - 1] beyond the table (fixed point)
+    auto cprime = [&](int i) -> double { const int k = i - 2; return A.cp[k < kResampleTab ? k : kResampleTab - 1]; };
     const double M1 = rhs(1) / 6.0, Mn2 = rhs(n - 2) / 6.0;
     M[(size_t)1 * 64] = M1;
     M[(size_t)(n - 2) * 64] = Mn2;
@@ -536,10 +534,13 @@ __global__ __launch_bounds__(kWgLanes) void wavelet_denoise_wg_kernel(WaveletWgA
         for (int o = tid; o < Nc; o += kWgLanes) {
             double a = 0.0, d = 0.0;
             if (2 * o - (kWF - 2) >= 0 && 2 * o + 1 < N) {  // the window lies inside the band: twelve reads at constant offsets, no index arithmetic
-                const double *pw = in + 2 * o + 1;
+                const double2 *pw = reinterpret_cast<const double2 *>(in + 2 * o - (kWF - 2));   // (band offsets are even: 16-byte reads, lane after lane)
+                double w[kWF];
+#pragma unroll
+                for (int j = 0; j < kWF / 2; ++j) { const double2 t2 = pw[j]; w[2 * j] = t2.x; w[2 * j + 1] = t2.y; }
 #pragma unroll
                 for (int j = 0; j < kWF; ++j) {
-                    const double v = pw[-j];
+                    const double v = w[kWF - 1 - j];         // in[2 o + 1 - j]
                     a += lo[j] * v;
                     d += hi[j] * v;
                 }
@@ -708,12 +709,13 @@ static int wavelet_denoise_impl(const double *x_dev, double *y_dev, int records,
     G.x = x_dev; G.y = y_dev; G.R = records; G.n = n; G.L = leads; G.epsilon = epsilon;
     int small = 0;                                           // A2 D2 A3 D3 A4 D4 live where x was
     for (int lev = 0; lev <= kLevels; ++lev) G.len[lev] = A.len[lev];
-    for (int lev = 2; lev <= kLevels; ++lev) { G.offA[lev] = small; small += A.len[lev] + 2; G.offD[lev] = small; small += A.len[lev] + 2; }
-    const int region0 = std::max(n, small);
+    auto even = [](int v) { return (v + 1) & ~1; };          // bands start on 16 bytes
+    for (int lev = 2; lev <= kLevels; ++lev) { G.offA[lev] = small; small += even(A.len[lev] + 2); G.offD[lev] = small; small += even(A.len[lev] + 2); }
+    const int region0 = even(std::max(n, small));
     G.offA[0] = 0;
     G.offA[1] = region0;
-    G.offD[1] = region0 + A.len[1] + 2;
-    const size_t lds = (size_t)(region0 + 2 * (A.len[1] + 2)) * sizeof(double);
+    G.offD[1] = region0 + even(A.len[1] + 2);
+    const size_t lds = (size_t)(region0 + 2 * even(A.len[1] + 2)) * sizeof(double);
     const size_t wgs = ((S + 7) / 8) * 8;
     const bool fits = lds <= 160 * 1024 - 64 && wgs <= 0x7FFFFFFFull;
     if (planar && !fits) { ecgb::set_error(std::string(fn) + ": the sequence's bands do not fit in LDS (n <= ~10 200)"); return ECGB_ERR_UNSUPPORTED; }
@@ -760,6 +762,8 @@ static int resample_cubic_impl(const double *x_dev, double *y_dev, int records, 
     if (scratch_bytes < ecgb_resample_cubic_scratch_bytes(records, n, leads)) { ecgb::set_error(std::string(fn) + ": scratch too small (ecgb_resample_cubic_scratch_bytes)"); return ECGB_ERR_INVALID; }
     ResampleArgs A{};
     A.x = x_dev; A.y = y_dev; A.M = scratch_dev; A.R = records; A.n = n; A.L = leads; A.m = m; A.flags = flags_dev;
+    A.cp[0] = 0.25;
+    for (int k = 1; k < kResampleTab; ++k) A.cp[k] = 1.0 / (4.0 - A.cp[k - 1]);
     if (out_lead) {
         if (leads > kMaxLeadMap) { ecgb::set_error(std::string(fn) + ": a lead map covers at most 32 leads"); return ECGB_ERR_UNSUPPORTED; }
         unsigned seen = 0;
