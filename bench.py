@@ -343,8 +343,9 @@ def bench_preprocess(dev, n_records=4096):
             "ms": ms, "records_per_s": n_records / (ms * 1e-3), "GB/s": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "stage_traffic": {"sweeps_of_16_bytes_per_sample": sweeps, "bytes": traffic, "GB/s": traffic / (ms * 1e-3) / 1e9,
                               "frac_of_hbm_peak": traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "bound": "recursion latency and vector-f64 issue, not HBM: 49 152 sequences are 768 waves (one per SIMD), a dependent f64 operation returns after ~38 cycles and "
-                     "a lone wave issues one f64 instruction per ~10 cycles (scripts/experiments/f64_rate.hip); profiles/r03/conditioning_pmc.txt",
+            "bound": "filter chain and spline: the HBM traffic of their sweeps (every filtfilt writes its forward result and reads it back reversed: 31.8 GB at ~4.8 TB/s, "
+                     "10 GB at ~3.7 TB/s); wavelet: vector issue (0.7 ms of float64 arithmetic at full rate inside 3.5 ms; index arithmetic and the median's "
+                     "comparisons are the rest); profiles/r03/conditioning_pmc.txt, DESIGN.md section 9",
             "segments_out": list(out.shape)}
 
 

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <string>
+#include <type_traits>
 
 #include "tokenizer.hpp"
 
@@ -50,7 +51,14 @@ struct FiltfiltArgs {
 #define ECGB_PRE_BLK 16
 #endif
 constexpr int kBlk = ECGB_PRE_BLK;
-template <int NB, typename SRC, typename DST, typename FLUSH>
+// The block length is a parameter per filter length (short filters could take longer blocks: two state variables instead of eight).  Measured with 32 for the
+// notches: 6.66 ms either way -- the chain is at the HBM traffic of its sweeps, not at the latency of a block's loads -- so both are 16 (24 / 32 spill for the 9-tap filter).
+#ifndef ECGB_PRE_BLK_SHORT
+#define ECGB_PRE_BLK_SHORT 16
+#endif
+constexpr int kBlkShort = ECGB_PRE_BLK_SHORT;
+constexpr int kBlkMax = kBlk > kBlkShort ? kBlk : kBlkShort;
+template <int NB, int BLK, typename SRC, typename DST, typename FLUSH>
 __device__ __forceinline__ void filtfilt_one(const Filt &F, int n, SRC src, double *ext, size_t S, size_t seq, DST dst, FLUSH flush)
 {
     const int e = F.edge, N = n + 2 * e;
@@ -71,20 +79,37 @@ __device__ __forceinline__ void filtfilt_one(const Filt &F, int n, SRC src, doub
     const double x0 = ext_at(0);
 #pragma unroll
     for (int k = 0; k < NB - 1; ++k) z[k] = F.zi[k] * x0;
-    double cur[kBlk], nxt[kBlk];
+    double cur[BLK], nxt[BLK];
+    // Every condition below is the same in all lanes (the lanes of a wave are at the same sample), and almost every block lies inside the signal: whole blocks take
+    // straight-line code -- BLK loads at constant offsets, BLK steps, BLK stores in one basic block, so the scheduler can start a step's independent products under
+    // the previous step's dependent chain -- and only the blocks that touch the padding or the end carry per-sample tests (written with the tests on every sample, the
+    // loop was ~450 basic blocks per filter and 5 scalar instructions per load).
     // ---- forward over the extended signal -> ext
 #pragma unroll
-    for (int u = 0; u < kBlk; ++u) cur[u] = ext_at(min(u, N - 1));
-    for (int i0 = 0; i0 < N; i0 += kBlk) {
+    for (int u = 0; u < BLK; ++u) cur[u] = ext_at(min(u, N - 1));
+    for (int i0 = 0; i0 < N; i0 += BLK) {
+        const int j0 = i0 + BLK;
+        if (j0 >= e && j0 + BLK <= e + n) {
 #pragma unroll
-        for (int u = 0; u < kBlk; ++u) nxt[u] = ext_at(min(i0 + kBlk + u, N - 1));      // the next block's loads fly while this one is filtered
-        double out[kBlk];
+            for (int u = 0; u < BLK; ++u) nxt[u] = src(j0 - e + u);                        // the next block's loads fly while this one is filtered
+        } else {
 #pragma unroll
-        for (int u = 0; u < kBlk; ++u) if (i0 + u < N) out[u] = step(cur[u]);
+            for (int u = 0; u < BLK; ++u) nxt[u] = ext_at(min(j0 + u, N - 1));
+        }
+        double out[BLK];
+        if (i0 + BLK <= N) {
 #pragma unroll
-        for (int u = 0; u < kBlk; ++u) if (i0 + u < N) ext[(size_t)(i0 + u) * S + seq] = out[u];
+            for (int u = 0; u < BLK; ++u) out[u] = step(cur[u]);
 #pragma unroll
-        for (int u = 0; u < kBlk; ++u) cur[u] = nxt[u];
+            for (int u = 0; u < BLK; ++u) ext[(size_t)(i0 + u) * S + seq] = out[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < BLK; ++u) if (i0 + u < N) out[u] = step(cur[u]);
+#pragma unroll
+            for (int u = 0; u < BLK; ++u) if (i0 + u < N) ext[(size_t)(i0 + u) * S + seq] = out[u];
+        }
+#pragma unroll
+        for (int u = 0; u < BLK; ++u) cur[u] = nxt[u];
     }
     // ---- backward over ext -> dst (the middle n samples)
     const double y0 = ext[(size_t)(N - 1) * S + seq];
@@ -92,21 +117,35 @@ __device__ __forceinline__ void filtfilt_one(const Filt &F, int n, SRC src, doub
     for (int k = 0; k < NB - 1; ++k) z[k] = F.zi[k] * y0;
     auto rev_at = [&](int i) -> double { return ext[(size_t)(N - 1 - min(i, N - 1)) * S + seq]; };
 #pragma unroll
-    for (int u = 0; u < kBlk; ++u) cur[u] = rev_at(u);
-    for (int i0 = 0; i0 < N; i0 += kBlk) {
+    for (int u = 0; u < BLK; ++u) cur[u] = rev_at(u);
+    for (int i0 = 0; i0 < N; i0 += BLK) {
+        const int j0 = i0 + BLK;
+        if (j0 + BLK <= N) {
 #pragma unroll
-        for (int u = 0; u < kBlk; ++u) nxt[u] = rev_at(i0 + kBlk + u);
-        double out[kBlk];
+            for (int u = 0; u < BLK; ++u) nxt[u] = ext[(size_t)(N - 1 - j0 - u) * S + seq];
+        } else {
 #pragma unroll
-        for (int u = 0; u < kBlk; ++u) if (i0 + u < N) out[u] = step(cur[u]);
-#pragma unroll
-        for (int u = 0; u < kBlk; ++u) {
-            const int pos = N - 1 - (i0 + u) - e;
-            dst(pos, out[u], u, i0 + u < N && pos >= 0 && pos < n);
+            for (int u = 0; u < BLK; ++u) nxt[u] = rev_at(j0 + u);
         }
-        flush(N - 1 - i0 - e);                               // the block's positions: this one downwards
+        double out[BLK];
+        const int top = N - 1 - i0 - e;                      // the block's positions: this one downwards
+        if (i0 + BLK <= N && top < n && top - (BLK - 1) >= 0) {
 #pragma unroll
-        for (int u = 0; u < kBlk; ++u) cur[u] = nxt[u];
+            for (int u = 0; u < BLK; ++u) out[u] = step(cur[u]);
+#pragma unroll
+            for (int u = 0; u < BLK; ++u) dst(top - u, out[u], u, true);
+        } else {
+#pragma unroll
+            for (int u = 0; u < BLK; ++u) if (i0 + u < N) out[u] = step(cur[u]);
+#pragma unroll
+            for (int u = 0; u < BLK; ++u) {
+                const int pos = top - u;
+                dst(pos, out[u], u, i0 + u < N && pos >= 0 && pos < n);
+            }
+        }
+        flush(top, std::integral_constant<int, BLK>{});
+#pragma unroll
+        for (int u = 0; u < BLK; ++u) cur[u] = nxt[u];
     }
 }
 
@@ -114,14 +153,14 @@ template <typename SRC, typename DST, typename FLUSH>
 __device__ __forceinline__ void filtfilt_dispatch(const Filt &F, int n, SRC src, double *ext, size_t S, size_t seq, DST dst, FLUSH flush)
 {
     switch (F.nb) {
-    case 2: filtfilt_one<2>(F, n, src, ext, S, seq, dst, flush); break;
-    case 3: filtfilt_one<3>(F, n, src, ext, S, seq, dst, flush); break;
-    case 4: filtfilt_one<4>(F, n, src, ext, S, seq, dst, flush); break;
-    case 5: filtfilt_one<5>(F, n, src, ext, S, seq, dst, flush); break;
-    case 6: filtfilt_one<6>(F, n, src, ext, S, seq, dst, flush); break;
-    case 7: filtfilt_one<7>(F, n, src, ext, S, seq, dst, flush); break;
-    case 8: filtfilt_one<8>(F, n, src, ext, S, seq, dst, flush); break;
-    default: filtfilt_one<9>(F, n, src, ext, S, seq, dst, flush); break;
+    case 2: filtfilt_one<2, kBlkShort>(F, n, src, ext, S, seq, dst, flush); break;
+    case 3: filtfilt_one<3, kBlkShort>(F, n, src, ext, S, seq, dst, flush); break;
+    case 4: filtfilt_one<4, kBlkShort>(F, n, src, ext, S, seq, dst, flush); break;
+    case 5: filtfilt_one<5, kBlk>(F, n, src, ext, S, seq, dst, flush); break;
+    case 6: filtfilt_one<6, kBlk>(F, n, src, ext, S, seq, dst, flush); break;
+    case 7: filtfilt_one<7, kBlk>(F, n, src, ext, S, seq, dst, flush); break;
+    case 8: filtfilt_one<8, kBlk>(F, n, src, ext, S, seq, dst, flush); break;
+    default: filtfilt_one<9, kBlk>(F, n, src, ext, S, seq, dst, flush); break;
     }
 }
 
@@ -131,7 +170,7 @@ __device__ __forceinline__ void filtfilt_dispatch(const Filt &F, int n, SRC src,
 template <bool PLANAR>
 __global__ __launch_bounds__(64) void filtfilt_kernel(FiltfiltArgs A)
 {
-    __shared__ double tile[PLANAR ? kBlk * 65 : 1];
+    __shared__ double tile[PLANAR ? kBlkMax * 65 : 1];
     const size_t S = (size_t)A.R * A.L;
     const size_t seq = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (seq >= S) return;
@@ -156,15 +195,16 @@ __global__ __launch_bounds__(64) void filtfilt_kernel(FiltfiltArgs A)
             } else if (ok) yout[(size_t)t * L] = v;
         };
         auto dst_m = [&](int t, double v, int, bool ok) { if (ok) mid[(size_t)t * 64] = v; };
-        auto no_flush = [](int) {};
-        auto flush_y = [&](int top) {                                             // the tile holds steps u = 0 .. kBlk - 1 of every lane: positions top - u
+        auto no_flush = [](int, auto) {};
+        auto flush_y = [&](int top, auto blk_c) {                                    // the tile holds steps u = 0 .. blk - 1 of every lane: positions top - u
             if (!PLANAR || !full_wave) return;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             double *y0 = A.y + ((size_t)blockIdx.x * 64) * (size_t)n;
+            constexpr int blk = decltype(blk_c)::value;
 #pragma unroll 4
-            for (int q = 0; q < kBlk; ++q) {
-                const int idx = q * 64 + lane, sq = idx / kBlk, u = idx % kBlk, pos = top - u;
+            for (int q = 0; q < blk; ++q) {
+                const int idx = q * 64 + lane, sq = idx / blk, u = idx % blk, pos = top - u;
                 if (pos >= 0 && pos < n) y0[(size_t)sq * n + pos] = tile[u * 65 + sq];
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
