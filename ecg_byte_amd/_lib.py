@@ -91,7 +91,7 @@ def lib():
     L.ecgb_filtfilt_scratch_bytes.restype = sz
     L.ecgb_filtfilt_f64.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), vp, vp, vp, vp, sz, vp]
     L.ecgb_filtfilt_f64.restype = C.c_int
-    L.ecgb_filtfilt_planar_f64.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), vp, vp, vp, vp, sz, vp, vp]
+    L.ecgb_filtfilt_planar_f64.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), vp, vp, vp, vp, sz, vp, vp, vp]
     L.ecgb_filtfilt_planar_f64.restype = C.c_int
     L.ecgb_wavelet_denoise_planar_f64.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, vp]
     L.ecgb_wavelet_denoise_planar_f64.restype = C.c_int

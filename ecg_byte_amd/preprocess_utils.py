@@ -111,18 +111,21 @@ _PLANAR_MAX_N = 10000       # the bands of a sequence live in LDS (ecgb_wavelet_
 def _condition_planar(x, orig_fs, target_fs, out_lead):
     """The filter chain, the wavelet shrinkage and the resampling of condition_records' fast path with the intermediates sequence-major
     ([records * leads][n]; include/ecgbyte.h): the same three stages, the same bits as advanced_ecg_filter -> wavelet_denoise -> nsample_ecg, the lead
-    reorder folded into the last store and the stages' "not finite" tests into the kernels.  Returns ([records, m, leads], flags [records] uint8)."""
+    reorder folded into the last store and the "not finite" tests -- of the stages' results and of the raw records -- into the kernels.
+    Returns ([records, m, leads], flags [records] uint8: a stage wrote a value that is not finite, raw_flags [records] uint8: the record came in with one; the two
+    are rows of one [2, records] tensor, so one copy brings both to the host)."""
     R, n, leads = x.shape
     filters = design_filters(orig_fs)
     taps, b, a, zi = _pack_filters(filters)
     nbytes = _L().ecgb_filtfilt_scratch_bytes(R, n, leads, 3 * max(taps))
     nres = _L().ecgb_resample_cubic_scratch_bytes(R, n, leads)
     scratch = torch.empty(max(nbytes, nres) // 8, dtype=torch.float64, device=x.device)
-    flags = torch.zeros(R, dtype=torch.uint8, device=x.device)
+    both = torch.zeros(2, R, dtype=torch.uint8, device=x.device)
+    flags, raw_flags = both[0], both[1]
     planar = torch.empty(R * leads * n, dtype=torch.float64, device=x.device)
     _lib.check(_L().ecgb_filtfilt_planar_f64(C.c_void_p(x.data_ptr()), C.c_void_p(planar.data_ptr()), R, n, leads, len(filters), taps,
                                              b.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), zi.ctypes.data_as(C.c_void_p),
-                                             C.c_void_p(scratch.data_ptr()), nbytes, C.c_void_p(flags.data_ptr()), _st()))
+                                             C.c_void_p(scratch.data_ptr()), nbytes, C.c_void_p(flags.data_ptr()), C.c_void_p(raw_flags.data_ptr()), _st()))
     _lib.check(_L().ecgb_wavelet_denoise_planar_f64(C.c_void_p(planar.data_ptr()), C.c_void_p(planar.data_ptr()), R, n, leads, 1e-10, _st()))
     m = int(n * target_fs / orig_fs)
     out = torch.empty((R, m, leads), dtype=torch.float64, device=x.device)
@@ -131,7 +134,7 @@ def _condition_planar(x, orig_fs, target_fs, out_lead):
         lead_map = (C.c_int * leads)(*out_lead)
     _lib.check(_L().ecgb_resample_cubic_planar_f64(C.c_void_p(planar.data_ptr()), C.c_void_p(out.data_ptr()), R, n, leads, m, lead_map,
                                                    C.c_void_p(scratch.data_ptr()), nres, C.c_void_p(flags.data_ptr()), _st()))
-    return out, flags
+    return out, flags, raw_flags
 
 
 def advanced_ecg_filter(ecg_data, fs=500, notch_freqs=[50, 60], highcut=100.0):
@@ -184,33 +187,45 @@ def condition_records(signals, reorder=True, seg_len=1250, orig_fs=500, target_f
     if signals.dim() != 3:
         raise ValueError("condition_records takes a batch [records, n, leads]")
     signals = signals.contiguous()
-    kept = nonfinite_records(signals) == 0
-    n_bad = int((~kept).sum().item())
-    if n_bad:
-        print(f"Warning: NaN values detected in {n_bad} record(s). Skipping these instances.")
-        signals = signals[kept]
-    if signals.shape[0] == 0:
-        n_out = int(signals.shape[1] * target_fs / orig_fs)
-        seg = signals.new_zeros((0, n_out // seg_len, seg_len, signals.shape[2]))
-        return (seg, kept) if return_kept else seg
-    # Fast path: the stages run back to back with no host synchronisation; every stage's "all finite" test stays a device scalar and is read ONCE at the end.
-    # A non-finite value anywhere (overflow of a filter: not seen on real records) sends the batch through the literal sequence below, check_nan_inf after
-    # every stage as the reference has it.  The lead permutation commutes with every per-lead stage: it is applied last, to the resampled half-size data.
-    x = signals
-    n, leads = x.shape[1], x.shape[2]
-    if _planar_pipeline and n % 2 == 0 and 96 <= n <= _PLANAR_MAX_N and leads <= 32 and (not reorder or leads == 12):
-        # sequence-major intermediates, the reorder in the last store, the tests in the kernels (see _condition_planar)
+    n, leads = signals.shape[1], signals.shape[2]
+    planar_ok = _planar_pipeline and n % 2 == 0 and 96 <= n <= _PLANAR_MAX_N and leads <= 32 and (not reorder or leads == 12) and signals.shape[0] > 0
+    if planar_ok:
+        # Fast path, sequence-major intermediates (see _condition_planar): the stages run back to back on EVERY record with no host synchronisation -- the test of the
+        # raw records is read off the first filter's loads instead of a pass of its own (a record that holds NaN / inf costs its share of the work and is dropped
+        # afterwards; the stages are per record, so the others are not touched) -- and the flags come to the host once, at the end.
         out_lead = None
         if reorder:
             new_indices = reorder_indices(torch.arange(12))        # output lead c = input lead new_indices[c]
             out_lead = [0] * 12
             for c, l in enumerate(new_indices.tolist()):
                 out_lead[l] = c
-        x, flags = _condition_planar(x, orig_fs, target_fs, out_lead)
-        if not bool(flags.any()):
+        x, flags, raw_flags = _condition_planar(signals, orig_fs, target_fs, out_lead)
+        host = torch.stack([flags, raw_flags]).cpu()
+        kept = (host[1] == 0).to(signals.device)
+        n_bad = int((host[1] != 0).sum())
+        if n_bad:
+            print(f"Warning: NaN values detected in {n_bad} record(s). Skipping these instances.")
+        if not bool(((host[0] != 0) & (host[1] == 0)).any()):   # every kept record left every stage finite
+            if n_bad:
+                x = x[kept]
             seg, _ = segment_ecg(x, None, seg_len)
             return (seg, kept) if return_kept else seg
+        signals = signals[kept] if n_bad else signals          # a stage overflowed: the literal sequence below, on the kept records
     else:
+        kept = nonfinite_records(signals) == 0
+        n_bad = int((~kept).sum().item())
+        if n_bad:
+            print(f"Warning: NaN values detected in {n_bad} record(s). Skipping these instances.")
+            signals = signals[kept]
+    if signals.shape[0] == 0:
+        n_out = int(signals.shape[1] * target_fs / orig_fs)
+        seg = signals.new_zeros((0, n_out // seg_len, seg_len, signals.shape[2]))
+        return (seg, kept) if return_kept else seg
+    # Per-stage path: every stage's "all finite" test stays a device scalar and is read ONCE at the end.
+    # A non-finite value anywhere (overflow of a filter: not seen on real records) sends the batch through the literal sequence below, check_nan_inf after
+    # every stage as the reference has it.  The lead permutation commutes with every per-lead stage: it is applied last, to the resampled half-size data.
+    x = signals
+    if not planar_ok:
         flags = []
         x = advanced_ecg_filter(x, fs=orig_fs); flags.append(nonfinite_records(x, 1))
         x = wavelet_denoise(x); flags.append(nonfinite_records(x, 1))

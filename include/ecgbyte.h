@@ -224,10 +224,11 @@ void ecgb_set_wavelet_workgroup_kernel(int on);
  *   ecgb_resample_cubic_planar_f64  x [records * leads][n] -> y [records, m, leads]; out_lead (host, may be NULL): lead l of the input becomes lead out_lead[l] of
  *                                   the output -- the MIMIC lead reorder (preprocess_utils.py:35-40) folded into the store; a permutation of 0 .. leads-1, leads <= 32
  * flags_dev (may be NULL): [records] bytes, zeroed by the caller; set to 1 where the stage wrote a value that is not finite (check_nan_inf's test,
- * preprocess_utils.py:26-33, without another pass over the data; the wavelet stage zeroes such values itself, line 62). */
+ * preprocess_utils.py:26-33, without another pass over the data; the wavelet stage zeroes such values itself, line 62).  raw_flags_dev (may be NULL): the same for
+ * the record as it came in -- process_instance's `np.isnan(signal).any()` skip (134-136; any value that is not finite raises it), read off the first filter's loads. */
 int ecgb_filtfilt_planar_f64(const double *x_dev, double *y_dev, int records, int n, int leads, int n_filters, const int *n_taps,
                              const double *b, const double *a, const double *zi, double *scratch_dev, size_t scratch_bytes,
-                             unsigned char *flags_dev, void *stream);
+                             unsigned char *flags_dev, unsigned char *raw_flags_dev, void *stream);
 int ecgb_wavelet_denoise_planar_f64(const double *x_dev, double *y_dev, int records, int n, int leads, double epsilon, void *stream);
 int ecgb_resample_cubic_planar_f64(const double *x_dev, double *y_dev, int records, int n, int leads, int m, const int *out_lead,
                                    double *scratch_dev, size_t scratch_bytes, unsigned char *flags_dev, void *stream);

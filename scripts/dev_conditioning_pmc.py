@@ -8,6 +8,6 @@ base = np.ascontiguousarray(synth.synth_ecg(64, 5000, seed=0).transpose(0, 2, 1)
 x = np.concatenate([base] * (R // 64)) + 0.01 * np.random.default_rng(0).standard_normal((R, 5000, 12))
 xd = torch.from_numpy(x).cuda()
 for _ in range(3):
-    out, flags = pp._condition_planar(xd, 500, 250, None)
+    out, flags, _ = pp._condition_planar(xd, 500, 250, None)
 torch.cuda.synchronize()
 print("ok", float(out.abs().max()), int(flags.sum()))

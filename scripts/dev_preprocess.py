@@ -53,7 +53,7 @@ flags = torch.zeros(R, dtype=torch.uint8, device="cuda")
 planar = torch.empty(R * leads * n, dtype=torch.float64, device="cuda"); out = torch.empty((R, 2500, leads), dtype=torch.float64, device="cuda")
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 vp = lambda t: C.c_void_p(t.data_ptr())
-t1, _ = timed(lambda: L_.check(lib.ecgb_filtfilt_planar_f64(vp(xd), vp(planar), R, n, leads, 4, taps, b.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), zi.ctypes.data_as(C.c_void_p), vp(scratch), nbytes, vp(flags), st())))
+t1, _ = timed(lambda: L_.check(lib.ecgb_filtfilt_planar_f64(vp(xd), vp(planar), R, n, leads, 4, taps, b.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), zi.ctypes.data_as(C.c_void_p), vp(scratch), nbytes, vp(flags), None, st())))
 t2, _ = timed(lambda: L_.check(lib.ecgb_wavelet_denoise_planar_f64(vp(planar), vp(planar), R, n, leads, 1e-10, st())))
 t3, _ = timed(lambda: L_.check(lib.ecgb_resample_cubic_planar_f64(vp(planar), vp(out), R, n, leads, 2500, None, vp(scratch), nres, vp(flags), st())))
 t4, _ = timed(lambda: pp._condition_planar(xd, 500, 250, None))

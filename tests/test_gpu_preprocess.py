@@ -141,9 +141,9 @@ def test_sequence_major_pipeline_is_the_three_stage_calls_bit_for_bit(pp, R, n, 
     got = pp.condition_records(x, reorder=reorder, seg_len=n // 4)
     assert got.shape == want.shape and torch.equal(got.view(torch.int64), want.view(torch.int64))
     # the stages one by one against the public per-stage functions
-    planar_out, flags = pp._condition_planar(x, 500, 250, None)
+    planar_out, flags, raw_flags = pp._condition_planar(x, 500, 250, None)
     ref = pp.nsample_ecg(pp.wavelet_denoise(pp.advanced_ecg_filter(x)), 500, 250)
-    assert torch.equal(planar_out.view(torch.int64), ref.view(torch.int64)) and not bool(flags.any())
+    assert torch.equal(planar_out.view(torch.int64), ref.view(torch.int64)) and not bool(flags.any()) and not bool(raw_flags.any())
 
 
 def test_sequence_major_pipeline_flags_records_that_leave_a_stage_not_finite(pp):
@@ -152,7 +152,8 @@ def test_sequence_major_pipeline_flags_records_that_leave_a_stage_not_finite(pp)
     x = _records(4, 1000, seed=11)
     x[2, 500, 4] = 1e308                                                                # finite on entry; the filter chain overflows around it
     xd = torch.from_numpy(x).cuda()
-    _, flags = pp._condition_planar(xd, 500, 250, None)
+    _, flags, raw_flags = pp._condition_planar(xd, 500, 250, None)
+    assert not bool(raw_flags.any())
     per_stage = pp.advanced_ecg_filter(xd)
     assert flags.cpu().tolist() == [0, 0, int(not bool(torch.isfinite(per_stage[2]).all())), 0]
     try:
@@ -161,6 +162,19 @@ def test_sequence_major_pipeline_flags_records_that_leave_a_stage_not_finite(pp)
     finally:
         pp.set_planar_pipeline(True)
     got = pp.condition_records(xd, seg_len=250)
+    assert torch.equal(got.view(torch.int64), want.view(torch.int64))
+    # ... and with a record that comes in with a NaN beside the one that overflows: dropped, the overflowing one still sends the rest through the literal sequence
+    x[0, 10, 0] = np.nan
+    xd = torch.from_numpy(x).cuda()
+    _, flags, raw_flags = pp._condition_planar(xd, 500, 250, None)
+    assert raw_flags.cpu().tolist() == [1, 0, 0, 0] and flags.cpu().tolist()[1::2] == [0, 0]
+    try:
+        pp.set_planar_pipeline(False)
+        want, want_kept = pp.condition_records(xd, seg_len=250, return_kept=True)
+    finally:
+        pp.set_planar_pipeline(True)
+    got, kept = pp.condition_records(xd, seg_len=250, return_kept=True)
+    assert kept.cpu().tolist() == want_kept.cpu().tolist() == [False, True, True, True]
     assert torch.equal(got.view(torch.int64), want.view(torch.int64))
 
 
