@@ -374,6 +374,24 @@ struct WaveletArgs {
     double epsilon;
 };
 
+// pywt.threshold(data, value, 'soft') = data * clip(1 - value / |data|, 0) followed by the reference's guard (preprocess_utils.py:57-59: zero where the result is
+// not finite or |data| <= epsilon).  The division is the expensive part of the stage (a float64 division is ~40 instructions around v_rcp_f64: 1.5 of the workgroup
+// kernel's 3.5 ms went here) and most detail coefficients lie under the threshold, where the quotient is >= 1 exactly when value >= |data| (IEEE division is monotone and
+// exact at 1), the clip gives 0 and the product is data * 0 (its sign kept): those take no division.  Written `mag <= thr` so that a NaN on either side takes the general
+// path and comes out as it always did (0 / 0, inf / inf and a NaN threshold included).
+__device__ __forceinline__ double soft_threshold(double c, double mag, double thr, double epsilon)
+{
+    double t;
+    if (mag <= thr) {
+        t = c * 0.0;
+    } else {
+        double f = 1.0 - thr / mag;
+        f = f < 0.0 ? 0.0 : f;                               // (NaN stays NaN and is zeroed by the test below)
+        t = c * f;
+    }
+    return (isfinite(t) && mag > epsilon) ? t : 0.0;
+}
+
 __global__ __launch_bounds__(64) void wavelet_denoise_kernel(WaveletArgs A)
 {
     const size_t S = (size_t)A.R * A.L;
@@ -478,10 +496,7 @@ __global__ __launch_bounds__(64) void wavelet_denoise_kernel(WaveletArgs A)
 #pragma unroll
             for (int q = 0; q < kOB; ++q) {
                 const double mag = fabs(c[q]);
-                double f = 1.0 - thr / mag;                  // pywt.threshold 'soft': data * clip(1 - value / |data|, 0)
-                f = f < 0.0 ? 0.0 : f;                       // (NaN, from 0 / 0, stays NaN and is zeroed by the test below)
-                const double t = c[q] * f;
-                c[q] = (isfinite(t) && mag > A.epsilon) ? t : 0.0;
+                c[q] = soft_threshold(c[q], mag, thr, A.epsilon);
             }
 #pragma unroll
             for (int q = 0; q < kOB; ++q) if (i0 + q < A.len[lev]) band(A.offD[lev], i0 + q) = c[q];
@@ -555,7 +570,7 @@ template <bool PLANAR>
 __global__ __launch_bounds__(kWgLanes) void wavelet_denoise_wg_kernel(WaveletWgArgs A)
 {
     extern __shared__ __align__(16) double s_w[];
-    __shared__ unsigned long long s_key[2];
+    __shared__ unsigned long long s_key[2 * (kWgLanes / 64)];
     __shared__ int s_nan;
     const size_t S = (size_t)A.R * A.L;
     const size_t per_xcd = (S + 7) / 8;
@@ -615,8 +630,9 @@ __global__ __launch_bounds__(kWgLanes) void wavelet_denoise_wg_kernel(WaveletWgA
         __syncthreads();
     }
     // ---- median of |cD4|: the k-th order statistic is the largest value with at most k values below it.  |cD4| goes to LDS once (where A1 was: dead until the
-    // synthesis rewrites it), every lane counts the values below its own (n4 broadcast reads) and the candidates meet in an LDS maximum on the bit patterns
-    // (monotone for x >= 0).  The same order statistics as the radix select of the kernel above.
+    // synthesis rewrites it), every lane counts the values below its own (n4 broadcast reads) and the candidates meet in a maximum on the bit patterns (monotone
+    // for x >= 0): across the wave by shuffles, across the four waves through LDS.  (With one LDS atomicMax per candidate -- a compare-and-swap loop on 64 bits, half
+    // the band contending for one address -- this section was 1.3 of the kernel's 3.5 ms.)  The same order statistics as the radix select of the kernel above.
     const int n4 = A.len[kLevels];
     const double *d4 = s_w + A.offD[kLevels];
     double *mag4 = s_w + A.offA[1];
@@ -624,10 +640,10 @@ __global__ __launch_bounds__(kWgLanes) void wavelet_denoise_wg_kernel(WaveletWgA
         bool nan_here = false;
         for (int i = tid; i < n4; i += kWgLanes) { const double v = d4[i]; nan_here |= isnan(v); mag4[i] = fabs(v); }
         if (nan_here) s_nan = 1;
-        if (tid < 2) s_key[tid] = 0ull;
     }
     __syncthreads();
     const bool any_nan = s_nan != 0;
+    unsigned long long cand_lo = 0ull, cand_hi = 0ull;
     if (!any_nan) {
         const int k_lo = (n4 & 1) ? n4 / 2 : n4 / 2 - 1, k_hi = n4 / 2;
         for (int i = tid; i < n4; i += kWgLanes) {
@@ -640,22 +656,32 @@ __global__ __launch_bounds__(kWgLanes) void wavelet_denoise_wg_kernel(WaveletWgA
             }
             for (; j < n4; ++j) below += mag4[j] < v ? 1 : 0;
             const unsigned long long key = (unsigned long long)__double_as_longlong(v);
-            if (below <= k_lo) atomicMax(&s_key[0], key);
-            if (below <= k_hi) atomicMax(&s_key[1], key);
+            if (below <= k_lo && key > cand_lo) cand_lo = key;
+            if (below <= k_hi && key > cand_hi) cand_hi = key;
         }
     }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long o_lo = __shfl_xor(cand_lo, d, 64), o_hi = __shfl_xor(cand_hi, d, 64);
+        cand_lo = o_lo > cand_lo ? o_lo : cand_lo;
+        cand_hi = o_hi > cand_hi ? o_hi : cand_hi;
+    }
+    if ((tid & 63) == 0) { s_key[(tid >> 6) * 2] = cand_lo; s_key[(tid >> 6) * 2 + 1] = cand_hi; }
     __syncthreads();
-    const double med_lo = __longlong_as_double((long long)s_key[0]), med_hi = __longlong_as_double((long long)s_key[1]);
+    unsigned long long key_lo = s_key[0], key_hi = s_key[1];
+#pragma unroll
+    for (int w = 1; w < kWgLanes / 64; ++w) {
+        key_lo = s_key[2 * w] > key_lo ? s_key[2 * w] : key_lo;
+        key_hi = s_key[2 * w + 1] > key_hi ? s_key[2 * w + 1] : key_hi;
+    }
+    const double med_lo = __longlong_as_double((long long)key_lo), med_hi = __longlong_as_double((long long)key_hi);
     const double med = any_nan ? __longlong_as_double(0x7ff8000000000000ll) : (n4 & 1) ? med_lo : 0.5 * (med_lo + med_hi);
     const double thr = med == 0.0 ? 0.0 : med / 0.6745;
     for (int lev = 1; lev <= kLevels; ++lev) {
         double *cd = s_w + A.offD[lev];
         for (int i = tid; i < A.len[lev]; i += kWgLanes) {
             const double c = cd[i], mag = fabs(c);
-            double f = 1.0 - thr / mag;                      // pywt.threshold 'soft': data * clip(1 - value / |data|, 0)
-            f = f < 0.0 ? 0.0 : f;
-            const double t = c * f;
-            cd[i] = (isfinite(t) && mag > A.epsilon) ? t : 0.0;
+            cd[i] = soft_threshold(c, mag, thr, A.epsilon);
         }
     }
     __syncthreads();
