@@ -316,7 +316,7 @@ def bench_preprocess(dev, n_records=4096):
     the device.  Algorithmic bytes: 480 KB read + 240 KB written per record.  The stages are recursions along time, one sequence (record, lead) per lane:
     4 096 records are 768 waves -- one per SIMD; fewer records take the same time (1 024: the same 20 ms), so the batch is what an offline pass over a corpus
     of 200 000 records would use.  `stage_traffic` is what the stages move as they are written (every filtfilt is a forward and a backward sweep through HBM,
-    the wavelet transform one, the spline two and a half), not the algorithmic bytes; `bound` says what the kernels actually run against."""
+    the wavelet transform one, the spline two and a quarter), not the algorithmic bytes; `bound` says what the kernels actually run against."""
     import torch
     from ecg_byte_amd import preprocess_utils as pp, synth
     base = np.ascontiguousarray(synth.synth_ecg(64, 5000, seed=0).transpose(0, 2, 1))
@@ -336,15 +336,15 @@ def bench_preprocess(dev, n_records=4096):
     samples = n_records * 5000 * 12
     # sweeps through HBM as the stages are written, 8 bytes read + 8 written per sample and sweep: 4 filters x (forward, backward); wavelet: ONE (round 3: a
     # workgroup per sequence keeps the bands in LDS -- the samples are read once and the result written once; the lane-per-sequence kernel moved ~5);
-    # spline: tridiagonal forward, back substitution, evaluation (half-size output) ~ 2.5; the raw-record finite test reads 8 bytes (the stages' tests are in the kernels)
-    sweeps = {"filter_chain": 8.0, "wavelet": 1.0, "resample": 2.5}
-    traffic = sum(sweeps.values()) * 16 * samples + 1.0 * 8 * samples
+    # spline: tridiagonal forward sweep, then back substitution and evaluation in one (36 bytes per sample) = 2.25; every finite test is in the kernels
+    sweeps = {"filter_chain": 8.0, "wavelet": 1.0, "resample": 2.25}
+    traffic = sum(sweeps.values()) * 16 * samples
     return {"workload": f"{n_records} raw records of 5000 x 12 float64: notch 50/60 Hz, band-pass, high-pass (filtfilt), db6 wavelet shrinkage, cubic resample to 250 Hz, 1250-sample segments",
             "ms": ms, "records_per_s": n_records / (ms * 1e-3), "GB/s": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "stage_traffic": {"sweeps_of_16_bytes_per_sample": sweeps, "bytes": traffic, "GB/s": traffic / (ms * 1e-3) / 1e9,
                               "frac_of_hbm_peak": traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "bound": "filter chain and spline: the HBM traffic of their sweeps (every filtfilt writes its forward result and reads it back reversed: 31.8 GB at ~4.8 TB/s, "
-                     "10 GB at ~3.7 TB/s); wavelet: vector issue (0.7 ms of float64 arithmetic at full rate inside 3.5 ms; index arithmetic and the median's "
+                     "8.8 GB at ~3.8 TB/s); wavelet: vector issue (0.7 ms of float64 arithmetic at full rate inside 3.05 ms; index arithmetic and the median's "
                      "comparisons are the rest); profiles/r03/conditioning_pmc.txt, DESIGN.md section 9",
             "segments_out": list(out.shape)}
 

@@ -244,6 +244,7 @@ __global__ __launch_bounds__(64) void filtfilt_kernel(FiltfiltArgs A)
 // 2 - sqrt(3) in double precision within ~20 rows), then  S(i + u) = y[i] + u (dy - (2 M[i] + M[i+1]) / 6) + u^2 M[i] / 2 + u^3 (M[i+1] - M[i]) / 6.
 // Agreement with scipy: the two solves differ by rounding only (1e-13 of the signal's range measured, tests/test_gpu_preprocess.py).
 constexpr int kMaxLeadMap = 32, kResampleTab = 32;
+constexpr int kFuseMin = 64;      // shorter signals: back substitution and evaluation as two sweeps (the first version; n = 4 .. 7 have their own closed forms)
 struct ResampleArgs {
     const double *x;                 // [R, n, L], or [R * L][n] (PLANAR_IN)
     double *y;                       // [R, m, L]
@@ -306,6 +307,73 @@ __global__ __launch_bounds__(64) void resample_cubic_kernel(ResampleArgs A)
         double Mnext = dprev;                                // M[n-3]
         double mc[kBlk], mn[kBlk];
         auto mcl = [&](int i) -> double { return M[(size_t)max(i, 2) * 64]; };
+        if (n >= kFuseMin) {
+            // ---- back substitution and evaluation in ONE descending sweep: the spline on [i, i + 1] needs M[i] and M[i + 1], and the back substitution hands the
+            // M's out from the top down -- so every block of rows is evaluated right where it is solved, from a per-lane column of an LDS tile (a row index is the same
+            // in every lane; registers cannot be indexed by it), and M is never written to memory or read back: 36 bytes of traffic per sample instead of 52.  Each output
+            // is the expression it was (same operands, same order); only the order in which the outputs are produced changes.
+            __shared__ double mt[(kBlk + 2) * 64];
+            double *col = mt + threadIdx.x;
+            int jc = m - 1;                                  // next output, descending
+            auto interval_of = [&](int j, double &sx) -> int {
+                sx = m > 1 ? (double)j * (double)(n - 1) / (double)(m - 1) : 0.0;
+                int i = (int)sx;
+                return i > n - 2 ? n - 2 : i;
+            };
+            // outputs jc, jc - 1, ... whose interval is >= lo; M[i] is col[(i - base) * 64]
+            auto eval_down = [&](int lo, int base) {
+                constexpr int kE = 8;
+                for (;;) {
+                    double y0[kE], y1[kE], m0[kE], m1[kE], uu[kE];
+                    int cnt = 0;
+#pragma unroll
+                    for (int u = 0; u < kE; ++u) {
+                        double sx;
+                        const int j = max(jc - u, 0);
+                        const int i = interval_of(j, sx);
+                        const bool ok = jc - u >= 0 && i >= lo;          // (intervals do not grow as j falls: the valid outputs are a prefix)
+                        cnt += ok ? 1 : 0;
+                        const int ic = max(i, lo);
+                        uu[u] = sx - (double)i;
+                        y0[u] = Y(ic); y1[u] = Y(ic + 1); m0[u] = col[(size_t)(ic - base) * 64]; m1[u] = col[(size_t)(ic + 1 - base) * 64];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kE; ++u) {
+                        if (u >= cnt) continue;
+                        const double c1 = (y1[u] - y0[u]) - (2.0 * m0[u] + m1[u]) / 6.0, c2 = 0.5 * m0[u], c3 = (m1[u] - m0[u]) / 6.0;
+                        const double v = y0[u] + uu[u] * (c1 + uu[u] * (c2 + uu[u] * c3));
+                        bad |= !isfinite(v);
+                        out[(size_t)(jc - u) * L] = v;
+                    }
+                    jc -= cnt;
+                    if (cnt < kE) break;
+                }
+            };
+            // intervals n - 2 and n - 3: M[n-3] (the forward sweep's last value), M[n-2], M[n-1] = 2 M[n-2] - M[n-3]
+            col[0] = dprev; col[64] = Mn2; col[128] = 2.0 * Mn2 - dprev;
+            eval_down(n - 3, n - 3);
+#pragma unroll
+            for (int u = 0; u < kBlk; ++u) mc[u] = mcl(n - 4 - u);
+            for (int i0 = n - 4; i0 >= 2; i0 -= kBlk) {
+#pragma unroll
+                for (int u = 0; u < kBlk; ++u) mn[u] = mcl(i0 - kBlk - u);
+                const int base = i0 - kBlk + 1;
+                col[(size_t)kBlk * 64] = Mnext;              // M[i0 + 1]
+#pragma unroll
+                for (int u = 0; u < kBlk; ++u) {
+                    const int i = i0 - u;
+                    if (i >= 2) { Mnext = mc[u] - cprime(i) * Mnext; col[(size_t)(kBlk - 1 - u) * 64] = Mnext; }
+                }
+                eval_down(max(base, 2), base);
+#pragma unroll
+                for (int u = 0; u < kBlk; ++u) mc[u] = mn[u];
+            }
+            // intervals 1 and 0: M[2] (the last value of the sweep), M[1], M[0] = 2 M[1] - M[2]
+            col[128] = Mnext; col[64] = M1; col[0] = 2.0 * M1 - Mnext;
+            eval_down(0, 0);
+            if (A.flags && bad) A.flags[r] = 1;
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < kBlk; ++u) mc[u] = mcl(n - 4 - u);
         for (int i0 = n - 4; i0 >= 2; i0 -= kBlk) {
