@@ -344,7 +344,7 @@ def bench_preprocess(dev, n_records=4096):
             "stage_traffic": {"sweeps_of_16_bytes_per_sample": sweeps, "bytes": traffic, "GB/s": traffic / (ms * 1e-3) / 1e9,
                               "frac_of_hbm_peak": traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "bound": "filter chain and spline: the HBM traffic of their sweeps (every filtfilt writes its forward result and reads it back reversed: 31.8 GB at ~4.8 TB/s, "
-                     "8.8 GB at ~3.8 TB/s); wavelet: vector issue (0.7 ms of float64 arithmetic at full rate inside 3.05 ms; index arithmetic and the median's "
+                     "8.8 GB at ~3.8 TB/s); wavelet: vector issue (0.7 ms of float64 arithmetic at full rate inside 2.65 ms; index arithmetic and the median's "
                      "comparisons are the rest); profiles/r03/conditioning_pmc.txt, DESIGN.md section 9",
             "segments_out": list(out.shape)}
 

@@ -614,7 +614,7 @@ __global__ __launch_bounds__(64) void wavelet_denoise_kernel(WaveletArgs A)
 
 // ---- the same stage with ONE WORKGROUP PER SEQUENCE (the path ecgb_wavelet_denoise_f64 takes whenever a sequence's bands fit in LDS) ------------------------
 // The transform is a pair of FIR filters, not a recursion: every coefficient of a level is independent of its neighbours, so the parallel axis can be TIME and the
-// sequence can stay on chip.  256 lanes share one sequence: the samples are read once into LDS, the four analysis levels, the median, the shrinkage and three of the
+// sequence can stay on chip.  512 lanes share one sequence: the samples are read once into LDS, the four analysis levels, the median, the shrinkage and three of the
 // four synthesis levels run LDS to LDS, and the last synthesis level writes the result -- 16 bytes of HBM traffic per sample where the lane-per-sequence kernel above
 // moves ~92 (every band written and read back through its time-major scratch, the median's sweeps).  Each coefficient is the sum the kernel above forms, term by term
 // in the same order, and the median is the same order statistic: the results are the same bits (tests/test_gpu_preprocess.py compares the two kernels).
@@ -631,7 +631,12 @@ struct WaveletWgArgs {
     double epsilon;
 };
 
-constexpr int kWgLanes = 256;
+// lanes per sequence: 512 (eight waves; two workgroups per CU = four waves per SIMD to overlap the kernel's fourteen short phases: 3.05 ms with 256 lanes, 2.69 with 512,
+// 4.31 with 1 024)
+#ifndef ECGB_WAVELET_LANES
+#define ECGB_WAVELET_LANES 512
+#endif
+constexpr int kWgLanes = ECGB_WAVELET_LANES;
 
 // PLANAR: x and y are [sequence][time] (what ecgb_filtfilt_planar_f64 writes): the workgroup's loads and stores are whole lines
 template <bool PLANAR>
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(kWgLanes) void wavelet_denoise_wg_kernel(WaveletWgA
     for (int k = 0; k < kWF; ++k) { lo[k] = kDb6Lo[k]; hi[k] = ((k & 1) ? 1.0 : -1.0) * kDb6Lo[kWF - 1 - k]; }
     if (tid == 0) s_nan = 0;
     // the samples: kLoadBatch loads per lane in flight before the first is used (n = 5000: one memory round trip for the sequence)
-    constexpr int kLoadBatch = 20;
+    constexpr int kLoadBatch = (5120 + kWgLanes - 1) / kWgLanes;      // n = 5000 in one batch
     for (int i0 = tid; i0 < n; i0 += kLoadBatch * kWgLanes) {
         double v[kLoadBatch];
 #pragma unroll
