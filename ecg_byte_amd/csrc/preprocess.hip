@@ -285,22 +285,40 @@ __global__ __launch_bounds__(64) void resample_cubic_kernel(ResampleArgs A)
         double yc[kBlk + 2], yn[kBlk + 2];
 #pragma unroll
         for (int u = 0; u < kBlk + 2; ++u) yc[u] = ycl(3 - 1 + u);          // rows 3 .. 3 + kBlk - 1 need Y(2) .. Y(3 + kBlk)
+        const double c_inf = A.cp[kResampleTab - 1];         // the pivots' fixed point (rows past the table)
         for (int i0 = 3; i0 <= n - 3; i0 += kBlk) {
+            // (whole blocks inside the signal and past the pivot table: straight-line code, as in filtfilt_one)
+            if (i0 + 2 * kBlk + 1 <= n - 1) {
 #pragma unroll
-            for (int u = 0; u < kBlk + 2; ++u) yn[u] = ycl(i0 + kBlk - 1 + u);
+                for (int u = 0; u < kBlk + 2; ++u) yn[u] = Y(i0 + kBlk - 1 + u);
+            } else {
+#pragma unroll
+                for (int u = 0; u < kBlk + 2; ++u) yn[u] = ycl(i0 + kBlk - 1 + u);
+            }
             double out[kBlk];
+            if (i0 - 2 >= kResampleTab - 1 && i0 + kBlk - 1 <= n - 4) {
 #pragma unroll
-            for (int u = 0; u < kBlk; ++u) {
-                const int i = i0 + u;
-                if (i <= n - 3) {
-                    double ri = 6.0 * (yc[u + 2] - 2.0 * yc[u + 1] + yc[u]);
-                    if (i == n - 3) ri -= Mn2;
-                    dprev = (ri - dprev) * cprime(i);        // cprime(i) = 1 / (4 - c'[i-1])
+                for (int u = 0; u < kBlk; ++u) {
+                    const double ri = 6.0 * (yc[u + 2] - 2.0 * yc[u + 1] + yc[u]);
+                    dprev = (ri - dprev) * c_inf;
                     out[u] = dprev;
                 }
-            }
 #pragma unroll
-            for (int u = 0; u < kBlk; ++u) if (i0 + u <= n - 3) M[(size_t)(i0 + u) * 64] = out[u];
+                for (int u = 0; u < kBlk; ++u) M[(size_t)(i0 + u) * 64] = out[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < kBlk; ++u) {
+                    const int i = i0 + u;
+                    if (i <= n - 3) {
+                        double ri = 6.0 * (yc[u + 2] - 2.0 * yc[u + 1] + yc[u]);
+                        if (i == n - 3) ri -= Mn2;
+                        dprev = (ri - dprev) * cprime(i);    // cprime(i) = 1 / (4 - c'[i-1])
+                        out[u] = dprev;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kBlk; ++u) if (i0 + u <= n - 3) M[(size_t)(i0 + u) * 64] = out[u];
+            }
 #pragma unroll
             for (int u = 0; u < kBlk + 2; ++u) yc[u] = yn[u];
         }

@@ -7,6 +7,7 @@ Same function names and argument meaning as the reference; the arrays are float6
 library these functions raise.
 """
 import ctypes as C
+import functools
 
 import numpy as np
 import torch
@@ -108,6 +109,15 @@ def filtfilt(filters, x):
 _PLANAR_MAX_N = 10000       # the bands of a sequence live in LDS (ecgb_wavelet_denoise_planar_f64)
 
 
+@functools.lru_cache(maxsize=8)
+def _reference_chain(fs):
+    """advanced_ecg_filter's four filters at sampling rate fs, designed and packed once (scipy's iirnotch / butter / lfilter_zi take ~0.4 ms of host time per call,
+    and the fast path of condition_records is otherwise one launch sequence and one synchronisation)."""
+    filters = design_filters(fs)
+    taps, b, a, zi = _pack_filters(filters)
+    return taps, b, a, zi, len(filters)
+
+
 def _condition_planar(x, orig_fs, target_fs, out_lead):
     """The filter chain, the wavelet shrinkage and the resampling of condition_records' fast path with the intermediates sequence-major
     ([records * leads][n]; include/ecgbyte.h): the same three stages, the same bits as advanced_ecg_filter -> wavelet_denoise -> nsample_ecg, the lead
@@ -115,15 +125,14 @@ def _condition_planar(x, orig_fs, target_fs, out_lead):
     Returns ([records, m, leads], flags [records] uint8: a stage wrote a value that is not finite, raw_flags [records] uint8: the record came in with one; the two
     are rows of one [2, records] tensor, so one copy brings both to the host)."""
     R, n, leads = x.shape
-    filters = design_filters(orig_fs)
-    taps, b, a, zi = _pack_filters(filters)
+    taps, b, a, zi, n_filters = _reference_chain(orig_fs)
     nbytes = _L().ecgb_filtfilt_scratch_bytes(R, n, leads, 3 * max(taps))
     nres = _L().ecgb_resample_cubic_scratch_bytes(R, n, leads)
     scratch = torch.empty(max(nbytes, nres) // 8, dtype=torch.float64, device=x.device)
     both = torch.zeros(2, R, dtype=torch.uint8, device=x.device)
     flags, raw_flags = both[0], both[1]
     planar = torch.empty(R * leads * n, dtype=torch.float64, device=x.device)
-    _lib.check(_L().ecgb_filtfilt_planar_f64(C.c_void_p(x.data_ptr()), C.c_void_p(planar.data_ptr()), R, n, leads, len(filters), taps,
+    _lib.check(_L().ecgb_filtfilt_planar_f64(C.c_void_p(x.data_ptr()), C.c_void_p(planar.data_ptr()), R, n, leads, n_filters, taps,
                                              b.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), zi.ctypes.data_as(C.c_void_p),
                                              C.c_void_p(scratch.data_ptr()), nbytes, C.c_void_p(flags.data_ptr()), C.c_void_p(raw_flags.data_ptr()), _st()))
     _lib.check(_L().ecgb_wavelet_denoise_planar_f64(C.c_void_p(planar.data_ptr()), C.c_void_p(planar.data_ptr()), R, n, leads, 1e-10, _st()))
