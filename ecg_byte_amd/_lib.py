@@ -146,6 +146,7 @@ def lib():
         "ecgb_softmax_bwd": [vp, vp, ci, ci, f32, vp],
         "ecgb_set_gemm_tile": [ci],
         "ecgb_set_gemm_backward_persistent": [ci],
+        "ecgb_get_gemm_backward_persistent": [],
         "ecgb_set_gemm_group_m": [ci],
         "ecgb_attn_decode": [vp, vp, vp, ll, ll, vp, ll, vp, ci, ci, ci, ci, ci, f32, vp],
         "ecgb_attn_decode_dyn": [vp, vp, vp, ll, ll, vp, ll, vp, ci, vp, ci, ci, ci, f32, vp],
@@ -158,6 +159,7 @@ def lib():
         "ecgb_gemm_nt_bf16_rope": [vp, ll, vp, ll, vp, ll, vp, ll, ci, vp, ll, ci, ci, ci, f32, vp, vp, ci, vp],
         "ecgb_set_gemm_w4": [ci],
         "ecgb_set_gemm_w4_group_m": [ci],
+        "ecgb_set_gemm_w4_sched": [ci],
         "ecgb_attn_decode_split_dyn": [vp, vp, vp, ll, ll, vp, ll, vp, ci, vp, ci, ci, ci, f32, ci, vp, sz, vp],
         "ecgb_gemm_tn_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, vp],
         "ecgb_sum_slabs_bf16": [vp, ll, ci, vp, sz, ci, vp],

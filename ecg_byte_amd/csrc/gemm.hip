@@ -2063,6 +2063,8 @@ extern "C" int ecgb_set_gemm_backward_persistent(int on)
     return ECGB_OK;
 }
 
+extern "C" int ecgb_get_gemm_backward_persistent(void) { return g_nn_persist; }
+
 extern "C" int ecgb_set_gemm_tile(int tile)
 {
     if (tile != 0 && tile != 128 && (tile < 256 || tile > 259)) { ecgb::set_error("ecgb_set_gemm_tile: 0, 128, 256, 257, 258 or 259"); return ECGB_ERR_INVALID; }

@@ -87,7 +87,14 @@ __device__ __forceinline__ void tile_rc(const W4Args &G, int tile, int &tm, int 
 // and fragment addresses of gemm_nn_kernel_m16p (gemm.hip), through the compiler's builtin so that hipcc carries the waits.  Plain store, no second pair.
 // LAY 2 (TN: the weight gradient dW = dY^T . X): A is [K, M] row-major as well -- both operands staged as contraction rows and gathered by transposing reads
 // (gemm_tn_kernel_tr's layout).  LAY 0: NT, LAY 1: NN.
-template <int EPI, bool CAT, int LAY = 0>
+// SCH: the schedule of a K-tile.  0 (round 3): ONE rendezvous per K-tile -- `s_waitcnt vmcnt(0)` + barrier between the two k-slices, all sixteen DMA pieces of
+// K-tile g + 2 issued under k-slice 1: a piece has 0.5 .. 1 K-tile of time to land and every wave waits for its own slowest piece before the barrier.
+// 1 (round 4): FOUR barriers per K-tile, each behind a wait for something long done (the shape of the library kernel's main loop, read off its disassembly:
+// DESIGN.md section 7) -- the B region of the current buffer is free once every wave has read its k-slice-1 B fragments (barrier 1, MFMA 21) and the DMA of
+// K-tile g + 2's B pieces starts right there, the A region after barrier 2 (MFMA 52); K-tile g + 1's B pieces are waited for with a COUNTED `vmcnt(18)` at
+// MFMA 68 (barrier 3, then its k-slice-0 B fragments are read), its A pieces with `vmcnt(15)` at MFMA 105 (barrier 4): a piece has 0.85 .. 1.35 K-tiles to land
+// and no wave ever waits for a piece it issued in the same K-tile.  Same MFMAs in the same order: the same bits.
+template <int EPI, bool CAT, int LAY = 0, int SCH = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_w4_kernel(W4Args G)
 {
     constexpr bool NN = LAY >= 1, TA = LAY == 2;              // B, A stored with the contraction index as the row
@@ -111,13 +118,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // `global_load_lds_dwordx4 v_offset, s[base]`: the scalar base is the K-tile's, the per-lane offset (row of the piece, swizzled chunk) is fixed for the
     // whole launch -- no address arithmetic in the loop.  (asm: through the builtin hipcc forms a 64-bit vector address per piece, four more instructions
     // between two MFMAs: 3 % of the kernel.)
-    unsigned voffA[8], voffB[8], voffA2[CAT ? 8 : 1], voffB2[CAT ? 8 : 1];
+    // Row-major operands (NT's A and B, NN's A): piece i = rows i*8 .. i*8+7 of the wave's 64, so its address is (scalar) i * 8 rows + (per lane) row L >> 3 and the
+    // swizzled chunk, which depends on i only through i & 1: TWO per-lane offsets per operand, the i * 8 rows go into the scalar base (round 4: eight offsets per
+    // operand -- sixteen more registers, thirty-two with a second pair -- pushed the CAT kernels into scratch inside the K loop under the four-barrier schedule).
+    // Operands stored as contraction rows (NN's B, TN's A and B) keep eight: their swizzle moves with the row.
+    unsigned voffA[TA ? 8 : 2], voffB[NN ? 8 : 2];
+    unsigned stepA = 0, stepB = 0, gluB = 0;                 // (scalars) bytes per 8 rows of the pair being staged; GLU: bytes from a gate row to its up row
+    auto lane_offsets = [&](long long lda_, long long ldb_) {
+        // recomputed from the lane number wherever the staged pair changes (twice per output tile with a second pair), through an opaque copy: left visible, hipcc
+        // kept both pairs' offsets alive across the K loop, spilled them, and its reloads at the loop's tail waited vmcnt(0) -- every DMA piece in flight -- per K-tile
+        unsigned ln = (unsigned)lane;
+        asm volatile("" : "+v"(ln));
+        const unsigned lrow = ln >> 3, ch0 = ((ln & 7) ^ ((ln >> 4) & 7)) << 4, ch1 = ch0 ^ 64u;     // chunk (L & 7) ^ ((L >> 4) + 4 (i & 1)) & 7, times 16 bytes
+        if constexpr (!TA) {
+            voffA[0] = lrow * (unsigned)(lda_ * 2) + ch0; voffA[1] = lrow * (unsigned)(lda_ * 2) + ch1;
+            stepA = (unsigned)(lda_ * 16);
+        }
+        if constexpr (!NN) {
+            voffB[0] = lrow * (unsigned)(ldb_ * 2) + ch0; voffB[1] = lrow * (unsigned)(ldb_ * 2) + ch1;
+            stepB = (unsigned)(ldb_ * 16);
+            gluB = (unsigned)((long long)G.glu_I * ldb_ * 2);
+        }
+    };
+    lane_offsets(G.lda, G.ldb);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int chunk = (lane & 7) ^ (((lane >> 4) + 4 * (i & 1)) & 7);
-        // B: tile row r = (wave * 8 + i) * 8 + (lane >> 3); GLU: that is weight row 16 * (r >> 5) + (r & 15) (+ glu_I: an up row)
-        const long long rb = (EPI == 0 || EPI == 3) ? (long long)(i * 8 + (lane >> 3)) : 16 * (i >> 2) + (i & 1) * 8 + (lane >> 3) + ((i >> 1) & 1) * (long long)G.glu_I;
-        voffA[i] = (unsigned)(((long long)(i * 8 + (lane >> 3)) * G.lda + chunk * 8) * 2);
         if constexpr (TA) {
             const int rk = i * 2 + (lane >> 5), rkt = wave * 16 + rk;
             voffA[i] = (unsigned)(((long long)rk * G.lda + ((lane & 31) ^ (((rkt & 7) << 1) ^ (rkt & 8))) * 8) * 2);
@@ -126,11 +151,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const int rk = i * 2 + (lane >> 5), rkt = wave * 16 + rk;
             const int chunkb = (lane & 31) ^ (((rkt & 7) << 1) ^ (rkt & 8));
             voffB[i] = (unsigned)(((long long)rk * G.ldb + chunkb * 8) * 2);
-        } else
-        voffB[i] = (unsigned)((rb * G.ldb + chunk * 8) * 2);
-        if constexpr (CAT) {
-            voffA2[i] = (unsigned)(((long long)(i * 8 + (lane >> 3)) * G.lda2 + chunk * 8) * 2);
-            voffB2[i] = (unsigned)((rb * G.ldb2 + chunk * 8) * 2);
         }
     }
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
@@ -138,7 +158,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // the K-tile the next stage brings: (round, K-tile) of the flat sequence and where its pieces start.  Past the end of the sequence the pointers stay on the
     // last K-tile: the loop body stages unconditionally (no branch inside the interleaved stretch), a repeated tile lands in a buffer nobody reads again.
     int st_kt = 0, st_it = 0;
-    bool st_second = false;                                                     // (CAT) the K-tile to stage comes from (A2, B2)
     const unsigned char *st_a = nullptr, *st_b = nullptr, *st_a2 = nullptr, *st_b2 = nullptr;
     auto stage_first = [&]() {                                                  // start of round st_it's tile
         int tm, tn;
@@ -151,7 +170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (CAT) {
             st_a2 = reinterpret_cast<const unsigned char *>(G.A2 + ra * G.lda2);
             st_b2 = reinterpret_cast<const unsigned char *>(G.B2 + rb * G.ldb2);
-            st_second = false;
+            lane_offsets(G.lda, G.ldb);                                          // (back on the first pair)
         }
     };
     auto stage_advance = [&]() {
@@ -159,19 +178,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             st_kt = 0;
             if (++st_it < my_tiles) stage_first();
         } else if (CAT && st_kt == KT1) {
-            st_a = st_a2; st_b = st_b2; st_second = true;
+            st_a = st_a2; st_b = st_b2;
+            if constexpr (CAT) lane_offsets(G.lda2, G.ldb2);                     // the second pair's strides: a wave-uniform branch once per tile, four multiply-adds
         } else {
             st_a += TA ? (long long)BK * G.lda * 2 : (long long)BK * 2;
             st_b += NN ? (long long)BK * G.ldb * 2 : (long long)BK * 2;
         }
     };
     auto dma_a = [&](unsigned buf_off, int i) {
-        const unsigned vo = CAT ? (st_second ? voffA2[CAT ? i : 0] : voffA[i]) : voffA[i];
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dma_base + buf_off + (unsigned)i * 1024u), "v"(vo), "s"(st_a) : "memory");
+        const unsigned vo = TA ? voffA[TA ? i : 0] : voffA[i & 1];
+        const unsigned char *base = TA ? st_a : st_a + (unsigned)i * stepA;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dma_base + buf_off + (unsigned)i * 1024u), "v"(vo), "s"(base) : "memory");
     };
     auto dma_b = [&](unsigned buf_off, int i) {
-        const unsigned vo = CAT ? (st_second ? voffB2[CAT ? i : 0] : voffB[i]) : voffB[i];
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dma_base + buf_off + (unsigned)kTileBytes + (unsigned)i * 1024u), "v"(vo), "s"(st_b) : "memory");
+        const unsigned vo = NN ? voffB[NN ? i : 0] : voffB[i & 1];
+        // B: tile row r = (wave * 8 + i) * 8 + (lane >> 3); GLU: that is weight row 16 * (r >> 5) + (r & 15) (+ glu_I: an up row)
+        const unsigned char *base = NN ? st_b : (EPI == 0 || EPI == 3) ? st_b + (unsigned)i * stepB : st_b + (unsigned)(2 * (i >> 2) + (i & 1)) * stepB + (unsigned)((i >> 1) & 1) * gluB;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dma_base + buf_off + (unsigned)kTileBytes + (unsigned)i * 1024u), "v"(vo), "s"(base) : "memory");
     };
 
     // ---- fragments: MFMA 16x16x32 operand = 16 rows x 32 k; lane (lm, lq) reads the 16-byte chunk ks*4 + lq of row (tile row) * 16 + lm.
@@ -223,11 +246,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // prologue: K-tiles 0 and 1 of the sequence in flight, 0 complete
     stage_first();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { dma_a(0u, i); dma_b(0u, i); }
+    for (int i = 0; i < 8; ++i) dma_b(0u, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_a(0u, i);
     if (total > 1) {
         stage_advance();
+        // (B pieces, then A pieces: the issue order of every K-tile -- SCH 1's counted waits rely on it)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { dma_a((unsigned)kBufBytes, i); dma_b((unsigned)kBufBytes, i); }
+        for (int i = 0; i < 8; ++i) dma_b((unsigned)kBufBytes, i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma_a((unsigned)kBufBytes, i);
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -246,6 +274,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int kt = 0; kt < KT; ++kt, ++g) {
             unsigned char *cur = lds + (g & 1) * kBufBytes, *nxt = lds + ((g + 1) & 1) * kBufBytes;
             const unsigned cur_off = (unsigned)(g & 1) * (unsigned)kBufBytes;
+            if constexpr (SCH == 1) {
+                // 128 MFMAs, m = 0 .. 127: k-slice 0 (fa0, fb0) then k-slice 1 (fa1, fb1), row i of A fragments outer, B fragment j inner; what is issued behind MFMA m:
+                //   1, 3 .. 15      fb1[0 .. 7]   <- cur (k-slice 1)                      20 / 21   lgkmcnt(0) / barrier 1: cur's B region is free
+                //   23, 26 .. 35    DMA B pieces 0 .. 4 of K-tile g + 2 -> cur            25, 28, 31, 34, 37, 39, 41, 43   fa1[0 .. 7] <- cur
+                //   51 / 52         lgkmcnt(0) / barrier 2: cur's A region is free        53, 56, 59   DMA B 5 .. 7      62, 65   DMA A 0, 1
+                //   68 / 69         vmcnt(18) / barrier 3: K-tile g + 1's B has landed    70, 72 .. 84   fb0[0 .. 7] <- nxt (k-slice 0)
+                //   86, 88, 90, 97, 101   DMA A 2 .. 6                                    105 / 106   vmcnt(15) / barrier 4: K-tile g + 1's A has landed
+                //   107, 109 .. 121 fa0[0 .. 7] <- nxt                                    125   DMA A 7
+                auto after = [&](const int m) __attribute__((always_inline)) {
+                    W4_FENCE();
+                    if (m <= 15 && (m & 1)) fb1[m >> 1] = frag_b(cur, 1, m >> 1);
+                    else if (m == 20 || m == 51) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    else if (m == 21 || m == 52 || m == 69 || m == 106) __builtin_amdgcn_s_barrier();
+                    else if (m == 23 || m == 26 || m == 29 || m == 32 || m == 35) dma_b(cur_off, (m - 23) / 3);
+                    else if (m == 25 || m == 28 || m == 31 || m == 34) fa1[(m - 25) / 3] = frag_a(cur, 1, (m - 25) / 3);
+                    else if (m == 37 || m == 39 || m == 41 || m == 43) fa1[4 + (m - 37) / 2] = frag_a(cur, 1, 4 + (m - 37) / 2);
+                    else if (m == 53 || m == 56 || m == 59) dma_b(cur_off, 5 + (m - 53) / 3);
+                    else if (m == 62 || m == 65) dma_a(cur_off, (m - 62) / 3);
+                    else if (m == 68) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                    else if (m >= 70 && m <= 84 && !(m & 1)) fb0[(m - 70) >> 1] = frag_b(nxt, 0, (m - 70) >> 1);
+                    else if (m == 86 || m == 88 || m == 90) dma_a(cur_off, 2 + (m - 86) / 2);
+                    else if (m == 97 || m == 101) dma_a(cur_off, 5 + (m - 97) / 4);
+                    else if (m == 105) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                    else if (m >= 107 && m <= 121 && (m & 1)) fa0[(m - 107) >> 1] = frag_a(nxt, 0, (m - 107) >> 1);
+                    else if (m == 125) dma_a(cur_off, 7);
+                    W4_FENCE();
+                };
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { W4_MFMA(i, j, fa0, fb0); after(i * 8 + j); }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { W4_MFMA(i, j, fa1, fb1); after(64 + i * 8 + j); }
+            } else {
             // ---- k-slice 0 of K-tile g (fragments read a block ago), the fragments of k-slice 1 read underneath: one ds_read per four MFMAs
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -277,6 +341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         W4_FENCE();
                     }
                 }
+            }
             if (g + 3 < total) stage_advance();
         }
         // ---- the tile is complete (the next tile's first two K-tiles are in flight, its first fragments in registers).  The wave's 128x128 block leaves through
@@ -406,7 +471,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 int g_w4_group_m = 8;
-int g_w4_cus = 0;
+int g_w4_sched = 1;              // 1: four barriers per K-tile with counted waits (round 4); 0: one rendezvous per K-tile (round 3), kept for A/B
+
+// CUs of the current device, rounded down to a multiple of the 8 XCDs (one persistent workgroup each); looked up per device, cached per device
+int w4_cus()
+{
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = (n & ~7) > 0 ? (n & ~7) : 8;
+    }
+    return cached[dev];
+}
 
 }  // namespace
 
@@ -417,11 +496,7 @@ namespace ecgb {
 // second wave per SIMD hides the tile hand-over better).
 bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long long ldb, const void *c_dev, long long ldc, int M, int N, int K)
 {
-    if (!g_w4_cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        g_w4_cus = (n & ~7) > 0 ? (n & ~7) : 8;                            // a multiple of the 8 XCDs
-    }
+    const int g_w4_cus = w4_cus();
     return M > 0 && N > 0 && K > 0 && M % 256 == 0 && N % 256 == 0 && K % BK == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
            (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)c_dev) & 15) == 0 && (long long)63 * lda * 2 + 128 <= 0xFFFFFFFFll && (long long)63 * ldb * 2 + 128 <= 0xFFFFFFFFll &&
            (long long)(M / 256) * (N / 256) / g_w4_cus * (K / BK) >= 256;
@@ -439,24 +514,29 @@ int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long lon
     G.lda = lda; G.ldb = ldb; G.ldc = ldc; G.M = M; G.N = N; G.K = K; G.tiles_m = M / 256; G.tiles_n = N / 256; G.alpha = alpha; G.group_m = g_w4_group_m;
     G.H = (unsigned short *)h_dev; G.ldh = ldh; G.glu_I = N / 2;
     const int which = lay ? 7 + lay : epi + (G.K2 ? 4 : 0);
-    void (*const kerns[10])(W4Args) = {gemm_nt_w4_kernel<0, false>, gemm_nt_w4_kernel<1, false>, gemm_nt_w4_kernel<2, false>, gemm_nt_w4_kernel<3, false>,
-                                       gemm_nt_w4_kernel<0, true>, gemm_nt_w4_kernel<1, true>, gemm_nt_w4_kernel<2, true>, gemm_nt_w4_kernel<3, true>,
-                                       gemm_nt_w4_kernel<0, false, 1>, gemm_nt_w4_kernel<0, false, 2>};
-    void (*kern)(W4Args) = kerns[which];
-    static bool attr_set[10] = {};
-    hipError_t e = hipSuccess;
-    if (!attr_set[which]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        attr_set[which] = (e == hipSuccess);
-    }
+#define W4_KERNS(S) {gemm_nt_w4_kernel<0, false, 0, S>, gemm_nt_w4_kernel<1, false, 0, S>, gemm_nt_w4_kernel<2, false, 0, S>, gemm_nt_w4_kernel<3, false, 0, S>, \
+                     gemm_nt_w4_kernel<0, true, 0, S>, gemm_nt_w4_kernel<1, true, 0, S>, gemm_nt_w4_kernel<2, true, 0, S>, gemm_nt_w4_kernel<3, true, 0, S>,     \
+                     gemm_nt_w4_kernel<0, false, 1, S>, gemm_nt_w4_kernel<0, false, 2, S>}
+    void (*const kerns[2][10])(W4Args) = {W4_KERNS(0), W4_KERNS(1)};
+#undef W4_KERNS
+    void (*kern)(W4Args) = kerns[g_w4_sched ? 1 : 0][which];
+    // (the attribute is per device: set on every launch, as everywhere else in the library -- a cached flag would be wrong on a second GPU)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(kern, dim3((unsigned)g_w4_cus), dim3(256), kLdsBytes, (hipStream_t)stream, G);
+        hipLaunchKernelGGL(kern, dim3((unsigned)w4_cus()), dim3(256), kLdsBytes, (hipStream_t)stream, G);
         e = hipGetLastError();
     }
     if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_w4_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
     return ECGB_OK;
 }
 }  // namespace ecgb
+
+extern "C" int ecgb_set_gemm_w4_sched(int s)
+{
+    if (s < 0 || s > 1) { ecgb::set_error("ecgb_set_gemm_w4_sched: 0 (one rendezvous per K-tile) or 1 (four barriers, counted waits)"); return ECGB_ERR_INVALID; }
+    g_w4_sched = s;
+    return ECGB_OK;
+}
 
 extern "C" int ecgb_set_gemm_w4_group_m(int g)
 {
@@ -494,7 +574,7 @@ extern "C" int ecgb_gemm_nt_bf16_rope(const void *a_dev, long long lda, const vo
     if (M % 256 || N % 256 || K % BK || K2 % BK || rope_cols % 64 || rope_cols < 0 || rope_cols > N || lda % 8 || ldb % 8 || ldc % 8 || (K2 > 0 && (lda2 % 8 || ldb2 % 8)) ||
         (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)c_dev | (uintptr_t)a2_dev | (uintptr_t)b2_dev | (uintptr_t)rope_cos_dev | (uintptr_t)rope_sin_dev) & 15) ||
         (long long)63 * lda * 2 + 128 > 0xFFFFFFFFll || (long long)63 * ldb * 2 + 128 > 0xFFFFFFFFll ||
-        (K2 > 0 && ((long long)63 * lda2 * 2 + 128 > 0xFFFFFFFFll || (long long)63 * ldb2 * 2 + 128 > 0xFFFFFFFFll)) || (long long)(M / 256) * (N / 256) < g_w4_cus) {
+        (K2 > 0 && ((long long)63 * lda2 * 2 + 128 > 0xFFFFFFFFll || (long long)63 * ldb2 * 2 + 128 > 0xFFFFFFFFll)) || (long long)(M / 256) * (N / 256) < w4_cus()) {
         ecgb::set_error("ecgb_gemm_nt_bf16_rope: whole 256x256 tiles (one per CU at least), K % 64, 16-byte aligned operands required");
         return ECGB_ERR_UNSUPPORTED;
     }

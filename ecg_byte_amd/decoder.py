@@ -201,6 +201,9 @@ class _LossFn(torch.autograd.Function):
 
 
 class HipCausalLM(nn.Module):
+    # HipAdam(overlap=True) needs the forward to wait per parameter group (`_wait_group`) and backward / inference to `sync_optimizer`: a subclass whose
+    # own forward / backward do not (HipGPT2LM) sets this False and gets the plain in-stream step
+    supports_optimizer_overlap = True
     def __init__(self, cfg: DecoderConfig, device="cuda", seed: int = 0):
         super().__init__()
         self.cfg = cfg
@@ -416,8 +419,8 @@ class HipCausalLM(nn.Module):
         yield "lm_head.weight", self.embed.data[: c.vocab_size]
 
     def state_dict(self, *a, **k):
-        self.sync_optimizer()
         """HF parameter names; with LoRA enabled also the adapters under peft's names (`lora_named`)."""
+        self.sync_optimizer()
         if self.lora is None:
             return {n: t.clone() for n, t in self._hf_named()}
         # peft's PeftModel.state_dict(): everything under `base_model.model.`, the wrapped projections' own weights under
@@ -431,8 +434,8 @@ class HipCausalLM(nn.Module):
         return sd
 
     def load_state_dict(self, sd, strict=True):
-        self.sync_optimizer()
         """Accepts HF names, and a peft checkpoint's spelling of them (`base_model.model.` prefix, `.base_layer.` infix)."""
+        self.sync_optimizer()
         def canon(n):
             if "lora_" in n:
                 return n
@@ -738,6 +741,7 @@ class HipCausalLM(nn.Module):
         shifted = torch.full((B, S), -100, dtype=torch.int64, device=dev)
         shifted[:, :-1] = labels[:, 1:]
         shifted = shifted.view(-1)
+        self._unlabelled_rows = shifted == -100                          # (backward: a row takes no gradient only if it is masked AND carries no loss)
         inv_count = ops.count_labels(shifted, c.vocab_size)
         rows = torch.arange(T, device=dev) if self.full_logits else torch.nonzero(shifted != -100).view(-1)
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -812,10 +816,10 @@ class HipCausalLM(nn.Module):
 
     # ---- inference -----------------------------------------------------------------------------
     def _hidden_states(self, input_ids, attention_mask=None, position_ids=None, kv_out=None):
-        self.sync_optimizer()
         """Final-normed hidden states [B*S, H] of a whole (left-padded) batch, nothing saved for backward.  kv_out: optional
         list of per-layer caches [B, cap, 2*Hkv*D]; rows [:S] receive the roped keys and the values (DynamicCache.update,
         cache_utils.py:408-470)."""
+        self.sync_optimizer()
         c = self.cfg
         D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
         dev = self.device
@@ -1212,7 +1216,11 @@ class HipCausalLM(nn.Module):
                 self.grad_sync.on_flat_ready(self._gflat, *self._granges[L - 1 - i])
         if not frozen:
             pad = c.pad_token_id if c.pad_token_id is not None else -1       # nn.Embedding(padding_idx): no lookup gradient for that row
-            live_ids = input_ids.view(-1).masked_fill(mask.reshape(-1) == 0, -1)   # masked positions: gradient exactly zero, skipped as one run
+            # Rows that are masked AND carry no loss have a gradient of exactly zero (never attended as keys, zero attention output as queries, no loss of their own):
+            # skipped as one run.  A masked row whose shifted label is valid (a hole in the mask, the last pad row in front of a labelled first token) still receives
+            # d hidden through its residual path, as HF autograd gives it: it stays.
+            dead = (mask.reshape(-1) == 0) & self._unlabelled_rows
+            live_ids = input_ids.view(-1).masked_fill(dead, -1)
             if sparse_embed:
                 self._embedding_grad_sparse(live_ids, g, pad)
             else:
@@ -1242,7 +1250,7 @@ class HipAdam:
         # which leave the memory system idle.  The gradient norm (needs every gradient) stays in front.  Same arithmetic, same bits.  Anything that
         # touches parameters through the model (backward, inference, state_dict, generate) waits for the whole step first (`sync_optimizer`); code
         # that reads `p.data` directly right after `step()` must call `model.sync_optimizer()` itself -- hence opt-in (bench.py, main.py).
-        self.overlap = bool(overlap) and hasattr(model, "_opt_groups") and torch.cuda.is_available()
+        self.overlap = bool(overlap) and getattr(model, "supports_optimizer_overlap", False) and hasattr(model, "_opt_groups") and torch.cuda.is_available()
         self._side = None
         self._acc = None
         self.init_lr = model.cfg.hidden_size ** -0.5

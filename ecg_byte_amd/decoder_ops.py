@@ -74,6 +74,11 @@ def set_gemm_w4_group_m(g=8):
     _lib.check(_L().ecgb_set_gemm_w4_group_m(int(g)))
 
 
+def set_gemm_w4_sched(s=1):
+    """K-tile schedule of the four-wave kernel: 1 four barriers behind counted waits (default), 0 one rendezvous per K-tile (round 3).  Same bits."""
+    _lib.check(_L().ecgb_set_gemm_w4_sched(int(s)))
+
+
 def gemm_tn_w4(a, b, alpha=1.0, out=None):
     """a [K, M]^T . b [K, N] (both row-major: the weight gradient dY^T . X) on the four-wave kernel (ecgb_gemm_tn_w4_bf16): M, N multiples of 256, K of 64."""
     K, M = a.shape
@@ -300,6 +305,11 @@ def set_gemm_backward_persistent(on: bool):
     """Input-gradient GEMMs with the persistent tile loop (default) or one tile per workgroup: the latter beside a gradient exchange that
     occupies CUs (parallel.GradAllReduce turns it off for world size > 1; ecgb_set_gemm_backward_persistent)."""
     _lib.check(_L().ecgb_set_gemm_backward_persistent(int(bool(on))))
+
+
+def get_gemm_backward_persistent() -> bool:
+    """The switch as it stands (ecgb_get_gemm_backward_persistent)."""
+    return bool(_L().ecgb_get_gemm_backward_persistent())
 
 
 def gemm_nt(a, b, out=None, alpha=1.0, accumulate_f32=False, accumulate=False, a2=None, b2=None):

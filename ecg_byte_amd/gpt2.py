@@ -62,6 +62,8 @@ class GPT2Config:
 
 
 class HipGPT2LM(HipCausalLM):
+    supports_optimizer_overlap = False   # its forward / backward carry no per-group waits: the optimizer step stays in-stream
+
     def __init__(self, cfg: GPT2Config, device="cuda", seed: int = 0):
         nn.Module.__init__(self)
         self.cfg = cfg
@@ -312,7 +314,9 @@ class HipGPT2LM(HipCausalLM):
             if self.grad_sync is not None:
                 self.grad_sync.on_flat_ready(self._gflat, *self._granges[L - 1 - i])
         g = undrop(g, c.embd_pdrop, seed_e)
-        dead = mask.reshape(-1) == 0     # masked positions: gradient exactly zero -- skipped instead of summed by one workgroup as one long run
+        # masked rows that carry no loss: gradient exactly zero -- skipped instead of summed by one workgroup as one long run (a masked row with a valid shifted
+        # label keeps its gradient, as autograd gives it: GPT-2 has no padding_idx)
+        dead = (mask.reshape(-1) == 0) & self._unlabelled_rows
         self._embedding_grad(self.embed, self.embed_grad_head, input_ids.view(-1).masked_fill(dead, -1), g, 1.0, -1)     # GPT-2's wte has no padding_idx
         self._embedding_grad(self.wpe, None, position_ids.reshape(-1).masked_fill(dead, -1).contiguous(), g, 1.0, -1)
         if self.grad_sync is not None:

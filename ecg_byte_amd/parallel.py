@@ -109,11 +109,12 @@ class GradAllReduce:
                 yield
                 return
             from . import decoder_ops as _ops
+            before = _ops.get_gemm_backward_persistent()                 # a caller (or a test) may have chosen the one-tile kernels itself: leave what was found
             _ops.set_gemm_backward_persistent(False)
             try:
                 yield
             finally:
-                _ops.set_gemm_backward_persistent(True)
+                _ops.set_gemm_backward_persistent(before)
         return scope()
 
     def _send(self, t):
@@ -131,6 +132,9 @@ class GradAllReduce:
         through a plain all-reduce.  RCCL orders the two collectives on its stream; gloo (CPU tests) has no reduce-scatter: there the shard is cut from
         an all-reduce, which exercises the same bookkeeping."""
         W = self.world
+        if not t.is_contiguous():
+            raise ValueError("GradAllReduce: a reduce-scatter bucket must be contiguous (a strided view would be reduced into a copy)")
+        t = t.view(-1)                                                   # (a parameter's .grad is N-dimensional: cut ELEMENTS, not rows)
         n = (t.numel() // W) * W
         body, rest = t[:n], t[n:]
         r = dist.get_rank(self.pg)

@@ -22,11 +22,12 @@ def _content_key(merges) -> bytes:
     """Digest of the WHOLE list (every expansion element and id).  The reference rebuilds its trie from `merges` on every call
     (lib.rs:153-161), so any mutation -- a replaced entry, an inner list edited in place -- is honoured there; a cache keyed on the
     object's identity or on a few sampled fields would keep serving the stale trie.  Serialising 4 000 entries and hashing them takes
-    ~1.5 ms, less than the reference's own per-call rebuild."""
+    ~1.5 ms, less than the reference's own per-call rebuild.  marshal format 2: later formats write back-references that depend on object
+    identity and reference counts, so equal lists could serialise differently (spurious misses); format 2 is a function of the content."""
     import hashlib
     import marshal
     try:
-        blob = marshal.dumps(merges)
+        blob = marshal.dumps(merges, 2)
     except ValueError:           # numpy integers and other non-marshallable element types
         import pickle
         blob = pickle.dumps([(list(map(int, seq)), int(tid)) for seq, tid in merges], protocol=5)

@@ -173,6 +173,7 @@ int ecgb_set_gemm_tile(int tile);
  * Persistent workgroups hold a static share of the tiles on every CU; beside a collective that occupies CUs (the gradient exchange of a
  * data-parallel backward) the one-tile kernels degrade gracefully where a static share would not.  parallel.GradAllReduce sets 0 for world > 1. */
 int ecgb_set_gemm_backward_persistent(int on);
+int ecgb_get_gemm_backward_persistent(void);   /* the switch as it stands (1 / 0): a scope that changes it restores what it found */
 /* Order in which an XCD's workgroups walk its range of output tiles: 0 or 1 = row by row (default); g > 1 = blocks of g tile rows, column by column (the ~32
  * tiles an XCD runs at a time are then g x 32 / g, both operand panels shared in its L2: measured 1-9 % slower at the C3 shapes, kept for A/B).  Same results. */
 int ecgb_set_gemm_group_m(int group_m);
@@ -306,6 +307,7 @@ int ecgb_gemm_tn_w4_bf16(const void *a_dev, long long lda, const void *b_dev, lo
                          int M, int N, int K, float alpha, void *stream);
 int ecgb_set_gemm_w4(int on);              /* 1 (default): ecgb_gemm_nt_bf16 / _cat / _glu send eligible problems to the four-wave kernel; 0: never; 2: every form it has (A/B, tests) */
 int ecgb_set_gemm_w4_group_m(int group_m);  /* its tile order: blocks of group_m tile rows (default 8; 0 = row by row) */
+int ecgb_set_gemm_w4_sched(int sched);      /* its K-tile schedule: 1 (default) four barriers per K-tile behind counted waits, 0 one rendezvous per K-tile (round 3; A/B).  Same bits. */
 
 /* ecgb_rmsnorm_fwd for the few rows of a decode step with adapters, followed in the same launch by the site's stacked LoRA down-projection of the normalised row:
  * t_dev [rows, ldt] (bf16) = lora_scale * y . A^T for the n_a rows of lora_a_dev [n_a, lda] -- bit for bit ecgb_gemm_nt_bf16(y, A, alpha = lora_scale) on the few-row

@@ -236,6 +236,22 @@ def test_rust_bpe_cache_honours_in_place_edits_of_the_merges_list():
     assert rust_bpe.tokenizer_for(npm).n_nodes == t2.n_nodes
 
 
+def test_rust_bpe_cache_key_is_a_function_of_the_content_not_of_object_identity():
+    """marshal formats 3+ write back-references for objects it has seen before (by identity, and only when their reference count says they may be shared): two
+    equal lists -- one built from shared int objects, one from distinct ones -- serialised differently and missed the cache.  The key uses format 2."""
+    import marshal
+    from ecg_byte_amd import rust_bpe
+    big = 70000                                                        # not a cached small int: `int(str(big))` is a distinct object every time
+    shared = [([big, big, big], 256 + 1), ([big, 257], 256 + 2)]
+    shared = [(seq, tid) for seq, tid in shared]
+    shared.append(shared[0])                                           # the same tuple object twice
+    distinct = [([int(str(big)) for _ in seq], int(str(tid))) for seq, tid in shared]
+    assert shared == distinct
+    assert marshal.dumps(shared) != marshal.dumps(distinct)            # what the default format did
+    assert rust_bpe._content_key(shared) == rust_bpe._content_key(distinct)
+    assert rust_bpe._content_key(shared) != rust_bpe._content_key(distinct[:-1])
+
+
 def test_device_entry_points_fail_loudly_without_gpu(lib):
     import torch
     if torch.cuda.is_available():
