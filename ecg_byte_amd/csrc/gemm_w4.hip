@@ -110,20 +110,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int my_tiles = 0;
     for (int it = 0; tile_of_round(w, it, nwg) < n_tiles; ++it) ++my_tiles;
     if (my_tiles == 0) return;
-    const long long total = (long long)my_tiles * KT;      // K-tiles of the flat sequence
+    const int total = my_tiles * KT;                       // K-tiles of the flat sequence (the host keeps it under 2^31)
 
     // ---- LDS-DMA: piece p = wave * 8 + i (i = 0..7) of an operand's K-tile is rows p*8 .. p*8+7; lane L brings the 16-byte chunk
     // (L & 7) ^ ((row >> 1) & 7) of row p*8 + (L >> 3) -- the swizzle sits on the global side, the LDS side of the DMA is linear.
-    // (row >> 1) & 7 = ((L >> 4) + 4 * (i & 1)) & 7.  One piece = two instructions: M0 <- where the piece lands, then
-    // `global_load_lds_dwordx4 v_offset, s[base]`: the scalar base is the K-tile's, the per-lane offset (row of the piece, swizzled chunk) is fixed for the
-    // whole launch -- no address arithmetic in the loop.  (asm: through the builtin hipcc forms a 64-bit vector address per piece, four more instructions
-    // between two MFMAs: 3 % of the kernel.)
-    // Row-major operands (NT's A and B, NN's A): piece i = rows i*8 .. i*8+7 of the wave's 64, so its address is (scalar) i * 8 rows + (per lane) row L >> 3 and the
-    // swizzled chunk, which depends on i only through i & 1: TWO per-lane offsets per operand, the i * 8 rows go into the scalar base (round 4: eight offsets per
-    // operand -- sixteen more registers, thirty-two with a second pair -- pushed the CAT kernels into scratch inside the K loop under the four-barrier schedule).
-    // Operands stored as contraction rows (NN's B, TN's A and B) keep eight: their swizzle moves with the row.
+    // (row >> 1) & 7 = ((L >> 4) + 4 * (i & 1)) & 7.
+    // A piece is `buffer_load_dwordx4 v_lane, s[descriptor], s_piece offen lds` with M0 = where it lands: the descriptor's base is the K-tile's (scalar, advanced once
+    // per K-tile), the per-lane offset (row L >> 3 of the piece, swizzled chunk; odd pieces: 8 rows further and the other swizzle) is fixed while the operand pair is,
+    // and the scalar offset moves to piece pair i >> 1 -- no address arithmetic per piece, so a piece is TWO instructions (`s_add_u32 m0, m0, 1024` and the load), and
+    // the schedule below puts each into an MFMA gap of its own.  (Round 3 wrote `s_mov m0; s_nop; global_load_lds v, s[base]` with the base formed per piece: five to six
+    // scalar instructions and the load in ONE gap -- with one wave per SIMD every instruction of the wave takes its 4-5 issue cycles out of the 16 an MFMA gives, and the
+    // matrix pipe idled behind each piece: MFMA busy 0.79 against 0.93 for the same loop without the pieces, 0.90 for the library kernel with them.)
+    // Operands stored as contraction rows (NN's B, TN's A and B): piece i = contraction rows 2i, 2i + 1 of the wave's 16, eight per-lane offsets (the swizzle moves with the row).
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
     unsigned voffA[TA ? 8 : 2], voffB[NN ? 8 : 2];
-    unsigned stepA = 0, stepB = 0, gluB = 0;                 // (scalars) bytes per 8 rows of the pair being staged; GLU: bytes from a gate row to its up row
+    // (scalars) byte offset of piece pair q = i >> 1 from the descriptor's base, INCLUDING the K-tile's offset inside the operand: the descriptor is set once per
+    // output tile (and per operand pair), a K-tile further is `s_add_u32 soff, soff, step` on each of these -- in place, one per MFMA gap, behind the offset's last use
+    // (a descriptor advanced per K-tile cost a dozen scalar copies at the loop's tail: the loop-carried values of every path meet there).  Contraction-row operands
+    // use entry 0 for all their pieces.
+    unsigned ksA[TA ? 1 : 4], ksB[NN ? 1 : 4];
+    unsigned pairB1 = 0, pairB2 = 0, pairB3 = 0, stepA2 = 0;     // what the entries are at K-tile 0 of the pair being staged (A: q * stepA2)
     auto lane_offsets = [&](long long lda_, long long ldb_) {
         // recomputed from the lane number wherever the staged pair changes (twice per output tile with a second pair), through an opaque copy: left visible, hipcc
         // kept both pairs' offsets alive across the K loop, spilled them, and its reloads at the loop's tail waited vmcnt(0) -- every DMA piece in flight -- per K-tile
@@ -131,14 +137,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("" : "+v"(ln));
         const unsigned lrow = ln >> 3, ch0 = ((ln & 7) ^ ((ln >> 4) & 7)) << 4, ch1 = ch0 ^ 64u;     // chunk (L & 7) ^ ((L >> 4) + 4 (i & 1)) & 7, times 16 bytes
         if constexpr (!TA) {
-            voffA[0] = lrow * (unsigned)(lda_ * 2) + ch0; voffA[1] = lrow * (unsigned)(lda_ * 2) + ch1;
-            stepA = (unsigned)(lda_ * 16);
+            const unsigned step = (unsigned)(lda_ * 16);                      // 8 rows
+            voffA[0] = lrow * (unsigned)(lda_ * 2) + ch0; voffA[1] = lrow * (unsigned)(lda_ * 2) + step + ch1;
+            stepA2 = 2 * step;
         }
         if constexpr (!NN) {
-            voffB[0] = lrow * (unsigned)(ldb_ * 2) + ch0; voffB[1] = lrow * (unsigned)(ldb_ * 2) + ch1;
-            stepB = (unsigned)(ldb_ * 16);
-            gluB = (unsigned)((long long)G.glu_I * ldb_ * 2);
+            const unsigned step = (unsigned)(ldb_ * 16);
+            voffB[0] = lrow * (unsigned)(ldb_ * 2) + ch0; voffB[1] = lrow * (unsigned)(ldb_ * 2) + step + ch1;
+            if constexpr (EPI == 0 || EPI == 3) { pairB1 = 2 * step; pairB2 = 4 * step; pairB3 = 6 * step; }
+            else {
+                // GLU: tile row r = (wave * 8 + i) * 8 + (L >> 3) is weight row 16 * (r >> 5) + (r & 15) (+ glu_I: an up row) -- pieces 0, 1: gate rows 0 .. 15 of the
+                // wave's 32, pieces 2, 3 the up rows of the same outputs, 4, 5 gate rows 16 .. 31, 6, 7 their up rows
+                const unsigned glu = (unsigned)((long long)G.glu_I * ldb_ * 2);
+                pairB1 = glu; pairB2 = 2 * step; pairB3 = 2 * step + glu;
+            }
         }
+    };
+    // K-tile kt of the pair being staged
+    auto soff_at = [&](unsigned kt, long long lda_, long long ldb_) {
+        const unsigned ka = TA ? kt * (unsigned)(BK * lda_ * 2) : kt * (unsigned)(BK * 2), kb = NN ? kt * (unsigned)(BK * ldb_ * 2) : kt * (unsigned)(BK * 2);
+        // (readfirstlane: wave-uniform by construction, but with a second operand pair hipcc carried these through vector registers and handed one to the
+        // load's scalar-offset operand; this runs once per output tile and operand pair)
+        auto u = [](unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); };
+        if constexpr (TA) ksA[0] = u(ka); else { ksA[0] = u(ka); ksA[TA ? 0 : 1] = u(ka + stepA2); ksA[TA ? 0 : 2] = u(ka + 2 * stepA2); ksA[TA ? 0 : 3] = u(ka + 3 * stepA2); }
+        if constexpr (NN) ksB[0] = u(kb); else { ksB[0] = u(kb); ksB[NN ? 0 : 1] = u(kb + pairB1); ksB[NN ? 0 : 2] = u(kb + pairB2); ksB[NN ? 0 : 3] = u(kb + pairB3); }
     };
     lane_offsets(G.lda, G.ldb);
 #pragma unroll
@@ -155,46 +177,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
     const unsigned dma_base = lds_base + (unsigned)wave * 8192u;                 // this wave's eight pieces of an operand tile
-    // the K-tile the next stage brings: (round, K-tile) of the flat sequence and where its pieces start.  Past the end of the sequence the pointers stay on the
-    // last K-tile: the loop body stages unconditionally (no branch inside the interleaved stretch), a repeated tile lands in a buffer nobody reads again.
+    // the K-tile the next stage brings: (round, K-tile) of the flat sequence, the descriptors of its operands and the scalar offsets above.  Past the end of the
+    // sequence they stay on the last K-tile: the loop body stages unconditionally (no branch inside the interleaved stretch), a repeated tile lands in a buffer
+    // nobody reads again.
     int st_kt = 0, st_it = 0;
-    const unsigned char *st_a = nullptr, *st_b = nullptr, *st_a2 = nullptr, *st_b2 = nullptr;
+    u32x4 srdA = {0u, 0u, 0xFFFFFFFFu, 0x00020000u}, srdB = {0u, 0u, 0xFFFFFFFFu, 0x00020000u};     // raw buffers: base, no stride, no bound, 32-bit data format
+    const unsigned char *st_a2 = nullptr, *st_b2 = nullptr;
+    auto set_base = [](u32x4 &srd, const unsigned char *p) {
+        const unsigned long long a = (unsigned long long)(uintptr_t)p;
+        srd[0] = (unsigned)a; srd[1] = (unsigned)(a >> 32) & 0xFFFFu;
+    };
+    const unsigned kstepA = TA ? (unsigned)(BK * G.lda * 2) : (unsigned)(BK * 2), kstepB = NN ? (unsigned)(BK * G.ldb * 2) : (unsigned)(BK * 2);
     auto stage_first = [&]() {                                                  // start of round st_it's tile
         int tm, tn;
         tile_rc(G, tile_of_round(w, st_it, nwg), tm, tn);
         const long long ra = (long long)tm * 256 + wave * 64, rb = (EPI == 0 || EPI == 3) ? (long long)tn * 256 + wave * 64 : (long long)tn * 128 + wave * 32;
-        st_a = TA ? reinterpret_cast<const unsigned char *>(G.A + (long long)wave * 16 * G.lda + (long long)tm * 256)
-                  : reinterpret_cast<const unsigned char *>(G.A + ra * G.lda);
-        st_b = NN ? reinterpret_cast<const unsigned char *>(G.B + (long long)wave * 16 * G.ldb + (long long)tn * 256)       // this wave's 16 contraction rows of K-tile 0, the tile's columns
-                  : reinterpret_cast<const unsigned char *>(G.B + rb * G.ldb);
+        set_base(srdA, TA ? reinterpret_cast<const unsigned char *>(G.A + (long long)wave * 16 * G.lda + (long long)tm * 256)
+                          : reinterpret_cast<const unsigned char *>(G.A + ra * G.lda));
+        set_base(srdB, NN ? reinterpret_cast<const unsigned char *>(G.B + (long long)wave * 16 * G.ldb + (long long)tn * 256)       // this wave's 16 contraction rows of K-tile 0, the tile's columns
+                          : reinterpret_cast<const unsigned char *>(G.B + rb * G.ldb));
         if constexpr (CAT) {
             st_a2 = reinterpret_cast<const unsigned char *>(G.A2 + ra * G.lda2);
             st_b2 = reinterpret_cast<const unsigned char *>(G.B2 + rb * G.ldb2);
             lane_offsets(G.lda, G.ldb);                                          // (back on the first pair)
         }
+        soff_at(0u, G.lda, G.ldb);
     };
-    auto stage_advance = [&]() {
+    // What the loop's tail does for the K-tile after the one just staged.  The K loop itself has already moved the scalar offsets one K-tile on (`dma_step_*`): nothing
+    // is left to do unless the output tile or the operand pair changes, or the sequence has ended (the offsets go back: the last K-tile is staged again).
+    auto stage_advance = [&](bool more) {
+        if (!more) { soff_at((unsigned)(CAT && st_kt >= KT1 ? st_kt - KT1 : st_kt), CAT && st_kt >= KT1 ? G.lda2 : G.lda, CAT && st_kt >= KT1 ? G.ldb2 : G.ldb); return; }
         if (++st_kt == KT) {
             st_kt = 0;
-            if (++st_it < my_tiles) stage_first();
+            ++st_it;
+            stage_first();
         } else if (CAT && st_kt == KT1) {
-            st_a = st_a2; st_b = st_b2;
-            if constexpr (CAT) lane_offsets(G.lda2, G.ldb2);                     // the second pair's strides: a wave-uniform branch once per tile, four multiply-adds
-        } else {
-            st_a += TA ? (long long)BK * G.lda * 2 : (long long)BK * 2;
-            st_b += NN ? (long long)BK * G.ldb * 2 : (long long)BK * 2;
+            set_base(srdA, st_a2); set_base(srdB, st_b2);
+            if constexpr (CAT) { lane_offsets(G.lda2, G.ldb2); soff_at(0u, G.lda2, G.ldb2); }     // the second pair's strides: a wave-uniform branch once per tile
         }
     };
+    // M0: `dma_dst` points it at this wave's first piece of an operand tile, `dma_next` moves it one piece on; each is one scalar instruction, and at least one other
+    // instruction (an MFMA) stands between a write of M0 and the load that uses it
+    constexpr bool NO_DMA = ((SCH >> 4) & 4) != 0;
+    auto dma_dst_a = [&](unsigned buf_off) { if constexpr (!NO_DMA) asm volatile("s_mov_b32 m0, %0" :: "s"(dma_base + buf_off) : "memory"); };
+    auto dma_dst_b = [&](unsigned buf_off) { if constexpr (!NO_DMA) asm volatile("s_mov_b32 m0, %0" :: "s"(dma_base + buf_off + (unsigned)kTileBytes) : "memory"); };
+    auto dma_next = [&]() { if constexpr (!NO_DMA) asm volatile("s_add_u32 m0, m0, 0x400" ::: "memory", "scc"); };
+    auto ld_a = [&](int i) {
+        if constexpr (!NO_DMA) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(TA ? voffA[TA ? i : 0] : voffA[i & 1]), "s"(srdA), "s"(ksA[TA ? 0 : (i >> 1)]) : "memory");
+    };
+    auto ld_b = [&](int i) {
+        if constexpr (!NO_DMA) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" :: "v"(NN ? voffB[NN ? i : 0] : voffB[i & 1]), "s"(srdB), "s"(ksB[NN ? 0 : (i >> 1)]) : "memory");
+    };
+    // one K-tile on (q: piece pair; contraction-row operands have the one entry).  Plain scalar adds, written behind the offset's last use in the schedule: as asm
+    // with an in/out scalar operand hipcc's divergence analysis takes the result for a per-lane value ("illegal VGPR to SGPR copy")
+    auto dma_step_a = [&](int q) {
+        if constexpr (TA) { if (q == 3) ksA[0] += kstepA; }            // (the one entry serves all eight pieces: behind the last)
+        else ksA[TA ? 0 : q] += (unsigned)(BK * 2);
+    };
+    auto dma_step_b = [&](int q) {
+        if constexpr (NN) { if (q == 3) ksB[0] += kstepB; }
+        else ksB[NN ? 0 : q] += (unsigned)(BK * 2);
+    };
+    // (prologue, and the round-3 schedule: a whole piece at once)
     auto dma_a = [&](unsigned buf_off, int i) {
-        const unsigned vo = TA ? voffA[TA ? i : 0] : voffA[i & 1];
-        const unsigned char *base = TA ? st_a : st_a + (unsigned)i * stepA;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dma_base + buf_off + (unsigned)i * 1024u), "v"(vo), "s"(base) : "memory");
+        if constexpr (NO_DMA) return;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(dma_base + buf_off + (unsigned)i * 1024u) : "memory");
+        ld_a(i);
     };
     auto dma_b = [&](unsigned buf_off, int i) {
-        const unsigned vo = NN ? voffB[NN ? i : 0] : voffB[i & 1];
-        // B: tile row r = (wave * 8 + i) * 8 + (lane >> 3); GLU: that is weight row 16 * (r >> 5) + (r & 15) (+ glu_I: an up row)
-        const unsigned char *base = NN ? st_b : (EPI == 0 || EPI == 3) ? st_b + (unsigned)i * stepB : st_b + (unsigned)(2 * (i >> 2) + (i & 1)) * stepB + (unsigned)((i >> 1) & 1) * gluB;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dma_base + buf_off + (unsigned)kTileBytes + (unsigned)i * 1024u), "v"(vo), "s"(base) : "memory");
+        if constexpr (NO_DMA) return;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(dma_base + buf_off + (unsigned)kTileBytes + (unsigned)i * 1024u) : "memory");
+        ld_b(i);
+    };
+    auto dma_step_all = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { dma_step_a(q); dma_step_b(q); }
     };
 
     // ---- fragments: MFMA 16x16x32 operand = 16 rows x 32 k; lane (lm, lq) reads the 16-byte chunk ks*4 + lq of row (tile row) * 16 + lm.
@@ -250,7 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < 8; ++i) dma_a(0u, i);
     if (total > 1) {
-        stage_advance();
+        dma_step_all(); stage_advance(true);
         // (B pieces, then A pieces: the issue order of every K-tile -- SCH 1's counted waits rely on it)
 #pragma unroll
         for (int i = 0; i < 8; ++i) dma_b((unsigned)kBufBytes, i);
@@ -260,7 +317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (total > 2) stage_advance();
+    if (total > 2) { dma_step_all(); stage_advance(true); }
     __builtin_amdgcn_s_barrier();
     bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
 #pragma unroll
@@ -268,37 +325,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < 8; ++i) fa0[i] = frag_a(lds, 0, i);
 
-    long long g = 0;
+    int g = 0;
     for (int it = 0; it < my_tiles; ++it) {
         // (two nested loops, not one flat one with the store under a test: with the store inside the K loop hipcc spilled the loop-carried fragments on every K-tile)
         for (int kt = 0; kt < KT; ++kt, ++g) {
             unsigned char *cur = lds + (g & 1) * kBufBytes, *nxt = lds + ((g + 1) & 1) * kBufBytes;
             const unsigned cur_off = (unsigned)(g & 1) * (unsigned)kBufBytes;
-            if constexpr (SCH == 1) {
+            if constexpr ((SCH & 15) == 1) {
                 // 128 MFMAs, m = 0 .. 127: k-slice 0 (fa0, fb0) then k-slice 1 (fa1, fb1), row i of A fragments outer, B fragment j inner; what is issued behind MFMA m:
                 //   1, 3 .. 15      fb1[0 .. 7]   <- cur (k-slice 1)                      20 / 21   lgkmcnt(0) / barrier 1: cur's B region is free
                 //   23, 26 .. 35    DMA B pieces 0 .. 4 of K-tile g + 2 -> cur            25, 28, 31, 34, 37, 39, 41, 43   fa1[0 .. 7] <- cur
+                //   (M0 is pointed at an operand's first piece at 22 / 60 and moved on behind every load, each in a gap of its own)
                 //   51 / 52         lgkmcnt(0) / barrier 2: cur's A region is free        53, 56, 59   DMA B 5 .. 7      62, 65   DMA A 0, 1
                 //   68 / 69         vmcnt(18) / barrier 3: K-tile g + 1's B has landed    70, 72 .. 84   fb0[0 .. 7] <- nxt (k-slice 0)
                 //   86, 88, 90, 97, 101   DMA A 2 .. 6                                    105 / 106   vmcnt(15) / barrier 4: K-tile g + 1's A has landed
                 //   107, 109 .. 121 fa0[0 .. 7] <- nxt                                    125   DMA A 7
+                constexpr int DBG = SCH >> 4;      // timing-only builds (wrong results): 1 no barriers, 2 no DMA waits, 4 no DMA
                 auto after = [&](const int m) __attribute__((always_inline)) {
                     W4_FENCE();
                     if (m <= 15 && (m & 1)) fb1[m >> 1] = frag_b(cur, 1, m >> 1);
                     else if (m == 20 || m == 51) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    else if (m == 21 || m == 52 || m == 69 || m == 106) __builtin_amdgcn_s_barrier();
-                    else if (m == 23 || m == 26 || m == 29 || m == 32 || m == 35) dma_b(cur_off, (m - 23) / 3);
+                    else if (m == 21 || m == 52 || m == 69 || m == 106) { if constexpr (!(DBG & 1)) __builtin_amdgcn_s_barrier(); }
+                    else if (m == 22) dma_dst_b(cur_off);
+                    else if (m == 23 || m == 26 || m == 29 || m == 32 || m == 35) ld_b((m - 23) / 3);
+                    else if (m == 24 || m == 27 || m == 30 || m == 33 || m == 36 || m == 54 || m == 57) dma_next();
                     else if (m == 25 || m == 28 || m == 31 || m == 34) fa1[(m - 25) / 3] = frag_a(cur, 1, (m - 25) / 3);
                     else if (m == 37 || m == 39 || m == 41 || m == 43) fa1[4 + (m - 37) / 2] = frag_a(cur, 1, 4 + (m - 37) / 2);
-                    else if (m == 53 || m == 56 || m == 59) dma_b(cur_off, 5 + (m - 53) / 3);
-                    else if (m == 62 || m == 65) dma_a(cur_off, (m - 62) / 3);
-                    else if (m == 68) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                    else if (m == 53 || m == 56 || m == 59) ld_b(5 + (m - 53) / 3);
+                    else if (m == 60) dma_dst_a(cur_off);
+                    else if (m == 62 || m == 65) ld_a((m - 62) / 3);
+                    else if (m == 63 || m == 66 || m == 87 || m == 89 || m == 95 || m == 99 || m == 103) dma_next();
+                    else if (m == 68) { if constexpr (!(DBG & 2)) asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); }
                     else if (m >= 70 && m <= 84 && !(m & 1)) fb0[(m - 70) >> 1] = frag_b(nxt, 0, (m - 70) >> 1);
-                    else if (m == 86 || m == 88 || m == 90) dma_a(cur_off, 2 + (m - 86) / 2);
-                    else if (m == 97 || m == 101) dma_a(cur_off, 5 + (m - 97) / 4);
-                    else if (m == 105) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                    else if (m == 86 || m == 88 || m == 90) ld_a(2 + (m - 86) / 2);
+                    else if (m == 97 || m == 101) ld_a(5 + (m - 97) / 4);
+                    else if (m == 105) { if constexpr (!(DBG & 2)) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); }
                     else if (m >= 107 && m <= 121 && (m & 1)) fa0[(m - 107) >> 1] = frag_a(nxt, 0, (m - 107) >> 1);
-                    else if (m == 125) dma_a(cur_off, 7);
+                    else if (m == 125) ld_a(7);
+                    else if (m == 38 || m == 40 || m == 55 || m == 61) dma_step_b(m == 38 ? 0 : m == 40 ? 1 : m == 55 ? 2 : 3);      // behind the offset's last use
+                    else if (m == 67 || m == 91 || m == 98 || m == 126) dma_step_a(m == 67 ? 0 : m == 91 ? 1 : m == 98 ? 2 : 3);
                     W4_FENCE();
                 };
 #pragma unroll
@@ -342,7 +407,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
             }
-            if (g + 3 < total) stage_advance();
+            if constexpr ((SCH & 15) != 1) dma_step_all();
+            stage_advance(g + 3 < total);
         }
         // ---- the tile is complete (the next tile's first two K-tiles are in flight, its first fragments in registers).  The wave's 128x128 block leaves through
         // 4 KiB of LDS of its own, one MFMA row of 16 x 128 at a time: a lane holds four consecutive columns of sixteen different rows, memory wants whole rows --
@@ -520,6 +586,11 @@ int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long lon
     void (*const kerns[2][10])(W4Args) = {W4_KERNS(0), W4_KERNS(1)};
 #undef W4_KERNS
     void (*kern)(W4Args) = kerns[g_w4_sched ? 1 : 0][which];
+    if (g_w4_sched >= 16 && which == 0) {                                  // timing-only diagnostics of the plain NT kernel
+        const int d = g_w4_sched >> 4;
+        kern = d == 1 ? gemm_nt_w4_kernel<0, false, 0, 17> : d == 2 ? gemm_nt_w4_kernel<0, false, 0, 33> : d == 3 ? gemm_nt_w4_kernel<0, false, 0, 49> :
+               d == 4 ? gemm_nt_w4_kernel<0, false, 0, 65> : d == 7 ? gemm_nt_w4_kernel<0, false, 0, 113> : kern;
+    }
     // (the attribute is per device: set on every launch, as everywhere else in the library -- a cached flag would be wrong on a second GPU)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e == hipSuccess) {
@@ -533,7 +604,7 @@ int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long lon
 
 extern "C" int ecgb_set_gemm_w4_sched(int s)
 {
-    if (s < 0 || s > 1) { ecgb::set_error("ecgb_set_gemm_w4_sched: 0 (one rendezvous per K-tile) or 1 (four barriers, counted waits)"); return ECGB_ERR_INVALID; }
+    if (s < 0 || (s > 1 && (s & 15) != 1)) { ecgb::set_error("ecgb_set_gemm_w4_sched: 0 (one rendezvous per K-tile) or 1 (four barriers, counted waits)"); return ECGB_ERR_INVALID; }
     g_w4_sched = s;
     return ECGB_OK;
 }
