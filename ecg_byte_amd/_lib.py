@@ -160,6 +160,7 @@ def lib():
         "ecgb_set_gemm_w4": [ci],
         "ecgb_set_gemm_w4_group_m": [ci],
         "ecgb_set_gemm_w4_sched": [ci],
+        "ecgb_set_gemm_w4_min_ktiles": [ci],
         "ecgb_attn_decode_split_dyn": [vp, vp, vp, ll, ll, vp, ll, vp, ci, vp, ci, ci, ci, f32, ci, vp, sz, vp],
         "ecgb_gemm_tn_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, vp],
         "ecgb_sum_slabs_bf16": [vp, ll, ci, vp, sz, ci, vp],

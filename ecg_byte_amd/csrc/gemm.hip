@@ -2258,8 +2258,8 @@ extern "C" int ecgb_gemm_nt_glu_bf16(const void *a_dev, long long lda, const voi
     }
     // whole tiles, no second operand pair: the four-wave kernel with the same epilogue (the same bits).  Measured at [32768, 2048] -> 2 x 8192: 1.853 against 1.863 ms, h only
     // 1.669 against 1.703 -- the activation is vector work that a wave alone on its SIMD cannot hide (under the profiler its MFMA pipes are 0.57 busy, the plain kernel's
-    // 0.65); with a LoRA pair behind it 1.952 against 1.935, so that form stays on the eight-wave kernel (g_gemm_w4 == 2 sends it to the four-wave one: tests).
-    if (g_gemm_w4 && g_gemm_tile == 0 && (K2 <= 0 || (g_gemm_w4 == 2 && (long long)(inter + 63) * ldb2 * 2 + 128 <= 0xFFFFFFFFll)) && (ldh & 7) == 0 && ((uintptr_t)h_dev & 15) == 0 && (!c_dev || ((ldc & 7) == 0 && ((uintptr_t)c_dev & 15) == 0)) &&
+    // 0.65); with a LoRA pair behind it 1.952 against 1.935 in round 3 -- and 1.75 against 1.94 with round 4's K-tile schedule, so that form goes there too now.
+    if (g_gemm_w4 && g_gemm_tile == 0 && (K2 <= 0 || (long long)(inter + 63) * ldb2 * 2 + 128 <= 0xFFFFFFFFll) && (ldh & 7) == 0 && ((uintptr_t)h_dev & 15) == 0 && (!c_dev || ((ldc & 7) == 0 && ((uintptr_t)c_dev & 15) == 0)) &&
         (long long)(inter + 63) * ldb * 2 + 128 <= 0xFFFFFFFFll && ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, h_dev, ldh, M, 2 * inter, K))
         return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, 2 * inter, K, alpha, stream, gelu_tanh ? 2 : 1, h_dev, ldh, a2_dev, lda2, b2_dev, ldb2, K2, nullptr, nullptr, 0, 0);
     GemmArgs G{};

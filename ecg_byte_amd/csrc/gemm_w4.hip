@@ -537,6 +537,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 int g_w4_group_m = 8;
+int g_w4_min_ktiles = 128;      // K-tiles per workgroup from which the entry points of gemm.hip send a problem here (round 3: 256; with round 4's schedule the qkv / o shapes gain too)
 int g_w4_sched = 1;              // 1: four barriers per K-tile with counted waits (round 4); 0: one rendezvous per K-tile (round 3), kept for A/B
 
 // CUs of the current device, rounded down to a multiple of the 8 XCDs (one persistent workgroup each); looked up per device, cached per device
@@ -565,7 +566,7 @@ bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long l
     const int g_w4_cus = w4_cus();
     return M > 0 && N > 0 && K > 0 && M % 256 == 0 && N % 256 == 0 && K % BK == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
            (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)c_dev) & 15) == 0 && (long long)63 * lda * 2 + 128 <= 0xFFFFFFFFll && (long long)63 * ldb * 2 + 128 <= 0xFFFFFFFFll &&
-           (long long)(M / 256) * (N / 256) / g_w4_cus * (K / BK) >= 256;
+           (long long)(M / 256) * (N / 256) / g_w4_cus * (K / BK) >= g_w4_min_ktiles;
 }
 
 // epi 0: C [M, N] plain.  epi 1 / 2 (SiLU / tanh-GELU): N = 2 * inter, B = [gate rows; up rows], H [M, inter] = act(gate) * up, C (gate|up) may be null.
@@ -606,6 +607,13 @@ extern "C" int ecgb_set_gemm_w4_sched(int s)
 {
     if (s < 0 || (s > 1 && (s & 15) != 1)) { ecgb::set_error("ecgb_set_gemm_w4_sched: 0 (one rendezvous per K-tile) or 1 (four barriers, counted waits)"); return ECGB_ERR_INVALID; }
     g_w4_sched = s;
+    return ECGB_OK;
+}
+
+extern "C" int ecgb_set_gemm_w4_min_ktiles(int n)
+{
+    if (n < 1) { ecgb::set_error("ecgb_set_gemm_w4_min_ktiles: n >= 1"); return ECGB_ERR_INVALID; }
+    g_w4_min_ktiles = n;
     return ECGB_OK;
 }
 

@@ -74,6 +74,11 @@ def set_gemm_w4_group_m(g=8):
     _lib.check(_L().ecgb_set_gemm_w4_group_m(int(g)))
 
 
+def set_gemm_w4_min_ktiles(n=128):
+    """K-tiles per workgroup from which the GEMM entry points pick the four-wave kernel."""
+    _lib.check(_L().ecgb_set_gemm_w4_min_ktiles(int(n)))
+
+
 def set_gemm_w4_sched(s=1):
     """K-tile schedule of the four-wave kernel: 1 four barriers behind counted waits (default), 0 one rendezvous per K-tile (round 3).  Same bits."""
     _lib.check(_L().ecgb_set_gemm_w4_sched(int(s)))
