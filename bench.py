@@ -249,30 +249,36 @@ def hbm_kernel_report(dev, B, S, cfg, n_vocab, reps=10):
     return out
 
 
-def bench_batch_sweep(tk, pc, xd, L, sizes=(1, 64, 1024, 4096), reps=20):
-    """the fused quantise + encode launch over B in {1, 64, 1024, 4096} records (inputs resident, HIP events on the launch stream)."""
+def bench_batch_sweep(tk, pc, xd, L, sizes=(1, 64, 1024, 4096, 16384, 65536), reps=20):
+    """the fused quantise + encode launch over B in {1, 64, 1024, 4096} records, and 16 384 / 65 536 (the bench batch of 4 096 is exactly ONE round
+    of resident waves -- one record per wave -- so its launch ends with the slowest record of the slowest SIMD; a corpus pass runs many rounds per launch, and this is
+    where that rate is measured rather than argued).  Inputs resident, HIP events on the launch stream; batches above the bench batch repeat its records."""
     import torch
     n = 12 * L
     out = []
     for B in sizes:
-        if B > xd.shape[0]:
+        free = torch.cuda.mem_get_info(xd.device)[0]
+        if B > xd.shape[0] and B * n * 12 > 0.8 * free:            # 8 bytes of signal + 4 of worst-case ids per sample
             continue
-        x = xd[:B]
+        x = xd[:B] if B <= xd.shape[0] else xd.repeat((B + xd.shape[0] - 1) // xd.shape[0], 1, 1)[:B].contiguous()
         ids = torch.empty((B, n), dtype=torch.int32, device=xd.device)
         counts = torch.empty((B,), dtype=torch.int32, device=xd.device)
+        r = reps if B <= 4096 else 5
         for _ in range(3):
             tk.quantize_encode(x, pc, ids_stride=n, out=(ids, counts))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(reps):
+        for _ in range(r):
             tk.quantize_encode(x, pc, ids_stride=n, out=(ids, counts))
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        ms = e0.elapsed_time(e1) / r
         toks = int(counts.sum().item())
         alg = B * 8 * n + 4 * toks
-        out.append({"records": B, "ms_per_launch": ms, "tokens_per_s": toks / (ms * 1e-3), "symbols_per_s": B * n / (ms * 1e-3),
+        out.append({"records": B, "ms_per_launch": ms, "ms_per_4096_records": ms * 4096 / B, "tokens_per_s": toks / (ms * 1e-3), "symbols_per_s": B * n / (ms * 1e-3),
                     "GB/s": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        del x, ids, counts
+        torch.cuda.empty_cache()
     return out
 
 
@@ -637,7 +643,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the train-step part (encode metric only)")
     ap.add_argument("--train-batch", type=int, default=32, help="samples per GPU per train step")
-    ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--train-steps", type=int, default=10, help="timed steps of every train leg (the boxes differ by 1-2 %: ten steps per figure, not two or three)")
     ap.add_argument("--full-logits", action="store_true", help="loss head over every row, as the reference materialises it")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 object (Gemma-2B dims LoRA step + generate)")
     ap.add_argument("--no-c1", action="store_true", help="skip the C1 object (12x1000 records + GPT-2-small forward, batch 4)")
@@ -686,8 +692,22 @@ def main():
             dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # A scaling run must be what it says: exit non-zero (no JSON line) if the process group is not --gpus ranks wide, or if two RCCL ranks sit on one device
+    # (the gloo one-device test hook is exempt: it exists to run the N = 2 code path on a one-GPU box and is never a measured run).
+    pg_world = dist.get_world_size() if dist.is_initialized() else 1
+    if world != args.gpus or pg_world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}, process group of {pg_world} ranks\n")
+        sys.exit(2)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
+    pg_backend = dist.get_backend() if dist.is_initialized() else None
+    if dist.is_initialized() and world > 1 and pg_backend == "nccl" and os.environ.get("ECGB_BENCH_ONE_DEVICE") != "1":
+        pr = torch.cuda.get_device_properties(dev)
+        mine = f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', -1):02x}:{getattr(pr, 'pci_device_id', -1):02x}/{getattr(pr, 'uuid', local_rank)}"
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        if len(set(seen)) != world:
+            sys.stderr.write(f"bench.py: {world} RCCL ranks on {len(set(seen))} distinct devices ({seen}): not a {world}-GPU run\n")
+            sys.exit(3)
 
     tag = "c2" if args.L == 5000 else "c1"
     vocab, merges, pc = load_tokenizer(tag)
@@ -748,7 +768,7 @@ def main():
         if not args.lora and not args.no_lora_leg:   # SURVEY.md §8d asks for both: full fine-tune (BASELINE C3 wording) and LoRA r16 (what the reference's script runs)
             import copy
             largs = copy.copy(args)
-            largs.lora, largs.no_cpu_baseline, largs.train_steps = True, True, min(args.train_steps, 3)
+            largs.lora, largs.no_cpu_baseline, largs.train_steps = True, True, args.train_steps
             lora = bench_train(largs, tk, vocab, merges, pc, world, rank, dev, x_train)
             train["lora_r16"] = {k: lora[k] for k in ("value", "unit", "ms_per_step", "steps", "final_loss", "roofline")}
             train["lora_r16"]["workload"] = lora["config"]["workload"]
@@ -757,7 +777,7 @@ def main():
         # the reference-equivalent loss head (modeling_llama.py:1209-1213 materialises every row's logits): the same step with the head over all B x S rows
         import copy
         fargs = copy.copy(args)
-        fargs.full_logits, fargs.no_cpu_baseline, fargs.train_steps, fargs.no_hbm_report = True, True, min(args.train_steps, 2), True
+        fargs.full_logits, fargs.no_cpu_baseline, fargs.train_steps, fargs.no_hbm_report = True, True, args.train_steps, True
         full = bench_train(fargs, tk, vocab, merges, pc, world, rank, dev, x_train)
         train["full_logits"] = {k: full[k] for k in ("value", "unit", "ms_per_step", "steps", "final_loss", "roofline")}
         train["full_logits"]["workload"] = full["config"]["workload"] + "; loss head over all rows, as the reference materialises them"
@@ -784,6 +804,7 @@ def main():
             "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64->u8->u32", "data": "synthetic",
+            "rccl_ranks": pg_world if pg_backend == "nccl" else 0, "backend": pg_backend,      # the process group this line was measured under (None: one plain process)
             "config": {"workload": f"C2: PTB-XL-shaped 12x{L} float64 records, vocab {len(merges)} merges, "
                                    f"quantise+encode, {B} records/GPU", "records_per_gpu": B,
                        "samples_per_record": n, "merges": len(merges), "parallelism": f"dp{world} (sharded records, no collective)"},

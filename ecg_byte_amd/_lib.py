@@ -142,6 +142,7 @@ def lib():
         "ecgb_sumsq": [vp, sz, ci, vp, vp],
         "ecgb_sumsq_multi_bf16": [vp, vp, vp, vp, ci, vp, vp, vp],
         "ecgb_adam_step": [vp, vp, ci, vp, vp, sz, vp, f32, f32, f32, f32, f32, f32, ci, vp],
+        "ecgb_adam_multi_bf16": [vp, vp, vp, vp, vp, vp, vp, ci, vp, f32, f32, f32, f32, f32, f32, ci, vp],
         "ecgb_softmax_causal_fwd": [vp, vp, ci, ci, ci, f32, vp],
         "ecgb_softmax_bwd": [vp, vp, ci, ci, f32, vp],
         "ecgb_set_gemm_tile": [ci],

@@ -2061,6 +2061,20 @@ int launched(const char *what)
     return ECGB_ERR_HIP;
 }
 
+// One kernel launch of the dispatch below: the dynamic-LDS attribute, then the launch; either failure is reported HERE with the kernel's name (a refused
+// attribute used to skip the launch silently and leave it to a later hipGetLastError -- which does not see it: the outputs stayed unwritten, status OK).
+template <typename Kern>
+int launch_attn(Kern kern, dim3 grid, dim3 block, int lds, void *stream, const AttnArgs &A, const char *what)
+{
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+        ecgb::set_error(std::string(what) + ": hipFuncSetAttribute(" + std::to_string(lds) + " bytes of dynamic LDS): " + hipGetErrorString(e));
+        return ECGB_ERR_HIP;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, A);
+    return launched(what);
+}
+
 }  // namespace
 
 extern "C" int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev, long long ldk, const void *v_dev, long long ldv,
@@ -2074,9 +2088,6 @@ extern "C" int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev
     int rc = check_args(A, head_dim, "ecgb_attn_fwd");
     if (rc) return rc;
     const dim3 grid((unsigned)((seq + 127) / 128) * (unsigned)n_q_heads * (unsigned)batch);   // 1-D: map_block() deals blocks to XCDs
-#define ECGB_FWD(D_) do { const int lds = 4 * 128 * D_ + 4 * ((seq + 63) & ~63); \
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_kernel<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) break; \
-        hipLaunchKernelGGL(attn_fwd_kernel<D_>, grid, dim3(256), lds, (hipStream_t)stream, A); } while (0)
     if (head_dim == 64) {
         const int lds = 6 * 128 * 64 + 4 * ((seq + 63) & ~63);
         if ((g_attn_dma & 3) == 2 && !(g_attn_dma & 0x100)) {
@@ -2084,15 +2095,13 @@ extern "C" int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev
             const LeanGeom lg = lean_geom(seq, n_q_heads, n_kv_heads, batch);
             A.lean_hw_log2 = lg.hw_log2;
             auto kf = g_lean_waves == 8 ? attn_fwd_lean_kernel<8> : attn_fwd_lean_kernel<4>;
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, ldl) == hipSuccess)
-                hipLaunchKernelGGL(kf, dim3(lg.grid), dim3(g_lean_waves * 64), ldl, (hipStream_t)stream, A);
-        } else if (g_attn_dma & 3) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess)
-                hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), lds, (hipStream_t)stream, A);
-        } else ECGB_FWD(64);
-    } else if (head_dim == 128) ECGB_FWD(128); else ECGB_FWD(256);
-#undef ECGB_FWD
-    return launched("attn_fwd_kernel");
+            return launch_attn(kf, dim3(lg.grid), dim3(g_lean_waves * 64), ldl, stream, A, "attn_fwd_lean_kernel");
+        }
+        if (g_attn_dma & 3) return launch_attn(attn_fwd_kernel<64, true>, grid, dim3(256), lds, stream, A, "attn_fwd_kernel<64, dma>");
+        return launch_attn(attn_fwd_kernel<64>, grid, dim3(256), 4 * 128 * 64 + 4 * ((seq + 63) & ~63), stream, A, "attn_fwd_kernel<64>");
+    }
+    if (head_dim == 128) return launch_attn(attn_fwd_kernel<128>, grid, dim3(256), 4 * 128 * 128 + 4 * ((seq + 63) & ~63), stream, A, "attn_fwd_kernel<128>");
+    return launch_attn(attn_fwd_kernel<256>, grid, dim3(256), 4 * 128 * 256 + 4 * ((seq + 63) & ~63), stream, A, "attn_fwd_kernel<256>");
 }
 
 namespace {
@@ -2145,13 +2154,7 @@ int attn_bwd_impl(const void *q_dev, long long ldq, const void *k_dev, long long
     const unsigned nblk = (unsigned)((seq + 127) / 128);
     const dim3 gq(nblk * (unsigned)n_q_heads * (unsigned)batch);          // 1-D: map_block() deals blocks to XCDs
     const unsigned gk = nblk * (unsigned)n_kv_heads * (unsigned)batch;
-#define ECGB_DKV(D_, DS_, W_) do { \
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_kernel<D_, DS_, W_>), hipFuncAttributeMaxDynamicSharedMemorySize, lk) != hipSuccess) break; \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D_, DS_, W_>), dim3(gk * DS_), dim3(256), lk, (hipStream_t)stream, A); } while (0)
-#define ECGB_BWD(D_) do { const int lq = 3 * 128 * D_ + 4 * ((seq + 63) & ~63); \
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dq_kernel<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, lq) != hipSuccess) break; \
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<D_>, gq, dim3(256), lq, (hipStream_t)stream, A); \
-        } while (0)
+    auto dq_generic = [&](auto kern, int D_, const char *what) { return launch_attn(kern, gq, dim3(256), 3 * 128 * D_ + 4 * ((seq + 63) & ~63), stream, A, what); };
     if (head_dim == 64) {
         const bool lean = (g_attn_dma & 3) == 2;
         if (g_attn_dma & 3) {
@@ -2160,34 +2163,34 @@ int attn_bwd_impl(const void *q_dev, long long ldq, const void *k_dev, long long
             const LeanGeom lg = lean_geom(seq, n_q_heads, n_kv_heads, batch);
             A.lean_hw_log2 = lg.hw_log2;
             auto kq = !lq_lean ? attn_bwd_dq_dma_kernel : g_lean_waves == 8 ? attn_bwd_dq_lean_kernel<8> : attn_bwd_dq_lean_kernel<4>;
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, lq) == hipSuccess)
-                hipLaunchKernelGGL(kq, lq_lean ? dim3(lg.grid) : gq, dim3(lq_lean ? g_lean_waves * 64 : 256), lq, (hipStream_t)stream, A);
+            rc = launch_attn(kq, lq_lean ? dim3(lg.grid) : gq, dim3(lq_lean ? g_lean_waves * 64 : 256), lq, stream, A, lq_lean ? "attn_bwd_dq_lean_kernel" : "attn_bwd_dq_dma_kernel");
         } else {
-            ECGB_BWD(64);
+            rc = dq_generic(attn_bwd_dq_kernel<64>, 64, "attn_bwd_dq_kernel<64>");
         }
+        if (rc) return rc;
         if (g_attn_dma & 3) {
             const bool lk_lean = lean && !(g_attn_dma & 0x400);
             const int lk = lk_lean ? kLeanRing * (2 * 128 * 64 + g_lean_waves * 256) : 3 * (2 * 128 * 64 + 1024);
             auto kk = !lk_lean ? attn_bwd_dkv_dma_kernel : g_lean_waves == 8 ? attn_bwd_dkv_lean_kernel<8> : attn_bwd_dkv_lean_kernel<4>;
             const unsigned gkl = (unsigned)(((seq + g_lean_waves * 32 - 1) / (g_lean_waves * 32) + 1) / 2) * (unsigned)n_kv_heads * (unsigned)batch;   // key blocks in pairs (j, n - 1 - j)
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, lk) == hipSuccess)
-                hipLaunchKernelGGL(kk, dim3(lk_lean ? gkl : gk), dim3(lk_lean ? g_lean_waves * 64 : 256), lk, (hipStream_t)stream, A);
-        } else {
-            const int lk = 4 * 128 * 64 + 512; ECGB_DKV(64, 1, 0);
+            return launch_attn(kk, dim3(lk_lean ? gkl : gk), dim3(lk_lean ? g_lean_waves * 64 : 256), lk, stream, A, lk_lean ? "attn_bwd_dkv_lean_kernel" : "attn_bwd_dkv_dma_kernel");
         }
+        return launch_attn(attn_bwd_dkv_kernel<64, 1, 0>, dim3(gk), dim3(256), 4 * 128 * 64 + 512, stream, A, "attn_bwd_dkv_kernel<64>");
     }
-    else if (head_dim == 128) { ECGB_BWD(128); const int lk = 4 * 128 * 128 + 512; ECGB_DKV(128, 1, 0); }
-    else {
-        ECGB_BWD(256);
-        const int lk = 4 * 128 * 256 + 512;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_bwd_dkv_pair_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, lk) == hipSuccess) {
-            hipLaunchKernelGGL(attn_bwd_dkv_pair_kernel<256>, dim3(gk * 2 * (unsigned)A.head_splits), dim3(256), lk, (hipStream_t)stream, A);
-            if (A.head_splits > 1) hipLaunchKernelGGL(attn_dkv_reduce_kernel<256>, dim3(2048), dim3(256), 0, (hipStream_t)stream, A);
-        }
+    if (head_dim == 128) {
+        rc = dq_generic(attn_bwd_dq_kernel<128>, 128, "attn_bwd_dq_kernel<128>");
+        if (rc) return rc;
+        return launch_attn(attn_bwd_dkv_kernel<128, 1, 0>, dim3(gk), dim3(256), 4 * 128 * 128 + 512, stream, A, "attn_bwd_dkv_kernel<128>");
     }
-#undef ECGB_BWD
-#undef ECGB_DKV
-    return launched("attn_bwd kernels");
+    rc = dq_generic(attn_bwd_dq_kernel<256>, 256, "attn_bwd_dq_kernel<256>");
+    if (rc) return rc;
+    rc = launch_attn(attn_bwd_dkv_pair_kernel<256>, dim3(gk * 2 * (unsigned)A.head_splits), dim3(256), 4 * 128 * 256 + 512, stream, A, "attn_bwd_dkv_pair_kernel<256>");
+    if (rc) return rc;
+    if (A.head_splits > 1) {
+        hipLaunchKernelGGL(attn_dkv_reduce_kernel<256>, dim3(2048), dim3(256), 0, (hipStream_t)stream, A);
+        return launched("attn_dkv_reduce_kernel<256>");
+    }
+    return ECGB_OK;
 }
 }  // namespace
 

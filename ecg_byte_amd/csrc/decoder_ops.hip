@@ -861,6 +861,56 @@ __global__ __launch_bounds__(256) void adam_kernel(unsigned short *p, const G *g
     }
 }
 
+
+// The same update over a LIST of bf16 parameter tensors in one launch (a full fine-tune step was ~100 launches of adam_kernel): block b takes chunk b = elements
+// [chunk_off[b], chunk_off[b] + 2^20) of tensor chunk_tensor[b] -- sumsq_multi_kernel's chunk table.  Eight elements per lane and trip where the four pointers allow
+// 16-byte accesses (the single-tensor kernel moves 2 and 4 bytes per lane and instruction); element by element the arithmetic of adam_kernel: the same bits.
+__global__ __launch_bounds__(256) void adam_multi_kernel(unsigned short *const *ps, const unsigned short *const *gs, float *const *ms, float *const *vs,
+                                                         const unsigned long long *counts, const int *chunk_tensor, const unsigned long long *chunk_off,
+                                                         const float *sumsq, float max_norm, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2)
+{
+    using u4 = __attribute__((ext_vector_type(4))) unsigned;
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    const float norm = sqrtf(*sumsq);
+    const float clip = fminf(1.0f, max_norm / (norm + 1e-6f));
+    const int t = chunk_tensor[blockIdx.x];
+    const unsigned long long off = chunk_off[blockIdx.x];
+    const unsigned long long n = min((unsigned long long)(1u << 20), counts[t] - off);
+    unsigned short *p = ps[t] + off;
+    const unsigned short *g = gs[t] + off;
+    float *m = ms[t] + off, *v = vs[t] + off;
+    auto one = [&](float pf, float gf, float &mm, float &vv) {
+        gf = gf * clip + wd * pf;
+        mm = b1 * mm + (1.f - b1) * gf;
+        vv = b2 * vv + (1.f - b2) * gf * gf;
+        const float denom = sqrtf(vv / bc2) + eps;
+        return f2bf(pf - lr * (mm / bc1) / denom);
+    };
+    const bool wide = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const unsigned long long n8 = wide ? (n & ~7ull) : 0ull;
+    for (unsigned long long i = (unsigned long long)threadIdx.x * 8; i < n8; i += 256 * 8) {
+        const u4 pw = *reinterpret_cast<const u4 *>(p + i), gw = *reinterpret_cast<const u4 *>(g + i);
+        float mm[8], vv[8];
+        *reinterpret_cast<f4 *>(mm) = *reinterpret_cast<const f4 *>(m + i); *reinterpret_cast<f4 *>(mm + 4) = *reinterpret_cast<const f4 *>(m + i + 4);
+        *reinterpret_cast<f4 *>(vv) = *reinterpret_cast<const f4 *>(v + i); *reinterpret_cast<f4 *>(vv + 4) = *reinterpret_cast<const f4 *>(v + i + 4);
+        u4 out;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const unsigned short lo = one(bf2f((unsigned short)(pw[w] & 0xFFFFu)), bf2f((unsigned short)(gw[w] & 0xFFFFu)), mm[2 * w], vv[2 * w]);
+            const unsigned short hi = one(bf2f((unsigned short)(pw[w] >> 16)), bf2f((unsigned short)(gw[w] >> 16)), mm[2 * w + 1], vv[2 * w + 1]);
+            out[w] = (unsigned)lo | ((unsigned)hi << 16);
+        }
+        *reinterpret_cast<f4 *>(m + i) = *reinterpret_cast<const f4 *>(mm); *reinterpret_cast<f4 *>(m + i + 4) = *reinterpret_cast<const f4 *>(mm + 4);
+        *reinterpret_cast<f4 *>(v + i) = *reinterpret_cast<const f4 *>(vv); *reinterpret_cast<f4 *>(v + i + 4) = *reinterpret_cast<const f4 *>(vv + 4);
+        *reinterpret_cast<u4 *>(p + i) = out;
+    }
+    for (unsigned long long i = n8 + threadIdx.x; i < n; i += 256) {
+        float mm = m[i], vv = v[i];
+        p[i] = one(bf2f(p[i]), bf2f(g[i]), mm, vv);
+        m[i] = mm; v[i] = vv;
+    }
+}
+
 // out[c][r] = in[r][c]  (bf16), 64x64 tiles through LDS
 __global__ __launch_bounds__(256) void transpose_kernel(const unsigned short *in, unsigned short *out, int R, int Cc)
 {
@@ -1275,6 +1325,20 @@ extern "C" int ecgb_adam_step(void *param_dev, const void *grad_dev, int grad_is
         hipLaunchKernelGGL(adam_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (unsigned short *)param_dev,
                            (const unsigned short *)grad_dev, m_dev, v_dev, n, sumsq_dev, max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
     ECGB_CHECK_LAUNCH("adam_step");
+}
+
+
+extern "C" int ecgb_adam_multi_bf16(void *const *params_dev, const void *const *grads_dev, float *const *m_dev, float *const *v_dev, const unsigned long long *counts_dev,
+                                    const int *chunk_tensor_dev, const unsigned long long *chunk_off_dev, int n_chunks, const float *sumsq_dev, float max_norm,
+                                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, void *stream)
+{
+    if (n_chunks <= 0) return ECGB_OK;
+    if (!params_dev || !grads_dev || !m_dev || !v_dev || !counts_dev || !chunk_tensor_dev || !chunk_off_dev || !sumsq_dev) { ecgb::set_error("ecgb_adam_multi_bf16: NULL argument"); return ECGB_ERR_INVALID; }
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, (unsigned short *const *)params_dev,
+                       (const unsigned short *const *)grads_dev, m_dev, v_dev, counts_dev, chunk_tensor_dev, chunk_off_dev, sumsq_dev, max_norm, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2);
+    ECGB_CHECK_LAUNCH("adam_multi");
 }
 
 extern "C" int ecgb_transpose_bf16(const void *in_dev, void *out_dev, int rows, int cols, void *stream)

@@ -1258,6 +1258,7 @@ class HipAdam:
         self.t = 0
         self.state = {}
         self._sumsq_plan = None
+        self._adam_tables = None
 
     def zero_grad(self):
         for p in self.model.parameters():
@@ -1291,8 +1292,20 @@ class HipAdam:
             ops.adam_step_(p.data, p.grad, st[0], st[1], acc, self.max_norm, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t)
 
         if not self.overlap:
-            for p in params:
-                update(p)
+            multi = self._sumsq_plan is not None and self._sumsq_plan.counts_host == [p.numel() for p in params] and \
+                all(p.data.dtype == torch.bfloat16 and p.data.is_contiguous() and p.grad.dtype == torch.bfloat16 and p.grad.is_contiguous() for p in params)
+            if multi:                                                # ONE launch for every parameter (was one per tensor: ~100 for a full fine-tune)
+                for p in params:
+                    st = self.state.get(id(p))
+                    if st is None or st[0].shape != p.shape:
+                        self.state[id(p)] = (torch.zeros(p.shape, dtype=torch.float32, device=p.device), torch.zeros(p.shape, dtype=torch.float32, device=p.device))
+                datas, ms, vs = [p.data for p in params], [self.state[id(p)][0] for p in params], [self.state[id(p)][1] for p in params]
+                if self._adam_tables is None or not self._adam_tables.matches(datas, grads, ms, vs):
+                    self._adam_tables = ops.AdamMultiPlan(datas, grads, ms, vs, self.model.device)
+                ops.adam_multi_(self._adam_tables, self._sumsq_plan, acc, self.max_norm, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t)
+            else:
+                for p in params:
+                    update(p)
         else:
             model = self.model
             model.sync_optimizer()                                   # (a previous overlapped step nobody waited for)

@@ -603,6 +603,26 @@ def adam_step_(p, g, m, v, sumsq_acc, max_norm, lr, beta1, beta2, eps, weight_de
                                    int(step), _st()))
 
 
+class AdamMultiPlan:
+    """Pointer tables (parameters, gradients, moments) of `adam_multi_` for a fixed list of tensors; rebuilt by the caller when an address changes."""
+
+    def __init__(self, params, grads, ms, vs, device):
+        self.key = tuple(t.data_ptr() for ts in (params, grads, ms, vs) for t in ts)
+        tab = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64).to(device)
+        self.p, self.g, self.m, self.v = tab(params), tab(grads), tab(ms), tab(vs)
+
+    def matches(self, params, grads, ms, vs):
+        return self.key == tuple(t.data_ptr() for ts in (params, grads, ms, vs) for t in ts)
+
+
+def adam_multi_(tables, chunks, sumsq_acc, max_norm, lr, beta1, beta2, eps, weight_decay, step):
+    """One launch of the Adam step over every tensor of `tables` (AdamMultiPlan; bf16 parameters and gradients, fp32 moments, all contiguous); `chunks` is the
+    SumsqPlan of the same tensor sizes.  The same bits as adam_step_ per tensor."""
+    _lib.check(_L().ecgb_adam_multi_bf16(_p(tables.p), _p(tables.g), _p(tables.m), _p(tables.v), _p(chunks.counts), _p(chunks.chunk_tensor), _p(chunks.chunk_off),
+                                         chunks.n_chunks, _p(sumsq_acc), float(max_norm), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                         int(step), _st()))
+
+
 FUSED_HEAD_DIMS = (64, 128, 256)     # head dims ecgb_attn_fwd / ecgb_attn_bwd take
 
 

@@ -207,6 +207,11 @@ int ecgb_sumsq_multi_bf16(const void *const *ptrs_dev, const unsigned long long 
 int ecgb_adam_step(void *param_dev, const void *grad_dev, int grad_is_fp32, float *m_dev, float *v_dev, size_t n,
                    const float *sumsq_dev, float max_norm, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, void *stream);
+/* The same step over a LIST of bf16 parameter tensors in ONE launch (pointer tables of the parameters, their bf16 gradients and their fp32 moments; the chunk
+ * table of ecgb_sumsq_multi_bf16): element by element ecgb_adam_step's arithmetic, the same bits; 16-byte accesses where the four pointers of a tensor allow. */
+int ecgb_adam_multi_bf16(void *const *params_dev, const void *const *grads_dev, float *const *m_dev, float *const *v_dev, const unsigned long long *counts_dev,
+                         const int *chunk_tensor_dev, const unsigned long long *chunk_off_dev, int n_chunks, const float *sumsq_dev, float max_norm,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, int step, void *stream);
 
 /* Attention probabilities, round 1: scores are materialised ([batch*heads, S, S] bf16) by batched
  * ecgb_gemm_nt_bf16 calls and normalised here (a fused flash-style kernel is the next step).

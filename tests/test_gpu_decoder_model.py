@@ -165,6 +165,48 @@ def test_gqa_4_to_1_vs_decoder_oracle(fused_attention):
     assert ((m.embed.grad[:515].float() - want).norm() / want.norm()).item() < 3e-2
 
 
+def test_masked_rows_with_a_valid_label_keep_their_embedding_gradient():
+    """Backward skips the embedding scatter of rows that are masked AND unlabelled (their gradient is exactly zero).  A masked row whose shifted label is valid --
+    a hole in the attention mask in front of a labelled token -- still receives d hidden through its residual path and autograd adds it to the row of its id:
+    checked against the fp32 oracle on an id that occurs nowhere else in the batch.  (A left-pad row in front of a labelled FIRST token is the same case for the
+    scatter, but its attention row has no visible key at all and the reference's softmax over an all-masked row is not a definition worth matching: not tested.)"""
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    from oracle import llama_ref as R
+    cfgd = dict(vocab_size=515, hidden_size=256, intermediate_size=448, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, head_dim=64, rms_norm_eps=1e-6)
+    params = R.random_params(cfgd, seed=11, device="cuda", std=0.05)
+    cfg = DecoderConfig(vocab_size=515, hidden_size=256, intermediate_size=448, num_hidden_layers=2, num_attention_heads=4,
+                        num_key_value_heads=2, rms_norm_eps=1e-6, rope_theta=10000.0, rope_scaling=None, pad_token_id=None)
+    m = HipCausalLM(cfg)
+    m.load_state_dict(params)
+    B, S = 2, 128
+    g = torch.Generator(device="cuda").manual_seed(6)
+    ids = torch.randint(0, 500, (B, S), device="cuda", generator=g)
+    mask = torch.ones(B, S, device="cuda")
+    mask[0, 100] = 0; ids[0, 100] = 510                    # a hole: row 100 is masked, labels[101] is valid
+    mask[1, :40] = 0; ids[1, :40] = 511                    # left padding, unlabelled: dead rows
+    pos = (torch.cumsum(mask, 1) - 1).clamp(min=0).long()
+    labels = torch.full((B, S), -100, device="cuda")
+    labels[0, 90:] = ids[0, 90:]; labels[1, 60:] = ids[1, 60:]
+    labels[0, 100] = -100                                  # (the hole itself is no target)
+    ref_p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = R.llama_loss(ref_p, cfgd, ids, mask, labels, pos, R.llama3_inv_freq(64, 10000.0, None).cuda())
+    ref.backward()
+    out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
+    out.loss.backward()
+    assert abs(out.loss.item() - ref.item()) <= 1e-2 * ref.item()
+    want, got = ref_p["model.embed_tokens.weight"].grad, m.embed.grad[:515].float()
+    # (the head is tied: every vocabulary row also carries the loss head's dE; what the INPUT rows add comes on top of it)
+    for tok in (510, 511):                                 # the masked-but-labelled row's id; the dead rows' id (head gradient only)
+        assert ((got[tok] - want[tok]).norm() / want[tok].norm()).item() < 5e-2, tok
+    m2 = HipCausalLM(cfg); m2.load_state_dict(params)      # the same batch with the hole's id moved elsewhere: row 510 must lose exactly the input row's share
+    ids2 = ids.clone(); ids2[0, 100] = 509
+    m2(input_ids=ids2, attention_mask=mask, labels=labels, position_ids=pos).loss.backward()
+    share = got[510] - m2.embed.grad[510].float()
+    assert share.norm().item() > 0.05 * got[510].norm().item()
+    assert ((got - want).norm() / want.norm()).item() < 3e-2
+
+
 def test_lora_adapters_vs_oracle():
     """LoRA mode (the reference's launch mode, main.py:131-155): frozen base, r = 16, alpha = 32, adapters on
     q,k,v,o,gate,up,down; dropout 0 for the parity check.  B is given non-zero values so that every adapter

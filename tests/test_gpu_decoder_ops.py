@@ -299,6 +299,35 @@ def test_adam_with_clipping_matches_torch(ops):
         _close(p, ref_p.detach(), atol=1e-3 * step, rtol=2 ** -7 * step)
 
 
+def test_multi_tensor_adam_is_the_per_tensor_step_bit_for_bit(ops):
+    """ecgb_adam_multi_bf16 (one launch over a list of parameters, 16-byte accesses) = ecgb_adam_step per tensor, bit for bit: parameters and both moments, over three
+    steps; sizes off the 8-element and the 2^20-element chunk grid, and a tensor whose storage is only 2-byte aligned (the element-wise path)."""
+    sizes = [10007, 8, 1, (1 << 20) + 24, 2048 * 64, 333]
+    base = [_bf(n + 1, seed=40 + i) for i, n in enumerate(sizes)]
+    ps = [b[1:] if i == 1 else b[:-1] for i, b in enumerate(base)]                # tensor 1 starts 2 bytes off a 16-byte boundary
+    gs = [(_bf(n + 1, scale=0.02, seed=60 + i))[1:] if i == 1 else _bf(n, scale=0.02, seed=60 + i) for i, n in enumerate(sizes)]
+    ps = [p.contiguous() if i != 1 else p for i, p in enumerate(ps)]
+    one = [p.clone() for p in ps]; many = [p.clone() for p in ps]
+    if True:                                                                      # keep the odd alignment in both copies
+        buf1, buf2 = torch.empty(sizes[1] + 1, dtype=torch.bfloat16, device="cuda"), torch.empty(sizes[1] + 1, dtype=torch.bfloat16, device="cuda")
+        buf1[1:].copy_(ps[1]); buf2[1:].copy_(ps[1]); one[1], many[1] = buf1[1:], buf2[1:]
+    m1 = [torch.zeros(n, device="cuda") for n in sizes]; v1 = [torch.zeros(n, device="cuda") for n in sizes]
+    m2 = [torch.zeros(n, device="cuda") for n in sizes]; v2 = [torch.zeros(n, device="cuda") for n in sizes]
+    chunks = ops.SumsqPlan(sizes, torch.device("cuda"))
+    tables = ops.AdamMultiPlan(many, gs, m2, v2, torch.device("cuda"))
+    assert tables.matches(many, gs, m2, v2) and not tables.matches(one, gs, m2, v2)
+    for step in range(1, 4):
+        acc = torch.zeros(1, device="cuda")
+        for g in gs:
+            ops.sumsq(g.contiguous(), acc)
+        for p, g, m, v in zip(one, gs, m1, v1):
+            ops.adam_step_(p, g, m, v, acc, 1.0, 1e-3, 0.9, 0.99, 1e-8, 1e-2, step)
+        ops.adam_multi_(tables, chunks, acc, 1.0, 1e-3, 0.9, 0.99, 1e-8, 1e-2, step)
+        for i in range(len(sizes)):
+            assert torch.equal(one[i], many[i]) and torch.equal(m1[i], m2[i]) and torch.equal(v1[i], v2[i]), (step, i)
+    assert not torch.equal(one[0], ps[0])
+
+
 @pytest.mark.parametrize("B,S,Hq,Hkv", [(2, 128, 4, 1), (1, 192, 2, 2), (3, 64, 2, 1), (2, 320, 8, 2)])
 def test_fused_attention_forward_backward(ops, B, S, Hq, Hkv):
     """Fused attention (no S x S tensor) vs an fp32 PyTorch reference with the reference's mask semantics

@@ -245,7 +245,7 @@ def test_rust_bpe_cache_key_is_a_function_of_the_content_not_of_object_identity(
     shared = [([big, big, big], 256 + 1), ([big, 257], 256 + 2)]
     shared = [(seq, tid) for seq, tid in shared]
     shared.append(shared[0])                                           # the same tuple object twice
-    distinct = [([int(str(big)) for _ in seq], int(str(tid))) for seq, tid in shared]
+    distinct = [([int(str(e)) for e in seq], int(str(tid))) for seq, tid in shared]
     assert shared == distinct
     assert marshal.dumps(shared) != marshal.dumps(distinct)            # what the default format did
     assert rust_bpe._content_key(shared) == rust_bpe._content_key(distinct)
