@@ -276,3 +276,77 @@ def segment_ecg(ecg_data, text_data, seg_len):
     seg = ecg_data[..., : num_segments * seg_len, :]
     seg = seg.reshape(*ecg_data.shape[:-2], num_segments, seg_len, ecg_data.shape[-1])
     return seg, [text_data] * num_segments
+
+
+# ---- the dataset-preparation driver around the conditioning (preprocess_utils.py:168-226, preprocess/preprocess_ecg.py:28-48) ------------------------------------
+# The reference runs process_instance per record in a process pool, twice: once to gather the global statistics Q1 consumes (compute_global_stats), once to write
+# the segment files ECGTokenDataset reads (process_and_save_instance).  Here a batch of raw records is conditioned once on the device (condition_records); these two
+# functions turn its output into the same statistics dict and the same files.  Reading the wfdb records stays with the caller.
+
+def compute_global_stats(segment_batches, sample_size=100000, skipped=0):
+    """preprocess_utils.py:168-214 over conditioned segments.  `segment_batches`: an iterable of arrays / tensors [records, segments, seg_len, leads] (what
+    condition_records returns, any device; records the reference would skip are simply absent, their number goes into `skipped`).  Global minimum and maximum are
+    reduced where the data lives; the percentile sample is the reference's: segments in order, each contributing `np.random.choice(seg.size, k, replace=False)` of
+    its values until `sample_size` are collected (whole segments but the last) -- the same calls on numpy's global generator, so `np.random.seed` reproduces the
+    reference's draw -- and `np.percentile(samples, 1 / 99)` on the host (100 000 doubles).  Returns the dict the reference saves as `{data}_dataset_stats.npy`."""
+    global_min, global_max = np.inf, -np.inf
+    samples, collected = [], 0
+    for batch in segment_batches:
+        t = batch if torch.is_tensor(batch) else torch.as_tensor(np.asarray(batch))
+        if t.dim() != 4:
+            raise ValueError("compute_global_stats: batches of [records, segments, seg_len, leads]")
+        if t.numel() == 0:
+            continue
+        lo, hi = torch.aminmax(t)
+        global_min, global_max = min(global_min, float(lo)), max(global_max, float(hi))
+        if collected < sample_size:
+            flat = t.reshape(-1, t.shape[2], t.shape[3])                     # instances in order, their segments in order (the reference's two loops)
+            need = -(-(sample_size - collected) // (t.shape[2] * t.shape[3]))
+            host = flat[:need].cpu().numpy()                                 # only the segments the sample can still draw from
+            for seg in host:
+                if collected >= sample_size:
+                    break
+                k = min(sample_size - collected, seg.size)
+                idx = np.random.choice(seg.size, k, replace=False)           # preprocess_utils.py:200
+                samples.append(seg.flat[idx])
+                collected += k
+    if not samples:
+        raise ValueError("compute_global_stats: no segments")
+    samples = np.concatenate(samples)
+    return {"global_min": global_min, "global_max": global_max, "percentile_1": np.percentile(samples, 1), "percentile_99": np.percentile(samples, 99),
+            "skipped_instances": int(skipped)}
+
+
+def save_dataset_stats(path, stats):
+    """preprocess/preprocess_ecg.py:36: the dict as a pickled .npy -- the file `--percentiles` names and ECGTokenDataset opens (data_loader.py:47)."""
+    np.save(path, stats)
+
+
+def process_and_save_batch(segments, texts, first_index, split_name, data, seg_len, root="./data", kept=None):
+    """process_and_save_instance (preprocess_utils.py:216-226) for a conditioned batch: record r of `segments` [records, n_seg, seg_len, leads] is instance
+    first_index + r of the split (with `kept`, the mask condition_records returns, r counts the KEPT records and the instance index skips the dropped ones, as
+    the reference's enumeration does); segment j goes to {root}/{data}_{seg_len}/ecg/{split}/ecg_{i}_{j}.npy as the (leads, seg_len) transpose the reference
+    saves, its text to .../text/{split}/text_{i}_{j}.json.  `texts`: one entry per ORIGINAL instance (the conversation / [type, question, answer] list).
+    Returns the instance indices written."""
+    import json
+    import os
+    ecg_dir = os.path.join(root, f"{data}_{seg_len}", "ecg", split_name)
+    text_dir = os.path.join(root, f"{data}_{seg_len}", "text", split_name)
+    os.makedirs(ecg_dir, exist_ok=True)
+    os.makedirs(text_dir, exist_ok=True)
+    seg = segments.cpu().numpy() if torch.is_tensor(segments) else np.asarray(segments)
+    if seg.ndim != 4 or seg.shape[2] != seg_len:
+        raise ValueError("process_and_save_batch: segments [records, n_seg, seg_len, leads]")
+    keep = np.ones(seg.shape[0], dtype=bool) if kept is None else np.asarray(kept.cpu() if torch.is_tensor(kept) else kept, dtype=bool)
+    originals = np.flatnonzero(keep)
+    if originals.size != seg.shape[0]:
+        raise ValueError("process_and_save_batch: `kept` must mark exactly the records present in `segments`")
+    written = []
+    for r, orig in enumerate(originals):
+        i = first_index + int(orig)
+        for j in range(seg.shape[1]):
+            np.save(os.path.join(ecg_dir, f"ecg_{i}_{j}.npy"), seg[r, j, :, :].T)          # shape (leads, seg_len), as preprocess_utils.py:221-223 saves it
+            with open(os.path.join(text_dir, f"text_{i}_{j}.json"), "w") as f:
+                json.dump(texts[int(orig)], f)
+        written.append(i)
+    return written

@@ -268,6 +268,45 @@ def test_lora_adapters_vs_oracle():
     assert torch.isfinite(out.loss)
 
 
+def test_lora_state_dict_has_pefts_documented_key_set_and_shapes():
+    """Checkpoint interchange, structurally: with `get_peft_model(llm, LoraConfig(r=16, lora_alpha=32, target_modules=[q, v, k, o, gate, down, up]_proj, bias="none"))`
+    (ecg_byte/main.py:131-155) peft 0.13's PeftModelForCausalLM.state_dict() holds, as its documentation lays out, every base parameter under `base_model.model.`,
+    the wrapped projections' own weights one level down under `.base_layer.`, and per wrapped Linear two adapter matrices `lora_A.default.weight` [r, in_features] and
+    `lora_B.default.weight` [out_features, r] (adapter name "default"; no bias entries; embeddings, norms and the tied head are not wrapped).  peft itself is not in
+    the tree (parity unpinned: its forward semantics are restated, oracle/llama_ref.py); this pins the names and shapes a reference checkpoint would be read by."""
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    L, H, I, Hq, Hkv, D, V, r = 2, 256, 448, 4, 2, 64, 515, 16
+    cfg = DecoderConfig(vocab_size=V, hidden_size=H, intermediate_size=I, num_hidden_layers=L, num_attention_heads=Hq, num_key_value_heads=Hkv,
+                        rms_norm_eps=1e-6, rope_theta=10000.0, rope_scaling=None, pad_token_id=V - 1)
+    m = HipCausalLM(cfg)
+    m.enable_lora(r=r, alpha=32, dropout=0.05)
+    want = {"base_model.model.model.embed_tokens.weight": (V, H), "base_model.model.model.norm.weight": (H,), "base_model.model.lm_head.weight": (V, H)}
+    proj = {"self_attn.q_proj": (Hq * D, H), "self_attn.k_proj": (Hkv * D, H), "self_attn.v_proj": (Hkv * D, H), "self_attn.o_proj": (H, Hq * D),
+            "mlp.gate_proj": (I, H), "mlp.up_proj": (I, H), "mlp.down_proj": (H, I)}
+    for i in range(L):
+        pre = f"base_model.model.model.layers.{i}."
+        want[pre + "input_layernorm.weight"] = (H,)
+        want[pre + "post_attention_layernorm.weight"] = (H,)
+        for name, (out_f, in_f) in proj.items():
+            want[pre + name + ".base_layer.weight"] = (out_f, in_f)
+            want[pre + name + ".lora_A.default.weight"] = (r, in_f)
+            want[pre + name + ".lora_B.default.weight"] = (out_f, r)
+    sd = m.state_dict()
+    assert set(sd) == set(want), (sorted(set(sd) ^ set(want))[:8])
+    for k, shape in want.items():
+        assert tuple(sd[k].shape) == shape, (k, tuple(sd[k].shape), shape)
+    assert all(v.dtype == torch.bfloat16 for v in sd.values())
+    assert not any("bias" in k for k in sd)                               # bias="none"
+    # peft's initialisation: lora_B zero (the adapted model starts as the base model), lora_A not
+    assert all(float(sd[k].float().abs().max()) == 0.0 for k in sd if "lora_B" in k) and all(float(sd[k].float().abs().max()) > 0.0 for k in sd if "lora_A" in k)
+    # and back: a peft-spelt checkpoint loads into a fresh adapted model, adapters included
+    m2 = HipCausalLM(cfg); m2.enable_lora(r=r, alpha=32, dropout=0.05)
+    sd2 = {k: (v + 0.125 if "lora_B" in k else v) for k, v in sd.items()}
+    m2.load_state_dict(sd2)
+    back = m2.state_dict()
+    assert all(torch.equal(back[k], sd2[k]) for k in sd2)
+
+
 def test_lora_dropout_masks_independent_per_module_and_replayed_in_backward():
     """peft draws one dropout mask PER MODULE (q, k and v are three LoraLayers over the same input): the stacked site's three blocks
     must see three different masks of x at the configured rate, and the backward must apply exactly the masks the forward drew
