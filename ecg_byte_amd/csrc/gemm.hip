@@ -2041,7 +2041,7 @@ namespace ecgb {
 bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long long ldb, const void *c_dev, long long ldc, int M, int N, int K);
 int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream,
                    int epi, void *h_dev, long long ldh, const void *a2_dev, long long lda2, const void *b2_dev, long long ldb2, int K2,
-                   const float *rope_cos, const float *rope_sin, int rope_cols, int lay);
+                   const float *rope_cos, const float *rope_sin, int rope_cols, int lay, const void *gu_dev = nullptr, long long ldgu = 0);
 }
 namespace { int g_gemm_w4 = 1; }
 extern "C" int ecgb_set_gemm_w4(int on)
@@ -2374,6 +2374,11 @@ extern "C" int ecgb_gemm_nn_glu_bwd_bf16(const void *dy_dev, long long lddy, con
         ecgb::set_error("ecgb_gemm_nn_glu_bwd_bf16: K % 64, M % 256, inter % 256, 16-byte aligned operands with strides % 8 required");
         return ECGB_ERR_UNSUPPORTED;
     }
+    // whole tiles and a long enough contraction per workgroup: the four-wave kernel on the NN layout with the same epilogue (the same bits; round 4).  Persistent: not
+    // while a gradient exchange may hold CUs (g_nn_persist).
+    if (g_gemm_w4 && g_nn_persist && g_gemm_tile == 0 && ((long long)15 * ldw + 256) * 2 <= 0xFFFFFFFFll && ecgb::gemm_w4_applies(dy_dev, lddy, w_dev, ldw, d_gate_up_dev, ldd, M, inter, K))
+        return ecgb::gemm_w4_launch(dy_dev, lddy, w_dev, ldw, d_gate_up_dev, ldd, M, inter, K, 1.0f, stream, gelu_tanh ? 5 : 4, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1,
+                                    gate_up_dev, ldgu);
     GemmArgs G{};
     G.group_m = g_gemm_group_m;
     G.A = (const unsigned short *)dy_dev; G.B = (const unsigned short *)w_dev; G.C = d_gate_up_dev;

@@ -45,9 +45,11 @@ struct W4Args {
     int K2;
     const float *rope_cos, *rope_sin;   // EPI 3: columns below rope_cols are heads of 64 that leave rotated (RoPE forward), row t with row t of the [M, 32] fp32 tables
     int rope_cols;
-    unsigned short *H;      // GLU epilogue (EPI != 0): act(gate) * up [M, glu_I]; B is [2 * glu_I, K], gate rows then up rows; C (gate|up, [M, 2 * glu_I]) may be null
+    unsigned short *H;      // GLU epilogue (EPI 1 / 2): act(gate) * up [M, glu_I]; B is [2 * glu_I, K], gate rows then up rows; C (gate|up, [M, 2 * glu_I]) may be null
     long long ldh;
     int glu_I;
+    const unsigned short *GU;   // GLU BACKWARD epilogue (EPI 4 / 5, NN layout): the forward's gate|up [M, 2 * glu_I]; the product [M, glu_I] is d(act(gate) * up) and
+    long long ldgu;             // C [M, 2 * glu_I] receives d gate | d up (ecgb_glu_bwd's arithmetic on the bf16-rounded product)
 };
 
 __device__ __forceinline__ unsigned pack2(float a, float b)
@@ -98,7 +100,8 @@ template <int EPI, bool CAT, int LAY = 0, int SCH = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_w4_kernel(W4Args G)
 {
     constexpr bool NN = LAY >= 1, TA = LAY == 2;              // B, A stored with the contraction index as the row
-    static_assert(!NN || (EPI == 0 && !CAT), "the NN / TN forms are the plain product");
+    static_assert(!NN || ((EPI == 0 || EPI >= 4) && !CAT), "the NN / TN forms are the plain product (NN: or the GLU backward behind it)");
+    static_assert(EPI < 4 || LAY == 1, "the GLU backward epilogue belongs to the down projection's input gradient: NN layout");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (!NN) {
             const unsigned step = (unsigned)(ldb_ * 16);
             voffB[0] = lrow * (unsigned)(ldb_ * 2) + ch0; voffB[1] = lrow * (unsigned)(ldb_ * 2) + step + ch1;
-            if constexpr (EPI == 0 || EPI == 3) { pairB1 = 2 * step; pairB2 = 4 * step; pairB3 = 6 * step; }
+            if constexpr (EPI == 0 || EPI >= 3) { pairB1 = 2 * step; pairB2 = 4 * step; pairB3 = 6 * step; }
             else {
                 // GLU: tile row r = (wave * 8 + i) * 8 + (L >> 3) is weight row 16 * (r >> 5) + (r & 15) (+ glu_I: an up row) -- pieces 0, 1: gate rows 0 .. 15 of the
                 // wave's 32, pieces 2, 3 the up rows of the same outputs, 4, 5 gate rows 16 .. 31, 6, 7 their up rows
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto stage_first = [&]() {                                                  // start of round st_it's tile
         int tm, tn;
         tile_rc(G, tile_of_round(w, st_it, nwg), tm, tn);
-        const long long ra = (long long)tm * 256 + wave * 64, rb = (EPI == 0 || EPI == 3) ? (long long)tn * 256 + wave * 64 : (long long)tn * 128 + wave * 32;
+        const long long ra = (long long)tm * 256 + wave * 64, rb = (EPI == 0 || EPI >= 3) ? (long long)tn * 256 + wave * 64 : (long long)tn * 128 + wave * 32;
         set_base(srdA, TA ? reinterpret_cast<const unsigned char *>(G.A + (long long)wave * 16 * G.lda + (long long)tm * 256)
                           : reinterpret_cast<const unsigned char *>(G.A + ra * G.lda));
         set_base(srdB, NN ? reinterpret_cast<const unsigned char *>(G.B + (long long)wave * 16 * G.ldb + (long long)tn * 256)       // this wave's 16 contraction rows of K-tile 0, the tile's columns
@@ -443,6 +446,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
                 asm volatile("" ::: "memory");
             }
+        } else if constexpr (EPI >= 4) {
+            // The down projection's input gradient with the GLU backward behind it (full fine-tune): the tile is d = d(act(gate) * up), rounded to bf16 as the plain
+            // kernel stores it; on the way out a lane takes gate and up of its eight columns and writes d gate = d * up * act'(gate) and d up = d * act(gate) --
+            // ecgb_glu_bwd's arithmetic, the same bits as the two kernels, one write and one read of [M, glu_I] less.
+            auto lo_f = [](unsigned x) { return __uint_as_float(x << 16); };
+            auto hi_f = [](unsigned x) { return __uint_as_float(x & 0xFFFF0000u); };
+            constexpr bool GELU = EPI == 5;
+            const int rr = lane >> 4, cc = lane & 15;
+            const long long col = (long long)tn * 256 + wc * 128 + cc * 8, row0 = (long long)tm * 256 + wr * 128 + rr;
+            unsigned short *cdst = G.C + row0 * G.ldc + col;
+            const unsigned short *gsrc = G.GU + row0 * G.ldgu + col;
+            const long long gI = G.glu_I;
+            // gate / up of MFMA rows i + 1 and i + 2 are in flight while row i is worked on (a ring of three register sets: one row ahead the tile's store was a chain
+            // of memory latencies, 14 us per tile with a wave alone on its SIMD)
+            constexpr int AHEAD = 2;
+            u4 gq[AHEAD + 1][4], uq[AHEAD + 1][4];
+            auto fetch = [&](int row16, int slot) {
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    gq[slot][ps] = *reinterpret_cast<const u4 *>(gsrc + (long long)(row16 * 16 + ps * 4) * G.ldgu);
+                    uq[slot][ps] = *reinterpret_cast<const u4 *>(gsrc + (long long)(row16 * 16 + ps * 4) * G.ldgu + gI);
+                }
+            };
+#pragma unroll
+            for (int k = 0; k < AHEAD; ++k) fetch(k, k);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i + AHEAD < 8) fetch(i + AHEAD, (i + AHEAD) % (AHEAD + 1));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    u2 v;
+                    v[0] = pack2(acc[i][j][0] * alpha, acc[i][j][1] * alpha);
+                    v[1] = pack2(acc[i][j][2] * alpha, acc[i][j][3] * alpha);
+                    const int c = j * 2 + (lq >> 1);
+                    *reinterpret_cast<u2 *>(stg + lm * 256 + ((c ^ lm) << 4) + (lq & 1) * 8) = v;
+                    acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int slot = i % (AHEAD + 1);
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int r = ps * 4 + rr;
+                    const u4 d = *reinterpret_cast<const u4 *>(stg + r * 256 + ((cc ^ r) << 4));
+                    u4 og, ou;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const float g0 = lo_f(gq[slot][ps][x]), g1 = hi_f(gq[slot][ps][x]), u0 = lo_f(uq[slot][ps][x]), u1 = hi_f(uq[slot][ps][x]), d0 = lo_f(d[x]), d1 = hi_f(d[x]);
+                        og[x] = pack2(d0 * u0 * ecgb::glu_act_grad<GELU>(g0), d1 * u1 * ecgb::glu_act_grad<GELU>(g1));
+                        ou[x] = pack2(d0 * ecgb::glu_act<GELU>(g0), d1 * ecgb::glu_act<GELU>(g1));
+                    }
+                    unsigned short *o = cdst + (long long)(i * 16 + ps * 4) * G.ldc;
+                    *reinterpret_cast<u4 *>(o) = og;
+                    *reinterpret_cast<u4 *>(o + gI) = ou;
+                }
+                asm volatile("" ::: "memory");
+            }
         } else if constexpr (EPI == 3) {
             // the q|k|v projection with RoPE's forward in the epilogue (modeling_llama.py:151-176: q_embed = q * cos + rotate_half(q) * sin, in the activation dtype).  Staged as
             // EPI 0; on the way out a lane takes its own 16-byte chunk and the chunk 32 columns away in the same head of 64, and writes
@@ -572,19 +631,20 @@ bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long l
 // epi 0: C [M, N] plain.  epi 1 / 2 (SiLU / tanh-GELU): N = 2 * inter, B = [gate rows; up rows], H [M, inter] = act(gate) * up, C (gate|up) may be null.
 int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream,
                    int epi, void *h_dev, long long ldh, const void *a2_dev, long long lda2, const void *b2_dev, long long ldb2, int K2,
-                   const float *rope_cos, const float *rope_sin, int rope_cols, int lay)
+                   const float *rope_cos, const float *rope_sin, int rope_cols, int lay, const void *gu_dev, long long ldgu)
 {
     W4Args G;
+    G.GU = (const unsigned short *)gu_dev; G.ldgu = ldgu;
     G.rope_cos = rope_cos; G.rope_sin = rope_sin; G.rope_cols = rope_cols;
     G.A2 = (const unsigned short *)a2_dev; G.B2 = (const unsigned short *)b2_dev; G.lda2 = lda2; G.ldb2 = ldb2; G.K2 = K2 > 0 ? K2 : 0;
     G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = (unsigned short *)c_dev;
     G.lda = lda; G.ldb = ldb; G.ldc = ldc; G.M = M; G.N = N; G.K = K; G.tiles_m = M / 256; G.tiles_n = N / 256; G.alpha = alpha; G.group_m = g_w4_group_m;
-    G.H = (unsigned short *)h_dev; G.ldh = ldh; G.glu_I = N / 2;
-    const int which = lay ? 7 + lay : epi + (G.K2 ? 4 : 0);
+    G.H = (unsigned short *)h_dev; G.ldh = ldh; G.glu_I = epi >= 4 ? N : N / 2;
+    const int which = epi >= 4 ? 6 + epi : lay ? 7 + lay : epi + (G.K2 ? 4 : 0);      // (10, 11: the NN product with the GLU backward behind it)
 #define W4_KERNS(S) {gemm_nt_w4_kernel<0, false, 0, S>, gemm_nt_w4_kernel<1, false, 0, S>, gemm_nt_w4_kernel<2, false, 0, S>, gemm_nt_w4_kernel<3, false, 0, S>, \
                      gemm_nt_w4_kernel<0, true, 0, S>, gemm_nt_w4_kernel<1, true, 0, S>, gemm_nt_w4_kernel<2, true, 0, S>, gemm_nt_w4_kernel<3, true, 0, S>,     \
-                     gemm_nt_w4_kernel<0, false, 1, S>, gemm_nt_w4_kernel<0, false, 2, S>}
-    void (*const kerns[2][10])(W4Args) = {W4_KERNS(0), W4_KERNS(1)};
+                     gemm_nt_w4_kernel<0, false, 1, S>, gemm_nt_w4_kernel<0, false, 2, S>, gemm_nt_w4_kernel<4, false, 1, S>, gemm_nt_w4_kernel<5, false, 1, S>}
+    void (*const kerns[2][12])(W4Args) = {W4_KERNS(0), W4_KERNS(1)};
 #undef W4_KERNS
     void (*kern)(W4Args) = kerns[g_w4_sched ? 1 : 0][which];
     if (g_w4_sched >= 16 && which == 0) {                                  // timing-only diagnostics of the plain NT kernel
@@ -635,7 +695,7 @@ extern "C" int ecgb_gemm_nt_w4_bf16(const void *a_dev, long long lda, const void
         ecgb::set_error("ecgb_gemm_nt_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
         return ECGB_ERR_UNSUPPORTED;
     }
-    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 0);
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, 0);
 }
 
 // The q|k|v projection with RoPE's forward in the epilogue: C = alpha * (A B^T [+ A2 B2^T]), then every head of 64 columns below rope_cols rotated with row t of the
@@ -657,7 +717,7 @@ extern "C" int ecgb_gemm_nt_bf16_rope(const void *a_dev, long long lda, const vo
         ecgb::set_error("ecgb_gemm_nt_bf16_rope: whole 256x256 tiles (one per CU at least), K % 64, 16-byte aligned operands required");
         return ECGB_ERR_UNSUPPORTED;
     }
-    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 3, nullptr, 0, a2_dev, lda2, b2_dev, ldb2, K2 > 0 ? K2 : 0, rope_cos_dev, rope_sin_dev, rope_cols, 0);
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 3, nullptr, 0, a2_dev, lda2, b2_dev, ldb2, K2 > 0 ? K2 : 0, rope_cos_dev, rope_sin_dev, rope_cols, 0, nullptr, 0);
 }
 
 // C = alpha * A . B with B [K, N] row-major on the four-wave kernel (tests, A/B; ecgb_gemm_nn_bf16 dispatches here for long contractions): whole tiles only.
@@ -671,7 +731,7 @@ extern "C" int ecgb_gemm_nn_w4_bf16(const void *a_dev, long long lda, const void
         ecgb::set_error("ecgb_gemm_nn_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
         return ECGB_ERR_UNSUPPORTED;
     }
-    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1);
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1, nullptr, 0);
 }
 
 // C[M, N] = alpha * A^T . B with A [K, M] and B [K, N] row-major (ecgb_gemm_tn_bf16's product: C = its [N, K] output, K here = its M) on the four-wave kernel, by name:
@@ -686,5 +746,5 @@ extern "C" int ecgb_gemm_tn_w4_bf16(const void *a_dev, long long lda, const void
         ecgb::set_error("ecgb_gemm_tn_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
         return ECGB_ERR_UNSUPPORTED;
     }
-    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 2);
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 2, nullptr, 0);
 }

@@ -522,10 +522,11 @@ def test_gemm_nt_persistent_tile_loop_is_bitwise_the_one_tile_kernel(ops, M, N, 
 
 
 @pytest.mark.parametrize("gelu_tanh", [False, True])
-@pytest.mark.parametrize("M,I,K", [(4096, 8192, 2048), (16384, 3072, 512), (8192, 2048, 192)])
+@pytest.mark.parametrize("M,I,K", [(4096, 8192, 2048), (16384, 3072, 512), (8192, 2048, 192), (8192, 8192, 2048)])
 def test_gemm_nn_with_glu_backward_is_bitwise_the_two_kernels(ops, M, I, K, gelu_tanh):
     """The down projection's input gradient with the GLU backward in the GEMM's epilogue (full fine-tune): d(gate|up) must be the bits of
-    gemm_nn followed by glu_bwd, on every launch; shapes outside whole 256x256 tiles are refused (the model takes the two kernels there)."""
+    gemm_nn followed by glu_bwd, on every launch; shapes outside whole 256x256 tiles are refused (the model takes the two kernels there).  The last shape is one
+    the entry point sends to the four-wave kernel (128 K-tiles per workgroup), the others stay on the eight-wave kernels: both against the two-kernel bits."""
     assert ops.nn_glu_bwd_eligible(32768, 8192, 2048) and not ops.nn_glu_bwd_eligible(1000, 8192, 2048) and not ops.nn_glu_bwd_eligible(4096, 8320, 2048)
     dy, w = _bf(M, K, seed=101), _bf(K, I, scale=K ** -0.5, seed=102)
     gu = _bf(M, 2 * I, seed=103)
