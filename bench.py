@@ -345,13 +345,17 @@ def bench_preprocess(dev, n_records=4096):
     # spline: tridiagonal forward sweep, then back substitution and evaluation in one (36 bytes per sample) = 2.25; every finite test is in the kernels
     sweeps = {"filter_chain": 8.0, "wavelet": 1.0, "resample": 2.25}
     traffic = sum(sweeps.values()) * 16 * samples
+    ach = alg / (ms * 1e-3) / 1e9
     return {"workload": f"{n_records} raw records of 5000 x 12 float64: notch 50/60 Hz, band-pass, high-pass (filtfilt), db6 wavelet shrinkage, cubic resample to 250 Hz, 1250-sample segments",
-            "ms": ms, "records_per_s": n_records / (ms * 1e-3), "GB/s": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "stage_traffic": {"sweeps_of_16_bytes_per_sample": sweeps, "bytes": traffic, "GB/s": traffic / (ms * 1e-3) / 1e9,
-                              "frac_of_hbm_peak": traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "bound": "filter chain and spline: the HBM traffic of their sweeps (every filtfilt writes its forward result and reads it back reversed: 31.8 GB at ~4.8 TB/s, "
-                     "8.8 GB at ~3.8 TB/s); wavelet: vector issue (0.7 ms of float64 arithmetic at full rate inside 2.65 ms; index arithmetic and the median's "
-                     "comparisons are the rest); profiles/r03/conditioning_pmc.txt, DESIGN.md section 9",
+            "ms": ms, "records_per_s": n_records / (ms * 1e-3),
+            # the roofline of the stage: ALGORITHMIC bytes (480 KB read + 240 KB written per record) over the measured time against the HBM peak
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": alg},
+            # what the kernels actually move (NOT a roofline: every filtfilt pass is a sweep through HBM scratch because scipy's recursion is kept sample by sample,
+            # bit for bit) -- `x_algorithmic` is the waste factor
+            "implementation_traffic": {"sweeps_of_16_bytes_per_sample": sweeps, "bytes": traffic, "GB/s": traffic / (ms * 1e-3) / 1e9, "x_algorithmic": traffic / alg},
+            "bound": "the filter chain's eight sweeps through HBM scratch (31.8 GB at ~4.8 TB/s): the recursion is scipy.signal.filtfilt(b, a)'s loop bit for bit, one lane per "
+                     "sequence; its block-parallel form (a scan of block states) is numerically unusable in scipy's direct-form coordinates -- A^79 has entries of 5e5 -- "
+                     "and was rejected (scripts/experiments/r04_filtfilt_scan.hip.txt); wavelet: vector issue; DESIGN.md section 9",
             "segments_out": list(out.shape)}
 
 
