@@ -359,11 +359,11 @@ def bench_preprocess(dev, n_records=4096):
             "segments_out": list(out.shape)}
 
 
-def mfma_busy_from_profile():
+def mfma_busy_from_profile(name="train_pmc.json"):
     """Per-kernel MFMA-pipe busy fraction and held clock of the train step's GEMM / attention kernels from the committed counter passes
     (profiles/r*/train_pmc.json: SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over SQ_BUSY_CYCLES / 32 shader engines).  Counters need their own rocprofv3
     passes, so the figures are NOT measured by the run that prints them; `source` names the profile."""
-    f = _latest_profile("train_pmc.json")
+    f = _latest_profile(name)
     if not f:
         return None
     with open(f) as fh:
@@ -789,6 +789,9 @@ def main():
         mb = mfma_busy_from_profile()
         if mb is not None:
             train["roofline"]["mfma_busy"] = mb
+        mbl = mfma_busy_from_profile("train_pmc_lora.json")                  # the LoRA leg's kernels (the pair forms of the GEMMs, the adapter GEMMs), counters of their own passes
+        if mbl is not None and "lora_r16" in train:
+            train["lora_r16"]["roofline"]["mfma_busy"] = mbl
     c5 = None
     if rank == 0 and world == 1 and not args.no_c5 and not args.no_train:
         c5 = bench_c5(args, dev)
