@@ -656,6 +656,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects of the line (batch sweep, tokenizer trainer, offline conditioning, full-logits leg)")
     ap.add_argument("--lora", action="store_true", help="train LoRA adapters (r16, alpha 32, dropout 0.05; frozen base) as the reference's script does")
     args = ap.parse_args()
+    # --gpus N must be what the launcher started: checked before anything is generated or initialised (exit 2, no line); the process group's own size is checked again below
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: start it as python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}\n")
+        sys.exit(2)
 
     # ONE line on stdout: libraries print there too (RCCL's version banner at the first collective under torch.distributed.run lands on file descriptor 1, in front of
     # the line).  Everything this process and its children write to stdout goes to stderr from here on; the JSON line is written to the real stdout at the end.

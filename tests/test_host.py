@@ -335,3 +335,18 @@ def test_inline_asm_lds_reads_are_not_used_before_their_wait():
     hits = chk.check(bad)
     assert len(hits) == 1 and hits[0][3] == [10, 11]
     assert chk.main() == 0
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    """bench.py --gpus N started with another WORLD_SIZE (a plain process asked for 2 GPUs, or a 2-rank launcher with --gpus 1) exits 2 before it generates or
+    initialises anything and prints no JSON line: a scaling record cannot be mislabelled.  (The process group's size and, under RCCL, one device per rank are
+    checked again after initialisation: tests/test_gpu_pipeline.py runs the two-rank path.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and r.stdout.strip() == "" and "WORLD_SIZE" in r.stderr
+    env["WORLD_SIZE"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and r.stdout.strip() == ""
