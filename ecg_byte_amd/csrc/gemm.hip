@@ -2041,7 +2041,8 @@ namespace ecgb {
 bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long long ldb, const void *c_dev, long long ldc, int M, int N, int K);
 int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream,
                    int epi, void *h_dev, long long ldh, const void *a2_dev, long long lda2, const void *b2_dev, long long ldb2, int K2,
-                   const float *rope_cos, const float *rope_sin, int rope_cols, int lay, const void *gu_dev = nullptr, long long ldgu = 0);
+                   const float *rope_cos, const float *rope_sin, int rope_cols, int lay, const void *gu_dev = nullptr, long long ldgu = 0,
+                   const void *ldt_dev = nullptr, const void *lat_dev = nullptr, float lscale = 0.f, unsigned lthr = 0, unsigned lseed = 0);
 }
 namespace { int g_gemm_w4 = 1; }
 extern "C" int ecgb_set_gemm_w4(int on)
@@ -2401,6 +2402,30 @@ extern "C" int ecgb_gemm_nn_glu_bwd_bf16(const void *dy_dev, long long lddy, con
     }
     if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nn_kernel (GLU backward): ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
     return ECGB_OK;
+}
+
+// The same on the down-projection site of a LoRA fine-tune: the adapter's share of the input gradient joins the product before the GLU backward,
+//   d(gate|up) = glu_bwd(gate|up, bf16(dY . W) + scale / (1 - p) * mask . (dt A)),   dt [M, 64] = dY . B_lora, A^T [inter, 64] (rank 16 in columns 0..15),
+// the forward's dropout mask replayed from (seed, p) as ecgb_lora_down drew it: ecgb_gemm_nn_bf16 + ecgb_lora_dx_glu in one launch, the same bits, d(act(gate) * up)
+// never written.  Four-wave kernel only: ECGB_ERR_UNSUPPORTED where it does not take the shape (the caller runs the two kernels).
+extern "C" int ecgb_gemm_nn_glu_bwd_lora_bf16(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *gate_up_dev, long long ldgu,
+                                              const void *dt_dev, const void *at_dev, void *d_gate_up_dev, long long ldd, int M, int inter, int K, int gelu_tanh,
+                                              float scale, float p, uint64_t seed, void *stream)
+{
+    if (!dy_dev || !w_dev || !gate_up_dev || !dt_dev || !at_dev || !d_gate_up_dev || M <= 0 || inter <= 0 || K <= 0 || !(p >= 0.f && p < 1.f)) {
+        ecgb::set_error("ecgb_gemm_nn_glu_bwd_lora_bf16: bad argument");
+        return ECGB_ERR_INVALID;
+    }
+    if (K % BK || M % 256 || inter % 256 || lddy % 8 || ldw % 8 || ldgu % 8 || ldd % 8 || ((uintptr_t)dy_dev & 15) || ((uintptr_t)w_dev & 15) || ((uintptr_t)gate_up_dev & 15) ||
+        ((uintptr_t)d_gate_up_dev & 15) || ((uintptr_t)dt_dev & 15) || ((uintptr_t)at_dev & 15) || (long long)M * inter > 0xFFFFFFFFll ||
+        !(g_gemm_w4 && g_nn_persist && g_gemm_tile == 0 && ((long long)15 * ldw + 256) * 2 <= 0xFFFFFFFFll && ecgb::gemm_w4_applies(dy_dev, lddy, w_dev, ldw, d_gate_up_dev, ldd, M, inter, K))) {
+        ecgb::set_error("ecgb_gemm_nn_glu_bwd_lora_bf16: whole 256x256 tiles with at least the four-wave kernel's share of K-tiles per CU, 16-byte aligned operands");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    const unsigned thr = (unsigned)(p * 65536.0f);                                   // as ecgb_lora_down / ecgb_lora_dx fill them (lora.hip)
+    const float lscale = scale / (1.0f - (float)thr / 65536.0f);
+    return ecgb::gemm_w4_launch(dy_dev, lddy, w_dev, ldw, d_gate_up_dev, ldd, M, inter, K, 1.0f, stream, gelu_tanh ? 7 : 6, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1,
+                                gate_up_dev, ldgu, dt_dev, at_dev, lscale, thr, (unsigned)(seed ^ (seed >> 32)));
 }
 
 #ifdef ECGB_PROFILE

@@ -50,6 +50,9 @@ struct W4Args {
     int glu_I;
     const unsigned short *GU;   // GLU BACKWARD epilogue (EPI 4 / 5, NN layout): the forward's gate|up [M, 2 * glu_I]; the product [M, glu_I] is d(act(gate) * up) and
     long long ldgu;             // C [M, 2 * glu_I] receives d gate | d up (ecgb_glu_bwd's arithmetic on the bf16-rounded product)
+    const unsigned short *LDT, *LAT;   // EPI 6 / 7: the down-projection site's LoRA adapter joins the product before the GLU backward -- dt [M, 64] = dY . B_lora and A_lora^T
+    float lscale;                      // [glu_I, 64] (rank 16 in columns 0..15), alpha / r / (1 - p), and the dropout mask of the forward replayed from (lseed, lthr):
+    unsigned lthr, lseed;              // ecgb_lora_dx_glu's arithmetic on the bf16-rounded product
 };
 
 __device__ __forceinline__ unsigned pack2(float a, float b)
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 {
     constexpr bool NN = LAY >= 1, TA = LAY == 2;              // B, A stored with the contraction index as the row
     static_assert(!NN || ((EPI == 0 || EPI >= 4) && !CAT), "the NN / TN forms are the plain product (NN: or the GLU backward behind it)");
+    static_assert(EPI <= 7, "EPI 0..7");
     static_assert(EPI < 4 || LAY == 1, "the GLU backward epilogue belongs to the down projection's input gradient: NN layout");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -452,15 +456,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // ecgb_glu_bwd's arithmetic, the same bits as the two kernels, one write and one read of [M, glu_I] less.
             auto lo_f = [](unsigned x) { return __uint_as_float(x << 16); };
             auto hi_f = [](unsigned x) { return __uint_as_float(x & 0xFFFF0000u); };
-            constexpr bool GELU = EPI == 5;
+            constexpr bool GELU = (EPI & 1) != 0, LORA = EPI >= 6;
             const int rr = lane >> 4, cc = lane & 15;
             const long long col = (long long)tn * 256 + wc * 128 + cc * 8, row0 = (long long)tm * 256 + wr * 128 + rr;
             unsigned short *cdst = G.C + row0 * G.ldc + col;
             const unsigned short *gsrc = G.GU + row0 * G.ldgu + col;
             const long long gI = G.glu_I;
+            // EPI 6 / 7 (LoRA fine-tune): the adapter's share of the input gradient, scale * mask . (dt A), joins the tile in the accumulators' own layout -- one more MFMA
+            // per 16 x 16 block (operand rows = 16 rows of A^T for the block's columns and 16 rows of dt, rank 16 in k 0..15, the rest zero: lora_dx_kernel's product,
+            // the same k slots), the forward's dropout mask regenerated from the element index, and bf16(bf16(product) + kept * scale) staged instead of bf16(product):
+            // ecgb_lora_dx_glu's bits without the product ever being written (0.64 ms of the layer's backward at [32768, 8192]).
+            bf16x8 atf[LORA ? 8 : 1], dtf[LORA ? 3 : 1];                       // (dt: a ring with gate / up below)
+            const unsigned short *dtp = nullptr;
+            unsigned hrow = 0, hstep = 0;
+            if constexpr (LORA) {
+                const bf16x8 zero = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                const unsigned short *atp = G.LAT + ((long long)tn * 256 + wc * 128 + lm) * 64 + 8 * (lq & 1);
+                dtp = G.LDT + ((long long)tm * 256 + wr * 128 + lm) * 64 + 8 * (lq & 1);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(atp + k * 16 * 64);
+                    atf[k] = lq < 2 ? a : zero;
+                }
+                // hash32(seed, k) = k * 0x9E3779B1 + seed, then the finaliser, k = (row * inter + col) / 2: the product is formed once per lane, a block further is an add
+                hrow = (((unsigned)(tm * 256 + wr * 128 + lm) * (unsigned)G.glu_I + (unsigned)(tn * 256 + wc * 128 + lq * 4)) >> 1) * 0x9E3779B1u + G.lseed;
+                hstep = 8u * (unsigned)G.glu_I * 0x9E3779B1u;
+            }
             // gate / up of MFMA rows i + 1 and i + 2 are in flight while row i is worked on (a ring of three register sets: one row ahead the tile's store was a chain
             // of memory latencies, 14 us per tile with a wave alone on its SIMD)
-            constexpr int AHEAD = 2;
+            constexpr int AHEAD = LORA ? 1 : 2;
             u4 gq[AHEAD + 1][4], uq[AHEAD + 1][4];
             auto fetch = [&](int row16, int slot) {
 #pragma unroll
@@ -468,6 +492,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     gq[slot][ps] = *reinterpret_cast<const u4 *>(gsrc + (long long)(row16 * 16 + ps * 4) * G.ldgu);
                     uq[slot][ps] = *reinterpret_cast<const u4 *>(gsrc + (long long)(row16 * 16 + ps * 4) * G.ldgu + gI);
                 }
+                if constexpr (LORA) dtf[slot] = *reinterpret_cast<const bf16x8 *>(dtp + row16 * 16 * 64);
             };
 #pragma unroll
             for (int k = 0; k < AHEAD; ++k) fetch(k, k);
@@ -479,6 +504,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     u2 v;
                     v[0] = pack2(acc[i][j][0] * alpha, acc[i][j][1] * alpha);
                     v[1] = pack2(acc[i][j][2] * alpha, acc[i][j][3] * alpha);
+                    if constexpr (LORA) {
+                        const bf16x8 dti = lq < 2 ? dtf[i % (AHEAD + 1)] : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                        // D'[col][row]: lane = row lm, regs = columns 4 lq ..  Written out (with the wait states the result needs before a VALU instruction may read it:
+                        // the compiler does not look inside) because the builtin's result was allocated in the accumulation half, all of which the tile holds --
+                        // 32 accumulators went to scratch and back per tile.
+                        f32x4 lo;
+                        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0\n\ts_nop 15\n\ts_nop 3" : "=v"(lo) : "v"(atf[j]), "v"(dti));
+                        float o[4] = {lo_f(v[0]), hi_f(v[0]), lo_f(v[1]), hi_f(v[1])};
+                        const unsigned hb = hrow + (unsigned)i * hstep;
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) {                      // keep_bits<1> of lora.hip: columns 2k, 2k + 1 take the low and the high field of hash32(seed, k)
+                            unsigned u = hb + (unsigned)(j * 8 + (e >> 1)) * 0x9E3779B1u;
+                            u ^= u >> 15; u *= 0x85EBCA77u;
+                            u ^= u >> 13; u *= 0xC2B2AE3Du;
+                            u ^= u >> 16;
+                            // (lora_dx_kernel adds the kept product to 0.f first: a product accumulated from +0 is never -0, the same bits without)
+                            o[e] = o[e] + ((u & 0xFFFFu) >= G.lthr ? lo[e] * G.lscale : 0.f);
+                            o[e + 1] = o[e + 1] + ((u >> 16) >= G.lthr ? lo[e + 1] * G.lscale : 0.f);
+                        }
+                        v[0] = pack2(o[0], o[1]);
+                        v[1] = pack2(o[2], o[3]);
+                    }
                     const int c = j * 2 + (lq >> 1);
                     *reinterpret_cast<u2 *>(stg + lm * 256 + ((c ^ lm) << 4) + (lq & 1) * 8) = v;
                     acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -631,20 +678,23 @@ bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long l
 // epi 0: C [M, N] plain.  epi 1 / 2 (SiLU / tanh-GELU): N = 2 * inter, B = [gate rows; up rows], H [M, inter] = act(gate) * up, C (gate|up) may be null.
 int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream,
                    int epi, void *h_dev, long long ldh, const void *a2_dev, long long lda2, const void *b2_dev, long long ldb2, int K2,
-                   const float *rope_cos, const float *rope_sin, int rope_cols, int lay, const void *gu_dev, long long ldgu)
+                   const float *rope_cos, const float *rope_sin, int rope_cols, int lay, const void *gu_dev, long long ldgu,
+                   const void *ldt_dev = nullptr, const void *lat_dev = nullptr, float lscale = 0.f, unsigned lthr = 0, unsigned lseed = 0)
 {
     W4Args G;
+    G.LDT = (const unsigned short *)ldt_dev; G.LAT = (const unsigned short *)lat_dev; G.lscale = lscale; G.lthr = lthr; G.lseed = lseed;
     G.GU = (const unsigned short *)gu_dev; G.ldgu = ldgu;
     G.rope_cos = rope_cos; G.rope_sin = rope_sin; G.rope_cols = rope_cols;
     G.A2 = (const unsigned short *)a2_dev; G.B2 = (const unsigned short *)b2_dev; G.lda2 = lda2; G.ldb2 = ldb2; G.K2 = K2 > 0 ? K2 : 0;
     G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = (unsigned short *)c_dev;
     G.lda = lda; G.ldb = ldb; G.ldc = ldc; G.M = M; G.N = N; G.K = K; G.tiles_m = M / 256; G.tiles_n = N / 256; G.alpha = alpha; G.group_m = g_w4_group_m;
     G.H = (unsigned short *)h_dev; G.ldh = ldh; G.glu_I = epi >= 4 ? N : N / 2;
-    const int which = epi >= 4 ? 6 + epi : lay ? 7 + lay : epi + (G.K2 ? 4 : 0);      // (10, 11: the NN product with the GLU backward behind it)
+    const int which = epi >= 4 ? 6 + epi : lay ? 7 + lay : epi + (G.K2 ? 4 : 0);      // (10, 11: the NN product with the GLU backward behind it; 12, 13: and the LoRA adapter's share)
 #define W4_KERNS(S) {gemm_nt_w4_kernel<0, false, 0, S>, gemm_nt_w4_kernel<1, false, 0, S>, gemm_nt_w4_kernel<2, false, 0, S>, gemm_nt_w4_kernel<3, false, 0, S>, \
                      gemm_nt_w4_kernel<0, true, 0, S>, gemm_nt_w4_kernel<1, true, 0, S>, gemm_nt_w4_kernel<2, true, 0, S>, gemm_nt_w4_kernel<3, true, 0, S>,     \
-                     gemm_nt_w4_kernel<0, false, 1, S>, gemm_nt_w4_kernel<0, false, 2, S>, gemm_nt_w4_kernel<4, false, 1, S>, gemm_nt_w4_kernel<5, false, 1, S>}
-    void (*const kerns[2][12])(W4Args) = {W4_KERNS(0), W4_KERNS(1)};
+                     gemm_nt_w4_kernel<0, false, 1, S>, gemm_nt_w4_kernel<0, false, 2, S>, gemm_nt_w4_kernel<4, false, 1, S>, gemm_nt_w4_kernel<5, false, 1, S>, \
+                     gemm_nt_w4_kernel<6, false, 1, S>, gemm_nt_w4_kernel<7, false, 1, S>}
+    void (*const kerns[2][14])(W4Args) = {W4_KERNS(0), W4_KERNS(1)};
 #undef W4_KERNS
     void (*kern)(W4Args) = kerns[g_w4_sched ? 1 : 0][which];
     if (g_w4_sched >= 16 && which == 0) {                                  // timing-only diagnostics of the plain NT kernel
@@ -695,7 +745,7 @@ extern "C" int ecgb_gemm_nt_w4_bf16(const void *a_dev, long long lda, const void
         ecgb::set_error("ecgb_gemm_nt_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
         return ECGB_ERR_UNSUPPORTED;
     }
-    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, 0);
+    return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0.f, 0, 0);
 }
 
 // The q|k|v projection with RoPE's forward in the epilogue: C = alpha * (A B^T [+ A2 B2^T]), then every head of 64 columns below rope_cols rotated with row t of the

@@ -73,11 +73,17 @@ struct LoraArgs {
     unsigned seed;
 };
 
-// the masks of one element: bit f = field f keeps it
+// the masks of one element: bit f = field f keeps it.  A site with ONE module (o, down: NF 1) spends a hash on an element PAIR -- elements 2k and 2k + 1 take the low
+// and the high field of hash32(seed, k): half the integer work where the mask is replayed (the backward kernels, and the down-projection's input-gradient GEMM
+// whose epilogue regenerates it with one wave per SIMD: gemm_w4.hip EPI 6 / 7 restates this rule).
 template <int NF>
 __device__ __forceinline__ unsigned keep_bits(const LoraArgs &L, unsigned idx)
 {
     if (L.thr == 0) return 0xFu;
+    if constexpr (NF == 1) {
+        const unsigned h = hash32(L.seed, idx >> 1);
+        return ((idx & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= L.thr ? 1u : 0u;
+    }
     const unsigned h0 = hash32(L.seed, idx);
     unsigned k = ((h0 & 0xFFFFu) >= L.thr ? 1u : 0u) | ((h0 >> 16) >= L.thr ? 2u : 0u);
     if constexpr (NF > 2) {
@@ -85,6 +91,23 @@ __device__ __forceinline__ unsigned keep_bits(const LoraArgs &L, unsigned idx)
         k |= ((h1 & 0xFFFFu) >= L.thr ? 4u : 0u) | ((h1 >> 16) >= L.thr ? 8u : 0u);
     }
     return k;
+}
+
+// keep_bits of N consecutive elements from an EVEN index (NF 1: one hash per pair)
+template <int NF, int N>
+__device__ __forceinline__ void keep_run(const LoraArgs &L, unsigned idx0, unsigned (&keep)[N])
+{
+    if constexpr (NF == 1) {
+#pragma unroll
+        for (int e = 0; e < N; e += 2) {
+            const unsigned h = L.thr ? hash32(L.seed, (idx0 >> 1) + (unsigned)(e >> 1)) : 0xFFFFFFFFu;
+            keep[e] = (h & 0xFFFFu) >= L.thr ? 1u : 0u;
+            keep[e + 1] = (h >> 16) >= L.thr ? 1u : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < N; ++e) keep[e] = keep_bits<NF>(L, idx0 + e);
+    }
 }
 
 // One wave = 16 rows of x over 1 / KW of the columns; a workgroup = 4 waves = 64 / KW rows.  K loop in steps of 32 (one
@@ -130,7 +153,8 @@ __global__ __launch_bounds__(256) void lora_down_kernel(LoraArgs L)
                 unsigned keep[8];
                 const unsigned idx0 = (unsigned)rowc[g] * (unsigned)L.in + (unsigned)(k0 + 32 * u + 8 * lq);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) keep[e] = keep_bits<NF>(L, idx0 + e);
+                for (int e = 0; e < 8; ++e) keep[e] = 0;
+                keep_run<NF, 8>(L, idx0, keep);                               // (in % 64 == 0: idx0 is even)
                 bf16x8 xm[NF];
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
@@ -238,7 +262,8 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraArgs L)
         unsigned keep[16];
         const unsigned idx0 = (unsigned)rowc * (unsigned)L.in + (unsigned)(c0 + 16 * lq);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { keep[e] = keep_bits<NF>(L, idx0 + e); sum[e] = 0.f; }
+        for (int e = 0; e < 16; ++e) { keep[e] = 0; sum[e] = 0.f; }
+        keep_run<NF, 16>(L, idx0, keep);
 #pragma unroll
         for (int s = 0; s < NSUB; ++s)
 #pragma unroll

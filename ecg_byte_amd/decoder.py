@@ -166,7 +166,9 @@ class LoraSite(nn.Module):
     def backward(self, dy, saved, model, dx, glu=None):
         """Sets A.grad / B.grad (slices of the model's flat gradient buffer) and adds the adapters' contribution to `dx` in place
         (dx already holds the base projection's dy . W).  glu = (gate|up, gelu_tanh) on the down-projection site: dx is d(act(gate) * up);
-        returns d(gate|up) from the same pass instead of writing dx back (ecgb_lora_dx_glu)."""
+        returns d(gate|up) from the same pass instead of writing dx back (ecgb_lora_dx_glu).  There dx may also be a callable that forms the
+        base projection's dy . W when asked: where the four-wave GEMM takes the shape, product, adapter share and GLU backward are one launch
+        (ops.gemm_nn_glu_bwd_lora, the frozen weight passed as glu[2]) and the callable is never called."""
         x, xd, t, p, seed = saved
         Bt = model._shadow(("lora_Bt", id(self)), self.B)                 # [64, out]
         At = model._shadow(("lora_At", id(self)), self.A)                 # [in, 64]
@@ -180,6 +182,12 @@ class LoraSite(nn.Module):
             model._lora_agrad(self.A, x, dt, self.n_sub, self.n_fields, self.scale, p, seed)
         if dx is None:                                                   # the caller needs no input gradient (the bottom layer over frozen embeddings)
             return None
+        if callable(dx):
+            if glu is not None and self.n_sub == 1 and len(glu) > 2:
+                d_gu = ops.gemm_nn_glu_bwd_lora(dy, glu[2], glu[0], dt, At, self.scale, p, seed, gelu_tanh=glu[1])
+                if d_gu is not None:
+                    return d_gu
+            dx = dx()
         if glu is not None and self.n_sub == 1:
             return ops.lora_dx_glu(dx, dt, At, glu[0], self.scale, p, seed, gelu_tanh=glu[1])
         ops.lora_dx_(dx, dt, At, self.n_sub, self.n_fields, self.scale, p, seed)
@@ -1176,12 +1184,12 @@ class HipCausalLM(nn.Module):
             if not frozen and ops.nn_glu_bwd_eligible(g.shape[0], I, H):
                 d_gu = ops.gemm_nn_glu_bwd(g, self.wdown[i].data, gu, gelu_tanh=self.gemma)       # dX of the down projection + GLU backward, one launch
             else:
-                d_hm = self._dx(g, ("wdown", i), self.wdown[i])    # [T, I]
-                if frozen:
-                    d_gu = self.lora[i]["down"].backward(g, ls[3], self, d_hm, glu=(gu, self.gemma))   # adapters + GLU backward in one pass
+                if frozen:                                         # adapters + GLU backward in one pass (with the product itself where the kernel takes the shape)
+                    d_gu = self.lora[i]["down"].backward(g, ls[3], self, lambda: self._dx(g, ("wdown", i), self.wdown[i]), glu=(gu, self.gemma, self.wdown[i].data))
                 else:
+                    d_hm = self._dx(g, ("wdown", i), self.wdown[i])    # [T, I]
                     d_gu = ops.glu_bwd(gu, d_hm, gelu_tanh=self.gemma)
-                del d_hm
+                    del d_hm
             del hm
             wgrad(d_gu, h2, self.wgu[i])
             d_h2 = self._dx(d_gu, ("wgu", i), self.wgu[i])         # [T, H]

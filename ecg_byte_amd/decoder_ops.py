@@ -474,6 +474,34 @@ def lora_dx_glu(dx, dt, At, gate_up, scale, p=0.0, seed=0, gelu_tanh=False):
     return d
 
 
+_fuse_lora_dx_glu = True
+
+
+def set_fuse_lora_dx_glu(on=True):
+    """A/B switch: the down-projection site's input gradient, adapter share and GLU backward in one launch (gemm_nn_glu_bwd_lora) or as gemm_nn + lora_dx_glu."""
+    global _fuse_lora_dx_glu
+    _fuse_lora_dx_glu = bool(on)
+
+
+def gemm_nn_glu_bwd_lora(dy, w, gate_up, dt, At, scale, p=0.0, seed=0, gelu_tanh=False):
+    """d(gate|up) [M, 2I] = glu_bwd(gate|up, bf16(dy @ w) + scale / (1 - p) * mask . (dt A)) in ONE launch (ecgb_gemm_nn_glu_bwd_lora_bf16: the down-projection
+    site of a LoRA fine-tune -- gemm_nn followed by lora_dx_glu, the same bits, d(act(gate) * up) never written), or None where the four-wave kernel does not
+    take the shape (the caller runs the two)."""
+    M, K = dy.shape
+    inter = w.shape[1]
+    assert w.shape[0] == K and gate_up.shape == (M, 2 * inter) and dt.shape == (M, 64) and At.shape == (inter, 64)
+    assert dy.stride(1) == 1 and w.stride(1) == 1 and gate_up.stride(1) == 1 and dt.is_contiguous() and At.is_contiguous()
+    if not _fuse_lora_dx_glu:
+        return None
+    d = torch.empty_like(gate_up)
+    rc = _L().ecgb_gemm_nn_glu_bwd_lora_bf16(_p(_bf(dy)), dy.stride(0), _p(_bf(w)), w.stride(0), _p(_bf(gate_up)), gate_up.stride(0), _p(_bf(dt)), _p(_bf(At)),
+                                             _p(d), d.stride(0), M, inter, K, int(gelu_tanh), float(scale), float(p), int(seed), _st())
+    if rc == -3:                                                         # ECGB_ERR_UNSUPPORTED
+        return None
+    _lib.check(rc)
+    return d
+
+
 def tn_splits(N, K, M, n_cu=256):
     """K-slices per 256x256 output tile of a weight-gradient product.  Skinny outputs (LoRA adapter gradients) are a pass over the long
     operand: enough workgroups to pull it at HBM speed.  Otherwise the slice count that minimises the makespan in contraction steps when

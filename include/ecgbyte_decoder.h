@@ -145,6 +145,15 @@ int ecgb_gemm_nn_bf16(const void *a_dev, long long lda, const void *b_dev, long 
  * The same bits as the two calls.  Whole 256x256 tiles only: M % 256 == 0 and inter % 256 == 0, else ECGB_ERR_UNSUPPORTED (callers take the two calls). */
 int ecgb_gemm_nn_glu_bwd_bf16(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *gate_up_dev, long long ldgu,
                               void *d_gate_up_dev, long long ldd, int M, int inter, int K, int gelu_tanh, void *stream);
+/* The same on the down-projection site of a LoRA fine-tune (peft LoraLayer on down_proj; ecg_byte/main.py:131-155): the adapter's share of the input gradient
+ * joins the product before the GLU backward,
+ *     d(gate|up) = ecgb_glu_bwd(gate_up, bf16(dY . W) + scale / (1 - p') * mask . (dt A)),   dt [M, 64] = dY . B_lora,   at_dev = A_lora^T [inter, 64]
+ * (rank 16 in columns 0..15, the rest zero), the forward's dropout mask replayed from (seed, p) as ecgb_lora_down drew it -- ecgb_gemm_nn_bf16 followed by
+ * ecgb_lora_dx_glu in one launch, the same bits, d(act(gate) * up) never written.  Four-wave kernel only: ECGB_ERR_UNSUPPORTED where it does not take the
+ * shape (whole 256x256 tiles, its share of K-tiles per CU) or the backward runs non-persistent; callers then take the two calls. */
+int ecgb_gemm_nn_glu_bwd_lora_bf16(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *gate_up_dev, long long ldgu,
+                                   const void *dt_dev, const void *at_dev, void *d_gate_up_dev, long long ldd, int M, int inter, int K, int gelu_tanh,
+                                   float scale, float p, uint64_t seed, void *stream);
 /* ecgb_gemm_nn_bf16 with the contraction cut into n_splits K-slices (few output tiles, a long contraction: the loss head's input gradient dlogits . E over the
  * vocabulary): slice s writes its fp32 partial product to slab s of slabs_dev (n_splits x M x N floats, 16-byte aligned), the slabs are added in slice
  * order into c_dev (bf16, contiguous [M, N]).  No atomics: the same bits every launch. */

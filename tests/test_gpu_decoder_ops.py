@@ -539,6 +539,55 @@ def test_gemm_nn_with_glu_backward_is_bitwise_the_two_kernels(ops, M, I, K, gelu
         ops.gemm_nn_glu_bwd(dy[:1000], w, gu[:1000], gelu_tanh=gelu_tanh)
 
 
+@pytest.mark.parametrize("gelu_tanh", [False, True])
+@pytest.mark.parametrize("p,seed", [(0.05, 4321), (0.0, 0), (0.3, (7 << 32) + 99)])
+@pytest.mark.parametrize("M,I,K", [(8192, 8192, 2048), (16384, 4096, 4096)])
+def test_down_site_backward_of_a_lora_fine_tune_in_one_launch_is_bitwise_the_two_kernels(ops, M, I, K, p, seed, gelu_tanh):
+    """The frozen down projection's input gradient, the adapter's share scale / (1 - p) * mask . (dt A) and the GLU backward in ONE launch of the four-wave
+    kernel (ecgb_gemm_nn_glu_bwd_lora_bf16, round 4): d(gate|up) must be the bits of gemm_nn followed by lora_dx_glu -- the forward's dropout mask regenerated
+    in the epilogue from the same (seed, element) rule, with and without dropout, a 64-bit seed, both activations, on every launch.  Shapes the four-wave
+    kernel does not take return None (the model then runs the two kernels), and so does the switch."""
+    dy, w = _bf(M, K, seed=141), _bf(K, I, scale=K ** -0.5, seed=142)
+    gu = _bf(M, 2 * I, seed=143)
+    dt, At = _bf(M, 64, scale=0.5, seed=144), _bf(I, 64, scale=0.05, seed=145)
+    dt[:, 16:] = 0
+    At[:, 16:] = 0
+    want = ops.lora_dx_glu(ops.gemm_nn(dy, w), dt, At, gu, 2.0, p, seed, gelu_tanh=gelu_tanh)
+    if p > 0:                                                        # the adapter's share and its mask are really in there
+        assert not torch.equal(want, ops.glu_bwd(gu, ops.gemm_nn(dy, w), gelu_tanh=gelu_tanh))
+        assert not torch.equal(want, ops.lora_dx_glu(ops.gemm_nn(dy, w), dt, At, gu, 2.0, 0.0, seed, gelu_tanh=gelu_tanh))
+    noise = torch.empty(64 << 20, device="cuda", dtype=torch.uint8)
+    for rep in range(3):
+        noise.random_()
+        got = ops.gemm_nn_glu_bwd_lora(dy, w, gu, dt, At, 2.0, p, seed, gelu_tanh=gelu_tanh)
+        assert got is not None and torch.equal(got, want), rep
+    assert ops.gemm_nn_glu_bwd_lora(dy[:1024], w, gu[:1024], dt[:1024], At, 2.0, p, seed, gelu_tanh=gelu_tanh) is None      # too few K-tiles per workgroup
+    ops.set_fuse_lora_dx_glu(False)
+    try:
+        assert ops.gemm_nn_glu_bwd_lora(dy, w, gu, dt, At, 2.0, p, seed, gelu_tanh=gelu_tanh) is None
+    finally:
+        ops.set_fuse_lora_dx_glu(True)
+
+
+def test_single_module_sites_draw_one_hash_per_element_pair_and_the_two_fields_are_independent(ops):
+    """A site with one module (o, down) spends one 32-bit hash on elements 2k, 2k + 1 (low and high 16-bit field): the drop rate of even and odd columns is p,
+    neighbours are dropped together p^2 of the time (independent fields), another seed gives another mask, and lora_da / lora_dx replay exactly this mask
+    (test_lora_da_replays_the_forward_masks, the test above)."""
+    T, K, p = 4096, 2048, 0.25
+    x = _bf(T, K, seed=151).abs() + 1                               # no zeros: a zero in the masked copy is a dropped element
+    A = _bf(64, K, scale=0.02, seed=152)
+    _, xd = ops.lora_down(x, A, 1, 1, 2.0, p, 99, keep_masked=True)
+    drop = (xd[0] == 0)
+    assert torch.equal(xd[0], torch.where(drop, torch.zeros_like(x), x))
+    even, odd = drop[:, 0::2].float(), drop[:, 1::2].float()
+    assert abs(even.mean().item() - p) < 3e-3 and abs(odd.mean().item() - p) < 3e-3
+    assert abs((even * odd).mean().item() - p * p) < 3e-3                                   # the pair's two fields
+    assert abs((odd[:, :-1] * even[:, 1:]).mean().item() - p * p) < 3e-3                    # neighbours of different pairs
+    assert abs((drop[:-1] & drop[1:]).float().mean().item() - p * p) < 3e-3                 # rows
+    _, xd2 = ops.lora_down(x, A, 1, 1, 2.0, p, 100, keep_masked=True)
+    assert abs(((xd2[0] == 0) & drop).float().mean().item() - p * p) < 3e-3
+
+
 @pytest.mark.parametrize("M,N,K", [(1280, 2048, 132608), (320, 768, 51584), (1000, 2048, 49152), (4096, 2048, 132608)])
 def test_gemm_nn_k_slices(ops, M, N, K):
     """The input gradient of the loss head (few labelled rows x hidden, contraction over the vocabulary): K-slices into fp32 slabs, summed in slice
