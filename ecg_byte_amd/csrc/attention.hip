@@ -1178,8 +1178,45 @@ __device__ __forceinline__ f32x16 splat16(float v)
     return r;
 }
 
+#ifndef ECGB_LEAN_DIAG
+#define ECGB_LEAN_DIAG 0      // timing-only diagnostics of the forward kernel (wrong results): 1 no tile DMA in the loop, 2 no barrier, 4 no exp, 8 two of the eight P.V MFMAs, 16 four of the eight Q.K MFMAs, 32 no row sum
+#endif
+#ifndef ECGB_LEAN_FWD_WGS
+#define ECGB_LEAN_FWD_WGS 2
+#endif
+#ifndef ECGB_LEAN_PRIO
+#define ECGB_LEAN_PRIO 1
+#endif
+#if ECGB_LEAN_PRIO
+#define LEAN_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define LEAN_PRIO(p) do { } while (0)
+#endif
 constexpr int kLeanRing = 3;      // LDS ring depth of the lean kernels: tiles (kRing - 1) ahead (4 measured the same as 3: the flight time is not what a wave waits for)
 template <int N> __device__ __forceinline__ void lean_wait_tiles() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// The batch row's key mask goes to LDS once per workgroup (floats, as the kernels read it); beside it one flag per 64-key tile: does the tile hold a padded (or
+// out-of-range) key?  A wave's 64 lanes fill exactly one tile per pass, so the flag is that pass's ballot.  After the barrier lean_pad_bits() gathers the first 64
+// flags into a scalar bit mask and a trip asks it instead of probing the tile's mask words (a blocking LDS round trip at the top of every trip).  Tiles past the
+// 64th (sequences over 4 096 keys) count as padded: they take the exact path, which is always right.
+template <int NW>
+__device__ __forceinline__ void lean_fill_mask(float *lds_maskrow, const float *mask_row, int S, int padded)
+{
+    unsigned *flags = reinterpret_cast<unsigned *>(lds_maskrow + padded);
+    for (int i = threadIdx.x; i < padded; i += NW * 64) {
+        const float v = (i < S) ? mask_row[i] : 0.f;
+        lds_maskrow[i] = v;
+        const bool z = __any(v == 0.f);
+        if ((threadIdx.x & 63) == 0 && (i >> 6) < 64) flags[i >> 6] = z ? 1u : 0u;
+    }
+}
+__device__ __forceinline__ unsigned long long lean_pad_bits(const float *lds_maskrow, int padded)
+{
+    const unsigned *flags = reinterpret_cast<const unsigned *>(lds_maskrow + padded);
+    const int n = min(padded >> 6, 64), lane = threadIdx.x & 63;
+    return __ballot(lane < n && flags[min(lane, n - 1)] != 0u);
+}
+__device__ __forceinline__ bool lean_tile_padded(unsigned long long padbits, int tile) { return tile >= 64 || ((padbits >> tile) & 1ull) != 0ull; }
 
 // NW waves per workgroup (4 or 8) share every K / V tile.  Measured with the phase timers (scripts/dev_prof_attn.py, 4 waves x 32 rows, two workgroups per CU):
 // 2 030 of a tile's 4 700 cycles went into ISSUING its four LDS-DMA pieces -- the vector memory path of a CU takes about 16 bytes per cycle, 32 KB per pair of
@@ -1187,7 +1224,7 @@ template <int N> __device__ __forceinline__ void lean_wait_tiles() { asm volatil
 // and -- grouped-query attention -- the waves of a workgroup are the HW = gcd(G, 8) query heads of the KV group times 8 / HW blocks of 32 rows (Llama: 4 heads
 // x 64 rows, where both row blocks need exactly the same tiles: no wave idles at a barrier under the causal mask; one head: 256 rows).
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_lean_kernel(AttnArgs A)
+__global__ __launch_bounds__(NW * 64, ECGB_LEAN_FWD_WGS) void attn_fwd_lean_kernel(AttnArgs A)
 {
     constexpr int D = 64, kTile = 128 * D, PPW = 8 / NW;      // PPW: 1 KiB pieces of a tile per wave and operand
     // Ring of kRing (K, V) tile pairs, kAhead = kRing - 1 tiles in flight, issued FIRST thing in a tile.  Measured (scripts/dev_attn_lean.py, C3 shape):
@@ -1195,8 +1232,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_lean_kernel(AttnArgs A)
     // four (three tiles ahead) measured the same as three.
     constexpr int kRing = kLeanRing, kAhead = kRing - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // kRing x (K, V) tiles + the row's key mask
-    auto lds_k2 = [&](int i) { return smem + i * 2 * kTile; };
-    auto lds_vt2 = [&](int i) { return smem + i * 2 * kTile + kTile; };
     float *lds_maskrow = reinterpret_cast<float *>(smem + 2 * kRing * kTile);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     const int hw_log2 = A.lean_hw_log2, R = (NW >> hw_log2) * 32;          // heads per workgroup (log2), query rows per workgroup
@@ -1220,29 +1255,38 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_lean_kernel(AttnArgs A)
         offK[i] = (unsigned)(((long long)r * A.ldk + ck * 8) * 2);  offKt[i] = (unsigned)(((long long)rt * A.ldk + ck * 8) * 2);
         offV[i] = (unsigned)(((long long)r * A.ldv + cv * 8) * 2);  offVt[i] = (unsigned)(((long long)rt * A.ldv + cv * 8) * 2);
     }
-    auto issue_tile = [&](int t, int buf) {                  // UNCONDITIONAL (the caller clamps t): the waits below stay counted
-        const bool tail = (t + 1) * 64 > A.S;
-        const unsigned char *kb = reinterpret_cast<const unsigned char *>(K + (rowbase + (long long)t * 64) * A.ldk);
-        const unsigned char *vb = reinterpret_cast<const unsigned char *>(V + (rowbase + (long long)t * 64) * A.ldv);
+    // The tile stream as RUNNING state (round 4): the next tile's global bases, its index and its ring slot advance by adds.  Formed from the tile index every trip
+    // (64-bit multiplies, a division by the ring depth) the issue was 50 scalar instructions per trip, a fifth of the trip's instruction count -- and a wave issues
+    // one instruction per ~4.5 cycles whatever its kind.  UNCONDITIONAL (past the last tile the last one is issued again): the waits below stay counted.
+    const unsigned char *kb_next = reinterpret_cast<const unsigned char *>(K + rowbase * A.ldk), *vb_next = reinterpret_cast<const unsigned char *>(V + rowbase * A.ldv);
+    const long long stepK = 128ll * A.ldk, stepV = 128ll * A.ldv;       // bytes from one 64-key tile to the next
+    const bool tail_last = (last_tile + 1) * 64 > A.S;
+    int t_next = 0;
+    unsigned slot_next = 0;                                             // byte offset of the ring slot the next tile lands in
+    auto issue_next = [&]() {
+        const bool tail = tail_last && t_next == last_tile;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb + (tail ? offKt[i] : offK[i])),
-                                             (__attribute__((address_space(3))) void *)(lds_k2(buf) + (wave * PPW + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb + (tail ? offVt[i] : offV[i])),
-                                             (__attribute__((address_space(3))) void *)(lds_vt2(buf) + (wave * PPW + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb_next + (tail ? offKt[i] : offK[i])),
+                                             (__attribute__((address_space(3))) void *)(smem + slot_next + (wave * PPW + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb_next + (tail ? offVt[i] : offV[i])),
+                                             (__attribute__((address_space(3))) void *)(smem + slot_next + kTile + (wave * PPW + i) * 1024), 16, 0, 0);
         }
+        if (t_next < last_tile) { ++t_next; kb_next += stepK; vb_next += stepV; }
+        slot_next = slot_next == (kRing - 1) * 2 * kTile ? 0u : slot_next + 2 * kTile;
     };
 #pragma unroll
-    for (int t = 0; t < kAhead; ++t) issue_tile(min(t, last_tile), t);
+    for (int t = 0; t < kAhead; ++t) issue_next();
     bf16x8 qf[4];
     load_row_frags<D>(qf, Q, A.ldq, rowbase + qi, qvalid, h);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // Q's fragments (younger than the tiles' pieces) are in: from here on the waits are counted
     scale_row_frags(qf, A.scale * kLog2e);                   // log2-domain scores straight out of the MFMA
-    for (int i = threadIdx.x; i < ((k_end + 63) & ~63); i += NW * 64) lds_maskrow[i] = (i < A.S) ? A.mask[rowbase + i] : 0.f;
+    lean_fill_mask<NW>(lds_maskrow, A.mask + rowbase, A.S, (k_end + 63) & ~63);
     f32x16 accO[2] = {splat16(0.f), splat16(0.f)};
     float m = -INFINITY, l = 0.f;                            // m: the row's reference (a deferred running maximum); -inf = no key seen yet
     f32x16 cinit = splat16(0.f);                             // -m in all sixteen registers: the initial accumulator of the score products
     __syncthreads();
+    const unsigned long long padbits = lean_pad_bits(lds_maskrow, (k_end + 63) & ~63);
     unsigned vtr[2];
     {
         const int a = lr >> 4, q = (lr & 15) >> 2, p = lr & 3;
@@ -1260,37 +1304,45 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_lean_kernel(AttnArgs A)
     unsigned long long prof_acc[7] = {};
     long long t_prof = clock64();
 #endif
+    unsigned vimg = 0;                                       // byte offset of the ring slot of the current tile
     for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
-        const unsigned vimg = (unsigned)((it % kRing) * 2 * kTile);
         const float *lds_mask = lds_maskrow + k0;
-        issue_tile(min(it + kAhead, last_tile), (it + kAhead) % kRing);      // FIRST thing in the tile: the pieces need their whole flight time (see kRing)
+#if !(ECGB_LEAN_DIAG & 1)
+        issue_next();                                        // FIRST thing in the tile: the pieces need their whole flight time (see kRing)
+#endif
         APROF(0);
         if (k0 <= wave_qmax) {
-            const bool need_mask = (k0 + 63 > qw0) || __any(lds_mask[lane] == 0.f);
+            const bool need_mask = (k0 + 63 > qw0) || lean_tile_padded(padbits, it);
             f32x16 sacc[2];
             bf16x8 kfr[2][4];                                   // [kb][ks]: K row fragments, four per batch; the second batch and the V^T fragments land under MFMAs
             lds_frags2x2_wait<0, 4096>(kfr[0][0], kfr[1][0], kfr[0][1], kfr[1][1], kbase[0] + vimg, kbase[1] + vimg);
+            LEAN_PRIO(1);
             sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][0], qf[0], cinit, 0, 0, 0);
             sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[1][0], qf[0], cinit, 0, 0, 0);
             sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][1], qf[1], sacc[0], 0, 0, 0);
             sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[1][1], qf[1], sacc[1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             lds_frags2x2_wait<0, 4096>(kfr[0][2], kfr[1][2], kfr[0][3], kfr[1][3], kbase[2] + vimg, kbase[3] + vimg);
+#if !(ECGB_LEAN_DIAG & 16)
 #pragma unroll
             for (int ks = 2; ks < 4; ++ks)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][ks], qf[ks], sacc[kb], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             bf16x8 vfr[2][2][2];                                // [kb][s2][db]: the tile's eight V^T fragments, read (and waited for) under the products above
             tr_frags4_wait<0, 16 * 128>(vfr[0], vtr[0] + vimg, vtr[0] + vimg + 1024, vtr[1] + vimg, vtr[1] + vimg + 1024);
             tr_frags4_wait<32 * 128, 48 * 128>(vfr[1], vtr[0] + vimg, vtr[0] + vimg + 1024, vtr[1] + vimg, vtr[1] + vimg + 1024);
             APROF(1);
+            LEAN_PRIO(0);
             bf16x8 pf[2][2];                                    // [kb][s2]: P as the B operand of P.V, packed as it is produced (the fp32 values are not kept)
             using u4 = __attribute__((ext_vector_type(4))) unsigned;
             bool exact = need_mask;
             if (!need_mask) {                                   // (uniform) fast path: p = exp2(score - reference) is the accumulator's exp2
-                float lsum = 0.f;
+                // the row sum as FOUR chains of eight adds (one per fragment of P): as one chain of 32 dependent adds it was 13 % of the kernel -- with two waves
+                // per SIMD nothing else of this wave can issue behind an add that waits for the previous one
+                float ls[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -1298,12 +1350,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_lean_kernel(AttnArgs A)
                         u4 w;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
+#if ECGB_LEAN_DIAG & 4
+                            const float e0 = sacc[kb][8 * s2 + 2 * j], e1 = sacc[kb][8 * s2 + 2 * j + 1];
+#else
                             const float e0 = fast_exp2(sacc[kb][8 * s2 + 2 * j]), e1 = fast_exp2(sacc[kb][8 * s2 + 2 * j + 1]);
-                            lsum += e0; lsum += e1;
+#endif
+#if !(ECGB_LEAN_DIAG & 32)
+                            ls[kb][s2] += e0; ls[kb][s2] += e1;
+#endif
                             w[j] = pack_bf16(e0, e1);
                         }
                         pf[kb][s2] = __builtin_bit_cast(bf16x8, w);
                     }
+                const float lsum = (ls[0][0] + ls[0][1]) + (ls[1][0] + ls[1][1]);
                 // not (lsum <= 2^10) also catches +inf; a row that has seen no key yet has no reference: exact path
                 exact = __any(!(lsum <= 1024.f) || m == -INFINITY);
                 if (!exact) l += lsum;
@@ -1336,7 +1395,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_lean_kernel(AttnArgs A)
                 const bool unseen = m == -INFINITY;
                 const float d = (t == -INFINITY) ? 0.f : (unseen ? t : fmaxf(t, 0.f));
                 const float alpha = unseen ? 1.f : fast_exp2(-d);   // (an unseen row's l and O are still zero)
-                float lsum = 0.f;
+                float ls[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -1345,11 +1404,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_lean_kernel(AttnArgs A)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float e0 = fast_exp2(sacc[kb][8 * s2 + 2 * j] - d), e1 = fast_exp2(sacc[kb][8 * s2 + 2 * j + 1] - d);
-                            lsum += e0; lsum += e1;
+                            ls[kb][s2] += e0; ls[kb][s2] += e1;
                             w[j] = pack_bf16(e0, e1);
                         }
                         pf[kb][s2] = __builtin_bit_cast(bf16x8, w);
                     }
+                const float lsum = (ls[0][0] + ls[0][1]) + (ls[1][0] + ls[1][1]);
                 l = l * alpha + lsum;
                 if (t != -INFINITY) m = unseen ? t : m + d;
                 if (__any(alpha != 1.f)) {
@@ -1361,18 +1421,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_lean_kernel(AttnArgs A)
                 if (__any(d != 0.f)) cinit = splat16(m == -INFINITY ? 0.f : -m);
             }
             APROF(2);
+            LEAN_PRIO(1);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
+#if ECGB_LEAN_DIAG & 8
+                        if (kb == 0 && s2 == 0)
+#endif
                         accO[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb][s2][db], pf[kb][s2], accO[db], 0, 0, 0);
+            LEAN_PRIO(0);
             APROF(3);
         }
+#if !(ECGB_LEAN_DIAG & 1)
         lean_wait_tiles<2 * PPW * (kAhead - 1)>();         // this wave's pieces of tile it + 1 have landed (the younger tiles' may still fly)
+#endif
         APROF(4);
+#if !(ECGB_LEAN_DIAG & 2)
         __builtin_amdgcn_s_barrier();                      // ... and everybody else's; all reads of tile it are done
+#endif
+        vimg = vimg == (kRing - 1) * 2 * kTile ? 0u : vimg + 2 * kTile;
         APROF(5);
 #ifdef ECGB_PROFILE
         prof_acc[6] += 1;
@@ -1396,8 +1466,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_lean_kernel(AttnArgs A
     constexpr int D = 64, kTile = 128 * D, PPW = 8 / NW;      // (waves, heads and rows of a workgroup: see attn_fwd_lean_kernel)
     constexpr int kRing = kLeanRing, kAhead = kRing - 1;   // (see attn_fwd_lean_kernel)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // kRing x (K, V) + 4 bytes per key
-    auto lds_k3 = [&](int i) { return smem + i * 2 * kTile; };
-    auto lds_v3 = [&](int i) { return smem + i * 2 * kTile + kTile; };
     float *lds_maskrow = reinterpret_cast<float *>(smem + 2 * kRing * kTile);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     const int hw_log2 = A.lean_hw_log2, R = (NW >> hw_log2) * 32;
@@ -1420,20 +1488,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_lean_kernel(AttnArgs A
         offK[i] = (unsigned)(((long long)r * A.ldk + c * 8) * 2);  offKt[i] = (unsigned)(((long long)rt * A.ldk + c * 8) * 2);
         offV[i] = (unsigned)(((long long)r * A.ldv + c * 8) * 2);  offVt[i] = (unsigned)(((long long)rt * A.ldv + c * 8) * 2);
     }
-    auto issue_tile = [&](int t, int buf) {
-        const bool tail = (t + 1) * 64 > A.S;
-        const unsigned char *kb = reinterpret_cast<const unsigned char *>(K + (rowbase + (long long)t * 64) * A.ldk);
-        const unsigned char *vb = reinterpret_cast<const unsigned char *>(V + (rowbase + (long long)t * 64) * A.ldv);
+    // (the tile stream as running state: see attn_fwd_lean_kernel)
+    const unsigned char *kb_next = reinterpret_cast<const unsigned char *>(K + rowbase * A.ldk), *vb_next = reinterpret_cast<const unsigned char *>(V + rowbase * A.ldv);
+    const long long stepK = 128ll * A.ldk, stepV = 128ll * A.ldv;       // bytes from one 64-key tile to the next
+    const bool tail_last = (last_tile + 1) * 64 > A.S;
+    int t_next = 0;
+    unsigned slot_next = 0;                                             // byte offset of the ring slot the next tile lands in
+    auto issue_next = [&]() {
+        const bool tail = tail_last && t_next == last_tile;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb + (tail ? offKt[i] : offK[i])),
-                                             (__attribute__((address_space(3))) void *)(lds_k3(buf) + (wave * PPW + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb + (tail ? offVt[i] : offV[i])),
-                                             (__attribute__((address_space(3))) void *)(lds_v3(buf) + (wave * PPW + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb_next + (tail ? offKt[i] : offK[i])),
+                                             (__attribute__((address_space(3))) void *)(smem + slot_next + (wave * PPW + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb_next + (tail ? offVt[i] : offV[i])),
+                                             (__attribute__((address_space(3))) void *)(smem + slot_next + kTile + (wave * PPW + i) * 1024), 16, 0, 0);
         }
+        if (t_next < last_tile) { ++t_next; kb_next += stepK; vb_next += stepV; }
+        slot_next = slot_next == (kRing - 1) * 2 * kTile ? 0u : slot_next + 2 * kTile;
     };
 #pragma unroll
-    for (int t = 0; t < kAhead; ++t) issue_tile(min(t, last_tile), t);
+    for (int t = 0; t < kAhead; ++t) issue_next();
     bf16x8 qf[4], dof[4], of[4];
     load_row_frags<D>(qf, Q, A.ldq, rowbase + qi, qvalid, h);
     load_row_frags<D>(dof, A.d_o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h);
@@ -1451,9 +1525,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_lean_kernel(AttnArgs A
     scale_row_frags(dof, -1.f);
     const f32x16 lseC = splat16(lse), delC = splat16(delta);
     f32x16 accQ[2] = {splat16(0.f), splat16(0.f)};
-    for (int i = threadIdx.x; i < ((k_end + 63) & ~63); i += NW * 64) lds_maskrow[i] = (i < A.S) ? A.mask[rowbase + i] : 0.f;
+    lean_fill_mask<NW>(lds_maskrow, A.mask + rowbase, A.S, (k_end + 63) & ~63);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the row loads above are younger than the tiles' pieces: one full wait, once)
     __syncthreads();
+    const unsigned long long padbits = lean_pad_bits(lds_maskrow, (k_end + 63) & ~63);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     unsigned trA[2], trB[2];
 #pragma unroll
@@ -1461,13 +1536,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_lean_kernel(AttnArgs A
     unsigned rbase[4];                                       // this lane's row fragment (row lr, k-step ks) inside an image; row 32 + lr is 4 KiB further
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) rbase[ks] = lds0 + lr * 128 + (((ks * 2 + h) ^ swz_u(lr)) << 4);
+    unsigned kimg = 0;                                       // byte offset of the ring slot of the current tile
     for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
-        issue_tile(min(it + kAhead, last_tile), (it + kAhead) % kRing);
-        const int buf = it % kRing;
-        const unsigned kimg = (unsigned)(buf * 2 * kTile);
+        issue_next();
         if (k0 <= wave_qmax) {
             const float *lds_mask = lds_maskrow + k0;
-            const bool need_mask = (k0 + 63 > qw0) || __any(lds_mask[lane] == 0.f);
+            const bool need_mask = (k0 + 63 > qw0) || lean_tile_padded(padbits, it);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 bf16x8 kfr[4], vfr[4];                        // row fragments of this key half: K and V images side by side (+ kTile), two k-steps per batch
@@ -1515,6 +1589,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_lean_kernel(AttnArgs A
         }
         lean_wait_tiles<2 * PPW * (kAhead - 1)>();
         __builtin_amdgcn_s_barrier();
+        kimg = kimg == (kRing - 1) * 2 * kTile ? 0u : kimg + 2 * kTile;
     }
     if (A.rope_cos) store_accT_rope_inv(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, -A.scale, A.rope_cos + (rowbase + qi) * 32, A.rope_sin + (rowbase + qi) * 32);
     else store_accT<2>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, -A.scale);
@@ -2091,7 +2166,7 @@ extern "C" int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev
     if (head_dim == 64) {
         const int lds = 6 * 128 * 64 + 4 * ((seq + 63) & ~63);
         if ((g_attn_dma & 3) == 2 && !(g_attn_dma & 0x100)) {
-            const int ldl = 2 * kLeanRing * 128 * 64 + 4 * ((seq + 63) & ~63);
+            const int ldl = 2 * kLeanRing * 128 * 64 + 4 * ((seq + 63) & ~63) + 256;   // K / V ring, the row's key mask, 64 tile flags
             const LeanGeom lg = lean_geom(seq, n_q_heads, n_kv_heads, batch);
             A.lean_hw_log2 = lg.hw_log2;
             auto kf = g_lean_waves == 8 ? attn_fwd_lean_kernel<8> : attn_fwd_lean_kernel<4>;
@@ -2159,7 +2234,7 @@ int attn_bwd_impl(const void *q_dev, long long ldq, const void *k_dev, long long
         const bool lean = (g_attn_dma & 3) == 2;
         if (g_attn_dma & 3) {
             const bool lq_lean = lean && !(g_attn_dma & 0x200);
-            const int lq = (lq_lean ? 2 * kLeanRing : 6) * 128 * 64 + 4 * ((seq + 63) & ~63);
+            const int lq = (lq_lean ? 2 * kLeanRing : 6) * 128 * 64 + 4 * ((seq + 63) & ~63) + (lq_lean ? 256 : 0);
             const LeanGeom lg = lean_geom(seq, n_q_heads, n_kv_heads, batch);
             A.lean_hw_log2 = lg.hw_log2;
             auto kq = !lq_lean ? attn_bwd_dq_dma_kernel : g_lean_waves == 8 ? attn_bwd_dq_lean_kernel<8> : attn_bwd_dq_lean_kernel<4>;
