@@ -168,6 +168,7 @@ def lib():
         "ecgb_gemm_nn_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, vp],
         "ecgb_gemm_nn_glu_bwd_bf16": [vp, ll, vp, ll, vp, ll, vp, ll, ci, ci, ci, ci, vp],
         "ecgb_gemm_nn_glu_bwd_lora_bf16": [vp, ll, vp, ll, vp, ll, vp, vp, vp, ll, ci, ci, ci, ci, f32, f32, C.c_uint64, vp],
+        "ecgb_gemm_nn_lora_bf16": [vp, ll, vp, ll, vp, vp, vp, ll, ci, ci, ci, f32, f32, C.c_uint64, vp],
         "ecgb_gemm_nn_splitk_bf16": [vp, ll, vp, ll, vp, vp, ci, ci, ci, ci, f32, vp],
         "ecgb_gemm_nt_glu_bf16": [vp, ll, vp, ll, vp, ll, vp, ll, ci, vp, ll, vp, ll, ci, ci, ci, f32, ci, vp],
         "ecgb_gemm_nt_bf16_cat": [vp, ll, vp, ll, vp, ll, vp, ll, ci, vp, ll, ci, ci, ci, f32, ci, vp],

@@ -1185,7 +1185,7 @@ __device__ __forceinline__ f32x16 splat16(float v)
 #define ECGB_LEAN_FWD_WGS 2
 #endif
 #ifndef ECGB_LEAN_PRIO
-#define ECGB_LEAN_PRIO 1
+#define ECGB_LEAN_PRIO 0      // 1: s_setprio 1 around the forward kernel's MFMA clusters (measured: no change, 0.248 against 0.250 ms)
 #endif
 #if ECGB_LEAN_PRIO
 #define LEAN_PRIO(p) __builtin_amdgcn_s_setprio(p)

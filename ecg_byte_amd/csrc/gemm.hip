@@ -2428,6 +2428,27 @@ extern "C" int ecgb_gemm_nn_glu_bwd_lora_bf16(const void *dy_dev, long long lddy
                                 gate_up_dev, ldgu, dt_dev, at_dev, lscale, thr, (unsigned)(seed ^ (seed >> 32)));
 }
 
+// The input gradient of a frozen projection with ONE LoRA module on it (o): dx = bf16(dY . W) + scale / (1 - p) * mask . (dt A) in one launch -- ecgb_gemm_nn_bf16 followed
+// by ecgb_lora_dx (one block), the same bits, no read-modify-write pass over dx.  Four-wave kernel only: ECGB_ERR_UNSUPPORTED where it does not take the shape.
+extern "C" int ecgb_gemm_nn_lora_bf16(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *dt_dev, const void *at_dev,
+                                      void *dx_dev, long long lddx, int M, int in, int K, float scale, float p, uint64_t seed, void *stream)
+{
+    if (!dy_dev || !w_dev || !dt_dev || !at_dev || !dx_dev || M <= 0 || in <= 0 || K <= 0 || !(p >= 0.f && p < 1.f)) {
+        ecgb::set_error("ecgb_gemm_nn_lora_bf16: bad argument");
+        return ECGB_ERR_INVALID;
+    }
+    if (K % BK || M % 256 || in % 256 || lddy % 8 || ldw % 8 || lddx % 8 || ((uintptr_t)dy_dev & 15) || ((uintptr_t)w_dev & 15) || ((uintptr_t)dx_dev & 15) ||
+        ((uintptr_t)dt_dev & 15) || ((uintptr_t)at_dev & 15) || (long long)M * in > 0xFFFFFFFFll ||
+        !(g_gemm_w4 && g_nn_persist && g_gemm_tile == 0 && ((long long)15 * ldw + 256) * 2 <= 0xFFFFFFFFll && ecgb::gemm_w4_applies(dy_dev, lddy, w_dev, ldw, dx_dev, lddx, M, in, K))) {
+        ecgb::set_error("ecgb_gemm_nn_lora_bf16: whole 256x256 tiles with at least the four-wave kernel's share of K-tiles per CU, 16-byte aligned operands");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    const unsigned thr = (unsigned)(p * 65536.0f);
+    const float lscale = scale / (1.0f - (float)thr / 65536.0f);
+    return ecgb::gemm_w4_launch(dy_dev, lddy, w_dev, ldw, dx_dev, lddx, M, in, K, 1.0f, stream, 8, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1,
+                                nullptr, 0, dt_dev, at_dev, lscale, thr, (unsigned)(seed ^ (seed >> 32)));
+}
+
 #ifdef ECGB_PROFILE
 extern "C" void ecgb_debug_gemm_profile(unsigned long long *out8, int reset)   // out8: 12 counters
 {

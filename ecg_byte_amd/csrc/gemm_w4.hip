@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 {
     constexpr bool NN = LAY >= 1, TA = LAY == 2;              // B, A stored with the contraction index as the row
     static_assert(!NN || ((EPI == 0 || EPI >= 4) && !CAT), "the NN / TN forms are the plain product (NN: or the GLU backward behind it)");
-    static_assert(EPI <= 7, "EPI 0..7");
+    static_assert(EPI <= 8, "EPI 0..8");
     static_assert(EPI < 4 || LAY == 1, "the GLU backward epilogue belongs to the down projection's input gradient: NN layout");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -456,11 +456,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // ecgb_glu_bwd's arithmetic, the same bits as the two kernels, one write and one read of [M, glu_I] less.
             auto lo_f = [](unsigned x) { return __uint_as_float(x << 16); };
             auto hi_f = [](unsigned x) { return __uint_as_float(x & 0xFFFF0000u); };
-            constexpr bool GELU = (EPI & 1) != 0, LORA = EPI >= 6;
+            constexpr bool GLU = EPI < 8, GELU = GLU && (EPI & 1) != 0, LORA = EPI >= 6;      // EPI 8: the adapter's share and a plain store (a single-module site without a GLU behind it: o)
             const int rr = lane >> 4, cc = lane & 15;
             const long long col = (long long)tn * 256 + wc * 128 + cc * 8, row0 = (long long)tm * 256 + wr * 128 + rr;
             unsigned short *cdst = G.C + row0 * G.ldc + col;
-            const unsigned short *gsrc = G.GU + row0 * G.ldgu + col;
+            const unsigned short *gsrc = GLU ? G.GU + row0 * G.ldgu + col : nullptr;
             const long long gI = G.glu_I;
             // EPI 6 / 7 (LoRA fine-tune): the adapter's share of the input gradient, scale * mask . (dt A), joins the tile in the accumulators' own layout -- one more MFMA
             // per 16 x 16 block (operand rows = 16 rows of A^T for the block's columns and 16 rows of dt, rank 16 in k 0..15, the rest zero: lora_dx_kernel's product,
@@ -489,8 +489,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             auto fetch = [&](int row16, int slot) {
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
-                    gq[slot][ps] = *reinterpret_cast<const u4 *>(gsrc + (long long)(row16 * 16 + ps * 4) * G.ldgu);
-                    uq[slot][ps] = *reinterpret_cast<const u4 *>(gsrc + (long long)(row16 * 16 + ps * 4) * G.ldgu + gI);
+                    if constexpr (GLU) {
+                        gq[slot][ps] = *reinterpret_cast<const u4 *>(gsrc + (long long)(row16 * 16 + ps * 4) * G.ldgu);
+                        uq[slot][ps] = *reinterpret_cast<const u4 *>(gsrc + (long long)(row16 * 16 + ps * 4) * G.ldgu + gI);
+                    }
                 }
                 if constexpr (LORA) dtf[slot] = *reinterpret_cast<const bf16x8 *>(dtp + row16 * 16 * 64);
             };
@@ -536,16 +538,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int ps = 0; ps < 4; ++ps) {
                     const int r = ps * 4 + rr;
                     const u4 d = *reinterpret_cast<const u4 *>(stg + r * 256 + ((cc ^ r) << 4));
-                    u4 og, ou;
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        const float g0 = lo_f(gq[slot][ps][x]), g1 = hi_f(gq[slot][ps][x]), u0 = lo_f(uq[slot][ps][x]), u1 = hi_f(uq[slot][ps][x]), d0 = lo_f(d[x]), d1 = hi_f(d[x]);
-                        og[x] = pack2(d0 * u0 * ecgb::glu_act_grad<GELU>(g0), d1 * u1 * ecgb::glu_act_grad<GELU>(g1));
-                        ou[x] = pack2(d0 * ecgb::glu_act<GELU>(g0), d1 * ecgb::glu_act<GELU>(g1));
-                    }
                     unsigned short *o = cdst + (long long)(i * 16 + ps * 4) * G.ldc;
-                    *reinterpret_cast<u4 *>(o) = og;
-                    *reinterpret_cast<u4 *>(o + gI) = ou;
+                    if constexpr (!GLU) {
+                        *reinterpret_cast<u4 *>(o) = d;
+                    } else {
+                        u4 og, ou;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const float g0 = lo_f(gq[slot][ps][x]), g1 = hi_f(gq[slot][ps][x]), u0 = lo_f(uq[slot][ps][x]), u1 = hi_f(uq[slot][ps][x]), d0 = lo_f(d[x]), d1 = hi_f(d[x]);
+                            og[x] = pack2(d0 * u0 * ecgb::glu_act_grad<GELU>(g0), d1 * u1 * ecgb::glu_act_grad<GELU>(g1));
+                            ou[x] = pack2(d0 * ecgb::glu_act<GELU>(g0), d1 * ecgb::glu_act<GELU>(g1));
+                        }
+                        *reinterpret_cast<u4 *>(o) = og;
+                        *reinterpret_cast<u4 *>(o + gI) = ou;
+                    }
                 }
                 asm volatile("" ::: "memory");
             }
@@ -689,12 +695,12 @@ int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long lon
     G.A = (const unsigned short *)a_dev; G.B = (const unsigned short *)b_dev; G.C = (unsigned short *)c_dev;
     G.lda = lda; G.ldb = ldb; G.ldc = ldc; G.M = M; G.N = N; G.K = K; G.tiles_m = M / 256; G.tiles_n = N / 256; G.alpha = alpha; G.group_m = g_w4_group_m;
     G.H = (unsigned short *)h_dev; G.ldh = ldh; G.glu_I = epi >= 4 ? N : N / 2;
-    const int which = epi >= 4 ? 6 + epi : lay ? 7 + lay : epi + (G.K2 ? 4 : 0);      // (10, 11: the NN product with the GLU backward behind it; 12, 13: and the LoRA adapter's share)
+    const int which = epi >= 4 ? 6 + epi : lay ? 7 + lay : epi + (G.K2 ? 4 : 0);      // (10, 11: the NN product with the GLU backward behind it; 12, 13: and the LoRA adapter's share; 14: the adapter's share and a plain store)
 #define W4_KERNS(S) {gemm_nt_w4_kernel<0, false, 0, S>, gemm_nt_w4_kernel<1, false, 0, S>, gemm_nt_w4_kernel<2, false, 0, S>, gemm_nt_w4_kernel<3, false, 0, S>, \
                      gemm_nt_w4_kernel<0, true, 0, S>, gemm_nt_w4_kernel<1, true, 0, S>, gemm_nt_w4_kernel<2, true, 0, S>, gemm_nt_w4_kernel<3, true, 0, S>,     \
                      gemm_nt_w4_kernel<0, false, 1, S>, gemm_nt_w4_kernel<0, false, 2, S>, gemm_nt_w4_kernel<4, false, 1, S>, gemm_nt_w4_kernel<5, false, 1, S>, \
-                     gemm_nt_w4_kernel<6, false, 1, S>, gemm_nt_w4_kernel<7, false, 1, S>}
-    void (*const kerns[2][14])(W4Args) = {W4_KERNS(0), W4_KERNS(1)};
+                     gemm_nt_w4_kernel<6, false, 1, S>, gemm_nt_w4_kernel<7, false, 1, S>, gemm_nt_w4_kernel<8, false, 1, S>}
+    void (*const kerns[2][15])(W4Args) = {W4_KERNS(0), W4_KERNS(1)};
 #undef W4_KERNS
     void (*kern)(W4Args) = kerns[g_w4_sched ? 1 : 0][which];
     if (g_w4_sched >= 16 && which == 0) {                                  // timing-only diagnostics of the plain NT kernel

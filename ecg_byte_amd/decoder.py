@@ -163,12 +163,13 @@ class LoraSite(nn.Module):
                 y = (y if glu[1] else None, ops.glu_fwd(y, gelu_tanh=glu[0]))
         return y, (x, xd, t, p, seed)
 
-    def backward(self, dy, saved, model, dx, glu=None):
+    def backward(self, dy, saved, model, dx, glu=None, weight=None):
         """Sets A.grad / B.grad (slices of the model's flat gradient buffer) and adds the adapters' contribution to `dx` in place
         (dx already holds the base projection's dy . W).  glu = (gate|up, gelu_tanh) on the down-projection site: dx is d(act(gate) * up);
-        returns d(gate|up) from the same pass instead of writing dx back (ecgb_lora_dx_glu).  There dx may also be a callable that forms the
-        base projection's dy . W when asked: where the four-wave GEMM takes the shape, product, adapter share and GLU backward are one launch
-        (ops.gemm_nn_glu_bwd_lora, the frozen weight passed as glu[2]) and the callable is never called."""
+        returns d(gate|up) from the same pass instead of writing dx back (ecgb_lora_dx_glu).  dx may also be a callable that forms the base
+        projection's dy . W when asked, with `weight` the frozen weight itself: on a single-module site (o, down) where the four-wave GEMM takes
+        the shape, product and adapter share (and the GLU backward) are ONE launch (ops.gemm_nn_lora / ops.gemm_nn_glu_bwd_lora) and the
+        callable is never called."""
         x, xd, t, p, seed = saved
         Bt = model._shadow(("lora_Bt", id(self)), self.B)                 # [64, out]
         At = model._shadow(("lora_At", id(self)), self.A)                 # [in, 64]
@@ -183,10 +184,13 @@ class LoraSite(nn.Module):
         if dx is None:                                                   # the caller needs no input gradient (the bottom layer over frozen embeddings)
             return None
         if callable(dx):
-            if glu is not None and self.n_sub == 1 and len(glu) > 2:
-                d_gu = ops.gemm_nn_glu_bwd_lora(dy, glu[2], glu[0], dt, At, self.scale, p, seed, gelu_tanh=glu[1])
-                if d_gu is not None:
-                    return d_gu
+            if self.n_sub == 1 and weight is not None:
+                if glu is not None:
+                    fused = ops.gemm_nn_glu_bwd_lora(dy, weight, glu[0], dt, At, self.scale, p, seed, gelu_tanh=glu[1])
+                else:
+                    fused = ops.gemm_nn_lora(dy, weight, dt, At, self.scale, p, seed)
+                if fused is not None:
+                    return fused
             dx = dx()
         if glu is not None and self.n_sub == 1:
             return ops.lora_dx_glu(dx, dt, At, glu[0], self.scale, p, seed, gelu_tanh=glu[1])
@@ -1185,7 +1189,7 @@ class HipCausalLM(nn.Module):
                 d_gu = ops.gemm_nn_glu_bwd(g, self.wdown[i].data, gu, gelu_tanh=self.gemma)       # dX of the down projection + GLU backward, one launch
             else:
                 if frozen:                                         # adapters + GLU backward in one pass (with the product itself where the kernel takes the shape)
-                    d_gu = self.lora[i]["down"].backward(g, ls[3], self, lambda: self._dx(g, ("wdown", i), self.wdown[i]), glu=(gu, self.gemma, self.wdown[i].data))
+                    d_gu = self.lora[i]["down"].backward(g, ls[3], self, lambda: self._dx(g, ("wdown", i), self.wdown[i]), glu=(gu, self.gemma), weight=self.wdown[i].data)
                 else:
                     d_hm = self._dx(g, ("wdown", i), self.wdown[i])    # [T, I]
                     d_gu = ops.glu_bwd(gu, d_hm, gelu_tanh=self.gemma)
@@ -1201,9 +1205,10 @@ class HipCausalLM(nn.Module):
             lngrad(self.ln2[i], dw)
             # attention output projection
             wgrad(g2, ao, self.wo[i])
-            d_ao = self._dx(g2, ("wo", i), self.wo[i])             # [T, Hq*D]
-            if frozen:
-                self.lora[i]["o"].backward(g2, ls[1], self, d_ao)
+            if frozen:                                             # [T, Hq*D]: product and adapter share in one launch where the kernel takes the shape
+                d_ao = self.lora[i]["o"].backward(g2, ls[1], self, lambda: self._dx(g2, ("wo", i), self.wo[i]), weight=self.wo[i].data)
+            else:
+                d_ao = self._dx(g2, ("wo", i), self.wo[i])
             # attention core
             if self.fused_attention:
                 d_qkv = ops.attn_bwd(qkv, mask, ao, d_ao, P, B, S, Hq, Hkv, D, scale, rope=(cos, sin))   # RoPE's backward inside (head_dim 64) or behind it

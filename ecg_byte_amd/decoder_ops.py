@@ -478,7 +478,8 @@ _fuse_lora_dx_glu = True
 
 
 def set_fuse_lora_dx_glu(on=True):
-    """A/B switch: the down-projection site's input gradient, adapter share and GLU backward in one launch (gemm_nn_glu_bwd_lora) or as gemm_nn + lora_dx_glu."""
+    """A/B switch: a single-module site's input gradient with the adapter share in the GEMM's epilogue (down: gemm_nn_glu_bwd_lora, with the GLU backward; o:
+    gemm_nn_lora) or as gemm_nn + lora_dx_glu / lora_dx_."""
     global _fuse_lora_dx_glu
     _fuse_lora_dx_glu = bool(on)
 
@@ -500,6 +501,23 @@ def gemm_nn_glu_bwd_lora(dy, w, gate_up, dt, At, scale, p=0.0, seed=0, gelu_tanh
         return None
     _lib.check(rc)
     return d
+
+
+def gemm_nn_lora(dy, w, dt, At, scale, p=0.0, seed=0):
+    """dx [M, in] = bf16(dy @ w) + scale / (1 - p) * mask . (dt A) in ONE launch (ecgb_gemm_nn_lora_bf16: the input gradient of a frozen projection with one LoRA
+    module on it -- gemm_nn followed by lora_dx_, the same bits), or None where the four-wave kernel does not take the shape / the switch is off."""
+    M, K = dy.shape
+    n_in = w.shape[1]
+    assert w.shape[0] == K and dt.shape == (M, 64) and At.shape == (n_in, 64) and dy.stride(1) == 1 and w.stride(1) == 1 and dt.is_contiguous() and At.is_contiguous()
+    if not _fuse_lora_dx_glu:
+        return None
+    dx = torch.empty((M, n_in), dtype=torch.bfloat16, device=dy.device)
+    rc = _L().ecgb_gemm_nn_lora_bf16(_p(_bf(dy)), dy.stride(0), _p(_bf(w)), w.stride(0), _p(_bf(dt)), _p(_bf(At)), _p(dx), dx.stride(0), M, n_in, K,
+                                     float(scale), float(p), int(seed), _st())
+    if rc == -3:                                                         # ECGB_ERR_UNSUPPORTED
+        return None
+    _lib.check(rc)
+    return dx
 
 
 def tn_splits(N, K, M, n_cu=256):

@@ -154,6 +154,10 @@ int ecgb_gemm_nn_glu_bwd_bf16(const void *dy_dev, long long lddy, const void *w_
 int ecgb_gemm_nn_glu_bwd_lora_bf16(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *gate_up_dev, long long ldgu,
                                    const void *dt_dev, const void *at_dev, void *d_gate_up_dev, long long ldd, int M, int inter, int K, int gelu_tanh,
                                    float scale, float p, uint64_t seed, void *stream);
+/* The input gradient of a frozen projection that carries ONE LoRA module (o_proj): dx [M, in] = bf16(dY . W) + scale / (1 - p') * mask . (dt A) in one launch --
+ * ecgb_gemm_nn_bf16 followed by ecgb_lora_dx (n_sub = n_fields = 1), the same bits.  Four-wave kernel only: ECGB_ERR_UNSUPPORTED otherwise (callers take the two calls). */
+int ecgb_gemm_nn_lora_bf16(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *dt_dev, const void *at_dev,
+                           void *dx_dev, long long lddx, int M, int in, int K, float scale, float p, uint64_t seed, void *stream);
 /* ecgb_gemm_nn_bf16 with the contraction cut into n_splits K-slices (few output tiles, a long contraction: the loss head's input gradient dlogits . E over the
  * vocabulary): slice s writes its fp32 partial product to slab s of slabs_dev (n_splits x M x N floats, 16-byte aligned), the slabs are added in slice
  * order into c_dev (bf16, contiguous [M, N]).  No atomics: the same bits every launch. */

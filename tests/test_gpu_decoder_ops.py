@@ -569,6 +569,23 @@ def test_down_site_backward_of_a_lora_fine_tune_in_one_launch_is_bitwise_the_two
         ops.set_fuse_lora_dx_glu(True)
 
 
+@pytest.mark.parametrize("p,seed", [(0.05, 4321), (0.0, 0)])
+@pytest.mark.parametrize("M,N,K", [(32768, 2048, 2048), (16384, 4096, 4096)])
+def test_input_gradient_of_a_single_module_site_in_one_launch_is_bitwise_the_two_kernels(ops, M, N, K, p, seed):
+    """The o projection's input gradient of a LoRA fine-tune: product and adapter share in one launch (ecgb_gemm_nn_lora_bf16) against gemm_nn followed by
+    lora_dx_ (one block): the same bits, every launch; None where the four-wave kernel does not take the shape."""
+    dy, w = _bf(M, K, seed=161), _bf(K, N, scale=K ** -0.5, seed=162)
+    dt, At = _bf(M, 64, scale=0.5, seed=163), _bf(N, 64, scale=0.05, seed=164)
+    dt[:, 16:] = 0
+    At[:, 16:] = 0
+    want = ops.lora_dx_(ops.gemm_nn(dy, w), dt, At, 1, 1, 2.0, p, seed)
+    assert not torch.equal(want, ops.gemm_nn(dy, w))
+    for rep in range(3):
+        got = ops.gemm_nn_lora(dy, w, dt, At, 2.0, p, seed)
+        assert got is not None and torch.equal(got, want), rep
+    assert ops.gemm_nn_lora(dy[:1024], w, dt[:1024], At, 2.0, p, seed) is None
+
+
 def test_single_module_sites_draw_one_hash_per_element_pair_and_the_two_fields_are_independent(ops):
     """A site with one module (o, down) spends one 32-bit hash on elements 2k, 2k + 1 (low and high 16-bit field): the drop rate of even and odd columns is p,
     neighbours are dropped together p^2 of the time (independent fields), another seed gives another mask, and lora_da / lora_dx replay exactly this mask
