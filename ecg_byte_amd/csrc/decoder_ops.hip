@@ -1122,6 +1122,54 @@ extern "C" int ecgb_embed_bwd(const int64_t *ids_dev, const void *dout_dev, floa
     ECGB_CHECK_LAUNCH("embed_bwd");
 }
 
+// The same for H = NC * 512 (2048: both model families): the row stays in registers between the sum of squares and the scaling -- the kernel above reads the
+// residual sum back from memory right after storing it (a fifth more load traffic and a store -> load round trip inside every row) -- and all of the row's loads
+// are in flight at once.  Same arithmetic, same bits.
+template <bool GEMMA, int NC>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_rows_kernel(const unsigned short *a, const unsigned short *b, const unsigned short *w, unsigned short *y,
+                                                               unsigned short *sum_out, float *rstd, size_t rows, float eps)
+{
+    constexpr int H = NC * 512;
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    bf16x8 g[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) g[k] = *reinterpret_cast<const bf16x8 *>(w + k * 512 + lane * 8);
+    for (size_t r = wave; r < rows; r += n_waves) {
+        bf16x8 v[NC], u[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            v[k] = *reinterpret_cast<const bf16x8 *>(a + r * H + k * 512 + lane * 8);
+            if (b) u[k] = *reinterpret_cast<const bf16x8 *>(b + r * H + k * 512 + lane * 8);
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            if (b) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[k][j] = f2bf(bf2f(v[k][j]) + bf2f(u[k][j]));
+                *reinterpret_cast<bf16x8 *>(sum_out + r * H + k * 512 + lane * 8) = v[k];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = bf2f(v[k][j]); ss += f * f; }
+        }
+        ss = wave_sum(ss);
+        const float rs = rsqrtf(ss / (float)H + eps);
+        if (lane == 0 && rstd) rstd[r] = rs;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (GEMMA) o[j] = f2bf(bf2f(v[k][j]) * rs * (1.0f + bf2f(g[k][j])));
+                else o[j] = f2bf(bf2f(f2bf(bf2f(v[k][j]) * rs)) * bf2f(g[k][j]));
+            }
+            *reinterpret_cast<bf16x8 *>(y + r * H + k * 512 + lane * 8) = o;
+        }
+    }
+}
+
 extern "C" int ecgb_embed_bwd_sorted(const int64_t *ids_sorted_dev, const int64_t *order_dev, const void *dout_dev, void *grad_table_dev,
                                     size_t tokens, int hidden, float scale, int64_t skip_id, void *stream)
 {
@@ -1133,11 +1181,24 @@ extern "C" int ecgb_embed_bwd_sorted(const int64_t *ids_sorted_dev, const int64_
     ECGB_CHECK_LAUNCH("embed_bwd_sorted");
 }
 
+namespace { int g_rms_fwd_rows = 1; }
+// A/B switch (tests, tuning): 1 (default) the register-resident forward for hidden 2048, 0 the generic kernel.  Same bits.
+extern "C" int ecgb_set_rmsnorm_fwd_rows(int on) { g_rms_fwd_rows = on ? 1 : 0; return ECGB_OK; }
+
 extern "C" int ecgb_rmsnorm_fwd(const void *x_dev, const void *residual_dev, const void *w_dev, void *y_dev, void *sum_out_dev,
                                 float *rstd_dev, size_t rows, int hidden, float eps, int gemma, void *stream)
 {
     if (hidden % 8 || (residual_dev && !sum_out_dev)) { ecgb::set_error("ecgb_rmsnorm_fwd: bad arguments"); return ECGB_ERR_INVALID; }
     const dim3 grid(grid_for(rows, 4));
+    if (hidden == 2048 && g_rms_fwd_rows) {
+        if (gemma)
+            hipLaunchKernelGGL((rmsnorm_fwd_rows_kernel<true, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x_dev, (const unsigned short *)residual_dev,
+                               (const unsigned short *)w_dev, (unsigned short *)y_dev, (unsigned short *)sum_out_dev, rstd_dev, rows, eps);
+        else
+            hipLaunchKernelGGL((rmsnorm_fwd_rows_kernel<false, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x_dev, (const unsigned short *)residual_dev,
+                               (const unsigned short *)w_dev, (unsigned short *)y_dev, (unsigned short *)sum_out_dev, rstd_dev, rows, eps);
+        ECGB_CHECK_LAUNCH("rmsnorm_fwd");
+    }
     if (gemma)
         hipLaunchKernelGGL(rmsnorm_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x_dev,
                            (const unsigned short *)residual_dev, (const unsigned short *)w_dev, (unsigned short *)y_dev,

@@ -156,6 +156,11 @@ def rmsnorm_fwd(x, w, eps, residual=None, gemma=False, lora=None):
     return y, rstd, (s if residual is not None else x)
 
 
+def set_rmsnorm_fwd_rows(on=True):
+    """A/B switch: rmsnorm_fwd at hidden 2048 with the row kept in registers (default) or the generic kernel.  Same bits."""
+    _lib.check(_L().ecgb_set_rmsnorm_fwd_rows(int(bool(on))))
+
+
 def rmsnorm_bwd(x, w, rstd, dy, dw_f32, dres=None, gemma=False):
     """dx (+ dres) of RMSNorm; dw_f32 [H] receives += the weight gradient, or None: frozen norm weights (LoRA), nothing is computed for them."""
     H = x.shape[-1]

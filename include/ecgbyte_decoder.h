@@ -207,6 +207,8 @@ int ecgb_ce_fwd_bwd(void *logits_dev, const int64_t *labels_dev, float *row_loss
 /* 1 (default): rows with ld <= 163 840 are held in registers by 1 024-thread workgroups -- one read of the logits, one write of the gradient;
  * 0: the three-sweep kernel (maximum, sum, gradient), which wider vocabularies always take.  Same loss and gradients up to the order of the fp32 sums. */
 int ecgb_set_ce_in_registers(int on);
+/* ecgb_rmsnorm_fwd at hidden 2048: 1 (default) the row kept in registers between the sum of squares and the scaling, 0 the generic kernel (A/B, tests).  Same bits. */
+int ecgb_set_rmsnorm_fwd_rows(int on);
 
 /* acc_dev += sum(g^2) */
 int ecgb_sumsq(const void *g_dev, size_t n, int is_fp32, float *acc_dev, void *stream);

@@ -586,6 +586,24 @@ def test_input_gradient_of_a_single_module_site_in_one_launch_is_bitwise_the_two
     assert ops.gemm_nn_lora(dy[:1024], w, dt[:1024], At, 2.0, p, seed) is None
 
 
+@pytest.mark.parametrize("gemma", [False, True])
+@pytest.mark.parametrize("rows,with_residual", [(4096, True), (1000, False), (7, True)])
+def test_rmsnorm_forward_with_the_row_in_registers_is_the_generic_kernel_bit_for_bit(ops, rows, with_residual, gemma):
+    """hidden 2048 (both model families) takes a kernel that keeps the row in registers between the sum of squares and the scaling: y, rstd and the
+    residual sum must be the generic kernel's bits."""
+    x, w = _bf(rows, 2048, seed=171), _bf(2048, scale=0.2, seed=172)
+    res = _bf(rows, 2048, seed=173) if with_residual else None
+    try:
+        ops.set_rmsnorm_fwd_rows(False)
+        want = ops.rmsnorm_fwd(x, w, 1e-6, residual=res, gemma=gemma)
+        ops.set_rmsnorm_fwd_rows(True)
+        got = ops.rmsnorm_fwd(x, w, 1e-6, residual=res, gemma=gemma)
+    finally:
+        ops.set_rmsnorm_fwd_rows(True)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
 def test_single_module_sites_draw_one_hash_per_element_pair_and_the_two_fields_are_independent(ops):
     """A site with one module (o, down) spends one 32-bit hash on elements 2k, 2k + 1 (low and high 16-bit field): the drop rate of even and odd columns is p,
     neighbours are dropped together p^2 of the time (independent fields), another seed gives another mask, and lora_da / lora_dx replay exactly this mask
