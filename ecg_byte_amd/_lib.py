@@ -121,6 +121,7 @@ def lib():
         "ecgb_set_attn_fwd_staging": [ci],
         "ecgb_set_ce_in_registers": [ci],
         "ecgb_set_rmsnorm_fwd_rows": [ci],
+        "ecgb_set_rmsnorm_bwd_rows_per_wg": [ci],
         "ecgb_set_attn_lean_waves": [ci],
         "ecgb_transpose_multi_bf16": [vp, vp, vp, vp, vp, ci, ci, vp],
         "ecgb_embed_bwd_sorted": [vp, vp, vp, vp, sz, ci, f32, C.c_int64, vp],

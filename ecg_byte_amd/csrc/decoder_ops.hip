@@ -1230,10 +1230,19 @@ extern "C" int ecgb_rmsnorm_lora_fwd(const void *x_dev, const void *residual_dev
     ECGB_CHECK_LAUNCH("rmsnorm_lora_fwd");
 }
 
+namespace { int g_rms_bwd_rows_per_wg = 64; }
+// (tuning) rows per workgroup of ecgb_rmsnorm_bwd at hidden 2048 / 4096; changes the scratch size ecgb_rmsnorm_bwd_scratch_floats reports and the order of the dw sum
+extern "C" int ecgb_set_rmsnorm_bwd_rows_per_wg(int n)
+{
+    if (n < 4 || n > 4096) { ecgb::set_error("ecgb_set_rmsnorm_bwd_rows_per_wg: 4..4096"); return ECGB_ERR_INVALID; }
+    g_rms_bwd_rows_per_wg = n;
+    return ECGB_OK;
+}
+
 extern "C" size_t ecgb_rmsnorm_bwd_scratch_floats(size_t rows, int hidden)
 {
     if (hidden != 2048 && hidden != 4096) return std::min<size_t>(std::max<size_t>(1, rows), 4096) * (size_t)hidden;   // one-wave workgroups
-    return std::min<size_t>(std::max<size_t>(1, rows / 64), 1024) * (size_t)hidden;
+    return std::min<size_t>(std::max<size_t>(1, rows / (size_t)g_rms_bwd_rows_per_wg), 2048) * (size_t)hidden;
 }
 
 // dst[c] += sum over b < n_rows of partials[b * ld + c], c < n, in row order (per-workgroup partial sums of a weight / bias gradient)
@@ -1250,7 +1259,7 @@ extern "C" int ecgb_rmsnorm_bwd(const void *x_dev, const void *w_dev, const floa
 {
     if (hidden % 8) { ecgb::set_error("ecgb_rmsnorm_bwd: hidden must be a multiple of 8"); return ECGB_ERR_INVALID; }
     if (hidden == 2048 || hidden == 4096) {   // rows per wave ~16: enough to amortise the end-of-kernel reduction, enough waves to fill the chip
-        const dim3 g2((unsigned)std::min<size_t>(std::max<size_t>(1, rows / 64), 1024));
+        const dim3 g2((unsigned)std::min<size_t>(std::max<size_t>(1, rows / (size_t)g_rms_bwd_rows_per_wg), 2048));
 #define ECGB_RMS_BWD_ROWS(G_, NC_) hipLaunchKernelGGL((rmsnorm_bwd_rows_kernel<G_, NC_>), g2, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x_dev, \
         (const unsigned short *)w_dev, rstd_dev, (const unsigned short *)dy_dev, (const unsigned short *)dres_dev, (unsigned short *)dx_dev, dw_dev, rows, scratch_dev)
         if (hidden == 2048) { if (gemma) ECGB_RMS_BWD_ROWS(true, 4); else ECGB_RMS_BWD_ROWS(false, 4); }

@@ -209,6 +209,8 @@ int ecgb_ce_fwd_bwd(void *logits_dev, const int64_t *labels_dev, float *row_loss
 int ecgb_set_ce_in_registers(int on);
 /* ecgb_rmsnorm_fwd at hidden 2048: 1 (default) the row kept in registers between the sum of squares and the scaling, 0 the generic kernel (A/B, tests).  Same bits. */
 int ecgb_set_rmsnorm_fwd_rows(int on);
+/* (tuning) rows per workgroup of ecgb_rmsnorm_bwd at hidden 2048 / 4096 (default 64; measured at [32768, 2048]: 112 us, 32: 121, 16: 143 -- the partial rows of dw grow): changes what ecgb_rmsnorm_bwd_scratch_floats reports and the order of the dw sum. */
+int ecgb_set_rmsnorm_bwd_rows_per_wg(int n);
 
 /* acc_dev += sum(g^2) */
 int ecgb_sumsq(const void *g_dev, size_t n, int is_fp32, float *acc_dev, void *stream);
