@@ -2097,6 +2097,181 @@ int g_attn_dma = 2;
 // slower end to end at the C3 shape although its tile loop is faster -- scripts/experiments/r03_attn_fwd_pingpong.hip.txt; kept for A-B: ecgb_set_attn_lean_waves)
 int g_lean_waves = 4;
 // forward / dQ lean kernels: HW = gcd(G, waves) query heads of a KV group per workgroup (a power of two), waves / HW blocks of 32 rows
+// =====================================================================================================
+// Round 4: head_dim 256 (Gemma) forward with LDS-DMA staging.  The register-staged kernel above spends more than half of a tile's 10 800 cycles moving the tile
+// (phase timers at the C5 shape: 2 530 issuing the next tile's loads into registers, 1 170 - 2 750 writing them to LDS -- the transposed V image most -- and up to 2 100
+// at the barrier behind the slower half) and keeps its 128 output accumulators in the register file's upper half as spill space of the forced VGPR form (445 registers:
+// a copy out and back around every product).  Here
+//   * K and V tiles (64 keys x 512 bytes each) go global -> LDS by LDS-DMA, 1 KiB (two rows) per wave-instruction, eight pieces per wave and operand, one tile ahead
+//     into a ring of two (a trip is > 4 000 cycles of MFMA: one tile of flight time is enough, and two stages are what 160 KB hold);
+//   * K lies as rows with 16-byte chunk c of row r at c ^ (r & 15): the sixteen rows sixteen lanes read as fragments fall on sixteen different bank groups;
+//     V lies as it is in memory ([key][d]) with its 64-byte group w of key row r at w ^ (r & 7): the P.V operand is gathered by transposing reads whose eight key rows
+//     then cover eight different groups.  Both swizzles are applied on the global side of the DMA;
+//   * all LDS reads are asm statements with their own wait (a read hipcc can see next to LDS-DMA gets a vmcnt(0) in front of it);
+//   * without the staging registers the kernel needs 328 registers instead of 445: 72 values live in the upper half between uses instead of 189.  (The P.V products written
+//     out as asm statements on "+a" accumulators kept all 128 there, ran at the same speed and were WRONG now and then in output columns 0..31 -- a wait-state rule between
+//     the statement's first MFMA and what hipcc places in front of it that 32 s_nops narrowed but did not close: the builtin stays.)
+// The softmax arithmetic is attn_fwd_kernel's (running maximum per tile, scores scaled inside the exp2's fma): the same values up to the order of the fp32 sums.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void attn_fwd_d256_kernel(AttnArgs A)
+{
+    constexpr int D = 256, kRow = D * 2, kTile = 64 * kRow, PPW = 8;      // bytes of a row / of a 64-key tile; 1 KiB pieces per wave and operand and tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x (K, V) tiles, the row's key mask, 64 tile flags
+    float *lds_maskrow = reinterpret_cast<float *>(smem + 4 * kTile);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
+    int qblk, head_in, group;
+    map_block((int)blockIdx.x, (A.S + 127) / 128, A.Hq / A.Hkv, A.B * A.Hkv, true, qblk, head_in, group);
+    const int b = group / A.Hkv, g = group % A.Hkv, hq = g * (A.Hq / A.Hkv) + head_in;
+    const int q0 = qblk * 128, qw0 = q0 + wave * 32;
+    const int qi = qw0 + lr;
+    const bool qvalid = qi < A.S;
+    const long long rowbase = (long long)b * A.S;
+    const unsigned short *Q = A.q + (long long)hq * D, *K = A.k + (long long)g * D, *V = A.v + (long long)g * D;
+    const int k_end = min(A.S, q0 + 128);
+    const int wave_qmax = qw0 + 31;
+    const int last_tile = (k_end - 1) / 64;
+    const int tail_rows = A.S - last_tile * 64;                           // rows of the last tile that exist (64: whole)
+    // piece i of this wave: tile rows (wave * 8 + i) * 2 + (lane >> 5), the lane's 16-byte slot lane & 31 of the LDS row takes global chunk slot ^ swizzle(row)
+    unsigned offK[PPW], offV[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int r = (wave * PPW + i) * 2 + (lane >> 5), slot = lane & 31;
+        offK[i] = (unsigned)(((long long)r * A.ldk + (slot ^ (r & 15)) * 8) * 2);
+        offV[i] = (unsigned)(((long long)r * A.ldv + (slot ^ ((r & 7) << 2)) * 8) * 2);
+    }
+    const unsigned char *kb_next = reinterpret_cast<const unsigned char *>(K + rowbase * A.ldk), *vb_next = reinterpret_cast<const unsigned char *>(V + rowbase * A.ldv);
+    const long long stepK = 128ll * A.ldk, stepV = 128ll * A.ldv;
+    int t_next = 0;
+    unsigned slot_next = 0;
+    auto issue_next = [&]() {                                             // UNCONDITIONAL (past the last tile the last one is issued again)
+        if (t_next == last_tile && tail_rows < 64) {                      // (uniform, once per workgroup at most) rows past the last key re-read it: masked as keys >= S
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const int r = (wave * PPW + i) * 2 + (lane >> 5), slot = lane & 31, rt = min(r, tail_rows - 1);
+                const unsigned ok = (unsigned)(((long long)rt * A.ldk + (slot ^ (r & 15)) * 8) * 2), ov = (unsigned)(((long long)rt * A.ldv + (slot ^ ((r & 7) << 2)) * 8) * 2);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb_next + ok),
+                                                 (__attribute__((address_space(3))) void *)(smem + slot_next + (wave * PPW + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb_next + ov),
+                                                 (__attribute__((address_space(3))) void *)(smem + slot_next + kTile + (wave * PPW + i) * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb_next + offK[i]),
+                                                 (__attribute__((address_space(3))) void *)(smem + slot_next + (wave * PPW + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb_next + offV[i]),
+                                                 (__attribute__((address_space(3))) void *)(smem + slot_next + kTile + (wave * PPW + i) * 1024), 16, 0, 0);
+            }
+        }
+        if (t_next < last_tile) { ++t_next; kb_next += stepK; vb_next += stepV; }
+        slot_next ^= 2 * kTile;
+    };
+    issue_next();
+    bf16x8 qf[D / 16];
+    load_row_frags<D>(qf, Q, A.ldq, rowbase + qi, qvalid, h);
+    lean_fill_mask<4>(lds_maskrow, A.mask + rowbase, A.S, (k_end + 63) & ~63);
+    f32x16 accO[D / 32];
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db) accO[db] = splat16(0.f);
+    float m = -INFINITY, l = 0.f;
+    const float sc = A.scale * kLog2e;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // tile 0 and Q
+    __syncthreads();
+    const unsigned long long padbits = lean_pad_bits(lds_maskrow, (k_end + 63) & ~63);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    // this lane's K row fragment (key lr, k-step 0) inside a K image: k-step ks is the address ^ (ks << 5), key 32 + lr 16 KiB further (the swizzle repeats every 16 rows)
+    const unsigned kbase = lr * kRow + ((h ^ (lr & 15)) << 4);      // (an offset: the XORs below must not see the LDS base)
+    // this lane's first transposing read inside a V image for d block 0: block db is the address ^ (db << 6), the second read 8 keys = 4 KiB further, the (kb, s2) row groups go
+    // into the offset field
+    unsigned vbase;
+    {
+        const int a = lr >> 4, q = (lr & 15) >> 2, p = lr & 3;
+        const int key = 4 * h + q;
+        vbase = key * kRow + ((((key & 7) << 2) | (2 * a + (p >> 1))) << 4) + (p & 1) * 8;
+    }
+    unsigned img = 0;                                                     // byte offset of the current tile's ring slot
+    for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
+        issue_next();                                                     // tile it + 1 into the other slot (its readers passed the barrier that ended the previous trip)
+        const float *lds_mask = lds_maskrow + k0;
+        if (k0 <= wave_qmax) {
+            const bool need_mask = (k0 + 63 > qw0) || lean_tile_padded(padbits, it);
+            f32x16 sacc[2] = {splat16(0.f), splat16(0.f)};
+#pragma unroll
+            for (int ks = 0; ks < D / 16; ks += 2) {                      // eight batches of four fragments (two k-steps x two key halves) and their four products
+                bf16x8 f00, f01, f10, f11;
+                lds_frags2x2_wait<0, 32 * kRow>(f00, f01, f10, f11, (kbase ^ (unsigned)(ks << 5)) + img + lds0, (kbase ^ (unsigned)((ks + 1) << 5)) + img + lds0);
+                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f00, qf[ks], sacc[0], 0, 0, 0);
+                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f01, qf[ks], sacc[1], 0, 0, 0);
+                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f10, qf[ks + 1], sacc[0], 0, 0, 0);
+                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f11, qf[ks + 1], sacc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float p[2][16];
+            float tmax = -INFINITY;
+            if (need_mask) {                                              // (uniform) the tile touches this wave's diagonal or holds padded keys
+                f4v mv[2][4];
+                const unsigned ma = (unsigned)(size_t)(__attribute__((address_space(3))) float *)const_cast<float *>(lds_mask) + 16 * h;
+                lds_rows4_wait<0>(mv[0], ma);
+                lds_rows4_wait<128>(mv[1], ma);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;       // key inside the tile
+                        const bool vis = (k0 + kl <= qi) & (mv[kb][r >> 2][r & 3] != 0.f);
+                        const float v = vis ? sacc[kb][r] : -INFINITY;
+                        p[kb][r] = v;
+                        tmax = fmaxf(tmax, v);
+                    }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { p[kb][r] = sacc[kb][r]; tmax = fmaxf(tmax, sacc[kb][r]); }
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sc;            // p holds raw scores; sc > 0, so the maximum scales with them
+            const float m_new = fmaxf(m, tmax);
+            const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;      // no key visible yet: every p below is exp2(-inf) = 0
+            const float alpha = fast_exp2(m - m_safe);                    // m = -inf -> 0 (accumulators are still zero then)
+            float lsum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float e = fast_exp2(__builtin_fmaf(p[kb][r], sc, -m_safe)); p[kb][r] = e; lsum += e; }
+            l = l * alpha + lsum;
+            m = m_new;
+            if (__any(alpha != 1.f)) {                                    // once the running maxima have settled the accumulators need no rescale
+#pragma unroll
+                for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accO[db][r] *= alpha;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x8 pf0 = frag_from_acc(&p[kb][0]), pf1 = frag_from_acc(&p[kb][8]);
+#pragma unroll
+                for (int dp = 0; dp < D / 64; ++dp) {                     // pairs of d blocks: four transposed fragments (two k-steps x two blocks) and their four products
+                    bf16x8 vfr[2][2];
+                    const unsigned a0 = (vbase ^ (unsigned)((2 * dp) << 6)) + img + lds0 + kTile, a1 = (vbase ^ (unsigned)((2 * dp + 1) << 6)) + img + lds0 + kTile;
+                    if (kb == 0) tr_frags4_wait<0, 16 * kRow>(vfr, a0, a0 + 8 * kRow, a1, a1 + 8 * kRow);
+                    else tr_frags4_wait<32 * kRow, 48 * kRow>(vfr, a0, a0 + 8 * kRow, a1, a1 + 8 * kRow);
+                    accO[2 * dp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[0][0], pf0, accO[2 * dp], 0, 0, 0);
+                    accO[2 * dp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[0][1], pf0, accO[2 * dp + 1], 0, 0, 0);
+                    accO[2 * dp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[1][0], pf1, accO[2 * dp], 0, 0, 0);
+                    accO[2 * dp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[1][1], pf1, accO[2 * dp + 1], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's pieces of tile it + 1 have landed
+        __builtin_amdgcn_s_barrier();                                     // ... and everybody else's; all reads of tile it are done
+        img ^= 2 * kTile;
+    }
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    store_accT<D / 32>(accO, A.o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h, inv);
+    if (qvalid && h == 0) A.lse[((long long)b * A.Hq + hq) * A.S + qi] = lt > 0.f ? m + log2f(lt) : INFINITY;
+}
+
 struct LeanGeom { int hw_log2; unsigned grid; };
 LeanGeom lean_geom(int seq, int n_q_heads, int n_kv_heads, int batch)
 {
@@ -2176,6 +2351,11 @@ extern "C" int ecgb_attn_fwd(const void *q_dev, long long ldq, const void *k_dev
         return launch_attn(attn_fwd_kernel<64>, grid, dim3(256), 4 * 128 * 64 + 4 * ((seq + 63) & ~63), stream, A, "attn_fwd_kernel<64>");
     }
     if (head_dim == 128) return launch_attn(attn_fwd_kernel<128>, grid, dim3(256), 4 * 128 * 128 + 4 * ((seq + 63) & ~63), stream, A, "attn_fwd_kernel<128>");
+    // head_dim 256: LDS-DMA staging (round 4) where its two-stage ring, the key mask and the tile flags fit the CU's 160 KB and the per-lane DMA offsets 32 bits; mode 0 of
+    // ecgb_set_attn_fwd_staging keeps the register-staged kernel (A/B, tests)
+    const long long lds256 = 4ll * 64 * 512 + 4ll * ((seq + 63) & ~63) + 256;
+    if ((g_attn_dma & 3) && lds256 <= 160 * 1024 && (ldk & 7) == 0 && (ldv & 7) == 0 && (((uintptr_t)k_dev | (uintptr_t)v_dev) & 15) == 0 && 64 * ldk * 2 + 512 <= 0xFFFFFFFFll && 64 * ldv * 2 + 512 <= 0xFFFFFFFFll)
+        return launch_attn(attn_fwd_d256_kernel, grid, dim3(256), (int)lds256, stream, A, "attn_fwd_d256_kernel");
     return launch_attn(attn_fwd_kernel<256>, grid, dim3(256), 4 * 128 * 256 + 4 * ((seq + 63) & ~63), stream, A, "attn_fwd_kernel<256>");
 }
 

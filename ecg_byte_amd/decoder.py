@@ -1178,7 +1178,10 @@ class HipCausalLM(nn.Module):
             if not frozen:
                 self._vgrad(param, dw32)
 
-        dw = None if frozen else torch.zeros(H, dtype=torch.float32, device=dev)        # frozen norm weights (LoRA): no weight gradient is computed
+        # fp32 rows for the norm weights' gradients: ONE zero fill per step (a fill per norm was 33 launches of a few microseconds each on a queue that is never empty);
+        # frozen norm weights (LoRA): no weight gradient is computed
+        dw_rows = None if frozen else iter(torch.zeros((2 * c.num_hidden_layers + 1, H), dtype=torch.float32, device=dev).unbind(0))
+        dw = None if frozen else next(dw_rows)
         g = ops.rmsnorm_bwd(xf, self.norm.data, rstdf, dhf, dw, gemma=self.gemma)          # grad of the residual stream
         lngrad(self.norm, dw)
         for i in reversed(range(c.num_hidden_layers)):
@@ -1200,7 +1203,7 @@ class HipCausalLM(nn.Module):
             if frozen:
                 self.lora[i]["gu"].backward(d_gu, ls[2], self, d_h2)
             del d_gu, gu
-            dw = None if frozen else torch.zeros(H, dtype=torch.float32, device=dev)
+            dw = None if frozen else next(dw_rows)
             g2 = ops.rmsnorm_bwd(x2, self.ln2[i].data, rstd2, d_h2, dw, dres=g, gemma=self.gemma)
             lngrad(self.ln2[i], dw)
             # attention output projection
@@ -1222,7 +1225,7 @@ class HipCausalLM(nn.Module):
             if frozen:
                 self.lora[i]["qkv"].backward(d_qkv, ls[0], self, d_h1)
             if not bottom:
-                dw = None if frozen else torch.zeros(H, dtype=torch.float32, device=dev)
+                dw = None if frozen else next(dw_rows)
                 g = ops.rmsnorm_bwd(x1, self.ln1[i].data, rstd1, d_h1, dw, dres=g2, gemma=self.gemma)
                 lngrad(self.ln1[i], dw)
             if self.grad_sync is not None:   # this layer's gradients are final: its range of the flat buffer may leave

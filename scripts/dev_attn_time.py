@@ -1,4 +1,5 @@
-"""Dev-only: the head_dim-64 attention kernels at the C3 shape (32 x 1024 tokens, 32 / 8 heads), forward and backward apart, HIP events, interleaved rounds.
+"""Dev-only: the attention kernels at the C3 shape (32 x 1024 tokens, 32 / 8 heads of 64; SHAPE=B,S,Hq,Hkv,D for another), forward and backward apart, HIP events,
+interleaved rounds.
 Usage: dev_attn_time.py [waves ...]   (lean workgroup widths to compare, default 4)
 ECGB_SO_B=<file in ecg_byte_amd/>: a second build of the library loaded beside the shipped one and timed in the same rounds (boxes differ by 5 %: only an
 in-process A/B can see a 3 % change); its outputs are compared with the first build's."""
@@ -8,7 +9,7 @@ import torch
 from ecg_byte_amd import _lib
 from ecg_byte_amd import decoder_ops as ops
 
-D, B, S, Hq, Hkv = 64, 32, 1024, 32, 8
+B, S, Hq, Hkv, D = [int(v) for v in os.environ.get("SHAPE", "32,1024,32,8,64").split(",")]      # SHAPE=8,2048,8,1,256: the C5 shape
 scale = 1 / math.sqrt(D)
 libs = {"A": _lib.lib()}
 if os.environ.get("ECGB_SO_B"):
