@@ -2272,6 +2272,159 @@ __global__ __launch_bounds__(256) void attn_fwd_d256_kernel(AttnArgs A)
     if (qvalid && h == 0) A.lse[((long long)b * A.Hq + hq) * A.S + qi] = lt > 0.f ? m + log2f(lt) : INFINITY;
 }
 
+// head_dim 256 dQ with LDS-DMA staging (round 4): the register-staged kernel writes three images per tile (K as rows, K transposed, V as rows) between two
+// barriers.  Here K and V land once each, as they lie in memory, in a two-stage ring; ONE swizzle serves the row fragments of both (S = K . Q^T, dP = V . dO^T) and the
+// transposing reads of K (dQ += dS . K): 16-byte chunk c of row r lies at c ^ f(r), f(r) = (r & 3) << 2 | (r >> 2) & 3 -- sixteen consecutive rows put one chunk on sixteen
+// different bank groups (f is a bijection of the row's low four bits), and the eight key rows of a transposing read put one 64-byte group on all four 64-byte positions of
+// the bank cycle, twice each (the group index moves with r & 3).  attn_bwd_dq_kernel's arithmetic in its order: the same bits.
+__device__ __forceinline__ int swz_f256(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+__global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
+{
+    constexpr int D = 256, kRow = D * 2, kTile = 64 * kRow, PPW = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x (K, V) tiles, the row's key mask, 64 tile flags
+    float *lds_maskrow = reinterpret_cast<float *>(smem + 4 * kTile);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
+    int qblk, head_in, group;
+    map_block((int)blockIdx.x, (A.S + 127) / 128, A.Hq / A.Hkv, A.B * A.Hkv, true, qblk, head_in, group);
+    const int b = group / A.Hkv, g = group % A.Hkv, hq = g * (A.Hq / A.Hkv) + head_in;
+    const int q0 = qblk * 128, qw0 = q0 + wave * 32;
+    const int qi = qw0 + lr;
+    const bool qvalid = qi < A.S;
+    const long long rowbase = (long long)b * A.S;
+    const unsigned short *Q = A.q + (long long)hq * D, *K = A.k + (long long)g * D, *V = A.v + (long long)g * D;
+    const int k_end = min(A.S, q0 + 128);
+    const int wave_qmax = qw0 + 31;
+    const int last_tile = (k_end - 1) / 64;
+    const int tail_rows = A.S - last_tile * 64;
+    unsigned offK[PPW], offV[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int r = (wave * PPW + i) * 2 + (lane >> 5), slot = lane & 31;
+        offK[i] = (unsigned)(((long long)r * A.ldk + (slot ^ swz_f256(r)) * 8) * 2);
+        offV[i] = (unsigned)(((long long)r * A.ldv + (slot ^ swz_f256(r)) * 8) * 2);
+    }
+    const unsigned char *kb_next = reinterpret_cast<const unsigned char *>(K + rowbase * A.ldk), *vb_next = reinterpret_cast<const unsigned char *>(V + rowbase * A.ldv);
+    const long long stepK = 128ll * A.ldk, stepV = 128ll * A.ldv;
+    int t_next = 0;
+    unsigned slot_next = 0;
+    auto issue_next = [&]() {                                             // (see attn_fwd_d256_kernel)
+        if (t_next == last_tile && tail_rows < 64) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const int r = (wave * PPW + i) * 2 + (lane >> 5), slot = lane & 31, rt = min(r, tail_rows - 1);
+                const unsigned ok = (unsigned)(((long long)rt * A.ldk + (slot ^ swz_f256(r)) * 8) * 2), ov = (unsigned)(((long long)rt * A.ldv + (slot ^ swz_f256(r)) * 8) * 2);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb_next + ok),
+                                                 (__attribute__((address_space(3))) void *)(smem + slot_next + (wave * PPW + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb_next + ov),
+                                                 (__attribute__((address_space(3))) void *)(smem + slot_next + kTile + (wave * PPW + i) * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb_next + offK[i]),
+                                                 (__attribute__((address_space(3))) void *)(smem + slot_next + (wave * PPW + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb_next + offV[i]),
+                                                 (__attribute__((address_space(3))) void *)(smem + slot_next + kTile + (wave * PPW + i) * 1024), 16, 0, 0);
+            }
+        }
+        if (t_next < last_tile) { ++t_next; kb_next += stepK; vb_next += stepV; }
+        slot_next ^= 2 * kTile;
+    };
+    issue_next();
+    bf16x8 qf[D / 16], dof[D / 16];
+    float delta = 0.f;
+    {
+        bf16x8 of[D / 16];
+        load_row_frags<D>(qf, Q, A.ldq, rowbase + qi, qvalid, h);
+        load_row_frags<D>(dof, A.d_o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h);
+        load_row_frags<D>(of, A.o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h);
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) delta += bf2f((unsigned short)dof[ks][j]) * bf2f((unsigned short)of[ks][j]);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const long long stat = ((long long)b * A.Hq + hq) * A.S + qi;
+    if (qvalid && h == 0) A.delta[stat] = delta;
+    const float lse = qvalid ? A.lse[stat] : INFINITY;
+    f32x16 accQ[D / 32];
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db) accQ[db] = splat16(0.f);
+    const float sc = A.scale * kLog2e;
+    lean_fill_mask<4>(lds_maskrow, A.mask + rowbase, A.S, (k_end + 63) & ~63);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // tile 0 and the row operands
+    __syncthreads();
+    const unsigned long long padbits = lean_pad_bits(lds_maskrow, (k_end + 63) & ~63);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    // this lane's row fragment (row lr, k-step 0) inside an image, as an offset: k-step ks is the offset ^ (ks << 5); row 32 + lr 16 KiB further; the V image kTile further
+    const unsigned rbase = lr * kRow + ((h ^ swz_f256(lr)) << 4);
+    // this lane's transposing reads inside a K image for d block 0, first (key 4 h + q) and second (8 keys further: f moves with bit 3 of the row): block db is the offset ^ (db << 6)
+    unsigned tbaseA, tbaseB;
+    {
+        const int a = lr >> 4, q = (lr & 15) >> 2, p = lr & 3;
+        const int cg = 2 * a + (p >> 1);                                 // 16-byte chunk inside the 64-byte group
+        const int k1 = 4 * h + q, k2 = k1 + 8;
+        tbaseA = k1 * kRow + ((((k1 & 3) << 2) | (cg ^ ((k1 >> 2) & 3))) << 4) + (p & 1) * 8;
+        tbaseB = k2 * kRow + ((((k2 & 3) << 2) | (cg ^ ((k2 >> 2) & 3))) << 4) + (p & 1) * 8;
+    }
+    unsigned img = 0;
+    for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
+        issue_next();
+        const float *lds_mask = lds_maskrow + k0;
+        if (k0 <= wave_qmax) {
+            const bool need_mask = (k0 + 63 > qw0) || lean_tile_padded(padbits, it);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x16 s = splat16(0.f), dp = splat16(0.f);
+#pragma unroll
+                for (int ks = 0; ks < D / 16; ks += 2) {                  // K and V fragments of two k-steps (the images side by side, kTile apart) and their four products
+                    bf16x8 kf0, vf0, kf1, vf1;
+                    const unsigned a0 = (rbase ^ (unsigned)(ks << 5)) + img + lds0, a1 = (rbase ^ (unsigned)((ks + 1) << 5)) + img + lds0;
+                    if (kb == 0) lds_frags2x2_wait<0, kTile>(kf0, vf0, kf1, vf1, a0, a1);
+                    else lds_frags2x2_wait<32 * kRow, kTile + 32 * kRow>(kf0, vf0, kf1, vf1, a0, a1);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, dof[ks], dp, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks + 1], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, dof[ks + 1], dp, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                float ds[16];
+                if (need_mask) {
+                    f4v mv[4];
+                    const unsigned ma = (unsigned)(size_t)(__attribute__((address_space(3))) float *)const_cast<float *>(lds_mask) + 16 * h;
+                    if (kb == 0) lds_rows4_wait<0>(mv, ma); else lds_rows4_wait<128>(mv, ma);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const bool vis = (k0 + kl <= qi) & (mv[r >> 2][r & 3] != 0.f);
+                        const float pr = vis ? fast_exp2(__builtin_fmaf(s[r], sc, -lse)) : 0.f;
+                        ds[r] = pr * (dp[r] - delta) * A.scale;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(__builtin_fmaf(s[r], sc, -lse)) * (dp[r] - delta) * A.scale;
+                }
+                const bf16x8 dsf0 = frag_from_acc(&ds[0]), dsf1 = frag_from_acc(&ds[8]);
+#pragma unroll
+                for (int dpair = 0; dpair < D / 64; ++dpair) {            // pairs of d blocks: four transposed K fragments (two k-steps x two blocks) and their four products
+                    bf16x8 ktf[2][2];
+                    const unsigned x0 = (unsigned)((2 * dpair) << 6), x1 = (unsigned)((2 * dpair + 1) << 6);
+                    if (kb == 0) tr_frags4_wait<0, 16 * kRow>(ktf, (tbaseA ^ x0) + img + lds0, (tbaseB ^ x0) + img + lds0, (tbaseA ^ x1) + img + lds0, (tbaseB ^ x1) + img + lds0);
+                    else tr_frags4_wait<32 * kRow, 48 * kRow>(ktf, (tbaseA ^ x0) + img + lds0, (tbaseB ^ x0) + img + lds0, (tbaseA ^ x1) + img + lds0, (tbaseB ^ x1) + img + lds0);
+                    accQ[2 * dpair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][0], dsf0, accQ[2 * dpair], 0, 0, 0);
+                    accQ[2 * dpair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][1], dsf0, accQ[2 * dpair + 1], 0, 0, 0);
+                    accQ[2 * dpair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][0], dsf1, accQ[2 * dpair], 0, 0, 0);
+                    accQ[2 * dpair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][1], dsf1, accQ[2 * dpair + 1], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        img ^= 2 * kTile;
+    }
+    store_accT<D / 32>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, 1.f);
+}
+
 struct LeanGeom { int hw_log2; unsigned grid; };
 LeanGeom lean_geom(int seq, int n_q_heads, int n_kv_heads, int batch)
 {
@@ -2437,7 +2590,12 @@ int attn_bwd_impl(const void *q_dev, long long ldq, const void *k_dev, long long
         if (rc) return rc;
         return launch_attn(attn_bwd_dkv_kernel<128, 1, 0>, dim3(gk), dim3(256), 4 * 128 * 128 + 512, stream, A, "attn_bwd_dkv_kernel<128>");
     }
-    rc = dq_generic(attn_bwd_dq_kernel<256>, 256, "attn_bwd_dq_kernel<256>");
+    // head_dim 256: LDS-DMA staging where the two-stage ring fits (see ecgb_attn_fwd); mode 0 of ecgb_set_attn_fwd_staging keeps the register-staged kernels
+    const long long lds256 = 4ll * 64 * 512 + 4ll * ((seq + 63) & ~63) + 256;
+    const bool dma256 = (g_attn_dma & 3) && lds256 <= 160 * 1024 && (ldk & 7) == 0 && (ldv & 7) == 0 && (((uintptr_t)k_dev | (uintptr_t)v_dev) & 15) == 0 &&
+                        64 * ldk * 2 + 512 <= 0xFFFFFFFFll && 64 * ldv * 2 + 512 <= 0xFFFFFFFFll;
+    if (dma256) rc = launch_attn(attn_bwd_dq_d256_kernel, gq, dim3(256), (int)lds256, stream, A, "attn_bwd_dq_d256_kernel");
+    else rc = dq_generic(attn_bwd_dq_kernel<256>, 256, "attn_bwd_dq_kernel<256>");
     if (rc) return rc;
     rc = launch_attn(attn_bwd_dkv_pair_kernel<256>, dim3(gk * 2 * (unsigned)A.head_splits), dim3(256), 4 * 128 * 256 + 512, stream, A, "attn_bwd_dkv_pair_kernel<256>");
     if (rc) return rc;
