@@ -106,6 +106,33 @@ def test_attention_dma_staging_is_bitwise_the_register_staging(B, S, Hq, Hkv, pa
         ops.set_attn_fwd_staging(2)
 
 
+@pytest.mark.parametrize("B,S,Hq,Hkv,pads", [(8, 2048, 8, 1, True), (8, 2048, 8, 1, False), (2, 300, 4, 2, True), (3, 70, 2, 1, True), (1, 4096, 2, 1, True)],
+                         ids=["c5-pads", "c5", "ragged-gqa", "short", "long"])
+def test_head_dim_256_attention_dma_staging_is_bitwise_the_register_staging(B, S, Hq, Hkv, pads):
+    """Gemma's head_dim 256 (round 4): forward, dQ and the dK / dV pair take their tiles by LDS-DMA into a two-stage ring, one image per tile read both ways; the
+    register-staged kernels (ecgb_set_attn_fwd_staging(0)) are the check -- same arithmetic in the same order, so the same bits, on a full chip and on every launch
+    (a read of a tile that has not landed, or a swizzle that sends a lane to the wrong chunk, would show).  Ragged ends exercise the tiles DMA cannot zero-fill."""
+    from ecg_byte_amd import decoder_ops as ops
+    D = 256
+    qkv, do = _bf(B * S, (Hq + 2 * Hkv) * D, seed=64), _bf(B * S, Hq * D, seed=65)
+    mask = torch.ones(B, S, device="cuda")
+    if pads:
+        for b in range(B):
+            mask[b, : (37 * b + 5) % (S // 2)] = 0
+    try:
+        ops.set_attn_fwd_staging(0)
+        o0, l0 = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, 1 / 16)
+        d0 = ops.attn_bwd(qkv, mask, o0, do, l0, B, S, Hq, Hkv, D, 1 / 16)
+        ops.set_attn_fwd_staging(2)
+        for rep in range(3):
+            o1, l1 = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, 1 / 16)
+            assert torch.equal(o0, o1) and torch.equal(l0, l1), rep
+            d1 = ops.attn_bwd(qkv, mask, o0, do, l0, B, S, Hq, Hkv, D, 1 / 16)
+            assert torch.equal(d0, d1), (rep, (d0.float() - d1.float()).abs().max().item())
+    finally:
+        ops.set_attn_fwd_staging(2)
+
+
 def _attn_ref_fp64(qkv, do, mask, B, S, Hq, Hkv, D, scale):
     """softmax(q k^T * scale + causal / padding mask) v and its gradients in float64 on the device, one batch row at a time."""
     q, k, v = qkv.view(B, S, Hq + 2 * Hkv, D).double().split([Hq, Hkv, Hkv], dim=2)
