@@ -1,5 +1,5 @@
 """Dev-only: the C3 train step (Llama-3.2-1B dims, seq 1024, batch 32, synthetic ids) with a switch flipped between rounds in ONE process -- boxes differ by 2 %,
-an A/B across gpurun calls cannot see 1 ms.  Usage: dev_train_ab.py [w4|rope_bwd|r4sched|r4dispatch|r4all|lora_dx] [lora]
+an A/B across gpurun calls cannot see 1 ms.  Usage: dev_train_ab.py [w4|rope_bwd|rope_fwd|r4sched|r4dispatch|r4all|lora_dx] [lora]
 (r4sched: the four-wave kernel's round-3 / round-4 K-tile schedule; r4dispatch: its dispatch threshold 256 / 128 K-tiles per workgroup; r4all: both; lora_dx: the down site's product + adapter share + GLU backward in one launch, LoRA only)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,7 +29,7 @@ def step():
 def r4sched(on): ops.set_gemm_w4_sched(1 if on else 0)
 def r4dispatch(on): ops.set_gemm_w4_min_ktiles(128 if on else 256)
 def r4all(on): r4sched(on); r4dispatch(on)
-switch = {"w4": ops.set_gemm_w4, "rope_bwd": ops.set_attn_bwd_rope_fusion, "r4sched": r4sched, "r4dispatch": r4dispatch, "r4all": r4all, "lora_dx": ops.set_fuse_lora_dx_glu}[what]
+switch = {"w4": ops.set_gemm_w4, "rope_bwd": ops.set_attn_bwd_rope_fusion, "r4sched": r4sched, "r4dispatch": r4dispatch, "r4all": r4all, "lora_dx": ops.set_fuse_lora_dx_glu, "rope_fwd": ops.set_gemm_rope_fusion}[what]
 for _ in range(3): step()
 res = {False: [], True: []}
 for rnd in range(4):
