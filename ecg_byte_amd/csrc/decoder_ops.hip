@@ -1122,6 +1122,7 @@ extern "C" int ecgb_embed_bwd(const int64_t *ids_dev, const void *dout_dev, floa
     ECGB_CHECK_LAUNCH("embed_bwd");
 }
 
+namespace {
 // The same for H = NC * 512 (2048: both model families): the row stays in registers between the sum of squares and the scaling -- the kernel above reads the
 // residual sum back from memory right after storing it (a fifth more load traffic and a store -> load round trip inside every row) -- and all of the row's loads
 // are in flight at once.  Same arithmetic, same bits.
@@ -1169,6 +1170,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_rows_kernel(const unsigned sh
         }
     }
 }
+}  // namespace
 
 extern "C" int ecgb_embed_bwd_sorted(const int64_t *ids_sorted_dev, const int64_t *order_dev, const void *dout_dev, void *grad_table_dev,
                                     size_t tokens, int hidden, float scale, int64_t skip_id, void *stream)
