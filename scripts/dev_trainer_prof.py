@@ -1,0 +1,15 @@
+"""Dev-only: the tokenizer trainer on the C2 corpus shape (2 000 synthetic records of 12 x 5000, 4 000 merges), for rocprofv3 --kernel-trace --stats."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from ecg_byte_amd.trainer import bpe_train_device
+rng = np.random.default_rng(1)
+n = 2000 * 12 * 5000
+# a random walk over 26 symbols: neighbouring samples differ by at most one level, like a quantised ECG
+steps = rng.integers(-1, 2, size=n, dtype=np.int8)
+sym = np.clip(np.cumsum(steps) % 52, 0, 51); sym = np.where(sym > 25, 51 - sym, sym).astype(np.uint8)
+text = torch.from_numpy(sym + 97).cuda()
+for rep in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ids, n_ids, pairs, n_done = bpe_train_device(text, 4000)
+    torch.cuda.synchronize(); print(f"{time.perf_counter() - t0:.3f} s, merges {int(n_done.item())}, ids {int(n_ids.item())}")
