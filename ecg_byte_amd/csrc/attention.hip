@@ -1170,6 +1170,13 @@ __device__ __forceinline__ void scale_row_frags(bf16x8 (&f)[4], float mul)
         f[ks] = __builtin_bit_cast(bf16x8, w);
     }
 }
+// the fragments negated (exact: the sign bit of each bf16): one XOR per dword where scale_row_frags(f, -1.f) spent an unpack, a multiply and a pack on every pair
+__device__ __forceinline__ void negate_row_frags(bf16x8 (&f)[4])
+{
+    using u4 = __attribute__((ext_vector_type(4))) unsigned;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f[ks] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u4, f[ks]) ^ 0x80008000u);
+}
 __device__ __forceinline__ f32x16 splat16(float v)
 {
     f32x16 r;
@@ -1522,7 +1529,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_lean_kernel(AttnArgs A
     if (qvalid && h == 0) A.delta[stat] = delta;
     const float lse = qvalid ? A.lse[stat] : INFINITY;
     scale_row_frags(qf, -A.scale * kLog2e);
-    scale_row_frags(dof, -1.f);
+    negate_row_frags(dof);
     const f32x16 lseC = splat16(lse), delC = splat16(delta);
     f32x16 accQ[2] = {splat16(0.f), splat16(0.f)};
     lean_fill_mask<NW>(lds_maskrow, A.mask + rowbase, A.S, (k_end + 63) & ~63);
@@ -1666,7 +1673,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_lean_kernel(AttnArgs 
     load_row_frags<D>(vf, A.v + (long long)g * D, A.ldv, rowbase + ki, kvalid, h);
     const bool kvis = kvalid && A.mask[rowbase + (kvalid ? ki : 0)] != 0.f;
     scale_row_frags(kf, -A.scale * kLog2e);
-    scale_row_frags(vf, -1.f);
+    negate_row_frags(vf);
     const int vis_lo = kvis ? ki : A.S;
     const unsigned vis_n = (unsigned)(A.S - vis_lo);
     const bool wave_all_keys = __all(kvis);                  // (uniform) no padded / out-of-range key among this wave's 32
