@@ -1189,7 +1189,13 @@ __device__ __forceinline__ f32x16 splat16(float v)
 #define ECGB_LEAN_DIAG 0      // timing-only diagnostics of the forward kernel (wrong results): 1 no tile DMA in the loop, 2 no barrier, 4 no exp, 8 two of the eight P.V MFMAs, 16 four of the eight Q.K MFMAs, 32 no row sum
 #endif
 #ifndef ECGB_LEAN_FWD_WGS
-#define ECGB_LEAN_FWD_WGS 2
+#define ECGB_LEAN_FWD_WGS 3      // waves per SIMD the forward kernel is compiled for (168 registers; 2: 206).  Three: -9 ... -14 % (see the kernel)
+#endif
+#ifndef ECGB_LEAN_DQ_WGS
+#define ECGB_LEAN_DQ_WGS 2
+#endif
+#ifndef ECGB_LEAN_DKV_WGS
+#define ECGB_LEAN_DKV_WGS 2
 #endif
 #ifndef ECGB_LEAN_PRIO
 #define ECGB_LEAN_PRIO 0      // 1: s_setprio 1 around the forward kernel's MFMA clusters (measured: no change, 0.248 against 0.250 ms)
@@ -1274,9 +1280,15 @@ __global__ __launch_bounds__(NW * 64, ECGB_LEAN_FWD_WGS) void attn_fwd_lean_kern
         const bool tail = tail_last && t_next == last_tile;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb_next + (tail ? offKt[i] : offK[i])),
+            unsigned ok = offK[i], ov = offV[i];
+            if (tail) {                                          // (uniform, the one partial tile a sequence can end with) rows past the last key re-read it
+                const int r = (wave * PPW + i) * 8 + (lane >> 3), slot = lane & 7, rt = min(r, A.S - 1 - last_tile * 64);
+                ok = (unsigned)(((long long)rt * A.ldk + (slot ^ ((r >> 1) & 7)) * 8) * 2);
+                ov = (unsigned)(((long long)rt * A.ldv + (slot ^ (((r >> 1) & 1) << 2)) * 8) * 2);
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb_next + ok),
                                              (__attribute__((address_space(3))) void *)(smem + slot_next + (wave * PPW + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb_next + (tail ? offVt[i] : offV[i])),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb_next + ov),
                                              (__attribute__((address_space(3))) void *)(smem + slot_next + kTile + (wave * PPW + i) * 1024), 16, 0, 0);
         }
         if (t_next < last_tile) { ++t_next; kb_next += stepK; vb_next += stepV; }
@@ -1303,6 +1315,7 @@ __global__ __launch_bounds__(NW * 64, ECGB_LEAN_FWD_WGS) void attn_fwd_lean_kern
             vtr[db] = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem + kTile + key * 128 +
                       (((db * 4 + 2 * a + (p >> 1)) ^ (((key >> 1) & 1) << 2)) << 4) + (p & 1) * 8;
     }
+    const unsigned lds_base_u = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
     unsigned kbase[4];                                       // this lane's K row fragment (key lr, k-step ks) inside a K image; key 32 + lr is 4 KiB further
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -1322,14 +1335,15 @@ __global__ __launch_bounds__(NW * 64, ECGB_LEAN_FWD_WGS) void attn_fwd_lean_kern
             const bool need_mask = (k0 + 63 > qw0) || lean_tile_padded(padbits, it);
             f32x16 sacc[2];
             bf16x8 kfr[2][4];                                   // [kb][ks]: K row fragments, four per batch; the second batch and the V^T fragments land under MFMAs
-            lds_frags2x2_wait<0, 4096>(kfr[0][0], kfr[1][0], kfr[0][1], kfr[1][1], kbase[0] + vimg, kbase[1] + vimg);
+            const unsigned kb0 = (unsigned)(lr * 128 + ((h ^ ((lr >> 1) & 7)) << 4)), kl0 = lds_base_u + vimg;      // k-step ks is the offset ^ (ks << 5): recomputed, not held
+            lds_frags2x2_wait<0, 4096>(kfr[0][0], kfr[1][0], kfr[0][1], kfr[1][1], kb0 + kl0, (kb0 ^ 32u) + kl0);
             LEAN_PRIO(1);
             sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][0], qf[0], cinit, 0, 0, 0);
             sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[1][0], qf[0], cinit, 0, 0, 0);
             sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[0][1], qf[1], sacc[0], 0, 0, 0);
             sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[1][1], qf[1], sacc[1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            lds_frags2x2_wait<0, 4096>(kfr[0][2], kfr[1][2], kfr[0][3], kfr[1][3], kbase[2] + vimg, kbase[3] + vimg);
+            lds_frags2x2_wait<0, 4096>(kfr[0][2], kfr[1][2], kfr[0][3], kfr[1][3], (kb0 ^ 64u) + kl0, (kb0 ^ 96u) + kl0);
 #if !(ECGB_LEAN_DIAG & 16)
 #pragma unroll
             for (int ks = 2; ks < 4; ++ks)
@@ -1338,9 +1352,7 @@ __global__ __launch_bounds__(NW * 64, ECGB_LEAN_FWD_WGS) void attn_fwd_lean_kern
                     sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][ks], qf[ks], sacc[kb], 0, 0, 0);
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            bf16x8 vfr[2][2][2];                                // [kb][s2][db]: the tile's eight V^T fragments, read (and waited for) under the products above
-            tr_frags4_wait<0, 16 * 128>(vfr[0], vtr[0] + vimg, vtr[0] + vimg + 1024, vtr[1] + vimg, vtr[1] + vimg + 1024);
-            tr_frags4_wait<32 * 128, 48 * 128>(vfr[1], vtr[0] + vimg, vtr[0] + vimg + 1024, vtr[1] + vimg, vtr[1] + vimg + 1024);
+            bf16x8 vfr[2][2][2];                                // [kb][s2][db]: the tile's eight V^T fragments
             APROF(1);
             LEAN_PRIO(0);
             bf16x8 pf[2][2];                                    // [kb][s2]: P as the B operand of P.V, packed as it is produced (the fp32 values are not kept)
@@ -1430,15 +1442,15 @@ __global__ __launch_bounds__(NW * 64, ECGB_LEAN_FWD_WGS) void attn_fwd_lean_kern
             APROF(2);
             LEAN_PRIO(1);
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 0) tr_frags4_wait<0, 16 * 128>(vfr[0], vtr[0] + vimg, vtr[0] + vimg + 1024, vtr[1] + vimg, vtr[1] + vimg + 1024);
+                else tr_frags4_wait<32 * 128, 48 * 128>(vfr[0], vtr[0] + vimg, vtr[0] + vimg + 1024, vtr[1] + vimg, vtr[1] + vimg + 1024);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
-#if ECGB_LEAN_DIAG & 8
-                        if (kb == 0 && s2 == 0)
-#endif
-                        accO[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb][s2][db], pf[kb][s2], accO[db], 0, 0, 0);
+                        accO[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[0][s2][db], pf[kb][s2], accO[db], 0, 0, 0);
+            }
             LEAN_PRIO(0);
             APROF(3);
         }
@@ -1468,7 +1480,7 @@ __global__ __launch_bounds__(NW * 64, ECGB_LEAN_FWD_WGS) void attn_fwd_lean_kern
 // dQ, lean form: lanes = queries.  Register operands: -Q * scale * log2 e and -dO; initial accumulators: the row's lse and delta.
 //   acc_s = lse - s,  p = exp2(-acc_s);   acc_dp = delta - dP;   dsn = p * acc_dp = -dS;   accQ += K^T . dsn  ->  dQ = -scale * accQ
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_lean_kernel(AttnArgs A)
+__global__ __launch_bounds__(NW * 64, ECGB_LEAN_DQ_WGS) void attn_bwd_dq_lean_kernel(AttnArgs A)
 {
     constexpr int D = 64, kTile = 128 * D, PPW = 8 / NW;      // (waves, heads and rows of a workgroup: see attn_fwd_lean_kernel)
     constexpr int kRing = kLeanRing, kAhead = kRing - 1;   // (see attn_fwd_lean_kernel)
@@ -1607,7 +1619,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_lean_kernel(AttnArgs A
 //   acc_s = lse_q - s,  p = exp2(-acc_s);  acc_dp = delta_q - dP;  dsn = p * acc_dp = -dS;  accV += dO^T . p;  accK += Q^T . dsn  ->  dK = -scale * accK
 // NW waves = NW x 32 keys per workgroup share every (Q, dO) tile (see attn_fwd_lean_kernel: the tile traffic, not the arithmetic, bounds the 4-wave kernel).
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_lean_kernel(AttnArgs A)
+__global__ __launch_bounds__(NW * 64, ECGB_LEAN_DKV_WGS) void attn_bwd_dkv_lean_kernel(AttnArgs A)
 {
     constexpr int D = 64, kTile = 128 * D, PPW = 8 / NW, kStep = 2 * kTile + NW * 256;      // Q image, dO image, one 256-byte statistics row per wave
     constexpr int kRing = kLeanRing, kAhead = kRing - 1;   // (see attn_fwd_lean_kernel)
