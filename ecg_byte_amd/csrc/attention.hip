@@ -1745,15 +1745,6 @@ __global__ __launch_bounds__(NW * 64, ECGB_LEAN_DKV_WGS) void attn_bwd_dkv_lean_
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr[ks], vf[ks], dp, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                bf16x8 qtf[2][2], dotf[2][2];                // [s2][db]: transposed fragments of this query half, read under the products above
-                if (qb == 0) {
-                    tr_frags4_wait<kTile, kTile + 16 * 128>(dotf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
-                    tr_frags4_wait<0, 16 * 128>(qtf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
-                } else {
-                    tr_frags4_wait<kTile + 32 * 128, kTile + 48 * 128>(dotf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
-                    tr_frags4_wait<32 * 128, 48 * 128>(qtf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
-                }
-                APROF(2);
                 float pr[16], ds[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1761,14 +1752,23 @@ __global__ __launch_bounds__(NW * 64, ECGB_LEAN_DKV_WGS) void attn_bwd_dkv_lean_
                     pr[r] = e;
                     ds[r] = e * dp[r];
                 }
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 pf = frag_from_acc(&pr[8 * s2]);
-                    const bf16x8 dsf = frag_from_acc(&ds[8 * s2]);
+                const bf16x8 pf0 = frag_from_acc(&pr[0]), pf1 = frag_from_acc(&pr[8]), dsf0 = frag_from_acc(&ds[0]), dsf1 = frag_from_acc(&ds[8]);
+                APROF(2);
+                {                                             // the transposed fragments one image at a time (dO, then Q): sixteen registers live instead of thirty-two
+                    bf16x8 tf[2][2];                          // [s2][db]
+                    if (qb == 0) tr_frags4_wait<kTile, kTile + 16 * 128>(tf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
+                    else tr_frags4_wait<kTile + 32 * 128, kTile + 48 * 128>(tf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
-                        accV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[s2][db], pf, accV[db], 0, 0, 0);
-                        accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s2][db], dsf, accK[db], 0, 0, 0);
+                        accV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[0][db], pf0, accV[db], 0, 0, 0);
+                        accV[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[1][db], pf1, accV[db], 0, 0, 0);
+                    }
+                    if (qb == 0) tr_frags4_wait<0, 16 * 128>(tf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
+                    else tr_frags4_wait<32 * 128, 48 * 128>(tf, trA[0] + img, trB[0] + img, trA[1] + img, trB[1] + img);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[0][db], dsf0, accK[db], 0, 0, 0);
+                        accK[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[1][db], dsf1, accK[db], 0, 0, 0);
                     }
                 }
                 APROF(3);
