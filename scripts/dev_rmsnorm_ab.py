@@ -16,7 +16,6 @@ def timed(fn, reps=50):
 
 
 torch.manual_seed(0)
-x, r, w = (torch.randn(32768, 2048, device="cuda").to(torch.bfloat16) for _ in range(2)) if False else (None, None, None)
 x = torch.randn(32768, 2048, device="cuda").to(torch.bfloat16); r = torch.randn(32768, 2048, device="cuda").to(torch.bfloat16); w = torch.randn(2048, device="cuda").to(torch.bfloat16)
 res = {0: [], 1: []}
 for rnd in range(4):
