@@ -434,18 +434,37 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TrainArgs A, uint32_t s
         s_cnt[threadIdx.x] = ti.count0;
         s_par[threadIdx.x] = ti.flags;
         __syncthreads();
-        if (same && threadIdx.x == 0) {
-            // lead parity of each tile: parity of the run of `left` ending just before it
-            uint32_t par = s_carry_par;
+        if (same) {                                          // (uniform)
+            // Lead parity of each tile = parity of the run of `left` ending just before it: the trailing-run parity of the nearest earlier tile that is not
+            // uniformly `left` (those are even-sized: parity passes through), else the carry.  One thread walking the 1 024 tiles of a round took up to 1.9 ms
+            // per merge on a corpus of 29 000 tiles (a third of the l == r merges' scan); a tile a thread, by ballots (thread_lead_parity's scheme).
+            const uint32_t lane_ = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
             const uint32_t lim = min(1024u, n_tiles - base);
-            for (uint32_t k = 0; k < lim; ++k) {
-                const uint32_t f = s_par[k];
-                if (par && (f & 1u)) s_cnt[k] -= 1u;        // odd entering run + odd leading run: one more id is consumed
-                s_par[k] = par;                              // this tile's lead parity
-                if (f & 2u) { /* uniform, even-sized tile: parity passes through */ }
-                else par = (f >> 2) & 1u;                    // trailing run parity, but if the lead run reaches the tail...
+            const uint32_t f = ti.flags;
+            const bool valid = threadIdx.x < lim;
+            const bool nonuni = valid && !(f & 2u);
+            const uint32_t tp = (f >> 2) & 1u;                   // the tile's trailing-run parity
+            const unsigned long long m = __ballot(nonuni);
+            const int last = m ? 63 - __clzll((long long)m) : 0;
+            const uint32_t last_tp = __shfl(tp, last, 64);
+            const unsigned long long before = m & ((1ull << lane_) - 1ull);
+            const int src = before ? 63 - __clzll((long long)before) : 0;
+            const uint32_t src_tp = __shfl(tp, src, 64);
+            if (lane_ == 0) s_wsum[wv_] = m ? (2u | last_tp) : 0u;      // (s_wsum is free here: the count scan below fills it after a barrier)
+            __syncthreads();
+            uint32_t par;
+            if (before) par = src_tp;
+            else {
+                par = s_carry_par;
+                for (int w = (int)wv_ - 1; w >= 0; --w)
+                    if (s_wsum[w] & 2u) { par = s_wsum[w] & 1u; break; }
             }
-            s_carry_par = par;
+            if (valid) {
+                if (par && (f & 1u)) s_cnt[threadIdx.x] -= 1u;      // odd entering run + odd leading run: one more id is consumed
+                s_par[threadIdx.x] = par;                            // this tile's lead parity
+            }
+            __syncthreads();                                     // everybody has read the carry and the waves' summaries
+            if (threadIdx.x == lim - 1) s_carry_par = nonuni ? tp : par;
         }
         __syncthreads();
         // block-exclusive scan of s_cnt
