@@ -336,7 +336,10 @@ __device__ __forceinline__ void classify(const Span &s, uint32_t l, uint32_t r, 
 // flags bit0: the run of `l` that starts the tile has odd length (then an odd entering run costs the
 //             tile one more id);  bit1: the whole tile is `l` (even-sized: parity passes through);
 //       bit2: parity of the run of `l` that ends the tile (for the next tile's lead parity).
-__global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint32_t src_sel)
+// n_partials > 0 (the one-rank trainer): the final arg-max over argmax_partial_kernel's results is done HERE, by every workgroup for itself (a few hundred pairs), and workgroup 0
+// commits it as argmax_final_kernel does -- one launch less per merge (6 us of 110).  Workgroups read nothing that workgroup 0 writes: the length is n_next of the merge being
+// committed, the pair is their own reduction, and `active` only ever goes from 1 to 0, which their own reduction finds too.
+__global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint32_t src_sel, uint32_t merge_index = 0, uint32_t n_partials = 0)
 {
     __shared__ uint32_t s_wave[kThreads / 64];
     __shared__ uint32_t s_cnt[kThreads / 64];
@@ -344,8 +347,45 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
     __shared__ uint32_t s_last[kThreads / 64];
     __shared__ uint32_t s_lead_extra;
     __shared__ uint32_t s_ids[kStageWords];
-    const TrainState st = *A.st;
+    __shared__ unsigned long long s_best[kThreads / 64];
+    __shared__ uint32_t s_bkey[kThreads / 64];
+    TrainState st = *A.st;
     if (!st.active) return;
+    if (n_partials > 0) {
+        unsigned long long best = 0;
+        uint32_t bkey = 0;
+        for (uint32_t i = threadIdx.x; i < n_partials; i += kThreads) {
+            const unsigned long long oc = A.partial[2 * i];
+            const uint32_t ok = (uint32_t)A.partial[2 * i + 1];
+            if (better(oc, ok, best, bkey)) { best = oc; bkey = ok; }
+        }
+        for (int d = 32; d > 0; d >>= 1) {
+            const unsigned long long oc = __shfl_down(best, d, 64);
+            const uint32_t ok = __shfl_down(bkey, d, 64);
+            if (better(oc, ok, best, bkey)) { best = oc; bkey = ok; }
+        }
+        if ((threadIdx.x & 63) == 0) { s_best[threadIdx.x >> 6] = best; s_bkey[threadIdx.x >> 6] = bkey; }
+        __syncthreads();
+        best = s_best[0]; bkey = s_bkey[0];
+        for (int w = 1; w < kThreads / 64; ++w) if (better(s_best[w], s_bkey[w], best, bkey)) { best = s_best[w]; bkey = s_bkey[w]; }
+        if (merge_index > 0) st.n_cur = st.n_next;                          // (the length merge_index - 1 left)
+        const uint32_t idx = ~bkey;
+        st.left = idx / A.V; st.right = idx % A.V;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                          // commit, as argmax_final_kernel does
+            TrainState *g = A.st;
+            if (merge_index > 0) g->n_cur = st.n_cur;
+            if (best != 0) {
+                g->left = st.left; g->right = st.right;
+                g->new_id = 256u + merge_index;                             // lib.rs:97
+                A.pairs_out[2 * merge_index] = st.left;
+                A.pairs_out[2 * merge_index + 1] = st.right;
+                g->done = merge_index + 1;
+            } else {
+                g->active = 0;                                              // lib.rs:88-90: pairs.is_empty() -> break
+            }
+        }
+        if (best == 0) return;
+    }
     const uint32_t *src = A.buf[src_sel];
     const uint64_t n = st.n_cur;
     const uint32_t l = st.left, r = st.right;
@@ -798,8 +838,7 @@ extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t nu
         const size_t live = (size_t)(256 + i) * V;
         const unsigned ag = (unsigned)std::max<size_t>(1, std::min<size_t>(kGrid, (live + kThreads * 8 - 1) / (kThreads * 8)));
         hipLaunchKernelGGL(argmax_partial_kernel, dim3(ag), dim3(kThreads), 0, st, A, i);
-        hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(kThreads), 0, st, A, i, ag);
-        hipLaunchKernelGGL(tile_count_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, i & 1u);
+        hipLaunchKernelGGL(tile_count_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, i & 1u, i, ag);      // (with the final arg-max and the commit of merge i - 1)
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, A, i & 1u);
         hipLaunchKernelGGL(rewrite_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, i & 1u);
     }
@@ -876,7 +915,7 @@ extern "C" int ecgb_bpe_shard_pick(ecgb_bpe_shard *h, uint32_t merge_index, long
     const unsigned ag = (unsigned)std::max<size_t>(1, std::min<size_t>(kGrid, (live + kThreads * 8 - 1) / (kThreads * 8)));
     hipLaunchKernelGGL(argmax_partial_kernel, dim3(ag), dim3(kThreads), 0, st, h->A, merge_index);
     hipLaunchKernelGGL(argmax_final_kernel, dim3(1), dim3(kThreads), 0, st, h->A, merge_index, ag);
-    hipLaunchKernelGGL(tile_count_kernel, dim3(h->tile_grid), dim3(kThreads), 0, st, h->A, merge_index & 1u);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(h->tile_grid), dim3(kThreads), 0, st, h->A, merge_index & 1u, 0u, 0u);
     hipLaunchKernelGGL(shard_summary_kernel, dim3(1), dim3(kThreads), 0, st, h->A, merge_index & 1u, summary_dev, 1);
     return check_hip(hipGetLastError(), "bpe shard pick");
 }
