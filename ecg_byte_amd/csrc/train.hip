@@ -252,13 +252,27 @@ __device__ __forceinline__ uint32_t halo_at(const Halo &h, int64_t i, uint64_t n
 // A lane's span out of LDS.  A lane's 19 ids lie 64 bytes apart from its neighbour's: read straight from memory, every one of the 19 loads of a wave touches 64
 // separate 64-byte segments (tile_count 40 us and rewrite 64 us per merge whatever the length: 1 TB/s).  So the workgroup brings the tile -- 4096 ids and the three
 // around it -- with consecutive lanes on consecutive words, parks it in LDS with one pad word per 16 (lane t's ids start at word 17 t: the lanes' reads hit 64
-// different banks), and every lane picks its span from there.  stage_tile ends with a barrier; callers put one before the next stage_tile (or re-use of s_ids).
+// different banks), and every lane picks its span from there.  tile_park ends with a barrier; callers put one before the next tile_park (or re-use of s_ids).
 constexpr uint32_t kStageWords = kTile + 3 + (kTile + 3) / kPerThread + 1;
-__device__ __forceinline__ void stage_tile(uint32_t *s_ids, const uint32_t *src, uint64_t base, uint64_t n, const Halo &h)
+// Staging in two halves, so that a workgroup's NEXT tile travels while it works on the current one (a tile staged when it is needed costs its memory latency every time:
+// the rewrite took 87 us per merge on a corpus it could stream in 40): tile_fetch requests the tile's words into registers, tile_park writes them to LDS (barrier inside).
+constexpr int kFetchWords = (kTile + 3 + kThreads - 1) / kThreads;
+struct TileRegs { uint32_t w[kFetchWords]; };
+__device__ __forceinline__ void tile_fetch(TileRegs &r, const uint32_t *src, uint64_t base, uint64_t n, const Halo &h)
 {
-    for (uint32_t j = threadIdx.x; j < kTile + 3; j += kThreads) {
+#pragma unroll
+    for (int k = 0; k < kFetchWords; ++k) {
+        const uint32_t j = threadIdx.x + (uint32_t)k * kThreads;
         const int64_t i = (int64_t)base + j - 1;
-        s_ids[j + j / kPerThread] = (i >= 0 && i < (int64_t)n) ? src[i] : halo_at(h, i, n);
+        r.w[k] = (j < kTile + 3) ? ((i >= 0 && i < (int64_t)n) ? src[i] : halo_at(h, i, n)) : 0u;
+    }
+}
+__device__ __forceinline__ void tile_park(uint32_t *s_ids, const TileRegs &r)
+{
+#pragma unroll
+    for (int k = 0; k < kFetchWords; ++k) {
+        const uint32_t j = threadIdx.x + (uint32_t)k * kThreads;
+        if (j < kTile + 3) s_ids[j + j / kPerThread] = r.w[k];
     }
     __syncthreads();
 }
@@ -391,10 +405,14 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
     const uint32_t l = st.left, r = st.right;
     const bool same = (l == r);
     const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
+    const Halo alone{kEmpty, {kEmpty, kEmpty, kEmpty}, 0, {0, 0, 0}};                                             // as if the shard stood alone: tile_scan adds what the neighbours change
+    TileRegs tr;
+    if (blockIdx.x < n_tiles) tile_fetch(tr, src, (uint64_t)blockIdx.x * kTile, n, alone);
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         Span s;
-        stage_tile(s_ids, src, (uint64_t)t * kTile, n, Halo{kEmpty, {kEmpty, kEmpty, kEmpty}, 0, {0, 0, 0}});   // as if the shard stood alone: tile_scan adds what the neighbours change
+        tile_park(s_ids, tr);
         span_from_lds(s, s_ids);
+        if (t + gridDim.x < n_tiles) tile_fetch(tr, src, (uint64_t)(t + gridDim.x) * kTile, n, alone);          // the next tile's words travel under this tile's work
         uint32_t dropped = 0, tail = 0;
         if (!same) {
 #pragma unroll
@@ -531,7 +549,7 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
     __shared__ int s_val[kHashSlots];
     __shared__ uint32_t s_wave[kThreads / 64];
     __shared__ uint32_t s_wsum[kThreads / 64];
-    __shared__ uint32_t s_ids[kStageWords];               // the tile on its way in (stage_tile), then its survivors on their way out
+    __shared__ uint32_t s_ids[kStageWords];               // the tile on its way in (tile_park), then its survivors on their way out
     const TrainState st = *A.st;
     if (!st.active) return;
     for (uint32_t i = threadIdx.x; i < kHashSlots; i += kThreads) { s_key[i] = kEmpty; s_val[i] = 0; }
@@ -543,14 +561,17 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
     const Halo halo = *A.halo;
     const SlabKey SK{l, r, X, V};
     const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
+    TileRegs tr;
+    if (blockIdx.x < n_tiles) tile_fetch(tr, src, (uint64_t)blockIdx.x * kTile, n, halo);
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t i0 = (uint64_t)t * kTile + threadIdx.x * kPerThread;
         const uint64_t off_word = A.tile_off[t];
         const uint32_t tile_par = (uint32_t)(off_word >> 63);
         const uint64_t tile_off = off_word & 0x7FFFFFFFFFFFFFFFull;
         Span s;
-        stage_tile(s_ids, src, (uint64_t)t * kTile, n, halo);
+        tile_park(s_ids, tr);
         span_from_lds(s, s_ids);
+        if (t + gridDim.x < n_tiles) tile_fetch(tr, src, (uint64_t)(t + gridDim.x) * kTile, n, halo);           // the next tile's words travel under this tile's work
         uint32_t lead_par = 0;
         if (l == r) lead_par = thread_lead_parity(trailing_l(s, l), tile_par, s_wave);
         uint32_t site_mask, second_mask, sa;
