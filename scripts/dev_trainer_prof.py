@@ -2,6 +2,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from ecg_byte_amd import _lib
+if os.environ.get("ECGB_SO"): _lib.SO_PATH = os.path.join(os.path.dirname(_lib.SO_PATH), os.environ["ECGB_SO"])
 from ecg_byte_amd.trainer import bpe_train_device
 rng = np.random.default_rng(1)
 n = 2000 * 12 * 5000
