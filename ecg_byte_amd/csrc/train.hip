@@ -562,6 +562,7 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
     const SlabKey SK{l, r, X, V};
     const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
     TileRegs tr;
+    uint32_t tiles_done = 0;
     if (blockIdx.x < n_tiles) tile_fetch(tr, src, (uint64_t)blockIdx.x * kTile, n, halo);
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t i0 = (uint64_t)t * kTile + threadIdx.x * kPerThread;
@@ -631,8 +632,12 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < tile_kept; i += kThreads) dst[tile_off + i] = s_ids[i];
-        delta_flush(s_key, s_val, A.table, A.slab, SK);      // (its barriers also fence s_ids before the next tile is staged)
+        // the count deltas stay in the workgroup's LDS table across its tiles and leave every eighth tile and at the end (a flush per tile was two barriers, a sweep of
+        // the 2 048 slots and as many global atomics as the tile had distinct pairs -- the same pairs tile after tile); a table that fills up overflows into memory as before
+        if (((++tiles_done) & 7u) == 0) delta_flush(s_key, s_val, A.table, A.slab, SK);
+        else __syncthreads();                                // (fences s_ids before the next tile is parked)
     }
+    delta_flush(s_key, s_val, A.table, A.slab, SK);
 }
 
 // =================================================================================================================
