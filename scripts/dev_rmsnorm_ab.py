@@ -40,3 +40,20 @@ for with_dw in (True, False):
             dw = torch.zeros(2048, device="cuda") if with_dw else None
             res.setdefault(n, []).append(timed(lambda: ops.rmsnorm_bwd(x, w, rstd, dy, dw, dres=r)))
     print("rmsnorm_bwd", "with dw" if with_dw else "frozen weights", "  ".join(f"{n} rows/wg: {min(v) * 1e3:.1f} us ({4 * x.numel() * 2 / min(v) / 1e9:.2f} TB/s)" for n, v in res.items()))
+
+# two builds of the library in one process (ECGB_SO_B): backward at the default rows per workgroup
+if os.environ.get("ECGB_SO_B"):
+    libs = {"A": _lib.lib()}
+    _lib._lib = None
+    _lib.SO_PATH = os.path.join(os.path.dirname(_lib.SO_PATH), os.environ["ECGB_SO_B"])
+    libs["B"] = _lib.lib()
+    for with_dw in (True, False):
+        res, outs = {k: [] for k in libs}, {}
+        for rnd in range(4):
+            for k, L2 in libs.items():
+                _lib._lib = L2
+                dw = torch.zeros(2048, device="cuda") if with_dw else None
+                outs[k] = (ops.rmsnorm_bwd(x, w, rstd, dy, dw, dres=r).clone(), None if dw is None else dw.clone())
+                res[k].append(timed(lambda: ops.rmsnorm_bwd(x, w, rstd, dy, dw, dres=r)))
+        same = torch.equal(outs["A"][0], outs["B"][0]) and (not with_dw or torch.equal(outs["A"][1], outs["B"][1]))
+        print("rmsnorm_bwd", "with dw" if with_dw else "frozen weights", "  ".join(f"{k}: {min(v) * 1e3:.1f} us ({4 * x.numel() * 2 / min(v) / 1e9:.2f} TB/s)" for k, v in res.items()), "  same bits", same)
