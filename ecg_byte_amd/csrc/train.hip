@@ -11,10 +11,11 @@
 // hash-map inserts dominating).  Here the ids live in HBM as uint32 and the pair counts in a dense
 // V x V table (V = 256 + num_merges) that is built once and then only PATCHED: a merge changes
 // counts only next to its sites, so the rewrite pass emits ~5 count deltas per site.  Per merge:
-//   1. arg-max over the live part of the table          (reads V_cur x V words)
-//   2. per-tile survivor counts                          (reads N_i)
-//   3. exclusive scan of the tile counts                 (one workgroup)
-//   4. rewrite + compaction + count deltas               (reads N_i, writes N_{i+1})
+//   1. arg-max: every row of the table keeps its maximum, only the rows a delta could have changed are read again (rowmax_kernel; the sharded form reads the
+//      live V_cur x V part, argmax_partial_kernel)
+//   2. survivor counts: each workgroup streams its contiguous range of tiles and leaves ONE record   (reads N_i)
+//   3. exclusive scan of the ranges' records             (one workgroup, as many records as workgroups)
+//   4. rewrite + compaction + count deltas: each workgroup walks its range in order, carrying the output offset and the run parity   (reads N_i, writes N_{i+1})
 // Runs of one symbol merged with itself ("aaa" -> "Xa") need the offset parity inside the run;
 // tiles and per-thread spans are even-sized, so parity is carried by a "last non-uniform span"
 // look-up instead of a full segmented scan.  No host synchronisation inside the merge loop: the
@@ -24,16 +25,20 @@
 #include <string>
 
 #include "tokenizer.hpp"
+#include <type_traits>
 
 #ifndef ECGB_TRAIN_PER_THREAD
-#define ECGB_TRAIN_PER_THREAD 16
+#define ECGB_TRAIN_PER_THREAD 8
+#endif
+#ifndef ECGB_RW_WAVES
+#define ECGB_RW_WAVES 5
 #endif
 
 namespace {
 
 constexpr int kThreads = 256;
 constexpr int kPerThread = ECGB_TRAIN_PER_THREAD;       // even: a span of one repeated symbol keeps run parity
-constexpr uint32_t kTile = kThreads * kPerThread;     // 4096 ids per tile
+constexpr uint32_t kTile = kThreads * kPerThread;     // 2048 ids per tile
 constexpr uint32_t kGrid = 2048;                      // persistent grid (8 workgroups per CU)
 constexpr uint32_t kHashSlots = 2048;                 // per-workgroup LDS table of count deltas
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
@@ -70,17 +75,49 @@ struct TrainArgs {
     uint64_t *table;       // V x V pair counts (64-bit: one pair can occur more than 2^32 times in a corpus that long)
     uint32_t V;
     uint32_t *buf[2];      // ping-pong id buffers
-    TileInfo *tiles;       // per tile
-    uint64_t *tile_off;    // per tile: exclusive output offset; lead parity in the top bit
+    TileInfo *tiles;       // per RANGE of tiles (a workgroup's contiguous share of the buffer, tile_range): what TileInfo says of a tile, of the whole range
+    uint64_t *tile_off;    // per range: exclusive output offset; lead parity in the top bit
     uint64_t *partial;     // kGrid arg-max partials: 2 words each, count and ~key
+    uint64_t *row_cnt;     // per row of the table: its largest count ...
+    uint32_t *row_key;     //  ... and ~index of that cell (the smallest index among equals), exact unless row_dirty
+    uint32_t *row_dirty;   // per row: a count of the row changed since row_cnt / row_key were taken (rowmax_kernel)
     uint32_t *pairs_out;   // 2 x num_merges
     uint64_t n0;           // initial length
 };
 
-// ---- LDS delta table --------------------------------------------------------------------
-__device__ __forceinline__ void table_add(uint64_t *table, uint32_t key, int d)
+// A workgroup barrier that orders LDS only.  __syncthreads() also drains every global load and store in flight (s_waitcnt vmcnt(0) before s_barrier): in the tile
+// loops below that is the NEXT tile on its way in and the last tile's survivors on their way out -- the loops never read global memory another thread of the
+// workgroup wrote, so their barriers need not wait for either.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Workgroup b of G walks tiles [first, first + count): contiguous and balanced.  A workgroup that walks its tiles IN ORDER carries the output offset and the run parity from
+// tile to tile itself, so the count pass leaves one record per workgroup, not per tile, and the scan between the two passes is over G records whatever the corpus
+// (per-tile records: a scan of 29 000 to 58 000 entries by one workgroup, 9 to 16 % of a merge).
+__device__ __forceinline__ void tile_range(uint32_t n_tiles, uint32_t b, uint32_t G, uint32_t &first, uint32_t &count)
 {
-    atomicAdd(reinterpret_cast<unsigned long long *>(&table[key]), (unsigned long long)(long long)d);   // two's complement: -1 adds 2^64 - 1
+    const uint32_t q = n_tiles / G, rem = n_tiles % G;
+    first = b * q + min(b, rem);
+    count = q + (b < rem ? 1u : 0u);
+}
+
+// ---- LDS delta table --------------------------------------------------------------------
+// arg-max order: the larger count, then the larger ~index (= the smaller (left, right)); a count of 0 is no pair at all
+__device__ __forceinline__ bool better(unsigned long long c, uint32_t k, unsigned long long bc, uint32_t bk)
+{
+    return c > bc || (c == bc && c != 0 && k > bk);
+}
+
+// A count delta goes into the table and, if it can change its row's maximum, marks the row for rowmax_kernel.  Within one merge a cell only grows (its pair holds the new
+// id) or only shrinks: a shrinking cell matters iff it IS the row's maximum; of a growing cell the last adder sees the final count, which matters iff it beats the maximum.
+// row_cnt / row_key are written by rowmax_kernel only, never while deltas flow.
+struct Tab { uint64_t *table; const uint64_t *row_cnt; const uint32_t *row_key; uint32_t *row_dirty; uint32_t V; };
+__device__ __forceinline__ Tab tab_of(const TrainArgs &A) { return Tab{A.table, A.row_cnt, A.row_key, A.row_dirty, A.V}; }
+__device__ __forceinline__ void table_add(const Tab &T, uint32_t key, int d)
+{
+    const unsigned long long was = atomicAdd(reinterpret_cast<unsigned long long *>(&T.table[key]), (unsigned long long)(long long)d);   // two's complement: -1 adds 2^64 - 1
+    const uint32_t row = key / T.V;
+    if (d < 0) { if (T.row_key[row] == ~key) T.row_dirty[row] = 1u; }
+    else if (better(was + (unsigned long long)d, ~key, T.row_cnt[row], T.row_key[row])) T.row_dirty[row] = 1u;
 }
 
 // Every count delta of a merge has `left`, `right` or the new id as one of its two ids (a pair disappears only next to a site, a
@@ -97,9 +134,10 @@ __device__ __forceinline__ uint32_t slab_index(const SlabKey &K, uint32_t a, uin
     return 5 * K.V + a;                      // b == K.x
 }
 
-__device__ __forceinline__ void delta_add(uint32_t *s_key, int *s_val, uint64_t *table, uint32_t key, int d)
+__device__ __forceinline__ void delta_add(uint32_t *s_key, int *s_val, const Tab &table, uint32_t key, int d)
 {
     uint32_t h = (key * 2654435761u) >> 21;   // 11 bits
+#pragma unroll 1                                  // (unrolled, the 32 probe chains of a span's walk were most of a 100 KB kernel: more than the instruction cache two CUs share)
     for (int probe = 0; probe < 16; ++probe) {
         const uint32_t prev = atomicCAS(&s_key[h], kEmpty, key);
         if (prev == kEmpty || prev == key) { atomicAdd(&s_val[h], d); return; }
@@ -109,9 +147,10 @@ __device__ __forceinline__ void delta_add(uint32_t *s_key, int *s_val, uint64_t 
 }
 
 // the same with the overflow going to the slab when the run is sharded
-__device__ __forceinline__ void delta_add_s(uint32_t *s_key, int *s_val, uint64_t *table, long long *slab, const SlabKey &K, uint32_t key, int d)
+__device__ __forceinline__ void delta_add_s(uint32_t *s_key, int *s_val, const Tab &table, long long *slab, const SlabKey &K, uint32_t key, int d)
 {
     uint32_t h = (key * 2654435761u) >> 21;
+#pragma unroll 1
     for (int probe = 0; probe < 16; ++probe) {
         const uint32_t prev = atomicCAS(&s_key[h], kEmpty, key);
         if (prev == kEmpty || prev == key) { atomicAdd(&s_val[h], d); return; }
@@ -121,11 +160,11 @@ __device__ __forceinline__ void delta_add_s(uint32_t *s_key, int *s_val, uint64_
     else table_add(table, key, d);
 }
 
-__device__ __forceinline__ void delta_flush(uint32_t *s_key, int *s_val, uint64_t *table, long long *slab = nullptr, SlabKey K = SlabKey{0, 0, 0, 0})
+__device__ __forceinline__ void delta_flush(uint32_t *s_key, int *s_val, const Tab &table, long long *slab = nullptr, SlabKey K = SlabKey{0, 0, 0, 0})
 {
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kHashSlots; i += kThreads) {
-        const uint32_t k = s_key[i];
+    lds_barrier();
+    for (uint32_t i = threadIdx.x; i < kHashSlots; i += kThreads) {       // (all of a lane's adds issued before the first old count is looked at: the eight more registers
+        const uint32_t k = s_key[i];                                      //  cost the rewrite a wave per SIMD -- built, 286 -> 335 ms over 4 000 merges)
         const int v = s_val[i];
         if (k != kEmpty && v != 0) {
             if (slab) atomicAdd(reinterpret_cast<unsigned long long *>(&slab[slab_index(K, k / K.V, k % K.V)]), (unsigned long long)(long long)v);
@@ -134,7 +173,7 @@ __device__ __forceinline__ void delta_flush(uint32_t *s_key, int *s_val, uint64_
         s_key[i] = kEmpty;
         s_val[i] = 0;
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // ---- 0. bytes -> ids, initial histogram ----------------------------------------------------
@@ -153,10 +192,10 @@ __global__ __launch_bounds__(kThreads) void init_kernel(TrainArgs A, const uint8
             if (i < n) {
                 const uint32_t a = text[i];
                 A.buf[0][i] = a;                                    // lib.rs:72
-                if (i + 1 < n) delta_add(s_key, s_val, A.table, a * A.V + text[i + 1], 1);   // ids.windows(2)
+                if (i + 1 < n) delta_add(s_key, s_val, tab_of(A), a * A.V + text[i + 1], 1);   // ids.windows(2)
             }
         }
-        delta_flush(s_key, s_val, A.table);
+        delta_flush(s_key, s_val, tab_of(A));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         A.st->n_cur = n; A.st->n_next = n; A.st->active = 1; A.st->done = 0;
@@ -166,11 +205,6 @@ __global__ __launch_bounds__(kThreads) void init_kernel(TrainArgs A, const uint8
 
 // ---- 1. arg-max ------------------------------------------------------------------------------
 // order: larger count first, then smaller (left, right) = larger ~index.  A zero count never wins.
-__device__ __forceinline__ bool better(unsigned long long c, uint32_t k, unsigned long long bc, uint32_t bk)
-{
-    return c > bc || (c == bc && c != 0 && k > bk);
-}
-
 __global__ __launch_bounds__(kThreads) void argmax_partial_kernel(TrainArgs A, uint32_t merge_index)
 {
     __shared__ unsigned long long s_cnt[kThreads / 64];
@@ -195,6 +229,74 @@ __global__ __launch_bounds__(kThreads) void argmax_partial_kernel(TrainArgs A, u
         for (int w = 1; w < kThreads / 64; ++w) if (better(s_cnt[w], s_key[w], best, bkey)) { best = s_cnt[w]; bkey = s_key[w]; }
         A.partial[2 * blockIdx.x] = best;
         A.partial[2 * blockIdx.x + 1] = bkey;
+    }
+}
+
+// The one-rank trainer's arg-max, first half: a merge changes the counts of a few rows of the table (those of its two ids, of the new id, and of the ids that stood before a
+// site), so each row keeps its own maximum (row_cnt, row_key) and only the rows a count delta touched since (row_dirty, set by table_add) are read again -- not the
+// (256 + i) x V table of every merge: 145 MB at 4 000 merges, a tenth of a merge's time and the traffic that pushed the id buffers out of the memory-side cache.
+// Workgroup b owns rows b, b + G, ..., a lane a row; partial[b] = the best of its rows, for tile_count_kernel's final reduction.
+constexpr uint32_t kRowGrid = 64;
+__global__ __launch_bounds__(kThreads) void rowmax_kernel(TrainArgs A, uint32_t merge_index)
+{
+    __shared__ unsigned long long s_cnt[kThreads / 64];
+    __shared__ uint32_t s_key[kThreads / 64];
+    __shared__ uint32_t s_rows[kThreads];
+    __shared__ uint32_t s_n;
+    const uint32_t v_cur = 256u + merge_index;            // ids that can exist so far: rows and columns below v_cur
+    unsigned long long my_best = 0;
+    uint32_t my_key = 0;
+    for (uint32_t row0 = blockIdx.x; row0 < v_cur; row0 += gridDim.x * kThreads) {       // (one trip up to 16 384 ids)
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const uint32_t row = row0 + threadIdx.x * gridDim.x;                             // a lane a row: its kept maximum, or its name on the list of rows to read again
+        if (row < v_cur) {
+            if (A.row_dirty[row]) s_rows[atomicAdd(&s_n, 1u)] = row;
+            else {
+                const unsigned long long oc = A.row_cnt[row];
+                const uint32_t ok = A.row_key[row];
+                if (better(oc, ok, my_best, my_key)) { my_best = oc; my_key = ok; }
+            }
+        }
+        __syncthreads();
+        const uint32_t n_again = s_n;
+        for (uint32_t q = 0; q < n_again; ++q) {                                         // (a handful per merge over the whole grid)
+            const uint32_t again = s_rows[q];
+            unsigned long long best = 0;
+            uint32_t bkey = 0;
+            const uint64_t *cells = A.table + (size_t)again * A.V;
+#pragma unroll 4
+            for (uint32_t c = threadIdx.x; c < v_cur; c += kThreads) {
+                const unsigned long long cnt = cells[c];
+                const uint32_t k = ~(again * A.V + c);
+                if (better(cnt, k, best, bkey)) { best = cnt; bkey = k; }
+            }
+            for (int d = 32; d > 0; d >>= 1) {
+                const unsigned long long oc = __shfl_down(best, d, 64);
+                const uint32_t ok = __shfl_down(bkey, d, 64);
+                if (better(oc, ok, best, bkey)) { best = oc; bkey = ok; }
+            }
+            if ((threadIdx.x & 63) == 0) { s_cnt[threadIdx.x >> 6] = best; s_key[threadIdx.x >> 6] = bkey; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int w = 1; w < kThreads / 64; ++w) if (better(s_cnt[w], s_key[w], best, bkey)) { best = s_cnt[w]; bkey = s_key[w]; }
+                A.row_cnt[again] = best; A.row_key[again] = bkey; A.row_dirty[again] = 0u;
+                if (better(best, bkey, my_best, my_key)) { my_best = best; my_key = bkey; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        const unsigned long long oc = __shfl_down(my_best, d, 64);
+        const uint32_t ok = __shfl_down(my_key, d, 64);
+        if (better(oc, ok, my_best, my_key)) { my_best = oc; my_key = ok; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { s_cnt[threadIdx.x >> 6] = my_best; s_key[threadIdx.x >> 6] = my_key; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kThreads / 64; ++w) if (better(s_cnt[w], s_key[w], my_best, my_key)) { my_best = s_cnt[w]; my_key = s_key[w]; }
+        A.partial[2 * blockIdx.x] = my_best; A.partial[2 * blockIdx.x + 1] = my_key;
     }
 }
 
@@ -256,25 +358,49 @@ __device__ __forceinline__ uint32_t halo_at(const Halo &h, int64_t i, uint64_t n
 constexpr uint32_t kStageWords = kTile + 3 + (kTile + 3) / kPerThread + 1;
 // Staging in two halves, so that a workgroup's NEXT tile travels while it works on the current one (a tile staged when it is needed costs its memory latency every time:
 // the rewrite took 87 us per merge on a corpus it could stream in 40): tile_fetch requests the tile's words into registers, tile_park writes them to LDS (barrier inside).
-constexpr int kFetchWords = (kTile + 3 + kThreads - 1) / kThreads;
-struct TileRegs { uint32_t w[kFetchWords]; };
+// The tile's own words travel sixteen bytes a lane (its start is aligned: buffers are, tiles are kTile words); the id before it and the two after by lanes 0, 1, 2.
+static_assert(kPerThread % 4 == 0, "a lane fetches its share of a tile in 16-byte pieces");
+constexpr int kFetchVecs = kPerThread / 4;
+struct TileRegs { uint4 v[kFetchVecs]; uint32_t h; };
+// position in the staged tile (0 = the id before the tile) of word c of a lane's k-th piece, and of the lane's neighbour word
+__device__ __forceinline__ uint32_t fetch_pos(int k, int c) { return 1u + ((uint32_t)k * kThreads + threadIdx.x) * 4u + (uint32_t)c; }
+__device__ __forceinline__ uint32_t fetch_pos_h() { return threadIdx.x == 0 ? 0u : kTile + threadIdx.x; }
 __device__ __forceinline__ void tile_fetch(TileRegs &r, const uint32_t *src, uint64_t base, uint64_t n, const Halo &h)
 {
+    if (base >= 1 && base + kTile + 2 <= n) {         // (uniform) a tile with its three neighbours inside the buffer -- all but the first and the last one or two: nothing to check
+        const uint4 *p = reinterpret_cast<const uint4 *>(src + base) + threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < kFetchWords; ++k) {
-        const uint32_t j = threadIdx.x + (uint32_t)k * kThreads;
-        const int64_t i = (int64_t)base + j - 1;
-        r.w[k] = (j < kTile + 3) ? ((i >= 0 && i < (int64_t)n) ? src[i] : halo_at(h, i, n)) : 0u;
+        for (int k = 0; k < kFetchVecs; ++k) r.v[k] = p[(uint32_t)k * kThreads];
+        r.h = threadIdx.x < 3 ? src[base + fetch_pos_h() - 1] : 0u;
+        return;
+    }
+    // a boundary tile: word by word, each checked (the compiler branches around and waits for every load -- two or three tiles of a merge)
+#pragma unroll
+    for (int k = 0; k < kFetchVecs; ++k) {
+        uint32_t w[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t i = (int64_t)base + fetch_pos(k, c) - 1;
+            w[c] = (i < (int64_t)n) ? src[i] : halo_at(h, i, n);
+        }
+        r.v[k] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    r.h = 0u;
+    if (threadIdx.x < 3) {
+        const int64_t i = (int64_t)base + fetch_pos_h() - 1;
+        r.h = (i >= 0 && i < (int64_t)n) ? src[i] : halo_at(h, i, n);
     }
 }
 __device__ __forceinline__ void tile_park(uint32_t *s_ids, const TileRegs &r)
 {
 #pragma unroll
-    for (int k = 0; k < kFetchWords; ++k) {
-        const uint32_t j = threadIdx.x + (uint32_t)k * kThreads;
-        if (j < kTile + 3) s_ids[j + j / kPerThread] = r.w[k];
+    for (int k = 0; k < kFetchVecs; ++k) {
+        const uint32_t w[4] = {r.v[k].x, r.v[k].y, r.v[k].z, r.v[k].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const uint32_t j = fetch_pos(k, c); s_ids[j + j / kPerThread] = w[c]; }
     }
-    __syncthreads();
+    if (threadIdx.x < 3) { const uint32_t j = fetch_pos_h(); s_ids[j + j / kPerThread] = r.h; }
+    lds_barrier();
 }
 __device__ __forceinline__ void span_from_lds(Span &s, const uint32_t *s_ids)
 {
@@ -296,7 +422,7 @@ __device__ __forceinline__ uint32_t trailing_l(const Span &s, uint32_t l)
 // the nearest previous thread whose span is not all `l` (spans are even-sized, so all-`l` spans
 // pass parity through); `tile_par` if every previous thread of the tile is all `l`.
 // Contains workgroup barriers: call from uniform control flow.
-__device__ __forceinline__ uint32_t thread_lead_parity(uint32_t tail, uint32_t tile_par, uint32_t *s_wave)
+__device__ __forceinline__ uint32_t thread_lead_parity(uint32_t tail, uint32_t tile_par, uint32_t *s_wave, uint32_t *next_tile_par = nullptr)
 {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned long long m = __ballot(tail != kPerThread);
@@ -306,7 +432,7 @@ __device__ __forceinline__ uint32_t thread_lead_parity(uint32_t tail, uint32_t t
     const int src = before ? 63 - __clzll((long long)before) : 0;
     const uint32_t src_tail = __shfl(tail, src, 64);
     if (lane == 0) s_wave[wv] = m ? (2u | (last_tail & 1u)) : 0u;
-    __syncthreads();
+    lds_barrier();
     uint32_t par;
     if (before) par = src_tail & 1u;
     else {
@@ -314,7 +440,13 @@ __device__ __forceinline__ uint32_t thread_lead_parity(uint32_t tail, uint32_t t
         for (int w = (int)wv - 1; w >= 0; --w)
             if (s_wave[w] & 2u) { par = s_wave[w] & 1u; break; }
     }
-    __syncthreads();
+    if (next_tile_par) {                                     // what the NEXT tile is handed: the last span that is not all `l` decides, else the parity passes through
+        uint32_t np = tile_par;
+        for (int w = kThreads / 64 - 1; w >= 0; --w)
+            if (s_wave[w] & 2u) { np = s_wave[w] & 1u; break; }
+        *next_tile_par = np;
+    }
+    lds_barrier();
     return par;
 }
 
@@ -407,12 +539,73 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
     const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
     const Halo alone{kEmpty, {kEmpty, kEmpty, kEmpty}, 0, {0, 0, 0}};                                             // as if the shard stood alone: tile_scan adds what the neighbours change
     TileRegs tr;
-    if (blockIdx.x < n_tiles) tile_fetch(tr, src, (uint64_t)blockIdx.x * kTile, n, alone);
-    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    uint32_t t_first, t_count;
+    tile_range(n_tiles, blockIdx.x, gridDim.x, t_first, t_count);
+    if (!same) {
+        // Two different ids (nearly every merge): an id is consumed iff it is `r` and follows `l` -- a fact about two neighbours, whatever lane holds them.  So the
+        // range streams through registers as it lies in memory (16 bytes a lane, the word before a lane's piece from the lane below), no LDS, no barrier until the one
+        // sum at the end.  Through the staged spans of the l == r path this pass ran at 2.3 TB/s on a corpus in HBM.
+        uint32_t dropped = 0;
+        const uint32_t lane = threadIdx.x & 63;
+        constexpr int kAhead = 4;                                                      // tiles requested together: a lane has 8 x 16 bytes in flight (one tile at a time, a
+        auto whole_tiles = [&](uint64_t base, auto n_const) {                          //  trip was one memory latency long: 2.3 TB/s on a corpus in HBM)
+            constexpr int NV = decltype(n_const)::value * kFetchVecs;
+            const uint4 *p = reinterpret_cast<const uint4 *>(src + base) + threadIdx.x;
+            uint4 v[NV];
+            uint32_t before[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                v[k] = p[(uint32_t)k * kThreads];
+                before[k] = 0u;
+                if (lane == 0) before[k] = src[base + ((uint64_t)k * kThreads + threadIdx.x) * 4u - 1u];
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const uint32_t up = __shfl_up(v[k].w, 1, 64);
+                const uint32_t a0 = lane == 0 ? before[k] : up;
+                dropped += (a0 == l && v[k].x == r ? 1u : 0u) + (v[k].x == l && v[k].y == r ? 1u : 0u) + (v[k].y == l && v[k].z == r ? 1u : 0u) +
+                           (v[k].z == l && v[k].w == r ? 1u : 0u);
+            }
+        };
+        uint32_t t = t_first;
+        const uint32_t t_end = t_first + t_count;
+        for (; t < t_end; ) {
+            const uint64_t base = (uint64_t)t * kTile;
+            if (t + kAhead <= t_end && base >= 1 && base + (uint64_t)kAhead * kTile <= n) {      // (uniform) whole tiles with an id before them
+                whole_tiles(base, std::integral_constant<int, kAhead>{});
+                t += kAhead;
+            } else if (base >= 1 && base + kTile <= n) {
+                whole_tiles(base, std::integral_constant<int, 1>{});
+                t += 1;
+            } else {                                                                    // the first tile, a partial last one
+                for (uint32_t k = threadIdx.x; k < kTile; k += kThreads) {
+                    const uint64_t i = base + k;
+                    if (i < n && i >= 1 && src[i - 1] == l && src[i] == r) ++dropped;
+                }
+                t += 1;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) dropped += __shfl_down(dropped, o, 64);
+        if (lane == 0) s_cnt[threadIdx.x >> 6] = dropped;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (int w = 0; w < kThreads / 64; ++w) total += s_cnt[w];
+            const uint64_t lo = min((uint64_t)t_first * kTile, n), hi = min((uint64_t)(t_first + t_count) * kTile, n);
+            A.tiles[blockIdx.x].count0 = (uint32_t)(hi - lo) - total;
+            A.tiles[blockIdx.x].flags = 0u;
+        }
+        return;
+    }
+    if (t_count) tile_fetch(tr, src, (uint64_t)t_first * kTile, n, alone);
+    // the range's record, built by thread 0 tile after tile exactly as tile_scan_kernel would chain the tiles' own records (entering parity 0): a tile of nothing but `l`
+    // hands the parity on; the first tile that is not decides what an odd entering run costs the range (bit0); the last one decides the parity the range hands on (bit2)
+    uint32_t r_count = 0, r_bit0 = 0, r_tp = 0, r_par = 0, r_seen = 0;
+    for (uint32_t t = t_first; t < t_first + t_count; ++t) {
         Span s;
         tile_park(s_ids, tr);
         span_from_lds(s, s_ids);
-        if (t + gridDim.x < n_tiles) tile_fetch(tr, src, (uint64_t)(t + gridDim.x) * kTile, n, alone);          // the next tile's words travel under this tile's work
+        if (t + 1 < t_first + t_count) tile_fetch(tr, src, (uint64_t)(t + 1) * kTile, n, alone);               // the next tile's words travel under this tile's work
         uint32_t dropped = 0, tail = 0;
         if (!same) {
 #pragma unroll
@@ -436,7 +629,7 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
                 s_first[threadIdx.x >> 6] = m ? (uint32_t)__ffsll((long long)m) - 1u : 64u;
                 s_last[threadIdx.x >> 6] = m ? (2u | (last_tail & 1u)) : 0u;
             }
-            __syncthreads();
+            lds_barrier();
             uint32_t first_thread = kThreads;
             for (int w = 0; w < kThreads / 64; ++w)
                 if (s_first[w] != 64u) { first_thread = w * 64 + s_first[w]; break; }
@@ -446,7 +639,7 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
                 for (int k = 1; k <= kPerThread; ++k) { if (s.a[k] == l && c == (uint32_t)(k - 1)) ++c; }
                 s_lead_extra = c;                     // leading `l` ids inside the first non-uniform span
             }
-            __syncthreads();
+            lds_barrier();
             if (threadIdx.x == 0) {
                 const bool whole = (first_thread == kThreads);
                 uint32_t tp = 0;
@@ -454,21 +647,32 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
                 flags = (whole ? 2u : (s_lead_extra & 1u)) | (tp << 2);
             }
         } else {
-            __syncthreads();
+            lds_barrier();
         }
         if (threadIdx.x == 0) {
             uint32_t total = 0;
             for (int w = 0; w < kThreads / 64; ++w) total += s_cnt[w];
             const uint32_t in_tile = (uint32_t)min((uint64_t)kTile, n - (uint64_t)t * kTile);
-            A.tiles[t].count0 = in_tile - total;
-            A.tiles[t].flags = flags;
+            uint32_t c = in_tile - total;
+            if (same) {
+                if (r_par && (flags & 1u)) c -= 1u;                      // odd run entering the tile + odd leading run: one more id is consumed
+                if (!(flags & 2u)) {
+                    if (!r_seen) { r_bit0 = flags & 1u; r_seen = 1u; }
+                    r_par = r_tp = (flags >> 2) & 1u;
+                }
+            }
+            r_count += c;
         }
-        __syncthreads();
+        lds_barrier();
+    }
+    if (threadIdx.x == 0) {
+        A.tiles[blockIdx.x].count0 = r_count;
+        A.tiles[blockIdx.x].flags = same ? (r_seen ? (r_bit0 | (r_tp << 2)) : 2u) : 0u;    // (an empty range: nothing but `l`, vacuously -- the parity passes through)
     }
 }
 
-// ---- 3. scan of tile counts (one workgroup) ---------------------------------------------------
-__global__ __launch_bounds__(1024) void tile_scan_kernel(TrainArgs A, uint32_t src_sel)
+// ---- 3. scan of the ranges' records (one workgroup; n_tiles = the number of ranges = the grid of the two passes around it) ----
+__global__ __launch_bounds__(1024) void tile_scan_kernel(TrainArgs A, uint32_t src_sel, uint32_t n_tiles)
 {
     __shared__ uint32_t s_cnt[1024];
     __shared__ uint32_t s_par[1024];
@@ -479,7 +683,6 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TrainArgs A, uint32_t s
     if (!st->active) return;
     const uint64_t n = st->n_cur;
     const bool same = st->left == st->right;
-    const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
     const Halo halo = *A.halo;
     if (threadIdx.x == 0) { s_carry = 0; s_carry_par = same ? halo.lead_par : 0u; }
     __syncthreads();
@@ -543,17 +746,29 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TrainArgs A, uint32_t s
 }
 
 // ---- 4. rewrite + compaction + count deltas ---------------------------------------------------
-__global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t src_sel)
+#ifdef ECGB_TRAIN_TIMING      // dev builds: shader-clock cycles of every workgroup's phases, summed (scripts/dev_trainer_phases.py)
+__device__ unsigned long long g_phase[16];
+#define PH_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) ph[i] += now_ - last_; last_ = now_; } while (0)
+#define PH_DECL unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long last_ = __builtin_readcyclecounter()
+#define PH_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_phase[i_], ph[i_]); atomicAdd(&g_phase[15], 1ull); } } while (0)
+#else
+#define PH_MARK(i) do {} while (0)
+#define PH_DECL do {} while (0)
+#define PH_FLUSH do {} while (0)
+#endif
+__global__ __launch_bounds__(kThreads, ECGB_RW_WAVES) void rewrite_kernel(TrainArgs A, uint32_t src_sel)
 {
     __shared__ uint32_t s_key[kHashSlots];
     __shared__ int s_val[kHashSlots];
     __shared__ uint32_t s_wave[kThreads / 64];
     __shared__ uint32_t s_wsum[kThreads / 64];
     __shared__ uint32_t s_ids[kStageWords];               // the tile on its way in (tile_park), then its survivors on their way out
+    PH_DECL;
     const TrainState st = *A.st;
     if (!st.active) return;
     for (uint32_t i = threadIdx.x; i < kHashSlots; i += kThreads) { s_key[i] = kEmpty; s_val[i] = 0; }
     __syncthreads();
+    PH_MARK(0);
     const uint32_t *src = A.buf[src_sel];
     uint32_t *dst = A.buf[src_sel ^ 1u];
     const uint64_t n = st.n_cur;
@@ -563,18 +778,46 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
     const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
     TileRegs tr;
     uint32_t tiles_done = 0;
-    if (blockIdx.x < n_tiles) tile_fetch(tr, src, (uint64_t)blockIdx.x * kTile, n, halo);
-    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    uint32_t t_first, t_count;
+    tile_range(n_tiles, blockIdx.x, gridDim.x, t_first, t_count);
+    const uint64_t off_word = A.tile_off[blockIdx.x];      // the range's output offset and the run parity entering it; from here on the workgroup carries both
+    uint64_t run_off = off_word & 0x7FFFFFFFFFFFFFFFull;
+    uint32_t run_par = (uint32_t)(off_word >> 63);
+    if (t_count) tile_fetch(tr, src, (uint64_t)t_first * kTile, n, halo);
+    // A tile's survivors leave one trip LATE, after the next tile has been parked: the counter of memory operations in flight retires in order, and the wait for the
+    // next tile's words (requested a whole trip earlier) must find nothing younger than them in flight -- stores issued just before it would have to drain first
+    // (the compiler cannot wait past them either: each store sits under its own lane mask, and it counts a skipped branch as no store).  So a trip takes the previous
+    // tile's survivors from LDS into registers, parks its own tile, and only then sends them out; the last tile's follow the loop.
+    uint32_t kept_prev = 0;
+    uint64_t out_prev = 0;
+    uint32_t sv[kPerThread];
+    auto survivors_take = [&]() {
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) sv[k] = s_ids[threadIdx.x + (uint32_t)k * kThreads];
+        lds_barrier();                                       // (everybody has its survivors in registers: s_ids is free for the next tile)
+    };
+    auto survivors_send = [&]() {
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            const uint32_t i = threadIdx.x + (uint32_t)k * kThreads;
+            if (i < kept_prev) dst[out_prev + i] = sv[k];
+        }
+    };
+    for (uint32_t t = t_first; t < t_first + t_count; ++t) {
+        survivors_take();
+        PH_MARK(5);
         const uint64_t i0 = (uint64_t)t * kTile + threadIdx.x * kPerThread;
-        const uint64_t off_word = A.tile_off[t];
-        const uint32_t tile_par = (uint32_t)(off_word >> 63);
-        const uint64_t tile_off = off_word & 0x7FFFFFFFFFFFFFFFull;
+        const uint32_t tile_par = run_par;
+        const uint64_t tile_off = run_off;
         Span s;
         tile_park(s_ids, tr);
+        PH_MARK(1);
+        survivors_send();
+        PH_MARK(6);
         span_from_lds(s, s_ids);
-        if (t + gridDim.x < n_tiles) tile_fetch(tr, src, (uint64_t)(t + gridDim.x) * kTile, n, halo);           // the next tile's words travel under this tile's work
+        if (t + 1 < t_first + t_count) tile_fetch(tr, src, (uint64_t)(t + 1) * kTile, n, halo);                 // the next tile's words travel under this tile's work
         uint32_t lead_par = 0;
-        if (l == r) lead_par = thread_lead_parity(trailing_l(s, l), tile_par, s_wave);
+        if (l == r) lead_par = thread_lead_parity(trailing_l(s, l), tile_par, s_wave, &run_par);
         uint32_t site_mask, second_mask, sa;
         classify(s, l, r, lead_par, site_mask, second_mask, sa);
         // Is the element BEFORE the span (a[0]) a site?  For l != r directly; for l == r, a[0] (if it
@@ -587,18 +830,23 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
         site_mask |= sa << (kPerThread + 1);
         // local survivors
         const uint32_t valid = (i0 < n) ? (uint32_t)min((uint64_t)kPerThread, n - i0) : 0u;
-        uint32_t kept = 0;
-#pragma unroll
-        for (int k = 1; k <= kPerThread; ++k) kept += ((uint32_t)k <= valid && !((second_mask >> k) & 1u)) ? 1u : 0u;
+        const uint32_t kept = __popc((((1u << valid) - 1u) << 1) & ~second_mask);
         uint32_t incl = kept;
         const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
         if (lane == 63) s_wsum[wv] = incl;
-        __syncthreads();                                     // (every lane has its span in registers: s_ids is free for the survivors)
+        PH_MARK(2);
+        lds_barrier();                                     // (every lane has its span in registers: s_ids is free for the survivors)
+        PH_MARK(3);
         uint32_t w_off = 0, tile_kept = 0;
         for (uint32_t w = 0; w < kThreads / 64; ++w) { if (w < wv) w_off += s_wsum[w]; tile_kept += s_wsum[w]; }
         uint32_t o = w_off + incl - kept;                    // inside the tile's output; it leaves LDS in one coalesced copy below
-        // walk the span: write survivors, emit count deltas
+        // walk the span: write survivors, emit count deltas.  A span with no site in or next to it (site_mask covers elements 0..17) keeps all its ids and changes no
+        // count -- nearly every span once the merged pairs are rare, which is most merges: sixteen stores instead of the walk's ~350 vector instructions
+        if ((site_mask | second_mask) == 0 && valid == (uint32_t)kPerThread) {
+#pragma unroll
+            for (int k = 1; k <= kPerThread; ++k) s_ids[o + (uint32_t)(k - 1)] = s.a[k];
+        } else
 #pragma unroll
         for (int k = 1; k <= kPerThread; ++k) {
             if ((uint32_t)k > valid) continue;
@@ -608,7 +856,7 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
             const bool site_next = (site_mask >> (k + 1)) & 1u;
             // old pair (a[k], a[k+1]) disappears iff a site starts at k-1, k or k+1
             if (s.a[k + 1] != kEmpty && (site_prev || is_site || site_next))
-                delta_add_s(s_key, s_val, A.table, A.slab, SK, s.a[k] * V + s.a[k + 1], -1);
+                delta_add_s(s_key, s_val, tab_of(A), A.slab, SK, s.a[k] * V + s.a[k + 1], -1);
             if (!is_second) {
                 const uint32_t val = is_site ? X : s.a[k];
                 s_ids[o++] = val;
@@ -626,18 +874,25 @@ __global__ __launch_bounds__(kThreads) void rewrite_kernel(TrainArgs A, uint32_t
                         next_site = (an == l && a19 == r);
                     }
                     const uint32_t next_val = next_site ? X : an;
-                    if (is_site || next_site) delta_add_s(s_key, s_val, A.table, A.slab, SK, val * V + next_val, 1);
+                    if (is_site || next_site) delta_add_s(s_key, s_val, tab_of(A), A.slab, SK, val * V + next_val, 1);
                 }
             }
         }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < tile_kept; i += kThreads) dst[tile_off + i] = s_ids[i];
+        PH_MARK(4);
+        kept_prev = tile_kept;
+        out_prev = tile_off;
+        run_off += tile_kept;
         // the count deltas stay in the workgroup's LDS table across its tiles and leave every eighth tile and at the end (a flush per tile was two barriers, a sweep of
         // the 2 048 slots and as many global atomics as the tile had distinct pairs -- the same pairs tile after tile); a table that fills up overflows into memory as before
-        if (((++tiles_done) & 7u) == 0) delta_flush(s_key, s_val, A.table, A.slab, SK);
-        else __syncthreads();                                // (fences s_ids before the next tile is parked)
+        if (((++tiles_done) & 7u) == 0) delta_flush(s_key, s_val, tab_of(A), A.slab, SK);
+        else lds_barrier();                                // (the survivors are all in s_ids)
+        PH_MARK(7);
     }
-    delta_flush(s_key, s_val, A.table, A.slab, SK);
+    survivors_take();
+    survivors_send();
+    delta_flush(s_key, s_val, tab_of(A), A.slab, SK);
+    PH_MARK(8);
+    PH_FLUSH;
 }
 
 // =================================================================================================================
@@ -674,14 +929,14 @@ __global__ __launch_bounds__(kThreads) void shard_count_kernel(TrainArgs A)
             const uint64_t i = base + k;
             if (i < n) {
                 const uint32_t b = (i + 1 < n) ? A.buf[0][i + 1] : halo.next[0];
-                if (b != kEmpty) delta_add(s_key, s_val, A.table, A.buf[0][i] * A.V + b, 1);
+                if (b != kEmpty) delta_add(s_key, s_val, tab_of(A), A.buf[0][i] * A.V + b, 1);
             }
         }
-        delta_flush(s_key, s_val, A.table);
+        delta_flush(s_key, s_val, tab_of(A));
     }
 }
 
-// One workgroup: the slice's summary for the merge in flight (after tile_count_kernel: the per-tile run facts are in A.tiles).
+// One workgroup: the slice's summary for the merge in flight.
 __global__ __launch_bounds__(kThreads) void shard_summary_kernel(TrainArgs A, uint32_t src_sel, long long *summary, int with_pair)
 {
     __shared__ long long s_last_other[kThreads / 64];
@@ -692,29 +947,26 @@ __global__ __launch_bounds__(kThreads) void shard_summary_kernel(TrainArgs A, ui
     const bool same = with_pair && st.active && st.left == st.right;
     long long all_l = 0, tail_par = 0;
     if (same && n > 0) {
-        const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
-        const uint64_t base = (uint64_t)(n_tiles - 1) * kTile;
-        const uint32_t sz = (uint32_t)(n - base);                       // the last tile may be partial (and odd-sized)
-        long long last_other = -1;                                      // last position of the last tile that is not `left`
-        for (uint32_t k = threadIdx.x; k < sz; k += kThreads) if (src[base + k] != l) last_other = k;
-        for (int d = 32; d > 0; d >>= 1) { const long long o = __shfl_down(last_other, d, 64); last_other = o > last_other ? o : last_other; }
-        if ((threadIdx.x & 63) == 0) s_last_other[threadIdx.x >> 6] = last_other;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < kThreads / 64; ++w) last_other = s_last_other[w] > last_other ? s_last_other[w] : last_other;
-            if (last_other >= 0) tail_par = (sz - 1 - last_other) & 1;
-            else {
-                tail_par = sz & 1;                                      // the whole last tile is `left`: the run reaches further back
-                all_l = 1;
-                for (long long t = (long long)n_tiles - 2; t >= 0; --t) {
-                    const uint32_t f = A.tiles[t].flags;
-                    if (f & 2u) continue;                               // a full tile of `left`: 4096 ids, parity unchanged
-                    tail_par ^= (f >> 2) & 1u;                          // parity of the run that ends this tile
-                    all_l = 0;
-                    break;
-                }
+        // the last id of the slice that is not `left`, looked for from the end a tile's worth at a time (nearly always found in the first)
+        __shared__ long long s_found;
+        long long found = -1;
+        for (uint64_t end = n; end > 0 && found < 0; ) {
+            const uint64_t base = end > kTile ? end - kTile : 0;
+            long long last_other = -1;
+            for (uint64_t i = base + threadIdx.x; i < end; i += kThreads) if (src[i] != l) last_other = (long long)i;
+            for (int d = 32; d > 0; d >>= 1) { const long long o = __shfl_down(last_other, d, 64); last_other = o > last_other ? o : last_other; }
+            if ((threadIdx.x & 63) == 0) s_last_other[threadIdx.x >> 6] = last_other;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int w = 1; w < kThreads / 64; ++w) last_other = s_last_other[w] > last_other ? s_last_other[w] : last_other;
+                s_found = last_other;
             }
+            __syncthreads();
+            found = s_found;
+            end = base;
         }
+        if (found >= 0) tail_par = (long long)((n - 1 - (uint64_t)found) & 1);
+        else { tail_par = (long long)(n & 1); all_l = 1; }              // nothing but `left`: the run reaches into the slice before
     }
     if (threadIdx.x == 0) {
         summary[0] = (long long)n;
@@ -801,7 +1053,7 @@ inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w)
 {
     const size_t V = 256 + (size_t)num_merges;
-    const size_t tiles = (n + kTile - 1) / kTile + 1;
+    const size_t tiles = kGrid;                                         // (records are per range of tiles: one per workgroup of the grid)
     uint8_t *p = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(scratch_dev) + 255) / 256 * 256);
     TrainArgs A;
     A.st = reinterpret_cast<TrainState *>(p); p += align256(sizeof(TrainState));
@@ -811,6 +1063,9 @@ TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w
     A.tiles = reinterpret_cast<TileInfo *>(p); p += align256(tiles * sizeof(TileInfo));
     A.tile_off = reinterpret_cast<uint64_t *>(p); p += align256(tiles * 8);
     A.partial = reinterpret_cast<uint64_t *>(p); p += align256(kGrid * 16);
+    A.row_cnt = reinterpret_cast<uint64_t *>(p); p += align256(V * 8);
+    A.row_key = reinterpret_cast<uint32_t *>(p); p += align256(V * 4);
+    A.row_dirty = reinterpret_cast<uint32_t *>(p); p += align256(V * 4);
     *halo_w = reinterpret_cast<Halo *>(p); p += align256(sizeof(Halo));
     A.halo = *halo_w;
     A.slab = reinterpret_cast<long long *>(p); p += align256(6 * V * 8);
@@ -825,9 +1080,9 @@ TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w
 extern "C" size_t ecgb_bpe_train_scratch_bytes(size_t n, uint32_t num_merges)
 {
     const size_t V = 256 + (size_t)num_merges;
-    const size_t tiles = (n + kTile - 1) / kTile + 1;
+    const size_t tiles = kGrid;                                         // (records are per range of tiles: one per workgroup of the grid)
     return align256(sizeof(TrainState)) + align256(V * V * 8) + 2 * align256(n * 4 + 64) + align256(tiles * sizeof(TileInfo)) +
-           align256(tiles * 8) + align256(kGrid * 16) + align256(sizeof(Halo)) + align256(6 * V * 8) + align256(2 * (size_t)num_merges * 4 + 8) + 1024;
+           align256(tiles * 8) + align256(kGrid * 16) + align256(V * 8) + 2 * align256(V * 4) + align256(sizeof(Halo)) + align256(6 * V * 8) + align256(2 * (size_t)num_merges * 4 + 8) + 1024;
 }
 
 extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t num_merges, uint32_t *pairs_dev,
@@ -858,14 +1113,14 @@ extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t nu
     if (rc) return rc;
     rc = check_hip(hipMemsetAsync(reinterpret_cast<uint8_t *>(halo_w) + 16, 0, sizeof(Halo) - 16, st), "hipMemsetAsync(halo)");
     if (rc) return rc;
+    rc = check_hip(hipMemsetAsync(A.row_cnt, 0, reinterpret_cast<uint8_t *>(A.row_dirty + V) - reinterpret_cast<uint8_t *>(A.row_cnt), st), "hipMemsetAsync(row maxima)");
+    if (rc) return rc;                                                   // (no row has a count yet; init_kernel's deltas mark the rows they touch)
     const unsigned tile_grid = (unsigned)std::max<size_t>(1, std::min<size_t>(kGrid, (n + kTile - 1) / kTile));
     hipLaunchKernelGGL(init_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, text_dev);
     for (uint32_t i = 0; i < num_merges; ++i) {
-        const size_t live = (size_t)(256 + i) * V;
-        const unsigned ag = (unsigned)std::max<size_t>(1, std::min<size_t>(kGrid, (live + kThreads * 8 - 1) / (kThreads * 8)));
-        hipLaunchKernelGGL(argmax_partial_kernel, dim3(ag), dim3(kThreads), 0, st, A, i);
-        hipLaunchKernelGGL(tile_count_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, i & 1u, i, ag);      // (with the final arg-max and the commit of merge i - 1)
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, A, i & 1u);
+        hipLaunchKernelGGL(rowmax_kernel, dim3(kRowGrid), dim3(kThreads), 0, st, A, i);
+        hipLaunchKernelGGL(tile_count_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, i & 1u, i, kRowGrid);  // (with the final arg-max and the commit of merge i - 1)
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, A, i & 1u, tile_grid);
         hipLaunchKernelGGL(rewrite_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, i & 1u);
     }
     hipLaunchKernelGGL(finish_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, num_merges, ids_out_dev, n_ids_dev,
@@ -951,7 +1206,7 @@ extern "C" int ecgb_bpe_shard_merge(ecgb_bpe_shard *h, uint32_t merge_index, con
     if (!h || !gathered_dev || rank < 0 || rank >= world || merge_index >= h->num_merges) { ecgb::set_error("ecgb_bpe_shard_merge: bad argument"); return ECGB_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(shard_halo_kernel, dim3(1), dim3(64), 0, st, h->A, h->halo_w, gathered_dev, rank, world, 1);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, h->A, merge_index & 1u);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, h->A, merge_index & 1u, h->tile_grid);
     hipLaunchKernelGGL(rewrite_kernel, dim3(h->tile_grid), dim3(kThreads), 0, st, h->A, merge_index & 1u);
     return check_hip(hipGetLastError(), "bpe shard merge");
 }
@@ -974,3 +1229,12 @@ extern "C" int ecgb_bpe_shard_finish(ecgb_bpe_shard *h, uint32_t *pairs_dev, uin
         rc = check_hip(hipMemcpyAsync(pairs_dev, h->A.pairs_out, 2 * (size_t)h->num_merges * 4, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(pairs)");
     return rc;
 }
+
+#ifdef ECGB_TRAIN_TIMING
+extern "C" int ecgb_dev_train_phases(unsigned long long *out16)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    unsigned long long zero[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
