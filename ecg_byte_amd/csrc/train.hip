@@ -14,8 +14,8 @@
 //   1. arg-max: every row of the table keeps its maximum, only the rows a delta could have changed are read again (rowmax_kernel; the sharded form reads the
 //      live V_cur x V part, argmax_partial_kernel)
 //   2. survivor counts: each workgroup streams its contiguous range of tiles and leaves ONE record   (reads N_i)
-//   3. exclusive scan of the ranges' records             (one workgroup, as many records as workgroups)
-//   4. rewrite + compaction + count deltas: each workgroup walks its range in order, carrying the output offset and the run parity   (reads N_i, writes N_{i+1})
+//   3. rewrite + compaction + count deltas: each workgroup chains the records below its own (its output offset, the run parity entering its range), then walks its
+//      range in order, carrying both   (reads N_i, writes N_{i+1})
 // Runs of one symbol merged with itself ("aaa" -> "Xa") need the offset parity inside the run;
 // tiles and per-thread spans are even-sized, so parity is carried by a "last non-uniform span"
 // look-up instead of a full segmented scan.  No host synchronisation inside the merge loop: the
@@ -39,7 +39,10 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kPerThread = ECGB_TRAIN_PER_THREAD;       // even: a span of one repeated symbol keeps run parity
 constexpr uint32_t kTile = kThreads * kPerThread;     // 2048 ids per tile
-constexpr uint32_t kGrid = 2048;                      // persistent grid (8 workgroups per CU)
+#ifndef ECGB_TRAIN_GRID
+#define ECGB_TRAIN_GRID 1280                                 // five rewrite workgroups a CU (its registers and LDS allow five): every workgroup resident, one round
+#endif
+constexpr uint32_t kGrid = ECGB_TRAIN_GRID;            // workgroups of the two passes (a multiple of kThreads: the rewrite's lanes share out the records)
 constexpr uint32_t kHashSlots = 2048;                 // per-workgroup LDS table of count deltas
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
 
@@ -76,7 +79,6 @@ struct TrainArgs {
     uint32_t V;
     uint32_t *buf[2];      // ping-pong id buffers
     TileInfo *tiles;       // per RANGE of tiles (a workgroup's contiguous share of the buffer, tile_range): what TileInfo says of a tile, of the whole range
-    uint64_t *tile_off;    // per range: exclusive output offset; lead parity in the top bit
     uint64_t *partial;     // kGrid arg-max partials: 2 words each, count and ~key
     uint64_t *row_cnt;     // per row of the table: its largest count ...
     uint32_t *row_key;     //  ... and ~index of that cell (the smallest index among equals), exact unless row_dirty
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
     const uint32_t l = st.left, r = st.right;
     const bool same = (l == r);
     const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
-    const Halo alone{kEmpty, {kEmpty, kEmpty, kEmpty}, 0, {0, 0, 0}};                                             // as if the shard stood alone: tile_scan adds what the neighbours change
+    const Halo alone{kEmpty, {kEmpty, kEmpty, kEmpty}, 0, {0, 0, 0}};                                             // as if the shard stood alone: the rewrite adds what the neighbours change
     TileRegs tr;
     uint32_t t_first, t_count;
     tile_range(n_tiles, blockIdx.x, gridDim.x, t_first, t_count);
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
         return;
     }
     if (t_count) tile_fetch(tr, src, (uint64_t)t_first * kTile, n, alone);
-    // the range's record, built by thread 0 tile after tile exactly as tile_scan_kernel would chain the tiles' own records (entering parity 0): a tile of nothing but `l`
+    // the range's record, built by thread 0 tile after tile exactly as the rewrite chains the ranges' records (entering parity 0): a tile of nothing but `l`
     // hands the parity on; the first tile that is not decides what an odd entering run costs the range (bit0); the last one decides the parity the range hands on (bit2)
     uint32_t r_count = 0, r_bit0 = 0, r_tp = 0, r_par = 0, r_seen = 0;
     for (uint32_t t = t_first; t < t_first + t_count; ++t) {
@@ -671,80 +673,6 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
     }
 }
 
-// ---- 3. scan of the ranges' records (one workgroup; n_tiles = the number of ranges = the grid of the two passes around it) ----
-__global__ __launch_bounds__(1024) void tile_scan_kernel(TrainArgs A, uint32_t src_sel, uint32_t n_tiles)
-{
-    __shared__ uint32_t s_cnt[1024];
-    __shared__ uint32_t s_par[1024];
-    __shared__ uint32_t s_wsum[16];
-    __shared__ uint64_t s_carry;
-    __shared__ uint32_t s_carry_par;
-    TrainState *st = A.st;
-    if (!st->active) return;
-    const uint64_t n = st->n_cur;
-    const bool same = st->left == st->right;
-    const Halo halo = *A.halo;
-    if (threadIdx.x == 0) { s_carry = 0; s_carry_par = same ? halo.lead_par : 0u; }
-    __syncthreads();
-    for (uint32_t base = 0; base < n_tiles; base += 1024) {
-        const uint32_t t = base + threadIdx.x;
-        TileInfo ti = { 0, 0 };
-        if (t < n_tiles) ti = A.tiles[t];
-        // a shard whose left neighbour ends in `left` while it starts with `right`: its first id is the second half of a site there
-        if (t == 0 && !same && n > 0 && halo.prev == st->left && A.buf[src_sel][0] == st->right) ti.count0 -= 1u;
-        s_cnt[threadIdx.x] = ti.count0;
-        s_par[threadIdx.x] = ti.flags;
-        __syncthreads();
-        if (same) {                                          // (uniform)
-            // Lead parity of each tile = parity of the run of `left` ending just before it: the trailing-run parity of the nearest earlier tile that is not
-            // uniformly `left` (those are even-sized: parity passes through), else the carry.  One thread walking the 1 024 tiles of a round took up to 1.9 ms
-            // per merge on a corpus of 29 000 tiles (a third of the l == r merges' scan); a tile a thread, by ballots (thread_lead_parity's scheme).
-            const uint32_t lane_ = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
-            const uint32_t lim = min(1024u, n_tiles - base);
-            const uint32_t f = ti.flags;
-            const bool valid = threadIdx.x < lim;
-            const bool nonuni = valid && !(f & 2u);
-            const uint32_t tp = (f >> 2) & 1u;                   // the tile's trailing-run parity
-            const unsigned long long m = __ballot(nonuni);
-            const int last = m ? 63 - __clzll((long long)m) : 0;
-            const uint32_t last_tp = __shfl(tp, last, 64);
-            const unsigned long long before = m & ((1ull << lane_) - 1ull);
-            const int src = before ? 63 - __clzll((long long)before) : 0;
-            const uint32_t src_tp = __shfl(tp, src, 64);
-            if (lane_ == 0) s_wsum[wv_] = m ? (2u | last_tp) : 0u;      // (s_wsum is free here: the count scan below fills it after a barrier)
-            __syncthreads();
-            uint32_t par;
-            if (before) par = src_tp;
-            else {
-                par = s_carry_par;
-                for (int w = (int)wv_ - 1; w >= 0; --w)
-                    if (s_wsum[w] & 2u) { par = s_wsum[w] & 1u; break; }
-            }
-            if (valid) {
-                if (par && (f & 1u)) s_cnt[threadIdx.x] -= 1u;      // odd entering run + odd leading run: one more id is consumed
-                s_par[threadIdx.x] = par;                            // this tile's lead parity
-            }
-            __syncthreads();                                     // everybody has read the carry and the waves' summaries
-            if (threadIdx.x == lim - 1) s_carry_par = nonuni ? tp : par;
-        }
-        __syncthreads();
-        // block-exclusive scan of s_cnt
-        uint32_t v = s_cnt[threadIdx.x];
-        uint32_t incl = v;
-        const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
-        if (lane == 63) s_wsum[wv] = incl;
-        __syncthreads();
-        uint64_t before = s_carry;
-        for (uint32_t w = 0; w < wv; ++w) before += s_wsum[w];
-        if (t < n_tiles) A.tile_off[t] = (before + incl - v) | ((uint64_t)(same ? s_par[threadIdx.x] : 0u) << 63);
-        __syncthreads();
-        if (threadIdx.x == 0) { uint32_t tot = 0; for (int w = 0; w < 16; ++w) tot += s_wsum[w]; s_carry += tot; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) st->n_next = s_carry;
-}
-
 // ---- 4. rewrite + compaction + count deltas ---------------------------------------------------
 #ifdef ECGB_TRAIN_TIMING      // dev builds: shader-clock cycles of every workgroup's phases, summed (scripts/dev_trainer_phases.py)
 __device__ unsigned long long g_phase[16];
@@ -764,6 +692,15 @@ __global__ __launch_bounds__(kThreads, ECGB_RW_WAVES) void rewrite_kernel(TrainA
     __shared__ uint32_t s_wsum[kThreads / 64];
     __shared__ uint32_t s_ids[kStageWords];               // the tile on its way in (tile_park), then its survivors on their way out
     PH_DECL;
+    constexpr int kRec = kGrid / kThreads;
+    static_assert(kGrid % kThreads == 0, "a lane takes kGrid / kThreads records");
+    uint32_t cnt[kRec], flg[kRec];                        // the count pass's records, a lane's share (requested first: they need nothing the state says)
+#pragma unroll
+    for (int q = 0; q < kRec; ++q) {
+        const uint32_t j = threadIdx.x * kRec + (uint32_t)q;
+        cnt[q] = 0u; flg[q] = 2u;                           // (past the grid: nothing, and the parity passes through)
+        if (j < gridDim.x) { const TileInfo ti = A.tiles[j]; cnt[q] = ti.count0; flg[q] = ti.flags; }
+    }
     const TrainState st = *A.st;
     if (!st.active) return;
     for (uint32_t i = threadIdx.x; i < kHashSlots; i += kThreads) { s_key[i] = kEmpty; s_val[i] = 0; }
@@ -780,10 +717,50 @@ __global__ __launch_bounds__(kThreads, ECGB_RW_WAVES) void rewrite_kernel(TrainA
     uint32_t tiles_done = 0;
     uint32_t t_first, t_count;
     tile_range(n_tiles, blockIdx.x, gridDim.x, t_first, t_count);
-    const uint64_t off_word = A.tile_off[blockIdx.x];      // the range's output offset and the run parity entering it; from here on the workgroup carries both
-    uint64_t run_off = off_word & 0x7FFFFFFFFFFFFFFFull;
-    uint32_t run_par = (uint32_t)(off_word >> 63);
     if (t_count) tile_fetch(tr, src, (uint64_t)t_first * kTile, n, halo);
+    // The range's output offset and the run parity entering it: every workgroup chains the (at most kGrid) records of the count pass for itself, under its first tile's
+    // flight -- a scan kernel between the two passes was a launch of 5.5 us per merge for 16 KB of records.  A lane takes kGrid / kThreads consecutive records.  For
+    // l == r a record's lead parity is the trailing-run parity of the nearest earlier record that is not all `l` (else what the left neighbour hands over), and an odd
+    // entering run costs a record with an odd leading run one more id: thread_lead_parity's scheme one level up.  From here on the workgroup carries both itself.
+    uint64_t run_off;
+    uint32_t run_par;
+    {
+        __shared__ unsigned long long s_below[kThreads / 64];
+        __shared__ unsigned long long s_own;
+        __shared__ uint32_t s_own_par;
+        const uint32_t G = gridDim.x, b = blockIdx.x;
+        // a shard whose left neighbour ends in `left` while it starts with `right`: its first id is the second half of a site there
+        if (threadIdx.x == 0 && l != r && n > 0 && halo.prev == l && src[0] == r) cnt[0] -= 1u;
+        uint32_t lead[kRec];
+#pragma unroll
+        for (int q = 0; q < kRec; ++q) lead[q] = 0u;
+        if (l == r) {                                               // (uniform)
+            uint32_t tail = kPerThread;                             // as thread_lead_parity reads a span: kPerThread = all `l`, else the parity in bit 0
+#pragma unroll
+            for (int q = 0; q < kRec; ++q) if (!(flg[q] & 2u)) tail = (flg[q] >> 2) & 1u;
+            uint32_t par = thread_lead_parity(tail, halo.lead_par, s_wave);
+#pragma unroll
+            for (int q = 0; q < kRec; ++q) {
+                lead[q] = par;
+                if (par && (flg[q] & 1u)) cnt[q] -= 1u;
+                if (!(flg[q] & 2u)) par = (flg[q] >> 2) & 1u;
+            }
+        }
+        unsigned long long below = 0;
+#pragma unroll
+        for (int q = 0; q < kRec; ++q) {
+            const uint32_t j = threadIdx.x * kRec + (uint32_t)q;
+            if (j < b) below += cnt[q];
+            if (j == b) { s_own = cnt[q]; s_own_par = lead[q]; }
+        }
+        for (int d = 32; d > 0; d >>= 1) below += __shfl_down(below, d, 64);
+        if ((threadIdx.x & 63) == 0) s_below[threadIdx.x >> 6] = below;
+        __syncthreads();
+        run_off = 0;
+        for (int w = 0; w < kThreads / 64; ++w) run_off += s_below[w];
+        run_par = s_own_par;
+        if (b == G - 1 && threadIdx.x == 0) A.st->n_next = run_off + s_own;      // the length this merge leaves (nobody reads it before the next launch)
+    }
     // A tile's survivors leave one trip LATE, after the next tile has been parked: the counter of memory operations in flight retires in order, and the wait for the
     // next tile's words (requested a whole trip earlier) must find nothing younger than them in flight -- stores issued just before it would have to drain first
     // (the compiler cannot wait past them either: each store sits under its own lane mask, and it counts a skipped branch as no store).  So a trip takes the previous
@@ -1061,7 +1038,6 @@ TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w
     A.buf[0] = reinterpret_cast<uint32_t *>(p); p += align256(n * 4 + 64);
     A.buf[1] = reinterpret_cast<uint32_t *>(p); p += align256(n * 4 + 64);
     A.tiles = reinterpret_cast<TileInfo *>(p); p += align256(tiles * sizeof(TileInfo));
-    A.tile_off = reinterpret_cast<uint64_t *>(p); p += align256(tiles * 8);
     A.partial = reinterpret_cast<uint64_t *>(p); p += align256(kGrid * 16);
     A.row_cnt = reinterpret_cast<uint64_t *>(p); p += align256(V * 8);
     A.row_key = reinterpret_cast<uint32_t *>(p); p += align256(V * 4);
@@ -1082,7 +1058,7 @@ extern "C" size_t ecgb_bpe_train_scratch_bytes(size_t n, uint32_t num_merges)
     const size_t V = 256 + (size_t)num_merges;
     const size_t tiles = kGrid;                                         // (records are per range of tiles: one per workgroup of the grid)
     return align256(sizeof(TrainState)) + align256(V * V * 8) + 2 * align256(n * 4 + 64) + align256(tiles * sizeof(TileInfo)) +
-           align256(tiles * 8) + align256(kGrid * 16) + align256(V * 8) + 2 * align256(V * 4) + align256(sizeof(Halo)) + align256(6 * V * 8) + align256(2 * (size_t)num_merges * 4 + 8) + 1024;
+           align256(kGrid * 16) + align256(V * 8) + 2 * align256(V * 4) + align256(sizeof(Halo)) + align256(6 * V * 8) + align256(2 * (size_t)num_merges * 4 + 8) + 1024;
 }
 
 extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t num_merges, uint32_t *pairs_dev,
@@ -1120,7 +1096,6 @@ extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t nu
     for (uint32_t i = 0; i < num_merges; ++i) {
         hipLaunchKernelGGL(rowmax_kernel, dim3(kRowGrid), dim3(kThreads), 0, st, A, i);
         hipLaunchKernelGGL(tile_count_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, i & 1u, i, kRowGrid);  // (with the final arg-max and the commit of merge i - 1)
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, A, i & 1u, tile_grid);
         hipLaunchKernelGGL(rewrite_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, i & 1u);
     }
     hipLaunchKernelGGL(finish_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, num_merges, ids_out_dev, n_ids_dev,
@@ -1206,7 +1181,6 @@ extern "C" int ecgb_bpe_shard_merge(ecgb_bpe_shard *h, uint32_t merge_index, con
     if (!h || !gathered_dev || rank < 0 || rank >= world || merge_index >= h->num_merges) { ecgb::set_error("ecgb_bpe_shard_merge: bad argument"); return ECGB_ERR_INVALID; }
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(shard_halo_kernel, dim3(1), dim3(64), 0, st, h->A, h->halo_w, gathered_dev, rank, world, 1);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, h->A, merge_index & 1u, h->tile_grid);
     hipLaunchKernelGGL(rewrite_kernel, dim3(h->tile_grid), dim3(kThreads), 0, st, h->A, merge_index & 1u);
     return check_hip(hipGetLastError(), "bpe shard merge");
 }
