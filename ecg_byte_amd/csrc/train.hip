@@ -1025,6 +1025,9 @@ int check_hip(hipError_t e, const char *what)
 }
 
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+// positions are 64-bit; tile numbers and a range's survivor count (a record of the count pass) are 32-bit: 2^42 ids over kGrid ranges of 2 048-id tiles keep both below 2^32
+constexpr size_t kMaxIds = (size_t)1 << 42;
+static_assert(kMaxIds / kTile < (1ull << 32) && kMaxIds / kGrid + kTile < (1ull << 32), "32-bit tile numbers and range counts");
 
 // carve the state of one trainer (or one shard) out of `scratch`
 TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w)
@@ -1069,8 +1072,8 @@ extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t nu
         ecgb::set_error("ecgb_bpe_train_hip: NULL argument");
         return ECGB_ERR_INVALID;
     }
-    if (n >= (1ull << 44) || num_merges > 65000u) {      // positions are 64-bit; 2^44 tiles-of-4096 still index with 32 bits
-        ecgb::set_error("ecgb_bpe_train_hip: text longer than 2^44 bytes or more than 65000 merges");
+    if (n >= kMaxIds || num_merges > 65000u) {
+        ecgb::set_error("ecgb_bpe_train_hip: text longer than 2^42 bytes or more than 65000 merges");
         return ECGB_ERR_UNSUPPORTED;
     }
     if (scratch_bytes < ecgb_bpe_train_scratch_bytes(n, num_merges)) {
@@ -1114,7 +1117,7 @@ struct ecgb_bpe_shard {
 
 extern "C" ecgb_bpe_shard *ecgb_bpe_shard_create(size_t n_local, uint32_t num_merges, void *scratch_dev, size_t scratch_bytes)
 {
-    if (!scratch_dev || n_local >= (1ull << 44) || num_merges > 65000u || scratch_bytes < ecgb_bpe_train_scratch_bytes(n_local, num_merges)) {
+    if (!scratch_dev || n_local >= kMaxIds || num_merges > 65000u || scratch_bytes < ecgb_bpe_train_scratch_bytes(n_local, num_merges)) {
         ecgb::set_error("ecgb_bpe_shard_create: bad argument or scratch smaller than ecgb_bpe_train_scratch_bytes()");
         return nullptr;
     }
