@@ -164,7 +164,7 @@ int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t num_merges, u
  * straddle record joins.  Here rank r holds a contiguous slice of that string; the result (merges, and the concatenation of the
  * ranks' final ids) is the single-device trainer's.  Every rank keeps the whole pair table (the arg-max needs no exchange) and per
  * merge the host enqueues:
- *     ecgb_bpe_shard_pick    arg-max, per-tile survivor counts, this slice's 8-word summary   -> all-gather the summaries (8 x world int64)
+ *     ecgb_bpe_shard_pick    arg-max, survivor counts (one record per workgroup range), this slice's 8-word summary   -> all-gather the summaries (8 x world int64)
  *     ecgb_bpe_shard_merge   neighbours from the gathered summaries (the id before the slice, the three after it, the parity of
  *                            a run of `left` entering it), rewrite + compaction, count deltas into the 6 x V slab
  *                                                                                             -> all-reduce (SUM) the slab (int64)
