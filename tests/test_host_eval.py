@@ -146,3 +146,29 @@ def test_global_stats_and_segment_files_are_what_the_reference_writes(tmp_path):
     assert json.load(open(txt[2])) == texts[2]
     with pytest.raises(ValueError):
         pp.process_and_save_batch(seg, texts, 0, "train", "x", 1250, root=str(tmp_path / "d2"), kept=torch.tensor([True, True, True, True]))
+
+
+def test_lora_site_initialises_as_peft_does_kaiming_uniform_a_and_zero_b():
+    """peft's LoraLayer.reset_lora_parameters (the reference's get_peft_model, main.py:131-155): lora_A by
+    nn.init.kaiming_uniform_(a=sqrt(5)) -- torch's own rule gives U(-1/sqrt(in), 1/sqrt(in)) for an [r, in] weight -- lora_B zeros, so a fresh adapter
+    changes nothing.  The stacked site must draw every live row from exactly that interval (and fill it), keep its padding rows zero, and start with B = 0."""
+    import math
+    import torch
+    from ecg_byte_amd.decoder import LoraSite
+    in_dim, n_sub, r = 512, 3, 16
+    ref = torch.empty(r, in_dim)
+    torch.nn.init.kaiming_uniform_(ref, a=math.sqrt(5))                 # what peft calls
+    gain = torch.nn.init.calculate_gain("leaky_relu", math.sqrt(5))
+    bound = gain * math.sqrt(3.0 / in_dim)
+    assert abs(bound - 1.0 / math.sqrt(in_dim)) < 1e-12 and float(ref.abs().max()) <= bound
+    site = LoraSite(in_dim, [(0, 64), (64, 32), (96, 32)], r, 32, 0.05, "cpu", torch.Generator().manual_seed(3))
+    A, B = site.A.detach().float(), site.B.detach().float()
+    assert A.shape == (64, in_dim) and B.shape == (128, 64) and site.scale == 2.0
+    live = A[: r * n_sub]
+    assert float(live.abs().max()) <= bound * (1 + 2 ** -8)             # (bf16 rounding of a value at the bound)
+    assert float(live.abs().max()) > 0.98 * bound                       # the interval is filled ...
+    assert abs(float(live.std()) - bound / math.sqrt(3.0)) < 0.02 * bound and abs(float(live.mean())) < 0.02 * bound    # ... uniformly
+    assert float(A[r * n_sub:].abs().max()) == 0.0 and float(B.abs().max()) == 0.0
+    # every block of B may only ever hold its own 16 columns
+    m = site.bmask.float()
+    assert m.sum().item() == 128 * r and all(float(m[lo:hi, 16 * b: 16 * b + 16].min()) == 1.0 for b, (lo, hi) in enumerate([(0, 64), (64, 96), (96, 128)]))
