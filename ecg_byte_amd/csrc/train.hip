@@ -82,7 +82,7 @@ struct TrainArgs {
     uint64_t *partial;     // kGrid arg-max partials: 2 words each, count and ~key
     uint64_t *row_cnt;     // per row of the table: its largest count ...
     uint32_t *row_key;     //  ... and ~index of that cell (the smallest index among equals), exact unless row_dirty
-    uint32_t *row_dirty;   // per row: a count of the row changed since row_cnt / row_key were taken (rowmax_kernel)
+    uint32_t *row_dirty;   // per row: not read yet since the table was built (rowmax_kernel reads it whole the first time)
     uint32_t *pairs_out;   // 2 x num_merges
     uint64_t n0;           // initial length
 };
@@ -109,17 +109,13 @@ __device__ __forceinline__ bool better(unsigned long long c, uint32_t k, unsigne
     return c > bc || (c == bc && c != 0 && k > bk);
 }
 
-// A count delta goes into the table and, if it can change its row's maximum, marks the row for rowmax_kernel.  Within one merge a cell only grows (its pair holds the new
-// id) or only shrinks: a shrinking cell matters iff it IS the row's maximum; of a growing cell the last adder sees the final count, which matters iff it beats the maximum.
-// row_cnt / row_key are written by rowmax_kernel only, never while deltas flow.
-struct Tab { uint64_t *table; const uint64_t *row_cnt; const uint32_t *row_key; uint32_t *row_dirty; uint32_t V; };
-__device__ __forceinline__ Tab tab_of(const TrainArgs &A) { return Tab{A.table, A.row_cnt, A.row_key, A.row_dirty, A.V}; }
+// A count delta goes into the table and nothing comes back: which rows' maxima it moved, rowmax_kernel finds out itself (marking the rows here -- comparing with the
+// row's kept maximum, or with the add's old count -- measured the same and put loads and returning atomics into a flush that otherwise only fires and forgets).
+struct Tab { uint64_t *table; };
+__device__ __forceinline__ Tab tab_of(const TrainArgs &A) { return Tab{A.table}; }
 __device__ __forceinline__ void table_add(const Tab &T, uint32_t key, int d)
 {
-    const unsigned long long was = atomicAdd(reinterpret_cast<unsigned long long *>(&T.table[key]), (unsigned long long)(long long)d);   // two's complement: -1 adds 2^64 - 1
-    const uint32_t row = key / T.V;
-    if (d < 0) { if (T.row_key[row] == ~key) T.row_dirty[row] = 1u; }
-    else if (better(was + (unsigned long long)d, ~key, T.row_cnt[row], T.row_key[row])) T.row_dirty[row] = 1u;
+    atomicAdd(reinterpret_cast<unsigned long long *>(&T.table[key]), (unsigned long long)(long long)d);   // two's complement: -1 adds 2^64 - 1
 }
 
 // Every count delta of a merge has `left`, `right` or the new id as one of its two ids (a pair disappears only next to a site, a
@@ -235,7 +231,8 @@ __global__ __launch_bounds__(kThreads) void argmax_partial_kernel(TrainArgs A, u
 }
 
 // The one-rank trainer's arg-max, first half: a merge changes the counts of a few rows of the table (those of its two ids, of the new id, and of the ids that stood before a
-// site), so each row keeps its own maximum (row_cnt, row_key) and only the rows a count delta touched since (row_dirty, set by table_add) are read again -- not the
+// site), so each row keeps its own maximum (row_cnt, row_key); only the rows whose kept cell no longer holds the kept count and the newest id's row are read
+// again, and every other row looks at its one cell in the newest id's column -- not the
 // (256 + i) x V table of every merge: 145 MB at 4 000 merges, a tenth of a merge's time and the traffic that pushed the id buffers out of the memory-side cache.
 // Workgroup b owns rows b, b + G, ..., a lane a row; partial[b] = the best of its rows, for tile_count_kernel's final reduction.
 constexpr uint32_t kRowGrid = 64;
@@ -246,6 +243,7 @@ __global__ __launch_bounds__(kThreads) void rowmax_kernel(TrainArgs A, uint32_t 
     __shared__ uint32_t s_rows[kThreads];
     __shared__ uint32_t s_n;
     const uint32_t v_cur = 256u + merge_index;            // ids that can exist so far: rows and columns below v_cur
+    const uint32_t newest = merge_index > 0 ? v_cur - 1u : kEmpty;    // the id the previous merge made: counts grew only in its row and its column
     unsigned long long my_best = 0;
     uint32_t my_key = 0;
     for (uint32_t row0 = blockIdx.x; row0 < v_cur; row0 += gridDim.x * kThreads) {       // (one trip up to 16 384 ids)
@@ -253,10 +251,19 @@ __global__ __launch_bounds__(kThreads) void rowmax_kernel(TrainArgs A, uint32_t 
         __syncthreads();
         const uint32_t row = row0 + threadIdx.x * gridDim.x;                             // a lane a row: its kept maximum, or its name on the list of rows to read again
         if (row < v_cur) {
-            if (A.row_dirty[row]) s_rows[atomicAdd(&s_n, 1u)] = row;
+            unsigned long long oc = A.row_cnt[row];
+            uint32_t ok = A.row_key[row];
+            // Within one merge a cell only shrinks or only grows.  A shrinking cell lowers the row's maximum iff it IS the maximum: the kept cell no longer holds the kept
+            // count.  A growing cell's pair holds the merge's new id: it lies in the newest id's row (all new: read) or column (one cell a row, looked at here).
+            bool again = A.row_dirty[row] || row == newest;                              // (row_dirty: not read yet since the table was built)
+            if (!again && oc != 0 && A.table[~ok] != oc) again = true;
+            if (again) s_rows[atomicAdd(&s_n, 1u)] = row;
             else {
-                const unsigned long long oc = A.row_cnt[row];
-                const uint32_t ok = A.row_key[row];
+                if (newest != kEmpty) {
+                    const uint32_t cell = row * A.V + newest;
+                    const unsigned long long c = A.table[cell];
+                    if (better(c, ~cell, oc, ok)) { oc = c; ok = ~cell; A.row_cnt[row] = oc; A.row_key[row] = ok; }
+                }
                 if (better(oc, ok, my_best, my_key)) { my_best = oc; my_key = ok; }
             }
         }
@@ -677,8 +684,8 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
 #ifdef ECGB_TRAIN_TIMING      // dev builds: shader-clock cycles of every workgroup's phases, summed (scripts/dev_trainer_phases.py)
 __device__ unsigned long long g_phase[16];
 #define PH_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) ph[i] += now_ - last_; last_ = now_; } while (0)
-#define PH_DECL unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long last_ = __builtin_readcyclecounter()
-#define PH_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_phase[i_], ph[i_]); atomicAdd(&g_phase[15], 1ull); } } while (0)
+#define PH_DECL unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long last_ = __builtin_readcyclecounter()
+#define PH_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_phase[i_], ph[i_]); atomicAdd(&g_phase[15], 1ull); } } while (0)
 #else
 #define PH_MARK(i) do {} while (0)
 #define PH_DECL do {} while (0)
@@ -761,6 +768,7 @@ __global__ __launch_bounds__(kThreads, ECGB_RW_WAVES) void rewrite_kernel(TrainA
         run_par = s_own_par;
         if (b == G - 1 && threadIdx.x == 0) A.st->n_next = run_off + s_own;      // the length this merge leaves (nobody reads it before the next launch)
     }
+    PH_MARK(9);
     // A tile's survivors leave one trip LATE, after the next tile has been parked: the counter of memory operations in flight retires in order, and the wait for the
     // next tile's words (requested a whole trip earlier) must find nothing younger than them in flight -- stores issued just before it would have to drain first
     // (the compiler cannot wait past them either: each store sits under its own lane mask, and it counts a skipped branch as no store).  So a trip takes the previous
@@ -866,7 +874,9 @@ __global__ __launch_bounds__(kThreads, ECGB_RW_WAVES) void rewrite_kernel(TrainA
         PH_MARK(7);
     }
     survivors_take();
+    PH_MARK(10);
     survivors_send();
+    PH_MARK(11);
     delta_flush(s_key, s_val, tab_of(A), A.slab, SK);
     PH_MARK(8);
     PH_FLUSH;
@@ -1025,8 +1035,8 @@ int check_hip(hipError_t e, const char *what)
 }
 
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
-// positions are 64-bit; tile numbers and a range's survivor count (a record of the count pass) are 32-bit: 2^42 ids over kGrid ranges of 2 048-id tiles keep both below 2^32
-constexpr size_t kMaxIds = (size_t)1 << 42;
+// positions are 64-bit; tile numbers and a range's survivor count (a record of the count pass) are 32-bit: 2^41 ids over kGrid (>= 1 024) ranges of 2 048-id tiles keep both below 2^32
+constexpr size_t kMaxIds = (size_t)1 << 41;
 static_assert(kMaxIds / kTile < (1ull << 32) && kMaxIds / kGrid + kTile < (1ull << 32), "32-bit tile numbers and range counts");
 
 // carve the state of one trainer (or one shard) out of `scratch`
@@ -1073,7 +1083,7 @@ extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t nu
         return ECGB_ERR_INVALID;
     }
     if (n >= kMaxIds || num_merges > 65000u) {
-        ecgb::set_error("ecgb_bpe_train_hip: text longer than 2^42 bytes or more than 65000 merges");
+        ecgb::set_error("ecgb_bpe_train_hip: text longer than 2^41 bytes or more than 65000 merges");
         return ECGB_ERR_UNSUPPORTED;
     }
     if (scratch_bytes < ecgb_bpe_train_scratch_bytes(n, num_merges)) {
@@ -1092,8 +1102,10 @@ extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t nu
     if (rc) return rc;
     rc = check_hip(hipMemsetAsync(reinterpret_cast<uint8_t *>(halo_w) + 16, 0, sizeof(Halo) - 16, st), "hipMemsetAsync(halo)");
     if (rc) return rc;
-    rc = check_hip(hipMemsetAsync(A.row_cnt, 0, reinterpret_cast<uint8_t *>(A.row_dirty + V) - reinterpret_cast<uint8_t *>(A.row_cnt), st), "hipMemsetAsync(row maxima)");
-    if (rc) return rc;                                                   // (no row has a count yet; init_kernel's deltas mark the rows they touch)
+    rc = check_hip(hipMemsetAsync(A.row_cnt, 0, reinterpret_cast<uint8_t *>(A.row_dirty) - reinterpret_cast<uint8_t *>(A.row_cnt), st), "hipMemsetAsync(row maxima)");
+    if (rc) return rc;
+    rc = check_hip(hipMemsetAsync(A.row_dirty, 1, V * 4, st), "hipMemsetAsync(row flags)");      // every row is read when the arg-max first comes to it
+    if (rc) return rc;
     const unsigned tile_grid = (unsigned)std::max<size_t>(1, std::min<size_t>(kGrid, (n + kTile - 1) / kTile));
     hipLaunchKernelGGL(init_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, text_dev);
     for (uint32_t i = 0; i < num_merges; ++i) {

@@ -1,16 +1,26 @@
-"""Dev-only: the tokenizer trainer on the C2 corpus shape (2 000 synthetic records of 12 x 5000, 4 000 merges), for rocprofv3 --kernel-trace --stats."""
+"""Dev-only: the tokenizer trainer on a corpus of the C2 shape (1.2e8 symbols, 4 000 merges) -- a quantised random walk, or with CORPUS=c2 the bench leg's own corpus -- for rocprofv3 --kernel-trace --stats."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ecg_byte_amd import _lib
 if os.environ.get("ECGB_SO"): _lib.SO_PATH = os.path.join(os.path.dirname(_lib.SO_PATH), os.environ["ECGB_SO"])
 from ecg_byte_amd.trainer import bpe_train_device
-rng = np.random.default_rng(1)
-n = 2000 * 12 * 5000
-# a random walk over 26 symbols: neighbouring samples differ by at most one level, like a quantised ECG
-steps = rng.integers(-1, 2, size=n, dtype=np.int8)
-sym = np.clip(np.cumsum(steps) % 52, 0, 51); sym = np.where(sym > 25, 51 - sym, sym).astype(np.uint8)
-text = torch.from_numpy(sym + 97).cuda()
+if os.environ.get("CORPUS") == "c2":                    # the bench's trainer leg: 2 000 synthetic records of seed 1, quantised with the C2 tokenizer's percentiles
+    import bench
+    from ecg_byte_amd.tokenizer import quantize
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from helpers import load_tokenizer
+    _, _, pc = load_tokenizer("c2")
+    x = bench.make_signals(2000, 5000, seed=1, start=0, workers=1)
+    text = (quantize(torch.from_numpy(x).cuda(), pc).view(-1) + 97).contiguous()
+    del x
+else:
+    rng = np.random.default_rng(1)
+    n = 2000 * 12 * 5000
+    # a random walk over 26 symbols: neighbouring samples differ by at most one level, like a quantised ECG
+    steps = rng.integers(-1, 2, size=n, dtype=np.int8)
+    sym = np.clip(np.cumsum(steps) % 52, 0, 51); sym = np.where(sym > 25, 51 - sym, sym).astype(np.uint8)
+    text = torch.from_numpy(sym + 97).cuda()
 for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ids, n_ids, pairs, n_done = bpe_train_device(text, 4000)
