@@ -189,3 +189,34 @@ def test_sharded_trainer_ranks_on_one_gpu(tmp_path, world):
         for r in range(world):
             assert O.pairs_to_vocab_merges([tuple(p) for p in outs[r][c][1]])[1] == want_merges, (c, r, len(text), cuts, nm)
         assert sum((outs[r][c][0] for r in range(world)), []) == want_ids, (c, len(text), cuts, nm)
+
+
+@pytest.mark.gpu
+def test_kept_row_maxima_pick_the_pairs_a_full_scan_of_the_table_picks_past_16384_ids():
+    """The one-rank trainer's arg-max keeps a maximum per table row and re-reads only the rows a merge can have moved (rowmax_kernel); the step-wise
+    (sharded) form scans the live table every merge (argmax_partial_kernel).  Same corpus, one rank: the same 17 000 merges and the same ids -- past the 16 384
+    ids one trip of rowmax_kernel covers, through merges of counts 1 with their ties, and down to a handful of ids left."""
+    from ecg_byte_amd.trainer import HipShard, bpe_train_device
+    rng = np.random.default_rng(17)
+    n, nm = 120_000, 17_000
+    # runs and repeats: a small alphabet with sticky symbols (l == r merges included), so that counts stay tied often
+    sym = rng.integers(0, 40, size=n)
+    stick = rng.random(n) < 0.35
+    for i in range(1, n):
+        if stick[i]:
+            sym[i] = sym[i - 1]
+    text = torch.from_numpy((sym + 40).astype(np.uint8)).cuda()
+    ids_a, n_ids, pairs_a, n_done = bpe_train_device(text, nm)
+    k = int(n_done)
+    shard = HipShard(text, nm)
+    summary, gathered = shard.new_words(8), shard.new_words(8)
+    shard.begin(summary); gathered.copy_(summary)
+    shard.count(gathered, 0, 1)
+    for i in range(nm):
+        shard.pick(i, summary); gathered.copy_(summary)
+        shard.merge(i, gathered, 0, 1)
+        shard.apply()
+    ids_b, pairs_b = shard.finish()
+    assert k == len(pairs_b) and k > 16_500, (k, len(pairs_b))
+    assert pairs_a[:k].cpu().tolist() == [list(p) for p in pairs_b]
+    assert ids_a[: int(n_ids)].cpu().tolist() == ids_b
