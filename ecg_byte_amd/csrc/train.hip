@@ -506,6 +506,36 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
     __shared__ uint32_t s_bkey[kThreads / 64];
     TrainState st = *A.st;
     if (!st.active) return;
+    // The first tiles of the workgroup's range are requested before anything else: which ids are compared needs the pair, the ids themselves only the length (a range
+    // at the end of a run is three or four tiles: asked for one after the other behind the arg-max, they were four memory round trips of a 10 us kernel).
+    constexpr int kAhead = 4;                                                      // tiles requested together: a lane has 8 x 16 bytes in flight
+    constexpr int kPreVecs = kAhead * kFetchVecs;
+    const uint32_t *const src = A.buf[src_sel];
+    const uint64_t n = (n_partials > 0 && merge_index > 0) ? st.n_next : st.n_cur;   // (the length merge_index - 1 left; the step-wise form has committed it already)
+    const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
+    uint32_t t_first, t_count;
+    tile_range(n_tiles, blockIdx.x, gridDim.x, t_first, t_count);
+    uint4 pre_v[kPreVecs];
+    uint32_t pre_b[kPreVecs];
+    uint32_t pre_n = 0;                                                            // leading tiles of the range that are whole and have an id before them
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) {
+        const uint64_t base = (uint64_t)(t_first + j) * kTile;
+        if (pre_n == (uint32_t)j && (uint32_t)j < t_count && base >= 1 && base + kTile <= n) pre_n = j + 1;
+    }
+#pragma unroll
+    for (int j = 0; j < kAhead; ++j) {
+        if ((uint32_t)j < pre_n) {                                                 // (uniform)
+            const uint64_t base = (uint64_t)(t_first + j) * kTile;
+            const uint4 *p = reinterpret_cast<const uint4 *>(src + base) + threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < kFetchVecs; ++k) {
+                pre_v[j * kFetchVecs + k] = p[(uint32_t)k * kThreads];
+                pre_b[j * kFetchVecs + k] = 0u;
+                if ((threadIdx.x & 63) == 0) pre_b[j * kFetchVecs + k] = src[base + ((uint64_t)k * kThreads + threadIdx.x) * 4u - 1u];
+            }
+        }
+    }
     if (n_partials > 0) {
         unsigned long long best = 0;
         uint32_t bkey = 0;
@@ -541,23 +571,29 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
         }
         if (best == 0) return;
     }
-    const uint32_t *src = A.buf[src_sel];
-    const uint64_t n = st.n_cur;
     const uint32_t l = st.left, r = st.right;
     const bool same = (l == r);
-    const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
     const Halo alone{kEmpty, {kEmpty, kEmpty, kEmpty}, 0, {0, 0, 0}};                                             // as if the shard stood alone: the rewrite adds what the neighbours change
     TileRegs tr;
-    uint32_t t_first, t_count;
-    tile_range(n_tiles, blockIdx.x, gridDim.x, t_first, t_count);
     if (!same) {
         // Two different ids (nearly every merge): an id is consumed iff it is `r` and follows `l` -- a fact about two neighbours, whatever lane holds them.  So the
         // range streams through registers as it lies in memory (16 bytes a lane, the word before a lane's piece from the lane below), no LDS, no barrier until the one
         // sum at the end.  Through the staged spans of the l == r path this pass ran at 2.3 TB/s on a corpus in HBM.
         uint32_t dropped = 0;
         const uint32_t lane = threadIdx.x & 63;
-        constexpr int kAhead = 4;                                                      // tiles requested together: a lane has 8 x 16 bytes in flight (one tile at a time, a
-        auto whole_tiles = [&](uint64_t base, auto n_const) {                          //  trip was one memory latency long: 2.3 TB/s on a corpus in HBM)
+        auto pairs_in = [&](const uint4 &v, uint32_t before) {                        // ids consumed among a lane's four: `r` right after `l`
+            const uint32_t up = __shfl_up(v.w, 1, 64);
+            const uint32_t a0 = lane == 0 ? before : up;
+            return (a0 == l && v.x == r ? 1u : 0u) + (v.x == l && v.y == r ? 1u : 0u) + (v.y == l && v.z == r ? 1u : 0u) + (v.z == l && v.w == r ? 1u : 0u);
+        };
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) {                                             // the tiles requested at the top
+            if ((uint32_t)j < pre_n) {
+#pragma unroll
+                for (int k = 0; k < kFetchVecs; ++k) dropped += pairs_in(pre_v[j * kFetchVecs + k], pre_b[j * kFetchVecs + k]);
+            }
+        }
+        auto whole_tiles = [&](uint64_t base, auto n_const) {                          // (one tile at a time, a trip was one memory latency long: 2.3 TB/s on a corpus in HBM)
             constexpr int NV = decltype(n_const)::value * kFetchVecs;
             const uint4 *p = reinterpret_cast<const uint4 *>(src + base) + threadIdx.x;
             uint4 v[NV];
@@ -576,7 +612,7 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
                            (v[k].z == l && v[k].w == r ? 1u : 0u);
             }
         };
-        uint32_t t = t_first;
+        uint32_t t = t_first + pre_n;
         const uint32_t t_end = t_first + t_count;
         for (; t < t_end; ) {
             const uint64_t base = (uint64_t)t * kTile;
