@@ -1102,6 +1102,15 @@ TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w
 
 }  // namespace
 
+// workgroups of the count and rewrite passes: kGrid, or fewer for tests (ranges of many tiles on small corpora: every chain the passes carry across tiles and ranges)
+static unsigned g_train_grid = kGrid;
+extern "C" int ecgb_set_bpe_train_grid(int workgroups)
+{
+    if (workgroups < 0 || workgroups > (int)kGrid) { ecgb::set_error("ecgb_set_bpe_train_grid: 0 (default) or 1 .. " + std::to_string(kGrid)); return ECGB_ERR_INVALID; }
+    g_train_grid = workgroups == 0 ? kGrid : (unsigned)workgroups;
+    return ECGB_OK;
+}
+
 extern "C" size_t ecgb_bpe_train_scratch_bytes(size_t n, uint32_t num_merges)
 {
     const size_t V = 256 + (size_t)num_merges;
@@ -1142,7 +1151,7 @@ extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t nu
     if (rc) return rc;
     rc = check_hip(hipMemsetAsync(A.row_dirty, 1, V * 4, st), "hipMemsetAsync(row flags)");      // every row is read when the arg-max first comes to it
     if (rc) return rc;
-    const unsigned tile_grid = (unsigned)std::max<size_t>(1, std::min<size_t>(kGrid, (n + kTile - 1) / kTile));
+    const unsigned tile_grid = (unsigned)std::max<size_t>(1, std::min<size_t>(g_train_grid, (n + kTile - 1) / kTile));
     hipLaunchKernelGGL(init_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, text_dev);
     for (uint32_t i = 0; i < num_merges; ++i) {
         hipLaunchKernelGGL(rowmax_kernel, dim3(kRowGrid), dim3(kThreads), 0, st, A, i);
@@ -1173,7 +1182,7 @@ extern "C" ecgb_bpe_shard *ecgb_bpe_shard_create(size_t n_local, uint32_t num_me
     h->A = layout(scratch_dev, n_local, num_merges, &h->halo_w);
     h->n = n_local;
     h->num_merges = num_merges;
-    h->tile_grid = (unsigned)std::max<size_t>(1, std::min<size_t>(kGrid, (n_local + kTile - 1) / kTile));
+    h->tile_grid = (unsigned)std::max<size_t>(1, std::min<size_t>(g_train_grid, (n_local + kTile - 1) / kTile));
     return h;
 }
 

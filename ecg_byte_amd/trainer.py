@@ -10,6 +10,11 @@ from . import _lib
 from .tokenizer import _ptr, _stream_ptr
 
 
+def set_train_grid(workgroups: int):
+    """Tests and tuning: workgroups of the trainer's count and rewrite passes (0 = default); see ecgb_set_bpe_train_grid in include/ecgbyte.h."""
+    _lib.check(_lib.lib().ecgb_set_bpe_train_grid(int(workgroups)))
+
+
 def bpe_train_device(text: torch.Tensor, num_merges: int):
     """text: CUDA uint8 1-D tensor.  Returns device tensors (ids int32[n], n_ids int64[1],
     pairs int32[num_merges, 2], n_done int32[1]); nothing is synchronised."""

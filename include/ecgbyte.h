@@ -159,6 +159,11 @@ int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t num_merges, u
                        uint32_t *n_done_dev, uint32_t *ids_out_dev, uint64_t *n_ids_dev,
                        void *scratch_dev, size_t scratch_bytes, void *stream);
 
+/* Tests and tuning: the number of workgroups of the trainer's count and rewrite passes (0 = the default, 1 280: five per CU).  Each workgroup walks a contiguous
+ * range of 2 048-id tiles; a small number makes ranges of many tiles out of a small corpus.  Every value gives the same merges and ids.  Process-wide; applies to
+ * trainers started afterwards (ecgb_bpe_train_hip, ecgb_bpe_shard_create).  ECGB_ERR_INVALID outside 0 .. 1 280. */
+int ecgb_set_bpe_train_grid(int workgroups);
+
 /* ---- tokenizer training on a corpus sharded over ranks (one process per GPU) ---------------------------
  * The reference trains on ONE string, the concatenation of every sampled record (tokenizer_utils.py:79-93), so pairs -- and merges --
  * straddle record joins.  Here rank r holds a contiguous slice of that string; the result (merges, and the concatenation of the

@@ -5,7 +5,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from oracle import oracle as O
-from ecg_byte_amd import rust_bpe
+from ecg_byte_amd import rust_bpe, trainer
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -20,6 +20,7 @@ while time.time() - t0 < budget:
         parts.append(chr(alpha[rng.integers(len(alpha))]) * r); total += r
     text = "".join(parts)[:n]
     k = int(rng.choice([1, 2, 5, 30, 200]))
+    trainer.set_train_grid(int(rng.choice([0, 0, 1, 2, 3, 7, 64])))      # few workgroups: ranges of many tiles, the chains carried across tiles and ranges
     ids, vocab, merges = rust_bpe.byte_pair_encoding(text, k, 2)
     oids, ovocab, omerges = O.byte_pair_encoding(text, k, fast=True)
     if list(ids) != list(oids) or merges != omerges or vocab != ovocab:

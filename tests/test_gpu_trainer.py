@@ -220,3 +220,25 @@ def test_kept_row_maxima_pick_the_pairs_a_full_scan_of_the_table_picks_past_1638
     assert k == len(pairs_b) and k > 16_500, (k, len(pairs_b))
     assert pairs_a[:k].cpu().tolist() == [list(p) for p in pairs_b]
     assert ids_a[: int(n_ids)].cpu().tolist() == ids_b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid", [1, 2, 3, 7, 50])
+def test_few_workgroups_walk_ranges_of_many_tiles_to_the_same_merges(grid):
+    """A workgroup of the count and rewrite passes walks a contiguous range of tiles and carries the output offset and the run parity across them; the workgroups
+    chain their ranges' records.  With a handful of workgroups a small corpus already makes ranges of ten and more tiles -- runs of one symbol (merged with itself)
+    across tile and range boundaries included: the oracle's merges and ids whatever the number of workgroups."""
+    from ecg_byte_amd import trainer
+    rng = np.random.default_rng(100 + grid)
+    parts, total, n = [], 0, 45_000
+    while total < n:
+        run = int(rng.integers(1, 5000)) if rng.random() < 0.02 else int(rng.integers(1, 6))
+        parts.append(chr(97 + int(rng.integers(3))) * run); total += run
+    text = "".join(parts)[:n]
+    want = O.byte_pair_encoding(text, 60, fast=True)
+    try:
+        trainer.set_train_grid(grid)
+        got = _train(text, 60)
+    finally:
+        trainer.set_train_grid(0)
+    assert list(got[0]) == list(want[0]) and got[2] == want[2]
