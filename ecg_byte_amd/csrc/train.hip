@@ -809,6 +809,10 @@ __global__ __launch_bounds__(kThreads, ECGB_RW_WAVES) void rewrite_kernel(TrainA
     // next tile's words (requested a whole trip earlier) must find nothing younger than them in flight -- stores issued just before it would have to drain first
     // (the compiler cannot wait past them either: each store sits under its own lane mask, and it counts a skipped branch as no store).  So a trip takes the previous
     // tile's survivors from LDS into registers, parks its own tile, and only then sends them out; the last tile's follow the loop.
+    // The merged pair's own count falls by one per site: as a count delta every lane of a wave with a site hit the SAME slot of the LDS table, one after the other (the
+    // early merges, a site every few ids).  Each lane counts its sites' (l, r) pairs in a register instead; one delta per wave leaves before the final flush.
+    const uint32_t key_lr = l * V + r;
+    int n_lr = 0;
     uint32_t kept_prev = 0;
     uint64_t out_prev = 0;
     uint32_t sv[kPerThread];
@@ -876,8 +880,11 @@ __global__ __launch_bounds__(kThreads, ECGB_RW_WAVES) void rewrite_kernel(TrainA
             const bool site_prev = (site_mask >> (k - 1)) & 1u;
             const bool site_next = (site_mask >> (k + 1)) & 1u;
             // old pair (a[k], a[k+1]) disappears iff a site starts at k-1, k or k+1
-            if (s.a[k + 1] != kEmpty && (site_prev || is_site || site_next))
-                delta_add_s(s_key, s_val, tab_of(A), A.slab, SK, s.a[k] * V + s.a[k + 1], -1);
+            if (s.a[k + 1] != kEmpty && (site_prev || is_site || site_next)) {
+                const uint32_t key = s.a[k] * V + s.a[k + 1];
+                if (key == key_lr) ++n_lr;                          // (the merged pair itself: every site's, counted in a register -- see n_lr)
+                else delta_add_s(s_key, s_val, tab_of(A), A.slab, SK, key, -1);
+            }
             if (!is_second) {
                 const uint32_t val = is_site ? X : s.a[k];
                 s_ids[o++] = val;
@@ -913,6 +920,8 @@ __global__ __launch_bounds__(kThreads, ECGB_RW_WAVES) void rewrite_kernel(TrainA
     PH_MARK(10);
     survivors_send();
     PH_MARK(11);
+    for (int d = 32; d > 0; d >>= 1) n_lr += __shfl_down(n_lr, d, 64);
+    if ((threadIdx.x & 63) == 0 && n_lr) delta_add_s(s_key, s_val, tab_of(A), A.slab, SK, key_lr, -n_lr);
     delta_flush(s_key, s_val, tab_of(A), A.slab, SK);
     PH_MARK(8);
     PH_FLUSH;
