@@ -93,8 +93,8 @@ struct TrainArgs {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Workgroup b of G walks tiles [first, first + count): contiguous and balanced.  A workgroup that walks its tiles IN ORDER carries the output offset and the run parity from
-// tile to tile itself, so the count pass leaves one record per workgroup, not per tile, and the scan between the two passes is over G records whatever the corpus
-// (per-tile records: a scan of 29 000 to 58 000 entries by one workgroup, 9 to 16 % of a merge).
+// tile to tile itself, so the count pass leaves one record per workgroup, not per tile, and the rewrite chains at most G records whatever the corpus
+// (per-tile records: a scan of 29 000 to 58 000 entries by one workgroup between the two passes, 9 to 16 % of a merge).
 __device__ __forceinline__ void tile_range(uint32_t n_tiles, uint32_t b, uint32_t G, uint32_t &first, uint32_t &count)
 {
     const uint32_t q = n_tiles / G, rem = n_tiles % G;
@@ -361,10 +361,10 @@ __global__ __launch_bounds__(kThreads) void argmax_final_kernel(TrainArgs A, uin
 }
 
 // ---- helpers for the rewrite ------------------------------------------------------------------
-// Per thread: 16 consecutive ids (+1 before, +2 after).  `lead_par` = parity of the number of
+// Per thread: kPerThread (8) consecutive ids (+1 before, +2 after).  `lead_par` = parity of the number of
 // consecutive `left` ids immediately before the thread's first id (only used when left == right).
 struct Span {
-    uint32_t a[kPerThread + 3];   // a[0] = id before the span, a[1..16] the span, a[17], a[18] after
+    uint32_t a[kPerThread + 3];   // a[0] = id before the span, a[1..kPerThread] the span, then the two after
 };
 
 __device__ __forceinline__ uint32_t halo_at(const Halo &h, int64_t i, uint64_t n)   // id at position i outside [0, n)
@@ -375,7 +375,7 @@ __device__ __forceinline__ uint32_t halo_at(const Halo &h, int64_t i, uint64_t n
 }
 
 // A lane's span out of LDS.  A lane's 19 ids lie 64 bytes apart from its neighbour's: read straight from memory, every one of the 19 loads of a wave touches 64
-// separate 64-byte segments (tile_count 40 us and rewrite 64 us per merge whatever the length: 1 TB/s).  So the workgroup brings the tile -- 4096 ids and the three
+// separate 64-byte segments (tile_count 40 us and rewrite 64 us per merge whatever the length: 1 TB/s).  So the workgroup brings the tile -- its kTile ids and the three
 // around it -- with consecutive lanes on consecutive words, parks it in LDS with one pad word per 16 (lane t's ids start at word 17 t: the lanes' reads hit 64
 // different banks), and every lane picks its span from there.  tile_park ends with a barrier; callers put one before the next tile_park (or re-use of s_ids).
 constexpr uint32_t kStageWords = kTile + 3 + (kTile + 3) / kPerThread + 1;
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(kThreads, ECGB_RW_WAVES) void rewrite_kernel(TrainA
         for (uint32_t w = 0; w < kThreads / 64; ++w) { if (w < wv) w_off += s_wsum[w]; tile_kept += s_wsum[w]; }
         uint32_t o = w_off + incl - kept;                    // inside the tile's output; it leaves LDS in one coalesced copy below
         // walk the span: write survivors, emit count deltas.  A span with no site in or next to it (site_mask covers elements 0..17) keeps all its ids and changes no
-        // count -- nearly every span once the merged pairs are rare, which is most merges: sixteen stores instead of the walk's ~350 vector instructions
+        // count -- nearly every span once the merged pairs are rare, which is most merges: kPerThread stores instead of the walk
         if ((site_mask | second_mask) == 0 && valid == (uint32_t)kPerThread) {
 #pragma unroll
             for (int k = 1; k <= kPerThread; ++k) s_ids[o + (uint32_t)(k - 1)] = s.a[k];
@@ -909,9 +909,9 @@ __global__ __launch_bounds__(kThreads, ECGB_RW_WAVES) void rewrite_kernel(TrainA
                     bool next_site;
                     if (kn <= kPerThread + 1) next_site = (site_mask >> kn) & 1u;
                     else {
-                        // kn == 18 (only when element 16 is a site): element 18 starts a site iff it and
-                        // element 19 match; for l == r it sits at an even run offset (16 was even, 17 odd)
-                        const uint64_t i19 = i0 + kPerThread + 2;   // a[19] = src[i0 - 1 + 19]
+                        // kn == kPerThread + 2 (only when the span's last element is a site): that element starts a site iff it and
+                        // the one after it match; for l == r it sits at an even run offset (the site's two elements before it were even, odd)
+                        const uint64_t i19 = i0 + kPerThread + 2;   // the id after a[kPerThread + 2]: src[i0 - 1 + kPerThread + 3]
                         const uint32_t a19 = (i19 < n) ? src[i19] : halo_at(halo, (int64_t)i19, n);
                         next_site = (an == l && a19 == r);
                     }
