@@ -256,6 +256,7 @@ class HipCausalLM(nn.Module):
         self._t = {}            # transposed shadow weights
         self._t_version = {}    # parameter version each shadow was made from
         self.embed_grad_head = None
+        self._head_buf = None
         self.full_logits = False   # True: run the loss head over every row, as the reference materialises it
         self._saved = None
         self.grad_sync = None      # parallel.GradAllReduce: told as soon as a layer's gradients are final
@@ -364,6 +365,7 @@ class HipCausalLM(nn.Module):
         self.config.vocab_size = n
         self.v_pad = v_pad
         self.embed_grad_head = None
+        self._head_buf = None
         self._t.pop("embed", None)
 
     def enable_lora(self, r=16, alpha=32, dropout=0.05, seed=0):
@@ -744,7 +746,8 @@ class HipCausalLM(nn.Module):
 
     def _loss_head(self, hf, labels, B, S):
         """Tied lm_head + ForCausalLMLoss (loss_utils.py:24-47) over the final hidden states hf [B*S, H]: returns (loss, d loss / d hf)
-        and leaves d loss / d E of the head in self.embed_grad_head (bf16 [v_pad, H]; unless the base is frozen)."""
+        and leaves d loss / d E of the head in self.embed_grad_head (bf16 [v_pad, H]: the table's slice of the flat gradient buffer, or a buffer of
+        its own when that slice holds a kept gradient or no gradient is being taken; unless the base is frozen)."""
         c = self.cfg
         H = c.hidden_size
         dev = self.device
@@ -758,8 +761,16 @@ class HipCausalLM(nn.Module):
         rows = torch.arange(T, device=dev) if self.full_logits else torch.nonzero(shifted != -100).view(-1)
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
         frozen = self.lora is not None
-        if not frozen and self.embed_grad_head is None:
-            self.embed_grad_head = torch.empty((self.v_pad, H), dtype=torch.bfloat16, device=dev)
+        if not frozen:
+            # The head's share of dE goes straight into the table's slice of the flat gradient buffer when that slice is free (training, no gradient kept from an
+            # earlier backward): the backward then finds it in place -- no [v_pad, H] buffer of its own (0.54 GB at Llama-3.2-1B's vocabulary) and no copy of it.
+            if torch.is_grad_enabled() and self.embed.grad is None:
+                self._grad_layout()
+                self.embed_grad_head = self._gview[id(self.embed)]
+            else:
+                if getattr(self, "_head_buf", None) is None:
+                    self._head_buf = torch.empty((self.v_pad, H), dtype=torch.bfloat16, device=dev)
+                self.embed_grad_head = self._head_buf
         dhf = torch.zeros((T, H), dtype=torch.bfloat16, device=dev)
 
         chunk = 4096
@@ -789,7 +800,9 @@ class HipCausalLM(nn.Module):
         without atomics (ecgb_embed_bwd_sorted)."""
         view, acc = self._grad_slot(param)
         if head is not None:
-            if acc:
+            if head.data_ptr() == view.data_ptr():
+                pass                                                     # (the loss head wrote it here: _loss_head)
+            elif acc:
                 ops.add(view, head, out=view)
             else:
                 view.copy_(head)
@@ -1163,7 +1176,8 @@ class HipCausalLM(nn.Module):
                         and self.embed.grad is None)
         if sparse_embed:
             view, _ = self._grad_slot(self.embed)
-            view.copy_(self.embed_grad_head)
+            if self.embed_grad_head.data_ptr() != view.data_ptr():
+                view.copy_(self.embed_grad_head)
             self.embed.grad = view
             off = (view.data_ptr() - self._gflat.data_ptr()) // 2
             self.grad_sync.on_flat_ready(self._gflat, off, off + view.numel())

@@ -99,6 +99,7 @@ class HipGPT2LM(HipCausalLM):
         self.lora = None
         self._t, self._t_version = {}, {}
         self.embed_grad_head = None
+        self._head_buf = None
         self.full_logits = False
         self._saved = None
         self.grad_sync = None
@@ -392,5 +393,6 @@ class HipGPT2LM(HipCausalLM):
         self.cfg.vocab_size = self.config.vocab_size = n
         self.v_pad = v_pad
         self.embed_grad_head = None
+        self._head_buf = None
         self._t.pop("embed", None)
         self._gflat = None
