@@ -282,6 +282,25 @@ def bench_batch_sweep(tk, pc, xd, L, sizes=(1, 64, 1024, 4096, 16384, 65536), re
     return out
 
 
+def device_selfcheck():
+    """Which GPU the line was measured on and whether it repeats a product bit for bit (torch.matmul, none of this repository's code: one GPU of the pool did not in
+    round 4 -- EXPERIMENTS.md section R4, tests/test_gpu_00_selfcheck.py; the train legs' figures from such a device are not to be trusted)."""
+    import subprocess
+    import torch
+    serial = None
+    try:
+        txt = subprocess.run(["rocm-smi", "--showserial"], capture_output=True, text=True, timeout=20).stdout
+        serial = next((ln.split(":")[-1].strip() for ln in txt.splitlines() if "Serial Number:" in ln), None)
+    except Exception:
+        pass
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = (torch.randn(2048, 512, device="cuda", generator=g) * 0.5).bfloat16()
+    w = (torch.randn(3072, 512, device="cuda", generator=g) * 0.05).bfloat16()
+    outs = [(x @ w.t()).clone() for _ in range(40)]
+    differ = sum(not torch.equal(outs[0], o) for o in outs[1:])
+    return {"serial": serial, "torch_matmul_launches_that_differ_from_the_first": differ, "of": 39, "repeats_bit_for_bit": differ == 0}
+
+
 def bench_trainer(pc, L, x, num_merges=4000):
     """rust_bpe.byte_pair_encoding on the device for the C2 tokenizer's own corpus (2 000 synthetic records, seed 1).
     Algorithmic bytes per merge i: 4 N_i (count) + 4 N_i + 4 N_{i+1} (rewrite); the N_i are recovered exactly from the result (undoing merge
@@ -800,6 +819,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_c5 and not args.no_train:
         c5 = bench_c5(args, dev)
     extras = {}
+    if rank == 0:
+        extras["device"] = device_selfcheck()
     if rank == 0 and world == 1 and not args.no_extras and L == 5000:
         extras["trainer"] = bench_trainer(pc, L, x_corpus)
         del x_corpus
