@@ -747,7 +747,7 @@ __global__ __launch_bounds__(kThreads, ECGB_RW_WAVES) void rewrite_kernel(TrainA
     __shared__ int s_val[kHashSlots];
     __shared__ uint32_t s_wave[kThreads / 64];
     __shared__ uint32_t s_wsum[kThreads / 64];
-    __shared__ uint32_t s_ids[kStageWords];               // the tile on its way in (tile_park), then its survivors on their way out
+    __shared__ __attribute__((aligned(16))) uint32_t s_ids[kStageWords];   // the tile on its way in (tile_park), then its survivors on their way out
     PH_DECL;
     constexpr int kRec = kGrid / kThreads;
     static_assert(kGrid % kThreads == 0, "a lane takes kGrid / kThreads records");
@@ -829,17 +829,28 @@ __global__ __launch_bounds__(kThreads, ECGB_RW_WAVES) void rewrite_kernel(TrainA
     int n_lr = 0;
     uint32_t kept_prev = 0;
     uint64_t out_prev = 0;
-    uint32_t sv[kPerThread];
+    // Sixteen bytes a lane (four survivors in a row): a wave's store is 1 KB of consecutive words wherever the tile's output begins.  Four bytes a lane was 256 bytes
+    // per store at an arbitrary word offset -- partly written 32- and 64-byte pieces at both ends of every one: WRITE_SIZE read 73 MB per merge for 46 MB of survivors
+    // (profiles/r04/trainer_hbm.json).
+    uint4 sv[kFetchVecs];
     auto survivors_take = [&]() {
 #pragma unroll
-        for (int k = 0; k < kPerThread; ++k) sv[k] = s_ids[threadIdx.x + (uint32_t)k * kThreads];
+        for (int k = 0; k < kFetchVecs; ++k) sv[k] = *reinterpret_cast<const uint4 *>(s_ids + (threadIdx.x + (uint32_t)k * kThreads) * 4u);
         lds_barrier();                                       // (everybody has its survivors in registers: s_ids is free for the next tile)
     };
     auto survivors_send = [&]() {
 #pragma unroll
-        for (int k = 0; k < kPerThread; ++k) {
-            const uint32_t i = threadIdx.x + (uint32_t)k * kThreads;
-            if (i < kept_prev) dst[out_prev + i] = sv[k];
+        for (int k = 0; k < kFetchVecs; ++k) {
+            const uint32_t i = (threadIdx.x + (uint32_t)k * kThreads) * 4u;
+            uint32_t *q = dst + out_prev + i;
+            if (i + 3u < kept_prev) {
+                typedef uint32_t u4_a4 __attribute__((ext_vector_type(4), aligned(4)));      // (one 16-byte store: the address is word-aligned only)
+                *reinterpret_cast<u4_a4 *>(q) = u4_a4{sv[k].x, sv[k].y, sv[k].z, sv[k].w};
+            } else {
+                if (i < kept_prev) q[0] = sv[k].x;
+                if (i + 1u < kept_prev) q[1] = sv[k].y;
+                if (i + 2u < kept_prev) q[2] = sv[k].z;
+            }
         }
     };
     for (uint32_t t = t_first; t < t_first + t_count; ++t) {
