@@ -184,8 +184,7 @@ __global__ __launch_bounds__(kThreads) void init_kernel(TrainArgs A, const uint8
     const uint64_t n = A.n0;
     const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
     // A lane takes kPerThread consecutive bytes: the pairs of a stretch of one symbol are one pair over and over, counted in a register and added once (a quantised ECG
-    // is mostly such stretches: one LDS add per pair was 2.8 ms for 1.2e8 symbols, every lane of a wave on the same few slots); the table leaves LDS every eighth tile.
-    uint32_t tiles_done = 0;
+    // is mostly such stretches: one LDS add per pair was 2.8 ms for 1.2e8 symbols, every lane of a wave on the same few slots); the table leaves LDS once, at the end.
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint64_t i0 = (uint64_t)t * kTile + (uint64_t)threadIdx.x * kPerThread;
         uint32_t a[kPerThread + 1];
@@ -206,7 +205,6 @@ __global__ __launch_bounds__(kThreads) void init_kernel(TrainArgs A, const uint8
             }
         }
         if (run_n) delta_add(s_key, s_val, tab_of(A), run_key, run_n);
-        if (((++tiles_done) & 7u) == 0) delta_flush(s_key, s_val, tab_of(A));
     }
     delta_flush(s_key, s_val, tab_of(A));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -771,7 +769,6 @@ __global__ __launch_bounds__(kThreads, ECGB_RW_WAVES) void rewrite_kernel(TrainA
     const SlabKey SK{l, r, X, V};
     const uint32_t n_tiles = (uint32_t)((n + kTile - 1) / kTile);
     TileRegs tr;
-    uint32_t tiles_done = 0;
     uint32_t t_first, t_count;
     tile_range(n_tiles, blockIdx.x, gridDim.x, t_first, t_count);
     if (t_count) tile_fetch(tr, src, (uint64_t)t_first * kTile, n, halo);
@@ -935,10 +932,10 @@ __global__ __launch_bounds__(kThreads, ECGB_RW_WAVES) void rewrite_kernel(TrainA
         kept_prev = tile_kept;
         out_prev = tile_off;
         run_off += tile_kept;
-        // the count deltas stay in the workgroup's LDS table across its tiles and leave every eighth tile and at the end (a flush per tile was two barriers, a sweep of
-        // the 2 048 slots and as many global atomics as the tile had distinct pairs -- the same pairs tile after tile); a table that fills up overflows into memory as before
-        if (((++tiles_done) & 7u) == 0) delta_flush(s_key, s_val, tab_of(A), A.slab, SK);
-        else lds_barrier();                                // (the survivors are all in s_ids)
+        // the count deltas stay in the workgroup's LDS table across ALL its tiles and leave once, after the loop (a flush per tile was two barriers, a sweep of the 2 048
+        // slots and as many global atomics as the tile had distinct pairs -- the same pairs tile after tile, from 1 280 workgroups onto the same few hundred cells of the
+        // table: every eighth tile still cost the early merges a quarter of their time); a table that fills up overflows into memory as before
+        lds_barrier();                                     // (the survivors are all in s_ids)
         PH_MARK(7);
     }
     survivors_take();
