@@ -368,8 +368,8 @@ struct Span {
 __device__ __forceinline__ uint32_t halo_at(const Halo &h, int64_t i, uint64_t n)   // id at position i outside [0, n)
 {
     if (i < 0) return i == -1 ? h.prev : kEmpty;
-    const uint64_t d = (uint64_t)i - n;
-    return d < 3 ? h.next[d] : kEmpty;
+    const uint64_t d = (uint64_t)i - n;                 // (no indexing by d: an indexed member put the whole struct, 32 bytes a lane, into scratch memory -- written and
+    return d == 0 ? h.next[0] : d == 1 ? h.next[1] : d == 2 ? h.next[2] : kEmpty;   //  read back by every lane of every launch: a quarter of the rewrite's HBM writes)
 }
 
 // A lane's span out of LDS.  A lane's 19 ids lie 64 bytes apart from its neighbour's: read straight from memory, every one of the 19 loads of a wave touches 64
@@ -477,26 +477,28 @@ __device__ __forceinline__ uint32_t thread_lead_parity(uint32_t tail, uint32_t t
 __device__ __forceinline__ void classify(const Span &s, uint32_t l, uint32_t r, uint32_t lead_par,
                                          uint32_t &site_mask, uint32_t &second_mask, uint32_t &site_after)
 {
-    site_mask = 0; second_mask = 0;
+    // (the masks are built in locals, by selects: updated through the reference parameters under conditions they lived in scratch memory -- a store per set bit and
+    // loads that wait on the same counter as the tile prefetch and the survivors' stores)
+    uint32_t sm = 0, sc = 0;
     if (l != r) {
 #pragma unroll
         for (int k = 1; k <= kPerThread; ++k) {
-            if (s.a[k] == l && s.a[k + 1] == r) site_mask |= 1u << k;
-            if (s.a[k - 1] == l && s.a[k] == r) second_mask |= 1u << k;
+            sm |= ((s.a[k] == l && s.a[k + 1] == r) ? 1u : 0u) << k;
+            sc |= ((s.a[k - 1] == l && s.a[k] == r) ? 1u : 0u) << k;
         }
         site_after = (s.a[kPerThread + 1] == l && s.a[kPerThread + 2] == r) ? 1u : 0u;
     } else {
         uint32_t q = lead_par;                                  // run offset parity of element 1
 #pragma unroll
         for (int k = 1; k <= kPerThread; ++k) {
-            if (s.a[k] == l) {
-                if (q == 0) { if (s.a[k + 1] == l) site_mask |= 1u << k; }
-                else second_mask |= 1u << k;
-                q ^= 1u;
-            } else q = 0;
+            const bool is_l = s.a[k] == l;
+            sm |= ((is_l && q == 0 && s.a[k + 1] == l) ? 1u : 0u) << k;
+            sc |= ((is_l && q != 0) ? 1u : 0u) << k;
+            q = is_l ? (q ^ 1u) : 0u;
         }
         site_after = (s.a[kPerThread + 1] == l && q == 0 && s.a[kPerThread + 2] == l) ? 1u : 0u;
     }
+    site_mask = sm; second_mask = sc;
 }
 
 // ---- 2. per-tile survivor counts (+ run facts of the tile for l == r merges) -------------------
