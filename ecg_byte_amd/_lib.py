@@ -164,6 +164,7 @@ def lib():
         "ecgb_gemm_nt_bf16_rope": [vp, ll, vp, ll, vp, ll, vp, ll, ci, vp, ll, ci, ci, ci, f32, vp, vp, ci, vp],
         "ecgb_set_gemm_w4": [ci],
         "ecgb_set_gemm_w4_group_m": [ci],
+        "ecgb_gemm_w4_span_ok": [ci, ll, ll, ll],
         "ecgb_set_gemm_w4_sched": [ci],
         "ecgb_set_gemm_w4_min_ktiles": [ci],
         "ecgb_attn_decode_split_dyn": [vp, vp, vp, ll, ll, vp, ll, vp, ci, vp, ci, ci, ci, f32, ci, vp, sz, vp],

@@ -2039,6 +2039,7 @@ int launch_gemm(GemmArgs &G, int batch, hipStream_t stream)
 // csrc/gemm_w4.hip: the four-wave kernel (128x128 wave tiles, one wave per SIMD) for plain NT products of whole 256x256 tiles
 namespace ecgb {
 bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long long ldb, const void *c_dev, long long ldc, int M, int N, int K);
+bool gemm_w4_span_ok(int lay, long long lda, long long ldb, long long K, long long extra_rows_b);      // 32-bit DMA offsets over the whole contraction (gemm_w4.hip)
 int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream,
                    int epi, void *h_dev, long long ldh, const void *a2_dev, long long lda2, const void *b2_dev, long long ldb2, int K2,
                    const float *rope_cos, const float *rope_sin, int rope_cols, int lay, const void *gu_dev = nullptr, long long ldgu = 0,
@@ -2109,7 +2110,7 @@ extern "C" int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b
         return ECGB_OK;
     }
     // whole 256x256 tiles, plain bf16 store, one problem, at least two tiles per CU: the four-wave kernel (the same bits; 1-6 % faster on the step's forward shapes)
-    if (g_gemm_w4 && g_gemm_tile == 0 && batch == 1 && accumulate_f32 == 0 && ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K))
+    if (g_gemm_w4 && g_gemm_tile == 0 && batch == 1 && accumulate_f32 == 0 && ecgb::gemm_w4_span_ok(0, lda, ldb, K, 0) && ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K))
         return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 0);
     return launch_gemm(G, batch, (hipStream_t)stream);
 }
@@ -2149,7 +2150,7 @@ extern "C" int ecgb_gemm_nt_bf16_cat(const void *a_dev, long long lda, const voi
         if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_skinny_kernel (cat): ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
         return ECGB_OK;
     }
-    if (g_gemm_w4 && g_gemm_tile == 0 && accumulate_f32 == 0 && (long long)63 * lda2 * 2 + 128 <= 0xFFFFFFFFll && (long long)63 * ldb2 * 2 + 128 <= 0xFFFFFFFFll &&
+    if (g_gemm_w4 && g_gemm_tile == 0 && accumulate_f32 == 0 && ecgb::gemm_w4_span_ok(0, lda2, ldb2, K2, 0) && ecgb::gemm_w4_span_ok(0, lda, ldb, K, 0) &&
         ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K))
         return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, a2_dev, lda2, b2_dev, ldb2, K2, nullptr, nullptr, 0, 0);
     return launch_gemm(G, 1, (hipStream_t)stream);
@@ -2206,7 +2207,7 @@ extern "C" int ecgb_gemm_tn_bf16(const void *a_dev, long long lda, const void *b
     // one K-slice, whole tiles, a long contraction: the four-wave kernel on the TN layout (the same bits; dW of the down projection 0.836 -> 0.785 ms, of gate|up 1.589 -> 1.574);
     // persistent, so not while a gradient exchange may hold CUs (g_nn_persist)
     if (splits == 1 && g_gemm_w4 && g_nn_persist && g_gemm_tile == 0 && N % 256 == 0 && K % 256 == 0 && (ldc & 7) == 0 && ((uintptr_t)c_dev & 15) == 0 &&
-        ((long long)15 * lda + 256) * 2 <= 0xFFFFFFFFll && ((long long)15 * ldb + 256) * 2 <= 0xFFFFFFFFll && ecgb::gemm_w4_applies(a_dev, 8, b_dev, 8, c_dev, ldc, N, K, M))
+        ecgb::gemm_w4_span_ok(2, lda, ldb, M, 0) && ecgb::gemm_w4_applies(a_dev, 8, b_dev, 8, c_dev, ldc, N, K, M))
         return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, N, K, M, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 2);
     G.accumulate_f32 = splits > 1 ? 1 : 0; G.alpha = alpha;      // splits > 1: c_dev is fp32 [splits][N, ldc], one slab per K-slice
     G.split_stride = (long long)N * ldc;
@@ -2260,8 +2261,8 @@ extern "C" int ecgb_gemm_nt_glu_bf16(const void *a_dev, long long lda, const voi
     // whole tiles, no second operand pair: the four-wave kernel with the same epilogue (the same bits).  Measured at [32768, 2048] -> 2 x 8192: 1.853 against 1.863 ms, h only
     // 1.669 against 1.703 -- the activation is vector work that a wave alone on its SIMD cannot hide (under the profiler its MFMA pipes are 0.57 busy, the plain kernel's
     // 0.65); with a LoRA pair behind it 1.952 against 1.935 in round 3 -- and 1.75 against 1.94 with round 4's K-tile schedule, so that form goes there too now.
-    if (g_gemm_w4 && g_gemm_tile == 0 && (K2 <= 0 || (long long)(inter + 63) * ldb2 * 2 + 128 <= 0xFFFFFFFFll) && (ldh & 7) == 0 && ((uintptr_t)h_dev & 15) == 0 && (!c_dev || ((ldc & 7) == 0 && ((uintptr_t)c_dev & 15) == 0)) &&
-        (long long)(inter + 63) * ldb * 2 + 128 <= 0xFFFFFFFFll && ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, h_dev, ldh, M, 2 * inter, K))
+    if (g_gemm_w4 && g_gemm_tile == 0 && (K2 <= 0 || ecgb::gemm_w4_span_ok(0, lda2, ldb2, K2, inter)) && (ldh & 7) == 0 && ((uintptr_t)h_dev & 15) == 0 && (!c_dev || ((ldc & 7) == 0 && ((uintptr_t)c_dev & 15) == 0)) &&
+        ecgb::gemm_w4_span_ok(0, lda, ldb, K, inter) && ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, h_dev, ldh, M, 2 * inter, K))
         return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, 2 * inter, K, alpha, stream, gelu_tanh ? 2 : 1, h_dev, ldh, a2_dev, lda2, b2_dev, ldb2, K2, nullptr, nullptr, 0, 0);
     GemmArgs G{};
     G.group_m = g_gemm_group_m;
@@ -2306,7 +2307,7 @@ extern "C" int ecgb_gemm_nn_bf16(const void *a_dev, long long lda, const void *b
     // long contractions of whole tiles, plain store: the four-wave kernel on the NN layout (the same bits; [32768, 16384] . [16384, 2048]: 1.63 against 1.72 ms).  It is
     // persistent: not while a gradient exchange may hold CUs (g_nn_persist, see above).
     if (g_gemm_w4 && g_nn_persist && g_gemm_tile == 0 && accumulate_f32 == 0 && (((uintptr_t)c_dev & 15) == 0) && (ldc & 7) == 0 && N % 256 == 0 &&
-        ((long long)15 * ldb + 256) * 2 <= 0xFFFFFFFFll && ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K))
+        ecgb::gemm_w4_span_ok(1, lda, ldb, K, 0) && ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K))
         return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1);
     GemmArgs G{};
     G.group_m = g_gemm_group_m;
@@ -2377,7 +2378,7 @@ extern "C" int ecgb_gemm_nn_glu_bwd_bf16(const void *dy_dev, long long lddy, con
     }
     // whole tiles and a long enough contraction per workgroup: the four-wave kernel on the NN layout with the same epilogue (the same bits; round 4).  Persistent: not
     // while a gradient exchange may hold CUs (g_nn_persist).
-    if (g_gemm_w4 && g_nn_persist && g_gemm_tile == 0 && ((long long)15 * ldw + 256) * 2 <= 0xFFFFFFFFll && ecgb::gemm_w4_applies(dy_dev, lddy, w_dev, ldw, d_gate_up_dev, ldd, M, inter, K))
+    if (g_gemm_w4 && g_nn_persist && g_gemm_tile == 0 && ecgb::gemm_w4_span_ok(1, lddy, ldw, K, 0) && ecgb::gemm_w4_applies(dy_dev, lddy, w_dev, ldw, d_gate_up_dev, ldd, M, inter, K))
         return ecgb::gemm_w4_launch(dy_dev, lddy, w_dev, ldw, d_gate_up_dev, ldd, M, inter, K, 1.0f, stream, gelu_tanh ? 5 : 4, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1,
                                     gate_up_dev, ldgu);
     GemmArgs G{};
@@ -2418,7 +2419,7 @@ extern "C" int ecgb_gemm_nn_glu_bwd_lora_bf16(const void *dy_dev, long long lddy
     }
     if (K % BK || M % 256 || inter % 256 || lddy % 8 || ldw % 8 || ldgu % 8 || ldd % 8 || ((uintptr_t)dy_dev & 15) || ((uintptr_t)w_dev & 15) || ((uintptr_t)gate_up_dev & 15) ||
         ((uintptr_t)d_gate_up_dev & 15) || ((uintptr_t)dt_dev & 15) || ((uintptr_t)at_dev & 15) || (long long)M * inter > 0xFFFFFFFFll ||
-        !(g_gemm_w4 && g_nn_persist && g_gemm_tile == 0 && ((long long)15 * ldw + 256) * 2 <= 0xFFFFFFFFll && ecgb::gemm_w4_applies(dy_dev, lddy, w_dev, ldw, d_gate_up_dev, ldd, M, inter, K))) {
+        !(g_gemm_w4 && g_nn_persist && g_gemm_tile == 0 && ecgb::gemm_w4_span_ok(1, lddy, ldw, K, 0) && ecgb::gemm_w4_applies(dy_dev, lddy, w_dev, ldw, d_gate_up_dev, ldd, M, inter, K))) {
         ecgb::set_error("ecgb_gemm_nn_glu_bwd_lora_bf16: whole 256x256 tiles with at least the four-wave kernel's share of K-tiles per CU, 16-byte aligned operands");
         return ECGB_ERR_UNSUPPORTED;
     }
@@ -2439,7 +2440,7 @@ extern "C" int ecgb_gemm_nn_lora_bf16(const void *dy_dev, long long lddy, const 
     }
     if (K % BK || M % 256 || in % 256 || lddy % 8 || ldw % 8 || lddx % 8 || ((uintptr_t)dy_dev & 15) || ((uintptr_t)w_dev & 15) || ((uintptr_t)dx_dev & 15) ||
         ((uintptr_t)dt_dev & 15) || ((uintptr_t)at_dev & 15) || (long long)M * in > 0xFFFFFFFFll ||
-        !(g_gemm_w4 && g_nn_persist && g_gemm_tile == 0 && ((long long)15 * ldw + 256) * 2 <= 0xFFFFFFFFll && ecgb::gemm_w4_applies(dy_dev, lddy, w_dev, ldw, dx_dev, lddx, M, in, K))) {
+        !(g_gemm_w4 && g_nn_persist && g_gemm_tile == 0 && ecgb::gemm_w4_span_ok(1, lddy, ldw, K, 0) && ecgb::gemm_w4_applies(dy_dev, lddy, w_dev, ldw, dx_dev, lddx, M, in, K))) {
         ecgb::set_error("ecgb_gemm_nn_lora_bf16: whole 256x256 tiles with at least the four-wave kernel's share of K-tiles per CU, 16-byte aligned operands");
         return ECGB_ERR_UNSUPPORTED;
     }

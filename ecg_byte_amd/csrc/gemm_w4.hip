@@ -669,6 +669,18 @@ int w4_cus()
 }  // namespace
 
 namespace ecgb {
+// The DMA descriptor of an operand is set ONCE per output tile and the K loop walks the contraction with 32-bit scalar offsets (soff_at / dma_step_*), so the largest
+// byte offset a piece ever uses must stay below 2^32: a row operand (NT's A and B, NN's A) reaches 63 rows (+ `extra_rows_b`: the GLU forms' up rows) plus the whole
+// contraction along the row; an operand stored as contraction rows (NN's B, TN's A and B: lay 1 / 2) reaches K + 15 rows.  Past that the eight-wave kernels
+// (64-bit pointers per K-tile) take the problem.
+bool gemm_w4_span_ok(int lay, long long lda, long long ldb, long long K, long long extra_rows_b)
+{
+    const long long lim = 0xFFFFFFFFll;
+    const long long a = lay == 2 ? (K + 15) * lda * 2 + 512 : 63 * lda * 2 + K * 2 + 128;
+    const long long b = lay >= 1 ? (K + 15) * ldb * 2 + 512 : (63 + extra_rows_b) * ldb * 2 + K * 2 + 128;
+    return lda > 0 && ldb > 0 && K > 0 && a <= lim && b <= lim;
+}
+
 // For gemm.hip's dispatch: does the four-wave kernel take this problem?  Whole 256x256 tiles, operands 16-byte aligned, per-lane DMA offsets within 32 bits, and
 // at least 256 K-tiles per workgroup (one persistent workgroup per CU with a static share of the tiles): measured on the step's shapes, the kernel gains 4-6 %
 // where a workgroup has 512 K-tiles and more ([32768, 8192] -> 2048, the loss head, gate|up) and loses 0-3 % at 128-192 (qkv, o: the eight-wave kernels'
@@ -703,11 +715,13 @@ int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long lon
     void (*const kerns[2][15])(W4Args) = {W4_KERNS(0), W4_KERNS(1)};
 #undef W4_KERNS
     void (*kern)(W4Args) = kerns[g_w4_sched ? 1 : 0][which];
+#ifdef ECGB_PROFILE
     if (g_w4_sched >= 16 && which == 0) {                                  // timing-only diagnostics of the plain NT kernel
         const int d = g_w4_sched >> 4;
         kern = d == 1 ? gemm_nt_w4_kernel<0, false, 0, 17> : d == 2 ? gemm_nt_w4_kernel<0, false, 0, 33> : d == 3 ? gemm_nt_w4_kernel<0, false, 0, 49> :
                d == 4 ? gemm_nt_w4_kernel<0, false, 0, 65> : d == 7 ? gemm_nt_w4_kernel<0, false, 0, 113> : kern;
     }
+#endif
     // (the attribute is per device: set on every launch, as everywhere else in the library -- a cached flag would be wrong on a second GPU)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e == hipSuccess) {
@@ -719,9 +733,19 @@ int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long lon
 }
 }  // namespace ecgb
 
+// 1 if the four-wave kernel's 32-bit DMA offsets cover an operand pair of these strides over a contraction of K (lay 0 NT, 1 NN, 2 TN), 0 otherwise: pure arithmetic,
+// no device needed (tests/test_host.py pins the >= 4 GiB cases the dispatch must hand to the eight-wave kernels).
+extern "C" int ecgb_gemm_w4_span_ok(int lay, long long lda, long long ldb, long long K) { return ecgb::gemm_w4_span_ok(lay, lda, ldb, K, 0) ? 1 : 0; }
+
 extern "C" int ecgb_set_gemm_w4_sched(int s)
 {
-    if (s < 0 || (s > 1 && (s & 15) != 1)) { ecgb::set_error("ecgb_set_gemm_w4_sched: 0 (one rendezvous per K-tile) or 1 (four barriers, counted waits)"); return ECGB_ERR_INVALID; }
+    // (17 / 33 / 49 / 65 / 113: timing-only builds WITHOUT barriers / DMA waits / DMA -- wrong results by design; they exist in the dev build only, `make prof`)
+#ifdef ECGB_PROFILE
+    const bool ok = s >= 0 && (s <= 1 || (s & 15) == 1);
+#else
+    const bool ok = s == 0 || s == 1;
+#endif
+    if (!ok) { ecgb::set_error("ecgb_set_gemm_w4_sched: 0 (one rendezvous per K-tile) or 1 (four barriers, counted waits)"); return ECGB_ERR_INVALID; }
     g_w4_sched = s;
     return ECGB_OK;
 }
@@ -747,7 +771,7 @@ extern "C" int ecgb_gemm_nt_w4_bf16(const void *a_dev, long long lda, const void
     if (!a_dev || !b_dev || !c_dev || M <= 0 || N <= 0 || K <= 0) { ecgb::set_error("ecgb_gemm_nt_w4_bf16: bad argument"); return ECGB_ERR_INVALID; }
     (void)ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K);          // (device properties)
     if (M % 256 || N % 256 || K % BK || lda % 8 || ldb % 8 || ldc % 8 || (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)c_dev) & 15) ||
-        (long long)63 * lda * 2 + 128 > 0xFFFFFFFFll || (long long)63 * ldb * 2 + 128 > 0xFFFFFFFFll) {
+        !ecgb::gemm_w4_span_ok(0, lda, ldb, K, 0)) {
         ecgb::set_error("ecgb_gemm_nt_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
         return ECGB_ERR_UNSUPPORTED;
     }
@@ -768,8 +792,7 @@ extern "C" int ecgb_gemm_nt_bf16_rope(const void *a_dev, long long lda, const vo
     (void)ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K);          // (device properties)
     if (M % 256 || N % 256 || K % BK || K2 % BK || rope_cols % 64 || rope_cols < 0 || rope_cols > N || lda % 8 || ldb % 8 || ldc % 8 || (K2 > 0 && (lda2 % 8 || ldb2 % 8)) ||
         (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)c_dev | (uintptr_t)a2_dev | (uintptr_t)b2_dev | (uintptr_t)rope_cos_dev | (uintptr_t)rope_sin_dev) & 15) ||
-        (long long)63 * lda * 2 + 128 > 0xFFFFFFFFll || (long long)63 * ldb * 2 + 128 > 0xFFFFFFFFll ||
-        (K2 > 0 && ((long long)63 * lda2 * 2 + 128 > 0xFFFFFFFFll || (long long)63 * ldb2 * 2 + 128 > 0xFFFFFFFFll)) || (long long)(M / 256) * (N / 256) < w4_cus()) {
+        !ecgb::gemm_w4_span_ok(0, lda, ldb, K, 0) || (K2 > 0 && !ecgb::gemm_w4_span_ok(0, lda2, ldb2, K2, 0)) || (long long)(M / 256) * (N / 256) < w4_cus()) {
         ecgb::set_error("ecgb_gemm_nt_bf16_rope: whole 256x256 tiles (one per CU at least), K % 64, 16-byte aligned operands required");
         return ECGB_ERR_UNSUPPORTED;
     }
@@ -783,7 +806,7 @@ extern "C" int ecgb_gemm_nn_w4_bf16(const void *a_dev, long long lda, const void
     if (!a_dev || !b_dev || !c_dev || M <= 0 || N <= 0 || K <= 0) { ecgb::set_error("ecgb_gemm_nn_w4_bf16: bad argument"); return ECGB_ERR_INVALID; }
     (void)ecgb::gemm_w4_applies(a_dev, lda, a_dev, lda, c_dev, ldc, M, N, K);          // (device properties)
     if (M % 256 || N % 256 || K % BK || lda % 8 || ldb % 8 || ldc % 8 || (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)c_dev) & 15) ||
-        (long long)63 * lda * 2 + 128 > 0xFFFFFFFFll || ((long long)15 * ldb + 256) * 2 > 0xFFFFFFFFll) {
+        !ecgb::gemm_w4_span_ok(1, lda, ldb, K, 0)) {
         ecgb::set_error("ecgb_gemm_nn_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
         return ECGB_ERR_UNSUPPORTED;
     }
@@ -798,7 +821,7 @@ extern "C" int ecgb_gemm_tn_w4_bf16(const void *a_dev, long long lda, const void
     if (!a_dev || !b_dev || !c_dev || M <= 0 || N <= 0 || K <= 0) { ecgb::set_error("ecgb_gemm_tn_w4_bf16: bad argument"); return ECGB_ERR_INVALID; }
     (void)ecgb::gemm_w4_applies(a_dev, 8, a_dev, 8, c_dev, ldc, M, N, K);              // (device properties)
     if (M % 256 || N % 256 || K % BK || lda % 8 || ldb % 8 || ldc % 8 || (((uintptr_t)a_dev | (uintptr_t)b_dev | (uintptr_t)c_dev) & 15) ||
-        ((long long)15 * lda + 256) * 2 > 0xFFFFFFFFll || ((long long)15 * ldb + 256) * 2 > 0xFFFFFFFFll) {
+        !ecgb::gemm_w4_span_ok(2, lda, ldb, K, 0)) {
         ecgb::set_error("ecgb_gemm_tn_w4_bf16: M, N multiples of 256, K of 64, operands 16-byte aligned with strides % 8 == 0");
         return ECGB_ERR_UNSUPPORTED;
     }

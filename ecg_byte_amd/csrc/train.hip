@@ -1135,7 +1135,8 @@ TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w
 
 }  // namespace
 
-// workgroups of the count and rewrite passes: kGrid, or fewer for tests (ranges of many tiles on small corpora: every chain the passes carry across tiles and ranges)
+// workgroups of the count and rewrite passes: kGrid, or fewer for tests (ranges of many tiles on small corpora: every chain the passes carry across tiles and ranges).
+// TEST HOOK: a process-wide value read once at the start of a run / at shard creation (a shard keeps its own copy) -- not synchronised, not for concurrent callers.
 static unsigned g_train_grid = kGrid;
 extern "C" int ecgb_set_bpe_train_grid(int workgroups)
 {
@@ -1185,6 +1186,8 @@ extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t nu
     rc = check_hip(hipMemsetAsync(A.row_dirty, 1, V * 4, st), "hipMemsetAsync(row flags)");      // every row is read when the arg-max first comes to it
     if (rc) return rc;
     const unsigned tile_grid = (unsigned)std::max<size_t>(1, std::min<size_t>(g_train_grid, (n + kTile - 1) / kTile));
+    // a range's survivor count is a 32-bit record (TileInfo.count0): the static_assert above covers kGrid ranges, a smaller test grid must keep the bound itself
+    if (n / tile_grid + kTile >= (1ull << 32)) { ecgb::set_error("ecgb_bpe_train_hip: " + std::to_string(n) + " ids over " + std::to_string(tile_grid) + " ranges overflow a range's 32-bit count (ecgb_set_bpe_train_grid is a test hook: use the default grid)"); return ECGB_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(init_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, text_dev);
     for (uint32_t i = 0; i < num_merges; ++i) {
         hipLaunchKernelGGL(rowmax_kernel, dim3(kRowGrid), dim3(kThreads), 0, st, A, i);
@@ -1210,6 +1213,10 @@ extern "C" ecgb_bpe_shard *ecgb_bpe_shard_create(size_t n_local, uint32_t num_me
     if (!scratch_dev || n_local >= kMaxIds || num_merges > 65000u || scratch_bytes < ecgb_bpe_train_scratch_bytes(n_local, num_merges)) {
         ecgb::set_error("ecgb_bpe_shard_create: bad argument or scratch smaller than ecgb_bpe_train_scratch_bytes()");
         return nullptr;
+    }
+    {
+        const size_t tg = std::max<size_t>(1, std::min<size_t>(g_train_grid, (n_local + kTile - 1) / kTile));
+        if (n_local / tg + kTile >= (1ull << 32)) { ecgb::set_error("ecgb_bpe_shard_create: ids per range overflow a range's 32-bit count (ecgb_set_bpe_train_grid is a test hook: use the default grid)"); return nullptr; }
     }
     ecgb_bpe_shard *h = new ecgb_bpe_shard;
     h->A = layout(scratch_dev, n_local, num_merges, &h->halo_w);

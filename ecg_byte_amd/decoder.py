@@ -204,10 +204,19 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, input_ids, attention_mask, labels, position_ids):
         ctx.model = model
-        return model._forward_loss(input_ids, attention_mask, labels, position_ids)
+        loss = model._forward_loss(input_ids, attention_mask, labels, position_ids)
+        # The model keeps ONE forward's state (`_saved`, and the tied head's dE, which the loss head writes during the forward -- into the embedding's slice of the flat
+        # gradient buffer when that is free): a second grad-enabled forward before this one's backward replaces both.  Each forward is numbered so that the backward of
+        # an overwritten one fails loudly instead of consuming the other forward's head gradient (validation passes belong under torch.no_grad()).
+        model._fwd_serial = getattr(model, "_fwd_serial", 0) + 1
+        ctx.fwd_serial = model._fwd_serial
+        return loss
 
     @staticmethod
     def backward(ctx, grad_out):
+        if getattr(ctx.model, "_fwd_serial", None) != ctx.fwd_serial or ctx.model._saved is None:
+            raise RuntimeError("backward() of a forward whose saved state a later grad-enabled forward has replaced (the model keeps one forward's activations and "
+                               "head gradient): run validation / extra losses under torch.no_grad(), or call backward() before the next forward")
         ctx.model._backward(grad_out)
         return None, None, None, None, None, None
 
@@ -764,6 +773,7 @@ class HipCausalLM(nn.Module):
         if not frozen:
             # The head's share of dE goes straight into the table's slice of the flat gradient buffer when that slice is free (training, no gradient kept from an
             # earlier backward): the backward then finds it in place -- no [v_pad, H] buffer of its own (0.54 GB at Llama-3.2-1B's vocabulary) and no copy of it.
+            # (`_wait_group("embed")` above must precede this: with the overlapped optimizer the update of the table may still be reading its gradient slice.)
             if torch.is_grad_enabled() and self.embed.grad is None:
                 self._grad_layout()
                 self.embed_grad_head = self._gview[id(self.embed)]

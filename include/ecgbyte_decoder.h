@@ -330,6 +330,7 @@ int ecgb_gemm_tn_w4_bf16(const void *a_dev, long long lda, const void *b_dev, lo
 int ecgb_set_gemm_w4(int on);              /* 1 (default): ecgb_gemm_nt_bf16 / _cat / _glu send eligible problems to the four-wave kernel; 0: never; 2: every form it has (A/B, tests) */
 int ecgb_set_gemm_w4_group_m(int group_m);  /* its tile order: blocks of group_m tile rows (default 8; 0 = row by row) */
 int ecgb_set_gemm_w4_min_ktiles(int n);     /* K-tiles per workgroup from which the dispatch picks the four-wave kernel (default 128) */
+int ecgb_gemm_w4_span_ok(int lay, long long lda, long long ldb, long long K);   /* 1 if the four-wave kernel's 32-bit DMA offsets cover these strides over a contraction of K (lay 0 NT, 1 NN, 2 TN); else the dispatch uses the eight-wave kernels.  Pure arithmetic, no device. */
 int ecgb_set_gemm_w4_sched(int sched);      /* its K-tile schedule: 1 (default) four barriers per K-tile behind counted waits, 0 one rendezvous per K-tile (round 3; A/B).  Same bits. */
 
 /* ecgb_rmsnorm_fwd for the few rows of a decode step with adapters, followed in the same launch by the site's stacked LoRA down-projection of the normalised row:

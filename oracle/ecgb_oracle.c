@@ -206,7 +206,7 @@ uint32_t ecgb_oracle_bpe_train(uint32_t *ids_io, size_t *n_io, uint32_t num_merg
 /* ------------------------------------------------------------------------------------
  * TrieNode (lib.rs:127-147) + encode_text (lib.rs:149-193).
  * The reference holds a HashMap<u32,TrieNode> per node; here one open-addressing edge
- * map keyed (node<<8 | byte) serves every node -- same mapping, same semantics:
+ * map keyed (node<<32 | element) serves every node (u32 elements, lib.rs:128) -- same mapping, same semantics:
  *   insert(): walk/create children, then node.token_id = Some(id)  (last insert wins)
  *   encode(): from i walk while a child exists, remember the deepest node carrying a
  *             token_id, emit it and advance by its length; no match -> emit the raw id.

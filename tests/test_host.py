@@ -24,17 +24,19 @@ def lib():
     return _lib.lib()
 
 
-def _header_functions():
-    src = open(os.path.join(ROOT, "include", "ecgbyte.h")).read()
+def _header_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
     return sorted(set(re.findall(r"\b(ecgb_[a-z_0-9]+)\s*\(", src)))
 
 
-def test_library_exports_every_declared_symbol(lib):
-    names = _header_functions()
-    assert len(names) >= 10
+@pytest.mark.parametrize("header,at_least", [("ecgbyte.h", 30), ("ecgbyte_decoder.h", 70)])
+def test_library_exports_every_declared_symbol(lib, header, at_least):
+    names = _header_functions(header)
+    assert len(names) >= at_least, (header, len(names))
     for name in names:
-        assert hasattr(lib, name), f"{name} declared in include/ecgbyte.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/{header} but not exported"
     assert lib.ecgb_version() >> 16 == 1
 
 
@@ -350,3 +352,17 @@ def test_bench_refuses_a_world_size_other_than_gpus():
     env["WORLD_SIZE"] = "2"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and r.stdout.strip() == ""
+
+
+def test_four_wave_gemm_refuses_operands_its_32_bit_dma_offsets_cannot_span(lib):
+    """The four-wave GEMM sets its DMA descriptor once per output tile and walks the contraction with 32-bit scalar offsets: an operand stored as contraction rows
+    reaches (K + 15) * ld * 2 bytes, a row operand 63 * ld * 2 + K * 2.  Operands of 4 GiB and more must go to the eight-wave kernels (round 4's advisor finding:
+    dW of gate|up with T >= 131 072 tokens at ld 16 384)."""
+    ok = lib.ecgb_gemm_w4_span_ok
+    assert ok(0, 2048, 2048, 2048) == 1 and ok(1, 8192, 2048, 8192) == 1 and ok(2, 16384, 2048, 32768) == 1      # the C3 step's shapes
+    assert ok(2, 16384, 2048, 131072) == 0          # dW of gate|up, T = 131 072: (K + 15) * 16 384 * 2 > 2^32
+    assert ok(2, 16384, 2048, 131072 - 64) == 1 and ok(2, 16384, 2048, 65536) == 1          # (131 023 rows of 32 KiB: 1.6 MB short of 2^32)
+    assert ok(1, 8192, 16384, 131072) == 0 and ok(1, 8192, 16384, 65536) == 1      # NN: B is the contraction-row operand
+    assert ok(1, 1 << 26, 2048, 4096) == 0          # NN's A is a row operand: 63 rows of 2^27 bytes
+    assert ok(0, 2048, 2048, 1 << 31) == 0          # NT: the contraction itself runs along the row
+    assert ok(0, 0, 2048, 64) == 0
