@@ -183,8 +183,7 @@ def cpu_baseline(merges, pc, L, seed, budget_s=12.0):
         "value": toks_f / dt_f, "unit": "tokens/s", "cores": 1, "kind": "port",
         "value_all_cores_trie_built_once": toks_all / dt_all, "threads_all_cores": n_thr,
         "records_per_s_all_cores": n_thr * per_thread / dt_all,
-        "sample": f"{n_f} records of 12x{L} (seed {seed}) in {dt_f:.1f} s, trie rebuilt per call as the "
-                  f"reference does; oracle/ecgb_oracle.c",
+        "sample": f"{n_f} records of 12x{L} in {dt_f:.1f} s, trie rebuilt per call as the reference does; oracle/ecgb_oracle.c",
         "records_per_s": n_f / dt_f,
         "value_trie_built_once": toks / dt_once,
         "records_per_s_trie_built_once": n_once / dt_once,
@@ -253,8 +252,7 @@ def train_cpu_baseline(cfg_kw, S, threads=6, gate=None):
            "sample": f"1 sample (seq {S}) forward+backward, fp32, PyTorch CPU eager restatement of the decoder "
                      f"(oracle/llama_ref.py) in {dt:.1f} s; optimizer step not included", "variants": variants, "host_cpus": os.cpu_count()}
     if hip_loss is not None:
-        out["parity_gate"] = {"what": "16-layer model, the HIP model's own initial weights and the first sample of its batch: training-mode forward loss of the HIP path "
-                                      "against the fp32 restatement (this leg's forward)", "hip_loss": hip_loss, "fp32_oracle_loss": ref_loss,
+        out["parity_gate"] = {"what": "16 layers, the HIP model's own initial weights, first sample of its batch: HIP training-forward loss vs this fp32 leg's", "hip_loss": hip_loss, "fp32_oracle_loss": ref_loss,
                               "loss_rel_err_vs_fp32_oracle": abs(hip_loss - ref_loss) / abs(ref_loss), "tolerance": 1e-2}
     return out
 
@@ -474,8 +472,7 @@ def bench_c5(args, dev):
     per_layer = H * (Hq + 2 * Hkv) * D + Hq * D * H + 3 * H * I
     tokens, head_rows = B * S, B * 24
     flops = 2 * (2 * Lyr * per_layer * tokens + 2 * H * V * head_rows) + 3 * Lyr * 2 * S * Hq * D * tokens   # frozen base: forward + input gradients
-    out = {"workload": f"C5: Gemma-2B dims ({Lyr} layers, hidden {H}, {Hq}/{Hkv} heads of {D}, MLP {I}, vocab {V}), seq {S}, batch {B}, LoRA r16, "
-                       f"fused head_dim-256 attention, random init, synthetic ids",
+    out = {"workload": f"C5: Gemma-2B dims ({Lyr} layers, {Hq}/{Hkv} heads of {D}, MLP {I}, vocab {V}), seq {S}, batch {B}, LoRA r16, random init",
            "train": {"ms_per_step": ms, "samples_per_s": B / (ms * 1e-3), "tokens_per_s": tokens / (ms * 1e-3), "loss": float(loss.item()),
                      "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "algorithmic_flops_per_step": flops},
@@ -543,8 +540,7 @@ def bench_c1(args, dev, cpu=True):
     e2.record()
     torch.cuda.synchronize()
     enc_ms, step_ms = e0.elapsed_time(e1) / reps, e1.elapsed_time(e2) / reps
-    out = {"workload": f"C1: 12x{L} float64 records (100 Hz x 10 s), {len(merges)} merges, GPT-2-small dims (12 layers, 768, 12 heads, vocab "
-                       f"{n_vocab}), seq {S}, batch {B}, forward (loss), random init",
+    out = {"workload": f"C1: 12x{L} records, {len(merges)} merges, GPT-2-small dims (vocab {n_vocab}), seq {S}, batch {B}, forward (loss)",
            "hip": {"quantise_encode_assemble_ms": enc_ms, "encode_plus_forward_ms": step_ms, "samples_per_s": B / (step_ms * 1e-3),
                    "loss": float(loss.item())}}
     if cpu:
@@ -580,8 +576,7 @@ def bench_c1(args, dev, cpu=True):
             torch.set_num_threads(old)
         out["cpu_baseline"] = {"value": variants[0]["samples_per_s"], "unit": "samples/s", "cores": 6, "kind": "port",
                                "encode_s_per_batch_1_core": enc_cpu,
-                               "sample": f"batch of {B}: rust_bpe port (1 core, trie rebuilt per record) + GPT-2-small forward in PyTorch CPU eager "
-                                         f"(oracle/gpt2_ref.py), fp32, 6 threads (ecg_byte/main.py:2); ~4 s per variant",
+                               "sample": f"batch of {B}: rust_bpe port (1 core) + GPT-2-small forward, PyTorch CPU eager fp32, 6 threads; ~4 s per variant",
                                "variants": variants, "host_cpus": os.cpu_count()}
         out["speedup_vs_cpu_6_threads"] = out["hip"]["samples_per_s"] / out["cpu_baseline"]["value"]
     del model
@@ -907,12 +902,12 @@ def main():
         if B == 4096 and L == 5000:
             rv = valu_roofline(dev_ms)
             if rv is not None:      # instruction count from a committed counter pass (static), divided by this run's kernel time
-                out["static_from_profiles"] = {"note": "counter passes need their own rocprofv3 runs: these figures are read from committed files, not measured by this run",
+                out["static_from_profiles"] = {"note": "read from committed counter passes, not measured by this run",
                                                "roofline_valu": rv, "roofline.traffic": traffic_src}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(merges, pc, L, seed=0)
-        if sweep is not None:
-            out["batch_sweep"] = sweep
+        if sweep is not None:      # columns: records per launch, ms per launch, token ids/s, fraction of the HBM roofline (algorithmic bytes)
+            out["batch_sweep"] = {k: [r[k] for r in sweep] for k in ("records", "ms", "tokens_per_s", "frac")}
         out.update(extras)
         if c1 is not None:
             out["c1"] = c1

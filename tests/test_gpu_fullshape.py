@@ -301,25 +301,42 @@ def test_llama_1b_dims_two_layers_vs_fp32_oracle(llama_1b_reference, fused_atten
 def test_llama_1b_all_sixteen_layers_vs_fp32_oracle():
     """The C3 model at its FULL depth ("at full size, loss of HIP path vs PyTorch-eager restatement on the same box within 1e-2 rel"): 16 layers at
     Llama-3.2-1B dims, S 1024, B 2 (one row left-padded), loss and every parameter gradient against the fp32 restatement run on this GPU with the same
-    bf16-representable weights -- sixteen layers of bf16 rounding compound, the two-layer gate above cannot see that (modeling_llama.py:859-979, loss_utils.py:32-47)."""
+    bf16-representable weights -- sixteen layers of bf16 rounding compound, the two-layer gate above cannot see that (modeling_llama.py:859-979, loss_utils.py:32-47).
+    Tolerances: loss 1e-2 relative (the survey's).  Gradients: 3e-2 in relative Frobenius norm as at two layers, or -- for the parameters sixteen bf16 layers away from
+    the loss, where rounding alone exceeds that -- 1.25 x the error of the SAME restatement run in bf16 by PyTorch eager (what the reference itself runs, main.py:142)."""
     from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
     from oracle import llama_ref as R
     cfgd = dict(LLAMA_1B, num_hidden_layers=16)
     inv = R.llama3_inv_freq(64, 500000.0, LLAMA3_SCALING).cuda()
     batch = _batch(2, 1024, cfgd["vocab_size"], cfgd["vocab_size"] - 1, seed=11, pads=[0, 411])
     params, ref_loss, grads = _oracle_grads(cfgd, inv, batch, seed=9)
+    # the bf16 eager run of the same restatement: its distance from fp32 is what bf16 arithmetic costs at this depth
+    ids, mask, labels, pos = batch
+    bf_p = {k: v.to(torch.bfloat16).requires_grad_(True) for k, v in params.items()}
+    bf_loss = R.llama_loss(bf_p, cfgd, ids, mask, labels, pos, inv)
+    bf_loss.backward()
+    eager_err = {k: ((bf_p[k].grad.float() - g).norm() / g.norm().clamp_min(1e-20)).item() for k, g in grads.items()}
+    del bf_p
     torch.cuda.empty_cache()
     cfg = DecoderConfig(**cfgd, rope_theta=500000.0, rope_scaling=dict(LLAMA3_SCALING), pad_token_id=cfgd["vocab_size"] - 1)
     m = HipCausalLM(cfg)
     m.load_state_dict(params)
     del params
-    ids, mask, labels, pos = batch
     out = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos)
     out.loss.backward()
     rel = abs(out.loss.item() - ref_loss) / ref_loss
     assert rel <= 1e-2, (out.loss.item(), ref_loss, rel)
-    worst = _compare_all_grads(m, cfgd, grads)
-    assert max(worst.values()) < 3e-2
+    worst = _compare_all_grads(m, cfgd, grads, tol=1.0)               # (collect every error first; judged below)
+    hf = {"embed": "model.embed_tokens.weight", "norm": "model.norm.weight"}
+    suffix = {"q": "self_attn.q_proj.weight", "k": "self_attn.k_proj.weight", "v": "self_attn.v_proj.weight", "o": "self_attn.o_proj.weight", "gate": "mlp.gate_proj.weight",
+              "up": "mlp.up_proj.weight", "down": "mlp.down_proj.weight", "ln1": "input_layernorm.weight", "ln2": "post_attention_layernorm.weight"}
+    bad = {}
+    for name, e in worst.items():
+        key = hf.get(name) or name[: name.rindex(".") + 1] + suffix[name[name.rindex(".") + 1:]]
+        allowed = max(3e-2, 1.25 * eager_err[key])
+        if not e < allowed:
+            bad[name] = (e, eager_err[key])
+    assert not bad, bad
     with torch.no_grad():                                             # the forward-only path (validation loss) at full depth
         ev = m(input_ids=ids, attention_mask=mask, labels=labels, position_ids=pos).loss.item()
     assert abs(ev - ref_loss) <= 1e-2 * ref_loss, (ev, ref_loss)
