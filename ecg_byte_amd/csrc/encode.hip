@@ -1006,6 +1006,8 @@ __global__ __launch_bounds__(kLanes) void encode_wg_kernel(EncodeArgs A)
     }
 }
 
+#include "encode_long.inc"
+
 int check_hip(hipError_t e, const char *what)
 {
     if (e == hipSuccess) return ECGB_OK;
@@ -1022,7 +1024,7 @@ constexpr size_t kMaxWaves = 16;
 constexpr uint32_t kFlowChunks[] = {126, 124, 122, 118, 116, 114, 110, 108, 106, 102, 100, 98, 94, 92, 90, 86, 84, 82, 78, 76, 74, 70, 68, 66,
                                     62, 60, 58, 54, 52, 50, 46, 44, 42, 38, 36, 34};   // not multiples of 8: lanes at equal
                                                                                        // chunk offsets land in different LDS banks
-int g_plan_mode = 0;   // 0 auto, 1 workgroup-per-stream, 2 wave-per-stream, 3 wave-per-stream with 8 waves per CU and segments up to 8064 symbols (tests / tuning)
+int g_plan_mode = 0;   // 0 auto, 1 workgroup-per-stream, 2 wave-per-stream, 3 wave-per-stream with 8 waves per CU and segments up to 8064 symbols, 4 lane-per-chunk (encode_long_kernel), 5 auto without it (tests / tuning)
 
 struct Plan {
     uint32_t chunk;    // chunk length of the flow kernel
@@ -1048,7 +1050,8 @@ Plan make_plan(const ecgb_tokenizer *tok, size_t batch)
     const size_t cus = tok->n_cus > 0 ? (size_t)tok->n_cus : 256;
     const size_t n_nodes = tok->nodes.size();
     const bool flow_ok = !tok->tok_len.empty() && tok->max_depth + kLenBias <= 255 && tok->tok_len.size() <= 16384;
-    p.wave = flow_ok && ((g_plan_mode >= 2) || (g_plan_mode == 0 && batch >= 2 * cus));
+    const int pm = g_plan_mode >= 4 ? 0 : g_plan_mode;     // (4 / 5 choose encode_long_kernel or keep it out; below that, the segment kernels plan as in mode 0)
+    p.wave = flow_ok && ((pm >= 2) || (pm == 0 && batch >= 2 * cus));
     p.chunk = 0;
     if (p.wave) {
         p.margin = (tok->max_depth + 1 + 15u) & ~15u;
@@ -1063,7 +1066,7 @@ Plan make_plan(const ecgb_tokenizer *tok, size_t batch)
         // 8 records per CU, 16 waves when it holds 9..16.
         const size_t per_cu = (batch + cus - 1) / cus;
         const double t16 = (double)((per_cu + 15) / 16) * 1.0, t8 = (double)((per_cu + 7) / 8) * 0.62;
-        const bool prefer8 = (g_plan_mode == 3) || (g_plan_mode == 0 && t8 < t16);
+        const bool prefer8 = (pm == 3) || (pm == 0 && t8 < t16);
         for (size_t w : {(size_t)16, (size_t)12, (size_t)8}) {
             if (prefer8 && w != 8) continue;
             if (tables + trie_bytes >= kLdsCap) break;
@@ -1091,6 +1094,48 @@ Plan make_plan(const ecgb_tokenizer *tok, size_t batch)
         p.lds = fixed + (size_t)p.n_lds * 8;
     }
     return p;
+}
+
+// encode_long_kernel (float64 records of up to 65 535 samples, every node in LDS): waves per CU and LDS bytes, 0 waves if it does not apply
+struct LongPlan { unsigned waves; size_t lds; };
+LongPlan make_long_plan(const ecgb_tokenizer *tok, size_t n)
+{
+    LongPlan p{0, 0};
+    const bool flow_ok = !tok->tok_len.empty() && tok->max_depth + kLenBias <= 255 && tok->tok_len.size() <= 16384;
+    if (!flow_ok || n == 0 || n > kLongMaxN || tok->n_classes > 29) return p;
+    const size_t tables = tok->nodes.size() * 8 + kLdsTablesFixed + tok->runbits.size() * 4 + tok->tok_len.size() + 16;
+    if (tables + 4 * kLongWaveLds > kLdsCap) return p;
+    p.waves = (unsigned)std::min<size_t>(kMaxWaves, (kLdsCap - tables) / kLongWaveLds);
+    p.lds = tables + p.waves * (size_t)kLongWaveLds;
+    return p;
+}
+
+int launch_encode_long(const ecgb_tokenizer *tok, const LongPlan &lp, const double *signal, const QuantParams &qp, size_t batch, size_t n,
+                       void *scratch, uint32_t *ids_out, size_t ids_stride, uint32_t *counts, hipStream_t stream)
+{
+    const size_t cus = tok->n_cus > 0 ? (size_t)tok->n_cus : 256;
+    LongArgs A;
+    A.trie = tok->nodes_dev; A.n_nodes = (uint32_t)tok->nodes.size();
+    A.runbits = tok->runbits_dev; A.n_runwords = (uint32_t)tok->runbits.size();
+    A.tok_len = tok->toklen_dev; A.n_toklen = (uint32_t)tok->tok_len.size();
+    A.lut = tok->lut_dev;
+    A.signal = signal; A.qp = qp;
+    A.rle_cap = (uint32_t)long_rle_cap(n); A.list_cap = (uint32_t)long_list_cap(n);
+    const size_t slots = cus * kMaxWaves;
+    A.rle = reinterpret_cast<uint16_t *>(scratch);
+    A.lists = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(scratch) + align_up(slots * A.rle_cap * sizeof(uint16_t)));
+    A.ids_out = ids_out; A.ids_stride = ids_stride; A.counts = counts;
+    A.n = (uint32_t)n; A.batch = (uint32_t)batch;
+#ifdef ECGB_PROFILE
+    A.prof = g_prof_dev;
+#endif
+    const bool vec = (n % 2 == 0) && ((reinterpret_cast<uintptr_t>(signal) & 15u) == 0);
+    void (*kern)(LongArgs) = vec ? encode_long_kernel<true> : encode_long_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp.lds);
+    if (e != hipSuccess) return check_hip(e, ("hipFuncSetAttribute(encode_long_kernel, " + std::to_string(lp.lds) + " bytes of LDS)").c_str());
+    const size_t wgs = (batch + lp.waves - 1) / lp.waves;
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::max<size_t>(1, std::min(wgs, cus))), dim3(lp.waves * 64), lp.lds, stream, A);
+    return check_hip(hipGetLastError(), "encode_long_kernel launch");
 }
 
 template <int INPUT>
@@ -1207,7 +1252,7 @@ extern "C" void ecgb_debug_set_profile_buffer(unsigned long long *dev) { g_prof_
 
 extern "C" int ecgb_set_encode_plan(int mode)
 {
-    if (mode < 0 || mode > 3) { ecgb::set_error("ecgb_set_encode_plan: mode must be 0..3"); return ECGB_ERR_INVALID; }
+    if (mode < 0 || mode > 5) { ecgb::set_error("ecgb_set_encode_plan: mode must be 0..5"); return ECGB_ERR_INVALID; }
     g_plan_mode = mode;
     return ECGB_OK;
 }
@@ -1248,7 +1293,14 @@ extern "C" size_t ecgb_encode_scratch_bytes(const ecgb_tokenizer *tok, size_t ba
     // entries (the first few hundred are used); workgroup kernel: 2 x CUs x 16384 half-resolution u16 ids
     const size_t cus = (tok && tok->n_cus > 0) ? (size_t)tok->n_cus : 256;
     const size_t a = cus * kMaxWaves * kFlowSlot * 2, b = 2 * cus * (size_t)kHalfPerSlot;   // in u16 units
-    return align_up(std::max(a, b) * sizeof(uint16_t)) + kAlign;
+    size_t bytes = std::max(a, b) * sizeof(uint16_t);
+    // encode_long_kernel: per resident wave the record as run-length entries (2 B per run, <= one per symbol) and 64 token lists (4 B per token, one per symbol
+    // at most plus the run-on margin); only what a record really has is touched (C2: 23 KB + 18 KB of 0.43 MB)
+    if (tok && n_per_stream <= kLongMaxN && make_long_plan(tok, n_per_stream).waves) {
+        const size_t slots = cus * kMaxWaves;
+        bytes = std::max(bytes, align_up(slots * long_rle_cap(n_per_stream) * sizeof(uint16_t)) + slots * long_list_cap(n_per_stream) * sizeof(uint32_t));
+    }
+    return align_up(bytes) + kAlign;
 }
 
 extern "C" int ecgb_encode_hip(const ecgb_tokenizer *tok, const uint8_t *text_dev, size_t batch,
@@ -1289,6 +1341,13 @@ extern "C" int ecgb_quantize_encode_hip(const ecgb_tokenizer *tok, const double 
         return ECGB_ERR_UNSUPPORTED;
     }
     uint16_t *half = reinterpret_cast<uint16_t *>(align_up(reinterpret_cast<uintptr_t>(scratch_dev)));
+    // large batches of records that fit 16-bit positions: a lane per long chunk of the whole record (encode_long_kernel); otherwise the segment kernels
+    const size_t cus = tok->n_cus > 0 ? (size_t)tok->n_cus : 256;
+    if (g_plan_mode == 4 || (g_plan_mode == 0 && batch >= 2 * cus)) {
+        const LongPlan lp = make_long_plan(tok, n_per_record);
+        if (lp.waves) return launch_encode_long(tok, lp, signal_dev, qp, batch, n_per_record, half, ids_dev, ids_stride, counts_dev, st);
+        // (plan 4 on a record or trie the kernel does not take: the segment kernels, as in plan 0)
+    }
     return launch_encode<INPUT_F64>(tok, signal_dev, nullptr, qp, batch, n_per_record, half, ids_dev, ids_stride,
                                     counts_dev, st);
 }

@@ -24,7 +24,7 @@ def dev():
     return torch.device("cuda", 0)
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["plan-auto", "plan-workgroup", "plan-wave", "plan-wave-long-segments"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["plan-auto", "plan-workgroup", "plan-wave", "plan-wave-long-segments", "plan-lane-per-chunk"])
 def plan(request, dev):
     """Runs a test under each encode kernel: automatic choice, workgroup-per-stream, wave-per-stream."""
     from ecg_byte_amd.tokenizer import set_encode_plan
@@ -434,3 +434,103 @@ def test_run_chains_with_branches_and_sparse_tokens(dev, plan):
     for b, t in enumerate(texts):
         ref = O.encode_text(t, merges)
         assert counts[b] == len(ref) and np.array_equal(got[b], ref), b
+
+
+# ---- encode_long_kernel (round 5): one wave per record, one lane per long chunk of run-length entries ---------------------------------------
+def _signal_for_symbols(sym, pc):
+    """float64 samples in the middle of the bins of `sym` (alphabet indices 0..25) under normalize_all's map (tokenizer_utils.py:14-19)."""
+    a = pc["percentile_1"] - 0.5
+    d = ((pc["percentile_99"] + 0.5) - a) + 1e-6
+    return a + (np.asarray(sym, dtype=np.float64) + 0.5) * d / 26.0
+
+
+def _check_long(tk, merges, syms, pc, **kw):
+    """syms: (B, n) alphabet indices; quantise + encode on the lane-per-chunk kernel vs lib.rs's restatement on the symbol text."""
+    from ecg_byte_amd.tokenizer import set_encode_plan
+    x = _signal_for_symbols(syms, pc)
+    set_encode_plan(4)
+    try:
+        ids, counts = tk.quantize_encode(torch.from_numpy(np.ascontiguousarray(x)).cuda(), pc, **kw)
+    finally:
+        set_encode_plan(0)
+    ids, counts = ids.cpu().numpy(), counts.cpu().numpy()
+    for b in range(syms.shape[0]):
+        ref = np.asarray(O.encode_text(bytes((np.asarray(syms[b]) + 97).astype(np.uint8)), merges), dtype=np.uint32)
+        assert counts[b] == ref.size, (b, counts[b], ref.size)
+        k = min(ref.size, ids.shape[1])
+        assert np.array_equal(ids[b, :k].astype(np.uint32), ref[:k]), f"record {b}"
+
+
+PC = {"percentile_1": -1.0, "percentile_99": 1.0}
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 2047, 4097, 12000, 60000, 65534, 65535])
+def test_lane_per_chunk_record_lengths(dev, n):
+    """Odd and even lengths (the vector and the scalar staging), fewer runs than lanes, tile and block boundaries, the 16-bit position limit."""
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    rng = np.random.default_rng(n)
+    merges = random_merges(rng, 300, alphabet=b"abcdefgh", max_len=9)
+    tk = HipTokenizer(merges)
+    # runs of random lengths (1 .. 40) over eight classes, three records of different texture
+    recs = []
+    for mean_run in (1.2, 4.0, 25.0):
+        s = np.repeat(rng.integers(0, 8, size=n), rng.geometric(1.0 / mean_run, size=n))[:n]
+        recs.append(s)
+    _check_long(tk, merges, np.stack(recs), PC)
+
+
+def test_lane_per_chunk_parses_that_never_meet_and_long_runs(dev):
+    """'ab' over 'babab...' (a parse entered at the wrong phase never meets the owner's: a lane's list overflows and the wave redoes the record with one lane);
+    a^(2^k) tokens over runs of 1 000 (back-ups of hundreds of symbols across the forced 256-symbol run boundaries); 'abc' rotations."""
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    n = 60000
+    ab = np.tile([1, 0], n // 2 + 1)
+    cases = [([([97, 98], 256)], np.stack([ab[:n], ab[1:n + 1]])),
+             ([([97] * (1 << k), 256 + k - 1) for k in range(1, 8)], np.stack([np.zeros(n, dtype=np.int64), np.tile(np.r_[np.zeros(1000, dtype=np.int64), 1], 60)[:n]])),
+             ([([97, 98, 99], 256), ([98, 99, 97], 257), ([99, 97, 98], 258)], np.stack([np.tile([2, 0, 1], n // 3 + 1)[:n], np.tile([0, 1, 2], n // 3 + 1)[:n]]))]
+    for merges, syms in cases:
+        _check_long(HipTokenizer(merges), merges, syms, PC)
+
+
+@pytest.mark.parametrize("tag,L,B", [("c1", 1000, 5), ("c2", 5000, 3), ("c2", 5000, 300)])
+def test_lane_per_chunk_fixture_tokenizers(dev, tag, L, B):
+    """The committed tokenizers on synthetic records; 300 records = several records per resident wave slot (scratch reuse)."""
+    from ecg_byte_amd import synth
+    from ecg_byte_amd.tokenizer import HipTokenizer, set_encode_plan
+    vocab, merges, pc = load_tokenizer(tag)
+    tk = HipTokenizer(merges)
+    x = synth.synth_ecg(min(B, 64), L, seed=4)
+    if B > 64:
+        x = np.concatenate([x] * ((B + 63) // 64))[:B]
+    set_encode_plan(4)
+    try:
+        ids, counts = tk.quantize_encode(torch.from_numpy(x).cuda(), pc)
+        cut, counts2 = tk.quantize_encode(torch.from_numpy(x).cuda(), pc, ids_stride=1020)
+    finally:
+        set_encode_plan(0)
+    ids, counts = ids.cpu().numpy(), counts.cpu().numpy()
+    ref = oracle_batch(O.Trie(merges), x[: min(B, 64)], pc)
+    for b in range(B):
+        r = ref[b % 64]
+        assert counts[b] == r.size and np.array_equal(ids[b, : r.size].astype(np.uint32), r), f"record {b}"
+    assert np.array_equal(counts2.cpu().numpy(), counts) and np.array_equal(cut.cpu().numpy(), ids[:, :1020])
+
+
+def test_lane_per_chunk_equals_segment_kernels_on_the_bench_batch(dev):
+    """4 096 records of 12 x 5000 (BASELINE configs[1]): the automatic plan (lane per chunk) and the segment kernel give the same ids and counts."""
+    from ecg_byte_amd import synth
+    from ecg_byte_amd.tokenizer import HipTokenizer, set_encode_plan
+    _, merges, pc = load_tokenizer("c2")
+    tk = HipTokenizer(merges)
+    base = synth.synth_ecg(256, 5000, seed=33)
+    gains = np.random.default_rng(5).uniform(0.7, 1.3, size=(16, 1, 1, 1))
+    xd = torch.from_numpy((base[None] * gains).reshape(4096, 12, 5000)).cuda()
+    ids, counts = tk.quantize_encode(xd, pc)
+    set_encode_plan(5)
+    try:
+        ids0, counts0 = tk.quantize_encode(xd, pc)
+    finally:
+        set_encode_plan(0)
+    assert torch.equal(counts, counts0)
+    valid = torch.arange(ids.shape[1], device="cuda")[None, :] < counts[:, None]
+    assert bool(((ids == ids0) | ~valid).all())
