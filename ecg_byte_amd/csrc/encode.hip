@@ -1024,7 +1024,7 @@ constexpr size_t kMaxWaves = 16;
 constexpr uint32_t kFlowChunks[] = {126, 124, 122, 118, 116, 114, 110, 108, 106, 102, 100, 98, 94, 92, 90, 86, 84, 82, 78, 76, 74, 70, 68, 66,
                                     62, 60, 58, 54, 52, 50, 46, 44, 42, 38, 36, 34};   // not multiples of 8: lanes at equal
                                                                                        // chunk offsets land in different LDS banks
-int g_plan_mode = 0;   // 0 auto, 1 workgroup-per-stream, 2 wave-per-stream, 3 wave-per-stream with 8 waves per CU and segments up to 8064 symbols, 4 lane-per-chunk (encode_long_kernel), 5 auto without it (tests / tuning)
+int g_plan_mode = 0;   // 0 auto, 1 workgroup-per-stream, 2 wave-per-stream, 3 wave-per-stream with 8 waves per CU and segments up to 8064 symbols, 4 lane-per-chunk (encode_long_kernel; opt-in: measured slower), 5 = 0 (tests / tuning)
 
 struct Plan {
     uint32_t chunk;    // chunk length of the flow kernel
@@ -1296,7 +1296,7 @@ extern "C" size_t ecgb_encode_scratch_bytes(const ecgb_tokenizer *tok, size_t ba
     size_t bytes = std::max(a, b) * sizeof(uint16_t);
     // encode_long_kernel: per resident wave the record as run-length entries (2 B per run, <= one per symbol) and 64 token lists (4 B per token, one per symbol
     // at most plus the run-on margin); only what a record really has is touched (C2: 23 KB + 18 KB of 0.43 MB)
-    if (tok && n_per_stream <= kLongMaxN && make_long_plan(tok, n_per_stream).waves) {
+    if (tok && g_plan_mode == 4 && n_per_stream <= kLongMaxN && make_long_plan(tok, n_per_stream).waves) {
         const size_t slots = cus * kMaxWaves;
         bytes = std::max(bytes, align_up(slots * long_rle_cap(n_per_stream) * sizeof(uint16_t)) + slots * long_list_cap(n_per_stream) * sizeof(uint32_t));
     }
@@ -1341,9 +1341,9 @@ extern "C" int ecgb_quantize_encode_hip(const ecgb_tokenizer *tok, const double 
         return ECGB_ERR_UNSUPPORTED;
     }
     uint16_t *half = reinterpret_cast<uint16_t *>(align_up(reinterpret_cast<uintptr_t>(scratch_dev)));
-    // large batches of records that fit 16-bit positions: a lane per long chunk of the whole record (encode_long_kernel); otherwise the segment kernels
-    const size_t cus = tok->n_cus > 0 ? (size_t)tok->n_cus : 256;
-    if (g_plan_mode == 4 || (g_plan_mode == 0 && batch >= 2 * cus)) {
+    // records that fit 16-bit positions, on request: a lane per long chunk of the whole record (encode_long_kernel); otherwise the segment kernels
+    // (plan 4 only: measured slower than the segment kernels at every batch size -- encode_long.inc has the numbers -- so the automatic plan does not take it)
+    if (g_plan_mode == 4) {
         const LongPlan lp = make_long_plan(tok, n_per_record);
         if (lp.waves) return launch_encode_long(tok, lp, signal_dev, qp, batch, n_per_record, half, ids_dev, ids_stride, counts_dev, st);
         // (plan 4 on a record or trie the kernel does not take: the segment kernels, as in plan 0)

@@ -110,8 +110,10 @@ int ecgb_encode_hip(const ecgb_tokenizer *tok, const uint8_t *text_dev, size_t b
 /* Which of the two encode kernels a call uses: 0 = automatic (wave-per-stream for batches of at
  * least 2 x CUs, workgroup-per-stream below), 1 = always workgroup-per-stream, 2 = always
  * wave-per-stream (falls back to workgroup-per-stream for tokenizers with an expansion longer than
- * 225 bytes), 3 = wave-per-stream with 8 waves per CU and segments of up to 8064 symbols.  All produce identical
- * output; the switch exists for tests and tuning.
+ * 225 bytes), 3 = wave-per-stream with 8 waves per CU and segments of up to 8064 symbols, 4 = (ecgb_quantize_encode_hip, records
+ * of <= 65 535 samples, trie in LDS; the others as 0) one wave per record with one lane per long chunk of run-length entries
+ * (encode_long_kernel: 2.6 x fewer loop trips, measured slower end to end -- opt-in; ecgb_encode_scratch_bytes() asks for its larger
+ * scratch only while this mode is set), 5 = 0.  All produce identical output; the switch exists for tests and tuning.
  * Process-wide, not thread-safe against concurrent encode calls. */
 int ecgb_set_encode_plan(int mode);
 

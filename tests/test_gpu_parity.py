@@ -517,7 +517,7 @@ def test_lane_per_chunk_fixture_tokenizers(dev, tag, L, B):
 
 
 def test_lane_per_chunk_equals_segment_kernels_on_the_bench_batch(dev):
-    """4 096 records of 12 x 5000 (BASELINE configs[1]): the automatic plan (lane per chunk) and the segment kernel give the same ids and counts."""
+    """4 096 records of 12 x 5000 (BASELINE configs[1]): the lane-per-chunk kernel (plan 4) and the segment kernel of the automatic plan give the same ids and counts."""
     from ecg_byte_amd import synth
     from ecg_byte_amd.tokenizer import HipTokenizer, set_encode_plan
     _, merges, pc = load_tokenizer("c2")
@@ -525,10 +525,10 @@ def test_lane_per_chunk_equals_segment_kernels_on_the_bench_batch(dev):
     base = synth.synth_ecg(256, 5000, seed=33)
     gains = np.random.default_rng(5).uniform(0.7, 1.3, size=(16, 1, 1, 1))
     xd = torch.from_numpy((base[None] * gains).reshape(4096, 12, 5000)).cuda()
-    ids, counts = tk.quantize_encode(xd, pc)
-    set_encode_plan(5)
+    ids0, counts0 = tk.quantize_encode(xd, pc)
+    set_encode_plan(4)
     try:
-        ids0, counts0 = tk.quantize_encode(xd, pc)
+        ids, counts = tk.quantize_encode(xd, pc)
     finally:
         set_encode_plan(0)
     assert torch.equal(counts, counts0)
