@@ -1008,6 +1008,58 @@ __global__ __launch_bounds__(kLanes) void encode_wg_kernel(EncodeArgs A)
 
 #include "encode_long.inc"
 
+// ==========================================================================================
+// Kernel 4 (the GENERAL form of a tokenizer: more than 29 byte values in the merges, 65 535 or more trie nodes, token ids >= 65 535 -- what the packed
+// 8-byte node cannot hold): lib.rs:149-193 as it is written, ONE LANE = ONE STREAM, the trie's edges in an open-addressing table in global memory
+// (key (node << 8 | byte) + 1, tokenizer.cpp build_general), 32-bit ids.  Slow (a dependent L2 read per symbol and lane) and total: it exists so that
+// `encode_text` has no merges list it refuses, not to be fast -- the a..z streams of the hot path never come here.
+struct GeneralArgs {
+    const uint64_t *keys;
+    const uint32_t *child, *token;
+    uint32_t cap_mask;
+    const uint8_t *text;      // batch x n bytes (or alphabet indices, see `add`)
+    uint32_t add;             // added to every input byte: 97 when the input is the quantiser's alphabet indices
+    uint32_t *ids_out;
+    size_t ids_stride;
+    uint32_t *counts;
+    uint32_t n, batch;
+};
+
+__device__ __forceinline__ uint64_t mix64_dev(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+
+__global__ __launch_bounds__(64) void encode_general_kernel(GeneralArgs A)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= A.batch) return;
+    const uint8_t *text = A.text + (size_t)b * A.n;
+    uint32_t *out = A.ids_out + (size_t)b * A.ids_stride;
+    uint32_t i = 0, cnt = 0;
+    while (i < A.n) {
+        uint32_t node = 0, j = i, best = ecgb::kNoToken32, blen = 0;
+        while (j < A.n) {                                                   // lib.rs:170-181: walk while a child exists, remember the deepest token
+            const uint64_t key = (((uint64_t)node << 8) | ((text[j] + A.add) & 0xFFu)) + 1;
+            uint32_t h = (uint32_t)mix64_dev(key) & A.cap_mask;
+            uint64_t k = A.keys[h];
+            while (k != 0 && k != key) { h = (h + 1) & A.cap_mask; k = A.keys[h]; }
+            if (k == 0) break;
+            node = A.child[h];
+            ++j;
+            const uint32_t t = A.token[node];
+            if (t != ecgb::kNoToken32) { best = t; blen = j - i; }
+        }
+        uint32_t id = best;
+        if (best == ecgb::kNoToken32) { id = (text[i] + A.add) & 0xFFu; blen = 1; }   // lib.rs:186-189 (dead for byte input: every byte is a token)
+        if (cnt < A.ids_stride) out[cnt] = id;
+        ++cnt;
+        i += blen;
+    }
+    A.counts[b] = cnt;
+}
+
 int check_hip(hipError_t e, const char *what)
 {
     if (e == hipSuccess) return ECGB_OK;
@@ -1222,6 +1274,17 @@ int launch_quantize(const double *x, size_t n, size_t rows, size_t sym_stride, d
     return check_hip(hipGetLastError(), "quantize kernel launch");
 }
 
+int launch_encode_general(const ecgb_tokenizer *tok, const uint8_t *text, uint32_t add, size_t batch, size_t n, uint32_t *ids_out, size_t ids_stride, uint32_t *counts, hipStream_t stream)
+{
+    GeneralArgs A;
+    A.keys = tok->g_keys_dev; A.child = tok->g_child_dev; A.token = tok->g_token_dev;
+    A.cap_mask = (uint32_t)(tok->g_keys.size() - 1);
+    A.text = text; A.add = add; A.ids_out = ids_out; A.ids_stride = ids_stride; A.counts = counts;
+    A.n = (uint32_t)n; A.batch = (uint32_t)batch;
+    hipLaunchKernelGGL(encode_general_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, stream, A);
+    return check_hip(hipGetLastError(), "encode_general_kernel launch");
+}
+
 int check_common(const ecgb_tokenizer *tok, size_t batch, size_t n, const void *ids, size_t ids_stride,
                  const void *counts, const void *scratch, size_t scratch_bytes, const char *who)
 {
@@ -1229,7 +1292,7 @@ int check_common(const ecgb_tokenizer *tok, size_t batch, size_t n, const void *
         ecgb::set_error(std::string(who) + ": NULL or zero-sized argument");
         return ECGB_ERR_INVALID;
     }
-    if (!tok->nodes_dev) {
+    if (tok->general ? !tok->g_keys_dev : !tok->nodes_dev) {
         ecgb::set_error(std::string(who) + ": tokenizer handle has no device copy (no GPU at creation)");
         return ECGB_ERR_NODEVICE;
     }
@@ -1291,6 +1354,7 @@ extern "C" size_t ecgb_encode_scratch_bytes(const ecgb_tokenizer *tok, size_t ba
 {
     // per resident stream slot (reused, L2-resident): flow kernel: CUs x 16 waves x a token list of up to 4096 4-byte
     // entries (the first few hundred are used); workgroup kernel: 2 x CUs x 16384 half-resolution u16 ids
+    if (tok && tok->general) return align_up(batch * n_per_stream) + kAlign;                  // the quantised symbols of ecgb_quantize_encode_hip; the walk itself needs none
     const size_t cus = (tok && tok->n_cus > 0) ? (size_t)tok->n_cus : 256;
     const size_t a = cus * kMaxWaves * kFlowSlot * 2, b = 2 * cus * (size_t)kHalfPerSlot;   // in u16 units
     size_t bytes = std::max(a, b) * sizeof(uint16_t);
@@ -1315,6 +1379,7 @@ extern "C" int ecgb_encode_hip(const ecgb_tokenizer *tok, const uint8_t *text_de
     hipStream_t st = (hipStream_t)stream;
     if (n_per_stream == 0) return check_hip(hipMemsetAsync(counts_dev, 0, batch * 4, st), "hipMemsetAsync");
     if (!text_dev) { ecgb::set_error("ecgb_encode_hip: NULL text"); return ECGB_ERR_INVALID; }
+    if (tok->general) return launch_encode_general(tok, text_dev, 0u, batch, n_per_stream, ids_dev, ids_stride, counts_dev, st);
     uint16_t *half = reinterpret_cast<uint16_t *>(align_up(reinterpret_cast<uintptr_t>(scratch_dev)));
     QuantParams qp;
     std::memset(&qp, 0, sizeof(qp));
@@ -1334,6 +1399,12 @@ extern "C" int ecgb_quantize_encode_hip(const ecgb_tokenizer *tok, const double 
     hipStream_t st = (hipStream_t)stream;
     if (n_per_record == 0) return check_hip(hipMemsetAsync(counts_dev, 0, batch * 4, st), "hipMemsetAsync");
     if (!signal_dev) { ecgb::set_error("ecgb_quantize_encode_hip: NULL signal"); return ECGB_ERR_INVALID; }
+    if (tok->general) {     // quantise into the scratch buffer (alphabet indices), then the general walk on index + 'a'
+        uint8_t *sym = reinterpret_cast<uint8_t *>(align_up(reinterpret_cast<uintptr_t>(scratch_dev)));
+        rc = ecgb_quantize_hip(signal_dev, batch * n_per_record, percentile_1, percentile_99, sym, nullptr, stream);
+        if (rc) return rc;
+        return launch_encode_general(tok, sym, 97u, batch, n_per_record, ids_dev, ids_stride, counts_dev, st);
+    }
     const QuantParams qp = make_quant_params(percentile_1, percentile_99);
     if (!qp.use_thresholds) {
         ecgb::set_error("ecgb_quantize_encode_hip: degenerate percentiles (percentile_99 + 1 + 1e-6 <= percentile_1 "

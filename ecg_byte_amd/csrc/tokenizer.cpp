@@ -44,6 +44,78 @@ struct BuildNode {
     BuildNode() { child.fill(-1); }
 };
 
+inline uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+
+// The general form: lib.rs:127-161 literally -- insert the 256 single bytes with id = byte, then every (expansion, id) in list order (a later duplicate
+// overwrites the token, lib.rs:145); an element above 255 is an edge no input byte follows, so only the prefix in front of it adds (token-less) nodes.
+void build_general(ecgb_tokenizer *tok, const uint32_t *flat_bytes, const uint32_t *offsets, const uint32_t *ids, size_t n_merges)
+{
+    size_t total = 256;
+    for (size_t i = 0; i < n_merges; ++i) total += offsets[i + 1] - offsets[i];
+    size_t cap = 1024;
+    while (cap < 2 * total + 2) cap <<= 1;
+    tok->g_keys.assign(cap, 0);
+    tok->g_child.assign(cap, 0);
+    tok->g_token.assign(1, ecgb::kNoToken32);      // node 0 = root
+    auto child = [&](uint32_t node, uint32_t byte, bool create) -> int64_t {
+        const uint64_t key = (((uint64_t)node << 8) | byte) + 1;
+        size_t h = (size_t)mix64(key) & (cap - 1);
+        while (tok->g_keys[h]) {
+            if (tok->g_keys[h] == key) return tok->g_child[h];
+            h = (h + 1) & (cap - 1);
+        }
+        if (!create) return -1;
+        tok->g_keys[h] = key;
+        tok->g_child[h] = (uint32_t)tok->g_token.size();
+        tok->g_token.push_back(ecgb::kNoToken32);
+        return tok->g_child[h];
+    };
+    uint32_t depth_max = 1;
+    auto insert = [&](const uint32_t *seq, size_t len, uint32_t id, bool with_token) {
+        uint32_t node = 0;
+        for (size_t k = 0; k < len; ++k) node = (uint32_t)child(node, seq[k], true);
+        if (with_token) tok->g_token[node] = id;
+        depth_max = std::max<uint32_t>(depth_max, (uint32_t)len);
+    };
+    for (uint32_t b = 0; b < 256; ++b) insert(&b, 1, b, true);
+    for (size_t i = 0; i < n_merges; ++i) {
+        const uint32_t *seq = flat_bytes + offsets[i];
+        const size_t len = offsets[i + 1] - offsets[i];
+        size_t reach = 0;
+        while (reach < len && seq[reach] <= 255u) ++reach;
+        insert(seq, reach, ids[i], reach == len);
+    }
+    tok->general = true;
+    tok->g_nodes = (uint32_t)tok->g_token.size();
+    tok->max_depth = depth_max;
+    tok->nodes.clear(); tok->runbits.clear(); tok->tok_len.clear();
+}
+
+// uploads the general form; the packed form's device pointers stay null except `lut_dev`/`nodes_dev` markers the entry points test
+int upload_general(ecgb_tokenizer *tok)
+{
+    int dev = -1, n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return ECGB_OK; }
+    tok->device = dev;
+    hipDeviceProp_t prop;
+    tok->n_cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    const size_t kb = tok->g_keys.size() * 8, cb = tok->g_child.size() * 4, tb = tok->g_token.size() * 4;
+    if (hipMalloc((void **)&tok->g_keys_dev, kb) != hipSuccess || hipMalloc((void **)&tok->g_child_dev, cb) != hipSuccess || hipMalloc((void **)&tok->g_token_dev, tb) != hipSuccess) {
+        ecgb::set_error("ecgb_tokenizer_create: hipMalloc failed (general trie)");
+        return ECGB_ERR_NOMEM;
+    }
+    if (hipMemcpy(tok->g_keys_dev, tok->g_keys.data(), kb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(tok->g_child_dev, tok->g_child.data(), cb, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(tok->g_token_dev, tok->g_token.data(), tb, hipMemcpyHostToDevice) != hipSuccess) {
+        ecgb::set_error("ecgb_tokenizer_create: hipMemcpy failed (general trie)");
+        return ECGB_ERR_HIP;
+    }
+    return ECGB_OK;
+}
+
 }  // namespace
 
 extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t *offsets,
@@ -76,10 +148,12 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
         }
         for (uint32_t b = 0; b < 256; ++b) {
             if (!used[b] || tok->byte_to_class[b] != kOtherClass) continue;
-            if (n_classes == kMaxClasses) {
-                delete tok;
-                set_error("ecgb_tokenizer_create: more than 29 distinct byte values (a..z plus 3) in the merges");
-                return ECGB_ERR_UNSUPPORTED;
+            if (n_classes == kMaxClasses) {      // more than 29 distinct byte values (a..z plus 3): the general form
+                build_general(tok, flat_bytes, offsets, ids, n_merges);
+                const int rc = upload_general(tok);
+                if (rc) { ecgb_tokenizer_destroy(tok); return rc; }
+                *out = tok;
+                return ECGB_OK;
             }
             tok->byte_to_class[b] = (uint8_t)n_classes;
             tok->class_to_byte[n_classes] = (uint8_t)b;
@@ -126,10 +200,14 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
             else walk_only(seq, reach);
         }
 
-        if (bn.size() >= 65535) {
-            delete tok;
-            set_error("ecgb_tokenizer_create: trie has >= 65535 nodes");
-            return ECGB_ERR_UNSUPPORTED;
+        bool wide_id = false;
+        for (size_t i = 0; i < n_merges; ++i) wide_id = wide_id || ids[i] >= kNoToken;
+        if (bn.size() >= 65535 || wide_id) {    // node numbers or token ids that do not fit the packed node's 16-bit fields: the general form
+            build_general(tok, flat_bytes, offsets, ids, n_merges);
+            const int rc = upload_general(tok);
+            if (rc) { ecgb_tokenizer_destroy(tok); return rc; }
+            *out = tok;
+            return ECGB_OK;
         }
         // ---- renumbering: breadth-first over blocks; a block = the branch children of a node in
         // class order, followed (for a chain head) by the whole same-class chain below it
@@ -183,7 +261,7 @@ extern "C" int ecgb_tokenizer_create(const uint32_t *flat_bytes, const uint32_t 
             }
             uint32_t token = kNoToken;
             if (i != 0 && n.token >= 0) {  // the root's own token is never consulted (lib.rs:170-181)
-                if (n.token >= (int64_t)kNoToken) {
+                if (n.token >= (int64_t)kNoToken) {      // (unreachable: wide ids took the general form above)
                     delete tok;
                     set_error("ecgb_tokenizer_create: token id >= 65535");
                     return ECGB_ERR_UNSUPPORTED;
@@ -270,6 +348,9 @@ extern "C" void ecgb_tokenizer_destroy(ecgb_tokenizer *tok)
     if (tok->runbits_dev) (void)hipFree(tok->runbits_dev);
     if (tok->toklen_dev) (void)hipFree(tok->toklen_dev);
     if (tok->lut_dev) (void)hipFree(tok->lut_dev);
+    if (tok->g_keys_dev) (void)hipFree(tok->g_keys_dev);
+    if (tok->g_child_dev) (void)hipFree(tok->g_child_dev);
+    if (tok->g_token_dev) (void)hipFree(tok->g_token_dev);
     delete tok;
 }
 
@@ -293,7 +374,7 @@ extern "C" int ecgb_tokenizer_info(const ecgb_tokenizer *tok, uint32_t *n_nodes,
                                    uint32_t *n_classes)
 {
     if (!tok) { ecgb::set_error("ecgb_tokenizer_info: NULL handle"); return ECGB_ERR_INVALID; }
-    if (n_nodes) *n_nodes = (uint32_t)tok->nodes.size();
+    if (n_nodes) *n_nodes = tok->general ? tok->g_nodes : (uint32_t)tok->nodes.size();
     if (max_depth) *max_depth = tok->max_depth;
     if (n_classes) *n_classes = tok->n_classes;
     return ECGB_OK;

@@ -12,6 +12,7 @@ constexpr uint32_t kMaxClasses = 29;      // usable symbol classes (bits 0..28 o
 constexpr uint32_t kOtherClass = 29;      // byte that occurs in no expansion and is not a..z; also the
                                           // end-of-stream sentinel: bit 29 is never set in any bitmap
 constexpr uint32_t kNoToken = 0xFFFFu;    // node carries no token id
+constexpr uint32_t kNoToken32 = 0xFFFFFFFFu;   // the same in the general form's 32-bit token array
 constexpr uint32_t kContFlag = 1u << 30;  // node has a child of the class it was entered by (its "continuation")
 constexpr uint32_t kHeadFlag = 1u << 31;  // node was entered by a different class than its parent was (or from the root)
 constexpr uint32_t kBranchMask = (1u << 30) - 1u;
@@ -52,6 +53,16 @@ struct ecgb_tokenizer {
     uint32_t n_classes = 0;
     uint32_t max_depth = 0;
     uint32_t n_merges = 0;
+    // GENERAL form (merges the packed layout cannot hold: more than 29 byte values, 65 535 or more nodes, token ids >= 65 535): the trie of lib.rs:127-147 as it
+    // is -- one open-addressing edge table keyed (node << 8 | byte) and a 32-bit token per node (kNoToken32 = none) -- walked by encode_general_kernel, one lane
+    // per stream: slow, and total.  `nodes` stays empty.
+    bool general = false;
+    std::vector<uint64_t> g_keys;      // (node << 8 | byte) + 1, 0 = empty slot; capacity a power of two
+    std::vector<uint32_t> g_child;
+    std::vector<uint32_t> g_token;     // per node
+    uint32_t g_nodes = 0;
+    uint64_t *g_keys_dev = nullptr;
+    uint32_t *g_child_dev = nullptr, *g_token_dev = nullptr;
     // device copies
     uint64_t *nodes_dev = nullptr;
     uint32_t *runbits_dev = nullptr;

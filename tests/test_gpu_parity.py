@@ -389,7 +389,7 @@ def test_trie_larger_than_lds(dev, plan):
     rng = np.random.default_rng(77)
     merges = random_merges(rng, 6500, alphabet=b"abcdefghijklmnopqrstuvwxyz", max_len=12, dup_frac=0.02)
     tk = HipTokenizer(merges)
-    assert tk.n_nodes > 24000
+    assert tk.n_nodes > 14000
     pool = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", dtype=np.uint8)
     texts = [bytes(rng.choice(pool, size=20011)) for _ in range(3)]
     # plant expansions so that deep (non-LDS) nodes are actually reached
@@ -534,3 +534,50 @@ def test_lane_per_chunk_equals_segment_kernels_on_the_bench_batch(dev):
     assert torch.equal(counts, counts0)
     valid = torch.arange(ids.shape[1], device="cuda")[None, :] < counts[:, None]
     assert bool(((ids == ids0) | ~valid).all())
+
+
+# ---- the general form (round 5): merges the packed trie cannot hold ---------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["256-byte-values", "wide-ids", "many-nodes"])
+def test_general_form_byte_level_merges_vs_oracle(dev, kind):
+    """Random byte-level merges over all 256 byte values / token ids above 65 535 / a trie of more than 65 535 nodes: `encode_text` through the drop-in module
+    and `encode_bytes` on batches, against lib.rs's restatement (lib.rs:149-193)."""
+    from ecg_byte_amd import rust_bpe
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    rng = np.random.default_rng({"256-byte-values": 1, "wide-ids": 2, "many-nodes": 3}[kind])
+    if kind == "256-byte-values":
+        merges = random_merges(rng, 800, alphabet=bytes(range(256)), max_len=6)
+        texts = [bytes(rng.integers(0, 256, size=5000).astype(np.uint8)) for _ in range(5)]
+        # make the merges hit: splice expansions into the texts
+        texts = [b"".join(bytes(merges[int(k)][0]) for k in rng.integers(0, 800, size=900))[:5000].ljust(5000, b"\x00") for _ in range(5)] + texts[:2]
+    elif kind == "wide-ids":
+        merges = [(seq, 70000 + 3 * i) for i, (seq, _) in enumerate(random_merges(rng, 300, alphabet=b"abcdef", max_len=8))]
+        texts = [bytes(rng.choice(list(b"abcdef"), size=4000).astype(np.uint8)) for _ in range(4)]
+    else:
+        merges = [(rng.integers(97, 123, size=6).tolist(), 256 + i) for i in range(24000)]
+        texts = [bytes(rng.integers(97, 123, size=3000).astype(np.uint8)) for _ in range(3)]
+        texts.append(b"".join(bytes(merges[int(k)][0]) for k in rng.integers(0, 24000, size=500)))
+        texts = [t[:3000].ljust(3000, b"a") for t in texts]
+    tk = HipTokenizer(merges)
+    got, counts = _encode_bytes(tk, texts)
+    for b, t in enumerate(texts):
+        ref = O.encode_text(t, merges)
+        assert counts[b] == len(ref) and np.array_equal(got[b], np.asarray(ref, dtype=np.uint32)), (kind, b)
+    if kind != "256-byte-values":                                           # the module takes `str`: ASCII texts
+        t = texts[0].decode("ascii")
+        assert rust_bpe.encode_text(t, merges) == [int(v) for v in O.encode_text(texts[0], merges)]
+
+
+def test_general_form_quantize_encode(dev):
+    """The fused entry point with a general-form handle: quantise into the scratch buffer, then the general walk."""
+    from ecg_byte_amd import synth
+    from ecg_byte_amd.tokenizer import HipTokenizer
+    _, merges, pc = load_tokenizer("c1")
+    wide = [(seq, 100000 + tid) for seq, tid in merges]                     # the C1 merges with ids that need 32 bits
+    tk = HipTokenizer(wide)
+    x = synth.synth_ecg(6, 1000, seed=2)
+    ids, counts = tk.quantize_encode(torch.from_numpy(x).cuda(), pc)
+    ids, counts = ids.cpu().numpy(), counts.cpu().numpy()
+    for b in range(6):
+        text = O.symbols_to_text(O.quantize(x[b], pc["percentile_1"], pc["percentile_99"]))
+        ref = np.asarray(O.encode_text(text, wide), dtype=np.uint32)
+        assert counts[b] == ref.size and np.array_equal(ids[b, : ref.size].astype(np.uint32), ref), b

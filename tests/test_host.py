@@ -190,12 +190,26 @@ def test_packed_trie_fixture_tokenizer(lib):
     assert _walk_packed(nodes, _classes(merges), text, _lens(merges), rb) == O.encode_text(text, merges)
 
 
-def test_tokenizer_limits_are_reported(lib):
+def test_merges_beyond_the_packed_trie_take_the_general_form(lib):
+    """More than 29 distinct byte values, token ids >= 65 535, 65 535 or more trie nodes: round 4 returned ECGB_ERR_UNSUPPORTED, `encode_text` (lib.rs:149-193)
+    refuses no merges list.  The handle is now built in the general form (edge table + 32-bit ids, walked by encode_general_kernel); the GPU parity of that walk
+    is tests/test_gpu_parity.py::test_general_form_*."""
     many = [([i, i + 1], 256 + i) for i in range(0, 80, 2)]          # > 29 symbol classes
     rc, h = _make_tok(lib, many)
-    assert rc == -3 and b"29 distinct" in lib.ecgb_last_error()
-    rc, h = _make_tok(lib, [([97, 98], 70000)])                        # token id does not fit
-    assert rc == -3
+    assert rc == 0 and h
+    n = C.c_uint32()
+    assert lib.ecgb_tokenizer_info(h, C.byref(n), None, None) == 0 and n.value == 1 + 256 + 40      # root, the 256 bytes, one node per merge
+    assert lib.ecgb_tokenizer_copy_nodes(h, None, 0) == 0                                            # no packed nodes
+    lib.ecgb_tokenizer_destroy(h)
+    rc, h = _make_tok(lib, [([97, 98], 70000)])                        # token id does not fit 16 bits
+    assert rc == 0 and h
+    lib.ecgb_tokenizer_destroy(h)
+    rng = np.random.default_rng(0)
+    big = [(rng.integers(97, 123, size=6).tolist(), 256 + i) for i in range(24000)]                 # > 65 535 nodes
+    rc, h = _make_tok(lib, big)
+    assert rc == 0 and h
+    assert lib.ecgb_tokenizer_info(h, C.byref(n), None, None) == 0 and n.value >= 65535
+    lib.ecgb_tokenizer_destroy(h)
 
 
 def test_expansion_elements_above_255_are_unreachable_nodes_like_the_reference(lib):
