@@ -931,6 +931,8 @@ class HipCausalLM(nn.Module):
         cos, sin = self._rope_tables(pos)
         x = ops.embed_fwd(tokens, self.embed.data, self.embed_scale)    # [B, H]
         delta = None
+        if getattr(self, "decode_fused", True) and not self.training and ops.decode_fusable(x.shape[0], c.hidden_size, Hq, Hkv, D):
+            return self._decode_layers_fused(x, cos, sin, mask, caches, n if n_dev is None else n_dev)
         for i in range(c.num_hidden_layers):
             if self.lora is not None and not self.training:             # adapters: the norm kernel forms the site's t = scale * h A^T on its way out
                 site = self.lora[i]["qkv"]
@@ -954,6 +956,42 @@ class HipCausalLM(nn.Module):
             h2, _, x = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma)
             _, hm, _ = self._proj_glu(i, h2, keep_gu=False)
             delta, _ = self._proj(i, "down", hm, self.wdown[i].data)
+        hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
+        return hf
+
+    def _decode_layers_fused(self, x, cos, sin, mask, caches, n):
+        """The layers of a decode step for one or two sequences on the fused kernels of csrc/decode.hip: per layer q|k|v with its norm and adapter branch in one launch,
+        RoPE + cache append + attention in two, o with its adapter's down-projection in one, the MLP in two to four (round 4: twelve launches a layer).  n: keys valid after
+        the append, an int or the graph's int32[1] device tensor.  The same bits as the separate kernels (tests/test_gpu_decode_fused.py)."""
+        c = self.cfg
+        D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        B, cap = x.shape[0], caches[0].shape[1]
+        scale = 1.0 / math.sqrt(D)
+        ns = ops.decode_attn_splits(cap)
+        pool = self.__dict__.setdefault("_dec_scratch", {})
+        key = (B, cap, ns)
+        scratch = pool.get(key)
+        if scratch is None:                                              # (first use: the warm-up step in front of a capture, never inside one)
+            if len(pool) >= 4:
+                pool.pop(next(iter(pool)))
+            scratch = pool[key] = ops.decode_attn_scratch(cap, B, Hq, Hkv, D, ns, x.device)
+        glu = 2 if self.gemma else 1
+        delta = None
+        for i in range(c.num_hidden_layers):
+            L = self.lora[i] if self.lora is not None else None
+            site = (lambda k: (L[k].A.data, 16 * L[k].n_sub, L[k].scale, L[k].B.data)) if L is not None else (lambda k: None)
+            qkv, x = ops.decode_norm_gemv(x, delta, self.ln1[i].data, c.rms_norm_eps, self.gemma, self.wqkv[i].data, lora=site("qkv"))
+            ao = ops.decode_attn(qkv, cos, sin, caches[i], mask, n, Hq, Hkv, D, scale, ns, scratch)
+            attn_delta = ops.decode_gemv(ao, self.wo[i].data, lora=site("o"))
+            if L is None:
+                hm, x = ops.decode_norm_gemv(x, attn_delta, self.ln2[i].data, c.rms_norm_eps, self.gemma, self.wgu[i].data, glu=glu)
+                delta = ops.decode_gemv(hm, self.wdown[i].data)
+            else:
+                # (with adapters the gate|up site keeps the norm + LoRA-down kernel: redone by each of the projection's 2 000 workgroups, A's 32 rows would be read 2 000 times)
+                h2, _, x, t2 = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma, lora=(L["gu"].A.data, L["gu"].scale))
+                _, hm, _ = self._proj_glu(i, h2, keep_gu=False, t_pre=t2)
+                sd = L["down"]
+                delta = ops.decode_gemv(hm, self.wdown[i].data, lora=site("down"), t=ops.decode_lora_t(hm, sd.A.data, 16 * sd.n_sub, sd.scale))
         hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
         return hf
 

@@ -811,3 +811,64 @@ def kv_append(qkv_new, col_off, cache, kv_len_dev):
     """cache[:, *kv_len_dev - 1] = qkv_new[:, col_off : col_off + cache.shape[2]]"""
     B, cap, W = cache.shape
     _lib.check(_L().ecgb_kv_append(_p(qkv_new), qkv_new.stride(0), col_off, W, _p(cache), cap, B, _p(kv_len_dev), _st()))
+
+
+# ---- the fused decode step (csrc/decode.hip): one or two sequences -------------------------------------------------------------------------------------
+def decode_fusable(B, H, Hq, Hkv, D):
+    """Shapes the fused decode kernels take: at most two sequences, hidden a multiple of 512 (<= 8192), head_dim 64 / 128 / 256, at most eight query heads a KV head."""
+    return B <= 2 and H % 512 == 0 and H <= 8192 and D in (64, 128, 256) and Hq % Hkv == 0 and Hq // Hkv <= 8
+
+
+def decode_norm_gemv(x, delta, norm_w, eps, gemma, w, lora=None, glu=0):
+    """(y, x_sum): y = rmsnorm(x + delta) W^T (+ the adapter branch), one launch (ecgb_decode_norm_gemv).  lora = (A [64, H], n_a used rows, scale, B [N or 2N, 64]).
+    glu 1 / 2: W = gate rows then up rows, y = act(gate) * up [M, N / 2 rows of W each]."""
+    M, H = x.shape
+    N = w.shape[0] // 2 if glu else w.shape[0]
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    xs = torch.empty_like(x) if delta is not None else x
+    A, n_a, scale, Bm = lora if lora is not None else (None, 0, 0.0, None)
+    _lib.check(_L().ecgb_decode_norm_gemv(_p(x), _p(delta), _p(norm_w), float(eps), int(gemma), M, H, _p(xs) if delta is not None else None, _p(w), w.stride(0), N,
+                                          _p(A), A.stride(0) if A is not None else 0, int(n_a), float(scale), _p(Bm), Bm.stride(0) if Bm is not None else 0,
+                                          _p(y), y.stride(0), int(glu), _st()))
+    return y, xs
+
+
+def decode_gemv(a, w, lora=None, t=None):
+    """y = a W^T (+ t B^T) for one or two rows.  lora = (A, n_a, scale, B): t formed in the kernel (K <= 4096) unless `t` [M, 64] is given (decode_lora_t)."""
+    M, K = a.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    A, n_a, scale, Bm = lora if lora is not None else (None, 0, 0.0, None)
+    _lib.check(_L().ecgb_decode_gemv(_p(a), a.stride(0), M, K, _p(w), w.stride(0), N, _p(A) if t is None else None, A.stride(0) if A is not None else 0, int(n_a), float(scale),
+                                     _p(t), _p(Bm), Bm.stride(0) if Bm is not None else 0, _p(y), y.stride(0), _st()))
+    return y
+
+
+def decode_lora_t(a, A, n_a, scale):
+    """t [M, 64] = bf16(scale * a A^T) over the n_a used rows of A (the down-projection site of a decode step: K a multiple of 2048)."""
+    M, K = a.shape
+    t = torch.empty((M, 64), dtype=torch.bfloat16, device=a.device)
+    _lib.check(_L().ecgb_decode_lora_t(_p(a), a.stride(0), M, K, _p(A), A.stride(0), int(n_a), float(scale), _p(t), _st()))
+    return t
+
+
+def decode_attn_splits(cap):
+    """Workgroups the keys of a (KV head, sequence) are split over: about sixteen keys each, at most 64, at least what keeps a split within 1 024 keys."""
+    return int(max(1, min(64, cap // 16), -(-cap // 1024)))
+
+
+def decode_attn_scratch(cap, B, Hq, Hkv, D, n_splits, device):
+    """The zeroed fp32 scratch of decode_attn (scores, statistics, partial outputs, tickets: the tickets must start at zero and are left at zero)."""
+    return torch.zeros(_L().ecgb_decode_attn_scratch_floats(cap, B, Hq, Hkv, D, n_splits), dtype=torch.float32, device=device)
+
+
+def decode_attn(qkv, cos, sin, cache, mask, kv_len, Hq, Hkv, D, scale, n_splits, scratch):
+    """One decode step's attention from the RAW q|k|v projection: RoPE, cache append at row kv_len - 1, split softmax attention (ecgb_decode_attn, two launches).
+    kv_len: an int or an int32[1] device tensor."""
+    B, cap, W = cache.shape
+    assert W == 2 * Hkv * D and cache.is_contiguous()
+    o = torch.empty((B, Hq * D), dtype=torch.bfloat16, device=qkv.device)
+    dyn = torch.is_tensor(kv_len)
+    _lib.check(_L().ecgb_decode_attn(_p(qkv), qkv.stride(0), _p(cos), _p(sin), _p(cache), cap, _p(mask), mask.stride(0), _p(o), B, 0 if dyn else int(kv_len),
+                                     _p(kv_len) if dyn else None, Hq, Hkv, D, float(scale), int(n_splits), _p(scratch), scratch.numel(), _st()))
+    return o

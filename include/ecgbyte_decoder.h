@@ -350,6 +350,29 @@ int ecgb_rope_append(void *qkv_dev, const float *cos_dev, const float *sin_dev, 
  * out[r] = index of the first maximum of the bf16 row x[r, 0:n] (rows `ld` elements apart).  One launch, no workspace. */
 int ecgb_argmax_bf16(const void *x_dev, long long ld, int rows, int n, int64_t *out_dev, void *stream);
 
+/* ---- the decode step of generate() for one or two sequences, fused (csrc/decode.hip; round 5) -----------------------------------------------------------------
+ * Replaces, per layer and token: ecgb_rmsnorm_lora_fwd + ecgb_gemm_nt_bf16_cat (q|k|v), ecgb_rope_append + ecgb_attn_decode_split (three kernels), the few-row GEMMs of
+ * the adapters' down-projections, ecgb_rmsnorm_fwd + the GLU GEMV.  Every sum is formed in the order of the kernels replaced: the same bits (tests/test_gpu_decode_fused.py).
+ * Reference: modeling_llama.py:635-701 (decoder layer), cache_utils.py:408-470 (DynamicCache.update), generation/utils.py:3131 (the per-token call). */
+
+/* residual add (delta may be NULL) + RMSNorm (gemma != 0: (1 + w) form) + optional LoRA branch (A [64, H], n_a rows used; B [N or 2 N, 64]) + projection of M <= 2 rows.
+ * glu 0: y[M, N] = h W^T (+ t B^T); glu 1 / 2: W = [gate rows; up rows] (N each), y = act(gate) * up (SiLU / tanh-GELU).  x_out = x + delta when delta is given. */
+int ecgb_decode_norm_gemv(const void *x_dev, const void *delta_dev, const void *norm_w_dev, float eps, int gemma, int M, int H, void *x_out_dev,
+                          const void *w_dev, long long ldw, int N, const void *lora_a_dev, long long lda, int n_a, float lora_scale, const void *lora_b_dev,
+                          long long ldb, void *y_dev, long long ldy, int glu, void *stream);
+/* y[M, N] = a W^T (+ t B^T), M <= 2: t = bf16(scale a A^T) formed inside (lora_a_dev, K <= 4096) or given (t_dev [M, 64]); both NULL: no adapter. */
+int ecgb_decode_gemv(const void *a_dev, long long lda_act, int M, int K, const void *w_dev, long long ldw, int N, const void *lora_a_dev, long long lda, int n_a,
+                     float lora_scale, const void *t_dev, const void *lora_b_dev, long long ldb, void *y_dev, long long ldy, void *stream);
+/* t[M, 64] = bf16(scale a A^T) for the n_a used rows of A [64, K] (the rest zero); K a multiple of 2048 (the down-projection site). */
+int ecgb_decode_lora_t(const void *a_dev, long long lda_act, int M, int K, const void *lora_a_dev, long long lda, int n_a, float lora_scale, void *t_dev, void *stream);
+/* scratch floats of ecgb_decode_attn; the last batch * n_kv_heads words (tickets) must be zero before the first call and are left zero by every call */
+size_t ecgb_decode_attn_scratch_floats(long long capacity, int batch, int n_q_heads, int n_kv_heads, int head_dim, int n_splits);
+/* One decode step's attention from the raw q|k|v projection [batch, (Hq + 2 Hkv) D]: RoPE on q and on the new key (ecgb_rope's arithmetic), key / value append at cache row
+ * len - 1 (cache [batch, capacity, 2 Hkv D]: keys | values), softmax(q K^T scale, keys with mask == 0 excluded) V -> o [batch, Hq D].  len = *kv_len_dev when given. */
+int ecgb_decode_attn(void *qkv_dev, long long ld_qkv, const float *cos_dev, const float *sin_dev, void *cache_dev, long long capacity, const float *attn_mask_dev,
+                     long long mask_ld, void *o_dev, int batch, int kv_len, const int *kv_len_dev, int n_q_heads, int n_kv_heads, int head_dim, float scale, int n_splits,
+                     float *scratch_dev, size_t scratch_floats, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,145 @@
+"""The fused decode-step kernels of csrc/decode.hip (round 5) against the separate kernels they replace, bit for bit: every sum is formed in the same order
+(rmsnorm_lora_fwd_kernel, gemm_nt_skinny_kernel<2, 1 / 4>, gemm_nt_skinny_glu_kernel, rope_append_kernel, attn_decode_scores / values / combine).
+Reference of the ops themselves: modeling_llama.py:67-72,193-224,238-258,526-614; the separate kernels are pinned against fp32 torch in tests/test_gpu_decoder_ops.py."""
+import math
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from ecg_byte_amd import decoder_ops
+    return decoder_ops
+
+
+def _bf(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(*shape, device="cuda", generator=g) * scale).to(torch.bfloat16)
+
+
+def _site(in_dim, out_dim, n_sub, seed):
+    """A LoRA site as decoder.LoraSite lays it out: A [64, in] with 16 * n_sub used rows, B [out, 64]."""
+    A = torch.zeros(64, in_dim, dtype=torch.bfloat16, device="cuda")
+    A[: 16 * n_sub] = _bf(16 * n_sub, in_dim, scale=in_dim ** -0.5, seed=seed)
+    B = _bf(out_dim, 64, scale=0.05, seed=seed + 1)
+    B[:, 16 * n_sub:] = 0
+    return A, 16 * n_sub, 2.0, B
+
+
+@pytest.mark.parametrize("M", [1, 2])
+@pytest.mark.parametrize("gemma", [False, True])
+@pytest.mark.parametrize("lora", [False, True])
+@pytest.mark.parametrize("with_delta", [True, False])
+def test_norm_gemv_equals_rmsnorm_then_few_row_gemm(ops, M, gemma, lora, with_delta):
+    H, N = 2048, 2560
+    x, delta, w = _bf(M, H, seed=1), (_bf(M, H, scale=0.3, seed=2) if with_delta else None), _bf(H, scale=0.2, seed=3)
+    W = _bf(N, H, scale=H ** -0.5, seed=4)
+    site = _site(H, N, 3, 10) if lora else None
+    y, xs = ops.decode_norm_gemv(x, delta, w, 1e-5, gemma, W, lora=site)
+    if lora:
+        h, _, xs_ref, t = ops.rmsnorm_fwd(x, w, 1e-5, residual=delta, gemma=gemma, lora=(site[0], site[2]))
+        ref = ops.gemm_nt(h, W, a2=t, b2=site[3])
+    else:
+        h, _, xs_ref = ops.rmsnorm_fwd(x, w, 1e-5, residual=delta, gemma=gemma)
+        ref = ops.gemm_nt(h, W)
+    assert torch.equal(y, ref)
+    assert torch.equal(xs, xs_ref)
+
+
+@pytest.mark.parametrize("M", [1, 2])
+@pytest.mark.parametrize("gemma", [False, True])
+def test_norm_gemv_glu_equals_rmsnorm_then_glu_gemv(ops, M, gemma):
+    H, I = 2048, 8192
+    x, delta, w = _bf(M, H, seed=5), _bf(M, H, scale=0.3, seed=6), _bf(H, scale=0.2, seed=7)
+    W = _bf(2 * I, H, scale=H ** -0.5, seed=8)
+    y, xs = ops.decode_norm_gemv(x, delta, w, 1e-6, gemma, W, glu=2 if gemma else 1)
+    h, _, xs_ref = ops.rmsnorm_fwd(x, w, 1e-6, residual=delta, gemma=gemma)
+    _, ref = ops.gemm_nt_glu(h, W, gelu_tanh=gemma, keep_gu=False)
+    assert torch.equal(y, ref) and torch.equal(xs, xs_ref)
+
+
+@pytest.mark.parametrize("M", [1, 2])
+@pytest.mark.parametrize("K,N", [(2048, 2048), (16384, 2048), (8192, 2048)])
+@pytest.mark.parametrize("mode", ["plain", "lora-inside", "t-given"])
+def test_gemv_equals_few_row_gemm(ops, M, K, N, mode):
+    if mode == "lora-inside" and K > 4096:
+        pytest.skip("t is formed inside only for K <= 4096")
+    a, W = _bf(M, K, seed=11), _bf(N, K, scale=K ** -0.5, seed=12)
+    site = _site(K, N, 1, 20)
+    if mode == "plain":
+        assert torch.equal(ops.decode_gemv(a, W), ops.gemm_nt(a, W))
+        return
+    t_ref = ops.gemm_nt(a, site[0], alpha=site[2])
+    ref = ops.gemm_nt(a, W, a2=t_ref, b2=site[3])
+    if mode == "lora-inside":
+        got = ops.decode_gemv(a, W, lora=site)
+    else:
+        t = ops.decode_lora_t(a, site[0], site[1], site[2]) if K % 2048 == 0 else t_ref
+        assert torch.equal(t, t_ref)
+        got = ops.decode_gemv(a, W, lora=site, t=t)
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,D", [(1, 8, 1, 256), (2, 32, 8, 64), (1, 8, 2, 128), (2, 8, 8, 64)])
+@pytest.mark.parametrize("dyn", [False, True])
+def test_decode_attn_equals_rope_append_then_split_attention(ops, B, Hq, Hkv, D, dyn):
+    """RoPE + append + attention in two launches = ecgb_rope_append + ecgb_attn_decode_split with the same number of splits: the same output, the same cache row.
+    Left-padded rows (mask 0) and a length that is not a multiple of anything."""
+    cap, n = 768, 613
+    QKV = (Hq + 2 * Hkv) * D
+    qkv = _bf(B, QKV, seed=31)
+    cache = _bf(B, cap, 2 * Hkv * D, seed=32)
+    mask = torch.ones(B, cap, device="cuda")
+    mask[:, n:] = 0
+    mask[0, :37] = 0
+    pos = torch.tensor([n - 1 - 37, n - 1][:B], device="cuda").float()
+    fr = pos[:, None] * torch.rand(D // 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))[None]
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    scale = 1.0 / math.sqrt(D)
+    ns = ops.decode_attn_splits(cap)
+    kv = torch.full((1,), n, dtype=torch.int32, device="cuda") if dyn else n
+    # reference: the separate kernels
+    q2, c2 = qkv.clone(), cache.clone()
+    ops.rope_append_(q2, cos, sin, Hq, Hkv, D, c2, kv)
+    ref = ops.attn_decode_split(q2, c2, mask, kv, Hq, Hkv, D, scale, ns)
+    c1 = cache.clone()
+    scratch = ops.decode_attn_scratch(cap, B, Hq, Hkv, D, ns, "cuda")
+    got = ops.decode_attn(qkv.clone(), cos, sin, c1, mask, kv, Hq, Hkv, D, scale, ns, scratch)
+    assert torch.equal(c1, c2)
+    assert torch.equal(got, ref)
+    # a second call on the same scratch (the tickets went back to zero): the same result
+    c3 = cache.clone()
+    assert torch.equal(ops.decode_attn(qkv.clone(), cos, sin, c3, mask, kv, Hq, Hkv, D, scale, ns, scratch), ref)
+
+
+@pytest.mark.parametrize("family,lora", [("llama", False), ("llama", True), ("gemma", True)])
+def test_fused_decode_step_equals_the_separate_kernels(family, lora):
+    """A whole generate() on a small model: the fused decode step against the twelve-launch step of round 4, token for token and (no graph) logit for logit."""
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    kw = dict(vocab_size=1000, hidden_size=512, intermediate_size=2048, num_hidden_layers=3, num_attention_heads=8, num_key_value_heads=2, head_dim=64, pad_token_id=999)
+    if family == "gemma":
+        kw.update(model_type="gemma", num_key_value_heads=1, head_dim=128, num_attention_heads=4, rms_norm_eps=1e-6)
+    m = HipCausalLM(DecoderConfig(**kw), seed=3)
+    if lora:
+        m.enable_lora(r=16, alpha=32, dropout=0.05)
+        g = torch.Generator(device="cuda").manual_seed(9)
+        for sites in m.lora:
+            for s in sites.values():
+                s.B.data.copy_((torch.randn(s.B.shape, device="cuda", generator=g) * 0.05).to(torch.bfloat16) * s.bmask)
+    m.eval()
+    ids = torch.randint(0, 990, (2, 40), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    mask = torch.ones(2, 40, device="cuda")
+    mask[0, :7] = 0
+    outs = {}
+    for fused in (True, False):
+        m.decode_fused = fused
+        seq, logits = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=12, pad_token_id=999, return_logits=True, use_graph=False)
+        seq_g = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=12, pad_token_id=999)
+        assert torch.equal(seq, seq_g)                               # the replayed graph = the eager loop
+        outs[fused] = (seq, logits)
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert torch.equal(outs[True][1], outs[False][1])
