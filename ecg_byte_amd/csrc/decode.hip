@@ -120,7 +120,7 @@ __device__ __forceinline__ void column_dot(float (&acc)[MR], const unsigned shor
     for (int k0 = k_lo + lane * 8; k0 < k_hi; k0 += 512 * U) {
         bf16x8 vb[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) vb[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(wrow + min(k0 + 512 * u, k_hi - 8)));   // (a weight row is read once)
+        for (int u = 0; u < U; ++u) vb[u] = *reinterpret_cast<const bf16x8 *>(wrow + min(k0 + 512 * u, k_hi - 8));
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = k0 + 512 * u;
@@ -219,8 +219,8 @@ __global__ __launch_bounds__(256) void decode_norm_gemv_kernel(NormGemvArgs G)
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int k = min(k0 + 512 * u, G.H - 8);
-                    vg[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(bg + k));
-                    vu[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8 *>(bu + k));
+                    vg[u] = *reinterpret_cast<const bf16x8 *>(bg + k);
+                    vu[u] = *reinterpret_cast<const bf16x8 *>(bu + k);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -276,24 +276,28 @@ struct GemvArgs {
 
 // 4 / 6: a projection of a few rows.  KS = 1: a wave a column; KS = 4: the four waves of a workgroup share a column, a contiguous quarter of the contraction each
 // (gemm_nt_skinny_kernel<2, 4>: long rows, few columns), their sums meet in LDS in wave order.
-template <int KS>
+// STAGE: the activations go through LDS first (needed where the adapter's t is formed here: every wave reads them sixteen times); otherwise the lanes read them from
+// global memory as gemm_nt_skinny_kernel does (L2-resident, a few KB) -- staging 32 KB of them per workgroup of a long-row projection cost more than the projection.
+template <int KS, bool STAGE>
 __global__ __launch_bounds__(256) void decode_gemv_kernel(GemvArgs G)
 {
     extern __shared__ __align__(16) unsigned short smem[];
-    unsigned short *s_a = smem;                                  // [M][K]
-    unsigned short *s_t = smem + kMaxRows * G.K;                 // [M][64]
+    unsigned short *s_t = smem;                                  // [M][64]
+    unsigned short *s_stage = smem + kMaxRows * kTRows;          // [M][K] when STAGE
     __shared__ float s_part[4][kMaxRows];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ks = wave % KS;
-    for (int i = threadIdx.x * 8; i < G.M * G.K; i += 256 * 8) {
-        const int m = i / G.K, k = i % G.K;
-        *reinterpret_cast<bf16x8 *>(s_a + m * G.K + k) = *reinterpret_cast<const bf16x8 *>(G.a + (long long)m * G.lda_act + k);
-    }
-    __syncthreads();
-    if (G.lA && !G.t_in) lora_t_rows(s_a, G.K, G.M, G.K, G.lA, G.lda, G.n_a, G.lscale, s_t, wave, 4, lane);
-    else if (G.t_in) {
-        for (int i = threadIdx.x; i < G.M * kTRows; i += 256) s_t[i] = G.t_in[i];
+    const unsigned short *s_a = G.a;
+    int a_stride = (int)G.lda_act;
+    if constexpr (STAGE) {
+        for (int i = threadIdx.x * 8; i < G.M * G.K; i += 256 * 8) {
+            const int m = i / G.K, k = i % G.K;
+            *reinterpret_cast<bf16x8 *>(s_stage + m * G.K + k) = *reinterpret_cast<const bf16x8 *>(G.a + (long long)m * G.lda_act + k);
+        }
         __syncthreads();
+        s_a = s_stage; a_stride = G.K;
+        if (G.lA && !G.t_in) lora_t_rows(s_stage, G.K, G.M, G.K, G.lA, G.lda, G.n_a, G.lscale, s_t, wave, 4, lane);
     }
+    const unsigned short *t_src = G.t_in ? G.t_in : s_t;       // (t formed before: read where it lies, as gemm_nt_skinny_kernel reads its second operand pair)
     const long long n = (long long)blockIdx.x * (4 / KS) + wave / KS;
     const bool live = n < G.N;
     const unsigned short *wrow = G.W + (live ? n : 0) * G.ldw;
@@ -301,8 +305,8 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(GemvArgs G)
     float acc[kMaxRows];
 #pragma unroll
     for (int m = 0; m < kMaxRows; ++m) acc[m] = 0.f;
-    column_dot<kMaxRows>(acc, wrow, k_lo, k_hi, s_a, G.K, G.M, lane);
-    if ((G.lA || G.t_in) && ks == 0) pair_dot<kMaxRows>(acc, G.lB + (live ? n : 0) * G.ldb, s_t, G.M, lane);
+    column_dot<kMaxRows>(acc, wrow, k_lo, k_hi, s_a, a_stride, G.M, lane);
+    if ((G.lA || G.t_in) && ks == 0) pair_dot<kMaxRows>(acc, G.lB + (live ? n : 0) * G.ldb, t_src, G.M, lane);
 #pragma unroll
     for (int m = 0; m < kMaxRows; ++m) acc[m] = wave_sum(acc[m]);
     if constexpr (KS > 1) {
@@ -550,12 +554,18 @@ __global__ __launch_bounds__(kAttnThreads) void decode_attn_values_kernel(AttnAr
     const int width = 2 * A.Hkv * D;
     const unsigned short *V = A.cache + (long long)b * A.cap * width + (long long)A.Hkv * D + (long long)g * D;
     const int piece = tid % TPR, slice = tid / TPR;
+    __shared__ float s_st[kAttnMaxG][2 * 64];                     // the splits' (maximum, sum) pairs of every head of the group
+    for (int i = tid; i < G * n_splits * 2; i += kAttnThreads) {
+        const int h = i / (n_splits * 2), r = i % (n_splits * 2);
+        s_st[h][r] = A.stats[((long long)b * A.Hq + g * G + h) * n_splits * 2 + r];
+    }
+    __syncthreads();
     float mx[kAttnMaxG], inv[kAttnMaxG];
 #pragma unroll
     for (int h = 0; h < kAttnMaxG; ++h) {
         mx[h] = -INFINITY; inv[h] = 0.f;
         if (h < G) {
-            const float *st = A.stats + ((long long)b * A.Hq + g * G + h) * n_splits * 2;
+            const float *st = s_st[h];
             float m = -INFINITY;
             for (int t = 0; t < n_splits; ++t) m = fmaxf(m, st[2 * t]);
             float l = 0.f;
@@ -610,7 +620,13 @@ __global__ __launch_bounds__(kAttnThreads) void decode_attn_values_kernel(AttnAr
         const int h = i / D, d = i % D;
         const float *p = A.partial + ((long long)b * A.Hq + g * G + h) * n_splits * D + d;
         float sum = 0.f;
-        for (int t = 0; t < n_splits; ++t) sum += __builtin_nontemporal_load(p + (long long)t * D);
+        for (int t0 = 0; t0 < n_splits; t0 += 16) {              // sixteen splits' values in flight, added in split order
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p[(long long)min(t0 + u, n_splits - 1) * D];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (t0 + u < n_splits) sum += v[u];
+        }
         A.o[((long long)b * A.Hq + g * G + h) * D + d] = f2bf(sum);
     }
     if (tid == 0) A.tickets[b * A.Hkv + g] = 0u;               // ready for the next launch (a replayed graph never clears the buffer itself)
@@ -676,17 +692,16 @@ extern "C" int ecgb_decode_gemv(const void *a_dev, long long lda_act, int M, int
     G.a = (const unsigned short *)a_dev; G.lda_act = lda_act; G.W = (const unsigned short *)w_dev; G.ldw = ldw;
     G.lA = t_dev ? nullptr : (const unsigned short *)lora_a_dev; G.lB = (const unsigned short *)lora_b_dev; G.t_in = (const unsigned short *)t_dev; G.lda = lda; G.ldb = ldb;
     G.y = (unsigned short *)y_dev; G.ldy = ldy; G.M = M; G.K = K; G.N = N; G.n_a = n_a; G.lscale = lora_scale;
-    const size_t lds = (size_t)(kMaxRows * K + kMaxRows * kTRows) * 2;
+    const bool stage = G.lA != nullptr;                                   // (t formed in the kernel: the activations are read once per row of A)
+    const size_t lds = (size_t)(kMaxRows * kTRows + (stage ? kMaxRows * K : 0)) * 2;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipSuccess;
     if (split) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(decode_gemv_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) hipLaunchKernelGGL((decode_gemv_kernel<4>), dim3((unsigned)N), dim3(256), lds, st, G);
+        if (stage) hipLaunchKernelGGL((decode_gemv_kernel<4, true>), dim3((unsigned)N), dim3(256), lds, st, G);
+        else hipLaunchKernelGGL((decode_gemv_kernel<4, false>), dim3((unsigned)N), dim3(256), lds, st, G);
     } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(decode_gemv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) hipLaunchKernelGGL((decode_gemv_kernel<1>), dim3((unsigned)((N + 3) / 4)), dim3(256), lds, st, G);
+        if (stage) hipLaunchKernelGGL((decode_gemv_kernel<1, true>), dim3((unsigned)((N + 3) / 4)), dim3(256), lds, st, G);
+        else hipLaunchKernelGGL((decode_gemv_kernel<1, false>), dim3((unsigned)((N + 3) / 4)), dim3(256), lds, st, G);
     }
-    if (e != hipSuccess) return check(e, "hipFuncSetAttribute(decode_gemv_kernel)");
     return check(hipGetLastError(), "decode_gemv_kernel launch");
 }
 
@@ -722,7 +737,7 @@ extern "C" int ecgb_decode_attn(void *qkv_dev, long long ld_qkv, const float *co
     }
     const int G = n_q_heads / n_kv_heads;
     if (n_q_heads % n_kv_heads || G > kAttnMaxG || (head_dim != 64 && head_dim != 128 && head_dim != 256) || ld_qkv % 8 || !aligned16(qkv_dev) || !aligned16(cache_dev) ||
-        (capacity + n_splits - 1) / n_splits > kAttnMaxChunk || scratch_floats < ecgb_decode_attn_scratch_floats(capacity, batch, n_q_heads, n_kv_heads, head_dim, n_splits)) {
+        (capacity + n_splits - 1) / n_splits > kAttnMaxChunk || n_splits > 64 || scratch_floats < ecgb_decode_attn_scratch_floats(capacity, batch, n_q_heads, n_kv_heads, head_dim, n_splits)) {
         ecgb::set_error("ecgb_decode_attn: head_dim 64 / 128 / 256, at most 8 query heads a KV head, at most 1024 keys a split, scratch of ecgb_decode_attn_scratch_floats()");
         return ECGB_ERR_UNSUPPORTED;
     }

@@ -931,7 +931,9 @@ class HipCausalLM(nn.Module):
         cos, sin = self._rope_tables(pos)
         x = ops.embed_fwd(tokens, self.embed.data, self.embed_scale)    # [B, H]
         delta = None
-        if getattr(self, "decode_fused", True) and not self.training and ops.decode_fusable(x.shape[0], c.hidden_size, Hq, Hkv, D):
+        # (opt-in: the fused kernels of csrc/decode.hip are bit-exact but measured no faster than the separate ones at the C5 shape -- 2.20 against 2.14 ms a token; every
+        #  kernel of the step sits on the ~5 us a dependent launch of a replayed graph costs, whatever it fuses: profiles/r05/README.md)
+        if getattr(self, "decode_fused", False) and not self.training and ops.decode_fusable(x.shape[0], c.hidden_size, Hq, Hkv, D):
             return self._decode_layers_fused(x, cos, sin, mask, caches, n if n_dev is None else n_dev)
         for i in range(c.num_hidden_layers):
             if self.lora is not None and not self.training:             # adapters: the norm kernel forms the site's t = scale * h A^T on its way out
@@ -967,21 +969,40 @@ class HipCausalLM(nn.Module):
         D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
         B, cap = x.shape[0], caches[0].shape[1]
         scale = 1.0 / math.sqrt(D)
-        ns = ops.decode_attn_splits(cap)
+        # attention: round 4's kernels (RoPE + append, scores, values, combine) unless `decode_fused_attn` is set -- the two-launch form of csrc/decode.hip is bit-exact
+        # and reads a KV group's keys once, but measured SLOWER at the C5 shape (82 against 25 us a layer: profiles/r05/README.md); kept for the record and the tests
+        fused_attn = bool(getattr(self, "decode_fused_attn", False))
+        dyn = torch.is_tensor(n)
+        ns, ns4 = ops.decode_attn_splits(cap), ops.decode_splits(cap, B, Hq)
         pool = self.__dict__.setdefault("_dec_scratch", {})
-        key = (B, cap, ns)
-        scratch = pool.get(key)
-        if scratch is None:                                              # (first use: the warm-up step in front of a capture, never inside one)
+        key = (B, cap, ns, ns4, fused_attn)
+        scratch = scratch4 = None
+        if key not in pool:                                              # (first use: the warm-up step in front of a capture, never inside one)
             if len(pool) >= 4:
                 pool.pop(next(iter(pool)))
-            scratch = pool[key] = ops.decode_attn_scratch(cap, B, Hq, Hkv, D, ns, x.device)
+            pool[key] = (ops.decode_attn_scratch(cap, B, Hq, Hkv, D, ns, x.device) if fused_attn else None,
+                         ops.decode_split_scratch(cap, B, Hq, D, ns4, x.device) if (ns4 > 1 and not fused_attn) else None)
+        scratch, scratch4 = pool[key]
         glu = 2 if self.gemma else 1
         delta = None
         for i in range(c.num_hidden_layers):
             L = self.lora[i] if self.lora is not None else None
             site = (lambda k: (L[k].A.data, 16 * L[k].n_sub, L[k].scale, L[k].B.data)) if L is not None else (lambda k: None)
-            qkv, x = ops.decode_norm_gemv(x, delta, self.ln1[i].data, c.rms_norm_eps, self.gemma, self.wqkv[i].data, lora=site("qkv"))
-            ao = ops.decode_attn(qkv, cos, sin, caches[i], mask, n, Hq, Hkv, D, scale, ns, scratch)
+            if L is None:
+                qkv, x = ops.decode_norm_gemv(x, delta, self.ln1[i].data, c.rms_norm_eps, self.gemma, self.wqkv[i].data)
+            else:   # (with adapters: the norm + LoRA-down kernel, then the projection with t given -- redone by each of the projection's workgroups the 48 rows of A cost more than the launch)
+                h1, _, x, t1 = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma, lora=(L["qkv"].A.data, L["qkv"].scale))
+                qkv = ops.decode_gemv(h1, self.wqkv[i].data, lora=site("qkv"), t=t1)
+            if fused_attn:
+                ao = ops.decode_attn(qkv, cos, sin, caches[i], mask, n, Hq, Hkv, D, scale, ns, scratch)
+            else:   # RoPE + append, then the attention kernels of round 4 (one workgroup a head for short caches, split over workgroups for long ones)
+                ops.rope_append_(qkv, cos, sin, Hq, Hkv, D, caches[i], n)
+                if ns4 > 1:
+                    ao = ops.attn_decode_split(qkv, caches[i], mask, n, Hq, Hkv, D, scale, ns4, scratch=scratch4 if dyn else None)
+                elif dyn:
+                    ao = ops.attn_decode_dyn(qkv, caches[i], mask, n, Hq, Hkv, D, scale)
+                else:
+                    ao = ops.attn_decode(qkv, caches[i], mask, n, Hq, Hkv, D, scale)
             attn_delta = ops.decode_gemv(ao, self.wo[i].data, lora=site("o"))
             if L is None:
                 hm, x = ops.decode_norm_gemv(x, attn_delta, self.ln2[i].data, c.rms_norm_eps, self.gemma, self.wgu[i].data, glu=glu)

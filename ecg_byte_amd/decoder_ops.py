@@ -853,8 +853,8 @@ def decode_lora_t(a, A, n_a, scale):
 
 
 def decode_attn_splits(cap):
-    """Workgroups the keys of a (KV head, sequence) are split over: about sixteen keys each, at most 64, at least what keeps a split within 1 024 keys."""
-    return int(max(1, min(64, cap // 16), -(-cap // 1024)))
+    """Workgroups the keys of a (KV head, sequence) are split over: about 32 keys each, at most 32, at least what keeps a split within 1 024 keys."""
+    return int(max(1, min(32, cap // 32), -(-cap // 1024)))
 
 
 def decode_attn_scratch(cap, B, Hq, Hkv, D, n_splits, device):

@@ -135,11 +135,14 @@ def test_fused_decode_step_equals_the_separate_kernels(family, lora):
     mask = torch.ones(2, 40, device="cuda")
     mask[0, :7] = 0
     outs = {}
-    for fused in (True, False):
-        m.decode_fused = fused
+    for mode in ("separate", "fused", "fused+attn"):
+        m.decode_fused, m.decode_fused_attn = mode != "separate", mode == "fused+attn"
+        m.__dict__.pop("_gen_graphs", None)
         seq, logits = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=12, pad_token_id=999, return_logits=True, use_graph=False)
         seq_g = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=12, pad_token_id=999)
-        assert torch.equal(seq, seq_g)                               # the replayed graph = the eager loop
-        outs[fused] = (seq, logits)
-    assert torch.equal(outs[True][0], outs[False][0])
-    assert torch.equal(outs[True][1], outs[False][1])
+        assert torch.equal(seq, seq_g), mode                         # the replayed graph = the eager loop
+        outs[mode] = (seq, logits)
+    assert torch.equal(outs["fused"][0], outs["separate"][0]) and torch.equal(outs["fused"][1], outs["separate"][1])        # the same attention kernels: the same bits
+    # the two-launch attention splits the keys differently from the short-cache kernel: the same tokens, logits equal up to the order of fp32 sums
+    assert torch.equal(outs["fused+attn"][0], outs["separate"][0])
+    assert torch.allclose(outs["fused+attn"][1], outs["separate"][1], atol=2e-2, rtol=2e-2)
