@@ -405,16 +405,27 @@ def bench_preprocess(dev, n_records=4096):
     base = np.ascontiguousarray(synth.synth_ecg(64, 5000, seed=0).transpose(0, 2, 1))
     x = np.concatenate([base] * (n_records // 64)) + 0.01 * np.random.default_rng(0).standard_normal((n_records, 5000, 12))
     xd = torch.from_numpy(x).to(dev)
-    out = pp.condition_records(xd, reorder=True, seg_len=1250)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 3
-    e0.record()
-    for _ in range(reps):
-        out = pp.condition_records(xd, reorder=True, seg_len=1250)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+
+    def timed(xin, reps=3):
+        o = pp.condition_records(xin, reorder=True, seg_len=1250)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            o = pp.condition_records(xin, reorder=True, seg_len=1250)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms = timed(xd)
+    # is the fraction parallelism-limited?  4 096 records are 49 152 sequences = 768 waves for 1 024 SIMDs; 16 384 and 65 536 records fill them four and sixteen times over
+    larger = {}
+    for nr in (16384, 32768):
+        if nr * 5000 * 12 * 8 * 8 > 0.7 * torch.cuda.mem_get_info(dev)[0]:       # (input, four planes of scratch, outputs)
+            continue
+        xl = xd.repeat(nr // n_records, 1, 1)
+        larger[str(nr)] = timed(xl, reps=1) * n_records / nr
+        del xl
+        torch.cuda.empty_cache()
     alg = n_records * (5000 * 12 * 8 + 2500 * 12 * 8)
     samples = n_records * 5000 * 12
     # sweeps through HBM as the stages are written, 8 bytes read + 8 written per sample and sweep: 4 filters x (forward, backward); wavelet: ONE (round 3: a
@@ -424,7 +435,7 @@ def bench_preprocess(dev, n_records=4096):
     traffic = sum(sweeps.values()) * 16 * samples
     ach = alg / (ms * 1e-3) / 1e9
     return {"workload": f"{n_records} raw records of 5000 x 12 float64: filtfilt chain, db6 wavelet shrinkage, resample to 250 Hz, segments",
-            "ms": ms, "records_per_s": n_records / (ms * 1e-3),
+            "ms": ms, "records_per_s": n_records / (ms * 1e-3), "ms_per_4096_records_at": larger,
             # the roofline of the stage: ALGORITHMIC bytes (480 KB read + 240 KB written per record) over the measured time against the HBM peak
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": alg},
             # what the kernels actually move (NOT a roofline: every filtfilt pass is a sweep through HBM scratch because scipy's recursion is kept sample by sample,
