@@ -1721,7 +1721,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs G)
     for (int m = 0; m < MR; ++m) acc[m] = 0.f;
     // four 16-byte pieces of the weight row in flight per lane: with one, a long row (K = 16 384: 32 pieces per lane) is a chain
     // of 32 memory latencies
-    constexpr int U = 4;
+    constexpr int U = KS == 4 ? 8 : 4;                      // (a quarter of a 16 384-wide row: eight pieces, one round trip)
     for (int k0 = k_lo + lane * 8; k0 < k_hi; k0 += 512 * U) {
         bf16x8 vb[U];
 #pragma unroll
@@ -1801,7 +1801,7 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_glu_kernel(GemmArgs G)
     float ag[MR], au[MR];
 #pragma unroll
     for (int m = 0; m < MR; ++m) { ag[m] = 0.f; au[m] = 0.f; }
-    constexpr int U = 2;                                   // 16-byte pieces of each of the two weight rows in flight per lane
+    constexpr int U = 4;                                   // 16-byte pieces of each of the two weight rows in flight per lane (round 5: four, a 2 048-wide row is ONE memory round trip; the same order of sums)
     auto fma8 = [&](const bf16x8 &va, const bf16x8 &vb, float &acc) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += __uint_as_float((unsigned)(unsigned short)va[j] << 16) * __uint_as_float((unsigned)(unsigned short)vb[j] << 16);
