@@ -212,7 +212,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["steps"] == 3
     assert out["config"]["records_per_gpu"] == 512
     # both ranks' tokens are in the aggregate: twice one rank's records
-    assert abs(out["records_per_s"] * out["ms_per_step"] * 1e-3 - 2 * 512) < 1e-6 * 1024
+    assert abs(out["records_per_s"] * out["ms_per_step"] * 1e-3 - 2 * 512) < 1e-4 * 1024
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0
     assert out["train"]["steps"] == 2 and np.isfinite(out["train"]["final_loss"]) and "dp2" in out["train"]["config"]["parallelism"]
     assert np.isfinite(out["train"]["lora_r16"]["final_loss"])
@@ -241,10 +241,12 @@ def test_bench_line_contract_single_gpu():
     assert out["vs_baseline"] is None and out["data"] == "synthetic" and "workload" in out["config"] and "model" not in out["config"]
     r = out["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 * r["frac"] and 0 < r["frac"] < 1      # (the line's floats carry six significant digits)
     assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.9
     # whole-job value = tokens of one launch / time of one launch
-    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - out["tokens_per_record"] * out["config"]["records_per_gpu"]) < 1e-6 * out["value"]
+    n_tok = out["tokens_per_record"] * out["config"]["records_per_gpu"]
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - n_tok) < 1e-4 * n_tok
+    assert len(lines[0]) < 8192, "the driver keeps 8 KB of the line"
     c = out["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "tokens/s" and c["value"] > 0 and "records" in c["sample"]
     assert c["quantiser_python_style_symbols_per_s"] < c["quantiser_c_symbols_per_s"]
