@@ -388,7 +388,7 @@ def bench_trainer(pc, L, x, num_merges=4000):
         N[i] = N[i + 1] + c
     assert N[0] == text.numel(), (N[0], text.numel())
     alg = sum(8 * N[i] + 4 * N[i + 1] for i in range(k))
-    return {"workload": f"{n_records} records of 12x{L} (seed 1) = {text.numel()} symbols, {num_merges} merges: the corpus of tests/golden/tokenizer_c2.pkl",
+    return {"workload": f"{n_records} records of 12x{L} = {text.numel()} symbols, {num_merges} merges (the corpus of tokenizer_c2.pkl)",
             "seconds": best, "merges_done": k, "final_ids": m, "compression": text.numel() / max(m, 1),
             "algorithmic_bytes": alg, "GB/s": alg / best / 1e9, "frac_of_hbm_peak": alg / best / 1e9 / HBM_PEAK_GBS,
             "merges_per_s": k / best}
@@ -704,10 +704,9 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
     achieved = flops / sec / 1e12
     out = {"metric": "train_samples_per_sec", "value": B * world / sec, "unit": "samples/s", "ms_per_step": sec * 1e3,
            "steps": args.train_steps, "dtype": "bf16", "final_loss": float(loss.item()),
-           "config": {"workload": f"C3: Llama-3.2-1B dims (16 layers, hidden 2048, 32/8 heads, vocab {n_vocab}), seq {S}, "
-                                  f"batch {B}/GPU, {'LoRA r16 on q,k,v,o,gate,up,down (frozen base)' if args.lora else 'full fine-tune'}, "
-                                  f"random init; batches built by quantise+encode+assemble on device",
-                      "loss_head_rows": "all" if model.full_logits else "labelled only (identical loss/gradients)",
+           "config": {"workload": f"C3: Llama-3.2-1B dims (16 layers, vocab {n_vocab}), seq {S}, batch {B}/GPU, "
+                                  f"{'LoRA r16 (frozen base)' if args.lora else 'full fine-tune'}, random init; batches by quantise+encode+assemble on device",
+                      "loss_head_rows": "all" if model.full_logits else "labelled",
                       "parallelism": f"dp{world}" + (f" (bucketed async all-reduce of the flat gradient buffer, backend {dist.get_backend()})" if dist.is_initialized() else "")},
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_nt_w4_kernel (NT / NN / TN, bf16 MFMA 16x16x32) + attention",
@@ -933,7 +932,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(merges, pc, L, seed=0)
         if sweep is not None:      # columns: records per launch, ms per launch, token ids/s, fraction of the HBM roofline (algorithmic bytes)
-            out["batch_sweep"] = {k: [r[k] for r in sweep] for k in ("records", "ms", "tokens_per_s", "frac")}
+            out["batch_sweep"] = {k: [r[k] for r in sweep] for k in ("records", "ms", "frac")}
         out.update(extras)
         if c1 is not None:
             out["c1"] = c1
