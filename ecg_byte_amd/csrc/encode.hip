@@ -1007,6 +1007,7 @@ __global__ __launch_bounds__(kLanes) void encode_wg_kernel(EncodeArgs A)
 }
 
 #include "encode_long.inc"
+#include "encode_pipe.inc"
 
 // ==========================================================================================
 // Kernel 4 (the GENERAL form of a tokenizer: more than 29 byte values in the merges, 65 535 or more trie nodes, token ids >= 65 535 -- what the packed
@@ -1190,6 +1191,48 @@ int launch_encode_long(const ecgb_tokenizer *tok, const LongPlan &lp, const doub
     return check_hip(hipGetLastError(), "encode_long_kernel launch");
 }
 
+// encode_pipe_kernel: stagers and walkers in one workgroup of sixteen waves, sixteen records a round.  rho: the ratio of consecutive chunk lengths (ECGB_PIPE_RHO, dev).
+int launch_encode_pipe(const ecgb_tokenizer *tok, const double *signal, const QuantParams &qp, size_t batch, size_t n, void *scratch, uint32_t *ids_out, size_t ids_stride,
+                       uint32_t *counts, hipStream_t stream)
+{
+    const size_t cus = tok->n_cus > 0 ? (size_t)tok->n_cus : 256;
+    PipeArgs P;
+    LongArgs &A = P.L;
+    A.trie = tok->nodes_dev; A.n_nodes = (uint32_t)tok->nodes.size();
+    A.runbits = tok->runbits_dev; A.n_runwords = (uint32_t)tok->runbits.size();
+    A.tok_len = tok->toklen_dev; A.n_toklen = (uint32_t)tok->tok_len.size();
+    A.lut = tok->lut_dev;
+    A.signal = signal; A.qp = qp;
+    A.rle_cap = (uint32_t)long_rle_cap(n); A.list_cap = (uint32_t)long_list_cap(n);
+    const size_t slots = cus * kMaxWaves;
+    A.rle = reinterpret_cast<uint16_t *>(scratch);
+    A.lists = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(scratch) + align_up(slots * A.rle_cap * sizeof(uint16_t)));
+    A.ids_out = ids_out; A.ids_stride = ids_stride; A.counts = counts;
+    A.n = (uint32_t)n; A.batch = (uint32_t)batch;
+#ifdef ECGB_PROFILE
+    A.prof = g_prof_dev;
+#endif
+    // chunk k = blocks [sched[k], sched[k + 1]): lengths fall geometrically along the record (a lane that starts later has less time)
+    const uint32_t nblk = (uint32_t)((n + kLongBlk - 1) / kLongBlk);
+    double rho = 0.975;
+    if (const char *e = getenv("ECGB_PIPE_RHO")) rho = atof(e);
+    double w[64], tot = 0.0, cum = 0.0;
+    for (int k = 0; k < 64; ++k) { w[k] = std::pow(rho, k); tot += w[k]; }
+    for (int k = 0; k < 64; ++k) { P.sched[k] = (uint16_t)std::min<double>(nblk, std::floor(cum / tot * nblk + 0.5)); cum += w[k]; }
+    P.sched[64] = (uint16_t)nblk;
+    for (int k = 1; k <= 64; ++k) if (P.sched[k] < P.sched[k - 1]) P.sched[k] = P.sched[k - 1];
+    const size_t tables = tok->nodes.size() * 8 + kLdsTablesFixed + tok->runbits.size() * 4 + tok->tok_len.size() + 16;
+    const size_t lds = tables + 8 * ((kPipeStageLds + 15) & ~15u) + 8 * (size_t)kPipeWalkLds + 16 * (size_t)kPipeSlotLds;
+    if (lds > kLdsCap) { ecgb::set_error("encode_pipe_kernel: the trie leaves no room for the pipeline's buffers"); return ECGB_ERR_UNSUPPORTED; }
+    const bool vec = (n % 2 == 0) && ((reinterpret_cast<uintptr_t>(signal) & 15u) == 0);
+    void (*kern)(PipeArgs) = vec ? encode_pipe_kernel<true> : encode_pipe_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return check_hip(e, ("hipFuncSetAttribute(encode_pipe_kernel, " + std::to_string(lds) + " bytes of LDS)").c_str());
+    const size_t wgs = (batch + 15) / 16;
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::max<size_t>(1, std::min(wgs, cus))), dim3(1024), lds, stream, P);
+    return check_hip(hipGetLastError(), "encode_pipe_kernel launch");
+}
+
 template <int INPUT>
 int launch_encode(const ecgb_tokenizer *tok, const double *signal, const uint8_t *raw, const QuantParams &qp,
                   size_t batch, size_t n, uint16_t *ids_half, uint32_t *ids_out, size_t ids_stride,
@@ -1315,7 +1358,7 @@ extern "C" void ecgb_debug_set_profile_buffer(unsigned long long *dev) { g_prof_
 
 extern "C" int ecgb_set_encode_plan(int mode)
 {
-    if (mode < 0 || mode > 5) { ecgb::set_error("ecgb_set_encode_plan: mode must be 0..5"); return ECGB_ERR_INVALID; }
+    if (mode < 0 || mode > 6) { ecgb::set_error("ecgb_set_encode_plan: mode must be 0..6"); return ECGB_ERR_INVALID; }
     g_plan_mode = mode;
     return ECGB_OK;
 }
@@ -1360,7 +1403,7 @@ extern "C" size_t ecgb_encode_scratch_bytes(const ecgb_tokenizer *tok, size_t ba
     size_t bytes = std::max(a, b) * sizeof(uint16_t);
     // encode_long_kernel: per resident wave the record as run-length entries (2 B per run, <= one per symbol) and 64 token lists (4 B per token, one per symbol
     // at most plus the run-on margin); only what a record really has is touched (C2: 23 KB + 18 KB of 0.43 MB)
-    if (tok && g_plan_mode == 4 && n_per_stream <= kLongMaxN && make_long_plan(tok, n_per_stream).waves) {
+    if (tok && (g_plan_mode == 4 || g_plan_mode == 6) && n_per_stream <= kLongMaxN && make_long_plan(tok, n_per_stream).waves) {
         const size_t slots = cus * kMaxWaves;
         bytes = std::max(bytes, align_up(slots * long_rle_cap(n_per_stream) * sizeof(uint16_t)) + slots * long_list_cap(n_per_stream) * sizeof(uint32_t));
     }
@@ -1414,6 +1457,10 @@ extern "C" int ecgb_quantize_encode_hip(const ecgb_tokenizer *tok, const double 
     uint16_t *half = reinterpret_cast<uint16_t *>(align_up(reinterpret_cast<uintptr_t>(scratch_dev)));
     // records that fit 16-bit positions, on request: a lane per long chunk of the whole record (encode_long_kernel); otherwise the segment kernels
     // (plan 4 only: measured slower than the segment kernels at every batch size -- encode_long.inc has the numbers -- so the automatic plan does not take it)
+    if (g_plan_mode == 6 && make_long_plan(tok, n_per_record).waves) {
+        rc = launch_encode_pipe(tok, signal_dev, qp, batch, n_per_record, half, ids_dev, ids_stride, counts_dev, st);
+        if (rc != ECGB_ERR_UNSUPPORTED) return rc;
+    }
     if (g_plan_mode == 4) {
         const LongPlan lp = make_long_plan(tok, n_per_record);
         if (lp.waves) return launch_encode_long(tok, lp, signal_dev, qp, batch, n_per_record, half, ids_dev, ids_stride, counts_dev, st);

@@ -37,7 +37,7 @@ def _stream_ptr():
 
 
 def set_encode_plan(mode: int) -> None:
-    """0 = automatic, 1 = workgroup-per-stream kernel, 2 / 3 = wave-per-stream kernel, 4 = lane-per-chunk kernel (encode_long_kernel; opt-in) (tests/tuning)."""
+    """0 = automatic, 1 = workgroup-per-stream kernel, 2 / 3 = wave-per-stream kernel, 4 = lane-per-chunk kernel (encode_long_kernel; opt-in), 6 = the same with stager and walker waves in one workgroup (encode_pipe_kernel) (tests/tuning)."""
     _lib.check(_lib.lib().ecgb_set_encode_plan(int(mode)))
 
 

@@ -444,11 +444,14 @@ def _signal_for_symbols(sym, pc):
     return a + (np.asarray(sym, dtype=np.float64) + 0.5) * d / 26.0
 
 
+LONG_PLAN = 4      # 4: encode_long_kernel; the tests below run a second time under 6 (encode_pipe_kernel: stagers and walkers in one workgroup)
+
+
 def _check_long(tk, merges, syms, pc, **kw):
     """syms: (B, n) alphabet indices; quantise + encode on the lane-per-chunk kernel vs lib.rs's restatement on the symbol text."""
     from ecg_byte_amd.tokenizer import set_encode_plan
     x = _signal_for_symbols(syms, pc)
-    set_encode_plan(4)
+    set_encode_plan(LONG_PLAN)
     try:
         ids, counts = tk.quantize_encode(torch.from_numpy(np.ascontiguousarray(x)).cuda(), pc, **kw)
     finally:
@@ -502,7 +505,7 @@ def test_lane_per_chunk_fixture_tokenizers(dev, tag, L, B):
     x = synth.synth_ecg(min(B, 64), L, seed=4)
     if B > 64:
         x = np.concatenate([x] * ((B + 63) // 64))[:B]
-    set_encode_plan(4)
+    set_encode_plan(LONG_PLAN)
     try:
         ids, counts = tk.quantize_encode(torch.from_numpy(x).cuda(), pc)
         cut, counts2 = tk.quantize_encode(torch.from_numpy(x).cuda(), pc, ids_stride=1020)
@@ -526,7 +529,7 @@ def test_lane_per_chunk_equals_segment_kernels_on_the_bench_batch(dev):
     gains = np.random.default_rng(5).uniform(0.7, 1.3, size=(16, 1, 1, 1))
     xd = torch.from_numpy((base[None] * gains).reshape(4096, 12, 5000)).cuda()
     ids0, counts0 = tk.quantize_encode(xd, pc)
-    set_encode_plan(4)
+    set_encode_plan(LONG_PLAN)
     try:
         ids, counts = tk.quantize_encode(xd, pc)
     finally:
@@ -581,3 +584,30 @@ def test_general_form_quantize_encode(dev):
         text = O.symbols_to_text(O.quantize(x[b], pc["percentile_1"], pc["percentile_99"]))
         ref = np.asarray(O.encode_text(text, wide), dtype=np.uint32)
         assert counts[b] == ref.size and np.array_equal(ids[b, : ref.size].astype(np.uint32), ref), b
+
+
+@pytest.fixture
+def pipe_plan():
+    global LONG_PLAN
+    LONG_PLAN = 6
+    yield
+    LONG_PLAN = 4
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 2047, 4097, 12000, 60000, 65534, 65535])
+def test_pipelined_stage_walk_record_lengths(dev, pipe_plan, n):
+    test_lane_per_chunk_record_lengths(dev, n)
+
+
+def test_pipelined_stage_walk_parses_that_never_meet_and_long_runs(dev, pipe_plan):
+    test_lane_per_chunk_parses_that_never_meet_and_long_runs(dev)
+
+
+@pytest.mark.parametrize("tag,L,B", [("c1", 1000, 5), ("c2", 5000, 3), ("c2", 5000, 300), ("c2", 5000, 9000)])
+def test_pipelined_stage_walk_fixture_tokenizers(dev, pipe_plan, tag, L, B):
+    """9 000 records: more than two rounds of sixteen records per workgroup (slots reused: the stager waits for the walker)."""
+    test_lane_per_chunk_fixture_tokenizers(dev, tag, L, B)
+
+
+def test_pipelined_stage_walk_equals_segment_kernels_on_the_bench_batch(dev, pipe_plan):
+    test_lane_per_chunk_equals_segment_kernels_on_the_bench_batch(dev)
