@@ -16,7 +16,7 @@ tok = HipTokenizer(merges)
 L = _lib.lib()
 L.ecgb_debug_set_profile_buffer.argtypes = [ctypes.c_void_p]
 L.ecgb_debug_set_profile_buffer.restype = None
-set_encode_plan(4)
+set_encode_plan(int(os.environ.get("PLAN", "4")))
 ids, counts = tok.quantize_encode(x, pc, ids_stride=8192)
 torch.cuda.synchronize()
 prof = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
