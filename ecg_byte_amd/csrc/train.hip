@@ -1096,6 +1096,8 @@ __global__ __launch_bounds__(kThreads) void finish_kernel(TrainArgs A, uint32_t 
     for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < s_n; i += (uint64_t)gridDim.x * kThreads) ids_out[i] = src[i];
 }
 
+#include "train_seg.inc"
+
 int check_hip(hipError_t e, const char *what)
 {
     if (e == hipSuccess) return ECGB_OK;
@@ -1108,8 +1110,13 @@ inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 constexpr size_t kMaxIds = (size_t)1 << 41;
 static_assert(kMaxIds / kTile < (1ull << 32) && kMaxIds / kGrid + kTile < (1ull << 32), "32-bit tile numbers and range counts");
 
+// An id buffer: n ids of 32 bits; in the slotted form (train_seg.inc) kGrid slots of ceil(n / G) ids rounded up to 16, 16 ids of padding before the first and a tile
+// and 16 ids after the last (whole-tile loads at a range's end run into the next slot, the last one's into the padding).
+inline size_t buf_bytes(size_t n) { return (n + 16 * (size_t)kGrid + 2 * (size_t)kTile + 64) * 4; }
+inline uint32_t slot_cap(size_t n, unsigned grid) { return (uint32_t)(((n + grid - 1) / grid + 15) / 16 * 16 + 16); }
+
 // carve the state of one trainer (or one shard) out of `scratch`
-TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w)
+TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w, RangeSum **sums = nullptr)
 {
     const size_t V = 256 + (size_t)num_merges;
     const size_t tiles = kGrid;                                         // (records are per range of tiles: one per workgroup of the grid)
@@ -1117,8 +1124,8 @@ TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w
     TrainArgs A;
     A.st = reinterpret_cast<TrainState *>(p); p += align256(sizeof(TrainState));
     A.table = reinterpret_cast<uint64_t *>(p); p += align256(V * V * 8);
-    A.buf[0] = reinterpret_cast<uint32_t *>(p); p += align256(n * 4 + 64);
-    A.buf[1] = reinterpret_cast<uint32_t *>(p); p += align256(n * 4 + 64);
+    A.buf[0] = reinterpret_cast<uint32_t *>(p); p += align256(buf_bytes(n));
+    A.buf[1] = reinterpret_cast<uint32_t *>(p); p += align256(buf_bytes(n));
     A.tiles = reinterpret_cast<TileInfo *>(p); p += align256(tiles * sizeof(TileInfo));
     A.partial = reinterpret_cast<uint64_t *>(p); p += align256(kGrid * 16);
     A.row_cnt = reinterpret_cast<uint64_t *>(p); p += align256(V * 8);
@@ -1129,8 +1136,30 @@ TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w
     A.slab = reinterpret_cast<long long *>(p); p += align256(6 * V * 8);
     A.V = (uint32_t)V;
     A.pairs_out = reinterpret_cast<uint32_t *>(p); p += align256(2 * (size_t)num_merges * 4 + 8);   // (sharded runs keep the pairs here)
+    if (sums) *sums = reinterpret_cast<RangeSum *>(p);
+    p += align256(2 * (size_t)kGrid * sizeof(RangeSum));
     A.n0 = n;
     return A;
+}
+
+template <typename IdT>
+int train_slotted(TrainArgs A, RangeSum *sums, const uint8_t *text_dev, size_t n, uint32_t num_merges, unsigned grid, uint32_t *n_done_dev, uint32_t *ids_out_dev,
+                  uint64_t *n_ids_dev, hipStream_t st)
+{
+    SegArgs<IdT> S;
+    S.A = A;
+    S.cap = slot_cap(n, grid);
+    S.buf[0] = reinterpret_cast<IdT *>(A.buf[0]) + 16;
+    S.buf[1] = reinterpret_cast<IdT *>(A.buf[1]) + 16;
+    S.sum[0] = sums;
+    S.sum[1] = sums + kGrid;
+    hipLaunchKernelGGL(seg_init_kernel<IdT>, dim3(grid), dim3(kThreads), 0, st, S, text_dev);
+    for (uint32_t i = 0; i < num_merges; ++i) {
+        hipLaunchKernelGGL(rowmax_kernel, dim3(kRowGrid), dim3(kThreads), 0, st, A, i);
+        hipLaunchKernelGGL(seg_merge_kernel<IdT>, dim3(grid), dim3(kThreads), 0, st, S, i, kRowGrid);   // (with the final arg-max and the commit)
+    }
+    hipLaunchKernelGGL(seg_finish_kernel<IdT>, dim3(grid), dim3(kThreads), 0, st, S, ids_out_dev, n_ids_dev, n_done_dev);
+    return check_hip(hipGetLastError(), "bpe train launches");
 }
 
 }  // namespace
@@ -1145,12 +1174,24 @@ extern "C" int ecgb_set_bpe_train_grid(int workgroups)
     return ECGB_OK;
 }
 
+// which merge step ecgb_bpe_train_hip runs: 0 = slotted ranges, one pass over the ids per merge (train_seg.inc), 16-bit ids when 256 + num_merges <= 65 536;
+// 1 = the same with 32-bit ids whatever the vocabulary; 2 = round 4's count pass + rewrite over a globally compacted buffer (what the sharded form runs).
+// Like the grid: a process-wide test and tuning hook read at the start of a run.
+static int g_train_form = 0;
+extern "C" int ecgb_set_bpe_train_form(int form)
+{
+    if (form < 0 || form > 2) { ecgb::set_error("ecgb_set_bpe_train_form: 0 (default), 1 or 2"); return ECGB_ERR_INVALID; }
+    g_train_form = form;
+    return ECGB_OK;
+}
+
 extern "C" size_t ecgb_bpe_train_scratch_bytes(size_t n, uint32_t num_merges)
 {
     const size_t V = 256 + (size_t)num_merges;
     const size_t tiles = kGrid;                                         // (records are per range of tiles: one per workgroup of the grid)
-    return align256(sizeof(TrainState)) + align256(V * V * 8) + 2 * align256(n * 4 + 64) + align256(tiles * sizeof(TileInfo)) +
-           align256(kGrid * 16) + align256(V * 8) + 2 * align256(V * 4) + align256(sizeof(Halo)) + align256(6 * V * 8) + align256(2 * (size_t)num_merges * 4 + 8) + 1024;
+    return align256(sizeof(TrainState)) + align256(V * V * 8) + 2 * align256(buf_bytes(n)) + align256(tiles * sizeof(TileInfo)) +
+           align256(kGrid * 16) + align256(V * 8) + 2 * align256(V * 4) + align256(sizeof(Halo)) + align256(6 * V * 8) + align256(2 * (size_t)num_merges * 4 + 8) +
+           align256(2 * (size_t)kGrid * sizeof(RangeSum)) + 1024;
 }
 
 extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t num_merges, uint32_t *pairs_dev,
@@ -1172,7 +1213,8 @@ extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t nu
     hipStream_t st = (hipStream_t)stream;
     const size_t V = 256 + (size_t)num_merges;
     Halo *halo_w;
-    TrainArgs A = layout(scratch_dev, n, num_merges, &halo_w);
+    RangeSum *sums;
+    TrainArgs A = layout(scratch_dev, n, num_merges, &halo_w, &sums);
     A.pairs_out = pairs_dev;
     A.slab = nullptr;                                                    // one rank: count deltas go straight into the table
     int rc = check_hip(hipMemsetAsync(A.table, 0, V * V * 8, st), "hipMemsetAsync(table)");
@@ -1188,6 +1230,10 @@ extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t nu
     const unsigned tile_grid = (unsigned)std::max<size_t>(1, std::min<size_t>(g_train_grid, (n + kTile - 1) / kTile));
     // a range's survivor count is a 32-bit record (TileInfo.count0): the static_assert above covers kGrid ranges, a smaller test grid must keep the bound itself
     if (n / tile_grid + kTile >= (1ull << 32)) { ecgb::set_error("ecgb_bpe_train_hip: " + std::to_string(n) + " ids over " + std::to_string(tile_grid) + " ranges overflow a range's 32-bit count (ecgb_set_bpe_train_grid is a test hook: use the default grid)"); return ECGB_ERR_UNSUPPORTED; }
+    if (g_train_form != 2) {
+        if (g_train_form == 0 && V <= 65536) return train_slotted<uint16_t>(A, sums, text_dev, n, num_merges, tile_grid, n_done_dev, ids_out_dev, n_ids_dev, st);
+        return train_slotted<uint32_t>(A, sums, text_dev, n, num_merges, tile_grid, n_done_dev, ids_out_dev, n_ids_dev, st);
+    }
     hipLaunchKernelGGL(init_kernel, dim3(tile_grid), dim3(kThreads), 0, st, A, text_dev);
     for (uint32_t i = 0; i < num_merges; ++i) {
         hipLaunchKernelGGL(rowmax_kernel, dim3(kRowGrid), dim3(kThreads), 0, st, A, i);
