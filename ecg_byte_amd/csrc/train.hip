@@ -115,6 +115,9 @@ struct Tab { uint64_t *table; };
 __device__ __forceinline__ Tab tab_of(const TrainArgs &A) { return Tab{A.table}; }
 __device__ __forceinline__ void table_add(const Tab &T, uint32_t key, int d)
 {
+#ifdef ECGB_DEV_NO_TABLE_ADD       // timing-only builds (wrong merges): what do the table's atomics cost?
+    if (d == 0x7fffffff)
+#endif
     atomicAdd(reinterpret_cast<unsigned long long *>(&T.table[key]), (unsigned long long)(long long)d);   // two's complement: -1 adds 2^64 - 1
 }
 
@@ -734,8 +737,8 @@ __global__ __launch_bounds__(kThreads) void tile_count_kernel(TrainArgs A, uint3
 #ifdef ECGB_TRAIN_TIMING      // dev builds: shader-clock cycles of every workgroup's phases, summed (scripts/dev_trainer_phases.py)
 __device__ unsigned long long g_phase[16];
 #define PH_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) ph[i] += now_ - last_; last_ = now_; } while (0)
-#define PH_DECL unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long last_ = __builtin_readcyclecounter()
-#define PH_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_phase[i_], ph[i_]); atomicAdd(&g_phase[15], 1ull); } } while (0)
+#define PH_DECL unsigned long long ph[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long last_ = __builtin_readcyclecounter()
+#define PH_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 15; ++i_) atomicAdd(&g_phase[i_], ph[i_]); atomicAdd(&g_phase[15], 1ull); } } while (0)
 #else
 #define PH_MARK(i) do {} while (0)
 #define PH_DECL do {} while (0)

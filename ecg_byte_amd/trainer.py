@@ -15,6 +15,11 @@ def set_train_grid(workgroups: int):
     _lib.check(_lib.lib().ecgb_set_bpe_train_grid(int(workgroups)))
 
 
+def set_train_form(form: int):
+    """Tests and tuning: 0 = slotted ranges, one pass per merge (default); 1 = the same with 32-bit ids; 2 = round 4's two passes; see ecgb_set_bpe_train_form."""
+    _lib.check(_lib.lib().ecgb_set_bpe_train_form(int(form)))
+
+
 def bpe_train_device(text: torch.Tensor, num_merges: int):
     """text: CUDA uint8 1-D tensor.  Returns device tensors (ids int32[n], n_ids int64[1],
     pairs int32[num_merges, 2], n_done int32[1]); nothing is synchronised."""

@@ -166,6 +166,11 @@ int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t num_merges, u
  * trainers started afterwards (ecgb_bpe_train_hip, ecgb_bpe_shard_create).  ECGB_ERR_INVALID outside 0 .. 1 280. */
 int ecgb_set_bpe_train_grid(int workgroups);
 
+/* Tests and tuning: which merge step ecgb_bpe_train_hip runs.  0 (default): every workgroup keeps its range of ids in a fixed slot of the buffer and compacts inside it --
+ * ONE pass over the ids per merge, ids 16 bits wide while 256 + num_merges <= 65 536; 1: the same with 32-bit ids; 2: round 4's count pass + rewrite over a globally
+ * compacted buffer (two passes; what the sharded form runs).  Every value gives the same merges and ids.  Process-wide.  ECGB_ERR_INVALID outside 0 .. 2. */
+int ecgb_set_bpe_train_form(int form);
+
 /* ---- tokenizer training on a corpus sharded over ranks (one process per GPU) ---------------------------
  * The reference trains on ONE string, the concatenation of every sampled record (tokenizer_utils.py:79-93), so pairs -- and merges --
  * straddle record joins.  Here rank r holds a contiguous slice of that string; the result (merges, and the concatenation of the

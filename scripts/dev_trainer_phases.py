@@ -22,7 +22,7 @@ else:
     text = torch.from_numpy(sym + 97).cuda()
 L = _lib.lib()
 out = (ctypes.c_ulonglong * 16)()
-names = ["start (records, state, table init)", "park (wait for the tile, LDS, barrier)", "span, classify, wave scan", "barrier", "walk", "survivors to registers, barrier", "survivors sent", "flush or barrier", "final flush", "chain of records", "last survivors to registers, barrier", "last survivors sent"]
+names = ["start (records, state, table init)", "park (wait for the tile, LDS, barrier)", "span, classify, wave scan", "barrier", "walk", "survivors to registers, barrier", "survivors sent", "flush or barrier", "final flush", "chain of records", "last survivors to registers, barrier", "last survivors sent", "range record, before the flush", "flush: first barrier", "flush: sweep and adds"]
 def phases(merges):
     bpe_train_device(text, merges); torch.cuda.synchronize()
     L.ecgb_dev_train_phases(out)
@@ -33,6 +33,6 @@ lo, hi = int(os.environ.get("FROM", "0")), int(os.environ.get("TO", "4000"))
 a = phases(lo) if lo > 0 else [0] * 16
 b = phases(hi)
 d = [y - x for x, y in zip(a, b)]
-tot = sum(d[:12])
+tot = sum(d[:15])
 print(f"merges {lo}..{hi}: workgroups {d[15]}, cycles per workgroup {tot / d[15]:.0f}")
 for i, nm in enumerate(names): print(f"  {nm:45s} {100.0 * d[i] / tot:5.1f} %   {d[i] / d[15]:9.0f} cycles per workgroup")

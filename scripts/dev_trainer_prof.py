@@ -21,7 +21,16 @@ else:
     steps = rng.integers(-1, 2, size=n, dtype=np.int8)
     sym = np.clip(np.cumsum(steps) % 52, 0, 51); sym = np.where(sym > 25, 51 - sym, sym).astype(np.uint8)
     text = torch.from_numpy(sym + 97).cuda()
-for rep in range(2):
+from ecg_byte_amd import trainer
+forms = [int(f) for f in os.environ.get("FORMS", "0").split(",")]          # ecgb_set_bpe_train_form: 0 slotted ranges + 16-bit ids, 1 slotted + 32-bit, 2 round 4's two passes
+ref = None
+for form in forms:
+  trainer.set_train_form(form)
+  for rep in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ids, n_ids, pairs, n_done = bpe_train_device(text, 4000)
-    torch.cuda.synchronize(); print(f"{time.perf_counter() - t0:.3f} s, merges {int(n_done.item())}, ids {int(n_ids.item())}")
+    torch.cuda.synchronize(); print(f"form {form}: {time.perf_counter() - t0:.3f} s, merges {int(n_done.item())}, ids {int(n_ids.item())}")
+  got = (ids[: int(n_ids.item())].clone(), pairs.clone())
+  if ref is None: ref = got
+  else: print("  same ids and merges as the first form:", torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]))
+trainer.set_train_form(0)

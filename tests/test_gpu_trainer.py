@@ -10,6 +10,19 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+@pytest.fixture(autouse=True, params=[0, 1, 2], ids=["slotted16", "slotted32", "two_pass"])
+def train_form(request):
+    """Every test of the file under the three merge steps of ecgb_bpe_train_hip (ecgb_set_bpe_train_form): ranges in fixed slots with one pass per merge and 16-bit
+    ids (the default), the same with 32-bit ids, round 4's count pass + rewrite.  The sharded form has its own kernels: once."""
+    from ecg_byte_amd import trainer
+    name = request.node.name
+    if request.param and ("sharded" in name or "kept_row_maxima" in name):
+        pytest.skip("does not go through ecgb_bpe_train_hip's merge step")
+    trainer.set_train_form(request.param)
+    yield request.param
+    trainer.set_train_form(0)
+
+
 def _train(text, num_merges):
     from ecg_byte_amd import rust_bpe
     return rust_bpe.byte_pair_encoding(text, num_merges, 1)
