@@ -1113,10 +1113,11 @@ inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 constexpr size_t kMaxIds = (size_t)1 << 41;
 static_assert(kMaxIds / kTile < (1ull << 32) && kMaxIds / kGrid + kTile < (1ull << 32), "32-bit tile numbers and range counts");
 
-// An id buffer: n ids of 32 bits; in the slotted form (train_seg.inc) kGrid slots of ceil(n / G) ids rounded up to 16, 16 ids of padding before the first and a tile
+// An id buffer: n ids of 32 bits; in the slotted form (train_seg.inc) up to 4 kGrid slots of ceil(n / R) ids rounded up to 16 and 16 more, 16 ids of padding before the first and a tile
 // and 16 ids after the last (whole-tile loads at a range's end run into the next slot, the last one's into the padding).
-inline size_t buf_bytes(size_t n) { return (n + 16 * (size_t)kGrid + 2 * (size_t)kTile + 64) * 4; }
-inline uint32_t slot_cap(size_t n, unsigned grid) { return (uint32_t)(((n + grid - 1) / grid + 15) / 16 * 16 + 16); }
+constexpr size_t kMaxRanges = 4 * (size_t)kGrid;                      // (a range a wave)
+inline size_t buf_bytes(size_t n) { return (n + 32 * kMaxRanges + 2 * (size_t)kTile + 64) * 4; }
+inline uint32_t slot_cap(size_t n, unsigned ranges) { return (uint32_t)(((n + ranges - 1) / ranges + 15) / 16 * 16 + 16); }
 
 // carve the state of one trainer (or one shard) out of `scratch`
 TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w, RangeSum **sums = nullptr)
@@ -1140,7 +1141,7 @@ TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w
     A.V = (uint32_t)V;
     A.pairs_out = reinterpret_cast<uint32_t *>(p); p += align256(2 * (size_t)num_merges * 4 + 8);   // (sharded runs keep the pairs here)
     if (sums) *sums = reinterpret_cast<RangeSum *>(p);
-    p += align256(2 * (size_t)kGrid * sizeof(RangeSum));
+    p += align256(2 * kMaxRanges * sizeof(RangeSum));
     A.n0 = n;
     return A;
 }
@@ -1151,17 +1152,18 @@ int train_slotted(TrainArgs A, RangeSum *sums, const uint8_t *text_dev, size_t n
 {
     SegArgs<IdT> S;
     S.A = A;
-    S.cap = slot_cap(n, grid);
+    S.ranges = std::min<uint32_t>(kSegRanges, grid * (kThreads / 64));      // (a range a wave; the tests' small grids: four ranges a workgroup of the old form)
+    S.cap = slot_cap(n, S.ranges);
     S.buf[0] = reinterpret_cast<IdT *>(A.buf[0]) + 16;
     S.buf[1] = reinterpret_cast<IdT *>(A.buf[1]) + 16;
     S.sum[0] = sums;
-    S.sum[1] = sums + kGrid;
+    S.sum[1] = sums + kMaxRanges;
     hipLaunchKernelGGL(seg_init_kernel<IdT>, dim3(grid), dim3(kThreads), 0, st, S, text_dev);
     for (uint32_t i = 0; i < num_merges; ++i) {
         hipLaunchKernelGGL(rowmax_kernel, dim3(kRowGrid), dim3(kThreads), 0, st, A, i);
-        hipLaunchKernelGGL(seg_merge_kernel<IdT>, dim3(grid), dim3(kThreads), 0, st, S, i, kRowGrid);   // (with the final arg-max and the commit)
+        hipLaunchKernelGGL(seg_merge_kernel<IdT>, dim3((S.ranges + kSegWaves - 1) / kSegWaves), dim3(kSegThreads), 0, st, S, i, kRowGrid);   // (with the final arg-max and the commit)
     }
-    hipLaunchKernelGGL(seg_finish_kernel<IdT>, dim3(grid), dim3(kThreads), 0, st, S, ids_out_dev, n_ids_dev, n_done_dev);
+    hipLaunchKernelGGL(seg_finish_kernel<IdT>, dim3(S.ranges), dim3(kThreads), 0, st, S, ids_out_dev, n_ids_dev, n_done_dev);
     return check_hip(hipGetLastError(), "bpe train launches");
 }
 
@@ -1194,7 +1196,7 @@ extern "C" size_t ecgb_bpe_train_scratch_bytes(size_t n, uint32_t num_merges)
     const size_t tiles = kGrid;                                         // (records are per range of tiles: one per workgroup of the grid)
     return align256(sizeof(TrainState)) + align256(V * V * 8) + 2 * align256(buf_bytes(n)) + align256(tiles * sizeof(TileInfo)) +
            align256(kGrid * 16) + align256(V * 8) + 2 * align256(V * 4) + align256(sizeof(Halo)) + align256(6 * V * 8) + align256(2 * (size_t)num_merges * 4 + 8) +
-           align256(2 * (size_t)kGrid * sizeof(RangeSum)) + 1024;
+           align256(2 * kMaxRanges * sizeof(RangeSum)) + 1024;
 }
 
 extern "C" int ecgb_bpe_train_hip(const uint8_t *text_dev, size_t n, uint32_t num_merges, uint32_t *pairs_dev,

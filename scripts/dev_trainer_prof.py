@@ -16,7 +16,7 @@ if os.environ.get("CORPUS") == "c2":                    # the bench's trainer le
     del x
 else:
     rng = np.random.default_rng(1)
-    n = 2000 * 12 * 5000
+    n = int(os.environ.get("N", 2000 * 12 * 5000))
     # a random walk over 26 symbols: neighbouring samples differ by at most one level, like a quantised ECG
     steps = rng.integers(-1, 2, size=n, dtype=np.int8)
     sym = np.clip(np.cumsum(steps) % 52, 0, 51); sym = np.where(sym > 25, 51 - sym, sym).astype(np.uint8)
