@@ -361,8 +361,9 @@ def device_selfcheck():
 
 def bench_trainer(pc, L, x, num_merges=4000):
     """rust_bpe.byte_pair_encoding on the device for the C2 tokenizer's own corpus (2 000 synthetic records, seed 1).
-    Algorithmic bytes per merge i: 4 N_i (count) + 4 N_i + 4 N_{i+1} (rewrite); the N_i are recovered exactly from the result (undoing merge
-    i splits every token 256 + i into its two children)."""
+    Algorithmic bytes per merge i: the ids read once and the survivors written once, two bytes an id (256 + 4 000 ids fit 16 bits): 2 N_i + 2 N_{i+1}; the
+    N_i are recovered exactly from the result (undoing merge i splits every token 256 + i into its two children).  Rounds 3-4 priced the two-pass form's own
+    traffic (12 bytes per id and merge: `frac_at_round4_bytes`, the yardstick of their 0.35)."""
     import torch
     from ecg_byte_amd.tokenizer import quantize
     from ecg_byte_amd.trainer import bpe_train_device
@@ -387,10 +388,12 @@ def bench_trainer(pc, L, x, num_merges=4000):
         cnt[pr[i, 1]] += c
         N[i] = N[i + 1] + c
     assert N[0] == text.numel(), (N[0], text.numel())
-    alg = sum(8 * N[i] + 4 * N[i + 1] for i in range(k))
+    alg = sum(2 * N[i] + 2 * N[i + 1] for i in range(k))
+    alg_r4 = sum(8 * N[i] + 4 * N[i + 1] for i in range(k))
     return {"workload": f"{n_records} records of 12x{L} = {text.numel()} symbols, {num_merges} merges (the corpus of tokenizer_c2.pkl)",
             "seconds": best, "merges_done": k, "final_ids": m, "compression": text.numel() / max(m, 1),
             "algorithmic_bytes": alg, "GB/s": alg / best / 1e9, "frac_of_hbm_peak": alg / best / 1e9 / HBM_PEAK_GBS,
+            "frac_at_round4_bytes": alg_r4 / best / 1e9 / HBM_PEAK_GBS, "form": "slotted ranges, one pass per merge, 16-bit ids",
             "merges_per_s": k / best}
 
 

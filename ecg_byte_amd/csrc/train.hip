@@ -16,6 +16,8 @@
 //   2. survivor counts: each workgroup streams its contiguous range of tiles and leaves ONE record   (reads N_i)
 //   3. rewrite + compaction + count deltas: each workgroup chains the records below its own (its output offset, the run parity entering its range), then walks its
 //      range in order, carrying both   (reads N_i, writes N_{i+1})
+// (The one-rank trainer's default since round 5 is train_seg.inc: every wave keeps its range of ids in a fixed slot and compacts inside it -- steps 2 and 3 become ONE pass,
+//  ids 16 bits wide while the vocabulary fits.  The two-pass form below is what the sharded entry points run, and ecgb_set_bpe_train_form(2).)
 // Runs of one symbol merged with itself ("aaa" -> "Xa") need the offset parity inside the run;
 // tiles and per-thread spans are even-sized, so parity is carried by a "last non-uniform span"
 // look-up instead of a full segmented scan.  No host synchronisation inside the merge loop: the
@@ -271,14 +273,14 @@ __global__ __launch_bounds__(kThreads) void rowmax_kernel(TrainArgs A, uint32_t 
             // Within one merge a cell only shrinks or only grows.  A shrinking cell lowers the row's maximum iff it IS the maximum: the kept cell no longer holds the kept
             // count.  A growing cell's pair holds the merge's new id: it lies in the newest id's row (all new: read) or column (one cell a row, looked at here).
             bool again = A.row_dirty[row] || row == newest;                              // (row_dirty: not read yet since the table was built)
-            if (!again && oc != 0 && A.table[~ok] != oc) again = true;
+            // the kept cell and the row's cell in the newest id's column, asked for together (one after the other they were two memory round trips of a 7 us kernel)
+            const uint32_t cell = row * A.V + (newest != kEmpty ? newest : 0u);
+            const unsigned long long kept_now = A.table[oc != 0 ? ~ok : cell];
+            const unsigned long long c = A.table[cell];
+            if (!again && oc != 0 && kept_now != oc) again = true;
             if (again) s_rows[atomicAdd(&s_n, 1u)] = row;
             else {
-                if (newest != kEmpty) {
-                    const uint32_t cell = row * A.V + newest;
-                    const unsigned long long c = A.table[cell];
-                    if (better(c, ~cell, oc, ok)) { oc = c; ok = ~cell; A.row_cnt[row] = oc; A.row_key[row] = ok; }
-                }
+                if (newest != kEmpty && better(c, ~cell, oc, ok)) { oc = c; ok = ~cell; A.row_cnt[row] = oc; A.row_key[row] = ok; }
                 if (better(oc, ok, my_best, my_key)) { my_best = oc; my_key = ok; }
             }
         }
@@ -289,11 +291,16 @@ __global__ __launch_bounds__(kThreads) void rowmax_kernel(TrainArgs A, uint32_t 
             unsigned long long best = 0;
             uint32_t bkey = 0;
             const uint64_t *cells = A.table + (size_t)again * A.V;
-#pragma unroll 4
-            for (uint32_t c = threadIdx.x; c < v_cur; c += kThreads) {
-                const unsigned long long cnt = cells[c];
-                const uint32_t k = ~(again * A.V + c);
-                if (better(cnt, k, best, bkey)) { best = cnt; bkey = k; }
+            // sixteen cells a lane in flight (four at a time a row of 4 256 counts was five memory round trips, one after the other)
+            for (uint32_t c0 = threadIdx.x; c0 < v_cur; c0 += 16 * kThreads) {
+                unsigned long long cnt[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const uint32_t c = c0 + (uint32_t)u * kThreads; cnt[u] = c < v_cur ? cells[c] : 0ull; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const uint32_t k = ~(again * A.V + c0 + (uint32_t)u * kThreads);
+                    if (better(cnt[u], k, best, bkey)) { best = cnt[u]; bkey = k; }
+                }
             }
             for (int d = 32; d > 0; d >>= 1) {
                 const unsigned long long oc = __shfl_down(best, d, 64);

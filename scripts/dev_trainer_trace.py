@@ -8,7 +8,7 @@ for k, v in per.items():
     if len(v) < 4000: continue
     v.sort(); v = v[-4000:]           # second repetition
     d = [e - s for s, e in v]
-    print(k, 'total ms', sum(d) / 1e6, ' per-merge us at merges 0,10,100,500,1000,2000,3999:', [round(d[i] / 1e3, 1) for i in (0, 10, 100, 500, 1000, 2000, 3999)])
+    print(k, 'total ms', sum(d) / 1e6, ' per-merge us at merges 0,10,100,500,1000,2000,3999:', [round(d[i] / 1e3, 1) for i in (0, 10, 100, 500, 1000, 2000, 3999)], ' mean of 3100..3900:', round(sum(d[3100:3900]) / 800e3, 2))
 # gaps: time between consecutive kernels in the second repetition
 allk = sorted((s, e) for v in per.values() for s, e in v)
 allk = allk[len(allk) // 2:]
