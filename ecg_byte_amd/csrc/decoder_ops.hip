@@ -64,10 +64,17 @@ __device__ __forceinline__ unsigned argmax_key(unsigned short b)
     if ((u & 0x7FFFu) > 0x7F80u) return 0xFFFFu;            // NaN: above everything
     return (u & 0x8000u) ? (0x7FFFu - (u & 0x7FFFu)) : (0x8000u | u);   // monotone in the bf16 value (-0 just below +0: torch compares them equal -- first index wins there, see below)
 }
+// One row over `parts` workgroups (a decode step's single row of 256 000 logits through ONE workgroup was 30 us: 512 KB through one CU, four memory round trips;
+// gridDim.y = parts).  Each part's best key goes into the row's slot of g_argmax_key by atomic max -- the maximum of the keys is what it is whatever the order --
+// and the part that arrives last writes the index and leaves slot and ticket as it found them (zero) for the next launch.
+constexpr int kArgmaxSlots = 4096;
+__device__ unsigned long long g_argmax_key[kArgmaxSlots];
+__device__ unsigned g_argmax_ticket[kArgmaxSlots];
 __global__ __launch_bounds__(1024) void argmax_rows_kernel(const unsigned short *x, long long ld, int n, long long *out)
 {
     __shared__ unsigned long long s_best[16];
     const unsigned short *row = x + (long long)blockIdx.x * ld;
+    const int parts = (int)gridDim.y, part = (int)blockIdx.y;
     // one 64-bit key per candidate: value key above, ~index below -- the maximum of the keys is the greatest value at the lowest index
     unsigned long long best = 0;
     auto take = [&](unsigned short b, int i) {
@@ -77,23 +84,24 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const unsigned short 
         best = key > best ? key : best;
     };
     const int head = (int)((16 - ((uintptr_t)row & 15)) & 15) / 2;     // elements before the first 16-byte boundary (rows of an odd-width matrix)
-    for (int i = threadIdx.x; i < min(head, n); i += 1024) take(row[i], i);
+    if (part == 0) for (int i = threadIdx.x; i < min(head, n); i += 1024) take(row[i], i);
     const int body = n > head ? (n - head) / 8 : 0;
-    constexpr int U = 8;                                      // 16-byte pieces in flight per thread: a 260 000-wide row is 32 pieces per thread, a chain of 32 memory latencies one at a time
-    for (int c0 = threadIdx.x; c0 < body; c0 += 1024 * U) {
+    const int per = (body + parts - 1) / parts, b_lo = min(body, part * per), b_hi = min(body, b_lo + per);      // this part's 16-byte pieces
+    constexpr int U = 8;                                      // 16-byte pieces in flight per thread
+    for (int c0 = b_lo + (int)threadIdx.x; c0 < b_hi; c0 += 1024 * U) {
         bf16x8 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const bf16x8 *>(row + head + min(c0 + 1024 * u, body - 1) * 8);
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const bf16x8 *>(row + head + (long long)min(c0 + 1024 * u, b_hi - 1) * 8);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = c0 + 1024 * u;
-            if (c < body) {
+            if (c < b_hi) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) take((unsigned short)v[u][j], head + c * 8 + j);
             }
         }
     }
-    for (int i = head + body * 8 + threadIdx.x; i < n; i += 1024) take(row[i], i);
+    if (part == parts - 1) for (int i = head + body * 8 + threadIdx.x; i < n; i += 1024) take(row[i], i);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         const unsigned long long o = __shfl_xor(best, d, 64);
@@ -104,7 +112,14 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const unsigned short 
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int w = 1; w < 16; ++w) best = s_best[w] > best ? s_best[w] : best;
-        out[blockIdx.x] = (long long)(0x7FFFFFFF - (unsigned)(best & 0xFFFFFFFFu));
+        if (parts == 1) { out[blockIdx.x] = (long long)(0x7FFFFFFF - (unsigned)(best & 0xFFFFFFFFu)); return; }
+        atomicMax(&g_argmax_key[blockIdx.x], best);
+        __threadfence();
+        if (atomicAdd(&g_argmax_ticket[blockIdx.x], 1u) == (unsigned)parts - 1u) {                 // the last part in
+            const unsigned long long all = atomicExch(&g_argmax_key[blockIdx.x], 0ull);
+            g_argmax_ticket[blockIdx.x] = 0u;
+            out[blockIdx.x] = (long long)(0x7FFFFFFF - (unsigned)(all & 0xFFFFFFFFu));
+        }
     }
 }
 
@@ -1100,7 +1115,10 @@ extern "C" int ecgb_set_ce_in_registers(int on) { g_ce_in_registers = on ? 1 : 0
 extern "C" int ecgb_argmax_bf16(const void *x_dev, long long ld, int rows, int n, int64_t *out_dev, void *stream)
 {
     if (!x_dev || !out_dev || rows <= 0 || n <= 0 || ld < n) { ecgb::set_error("ecgb_argmax_bf16: bad argument"); return ECGB_ERR_INVALID; }
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, (const unsigned short *)x_dev, ld, n, (long long *)out_dev);
+    // few rows of many columns (generate: one row of the vocabulary per sequence): a row over up to 32 workgroups; concurrent launches on different streams would share the
+    // slots, so only the few-row case, which the decode graph issues one at a time, splits
+    const unsigned parts = (rows <= 16 && rows <= kArgmaxSlots) ? (unsigned)std::max(1, std::min(32, n / 8192)) : 1u;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)rows, parts), dim3(1024), 0, (hipStream_t)stream, (const unsigned short *)x_dev, ld, n, (long long *)out_dev);
     ECGB_CHECK_LAUNCH("argmax_rows");
 }
 
