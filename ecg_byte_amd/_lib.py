@@ -160,6 +160,7 @@ def lib():
         "ecgb_attn_decode_split": [vp, vp, vp, ll, ll, vp, ll, vp, ci, ci, ci, ci, ci, f32, ci, vp, sz, vp],
         "ecgb_kv_append": [vp, ll, ll, ci, vp, ll, ci, vp, vp],
         "ecgb_argmax_bf16": [vp, ll, ci, ci, vp, vp],
+        "ecgb_decode_advance": [vp, ci, vp, vp, vp, vp, vp, ll, vp, ll, vp, ll, vp, ci, vp],
         "ecgb_gemm_nt_w4_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, vp],
         "ecgb_gemm_nn_w4_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, vp],
         "ecgb_gemm_tn_w4_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, vp],

@@ -111,6 +111,17 @@ def gemm_nt_w4(a, b, alpha=1.0, out=None):
     return out
 
 
+def decode_advance_(nxt, tok, pos, col, n_dev, out, mask, unfinished=None, pad_id=0, eos=None):
+    """The bookkeeping of one generated token per sequence in one launch (ecgb_decode_advance): finished sequences take pad_id, the token goes to out[:, col] and into
+    `tok`, mask[:, col] = 1, pos / col / n_dev advance, `unfinished` drops sequences that produced an eos id.  Everything in place."""
+    B = nxt.shape[0]
+    assert nxt.dtype == torch.int64 and out.dtype == torch.int64 and mask.dtype == torch.float32 and n_dev.dtype == torch.int32
+    assert out.stride(1) == 1 and mask.stride(1) == 1 and col.numel() == B and tok.numel() == B and pos.numel() == B
+    n_eos = 0 if eos is None else int(eos.numel())
+    _lib.check(_L().ecgb_decode_advance(_p(nxt), B, _p(tok), _p(pos), _p(col), _p(n_dev), _p(out), out.stride(0), _p(mask), mask.stride(0),
+                                        _p(unfinished) if n_eos else None, int(pad_id), _p(eos) if n_eos else None, n_eos, _st()))
+
+
 def argmax_rows(x, n=None):
     """torch.argmax(x[:, :n], -1) of a bf16 matrix (first index of the maximum), one launch without workspace (ecgb_argmax_bf16)."""
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1

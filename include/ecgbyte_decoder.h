@@ -350,6 +350,14 @@ int ecgb_rope_append(void *qkv_dev, const float *cos_dev, const float *sin_dev, 
  * out[r] = index of the first maximum of the bf16 row x[r, 0:n] (rows `ld` elements apart).  One launch, no workspace. */
 int ecgb_argmax_bf16(const void *x_dev, long long ld, int rows, int n, int64_t *out_dev, void *stream);
 
+/* What generate()'s loop does with the chosen tokens, for a decode step replayed from a graph (GenerationMixin._sample, generation/utils.py:3208-3232: finished sequences
+ * take pad_token_id, `input_ids = torch.cat([input_ids, next_tokens[:, None]], dim=-1)`, the attention mask grows by a column of ones, `unfinished_sequences` is and-ed with
+ * "not an eos id"), in ONE launch instead of six to eleven element-wise ones (5 us each in the graph).  For every sequence b of `batch`:
+ *     t = unfinished[b] ? next[b] : pad_id;   unfinished[b] &= t is none of eos[0..n_eos);   out[b][col[b]] = t;   mask[b][col[b]] = 1;   tok[b] = t;   pos[b] += 1;   col[b] += 1
+ * and *n_dev += 1.  All int64 except mask (float32) and n_dev (int32[1]); eos_dev may be NULL (n_eos 0): `unfinished` is then neither read nor written. */
+int ecgb_decode_advance(const int64_t *next_dev, int batch, int64_t *tok_dev, int64_t *pos_dev, int64_t *col_dev, int *n_dev, int64_t *out_dev, long long out_ld,
+                        float *mask_dev, long long mask_ld, int64_t *unfinished_dev, long long pad_id, const int64_t *eos_dev, int n_eos, void *stream);
+
 /* ---- the decode step of generate() for one or two sequences, fused (csrc/decode.hip; round 5) -----------------------------------------------------------------
  * Replaces, per layer and token: ecgb_rmsnorm_lora_fwd + ecgb_gemm_nt_bf16_cat (q|k|v), ecgb_rope_append + ecgb_attn_decode_split (three kernels), the few-row GEMMs of
  * the adapters' down-projections, ecgb_rmsnorm_fwd + the GLU GEMV.  Every sum is formed in the order of the kernels replaced: the same bits (tests/test_gpu_decode_fused.py).
