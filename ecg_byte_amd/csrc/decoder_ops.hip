@@ -1123,6 +1123,25 @@ extern "C" int ecgb_argmax_bf16(const void *x_dev, long long ld, int rows, int n
 }
 
 namespace {
+__global__ void rope_table_kernel(const long long *pos, int n, const float *inv_freq, int half, float *cos_out, float *sin_out)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n * half; k += gridDim.x * blockDim.x) {
+        const float fr = (float)pos[k / half] * inv_freq[k % half];
+        cos_out[k] = cosf(fr);
+        sin_out[k] = sinf(fr);
+    }
+}
+}  // namespace
+
+extern "C" int ecgb_rope_table(const int64_t *pos_dev, int n, const float *inv_freq_dev, int half, float *cos_out_dev, float *sin_out_dev, void *stream)
+{
+    if (!pos_dev || !inv_freq_dev || !cos_out_dev || !sin_out_dev || n <= 0 || half <= 0) { ecgb::set_error("ecgb_rope_table: bad argument"); return ECGB_ERR_INVALID; }
+    hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)std::min(64, (n * half + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const long long *)pos_dev, n, inv_freq_dev,
+                       half, cos_out_dev, sin_out_dev);
+    ECGB_CHECK_LAUNCH("rope_table");
+}
+
+namespace {
 __global__ void decode_advance_kernel(const long long *next, int batch, long long *tok, long long *pos, long long *col, int *n_dev, long long *out, long long out_ld,
                                       float *mask, long long mask_ld, long long *unfinished, long long pad_id, const long long *eos, int n_eos)
 {

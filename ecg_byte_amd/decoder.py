@@ -928,7 +928,10 @@ class HipCausalLM(nn.Module):
         D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
         QKV = self.qkv
         scale = 1.0 / math.sqrt(D)
-        cos, sin = self._rope_tables(pos)
+        if pos.dtype == torch.int64 and self.inv_freq.dtype == torch.float32:
+            cos, sin = ops.rope_table(pos, self.inv_freq)               # (the four element-wise kernels of _rope_tables in one launch, the same bits)
+        else:
+            cos, sin = self._rope_tables(pos)
         x = ops.embed_fwd(tokens, self.embed.data, self.embed_scale)    # [B, H]
         delta = None
         # (opt-in: the fused kernels of csrc/decode.hip are bit-exact but measured no faster than the separate ones at the C5 shape -- 2.20 against 2.14 ms a token; every

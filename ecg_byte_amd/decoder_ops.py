@@ -111,6 +111,17 @@ def gemm_nt_w4(a, b, alpha=1.0, out=None):
     return out
 
 
+def rope_table(pos, inv_freq):
+    """(cos, sin) [n, half] fp32 of float(pos) * inv_freq: the bits of the four torch kernels of `(pos.float()[:, None] * inv_freq[None, :]).cos() / .sin()`, one launch."""
+    pos = pos.reshape(-1)
+    assert pos.dtype == torch.int64 and inv_freq.dtype == torch.float32 and inv_freq.is_contiguous()
+    n, half = pos.numel(), inv_freq.numel()
+    cos = torch.empty((n, half), dtype=torch.float32, device=pos.device)
+    sin = torch.empty_like(cos)
+    _lib.check(_L().ecgb_rope_table(_p(pos.contiguous()), n, _p(inv_freq), half, _p(cos), _p(sin), _st()))
+    return cos, sin
+
+
 def decode_advance_(nxt, tok, pos, col, n_dev, out, mask, unfinished=None, pad_id=0, eos=None):
     """The bookkeeping of one generated token per sequence in one launch (ecgb_decode_advance): finished sequences take pad_id, the token goes to out[:, col] and into
     `tok`, mask[:, col] = 1, pos / col / n_dev advance, `unfinished` drops sequences that produced an eos id.  Everything in place."""

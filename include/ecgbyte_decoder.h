@@ -350,6 +350,10 @@ int ecgb_rope_append(void *qkv_dev, const float *cos_dev, const float *sin_dev, 
  * out[r] = index of the first maximum of the bf16 row x[r, 0:n] (rows `ld` elements apart).  One launch, no workspace. */
 int ecgb_argmax_bf16(const void *x_dev, long long ld, int rows, int n, int64_t *out_dev, void *stream);
 
+/* The RoPE table rows of a decode step: cos_out / sin_out [n, half] (fp32) = cos / sin of float(pos[i]) * inv_freq[j], the fp32 product rounded once -- the bits of
+ * `fr = pos.float()[:, None] * inv_freq[None, :]; fr.cos(), fr.sin()` (LlamaRotaryEmbedding.forward, modeling_llama.py:119-139, in fp32), one launch instead of four. */
+int ecgb_rope_table(const int64_t *pos_dev, int n, const float *inv_freq_dev, int half, float *cos_out_dev, float *sin_out_dev, void *stream);
+
 /* What generate()'s loop does with the chosen tokens, for a decode step replayed from a graph (GenerationMixin._sample, generation/utils.py:3208-3232: finished sequences
  * take pad_token_id, `input_ids = torch.cat([input_ids, next_tokens[:, None]], dim=-1)`, the attention mask grows by a column of ones, `unfinished_sequences` is and-ed with
  * "not an eos id"), in ONE launch instead of six to eleven element-wise ones (5 us each in the graph).  For every sequence b of `batch`:

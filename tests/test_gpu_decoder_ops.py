@@ -707,6 +707,16 @@ def test_decode_attention_single_and_split_kernels(ops, D, Hq, Hkv, B, n):
     assert ops.decode_splits(100, 1, 8) == 1 and ops.decode_splits(2048, 1, 8) == 32 and ops.decode_splits(700, 8, 8) == 10
 
 
+def test_rope_table_is_the_torch_expression_bit_for_bit(ops):
+    """ecgb_rope_table = (pos.float()[:, None] * inv_freq[None, :]).cos() / .sin() (modeling_llama.py:119-139 in fp32): the decode step's one launch for four."""
+    for D, theta in ((64, 500000.0), (256, 10000.0), (128, 10000.0)):
+        inv_freq = (1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.float32) / D))).cuda()
+        pos = torch.cat([torch.arange(0, 4200), torch.tensor([8191, 32767, 131071, 1 << 20])]).cuda()
+        fr = pos.float()[:, None] * inv_freq[None, :]
+        cos, sin = ops.rope_table(pos, inv_freq)
+        assert torch.equal(cos, fr.cos()) and torch.equal(sin, fr.sin()), D
+
+
 @pytest.mark.parametrize("rows,n,ld", [(1, 259759, 259776), (3, 1000, 1000), (8, 4099, 4103), (2, 7, 9), (5, 300, 304), (4, 70001, 70005), (16, 33000, 33008), (17, 33000, 33008)])
 def test_argmax_rows_is_torch_argmax(ops, rows, n, ld):
     """ecgb_argmax_bf16 (the greedy token choice of generate()) = torch.argmax over the first n columns: the FIRST index of the maximum with ties
