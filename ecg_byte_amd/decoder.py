@@ -958,8 +958,12 @@ class HipCausalLM(nn.Module):
                 else:
                     ao = ops.attn_decode_dyn(qkv, caches[i], mask, n_dev, Hq, Hkv, D, scale)
             attn_delta, _ = self._proj(i, "o", ao, self.wo[i].data)
-            h2, _, x = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma)
-            _, hm, _ = self._proj_glu(i, h2, keep_gu=False)
+            if self.lora is not None and not self.training:             # (the gate|up site's t on the norm's way out too: one launch less a layer, the same bits)
+                site = self.lora[i]["gu"]
+                h2, _, x, t2 = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma, lora=(site.A.data, site.scale))
+            else:
+                (h2, _, x), t2 = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma), None
+            _, hm, _ = self._proj_glu(i, h2, keep_gu=False, t_pre=t2)
             delta, _ = self._proj(i, "down", hm, self.wdown[i].data)
         hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
         return hf
