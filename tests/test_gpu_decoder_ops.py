@@ -707,6 +707,35 @@ def test_decode_attention_single_and_split_kernels(ops, D, Hq, Hkv, B, n):
     assert ops.decode_splits(100, 1, 8) == 1 and ops.decode_splits(2048, 1, 8) == 32 and ops.decode_splits(700, 8, 8) == 10
 
 
+def test_decode_advance_is_the_generate_loops_bookkeeping(ops):
+    """ecgb_decode_advance against the element-wise torch lines it replaces in the replayed decode step (generation/utils.py:3208-3232): finished sequences take the pad id,
+    the eos test on the padded token, the token into `out` / `tok`, the mask's new column, the counters; with and without eos ids."""
+    B, cap, pad = 5, 40, 7
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for eos in (None, torch.tensor([11, 13], device="cuda"), torch.tensor([pad], device="cuda")):
+        col = torch.randint(5, 30, (B, 1), device="cuda", generator=g)
+        st = dict(tok=torch.zeros(B, dtype=torch.long, device="cuda"), pos=torch.randint(0, 50, (B,), device="cuda", generator=g), col=col.clone(),
+                  n_dev=torch.full((1,), 9, dtype=torch.int32, device="cuda"), out=torch.randint(0, 99, (B, cap), device="cuda", generator=g),
+                  mask=torch.zeros((B, cap), device="cuda"), unfinished=torch.tensor([1, 0, 1, 1, 0], device="cuda"))
+        want = {k: v.clone() for k, v in st.items()}
+        for step in range(3):
+            nx = torch.tensor([11, 5, 20 + step, 13 if step == 1 else 2, 9], device="cuda")
+            # the torch lines
+            t = nx
+            if eos is not None:
+                t = nx * want["unfinished"] + pad * (1 - want["unfinished"])
+                want["unfinished"] = want["unfinished"] * (t[:, None] != eos[None, :]).all(1).long()
+            want["out"].scatter_(1, want["col"], t[:, None])
+            want["mask"].scatter_(1, want["col"], torch.ones((B, 1), device="cuda"))
+            want["tok"] = t.clone()
+            want["pos"] = want["pos"] + 1
+            want["n_dev"] = want["n_dev"] + 1
+            want["col"] = want["col"] + 1
+            ops.decode_advance_(nx, st["tok"], st["pos"], st["col"], st["n_dev"], st["out"], st["mask"], st["unfinished"], pad, eos)
+            for k in st:
+                assert torch.equal(st[k], want[k]), (k, step, eos)
+
+
 def test_rope_table_is_the_torch_expression_bit_for_bit(ops):
     """ecgb_rope_table = (pos.float()[:, None] * inv_freq[None, :]).cos() / .sin() (modeling_llama.py:119-139 in fp32): the decode step's one launch for four."""
     for D, theta in ((64, 500000.0), (256, 10000.0), (128, 10000.0)):
