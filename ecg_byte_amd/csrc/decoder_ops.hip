@@ -10,6 +10,7 @@
 //   Adam(weight_decay = L2)           ecg_byte/main.py:262-264 ; clip_grad_norm_ ecg_byte/runners/train.py:26
 #include <hip/hip_bf16.h>
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <string>
 
@@ -70,7 +71,7 @@ __device__ __forceinline__ unsigned argmax_key(unsigned short b)
 constexpr int kArgmaxSlots = 4096;
 __device__ unsigned long long g_argmax_key[kArgmaxSlots];
 __device__ unsigned g_argmax_ticket[kArgmaxSlots];
-__global__ __launch_bounds__(1024) void argmax_rows_kernel(const unsigned short *x, long long ld, int n, long long *out)
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const unsigned short *x, long long ld, int n, long long *out, int slot0)
 {
     __shared__ unsigned long long s_best[16];
     const unsigned short *row = x + (long long)blockIdx.x * ld;
@@ -113,11 +114,12 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const unsigned short 
 #pragma unroll
         for (int w = 1; w < 16; ++w) best = s_best[w] > best ? s_best[w] : best;
         if (parts == 1) { out[blockIdx.x] = (long long)(0x7FFFFFFF - (unsigned)(best & 0xFFFFFFFFu)); return; }
-        atomicMax(&g_argmax_key[blockIdx.x], best);
+        const int slot = slot0 + (int)blockIdx.x;
+        atomicMax(&g_argmax_key[slot], best);
         __threadfence();
-        if (atomicAdd(&g_argmax_ticket[blockIdx.x], 1u) == (unsigned)parts - 1u) {                 // the last part in
-            const unsigned long long all = atomicExch(&g_argmax_key[blockIdx.x], 0ull);
-            g_argmax_ticket[blockIdx.x] = 0u;
+        if (atomicAdd(&g_argmax_ticket[slot], 1u) == (unsigned)parts - 1u) {                 // the last part in
+            const unsigned long long all = atomicExch(&g_argmax_key[slot], 0ull);
+            g_argmax_ticket[slot] = 0u;
             out[blockIdx.x] = (long long)(0x7FFFFFFF - (unsigned)(all & 0xFFFFFFFFu));
         }
     }
@@ -1156,10 +1158,12 @@ extern "C" int ecgb_set_ce_in_registers(int on) { g_ce_in_registers = on ? 1 : 0
 extern "C" int ecgb_argmax_bf16(const void *x_dev, long long ld, int rows, int n, int64_t *out_dev, void *stream)
 {
     if (!x_dev || !out_dev || rows <= 0 || n <= 0 || ld < n) { ecgb::set_error("ecgb_argmax_bf16: bad argument"); return ECGB_ERR_INVALID; }
-    // few rows of many columns (generate: one row of the vocabulary per sequence): a row over up to 32 workgroups; concurrent launches on different streams would share the
-    // slots, so only the few-row case, which the decode graph issues one at a time, splits
-    const unsigned parts = (rows <= 16 && rows <= kArgmaxSlots) ? (unsigned)std::max(1, std::min(32, n / 8192)) : 1u;
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)rows, parts), dim3(1024), 0, (hipStream_t)stream, (const unsigned short *)x_dev, ld, n, (long long *)out_dev);
+    // few rows of many columns (generate: one row of the vocabulary per sequence): a row over up to 32 workgroups.  Every launch takes the next block of 16 slots (256
+    // blocks: launches in flight on different streams do not meet unless 256 of them are; a captured launch keeps its block on every replay)
+    static std::atomic<unsigned> next_block{0};
+    const unsigned parts = rows <= 16 ? (unsigned)std::max(1, std::min(32, n / 8192)) : 1u;
+    const int slot0 = parts > 1 ? (int)((next_block.fetch_add(1u) % (unsigned)(kArgmaxSlots / 16)) * 16u) : 0;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)rows, parts), dim3(1024), 0, (hipStream_t)stream, (const unsigned short *)x_dev, ld, n, (long long *)out_dev, slot0);
     ECGB_CHECK_LAUNCH("argmax_rows");
 }
 
