@@ -13,8 +13,11 @@ done
 python3 - <<PY > gpurun_out/${P}_trainer_hbm.json
 import json, subprocess, sys
 out = {}
-for k in ("rewrite_kernel", "tile_count_kernel", "rowmax_kernel", "init_kernel"):
-    out[k] = json.loads(subprocess.run([sys.executable, "scripts/pmc_summary.py", k, "gpurun_out/${P}_trainer_FETCH_SIZE", "gpurun_out/${P}_trainer_WRITE_SIZE"], capture_output=True, text=True).stdout)["counters"]
+for k in ("seg_merge_kernel", "seg_init_kernel", "rewrite_kernel", "tile_count_kernel", "rowmax_kernel", "init_kernel"):
+    try:
+        out[k] = json.loads(subprocess.run([sys.executable, "scripts/pmc_summary.py", k, "gpurun_out/${P}_trainer_FETCH_SIZE", "gpurun_out/${P}_trainer_WRITE_SIZE"], capture_output=True, text=True).stdout)["counters"]
+    except Exception:
+        continue          # (a kernel the form that ran does not launch)
 tot = 0.0
 for k, c in out.items():
     per = (2.0 * c.get("FETCH_SIZE", {}).get("per_launch_mean", 0.0) + c.get("WRITE_SIZE", {}).get("per_launch_mean", 0.0)) * 1024.0
