@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 auto after = [&](const int m) __attribute__((always_inline)) {
                     W4_FENCE();
                     if (m <= 15 && (m & 1)) fb1[m >> 1] = frag_b(cur, 1, m >> 1);
-                    else if (m == 20 || m == 51) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    else if (m == 20 || m == 51) __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0) -- as a builtin: hipcc's own wait insertion sees it and leaves out
+                                                                                                //  the per-row waits it would otherwise put before every first use of a fragment
                     else if (m == 21 || m == 52 || m == 69 || m == 106) { if constexpr (!(DBG & 1)) __builtin_amdgcn_s_barrier(); }
                     else if (m == 22) dma_dst_b(cur_off);
                     else if (m == 23 || m == 26 || m == 29 || m == 32 || m == 35) ld_b((m - 23) / 3);
