@@ -788,7 +788,8 @@ class HipCausalLM(nn.Module):
         for s0 in range(0, rows.numel(), chunk):
             r = rows[s0:s0 + chunk]
             n = r.numel()
-            npad = (n + 63) // 64 * 64                                   # the weight-gradient product contracts over the rows: K-step 64
+            npad = (n + 255) // 256 * 256                                # whole 256-row tiles: the head's two products then run on the four-wave kernel (0.75 of the MFMA pipe
+                                                                         # against 0.37 on the eight-wave one: profiles/r05/train_pmc.json); the rows are the weight-gradient product's K (step 64)
             hr = torch.zeros((npad, H), dtype=torch.bfloat16, device=dev)     # rows past n: zero states, label -100 -> zero logits, zero dlogits
             hr[:n] = hf.index_select(0, r)                               # gather (plumbing)
             lab = torch.full((npad,), -100, dtype=torch.int64, device=dev)
