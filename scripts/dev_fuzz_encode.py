@@ -12,7 +12,8 @@ from ecg_byte_amd.tokenizer import HipTokenizer, set_encode_plan
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t0 = time.time(); cases = 0; streams = 0
-alphabets = [b"abcdefghijklmnopqrstuvwxyz", b"abc", b"ab", b"ghij", b"abcxyz.,", b"mnopq\x80\xff", b"a"]
+alphabets = [b"abcdefghijklmnopqrstuvwxyz", b"abc", b"ab", b"ghij", b"abcxyz.,", b"mnopq\x80\xff", b"a",
+             bytes(range(40, 100)), bytes(range(256))]          # (over 29 byte values: the general form, edge table in HBM)
 while time.time() - t0 < budget:
     alpha = alphabets[rng.integers(len(alphabets))]
     max_len = int(rng.choice([3, 6, 12, 40, 120, 220]))
