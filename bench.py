@@ -720,7 +720,8 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
         del model, opt
         model = opt = None
         torch.cuda.empty_cache()
-        out["hbm_bound_kernels"] = hbm_kernel_report(dev, B, S, cfg, n_vocab)
+        rep = hbm_kernel_report(dev, B, S, cfg, n_vocab)      # columns (the line has 8 KB): kernel, ms per launch, fraction of the 8 TB/s spec (GB/s = frac x 8000)
+        out["hbm_bound_kernels"] = {k: [r[k] for r in rep] for k in ("kernel", "ms", "frac")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baselines are an N = 1 item
         cfg_kw = dict(vocab_size=n_vocab, hidden_size=H, intermediate_size=I, num_hidden_layers=Lyr,
                       num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads,
