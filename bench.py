@@ -69,6 +69,10 @@ def with_top_level_scalars(out):
             top["train_full_logits_ms_per_step"] = g("train", "full_logits", "ms_per_step")
             top["train_full_logits_roofline_frac"] = g("train", "full_logits", "roofline", "frac")
             top["train_loss_rel_err_vs_fp32_oracle"] = g("train", "cpu_baseline", "parity_gate", "loss_rel_err_vs_fp32_oracle")
+            top["train_lora_loss_rel_err_vs_fp32_oracle"] = g("train", "lora_r16", "cpu_baseline", "parity_gate", "loss_rel_err_vs_fp32_oracle")
+            top["c5_loss_rel_err_vs_fp32_oracle"] = g("c5", "train", "cpu_baseline", "parity_gate", "loss_rel_err_vs_fp32_oracle")
+            top["c1_loss_rel_err_vs_fp32_oracle"] = g("c1", "parity_gate", "loss_rel_err_vs_fp32_oracle")
+            top["train_lora_ms_per_step_from_disk"] = g("train", "lora_r16", "loader", "ms_per_step_from_disk")
             top["train_cpu_samples_per_s"] = g("train", "cpu_baseline", "value")
             top["c5_lora_ms_per_step"] = g("c5", "train", "ms_per_step")
             top["c5_generate_tokens_per_s"] = g("c5", "generate", "tokens_per_s")
@@ -198,19 +202,22 @@ def cpu_baseline(merges, pc, L, seed, budget_s=12.0):
 MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
 
 
-def _cpu_train_once(cfg_kw, S, threads, dtype, with_optimizer, base_params, batch=None):
+LLAMA3_ROPE = (500000.0, {"factor": 32.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 8192})
+
+
+def _cpu_train_once(cfg_kw, S, threads, dtype, with_optimizer, base_params, batch=None, lora_scale=None, rope=LLAMA3_ROPE):
     """One forward + backward of oracle/llama_ref.py on the host.  `batch` = (ids, mask, labels, positions) of ONE sample, or None for a synthetic one.
-    Returns (seconds, loss)."""
+    lora_scale: the frozen-base LoRA step (only the `.lora_A / .lora_B` entries of `base_params` train).  Returns (seconds, loss)."""
     import torch
     from oracle import llama_ref as R
     old = torch.get_num_threads()
     torch.set_num_threads(threads)
     try:
         cfgd = dict(cfg_kw)
-        params = {k: v.detach().to(dtype).clone() for k, v in base_params.items()}
-        for p in params.values():
-            p.requires_grad_(True)
-        opt = torch.optim.Adam(list(params.values()), lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2) if with_optimizer else None
+        trains = lambda k: lora_scale is None or ".lora_" in k
+        params = {k: (v.detach().to(dtype).clone().requires_grad_(True) if trains(k) else v.detach().to(dtype)) for k, v in base_params.items()}
+        trainable = [v for k, v in params.items() if trains(k)]
+        opt = torch.optim.Adam(trainable, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2) if with_optimizer else None
         if batch is not None:
             ids, mask, labels, pos = batch
         else:
@@ -219,44 +226,78 @@ def _cpu_train_once(cfg_kw, S, threads, dtype, with_optimizer, base_params, batc
             mask = torch.ones(1, S)
             pos = torch.arange(S)[None]
             labels = torch.full((1, S), -100); labels[:, -20:] = ids[:, -20:]
-        inv = R.llama3_inv_freq(cfgd["head_dim"], 500000.0, {"factor": 32.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
-                                                             "original_max_position_embeddings": 8192})
+        inv = R.llama3_inv_freq(cfgd["head_dim"], rope[0], rope[1])
         t0 = time.perf_counter()
-        loss = R.llama_loss(params, cfgd, ids, mask, labels, pos, inv)
+        loss = R.llama_loss(params, cfgd, ids, mask, labels, pos, inv, lora_scale=lora_scale)
         loss.backward()
         if opt is not None:
-            torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+            torch.nn.utils.clip_grad_norm_(trainable, 1.0)
             opt.step()
         return time.perf_counter() - t0, float(loss.detach().float())
     finally:
         torch.set_num_threads(old)
 
 
-def train_cpu_baseline(cfg_kw, S, threads=6, gate=None):
+def _gate_object(what, hip_loss, ref_loss):
+    return {"what": what, "hip_loss": hip_loss, "fp32_oracle_loss": ref_loss, "loss_rel_err_vs_fp32_oracle": abs(hip_loss - ref_loss) / abs(ref_loss), "tolerance": 1e-2}
+
+
+def train_cpu_baseline(cfg_kw, S, threads=6, gate=None, lora_scale=None, rope=LLAMA3_ROPE, variants=True, label="16 layers"):
     """One train step of the same architecture in plain PyTorch on the host CPU (the reference's CPU path is HF transformers on ATen
     CPU kernels).  `value`: fp32, batch 1, torch.set_num_threads(6) -- the reference's own setting, ecg_byte/main.py:2 -- forward +
     backward.  `variants`: all host cores, with the clip + Adam step, and bf16 weights / activations.
     `gate` = (state_dict of the HIP model as fp32 host tensors, its batch's first sample, the HIP path's loss on that sample): the timed fp32 leg then runs on the
-    HIP model's OWN weights and sample, and its loss is the full-size parity gate of SURVEY.md section 8d (HIP loss within 1e-2 rel of the fp32 restatement)."""
+    HIP model's OWN weights (and adapters) and sample, and its loss is the full-size parity gate of SURVEY.md section 8d (HIP loss within 1e-2 rel of the fp32 restatement)."""
     import torch
     from oracle import llama_ref as R
     if gate is not None:
         base, batch, hip_loss = gate
     else:
         base, batch, hip_loss = R.random_params(dict(cfg_kw), seed=0, dtype=torch.float32), None, None      # generated once: 1.24 G normal variates take longer than a step
-    dt, ref_loss = _cpu_train_once(cfg_kw, S, threads, torch.float32, False, base, batch)
+    dt, ref_loss = _cpu_train_once(cfg_kw, S, threads, torch.float32, False, base, batch, lora_scale, rope)
     n_all = max(1, min(os.cpu_count() or 1, 64))
-    variants = []
-    for dtype, thr, opt in ((torch.float32, n_all, True), (torch.bfloat16, n_all, False), (torch.bfloat16, threads, False)):
-        t, _ = _cpu_train_once(cfg_kw, S, thr, dtype, opt, base, batch)
-        variants.append({"dtype": str(dtype).replace("torch.", ""), "threads": thr, "optimizer_step": opt, "samples_per_s": 1.0 / t, "seconds": t})
+    var = []
+    if variants:
+        for dtype, thr, opt in ((torch.float32, n_all, True), (torch.bfloat16, n_all, False), (torch.bfloat16, threads, False)):
+            t, _ = _cpu_train_once(cfg_kw, S, thr, dtype, opt, base, batch, lora_scale, rope)
+            var.append({"dtype": str(dtype).replace("torch.", ""), "threads": thr, "optimizer_step": opt, "samples_per_s": 1.0 / t, "seconds": t})
     out = {"value": 1.0 / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-           "sample": f"1 sample (seq {S}) forward+backward, fp32, PyTorch CPU eager restatement of the decoder "
-                     f"(oracle/llama_ref.py) in {dt:.1f} s; optimizer step not included", "variants": variants, "host_cpus": os.cpu_count()}
+           "sample": f"1 sample (seq {S}) forward+backward{' (adapters only: frozen base)' if lora_scale is not None else ''}, fp32, PyTorch CPU eager restatement "
+                     f"of the decoder (oracle/llama_ref.py) in {dt:.1f} s; optimizer step not included", "host_cpus": os.cpu_count()}
+    if var:
+        out["variants"] = var
     if hip_loss is not None:
-        out["parity_gate"] = {"what": "16 layers, the HIP model's own initial weights, first sample of its batch: HIP training-forward loss vs this fp32 leg's", "hip_loss": hip_loss, "fp32_oracle_loss": ref_loss,
-                              "loss_rel_err_vs_fp32_oracle": abs(hip_loss - ref_loss) / abs(ref_loss), "tolerance": 1e-2}
+        out["parity_gate"] = _gate_object(f"{label}, the HIP model's own weights, first sample of its batch: HIP training-forward loss vs this fp32 leg's", hip_loss, ref_loss)
     return out
+
+
+def hip_gate_sample(model, opt, one, dev, lora_seed=None):
+    """(host fp32 parameter dict in the oracle's names, the sample on the host, the HIP training-forward loss on it) for `train_cpu_baseline(gate=...)`.
+    With LoRA on: dropout off for this one forward (the oracle has none) and lora_B drawn non-zero (peft's zero start would make the adapter branch a no-op
+    and the gate blind to it); both are restored afterwards -- the timed steps start from peft's initialisation with dropout 0.05."""
+    import torch
+    sites = [s for layer in model.lora for s in layer.values()] if model.lora is not None else []
+    saved_p = [s.p for s in sites]
+    if sites:
+        g = torch.Generator(device=dev).manual_seed(lora_seed or 5)
+        with torch.no_grad():
+            for s in sites:
+                s.B.copy_((torch.randn(s.B.shape, device=dev, generator=g) * 0.02).to(torch.bfloat16) * s.bmask)
+                s.p = 0.0
+    opt.zero_grad()
+    o = model(input_ids=one[0], attention_mask=one[1], labels=one[2], position_ids=one[3])
+    hip_loss = float(o.loss.item())
+    o.loss.backward()                                # (consumes the saved state; the gradients are dropped by the next zero_grad)
+    opt.zero_grad()
+    sd = {k: v.detach().float().cpu() for k, v in model._hf_named() if k != "lm_head.weight"}
+    if sites:
+        for name, t in model.lora_named():
+            sd[name.replace("base_model.model.", "").replace(".default.weight", "")] = t.detach().float().cpu()
+        with torch.no_grad():
+            for s, p in zip(sites, saved_p):
+                s.B.zero_()
+                s.p = p
+    return sd, tuple(t.cpu() for t in one), hip_loss
 
 
 def hbm_kernel_report(dev, B, S, cfg, n_vocab, reps=10):
@@ -473,6 +514,9 @@ def bench_c5(args, dev):
         opt.step_and_update_lr()
         return out.loss
 
+    gate = None
+    if not args.no_cpu_baseline:      # full-depth parity gate: 18 layers, one row of the batch (S 2048), adapters non-zero, dropout off, before any update
+        gate = hip_gate_sample(m, opt, [t[:1].contiguous() for t in (ids, mask, labels, pos)], dev, lora_seed=7)
     for _ in range(2):
         loss = step()
     torch.cuda.synchronize()
@@ -493,6 +537,13 @@ def bench_c5(args, dev):
                      "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "algorithmic_flops_per_step": flops},
                      "max_memory_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}}
+    if gate is not None:
+        n_all = max(1, min(os.cpu_count() or 1, 64))
+        cfg_kw = dict(vocab_size=V, hidden_size=H, intermediate_size=I, num_hidden_layers=Lyr, num_attention_heads=Hq, num_key_value_heads=Hkv, head_dim=D,
+                      rms_norm_eps=cfg.rms_norm_eps, model_type="gemma")
+        out["train"]["cpu_baseline"] = train_cpu_baseline(cfg_kw, S, threads=n_all, gate=gate, lora_scale=2.0, rope=(10000.0, None), variants=False,
+                                                          label="18 layers at Gemma-2B dims, LoRA r16 with non-zero lora_B and dropout off")
+        del gate
     m.eval()
     prompt = ids[:1, -600:].contiguous()
     pm = torch.ones_like(prompt, dtype=torch.float32)
@@ -589,11 +640,14 @@ def bench_c1(args, dev, cpu=True):
         n_all = max(1, min(os.cpu_count() or 1, 64))
         old = torch.get_num_threads()
         try:
+            base = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if k != "lm_head.weight"}     # the HIP model's own weights: its loss is the gate's
+            ref_loss = None
             for dtype, thr in ((torch.float32, 6), (torch.float32, n_all), (torch.bfloat16, n_all)):
                 torch.set_num_threads(thr)
-                params = G.random_params(cfgd, seed=0, dtype=dtype)
+                params = {k: v.to(dtype) for k, v in base.items()}
                 with torch.no_grad():
-                    G.gpt2_loss(params, cfgd, ids, mask, labels, pos)                     # warm-up
+                    l0 = float(G.gpt2_loss(params, cfgd, ids, mask, labels, pos).float())    # warm-up
+                    ref_loss = l0 if ref_loss is None else ref_loss                           # (the first variant: fp32)
                     t0 = time.perf_counter(); k = 0
                     while time.perf_counter() - t0 < 4.0:
                         G.gpt2_loss(params, cfgd, ids, mask, labels, pos)
@@ -607,13 +661,87 @@ def bench_c1(args, dev, cpu=True):
                                "encode_s_per_batch_1_core": enc_cpu,
                                "sample": f"batch of {B}: rust_bpe port (1 core) + GPT-2-small forward, PyTorch CPU eager fp32, 6 threads; ~4 s per variant",
                                "variants": variants, "host_cpus": os.cpu_count()}
+        out["parity_gate"] = _gate_object("12 layers, the HIP model's own weights, the timed batch of 4: HIP forward loss vs the fp32 CPU leg's (oracle/gpt2_ref.py)",
+                                          out["hip"]["loss"], ref_loss)
         out["speedup_vs_cpu_6_threads"] = out["hip"]["samples_per_s"] / out["cpu_baseline"]["value"]
     del model
     torch.cuda.empty_cache()
     return out
 
 
-def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
+LOADER_WORDS = ("sinus rhythm normal ecg atrial fibrillation with rapid ventricular response bradycardia otherwise left bundle branch block premature complexes "
+                "axis deviation possible inferior infarct age undetermined nonspecific t wave abnormality prolonged qt borderline first degree av").split()
+LOADER_QUESTION = "Could you please help me explain my ECG?"
+
+
+def write_loader_files(x, pc, vocab, merges, n):
+    """The reference's on-disk training set (preprocess_utils.py:215-226, file_utils.py:30-48): `ecg/ecg_{i}_{j}.npy` (12 x L float64) + `text/text_{i}_{j}.json`
+    pairs, the percentiles .npy and the tokenizer pickle, under a fresh directory in /tmp.  Returns the directory."""
+    import pickle
+    import tempfile
+    from ecg_byte_amd import file_utils as F
+    root = tempfile.mkdtemp(prefix="ecgb_loader_", dir="/tmp")
+    os.makedirs(os.path.join(root, "ecg")); os.makedirs(os.path.join(root, "text"))
+    rng = np.random.default_rng(11)
+    for i in range(min(n, x.shape[0])):
+        np.save(os.path.join(root, "ecg", f"ecg_{i}_0.npy"), x[i])
+        words = rng.choice(LOADER_WORDS, size=int(rng.integers(4, 33)))
+        with open(os.path.join(root, "text", f"text_{i}_0.json"), "w") as f:
+            json.dump(" ".join(words), f)
+    F.save_percentiles(os.path.join(root, "percentiles.npy"), pc["percentile_1"], pc["percentile_99"])
+    with open(os.path.join(root, "tok.pkl"), "wb") as f:
+        pickle.dump((vocab, merges), f)
+    return root
+
+
+def bench_loader(model, opt, dev, root, B, S, steps, resident_ms):
+    """The path the reference's loop actually runs (ecg_byte/data_loader.py:52-83, main.py:249-259: np.load + json + tokenizer inside __getitem__, num_workers=0), here
+    through `DeviceBatchLoader` (reader threads, pinned staging, copy on a side stream, ONE quantise + encode + assemble per batch on the device): the same LoRA train
+    step fed from the files `write_loader_files` wrote, against the figure with the batch resident in HBM.  `loader_stall_ms_per_step` = host time the training thread
+    spent waiting for a batch the readers had not finished.  The files were just written: they are read from the page cache, not from a disk."""
+    import torch
+    from types import SimpleNamespace
+    from helpers import WordTokenizer
+    from ecg_byte_amd import file_utils as F
+    from ecg_byte_amd.data_loader import DeviceBatchLoader, ECGTokenDataset
+    vocab, merges = F.load_vocab_and_merges(os.path.join(root, "tok.pkl"))
+    tok = WordTokenizer(LOADER_QUESTION.split() + list(LOADER_WORDS))
+    tok.add_tokens([f"signal_{k}" for k in vocab.keys()])                  # main.py:144-150
+    tok.add_tokens(["<sig_start>"], special_tokens=True)
+    tok.add_tokens(["<sig_end>"], special_tokens=True)
+    tok.add_special_tokens({"pad_token": "<pad>"})
+    sig, txt = F.align_signal_text_files(os.path.join(root, "ecg"), os.path.join(root, "text"))
+    ns = SimpleNamespace(percentiles=os.path.join(root, "percentiles.npy"), dataset="ptb_500", inference=False, pad_to_max=S - 4, dis=False, dev=False,
+                         toy=True, device=str(dev))
+    ds = ECGTokenDataset(sig, txt, vocab, merges, tokenizer=tok, args=ns)
+    runs = []
+    for workers in (1, 4):
+        ld = DeviceBatchLoader(ds, batch_size=B, shuffle=True, seed=0, workers=workers, drop_last=True)
+        it = iter(ld)
+
+        def run(n):
+            for _ in range(n):
+                b = next(it)
+                opt.zero_grad()
+                o = model(input_ids=b["tokenized_signal"], attention_mask=b["attn_mask"], labels=b["quantized_signal_ids_input"], position_ids=b["position_ids"])
+                o.loss.backward()
+                opt.step_and_update_lr()
+        run(2)
+        torch.cuda.synchronize()
+        stall0, t0 = ld.stall_s, time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        runs.append({"reader_threads": workers, "ms_per_step_from_disk": ms, "loader_stall_ms_per_step": (ld.stall_s - stall0) / steps * 1e3,
+                     "vs_resident": ms / resident_ms})
+        it.close()
+    best = min(runs, key=lambda r: r["ms_per_step_from_disk"])
+    return {"workload": f"{len(sig)} ecg_i_j.npy (12x5000 float64) + text_i_j.json pairs in /tmp (page cache), DeviceBatchLoader batch {B}, shuffle; the C3 LoRA step",
+            "ms_per_step": resident_ms, "ms_per_step_from_disk": best["ms_per_step_from_disk"], "loader_stall_ms_per_step": best["loader_stall_ms_per_step"],
+            "reader_threads": best["reader_threads"], "steps": steps, "runs": runs}
+
+
+def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host, loader_dir=None):
     """Train samples/s of Llama-3.2-1B (seq 1024, bf16, B per GPU) on the HIP decoder, batches built
     through the real front end: synthetic ECG -> quantise+encode -> LUT -> assemble."""
     import torch
@@ -656,19 +784,13 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
         return out.loss
 
     gate = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.lora:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # full-size parity gate: before any update, the training-mode forward of the 16-layer model on the first sample of its own batch;
-        # the fp32 restatement runs on the same weights and sample inside train_cpu_baseline (its timed fp32 leg)
+        # the fp32 restatement runs on the same weights (and adapters) and sample inside train_cpu_baseline (its timed fp32 leg)
         b0 = asm(x, pc, qs, ans)
         one = [b0[k][:1].contiguous() for k in ("tokenized_signal", "attn_mask", "quantized_signal_ids_input", "position_ids")]
-        opt.zero_grad()
-        o = model(input_ids=one[0], attention_mask=one[1], labels=one[2], position_ids=one[3])
-        hip_loss = float(o.loss.item())
-        o.loss.backward()                                # (consumes the saved state; the gradients are dropped by the next zero_grad)
-        opt.zero_grad()
-        sd = {k: v.detach().float().cpu() for k, v in model._hf_named()}
-        gate = (sd, (one[0].cpu(), one[1].cpu(), one[2].cpu(), one[3].cpu()), hip_loss)
-        del b0, o
+        gate = hip_gate_sample(model, opt, one, dev)
+        del b0, one
     for _ in range(max(1, min(args.warmup, 5))):   # a train step is 300x an encode step: a few warm-up steps are enough
         loss = step()
     torch.cuda.synchronize()
@@ -716,6 +838,8 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
                         "algorithmic_flops_per_step": flops, "step_ms_hip_events": ev0.elapsed_time(ev1) / args.train_steps}}
     if comm is not None:
         out["gradient_exchange"] = comm
+    if rank == 0 and world == 1 and loader_dir is not None:
+        out["loader"] = bench_loader(model, opt, dev, loader_dir, B, S, args.train_steps, sec * 1e3)
     if rank == 0 and not args.lora and not getattr(args, "no_hbm_report", False):
         del model, opt
         model = opt = None
@@ -726,7 +850,8 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host):
         cfg_kw = dict(vocab_size=n_vocab, hidden_size=H, intermediate_size=I, num_hidden_layers=Lyr,
                       num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads,
                       head_dim=cfg.head_dim, rms_norm_eps=cfg.rms_norm_eps)
-        out["cpu_baseline"] = train_cpu_baseline(cfg_kw, S, gate=gate)
+        out["cpu_baseline"] = train_cpu_baseline(cfg_kw, S, gate=gate, lora_scale=2.0 if args.lora else None, variants=not args.lora,
+                                                 label="16 layers, LoRA r16 with non-zero lora_B and dropout off" if args.lora else "16 layers")
     del model, opt
     torch.cuda.empty_cache()
     return out
@@ -774,6 +899,7 @@ def main():
     # this process initialises HIP / RCCL
     workers = int(os.environ.get("ECGB_BENCH_WORKERS", max(1, min(8, (os.cpu_count() or 1) // max(1, world)))))   # 1: no fork pool (profiler runs)
     x = make_signals(args.batch, args.L, seed=0, start=rank * args.batch, workers=workers)   # rank r owns records rB..rB+B-1
+    loader_dir = None
     x_train = None if args.no_train else make_signals(args.train_batch, args.L, seed=0,
                                                       start=10_000_000 + rank * args.train_batch, workers=workers)
     # the tokenizer trainer's corpus (2 000 records, seed 1: what tests/golden/tokenizer_c2.pkl was trained on) -- generated here, before HIP is up, like the rest
@@ -814,6 +940,8 @@ def main():
 
     tag = "c2" if args.L == 5000 else "c1"
     vocab, merges, pc = load_tokenizer(tag)
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_train and not args.no_lora_leg and not args.lora and args.L == 5000:
+        loader_dir = write_loader_files(x, pc, vocab, merges, 2048)       # the disk -> step leg's training set (the encode batch's first records)
     tk = HipTokenizer(merges)
     B, L = args.batch, args.L
     n = 12 * L
@@ -871,9 +999,9 @@ def main():
         if not args.lora and not args.no_lora_leg:   # SURVEY.md §8d asks for both: full fine-tune (BASELINE C3 wording) and LoRA r16 (what the reference's script runs)
             import copy
             largs = copy.copy(args)
-            largs.lora, largs.no_cpu_baseline, largs.train_steps = True, True, args.train_steps
-            lora = bench_train(largs, tk, vocab, merges, pc, world, rank, dev, x_train)
-            train["lora_r16"] = {k: lora[k] for k in ("value", "unit", "ms_per_step", "steps", "final_loss", "roofline")}
+            largs.lora, largs.train_steps = True, args.train_steps
+            lora = bench_train(largs, tk, vocab, merges, pc, world, rank, dev, x_train, loader_dir=loader_dir)
+            train["lora_r16"] = {k: lora[k] for k in ("value", "unit", "ms_per_step", "steps", "final_loss", "roofline", "cpu_baseline", "loader") if k in lora}
             train["lora_r16"]["roofline"].pop("kernel", None)
             train["lora_r16"]["workload"] = "the same step with LoRA r16 on q,k,v,o,gate,up,down (frozen base; ecg_byte/main.py:131-138)"
 
@@ -960,6 +1088,9 @@ def main():
                         break
         real_stdout.write(line + "\n")
         real_stdout.flush()
+    if loader_dir is not None:
+        import shutil
+        shutil.rmtree(loader_dir, ignore_errors=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -187,6 +187,7 @@ class DeviceBatchLoader:
         self.dataset, self.batch_size, self.shuffle, self.sampler = dataset, int(batch_size), shuffle, sampler
         self.drop_last, self.seed, self.workers, self.prefetch = drop_last, seed, max(1, workers), max(1, prefetch)
         self.epoch = 0
+        self.stall_s, self.batches_out = 0.0, 0       # host seconds the consumer spent waiting for a batch the readers had not finished; batches yielded
         if bool(dataset.args.inference) and self.batch_size != 1:
             raise ValueError("inference batches are single prompts (main.py:181-184 uses batch_size=1)")
 
@@ -232,7 +233,10 @@ class DeviceBatchLoader:
                     nxt += 1
 
             def pump():                                       # one finished host batch -> pinned -> device (side stream)
+                import time
+                t0 = time.perf_counter()
                 host = futures.popleft().result()
+                self.stall_s += time.perf_counter() - t0
                 submit()
                 if host is None:
                     staged.append(None)
@@ -250,6 +254,7 @@ class DeviceBatchLoader:
                 while futures and len(staged) < 2:            # the next batch's copy overlaps this batch's compute
                     pump()
                 cur = staged.popleft()
+                self.batches_out += 1
                 if cur is None:
                     yield None
                     continue
