@@ -1042,9 +1042,51 @@ class HipCausalLM(nn.Module):
             scores = scores.masked_fill(remove.scatter(-1, idx, remove), float("-inf"))
         return torch.multinomial(scores.softmax(-1), 1, generator=generator).squeeze(-1)
 
+    @torch.no_grad()
+    def _merged_weights(self):
+        """W + (alpha / r) B A of every adapted projection -- peft's merge_and_unload() -- in buffers that live on the model (the captured decode step of the merged
+        mode points at them: they are rewritten in place on every call, since the optimizer updates the adapters through raw pointers and no version counter sees it).
+        The update B A is formed by the library's own product (bf16 out, K = 64) and added in fp32, rounded once: NOT bit-identical to the unmerged branch, whose
+        t = A x is rounded to bf16 before it meets B."""
+        bufs = self.__dict__.get("_merged")
+        names = (("qkv", self.wqkv), ("o", self.wo), ("gu", self.wgu), ("down", self.wdown))
+        if bufs is None:
+            bufs = self.__dict__["_merged"] = {k: [torch.empty_like(w.data) for w in ws] for k, ws in names}
+        for k, ws in names:
+            for i, w in enumerate(ws):
+                site = self.lora[i][k]
+                delta = ops.gemm_nt(site.B.data, ops.transpose(site.A.data), alpha=site.scale)      # [out, in]: block b's rows only see its own rank-r rows of A
+                bufs[k][i].copy_(w.data.float() + delta.float())
+        return bufs
+
     def generate(self, input_ids=None, attention_mask=None, max_new_tokens=128, pad_token_id=None, eos_token_id=None,
                  use_cache=True, return_logits=False, use_graph=None, do_sample=None, temperature=None, top_k=None, top_p=None,
-                 generator=None, **_):
+                 generator=None, merge_adapters=False, **kw):
+        """merge_adapters=True (opt-in, LoRA models only): the adapters are folded into copies of the projection weights once per call and the decode step runs
+        without the five adapter branches per layer -- peft's `merge_and_unload()` for inference.  Not bit-identical to the unmerged step (see `_merged_weights`);
+        the reference's own eval loop (ecg_byte/runners/inference.py, main.py:181-195) generates with the adapters unmerged, which stays the default."""
+        if merge_adapters and self.lora is not None:
+            merged = self._merged_weights()
+            params = {"qkv": self.wqkv, "o": self.wo, "gu": self.wgu, "down": self.wdown}
+            saved_lora, saved = self.lora, {k: [w.data for w in ws] for k, ws in params.items()}
+            try:
+                self.lora = None
+                for k, ws in params.items():
+                    for w, mw in zip(ws, merged[k]):
+                        w.data = mw
+                return self._generate(input_ids, attention_mask, max_new_tokens, pad_token_id, eos_token_id, use_cache, return_logits, use_graph, do_sample,
+                                      temperature, top_k, top_p, generator)
+            finally:
+                self.lora = saved_lora
+                for k, ws in params.items():
+                    for w, d in zip(ws, saved[k]):
+                        w.data = d
+        return self._generate(input_ids, attention_mask, max_new_tokens, pad_token_id, eos_token_id, use_cache, return_logits, use_graph, do_sample,
+                              temperature, top_k, top_p, generator)
+
+    def _generate(self, input_ids=None, attention_mask=None, max_new_tokens=128, pad_token_id=None, eos_token_id=None,
+                  use_cache=True, return_logits=False, use_graph=None, do_sample=None, temperature=None, top_k=None, top_p=None,
+                  generator=None):
         """GenerationMixin.generate / _sample (generation/utils.py:1877, 3131-3250) as LLM.generate calls it
         (ecg_byte/models/llm.py:26-37): positions from the attention mask (utils.py:410-411), finished sequences keep emitting
         pad_token_id, stop when every sequence has produced eos_token_id or after max_new_tokens.  Greedy unless do_sample: the
@@ -1136,7 +1178,7 @@ class HipCausalLM(nn.Module):
         cap = -(-(S0 + max_new_tokens) // 128) * 128
         pad_id = pad_token_id if pad_token_id is not None else 0
         key = (B, cap, pad_id, None if eos is None else tuple(int(e) for e in eos.tolist()), sampling, self.training, self.embed.data_ptr(),
-               None if self.lora is None else self.lora[0]["qkv"].A.data_ptr())
+               None if self.lora is None else self.lora[0]["qkv"].A.data_ptr(), self.wqkv[0].data_ptr())      # (the last: base weights or their merged copies)
         graphs = self.__dict__.setdefault("_gen_graphs", {})
         st = graphs.get(key) if sampling is None else None                   # (a sampling step holds torch's sort / cumsum / multinomial: captured per call, see below)
         if st is None:

@@ -441,6 +441,49 @@ def test_generate_stops_when_every_sequence_finished():
     assert seq.shape[1] == ids.shape[1] + 6 and int(seq[0, -1]) == int(zg["eos_token_id"])   # HF returns as soon as all are done
 
 
+def test_generate_with_merged_adapters_follows_the_unmerged_greedy_path():
+    """generate(merge_adapters=True) -- peft's merge_and_unload() for inference: W + (alpha / r) B A folded once per call, the decode step without adapter branches.
+    Not bit-identical (the unmerged branch rounds t = A x to bf16 before B): compared step by step with the unmerged run as the greedy fixtures are compared with the
+    reference -- logits within bf16 tolerance while the paths agree, a path may only leave at a near-tie.  The replayed graph of the merged mode equals its eager loop,
+    and the model's own weights and adapters are untouched afterwards."""
+    zg, m = _load_generate()
+    m.enable_lora(r=16, alpha=32, dropout=0.05, seed=3)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    with torch.no_grad():
+        for layer in m.lora:
+            for site in layer.values():
+                site.B.copy_((torch.randn(site.B.shape, device="cuda", generator=g) * 0.05).to(torch.bfloat16) * site.bmask)
+    m.eval()
+    ids, mask = torch.from_numpy(zg["input_ids"]).cuda(), torch.from_numpy(zg["attention_mask"]).cuda()
+    S0 = ids.shape[1]
+    kw = dict(input_ids=ids, attention_mask=mask, max_new_tokens=24, pad_token_id=299)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    seq_u, log_u = m.generate(return_logits=True, **kw)
+    seq_m, log_m = m.generate(return_logits=True, merge_adapters=True, **kw)
+    assert not torch.equal(log_u, log_m)                                   # (a different arithmetic, not the same kernels)
+    tol = 3.0 * float(zg["ref_bf16_deviation"].max())
+    exact = _check_greedy(seq_m.cpu().numpy(), log_m.cpu().numpy(), seq_u.cpu().numpy(), log_u.cpu().numpy(), S0, tol)
+    assert exact >= 40, exact
+    # the adapters matter: without them the logits are somewhere else entirely
+    lora, m.lora = m.lora, None
+    log_0 = m.generate(return_logits=True, **kw)[1]
+    m.lora = lora
+    assert (log_0[:, 0] - log_u[:, 0]).abs().max().item() > 10 * tol
+    # graph replay of the merged mode = its eager loop; the captured merged step is reused and re-merged per call
+    a = m.generate(merge_adapters=True, use_graph=True, **kw)
+    b = m.generate(merge_adapters=True, use_graph=False, **kw)
+    assert torch.equal(a, b) and torch.equal(a, seq_m)
+    with torch.no_grad():
+        m.lora[0]["o"].B.mul_(-1.0)
+    a2 = m.generate(merge_adapters=True, use_graph=True, **kw)
+    assert torch.equal(a2, m.generate(merge_adapters=True, use_graph=False, **kw))
+    with torch.no_grad():
+        m.lora[0]["o"].B.mul_(-1.0)
+    after = m.state_dict()
+    assert before.keys() == after.keys() and all(torch.equal(before[k], after[k]) for k in before)
+    assert torch.equal(m.generate(**kw), seq_u)                            # and the unmerged mode is what it was
+
+
 # ---- Gemma block (config C5's family): goldens from the vendored GemmaForCausalLM, tests/golden/make_decoder_golden_gemma.py
 def _load_gemma():
     z = np.load(os.path.join(GOLDEN, "decoder_gemma_tiny.npz"))
