@@ -173,6 +173,7 @@ def lib():
         "ecgb_decode_gemv": [vp, ll, ci, ci, vp, ll, ci, vp, ll, ci, f32, vp, vp, ll, vp, ll, vp],
         "ecgb_decode_lora_t": [vp, ll, ci, ci, vp, ll, ci, f32, vp, vp],
         "ecgb_decode_attn": [vp, ll, vp, vp, vp, ll, vp, ll, vp, ci, ci, vp, ci, ci, ci, f32, ci, vp, sz, vp],
+        "ecgb_attn_decode_one": [vp, ll, vp, vp, vp, ll, ll, vp, ll, vp, ci, ci, vp, ci, ci, ci, f32, ci, vp, sz, vp],
         "ecgb_set_gemm_w4_sched": [ci],
         "ecgb_set_gemm_w4_min_ktiles": [ci],
         "ecgb_attn_decode_split_dyn": [vp, vp, vp, ll, ll, vp, ll, vp, ci, vp, ci, ci, ci, f32, ci, vp, sz, vp],
@@ -209,6 +210,8 @@ def lib():
     L.ecgb_partial_rows_sum_f32.restype = C.c_int
     L.ecgb_decode_attn_scratch_floats.argtypes = [ll, ci, ci, ci, ci, ci]
     L.ecgb_decode_attn_scratch_floats.restype = sz
+    L.ecgb_attn_decode_one_scratch_floats.argtypes = [ci, ci, ci, ci]
+    L.ecgb_attn_decode_one_scratch_floats.restype = sz
     L.ecgb_rmsnorm_bwd_scratch_floats.argtypes = [sz, ci]
     L.ecgb_rmsnorm_bwd_scratch_floats.restype = sz
     L.ecgb_lora_da_scratch_bytes.argtypes = [ci, ci, ci]

@@ -2108,6 +2108,205 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float *par
     o[((long long)b * Hq + hq) * D + tid] = (unsigned short)(pack_bf16(sum, 0.f) & 0xFFFFu);
 }
 
+// ---- round 6: the four launches of a decode step's attention (rope_append, scores, values, combine: 4.8 + 11.2 + 5.3 + 4.8 us a layer in the replayed graph at the
+// C5 shape, every one of them on the ~5 us floor of a dependent launch) as ONE.  grid (splits, Hq, B) as the split kernels; the workgroups of a (sequence, head) meet
+// twice through counters in device memory:
+//   0  RoPE of the head's q and of the KV head's new key in LDS (rope_append_kernel's arithmetic; the workgroup of split 0 of the group's first head writes the rotated
+//      key and the value to cache row len - 1 -- nobody reads that row in this launch: the split that owns key len - 1 takes it from LDS / from qkv)
+//   1  the split's scores into LDS, its maximum and sum of exponentials to `stats` (attn_decode_scores_kernel's sums);  counter A += 1, wait until it is `splits`
+//   2  softmax over the splits' statistics, P.V of the split's keys (attn_decode_values_kernel's sums) to `partial`;  counter B: the last to arrive adds the
+//      partial outputs in split order (attn_decode_combine_kernel) and clears both counters for the next launch (a replayed graph never clears them itself).
+// The same arithmetic in the same order: the same bits as the four launches (tests/test_gpu_decode_fused.py).  The wait in step 1 needs every workgroup of the
+// launch resident at once: the host only takes this form for splits * Hq * B <= 256.
+struct DecodeOneArgs {
+    const unsigned short *qkv;    // [B, (Hq + 2 Hkv) D]: the step's projection, not written (q and the new key are rotated into LDS)
+    long long ld_qkv;
+    const float *cs, *sn;         // RoPE tables of the step's positions [B, D / 2]
+    unsigned short *cache;        // [B, cap, ld]: keys | values
+    long long cap, ld;
+    const float *mask;
+    long long mask_ld;
+    float *stats, *partial;       // [B, Hq, splits, 2], [B, Hq, splits, D]
+    unsigned *cnt;                // [B, Hq, 2], zero between launches
+    unsigned short *o;            // [B, Hq D]
+    const int *len_dev;
+    int len_arg, Hq, Hkv;
+    float scale;
+};
+
+template <int D>
+__global__ __launch_bounds__(kSplitThreads) void attn_decode_one_kernel(DecodeOneArgs A)
+{
+    constexpr int NW = kSplitThreads / 64, EPL = D / 64, KU = 16, half = D / 2;
+    constexpr int TPR = D / 8, NS = kSplitThreads / TPR, VU = 8;
+    __shared__ __attribute__((aligned(16))) unsigned short s_q[D], s_kn[D];
+    __shared__ float s_red[2 * NW];
+    __shared__ float s_sc[kSplitMaxChunk];
+    __shared__ float s_part[NS * D];
+    __shared__ float s_st[2 * 64];                         // the splits' (maximum, sum) pairs (splits <= 64)
+    __shared__ unsigned s_last;
+    const int sp = blockIdx.x, hq = blockIdx.y, b = blockIdx.z, G = A.Hq / A.Hkv, g = hq / G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_splits = gridDim.x;
+    const int len = A.len_dev ? *A.len_dev : A.len_arg, chunk = (len + n_splits - 1) / n_splits;
+    const int k0 = sp * chunk, k1 = min(len, k0 + chunk);
+    const unsigned short *row = A.qkv + (long long)b * A.ld_qkv;
+    auto bf = [](float x) { return (unsigned short)(pack_bf16(x, 0.f) & 0xFFFFu); };
+    // ---- 0: RoPE -- piece c (eight elements) of a head's first half with piece c of its second half
+    if (tid < 2 * (half / 8)) {
+        const int c = tid % (half / 8), h = tid / (half / 8);                  // h 0: the query head; 1: the new key of its KV head
+        const unsigned short *p = row + (long long)(h == 0 ? hq : A.Hq + g) * D + c * 8;
+        bf16x8 a = *reinterpret_cast<const bf16x8 *>(p), bb = *reinterpret_cast<const bf16x8 *>(p + half);
+        const float *pc = A.cs + (size_t)b * half + c * 8, *ps = A.sn + (size_t)b * half + c * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float cc = bf2f(bf(pc[j])), ss = bf2f(bf(ps[j]));
+            const float x1 = bf2f((unsigned short)a[j]), x2 = bf2f((unsigned short)bb[j]);
+            a[j] = (short)bf(x1 * cc - x2 * ss); bb[j] = (short)bf(x2 * cc + x1 * ss);
+        }
+        unsigned short *dst = h == 0 ? s_q : s_kn;
+        *reinterpret_cast<bf16x8 *>(dst + c * 8) = a;
+        *reinterpret_cast<bf16x8 *>(dst + half + c * 8) = bb;
+        if (h == 1 && sp == 0 && hq == g * G) {                                // the append: rotated key
+            unsigned short *kc = A.cache + ((long long)b * A.cap + (len - 1)) * A.ld + (size_t)g * D + c * 8;
+            *reinterpret_cast<bf16x8 *>(kc) = a;
+            *reinterpret_cast<bf16x8 *>(kc + half) = bb;
+        }
+    }
+    if (sp == 0 && hq == g * G && tid >= 128 && tid < 128 + D / 8)             // the append: the value as it is
+        *reinterpret_cast<bf16x8 *>(A.cache + ((long long)b * A.cap + (len - 1)) * A.ld + (size_t)A.Hkv * D + (size_t)g * D + (tid - 128) * 8) =
+            *reinterpret_cast<const bf16x8 *>(row + (long long)(A.Hq + A.Hkv + g) * D + (tid - 128) * 8);
+    __syncthreads();
+    // ---- 1: scores (attn_decode_scores_kernel)
+    float qf[EPL], kn[EPL];
+#pragma unroll
+    for (int t = 0; t < EPL; ++t) { qf[t] = bf2f(s_q[lane * EPL + t]); kn[t] = bf2f(s_kn[lane * EPL + t]); }
+    const unsigned short *K = A.cache + (long long)b * A.cap * A.ld + (long long)g * D;
+    const float *mrow = A.mask + (long long)b * A.mask_ld;
+    float m = -INFINITY;
+    for (int j0 = k0 + wave; j0 < k1; j0 += KU * NW) {
+        float part[KU], mk[KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) mk[u] = mrow[min(j0 + u * NW, k1 - 1)];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int j = j0 + u * NW;
+            part[u] = 0.f;
+            if (j < k1) {
+                const unsigned short *kr = K + (long long)j * A.ld + lane * EPL;
+                if (j == len - 1) {                                            // the new key: its cache row is being written by another workgroup
+                    part[u] = qf[0] * kn[0];
+#pragma unroll
+                    for (int t = 1; t < EPL; ++t) part[u] += qf[t] * kn[t];
+                } else if constexpr (EPL == 4) {
+                    const uint2 kv = *reinterpret_cast<const uint2 *>(kr);
+                    part[u] = qf[0] * __uint_as_float(kv.x << 16) + qf[1] * __uint_as_float(kv.x & 0xFFFF0000u) +
+                              qf[2] * __uint_as_float(kv.y << 16) + qf[3] * __uint_as_float(kv.y & 0xFFFF0000u);
+                } else if constexpr (EPL == 2) {
+                    const unsigned kv = *reinterpret_cast<const unsigned *>(kr);
+                    part[u] = qf[0] * __uint_as_float(kv << 16) + qf[1] * __uint_as_float(kv & 0xFFFF0000u);
+                } else {
+                    part[u] = qf[0] * bf2f(kr[0]);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1)
+#pragma unroll
+            for (int u = 0; u < KU; ++u) part[u] += __shfl_xor(part[u], d, 64);
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int j = j0 + u * NW;
+            if (j < k1) {
+                const float sdot = (mk[u] != 0.f) ? part[u] * A.scale : -INFINITY;
+                if (lane == 0) s_sc[j - k0] = sdot;
+                m = fmaxf(m, sdot);
+            }
+        }
+    }
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = s_red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, s_red[w]);
+    float l = 0.f;
+    for (int j = k0 + tid; j < k1; j += kSplitThreads) l += (m == -INFINITY) ? 0.f : __expf(s_sc[j - k0] - m);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) l += __shfl_xor(l, d, 64);
+    if (lane == 0) s_red[NW + wave] = l;
+    __syncthreads();
+    float *st = A.stats + ((long long)b * A.Hq + hq) * n_splits * 2;
+    unsigned *cnt = A.cnt + ((long long)b * A.Hq + hq) * 2;
+    if (tid == 0) {
+        l = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) l += s_red[NW + w];
+        __hip_atomic_store(&st[2 * sp], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st[2 * sp + 1], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&cnt[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(&cnt[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)n_splits) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    // ---- 2: values (attn_decode_values_kernel)
+    if (tid < 2 * n_splits) s_st[tid] = __hip_atomic_load(&st[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    m = -INFINITY;
+    for (int t = 0; t < n_splits; ++t) m = fmaxf(m, s_st[2 * t]);
+    l = 0.f;
+    for (int t = 0; t < n_splits; ++t) l += (s_st[2 * t] == -INFINITY) ? 0.f : s_st[2 * t + 1] * __expf(s_st[2 * t] - m);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const unsigned short *V = A.cache + (long long)b * A.cap * A.ld + (long long)A.Hkv * D + (long long)g * D;
+    const unsigned short *vnew = row + (long long)(A.Hq + A.Hkv + g) * D;
+    const int piece = tid % TPR, slice = tid / TPR;
+    float acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = 0.f;
+    for (int j0 = k0 + slice; j0 < k1; j0 += VU * NS) {
+        bf16x8 vv[VU];
+        float sc[VU];
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int j = min(j0 + u * NS, k1 - 1);
+            vv[u] = *reinterpret_cast<const bf16x8 *>((j == len - 1 ? vnew : V + (long long)j * A.ld) + piece * 8);
+            sc[u] = s_sc[j - k0];
+        }
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int j = j0 + u * NS;
+            const float e = (m == -INFINITY) ? 0.f : __expf(sc[u] - m);
+            const float pj = (j < k1) ? bf2f(bf(e * inv)) : 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] += pj * bf2f((unsigned short)vv[u][t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s_part[slice * D + piece * 8 + t] = acc[t];
+    __syncthreads();
+    float *part_out = A.partial + ((long long)b * A.Hq + hq) * n_splits * D;
+    if (tid < D) {
+        float sum = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) sum += s_part[sl * D + tid];
+        __hip_atomic_store(&part_out[(long long)sp * D + tid], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                                           // (every store of the workgroup is issued before its ticket is taken)
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        s_last = __hip_atomic_fetch_add(&cnt[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_splits - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- the last workgroup of the (sequence, head): the splits' partial outputs in split order (attn_decode_combine_kernel)
+    if (tid < D) {
+        float sum = 0.f;
+        for (int t = 0; t < n_splits; ++t) sum += __hip_atomic_load(&part_out[(long long)t * D + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        A.o[((long long)b * A.Hq + hq) * D + tid] = bf(sum);
+    }
+    if (tid == 0) {
+        __hip_atomic_store(&cnt[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&cnt[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // head_dim 64 forward and backward: 2 = the lean kernels (LDS-DMA staging, softmax constants in the MFMA accumulators: the default), 1 = the round-2 LDS-DMA
 // kernels, 0 = the register-staged kernels (tests / A-B).  Bits 8 / 9 / 10 send the forward / dQ / dK-dV kernel alone back to mode 1 (A-B of one kernel).
 int g_attn_dma = 2;
@@ -2942,6 +3141,46 @@ extern "C" int ecgb_attn_decode_split_dyn(const void *q_dev, const void *k_cache
     if (!kv_len_dev) { ecgb::set_error("ecgb_attn_decode_split_dyn: NULL length pointer"); return ECGB_ERR_INVALID; }
     return launch_attn_decode_split("ecgb_attn_decode_split_dyn", q_dev, k_cache_dev, v_cache_dev, ld, capacity, attn_mask_dev, mask_ld, o_dev, batch, 0, kv_len_dev,
                                     n_q_heads, n_kv_heads, head_dim, scale, n_splits, scratch_dev, scratch_bytes, stream);
+}
+
+// floats of scratch ecgb_attn_decode_one needs (statistics, partial outputs, counters); the LAST batch * n_q_heads * 2 words (the counters) must be zero before the first call
+extern "C" size_t ecgb_attn_decode_one_scratch_floats(int batch, int n_q_heads, int head_dim, int n_splits)
+{
+    if (batch <= 0 || n_q_heads <= 0 || head_dim <= 0 || n_splits <= 0) return 0;
+    return (size_t)batch * n_q_heads * ((size_t)n_splits * (2 + (size_t)head_dim) + 2);
+}
+
+// A decode step's RoPE + cache append + attention in ONE launch, from the step's raw q|k|v projection (q and k NOT rotated in place): the bits of ecgb_rope_append
+// followed by ecgb_attn_decode_split[_dyn] with the same n_splits.  ECGB_ERR_UNSUPPORTED outside head_dim 64 / 128 / 256, n_splits <= 64, at most 2048 keys a split and
+// n_splits * n_q_heads * batch <= 256 workgroups (they wait for each other inside the launch: all of them must be resident).
+extern "C" int ecgb_attn_decode_one(const void *qkv_dev, long long ld_qkv, const float *cos_dev, const float *sin_dev, void *cache_dev, long long ld, long long capacity,
+                                    const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, const int *kv_len_dev, int n_q_heads, int n_kv_heads,
+                                    int head_dim, float scale, int n_splits, float *scratch_dev, size_t scratch_floats, void *stream)
+{
+    if (!qkv_dev || !cos_dev || !sin_dev || !cache_dev || !attn_mask_dev || !o_dev || !scratch_dev || batch <= 0 || n_q_heads <= 0 || n_kv_heads <= 0 || n_splits <= 0 ||
+        n_q_heads % n_kv_heads || capacity <= 0 || (!kv_len_dev && (kv_len <= 0 || kv_len > capacity))) {
+        ecgb::set_error("ecgb_attn_decode_one: bad argument");
+        return ECGB_ERR_INVALID;
+    }
+    const long long longest = kv_len_dev ? capacity : (long long)kv_len;
+    if ((head_dim != 64 && head_dim != 128 && head_dim != 256) || n_splits > 64 || (longest + n_splits - 1) / n_splits > kSplitMaxChunk ||
+        (long long)n_splits * n_q_heads * batch > 256 || ld % 8 || ld_qkv % 8 || ((uintptr_t)qkv_dev & 15) || ((uintptr_t)cache_dev & 15) ||
+        scratch_floats < ecgb_attn_decode_one_scratch_floats(batch, n_q_heads, head_dim, n_splits)) {
+        ecgb::set_error("ecgb_attn_decode_one: head_dim 64 / 128 / 256, at most 64 splits of at most 2048 keys, at most 256 workgroups, scratch of ecgb_attn_decode_one_scratch_floats()");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    DecodeOneArgs A;
+    A.qkv = (const unsigned short *)qkv_dev; A.ld_qkv = ld_qkv; A.cs = cos_dev; A.sn = sin_dev; A.cache = (unsigned short *)cache_dev; A.cap = capacity; A.ld = ld;
+    A.mask = attn_mask_dev; A.mask_ld = mask_ld;
+    A.stats = scratch_dev;
+    A.partial = A.stats + (size_t)batch * n_q_heads * n_splits * 2;
+    A.cnt = reinterpret_cast<unsigned *>(A.partial + (size_t)batch * n_q_heads * n_splits * head_dim);
+    A.o = (unsigned short *)o_dev; A.len_dev = kv_len_dev; A.len_arg = kv_len; A.Hq = n_q_heads; A.Hkv = n_kv_heads; A.scale = scale;
+    const dim3 grid((unsigned)n_splits, (unsigned)n_q_heads, (unsigned)batch);
+    if (head_dim == 64) hipLaunchKernelGGL(attn_decode_one_kernel<64>, grid, dim3(kSplitThreads), 0, (hipStream_t)stream, A);
+    else if (head_dim == 128) hipLaunchKernelGGL(attn_decode_one_kernel<128>, grid, dim3(kSplitThreads), 0, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(attn_decode_one_kernel<256>, grid, dim3(kSplitThreads), 0, (hipStream_t)stream, A);
+    return launched("attn_decode_one_kernel");
 }
 
 extern "C" int ecgb_attn_decode_dyn(const void *q_dev, const void *k_cache_dev, const void *v_cache_dev, long long ld, long long capacity,

@@ -225,6 +225,7 @@ class HipCausalLM(nn.Module):
     # HipAdam(overlap=True) needs the forward to wait per parameter group (`_wait_group`) and backward / inference to `sync_optimizer`: a subclass whose
     # own forward / backward do not (HipGPT2LM) sets this False and gets the plain in-stream step
     supports_optimizer_overlap = True
+    decode_attn_one = True      # a decode step's RoPE + append + attention as one launch where the shape allows (ops.decode_one_ok); False: round 4's four launches, the same bits
     def __init__(self, cfg: DecoderConfig, device="cuda", seed: int = 0):
         super().__init__()
         self.cfg = cfg
@@ -921,10 +922,10 @@ class HipCausalLM(nn.Module):
             ops.ce_fwd_bwd_(logits, shifted.index_select(0, r), inv_count, loss, c.vocab_size)
         return loss.squeeze(0)
 
-    def _decode_step(self, tokens, pos, mask, caches, n, n_dev=None, scratch=None):
+    def _decode_step(self, tokens, pos, mask, caches, n, n_dev=None, scratch=None, scratch_one=None):
         """Hidden state [B, H] of one new token per sequence, written at cache row n-1 (n = keys valid after the update).
         n_dev: int32[1] device tensor holding n -- then nothing in the launches depends on the step (graph replay); scratch: the
-        split decode attention's buffer the captured step owns."""
+        split decode attention's buffer the captured step owns (scratch_one: the one-launch attention's)."""
         c = self.cfg
         D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
         QKV = self.qkv
@@ -946,16 +947,17 @@ class HipCausalLM(nn.Module):
             else:
                 (h1, _, x), t1 = ops.rmsnorm_fwd(x, self.ln1[i].data, c.rms_norm_eps, residual=delta, gemma=self.gemma), None
             qkv, _ = self._proj(i, "qkv", h1, self.wqkv[i].data, t_pre=t1)         # [B, QKV]
-            ops.rope_append_(qkv, cos, sin, Hq, Hkv, D, caches[i], n if n_dev is None else n_dev)   # RoPE on q and k, the rotated k and v into the cache: one launch
             ns = ops.decode_splits(caches[i].shape[1], qkv.shape[0], Hq)
-            if n_dev is None:
-                if ns > 1:
-                    ao = ops.attn_decode_split(qkv, caches[i], mask, n, Hq, Hkv, D, scale, ns)
-                else:
-                    ao = ops.attn_decode(qkv, caches[i], mask, n, Hq, Hkv, D, scale)
+            nn = n if n_dev is None else n_dev
+            if self.decode_attn_one and ops.decode_one_ok(qkv.shape[0], Hq, D, ns, caches[i].shape[1]):
+                # round 6: RoPE + cache append + scores + values + combine in ONE launch (the bits of the four: tests/test_gpu_decode_fused.py)
+                ao = ops.attn_decode_one(qkv, cos, sin, caches[i], mask, nn, Hq, Hkv, D, scale, ns, scratch=scratch_one if n_dev is not None else None)
             else:
+                ops.rope_append_(qkv, cos, sin, Hq, Hkv, D, caches[i], nn)   # RoPE on q and k, the rotated k and v into the cache: one launch
                 if ns > 1:
-                    ao = ops.attn_decode_split(qkv, caches[i], mask, n_dev, Hq, Hkv, D, scale, ns, scratch=scratch)
+                    ao = ops.attn_decode_split(qkv, caches[i], mask, nn, Hq, Hkv, D, scale, ns, scratch=scratch if n_dev is not None else None)
+                elif n_dev is None:
+                    ao = ops.attn_decode(qkv, caches[i], mask, n, Hq, Hkv, D, scale)
                 else:
                     ao = ops.attn_decode_dyn(qkv, caches[i], mask, n_dev, Hq, Hkv, D, scale)
             attn_delta, _ = self._proj(i, "o", ao, self.wo[i].data)
@@ -1178,7 +1180,7 @@ class HipCausalLM(nn.Module):
         cap = -(-(S0 + max_new_tokens) // 128) * 128
         pad_id = pad_token_id if pad_token_id is not None else 0
         key = (B, cap, pad_id, None if eos is None else tuple(int(e) for e in eos.tolist()), sampling, self.training, self.embed.data_ptr(),
-               None if self.lora is None else self.lora[0]["qkv"].A.data_ptr(), self.wqkv[0].data_ptr())      # (the last: base weights or their merged copies)
+               None if self.lora is None else self.lora[0]["qkv"].A.data_ptr(), self.wqkv[0].data_ptr(), bool(self.decode_attn_one))      # (the last: base weights or their merged copies)
         graphs = self.__dict__.setdefault("_gen_graphs", {})
         st = graphs.get(key) if sampling is None else None                   # (a sampling step holds torch's sort / cumsum / multinomial: captured per call, see below)
         if st is None:
@@ -1195,7 +1197,10 @@ class HipCausalLM(nn.Module):
                                  ones_col=torch.ones((B, 1), dtype=torch.float32, device=dev),
                                  pad_t=torch.full((B,), pad_id, dtype=torch.long, device=dev), eos=eos, scratch=None)
             ns = ops.decode_splits(cap, B, c.num_attention_heads)
-            if ns > 1:
+            st.scratch_one = None
+            if self.decode_attn_one and ops.decode_one_ok(B, c.num_attention_heads, c.head_dim, ns, cap):
+                st.scratch_one = ops.decode_one_scratch(B, c.num_attention_heads, c.head_dim, ns, dev)
+            elif ns > 1:
                 st.scratch = ops.decode_split_scratch(cap, B, c.num_attention_heads, c.head_dim, ns, dev)
             if sampling is None:
                 graphs[key] = st
@@ -1226,7 +1231,7 @@ class HipCausalLM(nn.Module):
         eos_i64 = None if eos_s is None else eos_s.to(torch.int64).contiguous()
 
         def step():
-            last = self._decode_step(tok, pos, gmask, caches, None, n_dev, scratch=st.scratch)
+            last = self._decode_step(tok, pos, gmask, caches, None, n_dev, scratch=st.scratch, scratch_one=st.scratch_one)
             nx = pick(ops.gemm_nt(last, self.embed.data))
             # pad for finished sequences, the eos test, the token into `out` and `tok`, the mask's new column, the three counters: one launch (six to eleven
             # element-wise ones before, 5 us each in the replayed graph)

@@ -819,6 +819,38 @@ def attn_decode_split(qkv_new, cache, mask, kv_len, Hq, Hkv, D, scale, n_splits,
     return o
 
 
+def decode_one_ok(B, Hq, D, n_splits, cap):
+    """Does the one-launch decode attention (ecgb_attn_decode_one) take this step?  Its workgroups wait for each other inside the launch: all resident at once."""
+    return n_splits > 1 and n_splits <= 64 and n_splits * Hq * B <= 256 and D in (64, 128, 256) and -(-cap // n_splits) <= 2048
+
+
+def decode_one_scratch(B, Hq, D, n_splits, device):
+    """Scratch of attn_decode_one (statistics, partial outputs, the counters -- zero, and every launch leaves them zero)."""
+    return torch.zeros(_L().ecgb_attn_decode_one_scratch_floats(B, Hq, D, n_splits), dtype=torch.float32, device=device)
+
+
+_one_scratch = {}
+
+
+def attn_decode_one(qkv_new, cos, sin, cache, mask, kv_len, Hq, Hkv, D, scale, n_splits, scratch=None):
+    """rope_append_ + attn_decode_split in ONE launch (ecgb_attn_decode_one): RoPE of the new token's q and k, its rotated k and its v into cache row kv_len - 1,
+    softmax(q K^T scale + mask) V over the kv_len cached keys; qkv_new is left as it is.  The same bits as the separate launches with the same n_splits.
+    kv_len: an int or an int32[1] device tensor; scratch: a caller-owned buffer (decode_one_scratch) -- a captured graph must own the one it was captured with."""
+    B, cap, W = cache.shape
+    o = torch.empty((B, Hq * D), dtype=torch.bfloat16, device=qkv_new.device)
+    buf = scratch
+    if buf is None:
+        key = (qkv_new.device, B, Hq, D, n_splits)
+        buf = _one_scratch.get(key)
+        if buf is None:
+            _one_scratch.clear()
+            buf = _one_scratch[key] = decode_one_scratch(B, Hq, D, n_splits, qkv_new.device)
+    dyn = torch.is_tensor(kv_len)
+    _lib.check(_L().ecgb_attn_decode_one(_p(_bf(qkv_new)), qkv_new.stride(0), _p(cos), _p(sin), _p(cache), W, cap, _p(mask), mask.stride(0), _p(o), B,
+                                         0 if dyn else int(kv_len), _p(kv_len) if dyn else None, Hq, Hkv, D, float(scale), int(n_splits), _p(buf), buf.numel(), _st()))
+    return o
+
+
 def attn_decode_dyn(qkv_new, cache, mask, kv_len_dev, Hq, Hkv, D, scale):
     """attn_decode with the number of valid cache rows in device memory (int32[1]): replayable from a captured graph."""
     B, cap, W = cache.shape

@@ -307,6 +307,17 @@ int ecgb_attn_decode_split_dyn(const void *q_dev, const void *k_cache_dev, const
                                const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, const int *kv_len_dev, int n_q_heads,
                                int n_kv_heads, int head_dim, float scale, int n_splits, void *scratch_dev, size_t scratch_bytes, void *stream);
 
+/* Round 6: a decode step's RoPE + KV-cache append + attention in ONE launch, from the step's raw q|k|v projection [batch, (n_q + 2 n_kv) head_dim] (q and k are NOT
+ * rotated in place: the cache row kv_len - 1 and o are what leaves) -- replaces ecgb_rope_append + ecgb_attn_decode_split[_dyn] (cache_utils.py:408-470 DynamicCache.update,
+ * modeling_llama.py:526-614 at one query row), the same bits for the same n_splits.  The workgroups of a (sequence, head) meet through counters inside the launch, so all
+ * n_splits * n_q_heads * batch of them must be resident: ECGB_ERR_UNSUPPORTED above 256 (and outside head_dim 64 / 128 / 256, n_splits <= 64, 2048 keys a split); the
+ * caller then runs the separate launches.  scratch: ecgb_attn_decode_one_scratch_floats() floats whose LAST batch * n_q_heads * 2 words (the counters) are zero before
+ * the first call; every launch leaves them zero.  kv_len_dev: the number of valid cache rows AFTER the append in device memory (a replayed graph), else kv_len. */
+size_t ecgb_attn_decode_one_scratch_floats(int batch, int n_q_heads, int head_dim, int n_splits);
+int ecgb_attn_decode_one(const void *qkv_dev, long long ld_qkv, const float *cos_dev, const float *sin_dev, void *cache_dev, long long ld, long long capacity,
+                         const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, const int *kv_len_dev, int n_q_heads, int n_kv_heads,
+                         int head_dim, float scale, int n_splits, float *scratch_dev, size_t scratch_floats, void *stream);
+
 /* C = alpha * A . B^T like ecgb_gemm_nt_bf16 (plain bf16 store, one problem), on four waves per workgroup with 128x128 wave tiles (csrc/gemm_w4.hip).
  * Whole 256x256 tiles only: M and N multiples of 256, K of 64, 16-byte aligned operands; ECGB_ERR_UNSUPPORTED otherwise.  ecgb_gemm_nt_bf16 dispatches here
  * when the problem also has at least two tiles per CU (batch 1, plain store); the same bits as the eight-wave kernels. */

@@ -146,3 +146,77 @@ def test_fused_decode_step_equals_the_separate_kernels(family, lora):
     # the two-launch attention splits the keys differently from the short-cache kernel: the same tokens, logits equal up to the order of fp32 sums
     assert torch.equal(outs["fused+attn"][0], outs["separate"][0])
     assert torch.allclose(outs["fused+attn"][1], outs["separate"][1], atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("dyn", [False, True], ids=["host-length", "device-length"])
+@pytest.mark.parametrize("B,Hq,Hkv,D,cap,n,ns", [(1, 8, 1, 256, 768, 729, 12), (1, 8, 1, 256, 768, 600, 12), (2, 8, 2, 64, 1024, 1024, 16), (1, 32, 8, 64, 640, 577, 8),
+                                                (2, 4, 1, 128, 2048, 1301, 32), (1, 8, 1, 256, 768, 14, 12)],
+                         ids=["c5-step", "c5-first-step", "two-sequences", "llama1b", "d128-long", "more-splits-than-keys"])
+def test_one_launch_attention_equals_rope_append_and_split_attention(ops, B, Hq, Hkv, D, cap, n, ns, dyn):
+    """ecgb_attn_decode_one (round 6: RoPE + append + scores + values + combine, the splits' workgroups meeting through counters inside the launch) against
+    ecgb_rope_append followed by ecgb_attn_decode_split with the same split count: the attention output AND the cache bit for bit; repeated launches on one scratch
+    (the counters return to zero) repeat the bits; q|k|v itself is left unrotated."""
+    qkv = _bf(B, (Hq + 2 * Hkv) * D, seed=41)
+    cache = _bf(B, cap, 2 * Hkv * D, seed=42)
+    mask = torch.ones(B, cap, device="cuda")
+    mask[:, n:] = 0
+    mask[0, : min(37, n - 1)] = 0
+    pos = torch.tensor([n - 1 - min(37, n - 1), n - 1][:B], device="cuda").float()
+    fr = pos[:, None] * torch.rand(D // 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(6))[None]
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    scale = 1.0 / math.sqrt(D)
+    assert ops.decode_one_ok(B, Hq, D, ns, cap)
+    kv = torch.full((1,), n, dtype=torch.int32, device="cuda") if dyn else n
+    q2, c2 = qkv.clone(), cache.clone()
+    ops.rope_append_(q2, cos, sin, Hq, Hkv, D, c2, kv)
+    ref = ops.attn_decode_split(q2, c2, mask, kv, Hq, Hkv, D, scale, ns)
+    scratch = ops.decode_one_scratch(B, Hq, D, ns, "cuda")
+    q1 = qkv.clone()
+    for rep in range(3):
+        c1 = cache.clone()
+        got = ops.attn_decode_one(q1, cos, sin, c1, mask, kv, Hq, Hkv, D, scale, ns, scratch=scratch)
+        assert torch.equal(c1, c2), rep
+        assert torch.equal(got, ref), rep
+    assert torch.equal(q1, qkv)
+    assert float(scratch[-2 * B * Hq:].abs().max()) == 0.0                    # the counters went back to zero
+
+
+def test_one_launch_attention_refuses_launches_that_could_not_be_resident(ops):
+    assert not ops.decode_one_ok(4, 32, 64, 16, 1024) and not ops.decode_one_ok(1, 8, 256, 1, 256) and not ops.decode_one_ok(1, 8, 96, 8, 1024)
+    from ecg_byte_amd import _lib
+    B, Hq, Hkv, D, cap, ns = 4, 32, 8, 64, 1024, 16
+    qkv, cache, mask = _bf(B, (Hq + 2 * Hkv) * D), _bf(B, cap, 2 * Hkv * D), torch.ones(B, cap, device="cuda")
+    cos = sin = torch.zeros(B, D // 2, device="cuda")
+    with pytest.raises(_lib.EcgbError):
+        ops.attn_decode_one(qkv, cos, sin, cache, mask, 1000, Hq, Hkv, D, 0.125, ns)
+
+
+@pytest.mark.parametrize("family,lora", [("llama", False), ("gemma", True)])
+def test_generate_with_one_launch_attention_equals_four_launches(family, lora):
+    """generate() with caches long enough for the split attention (prompt 600): the one-launch attention step (default) against round 4's four launches, token for token,
+    logit for logit, eager loop and replayed graph."""
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    kw = dict(vocab_size=1000, hidden_size=512, intermediate_size=2048, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2, head_dim=64, pad_token_id=999)
+    if family == "gemma":
+        kw.update(model_type="gemma", num_key_value_heads=1, head_dim=256, num_attention_heads=4, rms_norm_eps=1e-6)
+    m = HipCausalLM(DecoderConfig(**kw), seed=5)
+    if lora:
+        m.enable_lora(r=16, alpha=32, dropout=0.05)
+        g = torch.Generator(device="cuda").manual_seed(9)
+        with torch.no_grad():
+            for sites in m.lora:
+                for s in sites.values():
+                    s.B.copy_((torch.randn(s.B.shape, device="cuda", generator=g) * 0.05).to(torch.bfloat16) * s.bmask)
+    m.eval()
+    ids = torch.randint(0, 990, (1, 600), device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    mask = torch.ones(1, 600, device="cuda")
+    mask[0, :11] = 0
+    outs = {}
+    for one in (False, True):
+        m.decode_attn_one = one
+        seq, logits = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=10, pad_token_id=999, return_logits=True, use_graph=False)
+        seq_g = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=10, pad_token_id=999)
+        seq_g2 = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=10, pad_token_id=999)     # the captured step replayed by a second call
+        assert torch.equal(seq, seq_g) and torch.equal(seq, seq_g2), one
+        outs[one] = (seq, logits)
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])

@@ -468,7 +468,7 @@ def test_generate_with_merged_adapters_follows_the_unmerged_greedy_path():
     lora, m.lora = m.lora, None
     log_0 = m.generate(return_logits=True, **kw)[1]
     m.lora = lora
-    assert (log_0[:, 0] - log_u[:, 0]).abs().max().item() > 10 * tol
+    assert (log_0[:, 0] - log_u[:, 0]).abs().max().item() > 3 * tol
     # graph replay of the merged mode = its eager loop; the captured merged step is reused and re-merged per call
     a = m.generate(merge_adapters=True, use_graph=True, **kw)
     b = m.generate(merge_adapters=True, use_graph=False, **kw)
@@ -645,6 +645,7 @@ def test_generate_long_prompt_takes_the_split_decode_attention(monkeypatch):
     mask[1, :9] = 0                                              # left padding on one row
     ids[1, :9] = 299
     mask = mask.cuda()
+    m.decode_attn_one = False                                    # (round 4's four launches: what this test counts; the one-launch form has its own tests)
     calls = {"split": 0, "one": 0}
     real_split, real_one = ops.attn_decode_split, ops.attn_decode
     monkeypatch.setattr(ops, "attn_decode_split", lambda *a, **k: (calls.__setitem__("split", calls["split"] + 1), real_split(*a, **k))[1])
@@ -673,11 +674,17 @@ def test_generate_long_prompt_graph_replay_equals_eager_loop():
     mask[0, :17] = 0
     ids[0, :17] = 299
     mask = mask.cuda()
-    m._gen_graphs = {}
-    for cut, new in ((0, 30), (40, 70), (3, 12)):
-        kw = dict(input_ids=ids[:, cut:], attention_mask=mask[:, cut:], max_new_tokens=new, pad_token_id=299)
-        assert torch.equal(m.generate(use_graph=True, **kw), m.generate(use_graph=False, **kw)), (cut, new)
-    assert len(m._gen_graphs) == 1 and next(iter(m._gen_graphs.values())).scratch is not None
+    seen = {}
+    for one in (False, True):                                    # round 4's four launches; round 6's one-launch attention (the default)
+        m.decode_attn_one = one
+        m._gen_graphs = {}
+        for cut, new in ((0, 30), (40, 70), (3, 12)):
+            kw = dict(input_ids=ids[:, cut:], attention_mask=mask[:, cut:], max_new_tokens=new, pad_token_id=299)
+            out = m.generate(use_graph=True, **kw)
+            assert torch.equal(out, m.generate(use_graph=False, **kw)), (one, cut, new)
+            assert torch.equal(seen.setdefault((cut, new), out), out)       # and both forms produce the same sequences
+        st = next(iter(m._gen_graphs.values()))
+        assert len(m._gen_graphs) == 1 and (st.scratch_one if one else st.scratch) is not None
 
 
 def test_generate_sampling_follows_the_warped_distribution(tmp_path):
