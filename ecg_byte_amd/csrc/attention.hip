@@ -2151,6 +2151,43 @@ __global__ __launch_bounds__(kSplitThreads) void attn_decode_one_kernel(DecodeOn
     const int k0 = sp * chunk, k1 = min(len, k0 + chunk);
     const unsigned short *row = A.qkv + (long long)b * A.ld_qkv;
     auto bf = [](float x) { return (unsigned short)(pack_bf16(x, 0.f) & 0xFFFFu); };
+    // Memory between the workgroups of a (sequence, head): everything they exchange (statistics, partial outputs, counters) is written and read with agent-scope
+    // RELAXED atomics -- stores that go through to the level the XCDs share, loads that do not stop at this XCD's L2 -- ordered by hand: a wave's stores are
+    // complete (s_waitcnt vmcnt(0)) before its workgroup's counter moves.  Release / acquire orderings on the counters cost a write-back of the whole L2 per
+    // arrival and an invalidate per poll: the launch took 24 us that way, as long as the four it replaces.
+    auto ld_f = [](const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto st_f = [](float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const unsigned short *K = A.cache + (long long)b * A.cap * A.ld + (long long)g * D;
+    const unsigned short *V = A.cache + (long long)b * A.cap * A.ld + (long long)A.Hkv * D + (long long)g * D;
+    const unsigned short *vnew = row + (long long)(A.Hq + A.Hkv + g) * D;
+    const float *mrow = A.mask + (long long)b * A.mask_ld;
+    const int piece = tid % TPR, slice = tid / TPR;
+    // ---- the first batch of keys and values is asked for before anything else (a split of the C5 step is one batch: 61 keys): the loads fly under the RoPE and
+    // the values' under the scores and the first meeting
+    using kraw_t = uint2;                                                      // EPL elements of a key row as raw bits (EPL 4: 8 bytes, 2: 4, 1: 2)
+    kraw_t kraw[KU];
+    float mk0[KU];
+    auto load_k = [&](int j0, kraw_t (&kr)[KU], float (&mk)[KU]) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int j = min(j0 + u * NW, k1 - 1);
+            mk[u] = mrow[j];
+            const unsigned short *p = K + (long long)j * A.ld + lane * EPL;
+            if constexpr (EPL == 4) kr[u] = *reinterpret_cast<const uint2 *>(p);
+            else if constexpr (EPL == 2) { kr[u].x = *reinterpret_cast<const unsigned *>(p); kr[u].y = 0u; }
+            else { kr[u].x = p[0]; kr[u].y = 0u; }
+        }
+    };
+    bf16x8 vraw[VU];
+    auto load_v = [&](int j0, bf16x8 (&vv)[VU]) {
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int j = min(j0 + u * NS, k1 - 1);
+            vv[u] = *reinterpret_cast<const bf16x8 *>((j == len - 1 ? vnew : V + (long long)j * A.ld) + piece * 8);
+        }
+    };
+    if (k0 + wave < k1) load_k(k0 + wave, kraw, mk0);
+    if (k0 + slice < k1) load_v(k0 + slice, vraw);
     // ---- 0: RoPE -- piece c (eight elements) of a head's first half with piece c of its second half
     if (tid < 2 * (half / 8)) {
         const int c = tid % (half / 8), h = tid / (half / 8);                  // h 0: the query head; 1: the new key of its KV head
@@ -2174,38 +2211,32 @@ __global__ __launch_bounds__(kSplitThreads) void attn_decode_one_kernel(DecodeOn
     }
     if (sp == 0 && hq == g * G && tid >= 128 && tid < 128 + D / 8)             // the append: the value as it is
         *reinterpret_cast<bf16x8 *>(A.cache + ((long long)b * A.cap + (len - 1)) * A.ld + (size_t)A.Hkv * D + (size_t)g * D + (tid - 128) * 8) =
-            *reinterpret_cast<const bf16x8 *>(row + (long long)(A.Hq + A.Hkv + g) * D + (tid - 128) * 8);
+            *reinterpret_cast<const bf16x8 *>(vnew + (tid - 128) * 8);
     __syncthreads();
     // ---- 1: scores (attn_decode_scores_kernel)
     float qf[EPL], kn[EPL];
 #pragma unroll
     for (int t = 0; t < EPL; ++t) { qf[t] = bf2f(s_q[lane * EPL + t]); kn[t] = bf2f(s_kn[lane * EPL + t]); }
-    const unsigned short *K = A.cache + (long long)b * A.cap * A.ld + (long long)g * D;
-    const float *mrow = A.mask + (long long)b * A.mask_ld;
     float m = -INFINITY;
     for (int j0 = k0 + wave; j0 < k1; j0 += KU * NW) {
-        float part[KU], mk[KU];
-#pragma unroll
-        for (int u = 0; u < KU; ++u) mk[u] = mrow[min(j0 + u * NW, k1 - 1)];
+        if (j0 != k0 + wave) load_k(j0, kraw, mk0);
+        float part[KU];
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int j = j0 + u * NW;
             part[u] = 0.f;
             if (j < k1) {
-                const unsigned short *kr = K + (long long)j * A.ld + lane * EPL;
                 if (j == len - 1) {                                            // the new key: its cache row is being written by another workgroup
                     part[u] = qf[0] * kn[0];
 #pragma unroll
                     for (int t = 1; t < EPL; ++t) part[u] += qf[t] * kn[t];
                 } else if constexpr (EPL == 4) {
-                    const uint2 kv = *reinterpret_cast<const uint2 *>(kr);
-                    part[u] = qf[0] * __uint_as_float(kv.x << 16) + qf[1] * __uint_as_float(kv.x & 0xFFFF0000u) +
-                              qf[2] * __uint_as_float(kv.y << 16) + qf[3] * __uint_as_float(kv.y & 0xFFFF0000u);
+                    part[u] = qf[0] * __uint_as_float(kraw[u].x << 16) + qf[1] * __uint_as_float(kraw[u].x & 0xFFFF0000u) +
+                              qf[2] * __uint_as_float(kraw[u].y << 16) + qf[3] * __uint_as_float(kraw[u].y & 0xFFFF0000u);
                 } else if constexpr (EPL == 2) {
-                    const unsigned kv = *reinterpret_cast<const unsigned *>(kr);
-                    part[u] = qf[0] * __uint_as_float(kv << 16) + qf[1] * __uint_as_float(kv & 0xFFFF0000u);
+                    part[u] = qf[0] * __uint_as_float(kraw[u].x << 16) + qf[1] * __uint_as_float(kraw[u].x & 0xFFFF0000u);
                 } else {
-                    part[u] = qf[0] * bf2f(kr[0]);
+                    part[u] = qf[0] * bf2f((unsigned short)kraw[u].x);
                 }
             }
         }
@@ -2217,7 +2248,7 @@ __global__ __launch_bounds__(kSplitThreads) void attn_decode_one_kernel(DecodeOn
         for (int u = 0; u < KU; ++u) {
             const int j = j0 + u * NW;
             if (j < k1) {
-                const float sdot = (mk[u] != 0.f) ? part[u] * A.scale : -INFINITY;
+                const float sdot = (mk0[u] != 0.f) ? part[u] * A.scale : -INFINITY;
                 if (lane == 0) s_sc[j - k0] = sdot;
                 m = fmaxf(m, sdot);
             }
@@ -2240,42 +2271,36 @@ __global__ __launch_bounds__(kSplitThreads) void attn_decode_one_kernel(DecodeOn
         l = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) l += s_red[NW + w];
-        __hip_atomic_store(&st[2 * sp], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&st[2 * sp + 1], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&cnt[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(&cnt[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)n_splits) __builtin_amdgcn_s_sleep(1);
+        st_f(&st[2 * sp], m);
+        st_f(&st[2 * sp + 1], l);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(&cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)n_splits) __builtin_amdgcn_s_sleep(1);
     }
     __syncthreads();
     // ---- 2: values (attn_decode_values_kernel)
-    if (tid < 2 * n_splits) s_st[tid] = __hip_atomic_load(&st[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 2 * n_splits) s_st[tid] = ld_f(&st[tid]);
     __syncthreads();
     m = -INFINITY;
     for (int t = 0; t < n_splits; ++t) m = fmaxf(m, s_st[2 * t]);
     l = 0.f;
     for (int t = 0; t < n_splits; ++t) l += (s_st[2 * t] == -INFINITY) ? 0.f : s_st[2 * t + 1] * __expf(s_st[2 * t] - m);
     const float inv = l > 0.f ? 1.f / l : 0.f;
-    const unsigned short *V = A.cache + (long long)b * A.cap * A.ld + (long long)A.Hkv * D + (long long)g * D;
-    const unsigned short *vnew = row + (long long)(A.Hq + A.Hkv + g) * D;
-    const int piece = tid % TPR, slice = tid / TPR;
     float acc[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = 0.f;
     for (int j0 = k0 + slice; j0 < k1; j0 += VU * NS) {
-        bf16x8 vv[VU];
+        if (j0 != k0 + slice) load_v(j0, vraw);
         float sc[VU];
 #pragma unroll
-        for (int u = 0; u < VU; ++u) {
-            const int j = min(j0 + u * NS, k1 - 1);
-            vv[u] = *reinterpret_cast<const bf16x8 *>((j == len - 1 ? vnew : V + (long long)j * A.ld) + piece * 8);
-            sc[u] = s_sc[j - k0];
-        }
+        for (int u = 0; u < VU; ++u) sc[u] = s_sc[min(j0 + u * NS, k1 - 1) - k0];
 #pragma unroll
         for (int u = 0; u < VU; ++u) {
             const int j = j0 + u * NS;
             const float e = (m == -INFINITY) ? 0.f : __expf(sc[u] - m);
             const float pj = (j < k1) ? bf2f(bf(e * inv)) : 0.f;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) acc[t] += pj * bf2f((unsigned short)vv[u][t]);
+            for (int t = 0; t < 8; ++t) acc[t] += pj * bf2f((unsigned short)vraw[u][t]);
         }
     }
 #pragma unroll
@@ -2286,19 +2311,23 @@ __global__ __launch_bounds__(kSplitThreads) void attn_decode_one_kernel(DecodeOn
         float sum = 0.f;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) sum += s_part[sl * D + tid];
-        __hip_atomic_store(&part_out[(long long)sp * D + tid], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_f(&part_out[(long long)sp * D + tid], sum);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // this wave's part of the partial output has arrived
     }
-    __syncthreads();                                                           // (every store of the workgroup is issued before its ticket is taken)
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        s_last = __hip_atomic_fetch_add(&cnt[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_splits - 1) ? 1u : 0u;
-    }
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&cnt[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_splits - 1) ? 1u : 0u;
     __syncthreads();
     if (!s_last) return;
     // ---- the last workgroup of the (sequence, head): the splits' partial outputs in split order (attn_decode_combine_kernel)
     if (tid < D) {
         float sum = 0.f;
-        for (int t = 0; t < n_splits; ++t) sum += __hip_atomic_load(&part_out[(long long)t * D + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int t0 = 0; t0 < n_splits; t0 += 16) {                            // sixteen splits' values in flight, added in split order
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = ld_f(&part_out[(long long)min(t0 + u, n_splits - 1) * D + tid]);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (t0 + u < n_splits) sum += v[u];
+        }
         A.o[((long long)b * A.Hq + hq) * D + tid] = bf(sum);
     }
     if (tid == 0) {
