@@ -1,0 +1,12 @@
+"""Dev-only: the HBM-bound kernels of the train step alone at the C3 shapes (bench.py's hbm_kernel_report): ms per launch and fraction of 8 TB/s."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from ecg_byte_amd.decoder import DecoderConfig
+cfg = DecoderConfig.llama_3_2_1b(vocab_size=132515, pad_token_id=132514)
+for rep in range(2):
+    for r in bench.hbm_kernel_report(torch.device("cuda", 0), 32, 1024, cfg, 132515, reps=20):
+        print(f"{r['kernel']:24s} {r['ms']*1e3:8.1f} us  {r['GB/s']:7.0f} GB/s  {r['frac']:.3f}")
+    print()

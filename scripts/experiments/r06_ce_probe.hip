@@ -1,0 +1,93 @@
+// Round 6 probe: what bounds ce_fwd_bwd_reg_kernel (0.51 of the HBM rate whatever its vector-instruction count)?  The kernel's memory pattern with the arithmetic
+// taken out piece by piece.  One workgroup of 512 threads holds a row of 132 608 bf16 in registers (40 loads of 16 bytes a thread), reduces, writes it back in place.
+//   MODE 0: load, two workgroup reductions with an exp per element each, store (the kernel's shape)      MODE 1: load, store (no arithmetic, no barriers)
+//   MODE 2: load only (one word stored per thread)                                                     MODE 3: as 0 with the reductions' exps removed (barriers kept)
+//   MODE 4: as 1 but a thread's 40 chunks are CONSECUTIVE (640 bytes a thread) instead of strided by 8 KB
+// hipcc --offload-arch=gfx950 -O3 -o /tmp/ce_probe scripts/experiments/r06_ce_probe.hip && /tmp/ce_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+constexpr int MAXC = 40;
+template <int MODE>
+__global__ __launch_bounds__(512) void probe(unsigned short *logits, size_t rows, size_t ld, int grid_rows)
+{
+    __shared__ float s_red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (size_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        unsigned short *p = logits + r * ld;
+        u32x4 v[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = MODE == 4 ? (tid * MAXC + i) * 8 : (i * 512 + tid) * 8;
+            v[i] = *reinterpret_cast<const u32x4 *>(p + (c < (int)ld ? c : 0));
+        }
+        float m = 0.f;
+        if (MODE == 0 || MODE == 3) {
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) m = fmaxf(m, __uint_as_float(v[i][d] << 16));
+            for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+            if (lane == 0) s_red[wv] = m;
+            __syncthreads();
+            for (int w = 0; w < 8; ++w) m = fmaxf(m, s_red[w]);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (MODE == 0) { s += __expf(__uint_as_float(v[i][d] << 16) - m); s += __expf(__uint_as_float(v[i][d] & 0xFFFF0000u) - m); }
+                    else s += __uint_as_float(v[i][d] << 16);
+                }
+            for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+            __syncthreads();
+            if (lane == 0) s_red[wv] = s;
+            __syncthreads();
+            m = 0.f;
+            for (int w = 0; w < 8; ++w) m += s_red[w];
+            __syncthreads();
+        }
+        if (MODE == 2) {
+            unsigned acc = 0;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) acc ^= v[i][0] ^ v[i][1] ^ v[i][2] ^ v[i][3];
+            if (acc == 0x12345u) p[tid] = 1;
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = MODE == 4 ? (tid * MAXC + i) * 8 : (i * 512 + tid) * 8;
+            u32x4 o = v[i];
+            if (MODE == 0) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const float a = __expf(__uint_as_float(v[i][d] << 16) - m), b = __expf(__uint_as_float(v[i][d] & 0xFFFF0000u) - m);
+                    o[d] = (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xFFFF0000u);
+                }
+            } else if (MODE == 3) o[0] ^= __float_as_uint(m) & 1u;
+            if (c < (int)ld) *reinterpret_cast<u32x4 *>(p + c) = o;
+        }
+    }
+}
+template <int MODE> float run(unsigned short *buf, size_t rows, size_t ld, int grid)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(probe<MODE>, dim3(grid), dim3(512), 0, 0, buf, rows, ld, 0);
+    hipEventRecord(e0);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(probe<MODE>, dim3(grid), dim3(512), 0, 0, buf, rows, ld, 0);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); return ms / 10.f;
+}
+int main()
+{
+    const size_t rows = 4096, ld = 132608;
+    unsigned short *buf; hipMalloc(&buf, rows * ld * 2); hipMemset(buf, 0x3c, rows * ld * 2);
+    const double gb = rows * ld * 2 * 2 / 1e9;
+    for (int grid : {4096, 1024, 512, 256}) {
+        const float t0 = run<0>(buf, rows, ld, grid), t1 = run<1>(buf, rows, ld, grid), t2 = run<2>(buf, rows, ld, grid), t3 = run<3>(buf, rows, ld, grid), t4 = run<4>(buf, rows, ld, grid);
+        printf("grid %4d: full %.0f us (%.2f TB/s)  copy %.0f us (%.2f)  load-only %.0f us (%.2f of one pass)  no-exp %.0f us (%.2f)  copy, consecutive chunks %.0f us (%.2f)\n",
+               grid, t0 * 1e3, gb / t0, t1 * 1e3, gb / t1, t2 * 1e3, gb / 2 / t2, t3 * 1e3, gb / t3, t4 * 1e3, gb / t4);
+    }
+    return 0;
+}
