@@ -175,6 +175,8 @@ def lib():
         "ecgb_decode_attn": [vp, ll, vp, vp, vp, ll, vp, ll, vp, ci, ci, vp, ci, ci, ci, f32, ci, vp, sz, vp],
         "ecgb_attn_decode_one": [vp, ll, vp, vp, vp, ll, ll, vp, ll, vp, ci, ci, vp, ci, ci, ci, f32, ci, vp, sz, vp],
         "ecgb_set_gemm_w4_sched": [ci],
+        "ecgb_set_stream_grid_cap": [ci],
+        "ecgb_set_rmsnorm_bwd_grid_cap": [ci],
         "ecgb_set_gemm_w4_min_ktiles": [ci],
         "ecgb_attn_decode_split_dyn": [vp, vp, vp, ll, ll, vp, ll, vp, ci, vp, ci, ci, ci, f32, ci, vp, sz, vp],
         "ecgb_gemm_tn_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, ci, vp],

@@ -55,6 +55,16 @@ unsigned grid_for(size_t items, unsigned per_block)
     return (unsigned)std::max<size_t>(1, std::min<size_t>(b, 256 * 16));
 }
 
+// Workgroups of the element-wise streams over [tokens, inter] (glu_fwd / glu_bwd): round 6 measured the PATTERN alone (three streams read, two written, no
+// arithmetic: scripts/experiments/r06_stream_probe.hip) at 4.7 TB/s with 4 096 workgroups walking the tensor in a grid-stride loop and 5.6 TB/s with 65 536 of
+// them, two trips each -- many short workgroups keep the mix of reads and writes at the memory side even; the kernels themselves are the same.
+size_t g_stream_grid_cap = (size_t)1 << 20;
+unsigned stream_grid(size_t items, unsigned per_block)
+{
+    size_t b = (items + per_block - 1) / per_block;
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(b, g_stream_grid_cap));
+}
+
 // ---- greedy token choice ---------------------------------------------------------------------
 // out[r] = index of the first maximum of x[r, 0:n] (torch.argmax's rule for ties; a NaN counts as the maximum, as it does there).  One workgroup per row, no
 // workspace: torch's own argmax over a 260 000-wide row is a two-pass reduction over a semaphore buffer it allocates per call -- three launches with the
@@ -1309,7 +1319,7 @@ extern "C" int ecgb_rmsnorm_fwd(const void *x_dev, const void *residual_dev, con
                                 float *rstd_dev, size_t rows, int hidden, float eps, int gemma, void *stream)
 {
     if (hidden % 8 || (residual_dev && !sum_out_dev)) { ecgb::set_error("ecgb_rmsnorm_fwd: bad arguments"); return ECGB_ERR_INVALID; }
-    const dim3 grid(grid_for(rows, 4));
+    const dim3 grid(hidden == 2048 && g_rms_fwd_rows ? stream_grid(rows, 4) : grid_for(rows, 4));
     if (hidden == 2048 && g_rms_fwd_rows) {
         if (gemma)
             hipLaunchKernelGGL((rmsnorm_fwd_rows_kernel<true, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x_dev, (const unsigned short *)residual_dev,
@@ -1359,10 +1369,21 @@ extern "C" int ecgb_set_rmsnorm_bwd_rows_per_wg(int n)
     return ECGB_OK;
 }
 
+namespace {
+int g_rms_bwd_grid_cap = 2048;
+size_t rms_bwd_grid(size_t rows) { return std::min<size_t>(std::max<size_t>(1, rows / (size_t)g_rms_bwd_rows_per_wg), (size_t)g_rms_bwd_grid_cap); }
+}
+extern "C" int ecgb_set_rmsnorm_bwd_grid_cap(int n)
+{
+    if (n < 1 || n > 65536) { ecgb::set_error("ecgb_set_rmsnorm_bwd_grid_cap: 1..65536"); return ECGB_ERR_INVALID; }
+    g_rms_bwd_grid_cap = n;
+    return ECGB_OK;
+}
+
 extern "C" size_t ecgb_rmsnorm_bwd_scratch_floats(size_t rows, int hidden)
 {
     if (hidden != 2048 && hidden != 4096) return std::min<size_t>(std::max<size_t>(1, rows), 4096) * (size_t)hidden;   // one-wave workgroups
-    return std::min<size_t>(std::max<size_t>(1, rows / (size_t)g_rms_bwd_rows_per_wg), 2048) * (size_t)hidden;
+    return rms_bwd_grid(rows) * (size_t)hidden;
 }
 
 // dst[c] += sum over b < n_rows of partials[b * ld + c], c < n, in row order (per-workgroup partial sums of a weight / bias gradient)
@@ -1379,7 +1400,8 @@ extern "C" int ecgb_rmsnorm_bwd(const void *x_dev, const void *w_dev, const floa
 {
     if (hidden % 8) { ecgb::set_error("ecgb_rmsnorm_bwd: hidden must be a multiple of 8"); return ECGB_ERR_INVALID; }
     if (hidden == 2048 || hidden == 4096) {   // rows per wave ~16: enough to amortise the end-of-kernel reduction, enough waves to fill the chip
-        const dim3 g2((unsigned)std::min<size_t>(std::max<size_t>(1, rows / (size_t)g_rms_bwd_rows_per_wg), 2048));
+        // frozen norm weights (dw NULL: the LoRA step) leave no per-workgroup partial row behind: one row a wave (round 6: 100 -> 94 us at [32 768, 2 048])
+        const dim3 g2(dw_dev ? (unsigned)rms_bwd_grid(rows) : (unsigned)std::min<size_t>(std::max<size_t>(1, rows / 4), 8192));
 #define ECGB_RMS_BWD_ROWS(G_, NC_) hipLaunchKernelGGL((rmsnorm_bwd_rows_kernel<G_, NC_>), g2, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)x_dev, \
         (const unsigned short *)w_dev, rstd_dev, (const unsigned short *)dy_dev, (const unsigned short *)dres_dev, (unsigned short *)dx_dev, dw_dev, rows, scratch_dev)
         if (hidden == 2048) { if (gemma) ECGB_RMS_BWD_ROWS(true, 4); else ECGB_RMS_BWD_ROWS(false, 4); }
@@ -1410,7 +1432,7 @@ extern "C" int ecgb_rope(void *x_dev, const float *cos_dev, const float *sin_dev
                          size_t row_stride, int inverse, void *stream)
 {
     if (head_dim % 16) { ecgb::set_error("ecgb_rope: head_dim must be a multiple of 16"); return ECGB_ERR_INVALID; }
-    const dim3 grid(grid_for(tokens * n_heads * (head_dim / 16), 256));
+    const dim3 grid(stream_grid(tokens * n_heads * (head_dim / 16), 256));
     if (inverse)
         hipLaunchKernelGGL(rope_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (unsigned short *)x_dev, cos_dev, sin_dev,
                            tokens, n_heads, head_dim, row_stride);
@@ -1437,7 +1459,7 @@ extern "C" int ecgb_rope_append(void *qkv_dev, const float *cos_dev, const float
 extern "C" int ecgb_glu_fwd(const void *gate_up_dev, void *h_dev, size_t tokens, int inter, int gelu_tanh, void *stream)
 {
     if (inter % 8) { ecgb::set_error("ecgb_glu_fwd: intermediate size must be a multiple of 8"); return ECGB_ERR_INVALID; }
-    const dim3 grid(grid_for(tokens * (inter / 8), 256));
+    const dim3 grid(stream_grid(tokens * (inter / 8), 256));
     if (gelu_tanh) hipLaunchKernelGGL(glu_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)gate_up_dev, (unsigned short *)h_dev, tokens, inter);
     else hipLaunchKernelGGL(glu_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)gate_up_dev, (unsigned short *)h_dev, tokens, inter);
     ECGB_CHECK_LAUNCH("glu_fwd");
@@ -1447,10 +1469,17 @@ extern "C" int ecgb_glu_bwd(const void *gate_up_dev, const void *dh_dev, void *d
                             int gelu_tanh, void *stream)
 {
     if (inter % 8) { ecgb::set_error("ecgb_glu_bwd: intermediate size must be a multiple of 8"); return ECGB_ERR_INVALID; }
-    const dim3 grid(grid_for(tokens * (inter / 8), 256));
+    const dim3 grid(stream_grid(tokens * (inter / 8), 256));
     if (gelu_tanh) hipLaunchKernelGGL(glu_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)gate_up_dev, (const unsigned short *)dh_dev, (unsigned short *)dgate_up_dev, tokens, inter);
     else hipLaunchKernelGGL(glu_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short *)gate_up_dev, (const unsigned short *)dh_dev, (unsigned short *)dgate_up_dev, tokens, inter);
     ECGB_CHECK_LAUNCH("glu_bwd");
+}
+
+extern "C" int ecgb_set_stream_grid_cap(int n)
+{
+    if (n < 1) { ecgb::set_error("ecgb_set_stream_grid_cap: n >= 1"); return ECGB_ERR_INVALID; }
+    g_stream_grid_cap = (size_t)n;
+    return ECGB_OK;
 }
 
 extern "C" int ecgb_add_bf16(const void *a_dev, const void *b_dev, void *out_dev, size_t n, void *stream)

@@ -713,6 +713,11 @@ def attn_fwd(qkv, mask, B, S, Hq, Hkv, D, scale):
     return o, lse
 
 
+def set_stream_grid_cap(n=1 << 20):
+    """A/B: the most workgroups glu_fwd / glu_bwd launch (rounds 2-5: 4096)."""
+    _lib.check(_L().ecgb_set_stream_grid_cap(int(n)))
+
+
 def set_ce_in_registers(on: bool = True):
     """ecgb_ce_fwd_bwd: hold each row of logits in registers (one read, one write; default) or run the three-sweep kernel (A/B, tests)."""
     _lib.check(_L().ecgb_set_ce_in_registers(int(bool(on))))

@@ -307,6 +307,11 @@ int ecgb_attn_decode_split_dyn(const void *q_dev, const void *k_cache_dev, const
                                const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, const int *kv_len_dev, int n_q_heads,
                                int n_kv_heads, int head_dim, float scale, int n_splits, void *scratch_dev, size_t scratch_bytes, void *stream);
 
+/* Tuning / A-B: the most workgroups ecgb_glu_fwd / ecgb_glu_bwd launch (default 2^20: one trip of a workgroup; rounds 2-5: 4 096 walking the tensor in a grid-stride loop). */
+int ecgb_set_stream_grid_cap(int n);
+/* Tuning: the most workgroups of ecgb_rmsnorm_bwd at hidden 2048 / 4096 (with ecgb_set_rmsnorm_bwd_rows_per_wg; changes ecgb_rmsnorm_bwd_scratch_floats and the order of the dw sum). */
+int ecgb_set_rmsnorm_bwd_grid_cap(int n);
+
 /* Round 6: a decode step's RoPE + KV-cache append + attention in ONE launch, from the step's raw q|k|v projection [batch, (n_q + 2 n_kv) head_dim] (q and k are NOT
  * rotated in place: the cache row kv_len - 1 and o are what leaves) -- replaces ecgb_rope_append + ecgb_attn_decode_split[_dyn] (cache_utils.py:408-470 DynamicCache.update,
  * modeling_llama.py:526-614 at one query row), the same bits for the same n_splits.  The workgroups of a (sequence, head) meet through counters inside the launch, so all

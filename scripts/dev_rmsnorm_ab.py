@@ -35,8 +35,9 @@ _, rstd, _ = ops.rmsnorm_fwd(x, w, 1e-6)
 for with_dw in (True, False):
     res = {}
     for rnd in range(3):
-        for n in (64, 32, 16, 8):
+        for n in (64, 32, 16, 8, 4):
             L.ecgb_set_rmsnorm_bwd_rows_per_wg(n)
+            L.ecgb_set_rmsnorm_bwd_grid_cap(8192)
             dw = torch.zeros(2048, device="cuda") if with_dw else None
             res.setdefault(n, []).append(timed(lambda: ops.rmsnorm_bwd(x, w, rstd, dy, dw, dres=r)))
     print("rmsnorm_bwd", "with dw" if with_dw else "frozen weights", "  ".join(f"{n} rows/wg: {min(v) * 1e3:.1f} us ({4 * x.numel() * 2 / min(v) / 1e9:.2f} TB/s)" for n, v in res.items()))
