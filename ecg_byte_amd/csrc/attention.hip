@@ -2117,7 +2117,7 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float *par
 //   2  softmax over the splits' statistics, P.V of the split's keys (attn_decode_values_kernel's sums) to `partial`;  counter B: the last to arrive adds the
 //      partial outputs in split order (attn_decode_combine_kernel) and clears both counters for the next launch (a replayed graph never clears them itself).
 // The same arithmetic in the same order: the same bits as the four launches (tests/test_gpu_decode_fused.py).  The wait in step 1 needs every workgroup of the
-// launch resident at once: the host only takes this form for splits * Hq * B <= 256.
+// launch resident at once: the host only takes this form for splits * Hq * B <= two workgroups a CU.
 struct DecodeOneArgs {
     const unsigned short *qkv;    // [B, (Hq + 2 Hkv) D]: the step's projection, not written (q and the new key are rotated into LDS)
     long long ld_qkv;
@@ -3181,7 +3181,7 @@ extern "C" size_t ecgb_attn_decode_one_scratch_floats(int batch, int n_q_heads, 
 
 // A decode step's RoPE + cache append + attention in ONE launch, from the step's raw q|k|v projection (q and k NOT rotated in place): the bits of ecgb_rope_append
 // followed by ecgb_attn_decode_split[_dyn] with the same n_splits.  ECGB_ERR_UNSUPPORTED outside head_dim 64 / 128 / 256, n_splits <= 64, at most 2048 keys a split and
-// n_splits * n_q_heads * batch <= 256 workgroups (they wait for each other inside the launch: all of them must be resident).
+// n_splits * n_q_heads * batch <= two workgroups a CU (they wait for each other inside the launch: all of them must be resident).
 extern "C" int ecgb_attn_decode_one(const void *qkv_dev, long long ld_qkv, const float *cos_dev, const float *sin_dev, void *cache_dev, long long ld, long long capacity,
                                     const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, const int *kv_len_dev, int n_q_heads, int n_kv_heads,
                                     int head_dim, float scale, int n_splits, float *scratch_dev, size_t scratch_floats, void *stream)
@@ -3192,10 +3192,13 @@ extern "C" int ecgb_attn_decode_one(const void *qkv_dev, long long ld_qkv, const
         return ECGB_ERR_INVALID;
     }
     const long long longest = kv_len_dev ? capacity : (long long)kv_len;
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 128;
+    // (two workgroups of 256 threads and 20 KB of LDS a CU are resident whatever else the kernel needs: the launch's workgroups wait for each other)
     if ((head_dim != 64 && head_dim != 128 && head_dim != 256) || n_splits > 64 || (longest + n_splits - 1) / n_splits > kSplitMaxChunk ||
-        (long long)n_splits * n_q_heads * batch > 256 || ld % 8 || ld_qkv % 8 || ((uintptr_t)qkv_dev & 15) || ((uintptr_t)cache_dev & 15) ||
+        (long long)n_splits * n_q_heads * batch > 2ll * n_cu || ld % 8 || ld_qkv % 8 || ((uintptr_t)qkv_dev & 15) || ((uintptr_t)cache_dev & 15) ||
         scratch_floats < ecgb_attn_decode_one_scratch_floats(batch, n_q_heads, head_dim, n_splits)) {
-        ecgb::set_error("ecgb_attn_decode_one: head_dim 64 / 128 / 256, at most 64 splits of at most 2048 keys, at most 256 workgroups, scratch of ecgb_attn_decode_one_scratch_floats()");
+        ecgb::set_error("ecgb_attn_decode_one: head_dim 64 / 128 / 256, at most 64 splits of at most 2048 keys, at most two workgroups a CU, scratch of ecgb_attn_decode_one_scratch_floats()");
         return ECGB_ERR_UNSUPPORTED;
     }
     DecodeOneArgs A;

@@ -152,7 +152,7 @@ class LoraSite(nn.Module):
         elif x.shape[0] <= 8 and p == 0.0:          # a decode step: the few-row GEMM reads A once at HBM speed
             t, xd = ops.gemm_nt(x, self.A.data, alpha=self.scale), None
         else:   # (training with dropout: the masks drawn here are kept as bits for the backward -- ops.set_lora_mask_bits)
-            t, xd, mbits = ops.lora_down(x, self.A.data, self.n_sub, self.n_fields, self.scale, p, seed, keep_masked=keep, want_mask=training)
+            t, xd, mbits = ops.lora_down(x, self.A.data, self.n_sub, self.n_fields, self.scale, p, seed, keep_masked=keep, want_mask=True)
         if glu is not None and ops.glu_fusable(x.shape[0], w.shape[0] // 2):
             y = ops.gemm_nt_glu(x, w, gelu_tanh=glu[0], keep_gu=glu[1], a2=t, b2=self.B.data)
         elif rope is not None:                              # the q|k|v site: RoPE in the projection's epilogue (or behind it: ops.gemm_nt_rope decides)

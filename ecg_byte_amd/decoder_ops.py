@@ -844,7 +844,17 @@ def attn_decode_split(qkv_new, cache, mask, kv_len, Hq, Hkv, D, scale, n_splits,
 
 def decode_one_ok(B, Hq, D, n_splits, cap):
     """Does the one-launch decode attention (ecgb_attn_decode_one) take this step?  Its workgroups wait for each other inside the launch: all resident at once."""
-    return n_splits > 1 and n_splits <= 64 and n_splits * Hq * B <= 256 and D in (64, 128, 256) and -(-cap // n_splits) <= 2048
+    return n_splits > 1 and n_splits <= 64 and n_splits * Hq * B <= 2 * _n_cus() and D in (64, 128, 256) and -(-cap // n_splits) <= 2048
+
+
+_n_cus_cached = {}
+
+
+def _n_cus():
+    dev = torch.cuda.current_device()
+    if dev not in _n_cus_cached:
+        _n_cus_cached[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    return _n_cus_cached[dev]
 
 
 def decode_one_scratch(B, Hq, D, n_splits, device):

@@ -334,7 +334,7 @@ int ecgb_set_rmsnorm_bwd_grid_cap(int n);
 /* Round 6: a decode step's RoPE + KV-cache append + attention in ONE launch, from the step's raw q|k|v projection [batch, (n_q + 2 n_kv) head_dim] (q and k are NOT
  * rotated in place: the cache row kv_len - 1 and o are what leaves) -- replaces ecgb_rope_append + ecgb_attn_decode_split[_dyn] (cache_utils.py:408-470 DynamicCache.update,
  * modeling_llama.py:526-614 at one query row), the same bits for the same n_splits.  The workgroups of a (sequence, head) meet through counters inside the launch, so all
- * n_splits * n_q_heads * batch of them must be resident: ECGB_ERR_UNSUPPORTED above 256 (and outside head_dim 64 / 128 / 256, n_splits <= 64, 2048 keys a split); the
+ * n_splits * n_q_heads * batch of them must be resident: ECGB_ERR_UNSUPPORTED above two workgroups a CU (and outside head_dim 64 / 128 / 256, n_splits <= 64, 2048 keys a split); the
  * caller then runs the separate launches.  scratch: ecgb_attn_decode_one_scratch_floats() floats whose LAST batch * n_q_heads * 2 words (the counters) are zero before
  * the first call; every launch leaves them zero.  kv_len_dev: the number of valid cache rows AFTER the append in device memory (a replayed graph), else kv_len. */
 size_t ecgb_attn_decode_one_scratch_floats(int batch, int n_q_heads, int head_dim, int n_splits);

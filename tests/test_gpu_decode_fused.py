@@ -149,9 +149,9 @@ def test_fused_decode_step_equals_the_separate_kernels(family, lora):
 
 
 @pytest.mark.parametrize("dyn", [False, True], ids=["host-length", "device-length"])
-@pytest.mark.parametrize("B,Hq,Hkv,D,cap,n,ns", [(1, 8, 1, 256, 768, 729, 12), (1, 8, 1, 256, 768, 600, 12), (2, 8, 2, 64, 1024, 1024, 16), (1, 32, 8, 64, 640, 577, 8),
+@pytest.mark.parametrize("B,Hq,Hkv,D,cap,n,ns", [(1, 8, 1, 256, 768, 729, 12), (1, 8, 1, 256, 768, 600, 12), (2, 8, 2, 64, 1024, 1024, 16), (1, 32, 8, 64, 640, 577, 8), (1, 32, 8, 64, 768, 700, 12),
                                                 (2, 4, 1, 128, 2048, 1301, 32), (1, 8, 1, 256, 768, 14, 12)],
-                         ids=["c5-step", "c5-first-step", "two-sequences", "llama1b", "d128-long", "more-splits-than-keys"])
+                         ids=["c5-step", "c5-first-step", "two-sequences", "llama1b", "llama1b-384-workgroups", "d128-long", "more-splits-than-keys"])
 def test_one_launch_attention_equals_rope_append_and_split_attention(ops, B, Hq, Hkv, D, cap, n, ns, dyn):
     """ecgb_attn_decode_one (round 6: RoPE + append + scores + values + combine, the splits' workgroups meeting through counters inside the launch) against
     ecgb_rope_append followed by ecgb_attn_decode_split with the same split count: the attention output AND the cache bit for bit; repeated launches on one scratch
@@ -183,6 +183,7 @@ def test_one_launch_attention_equals_rope_append_and_split_attention(ops, B, Hq,
 
 def test_one_launch_attention_refuses_launches_that_could_not_be_resident(ops):
     assert not ops.decode_one_ok(4, 32, 64, 16, 1024) and not ops.decode_one_ok(1, 8, 256, 1, 256) and not ops.decode_one_ok(1, 8, 96, 8, 1024)
+    assert ops.decode_one_ok(1, 32, 64, 12, 768)                               # Llama-3.2-1B, one sequence, a 768-row cache: 384 workgroups, under two a CU
     from ecg_byte_amd import _lib
     B, Hq, Hkv, D, cap, ns = 4, 32, 8, 64, 1024, 16
     qkv, cache, mask = _bf(B, (Hq + 2 * Hkv) * D), _bf(B, cap, 2 * Hkv * D), torch.ones(B, cap, device="cuda")

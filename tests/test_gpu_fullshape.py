@@ -238,7 +238,7 @@ def _oracle_grads(cfgd, inv_freq, batch, seed, std=0.02):
     loss = R.llama_loss(ref_p, cfgd, ids, mask, labels, pos, inv_freq)
     loss.backward()
     grads = {k: v.grad for k, v in ref_p.items()}
-    return params, float(loss), grads
+    return params, float(loss.detach()), grads
 
 
 def _compare_all_grads(m, cfgd, grads, tol=3e-2):
