@@ -194,12 +194,6 @@ def lib():
         "ecgb_gelu_new_bwd": [vp, vp, vp, sz, vp],
         "ecgb_colsum": [vp, vp, sz, ci, vp, vp],
         "ecgb_lora_down": [vp, vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, vp],
-        "ecgb_lora_down_m": [vp, vp, vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, vp],
-        "ecgb_lora_dx_m": [vp, vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, vp],
-        "ecgb_lora_da_m": [vp, vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, ci, vp, C.c_size_t, vp],
-        "ecgb_lora_dx_glu_m": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, ci, vp],
-        "ecgb_gemm_nn_glu_bwd_lora_bf16_m": [vp, ll, vp, ll, vp, ll, vp, vp, vp, vp, ll, ci, ci, ci, ci, f32, f32, C.c_uint64, vp],
-        "ecgb_gemm_nn_lora_bf16_m": [vp, ll, vp, ll, vp, vp, vp, vp, ll, ci, ci, ci, f32, f32, C.c_uint64, vp],
         "ecgb_lora_dx": [vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, vp],
         "ecgb_lora_da": [vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, ci, vp, C.c_size_t, vp],
         "ecgb_lora_dx_glu": [vp, vp, vp, vp, vp, ci, ci, ci, ci, f32, f32, C.c_uint64, ci, vp],
@@ -222,8 +216,6 @@ def lib():
     L.ecgb_attn_decode_one_scratch_floats.restype = sz
     L.ecgb_rmsnorm_bwd_scratch_floats.argtypes = [sz, ci]
     L.ecgb_rmsnorm_bwd_scratch_floats.restype = sz
-    L.ecgb_lora_mask_words.argtypes = [ci, ci, ci]
-    L.ecgb_lora_mask_words.restype = sz
     L.ecgb_lora_da_scratch_bytes.argtypes = [ci, ci, ci]
     L.ecgb_lora_da_scratch_bytes.restype = sz
     L.ecgb_attn_bwd_scratch_bytes.argtypes = [ci, ci, ci, ci, ci]

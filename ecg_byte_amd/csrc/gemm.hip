@@ -2043,7 +2043,7 @@ bool gemm_w4_span_ok(int lay, long long lda, long long ldb, long long K, long lo
 int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream,
                    int epi, void *h_dev, long long ldh, const void *a2_dev, long long lda2, const void *b2_dev, long long ldb2, int K2,
                    const float *rope_cos, const float *rope_sin, int rope_cols, int lay, const void *gu_dev = nullptr, long long ldgu = 0,
-                   const void *ldt_dev = nullptr, const void *lat_dev = nullptr, float lscale = 0.f, unsigned lthr = 0, unsigned lseed = 0, const void *lmask_dev = nullptr);
+                   const void *ldt_dev = nullptr, const void *lat_dev = nullptr, float lscale = 0.f, unsigned lthr = 0, unsigned lseed = 0);
 }
 namespace { int g_gemm_w4 = 1; }
 extern "C" int ecgb_set_gemm_w4(int on)
@@ -2409,20 +2409,9 @@ extern "C" int ecgb_gemm_nn_glu_bwd_bf16(const void *dy_dev, long long lddy, con
 //   d(gate|up) = glu_bwd(gate|up, bf16(dY . W) + scale / (1 - p) * mask . (dt A)),   dt [M, 64] = dY . B_lora, A^T [inter, 64] (rank 16 in columns 0..15),
 // the forward's dropout mask replayed from (seed, p) as ecgb_lora_down drew it: ecgb_gemm_nn_bf16 + ecgb_lora_dx_glu in one launch, the same bits, d(act(gate) * up)
 // never written.  Four-wave kernel only: ECGB_ERR_UNSUPPORTED where it does not take the shape (the caller runs the two kernels).
-extern "C" int ecgb_gemm_nn_glu_bwd_lora_bf16_m(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *gate_up_dev, long long ldgu,
-                                                const void *dt_dev, const void *at_dev, const void *mask_dev, void *d_gate_up_dev, long long ldd, int M, int inter, int K,
-                                                int gelu_tanh, float scale, float p, uint64_t seed, void *stream);
 extern "C" int ecgb_gemm_nn_glu_bwd_lora_bf16(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *gate_up_dev, long long ldgu,
                                               const void *dt_dev, const void *at_dev, void *d_gate_up_dev, long long ldd, int M, int inter, int K, int gelu_tanh,
                                               float scale, float p, uint64_t seed, void *stream)
-{
-    return ecgb_gemm_nn_glu_bwd_lora_bf16_m(dy_dev, lddy, w_dev, ldw, gate_up_dev, ldgu, dt_dev, at_dev, nullptr, d_gate_up_dev, ldd, M, inter, K, gelu_tanh, scale, p, seed, stream);
-}
-
-// ... with the forward's dropout mask given as bits (mask_dev: [M][inter / 32] words as ecgb_lora_down_m wrote them; NULL: replayed from the hash) -- the same bits either way
-extern "C" int ecgb_gemm_nn_glu_bwd_lora_bf16_m(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *gate_up_dev, long long ldgu,
-                                                const void *dt_dev, const void *at_dev, const void *mask_dev, void *d_gate_up_dev, long long ldd, int M, int inter, int K,
-                                                int gelu_tanh, float scale, float p, uint64_t seed, void *stream)
 {
     if (!dy_dev || !w_dev || !gate_up_dev || !dt_dev || !at_dev || !d_gate_up_dev || M <= 0 || inter <= 0 || K <= 0 || !(p >= 0.f && p < 1.f)) {
         ecgb::set_error("ecgb_gemm_nn_glu_bwd_lora_bf16: bad argument");
@@ -2437,21 +2426,13 @@ extern "C" int ecgb_gemm_nn_glu_bwd_lora_bf16_m(const void *dy_dev, long long ld
     const unsigned thr = (unsigned)(p * 65536.0f);                                   // as ecgb_lora_down / ecgb_lora_dx fill them (lora.hip)
     const float lscale = scale / (1.0f - (float)thr / 65536.0f);
     return ecgb::gemm_w4_launch(dy_dev, lddy, w_dev, ldw, d_gate_up_dev, ldd, M, inter, K, 1.0f, stream, gelu_tanh ? 7 : 6, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1,
-                                gate_up_dev, ldgu, dt_dev, at_dev, lscale, thr, (unsigned)(seed ^ (seed >> 32)), ((uintptr_t)mask_dev & 15) ? nullptr : mask_dev);
+                                gate_up_dev, ldgu, dt_dev, at_dev, lscale, thr, (unsigned)(seed ^ (seed >> 32)));
 }
 
 // The input gradient of a frozen projection with ONE LoRA module on it (o): dx = bf16(dY . W) + scale / (1 - p) * mask . (dt A) in one launch -- ecgb_gemm_nn_bf16 followed
 // by ecgb_lora_dx (one block), the same bits, no read-modify-write pass over dx.  Four-wave kernel only: ECGB_ERR_UNSUPPORTED where it does not take the shape.
-extern "C" int ecgb_gemm_nn_lora_bf16_m(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *dt_dev, const void *at_dev, const void *mask_dev,
-                                        void *dx_dev, long long lddx, int M, int in, int K, float scale, float p, uint64_t seed, void *stream);
 extern "C" int ecgb_gemm_nn_lora_bf16(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *dt_dev, const void *at_dev,
                                       void *dx_dev, long long lddx, int M, int in, int K, float scale, float p, uint64_t seed, void *stream)
-{
-    return ecgb_gemm_nn_lora_bf16_m(dy_dev, lddy, w_dev, ldw, dt_dev, at_dev, nullptr, dx_dev, lddx, M, in, K, scale, p, seed, stream);
-}
-
-extern "C" int ecgb_gemm_nn_lora_bf16_m(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *dt_dev, const void *at_dev, const void *mask_dev,
-                                        void *dx_dev, long long lddx, int M, int in, int K, float scale, float p, uint64_t seed, void *stream)
 {
     if (!dy_dev || !w_dev || !dt_dev || !at_dev || !dx_dev || M <= 0 || in <= 0 || K <= 0 || !(p >= 0.f && p < 1.f)) {
         ecgb::set_error("ecgb_gemm_nn_lora_bf16: bad argument");
@@ -2466,7 +2447,7 @@ extern "C" int ecgb_gemm_nn_lora_bf16_m(const void *dy_dev, long long lddy, cons
     const unsigned thr = (unsigned)(p * 65536.0f);
     const float lscale = scale / (1.0f - (float)thr / 65536.0f);
     return ecgb::gemm_w4_launch(dy_dev, lddy, w_dev, ldw, dx_dev, lddx, M, in, K, 1.0f, stream, 8, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, nullptr, 0, 1,
-                                nullptr, 0, dt_dev, at_dev, lscale, thr, (unsigned)(seed ^ (seed >> 32)), ((uintptr_t)mask_dev & 15) ? nullptr : mask_dev);
+                                nullptr, 0, dt_dev, at_dev, lscale, thr, (unsigned)(seed ^ (seed >> 32)));
 }
 
 #ifdef ECGB_PROFILE

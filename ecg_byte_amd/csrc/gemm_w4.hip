@@ -53,7 +53,6 @@ struct W4Args {
     const unsigned short *LDT, *LAT;   // EPI 6 / 7: the down-projection site's LoRA adapter joins the product before the GLU backward -- dt [M, 64] = dY . B_lora and A_lora^T
     float lscale;                      // [glu_I, 64] (rank 16 in columns 0..15), alpha / r / (1 - p), and the dropout mask of the forward replayed from (lseed, lthr):
     unsigned lthr, lseed;              // ecgb_lora_dx_glu's arithmetic on the bf16-rounded product
-    const unsigned *LMASK;             // round 6: the forward's mask as bits ([M][glu_I / 32] words, lora.hip) instead of the hash -- NULL: hash as before
 };
 
 __device__ __forceinline__ unsigned pack2(float a, float b)
@@ -471,15 +470,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             bf16x8 atf[LORA ? 8 : 1], dtf[LORA ? 3 : 1];                       // (dt: a ring with gate / up below)
             const unsigned short *dtp = nullptr;
             unsigned hrow = 0, hstep = 0;
-            u4 mq[LORA ? 3 : 1];                                               // the mask words of the lane's row: the wave's 128 columns are four words (a ring like dt)
-            const unsigned *mkp = nullptr;
-            long long mk_ld = 0;
-            if constexpr (LORA) {
-                if (G.LMASK && G.lthr) {
-                    mk_ld = (long long)(G.glu_I >> 5);
-                    mkp = G.LMASK + ((long long)tm * 256 + wr * 128 + lm) * mk_ld + (tn * 8 + wc * 4);
-                }
-            }
             if constexpr (LORA) {
                 const bf16x8 zero = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
                 const unsigned short *atp = G.LAT + ((long long)tn * 256 + wc * 128 + lm) * 64 + 8 * (lq & 1);
@@ -505,10 +495,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         uq[slot][ps] = *reinterpret_cast<const u4 *>(gsrc + (long long)(row16 * 16 + ps * 4) * G.ldgu + gI);
                     }
                 }
-                if constexpr (LORA) {
-                    dtf[slot] = *reinterpret_cast<const bf16x8 *>(dtp + row16 * 16 * 64);
-                    if (mkp) mq[slot] = *reinterpret_cast<const u4 *>(mkp + (long long)row16 * 16 * mk_ld);
-                }
+                if constexpr (LORA) dtf[slot] = *reinterpret_cast<const bf16x8 *>(dtp + row16 * 16 * 64);
             };
 #pragma unroll
             for (int k = 0; k < AHEAD; ++k) fetch(k, k);
@@ -529,11 +516,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0\n\ts_nop 15\n\ts_nop 3" : "=v"(lo) : "v"(atf[j]), "v"(dti));
                         float o[4] = {lo_f(v[0]), hi_f(v[0]), lo_f(v[1]), hi_f(v[1])};
                         const unsigned hb = hrow + (unsigned)i * hstep;
-                        if (mkp) {                                            // (uniform) the forward's bits: this lane's four columns of block j are a nibble of word j >> 1
-                            const unsigned nib = mq[i % (AHEAD + 1)][j >> 1] >> (16 * (j & 1) + 4 * lq);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = o[e] + (((nib >> e) & 1u) ? lo[e] * G.lscale : 0.f);
-                        } else
 #pragma unroll
                         for (int e = 0; e < 4; e += 2) {                      // keep_bits<1> of lora.hip: columns 2k, 2k + 1 take the low and the high field of hash32(seed, k)
                             unsigned u = hb + (unsigned)(j * 8 + (e >> 1)) * 0x9E3779B1u;
@@ -716,10 +698,9 @@ bool gemm_w4_applies(const void *a_dev, long long lda, const void *b_dev, long l
 int gemm_w4_launch(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev, long long ldc, int M, int N, int K, float alpha, void *stream,
                    int epi, void *h_dev, long long ldh, const void *a2_dev, long long lda2, const void *b2_dev, long long ldb2, int K2,
                    const float *rope_cos, const float *rope_sin, int rope_cols, int lay, const void *gu_dev, long long ldgu,
-                   const void *ldt_dev = nullptr, const void *lat_dev = nullptr, float lscale = 0.f, unsigned lthr = 0, unsigned lseed = 0, const void *lmask_dev = nullptr)
+                   const void *ldt_dev = nullptr, const void *lat_dev = nullptr, float lscale = 0.f, unsigned lthr = 0, unsigned lseed = 0)
 {
     W4Args G;
-    G.LMASK = (const unsigned *)lmask_dev;
     G.LDT = (const unsigned short *)ldt_dev; G.LAT = (const unsigned short *)lat_dev; G.lscale = lscale; G.lthr = lthr; G.lseed = lseed;
     G.GU = (const unsigned short *)gu_dev; G.ldgu = ldgu;
     G.rope_cos = rope_cos; G.rope_sin = rope_sin; G.rope_cols = rope_cols;

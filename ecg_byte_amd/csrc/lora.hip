@@ -71,12 +71,6 @@ struct LoraArgs {
     float scale;                  // alpha / r / (1 - p)
     unsigned thr;                 // keep iff field >= thr, thr = p * 65536 (0: no dropout)
     unsigned seed;
-    // Round 6: the masks ONCE.  lora_down writes what it drew as one bit per element and module -- mask[f][row][in / 32] words, bit c & 31 of word c >> 5 = field f
-    // keeps column c -- and the backward kernels (lora_da, lora_dx, the input-gradient GEMM's adapter fold) read bits instead of hashing every element again: the
-    // hash was evaluated three times per element (forward, dA, dX) and was what bound lora_da (64 hashes of ~12 vector instructions per lane and 64-row tile).
-    unsigned char *mask_out;      // lora_down: where the bits go (NULL: not kept)
-    const unsigned *mask;         // backward kernels: the bits lora_down wrote (NULL: hash again)
-    long long mask_plane;         // words per module: T * (in / 32)
 };
 
 // the masks of one element: bit f = field f keeps it.  A site with ONE module (o, down: NF 1) spends a hash on an element PAIR -- elements 2k and 2k + 1 take the low
@@ -168,12 +162,6 @@ __global__ __launch_bounds__(256) void lora_down_kernel(LoraArgs L)
                     for (int e = 0; e < 8; ++e) xm[f][e] = ((keep[e] >> f) & 1u) ? xv[g][u][e] : (short)0;
                     if (L.xd && row[g] < L.T)
                         *reinterpret_cast<bf16x8 *>(L.xd + f * plane + (size_t)row[g] * L.in + k0 + 32 * u + 8 * lq) = xm[f];
-                    if (L.mask_out && row[g] < L.T) {                          // the lane's eight columns of module f: one byte
-                        unsigned bits = 0;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) bits |= ((keep[e] >> f) & 1u) << e;
-                        L.mask_out[((size_t)f * L.mask_plane * 4) + (size_t)row[g] * (L.in / 8) + ((k0 + 32 * u) >> 3) + lq] = (unsigned char)bits;
-                    }
                 }
 #pragma unroll
                 for (int s = 0; s < NSUB; ++s)
@@ -275,16 +263,6 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(LoraArgs L)
         const unsigned idx0 = (unsigned)rowc * (unsigned)L.in + (unsigned)(c0 + 16 * lq);
 #pragma unroll
         for (int e = 0; e < 16; ++e) { keep[e] = 0; sum[e] = 0.f; }
-        if (L.mask && L.thr) {                                           // (uniform) the forward's bits: the lane's sixteen columns are half a word per module
-            unsigned hw[NF];
-#pragma unroll
-            for (int f = 0; f < NF; ++f)
-                hw[f] = L.mask[(size_t)f * L.mask_plane + (size_t)rowc * (L.in >> 5) + ((c0 + 16 * lq) >> 5)] >> (16 * (lq & 1));
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-#pragma unroll
-                for (int f = 0; f < NF; ++f) keep[e] |= ((hw[f] >> e) & 1u) << f;
-        } else
         keep_run<NF, 16>(L, idx0, keep);
 #pragma unroll
         for (int s = 0; s < NSUB; ++s)
@@ -423,27 +401,7 @@ __global__ __launch_bounds__(256, 2) void lora_da_kernel(LoraArgs L)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[sb][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // The forward's mask bits of a K-tile (L.mask): lane (lm, lq) fetches the two words -- this wave's 64 columns -- of ONE of the sixteen rows its lq group works on
-    // (row 8 lq + (lm & 7) of k-slice lm >> 3), a tile ahead; the lanes of the group then take each other's words by lane permutes.  (Every lane fetching its
-    // sixteen rows itself would hold 32 registers a module in flight.)
-    using u2 = __attribute__((ext_vector_type(2))) unsigned;
-    const bool masked = L.mask != nullptr && L.thr != 0;
-    const long long mword = (long long)min((col0 >> 5) + 2 * wave, (L.in >> 5) - 2);
-    auto mask_fetch = [&](int kt_, u2 (&m)[NF]) {
-        const int r = min(row_lo + kt_ * 64 + 32 * (lm >> 3) + 8 * lq + (lm & 7), L.T - 1);
-#pragma unroll
-        for (int f = 0; f < NF; ++f) m[f] = *reinterpret_cast<const u2 *>(L.mask + (size_t)f * L.mask_plane + (size_t)r * (L.in >> 5) + mword);
-    };
-    u2 mnext[NF];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) mnext[f] = (u2){0u, 0u};
-    if (masked) mask_fetch(0, mnext);
-
     for (int kt = 0; kt < KT; ++kt) {
-        u2 mcur[NF];
-#pragma unroll
-        for (int f = 0; f < NF; ++f) mcur[f] = mnext[f];
-        if (masked && kt + 1 < KT) mask_fetch(kt + 1, mnext);            // (before this trip's LDS-DMA: waiting for them later does not wait for the DMA)
         // inline asm reads: hipcc would drain the tile in flight (vmcnt 0) in front of an LDS read it can see next to LDS-DMA.  It neither counts asm
         // reads in lgkmcnt nor knows their results are pending (it may copy a destination register as soon as the statement is over): a group of
         // reads and its wait are ONE asm statement, the results exist when it ends
@@ -501,18 +459,7 @@ __global__ __launch_bounds__(256, 2) void lora_da_kernel(LoraArgs L)
                     }
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            unsigned rw[NF][8][2];                                       // the mask words of the lane's eight rows of this k-slice, shifted so that bit 0 / 16 is this lane's column
-            if (masked) {
-#pragma unroll
-                for (int f = 0; f < NF; ++f)
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const int src = (16 * lq + 8 * ks + r) * 4;     // the lane of the lq group that fetched row r of k-slice ks
-                        rw[f][r][0] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)mcur[f][0]) >> lm;
-                        rw[f][r][1] = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)mcur[f][1]) >> lm;
-                    }
-            }
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned col = (unsigned)(col0 + wave * 64 + 16 * j + lm);
@@ -521,17 +468,6 @@ __global__ __launch_bounds__(256, 2) void lora_da_kernel(LoraArgs L)
                 if (L.thr == 0) {
 #pragma unroll
                     for (int f = 0; f < NF; ++f) xm[f] = xv[ks][j];
-                } else if (masked) {
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) {
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) {
-                            // rows 2 w, 2 w + 1 of the lane's eight; this lane's column is bit 16 (j & 1) + lm of word j >> 1 (shifted down by lm above)
-                            const unsigned b0 = (rw[f][2 * w][j >> 1] >> (16 * (j & 1))) & 1u, b1 = (rw[f][2 * w + 1][j >> 1] >> (16 * (j & 1))) & 1u;
-                            const unsigned m = (b0 ? 0x0000FFFFu : 0u) | (b1 ? 0xFFFF0000u : 0u);
-                            xm[f][w] = (int)((unsigned)xv[ks][j][w] & m);
-                        }
-                    }
                 } else {
 #pragma unroll
                     for (int f = 0; f < NF; ++f) xm[f] = (i4){0, 0, 0, 0};
@@ -551,7 +487,6 @@ __global__ __launch_bounds__(256, 2) void lora_da_kernel(LoraArgs L)
                     acc[sb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xm[sb * NF / NSUB]), __builtin_bit_cast(bf16x8, dv[ks][sb]),
                                                                          acc[sb][j], 0, 0, 0);
             }
-        }
         if (kt + 1 < KT) {                                              // the next tile has landed (the one after it may still fly)
             if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -607,28 +542,13 @@ void fill(LoraArgs &L, int T, int in, float scale, float p, uint64_t seed)
 
 }  // namespace
 
-extern "C" size_t ecgb_lora_mask_words(int T, int in, int n_fields)
-{
-    if (T <= 0 || in <= 0 || in % 64 || n_fields < 1 || n_fields > 4) return 0;
-    return (size_t)n_fields * (size_t)T * (size_t)(in / 32);
-}
-
-extern "C" int ecgb_lora_down_m(const void *x_dev, const void *a_dev, void *t_dev, void *xd_dev, void *mask_out_dev, int T, int in, int n_sub, int n_fields,
-                                float scale, float p, uint64_t seed, void *stream);
 extern "C" int ecgb_lora_down(const void *x_dev, const void *a_dev, void *t_dev, void *xd_dev, int T, int in, int n_sub, int n_fields,
                               float scale, float p, uint64_t seed, void *stream)
-{
-    return ecgb_lora_down_m(x_dev, a_dev, t_dev, xd_dev, nullptr, T, in, n_sub, n_fields, scale, p, seed, stream);
-}
-
-extern "C" int ecgb_lora_down_m(const void *x_dev, const void *a_dev, void *t_dev, void *xd_dev, void *mask_out_dev, int T, int in, int n_sub, int n_fields,
-                                float scale, float p, uint64_t seed, void *stream)
 {
     if (!x_dev || !a_dev || !t_dev) { ecgb::set_error("ecgb_lora_down: NULL argument"); return ECGB_ERR_INVALID; }
     if (int rc = check_common("ecgb_lora_down", T, in, n_sub, n_fields, p)) return rc;
     LoraArgs L{};
     L.x = (const unsigned short *)x_dev; L.A = (const unsigned short *)a_dev; L.t = (unsigned short *)t_dev; L.xd = (unsigned short *)xd_dev;
-    L.mask_out = (unsigned char *)mask_out_dev; L.mask_plane = (long long)T * (in / 32);
     fill(L, T, in, scale, p, seed);
     if (in % 256 == 0 && T >= 8192 && n_sub > 1) {                   // fused sites: two row groups per wave share the A fragments
         const dim3 grid((unsigned)((T + 31) / 32));
@@ -645,22 +565,13 @@ extern "C" int ecgb_lora_down_m(const void *x_dev, const void *a_dev, void *t_de
     return ECGB_OK;
 }
 
-extern "C" int ecgb_lora_dx_m(const void *dt_dev, const void *at_dev, void *dx_dev, const void *mask_dev, int T, int in, int n_sub, int n_fields,
-                              float scale, float p, uint64_t seed, void *stream);
 extern "C" int ecgb_lora_dx(const void *dt_dev, const void *at_dev, void *dx_dev, int T, int in, int n_sub, int n_fields,
                             float scale, float p, uint64_t seed, void *stream)
-{
-    return ecgb_lora_dx_m(dt_dev, at_dev, dx_dev, nullptr, T, in, n_sub, n_fields, scale, p, seed, stream);
-}
-
-extern "C" int ecgb_lora_dx_m(const void *dt_dev, const void *at_dev, void *dx_dev, const void *mask_dev, int T, int in, int n_sub, int n_fields,
-                              float scale, float p, uint64_t seed, void *stream)
 {
     if (!dt_dev || !at_dev || !dx_dev) { ecgb::set_error("ecgb_lora_dx: NULL argument"); return ECGB_ERR_INVALID; }
     if (int rc = check_common("ecgb_lora_dx", T, in, n_sub, n_fields, p)) return rc;
     LoraArgs L{};
     L.dt = (const unsigned short *)dt_dev; L.A = (const unsigned short *)at_dev; L.dx = (unsigned short *)dx_dev;
-    L.mask = (const unsigned *)mask_dev; L.mask_plane = (long long)T * (in / 32);
     fill(L, T, in, scale, p, seed);
     const unsigned row_blocks = (unsigned)((T + 63) / 64);
     unsigned col_split = 1;                                          // few rows: split the columns over blockIdx.y to fill the chip
@@ -674,16 +585,8 @@ extern "C" int ecgb_lora_dx_m(const void *dt_dev, const void *at_dev, void *dx_d
 
 // ecgb_lora_dx followed by the GLU backward in one pass (the down-projection site: dx = d(act(gate) * up) [T, inter]):
 //   d(gate|up) = glu_bwd(gate|up, dx + scale/(1-p) * sum_b mask_b . (dt_b A_b));  dx itself is only read.
-extern "C" int ecgb_lora_dx_glu_m(const void *dt_dev, const void *at_dev, const void *dx_dev, const void *gate_up_dev, void *d_gate_up_dev, const void *mask_dev, int T,
-                                  int inter, int n_sub, int n_fields, float scale, float p, uint64_t seed, int gelu_tanh, void *stream);
 extern "C" int ecgb_lora_dx_glu(const void *dt_dev, const void *at_dev, const void *dx_dev, const void *gate_up_dev, void *d_gate_up_dev, int T,
                                 int inter, int n_sub, int n_fields, float scale, float p, uint64_t seed, int gelu_tanh, void *stream)
-{
-    return ecgb_lora_dx_glu_m(dt_dev, at_dev, dx_dev, gate_up_dev, d_gate_up_dev, nullptr, T, inter, n_sub, n_fields, scale, p, seed, gelu_tanh, stream);
-}
-
-extern "C" int ecgb_lora_dx_glu_m(const void *dt_dev, const void *at_dev, const void *dx_dev, const void *gate_up_dev, void *d_gate_up_dev, const void *mask_dev, int T,
-                                  int inter, int n_sub, int n_fields, float scale, float p, uint64_t seed, int gelu_tanh, void *stream)
 {
     if (!dt_dev || !at_dev || !dx_dev || !gate_up_dev || !d_gate_up_dev) { ecgb::set_error("ecgb_lora_dx_glu: NULL argument"); return ECGB_ERR_INVALID; }
     if (int rc = check_common("ecgb_lora_dx_glu", T, inter, n_sub, n_fields, p)) return rc;
@@ -691,7 +594,6 @@ extern "C" int ecgb_lora_dx_glu_m(const void *dt_dev, const void *at_dev, const 
     LoraArgs L{};
     L.dt = (const unsigned short *)dt_dev; L.A = (const unsigned short *)at_dev; L.dx = (unsigned short *)const_cast<void *>(dx_dev);
     L.gu = (const unsigned short *)gate_up_dev; L.dgu = (unsigned short *)d_gate_up_dev;
-    L.mask = (const unsigned *)mask_dev; L.mask_plane = (long long)T * (inter / 32);
     fill(L, T, inter, scale, p, seed);
     const unsigned row_blocks = (unsigned)((T + 63) / 64);
     unsigned col_split = 1;
@@ -727,23 +629,14 @@ extern "C" size_t ecgb_lora_da_scratch_bytes(int T, int in, int n_sub)
 }
 
 // dA [16 n_sub, in] (bf16, the first rows of the stacked A's gradient) (+)= scale / (1 - p) * dt[:, :16 n_sub]^T . (mask . x)
-extern "C" int ecgb_lora_da_m(const void *x_dev, const void *dt_dev, void *da_dev, const void *mask_dev, int T, int in, int n_sub, int n_fields, float scale, float p,
-                              uint64_t seed, int accumulate, void *scratch_dev, size_t scratch_bytes, void *stream);
 extern "C" int ecgb_lora_da(const void *x_dev, const void *dt_dev, void *da_dev, int T, int in, int n_sub, int n_fields, float scale, float p,
                             uint64_t seed, int accumulate, void *scratch_dev, size_t scratch_bytes, void *stream)
-{
-    return ecgb_lora_da_m(x_dev, dt_dev, da_dev, nullptr, T, in, n_sub, n_fields, scale, p, seed, accumulate, scratch_dev, scratch_bytes, stream);
-}
-
-extern "C" int ecgb_lora_da_m(const void *x_dev, const void *dt_dev, void *da_dev, const void *mask_dev, int T, int in, int n_sub, int n_fields, float scale, float p,
-                              uint64_t seed, int accumulate, void *scratch_dev, size_t scratch_bytes, void *stream)
 {
     if (!x_dev || !dt_dev || !da_dev || !scratch_dev) { ecgb::set_error("ecgb_lora_da: NULL argument"); return ECGB_ERR_INVALID; }
     if (int rc = check_common("ecgb_lora_da", T, in, n_sub, n_fields, p)) return rc;
     if (scratch_bytes < ecgb_lora_da_scratch_bytes(T, in, n_sub)) { ecgb::set_error("ecgb_lora_da: scratch smaller than ecgb_lora_da_scratch_bytes()"); return ECGB_ERR_INVALID; }
     LoraArgs L{};
     L.x = (const unsigned short *)x_dev; L.dt = (const unsigned short *)dt_dev; L.slab = (float *)scratch_dev;
-    L.mask = (const unsigned *)mask_dev; L.mask_plane = (long long)T * (in / 32);
     fill(L, T, in, scale, p, seed);
     L.chunk_rows = lora_da_chunk_rows(T, in);
     const int n_chunks = (T + L.chunk_rows - 1) / L.chunk_rows;

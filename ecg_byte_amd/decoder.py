@@ -140,7 +140,7 @@ class LoraSite(nn.Module):
         """y = x W^T + the adapter branch, [T, out].  Returns (y, what backward needs).
         glu = (gelu_tanh, keep_gu): the site is the fused gate|up projection and the GLU runs in the GEMM's epilogue; y is then the pair
         (gate|up or None, act(gate) * up)."""
-        p, seed, mbits = 0.0, 0, None
+        p, seed = 0.0, 0
         if training and self.p > 0:
             # One mask stream per (site, rank, call): data-parallel ranks draw DIFFERENT masks (torch's per-process generators give the
             # reference's DDP ranks different dropout too); `calls` restarts at 0 with a new process -- the reference never resumes
@@ -151,8 +151,8 @@ class LoraSite(nn.Module):
             t, xd = t_pre, None
         elif x.shape[0] <= 8 and p == 0.0:          # a decode step: the few-row GEMM reads A once at HBM speed
             t, xd = ops.gemm_nt(x, self.A.data, alpha=self.scale), None
-        else:   # (training with dropout: the masks drawn here are kept as bits for the backward -- ops.set_lora_mask_bits)
-            t, xd, mbits = ops.lora_down(x, self.A.data, self.n_sub, self.n_fields, self.scale, p, seed, keep_masked=keep, want_mask=True)
+        else:
+            t, xd = ops.lora_down(x, self.A.data, self.n_sub, self.n_fields, self.scale, p, seed, keep_masked=keep)
         if glu is not None and ops.glu_fusable(x.shape[0], w.shape[0] // 2):
             y = ops.gemm_nt_glu(x, w, gelu_tanh=glu[0], keep_gu=glu[1], a2=t, b2=self.B.data)
         elif rope is not None:                              # the q|k|v site: RoPE in the projection's epilogue (or behind it: ops.gemm_nt_rope decides)
@@ -161,7 +161,7 @@ class LoraSite(nn.Module):
             y = ops.gemm_nt(x, w, a2=t, b2=self.B.data)
             if glu is not None:
                 y = (y if glu[1] else None, ops.glu_fwd(y, gelu_tanh=glu[0]))
-        return y, (x, xd, t, p, seed, mbits)
+        return y, (x, xd, t, p, seed)
 
     def backward(self, dy, saved, model, dx, glu=None, weight=None):
         """Sets A.grad / B.grad (slices of the model's flat gradient buffer) and adds the adapters' contribution to `dx` in place
@@ -170,7 +170,7 @@ class LoraSite(nn.Module):
         projection's dy . W when asked, with `weight` the frozen weight itself: on a single-module site (o, down) where the four-wave GEMM takes
         the shape, product and adapter share (and the GLU backward) are ONE launch (ops.gemm_nn_lora / ops.gemm_nn_glu_bwd_lora) and the
         callable is never called."""
-        x, xd, t, p, seed, mbits = saved
+        x, xd, t, p, seed = saved
         Bt = model._shadow(("lora_Bt", id(self)), self.B)                 # [64, out]
         At = model._shadow(("lora_At", id(self)), self.A)                 # [in, 64]
         dt = ops.gemm_nt(dy, Bt)                                         # [T, 64] = dy . B
@@ -180,21 +180,21 @@ class LoraSite(nn.Module):
         if p == 0.0:
             model._wgrad(self.A, dt, x, alpha=keep_scale)                # no dropout: one product for all blocks
         else:                                                            # dA_b = dt_b^T . (mask_b . x), the masks replayed from the seed
-            model._lora_agrad(self.A, x, dt, self.n_sub, self.n_fields, self.scale, p, seed, mbits)
+            model._lora_agrad(self.A, x, dt, self.n_sub, self.n_fields, self.scale, p, seed)
         if dx is None:                                                   # the caller needs no input gradient (the bottom layer over frozen embeddings)
             return None
         if callable(dx):
             if self.n_sub == 1 and weight is not None:
                 if glu is not None:
-                    fused = ops.gemm_nn_glu_bwd_lora(dy, weight, glu[0], dt, At, self.scale, p, seed, gelu_tanh=glu[1], mask=mbits)
+                    fused = ops.gemm_nn_glu_bwd_lora(dy, weight, glu[0], dt, At, self.scale, p, seed, gelu_tanh=glu[1])
                 else:
-                    fused = ops.gemm_nn_lora(dy, weight, dt, At, self.scale, p, seed, mask=mbits)
+                    fused = ops.gemm_nn_lora(dy, weight, dt, At, self.scale, p, seed)
                 if fused is not None:
                     return fused
             dx = dx()
         if glu is not None and self.n_sub == 1:
-            return ops.lora_dx_glu(dx, dt, At, glu[0], self.scale, p, seed, gelu_tanh=glu[1], mask=mbits)
-        ops.lora_dx_(dx, dt, At, self.n_sub, self.n_fields, self.scale, p, seed, mask=mbits)
+            return ops.lora_dx_glu(dx, dt, At, glu[0], self.scale, p, seed, gelu_tanh=glu[1])
+        ops.lora_dx_(dx, dt, At, self.n_sub, self.n_fields, self.scale, p, seed)
         return dx if glu is None else ops.glu_bwd(glu[0], dx, gelu_tanh=glu[1])
 
 
@@ -686,11 +686,11 @@ class HipCausalLM(nn.Module):
             ops.gemm_tn(dy, xin, alpha=alpha, out=dst, accumulate=acc)
         param.grad = view
 
-    def _lora_agrad(self, param, x, dt, n_sub, n_fields, scale, p, seed, mask=None):
+    def _lora_agrad(self, param, x, dt, n_sub, n_fields, scale, p, seed):
         """Rows [0, 16 n_sub) of a stacked LoRA A's gradient (+)= scale / (1 - p) * dt^T . (mask . x) (ecgb_lora_da); the rows past them keep
-        the zeros the flat buffer was created with.  mask: the forward's masks as bits (round 6) or None (the hash again)."""
+        the zeros the flat buffer was created with."""
         view, acc = self._grad_slot(param)
-        ops.lora_da(x, dt, view[: 16 * n_sub], n_sub, n_fields, scale, p, seed, accumulate=acc, mask=mask)
+        ops.lora_da(x, dt, view[: 16 * n_sub], n_sub, n_fields, scale, p, seed, accumulate=acc)
         param.grad = view
 
     def _vgrad(self, param, g):

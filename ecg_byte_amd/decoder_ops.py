@@ -459,39 +459,25 @@ def dropout(x, p, seed, out=None):
     return out
 
 
-_lora_mask_bits = False
-
-
-def set_lora_mask_bits(on=True):
-    """Opt-in (round 6 experiment, measured and NOT the default): the forward's LoRA dropout masks kept as one bit per element and module and READ by the backward
-    kernels, instead of evaluated again from the counter hash by every kernel that needs them (rounds 3-5, the default).  The same results bit for bit; on the C3
-    LoRA step 158.5 ms against 155.2: lora_da gains (104.8 -> 82.9 us) but lora_down pays more for writing the bits than the readers save, and the input-gradient
-    GEMM's fold waits for its mask words (EXPERIMENTS.md section R6)."""
-    global _lora_mask_bits
-    _lora_mask_bits = bool(on)
-
-
-def lora_down(x, A, n_sub, n_fields, scale, p=0.0, seed=0, keep_masked=False, want_mask=False):
+def lora_down(x, A, n_sub, n_fields, scale, p=0.0, seed=0, keep_masked=False):
     """t = scale / (1 - p) * (mask_f . x) A_f^T for the stacked adapters A [64, in] (n_sub 16-row sub-blocks) of n_fields modules, each
-    with its own dropout mask (ecgb_lora_down).  Returns (t [T, 64], masked copies of x [n_fields, T, in] or None); with want_mask (and p > 0, the switch on) a third
-    value: the masks as bits, int32 [n_fields, T, in / 32] (ecgb_lora_down_m), which lora_da / lora_dx_ / lora_dx_glu / gemm_nn_lora / gemm_nn_glu_bwd_lora take as `mask`."""
+    with its own dropout mask (ecgb_lora_down).  Returns (t [T, 64], masked copies of x [n_fields, T, in] or None)."""
     T, K = x.shape
     t = torch.empty((T, 64), dtype=torch.bfloat16, device=x.device)
     xd = torch.empty((n_fields, T, K), dtype=torch.bfloat16, device=x.device) if keep_masked and p > 0 else None
-    mask = torch.empty((n_fields, T, K // 32), dtype=torch.int32, device=x.device) if want_mask and p > 0 and _lora_mask_bits else None
-    _lib.check(_L().ecgb_lora_down_m(_p(_bf(x)), _p(_bf(A)), _p(t), _p(xd), _p(mask), T, K, n_sub, n_fields, float(scale), float(p), int(seed), _st()))
-    return (t, xd, mask) if want_mask else (t, xd)
+    _lib.check(_L().ecgb_lora_down(_p(_bf(x)), _p(_bf(A)), _p(t), _p(xd), T, K, n_sub, n_fields, float(scale), float(p), int(seed), _st()))
+    return t, xd
 
 
-def lora_dx_(dx, dt, At, n_sub, n_fields, scale, p=0.0, seed=0, mask=None):
+def lora_dx_(dx, dt, At, n_sub, n_fields, scale, p=0.0, seed=0):
     """dx += scale / (1 - p) * sum_f mask_f . (dt_f A_f), in place; dt [T, 64], At = A^T [in, 64] (ecgb_lora_dx)."""
     T, K = dx.shape
-    assert dt.shape == (T, 64) and At.shape == (K, 64) and (mask is None or mask.shape == (n_fields, T, K // 32))
-    _lib.check(_L().ecgb_lora_dx_m(_p(_bf(dt)), _p(_bf(At)), _p(_bf(dx)), _p(mask), T, K, n_sub, n_fields, float(scale), float(p), int(seed), _st()))
+    assert dt.shape == (T, 64) and At.shape == (K, 64)
+    _lib.check(_L().ecgb_lora_dx(_p(_bf(dt)), _p(_bf(At)), _p(_bf(dx)), T, K, n_sub, n_fields, float(scale), float(p), int(seed), _st()))
     return dx
 
 
-def lora_da(x, dt, out, n_sub, n_fields, scale, p=0.0, seed=0, accumulate=False, mask=None):
+def lora_da(x, dt, out, n_sub, n_fields, scale, p=0.0, seed=0, accumulate=False):
     """out [16 * n_sub, in] (bf16, contiguous: the first rows of the stacked A's gradient) (+)= scale / (1 - p) * dt[:, :16 n_sub]^T . (mask_f . x),
     the dropout masks of ecgb_lora_down evaluated again from (seed, element index) (ecgb_lora_da): one pass over x for all modules of the site,
     no masked copies of x kept by the forward; row chunks meet in fp32 slabs added in order."""
@@ -499,21 +485,19 @@ def lora_da(x, dt, out, n_sub, n_fields, scale, p=0.0, seed=0, accumulate=False,
     assert dt.shape == (T, 64) and out.shape == (16 * n_sub, K) and out.dtype == torch.bfloat16 and out.is_contiguous()
     nbytes = _L().ecgb_lora_da_scratch_bytes(T, K, n_sub)
     scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-    assert mask is None or mask.shape == (n_fields, T, K // 32)
-    _lib.check(_L().ecgb_lora_da_m(_p(_bf(x)), _p(_bf(dt)), _p(out), _p(mask), T, K, n_sub, n_fields, float(scale), float(p), int(seed), int(accumulate),
-                                   _p(scratch), nbytes, _st()))
+    _lib.check(_L().ecgb_lora_da(_p(_bf(x)), _p(_bf(dt)), _p(out), T, K, n_sub, n_fields, float(scale), float(p), int(seed), int(accumulate),
+                                 _p(scratch), nbytes, _st()))
     return out
 
 
-def lora_dx_glu(dx, dt, At, gate_up, scale, p=0.0, seed=0, gelu_tanh=False, mask=None):
+def lora_dx_glu(dx, dt, At, gate_up, scale, p=0.0, seed=0, gelu_tanh=False):
     """d(gate|up) = glu_bwd(gate|up, dx + scale / (1 - p) * mask . (dt A)) in one pass (ecgb_lora_dx_glu: the down-projection site, one
     adapter block); dx [T, I] is only read."""
     T, inter = dx.shape
     assert dt.shape == (T, 64) and At.shape == (inter, 64) and gate_up.shape == (T, 2 * inter)
     d = torch.empty_like(gate_up)
-    assert mask is None or mask.shape == (1, T, inter // 32)
-    _lib.check(_L().ecgb_lora_dx_glu_m(_p(_bf(dt)), _p(_bf(At)), _p(_bf(dx)), _p(_bf(gate_up)), _p(d), _p(mask), T, inter, 1, 1, float(scale), float(p), int(seed),
-                                       int(gelu_tanh), _st()))
+    _lib.check(_L().ecgb_lora_dx_glu(_p(_bf(dt)), _p(_bf(At)), _p(_bf(dx)), _p(_bf(gate_up)), _p(d), T, inter, 1, 1, float(scale), float(p), int(seed),
+                                     int(gelu_tanh), _st()))
     return d
 
 
@@ -527,7 +511,7 @@ def set_fuse_lora_dx_glu(on=True):
     _fuse_lora_dx_glu = bool(on)
 
 
-def gemm_nn_glu_bwd_lora(dy, w, gate_up, dt, At, scale, p=0.0, seed=0, gelu_tanh=False, mask=None):
+def gemm_nn_glu_bwd_lora(dy, w, gate_up, dt, At, scale, p=0.0, seed=0, gelu_tanh=False):
     """d(gate|up) [M, 2I] = glu_bwd(gate|up, bf16(dy @ w) + scale / (1 - p) * mask . (dt A)) in ONE launch (ecgb_gemm_nn_glu_bwd_lora_bf16: the down-projection
     site of a LoRA fine-tune -- gemm_nn followed by lora_dx_glu, the same bits, d(act(gate) * up) never written), or None where the four-wave kernel does not
     take the shape (the caller runs the two)."""
@@ -538,16 +522,15 @@ def gemm_nn_glu_bwd_lora(dy, w, gate_up, dt, At, scale, p=0.0, seed=0, gelu_tanh
     if not _fuse_lora_dx_glu:
         return None
     d = torch.empty_like(gate_up)
-    assert mask is None or mask.shape == (1, M, inter // 32)
-    rc = _L().ecgb_gemm_nn_glu_bwd_lora_bf16_m(_p(_bf(dy)), dy.stride(0), _p(_bf(w)), w.stride(0), _p(_bf(gate_up)), gate_up.stride(0), _p(_bf(dt)), _p(_bf(At)), _p(mask),
-                                               _p(d), d.stride(0), M, inter, K, int(gelu_tanh), float(scale), float(p), int(seed), _st())
+    rc = _L().ecgb_gemm_nn_glu_bwd_lora_bf16(_p(_bf(dy)), dy.stride(0), _p(_bf(w)), w.stride(0), _p(_bf(gate_up)), gate_up.stride(0), _p(_bf(dt)), _p(_bf(At)),
+                                             _p(d), d.stride(0), M, inter, K, int(gelu_tanh), float(scale), float(p), int(seed), _st())
     if rc == -3:                                                         # ECGB_ERR_UNSUPPORTED
         return None
     _lib.check(rc)
     return d
 
 
-def gemm_nn_lora(dy, w, dt, At, scale, p=0.0, seed=0, mask=None):
+def gemm_nn_lora(dy, w, dt, At, scale, p=0.0, seed=0):
     """dx [M, in] = bf16(dy @ w) + scale / (1 - p) * mask . (dt A) in ONE launch (ecgb_gemm_nn_lora_bf16: the input gradient of a frozen projection with one LoRA
     module on it -- gemm_nn followed by lora_dx_, the same bits), or None where the four-wave kernel does not take the shape / the switch is off."""
     M, K = dy.shape
@@ -556,9 +539,8 @@ def gemm_nn_lora(dy, w, dt, At, scale, p=0.0, seed=0, mask=None):
     if not _fuse_lora_dx_glu:
         return None
     dx = torch.empty((M, n_in), dtype=torch.bfloat16, device=dy.device)
-    assert mask is None or mask.shape == (1, M, n_in // 32)
-    rc = _L().ecgb_gemm_nn_lora_bf16_m(_p(_bf(dy)), dy.stride(0), _p(_bf(w)), w.stride(0), _p(_bf(dt)), _p(_bf(At)), _p(mask), _p(dx), dx.stride(0), M, n_in, K,
-                                       float(scale), float(p), int(seed), _st())
+    rc = _L().ecgb_gemm_nn_lora_bf16(_p(_bf(dy)), dy.stride(0), _p(_bf(w)), w.stride(0), _p(_bf(dt)), _p(_bf(At)), _p(dx), dx.stride(0), M, n_in, K,
+                                     float(scale), float(p), int(seed), _st())
     if rc == -3:                                                         # ECGB_ERR_UNSUPPORTED
         return None
     _lib.check(rc)

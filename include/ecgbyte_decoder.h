@@ -307,25 +307,6 @@ int ecgb_attn_decode_split_dyn(const void *q_dev, const void *k_cache_dev, const
                                const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, const int *kv_len_dev, int n_q_heads,
                                int n_kv_heads, int head_dim, float scale, int n_splits, void *scratch_dev, size_t scratch_bytes, void *stream);
 
-/* Round 6: LoRA's dropout masks kept as BITS.  ecgb_lora_down_m also writes what it drew -- mask_out_dev: ecgb_lora_mask_words(T, in, n_fields) 32-bit words laid out
- * [n_fields][T][in / 32], bit (c & 31) of word (c >> 5) of a row = module f keeps column c -- and the backward entry points below take that buffer (mask_dev) and read
- * bits where ecgb_lora_da / ecgb_lora_dx / ecgb_lora_dx_glu / ecgb_gemm_nn_lora_bf16 / ecgb_gemm_nn_glu_bwd_lora_bf16 evaluate the counter hash again (three evaluations
- * per element and step became one).  mask_dev NULL (or p == 0): exactly the un-suffixed entry point.  The same results bit for bit (peft LoraLayer's dropout(x), main.py:131-138). */
-size_t ecgb_lora_mask_words(int T, int in, int n_fields);
-int ecgb_lora_down_m(const void *x_dev, const void *a_dev, void *t_dev, void *xd_dev, void *mask_out_dev, int T, int in, int n_sub, int n_fields,
-                     float scale, float p, uint64_t seed, void *stream);
-int ecgb_lora_dx_m(const void *dt_dev, const void *at_dev, void *dx_dev, const void *mask_dev, int T, int in, int n_sub, int n_fields,
-                   float scale, float p, uint64_t seed, void *stream);
-int ecgb_lora_dx_glu_m(const void *dt_dev, const void *at_dev, const void *dx_dev, const void *gate_up_dev, void *d_gate_up_dev, const void *mask_dev, int T,
-                       int inter, int n_sub, int n_fields, float scale, float p, uint64_t seed, int gelu_tanh, void *stream);
-int ecgb_lora_da_m(const void *x_dev, const void *dt_dev, void *da_dev, const void *mask_dev, int T, int in, int n_sub, int n_fields, float scale, float p,
-                   uint64_t seed, int accumulate, void *scratch_dev, size_t scratch_bytes, void *stream);
-int ecgb_gemm_nn_lora_bf16_m(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *dt_dev, const void *at_dev, const void *mask_dev,
-                             void *dx_dev, long long lddx, int M, int in, int K, float scale, float p, uint64_t seed, void *stream);
-int ecgb_gemm_nn_glu_bwd_lora_bf16_m(const void *dy_dev, long long lddy, const void *w_dev, long long ldw, const void *gate_up_dev, long long ldgu,
-                                     const void *dt_dev, const void *at_dev, const void *mask_dev, void *d_gate_up_dev, long long ldd, int M, int inter, int K,
-                                     int gelu_tanh, float scale, float p, uint64_t seed, void *stream);
-
 /* Tuning / A-B: the most workgroups ecgb_glu_fwd / ecgb_glu_bwd launch (default 2^20: one trip of a workgroup; rounds 2-5: 4 096 walking the tensor in a grid-stride loop). */
 int ecgb_set_stream_grid_cap(int n);
 /* Tuning: the most workgroups of ecgb_rmsnorm_bwd at hidden 2048 / 4096 (with ecgb_set_rmsnorm_bwd_rows_per_wg; changes ecgb_rmsnorm_bwd_scratch_floats and the order of the dw sum). */

@@ -29,8 +29,7 @@ def step():
 def r4sched(on): ops.set_gemm_w4_sched(1 if on else 0)
 def r4dispatch(on): ops.set_gemm_w4_min_ktiles(128 if on else 256)
 def r4all(on): r4sched(on); r4dispatch(on)
-switch = {"w4": ops.set_gemm_w4, "rope_bwd": ops.set_attn_bwd_rope_fusion, "r4sched": r4sched, "r4dispatch": r4dispatch, "r4all": r4all, "lora_dx": ops.set_fuse_lora_dx_glu, "rope_fwd": ops.set_gemm_rope_fusion,
-          "mask_bits": ops.set_lora_mask_bits}[what]   # (mask_bits: LoRA's dropout masks kept as bits for the backward, round 6; LoRA only)
+switch = {"w4": ops.set_gemm_w4, "rope_bwd": ops.set_attn_bwd_rope_fusion, "r4sched": r4sched, "r4dispatch": r4dispatch, "r4all": r4all, "lora_dx": ops.set_fuse_lora_dx_glu, "rope_fwd": ops.set_gemm_rope_fusion}[what]
 for _ in range(3): step()
 res = {False: [], True: []}
 for rnd in range(4):

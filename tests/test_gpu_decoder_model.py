@@ -321,7 +321,7 @@ def test_lora_dropout_masks_independent_per_module_and_replayed_in_backward():
     with torch.no_grad():
         site.B.copy_((torch.randn(512, 64, device="cuda") * 0.1).to(torch.bfloat16) * site.bmask)
     y, saved = site.project(x, w, training=True, keep=True)
-    _, xd, t, p_used, seed, mbits = saved
+    _, xd, t, p_used, seed = saved
     keep = (xd != 0) | (x[None] == 0)
     rate = 1.0 - keep.float().mean(dim=(1, 2))
     assert all(abs(float(r) - p) < 0.01 for r in rate), rate                 # every block drops ~p of the elements
@@ -343,9 +343,9 @@ def test_lora_dropout_masks_independent_per_module_and_replayed_in_backward():
             gr = torch.zeros_like(prm.data)
             for lo, hi, dy, xin in parts: gr[lo:hi] = ops.gemm_tn(dy, xin, alpha=alpha)
             prm.grad = gr
-        def _lora_agrad(self, prm, x, dt, n_sub, n_fields, scale, p, seed, mask=None):
+        def _lora_agrad(self, prm, x, dt, n_sub, n_fields, scale, p, seed):
             gr = torch.zeros_like(prm.data)
-            ops.lora_da(x, dt, gr[: 16 * n_sub], n_sub, n_fields, scale, p, seed, mask=mask)
+            ops.lora_da(x, dt, gr[: 16 * n_sub], n_sub, n_fields, scale, p, seed)
             prm.grad = gr
     dy = torch.randn(T, 512, device="cuda").to(torch.bfloat16)
     dx0 = torch.randn(T, K, device="cuda").to(torch.bfloat16)

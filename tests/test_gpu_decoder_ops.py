@@ -967,94 +967,3 @@ def test_rmsnorm_with_lora_down_projection_is_the_two_launches(ops, rows, gemma)
         t0 = ops.gemm_nt(y0, A, alpha=2.0)
         y1, r1, s1, t1 = ops.rmsnorm_fwd(x, w, 1e-5, residual=residual, gemma=gemma, lora=(A, 2.0))
         assert torch.equal(y1, y0) and torch.equal(r1, r0) and torch.equal(s1, s0) and torch.equal(t1, t0)
-
-
-# ---- round 6: LoRA's dropout masks as bits --------------------------------------------------------------------------------------------------------------------------
-def _unpack_mask(mask, K):
-    """int32 [F, T, K / 32] -> bool [F, T, K]: bit (c & 31) of word (c >> 5)."""
-    sh = torch.arange(32, device=mask.device, dtype=torch.int32)
-    return ((mask[..., None] >> sh) & 1).bool().reshape(mask.shape[0], mask.shape[1], K)
-
-
-@pytest.mark.parametrize("T,K,n_sub,n_fields", [(1024, 512, 3, 3), (8192, 2048, 3, 3), (8200, 2048, 2, 2), (1000, 8192, 1, 1), (32768, 2048, 1, 1), (70, 192, 2, 2)],
-                         ids=["qkv-small", "qkv-two-row-groups", "gate-up-ragged", "down-wide", "o-site", "tiny-odd"])
-def test_lora_down_writes_the_masks_it_drew_as_bits(ops, T, K, n_sub, n_fields):
-    """ecgb_lora_down_m: the bit of (module f, row, column) is set iff the masked copy of x the same launch wrote kept the element (peft LoraLayer's dropout(x),
-    main.py:131-138); t and the masked copies are the bits of the launch without the mask output."""
-    p = 0.25
-    x = _bf(T, K, seed=61)
-    x[x == 0] = 1.0                                                       # (so that a zero in the masked copy means dropped)
-    A = torch.zeros(64, K, dtype=torch.bfloat16, device="cuda")
-    A[: 16 * n_sub] = _bf(16 * n_sub, K, scale=K ** -0.5, seed=62)
-    t0, xd0 = ops.lora_down(x, A, n_sub, n_fields, 2.0, p, 4242, keep_masked=True)
-    ops.set_lora_mask_bits(True)
-    try:
-        t1, xd1, mask = ops.lora_down(x, A, n_sub, n_fields, 2.0, p, 4242, keep_masked=True, want_mask=True)
-    finally:
-        ops.set_lora_mask_bits(False)
-    assert torch.equal(t0, t1) and torch.equal(xd0, xd1)
-    assert mask.shape == (n_fields, T, K // 32) and mask.dtype == torch.int32
-    assert torch.equal(_unpack_mask(mask, K), xd1 != 0)
-    assert abs(float((xd1 != 0).float().mean()) - (1 - p)) < 0.01
-
-
-@pytest.mark.parametrize("T,K,n_sub,n_fields", [(4096, 2048, 3, 3), (4100, 2048, 2, 2), (2048, 8192, 1, 1), (300, 512, 1, 1), (8192, 2048, 1, 1)],
-                         ids=["qkv", "gate-up-ragged", "down", "small", "o"])
-def test_lora_backward_kernels_read_the_bits_instead_of_hashing(ops, T, K, n_sub, n_fields):
-    """lora_da, lora_dx_ and (one module) lora_dx_glu given the forward's bits against the same kernels replaying the hash: bit for bit."""
-    p, seed = 0.05, 991
-    x, dt = _bf(T, K, seed=63), _bf(T, 64, scale=0.1, seed=64)
-    dt[:, 16 * n_sub:] = 0
-    A = torch.zeros(64, K, dtype=torch.bfloat16, device="cuda")
-    A[: 16 * n_sub] = _bf(16 * n_sub, K, scale=K ** -0.5, seed=65)
-    ops.set_lora_mask_bits(True)
-    try:
-        _, _, mask = ops.lora_down(x, A, n_sub, n_fields, 2.0, p, seed, want_mask=True)
-    finally:
-        ops.set_lora_mask_bits(False)
-    a = ops.lora_da(x, dt, torch.zeros(16 * n_sub, K, dtype=torch.bfloat16, device="cuda"), n_sub, n_fields, 2.0, p, seed)
-    b = ops.lora_da(x, dt, torch.zeros(16 * n_sub, K, dtype=torch.bfloat16, device="cuda"), n_sub, n_fields, 2.0, p, seed, mask=mask)
-    assert torch.equal(a, b) and float(a.float().abs().max()) > 0
-    At = ops.transpose(A)
-    dx0 = _bf(T, K, seed=66)
-    a = ops.lora_dx_(dx0.clone(), dt, At, n_sub, n_fields, 2.0, p, seed)
-    b = ops.lora_dx_(dx0.clone(), dt, At, n_sub, n_fields, 2.0, p, seed, mask=mask)
-    assert torch.equal(a, b) and not torch.equal(a, dx0)
-    wrong = ops.lora_dx_(dx0.clone(), dt, At, n_sub, n_fields, 2.0, p, seed, mask=torch.zeros_like(mask))     # (the bits are what is read: all dropped -> nothing added)
-    assert torch.equal(wrong, dx0)
-    if n_sub == 1:
-        gu = _bf(T, 2 * K, seed=67)
-        for gelu in (False, True):
-            a = ops.lora_dx_glu(dx0, dt, At, gu, 2.0, p, seed, gelu_tanh=gelu)
-            b = ops.lora_dx_glu(dx0, dt, At, gu, 2.0, p, seed, gelu_tanh=gelu, mask=mask)
-            assert torch.equal(a, b)
-
-
-@pytest.mark.parametrize("glu", [None, False, True], ids=["o-site", "down-silu", "down-gelu"])
-def test_input_gradient_gemm_folds_the_adapter_with_the_bits(ops, glu):
-    """gemm_nn_lora / gemm_nn_glu_bwd_lora (the four-wave kernel's EPI 8 / 6 / 7) with the forward's bits against the hash replay: the same bits; at the C3 shapes
-    (32 768 rows: what the kernel takes)."""
-    p, seed = 0.05, 1717
-    M, K, n_in = 32768, 2048, (2048 if glu is None else 8192)
-    if glu is not None:
-        K, n_in = 2048, 8192
-    dy, w = _bf(M, K, scale=0.5, seed=68), _bf(K, n_in, scale=K ** -0.5, seed=69)
-    dt = _bf(M, 64, scale=0.1, seed=70)
-    dt[:, 16:] = 0
-    A = torch.zeros(64, n_in, dtype=torch.bfloat16, device="cuda")
-    A[:16] = _bf(16, n_in, scale=n_in ** -0.5, seed=71)
-    At = ops.transpose(A)
-    xin = _bf(M, n_in, seed=72)
-    ops.set_lora_mask_bits(True)
-    try:
-        _, _, mask = ops.lora_down(xin, A, 1, 1, 2.0, p, seed, want_mask=True)
-    finally:
-        ops.set_lora_mask_bits(False)
-    if glu is None:
-        a = ops.gemm_nn_lora(dy, w, dt, At, 2.0, p, seed)
-        b = ops.gemm_nn_lora(dy, w, dt, At, 2.0, p, seed, mask=mask)
-    else:
-        gu = _bf(M, 2 * n_in, seed=73)
-        a = ops.gemm_nn_glu_bwd_lora(dy, w, gu, dt, At, 2.0, p, seed, gelu_tanh=glu)
-        b = ops.gemm_nn_glu_bwd_lora(dy, w, gu, dt, At, 2.0, p, seed, gelu_tanh=glu, mask=mask)
-    assert a is not None and b is not None and torch.equal(a, b)

@@ -431,23 +431,6 @@ def test_lora_step_is_the_same_bits_twice():
         assert torch.equal(p1[k], p2[k]), k
 
 
-def test_lora_step_with_mask_bits_is_the_hash_replay_step_bit_for_bit():
-    """Round 6 (opt-in, ops.set_lora_mask_bits): the forward's dropout masks kept as bits and read by lora_da / lora_dx / the GEMM folds, against every kernel
-    evaluating the hash again (the default): loss, every adapter gradient and every updated adapter identical."""
-    from ecg_byte_amd import decoder_ops as ops
-    l1, g1, p1 = _one_step(True, seed=11)                                 # (the default: every kernel evaluates the hash)
-    ops.set_lora_mask_bits(True)
-    try:
-        l2, g2, p2 = _one_step(True, seed=11)
-    finally:
-        ops.set_lora_mask_bits(False)
-    assert torch.equal(l1, l2) and g1.keys() == g2.keys() and len(g1) > 0
-    for k in g1:
-        assert torch.equal(g1[k], g2[k]), k
-    for k in p1:
-        assert torch.equal(p1[k], p2[k]), k
-
-
 def test_full_finetune_step_is_the_same_bits_twice():
     """Full fine-tune: loss, every gradient (the tied embedding's too: its rows are scattered in sorted order, no atomics) and every
     updated weight repeat bit for bit."""
