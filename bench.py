@@ -104,24 +104,6 @@ def measured_traffic_bytes():
     return (2.0 * d["FETCH_SIZE"]["per_launch_mean"] + d["WRITE_SIZE"]["per_launch_mean"]) * 1024.0, os.path.relpath(f, ROOT)
 
 
-def valu_roofline(kernel_ms):
-    """Secondary roofline of the encode kernel: it is bound by vector-instruction issue and LDS latency, not by HBM.
-    achieved = vector instructions per launch (SQ_INSTS_VALU of the committed counter pass, profiles/r*/sq_pmc.json) / the kernel
-    time measured by THIS run; peak = 256 CUs x 4 SIMDs x one wave64 VALU instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md,
-    wave scheduling).  None if no counter profile is committed."""
-    f = _latest_profile("sq_pmc.json")
-    if not f:
-        return None
-    with open(f) as fh:
-        d = json.load(fh)
-    insts = d["counters"]["SQ_INSTS_VALU"]["per_launch_mean"]
-    peak = 256 * 4 * 2.4e9 / 2.0
-    ach = insts / (kernel_ms * 1e-3)
-    return {"bound": "valu_issue", "achieved": ach / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s", "frac": ach / peak,
-            "valu_insts_per_launch": insts, "valu_insts_per_record": d.get("derived", {}).get("valu_insts_per_record"),
-            "source": os.path.relpath(f, ROOT)}
-
-
 def _gen_chunk(args):
     from ecg_byte_amd import synth
     start, count, L, seed = args
@@ -189,11 +171,9 @@ def cpu_baseline(merges, pc, L, seed, budget_s=12.0):
     return {
         "value": toks_f / dt_f, "unit": "tokens/s", "cores": 1, "kind": "port",
         "value_all_cores_trie_built_once": toks_all / dt_all, "threads_all_cores": n_thr,
-        "records_per_s_all_cores": n_thr * per_thread / dt_all,
-        "sample": f"{n_f} records of 12x{L} in {dt_f:.1f} s, trie rebuilt per call as the reference does; oracle/ecgb_oracle.c",
+        "sample": f"{n_f} records of 12x{L} in {dt_f:.1f} s, trie rebuilt per call (as the reference); oracle/ecgb_oracle.c",
         "records_per_s": n_f / dt_f,
         "value_trie_built_once": toks / dt_once,
-        "records_per_s_trie_built_once": n_once / dt_once,
         "quantiser_python_style_symbols_per_s": n_py * 12 * L / dt_py,      # np.vectorize + join, one core (tokenizer_utils.py:14-19)
         "quantiser_c_symbols_per_s": n_c * 12 * L / dt_c,
         "host_cpus": os.cpu_count(),
@@ -261,14 +241,13 @@ def train_cpu_baseline(cfg_kw, S, threads=6, gate=None, lora_scale=None, rope=LL
     if variants:
         for dtype, thr, opt in ((torch.float32, n_all, True), (torch.bfloat16, n_all, False), (torch.bfloat16, threads, False)):
             t, _ = _cpu_train_once(cfg_kw, S, thr, dtype, opt, base, batch, lora_scale, rope)
-            var.append({"dtype": str(dtype).replace("torch.", ""), "threads": thr, "optimizer_step": opt, "samples_per_s": 1.0 / t, "seconds": t})
+            var.append({"dtype": str(dtype).replace("torch.", ""), "threads": thr, "optimizer_step": opt, "samples_per_s": 1.0 / t})
     out = {"value": 1.0 / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-           "sample": f"1 sample (seq {S}) fwd+bwd{' (adapters only)' if lora_scale is not None else ''}, fp32, oracle/llama_ref.py on the host, {dt:.1f} s; no optimizer step",
-           "host_cpus": os.cpu_count()}
+           "sample": f"1 sample (seq {S}) fwd+bwd{' (adapters only)' if lora_scale is not None else ''}, fp32, oracle/llama_ref.py, {dt:.1f} s"}
     if var:
-        out["variants"] = var
+        out["variants"] = {k: [v[k] for v in var] for k in var[0]}
     if hip_loss is not None:
-        out["parity_gate"] = _gate_object(f"{label}; HIP model's own weights, sample 0 of its batch: HIP training-forward loss vs this fp32 leg's", hip_loss, ref_loss)
+        out["parity_gate"] = _gate_object(f"{label}: HIP model's weights, sample 0, training forward vs this fp32 leg", hip_loss, ref_loss)
     return out
 
 
@@ -382,17 +361,21 @@ def bench_batch_sweep(tk, pc, xd, L, sizes=(1, 64, 1024, 4096, 16384, 65536), re
     return out
 
 
-def device_selfcheck():
-    """Which GPU the line was measured on and whether it repeats a product bit for bit (torch.matmul, none of this repository's code: one GPU of the pool did not in
-    round 4 -- EXPERIMENTS.md section R4, tests/test_gpu_00_selfcheck.py; the train legs' figures from such a device are not to be trusted)."""
+def gpu_serial():
+    """The GPU's serial number by rocm-smi.  Called BEFORE this process touches the GPU: rocm-smi is a script (the child execs an interpreter), and on this pool a process
+    that has initialised the GPU -- a forked child of one included, under `rocprofv3 --pmc` -- is refused such an exec."""
     import subprocess
-    import torch
-    serial = None
     try:
         txt = subprocess.run(["rocm-smi", "--showserial"], capture_output=True, text=True, timeout=20).stdout
-        serial = next((ln.split(":")[-1].strip() for ln in txt.splitlines() if "Serial Number:" in ln), None)
+        return next((ln.split(":")[-1].strip() for ln in txt.splitlines() if "Serial Number:" in ln), None)
     except Exception:
-        pass
+        return None
+
+
+def device_selfcheck(serial):
+    """Which GPU the line was measured on and whether it repeats a product bit for bit (torch.matmul, none of this repository's code: one GPU of the pool did not in
+    round 4 -- EXPERIMENTS.md section R4, tests/test_gpu_00_selfcheck.py; the train legs' figures from such a device are not to be trusted)."""
+    import torch
     g = torch.Generator(device="cuda").manual_seed(0)
     x = (torch.randn(2048, 512, device="cuda", generator=g) * 0.5).bfloat16()
     w = (torch.randn(3072, 512, device="cuda", generator=g) * 0.05).bfloat16()
@@ -432,11 +415,10 @@ def bench_trainer(pc, L, x, num_merges=4000):
     assert N[0] == text.numel(), (N[0], text.numel())
     alg = sum(2 * N[i] + 2 * N[i + 1] for i in range(k))
     alg_r4 = sum(8 * N[i] + 4 * N[i + 1] for i in range(k))
-    return {"workload": f"{n_records} records of 12x{L} = {text.numel()} symbols, {num_merges} merges (the corpus of tokenizer_c2.pkl)",
-            "seconds": best, "merges_done": k, "final_ids": m, "compression": text.numel() / max(m, 1),
+    return {"workload": f"{n_records} records of 12x{L} = {text.numel()} symbols, {num_merges} merges (tokenizer_c2.pkl's corpus)",
+            "seconds": best, "merges_done": k, "final_ids": m,
             "algorithmic_bytes": alg, "GB/s": alg / best / 1e9, "frac_of_hbm_peak": alg / best / 1e9 / HBM_PEAK_GBS,
-            "frac_at_round4_bytes": alg_r4 / best / 1e9 / HBM_PEAK_GBS, "form": "slotted ranges, one pass per merge, 16-bit ids",
-            "merges_per_s": k / best}
+            "frac_at_round4_bytes": alg_r4 / best / 1e9 / HBM_PEAK_GBS, "form": "slotted ranges, one pass per merge, 16-bit ids"}
 
 
 def bench_preprocess(dev, n_records=4096):
@@ -479,7 +461,7 @@ def bench_preprocess(dev, n_records=4096):
     sweeps = {"filter_chain": 8.0, "wavelet": 1.0, "resample": 2.25}
     traffic = sum(sweeps.values()) * 16 * samples
     ach = alg / (ms * 1e-3) / 1e9
-    return {"workload": f"{n_records} raw records of 5000 x 12 float64: filtfilt chain, db6 wavelet shrinkage, resample to 250 Hz, segments",
+    return {"workload": f"{n_records} raw records of 5000 x 12 float64: filter chain, wavelet shrinkage, resample, segments",
             "ms": ms, "records_per_s": n_records / (ms * 1e-3), "ms_per_4096_records_at": larger,
             # the roofline of the stage: ALGORITHMIC bytes (480 KB read + 240 KB written per record) over the measured time against the HBM peak
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes": alg},
@@ -533,17 +515,17 @@ def bench_c5(args, dev):
     per_layer = H * (Hq + 2 * Hkv) * D + Hq * D * H + 3 * H * I
     tokens, head_rows = B * S, B * 24
     flops = 2 * (2 * Lyr * per_layer * tokens + 2 * H * V * head_rows) + 3 * Lyr * 2 * S * Hq * D * tokens   # frozen base: forward + input gradients
-    out = {"workload": f"C5: Gemma-2B dims ({Lyr} layers, {Hq}/{Hkv} heads of {D}, MLP {I}, vocab {V}), seq {S}, batch {B}, LoRA r16, random init",
+    out = {"workload": f"C5: Gemma-2B dims ({Lyr} layers, vocab {V}), seq {S}, batch {B}, LoRA r16, random init",
            "train": {"ms_per_step": ms, "samples_per_s": B / (ms * 1e-3), "tokens_per_s": tokens / (ms * 1e-3), "loss": float(loss.item()),
                      "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "algorithmic_flops_per_step": flops},
+                                  "frac": flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "flops_per_step": flops},
                      "max_memory_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}}
     if gate is not None:
         n_all = max(1, min(os.cpu_count() or 1, 64))
         cfg_kw = dict(vocab_size=V, hidden_size=H, intermediate_size=I, num_hidden_layers=Lyr, num_attention_heads=Hq, num_key_value_heads=Hkv, head_dim=D,
                       rms_norm_eps=cfg.rms_norm_eps, model_type="gemma")
         out["train"]["cpu_baseline"] = train_cpu_baseline(cfg_kw, S, threads=n_all, gate=gate, lora_scale=2.0, rope=(10000.0, None), variants=False,
-                                                          label="18 layers, LoRA r16, lora_B != 0, dropout off")
+                                                          label="18 layers, LoRA r16 (B != 0, dropout off)")
         del gate
     m.eval()
     prompt = ids[:1, -600:].contiguous()
@@ -627,7 +609,7 @@ def bench_c1(args, dev, cpu=True):
     e2.record()
     torch.cuda.synchronize()
     enc_ms, step_ms = e0.elapsed_time(e1) / reps, e1.elapsed_time(e2) / reps
-    out = {"workload": f"C1: 12x{L} records, {len(merges)} merges, GPT-2-small dims (vocab {n_vocab}), seq {S}, batch {B}, forward (loss)",
+    out = {"workload": f"C1: 12x{L}, {len(merges)} merges, GPT-2-small (vocab {n_vocab}), seq {S}, batch {B}, forward",
            "hip": {"quantise_encode_assemble_ms": enc_ms, "encode_plus_forward_ms": step_ms, "samples_per_s": B / (step_ms * 1e-3),
                    "loss": float(loss.item())}}
     if cpu:
@@ -667,8 +649,8 @@ def bench_c1(args, dev, cpu=True):
         out["cpu_baseline"] = {"value": variants[0]["samples_per_s"], "unit": "samples/s", "cores": 6, "kind": "port",
                                "encode_s_per_batch_1_core": enc_cpu,
                                "sample": f"batch of {B}: rust_bpe port (1 core) + GPT-2-small forward, torch CPU fp32, 6 threads",
-                               "variants": variants, "host_cpus": os.cpu_count()}
-        out["parity_gate"] = _gate_object("12 layers; HIP model's own weights, the timed batch: HIP forward loss vs the fp32 CPU leg's (oracle/gpt2_ref.py)",
+                               "variants": {k: [v[k] for v in variants] for k in variants[0]}}
+        out["parity_gate"] = _gate_object("12 layers: HIP model's weights, the timed batch, forward vs the fp32 CPU leg",
                                           out["hip"]["loss"], ref_loss)
         out["speedup_vs_cpu_6_threads"] = out["hip"]["samples_per_s"] / out["cpu_baseline"]["value"]
     del model
@@ -835,13 +817,13 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host, loader_di
     achieved = flops / sec / 1e12
     out = {"metric": "train_samples_per_sec", "value": B * world / sec, "unit": "samples/s", "ms_per_step": sec * 1e3,
            "steps": args.train_steps, "dtype": "bf16", "final_loss": float(loss.item()),
-           "config": {"workload": f"C3: Llama-3.2-1B dims (16 layers, vocab {n_vocab}), seq {S}, batch {B}/GPU, "
-                                  f"{'LoRA r16 (frozen base)' if args.lora else 'full fine-tune'}, random init; batches by quantise+encode+assemble on device",
+           "config": {"workload": f"C3: Llama-3.2-1B dims (vocab {n_vocab}), seq {S}, batch {B}/GPU, "
+                                  f"{'LoRA r16' if args.lora else 'full fine-tune'}, random init; batches by quantise+encode+assemble on device",
                       "loss_head_rows": "all" if model.full_logits else "labelled",
                       "parallelism": f"dp{world}" + (f" (bucketed async all-reduce of the flat gradient buffer, backend {dist.get_backend()})" if dist.is_initialized() else "")},
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_nt_w4_kernel (NT / NN / TN, bf16 MFMA 16x16x32) + attention",
-                        "algorithmic_flops_per_step": flops, "step_ms_hip_events": ev0.elapsed_time(ev1) / args.train_steps}}
+                        "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_nt_w4_kernel (bf16 MFMA 16x16x32) + attention",
+                        "flops_per_step": flops, "step_ms_hip_events": ev0.elapsed_time(ev1) / args.train_steps}}
     if comm is not None:
         out["gradient_exchange"] = comm
     if rank == 0 and world == 1 and loader_dir is not None:
@@ -857,7 +839,7 @@ def bench_train(args, tk, vocab, merges, pc, world, rank, dev, x_host, loader_di
                       num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads,
                       head_dim=cfg.head_dim, rms_norm_eps=cfg.rms_norm_eps)
         out["cpu_baseline"] = train_cpu_baseline(cfg_kw, S, gate=gate, lora_scale=2.0 if args.lora else None, variants=not args.lora,
-                                                 label="16 layers, LoRA r16, lora_B != 0, dropout off" if args.lora else "16 layers")
+                                                 label="16 layers, LoRA r16 (B != 0, dropout off)" if args.lora else "16 layers")
     del model, opt
     torch.cuda.empty_cache()
     return out
@@ -906,6 +888,7 @@ def main():
     workers = int(os.environ.get("ECGB_BENCH_WORKERS", max(1, min(8, (os.cpu_count() or 1) // max(1, world)))))   # 1: no fork pool (profiler runs)
     x = make_signals(args.batch, args.L, seed=0, start=rank * args.batch, workers=workers)   # rank r owns records rB..rB+B-1
     loader_dir = None
+    serial = gpu_serial() if rank == 0 else None               # (before HIP is up in this process)
     x_train = None if args.no_train else make_signals(args.train_batch, args.L, seed=0,
                                                       start=10_000_000 + rank * args.train_batch, workers=workers)
     # the tokenizer trainer's corpus (2 000 records, seed 1: what tests/golden/tokenizer_c2.pkl was trained on) -- generated here, before HIP is up, like the rest
@@ -1033,7 +1016,7 @@ def main():
         c5 = bench_c5(args, dev)
     extras = {}
     if rank == 0:
-        extras["device"] = device_selfcheck()
+        extras["device"] = device_selfcheck(serial)
     if rank == 0 and world == 1 and not args.no_extras and L == 5000:
         extras["trainer"] = bench_trainer(pc, L, x_corpus)
         del x_corpus
@@ -1062,11 +1045,6 @@ def main():
                          "kernel": "encode_flow_kernel<INPUT_F64> (fused quantise+encode, one launch per step)",
                          "kernel_ms": dev_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if B == 4096 and L == 5000:
-            rv = valu_roofline(dev_ms)
-            if rv is not None:      # instruction count from a committed counter pass (static), divided by this run's kernel time
-                out["static_from_profiles"] = {"note": "read from committed counter passes, not measured by this run",
-                                               "roofline_valu": rv, "roofline.traffic": traffic_src}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(merges, pc, L, seed=0)
         if sweep is not None:      # columns: records per launch, ms per launch, token ids/s, fraction of the HBM roofline (algorithmic bytes)
@@ -1081,7 +1059,7 @@ def main():
         out = with_top_level_scalars(out)
         line = json.dumps(compact(out), separators=(",", ":"))
         if len(line) > 8000:                                    # the driver keeps the top level and an 8 KB tail: shed the bulkiest detail objects, never the scalars
-            for path in (("static_from_profiles",), ("preprocess", "implementation_traffic"), ("c1", "cpu_baseline", "variants"), ("train", "cpu_baseline", "variants"),
+            for path in (("preprocess", "implementation_traffic"), ("c1", "cpu_baseline", "variants"), ("train", "cpu_baseline", "variants"),
                          ("train", "lora_r16", "loader", "runs"), ("cpu_baseline", "sample"), ("batch_sweep",), ("train", "hbm_bound_kernels")):
                 d = out
                 for k in path[:-1]:
