@@ -2113,11 +2113,13 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float *par
 // twice through counters in device memory:
 //   0  RoPE of the head's q and of the KV head's new key in LDS (rope_append_kernel's arithmetic; the workgroup of split 0 of the group's first head writes the rotated
 //      key and the value to cache row len - 1 -- nobody reads that row in this launch: the split that owns key len - 1 takes it from LDS / from qkv)
-//   1  the split's scores into LDS, its maximum and sum of exponentials to `stats` (attn_decode_scores_kernel's sums);  counter A += 1, wait until it is `splits`
+//   1  the split's scores into LDS, its maximum and sum of exponentials to `stats` (attn_decode_scores_kernel's sums);  wait until every split's pair is there (a pair holds kDecodeOneEmpty until stored)
 //   2  softmax over the splits' statistics, P.V of the split's keys (attn_decode_values_kernel's sums) to `partial`;  counter B: the last to arrive adds the
-//      partial outputs in split order (attn_decode_combine_kernel) and clears both counters for the next launch (a replayed graph never clears them itself).
+//      partial outputs in split order (attn_decode_combine_kernel), puts the empty marks back and clears the counter for the next launch (a replayed graph never does itself).
 // The same arithmetic in the same order: the same bits as the four launches (tests/test_gpu_decode_fused.py).  The wait in step 1 needs every workgroup of the
 // launch resident at once: the host only takes this form for splits * Hq * B <= two workgroups a CU.
+// "not stored yet" in the splits' statistics: a NaN with a payload no arithmetic produces (a sum or maximum that IS NaN -- garbage in -- is the canonical one and ends the wait like any value)
+constexpr unsigned kDecodeOneEmpty = 0x7FC0DEADu;
 struct DecodeOneArgs {
     const unsigned short *qkv;    // [B, (Hq + 2 Hkv) D]: the step's projection, not written (q and the new key are rotated into LDS)
     long long ld_qkv;
@@ -2126,8 +2128,8 @@ struct DecodeOneArgs {
     long long cap, ld;
     const float *mask;
     long long mask_ld;
-    float *stats, *partial;       // [B, Hq, splits, 2], [B, Hq, splits, D]
-    unsigned *cnt;                // [B, Hq, 2], zero between launches
+    float *stats, *partial;       // [B, Hq, splits, 2] (kDecodeOneEmpty between launches), [B, Hq, splits, D]
+    unsigned *cnt;                // [B, Hq, 2], zero between launches (word 1: the tickets of the second meeting)
     unsigned short *o;            // [B, Hq D]
     const int *len_dev;
     int len_arg, Hq, Hkv;
@@ -2273,14 +2275,17 @@ __global__ __launch_bounds__(kSplitThreads) void attn_decode_one_kernel(DecodeOn
         for (int w = 0; w < NW; ++w) l += s_red[NW + w];
         st_f(&st[2 * sp], m);
         st_f(&st[2 * sp + 1], l);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(&cnt[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(&cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)n_splits) __builtin_amdgcn_s_sleep(1);
+    }
+    // ---- the first meeting: no counter.  A split's (maximum, sum) pair is kDecodeOneEmpty -- a NaN no sum produces -- until its workgroup has stored it (the scratch starts so and the last workgroup of
+    // the launch puts it back): lane t polls pair t itself -- one round trip from the store to the values, where a counter cost an atomic, a poll and a load
+    if (tid < 2 * n_splits) {
+        const unsigned *sb = reinterpret_cast<const unsigned *>(st) + tid;
+        unsigned v = __hip_atomic_load(sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (v == kDecodeOneEmpty) { __builtin_amdgcn_s_sleep(1); v = __hip_atomic_load(sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        s_st[tid] = __uint_as_float(v);
     }
     __syncthreads();
     // ---- 2: values (attn_decode_values_kernel)
-    if (tid < 2 * n_splits) s_st[tid] = ld_f(&st[tid]);
-    __syncthreads();
     m = -INFINITY;
     for (int t = 0; t < n_splits; ++t) m = fmaxf(m, s_st[2 * t]);
     l = 0.f;
@@ -2330,10 +2335,9 @@ __global__ __launch_bounds__(kSplitThreads) void attn_decode_one_kernel(DecodeOn
         }
         A.o[((long long)b * A.Hq + hq) * D + tid] = bf(sum);
     }
-    if (tid == 0) {
-        __hip_atomic_store(&cnt[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&cnt[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // ready for the next launch: every workgroup of the (sequence, head) has read the statistics (it took its ticket after that)
+    if (tid < 2 * n_splits) st_f(&st[tid], __uint_as_float(kDecodeOneEmpty));
+    if (tid == 0) __hip_atomic_store(&cnt[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // head_dim 64 forward and backward: 2 = the lean kernels (LDS-DMA staging, softmax constants in the MFMA accumulators: the default), 1 = the round-2 LDS-DMA
@@ -3172,7 +3176,8 @@ extern "C" int ecgb_attn_decode_split_dyn(const void *q_dev, const void *k_cache
                                     n_q_heads, n_kv_heads, head_dim, scale, n_splits, scratch_dev, scratch_bytes, stream);
 }
 
-// floats of scratch ecgb_attn_decode_one needs (statistics, partial outputs, counters); the LAST batch * n_q_heads * 2 words (the counters) must be zero before the first call
+// floats of scratch ecgb_attn_decode_one needs (statistics, partial outputs, counters): before the first call the FIRST batch * n_q_heads * n_splits * 2 floats (the
+// statistics) must hold the bit pattern 0x7FC0DEAD and the LAST batch * n_q_heads * 2 words (the counters) zero; every launch leaves them so
 extern "C" size_t ecgb_attn_decode_one_scratch_floats(int batch, int n_q_heads, int head_dim, int n_splits)
 {
     if (batch <= 0 || n_q_heads <= 0 || head_dim <= 0 || n_splits <= 0) return 0;

@@ -840,8 +840,10 @@ def _n_cus():
 
 
 def decode_one_scratch(B, Hq, D, n_splits, device):
-    """Scratch of attn_decode_one (statistics, partial outputs, the counters -- zero, and every launch leaves them zero)."""
-    return torch.zeros(_L().ecgb_attn_decode_one_scratch_floats(B, Hq, D, n_splits), dtype=torch.float32, device=device)
+    """Scratch of attn_decode_one: the splits' statistics (the bit pattern 0x7FC0DEAD = not stored yet), partial outputs, the counters (zero); every launch leaves them as it found them."""
+    buf = torch.zeros(_L().ecgb_attn_decode_one_scratch_floats(B, Hq, D, n_splits), dtype=torch.float32, device=device)
+    buf.view(torch.int32)[: B * Hq * n_splits * 2] = 0x7FC0DEAD
+    return buf
 
 
 _one_scratch = {}

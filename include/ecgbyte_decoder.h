@@ -316,8 +316,8 @@ int ecgb_set_rmsnorm_bwd_grid_cap(int n);
  * rotated in place: the cache row kv_len - 1 and o are what leaves) -- replaces ecgb_rope_append + ecgb_attn_decode_split[_dyn] (cache_utils.py:408-470 DynamicCache.update,
  * modeling_llama.py:526-614 at one query row), the same bits for the same n_splits.  The workgroups of a (sequence, head) meet through counters inside the launch, so all
  * n_splits * n_q_heads * batch of them must be resident: ECGB_ERR_UNSUPPORTED above two workgroups a CU (and outside head_dim 64 / 128 / 256, n_splits <= 64, 2048 keys a split); the
- * caller then runs the separate launches.  scratch: ecgb_attn_decode_one_scratch_floats() floats whose LAST batch * n_q_heads * 2 words (the counters) are zero before
- * the first call; every launch leaves them zero.  kv_len_dev: the number of valid cache rows AFTER the append in device memory (a replayed graph), else kv_len. */
+ * caller then runs the separate launches.  scratch: ecgb_attn_decode_one_scratch_floats() floats whose FIRST batch * n_q_heads * n_splits * 2 (the splits' statistics) hold
+ * the bit pattern 0x7FC0DEAD ("not stored yet") and whose LAST batch * n_q_heads * 2 words (the counters) are zero before the first call; every launch leaves them so.  kv_len_dev: the number of valid cache rows AFTER the append in device memory (a replayed graph), else kv_len. */
 size_t ecgb_attn_decode_one_scratch_floats(int batch, int n_q_heads, int head_dim, int n_splits);
 int ecgb_attn_decode_one(const void *qkv_dev, long long ld_qkv, const float *cos_dev, const float *sin_dev, void *cache_dev, long long ld, long long capacity,
                          const float *attn_mask_dev, long long mask_ld, void *o_dev, int batch, int kv_len, const int *kv_len_dev, int n_q_heads, int n_kv_heads,

@@ -178,7 +178,7 @@ def test_one_launch_attention_equals_rope_append_and_split_attention(ops, B, Hq,
         assert torch.equal(c1, c2), rep
         assert torch.equal(got, ref), rep
     assert torch.equal(q1, qkv)
-    assert float(scratch[-2 * B * Hq:].abs().max()) == 0.0                    # the counters went back to zero
+    assert float(scratch[-2 * B * Hq:].abs().max()) == 0.0 and bool((scratch.view(torch.int32)[: B * Hq * ns * 2] == 0x7FC0DEAD).all())   # counters back to zero, statistics back to "not stored yet"
 
 
 def test_one_launch_attention_refuses_launches_that_could_not_be_resident(ops):
@@ -221,3 +221,20 @@ def test_generate_with_one_launch_attention_equals_four_launches(family, lora):
         assert torch.equal(seq, seq_g) and torch.equal(seq, seq_g2), one
         outs[one] = (seq, logits)
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+
+
+def test_one_launch_attention_with_nan_inputs_returns(ops):
+    """Garbage in must come out as garbage, not as a wait that never ends: the splits wait for each other's statistics on a marker no arithmetic produces, so a
+    NaN sum of exponentials (NaN keys or queries) ends the wait like any value."""
+    B, Hq, Hkv, D, cap, n, ns = 1, 8, 1, 256, 768, 700, 12
+    qkv = _bf(B, (Hq + 2 * Hkv) * D, seed=51)
+    cache = _bf(B, cap, 2 * Hkv * D, seed=52)
+    cache[0, 100, :D] = float("nan")
+    qkv[0, 5] = float("nan")
+    mask = torch.ones(B, cap, device="cuda"); mask[:, n:] = 0
+    cos = sin = torch.zeros(B, D // 2, device="cuda")
+    scratch = ops.decode_one_scratch(B, Hq, D, ns, "cuda")
+    out = ops.attn_decode_one(qkv, cos, sin, cache, mask, n, Hq, Hkv, D, 1.0 / 16, ns, scratch=scratch)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out.float()).any())
+    assert bool((scratch.view(torch.int32)[: B * Hq * ns * 2] == 0x7FC0DEAD).all())
