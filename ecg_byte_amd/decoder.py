@@ -175,7 +175,8 @@ class LoraSite(nn.Module):
         At = model._shadow(("lora_At", id(self)), self.A)                 # [in, 64]
         dt = ops.gemm_nt(dy, Bt)                                         # [T, 64] = dy . B
         model._wgrad(self.B, dy, t)                                      # dB = dy^T . t  (t carries alpha / r and 1 / (1 - p))
-        self.B.grad.mul_(self.bmask)                                     # every block's rows keep only its own columns
+        if self.n_fields > 1:                                            # every block's rows keep only its own columns (one module: t is zero past its rank, dB with it)
+            self.B.grad.mul_(self.bmask)
         keep_scale = self.scale / (1.0 - int(p * 65536.0) / 65536.0)     # the keep probability ecgb_lora_down's 16-bit threshold gives
         if p == 0.0:
             model._wgrad(self.A, dt, x, alpha=keep_scale)                # no dropout: one product for all blocks
