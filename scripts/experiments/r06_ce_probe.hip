@@ -70,6 +70,48 @@ __global__ __launch_bounds__(512) void probe(unsigned short *logits, size_t rows
         }
     }
 }
+// MODE 5 (its own kernel): the row STREAMED twice by a workgroup of few registers -- read it (a running sum), then read it again (from L2 / the Infinity Cache) and write it
+// in place, 16 bytes a lane and trip; THREADS a workgroup, several workgroups a CU
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void probe_stream(unsigned short *logits, size_t rows, size_t ld)
+{
+    __shared__ float s_red[THREADS / 64];
+    const int tid = threadIdx.x;
+    for (size_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        unsigned short *p = logits + r * ld;
+        float s = 0.f;
+        for (int c = tid * 8; c < (int)ld; c += THREADS * 8 * 4) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4 *>(p + min(c + u * THREADS * 8, (int)ld - 8));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += __uint_as_float(v[u][0] << 16) + __uint_as_float(v[u][3] << 16);
+        }
+        for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+        if ((tid & 63) == 0) s_red[tid >> 6] = s;
+        __syncthreads();
+        s = 0.f;
+        for (int w = 0; w < THREADS / 64; ++w) s += s_red[w];
+        __syncthreads();
+        const unsigned bit = __float_as_uint(s) & 1u;
+        for (int c = tid * 8; c < (int)ld; c += THREADS * 8 * 4) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4 *>(p + min(c + u * THREADS * 8, (int)ld - 8));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { v[u][0] ^= bit; if (c + u * THREADS * 8 < (int)ld) *reinterpret_cast<u32x4 *>(p + c + u * THREADS * 8) = v[u]; }
+        }
+    }
+}
+template <int THREADS> float run_stream(unsigned short *buf, size_t rows, size_t ld, int grid)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(probe_stream<THREADS>, dim3(grid), dim3(THREADS), 0, 0, buf, rows, ld);
+    hipEventRecord(e0);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(probe_stream<THREADS>, dim3(grid), dim3(THREADS), 0, 0, buf, rows, ld);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); return ms / 10.f;
+}
 template <int MODE> float run(unsigned short *buf, size_t rows, size_t ld, int grid)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -88,6 +130,10 @@ int main()
         const float t0 = run<0>(buf, rows, ld, grid), t1 = run<1>(buf, rows, ld, grid), t2 = run<2>(buf, rows, ld, grid), t3 = run<3>(buf, rows, ld, grid), t4 = run<4>(buf, rows, ld, grid);
         printf("grid %4d: full %.0f us (%.2f TB/s)  copy %.0f us (%.2f)  load-only %.0f us (%.2f of one pass)  no-exp %.0f us (%.2f)  copy, consecutive chunks %.0f us (%.2f)\n",
                grid, t0 * 1e3, gb / t0, t1 * 1e3, gb / t1, t2 * 1e3, gb / 2 / t2, t3 * 1e3, gb / t3, t4 * 1e3, gb / t4);
+    }
+    for (int grid : {4096, 2048, 1024}) {
+        const float a = run_stream<256>(buf, rows, ld, grid), b = run_stream<512>(buf, rows, ld, grid), c = run_stream<1024>(buf, rows, ld, grid);
+        printf("streamed twice, grid %4d: 256 threads %.0f us (%.2f TB/s of read + write once)  512 threads %.0f us (%.2f)  1024 threads %.0f us (%.2f)\n", grid, a * 1e3, gb / a, b * 1e3, gb / b, c * 1e3, gb / c);
     }
     return 0;
 }
