@@ -75,6 +75,8 @@ def lib():
     L.ecgb_set_bpe_train_grid.restype = C.c_int
     L.ecgb_set_bpe_train_form.argtypes = [C.c_int]
     L.ecgb_set_bpe_train_form.restype = C.c_int
+    L.ecgb_set_bpe_train_fused.argtypes = [C.c_int]
+    L.ecgb_set_bpe_train_fused.restype = C.c_int
     L.ecgb_bpe_train_scratch_bytes.argtypes = [sz, u32]
     L.ecgb_bpe_train_scratch_bytes.restype = sz
     L.ecgb_bpe_train_hip.argtypes = [vp, sz, u32, vp, vp, vp, vp, vp, sz, vp]

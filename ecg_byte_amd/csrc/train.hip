@@ -253,52 +253,64 @@ __global__ __launch_bounds__(kThreads) void argmax_partial_kernel(TrainArgs A, u
 // (256 + i) x V table of every merge: 145 MB at 4 000 merges, a tenth of a merge's time and the traffic that pushed the id buffers out of the memory-side cache.
 // Workgroup b owns rows b, b + G, ..., a lane a row; partial[b] = the best of its rows, for tile_count_kernel's final reduction.
 constexpr uint32_t kRowGrid = 64;
-__global__ __launch_bounds__(kThreads) void rowmax_kernel(TrainArgs A, uint32_t merge_index)
+// COH: the table's cells were changed by atomics of THIS launch from other XCDs (the fused form of round 6: the row maxima behind the merge in the merge's own launch):
+// they are read by loads that do not stop at this XCD's L2.
+template <bool COH> __device__ __forceinline__ unsigned long long table_cell(const uint64_t *p)
 {
-    __shared__ unsigned long long s_cnt[kThreads / 64];
-    __shared__ uint32_t s_key[kThreads / 64];
-    __shared__ uint32_t s_rows[kThreads];
-    __shared__ uint32_t s_n;
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+// workgroup `wg` of `n_wg`, NT threads: rows wg, wg + n_wg, ..., a lane a row; partial[wg] = the best of its rows
+// `meet` (the fused form): called once, by every thread, between the loads of the rows' kept maxima (written by an earlier LAUNCH) and the first look at the table -- the
+// wait for the other workgroups' count deltas, with the kept maxima's round trip under it.
+struct NoMeet { __device__ __forceinline__ void operator()() const {} };
+template <int NT, bool COH, class Meet = NoMeet>
+__device__ __forceinline__ void rowmax_body(const TrainArgs &A, uint32_t merge_index, uint32_t wg, uint32_t n_wg, unsigned long long *s_cnt, uint32_t *s_key, uint32_t *s_rows, uint32_t *s_n,
+                                            Meet meet = Meet())
+{
+    bool met = false;
     const uint32_t v_cur = 256u + merge_index;            // ids that can exist so far: rows and columns below v_cur
     const uint32_t newest = merge_index > 0 ? v_cur - 1u : kEmpty;    // the id the previous merge made: counts grew only in its row and its column
     unsigned long long my_best = 0;
     uint32_t my_key = 0;
-    for (uint32_t row0 = blockIdx.x; row0 < v_cur; row0 += gridDim.x * kThreads) {       // (one trip up to 16 384 ids)
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
-        const uint32_t row = row0 + threadIdx.x * gridDim.x;                             // a lane a row: its kept maximum, or its name on the list of rows to read again
+    for (uint32_t row0 = wg; row0 < v_cur; row0 += n_wg * NT) {       // (one trip up to 16 384 ids)
+        if (threadIdx.x == 0) *s_n = 0;
+        const uint32_t row = row0 + threadIdx.x * n_wg;                                   // a lane a row: its kept maximum, or its name on the list of rows to read again
+        unsigned long long oc = 0;
+        uint32_t ok = 0, dirty = 0;
+        if (row < v_cur) { oc = A.row_cnt[row]; ok = A.row_key[row]; dirty = A.row_dirty[row]; }
+        if (!met) { meet(); met = true; }
+        __syncthreads();                                                                  // (s_n; the fused form: every lane's share of the meeting is over)
         if (row < v_cur) {
-            unsigned long long oc = A.row_cnt[row];
-            uint32_t ok = A.row_key[row];
             // Within one merge a cell only shrinks or only grows.  A shrinking cell lowers the row's maximum iff it IS the maximum: the kept cell no longer holds the kept
             // count.  A growing cell's pair holds the merge's new id: it lies in the newest id's row (all new: read) or column (one cell a row, looked at here).
-            bool again = A.row_dirty[row] || row == newest;                              // (row_dirty: not read yet since the table was built)
+            bool again = dirty || row == newest;                              // (row_dirty: not read yet since the table was built)
             // the kept cell and the row's cell in the newest id's column, asked for together (one after the other they were two memory round trips of a 7 us kernel)
             const uint32_t cell = row * A.V + (newest != kEmpty ? newest : 0u);
-            const unsigned long long kept_now = A.table[oc != 0 ? ~ok : cell];
-            const unsigned long long c = A.table[cell];
+            const unsigned long long kept_now = table_cell<COH>(A.table + (oc != 0 ? ~ok : cell));
+            const unsigned long long c = table_cell<COH>(A.table + cell);
             if (!again && oc != 0 && kept_now != oc) again = true;
-            if (again) s_rows[atomicAdd(&s_n, 1u)] = row;
+            if (again) s_rows[atomicAdd(s_n, 1u)] = row;
             else {
                 if (newest != kEmpty && better(c, ~cell, oc, ok)) { oc = c; ok = ~cell; A.row_cnt[row] = oc; A.row_key[row] = ok; }
                 if (better(oc, ok, my_best, my_key)) { my_best = oc; my_key = ok; }
             }
         }
         __syncthreads();
-        const uint32_t n_again = s_n;
+        const uint32_t n_again = *s_n;
         for (uint32_t q = 0; q < n_again; ++q) {                                         // (a handful per merge over the whole grid)
             const uint32_t again = s_rows[q];
             unsigned long long best = 0;
             uint32_t bkey = 0;
             const uint64_t *cells = A.table + (size_t)again * A.V;
             // sixteen cells a lane in flight (four at a time a row of 4 256 counts was five memory round trips, one after the other)
-            for (uint32_t c0 = threadIdx.x; c0 < v_cur; c0 += 16 * kThreads) {
+            for (uint32_t c0 = threadIdx.x; c0 < v_cur; c0 += 16 * NT) {
                 unsigned long long cnt[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) { const uint32_t c = c0 + (uint32_t)u * kThreads; cnt[u] = c < v_cur ? cells[c] : 0ull; }
+                for (int u = 0; u < 16; ++u) { const uint32_t c = c0 + (uint32_t)u * NT; cnt[u] = c < v_cur ? table_cell<COH>(cells + c) : 0ull; }
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    const uint32_t k = ~(again * A.V + c0 + (uint32_t)u * kThreads);
+                    const uint32_t k = ~(again * A.V + c0 + (uint32_t)u * NT);
                     if (better(cnt[u], k, best, bkey)) { best = cnt[u]; bkey = k; }
                 }
             }
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(kThreads) void rowmax_kernel(TrainArgs A, uint32_t 
             if ((threadIdx.x & 63) == 0) { s_cnt[threadIdx.x >> 6] = best; s_key[threadIdx.x >> 6] = bkey; }
             __syncthreads();
             if (threadIdx.x == 0) {
-                for (int w = 1; w < kThreads / 64; ++w) if (better(s_cnt[w], s_key[w], best, bkey)) { best = s_cnt[w]; bkey = s_key[w]; }
+                for (int w = 1; w < NT / 64; ++w) if (better(s_cnt[w], s_key[w], best, bkey)) { best = s_cnt[w]; bkey = s_key[w]; }
                 A.row_cnt[again] = best; A.row_key[again] = bkey; A.row_dirty[again] = 0u;
                 if (better(best, bkey, my_best, my_key)) { my_best = best; my_key = bkey; }
             }
@@ -326,9 +338,17 @@ __global__ __launch_bounds__(kThreads) void rowmax_kernel(TrainArgs A, uint32_t 
     if ((threadIdx.x & 63) == 0) { s_cnt[threadIdx.x >> 6] = my_best; s_key[threadIdx.x >> 6] = my_key; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < kThreads / 64; ++w) if (better(s_cnt[w], s_key[w], my_best, my_key)) { my_best = s_cnt[w]; my_key = s_key[w]; }
-        A.partial[2 * blockIdx.x] = my_best; A.partial[2 * blockIdx.x + 1] = my_key;
+        for (int w = 1; w < NT / 64; ++w) if (better(s_cnt[w], s_key[w], my_best, my_key)) { my_best = s_cnt[w]; my_key = s_key[w]; }
+        A.partial[2 * wg] = my_best; A.partial[2 * wg + 1] = my_key;
     }
+}
+__global__ __launch_bounds__(kThreads) void rowmax_kernel(TrainArgs A, uint32_t merge_index)
+{
+    __shared__ unsigned long long s_cnt[kThreads / 64];
+    __shared__ uint32_t s_key[kThreads / 64];
+    __shared__ uint32_t s_rows[kThreads];
+    __shared__ uint32_t s_n;
+    rowmax_body<kThreads, false>(A, merge_index, blockIdx.x, gridDim.x, s_cnt, s_key, s_rows, &s_n);
 }
 
 // One workgroup: commit the previous merge (length, counter), pick the pair of this one.
@@ -1153,6 +1173,8 @@ TrainArgs layout(void *scratch_dev, size_t n, uint32_t num_merges, Halo **halo_w
     return A;
 }
 
+int g_train_fused = 0;      // the slotted forms: the next merge's row maxima inside the merge's launch (round 6); 0: a launch of their own (ecgb_set_bpe_train_fused)
+
 template <typename IdT>
 int train_slotted(TrainArgs A, RangeSum *sums, const uint8_t *text_dev, size_t n, uint32_t num_merges, unsigned grid, uint32_t *n_done_dev, uint32_t *ids_out_dev,
                   uint64_t *n_ids_dev, hipStream_t st)
@@ -1166,9 +1188,20 @@ int train_slotted(TrainArgs A, RangeSum *sums, const uint8_t *text_dev, size_t n
     S.sum[0] = sums;
     S.sum[1] = sums + kMaxRanges;
     hipLaunchKernelGGL(seg_init_kernel<IdT>, dim3(grid), dim3(kThreads), 0, st, S, text_dev);
+    const unsigned merge_grid = (S.ranges + kSegWaves - 1) / kSegWaves;
+    // round 6: merge i + 1's row maxima in merge i's launch (its first workgroups, behind a meeting on per-workgroup flags) -- every workgroup of the launch must be
+    // resident for that: one a CU at most.  ecgb_set_bpe_train_fused(0): the arg-max as a launch of its own between two merges (round 5).
+    int dev = 0, n_cu = 0;
+    const bool fused = g_train_fused && hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+                       merge_grid <= (unsigned)n_cu;
+    if (fused) {
+        const int rc = check_hip(hipMemsetAsync(A.tiles, 0, (size_t)merge_grid * sizeof(uint32_t), st), "hipMemsetAsync(flags)");
+        if (rc) return rc;
+    }
+    const uint32_t n_row_wg = fused ? std::min<uint32_t>(kRowGrid, merge_grid) : kRowGrid;
     for (uint32_t i = 0; i < num_merges; ++i) {
-        hipLaunchKernelGGL(rowmax_kernel, dim3(kRowGrid), dim3(kThreads), 0, st, A, i);
-        hipLaunchKernelGGL(seg_merge_kernel<IdT>, dim3((S.ranges + kSegWaves - 1) / kSegWaves), dim3(kSegThreads), 0, st, S, i, kRowGrid);   // (with the final arg-max and the commit)
+        if (!fused || i == 0) hipLaunchKernelGGL(rowmax_kernel, dim3(n_row_wg), dim3(kThreads), 0, st, A, i);
+        hipLaunchKernelGGL(seg_merge_kernel<IdT>, dim3(merge_grid), dim3(kSegThreads), 0, st, S, i, n_row_wg, fused ? n_row_wg : 0u);   // (with the final arg-max and the commit)
     }
     hipLaunchKernelGGL(seg_finish_kernel<IdT>, dim3(S.ranges), dim3(kThreads), 0, st, S, ids_out_dev, n_ids_dev, n_done_dev);
     return check_hip(hipGetLastError(), "bpe train launches");
@@ -1190,6 +1223,7 @@ extern "C" int ecgb_set_bpe_train_grid(int workgroups)
 // 1 = the same with 32-bit ids whatever the vocabulary; 2 = round 4's count pass + rewrite over a globally compacted buffer (what the sharded form runs).
 // Like the grid: a process-wide test and tuning hook read at the start of a run.
 static int g_train_form = 0;
+extern "C" int ecgb_set_bpe_train_fused(int on) { g_train_fused = on ? 1 : 0; return ECGB_OK; }
 extern "C" int ecgb_set_bpe_train_form(int form)
 {
     if (form < 0 || form > 2) { ecgb::set_error("ecgb_set_bpe_train_form: 0 (default), 1 or 2"); return ECGB_ERR_INVALID; }

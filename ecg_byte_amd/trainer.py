@@ -20,6 +20,12 @@ def set_train_form(form: int):
     _lib.check(_lib.lib().ecgb_set_bpe_train_form(int(form)))
 
 
+def set_train_fused(on: bool = True):
+    """Tests and tuning (forms 0 / 1): the next merge's row maxima inside the merge's launch (one launch per merge; measured 2 % slower than the default, a launch of their
+    own -- EXPERIMENTS.md R6); see ecgb_set_bpe_train_fused.  set_train_fused(False) restores the default."""
+    _lib.check(_lib.lib().ecgb_set_bpe_train_fused(int(bool(on))))
+
+
 def bpe_train_device(text: torch.Tensor, num_merges: int):
     """text: CUDA uint8 1-D tensor.  Returns device tensors (ids int32[n], n_ids int64[1],
     pairs int32[num_merges, 2], n_done int32[1]); nothing is synchronised."""

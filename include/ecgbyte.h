@@ -170,6 +170,12 @@ int ecgb_set_bpe_train_grid(int workgroups);
  * ONE pass over the ids per merge, ids 16 bits wide while 256 + num_merges <= 65 536; 1: the same with 32-bit ids; 2: round 4's count pass + rewrite over a globally
  * compacted buffer (two passes; what the sharded form runs).  Every value gives the same merges and ids.  Process-wide.  ECGB_ERR_INVALID outside 0 .. 2. */
 int ecgb_set_bpe_train_form(int form);
+/* Tests and tuning (forms 0 / 1): 0 (default) = the arg-max's row maxima are a launch of their own between two merges (round 5); 1 = those of merge i + 1 run inside merge
+ * i's launch (its first workgroups, once every workgroup of the launch has flagged that its count deltas are in the table) -- ONE launch per merge (lib.rs:85-110: pick the
+ * pair, merge).  The same merges and ids.  Measured on the C2 corpus (EXPERIMENTS.md R6): 30.2 us a merge against 29.5 -- the meeting inside the launch (a flag store, a poll
+ * and table reads that all have to go past the XCD's L2) costs what the launch boundary did, so it is not the default.  Taken only while the merge launch has at most one
+ * workgroup a CU (its workgroups wait for each other).  Process-wide. */
+int ecgb_set_bpe_train_fused(int on);
 
 /* ---- tokenizer training on a corpus sharded over ranks (one process per GPU) ---------------------------
  * The reference trains on ONE string, the concatenation of every sampled record (tokenizer_utils.py:79-93), so pairs -- and merges --

@@ -22,6 +22,7 @@ while time.time() - t0 < budget:
     k = int(rng.choice([1, 2, 5, 30, 200]))
     trainer.set_train_grid(int(rng.choice([0, 0, 1, 2, 3, 7, 64])))      # few workgroups: ranges of many tiles, the chains carried across tiles and ranges
     trainer.set_train_form(int(rng.choice([0, 0, 1, 2])))                 # slotted ranges with 16-bit ids (the default), with 32-bit ids, round 4's two passes
+    trainer.set_train_fused(bool(rng.integers(2)))                         # the next merge's row maxima inside the merge's launch, or a launch of their own
     ids, vocab, merges = rust_bpe.byte_pair_encoding(text, k, 2)
     oids, ovocab, omerges = O.byte_pair_encoding(text, k, fast=True)
     if list(ids) != list(oids) or merges != omerges or vocab != ovocab:
@@ -30,5 +31,5 @@ while time.time() - t0 < budget:
         open("gpurun_out/fuzz_trainer_text.txt", "w").write(text)
         raise SystemExit(1)
     cases += 1
-trainer.set_train_grid(0); trainer.set_train_form(0)
+trainer.set_train_grid(0); trainer.set_train_form(0); trainer.set_train_fused(False)
 print(f"trainer fuzz ok: {cases} corpora in {time.time() - t0:.0f} s")

@@ -10,17 +10,20 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-@pytest.fixture(autouse=True, params=[0, 1, 2], ids=["slotted16", "slotted32", "two_pass"])
+@pytest.fixture(autouse=True, params=[0, 1, 2, 3], ids=["slotted16", "slotted32", "two_pass", "slotted16_one_launch"])
 def train_form(request):
-    """Every test of the file under the three merge steps of ecgb_bpe_train_hip (ecgb_set_bpe_train_form): ranges in fixed slots with one pass per merge and 16-bit
-    ids (the default), the same with 32-bit ids, round 4's count pass + rewrite.  The sharded form has its own kernels: once."""
+    """Every test of the file under the merge steps of ecgb_bpe_train_hip (ecgb_set_bpe_train_form / _fused): ranges in fixed slots with one pass per merge and 16-bit ids
+    (the default), the same with 32-bit ids, round 4's count pass + rewrite, and the default form with the next merge's row maxima inside the merge's launch (round 6: ONE
+    launch per merge; built, merge-for-merge the same, 2 % slower -- not the default).  The sharded form has its own kernels: once."""
     from ecg_byte_amd import trainer
     name = request.node.name
     if request.param and ("sharded" in name or "kept_row_maxima" in name):
         pytest.skip("does not go through ecgb_bpe_train_hip's merge step")
-    trainer.set_train_form(request.param)
+    trainer.set_train_form(0 if request.param == 3 else request.param)
+    trainer.set_train_fused(request.param == 3)
     yield request.param
     trainer.set_train_form(0)
+    trainer.set_train_fused(False)
 
 
 def _train(text, num_merges):
