@@ -16,401 +16,10 @@
 // (h = lane >> 5), and the transposed LDS tile is read in that same k order (two 8-byte reads).
 // The backward kernels reuse the scheme with the roles permuted (lanes = queries for dQ, lanes = keys
 // for dK/dV, which loops over the query heads of its KV group, so no atomics anywhere).
-#include <hip/hip_runtime.h>
-
-#include <string>
-#include <type_traits>
-
-#include "tokenizer.hpp"
+#include "attention_common.inc"
 
 namespace {
 
-using bf16x8 = __attribute__((ext_vector_type(8))) short;
-using bf16x4 = __attribute__((ext_vector_type(4))) short;
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-constexpr float kLog2e = 1.4426950408889634f;
-// 2^x as one v_exp_f32 (results below 2^-126 flush to zero, which a softmax weight may)
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-// max(a, b, c) as ONE instruction: fmaxf on MFMA results costs a canonicalising v_max per operand on top.  The caller orders it behind
-// the MFMAs that produce its operands (see attn_fwd_kernel).
-__device__ __forceinline__ float max3(float a, float b, float c)
-{
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
-
-struct AttnArgs {
-    const unsigned short *q, *k, *v;      // [B*S rows]; row strides ldq/ldk/ldv; head hq at q + hq*D, kv head g at k + g*D
-    long long ldq, ldk, ldv;
-    const float *mask;                    // [B, S]
-    unsigned short *o;                    // forward output / (backward) forward output, row stride ldo
-    long long ldo;
-    float *lse;                           // [B, Hq, S]  (log2 domain, scale folded in; +inf for rows without keys)
-    const unsigned short *d_o;            // backward: dO, row stride ldo
-    float *delta;                         // [B, Hq, S]  rowsum(dO * O)
-    unsigned short *dq, *dk, *dv;         // backward outputs, row strides lddq / lddk / lddv
-    long long lddq, lddk, lddv;
-    int B, S, Hq, Hkv;
-    float scale;
-    // dK/dV with the query heads of a KV group split over `head_splits` workgroups (few key blocks, one KV head: Gemma): split h writes its
-    // fp32 partial sums to slab [which (0 = dK, 1 = dV)][h][B * S][D]; attn_dkv_reduce_kernel adds the slabs in order
-    float *slab;
-    int head_splits;
-    int lean_hw_log2;                     // lean forward / dQ kernels: log2 of the query heads of a KV group that share a workgroup's K / V tiles
-    const float *rope_cos, *rope_sin;     // lean backward kernels, optional ([B * S, 32] fp32): dQ and dK leave with RoPE's inverse rotation applied (store_accT_rope_inv)
-};
-
-#ifdef ECGB_PROFILE
-// dev builds only (`make prof`, scripts/dev_prof_attn.py): cycles per phase of the forward loop, summed over waves
-__device__ unsigned long long g_attn_prof[64];   // [wave of the workgroup (up to 8)][phase]
-#define APROF(k) do { const long long t_now = clock64(); prof_acc[k] += (unsigned long long)(t_now - t_prof); t_prof = clock64(); } while (0)
-#else
-#define APROF(k) do { } while (0)
-#endif
-
-// ---- workgroup -> (block, head, batch) ------------------------------------------------------------------------------------------
-// Under the causal mask the work of a block grows with its index (query blocks) or shrinks with it (key blocks), and the hardware deals
-// consecutive workgroups to the 8 XCDs in turn: with the block index as blockIdx.x and 8 blocks per head (S = 1024), XCD k ran block k of
-// EVERY head -- XCD 7 had 16 K/V tiles per workgroup, XCD 0 two, and the kernel took as long as XCD 7 (1.8 x the balanced time; the
-// counters showed 1.1 resident waves per SIMD where 2 fit).  The grids are 1-D now:
-//   * (batch, KV head) groups a multiple of 8: group -> XCD group % 8, so a group's K and V stay in ONE L2; inside the XCD the groups run
-//     one after the other, each with its heaviest blocks first;
-//   * otherwise: the block index is rotated by the head index, so every XCD still sees every block size.
-// n_blk blocks, `heads` workgroups per block and group (the query heads of the group for forward / dQ, 1 for dK/dV, whose workgroups
-// loop over the heads themselves).
-__device__ __forceinline__ void map_block(int L, int n_blk, int heads, int n_groups, bool heavy_last, int &blk, int &head_in, int &group)
-{
-    const int per_group = n_blk * heads;
-    if ((n_groups & 7) == 0) {
-        const int xcd = L & 7, j = L >> 3;
-        group = (j / per_group) * 8 + xcd;
-        const int inner = j % per_group, rank = inner / heads;
-        head_in = inner % heads;
-        blk = heavy_last ? n_blk - 1 - rank : rank;
-    } else {
-        const int hl = L / n_blk, r = L % n_blk;
-        blk = (r + hl) % n_blk;
-        group = hl / heads;
-        head_in = hl % heads;
-    }
-}
-
-// ---- LDS tile helpers (tiles of 64 rows x D) -----------------------------------------------------------
-// Staging work item = 4 consecutive rows x one 16-byte chunk (8 d): 16 row groups x D/8 chunks per tile, i.e.
-// 128 items for D = 64 -- threads 0..127 take one tile, 128..255 another.  The four 16-byte global loads of an
-// item are issued back to back into registers (`Stage4`), one tile AHEAD of its use, and written to LDS
-// after the barrier that retires the previous tile: plain image (row r at r*D*2 bytes, 16-byte slot c at
-// c ^ ((r >> 1) & 7)) and/or transposed image ([D][64]: row d at d*128 bytes, the 8-byte slot holding rows
-// 4*rg..4*rg+3 at rg ^ (d & 15)).
-struct Stage4 { bf16x8 v[4]; int nvalid; };   // nvalid: rows of the tile that exist (the others are zeroed when written to LDS)
-
-template <int D>
-__device__ __forceinline__ void stage_load(Stage4 &st, const unsigned short *g, long long ld, int row0, int rows_valid, int item)
-{
-    const int rg = item % 16, c = item / 16;
-    // branch-free and unconditional: a conditional load is a basic block of its own and hipcc waits for it (vmcnt 0) before
-    // the next one; zeroing the out-of-range rows HERE would make the wait land right behind the loads.  Out-of-range rows
-    // read the last valid row; stage_write_* zeroes them.
-    st.nvalid = rows_valid - row0;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int r = row0 + rg * 4 + t;
-        st.v[t] = *reinterpret_cast<const bf16x8 *>(g + (long long)min(r, rows_valid - 1) * ld + c * 8);
-    }
-}
-template <int D>
-__device__ __forceinline__ void stage_write_plain(unsigned char *lds, const Stage4 &st, int item)
-{
-    const int rg = item % 16, c = item / 16;
-    if (st.nvalid >= 64) {            // (uniform) nothing to zero
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int r = rg * 4 + t;
-            *reinterpret_cast<bf16x8 *>(lds + r * (D * 2) + ((c ^ ((r >> 1) & 7)) << 4)) = st.v[t];
-        }
-        return;
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int r = rg * 4 + t;
-        *reinterpret_cast<bf16x8 *>(lds + r * (D * 2) + ((c ^ ((r >> 1) & 7)) << 4)) = (r < st.nvalid) ? st.v[t] : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    }
-}
-__device__ __forceinline__ void stage_write_transposed(unsigned char *lds, const Stage4 &st, int item)
-{
-    const int rg = item % 16, c = item / 16;
-    const bool whole = st.nvalid >= 64;        // (uniform) nothing to zero
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int d = c * 8 + j;
-        bf16x4 w;
-        w[0] = st.v[0][j]; w[1] = st.v[1][j]; w[2] = st.v[2][j]; w[3] = st.v[3][j];
-        if (!whole) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) if (rg * 4 + t >= st.nvalid) w[t] = 0;
-        }
-        *reinterpret_cast<bf16x4 *>(lds + d * 128 + ((rg ^ (d & 15)) << 3)) = w;
-    }
-}
-// A-operand fragment of a plain tile: row r, k = 16*ks + 8*h .. +7
-template <int D>
-__device__ __forceinline__ bf16x8 frag_plain(const unsigned char *lds, int r, int ks, int h)
-{
-    const int c = ks * 2 + h;
-    return *reinterpret_cast<const bf16x8 *>(lds + r * (D * 2) + ((c ^ ((r >> 1) & 7)) << 4));
-}
-// A-operand fragment of a transposed tile for accumulator-order k: row d, block kb (32 rows), k-step s (16 rows):
-// elements 0..3 = rows kb*32 + 16s + 4h + 0..3, elements 4..7 = rows kb*32 + 16s + 8 + 4h + 0..3
-__device__ __forceinline__ bf16x8 frag_transposed(const unsigned char *lds, int d, int kb, int s, int h)
-{
-    const int r0 = kb * 32 + 16 * s + 4 * h;
-    const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(lds + d * 128 + ((((r0 >> 2) ^ (d & 15))) << 3));
-    const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(lds + d * 128 + (((((r0 + 8) >> 2) ^ (d & 15))) << 3));
-    bf16x8 f;
-    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-    return f;
-}
-// ---- LDS-DMA staging of the backward kernels (head_dim 64) ---------------------------------------------------------------------------
-// A tile of 64 rows x 128 bytes lands as it lies in memory, 16-byte chunk c of row r at c ^ u(r), u(r) = bit 1 of r << 2 | bits 2-3 of r: one image
-// serves BOTH kinds of read conflict-free -- the row fragments (ds_read_b128: the 8 row pairs 16 lanes address land on 8 different chunk positions, u
-// is a bijection of bits 1-3 of r) and the transposing reads (ds_read_b64_tr_b16: the 4 rows x 64 bytes 32 lanes address cover rows 0,1 in one
-// 64-byte half of the row and rows 2,3 in the other).  The swizzle is applied on the global address of the DMA (its LDS side is lane-linear).
-__device__ __forceinline__ int swz_u(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
-__device__ __forceinline__ bf16x8 frag_plain_u(const unsigned char *lds, int r, int ks, int h)
-{
-    return *reinterpret_cast<const bf16x8 *>(lds + r * 128 + (((ks * 2 + h) ^ swz_u(r)) << 4));
-}
-// Inline-asm LDS reads next to LDS-DMA (a read hipcc can see there gets a vmcnt(0) in front of it: every tile in flight drained).  hipcc neither counts
-// such reads in lgkmcnt nor knows their results are pending: it may copy a destination register the moment the asm statement is over (and it did --
-// v_mov of registers still in flight, stale data on a busy chip), and passing the registers through a later wait statement does not help: the
-// copy is made BEFORE that statement.  So a group of reads and its wait are ONE asm statement, and the results exist when it ends.  Placed right
-// behind the issue of a tile's first MFMAs, the wait runs under them.
-using i2v = __attribute__((ext_vector_type(2))) int;
-using i4v = __attribute__((ext_vector_type(4))) int;
-using f4v = __attribute__((ext_vector_type(4))) float;
-// the four transposed fragments f[s2][db] (rows = d 32 db .., k = 32 tile rows in accumulator order) of one half of a tile image: (a0, b0) / (a1, b1)
-// are the lane's first / second read address for db = 0 / 1, OFF0 / OFF1 the byte offsets of the s2 = 0 / 1 row groups
-template <int OFF0, int OFF1>
-__device__ __forceinline__ void tr_frags4_wait(bf16x8 (&f)[2][2], unsigned a0, unsigned b0, unsigned a1, unsigned b1)
-{
-    i2v r0, r1, r2, r3, r4, r5, r6, r7;
-    asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
-                 "ds_read_b64_tr_b16 %1, %9 offset:%12\n\t"
-                 "ds_read_b64_tr_b16 %2, %10 offset:%12\n\t"
-                 "ds_read_b64_tr_b16 %3, %11 offset:%12\n\t"
-                 "ds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
-                 "ds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
-                 "ds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
-                 "ds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
-                 : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "n"(OFF0), "n"(OFF1)
-                 : "memory");
-    f[0][0] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(r0, r1, 0, 1, 2, 3));
-    f[0][1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(r2, r3, 0, 1, 2, 3));
-    f[1][0] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(r4, r5, 0, 1, 2, 3));
-    f[1][1] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(r6, r7, 0, 1, 2, 3));
-}
-// four 16-byte reads 32 bytes apart (a lane's four runs of four keys / queries in a row of floats), from byte offset OFF
-template <int OFF>
-__device__ __forceinline__ void lds_rows4_wait(f4v (&m)[4], unsigned a)
-{
-    asm volatile("ds_read_b128 %0, %4 offset:%5\n\t"
-                 "ds_read_b128 %1, %4 offset:%6\n\t"
-                 "ds_read_b128 %2, %4 offset:%7\n\t"
-                 "ds_read_b128 %3, %4 offset:%8\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3])
-                 : "v"(a), "n"(OFF), "n"(OFF + 32), "n"(OFF + 64), "n"(OFF + 96)
-                 : "memory");
-}
-// four row fragments -- two lane addresses x two byte offsets -- and their wait as one statement (see above); issued right behind a group of MFMAs, the
-// wait runs under them.  (Compiler-visible ds_read_b128 are issued one pair at a time just ahead of the MFMAs that use them: every pair then exposes an
-// LDS round trip -- ~650 cycles for the eight MFMAs of a score product instead of 256.)
-template <int OFF0, int OFF1>
-__device__ __forceinline__ void lds_frags2x2_wait(bf16x8 &f00, bf16x8 &f01, bf16x8 &f10, bf16x8 &f11, unsigned a0, unsigned a1)
-{
-    i4v r0, r1, r2, r3;
-    asm volatile("ds_read_b128 %0, %4 offset:%6\n\t"
-                 "ds_read_b128 %1, %4 offset:%7\n\t"
-                 "ds_read_b128 %2, %5 offset:%6\n\t"
-                 "ds_read_b128 %3, %5 offset:%7\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-                 : "v"(a0), "v"(a1), "n"(OFF0), "n"(OFF1)
-                 : "memory");
-    f00 = __builtin_bit_cast(bf16x8, r0); f01 = __builtin_bit_cast(bf16x8, r1);
-    f10 = __builtin_bit_cast(bf16x8, r2); f11 = __builtin_bit_cast(bf16x8, r3);
-}
-// the dK/dV kernel's reads in front of a query half's first products -- the lane's lse and delta runs (2 x four 16-byte reads 32 bytes apart, from byte offsets
-// SOFF and SOFF + 256 of the statistics) and the first batch of row fragments (two lane addresses x two byte offsets) -- as ONE statement with one wait: apart they
-// were three LDS round trips in a row (~150 cycles each) before the first MFMA of every query half could issue
-template <int SOFF, int OFF0, int OFF1>
-__device__ __forceinline__ void lds_stats_frags_wait(f4v (&m0)[4], f4v (&m1)[4], bf16x8 &f00, bf16x8 &f01, bf16x8 &f10, bf16x8 &f11, unsigned sa, unsigned a0, unsigned a1)
-{
-    i4v r0, r1, r2, r3;
-    asm volatile("ds_read_b128 %0, %12 offset:%15\n\t"
-                 "ds_read_b128 %1, %12 offset:%16\n\t"
-                 "ds_read_b128 %2, %12 offset:%17\n\t"
-                 "ds_read_b128 %3, %12 offset:%18\n\t"
-                 "ds_read_b128 %4, %12 offset:%19\n\t"
-                 "ds_read_b128 %5, %12 offset:%20\n\t"
-                 "ds_read_b128 %6, %12 offset:%21\n\t"
-                 "ds_read_b128 %7, %12 offset:%22\n\t"
-                 "ds_read_b128 %8, %13 offset:%23\n\t"
-                 "ds_read_b128 %9, %13 offset:%24\n\t"
-                 "ds_read_b128 %10, %14 offset:%23\n\t"
-                 "ds_read_b128 %11, %14 offset:%24\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(m0[0]), "=&v"(m0[1]), "=&v"(m0[2]), "=&v"(m0[3]), "=&v"(m1[0]), "=&v"(m1[1]), "=&v"(m1[2]), "=&v"(m1[3]),
-                   "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-                 : "v"(sa), "v"(a0), "v"(a1), "n"(SOFF), "n"(SOFF + 32), "n"(SOFF + 64), "n"(SOFF + 96), "n"(SOFF + 256), "n"(SOFF + 256 + 32), "n"(SOFF + 256 + 64),
-                   "n"(SOFF + 256 + 96), "n"(OFF0), "n"(OFF1)
-                 : "memory");
-    f00 = __builtin_bit_cast(bf16x8, r0); f01 = __builtin_bit_cast(bf16x8, r1);
-    f10 = __builtin_bit_cast(bf16x8, r2); f11 = __builtin_bit_cast(bf16x8, r3);
-}
-// byte offset inside a tile image of this lane's transposing read for fragment (db, kb = 0, s2 = 0): row_add = 0 for the first read, 8 for the second
-// (bit 3 of the row enters u, so the two are computed separately); the other (kb, s2) are 32 kb + 16 s2 rows further down, which leaves u alone: they go
-// into the instruction's offset field
-__device__ __forceinline__ unsigned tr_off_u(int db, int lr, int h, int row_add)
-{
-    const int a = lr >> 4, q = (lr & 15) >> 2, p = lr & 3;
-    const int key = 4 * h + q + row_add;
-    const int chunk = db * 4 + 2 * a + (p >> 1);
-    return (unsigned)(key * 128 + ((chunk ^ swz_u(key)) << 4) + (p & 1) * 8);
-}
-// two fp32 -> packed bf16 pair, one v_cvt_pk_bf16_f32 (round to nearest even)
-using bf2_t = __attribute__((ext_vector_type(2))) __bf16;
-__device__ __forceinline__ unsigned pack_bf16(float a, float b)
-{
-    bf2_t v;
-    v[0] = (__bf16)a; v[1] = (__bf16)b;
-    return __builtin_bit_cast(unsigned, v);
-}
-// B-operand fragment made from accumulator registers 8s..8s+7
-__device__ __forceinline__ bf16x8 frag_from_acc(const float *p8)
-{
-    using u4 = __attribute__((ext_vector_type(4))) unsigned;
-    u4 w;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = pack_bf16(p8[2 * j], p8[2 * j + 1]);
-    return __builtin_bit_cast(bf16x8, w);
-}
-// row-operand fragments held in registers: row `row` of a global matrix, k = 16*ks + 8*h .. +7
-template <int D>
-__device__ __forceinline__ void load_row_frags(bf16x8 (&f)[D / 16], const unsigned short *g, long long ld, long long row, bool valid, int h)
-{
-#pragma unroll
-    for (int ks = 0; ks < D / 16; ++ks) {
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (valid) v = *reinterpret_cast<const bf16x8 *>(g + row * ld + ks * 16 + h * 8);
-        f[ks] = v;
-    }
-}
-// accumulator (lane = row index, registers = d) -> global [row][d]: 4 consecutive d per register group
-// 16-byte stores: a row's 8 consecutive columns are split over the two half-waves (lane i: columns 8 k .. + 3, lane i + 32: + 4 .. + 7); one
-// v_permlane32_swap per dword on the register pair of column groups (2 k, 2 k + 1) leaves lane i with group 2 k whole and lane i + 32 with group
-// 2 k + 1 whole -- half the store instructions for the same bytes (the store tail is issue-bound: cdna_hip_programming.md T21).
-template <int NB>
-__device__ __forceinline__ void store_accT(const f32x16 (&acc)[NB], unsigned short *g, long long ld, long long row, bool valid, int h, float mul)
-{
-    if (!valid) return;
-    if ((ld & 7) == 0 && ((size_t)g & 15) == 0) {            // (uniform)
-        using u4 = __attribute__((ext_vector_type(4))) unsigned;
-#pragma unroll
-        for (int db = 0; db < NB; ++db)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                unsigned a0 = pack_bf16(acc[db][8 * k + 0] * mul, acc[db][8 * k + 1] * mul), a1 = pack_bf16(acc[db][8 * k + 2] * mul, acc[db][8 * k + 3] * mul);
-                unsigned b0 = pack_bf16(acc[db][8 * k + 4] * mul, acc[db][8 * k + 5] * mul), b1 = pack_bf16(acc[db][8 * k + 6] * mul, acc[db][8 * k + 7] * mul);
-                const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                u4 v;
-                v[0] = r0[0]; v[1] = r1[0]; v[2] = r0[1]; v[3] = r1[1];
-                *reinterpret_cast<u4 *>(g + row * ld + db * 32 + 16 * k + 8 * h) = v;
-            }
-        return;
-    }
-#pragma unroll
-    for (int db = 0; db < NB; ++db)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            using u2 = __attribute__((ext_vector_type(2))) unsigned;
-            u2 v;
-            v[0] = pack_bf16(acc[db][gq * 4 + 0] * mul, acc[db][gq * 4 + 1] * mul);
-            v[1] = pack_bf16(acc[db][gq * 4 + 2] * mul, acc[db][gq * 4 + 3] * mul);
-            *reinterpret_cast<u2 *>(g + row * ld + db * 32 + gq * 8 + 4 * h) = v;
-        }
-}
-
-// store_accT<2> with RoPE's backward folded in (head_dim 64: the gradient with respect to the UNROTATED q / k).  The separate pass (ecgb_rope inverse, in place on d_qkv)
-// reads the bf16 gradient back, rotates in fp32 with cos / sin rounded to bf16 and rounds once more: exactly that happens here on the packed values before they
-// leave -- the same bits, one read and one write of the q|k gradient less (1.0 ms of a C3 step).  After the group swap a lane holds columns 16 k + 8 h + j of both
-// 32-column halves: the pairs (d, d + 32) a rotation mixes are in one lane.  cs / sn: this row's 32 cosines / sines.
-__device__ __forceinline__ void store_accT_rope_inv(const f32x16 (&acc)[2], unsigned short *g, long long ld, long long row, bool valid, int h, float mul,
-                                                    const float *cs, const float *sn)
-{
-    if (!valid) return;
-    using u4 = __attribute__((ext_vector_type(4))) unsigned;
-    using f4 = __attribute__((ext_vector_type(4))) float;
-    auto lo_f = [](unsigned x) { return __uint_as_float(x << 16); };
-    auto hi_f = [](unsigned x) { return __uint_as_float(x & 0xFFFF0000u); };
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        u4 v[2];
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            unsigned a0 = pack_bf16(acc[db][8 * k + 0] * mul, acc[db][8 * k + 1] * mul), a1 = pack_bf16(acc[db][8 * k + 2] * mul, acc[db][8 * k + 3] * mul);
-            unsigned b0 = pack_bf16(acc[db][8 * k + 4] * mul, acc[db][8 * k + 5] * mul), b1 = pack_bf16(acc[db][8 * k + 6] * mul, acc[db][8 * k + 7] * mul);
-            const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-            const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-            v[db][0] = r0[0]; v[db][1] = r1[0]; v[db][2] = r0[1]; v[db][3] = r1[1];
-        }
-        const f4 c0 = *reinterpret_cast<const f4 *>(cs + 16 * k + 8 * h), c1 = *reinterpret_cast<const f4 *>(cs + 16 * k + 8 * h + 4);
-        const f4 s0 = *reinterpret_cast<const f4 *>(sn + 16 * k + 8 * h), s1 = *reinterpret_cast<const f4 *>(sn + 16 * k + 8 * h + 4);
-        u4 o1, o2;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float ca = w < 2 ? c0[2 * w] : c1[2 * w - 4], cb = w < 2 ? c0[2 * w + 1] : c1[2 * w - 3];
-            const float sa = w < 2 ? s0[2 * w] : s1[2 * w - 4], sb = w < 2 ? s0[2 * w + 1] : s1[2 * w - 3];
-            const unsigned cc = pack_bf16(ca, cb), ss = pack_bf16(sa, sb);          // HF holds cos / sin in the activation dtype
-            const float x1a = lo_f(v[0][w]), x1b = hi_f(v[0][w]), x2a = lo_f(v[1][w]), x2b = hi_f(v[1][w]);
-            o1[w] = pack_bf16(x1a * lo_f(cc) + x2a * lo_f(ss), x1b * hi_f(cc) + x2b * hi_f(ss));
-            o2[w] = pack_bf16(x2a * lo_f(cc) - x1a * lo_f(ss), x2b * hi_f(cc) - x1b * hi_f(ss));
-        }
-        *reinterpret_cast<u4 *>(g + row * ld + 16 * k + 8 * h) = o1;
-        *reinterpret_cast<u4 *>(g + row * ld + 32 + 16 * k + 8 * h) = o2;
-    }
-}
-
-// the same into a contiguous fp32 [row][D] slab
-template <int NB>
-__device__ __forceinline__ void store_accT_f32(const f32x16 (&acc)[NB], float *g, long long ld, long long row, bool valid, int h)
-{
-    if (!valid) return;
-#pragma unroll
-    for (int db = 0; db < NB; ++db)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            using f4 = __attribute__((ext_vector_type(4))) float;
-            f4 v;
-            v[0] = acc[db][gq * 4 + 0]; v[1] = acc[db][gq * 4 + 1]; v[2] = acc[db][gq * 4 + 2]; v[3] = acc[db][gq * 4 + 3];
-            *reinterpret_cast<f4 *>(g + row * ld + db * 32 + gq * 8 + 4 * h) = v;
-        }
-}
-
-// =====================================================================================================
-// forward: 1-D grid of ceil(S/128) x Hq x B workgroups, dealt by map_block()
-// DMA (head_dim 64): K and V tiles go global -> LDS by LDS-DMA (global_load_lds, no register round trip, no LDS write instructions), two
-// tiles ahead into a ring of three buffers; V stays as it lies in memory ([key][d], 16-byte chunk c of key row r at c ^ 4 ((r >> 1) & 1)) and
-// the P.V operand (V^T rows in accumulator order) is gathered by transposing LDS reads.  The register-staged form spent 60 % of a wave's
-// time per tile issuing loads, waiting for them and writing both images (scripts/dev_prof_attn.py).
 template <int D, bool DMA = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs A)
 {
@@ -1177,13 +786,6 @@ __device__ __forceinline__ void negate_row_frags(bf16x8 (&f)[4])
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) f[ks] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u4, f[ks]) ^ 0x80008000u);
 }
-__device__ __forceinline__ f32x16 splat16(float v)
-{
-    f32x16 r;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r[i] = v;
-    return r;
-}
 
 #ifndef ECGB_LEAN_DIAG
 #define ECGB_LEAN_DIAG 0      // timing-only diagnostics of the forward kernel (wrong results): 1 no tile DMA in the loop, 2 no barrier, 4 no exp, 8 two of the eight P.V MFMAs, 16 four of the eight Q.K MFMAs, 32 no row sum
@@ -1208,28 +810,6 @@ __device__ __forceinline__ f32x16 splat16(float v)
 constexpr int kLeanRing = 3;      // LDS ring depth of the lean kernels: tiles (kRing - 1) ahead (4 measured the same as 3: the flight time is not what a wave waits for)
 template <int N> __device__ __forceinline__ void lean_wait_tiles() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-// The batch row's key mask goes to LDS once per workgroup (floats, as the kernels read it); beside it one flag per 64-key tile: does the tile hold a padded (or
-// out-of-range) key?  A wave's 64 lanes fill exactly one tile per pass, so the flag is that pass's ballot.  After the barrier lean_pad_bits() gathers the first 64
-// flags into a scalar bit mask and a trip asks it instead of probing the tile's mask words (a blocking LDS round trip at the top of every trip).  Tiles past the
-// 64th (sequences over 4 096 keys) count as padded: they take the exact path, which is always right.
-template <int NW>
-__device__ __forceinline__ void lean_fill_mask(float *lds_maskrow, const float *mask_row, int S, int padded)
-{
-    unsigned *flags = reinterpret_cast<unsigned *>(lds_maskrow + padded);
-    for (int i = threadIdx.x; i < padded; i += NW * 64) {
-        const float v = (i < S) ? mask_row[i] : 0.f;
-        lds_maskrow[i] = v;
-        const bool z = __any(v == 0.f);
-        if ((threadIdx.x & 63) == 0 && (i >> 6) < 64) flags[i >> 6] = z ? 1u : 0u;
-    }
-}
-__device__ __forceinline__ unsigned long long lean_pad_bits(const float *lds_maskrow, int padded)
-{
-    const unsigned *flags = reinterpret_cast<const unsigned *>(lds_maskrow + padded);
-    const int n = min(padded >> 6, 64), lane = threadIdx.x & 63;
-    return __ballot(lane < n && flags[min(lane, n - 1)] != 0u);
-}
-__device__ __forceinline__ bool lean_tile_padded(unsigned long long padbits, int tile) { return tile >= 64 || ((padbits >> tile) & 1ull) != 0ull; }
 
 // NW waves per workgroup (4 or 8) share every K / V tile.  Measured with the phase timers (scripts/dev_prof_attn.py, 4 waves x 32 rows, two workgroups per CU):
 // 2 030 of a tile's 4 700 cycles went into ISSUING its four LDS-DMA pieces -- the vector memory path of a CU takes about 16 bytes per cycle, 32 KB per pair of
@@ -2523,158 +2103,9 @@ __global__ __launch_bounds__(256) void attn_fwd_d256_kernel(AttnArgs A)
     if (qvalid && h == 0) A.lse[((long long)b * A.Hq + hq) * A.S + qi] = lt > 0.f ? m + log2f(lt) : INFINITY;
 }
 
-// head_dim 256 dQ with LDS-DMA staging (round 4): the register-staged kernel writes three images per tile (K as rows, K transposed, V as rows) between two
-// barriers.  Here K and V land once each, as they lie in memory, in a two-stage ring; ONE swizzle serves the row fragments of both (S = K . Q^T, dP = V . dO^T) and the
-// transposing reads of K (dQ += dS . K): 16-byte chunk c of row r lies at c ^ f(r), f(r) = (r & 3) << 2 | (r >> 2) & 3 -- sixteen consecutive rows put one chunk on sixteen
-// different bank groups (f is a bijection of the row's low four bits), and the eight key rows of a transposing read put one 64-byte group on all four 64-byte positions of
-// the bank cycle, twice each (the group index moves with r & 3).  attn_bwd_dq_kernel's arithmetic in its order: the same bits.
-__device__ __forceinline__ int swz_f256(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
-__global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
-{
-    constexpr int D = 256, kRow = D * 2, kTile = 64 * kRow, PPW = 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x (K, V) tiles, the row's key mask, 64 tile flags
-    float *lds_maskrow = reinterpret_cast<float *>(smem + 4 * kTile);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
-    int qblk, head_in, group;
-    map_block((int)blockIdx.x, (A.S + 127) / 128, A.Hq / A.Hkv, A.B * A.Hkv, true, qblk, head_in, group);
-    const int b = group / A.Hkv, g = group % A.Hkv, hq = g * (A.Hq / A.Hkv) + head_in;
-    const int q0 = qblk * 128, qw0 = q0 + wave * 32;
-    const int qi = qw0 + lr;
-    const bool qvalid = qi < A.S;
-    const long long rowbase = (long long)b * A.S;
-    const unsigned short *Q = A.q + (long long)hq * D, *K = A.k + (long long)g * D, *V = A.v + (long long)g * D;
-    const int k_end = min(A.S, q0 + 128);
-    const int wave_qmax = qw0 + 31;
-    const int last_tile = (k_end - 1) / 64;
-    const int tail_rows = A.S - last_tile * 64;
-    unsigned offK[PPW], offV[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int r = (wave * PPW + i) * 2 + (lane >> 5), slot = lane & 31;
-        offK[i] = (unsigned)(((long long)r * A.ldk + (slot ^ swz_f256(r)) * 8) * 2);
-        offV[i] = (unsigned)(((long long)r * A.ldv + (slot ^ swz_f256(r)) * 8) * 2);
-    }
-    const unsigned char *kb_next = reinterpret_cast<const unsigned char *>(K + rowbase * A.ldk), *vb_next = reinterpret_cast<const unsigned char *>(V + rowbase * A.ldv);
-    const long long stepK = 128ll * A.ldk, stepV = 128ll * A.ldv;
-    int t_next = 0;
-    unsigned slot_next = 0;
-    auto issue_next = [&]() {                                             // (see attn_fwd_d256_kernel)
-        if (t_next == last_tile && tail_rows < 64) {
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                const int r = (wave * PPW + i) * 2 + (lane >> 5), slot = lane & 31, rt = min(r, tail_rows - 1);
-                const unsigned ok = (unsigned)(((long long)rt * A.ldk + (slot ^ swz_f256(r)) * 8) * 2), ov = (unsigned)(((long long)rt * A.ldv + (slot ^ swz_f256(r)) * 8) * 2);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb_next + ok),
-                                                 (__attribute__((address_space(3))) void *)(smem + slot_next + (wave * PPW + i) * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb_next + ov),
-                                                 (__attribute__((address_space(3))) void *)(smem + slot_next + kTile + (wave * PPW + i) * 1024), 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kb_next + offK[i]),
-                                                 (__attribute__((address_space(3))) void *)(smem + slot_next + (wave * PPW + i) * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vb_next + offV[i]),
-                                                 (__attribute__((address_space(3))) void *)(smem + slot_next + kTile + (wave * PPW + i) * 1024), 16, 0, 0);
-            }
-        }
-        if (t_next < last_tile) { ++t_next; kb_next += stepK; vb_next += stepV; }
-        slot_next ^= 2 * kTile;
-    };
-    issue_next();
-    bf16x8 qf[D / 16], dof[D / 16];
-    float delta = 0.f;
-    {
-        bf16x8 of[D / 16];
-        load_row_frags<D>(qf, Q, A.ldq, rowbase + qi, qvalid, h);
-        load_row_frags<D>(dof, A.d_o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h);
-        load_row_frags<D>(of, A.o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h);
-#pragma unroll
-        for (int ks = 0; ks < D / 16; ++ks)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) delta += bf2f((unsigned short)dof[ks][j]) * bf2f((unsigned short)of[ks][j]);
-    }
-    delta += __shfl_xor(delta, 32, 64);
-    const long long stat = ((long long)b * A.Hq + hq) * A.S + qi;
-    if (qvalid && h == 0) A.delta[stat] = delta;
-    const float lse = qvalid ? A.lse[stat] : INFINITY;
-    f32x16 accQ[D / 32];
-#pragma unroll
-    for (int db = 0; db < D / 32; ++db) accQ[db] = splat16(0.f);
-    const float sc = A.scale * kLog2e;
-    lean_fill_mask<4>(lds_maskrow, A.mask + rowbase, A.S, (k_end + 63) & ~63);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // tile 0 and the row operands
-    __syncthreads();
-    const unsigned long long padbits = lean_pad_bits(lds_maskrow, (k_end + 63) & ~63);
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    // this lane's row fragment (row lr, k-step 0) inside an image, as an offset: k-step ks is the offset ^ (ks << 5); row 32 + lr 16 KiB further; the V image kTile further
-    const unsigned rbase = lr * kRow + ((h ^ swz_f256(lr)) << 4);
-    // this lane's transposing reads inside a K image for d block 0, first (key 4 h + q) and second (8 keys further: f moves with bit 3 of the row): block db is the offset ^ (db << 6)
-    unsigned tbaseA, tbaseB;
-    {
-        const int a = lr >> 4, q = (lr & 15) >> 2, p = lr & 3;
-        const int cg = 2 * a + (p >> 1);                                 // 16-byte chunk inside the 64-byte group
-        const int k1 = 4 * h + q, k2 = k1 + 8;
-        tbaseA = k1 * kRow + ((((k1 & 3) << 2) | (cg ^ ((k1 >> 2) & 3))) << 4) + (p & 1) * 8;
-        tbaseB = k2 * kRow + ((((k2 & 3) << 2) | (cg ^ ((k2 >> 2) & 3))) << 4) + (p & 1) * 8;
-    }
-    unsigned img = 0;
-    for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
-        issue_next();
-        const float *lds_mask = lds_maskrow + k0;
-        if (k0 <= wave_qmax) {
-            const bool need_mask = (k0 + 63 > qw0) || lean_tile_padded(padbits, it);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                f32x16 s = splat16(0.f), dp = splat16(0.f);
-#pragma unroll
-                for (int ks = 0; ks < D / 16; ks += 2) {                  // K and V fragments of two k-steps (the images side by side, kTile apart) and their four products
-                    bf16x8 kf0, vf0, kf1, vf1;
-                    const unsigned a0 = (rbase ^ (unsigned)(ks << 5)) + img + lds0, a1 = (rbase ^ (unsigned)((ks + 1) << 5)) + img + lds0;
-                    if (kb == 0) lds_frags2x2_wait<0, kTile>(kf0, vf0, kf1, vf1, a0, a1);
-                    else lds_frags2x2_wait<32 * kRow, kTile + 32 * kRow>(kf0, vf0, kf1, vf1, a0, a1);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, dof[ks], dp, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks + 1], s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, dof[ks + 1], dp, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                float ds[16];
-                if (need_mask) {
-                    f4v mv[4];
-                    const unsigned ma = (unsigned)(size_t)(__attribute__((address_space(3))) float *)const_cast<float *>(lds_mask) + 16 * h;
-                    if (kb == 0) lds_rows4_wait<0>(mv, ma); else lds_rows4_wait<128>(mv, ma);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const bool vis = (k0 + kl <= qi) & (mv[r >> 2][r & 3] != 0.f);
-                        const float pr = vis ? fast_exp2(__builtin_fmaf(s[r], sc, -lse)) : 0.f;
-                        ds[r] = pr * (dp[r] - delta) * A.scale;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(__builtin_fmaf(s[r], sc, -lse)) * (dp[r] - delta) * A.scale;
-                }
-                const bf16x8 dsf0 = frag_from_acc(&ds[0]), dsf1 = frag_from_acc(&ds[8]);
-#pragma unroll
-                for (int dpair = 0; dpair < D / 64; ++dpair) {            // pairs of d blocks: four transposed K fragments (two k-steps x two blocks) and their four products
-                    bf16x8 ktf[2][2];
-                    const unsigned x0 = (unsigned)((2 * dpair) << 6), x1 = (unsigned)((2 * dpair + 1) << 6);
-                    if (kb == 0) tr_frags4_wait<0, 16 * kRow>(ktf, (tbaseA ^ x0) + img + lds0, (tbaseB ^ x0) + img + lds0, (tbaseA ^ x1) + img + lds0, (tbaseB ^ x1) + img + lds0);
-                    else tr_frags4_wait<32 * kRow, 48 * kRow>(ktf, (tbaseA ^ x0) + img + lds0, (tbaseB ^ x0) + img + lds0, (tbaseA ^ x1) + img + lds0, (tbaseB ^ x1) + img + lds0);
-                    accQ[2 * dpair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][0], dsf0, accQ[2 * dpair], 0, 0, 0);
-                    accQ[2 * dpair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][1], dsf0, accQ[2 * dpair + 1], 0, 0, 0);
-                    accQ[2 * dpair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][0], dsf1, accQ[2 * dpair], 0, 0, 0);
-                    accQ[2 * dpair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][1], dsf1, accQ[2 * dpair + 1], 0, 0, 0);
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        img ^= 2 * kTile;
-    }
-    store_accT<D / 32>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, 1.f);
-}
+// head_dim 256 dQ: attention_d256.hip (round 6; round 4's LDS-DMA kernel with asm reads is in the history).  The swizzle its images and the dK / dV kernel's share: 16-byte
+// chunk c of row r lies at c ^ f(r), f(r) = (r & 3) << 2 | (r >> 2) & 3 (attention_common.inc) -- sixteen consecutive rows put one chunk on sixteen different bank groups, and
+// the eight key rows of a transposing read put one 64-byte group on all four 64-byte positions of the bank cycle, twice each.
 
 // head_dim 256 dK / dV with LDS-DMA staging (round 4): attn_bwd_dkv_body<256, 1, WHICH> (dV pass: WHICH 1, dK pass: WHICH 2, two workgroups of one launch) with the step's Q and
 // dO tiles and the tile's row statistics landing by LDS-DMA in a two-stage ring, one image per tile read both ways (rows for S / dP, transposing reads for dO^T . P and
@@ -3028,7 +2459,7 @@ int attn_bwd_impl(const void *q_dev, long long ldq, const void *k_dev, long long
     const long long lds256 = 4ll * 64 * 512 + 4ll * ((seq + 63) & ~63) + 256;
     const bool dma256 = (g_attn_dma & 3) && lds256 <= 160 * 1024 && (ldk & 7) == 0 && (ldv & 7) == 0 && (((uintptr_t)k_dev | (uintptr_t)v_dev) & 15) == 0 &&
                         64 * ldk * 2 + 512 <= 0xFFFFFFFFll && 64 * ldv * 2 + 512 <= 0xFFFFFFFFll;
-    if (dma256) rc = launch_attn(attn_bwd_dq_d256_kernel, gq, dim3(256), (int)lds256, stream, A, "attn_bwd_dq_d256_kernel");
+    if (dma256) rc = ecgb_attn::launch_bwd_dq_d256(A, gq.x, seq, stream);
     else rc = dq_generic(attn_bwd_dq_kernel<256>, 256, "attn_bwd_dq_kernel<256>");
     if (rc) return rc;
     if ((g_attn_dma & 3) && (ldq & 7) == 0 && (ldo & 7) == 0 && (((uintptr_t)q_dev | (uintptr_t)do_dev) & 15) == 0 && 64 * ldq * 2 + 512 <= 0xFFFFFFFFll && 64 * ldo * 2 + 512 <= 0xFFFFFFFFll)

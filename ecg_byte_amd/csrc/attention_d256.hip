@@ -1,0 +1,263 @@
+// attention_d256.hip -- head_dim 256 (Gemma) attention kernels, round 6: LDS reads the compiler can see, issued under the products of the group before.
+// Compiled without -amdgpu-mfma-vgpr-form (Makefile): these kernels run one wave per SIMD with up to 160 accumulators, which live in the accumulation registers; the flag
+// (right for the two-waves-per-SIMD kernels of attention.hip) would park them there and copy sixteen registers in and out around every product.
+// Reference: see attention.hip (modeling_gemma.py:201-300 for this head layout).
+#include "attention_common.inc"
+
+namespace {
+
+// ---- round 6: the head_dim-256 kernels with LDS reads the compiler can see -------------------------------------------------------------------------------------
+// Round 4's kernels read LDS through asm statements that end in their own lgkmcnt(0) (a ds_read hipcc can see next to LDS-DMA gets a vmcnt(0) in front of it -- the DMA may
+// write what the read reads, as far as it knows): every group of four fragments was an exposed LDS round trip (~150 cycles) in front of its four MFMAs (128 cycles) on a SIMD
+// that holds ONE wave.  hipcc tells LDS objects apart, though: with the ring's two stages as two __shared__ arrays and the tile loop unrolled by two, a read of the stage being
+// worked on needs no wait for the DMA into the other one, so the reads can be ordinary loads, counted by the compiler -- and issued a group AHEAD of the MFMAs that use them.
+// The arithmetic and its order are unchanged: the same bits as the round-4 kernels and the register-staged ones.
+#define SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
+#define SG_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
+#define SG_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
+// 1 KiB global -> LDS (16 bytes a lane from base + off, to lds + 16 lane), as an asm statement: with an LDS-DMA it can see pending, hipcc waits for lgkmcnt(0) in front of
+// every use of an LDS read (the reads issued under the last product included); what the DMA writes is read only behind the kernel's own vmcnt(0) + barrier
+__device__ __forceinline__ void lds_dma16(unsigned char *lds, const unsigned char *base, unsigned off)
+{
+    const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(la), "v"(off), "s"(base) : "memory");   // (m0: nothing else of these kernels uses it)
+}
+__device__ __forceinline__ bf16x8 lds_frag_c(const unsigned char *p) { return *reinterpret_cast<const bf16x8 *>(p); }
+__device__ __forceinline__ bf16x8 lds_tr_frag_c(const unsigned char *a, const unsigned char *b)
+{
+    using s4 = __attribute__((ext_vector_type(4))) short;
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)const_cast<unsigned char *>(a));
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)const_cast<unsigned char *>(b));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
+{
+    constexpr int D = 256, kRow = D * 2, kTile = 64 * kRow, PPW = 8;
+    __shared__ __attribute__((aligned(16))) unsigned char ring0[2 * kTile];     // a stage: the K image, the V image
+    __shared__ __attribute__((aligned(16))) unsigned char ring1[2 * kTile];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];        // the row's key mask, 64 tile flags
+    float *lds_maskrow = reinterpret_cast<float *>(smem);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
+    int qblk, head_in, group;
+    map_block((int)blockIdx.x, (A.S + 127) / 128, A.Hq / A.Hkv, A.B * A.Hkv, true, qblk, head_in, group);
+    const int b = group / A.Hkv, g = group % A.Hkv, hq = g * (A.Hq / A.Hkv) + head_in;
+    const int q0 = qblk * 128, qw0 = q0 + wave * 32;
+    const int qi = qw0 + lr;
+    const bool qvalid = qi < A.S;
+    const long long rowbase = (long long)b * A.S;
+    const unsigned short *Q = A.q + (long long)hq * D, *K = A.k + (long long)g * D, *V = A.v + (long long)g * D;
+    const int k_end = min(A.S, q0 + 128);
+    const int wave_qmax = qw0 + 31;
+    const int last_tile = (k_end - 1) / 64;
+    const int tail_rows = A.S - last_tile * 64;
+    // piece i of this wave: tile rows r0 + 2 i (r0 = 16 wave + the lane's half), the lane's 16-byte slot lane & 31 of the LDS row takes global chunk slot ^ swizzle(row)
+    const int r0 = wave * (2 * PPW) + (lane >> 5);
+    // swz_f256(r0 + 2 i) = 4 (lane >> 5) + 8 (i & 1) + (i >> 1): the pieces' chunks differ by a constant XOR
+    const unsigned chunk0 = (unsigned)((((lane & 31) ^ ((lane >> 5) << 2)) * 8) * 2);
+    const unsigned ldk2 = (unsigned)(A.ldk * 2), ldv2 = (unsigned)(A.ldv * 2);
+    const unsigned char *kb_next = reinterpret_cast<const unsigned char *>(K + rowbase * A.ldk), *vb_next = reinterpret_cast<const unsigned char *>(V + rowbase * A.ldv);
+    const long long stepK = 128ll * A.ldk, stepV = 128ll * A.ldv;
+    int t_next = 0, rmax_next = last_tile == 0 ? tail_rows - 1 : 63;      // the last row of the next tile that exists: a tile that ends past the sequence re-reads it (masked as keys >= S)
+    // piece i of the NEXT tile's K (which = 0) / V (which = 1) image into stage `dst` (no branch: a piece goes between two groups of MFMAs)
+    auto issue_piece = [&](unsigned char *dst, int which, int i) __attribute__((always_inline)) {
+        const unsigned off = (unsigned)min(r0 + 2 * i, rmax_next) * (which ? ldv2 : ldk2) + (chunk0 ^ (unsigned)((((i & 1) << 3) | (i >> 1)) << 4));
+        lds_dma16(dst + which * kTile + (wave * PPW + i) * 1024, which ? vb_next : kb_next, off);
+    };
+    auto advance_next = [&]() { if (t_next < last_tile) { ++t_next; kb_next += stepK; vb_next += stepV; if (t_next == last_tile) rmax_next = tail_rows - 1; } };
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) { issue_piece(ring0, 0, i); issue_piece(ring0, 1, i); }
+    advance_next();
+    bf16x8 qf[D / 16], dof[D / 16];
+    float delta = 0.f;
+    {
+        bf16x8 of[D / 16];
+        load_row_frags<D>(qf, Q, A.ldq, rowbase + qi, qvalid, h);
+        load_row_frags<D>(dof, A.d_o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h);
+        load_row_frags<D>(of, A.o + (long long)hq * D, A.ldo, rowbase + qi, qvalid, h);
+#pragma unroll
+        for (int ks = 0; ks < D / 16; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) delta += bf2f((unsigned short)dof[ks][j]) * bf2f((unsigned short)of[ks][j]);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const long long stat = ((long long)b * A.Hq + hq) * A.S + qi;
+    if (qvalid && h == 0) A.delta[stat] = delta;
+    const float lse = qvalid ? A.lse[stat] : INFINITY;
+    f32x16 accQ[D / 32];
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db) accQ[db] = splat16(0.f);
+    const float sc = A.scale * kLog2e;
+    lean_fill_mask<4>(lds_maskrow, A.mask + rowbase, A.S, (k_end + 63) & ~63);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // tile 0 and the row operands
+    __syncthreads();
+    const unsigned long long padbits = lean_pad_bits(lds_maskrow, (k_end + 63) & ~63);
+    // this lane's row fragment (row lr, k-step 0) inside an image, as an offset: k-step ks is the offset ^ (ks << 5); row 32 + lr 16 KiB further; the V image kTile further
+    const unsigned rbase = lr * kRow + ((h ^ swz_f256(lr)) << 4);
+    // this lane's transposing reads inside a K image for d block 0, first (key 4 h + q) and second (8 keys further: f moves with bit 3 of the row): block db is the offset ^ (db << 6)
+    unsigned tbaseA, tbaseB;
+    {
+        const int a = lr >> 4, q = (lr & 15) >> 2, p = lr & 3;
+        const int cg = 2 * a + (p >> 1);                                 // 16-byte chunk inside the 64-byte group
+        const int k1 = 4 * h + q, k2 = k1 + 8;
+        tbaseA = k1 * kRow + ((((k1 & 3) << 2) | (cg ^ ((k1 >> 2) & 3))) << 4) + (p & 1) * 8;
+        tbaseB = k2 * kRow + ((((k2 & 3) << 2) | (cg ^ ((k2 >> 2) & 3))) << 4) + (p & 1) * 8;
+    }
+    // the four row fragments of group gp (k-steps 2 gp, 2 gp + 1) of key half kb: K, V, K, V
+    auto load_sdp = [&](bf16x8 (&f)[4], const unsigned char *cur, int kb, int gp) __attribute__((always_inline)) {
+        unsigned rb = rbase;
+        asm volatile("" : "+v"(rb));                                      // (made here, one XOR a fragment pair: hipcc otherwise keeps every address of both stages in a register of its own)
+        const unsigned a0 = (rb ^ (unsigned)((2 * gp) << 5)) + kb * 32 * kRow, a1 = (rb ^ (unsigned)((2 * gp + 1) << 5)) + kb * 32 * kRow;
+        f[0] = lds_frag_c(cur + a0); f[1] = lds_frag_c(cur + a0 + kTile);
+        f[2] = lds_frag_c(cur + a1); f[3] = lds_frag_c(cur + a1 + kTile);
+    };
+    // the four transposed K fragments [k-step s2][d block 2 dpair + j] of key half kb
+    auto load_tr = [&](bf16x8 (&f)[2][2], const unsigned char *cur, int kb, int dpair) __attribute__((always_inline)) {
+        const unsigned x0 = (unsigned)((2 * dpair) << 6), x1 = (unsigned)((2 * dpair + 1) << 6);
+        unsigned ta = tbaseA, tb = tbaseB;
+        asm volatile("" : "+v"(ta), "+v"(tb));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const unsigned off = (kb * 32 + s2 * 16) * kRow;
+            f[s2][0] = lds_tr_frag_c(cur + (ta ^ x0) + off, cur + (tb ^ x0) + off);
+            f[s2][1] = lds_tr_frag_c(cur + (ta ^ x1) + off, cur + (tb ^ x1) + off);
+        }
+    };
+#ifdef ECGB_PROFILE
+    unsigned long long prof_acc[7] = {};
+    long long t_prof = clock64();
+#endif
+    auto trip = [&](const unsigned char *cur, unsigned char *nxt, const int k0, const int it) __attribute__((always_inline)) {
+        APROF(5);
+        const float *lds_mask = lds_maskrow + k0;
+        if (k0 <= wave_qmax && k0 < k_end) {
+            const bool need_mask = (k0 + 63 > qw0) || lean_tile_padded(padbits, it);
+            // the tile's 64 keys' mask words as bits in scalar registers (a lane a key, one ballot), for the half-wave's keys 4 h + ...: a shift by 4 for the upper half
+            const unsigned long long keybits = need_mask ? __ballot(lds_mask[lane] != 0.f) : ~0ull;
+            bf16x8 cf[4];
+            load_sdp(cf, cur, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x16 s = splat16(0.f), dp = splat16(0.f);
+                bf16x8 ktf[2][2];
+#pragma unroll
+                for (int gp = 0; gp < D / 32; ++gp) {                     // a group AHEAD: the next group's fragments (or the first transposed ones) are asked for, then this group's products issue
+                    bf16x8 nf[4];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (gp + 1 < D / 32) load_sdp(nf, cur, kb, gp + 1);
+                    else load_tr(ktf, cur, kb, 0);
+                    issue_piece(nxt, kb, gp);                             // the next tile's K pieces under key half 0's products, its V pieces under key half 1's
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[0], qf[2 * gp], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[1], dof[2 * gp], dp, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[2], qf[2 * gp + 1], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[3], dof[2 * gp + 1], dp, 0, 0, 0);
+                    // the order of issue: a product, then the reads that fit under it (a wave issues in order and is alone on its SIMD: reads in FRONT of the products are
+                    // issued while the matrix pipe has nothing left to do)
+                    if (gp + 1 < D / 32) {
+                        SG_MFMA(1); SG_DSR(1); SG_MFMA(1); SG_DSR(1); SG_MFMA(1); SG_DSR(1); SG_VMEM(1); SG_MFMA(1); SG_DSR(1);
+                    } else {
+                        SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); SG_VMEM(1); SG_MFMA(1); SG_DSR(2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (gp + 1 < D / 32) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) cf[j] = nf[j];
+                    }
+                }
+                APROF(0);
+                float ds[16];
+                if (need_mask) {
+                    const unsigned kbits = (unsigned)(keybits >> (kb * 32)) >> (4 * h);      // this half-wave's keys 4 h + ... of the key half
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const bool vis = (k0 + kl <= qi) & ((kbits & (1u << ((r & 3) + 8 * (r >> 2)))) != 0u);
+                        const float pr = vis ? fast_exp2(__builtin_fmaf(s[r], sc, -lse)) : 0.f;
+                        ds[r] = pr * (dp[r] - delta) * A.scale;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(__builtin_fmaf(s[r], sc, -lse)) * (dp[r] - delta) * A.scale;
+                }
+                const bf16x8 dsf0 = frag_from_acc(&ds[0]), dsf1 = frag_from_acc(&ds[8]);
+                APROF(1);
+#pragma unroll
+                for (int dpair = 0; dpair < D / 64; ++dpair) {
+                    bf16x8 ntf[2][2];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dpair + 1 < D / 64) load_tr(ntf, cur, kb, dpair + 1);
+                    else if (kb == 0) load_sdp(cf, cur, 1, 0);            // (key half 1 of the same tile; the next tile's first group waits for the barrier)
+                    accQ[2 * dpair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][0], dsf0, accQ[2 * dpair], 0, 0, 0);
+                    accQ[2 * dpair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][1], dsf0, accQ[2 * dpair + 1], 0, 0, 0);
+                    accQ[2 * dpair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][0], dsf1, accQ[2 * dpair], 0, 0, 0);
+                    accQ[2 * dpair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][1], dsf1, accQ[2 * dpair + 1], 0, 0, 0);
+                    if (dpair + 1 < D / 64) { SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); }
+                    else if (kb == 0) { SG_MFMA(1); SG_DSR(1); SG_MFMA(1); SG_DSR(1); SG_MFMA(1); SG_DSR(1); SG_MFMA(1); SG_DSR(1); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dpair + 1 < D / 64) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) { ktf[s2][0] = ntf[s2][0]; ktf[s2][1] = ntf[s2][1]; }
+                    }
+                }
+                APROF(2);
+            }
+#ifdef ECGB_PROFILE
+            prof_acc[6] += 1;
+#endif
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) { issue_piece(nxt, 0, i); issue_piece(nxt, 1, i); }
+        }
+        advance_next();
+        APROF(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's pieces of tile it + 1 have landed
+        APROF(4);
+        __builtin_amdgcn_s_barrier();                                     // ... and everybody else's; all reads of tile it are done
+    };
+    for (int k0 = 0, it = 0; k0 < k_end; k0 += 128, it += 2) {           // (an odd number of tiles: one more trip that no wave works on)
+        trip(ring0, ring1, k0, it);
+        trip(ring1, ring0, k0 + 64, it + 1);
+    }
+#ifdef ECGB_PROFILE
+    if ((threadIdx.x & 63) == 0)
+        for (int kk = 0; kk < 7; ++kk) atomicAdd(&g_attn_prof[(threadIdx.x >> 6) * 8 + kk], prof_acc[kk]);
+#endif
+    store_accT<D / 32>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, 1.f);
+}
+
+int launched256(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return ECGB_OK;
+    ecgb::set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return ECGB_ERR_HIP;
+}
+template <typename Kern>
+int launch256(Kern kern, unsigned grid, int lds, void *stream, const AttnArgs &A, const char *what)
+{
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+        ecgb::set_error(std::string(what) + ": hipFuncSetAttribute(" + std::to_string(lds) + " bytes of dynamic LDS): " + hipGetErrorString(e));
+        return ECGB_ERR_HIP;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, A);
+    return launched256(what);
+}
+
+}  // namespace
+
+#ifdef ECGB_PROFILE
+// dev builds only (scripts/dev_prof_attn_d256.py): this file's phase timers
+extern "C" void ecgb_debug_attn256_profile(unsigned long long *out64, int reset)
+{
+    if (out64) (void)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_attn_prof), 64 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[64] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), z, sizeof z); }
+}
+#endif
+
+namespace ecgb_attn {
+// dynamic LDS: the row's key mask and the tile flags (the ring is static)
+int launch_bwd_dq_d256(const AttnArgs &A, unsigned grid, int seq, void *stream)
+{
+    return launch256(attn_bwd_dq_d256_kernel, grid, 4 * ((seq + 63) & ~63) + 256, stream, A, "attn_bwd_dq_d256_kernel");
+}
+}  // namespace ecgb_attn
