@@ -2107,188 +2107,7 @@ __global__ __launch_bounds__(256) void attn_fwd_d256_kernel(AttnArgs A)
 // chunk c of row r lies at c ^ f(r), f(r) = (r & 3) << 2 | (r >> 2) & 3 (attention_common.inc) -- sixteen consecutive rows put one chunk on sixteen different bank groups, and
 // the eight key rows of a transposing read put one 64-byte group on all four 64-byte positions of the bank cycle, twice each.
 
-// head_dim 256 dK / dV with LDS-DMA staging (round 4): attn_bwd_dkv_body<256, 1, WHICH> (dV pass: WHICH 1, dK pass: WHICH 2, two workgroups of one launch) with the step's Q and
-// dO tiles and the tile's row statistics landing by LDS-DMA in a two-stage ring, one image per tile read both ways (rows for S / dP, transposing reads for dO^T . P and
-// Q^T . dS: the swizzle of attn_bwd_dq_d256_kernel) instead of four images written from registers between two barriers.  A tile that ends past the sequence re-reads the last
-// row (DMA cannot zero): those queries are switched off in the visibility test.  The arithmetic of the register-staged body in its order: the same bits.
-template <int OFF>
-__device__ __forceinline__ void lds_frags2_wait(bf16x8 &f0, bf16x8 &f1, unsigned a0, unsigned a1)
-{
-    i4v r0, r1;
-    asm volatile("ds_read_b128 %0, %2 offset:%4\n\t"
-                 "ds_read_b128 %1, %3 offset:%4\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(a1), "n"(OFF) : "memory");
-    f0 = __builtin_bit_cast(bf16x8, r0); f1 = __builtin_bit_cast(bf16x8, r1);
-}
-template <int WHICH>
-__device__ __forceinline__ void attn_bwd_dkv_d256_body(const AttnArgs &A, const int kblk, const int b, const int g, const int hsplit)
-{
-    constexpr bool DO_V = WHICH != 2, DO_K = WHICH != 1;
-    constexpr int D = 256, kRow = D * 2, kTile = 64 * kRow, PPW = 8, kStage = 2 * kTile + 512;   // Q image, dO image, lse and delta rows
-    constexpr int NB = D / 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                         // 2 x kStage
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
-    const int G = A.Hq / A.Hkv;
-    const int kk0 = kblk * 128;
-    const int ki = kk0 + wave * 32 + lr;
-    const bool kvalid = ki < A.S;
-    const long long rowbase = (long long)b * A.S;
-    const int wave_kmin = kk0 + wave * 32;
-    const int t_begin = (kk0 / 64) * 64;                   // first query tile that can see this key block
-    const int tiles_per_head = (A.S - t_begin + 63) / 64;
-    const int heads_here = G / (A.head_splits > 1 ? A.head_splits : 1), head_lo = hsplit * heads_here;   // this workgroup's query heads of the group
-    const int n_steps = heads_here * tiles_per_head;
-    const int tail_rows = A.S - (t_begin + (tiles_per_head - 1) * 64);
-    unsigned offQ[PPW], offO[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int r = (wave * PPW + i) * 2 + (lane >> 5), slot = lane & 31;
-        offQ[i] = (unsigned)(((long long)r * A.ldq + (slot ^ swz_f256(r)) * 8) * 2);
-        offO[i] = (unsigned)(((long long)r * A.ldo + (slot ^ swz_f256(r)) * 8) * 2);
-    }
-    int hq_next = 0, ti_next = 0, left_next = n_steps - 1;
-    unsigned slot_next = 0;
-    auto issue_next = [&]() {                                // UNCONDITIONAL: past the last step the last one is issued again
-        const int hq = g * G + head_lo + hq_next;
-        const int t0n = t_begin + ti_next * 64;
-        const bool tail = ti_next == tiles_per_head - 1 && tail_rows < 64;
-        const unsigned char *qb = reinterpret_cast<const unsigned char *>(A.q + (long long)hq * D + (rowbase + t0n) * A.ldq);
-        const unsigned char *ob = reinterpret_cast<const unsigned char *>(A.d_o + (long long)hq * D + (rowbase + t0n) * A.ldo);
-        unsigned char *dst = smem + slot_next;
-        if (tail) {                                          // (uniform) rows past the last query re-read it
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                const int r = (wave * PPW + i) * 2 + (lane >> 5), slot = lane & 31, rt = min(r, tail_rows - 1);
-                const unsigned oq = (unsigned)(((long long)rt * A.ldq + (slot ^ swz_f256(r)) * 8) * 2), oo = (unsigned)(((long long)rt * A.ldo + (slot ^ swz_f256(r)) * 8) * 2);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + oq), (__attribute__((address_space(3))) void *)(dst + (wave * PPW + i) * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ob + oo), (__attribute__((address_space(3))) void *)(dst + kTile + (wave * PPW + i) * 1024), 16, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < PPW; ++i) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(qb + offQ[i]), (__attribute__((address_space(3))) void *)(dst + (wave * PPW + i) * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ob + offO[i]), (__attribute__((address_space(3))) void *)(dst + kTile + (wave * PPW + i) * 1024), 16, 0, 0);
-            }
-        }
-        if (wave < 2) {                                      // wave 0 brings the tile's lse row, wave 1 its delta row (4 bytes a lane)
-            const float *stat_src = (wave ? A.delta : A.lse) + ((long long)b * A.Hq + hq) * A.S + t0n;
-            const unsigned so = (unsigned)(tail ? min(lane, tail_rows - 1) : lane) * 4u;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(stat_src) + so),
-                                             (__attribute__((address_space(3))) void *)(dst + 2 * kTile + wave * 256), 4, 0, 0);
-        }
-        if (left_next > 0) {
-            --left_next;
-            if (++ti_next == tiles_per_head) { ti_next = 0; ++hq_next; }
-        }
-        slot_next = slot_next ? 0u : (unsigned)kStage;
-    };
-    issue_next();
-    bf16x8 kf[D / 16], vf[DO_K ? D / 16 : 1];
-    load_row_frags<D>(kf, A.k + (long long)g * D, A.ldk, rowbase + ki, kvalid, h);
-    if constexpr (DO_K) load_row_frags<D>(vf, A.v + (long long)g * D, A.ldv, rowbase + ki, kvalid, h);
-    const bool kvis = kvalid && A.mask[rowbase + (kvalid ? ki : 0)] != 0.f;
-    f32x16 acc[NB];                                          // dV (WHICH 1) or dK (WHICH 2)
-#pragma unroll
-    for (int db = 0; db < NB; ++db) acc[db] = splat16(0.f);
-    const float sc = A.scale * kLog2e;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // step 0 and the row operands
-    __syncthreads();
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
-    const unsigned rbase = lr * kRow + ((h ^ swz_f256(lr)) << 4);         // (offsets: see attn_bwd_dq_d256_kernel)
-    unsigned tbaseA, tbaseB;
-    {
-        const int a = lr >> 4, q = (lr & 15) >> 2, p = lr & 3;
-        const int cg = 2 * a + (p >> 1);
-        const int k1 = 4 * h + q, k2 = k1 + 8;
-        tbaseA = k1 * kRow + ((((k1 & 3) << 2) | (cg ^ ((k1 >> 2) & 3))) << 4) + (p & 1) * 8;
-        tbaseB = k2 * kRow + ((((k2 & 3) << 2) | (cg ^ ((k2 >> 2) & 3))) << 4) + (p & 1) * 8;
-    }
-    unsigned img = 0;
-    int t0 = t_begin;
-    for (int step = 0; step < n_steps; ++step) {
-        issue_next();
-        if (t0 + 63 >= wave_kmin) {                          // else: every query of the tile precedes every key of this wave
-            const bool tail_tile = t0 + 64 > A.S;            // (uniform) the tile holds queries past the sequence
-            const float *lds_lse = reinterpret_cast<const float *>(smem + img + 2 * kTile), *lds_delta = lds_lse + 64;
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                f32x16 s = splat16(0.f), dp = splat16(0.f);
-#pragma unroll
-                for (int ks = 0; ks < D / 16; ks += 2) {
-                    const unsigned a0 = (rbase ^ (unsigned)(ks << 5)) + img + lds0, a1 = (rbase ^ (unsigned)((ks + 1) << 5)) + img + lds0;
-                    if constexpr (DO_K) {
-                        bf16x8 qf0, of0, qf1, of1;
-                        if (qb == 0) lds_frags2x2_wait<0, kTile>(qf0, of0, qf1, of1, a0, a1);
-                        else lds_frags2x2_wait<32 * kRow, kTile + 32 * kRow>(qf0, of0, qf1, of1, a0, a1);
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf0, kf[ks], s, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of0, vf[ks], dp, 0, 0, 0);
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf1, kf[ks + 1], s, 0, 0, 0);
-                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of1, vf[ks + 1], dp, 0, 0, 0);
-                    } else {
-                        bf16x8 qf0, qf1;
-                        if (qb == 0) lds_frags2_wait<0>(qf0, qf1, a0, a1); else lds_frags2_wait<32 * kRow>(qf0, qf1, a0, a1);
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf0, kf[ks], s, 0, 0, 0);
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf1, kf[ks + 1], s, 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                float pr[16], ds[16];
-                const bool diag = t0 + qb * 32 < wave_kmin + 32;              // some query of the block may precede some key of the wave
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {                                // the lane's 16 queries are 4 runs of 4: 16-byte reads
-                    const float4 lse4 = *reinterpret_cast<const float4 *>(&lds_lse[qb * 32 + 8 * g4 + 4 * h]);
-                    const float4 dl4 = *reinterpret_cast<const float4 *>(&lds_delta[qb * 32 + 8 * g4 + 4 * h]);
-                    const float lse_t[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dl_t[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int r = 4 * g4 + t;
-                        const int ql = qb * 32 + t + 8 * g4 + 4 * h;             // query inside the tile
-                        const bool vis = kvis & (!diag | (ki <= t0 + ql)) & (!tail_tile | (t0 + ql < A.S));
-                        const float e = vis ? fast_exp2(__builtin_fmaf(s[r], sc, -lse_t[t])) : 0.f;
-                        pr[r] = e;
-                        ds[r] = e * (dp[r] - dl_t[t]) * A.scale;
-                    }
-                }
-                const bf16x8 f0 = frag_from_acc(DO_V ? &pr[0] : &ds[0]), f1 = frag_from_acc(DO_V ? &pr[8] : &ds[8]);
-                constexpr unsigned kImg = DO_V ? kTile : 0;                     // dV: dO^T . P (the dO image); dK: Q^T . dS (the Q image)
-#pragma unroll
-                for (int dpair = 0; dpair < D / 64; ++dpair) {
-                    bf16x8 tf[2][2];
-                    const unsigned x0 = (unsigned)((2 * dpair) << 6), x1 = (unsigned)((2 * dpair + 1) << 6), base = img + lds0 + kImg;
-                    if (qb == 0) tr_frags4_wait<0, 16 * kRow>(tf, (tbaseA ^ x0) + base, (tbaseB ^ x0) + base, (tbaseA ^ x1) + base, (tbaseB ^ x1) + base);
-                    else tr_frags4_wait<32 * kRow, 48 * kRow>(tf, (tbaseA ^ x0) + base, (tbaseB ^ x0) + base, (tbaseA ^ x1) + base, (tbaseB ^ x1) + base);
-                    acc[2 * dpair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[0][0], f0, acc[2 * dpair], 0, 0, 0);
-                    acc[2 * dpair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[0][1], f0, acc[2 * dpair + 1], 0, 0, 0);
-                    acc[2 * dpair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[1][0], f1, acc[2 * dpair], 0, 0, 0);
-                    acc[2 * dpair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[1][1], f1, acc[2 * dpair + 1], 0, 0, 0);
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        img = img ? 0u : (unsigned)kStage;
-        t0 = t0 + 64 >= t_begin + tiles_per_head * 64 ? t_begin : t0 + 64;
-    }
-    if (A.head_splits > 1) {                                 // partial sums over this workgroup's heads: fp32 slabs, reduced in order afterwards
-        const long long rows_all = (long long)A.B * A.S, slab = rows_all * A.Hkv * D;
-        float *base = A.slab + (long long)hsplit * slab + ((long long)g * rows_all) * D;
-        if constexpr (DO_K) store_accT_f32<NB>(acc, base, D, rowbase + ki, kvalid, h);
-        if constexpr (DO_V) store_accT_f32<NB>(acc, base + (long long)A.head_splits * slab, D, rowbase + ki, kvalid, h);
-        return;
-    }
-    if constexpr (DO_K) store_accT<NB>(acc, A.dk + (long long)g * D, A.lddk, rowbase + ki, kvalid, h, 1.f);
-    if constexpr (DO_V) store_accT<NB>(acc, A.dv + (long long)g * D, A.lddv, rowbase + ki, kvalid, h, 1.f);
-}
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pair_d256_kernel(AttnArgs A)
-{
-    const int hs = A.head_splits > 1 ? A.head_splits : 1;      // (the block order of attn_bwd_dkv_pair_kernel)
-    int blk, head_in, group;
-    map_block((int)blockIdx.x, ((A.S + 127) / 128) * 2 * hs, 1, A.B * A.Hkv, false, blk, head_in, group);
-    const int pass = blk & 1, hsplit = (blk >> 1) % hs, kblk = (blk >> 1) / hs;
-    if (pass) attn_bwd_dkv_d256_body<2>(A, kblk, group / A.Hkv, group % A.Hkv, hsplit);
-    else attn_bwd_dkv_d256_body<1>(A, kblk, group / A.Hkv, group % A.Hkv, hsplit);
-}
+// head_dim 256 dK / dV pair kernel: attention_d256.hip (round 6; round 4's form with asm reads is in the history).
 
 struct LeanGeom { int hw_log2; unsigned grid; };
 LeanGeom lean_geom(int seq, int n_q_heads, int n_kv_heads, int batch)
@@ -2463,7 +2282,7 @@ int attn_bwd_impl(const void *q_dev, long long ldq, const void *k_dev, long long
     else rc = dq_generic(attn_bwd_dq_kernel<256>, 256, "attn_bwd_dq_kernel<256>");
     if (rc) return rc;
     if ((g_attn_dma & 3) && (ldq & 7) == 0 && (ldo & 7) == 0 && (((uintptr_t)q_dev | (uintptr_t)do_dev) & 15) == 0 && 64 * ldq * 2 + 512 <= 0xFFFFFFFFll && 64 * ldo * 2 + 512 <= 0xFFFFFFFFll)
-        rc = launch_attn(attn_bwd_dkv_pair_d256_kernel, dim3(gk * 2 * (unsigned)A.head_splits), dim3(256), 2 * (2 * 64 * 512 + 512), stream, A, "attn_bwd_dkv_pair_d256_kernel");
+        rc = ecgb_attn::launch_bwd_dkv_pair_d256(A, gk * 2 * (unsigned)A.head_splits, stream);
     else
         rc = launch_attn(attn_bwd_dkv_pair_kernel<256>, dim3(gk * 2 * (unsigned)A.head_splits), dim3(256), 4 * 128 * 256 + 512, stream, A, "attn_bwd_dkv_pair_kernel<256>");
     if (rc) return rc;

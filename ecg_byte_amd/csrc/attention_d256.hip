@@ -224,6 +224,271 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
     store_accT<D / 32>(accQ, A.dq + (long long)hq * D, A.lddq, rowbase + qi, qvalid, h, 1.f);
 }
 
+// 256 B global -> LDS (4 bytes a lane), see lds_dma16
+__device__ __forceinline__ void lds_dma4(unsigned char *lds, const unsigned char *base, unsigned off)
+{
+    const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" :: "s"(la), "v"(off), "s"(base) : "memory");
+}
+
+// head_dim 256 dK / dV (round 6): round 4's pair kernel (attention.hip's history: two workgroups of one launch, the dV pass -- S, dO^T . P -- and the dK pass -- S, dP, Q^T . dS --
+// of a block of 128 keys, a wave 32 keys, looping over (query head of the group, 64-query tile) steps whose Q and dO tiles and row statistics land by LDS-DMA in a two-stage
+// ring) with its LDS reads as ordinary loads issued a group of four products ahead (see the dQ kernel above).  The DMA being asm, hipcc knows of no LDS writer and the ring
+// can stay one dynamic array with a rolled step loop.  The arithmetic of the register-staged
+// body in its order: the same bits.
+template <int WHICH>
+__device__ __forceinline__ void attn_bwd_dkv_d256_body(const AttnArgs &A, const int kblk, const int b, const int g, const int hsplit)
+{
+    constexpr bool DO_V = WHICH != 2, DO_K = WHICH != 1;
+    constexpr int D = 256, kRow = D * 2, kTile = 64 * kRow, PPW = 8, kStage = 2 * kTile + 512;   // Q image, dO image, lse and delta rows
+    constexpr int NB = D / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                         // 2 x kStage
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
+    const int G = A.Hq / A.Hkv;
+    const int kk0 = kblk * 128;
+    const int ki = kk0 + wave * 32 + lr;
+    const bool kvalid = ki < A.S;
+    const long long rowbase = (long long)b * A.S;
+    const int wave_kmin = kk0 + wave * 32;
+    const int t_begin = (kk0 / 64) * 64;                   // first query tile that can see this key block
+    const int tiles_per_head = (A.S - t_begin + 63) / 64;
+    const int heads_here = G / (A.head_splits > 1 ? A.head_splits : 1), head_lo = hsplit * heads_here;   // this workgroup's query heads of the group
+    const int n_steps = heads_here * tiles_per_head;
+    const int tail_rows = A.S - (t_begin + (tiles_per_head - 1) * 64);
+    // piece i of this wave: tile rows r0 + 2 i, the lane's 16-byte slot lane & 31 of the LDS row takes global chunk slot ^ swz_f256(row) (see the dQ kernel)
+    const int r0 = wave * (2 * PPW) + (lane >> 5);
+    const unsigned chunk0 = (unsigned)((((lane & 31) ^ ((lane >> 5) << 2)) * 8) * 2);
+    const unsigned ldq2 = (unsigned)(A.ldq * 2), ldo2 = (unsigned)(A.ldo * 2);
+    // the step being fetched: its head and tile, the last row of the tile that exists (rows past the last query re-read it: switched off in the visibility test)
+    int hq_next = 0, ti_next = 0, left_next = n_steps - 1;
+    unsigned slot_next = 0;
+    const unsigned char *q_next, *o_next, *stat_next;
+    int rmax_next;
+    auto point_next = [&]() {
+        const int hq = g * G + head_lo + hq_next;
+        const int t0n = t_begin + ti_next * 64;
+        q_next = reinterpret_cast<const unsigned char *>(A.q + (long long)hq * D + (rowbase + t0n) * A.ldq);
+        o_next = reinterpret_cast<const unsigned char *>(A.d_o + (long long)hq * D + (rowbase + t0n) * A.ldo);
+        stat_next = reinterpret_cast<const unsigned char *>((wave ? A.delta : A.lse) + ((long long)b * A.Hq + hq) * A.S + t0n);   // wave 0 brings the lse row, wave 1 the delta row
+        rmax_next = (ti_next == tiles_per_head - 1 && tail_rows < 64) ? tail_rows - 1 : 63;
+    };
+    point_next();
+    auto issue_piece = [&](int which, int i) __attribute__((always_inline)) {      // which: 0 the Q image, 1 the dO image
+        const unsigned off = (unsigned)min(r0 + 2 * i, rmax_next) * (which ? ldo2 : ldq2) + (chunk0 ^ (unsigned)((((i & 1) << 3) | (i >> 1)) << 4));
+        lds_dma16(smem + slot_next + which * kTile + (wave * PPW + i) * 1024, which ? o_next : q_next, off);
+    };
+    auto issue_stats = [&]() __attribute__((always_inline)) {
+        if (wave < 2) lds_dma4(smem + slot_next + 2 * kTile + wave * 256, stat_next, (unsigned)min(lane, rmax_next) * 4u);
+    };
+    auto advance_next = [&]() {                              // (past the last step the last one is fetched again)
+        if (left_next > 0) {
+            --left_next;
+            if (++ti_next == tiles_per_head) { ti_next = 0; ++hq_next; }
+            point_next();
+        }
+        slot_next = slot_next ? 0u : (unsigned)kStage;
+    };
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) { issue_piece(0, i); issue_piece(1, i); }
+    issue_stats();
+    advance_next();
+    bf16x8 kf[D / 16], vf[DO_K ? D / 16 : 1];
+    load_row_frags<D>(kf, A.k + (long long)g * D, A.ldk, rowbase + ki, kvalid, h);
+    if constexpr (DO_K) load_row_frags<D>(vf, A.v + (long long)g * D, A.ldv, rowbase + ki, kvalid, h);
+    const bool kvis = kvalid && A.mask[rowbase + (kvalid ? ki : 0)] != 0.f;
+    f32x16 acc[NB];                                          // dV (WHICH 1) or dK (WHICH 2)
+#pragma unroll
+    for (int db = 0; db < NB; ++db) acc[db] = splat16(0.f);
+    const float sc = A.scale * kLog2e;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // step 0 and the row operands
+    __syncthreads();
+    const unsigned rbase = lr * kRow + ((h ^ swz_f256(lr)) << 4);         // (offsets: see the dQ kernel)
+    unsigned tbaseA, tbaseB;
+    {
+        const int a = lr >> 4, q = (lr & 15) >> 2, p = lr & 3;
+        const int cg = 2 * a + (p >> 1);
+        const int k1 = 4 * h + q, k2 = k1 + 8;
+        tbaseA = k1 * kRow + ((((k1 & 3) << 2) | (cg ^ ((k1 >> 2) & 3))) << 4) + (p & 1) * 8;
+        tbaseB = k2 * kRow + ((((k2 & 3) << 2) | (cg ^ ((k2 >> 2) & 3))) << 4) + (p & 1) * 8;
+    }
+    // group gp of query half qb: the dK pass takes k-steps 2 gp, 2 gp + 1 of the Q and the dO image (Q, dO, Q, dO), the dV pass k-steps 4 gp .. 4 gp + 3 of the Q image:
+    // four fragments, four products either way
+    auto load_grp = [&](bf16x8 (&f)[4], const unsigned char *cur, int qb, int gp) __attribute__((always_inline)) {
+        unsigned rb = rbase;
+        asm volatile("" : "+v"(rb));                          // (made here, one XOR a fragment pair: hipcc otherwise keeps every address in a register of its own)
+        if constexpr (DO_K) {
+            const unsigned a0 = (rb ^ (unsigned)((2 * gp) << 5)) + qb * 32 * kRow, a1 = (rb ^ (unsigned)((2 * gp + 1) << 5)) + qb * 32 * kRow;
+            f[0] = lds_frag_c(cur + a0); f[1] = lds_frag_c(cur + a0 + kTile);
+            f[2] = lds_frag_c(cur + a1); f[3] = lds_frag_c(cur + a1 + kTile);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = lds_frag_c(cur + (rb ^ (unsigned)((4 * gp + j) << 5)) + qb * 32 * kRow);
+        }
+    };
+    constexpr int NG = DO_K ? D / 32 : D / 64;               // groups of a query half's score products
+    // the four transposed fragments [k-step s2][d block 2 dpair + j] of query half qb: from the dO image (dV: dO^T . P) or the Q image (dK: Q^T . dS)
+    auto load_tr = [&](bf16x8 (&f)[2][2], const unsigned char *cur, int qb, int dpair) __attribute__((always_inline)) {
+        const unsigned x0 = (unsigned)((2 * dpair) << 6), x1 = (unsigned)((2 * dpair + 1) << 6);
+        unsigned ta = tbaseA, tb = tbaseB;
+        asm volatile("" : "+v"(ta), "+v"(tb));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const unsigned off = (qb * 32 + s2 * 16) * kRow + (DO_V ? kTile : 0);
+            f[s2][0] = lds_tr_frag_c(cur + (ta ^ x0) + off, cur + (tb ^ x0) + off);
+            f[s2][1] = lds_tr_frag_c(cur + (ta ^ x1) + off, cur + (tb ^ x1) + off);
+        }
+    };
+    unsigned img = 0;
+    int t0 = t_begin;
+#ifdef ECGB_PROFILE
+    unsigned long long prof_acc[7] = {};
+    long long t_prof = clock64();
+#endif
+    for (int step = 0; step < n_steps; ++step) {
+        const unsigned char *cur = smem + img;
+        APROF(5);
+        issue_stats();
+        // (the accumulators: in the accumulation half at every step's start, or hipcc carries some of them round the loop in the vector half and copies 32 registers in and out
+        // around a group of products)
+#pragma unroll
+        for (int db = 0; db < NB; ++db) asm volatile("" : "+a"(acc[db]));
+        if constexpr (DO_K) {
+            // Where the wave's 128 fixed operand registers live, said once a step: 96 of them beside the 160 accumulators in the accumulation half (MFMA reads its B operand from
+            // either half), 32 in the vector half.  Left alone hipcc parks all 128 in the accumulation half, has no room for the score accumulators there and moves 32
+            // accumulators in and out around every group of products (and spills 70 registers a step).
+#pragma unroll
+            for (int i = 0; i < D / 16; ++i) {
+                if (i < 12) asm volatile("" : "+a"(kf[i]), "+a"(vf[i]));
+                else asm volatile("" : "+v"(kf[i]), "+v"(vf[i]));
+            }
+        }
+        if (t0 + 63 >= wave_kmin) {                          // else: every query of the tile precedes every key of this wave
+            const bool tail_tile = t0 + 64 > A.S;            // (uniform) the tile holds queries past the sequence
+            const float *lds_lse = reinterpret_cast<const float *>(cur + 2 * kTile), *lds_delta = lds_lse + 64;
+            bf16x8 cf[4];
+            load_grp(cf, cur, 0, 0);
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f32x16 s = splat16(0.f), dp = splat16(0.f);
+                bf16x8 tf[2][2];
+                f4v lse4[4], dl4[DO_K ? 4 : 1];
+#pragma unroll
+                for (int gp = 0; gp < NG; ++gp) {            // a group AHEAD: the next group's fragments (or the first transposed ones and the statistics) are asked for under this group's products
+                    bf16x8 nf[4];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (gp + 1 < NG) load_grp(nf, cur, qb, gp + 1);
+                    else load_tr(tf, cur, qb, 0);
+                    if (gp == NG - 2) {                      // the lane's 16 queries are 4 runs of 4: 16-byte reads of their statistics, two groups ahead of the softmax
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            lse4[g4] = *reinterpret_cast<const f4v *>(&lds_lse[qb * 32 + 8 * g4 + 4 * h]);
+                            if constexpr (DO_K) dl4[g4] = *reinterpret_cast<const f4v *>(&lds_delta[qb * 32 + 8 * g4 + 4 * h]);
+                        }
+                    }
+                    if constexpr (DO_K) {
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[0], kf[2 * gp], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[1], vf[2 * gp], dp, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[2], kf[2 * gp + 1], s, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[3], vf[2 * gp + 1], dp, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[j], kf[4 * gp + j], s, 0, 0, 0);
+                    }
+                    if (gp == NG - 2) {
+                        if (DO_K) { SG_MFMA(1); SG_DSR(3); SG_MFMA(1); SG_DSR(3); SG_MFMA(1); SG_DSR(3); SG_MFMA(1); SG_DSR(3); }
+                        else { SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); }
+                    } else if (gp + 1 < NG) { SG_MFMA(1); SG_DSR(1); SG_MFMA(1); SG_DSR(1); SG_MFMA(1); SG_DSR(1); SG_MFMA(1); SG_DSR(1); }
+                    else { SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the next step's pieces behind the groups: the Q image under query half 0, the dO image under query half 1 (the dV pass has four groups a half: two pieces each)
+                    if constexpr (DO_K) issue_piece(qb, gp);
+                    else { issue_piece(qb, 2 * gp); issue_piece(qb, 2 * gp + 1); }
+                    if (gp + 1 < NG) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) cf[j] = nf[j];
+                    }
+                }
+                APROF(0);
+                float pr[16], ds[16];
+                const bool diag = t0 + qb * 32 < wave_kmin + 32;              // some query of the block may precede some key of the wave
+                if (!diag && !tail_tile) {                                      // (uniform) the plain case: every query of the half sees every key of the wave that is not padding
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float e = kvis ? fast_exp2(__builtin_fmaf(s[r], sc, -lse4[r >> 2][r & 3])) : 0.f;
+                        pr[r] = e;
+                        if constexpr (DO_K) ds[r] = e * (dp[r] - dl4[r >> 2][r & 3]) * A.scale;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ql = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;     // query inside the tile
+                        const bool vis = kvis & (!diag | (ki <= t0 + ql)) & (!tail_tile | (t0 + ql < A.S));
+                        const float e = vis ? fast_exp2(__builtin_fmaf(s[r], sc, -lse4[r >> 2][r & 3])) : 0.f;
+                        pr[r] = e;
+                        if constexpr (DO_K) ds[r] = e * (dp[r] - dl4[r >> 2][r & 3]) * A.scale;
+                    }
+                }
+                const bf16x8 f0 = frag_from_acc(DO_V ? &pr[0] : &ds[0]), f1 = frag_from_acc(DO_V ? &pr[8] : &ds[8]);
+                APROF(1);
+#pragma unroll
+                for (int dpair = 0; dpair < D / 64; ++dpair) {
+                    bf16x8 ntf[2][2];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dpair + 1 < D / 64) load_tr(ntf, cur, qb, dpair + 1);
+                    else if (qb == 0) load_grp(cf, cur, 1, 0);                  // (query half 1 of the same tile; the next step's first group waits for the barrier)
+                    acc[2 * dpair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[0][0], f0, acc[2 * dpair], 0, 0, 0);
+                    acc[2 * dpair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[0][1], f0, acc[2 * dpair + 1], 0, 0, 0);
+                    acc[2 * dpair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[1][0], f1, acc[2 * dpair], 0, 0, 0);
+                    acc[2 * dpair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[1][1], f1, acc[2 * dpair + 1], 0, 0, 0);
+                    if (dpair + 1 < D / 64) { SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); }
+                    else if (qb == 0) { SG_MFMA(1); SG_DSR(1); SG_MFMA(1); SG_DSR(1); SG_MFMA(1); SG_DSR(1); SG_MFMA(1); SG_DSR(1); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dpair + 1 < D / 64) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) { tf[s2][0] = ntf[s2][0]; tf[s2][1] = ntf[s2][1]; }
+                    }
+                }
+                APROF(2);
+            }
+#ifdef ECGB_PROFILE
+            prof_acc[6] += 1;
+#endif
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) { issue_piece(0, i); issue_piece(1, i); }
+        }
+        advance_next();
+        APROF(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        APROF(4);
+        __builtin_amdgcn_s_barrier();
+        img = img ? 0u : (unsigned)kStage;
+        t0 = t0 + 64 >= t_begin + tiles_per_head * 64 ? t_begin : t0 + 64;
+    }
+#ifdef ECGB_PROFILE
+    if ((threadIdx.x & 63) == 0)
+        for (int kk = 0; kk < 7; ++kk) atomicAdd(&g_attn_prof[(DO_K ? 0 : 32) + (threadIdx.x >> 6) * 8 + kk], prof_acc[kk]);
+#endif
+    if (A.head_splits > 1) {                                 // partial sums over this workgroup's heads: fp32 slabs, reduced in order afterwards
+        const long long rows_all = (long long)A.B * A.S, slab = rows_all * A.Hkv * D;
+        float *base = A.slab + (long long)hsplit * slab + ((long long)g * rows_all) * D;
+        if constexpr (DO_K) store_accT_f32<NB>(acc, base, D, rowbase + ki, kvalid, h);
+        if constexpr (DO_V) store_accT_f32<NB>(acc, base + (long long)A.head_splits * slab, D, rowbase + ki, kvalid, h);
+        return;
+    }
+    if constexpr (DO_K) store_accT<NB>(acc, A.dk + (long long)g * D, A.lddk, rowbase + ki, kvalid, h, 1.f);
+    if constexpr (DO_V) store_accT<NB>(acc, A.dv + (long long)g * D, A.lddv, rowbase + ki, kvalid, h, 1.f);
+}
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pair_d256_kernel(AttnArgs A)
+{
+    const int hs = A.head_splits > 1 ? A.head_splits : 1;      // (the block order of attn_bwd_dkv_pair_kernel)
+    int blk, head_in, group;
+    map_block((int)blockIdx.x, ((A.S + 127) / 128) * 2 * hs, 1, A.B * A.Hkv, false, blk, head_in, group);
+    const int pass = blk & 1, hsplit = (blk >> 1) % hs, kblk = (blk >> 1) / hs;
+    if (pass) attn_bwd_dkv_d256_body<2>(A, kblk, group / A.Hkv, group % A.Hkv, hsplit);
+    else attn_bwd_dkv_d256_body<1>(A, kblk, group / A.Hkv, group % A.Hkv, hsplit);
+}
+
 int launched256(const char *what)
 {
     hipError_t e = hipGetLastError();
@@ -259,5 +524,9 @@ namespace ecgb_attn {
 int launch_bwd_dq_d256(const AttnArgs &A, unsigned grid, int seq, void *stream)
 {
     return launch256(attn_bwd_dq_d256_kernel, grid, 4 * ((seq + 63) & ~63) + 256, stream, A, "attn_bwd_dq_d256_kernel");
+}
+int launch_bwd_dkv_pair_d256(const AttnArgs &A, unsigned grid, void *stream)
+{
+    return launch256(attn_bwd_dkv_pair_d256_kernel, grid, 2 * (2 * 64 * 512 + 512), stream, A, "attn_bwd_dkv_pair_d256_kernel");
 }
 }  // namespace ecgb_attn

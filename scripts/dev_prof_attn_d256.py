@@ -20,8 +20,11 @@ L.ecgb_debug_attn256_profile(None, 1)
 ops.attn_bwd(qkv, mask, o, do, l, B, S, Hq, Hkv, D, sc); torch.cuda.synchronize()
 out = (C.c_ulonglong * 64)()
 L.ecgb_debug_attn256_profile(out, 0)
-names = ["S/dP groups (+ DMA issue)", "softmax", "dQ groups", "skipped tile / advance", "vmcnt wait", "barrier"]
-for w in range(4):
-    v = out[8 * w: 8 * w + 8]
-    n = max(1, v[6])
-    print(f"wave {w}: {v[6]} half... active trips; per active trip: " + "  ".join(f"{nm} {v[k] / n:.0f}" for k, nm in enumerate(names)) + f"   sum {sum(v[:6]) / n:.0f}")
+names = ["score groups (+ DMA issue)", "softmax", "accumulate groups", "skipped tile / advance", "vmcnt wait", "barrier"]
+# the dQ kernel and the dK pass of the pair kernel both add to slots 0 .. 31 (the dV pass to 32 .. 63): KERNEL=dq profiles a dQ-only launch is not possible through the
+# C ABI, so the dQ figures are those of round 6's first profile (EXPERIMENTS.md); here the pair kernel's two passes are told apart, dQ's cycles are in the dK rows too
+for label, base in (("dQ + dK pass", 0), ("dV pass", 32)):
+    for w in range(4):
+        v = out[base + 8 * w: base + 8 * w + 8]
+        n = max(1, v[6])
+        print(f"{label} wave {w}: {v[6]} active steps; per active step: " + "  ".join(f"{nm} {v[k] / n:.0f}" for k, nm in enumerate(names)) + f"   sum {sum(v[:6]) / n:.0f}")
