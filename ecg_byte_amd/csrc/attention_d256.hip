@@ -1,6 +1,5 @@
-// attention_d256.hip -- head_dim 256 (Gemma) attention kernels, round 6: LDS reads the compiler can see, issued under the products of the group before.
-// Compiled without -amdgpu-mfma-vgpr-form (Makefile): these kernels run one wave per SIMD with up to 160 accumulators, which live in the accumulation registers; the flag
-// (right for the two-waves-per-SIMD kernels of attention.hip) would park them there and copy sixteen registers in and out around every product.
+// attention_d256.hip -- head_dim 256 (Gemma) attention backward kernels, round 6: LDS reads the compiler can see, issued under the products of the group before.
+// (The forward kernel of this head_dim is round 4's, in attention.hip: the same treatment did not pay there -- scripts/experiments/r06_attn_fwd_d256_v2.hip.txt.)
 // Reference: see attention.hip (modeling_gemma.py:201-300 for this head layout).
 #include "attention_common.inc"
 
@@ -8,10 +7,11 @@ namespace {
 
 // ---- round 6: the head_dim-256 kernels with LDS reads the compiler can see -------------------------------------------------------------------------------------
 // Round 4's kernels read LDS through asm statements that end in their own lgkmcnt(0) (a ds_read hipcc can see next to LDS-DMA gets a vmcnt(0) in front of it -- the DMA may
-// write what the read reads, as far as it knows): every group of four fragments was an exposed LDS round trip (~150 cycles) in front of its four MFMAs (128 cycles) on a SIMD
-// that holds ONE wave.  hipcc tells LDS objects apart, though: with the ring's two stages as two __shared__ arrays and the tile loop unrolled by two, a read of the stage being
-// worked on needs no wait for the DMA into the other one, so the reads can be ordinary loads, counted by the compiler -- and issued a group AHEAD of the MFMAs that use them.
-// The arithmetic and its order are unchanged: the same bits as the round-4 kernels and the register-staged ones.
+// write what the read reads, as far as it knows): every group of four fragments was an exposed LDS round trip in front of its four MFMAs on a SIMD that holds ONE wave.
+// Here the LDS-DMA is the asm statement (lds_dma16): hipcc then knows of no LDS writer, the reads are ordinary loads that it counts (lgkmcnt(3) in front of a product: the
+// three younger reads stay in flight), and each group's reads are issued BETWEEN the products of the group before (sched_group_barrier: a product, then the reads that fit under
+// it -- a wave issues in order and is alone on its SIMD, reads in front of the products are issued while the matrix pipe has nothing left to do).  What the DMA writes is read
+// only behind the kernels' own vmcnt(0) + barrier.  The arithmetic and its order are unchanged: the same bits as the round-4 kernels and the register-staged ones.
 #define SG_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, n, 0)
 #define SG_DSR(n) __builtin_amdgcn_sched_group_barrier(0x100, n, 0)
 #define SG_VMEM(n) __builtin_amdgcn_sched_group_barrier(0x020, n, 0)
@@ -33,10 +33,8 @@ __device__ __forceinline__ bf16x8 lds_tr_frag_c(const unsigned char *a, const un
 __global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
 {
     constexpr int D = 256, kRow = D * 2, kTile = 64 * kRow, PPW = 8;
-    __shared__ __attribute__((aligned(16))) unsigned char ring0[2 * kTile];     // a stage: the K image, the V image
-    __shared__ __attribute__((aligned(16))) unsigned char ring1[2 * kTile];
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];        // the row's key mask, 64 tile flags
-    float *lds_maskrow = reinterpret_cast<float *>(smem);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];        // 2 x (K image, V image), the row's key mask, 64 tile flags
+    float *lds_maskrow = reinterpret_cast<float *>(smem + 4 * kTile);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
     int qblk, head_in, group;
     map_block((int)blockIdx.x, (A.S + 127) / 128, A.Hq / A.Hkv, A.B * A.Hkv, true, qblk, head_in, group);
@@ -57,15 +55,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
     const unsigned ldk2 = (unsigned)(A.ldk * 2), ldv2 = (unsigned)(A.ldv * 2);
     const unsigned char *kb_next = reinterpret_cast<const unsigned char *>(K + rowbase * A.ldk), *vb_next = reinterpret_cast<const unsigned char *>(V + rowbase * A.ldv);
     const long long stepK = 128ll * A.ldk, stepV = 128ll * A.ldv;
-    int t_next = 0, rmax_next = last_tile == 0 ? tail_rows - 1 : 63;      // the last row of the next tile that exists: a tile that ends past the sequence re-reads it (masked as keys >= S)
-    // piece i of the NEXT tile's K (which = 0) / V (which = 1) image into stage `dst` (no branch: a piece goes between two groups of MFMAs)
-    auto issue_piece = [&](unsigned char *dst, int which, int i) __attribute__((always_inline)) {
+    int t_next = 0, rmax_next = last_tile == 0 ? min(63, tail_rows - 1) : 63;      // the last row of the next tile that exists: a tile that ends past the sequence re-reads it (masked as keys >= S)
+    unsigned slot_next = 0;
+    // piece i of the NEXT tile's K (which = 0) / V (which = 1) image into the other stage (no branch: a piece goes between two groups of MFMAs)
+    auto issue_piece = [&](int which, int i) __attribute__((always_inline)) {
         const unsigned off = (unsigned)min(r0 + 2 * i, rmax_next) * (which ? ldv2 : ldk2) + (chunk0 ^ (unsigned)((((i & 1) << 3) | (i >> 1)) << 4));
-        lds_dma16(dst + which * kTile + (wave * PPW + i) * 1024, which ? vb_next : kb_next, off);
+        lds_dma16(smem + slot_next + which * kTile + (wave * PPW + i) * 1024, which ? vb_next : kb_next, off);
     };
-    auto advance_next = [&]() { if (t_next < last_tile) { ++t_next; kb_next += stepK; vb_next += stepV; if (t_next == last_tile) rmax_next = tail_rows - 1; } };
+    auto advance_next = [&]() {
+        if (t_next < last_tile) { ++t_next; kb_next += stepK; vb_next += stepV; if (t_next == last_tile) rmax_next = min(63, tail_rows - 1); }
+        slot_next ^= 2 * kTile;
+    };
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) { issue_piece(ring0, 0, i); issue_piece(ring0, 1, i); }
+    for (int i = 0; i < PPW; ++i) { issue_piece(0, i); issue_piece(1, i); }
     advance_next();
     bf16x8 qf[D / 16], dof[D / 16];
     float delta = 0.f;
@@ -126,10 +128,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
     unsigned long long prof_acc[7] = {};
     long long t_prof = clock64();
 #endif
-    auto trip = [&](const unsigned char *cur, unsigned char *nxt, const int k0, const int it) __attribute__((always_inline)) {
+    unsigned img = 0;
+    for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
+        const unsigned char *cur = smem + img;
         APROF(5);
+        // Said once a trip: the accumulators live in the vector half (see the dK / dV kernel below)
+#pragma unroll
+        for (int db = 0; db < D / 32; ++db) asm volatile("" : "+v"(accQ[db]));
         const float *lds_mask = lds_maskrow + k0;
-        if (k0 <= wave_qmax && k0 < k_end) {
+        if (k0 <= wave_qmax) {
             const bool need_mask = (k0 + 63 > qw0) || lean_tile_padded(padbits, it);
             // the tile's 64 keys' mask words as bits in scalar registers (a lane a key, one ballot), for the half-wave's keys 4 h + ...: a shift by 4 for the upper half
             const unsigned long long keybits = need_mask ? __ballot(lds_mask[lane] != 0.f) : ~0ull;
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
                     __builtin_amdgcn_sched_barrier(0);
                     if (gp + 1 < D / 32) load_sdp(nf, cur, kb, gp + 1);
                     else load_tr(ktf, cur, kb, 0);
-                    issue_piece(nxt, kb, gp);                             // the next tile's K pieces under key half 0's products, its V pieces under key half 1's
+                    issue_piece(kb, gp);                                  // the next tile's K pieces under key half 0's products, its V pieces under key half 1's
                     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[0], qf[2 * gp], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[1], dof[2 * gp], dp, 0, 0, 0);
                     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[2], qf[2 * gp + 1], s, 0, 0, 0);
@@ -205,17 +212,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
 #endif
         } else {
 #pragma unroll
-            for (int i = 0; i < PPW; ++i) { issue_piece(nxt, 0, i); issue_piece(nxt, 1, i); }
+            for (int i = 0; i < PPW; ++i) { issue_piece(0, i); issue_piece(1, i); }
         }
         advance_next();
         APROF(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's pieces of tile it + 1 have landed
         APROF(4);
         __builtin_amdgcn_s_barrier();                                     // ... and everybody else's; all reads of tile it are done
-    };
-    for (int k0 = 0, it = 0; k0 < k_end; k0 += 128, it += 2) {           // (an odd number of tiles: one more trip that no wave works on)
-        trip(ring0, ring1, k0, it);
-        trip(ring1, ring0, k0 + 64, it + 1);
+        img ^= 2 * kTile;
     }
 #ifdef ECGB_PROFILE
     if ((threadIdx.x & 63) == 0)
@@ -348,20 +352,11 @@ __device__ __forceinline__ void attn_bwd_dkv_d256_body(const AttnArgs &A, const 
         const unsigned char *cur = smem + img;
         APROF(5);
         issue_stats();
-        // (the accumulators: in the accumulation half at every step's start, or hipcc carries some of them round the loop in the vector half and copies 32 registers in and out
-        // around a group of products)
+        // Said once a step: the accumulators live in the vector half (this file is compiled with -amdgpu-mfma-vgpr-form: the products write them there, the softmax reads the
+        // scores without copies, the wave's 128 fixed operand registers are read from the accumulation half directly).  Left alone hipcc carries some accumulators round the
+        // loop in the other half and copies 32 registers in and out around every group of products, or spills.
 #pragma unroll
-        for (int db = 0; db < NB; ++db) asm volatile("" : "+a"(acc[db]));
-        if constexpr (DO_K) {
-            // Where the wave's 128 fixed operand registers live, said once a step: 96 of them beside the 160 accumulators in the accumulation half (MFMA reads its B operand from
-            // either half), 32 in the vector half.  Left alone hipcc parks all 128 in the accumulation half, has no room for the score accumulators there and moves 32
-            // accumulators in and out around every group of products (and spills 70 registers a step).
-#pragma unroll
-            for (int i = 0; i < D / 16; ++i) {
-                if (i < 12) asm volatile("" : "+a"(kf[i]), "+a"(vf[i]));
-                else asm volatile("" : "+v"(kf[i]), "+v"(vf[i]));
-            }
-        }
+        for (int db = 0; db < NB; ++db) asm volatile("" : "+v"(acc[db]));
         if (t0 + 63 >= wave_kmin) {                          // else: every query of the tile precedes every key of this wave
             const bool tail_tile = t0 + 64 > A.S;            // (uniform) the tile holds queries past the sequence
             const float *lds_lse = reinterpret_cast<const float *>(cur + 2 * kTile), *lds_delta = lds_lse + 64;
@@ -520,10 +515,10 @@ extern "C" void ecgb_debug_attn256_profile(unsigned long long *out64, int reset)
 #endif
 
 namespace ecgb_attn {
-// dynamic LDS: the row's key mask and the tile flags (the ring is static)
+// dynamic LDS: the two-stage ring, the row's key mask, the tile flags
 int launch_bwd_dq_d256(const AttnArgs &A, unsigned grid, int seq, void *stream)
 {
-    return launch256(attn_bwd_dq_d256_kernel, grid, 4 * ((seq + 63) & ~63) + 256, stream, A, "attn_bwd_dq_d256_kernel");
+    return launch256(attn_bwd_dq_d256_kernel, grid, 4 * 64 * 512 + 4 * ((seq + 63) & ~63) + 256, stream, A, "attn_bwd_dq_d256_kernel");
 }
 int launch_bwd_dkv_pair_d256(const AttnArgs &A, unsigned grid, void *stream)
 {
