@@ -22,6 +22,15 @@ __device__ __forceinline__ void lds_dma16(unsigned char *lds, const unsigned cha
     const unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(la), "v"(off), "s"(base) : "memory");   // (m0: nothing else of these kernels uses it)
 }
+// LDS reads hipcc can see, by LDS address: a row fragment (ds_read_b128), a transposed one (two ds_read_b64_tr_b16)
+__device__ __forceinline__ bf16x8 lds_frag_a(unsigned a) { return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8 *>((size_t)a); }
+__device__ __forceinline__ bf16x8 lds_tr_frag_a(unsigned a, unsigned b)
+{
+    using s4 = __attribute__((ext_vector_type(4))) short;
+    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)(size_t)a);
+    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4 *)(size_t)b);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 __device__ __forceinline__ bf16x8 lds_frag_c(const unsigned char *p) { return *reinterpret_cast<const bf16x8 *>(p); }
 __device__ __forceinline__ bf16x8 lds_tr_frag_c(const unsigned char *a, const unsigned char *b)
 {
@@ -55,15 +64,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
     const unsigned ldk2 = (unsigned)(A.ldk * 2), ldv2 = (unsigned)(A.ldv * 2);
     const unsigned char *kb_next = reinterpret_cast<const unsigned char *>(K + rowbase * A.ldk), *vb_next = reinterpret_cast<const unsigned char *>(V + rowbase * A.ldv);
     const long long stepK = 128ll * A.ldk, stepV = 128ll * A.ldv;
-    int t_next = 0, rmax_next = last_tile == 0 ? min(63, tail_rows - 1) : 63;      // the last row of the next tile that exists: a tile that ends past the sequence re-reads it (masked as keys >= S)
+    int t_next = 0;
     unsigned slot_next = 0;
-    // piece i of the NEXT tile's K (which = 0) / V (which = 1) image into the other stage (no branch: a piece goes between two groups of MFMAs)
+    // The pieces' row offsets from the tile's first row, kept (the chunk is a constant XOR): a piece between two groups of MFMAs is then one XOR and the load (made where it is
+    // issued each cost four vector instructions, and the groups are bound by what the wave can issue beside an MFMA: 5.7 vector instructions a product, EXPERIMENTS.md R6).
+    // A tile that ends past the sequence re-reads its last row (masked as keys >= S): its offsets are made when it comes up, once a workgroup at most.
+    unsigned offK[PPW], offV[PPW];
+    auto piece_offsets = [&](int rmax) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const unsigned row = (unsigned)min(r0 + 2 * i, rmax), ch = chunk0 ^ (unsigned)((((i & 1) << 3) | (i >> 1)) << 4);
+            offK[i] = row * ldk2 + ch; offV[i] = row * ldv2 + ch;
+        }
+    };
+    piece_offsets(last_tile == 0 ? min(63, tail_rows - 1) : 63);
+    // piece i of the NEXT tile's K (which = 0) / V (which = 1) image into the other stage
     auto issue_piece = [&](int which, int i) __attribute__((always_inline)) {
-        const unsigned off = (unsigned)min(r0 + 2 * i, rmax_next) * (which ? ldv2 : ldk2) + (chunk0 ^ (unsigned)((((i & 1) << 3) | (i >> 1)) << 4));
-        lds_dma16(smem + slot_next + which * kTile + (wave * PPW + i) * 1024, which ? vb_next : kb_next, off);
+        lds_dma16(smem + slot_next + which * kTile + (wave * PPW + i) * 1024, which ? vb_next : kb_next, which ? offV[i] : offK[i]);
     };
     auto advance_next = [&]() {
-        if (t_next < last_tile) { ++t_next; kb_next += stepK; vb_next += stepV; if (t_next == last_tile) rmax_next = min(63, tail_rows - 1); }
+        if (t_next < last_tile) {
+            ++t_next; kb_next += stepK; vb_next += stepV;
+            if (t_next == last_tile && tail_rows < 64) piece_offsets(tail_rows - 1);      // (uniform)
+        }
         slot_next ^= 2 * kTile;
     };
 #pragma unroll
@@ -102,35 +125,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
         const int cg = 2 * a + (p >> 1);                                 // 16-byte chunk inside the 64-byte group
         const int k1 = 4 * h + q, k2 = k1 + 8;
         tbaseA = k1 * kRow + ((((k1 & 3) << 2) | (cg ^ ((k1 >> 2) & 3))) << 4) + (p & 1) * 8;
-        tbaseB = k2 * kRow + ((((k2 & 3) << 2) | (cg ^ ((k2 >> 2) & 3))) << 4) + (p & 1) * 8;
+        tbaseB = k2 * kRow + ((((k2 & 3) << 2) | (cg ^ ((k2 >> 2) & 3))) << 4) + (p & 1) * 8;      // = tbaseA ^ (4096 | 32): k1 < 8, and (k >> 2) & 3 moves by 2
+        (void)tbaseB;
     }
+    // The lane's read addresses are LDS ADDRESSES (the ring is the kernel's only LDS object and starts at address 0 -- checked below): the current stage is bit 16 of them,
+    // a k-step / d block an XOR of bits 5 - 8, so that one register a kind, flipped once a trip, and one XOR a fragment address is all the arithmetic the reads need (with
+    // the stage added at the reads: five vector instructions a group of four products, and the groups are bound by what a wave can issue beside an MFMA).  The second
+    // transposing read (8 keys further) is the first ^ (4096 | 32): the row and bit 1 of the swizzle's chunk.
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)smem != 0u) __builtin_trap();
+    unsigned sbase = rbase, tbase = tbaseA;
     // the four row fragments of group gp (k-steps 2 gp, 2 gp + 1) of key half kb: K, V, K, V
-    auto load_sdp = [&](bf16x8 (&f)[4], const unsigned char *cur, int kb, int gp) __attribute__((always_inline)) {
-        unsigned rb = rbase;
-        asm volatile("" : "+v"(rb));                                      // (made here, one XOR a fragment pair: hipcc otherwise keeps every address of both stages in a register of its own)
-        const unsigned a0 = (rb ^ (unsigned)((2 * gp) << 5)) + kb * 32 * kRow, a1 = (rb ^ (unsigned)((2 * gp + 1) << 5)) + kb * 32 * kRow;
-        f[0] = lds_frag_c(cur + a0); f[1] = lds_frag_c(cur + a0 + kTile);
-        f[2] = lds_frag_c(cur + a1); f[3] = lds_frag_c(cur + a1 + kTile);
+    auto load_sdp = [&](bf16x8 (&f)[4], int kb, int gp) __attribute__((always_inline)) {
+        const unsigned a0 = (sbase ^ (unsigned)((2 * gp) << 5)) + kb * 32 * kRow, a1 = (sbase ^ (unsigned)((2 * gp + 1) << 5)) + kb * 32 * kRow;
+        f[0] = lds_frag_a(a0); f[1] = lds_frag_a(a0 + kTile);
+        f[2] = lds_frag_a(a1); f[3] = lds_frag_a(a1 + kTile);
     };
     // the four transposed K fragments [k-step s2][d block 2 dpair + j] of key half kb
-    auto load_tr = [&](bf16x8 (&f)[2][2], const unsigned char *cur, int kb, int dpair) __attribute__((always_inline)) {
+    auto load_tr = [&](bf16x8 (&f)[2][2], int kb, int dpair) __attribute__((always_inline)) {
         const unsigned x0 = (unsigned)((2 * dpair) << 6), x1 = (unsigned)((2 * dpair + 1) << 6);
-        unsigned ta = tbaseA, tb = tbaseB;
-        asm volatile("" : "+v"(ta), "+v"(tb));
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const unsigned off = (kb * 32 + s2 * 16) * kRow;
-            f[s2][0] = lds_tr_frag_c(cur + (ta ^ x0) + off, cur + (tb ^ x0) + off);
-            f[s2][1] = lds_tr_frag_c(cur + (ta ^ x1) + off, cur + (tb ^ x1) + off);
+            f[s2][0] = lds_tr_frag_a((tbase ^ x0) + off, (tbase ^ x0 ^ 4128u) + off);
+            f[s2][1] = lds_tr_frag_a((tbase ^ x1) + off, (tbase ^ x1 ^ 4128u) + off);
         }
     };
 #ifdef ECGB_PROFILE
     unsigned long long prof_acc[7] = {};
     long long t_prof = clock64();
 #endif
-    unsigned img = 0;
     for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
-        const unsigned char *cur = smem + img;
         APROF(5);
         // Said once a trip: the accumulators live in the vector half (see the dK / dV kernel below)
 #pragma unroll
@@ -141,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
             // the tile's 64 keys' mask words as bits in scalar registers (a lane a key, one ballot), for the half-wave's keys 4 h + ...: a shift by 4 for the upper half
             const unsigned long long keybits = need_mask ? __ballot(lds_mask[lane] != 0.f) : ~0ull;
             bf16x8 cf[4];
-            load_sdp(cf, cur, 0, 0);
+            load_sdp(cf, 0, 0);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 f32x16 s = splat16(0.f), dp = splat16(0.f);
@@ -150,8 +174,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
                 for (int gp = 0; gp < D / 32; ++gp) {                     // a group AHEAD: the next group's fragments (or the first transposed ones) are asked for, then this group's products issue
                     bf16x8 nf[4];
                     __builtin_amdgcn_sched_barrier(0);
-                    if (gp + 1 < D / 32) load_sdp(nf, cur, kb, gp + 1);
-                    else load_tr(ktf, cur, kb, 0);
+                    if (gp + 1 < D / 32) load_sdp(nf, kb, gp + 1);
+                    else load_tr(ktf, kb, 0);
                     issue_piece(kb, gp);                                  // the next tile's K pieces under key half 0's products, its V pieces under key half 1's
                     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[0], qf[2 * gp], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf[1], dof[2 * gp], dp, 0, 0, 0);
@@ -191,8 +215,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
                 for (int dpair = 0; dpair < D / 64; ++dpair) {
                     bf16x8 ntf[2][2];
                     __builtin_amdgcn_sched_barrier(0);
-                    if (dpair + 1 < D / 64) load_tr(ntf, cur, kb, dpair + 1);
-                    else if (kb == 0) load_sdp(cf, cur, 1, 0);            // (key half 1 of the same tile; the next tile's first group waits for the barrier)
+                    if (dpair + 1 < D / 64) load_tr(ntf, kb, dpair + 1);
+                    else if (kb == 0) load_sdp(cf, 1, 0);            // (key half 1 of the same tile; the next tile's first group waits for the barrier)
                     accQ[2 * dpair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][0], dsf0, accQ[2 * dpair], 0, 0, 0);
                     accQ[2 * dpair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][1], dsf0, accQ[2 * dpair + 1], 0, 0, 0);
                     accQ[2 * dpair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][0], dsf1, accQ[2 * dpair], 0, 0, 0);
@@ -219,7 +243,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_d256_kernel(AttnArgs A)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's pieces of tile it + 1 have landed
         APROF(4);
         __builtin_amdgcn_s_barrier();                                     // ... and everybody else's; all reads of tile it are done
-        img ^= 2 * kTile;
+        sbase ^= 2 * kTile; tbase ^= 2 * kTile;
     }
 #ifdef ECGB_PROFILE
     if ((threadIdx.x & 63) == 0)
