@@ -133,6 +133,32 @@ def test_head_dim_256_attention_dma_staging_is_bitwise_the_register_staging(B, S
         ops.set_attn_fwd_staging(2)
 
 
+@pytest.mark.parametrize("B,S,Hq,Hkv", [(1, 1, 1, 1), (2, 63, 2, 2), (1, 64, 8, 1), (3, 65, 4, 1), (2, 127, 2, 1), (1, 128, 4, 4), (2, 129, 8, 2), (1, 191, 2, 1), (2, 192, 4, 2),
+                                        (1, 200, 8, 8), (2, 449, 8, 1), (1, 1000, 4, 2)])
+@pytest.mark.parametrize("pads", [False, True], ids=["full", "pads"])
+def test_head_dim_256_backward_kernels_at_the_edges_of_their_tiles(B, S, Hq, Hkv, pads):
+    """Round 6's head_dim-256 dQ and dK / dV kernels (csrc/attention_d256.hip: LDS reads scheduled by the compiler, LDS-DMA as asm, a two-stage ring whose dummy / ragged tiles
+    re-read the last row) at sequence lengths around the 64-row tile and the 128-row block, one to eight query heads a KV head (the dK / dV pair kernel splits a group's heads
+    over workgroups when the grid is small: fp32 slabs + the ordered reduction), with and without left padding: bit for bit the register-staged kernels."""
+    from ecg_byte_amd import decoder_ops as ops
+    D = 256
+    qkv, do = _bf(B * S, (Hq + 2 * Hkv) * D, seed=70 + S), _bf(B * S, Hq * D, seed=71 + S)
+    mask = torch.ones(B, S, device="cuda")
+    if pads:
+        for b in range(B):
+            mask[b, : (29 * b + 3) % max(1, S // 2 + 1)] = 0
+    try:
+        ops.set_attn_fwd_staging(0)
+        o0, l0 = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, 1 / 16)
+        d0 = ops.attn_bwd(qkv, mask, o0, do, l0, B, S, Hq, Hkv, D, 1 / 16)
+        ops.set_attn_fwd_staging(2)
+        for rep in range(2):
+            d1 = ops.attn_bwd(qkv, mask, o0, do, l0, B, S, Hq, Hkv, D, 1 / 16)
+            assert torch.equal(d0, d1), (rep, (d0.float() - d1.float()).abs().max().item())
+    finally:
+        ops.set_attn_fwd_staging(2)
+
+
 def _attn_ref_fp64(qkv, do, mask, B, S, Hq, Hkv, D, scale):
     """softmax(q k^T * scale + causal / padding mask) v and its gradients in float64 on the device, one batch row at a time."""
     q, k, v = qkv.view(B, S, Hq + 2 * Hkv, D).double().split([Hq, Hkv, Hkv], dim=2)
