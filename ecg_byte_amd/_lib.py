@@ -163,6 +163,8 @@ def lib():
         "ecgb_kv_append": [vp, ll, ll, ci, vp, ll, ci, vp, vp],
         "ecgb_argmax_bf16": [vp, ll, ci, ci, vp, vp],
         "ecgb_decode_advance": [vp, ci, vp, vp, vp, vp, vp, ll, vp, ll, vp, ll, vp, ci, vp],
+        "ecgb_decode_advance_e": [vp, ci, vp, vp, vp, vp, vp, ll, vp, ll, vp, ll, vp, ci, vp, vp],
+        "ecgb_gemm_nt_bf16_lora_decode": [vp, ll, vp, ll, vp, ll, f32, vp, ll, ci, vp, vp, ll, ci, ci, ci, vp, vp],
         "ecgb_rope_table": [vp, ci, vp, ci, vp, vp, vp],
         "ecgb_gemm_nt_w4_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, vp],
         "ecgb_gemm_nn_w4_bf16": [vp, ll, vp, ll, vp, ll, ci, ci, ci, f32, vp],

@@ -1198,7 +1198,7 @@ extern "C" int ecgb_rope_table(const int64_t *pos_dev, int n, const float *inv_f
 
 namespace {
 __global__ void decode_advance_kernel(const long long *next, int batch, long long *tok, long long *pos, long long *col, int *n_dev, long long *out, long long out_ld,
-                                      float *mask, long long mask_ld, long long *unfinished, long long pad_id, const long long *eos, int n_eos)
+                                      float *mask, long long mask_ld, long long *unfinished, long long pad_id, const long long *eos, int n_eos, int *epoch)
 {
     for (int b = threadIdx.x; b < batch; b += blockDim.x) {
         long long t = next[b];
@@ -1216,7 +1216,7 @@ __global__ void decode_advance_kernel(const long long *next, int batch, long lon
         pos[b] += 1;
         col[b] = c + 1;
     }
-    if (threadIdx.x == 0) *n_dev += 1;
+    if (threadIdx.x == 0) { *n_dev += 1; if (epoch) *epoch += 1; }
 }
 }  // namespace
 
@@ -1228,8 +1228,20 @@ extern "C" int ecgb_decode_advance(const int64_t *next_dev, int batch, int64_t *
         return ECGB_ERR_INVALID;
     }
     hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const long long *)next_dev, batch, (long long *)tok_dev, (long long *)pos_dev,
-                       (long long *)col_dev, n_dev, (long long *)out_dev, out_ld, mask_dev, mask_ld, (long long *)unfinished_dev, pad_id, (const long long *)eos_dev, n_eos);
+                       (long long *)col_dev, n_dev, (long long *)out_dev, out_ld, mask_dev, mask_ld, (long long *)unfinished_dev, pad_id, (const long long *)eos_dev, n_eos, (int *)nullptr);
     ECGB_CHECK_LAUNCH("decode_advance");
+}
+
+extern "C" int ecgb_decode_advance_e(const int64_t *next_dev, int batch, int64_t *tok_dev, int64_t *pos_dev, int64_t *col_dev, int *n_dev, int64_t *out_dev, long long out_ld,
+                                     float *mask_dev, long long mask_ld, int64_t *unfinished_dev, long long pad_id, const int64_t *eos_dev, int n_eos, int *epoch_dev, void *stream)
+{
+    if (!next_dev || !tok_dev || !pos_dev || !col_dev || !n_dev || !out_dev || !mask_dev || !epoch_dev || batch <= 0 || n_eos < 0 || (n_eos > 0 && (!eos_dev || !unfinished_dev))) {
+        ecgb::set_error("ecgb_decode_advance_e: bad argument");
+        return ECGB_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const long long *)next_dev, batch, (long long *)tok_dev, (long long *)pos_dev,
+                       (long long *)col_dev, n_dev, (long long *)out_dev, out_ld, mask_dev, mask_ld, (long long *)unfinished_dev, pad_id, (const long long *)eos_dev, n_eos, epoch_dev);
+    ECGB_CHECK_LAUNCH("decode_advance_e");
 }
 
 extern "C" int ecgb_embed_fwd(const int64_t *ids_dev, const void *table_dev, void *out_dev, size_t tokens, int hidden,

@@ -1707,18 +1707,32 @@ __global__ __launch_bounds__(512) void gemm_nn_kernel_m16pp(GemmArgs G)
 // across the wave.  Same accumulate modes as the tiled kernels.
 // KS = waves that share one output column, each with a contiguous 1/KS of the contraction (long rows, few columns: more
 // waves in flight); their sums meet in LDS.
-template <int MR, int KS>
-__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs G)
+// MODE 0: the product.  MODE 1 / 2 (round 6, gemm_nt_skinny_lora_kernel): the adapter's down-projection t = scale * x A^T and the projection that consumes it in ONE launch --
+// the launch's first workgroups run MODE 1 (the t columns: the same code and order of sums as a launch of their own; an element leaves as ONE 64-bit word, its bf16 bits under
+// the step's epoch, in a store other XCDs can see), the others MODE 2 (the projection: a wave asks for the K2 words of a row -- a lane a word, past its XCD's L2 -- together with
+// its first weight pieces, and looks at them behind its weight row; words that do not carry the epoch yet are asked for again).  Data and "it is there" in one word: one memory
+// round trip, under the weight row's own, where flags beside the data were three in a row behind it (measured: 12.3 us for the o site against 4.6 + 5.2 as two launches).
+// The epoch is a device word that grows by one a decode step (ecgb_decode_advance_e): nothing to reset, a replayed graph carries no per-step argument.
+struct SkinnySync { unsigned long long *t64; const int *epoch; int pre_blocks; };
+template <int MR, int KS, int MODE>
+__device__ __forceinline__ void skinny_body(const GemmArgs &G, const long long blk, float (*s_part)[MR], const SkinnySync &Y)
 {
-    __shared__ float s_part[4][MR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ks = wave % KS;
-    const long long n = (long long)blockIdx.x * (4 / KS) + wave / KS;
+    const long long n = blk * (4 / KS) + wave / KS;
     const bool live = n < G.N;
     const unsigned short *b = G.B + (live ? n : 0) * G.ldb;
     const int k_lo = ks * (G.K / KS), k_hi = k_lo + G.K / KS;      // G.K % (8 * KS) == 0 (checked by the launcher)
     float acc[MR];
 #pragma unroll
     for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+    unsigned long long tw[MR] = {};
+    if constexpr (MODE == 2) {
+        if (ks == 0) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+                if (m < G.M) tw[m] = __hip_atomic_load(&Y.t64[(long long)m * G.K2 + min(lane, G.K2 - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     // four 16-byte pieces of the weight row in flight per lane: with one, a long row (K = 16 384: 32 pieces per lane) is a chain
     // of 32 memory latencies
     constexpr int U = KS == 4 ? 8 : 4;                      // (a quarter of a 16 384-wide row: eight pieces, one round trip)
@@ -1745,14 +1759,38 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs G)
         }
     }
     if (G.K2 > 0 && ks == 0) {                               // second operand pair (the LoRA branch of a decode step: K2 = 64, one piece for eight lanes)
+        if constexpr (MODE == 2) {                           // t is being written by this launch's first workgroups: every word of the row must carry the step's epoch (K2 <= 64)
+            const unsigned long long want = (unsigned long long)(unsigned)*Y.epoch;
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                if (m < G.M) {
+                    while (!__all(lane >= G.K2 || (tw[m] >> 16) == want)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        tw[m] = __hip_atomic_load(&Y.t64[(long long)m * G.K2 + min(lane, G.K2 - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
+        float tg[MR][8];                                     // MODE 2: lane L takes t[8 L .. 8 L + 7] from the lanes that hold them (every lane of the wave takes part in the shuffles)
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tg[m][j] = __uint_as_float(((unsigned)__shfl((int)(unsigned)tw[m], (lane * 8 + j) & 63, 64) & 0xFFFFu) << 16);
+        }
         for (int k = lane * 8; k < G.K2; k += 512) {
             const bf16x8 vb = *reinterpret_cast<const bf16x8 *>(G.B2 + (live ? n : 0) * G.ldb2 + k);
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
                 if (m < G.M) {
-                    const bf16x8 va = *reinterpret_cast<const bf16x8 *>(G.A2 + (long long)m * G.lda2 + k);
+                    if constexpr (MODE == 2) {               // ... and adds the products in the order of the plain form
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[m] += __uint_as_float((unsigned)(unsigned short)va[j] << 16) * __uint_as_float((unsigned)(unsigned short)vb[j] << 16);
+                        for (int j = 0; j < 8; ++j) acc[m] += tg[m][j] * __uint_as_float((unsigned)(unsigned short)vb[j] << 16);
+                    } else {
+                        const bf16x8 va = *reinterpret_cast<const bf16x8 *>(G.A2 + (long long)m * G.lda2 + k);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[m] += __uint_as_float((unsigned)(unsigned short)va[j] << 16) * __uint_as_float((unsigned)(unsigned short)vb[j] << 16);
+                    }
                 }
             }
         }
@@ -1782,10 +1820,28 @@ __global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs G)
             if (G.accumulate_f32 == 1) reinterpret_cast<float *>(G.C)[(long long)m * G.ldc + n] += v;
             else {
                 unsigned short *q = reinterpret_cast<unsigned short *>(G.C) + (long long)m * G.ldc + n;
-                *q = f2bf_rn(G.accumulate_f32 == 2 ? __uint_as_float((unsigned)*q << 16) + v : v);
+                const unsigned short r = f2bf_rn(G.accumulate_f32 == 2 ? __uint_as_float((unsigned)*q << 16) + v : v);
+                if constexpr (MODE == 1)                     // (G.C is not written in this mode: the element and the epoch as one word)
+                    __hip_atomic_store(&Y.t64[(long long)m * G.N + n], ((unsigned long long)(unsigned)*Y.epoch << 16) | r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *q = r;
             }
         }
     }
+}
+template <int MR, int KS>
+__global__ __launch_bounds__(256) void gemm_nt_skinny_kernel(GemmArgs G)
+{
+    __shared__ float s_part[4][MR];
+    skinny_body<MR, KS, 0>(G, blockIdx.x, s_part, SkinnySync{});
+}
+// P: the adapter's down-projection (C = t, N = the t columns), G: the projection with A2 = t; grid = Y.pre_blocks + G's blocks (the t columns FIRST: they are dispatched first
+// and wait for nobody)
+template <int MR, int KS>
+__global__ __launch_bounds__(256) void gemm_nt_skinny_lora_kernel(GemmArgs G, GemmArgs P, SkinnySync Y)
+{
+    __shared__ float s_part[4][MR];
+    if ((int)blockIdx.x < Y.pre_blocks) skinny_body<MR, KS, 1>(P, blockIdx.x, s_part, Y);
+    else skinny_body<MR, KS, 2>(G, (long long)blockIdx.x - Y.pre_blocks, s_part, Y);
 }
 
 // The gate|up projection of a decode step with the GLU folded in: one wave per column n of H computes the gate column n and the up column n + glu_I (both weight rows
@@ -2154,6 +2210,39 @@ extern "C" int ecgb_gemm_nt_bf16_cat(const void *a_dev, long long lda, const voi
         ecgb::gemm_w4_applies(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K))
         return ecgb::gemm_w4_launch(a_dev, lda, b_dev, ldb, c_dev, ldc, M, N, K, alpha, stream, 0, nullptr, 0, a2_dev, lda2, b2_dev, ldb2, K2, nullptr, nullptr, 0, 0);
     return launch_gemm(G, 1, (hipStream_t)stream);
+}
+
+// One launch for a decode step's adapter site (o, down): t = t_scale * x A_lora^T by the launch's first workgroups (into t64_dev: [M, K2] 64-bit words, an element's bf16 bits
+// under the step's epoch), y = x W^T + t B_lora^T by the others (see skinny_body).  The bits of ecgb_gemm_nt_bf16(x, A_lora, alpha = t_scale) followed by
+// ecgb_gemm_nt_bf16_cat.  M <= 2, K2 <= 64; epoch_dev: a device word that differs from one call on this site to the next (ecgb_decode_advance_e adds one a step).
+extern "C" int ecgb_gemm_nt_bf16_lora_decode(const void *x_dev, long long ldx, const void *w_dev, long long ldw, const void *a_lora_dev, long long lda_lora, float t_scale,
+                                             const void *b_lora_dev, long long ldb_lora, int K2, unsigned long long *t64_dev, void *y_dev, long long ldy, int M, int N, int K,
+                                             const int *epoch_dev, void *stream)
+{
+    if (!x_dev || !w_dev || !a_lora_dev || !b_lora_dev || !t64_dev || !y_dev || !epoch_dev || M <= 0 || N <= 0 || K <= 0 || K2 <= 0) {
+        ecgb::set_error("ecgb_gemm_nt_bf16_lora_decode: bad argument");
+        return ECGB_ERR_INVALID;
+    }
+    if (M > 2 || K2 > 64 || K % BK || K2 % 8 || ldx % 8 || ldw % 8 || lda_lora % 8 || ldb_lora % 8 ||
+        (((uintptr_t)x_dev | (uintptr_t)w_dev | (uintptr_t)a_lora_dev | (uintptr_t)b_lora_dev) & 15) || ((uintptr_t)t64_dev & 7)) {
+        ecgb::set_error("ecgb_gemm_nt_bf16_lora_decode: one or two rows, K a multiple of 64, K2 <= 64, operands 16-byte aligned with strides % 8 == 0");
+        return ECGB_ERR_UNSUPPORTED;
+    }
+    const bool split = (K >= 8192 && K % 32 == 0 && N <= 8192);            // (ecgb_gemm_nt_bf16's rule; K2 <= 8192 always: both products take the same kernel form)
+    if (split != (K >= 8192 && K % 32 == 0)) { ecgb::set_error("ecgb_gemm_nt_bf16_lora_decode: the two products would take different kernels"); return ECGB_ERR_UNSUPPORTED; }
+    GemmArgs G{}, P{};
+    G.A = (const unsigned short *)x_dev; G.B = (const unsigned short *)w_dev; G.C = y_dev;
+    G.M = M; G.N = N; G.K = K; G.lda = ldx; G.ldb = ldw; G.ldc = ldy; G.accumulate_f32 = 0; G.alpha = 1.f;
+    G.A2 = nullptr; G.B2 = (const unsigned short *)b_lora_dev; G.lda2 = 0; G.ldb2 = ldb_lora; G.K2 = K2; G.div_a = G.div_b = 1;      // (A2: the words of t64_dev)
+    P.A = (const unsigned short *)x_dev; P.B = (const unsigned short *)a_lora_dev; P.C = t64_dev;
+    P.M = M; P.N = K2; P.K = K; P.lda = ldx; P.ldb = lda_lora; P.ldc = K2; P.accumulate_f32 = 0; P.alpha = t_scale; P.K2 = 0; P.div_a = P.div_b = 1;
+    SkinnySync Y{t64_dev, epoch_dev, split ? K2 : (K2 + 3) / 4};
+    const dim3 grid((unsigned)Y.pre_blocks + (split ? (unsigned)N : (unsigned)((N + 3) / 4)));
+    if (split) hipLaunchKernelGGL((gemm_nt_skinny_lora_kernel<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, G, P, Y);
+    else hipLaunchKernelGGL((gemm_nt_skinny_lora_kernel<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, G, P, Y);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ecgb::set_error(std::string("gemm_nt_skinny_lora_kernel: ") + hipGetErrorString(e)); return ECGB_ERR_HIP; }
+    return ECGB_OK;
 }
 
 extern "C" int ecgb_gemm_nt_bf16_heads(const void *a_dev, long long lda, const void *b_dev, long long ldb, void *c_dev,

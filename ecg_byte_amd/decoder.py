@@ -136,10 +136,11 @@ class LoraSite(nn.Module):
         lo = 16 * self.spb * b
         return lo, lo + self.r
 
-    def project(self, x, w, training, keep=False, glu=None, rope=None, t_pre=None):
+    def project(self, x, w, training, keep=False, glu=None, rope=None, t_pre=None, sync=None):
         """y = x W^T + the adapter branch, [T, out].  Returns (y, what backward needs).
         glu = (gelu_tanh, keep_gu): the site is the fused gate|up projection and the GLU runs in the GEMM's epilogue; y is then the pair
-        (gate|up or None, act(gate) * up)."""
+        (gate|up or None, act(gate) * up).  sync: the model's decode-step counter (int32[1], a new value every step) -- a decode step's o / down site then forms t and the
+        projection in ONE launch (ops.gemm_nt_lora_decode: the same bits)."""
         p, seed = 0.0, 0
         if training and self.p > 0:
             # One mask stream per (site, rank, call): data-parallel ranks draw DIFFERENT masks (torch's per-process generators give the
@@ -147,6 +148,10 @@ class LoraSite(nn.Module):
             # training -- and HipCausalLM.lora_rng_state() / set_lora_rng_state() carry it across a checkpoint.
             self.calls += 1
             p, seed = self.p, (self.seed + 7919 * self.calls + 104729 * _dp_rank()) & 0x7FFFFFFF
+        if sync is not None and t_pre is None and p == 0.0 and glu is None and rope is None and ops.lora_decode_ok(x.shape[0], w.shape[0], x.shape[1], self.A.shape[0]):
+            if getattr(self, "dec_t64", None) is None or self.dec_t64.device != x.device:
+                self.dec_t64 = torch.zeros((2, self.A.shape[0]), dtype=torch.int64, device=x.device)      # (the counter starts at 1: zero is no step's value)
+            return ops.gemm_nt_lora_decode(x, w, self.A.data, self.scale, self.B.data, self.dec_t64, sync), None
         if t_pre is not None and p == 0.0:          # a decode step whose norm kernel already formed t = scale * x A^T (ops.rmsnorm_fwd(lora=...))
             t, xd = t_pre, None
         elif x.shape[0] <= 8 and p == 0.0:          # a decode step: the few-row GEMM reads A once at HBM speed
@@ -227,6 +232,8 @@ class HipCausalLM(nn.Module):
     # own forward / backward do not (HipGPT2LM) sets this False and gets the plain in-stream step
     supports_optimizer_overlap = True
     decode_attn_one = True      # a decode step's RoPE + append + attention as one launch where the shape allows (ops.decode_one_ok); False: round 4's four launches, the same bits
+    decode_lora_one = False     # True: a decode step's o / down adapter sites form t = scale * x A^T inside the projection's launch (ops.gemm_nt_lora_decode: two launches a layer less, the same
+                                # bits) -- measured 503 against 508 tokens/s at the C5 shape: two dependent dot products and a hand-over between XCDs take what the launch boundary took
     def __init__(self, cfg: DecoderConfig, device="cuda", seed: int = 0):
         super().__init__()
         self.cfg = cfg
@@ -521,7 +528,7 @@ class HipCausalLM(nn.Module):
             return ops.gemm_nn_splitk(dy, p.data, splits)
         return ops.gemm_nt(dy, self._shadow(key, p))
 
-    def _proj(self, i, key, x, w, training=False, keep=False, rope=None, t_pre=None):
+    def _proj(self, i, key, x, w, training=False, keep=False, rope=None, t_pre=None, sync=None):
         """One projection of layer i ("qkv", "o", "gu", "down"): x W^T, plus the LoRA branch of the site when adapters are on
         (in the same launch).  rope = (cos, sin, columns): the q|k|v projection leaves with its q and k heads rotated (apply_rotary_pos_emb in the GEMM's
         epilogue where the kernel takes the shape, else as the separate pass).  Returns (y, what the adapter's backward needs or None)."""
@@ -529,7 +536,7 @@ class HipCausalLM(nn.Module):
             if rope is not None:
                 return ops.gemm_nt_rope(x, w, rope[0], rope[1], rope[2]), None
             return ops.gemm_nt(x, w), None
-        return self.lora[i][key].project(x, w, training, keep, rope=rope, t_pre=t_pre)
+        return self.lora[i][key].project(x, w, training, keep, rope=rope, t_pre=t_pre, sync=sync)
 
     def _proj_glu(self, i, x, training=False, keep=False, keep_gu=True, t_pre=None):
         """The MLP's gate|up projection with the GLU in the GEMM's epilogue: returns (gate|up [T, 2I] or None, act(gate) * up [T, I],
@@ -923,10 +930,11 @@ class HipCausalLM(nn.Module):
             ops.ce_fwd_bwd_(logits, shifted.index_select(0, r), inv_count, loss, c.vocab_size)
         return loss.squeeze(0)
 
-    def _decode_step(self, tokens, pos, mask, caches, n, n_dev=None, scratch=None, scratch_one=None):
+    def _decode_step(self, tokens, pos, mask, caches, n, n_dev=None, scratch=None, scratch_one=None, epoch_advanced=False):
         """Hidden state [B, H] of one new token per sequence, written at cache row n-1 (n = keys valid after the update).
         n_dev: int32[1] device tensor holding n -- then nothing in the launches depends on the step (graph replay); scratch: the
-        split decode attention's buffer the captured step owns (scratch_one: the one-launch attention's)."""
+        split decode attention's buffer the captured step owns (scratch_one: the one-launch attention's).  epoch_advanced: the caller advances the model's step counter
+        itself (ops.decode_advance_(epoch=...) behind the step, as the captured loop does); else the step does it here, a launch of its own."""
         c = self.cfg
         D, Hq, Hkv = c.head_dim, c.num_attention_heads, c.num_key_value_heads
         QKV = self.qkv
@@ -937,6 +945,13 @@ class HipCausalLM(nn.Module):
             cos, sin = self._rope_tables(pos)
         x = ops.embed_fwd(tokens, self.embed.data, self.embed_scale)    # [B, H]
         delta = None
+        # round 6: the o and down sites of a step with adapters form t = scale * x A^T inside the projection's launch (two launches a layer less), the launch's workgroups meeting
+        # on flags that hold the model's step counter -- a device word with a new value every step
+        sync = None
+        if self.lora is not None and not self.training and self.decode_lora_one:
+            sync = self._decode_epoch(x.device)
+            if not epoch_advanced:
+                sync.add_(1)
         # (opt-in: the fused kernels of csrc/decode.hip are bit-exact but measured no faster than the separate ones at the C5 shape -- 2.20 against 2.14 ms a token; every
         #  kernel of the step sits on the ~5 us a dependent launch of a replayed graph costs, whatever it fuses: profiles/r05/README.md)
         if getattr(self, "decode_fused", False) and not self.training and ops.decode_fusable(x.shape[0], c.hidden_size, Hq, Hkv, D):
@@ -961,16 +976,23 @@ class HipCausalLM(nn.Module):
                     ao = ops.attn_decode(qkv, caches[i], mask, n, Hq, Hkv, D, scale)
                 else:
                     ao = ops.attn_decode_dyn(qkv, caches[i], mask, n_dev, Hq, Hkv, D, scale)
-            attn_delta, _ = self._proj(i, "o", ao, self.wo[i].data)
+            attn_delta, _ = self._proj(i, "o", ao, self.wo[i].data, sync=sync)
             if self.lora is not None and not self.training:             # (the gate|up site's t on the norm's way out too: one launch less a layer, the same bits)
                 site = self.lora[i]["gu"]
                 h2, _, x, t2 = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma, lora=(site.A.data, site.scale))
             else:
                 (h2, _, x), t2 = ops.rmsnorm_fwd(x, self.ln2[i].data, c.rms_norm_eps, residual=attn_delta, gemma=self.gemma), None
             _, hm, _ = self._proj_glu(i, h2, keep_gu=False, t_pre=t2)
-            delta, _ = self._proj(i, "down", hm, self.wdown[i].data)
+            delta, _ = self._proj(i, "down", hm, self.wdown[i].data, sync=sync)
         hf, _, _ = ops.rmsnorm_fwd(x, self.norm.data, c.rms_norm_eps, residual=delta, gemma=self.gemma)
         return hf
+
+    def _decode_epoch(self, dev):
+        """The decode steps' counter (int32[1] on the device, 1 at first, + 1 every step for the model's lifetime)."""
+        e = self.__dict__.get("_dec_epoch")
+        if e is None or e.device != dev:
+            e = self.__dict__["_dec_epoch"] = torch.ones(1, dtype=torch.int32, device=dev)
+        return e
 
     def _decode_layers_fused(self, x, cos, sin, mask, caches, n):
         """The layers of a decode step for one or two sequences on the fused kernels of csrc/decode.hip: per layer q|k|v with its norm and adapter branch in one launch,
@@ -1181,7 +1203,7 @@ class HipCausalLM(nn.Module):
         cap = -(-(S0 + max_new_tokens) // 128) * 128
         pad_id = pad_token_id if pad_token_id is not None else 0
         key = (B, cap, pad_id, None if eos is None else tuple(int(e) for e in eos.tolist()), sampling, self.training, self.embed.data_ptr(),
-               None if self.lora is None else self.lora[0]["qkv"].A.data_ptr(), self.wqkv[0].data_ptr(), bool(self.decode_attn_one))      # (the last: base weights or their merged copies)
+               None if self.lora is None else self.lora[0]["qkv"].A.data_ptr(), self.wqkv[0].data_ptr(), bool(self.decode_attn_one), bool(self.decode_lora_one))      # (the last: base weights or their merged copies)
         graphs = self.__dict__.setdefault("_gen_graphs", {})
         st = graphs.get(key) if sampling is None else None                   # (a sampling step holds torch's sort / cumsum / multinomial: captured per call, see below)
         if st is None:
@@ -1232,11 +1254,12 @@ class HipCausalLM(nn.Module):
         eos_i64 = None if eos_s is None else eos_s.to(torch.int64).contiguous()
 
         def step():
-            last = self._decode_step(tok, pos, gmask, caches, None, n_dev, scratch=st.scratch, scratch_one=st.scratch_one)
+            one = self.lora is not None and not self.training and self.decode_lora_one
+            last = self._decode_step(tok, pos, gmask, caches, None, n_dev, scratch=st.scratch, scratch_one=st.scratch_one, epoch_advanced=one)
             nx = pick(ops.gemm_nt(last, self.embed.data))
             # pad for finished sequences, the eos test, the token into `out` and `tok`, the mask's new column, the three counters: one launch (six to eleven
             # element-wise ones before, 5 us each in the replayed graph)
-            ops.decode_advance_(nx.to(torch.int64), tok, pos, col, n_dev, out, gmask, unfinished, pad_id, eos_i64)
+            ops.decode_advance_(nx.to(torch.int64), tok, pos, col, n_dev, out, gmask, unfinished, pad_id, eos_i64, epoch=self._decode_epoch(dev) if one else None)
 
         if st.graph is None:
             state = (tok, pos, n_dev, col, unfinished, out, gmask)

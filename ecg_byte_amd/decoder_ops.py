@@ -122,15 +122,38 @@ def rope_table(pos, inv_freq):
     return cos, sin
 
 
-def decode_advance_(nxt, tok, pos, col, n_dev, out, mask, unfinished=None, pad_id=0, eos=None):
+def decode_advance_(nxt, tok, pos, col, n_dev, out, mask, unfinished=None, pad_id=0, eos=None, epoch=None):
     """The bookkeeping of one generated token per sequence in one launch (ecgb_decode_advance): finished sequences take pad_id, the token goes to out[:, col] and into
-    `tok`, mask[:, col] = 1, pos / col / n_dev advance, `unfinished` drops sequences that produced an eos id.  Everything in place."""
+    `tok`, mask[:, col] = 1, pos / col / n_dev advance, `unfinished` drops sequences that produced an eos id.  Everything in place.  epoch (int32[1]): += 1 too
+    (ecgb_decode_advance_e: the step counter of the one-launch adapter sites)."""
     B = nxt.shape[0]
     assert nxt.dtype == torch.int64 and out.dtype == torch.int64 and mask.dtype == torch.float32 and n_dev.dtype == torch.int32
     assert out.stride(1) == 1 and mask.stride(1) == 1 and col.numel() == B and tok.numel() == B and pos.numel() == B
     n_eos = 0 if eos is None else int(eos.numel())
+    if epoch is not None:
+        assert epoch.dtype == torch.int32 and epoch.numel() == 1
+        _lib.check(_L().ecgb_decode_advance_e(_p(nxt), B, _p(tok), _p(pos), _p(col), _p(n_dev), _p(out), out.stride(0), _p(mask), mask.stride(0),
+                                              _p(unfinished) if n_eos else None, int(pad_id), _p(eos) if n_eos else None, n_eos, _p(epoch), _st()))
+        return
     _lib.check(_L().ecgb_decode_advance(_p(nxt), B, _p(tok), _p(pos), _p(col), _p(n_dev), _p(out), out.stride(0), _p(mask), mask.stride(0),
                                         _p(unfinished) if n_eos else None, int(pad_id), _p(eos) if n_eos else None, n_eos, _st()))
+
+
+def lora_decode_ok(M, N, K, K2=64):
+    """Does ecgb_gemm_nt_bf16_lora_decode take the site (one or two rows; both products in the same column-per-wave kernel)?"""
+    return M <= 2 and K2 <= 64 and K % 64 == 0 and not (K >= 8192 and K % 32 == 0 and N > 8192)
+
+
+def gemm_nt_lora_decode(x, w, lora_a, t_scale, lora_b, t64, epoch):
+    """A decode step's adapter site in one launch (ecgb_gemm_nt_bf16_lora_decode): y = x W^T + (t_scale * x A^T) B^T, the bits of gemm_nt(x, A, alpha=t_scale) followed by
+    gemm_nt(x, w, a2=t, b2=B).  t64: int64[M, K2] owned by the site (t's bf16 bits under the epoch, zeros at first); epoch: int32[1], a value no earlier call on the site had."""
+    M, K = x.shape
+    N, K2 = w.shape[0], lora_a.shape[0]
+    assert lora_a.shape[1] == K and lora_b.shape == (N, K2) and t64.dtype == torch.int64 and t64.numel() >= M * K2 and epoch.dtype == torch.int32
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_L().ecgb_gemm_nt_bf16_lora_decode(_p(x), x.stride(0), _p(w), w.stride(0), _p(lora_a), lora_a.stride(0), float(t_scale), _p(lora_b), lora_b.stride(0), K2,
+                                                   _p(t64), _p(y), y.stride(0), M, N, K, _p(epoch), _st()))
+    return y
 
 
 def argmax_rows(x, n=None):

@@ -89,6 +89,16 @@ int ecgb_gemm_nt_bf16(const void *a_dev, long long lda, const void *b_dev, long 
 int ecgb_gemm_nt_bf16_cat(const void *a_dev, long long lda, const void *b_dev, long long ldb, const void *a2_dev, long long lda2,
                           const void *b2_dev, long long ldb2, int K2, void *c_dev, long long ldc, int M, int N, int K, float alpha,
                           int accumulate_f32, void *stream);
+/* A decode step's adapter site (o, down: peft LoraLayer.forward at one or two rows, M <= 2) in ONE launch instead of two: the launch's first workgroups form
+ * t[M, K2] = t_scale * x . lora_A^T, the others y[M, N] = x . W^T + t . lora_B^T.  t travels through t64_dev ([M, K2] 64-bit words owned by the site, K2 <= 64): an element's
+ * bf16 bits under the value of *epoch_dev in bits 16 .. 47, ONE store that other XCDs can see; a wave of the projection asks for the row's words with its first weight pieces
+ * and uses them behind its weight row once every word carries the epoch.  *epoch_dev must differ from one call on the site to the next (ecgb_decode_advance_e adds one a
+ * step; a fresh t64_dev must hold no current epoch: zeros, the counter starting at 1).  The bits of ecgb_gemm_nt_bf16(x, lora_A, alpha = t_scale) followed by
+ * ecgb_gemm_nt_bf16_cat: every sum in the same order (tests/test_gpu_decode_fused.py).  ECGB_ERR_UNSUPPORTED where the two products would take different column-per-wave kernels
+ * (N > 8192 with K >= 8192), M > 2 or K2 > 64: use the two calls. */
+int ecgb_gemm_nt_bf16_lora_decode(const void *x_dev, long long ldx, const void *w_dev, long long ldw, const void *a_lora_dev, long long lda_lora, float t_scale,
+                                  const void *b_lora_dev, long long ldb_lora, int K2, unsigned long long *t64_dev, void *y_dev, long long ldy, int M, int N, int K,
+                                  const int *epoch_dev, void *stream);
 
 /* LoRA adapter branch (peft LoraLayer, ecg_byte/main.py:131-155), stacked adapters of a fused projection.  The stacked down-projection
  * has n_sub 16-row sub-blocks (a_dev = [16 * n_sub, in]) split evenly over n_fields modules ("blocks": q | k | v share one x but each
@@ -377,6 +387,9 @@ int ecgb_rope_table(const int64_t *pos_dev, int n, const float *inv_freq_dev, in
  * and *n_dev += 1.  All int64 except mask (float32) and n_dev (int32[1]); eos_dev may be NULL (n_eos 0): `unfinished` is then neither read nor written. */
 int ecgb_decode_advance(const int64_t *next_dev, int batch, int64_t *tok_dev, int64_t *pos_dev, int64_t *col_dev, int *n_dev, int64_t *out_dev, long long out_ld,
                         float *mask_dev, long long mask_ld, int64_t *unfinished_dev, long long pad_id, const int64_t *eos_dev, int n_eos, void *stream);
+/* The same, and *epoch_dev += 1 (int32[1]): the step counter the one-launch adapter sites of a replayed decode step synchronise on (ecgb_gemm_nt_bf16_lora_decode). */
+int ecgb_decode_advance_e(const int64_t *next_dev, int batch, int64_t *tok_dev, int64_t *pos_dev, int64_t *col_dev, int *n_dev, int64_t *out_dev, long long out_ld,
+                          float *mask_dev, long long mask_ld, int64_t *unfinished_dev, long long pad_id, const int64_t *eos_dev, int n_eos, int *epoch_dev, void *stream);
 
 /* ---- the decode step of generate() for one or two sequences, fused (csrc/decode.hip; round 5) -----------------------------------------------------------------
  * Replaces, per layer and token: ecgb_rmsnorm_lora_fwd + ecgb_gemm_nt_bf16_cat (q|k|v), ecgb_rope_append + ecgb_attn_decode_split (three kernels), the few-row GEMMs of

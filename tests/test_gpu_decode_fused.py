@@ -238,3 +238,62 @@ def test_one_launch_attention_with_nan_inputs_returns(ops):
     torch.cuda.synchronize()
     assert bool(torch.isnan(out.float()).any())
     assert bool((scratch.view(torch.int32)[: B * Hq * ns * 2] == 0x7FC0DEAD).all())
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 2048, 2048), (2, 2048, 2048), (1, 16384, 2048), (2, 16384, 2048), (1, 512, 1536), (1, 8192, 512), (1, 2048, 8200)])
+def test_one_launch_adapter_site_equals_the_two_launches(ops, M, K, N):
+    """Round 6: a decode step's o / down adapter site -- t = scale * x A^T by the launch's first workgroups, x W^T + t B^T by the others, t handed over in 64-bit words that carry a step
+    counter (ecgb_gemm_nt_bf16_lora_decode) -- against the launch pair it replaces, bit for bit, over several steps on ONE word buffer (every step a new counter value, as
+    ecgb_decode_advance_e gives it: the words of the step before are stale, not wrong)."""
+    w, a, b = _bf(N, K, scale=0.05, seed=1), _bf(64, K, scale=0.05, seed=2), _bf(N, 64, scale=0.1, seed=3)
+    a[48:] = 0                                                                  # (a site of three modules: rows past 16 * n_sub are zero)
+    t64 = torch.zeros((M, 64), dtype=torch.int64, device="cuda")
+    epoch = torch.ones(1, dtype=torch.int32, device="cuda")
+    assert ops.lora_decode_ok(M, N, K)
+    for step in range(6):
+        x = _bf(M, K, seed=10 + step)
+        t_ref = ops.gemm_nt(x, a, alpha=0.5)
+        y_ref = ops.gemm_nt(x, w, a2=t_ref, b2=b)
+        y = ops.gemm_nt_lora_decode(x, w, a, 0.5, b, t64, epoch)
+        assert torch.equal(y, y_ref), step
+        assert torch.equal((t64 & 0xFFFF).to(torch.int16).view(torch.bfloat16), t_ref) and bool(((t64 >> 16) == epoch.long()).all())
+        epoch += 1
+
+
+def test_one_launch_adapter_site_refuses_what_the_two_kernels_would_split_differently(ops):
+    from ecg_byte_amd import _lib
+    assert not ops.lora_decode_ok(1, 16384, 8192) and not ops.lora_decode_ok(3, 2048, 2048)
+    x, w, a, b = _bf(1, 8192), _bf(16384, 8192, scale=0.05), _bf(64, 8192, scale=0.05), _bf(16384, 64)
+    with pytest.raises(_lib.EcgbError):
+        ops.gemm_nt_lora_decode(x, w, a, 1.0, b, torch.zeros((1, 64), dtype=torch.int64, device="cuda"), torch.ones(1, dtype=torch.int32, device="cuda"))
+
+
+@pytest.mark.parametrize("family", ["llama", "gemma"])
+def test_generate_with_one_launch_adapter_sites_equals_the_separate_launches(family):
+    """generate() with adapters: the o / down sites as one launch each (opt-in: decode_lora_one) against the launch pairs, token for token and logit for logit, the eager loop and the replayed
+    graph (whose warm-up step, capture and first replay all see the same cache length: the step counter is what tells their launches apart), twice on one captured graph."""
+    from ecg_byte_amd.decoder import DecoderConfig, HipCausalLM
+    kw = dict(vocab_size=1000, hidden_size=512, intermediate_size=2048, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=2, head_dim=64, pad_token_id=999)
+    if family == "gemma":
+        kw.update(model_type="gemma", num_key_value_heads=1, head_dim=256, num_attention_heads=4, rms_norm_eps=1e-6, intermediate_size=8192)    # (8 192: the down site's four-wave columns)
+    m = HipCausalLM(DecoderConfig(**kw), seed=5)
+    m.enable_lora(r=16, alpha=32, dropout=0.05)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    with torch.no_grad():
+        for sites in m.lora:
+            for s in sites.values():
+                s.B.copy_((torch.randn(s.B.shape, device="cuda", generator=g) * 0.05).to(torch.bfloat16) * s.bmask)
+    m.eval()
+    ids = torch.randint(0, 990, (1, 300), device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    mask = torch.ones(1, 300, device="cuda")
+    mask[0, :7] = 0
+    outs = {}
+    for one in (False, True):
+        m.decode_lora_one = one
+        seq, logits = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=12, pad_token_id=999, return_logits=True, use_graph=False)
+        seq_g = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=12, pad_token_id=999)
+        seq_g2 = m.generate(input_ids=ids, attention_mask=mask, max_new_tokens=12, pad_token_id=999)     # the captured step replayed by a second call
+        assert torch.equal(seq, seq_g) and torch.equal(seq, seq_g2), one
+        outs[one] = (seq, logits)
+    m.decode_lora_one = False
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
