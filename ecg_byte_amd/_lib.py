@@ -125,6 +125,7 @@ def lib():
         "ecgb_embed_fwd": [vp, vp, vp, sz, ci, f32, vp],
         "ecgb_embed_bwd": [vp, vp, vp, sz, ci, f32, vp],
         "ecgb_set_attn_fwd_staging": [ci],
+        "ecgb_set_attn_d256_pass_p": [ci],
         "ecgb_set_ce_in_registers": [ci],
         "ecgb_set_rmsnorm_fwd_rows": [ci],
         "ecgb_set_rmsnorm_bwd_rows_per_wg": [ci],

@@ -1923,6 +1923,10 @@ __global__ __launch_bounds__(kSplitThreads) void attn_decode_one_kernel(DecodeOn
 // head_dim 64 forward and backward: 2 = the lean kernels (LDS-DMA staging, softmax constants in the MFMA accumulators: the default), 1 = the round-2 LDS-DMA
 // kernels, 0 = the register-staged kernels (tests / A-B).  Bits 8 / 9 / 10 send the forward / dQ / dK-dV kernel alone back to mode 1 (A-B of one kernel).
 int g_attn_dma = 2;
+// head_dim 256 backward: 0 (default) = the pair kernel (the dK pass and the dV pass each form the scores), 1 = the dK pass hands its probabilities to a dV kernel through the
+// scratch (ecgb_attn_bwd_scratch_bytes then asks for batch * heads * seq^2 bf16 more).  Measured at the C5 shape: 270 + 131 us against the pair's 447, 0.66 against 0.68 ms
+// for the whole backward -- not worth a transient S x S tensor in HBM by default (ecgb_set_attn_d256_pass_p; the same bits either way)
+int g_attn_d256_pass_p = 0;
 
 // waves per workgroup of the lean kernels: 4 (default; two workgroups per CU) or 8 (one workgroup per CU, a K / V tile serves twice the rows: measured 15 %
 // slower end to end at the C3 shape although its tile loop is faster -- scripts/experiments/r03_attn_fwd_pingpong.hip.txt; kept for A-B: ecgb_set_attn_lean_waves)
@@ -2211,11 +2215,21 @@ int dkv_head_splits(int batch, int seq, int n_q_heads, int n_kv_heads, int head_
 }
 }  // namespace
 
+namespace {
+// head_dim 256 (round 6): room for the probabilities the dK pass hands to the dV kernel (AttnArgs::pbuf), bf16 over whole 128-key x 64-query tiles
+size_t attn_bwd_p_bytes(int batch, int seq, int n_q_heads, int head_dim)
+{
+    if (head_dim != 256 || !g_attn_d256_pass_p) return 0;
+    return (size_t)batch * n_q_heads * ((seq + 127) / 128) * ((seq + 63) / 64) * (128 * 64 * 2);
+}
+}  // namespace
+
 extern "C" size_t ecgb_attn_bwd_scratch_bytes(int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim)
 {
     if (batch <= 0 || seq <= 0 || n_q_heads <= 0 || n_kv_heads <= 0 || n_q_heads % n_kv_heads) return 0;
     const int hs = dkv_head_splits(batch, seq, n_q_heads, n_kv_heads, head_dim);
-    return hs > 1 ? (size_t)2 * hs * batch * seq * n_kv_heads * head_dim * sizeof(float) : 0;
+    const size_t slabs = hs > 1 ? (size_t)2 * hs * batch * seq * n_kv_heads * head_dim * sizeof(float) : 0;
+    return slabs + attn_bwd_p_bytes(batch, seq, n_q_heads, head_dim);
 }
 
 namespace {
@@ -2238,11 +2252,14 @@ int attn_bwd_impl(const void *q_dev, long long ldq, const void *k_dev, long long
     if (lddq % 4 || lddk % 4 || lddv % 4) { ecgb::set_error("ecgb_attn_bwd: gradient row strides must be multiples of 4"); return ECGB_ERR_UNSUPPORTED; }
     A.head_splits = dkv_head_splits(batch, seq, n_q_heads, n_kv_heads, head_dim);
     A.slab = (float *)scratch_dev;
-    if (A.head_splits > 1 && (!scratch_dev || ((uintptr_t)scratch_dev & 15) ||
-                              scratch_bytes < ecgb_attn_bwd_scratch_bytes(batch, seq, n_q_heads, n_kv_heads, head_dim))) {
-        ecgb::set_error("ecgb_attn_bwd: scratch of ecgb_attn_bwd_scratch_bytes() bytes (16-byte aligned) required for this shape");
+    const size_t slab_bytes = A.head_splits > 1 ? (size_t)2 * A.head_splits * batch * seq * n_kv_heads * head_dim * sizeof(float) : 0;
+    if (A.head_splits > 1 && (!scratch_dev || ((uintptr_t)scratch_dev & 15) || scratch_bytes < slab_bytes)) {
+        ecgb::set_error("ecgb_attn_bwd: scratch for the partial dK / dV slabs (16-byte aligned; ecgb_attn_bwd_scratch_bytes() says how much) required for this shape");
         return ECGB_ERR_INVALID;
     }
+    // (head_dim 256: with the whole of ecgb_attn_bwd_scratch_bytes() the dK pass hands its probabilities to the dV kernel; with the slabs' share alone the dV pass forms them again)
+    const size_t p_bytes = attn_bwd_p_bytes(batch, seq, n_q_heads, head_dim);
+    const bool pass_p = g_attn_d256_pass_p && p_bytes > 0 && scratch_dev && ((uintptr_t)scratch_dev & 15) == 0 && scratch_bytes >= slab_bytes + p_bytes;
     const unsigned nblk = (unsigned)((seq + 127) / 128);
     const dim3 gq(nblk * (unsigned)n_q_heads * (unsigned)batch);          // 1-D: map_block() deals blocks to XCDs
     const unsigned gk = nblk * (unsigned)n_kv_heads * (unsigned)batch;
@@ -2282,7 +2299,14 @@ int attn_bwd_impl(const void *q_dev, long long ldq, const void *k_dev, long long
     else rc = dq_generic(attn_bwd_dq_kernel<256>, 256, "attn_bwd_dq_kernel<256>");
     if (rc) return rc;
     if ((g_attn_dma & 3) && (ldq & 7) == 0 && (ldo & 7) == 0 && (((uintptr_t)q_dev | (uintptr_t)do_dev) & 15) == 0 && 64 * ldq * 2 + 512 <= 0xFFFFFFFFll && 64 * ldo * 2 + 512 <= 0xFFFFFFFFll)
-        rc = ecgb_attn::launch_bwd_dkv_pair_d256(A, gk * 2 * (unsigned)A.head_splits, stream);
+    {
+        if (pass_p) {
+            A.pbuf = reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(scratch_dev) + slab_bytes);
+            rc = ecgb_attn::launch_bwd_dk_then_dv_d256(A, gk * (unsigned)A.head_splits, stream);
+        } else {
+            rc = ecgb_attn::launch_bwd_dkv_pair_d256(A, gk * 2 * (unsigned)A.head_splits, stream);
+        }
+    }
     else
         rc = launch_attn(attn_bwd_dkv_pair_kernel<256>, dim3(gk * 2 * (unsigned)A.head_splits), dim3(256), 4 * 128 * 256 + 512, stream, A, "attn_bwd_dkv_pair_kernel<256>");
     if (rc) return rc;
@@ -2508,6 +2532,8 @@ extern "C" int ecgb_set_attn_lean_waves(int waves)
     g_lean_waves = waves;
     return ECGB_OK;
 }
+extern "C" int ecgb_set_attn_d256_pass_p(int on) { g_attn_d256_pass_p = on ? 1 : 0; return ECGB_OK; }
+
 extern "C" int ecgb_set_attn_fwd_staging(int mode)
 {
     if ((mode & 3) == 3 || (mode & ~0x703)) { ecgb::set_error("ecgb_set_attn_fwd_staging: mode 0, 1 or 2 (| 0x100 | 0x200 | 0x400)"); return ECGB_ERR_INVALID; }

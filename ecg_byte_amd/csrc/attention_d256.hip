@@ -367,7 +367,7 @@ __device__ __forceinline__ void attn_bwd_dkv_d256_body(const AttnArgs &A, const 
         }
     };
     unsigned img = 0;
-    int t0 = t_begin;
+    int t0 = t_begin, hq_cur = 0;                            // the step at hand: its tile's first query, its head (of this workgroup's)
 #ifdef ECGB_PROFILE
     unsigned long long prof_acc[7] = {};
     long long t_prof = clock64();
@@ -448,6 +448,14 @@ __device__ __forceinline__ void attn_bwd_dkv_d256_body(const AttnArgs &A, const 
                     }
                 }
                 const bf16x8 f0 = frag_from_acc(DO_V ? &pr[0] : &ds[0]), f1 = frag_from_acc(DO_V ? &pr[8] : &ds[8]);
+                if constexpr (DO_K) {
+                    if (A.pbuf) {                                                // (uniform) the probabilities as the dV products' fragments: 2 x 1 KiB a wave and query half, coalesced
+                        const long long piece = ((((((long long)b * A.Hq + (g * G + head_lo + hq_cur)) * ((A.S + 127) / 128) + kblk) * ((A.S + 63) / 64) + t0 / 64) * 4 + wave) * 2 + qb) * 2;
+                        bf16x8 *dst = reinterpret_cast<bf16x8 *>(A.pbuf) + piece * 64 + lane;
+                        dst[0] = frag_from_acc(&pr[0]);
+                        dst[64] = frag_from_acc(&pr[8]);
+                    }
+                }
                 APROF(1);
 #pragma unroll
                 for (int dpair = 0; dpair < D / 64; ++dpair) {
@@ -482,7 +490,7 @@ __device__ __forceinline__ void attn_bwd_dkv_d256_body(const AttnArgs &A, const 
         APROF(4);
         __builtin_amdgcn_s_barrier();
         img = img ? 0u : (unsigned)kStage;
-        t0 = t0 + 64 >= t_begin + tiles_per_head * 64 ? t_begin : t0 + 64;
+        if (t0 + 64 >= t_begin + tiles_per_head * 64) { t0 = t_begin; ++hq_cur; } else t0 += 64;
     }
 #ifdef ECGB_PROFILE
     if ((threadIdx.x & 63) == 0)
@@ -497,6 +505,154 @@ __device__ __forceinline__ void attn_bwd_dkv_d256_body(const AttnArgs &A, const 
     }
     if constexpr (DO_K) store_accT<NB>(acc, A.dk + (long long)g * D, A.lddk, rowbase + ki, kvalid, h, 1.f);
     if constexpr (DO_V) store_accT<NB>(acc, A.dv + (long long)g * D, A.lddv, rowbase + ki, kvalid, h, 1.f);
+}
+// head_dim 256 dV from the probabilities the dK pass left (A.pbuf): dV = sum over the group's heads and the query tiles of dO^T . P for a block of 128 keys, a wave 32 keys.
+// No scores, no softmax, no K: a step is the tile's dO image by LDS-DMA (a ring of two), the wave's P fragments by two 16-byte loads a query half (a step ahead, in
+// registers) and 32 products whose transposing reads issue under the products of the group before.  The products and their order are the pair kernel's dV pass: the same bits.
+__global__ __launch_bounds__(256, 1) void attn_bwd_dv_d256_kernel(AttnArgs A)
+{
+    constexpr int D = 256, kRow = D * 2, kTile = 64 * kRow, PPW = 8, NB = D / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                         // 2 x the dO image
+    const int hs = A.head_splits > 1 ? A.head_splits : 1;
+    int blk, head_in, group;
+    map_block((int)blockIdx.x, ((A.S + 127) / 128) * hs, 1, A.B * A.Hkv, false, blk, head_in, group);
+    const int hsplit = blk % hs, kblk = blk / hs, b = group / A.Hkv, g = group % A.Hkv;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 31, h = lane >> 5;
+    const int G = A.Hq / A.Hkv;
+    const int kk0 = kblk * 128;
+    const int ki = kk0 + wave * 32 + lr;
+    const bool kvalid = ki < A.S;
+    const long long rowbase = (long long)b * A.S;
+    const int wave_kmin = kk0 + wave * 32;
+    const int t_begin = (kk0 / 64) * 64;
+    const int tiles_per_head = (A.S - t_begin + 63) / 64;
+    const int heads_here = G / hs, head_lo = hsplit * heads_here;
+    const int n_steps = heads_here * tiles_per_head;
+    const int tail_rows = A.S - (t_begin + (tiles_per_head - 1) * 64);
+    const int r0 = wave * (2 * PPW) + (lane >> 5);
+    const unsigned chunk0 = (unsigned)((((lane & 31) ^ ((lane >> 5) << 2)) * 8) * 2);
+    const unsigned ldo2 = (unsigned)(A.ldo * 2);
+    int hq_next = 0, ti_next = 0, left_next = n_steps - 1;
+    unsigned slot_next = 0;
+    const unsigned char *o_next;
+    const bf16x8 *p_next;                                    // the next step's P pieces of this wave
+    int rmax_next, t0_next;
+    auto point_next = [&]() {
+        const int hq = g * G + head_lo + hq_next;
+        t0_next = t_begin + ti_next * 64;
+        o_next = reinterpret_cast<const unsigned char *>(A.d_o + (long long)hq * D + (rowbase + t0_next) * A.ldo);
+        p_next = reinterpret_cast<const bf16x8 *>(A.pbuf) + ((((((long long)b * A.Hq + hq) * ((A.S + 127) / 128) + kblk) * ((A.S + 63) / 64) + t0_next / 64) * 4 + wave) * 4) * 64 + lane;
+        rmax_next = (ti_next == tiles_per_head - 1 && tail_rows < 64) ? tail_rows - 1 : 63;
+    };
+    point_next();
+    auto issue_piece = [&](int i) __attribute__((always_inline)) {
+        const unsigned off = (unsigned)min(r0 + 2 * i, rmax_next) * ldo2 + (chunk0 ^ (unsigned)((((i & 1) << 3) | (i >> 1)) << 4));
+        lds_dma16(smem + slot_next + (wave * PPW + i) * 1024, o_next, off);
+    };
+    bf16x8 pn[4] = {};                                       // the next step's fragments: [query half][k-step]; a step this wave skips left no P behind and asks for none
+    auto load_p = [&]() __attribute__((always_inline)) {
+        if (t0_next + 63 >= wave_kmin) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pn[j] = p_next[j * 64];
+        }
+    };
+    auto advance_next = [&]() {
+        if (left_next > 0) {
+            --left_next;
+            if (++ti_next == tiles_per_head) { ti_next = 0; ++hq_next; }
+            point_next();
+        }
+        slot_next ^= (unsigned)kTile;
+    };
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_piece(i);
+    load_p();
+    advance_next();
+    f32x16 acc[NB];
+#pragma unroll
+    for (int db = 0; db < NB; ++db) acc[db] = splat16(0.f);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned tbaseA, tbaseB;
+    {
+        const int a = lr >> 4, q = (lr & 15) >> 2, p = lr & 3;
+        const int cg = 2 * a + (p >> 1);
+        const int k1 = 4 * h + q, k2 = k1 + 8;
+        tbaseA = k1 * kRow + ((((k1 & 3) << 2) | (cg ^ ((k1 >> 2) & 3))) << 4) + (p & 1) * 8;
+        tbaseB = k2 * kRow + ((((k2 & 3) << 2) | (cg ^ ((k2 >> 2) & 3))) << 4) + (p & 1) * 8;
+    }
+    auto load_tr = [&](bf16x8 (&f)[2][2], const unsigned char *cur, int qb, int dpair) __attribute__((always_inline)) {
+        const unsigned x0 = (unsigned)((2 * dpair) << 6), x1 = (unsigned)((2 * dpair + 1) << 6);
+        unsigned ta = tbaseA, tb = tbaseB;
+        asm volatile("" : "+v"(ta), "+v"(tb));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const unsigned off = (qb * 32 + s2 * 16) * kRow;
+            f[s2][0] = lds_tr_frag_c(cur + (ta ^ x0) + off, cur + (tb ^ x0) + off);
+            f[s2][1] = lds_tr_frag_c(cur + (ta ^ x1) + off, cur + (tb ^ x1) + off);
+        }
+    };
+    unsigned img = 0;
+    int t0 = t_begin;
+    for (int step = 0; step < n_steps; ++step) {
+        const unsigned char *cur = smem + img;
+#pragma unroll
+        for (int db = 0; db < NB; ++db) asm volatile("" : "+v"(acc[db]));           // (see the pair kernel)
+        bf16x8 pc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pc[j] = pn[j];
+        const bool active = t0 + 63 >= wave_kmin;
+        load_p();                                            // the step after this one (its loads and this step's DMA are both waited for at the step's end)
+        if (active) {
+            bf16x8 tf[2][2];
+            load_tr(tf, cur, 0, 0);
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+                for (int dpair = 0; dpair < D / 64; ++dpair) {
+                    bf16x8 ntf[2][2];
+                    const bool more = dpair + 1 < D / 64 || qb == 0;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dpair + 1 < D / 64) load_tr(ntf, cur, qb, dpair + 1);
+                    else if (qb == 0) load_tr(ntf, cur, 1, 0);
+                    acc[2 * dpair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[0][0], pc[2 * qb], acc[2 * dpair], 0, 0, 0);
+                    acc[2 * dpair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[0][1], pc[2 * qb], acc[2 * dpair + 1], 0, 0, 0);
+                    acc[2 * dpair] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[1][0], pc[2 * qb + 1], acc[2 * dpair], 0, 0, 0);
+                    acc[2 * dpair + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[1][1], pc[2 * qb + 1], acc[2 * dpair + 1], 0, 0, 0);
+                    if (more) { SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); SG_MFMA(1); SG_DSR(2); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_piece(qb * 4 + dpair);             // the next step's dO pieces behind the groups
+                    if (more) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) { tf[s2][0] = ntf[s2][0]; tf[s2][1] = ntf[s2][1]; }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) issue_piece(i);
+        }
+        advance_next();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        img ^= (unsigned)kTile;
+        t0 = t0 + 64 >= t_begin + tiles_per_head * 64 ? t_begin : t0 + 64;
+    }
+    if (A.head_splits > 1) {
+        const long long rows_all = (long long)A.B * A.S, slab = rows_all * A.Hkv * D;
+        float *base = A.slab + (long long)hsplit * slab + ((long long)g * rows_all) * D;
+        store_accT_f32<NB>(acc, base + (long long)A.head_splits * slab, D, rowbase + ki, kvalid, h);
+        return;
+    }
+    store_accT<NB>(acc, A.dv + (long long)g * D, A.lddv, rowbase + ki, kvalid, h, 1.f);
+}
+// the dK pass alone (with its P stores: A.pbuf), one workgroup a (key block, head split, batch row and KV head)
+__global__ __launch_bounds__(256, 1) void attn_bwd_dk_d256_kernel(AttnArgs A)
+{
+    const int hs = A.head_splits > 1 ? A.head_splits : 1;
+    int blk, head_in, group;
+    map_block((int)blockIdx.x, ((A.S + 127) / 128) * hs, 1, A.B * A.Hkv, false, blk, head_in, group);
+    attn_bwd_dkv_d256_body<2>(A, blk / hs, group / A.Hkv, group % A.Hkv, blk % hs);
 }
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_pair_d256_kernel(AttnArgs A)
 {
@@ -543,6 +699,12 @@ namespace ecgb_attn {
 int launch_bwd_dq_d256(const AttnArgs &A, unsigned grid, int seq, void *stream)
 {
     return launch256(attn_bwd_dq_d256_kernel, grid, 4 * 64 * 512 + 4 * ((seq + 63) & ~63) + 256, stream, A, "attn_bwd_dq_d256_kernel");
+}
+int launch_bwd_dk_then_dv_d256(const AttnArgs &A, unsigned grid_each, void *stream)
+{
+    const int rc = launch256(attn_bwd_dk_d256_kernel, grid_each, 2 * (2 * 64 * 512 + 512), stream, A, "attn_bwd_dk_d256_kernel");
+    if (rc) return rc;
+    return launch256(attn_bwd_dv_d256_kernel, grid_each, 2 * 64 * 512, stream, A, "attn_bwd_dv_d256_kernel");
 }
 int launch_bwd_dkv_pair_d256(const AttnArgs &A, unsigned grid, void *stream)
 {

@@ -751,6 +751,12 @@ def set_attn_lean_waves(waves: int = 4):
     _lib.check(_L().ecgb_set_attn_lean_waves(int(waves)))
 
 
+def set_attn_d256_pass_p(on: bool = False):
+    """head_dim 256 backward (tests, A/B): both passes of the pair kernel form the scores (default), or the dK pass hands its probabilities to a dV kernel through the scratch
+    (attn_bwd then allocates B * Hq * S^2 bf16 more a call: 3 % faster at the C5 shape, the same bits)."""
+    _lib.check(_L().ecgb_set_attn_d256_pass_p(int(bool(on))))
+
+
 def set_attn_fwd_staging(mode: int = 2):
     """head_dim 64 forward / backward kernels: 2 = lean LDS-DMA kernels (default: softmax constants in the MFMA accumulators, deferred running
     maximum), 1 = the round-2 LDS-DMA kernels, 0 = the register-staged kernels (tests, A/B).  With 2: | 0x100 / 0x200 / 0x400 keeps the forward /
@@ -774,7 +780,7 @@ def attn_bwd(qkv, mask, o, do, lse, B, S, Hq, Hkv, D, scale, rope=None):
     QKV = qkv.shape[1]
     d_qkv = torch.empty_like(qkv)
     delta = torch.empty((B, Hq, S), dtype=torch.float32, device=qkv.device)
-    nbytes = _L().ecgb_attn_bwd_scratch_bytes(B, S, Hq, Hkv, D)          # partial dK / dV slabs (head_dim 256 with few key blocks), else 0
+    nbytes = _L().ecgb_attn_bwd_scratch_bytes(B, S, Hq, Hkv, D)          # head_dim 256: partial dK / dV slabs (few key blocks) + the probabilities from the dK pass to the dV kernel; else 0
     scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=qkv.device) if nbytes else None
     if rope is not None and _fuse_rope_bwd and D == 64:
         cos, sin = rope

@@ -268,8 +268,13 @@ int ecgb_set_attn_fwd_staging(int mode);
 /* waves per workgroup of the lean kernels: 4 (default) or 8 (a K / V tile serves gcd(G, 8) query heads x 256 / gcd rows; A/B). */
 int ecgb_set_attn_lean_waves(int waves);
 /* scratch of ecgb_attn_bwd: fp32 partial dK / dV slabs when the query heads of a KV group are split over workgroups (head_dim 256 with
- * few key blocks: Gemma); 0 for every other shape (scratch_dev may then be null). */
+ * few key blocks: Gemma); 0 for every other shape (scratch_dev may then be null).  With ecgb_set_attn_d256_pass_p(1) also, behind the slabs, room for the probabilities
+ * (bf16, batch * n_q_heads * seq^2 rounded up to whole 128 x 64 tiles; transient) that the dK pass then hands to a dV kernel instead of both passes forming the scores;
+ * a scratch that holds the slabs but not the probabilities is accepted (the pair kernel runs). */
 size_t ecgb_attn_bwd_scratch_bytes(int batch, int seq, int n_q_heads, int n_kv_heads, int head_dim);
+/* head_dim 256 backward: 0 (default) = the pair kernel (the dV pass forms the scores a second time), 1 = the probabilities travel from the dK pass to a dV kernel through the
+ * scratch where it has room (the same bits; at Gemma-2B dims, batch 8, seq 2048: 0.66 against 0.68 ms a layer for 537 MB of transient scratch). */
+int ecgb_set_attn_d256_pass_p(int on);
 int ecgb_attn_bwd(const void *q_dev, long long ldq, const void *k_dev, long long ldk, const void *v_dev, long long ldv,
                   const float *attn_mask_dev, const void *o_dev, const void *do_dev, long long ldo, const float *lse_dev,
                   float *delta_dev, void *dq_dev, long long lddq, void *dk_dev, long long lddk, void *dv_dev,

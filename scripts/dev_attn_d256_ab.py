@@ -35,6 +35,9 @@ mask = torch.ones(B, S, device="cuda")
 if os.environ.get("PADS"):
     for b in range(B): mask[b, : (37 * b) % (S // 2)] = 0
 outs, res = {}, {n: ([], []) for n in names}
+if os.environ.get("PASS_P") is not None:                                   # PASS_P=1: the dK pass hands its probabilities to a dV kernel (default 0: the pair kernel)
+    for L in libs.values():
+        if hasattr(L, "ecgb_set_attn_d256_pass_p"): L.ecgb_set_attn_d256_pass_p(int(os.environ["PASS_P"]))
 for rnd in range(int(os.environ.get("ROUNDS", "4"))):
     for n, L in libs.items():
         _lib._lib = L

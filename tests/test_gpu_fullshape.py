@@ -152,11 +152,14 @@ def test_head_dim_256_backward_kernels_at_the_edges_of_their_tiles(B, S, Hq, Hkv
         o0, l0 = ops.attn_fwd(qkv, mask, B, S, Hq, Hkv, D, 1 / 16)
         d0 = ops.attn_bwd(qkv, mask, o0, do, l0, B, S, Hq, Hkv, D, 1 / 16)
         ops.set_attn_fwd_staging(2)
-        for rep in range(2):
-            d1 = ops.attn_bwd(qkv, mask, o0, do, l0, B, S, Hq, Hkv, D, 1 / 16)
-            assert torch.equal(d0, d1), (rep, (d0.float() - d1.float()).abs().max().item())
+        for pass_p in (True, False):                                              # the dK pass's probabilities handed to a dV kernel (opt-in) / formed again by the pair kernel's dV pass (default)
+            ops.set_attn_d256_pass_p(pass_p)
+            for rep in range(2):
+                d1 = ops.attn_bwd(qkv, mask, o0, do, l0, B, S, Hq, Hkv, D, 1 / 16)
+                assert torch.equal(d0, d1), (pass_p, rep, (d0.float() - d1.float()).abs().max().item())
     finally:
         ops.set_attn_fwd_staging(2)
+        ops.set_attn_d256_pass_p(False)
 
 
 def _attn_ref_fp64(qkv, do, mask, B, S, Hq, Hkv, D, scale):
