@@ -1978,6 +1978,18 @@ __global__ __launch_bounds__(256) void attn_fwd_d256_kernel(AttnArgs A)
     const long long stepK = 128ll * A.ldk, stepV = 128ll * A.ldv;
     int t_next = 0;
     unsigned slot_next = 0;
+    // piece i of the next tile's K and of its V image (round 6: a K piece behind each group of the score products, a V piece behind each group of the P.V products -- issued together at the top of the trip the sixteen pieces
+    // held the wave for ~1 000 cycles with the matrix pipe idle; behind a group they run under its four MFMAs)
+    auto issue_piece = [&](int which, int i) __attribute__((always_inline)) {      // which: 0 the K image, 1 the V image
+        unsigned off = which ? offV[i] : offK[i];
+        if (t_next == last_tile && tail_rows < 64) {                      // (uniform, once per workgroup at most) rows past the last key re-read it: masked as keys >= S
+            const int r = (wave * PPW + i) * 2 + (lane >> 5), slot = lane & 31, rt = min(r, tail_rows - 1);
+            off = which ? (unsigned)(((long long)rt * A.ldv + (slot ^ ((r & 7) << 2)) * 8) * 2) : (unsigned)(((long long)rt * A.ldk + (slot ^ (r & 15)) * 8) * 2);
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((which ? vb_next : kb_next) + off),
+                                         (__attribute__((address_space(3))) void *)(smem + slot_next + which * kTile + (wave * PPW + i) * 1024), 16, 0, 0);
+    };
+    auto advance_next = [&]() { if (t_next < last_tile) { ++t_next; kb_next += stepK; vb_next += stepV; } slot_next ^= 2 * kTile; };
     auto issue_next = [&]() {                                             // UNCONDITIONAL (past the last tile the last one is issued again)
         if (t_next == last_tile && tail_rows < 64) {                      // (uniform, once per workgroup at most) rows past the last key re-read it: masked as keys >= S
 #pragma unroll
@@ -2026,8 +2038,8 @@ __global__ __launch_bounds__(256) void attn_fwd_d256_kernel(AttnArgs A)
     }
     unsigned img = 0;                                                     // byte offset of the current tile's ring slot
     for (int k0 = 0, it = 0; k0 < k_end; k0 += 64, ++it) {
-        issue_next();                                                     // tile it + 1 into the other slot (its readers passed the barrier that ended the previous trip)
-        const float *lds_mask = lds_maskrow + k0;
+        const float *lds_mask = lds_maskrow + k0;                         // (tile it + 1 goes into the other slot: its readers passed the barrier that ended the previous trip)
+        if (k0 > wave_qmax) issue_next();
         if (k0 <= wave_qmax) {
             const bool need_mask = (k0 + 63 > qw0) || lean_tile_padded(padbits, it);
             f32x16 sacc[2] = {splat16(0.f), splat16(0.f)};
@@ -2039,6 +2051,8 @@ __global__ __launch_bounds__(256) void attn_fwd_d256_kernel(AttnArgs A)
                 sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f01, qf[ks], sacc[1], 0, 0, 0);
                 sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f10, qf[ks + 1], sacc[0], 0, 0, 0);
                 sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f11, qf[ks + 1], sacc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_piece(0, ks / 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
             float p[2][16];
@@ -2094,8 +2108,12 @@ __global__ __launch_bounds__(256) void attn_fwd_d256_kernel(AttnArgs A)
                     accO[2 * dp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[0][1], pf0, accO[2 * dp + 1], 0, 0, 0);
                     accO[2 * dp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[1][0], pf1, accO[2 * dp], 0, 0, 0);
                     accO[2 * dp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[1][1], pf1, accO[2 * dp + 1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_piece(1, kb * 4 + dp);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            advance_next();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's pieces of tile it + 1 have landed
         __builtin_amdgcn_s_barrier();                                     // ... and everybody else's; all reads of tile it are done
